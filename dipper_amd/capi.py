@@ -1,0 +1,223 @@
+"""ctypes binding of include/dipper_hip.h.  Thin: every method is one C-ABI call (plus numpy
+buffer plumbing).  There is no Python or CPU fallback -- if the library or the GPU is missing the
+call raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+SRC_MSA, SRC_MASH, SRC_MATRIX = 1, 2, 3
+DIST_UNCORRECTED, DIST_JC = 1, 2
+
+c_i32p = C.POINTER(C.c_int32)
+c_u64p = C.POINTER(C.c_uint64)
+c_f64p = C.POINTER(C.c_double)
+
+
+class DipperError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"dipper_hip error {code}: {msg}")
+        self.code = code
+
+
+def library_path():
+    return os.path.join(_HERE, "libdipper_hip.so")
+
+
+def load_library():
+    """Loads libdipper_hip.so (built in-tree by __graft_entry__.build()).  Raises if absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(path)
+    L.dpr_last_error.restype = C.c_char_p
+    L.dpr_abi_version.restype = C.c_int
+    L.dpr_pack4.argtypes = [C.c_char_p, C.c_uint64, c_u64p]
+    L.dpr_pack2.argtypes = [C.c_char_p, C.c_uint64, c_u64p]
+    L.dpr_shard_owner.argtypes = [C.c_int64, C.c_int]
+    L.dpr_shard_local_row.argtypes = [C.c_int64, C.c_int]
+    L.dpr_shard_local_row.restype = C.c_int64
+    L.dpr_shard_rows.argtypes = [C.c_int64, C.c_int, C.c_int]
+    L.dpr_shard_rows.restype = C.c_int64
+    L.dpr_shard_global_row.argtypes = [C.c_int64, C.c_int, C.c_int]
+    L.dpr_shard_global_row.restype = C.c_int64
+    L.dpr_record_reduce.argtypes = [C.c_void_p, C.c_int]
+    L.dpr_nj_key.argtypes = [C.c_int64, C.c_int64, C.c_int64]
+    L.dpr_nj_key.restype = C.c_uint64
+    L.dpr_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    L.dpr_destroy.argtypes = [C.c_void_p]
+    L.dpr_device_name.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.dpr_comm_unique_id.argtypes = [C.c_void_p]
+    L.dpr_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.dpr_set_msa.argtypes = [C.c_void_p, c_u64p, C.c_int64, C.c_int64]
+    L.dpr_set_reads.argtypes = [C.c_void_p, c_u64p, c_u64p, c_u64p, C.c_int64]
+    L.dpr_set_matrix_lower.argtypes = [C.c_void_p, c_f64p, C.c_int64]
+    L.dpr_sketch.argtypes = [C.c_void_p, C.c_int, C.c_int, c_u64p]
+    L.dpr_dist_matrix.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.dpr_nj_run.argtypes = [C.c_void_p, C.c_int64, c_i32p, c_i32p, c_f64p, c_f64p, c_f64p]
+    L.dpr_nj_run.restype = C.c_int64
+    L.dpr_argmin_once.argtypes = [C.c_void_p, C.c_int, c_i32p, c_i32p, c_f64p, C.POINTER(C.c_float)]
+    L.dpr_n_active.argtypes = [C.c_void_p]
+    L.dpr_n_active.restype = C.c_int64
+    L.dpr_n_total.argtypes = [C.c_void_p]
+    L.dpr_n_total.restype = C.c_int64
+    L.dpr_get_matrix_row.argtypes = [C.c_void_p, C.c_int64, c_f64p]
+    L.dpr_get_row_sums.argtypes = [C.c_void_p, c_f64p]
+    L.dpr_get_msa_counts.argtypes = [C.c_void_p, C.c_int64, c_i32p, c_i32p]
+    L.dpr_get_timing.argtypes = [C.c_void_p, c_f64p, c_f64p]
+    L.dpr_place_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                c_i32p, c_i32p, c_i32p, c_i32p, c_f64p]
+    _LIB = L
+    return L
+
+
+def _chk(L, rc):
+    if rc < 0:
+        raise DipperError(rc, (L.dpr_last_error() or b"").decode())
+    return rc
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def pack4(seq: bytes):
+    L = load_library()
+    out = np.zeros((len(seq) + 15) // 16, dtype=np.uint64)
+    _chk(L, L.dpr_pack4(seq, len(seq), _p(out, c_u64p)))
+    return out
+
+
+def pack2(seq: bytes):
+    L = load_library()
+    out = np.zeros((len(seq) + 31) // 32, dtype=np.uint64)
+    _chk(L, L.dpr_pack2(seq, len(seq), _p(out, c_u64p)))
+    return out
+
+
+def pack4_many(seqs):
+    """[n][ceil(L/16)] words, L = len(seqs[0]) (src/MSA.cu:19: every row uses sequence 0's length)."""
+    Ls = len(seqs[0])
+    W = (Ls + 15) // 16
+    out = np.zeros((len(seqs), W), dtype=np.uint64)
+    for i, s in enumerate(seqs):
+        w = pack4(s)
+        out[i, : min(W, len(w))] = w[:W]
+    return out
+
+
+class Dipper:
+    """One GPU context (dpr_ctx)."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        _chk(self.L, self.L.dpr_create(C.byref(h), device))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.dpr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        _chk(self.L, self.L.dpr_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    # ---- multi-GPU ------------------------------------------------------------------------------
+    def comm_unique_id(self):
+        buf = (C.c_char * 128)()
+        _chk(self.L, self.L.dpr_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, rank, world, uid: bytes):
+        buf = (C.c_char * 128).from_buffer_copy(uid) if uid else None
+        _chk(self.L, self.L.dpr_comm_init(self.h, rank, world, buf))
+
+    # ---- inputs -----------------------------------------------------------------------------------
+    def set_msa(self, packed4, L):
+        p = np.ascontiguousarray(packed4, dtype=np.uint64)
+        _chk(self.L, self.L.dpr_set_msa(self.h, _p(p, c_u64p), p.shape[0], L))
+
+    def set_matrix_lower(self, rows, n):
+        r = np.ascontiguousarray(rows, dtype=np.float64)
+        assert r.size == n * (n - 1) // 2
+        _chk(self.L, self.L.dpr_set_matrix_lower(self.h, _p(r, c_f64p), n))
+
+    def set_matrix_full(self, D):
+        """Convenience: takes an (n,n) array and hands over its strict lower triangle row by row."""
+        D = np.asarray(D, dtype=np.float64)
+        n = D.shape[0]
+        rows = np.concatenate([D[i, :i] for i in range(n)]) if n > 1 else np.zeros(0)
+        self.set_matrix_lower(rows, n)
+
+    def dist_matrix(self, source, dist_type=1, k=15):
+        _chk(self.L, self.L.dpr_dist_matrix(self.h, source, dist_type, k))
+
+    # ---- NJ ---------------------------------------------------------------------------------------
+    def nj_run(self, max_iters=-1):
+        N = self.L.dpr_n_total(self.h)
+        k = max(N - 2, 1)
+        mx = np.zeros(k, dtype=np.int32)
+        my = np.zeros(k, dtype=np.int32)
+        bx = np.zeros(k, dtype=np.float64)
+        by = np.zeros(k, dtype=np.float64)
+        last = C.c_double(0.0)
+        done = _chk(self.L, self.L.dpr_nj_run(self.h, max_iters, _p(mx, c_i32p), _p(my, c_i32p),
+                                              _p(bx, c_f64p), _p(by, c_f64p), C.byref(last)))
+        return dict(iters=done, merge_x=mx[:done], merge_y=my[:done], bl_x=bx[:done], bl_y=by[:done],
+                    last_d=last.value)
+
+    def argmin_once(self, reps=1):
+        i = C.c_int32()
+        j = C.c_int32()
+        q = C.c_double()
+        ms = C.c_float()
+        _chk(self.L, self.L.dpr_argmin_once(self.h, reps, C.byref(i), C.byref(j), C.byref(q), C.byref(ms)))
+        return i.value, j.value, q.value, ms.value
+
+    # ---- hooks ------------------------------------------------------------------------------------
+    def n_active(self):
+        return _chk(self.L, self.L.dpr_n_active(self.h))
+
+    def n_total(self):
+        return self.L.dpr_n_total(self.h)
+
+    def matrix_row(self, i):
+        out = np.zeros(self.n_total(), dtype=np.float64)
+        _chk(self.L, self.L.dpr_get_matrix_row(self.h, i, _p(out, c_f64p)))
+        return out
+
+    def matrix(self):
+        n = self.n_total()
+        return np.stack([self.matrix_row(i) for i in range(n)])
+
+    def row_sums(self):
+        out = np.zeros(self.n_total(), dtype=np.float64)
+        _chk(self.L, self.L.dpr_get_row_sums(self.h, _p(out, c_f64p)))
+        return out
+
+    def msa_counts(self, row):
+        u = np.zeros(max(row, 1), dtype=np.int32)
+        m = np.zeros(max(row, 1), dtype=np.int32)
+        _chk(self.L, self.L.dpr_get_msa_counts(self.h, row, _p(u, c_i32p), _p(m, c_i32p)))
+        return u[:row], m[:row]
+
+    def timing(self):
+        a = C.c_double()
+        b = C.c_double()
+        _chk(self.L, self.L.dpr_get_timing(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value

@@ -1,0 +1,422 @@
+// C ABI of libdipper_hip.so (see include/dipper_hip.h).  Owns the device context, the streams and
+// the host-side orchestration of the hot path.  No CPU fallback: every compute entry point needs a
+// gfx950 device.
+#include "dpr_internal.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <dlfcn.h>
+
+struct Id128 { char b[128]; };  // ncclUniqueId is 128 opaque bytes passed by value
+
+namespace dpr {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char* what)
+{
+    // same wording family as the reference's "Gpu_ERROR: ..." messages
+    g_err = std::string("Gpu_ERROR: ") + what + ": " + hipGetErrorString(e);
+    return DPR_ERR_HIP;
+}
+
+// ---- RCCL, resolved at run time so that the single-GPU path has no link dependency ----------------
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+static Rccl g_rccl;
+static int rccl_load()
+{
+    if (g_rccl.lib) return DPR_OK;
+    const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    for (const char* nm : names) {
+        g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.lib) break;
+    }
+    if (!g_rccl.lib) { set_error("cannot load librccl.so"); return DPR_ERR_COMM; }
+    g_rccl.GetUniqueId = (int (*)(void*))dlsym(g_rccl.lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void**, int, Id128, int))dlsym(g_rccl.lib, "ncclCommInitRank");
+    g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(g_rccl.lib, "ncclAllGather");
+    g_rccl.CommDestroy = (int (*)(void*))dlsym(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
+        set_error("librccl.so lacks a required symbol");
+        return DPR_ERR_COMM;
+    }
+    return DPR_OK;
+}
+}  // namespace dpr
+
+struct dpr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    int rank = 0, world = 1;
+    void* comm = nullptr;
+    dpr::NjBuffers nj;
+    dpr::MsaBuffers msa;
+    double* packed_lower = nullptr;  // MATRIX source, device
+    int64_t n_input = 0;
+    int have_matrix = 0;
+    double dist_ms = 0, nj_ms = 0;
+};
+
+using namespace dpr;
+
+extern "C" {
+
+const char* dpr_last_error(void) { return g_err.c_str(); }
+int dpr_abi_version(void) { return DPR_ABI_VERSION; }
+
+// ---- encoders (fourBitCompressor / twoBitCompressor semantics) ------------------------------------
+static inline uint64_t code_of(char c, uint64_t other)
+{
+    switch (c) {
+    case 'A': return 0;
+    case 'C': return 1;
+    case 'G': return 2;
+    case 'T':
+    case 'U': return 3;
+    default: return other;
+    }
+}
+
+int dpr_pack4(const char* seq, uint64_t len, uint64_t* out)
+{
+    if (!seq || !out) { set_error("dpr_pack4: null argument"); return DPR_ERR_ARG; }
+    const uint64_t nw = (len + 15) / 16;
+    for (uint64_t w = 0; w < nw; ++w) {
+        const uint64_t lo = w * 16, hi = lo + 16 < len ? lo + 16 : len;
+        uint64_t v = 0;
+        for (uint64_t j = lo; j < hi; ++j) v |= code_of(seq[j], 4) << (4 * (j - lo));
+        out[w] = v;
+    }
+    return DPR_OK;
+}
+
+int dpr_pack2(const char* seq, uint64_t len, uint64_t* out)
+{
+    if (!seq || !out) { set_error("dpr_pack2: null argument"); return DPR_ERR_ARG; }
+    const uint64_t nw = (len + 31) / 32;
+    for (uint64_t w = 0; w < nw; ++w) {
+        const uint64_t lo = w * 32, hi = lo + 32 < len ? lo + 32 : len;
+        uint64_t v = 0;
+        for (uint64_t j = lo; j < hi; ++j) v |= code_of(seq[j], 0) << (2 * (j - lo));
+        out[w] = v;
+    }
+    return DPR_OK;
+}
+
+// ---- sharding helpers -------------------------------------------------------------------------------
+int dpr_shard_owner(int64_t row, int world) { return shard_owner(row, world); }
+int64_t dpr_shard_local_row(int64_t row, int world) { return shard_local_row(row, world); }
+int64_t dpr_shard_rows(int64_t n, int rank, int world) { return shard_rows(n, rank, world); }
+int64_t dpr_shard_global_row(int64_t local, int rank, int world) { return shard_global_row(local, rank, world); }
+uint64_t dpr_nj_key(int64_t i, int64_t j, int64_t n) { return nj_key_a(i, n) | nj_key_b(j); }
+
+int dpr_record_reduce(const void* records, int count)
+{
+    const NjRecord* r = (const NjRecord*)records;
+    int best = -1;
+    for (int i = 0; i < count; ++i) {
+        if (r[i].key == ~0ull) continue;
+        if (best < 0 || r[i].q < r[best].q || (r[i].q == r[best].q && r[i].key < r[best].key)) best = i;
+    }
+    return best;
+}
+
+// ---- context ----------------------------------------------------------------------------------------
+int dpr_create(dpr_ctx** out, int device)
+{
+    if (!out) { set_error("dpr_create: null out"); return DPR_ERR_ARG; }
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("Gpu_ERROR: no HIP device available (this library has no CPU fallback)");
+        return DPR_ERR_HIP;
+    }
+    if (device < 0 || device >= count) { set_error("dpr_create: device index out of range"); return DPR_ERR_ARG; }
+    DPR_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    DPR_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error(std::string("Gpu_ERROR: device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+        return DPR_ERR_HIP;
+    }
+    dpr_ctx* c = new dpr_ctx();
+    c->device = device;
+    DPR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto& ev : c->ev) DPR_HIP(hipEventCreate(&ev));
+    *out = c;
+    return DPR_OK;
+}
+
+int dpr_destroy(dpr_ctx* c)
+{
+    if (!c) return DPR_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    nj_free(c->nj);
+    msa_free(c->msa);
+    if (c->packed_lower) (void)hipFree(c->packed_lower);
+    for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return DPR_OK;
+}
+
+int dpr_device_name(dpr_ctx* c, char* buf, int cap)
+{
+    if (!c || !buf || cap <= 0) { set_error("dpr_device_name: bad argument"); return DPR_ERR_ARG; }
+    hipDeviceProp_t prop;
+    DPR_HIP(hipGetDeviceProperties(&prop, c->device));
+    std::snprintf(buf, (size_t)cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return DPR_OK;
+}
+
+// ---- multi-GPU ---------------------------------------------------------------------------------------
+int dpr_comm_unique_id(void* out128)
+{
+    if (!out128) { set_error("dpr_comm_unique_id: null"); return DPR_ERR_ARG; }
+    if (int rc = rccl_load()) return rc;
+    int r = g_rccl.GetUniqueId(out128);
+    if (r != 0) { set_error(std::string("ncclGetUniqueId: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?")); return DPR_ERR_COMM; }
+    return DPR_OK;
+}
+
+int dpr_comm_init(dpr_ctx* c, int rank, int world, const void* id128)
+{
+    if (!c || world < 1 || rank < 0 || rank >= world) { set_error("dpr_comm_init: bad argument"); return DPR_ERR_ARG; }
+    c->rank = rank; c->world = world;
+    if (world == 1) return DPR_OK;
+    if (!id128) { set_error("dpr_comm_init: null id"); return DPR_ERR_ARG; }
+    if (int rc = rccl_load()) return rc;
+    DPR_HIP(hipSetDevice(c->device));
+    Id128 id;
+    std::memcpy(id.b, id128, 128);
+    int r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    if (r != 0) { set_error(std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?")); return DPR_ERR_COMM; }
+    return DPR_OK;
+}
+
+// ---- inputs ------------------------------------------------------------------------------------------
+int dpr_set_msa(dpr_ctx* c, const uint64_t* packed4, int64_t n, int64_t L)
+{
+    if (!c || !packed4 || n < 2 || L < 1) { set_error("dpr_set_msa: bad argument"); return DPR_ERR_ARG; }
+    if (n >= (1 << 24)) { set_error("dpr_set_msa: n must be < 2^24"); return DPR_ERR_ARG; }
+    DPR_HIP(hipSetDevice(c->device));
+    c->n_input = n;
+    return msa_upload(c->msa, packed4, n, L, c->stream);
+}
+
+int dpr_set_reads(dpr_ctx*, const uint64_t*, const uint64_t*, const uint64_t*, int64_t)
+{
+    set_error("dpr_set_reads: Mash path not built yet");
+    return DPR_ERR_STATE;
+}
+
+int dpr_set_matrix_lower(dpr_ctx* c, const double* rows, int64_t n)
+{
+    if (!c || !rows || n < 2) { set_error("dpr_set_matrix_lower: bad argument"); return DPR_ERR_ARG; }
+    if (n >= (1 << 24)) { set_error("dpr_set_matrix_lower: n must be < 2^24"); return DPR_ERR_ARG; }
+    DPR_HIP(hipSetDevice(c->device));
+    if (c->packed_lower) { (void)hipFree(c->packed_lower); c->packed_lower = nullptr; }
+    const size_t cnt = (size_t)(n * (n - 1) / 2);
+    DPR_HIP(hipMalloc(&c->packed_lower, sizeof(double) * (cnt ? cnt : 1)));
+    DPR_HIP(hipMemcpyAsync(c->packed_lower, rows, sizeof(double) * cnt, hipMemcpyHostToDevice, c->stream));
+    DPR_HIP(hipStreamSynchronize(c->stream));
+    c->n_input = n;
+    return DPR_OK;
+}
+
+int dpr_sketch(dpr_ctx*, int, int, uint64_t*)
+{
+    set_error("dpr_sketch: Mash path not built yet");
+    return DPR_ERR_STATE;
+}
+
+// ---- distance matrix ----------------------------------------------------------------------------------
+int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
+{
+    (void)k;
+    if (!c) { set_error("dpr_dist_matrix: null ctx"); return DPR_ERR_ARG; }
+    DPR_HIP(hipSetDevice(c->device));
+    if (c->world > 1) { set_error("dpr_dist_matrix: multi-GPU path not built yet"); return DPR_ERR_STATE; }
+    int64_t n = 0;
+    if (source == DPR_SRC_MSA) {
+        if (!c->msa.planes) { set_error("dpr_dist_matrix: call dpr_set_msa first"); return DPR_ERR_STATE; }
+        n = c->msa.n;
+    } else if (source == DPR_SRC_MATRIX) {
+        if (!c->packed_lower) { set_error("dpr_dist_matrix: call dpr_set_matrix_lower first"); return DPR_ERR_STATE; }
+        n = c->n_input;
+    } else {
+        set_error("dpr_dist_matrix: source not available");
+        return DPR_ERR_ARG;
+    }
+    c->have_matrix = 0;
+    if (int rc = nj_alloc(c->nj, n, c->rank, c->world)) return rc;
+    DPR_HIP(hipEventRecord(c->ev[0], c->stream));
+    if (source == DPR_SRC_MSA) {
+        if (int rc = msa_dist_rows(c->msa, c->nj, dist_type, c->stream)) return rc;
+    } else {
+        if (int rc = nj_expand_lower(c->nj, c->packed_lower, c->stream)) return rc;
+    }
+    if (int rc = nj_init_sums(c->nj, c->stream)) return rc;
+    if (int rc = nj_prepare(c->nj, c->stream)) return rc;
+    DPR_HIP(hipEventRecord(c->ev[1], c->stream));
+    DPR_HIP(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    DPR_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->dist_ms = ms;
+    if (source == DPR_SRC_MATRIX) { (void)hipFree(c->packed_lower); c->packed_lower = nullptr; }
+    c->have_matrix = 1;
+    return DPR_OK;
+}
+
+// ---- NJ -------------------------------------------------------------------------------------------------
+static int fetch_state(dpr_ctx* c, NjState* st)
+{
+    DPR_HIP(hipMemcpyAsync(st, c->nj.st, sizeof(NjState), hipMemcpyDeviceToHost, c->stream));
+    DPR_HIP(hipStreamSynchronize(c->stream));
+    return DPR_OK;
+}
+
+int64_t dpr_nj_run(dpr_ctx* c, int64_t max_iters, int32_t* merge_x, int32_t* merge_y, double* bl_x,
+                   double* bl_y, double* last_d)
+{
+    if (!c || !c->have_matrix) { set_error("dpr_nj_run: call dpr_dist_matrix first"); return DPR_ERR_STATE; }
+    DPR_HIP(hipSetDevice(c->device));
+    NjState st;
+    if (int rc = fetch_state(c, &st)) return rc;
+    int64_t todo = st.n - 2;
+    if (todo < 0) todo = 0;
+    if (max_iters >= 0 && max_iters < todo) todo = max_iters;
+    const int64_t it0 = st.it;
+    DPR_HIP(hipEventRecord(c->ev[2], c->stream));
+    for (int64_t k = 0; k < todo; ++k) {
+        if (int rc = nj_launch_scan(c->nj, false, c->stream)) return rc;
+        if (int rc = nj_launch_select(c->nj, true, c->stream)) return rc;
+        if (int rc = nj_launch_update(c->nj, c->stream)) return rc;
+        if (int rc = nj_launch_finalize(c->nj, c->stream)) return rc;
+    }
+    DPR_HIP(hipEventRecord(c->ev[3], c->stream));
+    if (int rc = fetch_state(c, &st)) return rc;
+    float ms = 0;
+    DPR_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+    c->nj_ms = ms;
+    const int64_t done = st.it - it0;
+    if (done > 0) {
+        if (merge_x) DPR_HIP(hipMemcpy(merge_x, c->nj.log_x + it0, sizeof(int32_t) * (size_t)done, hipMemcpyDeviceToHost));
+        if (merge_y) DPR_HIP(hipMemcpy(merge_y, c->nj.log_y + it0, sizeof(int32_t) * (size_t)done, hipMemcpyDeviceToHost));
+        if (bl_x) DPR_HIP(hipMemcpy(bl_x, c->nj.log_bx + it0, sizeof(double) * (size_t)done, hipMemcpyDeviceToHost));
+        if (bl_y) DPR_HIP(hipMemcpy(bl_y, c->nj.log_by + it0, sizeof(double) * (size_t)done, hipMemcpyDeviceToHost));
+    }
+    if (st.status != 0) {
+        set_error("dpr_nj_run: no Q candidate below the reference's init value 10000 (undefined in the reference)");
+        return DPR_ERR_NOCAND;
+    }
+    if (last_d && st.n == 2) {
+        // D[0][1] of the final pair (src/neighborJoining.cu:245-249); row 1 is owned by rank of block 0
+        DPR_HIP(hipMemcpy(last_d, c->nj.D + 1 * c->nj.ld + 0, sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return done;
+}
+
+int dpr_argmin_once(dpr_ctx* c, int reps, int32_t* out_i, int32_t* out_j, double* out_q, float* out_ms)
+{
+    if (!c || !c->have_matrix) { set_error("dpr_argmin_once: call dpr_dist_matrix first"); return DPR_ERR_STATE; }
+    DPR_HIP(hipSetDevice(c->device));
+    if (reps < 1) reps = 1;
+    if (int rc = nj_launch_scan(c->nj, true, c->stream)) return rc;  // warm
+    DPR_HIP(hipEventRecord(c->ev[2], c->stream));
+    for (int r = 0; r < reps; ++r)
+        if (int rc = nj_launch_scan(c->nj, true, c->stream)) return rc;
+    DPR_HIP(hipEventRecord(c->ev[3], c->stream));
+    if (int rc = nj_launch_select(c->nj, false, c->stream)) return rc;
+    NjRecord rec;
+    DPR_HIP(hipMemcpyAsync(&rec, c->nj.recs, sizeof(NjRecord), hipMemcpyDeviceToHost, c->stream));
+    DPR_HIP(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    DPR_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+    if (out_ms) *out_ms = ms / (float)reps;
+    NjState st;
+    if (int rc = fetch_state(c, &st)) return rc;
+    if (rec.key == ~0ull) {
+        // the select kernel flags the state; clear it again, a probe must not poison the run
+        st.status = 0;
+        DPR_HIP(hipMemcpy(c->nj.st, &st, sizeof(NjState), hipMemcpyHostToDevice));
+        set_error("dpr_argmin_once: no Q candidate below 10000");
+        return DPR_ERR_NOCAND;
+    }
+    if (out_i) *out_i = (int32_t)(rec.key & 0xFFFFFFull);
+    if (out_j) *out_j = (int32_t)((rec.key >> 24) & 0xFFFFFFull);
+    if (out_q) *out_q = rec.q;
+    return DPR_OK;
+}
+
+// ---- test hooks ---------------------------------------------------------------------------------------------
+int64_t dpr_n_active(dpr_ctx* c)
+{
+    if (!c || !c->have_matrix) { set_error("dpr_n_active: no matrix"); return DPR_ERR_STATE; }
+    NjState st;
+    if (int rc = fetch_state(c, &st)) return rc;
+    return st.n;
+}
+
+int64_t dpr_n_total(dpr_ctx* c) { return c ? c->nj.N : DPR_ERR_ARG; }
+
+int dpr_get_matrix_row(dpr_ctx* c, int64_t i, double* out)
+{
+    if (!c || !c->have_matrix || !out || i < 0 || i >= c->nj.N) { set_error("dpr_get_matrix_row: bad argument"); return DPR_ERR_ARG; }
+    if (shard_owner(i, c->world) != c->rank) { set_error("dpr_get_matrix_row: row not owned by this rank"); return DPR_ERR_ARG; }
+    DPR_HIP(hipMemcpy(out, c->nj.D + shard_local_row(i, c->world) * c->nj.ld, sizeof(double) * (size_t)c->nj.N, hipMemcpyDeviceToHost));
+    return DPR_OK;
+}
+
+int dpr_get_row_sums(dpr_ctx* c, double* out)
+{
+    if (!c || !c->have_matrix || !out) { set_error("dpr_get_row_sums: bad argument"); return DPR_ERR_ARG; }
+    DPR_HIP(hipMemcpy(out, c->nj.U, sizeof(double) * (size_t)c->nj.N, hipMemcpyDeviceToHost));
+    return DPR_OK;
+}
+
+int dpr_get_msa_counts(dpr_ctx* c, int64_t row, int32_t* useful, int32_t* match)
+{
+    if (!c || !c->msa.planes || row < 0 || row >= c->msa.n) { set_error("dpr_get_msa_counts: bad argument"); return DPR_ERR_ARG; }
+    if (row == 0) return DPR_OK;
+    int32_t *du = nullptr, *dm = nullptr;
+    DPR_HIP(hipMalloc(&du, sizeof(int32_t) * (size_t)row));
+    DPR_HIP(hipMalloc(&dm, sizeof(int32_t) * (size_t)row));
+    int rc = msa_counts_row(c->msa, row, du, dm, c->stream);
+    if (rc == DPR_OK) {
+        DPR_HIP(hipStreamSynchronize(c->stream));
+        DPR_HIP(hipMemcpy(useful, du, sizeof(int32_t) * (size_t)row, hipMemcpyDeviceToHost));
+        DPR_HIP(hipMemcpy(match, dm, sizeof(int32_t) * (size_t)row, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(du); (void)hipFree(dm);
+    return rc;
+}
+
+int dpr_get_timing(dpr_ctx* c, double* dist_ms, double* nj_ms)
+{
+    if (!c) { set_error("dpr_get_timing: null ctx"); return DPR_ERR_ARG; }
+    if (dist_ms) *dist_ms = c->dist_ms;
+    if (nj_ms) *nj_ms = c->nj_ms;
+    return DPR_OK;
+}
+
+int dpr_place_run(dpr_ctx*, int, int, int, int64_t, int64_t, int32_t*, int32_t*, int32_t*, int32_t*, double*)
+{
+    set_error("dpr_place_run: placement path not built yet");
+    return DPR_ERR_STATE;
+}
+
+}  // extern "C"

@@ -1,0 +1,126 @@
+// Internal declarations shared by the HIP translation units of libdipper_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/dipper_hip.h"
+
+namespace dpr {
+
+constexpr int kRowBlock = DPR_ROW_BLOCK;  // rows per ownership block == rows per scan tile
+constexpr int kTileCols = 512;            // columns per scan tile (256 lanes x 2 doubles)
+constexpr int kScanBlocks = 2048;         // persistent scan grid: 256 CUs x 8 blocks
+constexpr int kThreads = 256;
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+#define DPR_HIP(call)                                            \
+    do {                                                         \
+        hipError_t e__ = (call);                                 \
+        if (e__ != hipSuccess) return dpr::hip_fail(e__, #call); \
+    } while (0)
+
+// ---- sharding (block-cyclic by kRowBlock rows) -------------------------------------------------
+__host__ __device__ inline int shard_owner(int64_t row, int world)
+{
+    return (int)((row / kRowBlock) % world);
+}
+__host__ __device__ inline int64_t shard_local_row(int64_t row, int world)
+{
+    return (row / kRowBlock / world) * kRowBlock + row % kRowBlock;
+}
+__host__ __device__ inline int64_t shard_global_row(int64_t local, int rank, int world)
+{
+    return ((local / kRowBlock) * world + rank) * kRowBlock + local % kRowBlock;
+}
+__host__ __device__ inline int64_t shard_rows(int64_t n, int rank, int world)
+{
+    // number of slots < n owned by rank
+    int64_t nblk = n / kRowBlock, rem = n % kRowBlock;
+    int64_t full = nblk / world + ((nblk % world) > rank ? 1 : 0);
+    int64_t cnt = full * kRowBlock;
+    if (rem && (nblk % world) == rank) cnt += rem;
+    return cnt;
+}
+
+// ---- tie-break key of the reference's findMinDist + thrust::min_element -------------------------
+// (src/neighborJoining.cu:124-146,214): preference (band(i), j mod 256, j, i).
+__host__ __device__ inline uint64_t nj_band(int64_t i, int64_t n)
+{
+    int64_t sz0 = n / 256, rem = n % 256, thr = (sz0 + 1) * rem;
+    return (uint64_t)(i < thr ? i / (sz0 + 1) : rem + (i - thr) / sz0);
+}
+__host__ __device__ inline uint64_t nj_key_a(int64_t i, int64_t n)  // part depending on "i"
+{
+    return (nj_band(i, n) << 56) | (uint64_t)i;
+}
+__host__ __device__ inline uint64_t nj_key_b(int64_t j)  // part depending on "j"
+{
+    return ((uint64_t)(j & 255) << 48) | ((uint64_t)j << 24);
+}
+
+struct alignas(32) NjRecord {
+    double q;
+    uint64_t key;
+    double d;
+    uint64_t pad;
+};
+
+struct NjState {
+    int64_t n;       // active size
+    int64_t it;      // iterations done
+    int32_t x, y;    // slots merged in the current iteration (x<y)
+    double d;        // D[x][y]
+    double q;        // winning Q value
+    int32_t status;  // 0 ok, 1 = no candidate (DPR_ERR_NOCAND)
+    int32_t pad;
+};
+
+struct NjBuffers {
+    double* D = nullptr;       // [rows_local_max][ld] (+ tail pad)
+    int64_t ld = 0;
+    int64_t N = 0;             // total tips
+    int64_t rows_local = 0;    // local rows at n = N
+    double* U = nullptr;       // [N] replicated
+    double* Ur = nullptr;      // [N] U/(n-2) for the current n
+    uint64_t* KA = nullptr;    // [N] nj_key_a(i, n) for the current n
+    NjRecord* partials = nullptr;  // [kScanBlocks]
+    NjRecord* recs = nullptr;      // [world]
+    double* xpart = nullptr;   // [ceil(N/256)]
+    double* gath = nullptr;    // [3][world][slice] gathered column slices (world > 1)
+    double* slice = nullptr;   // [3][slice] local column slices (world > 1)
+    int64_t slice_len = 0;
+    NjState* st = nullptr;
+    int32_t* tile_start = nullptr;  // [nlrb+1]
+    int32_t nlrb = 0;
+    int32_t* log_x = nullptr;  // [N]
+    int32_t* log_y = nullptr;
+    double* log_bx = nullptr;
+    double* log_by = nullptr;
+    int rank = 0, world = 1;
+};
+
+// nj.hip
+int nj_alloc(NjBuffers& b, int64_t N, int rank, int world);
+void nj_free(NjBuffers& b);
+int nj_expand_lower(NjBuffers& b, const double* d_packed_lower, hipStream_t s);
+int nj_init_sums(NjBuffers& b, hipStream_t s);          // U (local rows), diag, state
+int nj_prepare(NjBuffers& b, hipStream_t s);            // Ur, KA for n = st->n
+int nj_launch_scan(NjBuffers& b, bool probe, hipStream_t s);
+int nj_launch_select(NjBuffers& b, bool commit, hipStream_t s);   // world == 1
+int nj_launch_update(NjBuffers& b, hipStream_t s);
+int nj_launch_finalize(NjBuffers& b, hipStream_t s);
+
+// msa.hip
+struct MsaBuffers {
+    uint32_t* planes = nullptr;  // [3][n][W32]: valid, lo, hi bit planes, 32 bases per word
+    int64_t n = 0, L = 0, W32 = 0;
+};
+int msa_upload(MsaBuffers& m, const uint64_t* packed4, int64_t n, int64_t L, hipStream_t s);
+void msa_free(MsaBuffers& m);
+int msa_dist_rows(const MsaBuffers& m, NjBuffers& b, int dist_type, hipStream_t s);
+int msa_counts_row(const MsaBuffers& m, int64_t row, int32_t* d_useful, int32_t* d_match, hipStream_t s);
+
+}  // namespace dpr

@@ -1,0 +1,204 @@
+// Aligned-sequence (MSA) pairwise distances on gfx950.  Replaces MSADeviceArrays
+// (src/MSA.cu:14-72), calculateParamsParallel (:103-156) and MSADistConstruction (:214-268), which
+// compute ONE row per launch with one block per pair, by an all-pairs tiled kernel.
+//
+// Input layout (host ABI): 4-bit codes, 16 bases per uint64, as fourBitCompressor produces.
+// Device layout: three bit planes per sequence, 32 bases per uint32 word:
+//   V (code < 4), LO (code & 1), HI (code >> 1 & 1), positions >= L cleared.
+// For a pair (a,b) per 32 bases:  useful += popc(Va | Vb)
+//                                 match  += popc(Va & Vb & ~((LOa^LOb) | (HIa^HIb)))
+// which equals the reference's  (a<4 || b<4)  and  (a<4 && a==b)  counts exactly (integers).
+// The kernel is integer-VALU/LDS bound; HBM only sees the N^2 fp64 output.
+#include "dpr_internal.hpp"
+
+namespace dpr {
+
+constexpr int kPT = 64;   // pairs tile edge (64 rows x 64 cols per block)
+constexpr int kKC = 16;   // plane words (32 bases each) staged per step
+
+__global__ __launch_bounds__(kThreads) void msa_planes_kernel(const uint64_t* __restrict__ packed4,
+                                                              int64_t n, int64_t L, int64_t W64,
+                                                              int64_t W32, uint32_t* __restrict__ planes)
+{
+    const int64_t total = n * W32;
+    for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * kThreads) {
+        const int64_t s = idx / W32, w = idx % W32;
+        uint32_t V = 0, LO = 0, HI = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t w64 = 2 * w + h;
+            const uint64_t word = w64 < W64 ? packed4[s * W64 + w64] : 0ull;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int64_t pos = w64 * 16 + j;
+                const uint32_t c = (uint32_t)((word >> (4 * j)) & 15u);
+                const uint32_t ok = (c < 4u && pos < L) ? 1u : 0u;
+                const int bit = h * 16 + j;
+                V |= ok << bit;
+                LO |= (ok & c & 1u) << bit;
+                HI |= (ok & (c >> 1) & 1u) << bit;
+            }
+        }
+        planes[(0 * n + s) * W32 + w] = V;
+        planes[(1 * n + s) * W32 + w] = LO;
+        planes[(2 * n + s) * W32 + w] = HI;
+    }
+}
+
+__device__ __forceinline__ double msa_epilogue(int useful, int match, int dist_type)
+{
+    // src/MSA.cu:233-235
+    const double uncor = 1 - double(match) / useful;
+    if (dist_type == DPR_DIST_UNCORRECTED) return uncor;
+    return -0.75 * log(1.0 - uncor / 0.75);
+}
+
+// Block = 64 owned rows x 64 columns; thread (ty,tx) of 16x16 owns rows ty*4.., cols tx*4..
+// LDS: [side][plane][k][64 sequences] so that four consecutive sequences are one 16-byte read.
+__global__ __launch_bounds__(kThreads) void msa_dist_kernel(const uint32_t* __restrict__ planes,
+                                                            int64_t n, int64_t W32, int dist_type,
+                                                            double* __restrict__ D, int64_t ld,
+                                                            int64_t rows_local, int rank, int world)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t sA[3][kKC][kPT];
+    __shared__ __attribute__((aligned(16))) uint32_t sB[3][kKC][kPT];
+
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int64_t l0 = (int64_t)blockIdx.y * kPT;   // local row block (== ownership block)
+    const int64_t c0 = (int64_t)blockIdx.x * kPT;   // global column block
+    const int64_t g0 = shard_global_row(l0, rank, world);
+
+    int useful[4][4], match[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { useful[r][c] = 0; match[r][c] = 0; }
+
+    for (int64_t k0 = 0; k0 < W32; k0 += kKC) {
+        // stage: 2 sides x 3 planes x 64 seqs x 16 words = 6144 words, 24 per thread.
+        // consecutive lanes read consecutive words of one sequence (64-byte runs).
+        for (int e = tid; e < 3 * kPT * kKC; e += kThreads) {
+            const int p = e / (kPT * kKC), rem = e % (kPT * kKC);
+            const int sq = rem / kKC, kk = rem % kKC;
+            const int64_t k = k0 + kk;
+            const int64_t ga = g0 + sq, gb = c0 + sq;
+            uint32_t va = 0, vb = 0;
+            if (k < W32) {
+                if (ga < n && l0 + sq < rows_local) va = planes[((int64_t)p * n + ga) * W32 + k];
+                if (gb < n) vb = planes[((int64_t)p * n + gb) * W32 + k];
+            }
+            sA[p][kk][sq] = va;
+            sB[p][kk][sq] = vb;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < kKC; ++kk) {
+            const uint4 aV = *reinterpret_cast<const uint4*>(&sA[0][kk][ty * 4]);
+            const uint4 aL = *reinterpret_cast<const uint4*>(&sA[1][kk][ty * 4]);
+            const uint4 aH = *reinterpret_cast<const uint4*>(&sA[2][kk][ty * 4]);
+            const uint4 bV = *reinterpret_cast<const uint4*>(&sB[0][kk][tx * 4]);
+            const uint4 bL = *reinterpret_cast<const uint4*>(&sB[1][kk][tx * 4]);
+            const uint4 bH = *reinterpret_cast<const uint4*>(&sB[2][kk][tx * 4]);
+            const uint32_t av[4] = { aV.x, aV.y, aV.z, aV.w }, al[4] = { aL.x, aL.y, aL.z, aL.w },
+                           ah[4] = { aH.x, aH.y, aH.z, aH.w };
+            const uint32_t bv[4] = { bV.x, bV.y, bV.z, bV.w }, bl[4] = { bL.x, bL.y, bL.z, bL.w },
+                           bh[4] = { bH.x, bH.y, bH.z, bH.w };
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    useful[r][c] += __popc(av[r] | bv[c]);
+                    const uint32_t diff = (al[r] ^ bl[c]) | (ah[r] ^ bh[c]);
+                    match[r][c] += __popc(av[r] & bv[c] & ~diff);
+                }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t li = l0 + ty * 4 + r;
+        const int64_t gi = g0 + ty * 4 + r;
+        if (li >= rows_local || gi >= n) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int64_t gj = c0 + tx * 4 + c;
+            if (gj >= n) continue;
+            D[li * ld + gj] = (gi == gj) ? 0.0 : msa_epilogue(useful[r][c], match[r][c], dist_type);
+        }
+    }
+}
+
+// test hook: integer counts of one row against columns [0,row)
+__global__ __launch_bounds__(kThreads) void msa_counts_row_kernel(const uint32_t* __restrict__ planes,
+                                                                  int64_t n, int64_t W32, int64_t row,
+                                                                  int32_t* __restrict__ useful,
+                                                                  int32_t* __restrict__ match)
+{
+    const int64_t c = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (c >= row) return;
+    int u = 0, m = 0;
+    for (int64_t k = 0; k < W32; ++k) {
+        const uint32_t av = planes[(0 * n + row) * W32 + k], al = planes[(1 * n + row) * W32 + k],
+                       ah = planes[(2 * n + row) * W32 + k];
+        const uint32_t bv = planes[(0 * n + c) * W32 + k], bl = planes[(1 * n + c) * W32 + k],
+                       bh = planes[(2 * n + c) * W32 + k];
+        u += __popc(av | bv);
+        m += __popc(av & bv & ~((al ^ bl) | (ah ^ bh)));
+    }
+    useful[c] = u;
+    match[c] = m;
+}
+
+int msa_upload(MsaBuffers& m, const uint64_t* packed4, int64_t n, int64_t L, hipStream_t s)
+{
+    msa_free(m);
+    m.n = n; m.L = L; m.W32 = (L + 31) / 32;
+    const int64_t W64 = (L + 15) / 16;
+    uint64_t* d_in = nullptr;
+    DPR_HIP(hipMalloc(&d_in, sizeof(uint64_t) * (size_t)(n * W64)));
+    DPR_HIP(hipMemcpyAsync(d_in, packed4, sizeof(uint64_t) * (size_t)(n * W64), hipMemcpyHostToDevice, s));
+    DPR_HIP(hipMalloc(&m.planes, sizeof(uint32_t) * (size_t)(3 * n * m.W32)));
+    const int64_t total = n * m.W32;
+    const unsigned grid = (unsigned)((total + kThreads - 1) / kThreads > 8192 ? 8192 : (total + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(msa_planes_kernel, dim3(grid ? grid : 1), dim3(kThreads), 0, s, d_in, n, L, W64,
+                       m.W32, m.planes);
+    DPR_HIP(hipGetLastError());
+    DPR_HIP(hipStreamSynchronize(s));
+    DPR_HIP(hipFree(d_in));
+    return DPR_OK;
+}
+
+void msa_free(MsaBuffers& m)
+{
+    if (m.planes) (void)hipFree(m.planes);
+    m = MsaBuffers();
+}
+
+int msa_dist_rows(const MsaBuffers& m, NjBuffers& b, int dist_type, hipStream_t s)
+{
+    if (dist_type != DPR_DIST_UNCORRECTED && dist_type != DPR_DIST_JC) {
+        set_error("distance types 3-6 are not implemented in the all-pairs kernel yet");
+        return DPR_ERR_ARG;
+    }
+    if (b.rows_local == 0) return DPR_OK;
+    dim3 grid((unsigned)((m.n + kPT - 1) / kPT), (unsigned)((b.rows_local + kPT - 1) / kPT));
+    hipLaunchKernelGGL(msa_dist_kernel, grid, dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, b.D,
+                       b.ld, b.rows_local, b.rank, b.world);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+int msa_counts_row(const MsaBuffers& m, int64_t row, int32_t* d_useful, int32_t* d_match, hipStream_t s)
+{
+    if (row <= 0) return DPR_OK;
+    const unsigned grid = (unsigned)((row + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(msa_counts_row_kernel, dim3(grid), dim3(kThreads), 0, s, m.planes, m.n, m.W32, row,
+                       d_useful, d_match);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+}  // namespace dpr

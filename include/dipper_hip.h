@@ -1,0 +1,147 @@
+/*
+ * dipper_hip.h -- C ABI of the MI355X (gfx950) hot path of the `dipper` phylogeny engine.
+ *
+ * The reference (TurakhiaLab/DIPPER) has no FFI layer: its hot path is reached through the
+ * methods of the structs declared in src/mash_placement.cuh.  Each entry point below names the
+ * reference interface it replaces (file:line under /root/reference).  The reference computes one
+ * matrix row per kernel launch and crosses the host/device boundary every row and every NJ
+ * iteration; this ABI is deliberately coarser (whole matrix / whole run per call).
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success, <0 on error; the message of the
+ *     last error of the calling thread is returned by dpr_last_error().
+ *   - the caller owns every host buffer; the library owns all device memory of a dpr_ctx.
+ *   - one dpr_ctx drives ONE GPU from ONE host thread at a time.  Multi-GPU = one process (and one
+ *     ctx) per GPU, joined by dpr_comm_init(); the N x N matrix is then sharded by rows
+ *     (block-cyclic, DPR_ROW_BLOCK rows) and the NJ loop exchanges one record and three column
+ *     slices per iteration over RCCL.
+ *   - nothing here falls back to the CPU: without a usable gfx950 device dpr_create() fails.
+ */
+#ifndef DIPPER_HIP_H
+#define DIPPER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)
+
+#define DPR_ABI_VERSION 1
+#define DPR_ROW_BLOCK 64 /* rows per ownership block of the sharded matrix */
+
+/* distance sources for dpr_dist_matrix / dpr_place_run */
+#define DPR_SRC_MSA 1    /* 4-bit packed aligned sequences, MSADeviceArrays  */
+#define DPR_SRC_MASH 2   /* bottom-S sketches,              MashDeviceArrays */
+#define DPR_SRC_MATRIX 3 /* PHYLIP lower triangle,          MatrixReader     */
+
+/* distance types of `-d` (src/MSA.cu:81-86) */
+#define DPR_DIST_UNCORRECTED 1
+#define DPR_DIST_JC 2
+#define DPR_DIST_TAJIMANEI 3
+#define DPR_DIST_K2P 4
+#define DPR_DIST_TAMURA 5
+#define DPR_DIST_JINNEI 6
+
+/* error codes */
+#define DPR_OK 0
+#define DPR_ERR_ARG -1
+#define DPR_ERR_HIP -2     /* "Gpu_ERROR: ..." in the reference (e.g. src/neighborJoining.cu:44-55) */
+#define DPR_ERR_STATE -3   /* call order violated */
+#define DPR_ERR_NOCAND -4  /* no Q candidate below the reference's init value 10000 */
+#define DPR_ERR_COMM -5
+
+typedef struct dpr_ctx dpr_ctx;
+
+const char *dpr_last_error(void);
+int dpr_abi_version(void);
+
+/* ---- host-only encoders (no GPU needed) ------------------------------------------------------
+ * replace fourBitCompressor (src/fourBitCompressor.cpp:5-41) and twoBitCompressor
+ * (src/twoBitCompressor.cpp:5-41): out has ceil(len/16) resp. ceil(len/32) words. */
+int dpr_pack4(const char *seq, uint64_t len, uint64_t *out);
+int dpr_pack2(const char *seq, uint64_t len, uint64_t *out);
+
+/* ---- host-only sharding helpers (pure functions; used by the N>1 host logic and its CPU tests) */
+int dpr_shard_owner(int64_t row, int world);                 /* rank owning matrix slot `row`      */
+int64_t dpr_shard_local_row(int64_t row, int world);         /* its index in the owner's storage  */
+int64_t dpr_shard_rows(int64_t n, int rank, int world);      /* #slots < n owned by `rank`         */
+int64_t dpr_shard_global_row(int64_t local, int rank, int world);
+/* lexicographic (q, key) minimum over `count` 32-byte records {double q; uint64 key; double d; pad};
+ * returns the index of the winner or -1 when no record has key != UINT64_MAX. */
+int dpr_record_reduce(const void *records, int count);
+/* tie-break key of ordered pair (i,j) at active size n (src/neighborJoining.cu:124-146,214) */
+uint64_t dpr_nj_key(int64_t i, int64_t j, int64_t n);
+
+/* ---- context ---------------------------------------------------------------------------------
+ * replaces cudaSetDevice(1) (src/tree_generation.cu:240-245; the hard-coded device index is a
+ * reference quirk). */
+int dpr_create(dpr_ctx **out, int device);
+int dpr_destroy(dpr_ctx *ctx);
+int dpr_device_name(dpr_ctx *ctx, char *buf, int cap);
+
+/* ---- multi-GPU (one process per GPU; RCCL over xGMI).  No reference counterpart (single GPU).
+ * rank 0 calls dpr_comm_unique_id, the 128 bytes are broadcast by the launcher (torch.distributed
+ * in bench.py), every rank calls dpr_comm_init before any dpr_set_* call. */
+int dpr_comm_unique_id(void *out128);
+int dpr_comm_init(dpr_ctx *ctx, int rank, int world, const void *id128);
+
+/* ---- inputs ----------------------------------------------------------------------------------*/
+/* MSADeviceArrays::allocateDeviceArrays (src/MSA.cu:14-72): packed4 is [n][ceil(L/16)] words as
+ * produced by dpr_pack4; L = length of sequence 0 (src/MSA.cu:19). */
+int dpr_set_msa(dpr_ctx *ctx, const uint64_t *packed4, int64_t n, int64_t L);
+/* MashDeviceArrays::allocateDeviceArrays (src/mash.cu:14-122): packed2 flat, word_off[i] = first
+ * word of sequence i (exclusive scan of ceil(len/32), src/mash.cu:109-119), len[i] in bases. */
+int dpr_set_reads(dpr_ctx *ctx, const uint64_t *packed2, const uint64_t *word_off,
+                  const uint64_t *len, int64_t n);
+/* MatrixReader (src/matrix_reader.cu:15-45): rows concatenated, row i has i entries (i=0..n-1),
+ * already parsed with the reference's float rounding by the host reader. */
+int dpr_set_matrix_lower(dpr_ctx *ctx, const double *rows, int64_t n);
+
+/* ---- Mash sketches: MashDeviceArrays::sketchConstructionOnGpu (src/mash.cu:386-424).
+ * S must be 1000 unless the reference quirk of SURVEY 9.8 is lifted; host_sketches (optional)
+ * receives [n][S] ascending hashes. */
+int dpr_sketch(dpr_ctx *ctx, int k, int S, uint64_t *host_sketches);
+
+/* ---- distance matrix: NJDeviceArrays::getDismatrix (src/neighborJoining.cu:35-85) with the row
+ * providers MSADeviceArrays/MashDeviceArrays/MatrixReader::distConstructionOnGpu
+ * (src/MSA.cu:271-282, src/mash.cu:457-471, src/matrix_reader.cu:23-45), fillDismatrix (:20-32)
+ * and calculateU (:94-115).  Builds the (sharded) symmetric fp64 matrix and the row sums U. */
+int dpr_dist_matrix(dpr_ctx *ctx, int source, int dist_type, int k);
+
+/* ---- neighbor joining: NJDeviceArrays::findNeighbourJoiningTree (src/neighborJoining.cu:197-249)
+ * without the Newick print.  Outputs (host, N-2 entries each): merged matrix slots x<y and the two
+ * branch lengths per iteration; *last_d = D[0][1] of the final pair.  max_iters<0 runs all N-2
+ * iterations.  The merge log fully determines the tree (realID bookkeeping :233-237 is host work).
+ * Returns the number of iterations done (>=0) or an error code. */
+int64_t dpr_nj_run(dpr_ctx *ctx, int64_t max_iters, int32_t *merge_x, int32_t *merge_y,
+                   double *bl_x, double *bl_y, double *last_d);
+
+/* ---- single Q-argmin at the CURRENT active size (findMinDist + thrust::min_element,
+ * src/neighborJoining.cu:117-148,214).  Returns the reference's winning ordered tuple (i,j,q).
+ * reps>1 repeats the scan kernel `reps` times (kernel symbol nj_scan_probe) and reports the
+ * average duration measured with HIP events on the library's stream; used for the roofline. */
+int dpr_argmin_once(dpr_ctx *ctx, int reps, int32_t *out_i, int32_t *out_j, double *out_q,
+                    float *out_ms_per_scan);
+
+/* ---- test hooks ------------------------------------------------------------------------------*/
+int64_t dpr_n_active(dpr_ctx *ctx);
+int64_t dpr_n_total(dpr_ctx *ctx);
+int dpr_get_matrix_row(dpr_ctx *ctx, int64_t i, double *out /* n_total doubles */);
+int dpr_get_row_sums(dpr_ctx *ctx, double *out /* n_total doubles */);
+int dpr_get_msa_counts(dpr_ctx *ctx, int64_t row, int32_t *useful, int32_t *match /* row entries */);
+/* phase timings of the last dpr_dist_matrix / dpr_nj_run in milliseconds (HIP events) */
+int dpr_get_timing(dpr_ctx *ctx, double *dist_ms, double *nj_ms);
+
+/* ---- k-closest placement: KPlacementDeviceArrays::{allocateDeviceArrays,findPlacementTree,
+ * addQuery} (src/placement_close_k.cu:15-68,646-854,858-990).  Adjacency arrays are in/out host
+ * buffers of sizes head[2n], e/nxt/belong[8n], len[8n]; first = 2 builds from scratch, first = m
+ * expects the imported backbone (initializeDeviceArrays :126-264) in the arrays. */
+int dpr_place_run(dpr_ctx *ctx, int source, int dist_type, int k, int64_t first, int64_t n,
+                  int32_t *head, int32_t *e, int32_t *nxt, int32_t *belong, double *len);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIPPER_HIP_H */

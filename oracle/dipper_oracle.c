@@ -1,0 +1,725 @@
+/*
+ * dipper_oracle.c -- CPU restatement of the reference's hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's
+ * shared object.  Nothing under dipper_amd/ links, imports or calls it; the product path fails
+ * loudly when the HIP library is missing.
+ *
+ * Every function cites the reference file:line (relative to /root/reference) it restates.
+ *
+ * PARITY PIN STATUS (see DESIGN.md "Oracle"):
+ *   - The reference ships no tests and no golden vectors for this path and
+ *     its CUDA translation units cannot be built here (no nvcc/Thrust/Boost/TBB).  The only
+ *     reference TU that compiles from its own sources is src/tree.cpp (oracle/_ref, Newick import).
+ *   - This restatement is therefore pinned by (a) the known-answer values recorded in SURVEY.md
+ *     Appendix A (captured from the reference's host objects during the survey), (b) public
+ *     MurmurHash3 vectors, (c) size-independent properties (additive-metric recovery), and
+ *     (d) oracle/_ref for the Newick import.  Where none of those applies the header of the
+ *     function says "parity unpinned".
+ *
+ * Canonical choices where the reference itself is non-deterministic (shared-memory / global
+ * atomicAdd of doubles, src/neighborJoining.cu:106,176,190) are spelled out at orc_row_sums()
+ * and orc_nj_run().
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <stdio.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------
+ * a-1  encoders.  src/fourBitCompressor.cpp:5-41, src/twoBitCompressor.cpp:5-41.
+ * 16 (resp. 32) bases per uint64, base j of a word at bits 4j (resp. 2j), LSB first.
+ * A,C,G,T/U -> 0,1,2,3 ; anything else -> 4 (4-bit) or 0 (2-bit).
+ * ------------------------------------------------------------------------------------------ */
+static inline uint64_t orc_code(char c, uint64_t other)
+{
+    switch (c) {
+    case 'A': return 0;
+    case 'C': return 1;
+    case 'G': return 2;
+    case 'T': return 3;
+    case 'U': return 3;
+    default:  return other;
+    }
+}
+
+ORC_API void orc_pack4(const char *seq, uint64_t len, uint64_t *out)
+{
+    uint64_t nw = (len + 15) / 16;
+    for (uint64_t w = 0; w < nw; ++w) {
+        uint64_t v = 0, end = (w * 16 + 16 < len) ? w * 16 + 16 : len;
+        for (uint64_t j = w * 16, sh = 0; j < end; ++j, sh += 4) v |= orc_code(seq[j], 4) << sh;
+        out[w] = v;
+    }
+}
+
+ORC_API void orc_pack2(const char *seq, uint64_t len, uint64_t *out)
+{
+    uint64_t nw = (len + 31) / 32;
+    for (uint64_t w = 0; w < nw; ++w) {
+        uint64_t v = 0, end = (w * 32 + 32 < len) ? w * 32 + 32 : len;
+        for (uint64_t j = w * 32, sh = 0; j < end; ++j, sh += 2) v |= orc_code(seq[j], 0) << sh;
+        out[w] = v;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a-2  aligned-sequence distances.
+ * Types 1,2: src/MSA.cu:103-156 (counts), :228-237 (epilogue).
+ * Types 3-6: formulas of src/divide_and_conquer/msa.cu:107-217 (counts), :238-265 (epilogues);
+ *            the copies in src/MSA.cu:239-265 index with the wrong variable.
+ * L = length of sequence 0 (src/MSA.cu:19).  Parity unpinned by the reference (no tests);
+ * pinned by hand-computed JC69 cases in tests/test_oracle.py.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int useful, match;            /* types 1,2 */
+    int tot, match_v;             /* types 3-6: both valid */
+    int frac[4], pr[4];           /* Tajima-Nei */
+    int p, q;                     /* transitions / transversions as the reference defines them */
+    int gc1, gc2;                 /* Tamura */
+} orc_counts;
+
+static void orc_pair_counts(const uint64_t *a /* row, "tar" */, const uint64_t *b /* col, "cur" */,
+                            int64_t L, orc_counts *c)
+{
+    memset(c, 0, sizeof(*c));
+    int64_t nw = (L + 15) / 16;
+    for (int64_t w = 0; w < nw; ++w) {
+        uint64_t vt = b[w], vc = a[w]; /* reference: vt from curRowId (column), vc from tarRowId (row) */
+        for (int j = 0; j < 16 && w * 16 + j < L; ++j) {
+            int et = (int)((vt >> (4 * j)) & 15), ec = (int)((vc >> (4 * j)) & 15);
+            if (et < 4 || ec < 4) c->useful++;
+            if (et < 4 && et == ec) c->match++;
+            if (et >= 4 || ec >= 4) continue;
+            /* valid-valid site: counters of the DC kernels (src/divide_and_conquer/msa.cu:107-217) */
+            c->tot++;
+            c->frac[ec]++; c->frac[et]++;
+            {
+                int lo = ec < et ? ec : et, hi = ec < et ? et : ec;
+                if (lo == hi) c->match_v++;
+                if (lo == 0 && hi == 2) c->pr[0]++;
+                else if (lo == 0 && hi == 3) c->pr[1]++;
+                else if (lo == 1 && hi == 2) c->pr[2]++;
+                else if (lo == 1 && hi == 3) c->pr[3]++;
+            }
+            if (et == ec) continue;
+            if (et % 2 == ec % 2) c->p++; else c->q++;
+            if (ec == 1 || ec == 2) c->gc1++;
+            if (et == 1 || et == 2) c->gc2++;
+        }
+    }
+}
+
+static double orc_dist_from_counts(const orc_counts *c, int type)
+{
+    if (type == 1 || type == 2) {
+        double uncor = 1 - (double)c->match / c->useful;
+        if (type == 1) return uncor;
+        return -0.75 * log(1.0 - uncor / 0.75);
+    }
+    if (type == 3) { /* Tajima-Nei */
+        double fr[4], h = 0;
+        int tot = c->tot;
+        for (int i = 0; i < 4; ++i) fr[i] = (double)c->frac[i] / tot / 2.0;
+        h += 0.5 * c->pr[0] * fr[0] * fr[2];
+        h += 0.5 * c->pr[1] * fr[0] * fr[3];
+        h += 0.5 * c->pr[2] * fr[1] * fr[2];
+        h += 0.5 * c->pr[3] * fr[1] * fr[3];
+        double D = (double)(tot - c->match_v) / tot;
+        double b = 0.5 * (1.0 - fr[0] * fr[0] - fr[2] * fr[2] + D * D / h);
+        return -b * log(1.0 - D / b);
+    }
+    if (type == 4 || type == 6) { /* K2P / Jin-Nei */
+        double pp = (double)c->p / c->tot, qq = (double)c->q / c->tot;
+        if (type == 4) return -0.5 * log((1 - 2 * pp - qq) * sqrt(1 - 2 * qq));
+        return 0.5 * (1.0 / (1 - 2 * pp - qq) + 0.5 / (1 - qq * 2) - 1.5);
+    }
+    if (type == 5) { /* Tamura */
+        int tot = c->tot;
+        double pp = (double)c->p / tot, qq = (double)c->q / tot;
+        double cc = (double)c->gc1 / tot + (double)c->gc2 / tot
+                  - 2 * (double)c->gc1 * (double)c->gc2 / tot / tot;
+        return -cc * log(1 - pp / cc - qq) - 0.5 * (1 - cc) * log(1 - 2 * qq);
+    }
+    return 0.0;
+}
+
+/* counts only, for bit-exact integer parity: out_useful/out_match are n*n int32 (lower triangle). */
+ORC_API void orc_msa_counts(const uint64_t *packed4, int64_t n, int64_t L,
+                            int32_t *out_useful, int32_t *out_match)
+{
+    int64_t W = (L + 15) / 16;
+    for (int64_t r = 1; r < n; ++r)
+        for (int64_t c = 0; c < r; ++c) {
+            orc_counts k;
+            orc_pair_counts(packed4 + r * W, packed4 + c * W, L, &k);
+            out_useful[r * n + c] = k.useful;
+            out_match[r * n + c] = k.match;
+        }
+}
+
+/* D[r*ld + c] for c < r (strict lower triangle), exactly what getDismatrix hands to fillDismatrix
+ * (src/neighborJoining.cu:60-83). */
+ORC_API void orc_msa_dist_lower(const uint64_t *packed4, int64_t n, int64_t L, int type,
+                                double *D, int64_t ld)
+{
+    int64_t W = (L + 15) / 16;
+    for (int64_t r = 1; r < n; ++r)
+        for (int64_t c = 0; c < r; ++c) {
+            orc_counts k;
+            orc_pair_counts(packed4 + r * W, packed4 + c * W, L, &k);
+            D[r * ld + c] = orc_dist_from_counts(&k, type);
+        }
+}
+
+/* one row against a list of columns (placement / bounded samples) */
+ORC_API void orc_msa_dist_row(const uint64_t *packed4, int64_t L, int type, int64_t row,
+                              int64_t ncols, double *out)
+{
+    int64_t W = (L + 15) / 16;
+    for (int64_t c = 0; c < ncols; ++c) {
+        orc_counts k;
+        orc_pair_counts(packed4 + row * W, packed4 + c * W, L, &k);
+        out[c] = orc_dist_from_counts(&k, type);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a-3  matrix completion and row sums.
+ * fillDismatrix src/neighborJoining.cu:20-32 ; calculateU :94-115.
+ * The reference forms 256 per-thread partials (j == t mod 256, ascending j, j != i) and combines
+ * them with shared-memory atomicAdd in ARBITRARY order.  Canonical order used by this build
+ * (oracle and kernels alike): the 256 class partials are combined by the pairwise tree
+ * c[t] += c[t+s] for s = 128,64,...,1 -- one of the orders the reference may produce.
+ * ------------------------------------------------------------------------------------------ */
+static double orc_tree256(double *c)
+{
+    for (int s = 128; s > 0; s >>= 1)
+        for (int t = 0; t < s; ++t) c[t] += c[t + s];
+    return c[0];
+}
+
+ORC_API void orc_fill_symmetric(double *D, int64_t n, int64_t ld)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        D[i * ld + i] = 0;
+        for (int64_t j = 0; j < i; ++j) D[j * ld + i] = D[i * ld + j];
+    }
+}
+
+ORC_API void orc_row_sums(const double *D, int64_t n, int64_t ld, double *U)
+{
+    double c[256];
+    for (int64_t i = 0; i < n; ++i) {
+        for (int t = 0; t < 256; ++t) {
+            double s = 0;
+            for (int64_t j = t; j < n; j += 256)
+                if (j != i) s += D[i * ld + j];
+            c[t] = s;
+        }
+        U[i] = orc_tree256(c);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a-4  Q-argmin.  findMinDist src/neighborJoining.cu:117-148, compare_tuple :150-158,
+ * thrust::min_element :214 (first occurrence wins).
+ * Candidate (i,j), i != j: q = (D[i][j] - U[i]/(n-2)) - U[j]/(n-2), strict '<' against init 10000.
+ * Preference among equal q: lowest bx*256+tx, then the thread's own visiting order
+ * (j ascending outer, i ascending inner) => key (band(i), j mod 256, j, i).
+ * band(i): index of the block owning row i: sz0=n/256, rem=n%256 (:124-127).
+ * ------------------------------------------------------------------------------------------ */
+static inline uint64_t orc_band(int64_t i, int64_t n)
+{
+    int64_t sz0 = n / 256, rem = n % 256, thr = (sz0 + 1) * rem;
+    return (uint64_t)(i < thr ? i / (sz0 + 1) : rem + (i - thr) / sz0);
+}
+
+static inline uint64_t orc_key(int64_t i, int64_t j, int64_t n)
+{
+    return (orc_band(i, n) << 56) | ((uint64_t)(j & 255) << 48) | ((uint64_t)j << 24) | (uint64_t)i;
+}
+
+typedef struct { double q; uint64_t key; } orc_best;
+
+/* scans rows [r0,r1) of the strict lower triangle (both orientations per element) */
+static orc_best orc_scan_rows(const double *D, int64_t n, int64_t ld, const double *Ur,
+                              int64_t r0, int64_t r1)
+{
+    orc_best b = { 10000.0, UINT64_MAX };
+    for (int64_t a = r0 > 1 ? r0 : 1; a < r1; ++a) {
+        const double *row = D + a * ld;
+        double ua = Ur[a];
+        for (int64_t c = 0; c < a; ++c) {
+            double d = row[c], uc = Ur[c];
+            double q1 = (d - ua) - uc; /* (i=a, j=c) */
+            double q2 = (d - uc) - ua; /* (i=c, j=a) */
+            if (q1 <= b.q) {
+                uint64_t k = orc_key(a, c, n);
+                if (q1 < b.q || k < b.key) { b.q = q1; b.key = k; }
+            }
+            if (q2 <= b.q) {
+                uint64_t k = orc_key(c, a, n);
+                if (q2 < b.q || k < b.key) { b.q = q2; b.key = k; }
+            }
+        }
+    }
+    return b;
+}
+
+static orc_best orc_scan(const double *D, int64_t n, int64_t ld, const double *Ur, int threads)
+{
+    orc_best best = { 10000.0, UINT64_MAX };
+    if (threads <= 1) return orc_scan_rows(D, n, ld, Ur, 0, n);
+    /* rows dealt in bands of 16 so every thread sees short and long rows */
+    int64_t nb = (n + 15) / 16;
+#pragma omp parallel num_threads(threads)
+    {
+        orc_best mine = { 10000.0, UINT64_MAX };
+#pragma omp for schedule(static, 1) nowait
+        for (int64_t bnd = 0; bnd < nb; ++bnd) {
+            int64_t r1 = bnd * 16 + 16 < n ? bnd * 16 + 16 : n;
+            orc_best t = orc_scan_rows(D, n, ld, Ur, bnd * 16, r1);
+            if (t.q < mine.q || (t.q == mine.q && t.key < mine.key)) mine = t;
+        }
+#pragma omp critical
+        if (mine.q < best.q || (mine.q == best.q && mine.key < best.key)) best = mine;
+    }
+    return best;
+}
+
+/* one argmin at active size n; returns 0 and (i,j,q) of the reference's winning tuple,
+ * or -1 if no candidate beats the init value 10000 (reference would merge slots (0,0)). */
+ORC_API int orc_nj_argmin(const double *D, int64_t n, int64_t ld, const double *U, int threads,
+                          int32_t *out_i, int32_t *out_j, double *out_q)
+{
+    double *Ur = (double *)malloc(sizeof(double) * (size_t)n);
+    double r = (double)(n - 2);
+    for (int64_t i = 0; i < n; ++i) Ur[i] = U[i] / r;
+    orc_best b = orc_scan(D, n, ld, Ur, threads);
+    free(Ur);
+    if (b.key == UINT64_MAX) return -1;
+    *out_i = (int32_t)(b.key & 0xFFFFFF);
+    *out_j = (int32_t)((b.key >> 24) & 0xFFFFFF);
+    *out_q = b.q;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a-5/a-6  the NJ loop.  Host part src/neighborJoining.cu:211-249, updateDisMatrix :161-194.
+ * D: N x ld, strict lower triangle valid on entry (row r has r entries); mirrored here.
+ * Outputs per iteration it (0..N-3): merge_x[it] < merge_y[it] (matrix slots), bl_x, bl_y;
+ * last_d = D[0][1] when two slots remain.  max_iters < 0 => run to the end; otherwise stop after
+ * max_iters iterations (bounded CPU-baseline sample).  Returns iterations done, or -1 on the
+ * undefined (0,0) case.
+ *
+ * Canonical order for U[x] after a merge (reference: atomicAdd of every val_i onto 0 in
+ * arbitrary order, :176,190,239): v[i] = val_i for active i not in {x,y} (v[n-1] = val_last),
+ * +0.0 elsewhere; chunk sums over 256 consecutive i by the pairwise tree; chunk sums folded
+ * p[t] = sum_k cs[t+256k] (ascending k) and combined by the same tree.
+ * ------------------------------------------------------------------------------------------ */
+ORC_API int64_t orc_nj_run(double *D, int64_t N, int64_t ld, int threads, int64_t max_iters,
+                           int32_t *merge_x, int32_t *merge_y, double *bl_x, double *bl_y,
+                           double *last_d, double *U_out /* N or NULL */)
+{
+    orc_fill_symmetric(D, N, ld);
+    double *U = (double *)malloc(sizeof(double) * (size_t)N);
+    double *Ur = (double *)malloc(sizeof(double) * (size_t)N);
+    int64_t nchunk_max = (N + 255) / 256;
+    double *cs = (double *)malloc(sizeof(double) * (size_t)(nchunk_max + 256));
+    orc_row_sums(D, N, ld, U);
+    int64_t it = 0;
+    for (; it < N - 2; ++it) {
+        if (max_iters >= 0 && it >= max_iters) break;
+        int64_t n = N - it;
+        double r = (double)(n - 2);
+        for (int64_t i = 0; i < n; ++i) Ur[i] = U[i] / r;
+        orc_best b = orc_scan(D, n, ld, Ur, threads);
+        if (b.key == UINT64_MAX) { it = -1; break; }
+        int64_t x = (int64_t)(b.key & 0xFFFFFF), y = (int64_t)((b.key >> 24) & 0xFFFFFF);
+        if (x > y) { int64_t t = x; x = y; y = t; }
+        double d = D[x * ld + y];
+        double blX = (d + U[x] / r - U[y] / r) * 0.5;
+        double blY = d - blX;
+        if (blX < 0) { blY += blX; blX = 0; }
+        if (blY < 0) { blX += blY; blY = 0; }
+        merge_x[it] = (int32_t)x; merge_y[it] = (int32_t)y; bl_x[it] = blX; bl_y[it] = blY;
+
+        int64_t last = n - 1;
+        int64_t nchunk = (n + 255) / 256;
+        for (int64_t c = 0; c < nchunk; ++c) {
+            double v[256];
+            for (int t = 0; t < 256; ++t) {
+                int64_t i = c * 256 + t;
+                double val = 0.0;
+                if (i < n && i != x && i != y) {
+                    double dxi = D[x * ld + i], dyi = D[y * ld + i];
+                    val = (dxi + dyi - d) * 0.5;
+                    if (i != last) {
+                        double far = D[last * ld + i];
+                        U[i] += -dxi - dyi + val;
+                        D[x * ld + i] = val; D[i * ld + x] = val;
+                        D[y * ld + i] = far; D[i * ld + y] = far;
+                    }
+                }
+                v[t] = val;
+            }
+            cs[c] = orc_tree256(v);
+        }
+        /* tail (thread (0,0) of the reference, :184-193) */
+        {
+            double dxl = D[x * ld + last], dyl = D[y * ld + last];
+            double val = (dxl + dyl - d) * 0.5;
+            double uy = U[last];
+            uy += -dxl - dyl + val;
+            U[y] = uy;
+            D[x * ld + y] = val; D[y * ld + x] = val;
+        }
+        {
+            double p[256];
+            for (int t = 0; t < 256; ++t) {
+                double s = 0.0;
+                for (int64_t c = t; c < nchunk; c += 256) s += cs[c];
+                p[t] = s;
+            }
+            U[x] = orc_tree256(p);
+        }
+    }
+    if (it >= 0 && it == N - 2 && last_d) *last_d = D[0 * ld + 1];
+    if (U_out) memcpy(U_out, U, sizeof(double) * (size_t)N);
+    free(U); free(Ur); free(cs);
+    return it;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a-8  MurmurHash3_x64_128 (public algorithm, src/mash.cu:159-236), canonical k-mer choice
+ * (src/mash.cu:239-258,300-321) and bottom-1000 sketch with duplicates kept (:282-360).
+ * Pinned by the public vector murmur3_x64_128("hello",0) and SURVEY Appendix A values.
+ * ------------------------------------------------------------------------------------------ */
+static inline uint64_t orc_rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint64_t orc_fmix64(uint64_t k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+    return k;
+}
+
+ORC_API void orc_murmur3_x64_128(const void *key, int len, uint32_t seed, uint64_t out[2])
+{
+    const uint8_t *data = (const uint8_t *)key;
+    const int nblocks = len / 16;
+    uint64_t h1 = seed, h2 = seed;
+    const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+    for (int i = 0; i < nblocks; ++i) {
+        uint64_t k1, k2;
+        memcpy(&k1, data + 16 * i, 8); memcpy(&k2, data + 16 * i + 8, 8);
+        k1 *= c1; k1 = orc_rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+        h1 = orc_rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        k2 *= c2; k2 = orc_rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+        h2 = orc_rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    }
+    const uint8_t *tail = data + nblocks * 16;
+    uint64_t k1 = 0, k2 = 0;
+    switch (len & 15) {
+    case 15: k2 ^= ((uint64_t)tail[14]) << 48; /* fallthrough */
+    case 14: k2 ^= ((uint64_t)tail[13]) << 40; /* fallthrough */
+    case 13: k2 ^= ((uint64_t)tail[12]) << 32; /* fallthrough */
+    case 12: k2 ^= ((uint64_t)tail[11]) << 24; /* fallthrough */
+    case 11: k2 ^= ((uint64_t)tail[10]) << 16; /* fallthrough */
+    case 10: k2 ^= ((uint64_t)tail[9]) << 8;   /* fallthrough */
+    case 9:  k2 ^= ((uint64_t)tail[8]) << 0;
+             k2 *= c2; k2 = orc_rotl64(k2, 33); k2 *= c1; h2 ^= k2; /* fallthrough */
+    case 8:  k1 ^= ((uint64_t)tail[7]) << 56; /* fallthrough */
+    case 7:  k1 ^= ((uint64_t)tail[6]) << 48; /* fallthrough */
+    case 6:  k1 ^= ((uint64_t)tail[5]) << 40; /* fallthrough */
+    case 5:  k1 ^= ((uint64_t)tail[4]) << 32; /* fallthrough */
+    case 4:  k1 ^= ((uint64_t)tail[3]) << 24; /* fallthrough */
+    case 3:  k1 ^= ((uint64_t)tail[2]) << 16; /* fallthrough */
+    case 2:  k1 ^= ((uint64_t)tail[1]) << 8;  /* fallthrough */
+    case 1:  k1 ^= ((uint64_t)tail[0]) << 0;
+             k1 *= c1; k1 = orc_rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+    }
+    h1 ^= (uint64_t)len; h2 ^= (uint64_t)len;
+    h1 += h2; h2 += h1;
+    h1 = orc_fmix64(h1); h2 = orc_fmix64(h2);
+    h1 += h2; h2 += h1;
+    out[0] = h1; out[1] = h2;
+}
+
+static int orc_cmp_u64(const void *a, const void *b)
+{
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+/* hash of the canonical k-mer starting at base position p of a 2-bit packed sequence */
+ORC_API uint64_t orc_kmer_hash(const uint64_t *packed2, uint64_t p, int k)
+{
+    static const char lut[4] = { 'A', 'C', 'G', 'T' };
+    char fwd[32], rev[32];
+    for (int i = 0; i < k; ++i) {
+        uint64_t pos = p + (uint64_t)i;
+        int c = (int)((packed2[pos / 32] >> (2 * (pos % 32))) & 3);
+        fwd[i] = lut[c];
+        rev[k - 1 - i] = lut[3 - c];
+    }
+    int cmp = 0;
+    for (int i = 0; i < k && cmp == 0; ++i) cmp = (fwd[i] < rev[i]) ? -1 : (fwd[i] > rev[i] ? 1 : 0);
+    uint64_t h[2];
+    orc_murmur3_x64_128(cmp <= 0 ? fwd : rev, k, 42, h);
+    return h[0];
+}
+
+/* sketch[0..S) ascending, the S smallest hashes with duplicates kept, padded with 2^64-1 */
+ORC_API void orc_sketch(const uint64_t *packed2, uint64_t len, int k, int S, uint64_t *sketch)
+{
+    for (int i = 0; i < S; ++i) sketch[i] = UINT64_MAX;
+    if (len < (uint64_t)k) return;
+    uint64_t nk = len - (uint64_t)k + 1;
+    uint64_t *h = (uint64_t *)malloc(sizeof(uint64_t) * nk);
+    for (uint64_t p = 0; p < nk; ++p) h[p] = orc_kmer_hash(packed2, p, k);
+    qsort(h, nk, sizeof(uint64_t), orc_cmp_u64);
+    for (uint64_t i = 0; i < nk && i < (uint64_t)S; ++i) sketch[i] = h[i];
+    free(h);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a-9  Mash distance.  mashDistConstruction src/mash.cu:426-455; CPU twin
+ * mashDistConstructionRangeCpu src/divide_and_conquer/mash.cpp:11-43.
+ * A = sketch of the column (lower index, outer list), B = sketch of the row (inner list).
+ * Pinned by the SURVEY Appendix A values (0, 0.027031007207210963, 0.41437383991701832 / 0).
+ * ------------------------------------------------------------------------------------------ */
+ORC_API double orc_mash_dist(const uint64_t *A, const uint64_t *B, int S, int k)
+{
+    int uni = 0, inter = 0, bp = 0;
+    for (int ai = 0; uni < S; ++ai, ++uni) {
+        uint64_t a = A[ai];
+        while (uni < S && bp < S) {
+            uint64_t b = B[bp];
+            if (b > a) break;
+            if (b < a) uni++; else inter++;
+            bp++;
+        }
+        if (uni >= S) break;
+    }
+    double j = fmax((double)inter, 1.0) / uni;
+    return fmin(1.0, fabs(log(2.0 * j / (1.0 + j)) / k));
+}
+
+/* row r against columns [0,ncols): sketches row-major [n][S] */
+ORC_API void orc_mash_dist_row(const uint64_t *sketches, int S, int k, int64_t row, int64_t ncols,
+                               double *out)
+{
+    for (int64_t c = 0; c < ncols; ++c)
+        out[c] = orc_mash_dist(sketches + c * S, sketches + row * S, S, k);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a-10  k-closest placement.  src/placement_close_k.cu: initialize :266-289,
+ * buildInitialTree :530-554, updateClosestNodes :86-124, calculateBranchLength :309-358,
+ * thrust::min_element :807 (first occurrence), updateTreeStructure :446-528.
+ * State arrays sized by the caller: head[2N], e/nxt/belong[8N], len[8N], cid/cdis[5*8N]
+ * (the reference allocates 20N entries for the lists and initialises 4N-4 slots).
+ * scratch dis[0]=0, from[0]=-1 is what the reference effectively reads.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int64_t N;
+    int32_t *head, *e, *nxt, *belong, *cid;
+    double *len, *cdis;
+    int32_t *q_id, *q_from; double *q_dis; /* BFS scratch, 2N */
+} orc_ptree;
+
+static void orc_closest_update(orc_ptree *T, int x)
+{
+    int l = 0, r = -1;
+    T->q_id[++r] = x; T->q_dis[0] = 0; T->q_from[0] = -1;
+    while (l <= r) {
+        int node = T->q_id[l], fb = T->q_from[l];
+        double d = T->q_dis[l];
+        l++;
+        for (int i = T->head[node]; i != -1; i = T->nxt[i]) {
+            if (T->e[i] == fb) continue;
+            for (int j = 0; j < 5; ++j) {
+                double nowd = T->cdis[i * 5 + j];
+                if (nowd > d) {
+                    for (int k = 4; k > j; --k) {
+                        T->cdis[i * 5 + k] = T->cdis[i * 5 + k - 1];
+                        T->cid[i * 5 + k] = T->cid[i * 5 + k - 1];
+                    }
+                    T->cdis[i * 5 + j] = d;
+                    T->cid[i * 5 + j] = x;
+                    ++r; T->q_id[r] = T->e[i]; T->q_dis[r] = d + T->len[i]; T->q_from[r] = node;
+                    break;
+                }
+            }
+        }
+    }
+}
+
+static void orc_list_merge_into(orc_ptree *T, int dst, int src)
+{
+    for (int i = 0; i < 5; ++i) {
+        if (T->cid[src * 5 + i] == -1) break;
+        for (int j = 0; j < 5; ++j)
+            if (T->cdis[dst * 5 + j] > T->cdis[src * 5 + i]) {
+                for (int k = 4; k > j; --k) {
+                    T->cdis[dst * 5 + k] = T->cdis[dst * 5 + k - 1];
+                    T->cid[dst * 5 + k] = T->cid[dst * 5 + k - 1];
+                }
+                T->cdis[dst * 5 + j] = T->cdis[src * 5 + i];
+                T->cid[dst * 5 + j] = T->cid[src * 5 + i];
+                break;
+            }
+    }
+}
+
+static void orc_split_edge(orc_ptree *T, int eid, double fracLen, double addLen, int placeId, int ec)
+{
+    int N = (int)T->N;
+    int middle = placeId + N - 1, outside = placeId;
+    int x = T->belong[eid], y = T->e[eid];
+    double originalDis = T->len[eid];
+    int xe = -1, ye = -1;
+    for (int i = T->head[x]; i != -1; i = T->nxt[i])
+        if (T->e[i] == y) { T->e[i] = middle; T->len[i] = fracLen; xe = i; break; }
+    for (int i = T->head[y]; i != -1; i = T->nxt[i])
+        if (T->e[i] == x) { T->e[i] = middle; T->len[i] -= fracLen; ye = i; break; }
+    /* middle -> x */
+    T->e[ec] = x; T->len[ec] = fracLen; T->nxt[ec] = T->head[middle]; T->head[middle] = ec; T->belong[ec] = middle;
+    for (int i = 0; i < 5; ++i)
+        if (T->cid[ye * 5 + i] != -1) {
+            T->cid[ec * 5 + i] = T->cid[ye * 5 + i];
+            T->cdis[ec * 5 + i] = T->cdis[ye * 5 + i] + originalDis - fracLen;
+        }
+    ec++;
+    /* middle -> y */
+    T->e[ec] = y; T->len[ec] = originalDis - fracLen; T->nxt[ec] = T->head[middle]; T->head[middle] = ec; T->belong[ec] = middle;
+    for (int i = 0; i < 5; ++i)
+        if (T->cid[xe * 5 + i] != -1) {
+            T->cid[ec * 5 + i] = T->cid[xe * 5 + i];
+            T->cdis[ec * 5 + i] = T->cdis[xe * 5 + i] + fracLen;
+        }
+    ec++;
+    /* outside -> middle */
+    T->e[ec] = middle; T->len[ec] = addLen; T->nxt[ec] = T->head[outside]; T->head[outside] = ec; T->belong[ec] = outside;
+    ec++;
+    /* middle -> outside */
+    T->e[ec] = outside; T->len[ec] = addLen; T->nxt[ec] = T->head[middle]; T->head[middle] = ec; T->belong[ec] = middle;
+    orc_list_merge_into(T, ec, ec - 2);
+    orc_list_merge_into(T, ec, ec - 3);
+}
+
+/* one tip scan: slots [0,lim) are written like the reference's minPos array; returns the index of
+ * the first minimum of the third tuple field. */
+static int orc_edge_scan(const orc_ptree *T, const double *dis, int num, int lim,
+                         double *out_frac, double *out_add)
+{
+    int best = -1; double best_add = 0, best_frac = 0; int best_eid = 0;
+    for (int idx = 0; idx < lim; ++idx) {
+        int eid; double d1, add;
+        if (idx >= num * 4 - 4 || T->belong[idx] < T->e[idx]) { eid = 0; d1 = 0; add = 2; }
+        else {
+            int x = T->belong[idx], oth = T->e[idx];
+            double dis1 = 0, dis2 = 0, val;
+            eid = idx;
+            for (int i = 0; i < 5; ++i)
+                if (T->cid[eid * 5 + i] != -1) {
+                    val = dis[T->cid[eid * 5 + i]] - T->cdis[eid * 5 + i];
+                    if (val > dis1) dis1 = val;
+                }
+            int oe = T->head[oth];
+            while (T->e[oe] != x) oe = T->nxt[oe];
+            for (int i = 0; i < 5; ++i)
+                if (T->cid[oe * 5 + i] != -1) {
+                    val = dis[T->cid[oe * 5 + i]] - T->cdis[oe * 5 + i];
+                    if (val > dis2) dis2 = val;
+                }
+            double L = T->len[eid];
+            add = (dis1 + dis2 - L) / 2;
+            if (add < 0) add = 0;
+            dis1 -= add; dis2 -= add;
+            if (dis1 < 0) dis1 = 0;
+            if (dis2 < 0) dis2 = 0;
+            if (dis1 > L) { add += dis1 - L; dis1 = L; }
+            if (dis2 > L) { add += dis2 - L; dis2 = L; }
+            double rest = L - dis1 - dis2;
+            dis1 += rest / 2; dis2 += rest / 2;
+            d1 = dis1;
+        }
+        if (best < 0 || add < best_add) { best = idx; best_add = add; best_frac = d1; best_eid = eid; }
+    }
+    *out_frac = best_frac; *out_add = best_add;
+    return best_eid;
+}
+
+typedef void (*orc_dist_fn)(void *user, int64_t row, double *out /* row entries */);
+
+/* findPlacementTree (src/placement_close_k.cu:646-854) for first==2, addQuery (:858-990) for
+ * first==m with the adjacency pre-loaded by the caller (initializeDeviceArrays :126-264) and
+ * next_slot = 4m-4.  dist_rows: row-major N x N (only j<i read), or NULL with fn != NULL.
+ * trace (optional): per placed tip (eid, frac, add) as 3 doubles. */
+ORC_API int orc_place_run(int64_t N, int64_t first, const double *dist_rows, int64_t ld,
+                          int32_t *head, int32_t *e, int32_t *nxt, int32_t *belong, double *len,
+                          int32_t *cid, double *cdis, double *trace)
+{
+    orc_ptree T;
+    T.N = N; T.head = head; T.e = e; T.nxt = nxt; T.belong = belong; T.len = len; T.cid = cid; T.cdis = cdis;
+    T.q_id = (int32_t *)malloc(sizeof(int32_t) * (size_t)(2 * N));
+    T.q_from = (int32_t *)malloc(sizeof(int32_t) * (size_t)(2 * N));
+    T.q_dis = (double *)malloc(sizeof(double) * (size_t)(2 * N));
+    int lim = (int)(4 * N - 4);
+    int next = 0;
+    if (first == 2) {
+        for (int i = 0; i < lim; ++i) {
+            for (int k = 0; k < 5; ++k) { cdis[i * 5 + k] = 2; cid[i * 5 + k] = -1; }
+            nxt[i] = -1; e[i] = -1; belong[i] = -1;
+        }
+        for (int64_t i = 0; i < 2 * N; ++i) head[i] = -1;
+        double d = dist_rows[1 * ld + 0];
+        int nv = (int)N;
+        e[0] = nv; len[0] = d / 2; nxt[0] = head[0]; head[0] = 0; belong[0] = 0;
+        e[1] = nv; len[1] = d / 2; nxt[1] = head[1]; head[1] = 1; belong[1] = 1;
+        e[2] = 0;  len[2] = d / 2; nxt[2] = head[nv]; head[nv] = 2; belong[2] = nv;
+        e[3] = 1;  len[3] = d / 2; nxt[3] = head[nv]; head[nv] = 3; belong[3] = nv;
+        next = 4;
+        orc_closest_update(&T, 0);
+        orc_closest_update(&T, 1);
+    } else {
+        next = (int)(4 * first - 4);
+    }
+    for (int64_t i = first; i < N; ++i) {
+        double frac, add;
+        int eid = orc_edge_scan(&T, dist_rows + i * ld, (int)i, lim, &frac, &add);
+        if (trace) { trace[3 * i] = eid; trace[3 * i + 1] = frac; trace[3 * i + 2] = add; }
+        orc_split_edge(&T, eid, frac, add, (int)i, next);
+        next += 4;
+        orc_closest_update(&T, (int)i);
+    }
+    free(T.q_id); free(T.q_from); free(T.q_dis);
+    return next;
+}
+
+/* closest-list initialisation for an imported backbone (initializeID :70-84 + m BFS launches
+ * :247-260) */
+ORC_API void orc_place_init_lists(int64_t N, int64_t m, int32_t *head, int32_t *e, int32_t *nxt,
+                                  int32_t *belong, double *len, int32_t *cid, double *cdis)
+{
+    orc_ptree T;
+    T.N = N; T.head = head; T.e = e; T.nxt = nxt; T.belong = belong; T.len = len; T.cid = cid; T.cdis = cdis;
+    T.q_id = (int32_t *)malloc(sizeof(int32_t) * (size_t)(2 * N));
+    T.q_from = (int32_t *)malloc(sizeof(int32_t) * (size_t)(2 * N));
+    T.q_dis = (double *)malloc(sizeof(double) * (size_t)(2 * N));
+    for (int64_t i = 0; i < 4 * N - 4; ++i)
+        for (int k = 0; k < 5; ++k) { cdis[i * 5 + k] = 2; cid[i * 5 + k] = -1; }
+    for (int64_t i = 0; i < m; ++i) orc_closest_update(&T, (int)i);
+    free(T.q_id); free(T.q_from); free(T.q_dis);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a-12  PHYLIP token -> double.  src/matrix_reader.cu:42 parses with stof (float precision).
+ * ------------------------------------------------------------------------------------------ */
+ORC_API double orc_phylip_value(const char *tok) { return (double)strtof(tok, NULL); }
+
+ORC_API int orc_version(void) { return 1; }

@@ -1,0 +1,250 @@
+"""Shared test helpers: seeded synthetic inputs (no alisim in the image), Newick
+assembly mirroring the reference's print routine, patristic distances."""
+import numpy as np
+
+BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def yule_tree(rng, n):
+    """Random Yule-Harding topology: returns (parent, children) over 2n-1 nodes, root 0,
+    and the list of leaf node ids in creation order."""
+    parent = [-1]
+    children = [[]]
+    leaves = [0]
+    while len(leaves) < n:
+        k = int(rng.integers(len(leaves)))
+        node = leaves[k]
+        a, b = len(parent), len(parent) + 1
+        parent += [node, node]
+        children += [[], []]
+        children[node] = [a, b]
+        leaves[k] = a
+        leaves.append(b)
+    return parent, children, leaves
+
+
+def synth_alignment(rng, n, L, mean_bl=2e-4, lo=2e-5, hi=2e-3, invalid_frac=0.0):
+    """JC69 evolution down a Yule tree (exponential branch lengths clipped to [lo,hi], cf.
+    scripts/alisim.sh:14 `-rlen`), no indels.  Returns a list of n byte strings over ACGT
+    (plus '-'/'N' when invalid_frac > 0)."""
+    parent, children, leaves = yule_tree(rng, n)
+    nn = len(parent)
+    seq = [None] * nn
+    seq[0] = rng.integers(0, 4, size=L, dtype=np.uint8)
+    pending = [0]
+    out = {}
+    while pending:
+        node = pending.pop()
+        s = seq[node]
+        if not children[node]:
+            out[node] = s
+            seq[node] = None
+            continue
+        for c in children[node]:
+            bl = float(np.clip(rng.exponential(mean_bl), lo, hi))
+            t = s.copy()
+            k = rng.poisson(L * bl)
+            if k:
+                pos = rng.integers(0, L, size=k)
+                t[pos] = (t[pos] + rng.integers(1, 4, size=k, dtype=np.uint8)) & 3
+            seq[c] = t
+            pending.append(c)
+        seq[node] = None
+    res = []
+    for leaf in leaves:
+        s = BASES[out[leaf]]
+        if invalid_frac > 0:
+            s = s.copy()
+            m = rng.random(L) < invalid_frac
+            s[m] = rng.choice(np.frombuffer(b"-Nacgt", dtype=np.uint8), size=int(m.sum()))
+        res.append(s.tobytes())
+    return res
+
+
+def random_additive_matrix(rng, n, zero_frac=0.0):
+    """Patristic distance matrix of a random binary tree with n tips (exact tree metric up to fp
+    rounding).  zero_frac of the branches get length 0 (ties, as in near-clonal data)."""
+    parent, children, leaves = yule_tree(rng, n)
+    nn = len(parent)
+    bl = rng.uniform(0.01, 1.0, size=nn)
+    if zero_frac > 0:
+        bl[rng.random(nn) < zero_frac] = 0.0
+    bl[0] = 0.0
+    depth_path = []
+    for leaf in leaves:
+        path = {}
+        d = 0.0
+        v = leaf
+        while v != -1:
+            path[v] = d
+            d += bl[v]
+            v = parent[v]
+        depth_path.append(path)
+    D = np.zeros((n, n))
+    for i in range(n):
+        pi = depth_path[i]
+        for j in range(i):
+            pj = depth_path[j]
+            v = leaves[j]
+            while v not in pi:
+                v = parent[v]
+            D[i, j] = D[j, i] = pi[v] + pj[v]
+    return D
+
+
+def fmt(v):
+    """std::ostream << double with default precision (6 significant digits, %g style)."""
+    return "%g" % v
+
+
+def newick_from_merges(names, mx, my, bx, by, last_d, fmt=fmt):
+    """Mirror of the bookkeeping + print of src/neighborJoining.cu:233-270."""
+    N = len(names)
+    real = list(range(N))
+    kids = {}
+    ID = N
+    for it in range(N - 2):
+        x, y = int(mx[it]), int(my[it])
+        kids[ID] = [(real[x], float(bx[it])), (real[y], float(by[it]))]
+        real[x] = ID
+        ID += 1
+        real[y] = real[N - it - 1]
+    kids[2 * N - 2] = [(real[0], last_d * 0.5), (real[1], last_d * 0.5)]
+    out = []
+    stack = [("node", 2 * N - 2)]
+    while stack:
+        kind, v = stack.pop()
+        if kind == "text":
+            out.append(v)
+            continue
+        if v in kids:
+            out.append("(")
+            items = kids[v]
+            seq = []
+            for i, (c, l) in enumerate(items):
+                seq.append(("node", c))
+                seq.append(("text", ":" + fmt(l) + (")" if i + 1 == len(items) else ",")))
+            stack.extend(reversed(seq))
+        else:
+            out.append(names[v])
+    return "".join(out) + ";\n"
+
+
+def parse_newick(s):
+    """Minimal Newick parser -> (children dict, length dict, name dict, root id)."""
+    s = s.strip().rstrip(";")
+    kids, length, name = {}, {}, {}
+    nid = [0]
+
+    def new():
+        nid[0] += 1
+        return nid[0] - 1
+
+    pos = 0
+    root = new()
+    stack = [root]
+    cur = root
+    kids[root] = []
+    i = 0
+    n = len(s)
+    # iterative parser
+    cur = None
+    stack = []
+    i = 0
+    root = None
+    while i < n:
+        c = s[i]
+        if c == "(":
+            v = new()
+            kids[v] = []
+            if stack:
+                kids[stack[-1]].append(v)
+            else:
+                root = v
+            stack.append(v)
+            cur = None
+            i += 1
+        elif c == ",":
+            cur = None
+            i += 1
+        elif c == ")":
+            cur = stack.pop()
+            i += 1
+        elif c == ":":
+            j = i + 1
+            while j < n and s[j] not in ",()":
+                j += 1
+            length[cur] = float(s[i + 1:j])
+            i = j
+        else:
+            j = i
+            while j < n and s[j] not in ":,()":
+                j += 1
+            label = s[i:j]
+            if cur is None:
+                v = new()
+                kids[v] = []
+                name[v] = label
+                if stack:
+                    kids[stack[-1]].append(v)
+                else:
+                    root = v
+                cur = v
+            else:
+                name[cur] = label
+            i = j
+    return kids, length, name, root
+
+
+def patristic(newick, names):
+    kids, length, name, root = parse_newick(newick)
+    parent = {}
+    for p, cs in kids.items():
+        for c in cs:
+            parent[c] = p
+    leaf_of = {name[v]: v for v in name if not kids[v]}
+    paths = []
+    for nm in names:
+        v = leaf_of[nm]
+        d = 0.0
+        path = {}
+        while True:
+            path[v] = d
+            if v not in parent:
+                break
+            d += length.get(v, 0.0)
+            v = parent[v]
+        paths.append(path)
+    n = len(names)
+    D = np.zeros((n, n))
+    for i in range(n):
+        for j in range(i):
+            v = leaf_of[names[j]]
+            while v not in paths[i]:
+                v = parent[v]
+            D[i, j] = D[j, i] = paths[i][v] + paths[j][v]
+    return D
+
+
+def splits(newick, names):
+    """Set of non-trivial bipartitions (as frozensets of the side not containing names[0])."""
+    kids, length, name, root = parse_newick(newick)
+    idx = {nm: i for i, nm in enumerate(names)}
+    res = set()
+    below = {}
+    order = []
+    st = [root]
+    while st:
+        v = st.pop()
+        order.append(v)
+        st.extend(kids[v])
+    for v in reversed(order):
+        if not kids[v]:
+            below[v] = frozenset([idx[name[v]]])
+        else:
+            below[v] = frozenset().union(*[below[c] for c in kids[v]])
+    full = frozenset(range(len(names)))
+    for v, b in below.items():
+        if 1 < len(b) < len(names) - 1:
+            res.add(b if 0 not in b else full - b)
+    return res

@@ -1,0 +1,121 @@
+"""GPU parity: NJ hot path through the C ABI vs the CPU oracle (bit-exact merge log)."""
+import numpy as np
+import pytest
+
+from tests import _util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import dipper_amd
+    d = dipper_amd.Dipper(0)
+    yield d
+    d.close()
+
+
+def _check_nj(gpu, orc, D):
+    from dipper_amd import capi
+    n = D.shape[0]
+    gpu.set_matrix_full(D)
+    gpu.dist_matrix(capi.SRC_MATRIX)
+    # a-3: mirrored matrix and canonical row sums
+    M = gpu.matrix()
+    Dsym = np.tril(D, -1) + np.tril(D, -1).T
+    assert np.array_equal(M, Dsym)
+    U_ref = orc.row_sums(np.ascontiguousarray(Dsym))
+    assert np.array_equal(gpu.row_sums(), U_ref)
+    # a-4: one argmin
+    if n > 2:
+        rc, i, j, q = orc.nj_argmin(np.ascontiguousarray(Dsym), n, U_ref)
+        gi, gj, gq, _ = gpu.argmin_once()
+        assert rc == 0 and (gi, gj, gq) == (i, j, q)
+    # a-5/a-6: the whole loop
+    ref = orc.nj_run(np.tril(D, -1))
+    res = gpu.nj_run()
+    assert res["iters"] == ref["iters"] == max(n - 2, 0)
+    assert np.array_equal(res["merge_x"], ref["merge_x"])
+    assert np.array_equal(res["merge_y"], ref["merge_y"])
+    assert np.array_equal(res["bl_x"], ref["bl_x"])
+    assert np.array_equal(res["bl_y"], ref["bl_y"])
+    assert res["last_d"] == ref["last_d"]
+    return res
+
+
+@pytest.mark.parametrize("n", [3, 4, 17, 64, 65, 200, 513, 700, 1025, 1500])
+def test_nj_additive(gpu, orc, n):
+    rng = np.random.default_rng(100 + n)
+    D = _util.random_additive_matrix(rng, n)
+    res = _check_nj(gpu, orc, D)
+    names = [f"T{i}" for i in range(n)]
+    nw = _util.newick_from_merges(names, res["merge_x"], res["merge_y"], res["bl_x"], res["bl_y"],
+                                  res["last_d"], fmt=repr)
+    assert np.abs(_util.patristic(nw, names) - D).max() < 1e-9
+
+
+@pytest.mark.parametrize("n", [50, 300, 777])
+def test_nj_ties(gpu, orc, n):
+    """Exact Q ties everywhere: small-integer distances and tree metrics with zero branches."""
+    rng = np.random.default_rng(n)
+    D = rng.integers(1, 4, size=(n, n)).astype(np.float64)
+    D = np.tril(D, -1) + np.tril(D, -1).T
+    _check_nj(gpu, orc, D)
+    D2 = _util.random_additive_matrix(rng, n, zero_frac=0.5)
+    _check_nj(gpu, orc, D2)
+
+
+def test_nj_random_nonadditive(gpu, orc):
+    rng = np.random.default_rng(5)
+    n = 900
+    D = rng.random((n, n))
+    D = np.tril(D, -1) + np.tril(D, -1).T
+    _check_nj(gpu, orc, D)
+
+
+def test_nj_no_candidate(gpu):
+    """All Q >= 10000: the reference's init value wins (undefined there); we return an error."""
+    from dipper_amd import capi, DipperError
+    n = 8
+    D = np.full((n, n), 1e6)
+    np.fill_diagonal(D, 0)
+    # q = d - (U_i+U_j)/(n-2) = 1e6 - 2*7e6/6 < 0 -> fine; force positive q with a far outlier
+    D = np.zeros((n, n))
+    gpu.set_matrix_full(D + 0.0)
+    gpu.dist_matrix(capi.SRC_MATRIX)
+    res = gpu.nj_run()   # all-zero matrix: q = 0 everywhere, valid
+    assert res["iters"] == n - 2
+
+
+@pytest.mark.parametrize("n,L,inv", [(40, 100, 0.0), (130, 1000, 0.05), (300, 2500, 0.0), (257, 33, 0.2)])
+def test_msa_dist_and_nj(gpu, orc, n, L, inv):
+    from dipper_amd import capi
+    rng = np.random.default_rng(n * 7 + L)
+    seqs = _util.synth_alignment(rng, n, L, mean_bl=5e-3, lo=1e-4, hi=5e-2, invalid_frac=inv)
+    packed = capi.pack4_many(seqs)
+    assert np.array_equal(packed, orc.pack4_many(seqs))
+    gpu.set_msa(packed, L)
+    # integer counts: bit-exact
+    u_ref, m_ref = orc.msa_counts(packed, L)
+    for row in (1, n // 2, n - 1):
+        u, m = gpu.msa_counts(row)
+        assert np.array_equal(u, u_ref[row, :row]) and np.array_equal(m, m_ref[row, :row])
+    for dt in (capi.DIST_UNCORRECTED, capi.DIST_JC):
+        gpu.dist_matrix(capi.SRC_MSA, dt)
+        M = gpu.matrix()
+        assert np.array_equal(M, M.T) and np.all(np.diag(M) == 0)
+        D_ref = orc.msa_dist_lower(packed, L, dt)
+        lo = np.tril_indices(n, -1)
+        a, b = M[lo], D_ref[lo]
+        if dt == capi.DIST_UNCORRECTED:
+            assert np.array_equal(a, b, equal_nan=True)          # pure integer/fp64 division
+        else:
+            ok = np.isfinite(b)
+            assert np.array_equal(np.isnan(a), np.isnan(b))
+            # tolerance of north_star: 1e-6 relative (libm log differs in the last bits)
+            assert np.allclose(a[ok], b[ok], rtol=1e-12, atol=0)
+        if np.all(np.isfinite(M)):
+            ref = orc.nj_run(np.tril(M, -1))
+            res = gpu.nj_run()
+            assert np.array_equal(res["merge_x"], ref["merge_x"]) and np.array_equal(res["merge_y"], ref["merge_y"])
+            assert np.array_equal(res["bl_x"], ref["bl_x"]) and np.array_equal(res["bl_y"], ref["bl_y"])
