@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json):
+tips/sec for packed aligned tips -> JC distances -> conventional NJ -> merge log at N = 30k on
+MI355X, plus the Q-argmin HBM roofline and a CPU NJ baseline timed on the host cores.
+
+One "step" = one pass of the hot path over one batch of synthetic input that is already resident
+in HBM (bit-plane sequences): all-pairs JC69 distance matrix + row sums + all N-2 NJ iterations.
+Run as `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches it under
+torch.distributed.run (one rank per GPU, RCCL).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_input(n, L, seed):
+    """Seeded stand-in for `iqtree2 --alisim` (scripts/alisim.sh:14): Yule-Harding tree, JC69,
+    branch lengths exponential(2e-5) clipped to [2e-6, 2e-4], no indels."""
+    from tests import _util
+    rng = np.random.default_rng(seed)
+    return _util.synth_alignment(rng, n, L, mean_bl=2e-5, lo=2e-6, hi=2e-4)
+
+
+def pmc_traffic(n, world):
+    """HBM bytes per scan launch from the committed rocprofv3 --pmc passes of
+    `bench.py --probe-only` (profiles/pmc_scan.json; FETCH_SIZE doubled per the gfx950 correction of
+    MI355X_MICROARCH.md, WRITE_SIZE as is).  None when no matching measurement is committed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_scan.json")) as f:
+            rec = json.load(f)
+        if rec.get("n_active") == n and rec.get("n_gpus") == world:
+            return rec["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
+def cpu_baseline(dip, n, budget_s=20.0):
+    """CPU NJ (the oracle's restatement of the reference's arithmetic, OpenMP over row bands) on a
+    bounded sample: the first k iterations at full size on the same matrix, extrapolated to the
+    whole run by the sum of n^2.  Distances are NOT included (the matrix is copied from the GPU)."""
+    import psutil
+    from tests import _orc
+    orc = _orc.load()
+    cores = os.cpu_count() or 1
+    need = n * n * 8 * 1.15
+    avail = psutil.virtual_memory().available
+    ns = n
+    if need > 0.5 * avail:
+        ns = int((0.5 * avail / 9.2) ** 0.5)
+        log(f"[cpu_baseline] host memory {avail/2**30:.0f} GiB: sampling the leading {ns} tips")
+    D = np.zeros((ns, ns), dtype=np.float64)
+    for i in range(ns):
+        D[i, :] = dip.matrix_row(i)[:ns]
+    D = np.tril(D, -1)
+    # calibrate: 2 iterations, then as many as fit the budget
+    import ctypes as C
+    from tests._orc import _p, c_f64p, c_i32p
+    k_max = 64
+    mx = np.zeros(k_max, np.int32); my = np.zeros(k_max, np.int32)
+    bx = np.zeros(k_max); by = np.zeros(k_max)
+    last = C.c_double()
+
+    def run(k):
+        Dc = D.copy()
+        t0 = time.perf_counter()
+        orc.lib.orc_nj_run(_p(Dc, c_f64p), ns, ns, cores, k, _p(mx, c_i32p), _p(my, c_i32p),
+                           _p(bx, c_f64p), _p(by, c_f64p), C.byref(last), None)
+        return time.perf_counter() - t0
+
+    t0 = run(0)            # mirror + row sums only
+    t2 = run(2)
+    per_it = max((t2 - t0) / 2, 1e-6)
+    k = int(max(2, min(k_max, (budget_s - t2) / per_it)))
+    tk = run(k) if k > 2 else t2
+    per_it = (tk - t0) / k
+    s_sample = sum(float(ns - i) ** 2 for i in range(k))
+    s_full = sum(float(m) ** 2 for m in range(3, n + 1))
+    t_full = t0 * (n / ns) ** 2 + per_it * k * s_full / s_sample
+    return {
+        "value": n / t_full, "unit": "tips/s", "cores": cores, "kind": "port",
+        "sample": f"oracle NJ (reference arithmetic, OpenMP {cores} threads) on the same matrix "
+                  f"(leading {ns} tips): init + first {k} iterations timed ({tk:.1f} s), "
+                  f"extrapolated to all {n-2} iterations of N={n} by sum(n^2); distance stage excluded",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tips", type=int, default=30000)
+    ap.add_argument("--sites", type=int, default=10000)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--probe-reps", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--probe-only", action="store_true",
+                    help="skip the timed steps; only build the matrix and run the roofline probe "
+                         "(used for the rocprofv3 --pmc passes)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE")
+
+    import torch
+    import dipper_amd
+    from dipper_amd import capi
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n, L = args.tips, args.sites
+    t0 = time.perf_counter()
+    seqs = make_input(n, L, args.seed)
+    packed = capi.pack4_many(seqs)
+    del seqs
+    log(f"[bench r{rank}] synthetic input {n} x {L} generated+packed in {time.perf_counter()-t0:.1f}s")
+
+    dip = dipper_amd.Dipper(local_rank)
+    if world > 1:
+        uid = [dip.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        dip.comm_init(rank, world, uid[0])
+    dip.set_msa(packed, L)          # H2D + bit-plane conversion: inputs now resident in HBM
+    if rank == 0:
+        log(f"[bench] device: {dip.device_name()}")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        dip.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+        res = dip.nj_run()
+        assert res["iters"] == n - 2
+        return res
+
+    phase = []
+    if args.probe_only:
+        args.steps = args.warmup = 0
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        phase.append(dip.timing())
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / max(args.steps, 1) * 1e3 if args.steps else float("nan")
+
+    # ---- roofline of the dominant kernel: Q-argmin scan at n = N on a fresh matrix ----------------
+    dip.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+    _, _, _, scan_ms = dip.argmin_once(reps=args.probe_reps)
+    rows_local = capi.load_library().dpr_shard_rows(n, rank, world)
+    alg_bytes = 4.0 * n * n / world + 4.0 * n   # strict lower triangle of this rank's rows + U once
+    achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, world),
+                "kernel": "nj_scan_kernel<true> (probe instantiation of the Q-argmin scan)",
+                "n_active": n, "algorithmic_bytes": alg_bytes, "ms": scan_ms, "rows_local": int(rows_local)}
+
+    out = {
+        "metric": "tips/sec packed aligned tips -> JC distances -> NJ merge log at N=%d" % n,
+        "value": n / (ms_per_step * 1e-3),
+        "unit": "tips/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic (seeded Yule-Harding tree, JC69, L=%d, no indels)" % L,
+        "config": {"workload": "configs[1]: %d aligned tips, -d 2 (JC69), conventional NJ" % n,
+                   "tips": n, "sites": L, "parallelism": "rows%d" % world},
+        "phase_ms": {"dist": float(np.mean([p[0] for p in phase])) if phase else None,
+                     "nj": float(np.mean([p[1] for p in phase])) if phase else None},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(dip, n)
+        except Exception as e:  # the baseline must never take the bench line down
+            out["cpu_baseline"] = {"value": None, "unit": "tips/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": f"failed: {e!r}"}
+    dip.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
