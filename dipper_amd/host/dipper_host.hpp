@@ -1,0 +1,69 @@
+// Host side of the `dipper` command line (plain C++17, no Boost/TBB): input readers, encoders,
+// the reference's operator interface for the hot path re-expressed over the C ABI of
+// include/dipper_hip.h, and Newick output.
+//
+// The struct and method names follow src/mash_placement.cuh of the reference so that a reader of
+// the reference finds the same vocabulary; the granularity differs (whole matrix / whole run per
+// call instead of one row per call), see INTEGRATION.md.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <iosfwd>
+#include <string>
+#include <vector>
+
+#include "../../include/dipper_hip.h"
+
+namespace dipper {
+
+struct Param {  // src/mash_placement.cuh:16-32
+    uint64_t kmerSize = 15, sketchSize = 1000, threshold = 1, distanceType = 1;
+    std::string in = "r", out = "t";
+    uint64_t batchSize = 0, backboneSize = 0;
+};
+
+[[noreturn]] void die(const std::string& msg);   // prints msg to stderr, exit(1)
+void gpuCheck(int rc, const char* what);         // "Gpu_ERROR"-style exit on rc < 0
+
+// FASTA (plain or gz), klib-kseq semantics: name = header up to the first whitespace
+// (src/tree_generation.cu:132-154, src/kseq.h).
+void readSequences(const std::string& path, std::vector<std::string>& seqs, std::vector<std::string>& names);
+
+// Input-order shuffle of the reference (src/tree_generation.cu:341-344,470-473): ids[i] = slot of
+// input sequence i.  seed < 0 keeps the input order.
+std::vector<int> shuffledIds(size_t n, long long seed);
+
+// PHYLIP distance matrix (lower-triangular or square), src/matrix_reader.cu:23-45 +
+// src/tree_generation.cu:608-611: values parsed with float precision (stof).
+struct MatrixReader {
+    int numSequences = 0;
+    std::vector<std::string> name;
+    std::vector<double> lower;  // row i has i entries
+    void read(const std::string& path);
+};
+
+struct DeviceContext {  // replaces cudaSetDevice (src/tree_generation.cu:240-245)
+    dpr_ctx* ctx = nullptr;
+    explicit DeviceContext(int device);
+    ~DeviceContext();
+};
+
+struct MSADeviceArrays {  // src/mash_placement.cuh:87-98
+    size_t numSequences = 0;
+    int seqLen = 0;
+    // seqs[i] goes to slot ids[i]; packs with the 4-bit encoder in parallel and uploads
+    void allocateDeviceArrays(DeviceContext& dev, const std::vector<std::string>& seqs, const std::vector<int>& ids);
+};
+
+struct NJDeviceArrays {  // src/mash_placement.cuh:199-212
+    int d_numSequences = 0;
+    void getDismatrix(DeviceContext& dev, int numSequences, Param& params, MatrixReader* matrixReader);
+    void findNeighbourJoiningTree(DeviceContext& dev, std::vector<std::string>& name, std::ostream& output_);
+};
+
+// Newick text of an NJ merge log (bookkeeping + print of src/neighborJoining.cu:233-270), iterative.
+void writeNewickFromMerges(std::ostream& os, const std::vector<std::string>& name, const std::vector<int32_t>& mx,
+                           const std::vector<int32_t>& my, const std::vector<double>& bx,
+                           const std::vector<double>& by, double last_d);
+
+}  // namespace dipper

@@ -248,3 +248,81 @@ def splits(newick, names):
         if 1 < len(b) < len(names) - 1:
             res.add(b if 0 not in b else full - b)
     return res
+
+
+def newick_from_placement(names, head, e, nxt, length, N, fmt=fmt):
+    """Mirror of KPlacementDeviceArrays::printTree (src/placement_close_k.cu:568-643): root = node
+    N, children in adjacency-list order, the edge back to the parent skipped."""
+    out = []
+    stack = [("node", N, -1)]
+    while stack:
+        item = stack.pop()
+        if item[0] == "text":
+            out.append(item[1])
+            continue
+        _, node, frm = item
+        if nxt[head[node]] != -1:
+            out.append("(")
+            pos = []
+            i = head[node]
+            while i != -1:
+                if e[i] != frm:
+                    pos.append(i)
+                i = nxt[i]
+            seq = []
+            for k, p in enumerate(pos):
+                seq.append(("node", int(e[p]), node))
+                seq.append(("text", ":" + fmt(float(length[p])) + (")" if k + 1 == len(pos) else ",")))
+            stack.extend(reversed(seq))
+        else:
+            out.append(names[node])
+    return "".join(out) + ";\n"
+
+
+def ref_findmin_emulation(D, U, n):
+    """Literal (slow) emulation of findMinDist<<<256,256>>> + thrust::min_element
+    (src/neighborJoining.cu:117-148,214): returns the winning tuple (x, y, q)."""
+    gs = bs = 256
+    best = None
+    r = float(n - 2)
+    for bx in range(gs):
+        sz = n // gs
+        st = sz * bx
+        if n % gs > bx:
+            sz += 1
+        st += min(bx, n % gs)
+        ed = st + sz
+        if sz == 0:
+            continue
+        for tx in range(bs):
+            minD, x, y = 10000.0, 0, 0
+            for j in range(tx, n, bs):
+                colU = U[j] / r
+                for i in range(st, ed):
+                    temp = D[i, j] - U[i] / r - colU
+                    if i != j and temp < minD:
+                        minD, x, y = temp, i, j
+            if best is None or minD < best[2]:
+                best = (x, y, minD)
+    return best
+
+
+def write_phylip_lower(path, names, D, sep="\t", digits=9):
+    with open(path, "w") as f:
+        f.write(f"{len(names)}\n")
+        for i, nm in enumerate(names):
+            f.write(nm)
+            for j in range(i):
+                f.write(sep + ("%.*g" % (digits, D[i, j])))
+            f.write("\n")
+
+
+def write_fasta(path, names, seqs, width=0):
+    with open(path, "wb") as f:
+        for nm, s in zip(names, seqs):
+            f.write(b">" + nm.encode() + b" some comment\n")
+            if width:
+                for k in range(0, len(s), width):
+                    f.write(s[k:k + width] + b"\n")
+            else:
+                f.write(s + b"\n")
