@@ -51,10 +51,12 @@ def load_library():
     L.dpr_nj_key.argtypes = [C.c_int64, C.c_int64, C.c_int64]
     L.dpr_nj_key.restype = C.c_uint64
     L.dpr_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    L.dpr_create_virtual.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int]
     L.dpr_destroy.argtypes = [C.c_void_p]
     L.dpr_device_name.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.dpr_comm_unique_id.argtypes = [C.c_void_p]
     L.dpr_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.dpr_comm_selftest.argtypes = [C.c_void_p]
     L.dpr_set_msa.argtypes = [C.c_void_p, c_u64p, C.c_int64, C.c_int64]
     L.dpr_set_reads.argtypes = [C.c_void_p, c_u64p, c_u64p, c_u64p, C.c_int64]
     L.dpr_set_matrix_lower.argtypes = [C.c_void_p, c_f64p, C.c_int64]
@@ -115,10 +117,13 @@ def pack4_many(seqs):
 class Dipper:
     """One GPU context (dpr_ctx)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, virtual_world=0):
         self.L = load_library()
         h = C.c_void_p()
-        _chk(self.L, self.L.dpr_create(C.byref(h), device))
+        if virtual_world:
+            _chk(self.L, self.L.dpr_create_virtual(C.byref(h), device, virtual_world))
+        else:
+            _chk(self.L, self.L.dpr_create(C.byref(h), device))
         self.h = h
 
     def close(self):
@@ -146,6 +151,9 @@ class Dipper:
     def comm_init(self, rank, world, uid: bytes):
         buf = (C.c_char * 128).from_buffer_copy(uid) if uid else None
         _chk(self.L, self.L.dpr_comm_init(self.h, rank, world, buf))
+
+    def comm_selftest(self):
+        _chk(self.L, self.L.dpr_comm_selftest(self.h))
 
     # ---- inputs -----------------------------------------------------------------------------------
     def set_msa(self, packed4, L):

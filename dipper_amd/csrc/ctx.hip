@@ -57,9 +57,10 @@ struct dpr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
-    int rank = 0, world = 1;
+    int rank = 0, world = 1;  // RCCL rank/world, or world = number of virtual ranks
+    int vworld = 0;           // > 0: all ranks live in this context on one device (validation mode)
     void* comm = nullptr;
-    dpr::NjBuffers nj;
+    std::vector<dpr::NjBuffers> nj = std::vector<dpr::NjBuffers>(1);  // one per rank held here
     dpr::MsaBuffers msa;
     double* packed_lower = nullptr;  // MATRIX source, device
     int64_t n_input = 0;
@@ -68,6 +69,76 @@ struct dpr_ctx {
 };
 
 using namespace dpr;
+
+// ---- exchange step of the sharded path: RCCL all-gather, or device copies between virtual ranks --
+enum ExKind { EX_RECS, EX_SLICES, EX_U };
+static const int kNcclUint8 = 1, kNcclFloat64 = 8;
+
+static int exchange(dpr_ctx* c, ExKind kind)
+{
+    if (c->world == 1) return DPR_OK;
+    if (c->vworld > 0) {
+        for (int r = 0; r < c->vworld; ++r) {
+            NjBuffers& src = c->nj[(size_t)r];
+            for (int t = 0; t < c->vworld; ++t) {
+                NjBuffers& dst = c->nj[(size_t)t];
+                if (kind == EX_RECS) {
+                    if (t == r) continue;
+                    DPR_HIP(hipMemcpyAsync(dst.recs + r, src.recs + r, sizeof(NjRecord), hipMemcpyDeviceToDevice, c->stream));
+                } else {
+                    const size_t cnt = (size_t)(kind == EX_SLICES ? 3 : 1) * (size_t)src.slice_len;
+                    DPR_HIP(hipMemcpyAsync(dst.gath + (size_t)r * cnt, src.slice, cnt * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                }
+            }
+        }
+        return DPR_OK;
+    }
+    NjBuffers& b = c->nj[0];
+    int rc;
+    if (kind == EX_RECS)
+        rc = g_rccl.AllGather(b.recs + c->rank, b.recs, sizeof(NjRecord), kNcclUint8, c->comm, c->stream);
+    else
+        rc = g_rccl.AllGather(b.slice, b.gath, (size_t)(kind == EX_SLICES ? 3 : 1) * (size_t)b.slice_len, kNcclFloat64, c->comm, c->stream);
+    if (rc != 0) {
+        set_error(std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
+        return DPR_ERR_COMM;
+    }
+    return DPR_OK;
+}
+
+static NjBuffers* owner_buffers(dpr_ctx* c, int64_t row)
+{
+    const int o = shard_owner(row, c->world);
+    if (c->vworld > 0) return &c->nj[(size_t)o];
+    return o == c->rank ? &c->nj[0] : nullptr;
+}
+
+// one NJ iteration on every rank held by this context
+static int nj_iteration(dpr_ctx* c)
+{
+    if (c->world == 1) {
+        NjBuffers& b = c->nj[0];
+        if (int rc = nj_launch_scan(b, false, c->stream)) return rc;
+        if (int rc = nj_launch_select(b, true, c->stream)) return rc;
+        if (int rc = nj_launch_update(b, c->stream)) return rc;
+        return nj_launch_finalize(b, c->stream);
+    }
+    for (auto& b : c->nj) {
+        if (int rc = nj_launch_scan(b, false, c->stream)) return rc;
+        if (int rc = nj_launch_select(b, false, c->stream)) return rc;
+    }
+    if (int rc = exchange(c, EX_RECS)) return rc;
+    for (auto& b : c->nj) {
+        if (int rc = nj_launch_commit(b, c->stream)) return rc;
+        if (int rc = nj_launch_extract(b, c->stream)) return rc;
+    }
+    if (int rc = exchange(c, EX_SLICES)) return rc;
+    for (auto& b : c->nj) {
+        if (int rc = nj_launch_update(b, c->stream)) return rc;
+        if (int rc = nj_launch_finalize(b, c->stream)) return rc;
+    }
+    return DPR_OK;
+}
 
 extern "C" {
 
@@ -164,12 +235,23 @@ int dpr_destroy(dpr_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    nj_free(c->nj);
+    for (auto& b : c->nj) nj_free(b);
     msa_free(c->msa);
     if (c->packed_lower) (void)hipFree(c->packed_lower);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    return DPR_OK;
+}
+
+int dpr_create_virtual(dpr_ctx** out, int device, int world)
+{
+    if (world < 1 || world > 64) { set_error("dpr_create_virtual: world out of range"); return DPR_ERR_ARG; }
+    if (int rc = dpr_create(out, device)) return rc;
+    dpr_ctx* c = *out;
+    c->world = world;
+    c->vworld = world > 1 ? world : 0;
+    c->nj = std::vector<NjBuffers>((size_t)world);
     return DPR_OK;
 }
 
@@ -195,6 +277,7 @@ int dpr_comm_unique_id(void* out128)
 int dpr_comm_init(dpr_ctx* c, int rank, int world, const void* id128)
 {
     if (!c || world < 1 || rank < 0 || rank >= world) { set_error("dpr_comm_init: bad argument"); return DPR_ERR_ARG; }
+    if (c->vworld > 0) { set_error("dpr_comm_init: context holds virtual ranks"); return DPR_ERR_STATE; }
     c->rank = rank; c->world = world;
     if (world == 1) return DPR_OK;
     if (!id128) { set_error("dpr_comm_init: null id"); return DPR_ERR_ARG; }
@@ -204,6 +287,41 @@ int dpr_comm_init(dpr_ctx* c, int rank, int world, const void* id128)
     std::memcpy(id.b, id128, 128);
     int r = g_rccl.CommInitRank(&c->comm, world, id, rank);
     if (r != 0) { set_error(std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?")); return DPR_ERR_COMM; }
+    return DPR_OK;
+}
+
+// RCCL plumbing self-test on ONE GPU: 1-rank communicator + all-gather of one record.  Exercises the
+// dlopen'ed entry points, the by-value ncclUniqueId ABI and the datatype constants used by exchange().
+int dpr_comm_selftest(dpr_ctx* c)
+{
+    if (!c) { set_error("dpr_comm_selftest: null ctx"); return DPR_ERR_ARG; }
+    if (int rc = rccl_load()) return rc;
+    DPR_HIP(hipSetDevice(c->device));
+    Id128 id;
+    int r = g_rccl.GetUniqueId(&id);
+    if (r != 0) { set_error("ncclGetUniqueId failed"); return DPR_ERR_COMM; }
+    void* comm = nullptr;
+    r = g_rccl.CommInitRank(&comm, 1, id, 0);
+    if (r != 0) { set_error(std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?")); return DPR_ERR_COMM; }
+    NjRecord h{ -1.5, 42ull, 2.25, 7ull }, back{ 0, 0, 0, 0 };
+    NjRecord* d = nullptr;
+    double *ds = nullptr, *dg = nullptr;
+    DPR_HIP(hipMalloc(&d, sizeof(NjRecord)));
+    DPR_HIP(hipMalloc(&ds, sizeof(double) * 192));
+    DPR_HIP(hipMalloc(&dg, sizeof(double) * 192));
+    std::vector<double> hs(192), hg(192, 0.0);
+    for (int i = 0; i < 192; ++i) hs[(size_t)i] = 0.5 * i;
+    DPR_HIP(hipMemcpy(d, &h, sizeof(NjRecord), hipMemcpyHostToDevice));
+    DPR_HIP(hipMemcpy(ds, hs.data(), sizeof(double) * 192, hipMemcpyHostToDevice));
+    r = g_rccl.AllGather(d, d, sizeof(NjRecord), kNcclUint8, comm, c->stream);          // in place
+    if (r == 0) r = g_rccl.AllGather(ds, dg, 192, kNcclFloat64, comm, c->stream);
+    DPR_HIP(hipStreamSynchronize(c->stream));
+    DPR_HIP(hipMemcpy(&back, d, sizeof(NjRecord), hipMemcpyDeviceToHost));
+    DPR_HIP(hipMemcpy(hg.data(), dg, sizeof(double) * 192, hipMemcpyDeviceToHost));
+    (void)hipFree(d); (void)hipFree(ds); (void)hipFree(dg);
+    g_rccl.CommDestroy(comm);
+    if (r != 0) { set_error("ncclAllGather failed"); return DPR_ERR_COMM; }
+    if (back.q != h.q || back.key != h.key || back.d != h.d || hg != hs) { set_error("dpr_comm_selftest: data mismatch"); return DPR_ERR_COMM; }
     return DPR_OK;
 }
 
@@ -249,7 +367,7 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
     (void)k;
     if (!c) { set_error("dpr_dist_matrix: null ctx"); return DPR_ERR_ARG; }
     DPR_HIP(hipSetDevice(c->device));
-    if (c->world > 1) { set_error("dpr_dist_matrix: multi-GPU path not built yet"); return DPR_ERR_STATE; }
+    if (c->world > 1 && c->vworld == 0 && !c->comm) { set_error("dpr_dist_matrix: dpr_comm_init was not called"); return DPR_ERR_STATE; }
     int64_t n = 0;
     if (source == DPR_SRC_MSA) {
         if (!c->msa.planes) { set_error("dpr_dist_matrix: call dpr_set_msa first"); return DPR_ERR_STATE; }
@@ -262,15 +380,24 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
         return DPR_ERR_ARG;
     }
     c->have_matrix = 0;
-    if (int rc = nj_alloc(c->nj, n, c->rank, c->world)) return rc;
+    for (size_t r = 0; r < c->nj.size(); ++r)
+        if (int rc = nj_alloc(c->nj[r], n, c->vworld > 0 ? (int)r : c->rank, c->world)) return rc;
     DPR_HIP(hipEventRecord(c->ev[0], c->stream));
-    if (source == DPR_SRC_MSA) {
-        if (int rc = msa_dist_rows(c->msa, c->nj, dist_type, c->stream)) return rc;
-    } else {
-        if (int rc = nj_expand_lower(c->nj, c->packed_lower, c->stream)) return rc;
+    for (auto& b : c->nj) {
+        if (source == DPR_SRC_MSA) {
+            if (int rc = msa_dist_rows(c->msa, b, dist_type, c->stream)) return rc;
+        } else {
+            if (int rc = nj_expand_lower(b, c->packed_lower, c->stream)) return rc;
+        }
+        if (int rc = nj_init_sums(b, c->stream)) return rc;
     }
-    if (int rc = nj_init_sums(c->nj, c->stream)) return rc;
-    if (int rc = nj_prepare(c->nj, c->stream)) return rc;
+    if (c->world > 1) {
+        if (int rc = exchange(c, EX_U)) return rc;
+        for (auto& b : c->nj)
+            if (int rc = nj_launch_unpack_u(b, c->stream)) return rc;
+    }
+    for (auto& b : c->nj)
+        if (int rc = nj_prepare(b, c->stream)) return rc;
     DPR_HIP(hipEventRecord(c->ev[1], c->stream));
     DPR_HIP(hipStreamSynchronize(c->stream));
     float ms = 0;
@@ -284,7 +411,7 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
 // ---- NJ -------------------------------------------------------------------------------------------------
 static int fetch_state(dpr_ctx* c, NjState* st)
 {
-    DPR_HIP(hipMemcpyAsync(st, c->nj.st, sizeof(NjState), hipMemcpyDeviceToHost, c->stream));
+    DPR_HIP(hipMemcpyAsync(st, c->nj[0].st, sizeof(NjState), hipMemcpyDeviceToHost, c->stream));
     DPR_HIP(hipStreamSynchronize(c->stream));
     return DPR_OK;
 }
@@ -301,12 +428,8 @@ int64_t dpr_nj_run(dpr_ctx* c, int64_t max_iters, int32_t* merge_x, int32_t* mer
     if (max_iters >= 0 && max_iters < todo) todo = max_iters;
     const int64_t it0 = st.it;
     DPR_HIP(hipEventRecord(c->ev[2], c->stream));
-    for (int64_t k = 0; k < todo; ++k) {
-        if (int rc = nj_launch_scan(c->nj, false, c->stream)) return rc;
-        if (int rc = nj_launch_select(c->nj, true, c->stream)) return rc;
-        if (int rc = nj_launch_update(c->nj, c->stream)) return rc;
-        if (int rc = nj_launch_finalize(c->nj, c->stream)) return rc;
-    }
+    for (int64_t k = 0; k < todo; ++k)
+        if (int rc = nj_iteration(c)) return rc;
     DPR_HIP(hipEventRecord(c->ev[3], c->stream));
     if (int rc = fetch_state(c, &st)) return rc;
     float ms = 0;
@@ -314,18 +437,29 @@ int64_t dpr_nj_run(dpr_ctx* c, int64_t max_iters, int32_t* merge_x, int32_t* mer
     c->nj_ms = ms;
     const int64_t done = st.it - it0;
     if (done > 0) {
-        if (merge_x) DPR_HIP(hipMemcpy(merge_x, c->nj.log_x + it0, sizeof(int32_t) * (size_t)done, hipMemcpyDeviceToHost));
-        if (merge_y) DPR_HIP(hipMemcpy(merge_y, c->nj.log_y + it0, sizeof(int32_t) * (size_t)done, hipMemcpyDeviceToHost));
-        if (bl_x) DPR_HIP(hipMemcpy(bl_x, c->nj.log_bx + it0, sizeof(double) * (size_t)done, hipMemcpyDeviceToHost));
-        if (bl_y) DPR_HIP(hipMemcpy(bl_y, c->nj.log_by + it0, sizeof(double) * (size_t)done, hipMemcpyDeviceToHost));
+        if (merge_x) DPR_HIP(hipMemcpy(merge_x, c->nj[0].log_x + it0, sizeof(int32_t) * (size_t)done, hipMemcpyDeviceToHost));
+        if (merge_y) DPR_HIP(hipMemcpy(merge_y, c->nj[0].log_y + it0, sizeof(int32_t) * (size_t)done, hipMemcpyDeviceToHost));
+        if (bl_x) DPR_HIP(hipMemcpy(bl_x, c->nj[0].log_bx + it0, sizeof(double) * (size_t)done, hipMemcpyDeviceToHost));
+        if (bl_y) DPR_HIP(hipMemcpy(bl_y, c->nj[0].log_by + it0, sizeof(double) * (size_t)done, hipMemcpyDeviceToHost));
     }
     if (st.status != 0) {
         set_error("dpr_nj_run: no Q candidate below the reference's init value 10000 (undefined in the reference)");
         return DPR_ERR_NOCAND;
     }
     if (last_d && st.n == 2) {
-        // D[0][1] of the final pair (src/neighborJoining.cu:245-249); row 1 is owned by rank of block 0
-        DPR_HIP(hipMemcpy(last_d, c->nj.D + 1 * c->nj.ld + 0, sizeof(double), hipMemcpyDeviceToHost));
+        // D[0][1] of the final pair (src/neighborJoining.cu:245-249); row 1 lives on rank 0
+        NjBuffers& b0 = c->nj[0];
+        if (c->world == 1 || c->vworld > 0) {
+            DPR_HIP(hipMemcpy(last_d, b0.D + 1 * b0.ld + 0, sizeof(double), hipMemcpyDeviceToHost));
+        } else {
+            NjRecord rec{ 0.0, 0ull, 0.0, 0ull };
+            if (c->rank == 0) DPR_HIP(hipMemcpy(&rec.d, b0.D + 1 * b0.ld + 0, sizeof(double), hipMemcpyDeviceToHost));
+            DPR_HIP(hipMemcpy(b0.recs + c->rank, &rec, sizeof(NjRecord), hipMemcpyHostToDevice));
+            if (int rc = exchange(c, EX_RECS)) return rc;
+            DPR_HIP(hipStreamSynchronize(c->stream));
+            DPR_HIP(hipMemcpy(&rec, b0.recs + 0, sizeof(NjRecord), hipMemcpyDeviceToHost));
+            *last_d = rec.d;
+        }
     }
     return done;
 }
@@ -335,27 +469,25 @@ int dpr_argmin_once(dpr_ctx* c, int reps, int32_t* out_i, int32_t* out_j, double
     if (!c || !c->have_matrix) { set_error("dpr_argmin_once: call dpr_dist_matrix first"); return DPR_ERR_STATE; }
     DPR_HIP(hipSetDevice(c->device));
     if (reps < 1) reps = 1;
-    if (int rc = nj_launch_scan(c->nj, true, c->stream)) return rc;  // warm
+    for (auto& b : c->nj)
+        if (int rc = nj_launch_scan(b, true, c->stream)) return rc;  // warm
     DPR_HIP(hipEventRecord(c->ev[2], c->stream));
     for (int r = 0; r < reps; ++r)
-        if (int rc = nj_launch_scan(c->nj, true, c->stream)) return rc;
+        for (auto& b : c->nj)
+            if (int rc = nj_launch_scan(b, true, c->stream)) return rc;
     DPR_HIP(hipEventRecord(c->ev[3], c->stream));
-    if (int rc = nj_launch_select(c->nj, false, c->stream)) return rc;
-    NjRecord rec;
-    DPR_HIP(hipMemcpyAsync(&rec, c->nj.recs, sizeof(NjRecord), hipMemcpyDeviceToHost, c->stream));
+    for (auto& b : c->nj)
+        if (int rc = nj_launch_select(b, false, c->stream)) return rc;
+    if (int rc = exchange(c, EX_RECS)) return rc;
+    std::vector<NjRecord> recs((size_t)c->world);
+    DPR_HIP(hipMemcpyAsync(recs.data(), c->nj[0].recs, sizeof(NjRecord) * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
     DPR_HIP(hipStreamSynchronize(c->stream));
     float ms = 0;
     DPR_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
     if (out_ms) *out_ms = ms / (float)reps;
-    NjState st;
-    if (int rc = fetch_state(c, &st)) return rc;
-    if (rec.key == ~0ull) {
-        // the select kernel flags the state; clear it again, a probe must not poison the run
-        st.status = 0;
-        DPR_HIP(hipMemcpy(c->nj.st, &st, sizeof(NjState), hipMemcpyHostToDevice));
-        set_error("dpr_argmin_once: no Q candidate below 10000");
-        return DPR_ERR_NOCAND;
-    }
+    const int w = dpr_record_reduce(recs.data(), c->world);
+    if (w < 0) { set_error("dpr_argmin_once: no Q candidate below 10000"); return DPR_ERR_NOCAND; }
+    const NjRecord& rec = recs[(size_t)w];
     if (out_i) *out_i = (int32_t)(rec.key & 0xFFFFFFull);
     if (out_j) *out_j = (int32_t)((rec.key >> 24) & 0xFFFFFFull);
     if (out_q) *out_q = rec.q;
@@ -371,20 +503,21 @@ int64_t dpr_n_active(dpr_ctx* c)
     return st.n;
 }
 
-int64_t dpr_n_total(dpr_ctx* c) { return c ? c->nj.N : DPR_ERR_ARG; }
+int64_t dpr_n_total(dpr_ctx* c) { return c ? c->nj[0].N : DPR_ERR_ARG; }
 
 int dpr_get_matrix_row(dpr_ctx* c, int64_t i, double* out)
 {
-    if (!c || !c->have_matrix || !out || i < 0 || i >= c->nj.N) { set_error("dpr_get_matrix_row: bad argument"); return DPR_ERR_ARG; }
-    if (shard_owner(i, c->world) != c->rank) { set_error("dpr_get_matrix_row: row not owned by this rank"); return DPR_ERR_ARG; }
-    DPR_HIP(hipMemcpy(out, c->nj.D + shard_local_row(i, c->world) * c->nj.ld, sizeof(double) * (size_t)c->nj.N, hipMemcpyDeviceToHost));
+    if (!c || !c->have_matrix || !out || i < 0 || i >= c->nj[0].N) { set_error("dpr_get_matrix_row: bad argument"); return DPR_ERR_ARG; }
+    NjBuffers* b = owner_buffers(c, i);
+    if (!b) { set_error("dpr_get_matrix_row: row not owned by this rank"); return DPR_ERR_ARG; }
+    DPR_HIP(hipMemcpy(out, b->D + shard_local_row(i, c->world) * b->ld, sizeof(double) * (size_t)b->N, hipMemcpyDeviceToHost));
     return DPR_OK;
 }
 
 int dpr_get_row_sums(dpr_ctx* c, double* out)
 {
     if (!c || !c->have_matrix || !out) { set_error("dpr_get_row_sums: bad argument"); return DPR_ERR_ARG; }
-    DPR_HIP(hipMemcpy(out, c->nj.U, sizeof(double) * (size_t)c->nj.N, hipMemcpyDeviceToHost));
+    DPR_HIP(hipMemcpy(out, c->nj[0].U, sizeof(double) * (size_t)c->nj[0].N, hipMemcpyDeviceToHost));
     return DPR_OK;
 }
 

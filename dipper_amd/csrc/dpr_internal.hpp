@@ -111,6 +111,9 @@ int nj_prepare(NjBuffers& b, hipStream_t s);            // Ur, KA for n = st->n
 int nj_launch_scan(NjBuffers& b, bool probe, hipStream_t s);
 int nj_launch_select(NjBuffers& b, bool commit, hipStream_t s);   // world == 1
 int nj_launch_update(NjBuffers& b, hipStream_t s);
+int nj_launch_commit(NjBuffers& b, hipStream_t s);    // world > 1: reduce b.recs[world] + commit
+int nj_launch_extract(NjBuffers& b, hipStream_t s);   // world > 1: column slices of x, y, n-1
+int nj_launch_unpack_u(NjBuffers& b, hipStream_t s);  // world > 1: gathered row sums -> U
 int nj_launch_finalize(NjBuffers& b, hipStream_t s);
 
 // msa.hip

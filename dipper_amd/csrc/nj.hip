@@ -91,7 +91,8 @@ __global__ __launch_bounds__(kThreads) void nj_expand_lower_kernel(const double*
 __global__ __launch_bounds__(kThreads) void nj_row_sums_kernel(const double* __restrict__ D,
                                                                int64_t ld, int64_t N,
                                                                int64_t rows_local, int rank,
-                                                               int world, double* __restrict__ U)
+                                                               int world, double* __restrict__ U,
+                                                               int local_index)
 {
     __shared__ double s[kThreads];
     for (int64_t li = blockIdx.x; li < rows_local; li += gridDim.x) {
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(kThreads) void nj_row_sums_kernel(const double* __r
         for (int64_t j = threadIdx.x; j < N; j += kThreads)
             if (j != i) acc += row[j];
         const double tot = block_tree256(acc, s);
-        if (threadIdx.x == 0) U[i] = tot;
+        if (threadIdx.x == 0) U[local_index ? li : i] = tot;
         __syncthreads();
     }
 }
@@ -250,9 +251,12 @@ __global__ __launch_bounds__(kThreads) void nj_select_kernel(
     for (int i = threadIdx.x; i < nparts; i += kThreads) best_update(bq, bk, partials[i].q, partials[i].key);
     block_best(bq, bk, sq, sk);
     if (threadIdx.x != 0) return;
-    if (st->status != 0) return;
+    if (st->status != 0) {
+        if (out) { out->q = 10000.0; out->key = ~0ull; out->d = 0.0; out->pad = 0; }
+        return;
+    }
     if (bk == ~0ull) {
-        st->status = 1;
+        if (COMMIT) st->status = 1;
         if (out) { out->q = bq; out->key = bk; out->d = 0.0; out->pad = 0; }
         return;
     }
@@ -323,6 +327,113 @@ __global__ __launch_bounds__(kThreads) void nj_update_kernel(double* __restrict_
     if (threadIdx.x == 0) xpart[blockIdx.x] = cs;
 }
 
+// ------------------------------------------------------------------------------------------------
+// world > 1.  Per iteration: local record -> all-gather -> commit (identical on every rank) ->
+// column slices of x, y, n-1 for the owned rows -> all-gather -> update.
+// ------------------------------------------------------------------------------------------------
+__global__ void nj_commit_kernel(NjState* __restrict__ st, const double* __restrict__ U,
+                                 const NjRecord* __restrict__ recs, int world,
+                                 int32_t* __restrict__ log_x, int32_t* __restrict__ log_y,
+                                 double* __restrict__ log_bx, double* __restrict__ log_by)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (st->status != 0) return;
+    double bq = 10000.0, d = 0.0;
+    uint64_t bk = ~0ull;
+    for (int r = 0; r < world; ++r) {
+        const double q = recs[r].q;
+        const uint64_t k = recs[r].key;
+        if ((q < bq) | ((q == bq) & (k < bk))) { bq = q; bk = k; d = recs[r].d; }
+    }
+    if (bk == ~0ull) { st->status = 1; return; }
+    const int64_t i = (int64_t)(bk & 0xFFFFFFull), j = (int64_t)((bk >> 24) & 0xFFFFFFull);
+    const int64_t x = i < j ? i : j, y = i < j ? j : i;
+    const int64_t n = st->n;
+    const double r = (double)(n - 2);
+    double blX = (d + U[x] / r - U[y] / r) * 0.5;
+    double blY = d - blX;
+    if (blX < 0) { blY += blX; blX = 0; }
+    if (blY < 0) { blX += blY; blY = 0; }
+    const int64_t it = st->it;
+    log_x[it] = (int32_t)x; log_y[it] = (int32_t)y; log_bx[it] = blX; log_by[it] = blY;
+    st->x = (int32_t)x; st->y = (int32_t)y; st->d = d; st->q = bq;
+}
+
+// slice[v][li] = D[li][c_v] for c = (x, y, n-1), owned rows with global index < n
+__global__ __launch_bounds__(kThreads) void nj_extract_kernel(const double* __restrict__ D, int64_t ld,
+                                                              const NjState* __restrict__ st,
+                                                              double* __restrict__ slice,
+                                                              int64_t slice_len, int64_t rows_local,
+                                                              int rank, int world)
+{
+    if (st->status != 0) return;
+    const int64_t li = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (li >= rows_local) return;
+    const int64_t n = st->n;
+    const int64_t i = shard_global_row(li, rank, world);
+    if (i >= n) return;
+    const double* row = D + li * ld;
+    slice[0 * slice_len + li] = row[st->x];
+    slice[1 * slice_len + li] = row[st->y];
+    slice[2 * slice_len + li] = row[n - 1];
+}
+
+// gathered layout: gath[(r*3 + v)*slice_len + li]
+__global__ __launch_bounds__(kThreads) void nj_update_sharded_kernel(
+    double* __restrict__ D, int64_t ld, const NjState* __restrict__ st, double* __restrict__ U,
+    double* __restrict__ Ur, uint64_t* __restrict__ KA, double* __restrict__ xpart,
+    const double* __restrict__ gath, int64_t slice_len, int rank, int world)
+{
+    __shared__ double s[kThreads];
+    const int64_t n = st->n;
+    if (st->status != 0) return;
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if ((int64_t)blockIdx.x * kThreads >= n) return;
+    const int64_t x = st->x, y = st->y, last = n - 1;
+    const double d = st->d;
+    const int64_t n1 = n - 1;
+    const double r1 = (double)(n1 - 2);
+    const bool own_x = shard_owner(x, world) == rank, own_y = shard_owner(y, world) == rank;
+    const int64_t lx = shard_local_row(x, world), ly = shard_local_row(y, world);
+
+    double val = 0.0;
+    if (i < n && i != x && i != y) {
+        const int ro = shard_owner(i, world);
+        const int64_t li = shard_local_row(i, world);
+        const double* g = gath + (int64_t)ro * 3 * slice_len + li;
+        const double dxi = g[0], dyi = g[slice_len];
+        val = (dxi + dyi - d) * 0.5;
+        if (i != last) {
+            const double far = g[2 * slice_len];
+            const double u = U[i] + (-dxi - dyi + val);
+            U[i] = u;
+            Ur[i] = u / r1;
+            if (own_x) D[lx * ld + i] = val;
+            if (own_y) D[ly * ld + i] = far;
+            if (ro == rank) { D[li * ld + x] = val; D[li * ld + y] = far; }
+        } else {
+            const double uy = U[last] + (-dxi - dyi + val);
+            U[y] = uy;
+            Ur[y] = uy / r1;
+            if (own_x) D[lx * ld + y] = val;
+            if (own_y) D[ly * ld + x] = val;
+        }
+    }
+    if (i < n1) KA[i] = nj_key_a(i, n1);
+    const double cs = block_tree256(val, s);
+    if (threadIdx.x == 0) xpart[blockIdx.x] = cs;
+}
+
+// initial row sums: Uloc[li] for owned rows (gathered by the caller), then U[i] = gathU[owner][li]
+__global__ __launch_bounds__(kThreads) void nj_unpack_u_kernel(const double* __restrict__ gathU,
+                                                               int64_t slice_len, int64_t N, int world,
+                                                               double* __restrict__ U)
+{
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= N) return;
+    U[i] = gathU[(int64_t)shard_owner(i, world) * slice_len + shard_local_row(i, world)];
+}
+
 // U[x] = canonical sum of the chunk sums; advance the state to n-1.
 __global__ __launch_bounds__(kThreads) void nj_finalize_kernel(NjState* __restrict__ st,
                                                                double* __restrict__ U,
@@ -371,6 +482,17 @@ int nj_alloc(NjBuffers& b, int64_t N, int rank, int world)
     DPR_HIP(hipMalloc(&b.partials, sizeof(NjRecord) * kScanBlocks));
     DPR_HIP(hipMalloc(&b.recs, sizeof(NjRecord) * (size_t)(world > 1 ? world : 1)));
     DPR_HIP(hipMalloc(&b.xpart, sizeof(double) * (size_t)((N + kThreads - 1) / kThreads + 1)));
+    {
+        // uniform slice length: local rows of rank 0 at n = N, padded to whole ownership blocks
+        const int64_t nblk = (N + kRowBlock - 1) / kRowBlock;
+        b.slice_len = ((nblk + world - 1) / world) * kRowBlock;
+        if (world > 1) {
+            DPR_HIP(hipMalloc(&b.slice, sizeof(double) * (size_t)(3 * b.slice_len)));
+            DPR_HIP(hipMalloc(&b.gath, sizeof(double) * (size_t)(3 * b.slice_len * world)));
+            DPR_HIP(hipMemset(b.slice, 0, sizeof(double) * (size_t)(3 * b.slice_len)));
+            DPR_HIP(hipMemset(b.gath, 0, sizeof(double) * (size_t)(3 * b.slice_len * world)));
+        }
+    }
     DPR_HIP(hipMalloc(&b.st, sizeof(NjState)));
     DPR_HIP(hipMalloc(&b.log_x, sizeof(int32_t) * (size_t)(N + 1)));
     DPR_HIP(hipMalloc(&b.log_y, sizeof(int32_t) * (size_t)(N + 1)));
@@ -415,8 +537,9 @@ int nj_init_sums(NjBuffers& b, hipStream_t s)
 {
     if (b.rows_local > 0) {
         const unsigned grid = (unsigned)(b.rows_local < 4096 ? b.rows_local : 4096);
+        // world > 1: sums of the owned rows go to slice[0..rows_local) and are all-gathered by the caller
         hipLaunchKernelGGL(nj_row_sums_kernel, dim3(grid), dim3(kThreads), 0, s, b.D, b.ld, b.N,
-                           b.rows_local, b.rank, b.world, b.U);
+                           b.rows_local, b.rank, b.world, b.world > 1 ? b.slice : b.U, b.world > 1 ? 1 : 0);
         DPR_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(nj_state_init_kernel, dim3(1), dim3(1), 0, s, b.st, b.N);
@@ -445,16 +568,44 @@ int nj_launch_scan(NjBuffers& b, bool probe, hipStream_t s)
     return DPR_OK;
 }
 
+// commit = true: world == 1, reduce + commit.  commit = false: local record only, written to
+// b.recs[b.rank] (all-gathered in place by the caller when world > 1).
 int nj_launch_select(NjBuffers& b, bool commit, hipStream_t s)
 {
     if (commit)
         hipLaunchKernelGGL(nj_select_kernel<true>, dim3(1), dim3(kThreads), 0, s, b.D, b.ld, b.st, b.U,
                            b.partials, kScanBlocks, b.rank, b.world, b.log_x, b.log_y, b.log_bx,
-                           b.log_by, b.recs);
+                           b.log_by, b.recs + b.rank);
     else
         hipLaunchKernelGGL(nj_select_kernel<false>, dim3(1), dim3(kThreads), 0, s, b.D, b.ld, b.st, b.U,
                            b.partials, kScanBlocks, b.rank, b.world, b.log_x, b.log_y, b.log_bx,
-                           b.log_by, b.recs);
+                           b.log_by, b.recs + b.rank);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+int nj_launch_unpack_u(NjBuffers& b, hipStream_t s)
+{
+    const unsigned grid = (unsigned)((b.N + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(nj_unpack_u_kernel, dim3(grid), dim3(kThreads), 0, s, b.gath, b.slice_len, b.N, b.world, b.U);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+int nj_launch_commit(NjBuffers& b, hipStream_t s)
+{
+    hipLaunchKernelGGL(nj_commit_kernel, dim3(1), dim3(64), 0, s, b.st, b.U, b.recs, b.world, b.log_x, b.log_y,
+                       b.log_bx, b.log_by);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+int nj_launch_extract(NjBuffers& b, hipStream_t s)
+{
+    if (b.rows_local == 0) return DPR_OK;
+    const unsigned grid = (unsigned)((b.rows_local + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(nj_extract_kernel, dim3(grid), dim3(kThreads), 0, s, b.D, b.ld, b.st, b.slice, b.slice_len,
+                       b.rows_local, b.rank, b.world);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
@@ -462,6 +613,12 @@ int nj_launch_select(NjBuffers& b, bool commit, hipStream_t s)
 int nj_launch_update(NjBuffers& b, hipStream_t s)
 {
     const unsigned grid = (unsigned)((b.N + kThreads - 1) / kThreads);
+    if (b.world > 1) {
+        hipLaunchKernelGGL(nj_update_sharded_kernel, dim3(grid), dim3(kThreads), 0, s, b.D, b.ld, b.st, b.U, b.Ur,
+                           b.KA, b.xpart, b.gath, b.slice_len, b.rank, b.world);
+        DPR_HIP(hipGetLastError());
+        return DPR_OK;
+    }
     hipLaunchKernelGGL(nj_update_kernel, dim3(grid), dim3(kThreads), 0, s, b.D, b.ld, b.st, b.U, b.Ur,
                        b.KA, b.xpart);
     DPR_HIP(hipGetLastError());

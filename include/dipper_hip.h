@@ -78,6 +78,11 @@ uint64_t dpr_nj_key(int64_t i, int64_t j, int64_t n);
  * reference quirk). */
 int dpr_create(dpr_ctx **out, int device);
 int dpr_destroy(dpr_ctx *ctx);
+/* Validation mode of the multi-GPU path: ONE context holds `world` virtual ranks on one device and
+ * runs the sharded algorithm (same kernels, same per-rank buffers) with the two per-iteration
+ * all-gathers done as device copies instead of RCCL.  Used to prove on a 1-GPU box that the sharded
+ * result is bit-identical to the single-rank result. */
+int dpr_create_virtual(dpr_ctx **out, int device, int world);
 int dpr_device_name(dpr_ctx *ctx, char *buf, int cap);
 
 /* ---- multi-GPU (one process per GPU; RCCL over xGMI).  No reference counterpart (single GPU).
@@ -85,6 +90,8 @@ int dpr_device_name(dpr_ctx *ctx, char *buf, int cap);
  * in bench.py), every rank calls dpr_comm_init before any dpr_set_* call. */
 int dpr_comm_unique_id(void *out128);
 int dpr_comm_init(dpr_ctx *ctx, int rank, int world, const void *id128);
+/* 1-rank RCCL round trip on this context's GPU (plumbing check on a single-GPU box) */
+int dpr_comm_selftest(dpr_ctx *ctx);
 
 /* ---- inputs ----------------------------------------------------------------------------------*/
 /* MSADeviceArrays::allocateDeviceArrays (src/MSA.cu:14-72): packed4 is [n][ceil(L/16)] words as
