@@ -72,6 +72,8 @@ def load_library():
     L.dpr_get_matrix_row.argtypes = [C.c_void_p, C.c_int64, c_f64p]
     L.dpr_get_row_sums.argtypes = [C.c_void_p, c_f64p]
     L.dpr_get_msa_counts.argtypes = [C.c_void_p, C.c_int64, c_i32p, c_i32p]
+    L.dpr_get_kmer_hashes.argtypes = [C.c_void_p, C.c_int64, C.c_int, c_u64p, c_u64p, c_u64p]
+    L.dpr_get_place_state.argtypes = [C.c_void_p, c_i32p, c_f64p, c_f64p]
     L.dpr_get_timing.argtypes = [C.c_void_p, c_f64p, c_f64p]
     L.dpr_place_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                 c_i32p, c_i32p, c_i32p, c_i32p, c_f64p]
@@ -171,6 +173,46 @@ class Dipper:
         n = D.shape[0]
         rows = np.concatenate([D[i, :i] for i in range(n)]) if n > 1 else np.zeros(0)
         self.set_matrix_lower(rows, n)
+
+    def set_reads(self, seqs):
+        """seqs: list of byte strings (unaligned reads); packs with the 2-bit encoder."""
+        words = [pack2(s) for s in seqs]
+        lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+        nw = np.array([len(w) for w in words], dtype=np.uint64)
+        off = np.zeros(len(seqs), dtype=np.uint64)
+        off[1:] = np.cumsum(nw)[:-1]
+        flat = np.concatenate(words) if len(words) else np.zeros(0, np.uint64)
+        if flat.size == 0:
+            flat = np.zeros(1, np.uint64)
+        self._reads = (np.ascontiguousarray(flat), off, lens)
+        _chk(self.L, self.L.dpr_set_reads(self.h, _p(self._reads[0], c_u64p), _p(off, c_u64p), _p(lens, c_u64p), len(seqs)))
+
+    def sketch(self, k=15, S=1000, fetch=True):
+        n = len(self._reads[2])
+        out = np.zeros((n, S), dtype=np.uint64) if fetch else None
+        _chk(self.L, self.L.dpr_sketch(self.h, k, S, _p(out, c_u64p) if fetch else None))
+        return out
+
+    def kmer_hashes(self, seq, k):
+        _, off, lens = self._reads
+        nk = max(int(lens[seq]) - k + 1, 0)
+        out = np.zeros(max(nk, 1), dtype=np.uint64)
+        _chk(self.L, self.L.dpr_get_kmer_hashes(self.h, seq, k, _p(off, c_u64p), _p(lens, c_u64p), _p(out, c_u64p)))
+        return out[:nk]
+
+    def place_run(self, source, n, first=2, dist_type=1, k=15, state=None):
+        st = state or dict(head=np.full(2 * n, -1, np.int32), e=np.full(8 * n, -1, np.int32),
+                           nxt=np.full(8 * n, -1, np.int32), belong=np.full(8 * n, -1, np.int32),
+                           len=np.full(8 * n, 2.0, np.float64))
+        _chk(self.L, self.L.dpr_place_run(self.h, source, dist_type, k, first, n, _p(st["head"], c_i32p),
+                                          _p(st["e"], c_i32p), _p(st["nxt"], c_i32p), _p(st["belong"], c_i32p),
+                                          _p(st["len"], c_f64p)))
+        cid = np.zeros(40 * n, np.int32)
+        cdis = np.zeros(40 * n, np.float64)
+        trace = np.zeros(3 * n, np.float64)
+        _chk(self.L, self.L.dpr_get_place_state(self.h, _p(cid, c_i32p), _p(cdis, c_f64p), _p(trace, c_f64p)))
+        st.update(cid=cid, cdis=cdis, trace=trace.reshape(n, 3))
+        return st
 
     def dist_matrix(self, source, dist_type=1, k=15):
         _chk(self.L, self.L.dpr_dist_matrix(self.h, source, dist_type, k))

@@ -62,6 +62,9 @@ struct dpr_ctx {
     void* comm = nullptr;
     std::vector<dpr::NjBuffers> nj = std::vector<dpr::NjBuffers>(1);  // one per rank held here
     dpr::MsaBuffers msa;
+    dpr::MashBuffers mash;
+    dpr::PlaceBuffers place;
+    double* place_trace = nullptr;   // [3N] (eid, frac, add) per placed tip
     double* packed_lower = nullptr;  // MATRIX source, device
     int64_t n_input = 0;
     int have_matrix = 0;
@@ -237,6 +240,9 @@ int dpr_destroy(dpr_ctx* c)
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     for (auto& b : c->nj) nj_free(b);
     msa_free(c->msa);
+    mash_free(c->mash);
+    place_free(c->place);
+    if (c->place_trace) (void)hipFree(c->place_trace);
     if (c->packed_lower) (void)hipFree(c->packed_lower);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -335,10 +341,13 @@ int dpr_set_msa(dpr_ctx* c, const uint64_t* packed4, int64_t n, int64_t L)
     return msa_upload(c->msa, packed4, n, L, c->stream);
 }
 
-int dpr_set_reads(dpr_ctx*, const uint64_t*, const uint64_t*, const uint64_t*, int64_t)
+int dpr_set_reads(dpr_ctx* c, const uint64_t* packed2, const uint64_t* word_off, const uint64_t* len, int64_t n)
 {
-    set_error("dpr_set_reads: Mash path not built yet");
-    return DPR_ERR_STATE;
+    if (!c || !packed2 || !word_off || !len || n < 2) { set_error("dpr_set_reads: bad argument"); return DPR_ERR_ARG; }
+    if (n >= (1 << 24)) { set_error("dpr_set_reads: n must be < 2^24"); return DPR_ERR_ARG; }
+    DPR_HIP(hipSetDevice(c->device));
+    c->n_input = n;
+    return mash_upload(c->mash, packed2, word_off, len, n, c->stream);
 }
 
 int dpr_set_matrix_lower(dpr_ctx* c, const double* rows, int64_t n)
@@ -355,16 +364,37 @@ int dpr_set_matrix_lower(dpr_ctx* c, const double* rows, int64_t n)
     return DPR_OK;
 }
 
-int dpr_sketch(dpr_ctx*, int, int, uint64_t*)
+int dpr_sketch(dpr_ctx* c, int k, int S, uint64_t* host_sketches)
 {
-    set_error("dpr_sketch: Mash path not built yet");
-    return DPR_ERR_STATE;
+    if (!c || !c->mash.packed2) { set_error("dpr_sketch: call dpr_set_reads first"); return DPR_ERR_STATE; }
+    DPR_HIP(hipSetDevice(c->device));
+    if (int rc = mash_sketch(c->mash, k, S, c->stream)) return rc;
+    DPR_HIP(hipStreamSynchronize(c->stream));
+    if (host_sketches)
+        DPR_HIP(hipMemcpy(host_sketches, c->mash.sketches, sizeof(uint64_t) * (size_t)(c->mash.n * S), hipMemcpyDeviceToHost));
+    return DPR_OK;
+}
+
+int dpr_get_kmer_hashes(dpr_ctx* c, int64_t seq, int k, const uint64_t* word_off, const uint64_t* len, uint64_t* out)
+{
+    if (!c || !c->mash.packed2 || seq < 0 || seq >= c->mash.n || !out || k < 1 || k > 15) { set_error("dpr_get_kmer_hashes: bad argument"); return DPR_ERR_ARG; }
+    const uint64_t L = len[seq];
+    if (L < (uint64_t)k) return DPR_OK;
+    const uint64_t nk = L - (uint64_t)k + 1;
+    uint64_t* d = nullptr;
+    DPR_HIP(hipMalloc(&d, sizeof(uint64_t) * nk));
+    int rc = mash_hash_positions(c->mash, seq, k, d, L, word_off[seq], c->stream);
+    if (rc == DPR_OK) {
+        DPR_HIP(hipStreamSynchronize(c->stream));
+        DPR_HIP(hipMemcpy(out, d, sizeof(uint64_t) * nk, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d);
+    return rc;
 }
 
 // ---- distance matrix ----------------------------------------------------------------------------------
 int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
 {
-    (void)k;
     if (!c) { set_error("dpr_dist_matrix: null ctx"); return DPR_ERR_ARG; }
     DPR_HIP(hipSetDevice(c->device));
     if (c->world > 1 && c->vworld == 0 && !c->comm) { set_error("dpr_dist_matrix: dpr_comm_init was not called"); return DPR_ERR_STATE; }
@@ -375,6 +405,10 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
     } else if (source == DPR_SRC_MATRIX) {
         if (!c->packed_lower) { set_error("dpr_dist_matrix: call dpr_set_matrix_lower first"); return DPR_ERR_STATE; }
         n = c->n_input;
+    } else if (source == DPR_SRC_MASH) {
+        if (!c->mash.sketches) { set_error("dpr_dist_matrix: call dpr_set_reads and dpr_sketch first"); return DPR_ERR_STATE; }
+        if (k != c->mash.k) { set_error("dpr_dist_matrix: k differs from the sketch k"); return DPR_ERR_ARG; }
+        n = c->mash.n;
     } else {
         set_error("dpr_dist_matrix: source not available");
         return DPR_ERR_ARG;
@@ -386,6 +420,11 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
     for (auto& b : c->nj) {
         if (source == DPR_SRC_MSA) {
             if (int rc = msa_dist_rows(c->msa, b, dist_type, c->stream)) return rc;
+        } else if (source == DPR_SRC_MASH) {
+            for (int64_t r0 = 0; r0 < b.rows_local; r0 += 32768) {
+                const int64_t nr = b.rows_local - r0 < 32768 ? b.rows_local - r0 : 32768;
+                if (int rc = mash_dist_rows(c->mash, r0, nr, b.rank, b.world, true, n, b.D + r0 * b.ld, b.ld, c->stream)) return rc;
+            }
         } else {
             if (int rc = nj_expand_lower(b, c->packed_lower, c->stream)) return rc;
         }
@@ -546,10 +585,78 @@ int dpr_get_timing(dpr_ctx* c, double* dist_ms, double* nj_ms)
     return DPR_OK;
 }
 
-int dpr_place_run(dpr_ctx*, int, int, int, int64_t, int64_t, int32_t*, int32_t*, int32_t*, int32_t*, double*)
+int dpr_place_run(dpr_ctx* c, int source, int dist_type, int k, int64_t first, int64_t n, int32_t* head,
+                  int32_t* e, int32_t* nxt, int32_t* belong, double* len)
 {
-    set_error("dpr_place_run: placement path not built yet");
-    return DPR_ERR_STATE;
+    if (!c || !head || !e || !nxt || !belong || !len || n < 3 || first < 2 || first > n) { set_error("dpr_place_run: bad argument"); return DPR_ERR_ARG; }
+    DPR_HIP(hipSetDevice(c->device));
+    if (source == DPR_SRC_MSA) {
+        if (!c->msa.planes || c->msa.n != n) { set_error("dpr_place_run: call dpr_set_msa with n sequences first"); return DPR_ERR_STATE; }
+    } else if (source == DPR_SRC_MASH) {
+        if (!c->mash.sketches || c->mash.n != n) { set_error("dpr_place_run: call dpr_set_reads and dpr_sketch first"); return DPR_ERR_STATE; }
+        if (k != c->mash.k) { set_error("dpr_place_run: k differs from the sketch k"); return DPR_ERR_ARG; }
+    } else if (source == DPR_SRC_MATRIX) {
+        if (!c->packed_lower || c->n_input != n) { set_error("dpr_place_run: call dpr_set_matrix_lower first"); return DPR_ERR_STATE; }
+    } else { set_error("dpr_place_run: unknown source"); return DPR_ERR_ARG; }
+    if (int rc = place_alloc(c->place, n)) return rc;
+    PlaceBuffers& p = c->place;
+    if (c->place_trace) { (void)hipFree(c->place_trace); c->place_trace = nullptr; }
+    DPR_HIP(hipMalloc(&c->place_trace, sizeof(double) * (size_t)(3 * n)));
+    DPR_HIP(hipMemsetAsync(c->place_trace, 0, sizeof(double) * (size_t)(3 * n), c->stream));
+    const int64_t R = 256;                       // distance rows per batch
+    const int64_t ldb = (n + 15) / 16 * 16;
+    double* rows = nullptr;
+    if (source != DPR_SRC_MATRIX) DPR_HIP(hipMalloc(&rows, sizeof(double) * (size_t)(R * ldb)));
+    auto row_ptr = [&](int64_t i, int64_t i0) -> const double* {
+        return source == DPR_SRC_MATRIX ? c->packed_lower + i * (i - 1) / 2 : rows + (i - i0) * ldb;
+    };
+    auto fill_rows = [&](int64_t i0, int64_t nr) -> int {
+        if (source == DPR_SRC_MSA) return msa_dist_block_rows(c->msa, i0, nr, 0, 0, i0 + nr, dist_type, rows, ldb, c->stream);
+        if (source == DPR_SRC_MASH) return mash_dist_rows(c->mash, i0, nr, 0, 0, false, i0 + nr, rows, ldb, c->stream);
+        return DPR_OK;
+    };
+    DPR_HIP(hipEventRecord(c->ev[2], c->stream));
+    int64_t start = first;
+    if (first == 2) {
+        if (int rc = place_init_fresh(p, c->stream)) return rc;
+        if (int rc = fill_rows(1, 1)) return rc;
+        if (int rc = place_initial_tree(p, row_ptr(1, 1), c->stream)) return rc;
+    } else {
+        DPR_HIP(hipMemcpyAsync(p.head, head, sizeof(int32_t) * (size_t)(2 * n), hipMemcpyHostToDevice, c->stream));
+        DPR_HIP(hipMemcpyAsync(p.e, e, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyHostToDevice, c->stream));
+        DPR_HIP(hipMemcpyAsync(p.nxt, nxt, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyHostToDevice, c->stream));
+        DPR_HIP(hipMemcpyAsync(p.belong, belong, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyHostToDevice, c->stream));
+        DPR_HIP(hipMemcpyAsync(p.len, len, sizeof(double) * (size_t)(8 * n), hipMemcpyHostToDevice, c->stream));
+        if (int rc = place_import_backbone(p, first, c->stream)) return rc;
+    }
+    for (int64_t i0 = start; i0 < n; i0 += R) {
+        const int64_t nr = n - i0 < R ? n - i0 : R;
+        if (int rc = fill_rows(i0, nr)) return rc;
+        for (int64_t i = i0; i < i0 + nr; ++i)
+            if (int rc = place_tip(p, row_ptr(i, i0), i, c->place_trace, c->stream)) return rc;
+    }
+    DPR_HIP(hipEventRecord(c->ev[3], c->stream));
+    DPR_HIP(hipMemcpyAsync(head, p.head, sizeof(int32_t) * (size_t)(2 * n), hipMemcpyDeviceToHost, c->stream));
+    DPR_HIP(hipMemcpyAsync(e, p.e, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
+    DPR_HIP(hipMemcpyAsync(nxt, p.nxt, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
+    DPR_HIP(hipMemcpyAsync(belong, p.belong, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
+    DPR_HIP(hipMemcpyAsync(len, p.len, sizeof(double) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
+    DPR_HIP(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    DPR_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+    c->nj_ms = ms;
+    if (rows) (void)hipFree(rows);
+    return DPR_OK;
+}
+
+int dpr_get_place_state(dpr_ctx* c, int32_t* cid, double* cdis, double* trace)
+{
+    if (!c || !c->place.cid) { set_error("dpr_get_place_state: no placement state"); return DPR_ERR_STATE; }
+    const int64_t n = c->place.N;
+    if (cid) DPR_HIP(hipMemcpy(cid, c->place.cid, sizeof(int32_t) * (size_t)(40 * n), hipMemcpyDeviceToHost));
+    if (cdis) DPR_HIP(hipMemcpy(cdis, c->place.cdis, sizeof(double) * (size_t)(40 * n), hipMemcpyDeviceToHost));
+    if (trace) DPR_HIP(hipMemcpy(trace, c->place_trace, sizeof(double) * (size_t)(3 * n), hipMemcpyDeviceToHost));
+    return DPR_OK;
 }
 
 }  // extern "C"

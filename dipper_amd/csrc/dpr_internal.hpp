@@ -126,4 +126,46 @@ void msa_free(MsaBuffers& m);
 int msa_dist_rows(const MsaBuffers& m, NjBuffers& b, int dist_type, hipStream_t s);
 int msa_counts_row(const MsaBuffers& m, int64_t row, int32_t* d_useful, int32_t* d_match, hipStream_t s);
 
+// mash.hip
+struct MashBuffers {
+    uint64_t* packed2 = nullptr;   // flat 2-bit packed reads
+    uint64_t* word_off = nullptr;  // [n]
+    uint64_t* len = nullptr;       // [n] bases
+    uint64_t* sketches = nullptr;  // [n][S] ascending
+    uint64_t total_words = 0;
+    int64_t n = 0;
+    int S = 0, k = 0;
+};
+int mash_upload(MashBuffers& m, const uint64_t* packed2, const uint64_t* word_off, const uint64_t* len,
+                int64_t n, hipStream_t s);
+void mash_free(MashBuffers& m);
+int mash_sketch(MashBuffers& m, int k, int S, hipStream_t s);
+// rows r0..r0+nr (world > 0: owned local rows of (rank,world); world == 0: plain tip ids) x columns
+// [0,ncols) -> out[t*ld + j]; full = also j >= i
+int mash_dist_rows(const MashBuffers& m, int64_t r0, int64_t nr, int rank, int world, bool full,
+                   int64_t ncols, double* out, int64_t ld, hipStream_t s);
+int mash_hash_positions(const MashBuffers& m, int64_t seq, int k, uint64_t* d_out, uint64_t len, uint64_t word_off,
+                        hipStream_t s);
+
+// msa.hip: same row-provider shape as mash_dist_rows
+int msa_dist_block_rows(const MsaBuffers& m, int64_t r0, int64_t nr, int rank, int world, int64_t ncols,
+                        int dist_type, double* out, int64_t ld, hipStream_t s);
+
+// place.hip
+struct PlaceBuffers {
+    int64_t N = 0;
+    int32_t *head = nullptr, *e = nullptr, *nxt = nullptr, *belong = nullptr, *rev = nullptr, *cid = nullptr;
+    double *len = nullptr, *cdis = nullptr;
+    int32_t *q_id = nullptr, *q_from = nullptr;
+    double* q_dis = nullptr;
+    void* partials = nullptr;
+    int nparts_max = 0;
+};
+int place_alloc(PlaceBuffers& p, int64_t N);
+void place_free(PlaceBuffers& p);
+int place_init_fresh(PlaceBuffers& p, hipStream_t s);
+int place_initial_tree(PlaceBuffers& p, const double* d_dis_row1, hipStream_t s);
+int place_import_backbone(PlaceBuffers& p, int64_t m, hipStream_t s);
+int place_tip(PlaceBuffers& p, const double* d_dis, int64_t tip, double* d_trace, hipStream_t s);
+
 }  // namespace dpr

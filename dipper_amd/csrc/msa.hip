@@ -59,7 +59,8 @@ __device__ __forceinline__ double msa_epilogue(int useful, int match, int dist_t
 __global__ __launch_bounds__(kThreads) void msa_dist_kernel(const uint32_t* __restrict__ planes,
                                                             int64_t n, int64_t W32, int dist_type,
                                                             double* __restrict__ D, int64_t ld,
-                                                            int64_t rows_local, int rank, int world)
+                                                            int64_t rows_local, int rank, int world,
+                                                            int64_t row0)
 {
     __shared__ __attribute__((aligned(16))) uint32_t sA[3][kKC][kPT];
     __shared__ __attribute__((aligned(16))) uint32_t sB[3][kKC][kPT];
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(kThreads) void msa_dist_kernel(const uint32_t* __re
     const int tx = tid & 15, ty = tid >> 4;
     const int64_t l0 = (int64_t)blockIdx.y * kPT;   // local row block (== ownership block)
     const int64_t c0 = (int64_t)blockIdx.x * kPT;   // global column block
-    const int64_t g0 = shard_global_row(l0, rank, world);
+    // world > 0: rows are the owned rows of (rank, world); world == 0: plain tip ids row0 + l
+    const int64_t g0 = world > 0 ? shard_global_row(l0, rank, world) : row0 + l0;
 
     int useful[4][4], match[4][4];
 #pragma unroll
@@ -186,7 +188,23 @@ int msa_dist_rows(const MsaBuffers& m, NjBuffers& b, int dist_type, hipStream_t 
     if (b.rows_local == 0) return DPR_OK;
     dim3 grid((unsigned)((m.n + kPT - 1) / kPT), (unsigned)((b.rows_local + kPT - 1) / kPT));
     hipLaunchKernelGGL(msa_dist_kernel, grid, dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, b.D,
-                       b.ld, b.rows_local, b.rank, b.world);
+                       b.ld, b.rows_local, b.rank, b.world, (int64_t)0);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+int msa_dist_block_rows(const MsaBuffers& m, int64_t r0, int64_t nr, int rank, int world, int64_t ncols,
+                        int dist_type, double* out, int64_t ld, hipStream_t s)
+{
+    if (dist_type != DPR_DIST_UNCORRECTED && dist_type != DPR_DIST_JC) {
+        set_error("distance types 3-6 are not implemented in the all-pairs kernel yet");
+        return DPR_ERR_ARG;
+    }
+    if (nr <= 0 || ncols <= 0) return DPR_OK;
+    (void)rank;
+    dim3 grid((unsigned)((ncols + kPT - 1) / kPT), (unsigned)((nr + kPT - 1) / kPT));
+    hipLaunchKernelGGL(msa_dist_kernel, grid, dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, out, ld, nr,
+                       0, world, r0);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }

@@ -137,7 +137,13 @@ int64_t dpr_n_total(dpr_ctx *ctx);
 int dpr_get_matrix_row(dpr_ctx *ctx, int64_t i, double *out /* n_total doubles */);
 int dpr_get_row_sums(dpr_ctx *ctx, double *out /* n_total doubles */);
 int dpr_get_msa_counts(dpr_ctx *ctx, int64_t row, int32_t *useful, int32_t *match /* row entries */);
-/* phase timings of the last dpr_dist_matrix / dpr_nj_run in milliseconds (HIP events) */
+/* MurmurHash3 value of every k-mer position of read `seq` (len-k+1 values), sketch kernel's hash path */
+int dpr_get_kmer_hashes(dpr_ctx *ctx, int64_t seq, int k, const uint64_t *word_off, const uint64_t *len,
+                        uint64_t *out);
+/* closest lists (40n ints / doubles, 5 per slot) and per-tip trace (eid, frac, add) of the last
+ * dpr_place_run; any pointer may be NULL */
+int dpr_get_place_state(dpr_ctx *ctx, int32_t *cid, double *cdis, double *trace);
+/* phase timings of the last dpr_dist_matrix / dpr_nj_run (or dpr_place_run) in milliseconds (HIP events) */
 int dpr_get_timing(dpr_ctx *ctx, double *dist_ms, double *nj_ms);
 
 /* ---- k-closest placement: KPlacementDeviceArrays::{allocateDeviceArrays,findPlacementTree,

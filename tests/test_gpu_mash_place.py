@@ -1,0 +1,127 @@
+"""GPU parity of the Mash path (a-8, a-9) and k-closest placement (a-10) through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import _util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import dipper_amd
+    d = dipper_amd.Dipper(0)
+    yield d
+    d.close()
+
+
+def _reads(rng, n, lo, hi, related=True):
+    base = rng.integers(0, 4, size=hi, dtype=np.uint8)
+    out = []
+    for i in range(n):
+        L = int(rng.integers(lo, hi + 1))
+        s = base[:L].copy() if related else rng.integers(0, 4, size=L, dtype=np.uint8)
+        k = rng.poisson(L * 0.03)
+        if k:
+            pos = rng.integers(0, L, size=k)
+            s[pos] = rng.integers(0, 4, size=k, dtype=np.uint8)
+        b = _util.BASES[s].copy()
+        if i % 7 == 3 and L > 10:
+            b[rng.integers(0, L, size=3)] = ord("N")       # 2-bit packing maps these to 'A'
+        out.append(b.tobytes())
+    return out
+
+
+@pytest.mark.parametrize("k", [15, 8, 2])
+def test_kmer_hashes_and_sketches(gpu, orc, k):
+    rng = np.random.default_rng(k)
+    seqs = _reads(rng, 12, 200, 3000)
+    seqs += [b"ACG", b"ACGTACGTACGTACG", b"ACGT" * 10, b"A" * 100, _reads(rng, 1, 20000, 20000)[0]]  # short, == k, duplicates, >1 chunk
+    gpu.set_reads(seqs)
+    for q, s in enumerate(seqs):
+        h = gpu.kmer_hashes(q, k)
+        p2 = orc.pack2(s)
+        ref = np.array([orc.lib.orc_kmer_hash(p2.ctypes.data_as(C.POINTER(C.c_uint64)), p, k) for p in range(max(len(s) - k + 1, 0))], dtype=np.uint64)
+        assert np.array_equal(h, ref), (q, k)
+    sk = gpu.sketch(k=k, S=1000)
+    for q, s in enumerate(seqs):
+        assert np.array_equal(sk[q], orc.sketch(orc.pack2(s), len(s), k=k, S=1000)), (q, k)
+
+
+def test_mash_dist_matrix_and_nj(gpu, orc):
+    from dipper_amd import capi
+    rng = np.random.default_rng(5)
+    seqs = _reads(rng, 70, 1500, 4000) + [b"ACGT" * 300, b"ACGT" * 280 + b"TTGACC" * 20, b"AC", b"G" * 14]
+    n = len(seqs)
+    gpu.set_reads(seqs)
+    sk = gpu.sketch(k=15, S=1000)
+    gpu.dist_matrix(capi.SRC_MASH, 0, 15)
+    M = gpu.matrix()
+    assert np.array_equal(M, M.T) and np.all(np.diag(M) == 0)
+    for i in range(n):
+        ref = orc.mash_dist_row(sk, 15, i, i)
+        assert np.allclose(M[i, :i], ref, rtol=1e-12, atol=0), i
+    ref = orc.nj_run(np.tril(M, -1))
+    res = gpu.nj_run()
+    for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
+        assert np.array_equal(res[key], ref[key]), key
+
+
+def _same_state(a, b, n):
+    live = 4 * n - 4
+    for key in ("head", "e", "nxt", "belong", "len"):
+        x, y = a[key], b[key]
+        m = len(x) if key == "head" else live
+        assert np.array_equal(x[:m], y[:m]), key
+    assert np.array_equal(a["cid"][:5 * live], b["cid"][:5 * live])
+    assert np.array_equal(a["cdis"][:5 * live], b["cdis"][:5 * live])
+    assert np.array_equal(a["trace"][2:], b["trace"][2:])
+
+
+@pytest.mark.parametrize("n", [3, 4, 9, 64, 300, 1100])
+def test_placement_matrix_source(gpu, orc, n):
+    from dipper_amd import capi
+    rng = np.random.default_rng(n)
+    D = _util.random_additive_matrix(rng, n, zero_frac=0.3 if n > 9 else 0.0)
+    D *= 0.9 / D.max()
+    gpu.set_matrix_full(D)
+    got = gpu.place_run(capi.SRC_MATRIX, n)
+    ref = orc.place_run(D)
+    _same_state(got, ref, n)
+    names = [f"T{i}" for i in range(n)]
+    nw = _util.newick_from_placement(names, got["head"], got["e"], got["nxt"], got["len"], n, fmt=repr)
+    assert np.abs(_util.patristic(nw, names) - D).max() < 1e-12 * n
+
+
+def test_placement_noisy_matrix(gpu, orc):
+    """non-additive input: clamps and ties of calculateBranchLength all get exercised"""
+    from dipper_amd import capi
+    rng = np.random.default_rng(99)
+    n = 500
+    D = np.round(rng.random((n, n)) * 0.5, 2)
+    D = np.tril(D, -1) + np.tril(D, -1).T
+    gpu.set_matrix_full(D)
+    got = gpu.place_run(capi.SRC_MATRIX, n)
+    _same_state(got, orc.place_run(D), n)
+
+
+def test_placement_msa_and_mash_sources(gpu, orc):
+    from dipper_amd import capi
+    rng = np.random.default_rng(123)
+    n, L = 400, 2000
+    seqs = _util.synth_alignment(rng, n, L, mean_bl=5e-3, lo=1e-4, hi=5e-2)
+    gpu.set_msa(capi.pack4_many(seqs), L)
+    gpu.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+    M = gpu.matrix()
+    got = gpu.place_run(capi.SRC_MSA, n, dist_type=capi.DIST_JC)
+    _same_state(got, orc.place_run(M), n)
+
+    reads = _reads(rng, 300, 3000, 6000)
+    gpu.set_reads(reads)
+    gpu.sketch(k=15, S=1000, fetch=False)
+    gpu.dist_matrix(capi.SRC_MASH, 0, 15)
+    M = gpu.matrix()
+    got = gpu.place_run(capi.SRC_MASH, len(reads), k=15)
+    _same_state(got, orc.place_run(M), len(reads))
