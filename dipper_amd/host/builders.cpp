@@ -2,6 +2,8 @@
 #include "dipper_host.hpp"
 
 #include <algorithm>
+#include <cctype>
+#include <cstdlib>
 #include <iostream>
 #include <thread>
 
@@ -70,6 +72,221 @@ void NJDeviceArrays::findNeighbourJoiningTree(DeviceContext& dev, std::vector<st
     const int64_t done = dpr_nj_run(dev.ctx, -1, mx.data(), my.data(), bx.data(), by.data(), &last);
     if (done < 0) gpuCheck((int)done, "dpr_nj_run");
     writeNewickFromMerges(output_, name, mx, my, bx, by, last);
+}
+
+void MashDeviceArrays::allocateDeviceArrays(DeviceContext& dev, const std::vector<std::string>& seqs,
+                                            const std::vector<int>& ids)
+{
+    numSequences = seqs.size();
+    if (numSequences < 2) die("ERROR: need at least two sequences");
+    std::vector<uint64_t> lens(numSequences), off(numSequences), nw(numSequences);
+    for (size_t i = 0; i < numSequences; ++i) {
+        lens[(size_t)ids[i]] = seqs[i].size();
+        nw[(size_t)ids[i]] = (seqs[i].size() + 31) / 32;
+    }
+    uint64_t total = 0;
+    for (size_t s = 0; s < numSequences; ++s) { off[s] = total; total += nw[s]; }  // exclusive scan (src/mash.cu:109-119)
+    std::vector<uint64_t> flat(total + 1, 0);
+    unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; ++t)
+        pool.emplace_back([&, t] {
+            for (size_t i = t; i < numSequences; i += nt)
+                if (!seqs[i].empty()) dpr_pack2(seqs[i].data(), seqs[i].size(), flat.data() + off[(size_t)ids[i]]);
+        });
+    for (auto& th : pool) th.join();
+    gpuCheck(dpr_set_reads(dev.ctx, flat.data(), off.data(), lens.data(), (int64_t)numSequences), "dpr_set_reads");
+}
+
+void MashDeviceArrays::sketchConstructionOnGpu(DeviceContext& dev, Param& params)
+{
+    gpuCheck(dpr_sketch(dev.ctx, (int)params.kmerSize, (int)params.sketchSize, nullptr), "dpr_sketch");
+}
+
+// ---- Newick import ---------------------------------------------------------------------------------
+Tree::Tree(const std::string& newick_in, size_t totalLeaves)
+{
+    std::string s;
+    for (char c : newick_in) if (c != '\n' && c != '\r') s.push_back(c);
+    size_t nextInternal = totalLeaves, nextLeaf = 0;
+    std::vector<int> stack;
+    int last = -1;  // node whose label / length is being read
+    auto parse_len = [&](size_t& i) {
+        std::string num;
+        size_t j = i + 1;
+        while (j < s.size() && s[j] != ',' && s[j] != ')' && s[j] != '(' && s[j] != ';') {
+            const char c = s[j];
+            if (std::isdigit((unsigned char)c) || c == '.' || c == 'e' || c == 'E' || c == '-' || c == '+') num.push_back(c);
+            ++j;
+        }
+        i = j - 1;
+        return num.empty() ? 0.0 : (double)std::strtof(num.c_str(), nullptr);
+    };
+    for (size_t i = 0; i < s.size(); ++i) {
+        const char c = s[i];
+        if (c == '(') {
+            Node nd;
+            nd.idx = (int)nextInternal++;
+            nd.name = "node_" + std::to_string(nd.idx);
+            nd.parent = stack.empty() ? -1 : stack.back();
+            nodes.push_back(nd);
+            const int id = (int)nodes.size() - 1;
+            if (nd.parent >= 0) nodes[(size_t)nd.parent].children.push_back(id); else root = id;
+            stack.push_back(id);
+            last = -1;
+        } else if (c == ')') {
+            if (stack.empty()) die("ERROR: incorrect Newick format!");
+            last = stack.back();
+            stack.pop_back();
+            // an internal label / support value after ')' is ignored, as in the reference
+            size_t j = i + 1;
+            while (j < s.size() && s[j] != ':' && s[j] != ',' && s[j] != ')' && s[j] != ';') ++j;
+            i = j - 1;
+        } else if (c == ',') {
+            last = -1;
+        } else if (c == ':') {
+            const double v = parse_len(i);
+            if (last >= 0) nodes[(size_t)last].bl = v;
+        } else if (c == ';') {
+            break;
+        } else if (std::isspace((unsigned char)c)) {
+            continue;
+        } else {
+            // leaf label (quoted labels keep their inner text)
+            std::string name;
+            size_t j = i;
+            if (c == '\'') {
+                ++j;
+                while (j < s.size() && s[j] != '\'') name.push_back(s[j++]);
+                ++j;
+            } else {
+                while (j < s.size() && s[j] != ':' && s[j] != ',' && s[j] != ')' && s[j] != '(' && s[j] != ';') name.push_back(s[j++]);
+            }
+            i = j - 1;
+            if (stack.empty()) die("ERROR: incorrect Newick format!");
+            Node nd;
+            nd.idx = (int)nextLeaf++;
+            nd.name = name;
+            nd.parent = stack.back();
+            nodes.push_back(nd);
+            last = (int)nodes.size() - 1;
+            nodes[(size_t)nd.parent].children.push_back(last);
+        }
+    }
+    if (!stack.empty()) die("ERROR: incorrect Newick format!");
+    if (root < 0) die("ERROR: Tree found empty!");
+    nodes[(size_t)root].bl = 0;
+    m_numLeaves = nextLeaf;
+}
+
+int Tree::findLeaf(const std::string& name) const
+{
+    for (size_t i = 0; i < nodes.size(); ++i)
+        if (nodes[i].children.empty() && nodes[i].name == name) return (int)i;
+    return -1;
+}
+
+// ---- placement ----------------------------------------------------------------------------------------
+void KPlacementDeviceArrays::allocateDeviceArrays(size_t num, int backbone)
+{
+    numSequences = (int)num;
+    backboneSize = backbone;
+    bd = 2;
+    h_head.assign(num * 2, -1);
+    h_e.assign(num * 8, -1);
+    h_nxt.assign(num * 8, -1);
+    h_belong.assign(num * 8, -1);
+    h_len.assign(num * 8, 2.0);
+}
+
+void KPlacementDeviceArrays::initializeDeviceArrays(const Tree& t)
+{
+    // post-order DFS; per tree edge two directed slots (child->parent, parent->child), each pushed
+    // at the front of its source's list (src/placement_close_k.cu:160-183)
+    size_t edgeCount = 0;
+    struct Frame { int node; size_t next; };
+    std::vector<Frame> st;
+    st.push_back(Frame{ t.root, 0 });
+    while (!st.empty()) {
+        Frame& f = st.back();
+        const Node& nd = t.nodes[(size_t)f.node];
+        if (f.next < nd.children.size()) {
+            const int c = nd.children[f.next++];
+            st.push_back(Frame{ c, 0 });
+            continue;
+        }
+        if (nd.parent >= 0) {
+            const int x = nd.idx, y = t.nodes[(size_t)nd.parent].idx;
+            if (edgeCount + 2 > h_e.size()) die("ERROR: backbone tree does not fit the allocated arrays");
+            h_e[edgeCount] = y; h_len[edgeCount] = nd.bl; h_belong[edgeCount] = x;
+            h_nxt[edgeCount] = h_head[(size_t)x]; h_head[(size_t)x] = (int32_t)edgeCount; edgeCount++;
+            h_e[edgeCount] = x; h_len[edgeCount] = nd.bl; h_belong[edgeCount] = y;
+            h_nxt[edgeCount] = h_head[(size_t)y]; h_head[(size_t)y] = (int32_t)edgeCount; edgeCount++;
+        }
+        st.pop_back();
+    }
+}
+
+static int sourceOf(const Param& params)
+{
+    return params.in == "r" ? DPR_SRC_MASH : (params.in == "m" ? DPR_SRC_MSA : DPR_SRC_MATRIX);
+}
+
+void KPlacementDeviceArrays::findPlacementTree(DeviceContext& dev, Param& params)
+{
+    gpuCheck(dpr_place_run(dev.ctx, sourceOf(params), (int)params.distanceType, (int)params.kmerSize, 2, numSequences,
+                           h_head.data(), h_e.data(), h_nxt.data(), h_belong.data(), h_len.data()), "dpr_place_run");
+    double dist_ms = 0, tree_ms = 0;
+    dpr_get_timing(dev.ctx, &dist_ms, &tree_ms);
+    std::cerr << "Distance + Tree Operation Time " << (long long)tree_ms << " ms\n";
+}
+
+void KPlacementDeviceArrays::addQuery(DeviceContext& dev, Param& params)
+{
+    gpuCheck(dpr_place_run(dev.ctx, sourceOf(params), (int)params.distanceType, (int)params.kmerSize, backboneSize,
+                           numSequences, h_head.data(), h_e.data(), h_nxt.data(), h_belong.data(), h_len.data()),
+             "dpr_place_run");
+    double dist_ms = 0, tree_ms = 0;
+    dpr_get_timing(dev.ctx, &dist_ms, &tree_ms);
+    std::cerr << "Distance + Tree Operation Time " << (long long)tree_ms << " ms\n";
+}
+
+// printTree (src/placement_close_k.cu:568-643), iterative: root = node numSequences+bd-2, children in
+// adjacency-list order, the edge back to the parent skipped; a node with a single adjacency entry is a leaf.
+void KPlacementDeviceArrays::printTree(const std::vector<std::string>& name, std::ostream& output_)
+{
+    struct Frame { int node, from; std::vector<int> pos; size_t next; };
+    auto make = [&](int node, int from) {
+        Frame f{ node, from, {}, 0 };
+        for (int i = h_head[(size_t)node]; i != -1; i = h_nxt[(size_t)i])
+            if (h_e[(size_t)i] != from) f.pos.push_back(i);
+        return f;
+    };
+    auto is_internal = [&](int node) { return h_nxt[(size_t)h_head[(size_t)node]] != -1; };
+    const int root = numSequences + bd - 2;
+    std::vector<Frame> st;
+    if (!is_internal(root)) { output_ << name[(size_t)root] << ";\n"; return; }
+    output_ << "(";
+    st.push_back(make(root, -1));
+    while (!st.empty()) {
+        Frame& f = st.back();
+        if (f.next == f.pos.size()) {
+            st.pop_back();
+            if (st.empty()) break;
+            Frame& up = st.back();
+            output_ << ":" << h_len[(size_t)up.pos[up.next - 1]] << (up.next == up.pos.size() ? ')' : ',');
+            continue;
+        }
+        const int slot = f.pos[f.next++];
+        const int child = h_e[(size_t)slot];
+        if (is_internal(child)) {
+            output_ << "(";
+            st.push_back(make(child, f.node));
+        } else {
+            output_ << name[(size_t)child] << ":" << h_len[(size_t)slot] << (f.next == f.pos.size() ? ')' : ',');
+        }
+    }
+    output_ << ";\n";
 }
 
 }  // namespace dipper

@@ -61,6 +61,42 @@ struct NJDeviceArrays {  // src/mash_placement.cuh:199-212
     void findNeighbourJoiningTree(DeviceContext& dev, std::vector<std::string>& name, std::ostream& output_);
 };
 
+struct MashDeviceArrays {  // src/mash_placement.cuh:34-50
+    size_t numSequences = 0;
+    // 2-bit packing in parallel (src/tree_generation.cu:480-490) + upload; seqs[i] goes to slot ids[i]
+    void allocateDeviceArrays(DeviceContext& dev, const std::vector<std::string>& seqs, const std::vector<int>& ids);
+    void sketchConstructionOnGpu(DeviceContext& dev, Param& params);
+};
+
+// Newick import with the reference's id assignment (src/tree.cpp:216-361): leaves get idx 0,1,.. in
+// order of appearance, internal nodes totalLeaves, totalLeaves+1, .. in order of '(' and the name
+// "node_<idx>"; branch lengths parsed with float precision (stof); the root's length is set to 0.
+struct Node {
+    std::string name;
+    int idx = -1;
+    double bl = 0.0;
+    int parent = -1;             // index into Tree::nodes
+    std::vector<int> children;   // indices into Tree::nodes
+};
+struct Tree {
+    std::vector<Node> nodes;     // creation order (pre-order)
+    int root = -1;
+    size_t m_numLeaves = 0;
+    Tree(const std::string& newick, size_t totalLeaves);
+    int findLeaf(const std::string& name) const;   // node index or -1
+};
+
+struct KPlacementDeviceArrays {  // src/mash_placement.cuh:167-197
+    int numSequences = 0, backboneSize = -1, bd = 2;
+    std::vector<int32_t> h_head, h_e, h_nxt, h_belong;
+    std::vector<double> h_len;
+    void allocateDeviceArrays(size_t num, int backboneSize = -1);
+    void initializeDeviceArrays(const Tree& t);   // backbone -> forward-star adjacency (src/placement_close_k.cu:126-264)
+    void findPlacementTree(DeviceContext& dev, Param& params);
+    void addQuery(DeviceContext& dev, Param& params);
+    void printTree(const std::vector<std::string>& name, std::ostream& output_);
+};
+
 // Newick text of an NJ merge log (bookkeeping + print of src/neighborJoining.cu:233-270), iterative.
 void writeNewickFromMerges(std::ostream& os, const std::vector<std::string>& name, const std::vector<int32_t>& mx,
                            const std::vector<int32_t>& my, const std::vector<double>& bx,

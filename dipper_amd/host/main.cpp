@@ -9,6 +9,8 @@
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <memory>
+#include <unordered_map>
 
 using namespace dipper;
 
@@ -59,7 +61,7 @@ static const Opt kOpts[] = {
     { "output-format", 'o', true }, { "algorithm", 'm', true }, { "placement-mode", 'p', true },
     { "kmer-size", 'k', true }, { "sketch-size", 's', true }, { "distance-type", 'd', true },
     { "add", 'a', false }, { "input-tree", 't', true }, { "help", 'h', false },
-    { "seed", 0, true }, { "device", 0, true },
+    { "seed", 0, true }, { "device", 0, true }, { "dump-tree", 0, true },
 };
 
 static void usageError(const std::string& what)
@@ -122,6 +124,19 @@ int main(int argc, char** argv)
     auto inputStart = std::chrono::high_resolution_clock::now();
     auto vm = parseArguments(argc, argv);
     if (vm.count("help")) { std::cerr << kHelp << std::endl; return 0; }
+    if (vm.count("dump-tree")) {
+        // developer aid (no GPU): parse --input-tree with totalLeaves = arg and print the node table
+        std::ifstream tf(strOr(vm, "input-tree", ""));
+        if (!tf) { std::cerr << "ERROR: Unable to open input tree file: " << strOr(vm, "input-tree", "") << "\n"; return 1; }
+        std::string nwk;
+        std::getline(tf, nwk);
+        Tree t(nwk, (size_t)stoiOr(vm, "dump-tree", 0));
+        std::printf("%zu %zu %d\n", t.nodes.size(), t.m_numLeaves, t.nodes[(size_t)t.root].idx);
+        for (const Node& nd : t.nodes)
+            std::printf("%d %d %.17g %d %s\n", nd.idx, nd.parent >= 0 ? t.nodes[(size_t)nd.parent].idx : -1, nd.bl,
+                        nd.children.empty() ? 1 : 0, nd.name.c_str());
+        return 0;
+    }
     for (const char* req : { "input-format", "input-file", "output-file" })
         if (!vm.count(req)) usageError(std::string("the option '--") + req + "' is required but missing");
     if (vm.count("add") && !vm.count("input-tree"))
@@ -140,59 +155,148 @@ int main(int argc, char** argv)
     try { if (vm.count("seed")) seed = std::stoll(vm["seed"]); } catch (...) {}
     const int device = (int)stoiOr(vm, "device", 0);
     const std::string inputFile = vm["input-file"], outputFile = vm["output-file"];
-    (void)placemode;
 
     const int placement_thr = 30000, dc_thr = 1000000;  // src/tree_generation.cu:247-248
+    auto ms_since = [](std::chrono::high_resolution_clock::time_point t0) {
+        return (long long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+    };
+    auto open_out = [&]() {
+        auto os = std::make_unique<std::ofstream>(outputFile.c_str());
+        if (!*os) die("ERROR: cannot open output file: " + outputFile);
+        return os;
+    };
+    // mode selection of the reference (src/tree_generation.cu:377,422,450): 1 = placement, 3 = DC, 2 = NJ
+    auto pick_mode = [&](long long n) {
+        if (algo == "1" || (algo == "0" && n >= placement_thr && n < dc_thr)) return 1;
+        if (algo == "3" || (algo == "0" && n >= dc_thr)) return 3;
+        return 2;
+    };
+    auto note_exact = [&]() {
+        if (placemode == "0") std::cerr << "Note: exact placement mode is not built; using k-closest placement\n";
+    };
 
-    if (add) die("--add needs the k-closest placement path, which is not built yet in this round");
+    if (add) {
+        // src/tree_generation.cu:252-332
+        std::ifstream treeFileStream(strOr(vm, "input-tree", ""));
+        if (!treeFileStream) { std::cerr << "ERROR: Unable to open input tree file: " << strOr(vm, "input-tree", "") << "\n"; return 1; }
+        if (!(params.out == "t" && (params.in == "r" || params.in == "m"))) {
+            std::cerr << "Adding new sequnces only supported with input aligned and unaligned sequences\n";
+            return 1;
+        }
+        std::vector<std::string> seqs, names, namesDump;
+        readSequences(inputFile, seqs, namesDump);
+        std::cerr << "Read " << seqs.size() << " sequences from input file.\n";
+        if (seqs.empty()) die("No sequences found in the input file.");
+        std::string newickTree;
+        std::getline(treeFileStream, newickTree);
+        Tree t(newickTree, namesDump.size());
+        std::cerr << "Tree loaded successfully with " << t.nodes.size() << " nodes and root " << t.nodes[(size_t)t.root].name << ".\n";
+        const size_t backboneSize = t.m_numLeaves, numSequences = seqs.size();
+        std::unordered_map<std::string, int> leafIdx;
+        for (const Node& nd : t.nodes) if (nd.children.empty()) leafIdx[nd.name] = nd.idx;
+        names.assign(backboneSize, "");
+        std::vector<int> ids(numSequences);
+        size_t found = 0;
+        for (size_t i = 0; i < numSequences; ++i) {
+            auto it = leafIdx.find(namesDump[i]);
+            if (it == leafIdx.end()) { names.push_back(namesDump[i]); ids[i] = (int)names.size() - 1; }
+            else { names[(size_t)it->second] = namesDump[i]; ids[i] = it->second; ++found; }
+        }
+        if (found != backboneSize || names.size() != numSequences) die("ERROR: every backbone tip needs exactly one sequence in the input file");
+        if (backboneSize >= numSequences) die("ERROR: no query sequences to add");
+        auto output_ = open_out();
+        DeviceContext dev(device);
+        KPlacementDeviceArrays kplacementDeviceArrays;
+        if (params.in == "r") {
+            MashDeviceArrays mashDeviceArrays;
+            std::cerr << "Allocating Mash Device Arrays" << std::endl;
+            mashDeviceArrays.allocateDeviceArrays(dev, seqs, ids);
+            std::cerr << "Sketch Construction in Progress" << std::endl;
+            mashDeviceArrays.sketchConstructionOnGpu(dev, params);
+        } else {
+            MSADeviceArrays msaDeviceArrays;
+            msaDeviceArrays.allocateDeviceArrays(dev, seqs, ids);
+        }
+        kplacementDeviceArrays.allocateDeviceArrays(numSequences, (int)backboneSize);
+        kplacementDeviceArrays.initializeDeviceArrays(t);
+        kplacementDeviceArrays.addQuery(dev, params);
+        kplacementDeviceArrays.printTree(names, *output_);
+        return 0;
+    }
 
-    if (params.in == "m" && params.out == "t") {
+    if ((params.in == "m" || params.in == "r") && params.out == "t") {
+        const bool aligned = params.in == "m";
         std::vector<std::string> seqs, names_, names;
         readSequences(inputFile, seqs, names_);
         const size_t numSequences = seqs.size();
-        if (numSequences < 2) die("ERROR: need at least two sequences in " + inputFile);
+        if (numSequences < 3) die("ERROR: need at least three sequences in " + inputFile);
         names.resize(numSequences);
         const std::vector<int> ids = shuffledIds(numSequences, seed);
         for (size_t i = 0; i < numSequences; ++i) names[(size_t)ids[i]] = names_[i];
-        std::ofstream output_(outputFile.c_str());
-        if (!output_) die("ERROR: cannot open output file: " + outputFile);
+        auto output_ = open_out();
         DeviceContext dev(device);
         MSADeviceArrays msaDeviceArrays;
-        msaDeviceArrays.allocateDeviceArrays(dev, seqs, ids);
-        auto inputEnd = std::chrono::high_resolution_clock::now();
-        std::cerr << "Input in: " << std::chrono::duration_cast<std::chrono::milliseconds>(inputEnd - inputStart).count() << " ms\n";
-        const bool wantPlacement = algo == "1" || (algo == "0" && (int)numSequences >= placement_thr && (int)numSequences < dc_thr);
-        const bool wantDC = algo == "3" || (algo == "0" && (int)numSequences >= dc_thr);
-        if (wantPlacement) die("k-closest placement mode is not built yet in this round (use -m 2 for conventional NJ)");
-        if (wantDC) die("divide-and-conquer mode is not built yet in this round (use -m 2 for conventional NJ)");
-        std::cerr << "Using conventional NJ\n";
-        if (numSequences >= 40000)
-            std::cerr << "Warning: forcing conventional NJ on large datasets might result in unexpected behavior\n";
-        auto t0 = std::chrono::high_resolution_clock::now();
-        NJDeviceArrays njDeviceArrays;
-        njDeviceArrays.getDismatrix(dev, (int)numSequences, params, nullptr);
-        njDeviceArrays.findNeighbourJoiningTree(dev, names, output_);
-        auto t1 = std::chrono::high_resolution_clock::now();
-        std::cerr << "Tree Created in: " << std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count() << " ms\n";
-    } else if (params.in == "r" && params.out == "t") {
-        die("unaligned input (-i r) needs the Mash path, which is not built yet in this round");
+        MashDeviceArrays mashDeviceArrays;
+        const int mode = pick_mode((long long)numSequences);
+        if (aligned) msaDeviceArrays.allocateDeviceArrays(dev, seqs, ids);
+        else mashDeviceArrays.allocateDeviceArrays(dev, seqs, ids);
+        std::cerr << "Input in: " << ms_since(inputStart) << " ms\n";
+        if (mode == 3) die("divide-and-conquer mode is not built yet (rank 1 of the 'next' rows, DESIGN.md); use -m 1 or -m 2");
+        auto createArrayStart = std::chrono::high_resolution_clock::now();
+        if (!aligned) {
+            // the reference sketches only in placement/DC mode (-i r + NJ reads unsketched
+            // memory there); the intended behaviour is to sketch first
+            std::cerr << "Allocated in: " << ms_since(createArrayStart) << " ms\n";
+            auto t0 = std::chrono::high_resolution_clock::now();
+            mashDeviceArrays.sketchConstructionOnGpu(dev, params);
+            std::cerr << "Sketch Created in: " << ms_since(t0) << " ms\n";
+        }
+        if (mode == 1) {
+            std::cerr << (aligned ? "Using k-closest placement mode\n" : "Using k-closest placement mode\n");
+            note_exact();
+            KPlacementDeviceArrays kplacementDeviceArrays;
+            kplacementDeviceArrays.allocateDeviceArrays(numSequences);
+            if (aligned) std::cerr << "Allocated in: " << ms_since(createArrayStart) << " ms\n";
+            auto t0 = std::chrono::high_resolution_clock::now();
+            kplacementDeviceArrays.findPlacementTree(dev, params);
+            const long long tree_ms = ms_since(t0);
+            kplacementDeviceArrays.printTree(names, *output_);
+            std::cerr << "Tree Created in: " << tree_ms << " ms\n";
+        } else {
+            std::cerr << "Using conventional NJ\n";
+            if (numSequences >= 40000)
+                std::cerr << "Warning: forcing conventional NJ on large datasets might result in unexpected behavior\n";
+            auto t0 = std::chrono::high_resolution_clock::now();
+            NJDeviceArrays njDeviceArrays;
+            njDeviceArrays.getDismatrix(dev, (int)numSequences, params, nullptr);
+            njDeviceArrays.findNeighbourJoiningTree(dev, names, *output_);
+            std::cerr << "Tree Created in: " << ms_since(t0) << " ms\n";
+        }
     } else if (params.in == "d" && params.out == "t") {
         MatrixReader matrixReader;
         matrixReader.read(inputFile);
         const int numSequences = matrixReader.numSequences;
-        std::ofstream output_(outputFile.c_str());
-        if (!output_) die("ERROR: cannot open output file: " + outputFile);
-        const bool wantPlacement = algo == "1" || (algo == "0" && numSequences >= placement_thr && numSequences < dc_thr);
-        const bool wantDC = algo == "3" || (algo == "0" && numSequences >= dc_thr);
-        if (wantDC) { std::cerr << "Divide-and-conquer mode not supported with input matrix\n"; return 1; }
-        if (wantPlacement) die("k-closest placement mode is not built yet in this round (use -m 2 for conventional NJ)");
-        std::cerr << "Using conventional NJ\n";
-        if (numSequences >= 40000)
-            std::cerr << "Warning: forcing conventional NJ on large datasets might result in unexpected behavior\n";
+        if (numSequences < 3) die("ERROR: need at least three taxa in " + inputFile);
+        auto output_ = open_out();
+        const int mode = pick_mode(numSequences);
+        if (mode == 3) { std::cerr << "Divide-and-conquer mode not supported with input matrix\n"; return 1; }
         DeviceContext dev(device);
-        NJDeviceArrays njDeviceArrays;
-        njDeviceArrays.getDismatrix(dev, numSequences, params, &matrixReader);
-        njDeviceArrays.findNeighbourJoiningTree(dev, matrixReader.name, output_);
+        if (mode == 1) {
+            std::cerr << "Using k-closest placement mode\n";
+            note_exact();
+            gpuCheck(dpr_set_matrix_lower(dev.ctx, matrixReader.lower.data(), numSequences), "dpr_set_matrix_lower");
+            KPlacementDeviceArrays kplacementDeviceArrays;
+            kplacementDeviceArrays.allocateDeviceArrays((size_t)numSequences);
+            kplacementDeviceArrays.findPlacementTree(dev, params);
+            kplacementDeviceArrays.printTree(matrixReader.name, *output_);
+        } else {
+            std::cerr << "Using conventional NJ\n";
+            if (numSequences >= 40000)
+                std::cerr << "Warning: forcing conventional NJ on large datasets might result in unexpected behavior\n";
+            NJDeviceArrays njDeviceArrays;
+            njDeviceArrays.getDismatrix(dev, numSequences, params, &matrixReader);
+            njDeviceArrays.findNeighbourJoiningTree(dev, matrixReader.name, *output_);
+        }
     } else {
         std::printf("Invalid input-output combinations!!!!!\n");
         return 1;

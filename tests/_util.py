@@ -140,17 +140,11 @@ def parse_newick(s):
         nid[0] += 1
         return nid[0] - 1
 
-    pos = 0
-    root = new()
-    stack = [root]
-    cur = root
-    kids[root] = []
-    i = 0
-    n = len(s)
     # iterative parser
     cur = None
     stack = []
     i = 0
+    n = len(s)
     root = None
     while i < n:
         c = s[i]
@@ -326,3 +320,41 @@ def write_fasta(path, names, seqs, width=0):
                     f.write(s[k:k + width] + b"\n")
             else:
                 f.write(s + b"\n")
+
+
+def backbone_state(orc, newick, N):
+    """Mirror of Tree::Tree id assignment (src/tree.cpp:216-361) + initializeDeviceArrays
+    (src/placement_close_k.cu:126-264): returns (state arrays, backbone leaf names by idx)."""
+    kids, length, name, root = parse_newick(newick)
+    order = sorted(kids.keys())          # creation order: '(' and leaf labels as they appear
+    idx, nl, ni = {}, 0, 0
+    for v in order:
+        if kids[v]:
+            idx[v] = N + ni
+            ni += 1
+        else:
+            idx[v] = nl
+            nl += 1
+    parent = {c: p for p, cs in kids.items() for c in cs}
+    bl = {v: float(np.float32(length.get(v, 0.0))) for v in order}
+    bl[root] = 0.0
+    st = orc.place_alloc(N)
+    ec = 0
+    stack = [(root, 0)]
+    while stack:
+        v, k = stack.pop()
+        if k < len(kids[v]):
+            stack.append((v, k + 1))
+            stack.append((kids[v][k], 0))
+            continue
+        if v in parent:
+            x, y = idx[v], idx[parent[v]]
+            for (src, dst) in ((x, y), (y, x)):
+                st["e"][ec] = dst; st["len"][ec] = bl[v]; st["belong"][ec] = src
+                st["nxt"][ec] = st["head"][src]; st["head"][src] = ec
+                ec += 1
+    leaf_names = [None] * nl
+    for v in order:
+        if not kids[v]:
+            leaf_names[idx[v]] = name[v]
+    return st, leaf_names

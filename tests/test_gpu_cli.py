@@ -92,3 +92,83 @@ def test_msa_jc_default_shuffle(tmp_path, orc):
     assert _util.splits(got, names) == _util.splits(expect, names)
     P1, P2 = _util.patristic(got, names), _util.patristic(expect, names)
     assert np.allclose(P1, P2, rtol=2e-5, atol=1e-9)
+
+
+def _api_matrix(kind, seqs, L=None, dt=2):
+    import dipper_amd
+    from dipper_amd import capi
+    d = dipper_amd.Dipper(0)
+    try:
+        if kind == "m":
+            d.set_msa(capi.pack4_many(seqs), L)
+            d.dist_matrix(capi.SRC_MSA, dt)
+        else:
+            d.set_reads(seqs)
+            d.sketch(15, 1000, fetch=False)
+            d.dist_matrix(capi.SRC_MASH, 0, 15)
+        return d.matrix()
+    finally:
+        d.close()
+
+
+def test_placement_modes_end_to_end(tmp_path, orc):
+    """-m 1 for aligned, unaligned and matrix input: the Newick text equals the oracle's placement
+    run on the same distances (src/placement_close_k.cu:646-854 + printTree :568-643)."""
+    rng = np.random.default_rng(31)
+    n, L = 180, 1200
+    seqs = _util.synth_alignment(rng, n, L, mean_bl=5e-3, lo=1e-4, hi=5e-2)
+    names = [f"T{i+1}" for i in range(n)]
+    fa = tmp_path / "a.fa"
+    _util.write_fasta(str(fa), names, seqs)
+    for kind, extra in (("m", ["-d", "2"]), ("r", [])):
+        out = tmp_path / f"{kind}.nwk"
+        r = run("-i", kind, "-I", str(fa), "-O", str(out), "-m", "1", "--seed", "-1", *extra)
+        assert r.returncode == 0, r.stderr
+        assert "k-closest placement mode" in r.stderr
+        M = _api_matrix(kind, seqs, L)
+        st = orc.place_run(M)
+        assert out.read_text() == _util.newick_from_placement(names, st["head"], st["e"], st["nxt"], st["len"], n)
+    # matrix input
+    D = _util.random_additive_matrix(rng, 150)
+    D *= 0.9 / D.max()
+    nm = [f"X{i}" for i in range(150)]
+    phy = tmp_path / "d.phy"
+    _util.write_phylip_lower(str(phy), nm, D)
+    out = tmp_path / "d.nwk"
+    assert run("-i", "d", "-I", str(phy), "-O", str(out), "-m", "1").returncode == 0
+    Dr = np.zeros_like(D)
+    for i in range(150):
+        for j in range(i):
+            Dr[i, j] = Dr[j, i] = orc.phylip_value("%.9g" % D[i, j])
+    st = orc.place_run(Dr)
+    assert out.read_text() == _util.newick_from_placement(nm, st["head"], st["e"], st["nxt"], st["len"], 150)
+
+
+@pytest.mark.parametrize("kind", ["m", "r"])
+def test_add_queries_to_backbone(tmp_path, orc, kind):
+    """--add (src/tree_generation.cu:252-332, addQuery src/placement_close_k.cu:858-990)."""
+    rng = np.random.default_rng(77)
+    n, m, L = 240, 180, 1500
+    seqs = _util.synth_alignment(rng, n, L, mean_bl=5e-3, lo=1e-4, hi=5e-2)
+    names = [f"T{i+1}" for i in range(n)]
+    # shuffle the file order so that backbone tips and queries interleave
+    perm = rng.permutation(n)
+    back = sorted(perm[:m].tolist())
+    fa_b, fa_all = tmp_path / "b.fa", tmp_path / "all.fa"
+    _util.write_fasta(str(fa_b), [names[i] for i in back], [seqs[i] for i in back])
+    _util.write_fasta(str(fa_all), [names[i] for i in perm], [seqs[i] for i in perm])
+    bb = tmp_path / "backbone.nwk"
+    extra = ["-d", "2"] if kind == "m" else []
+    assert run("-i", kind, "-I", str(fa_b), "-O", str(bb), "-m", "1", "--seed", "3", *extra).returncode == 0
+    out = tmp_path / "added.nwk"
+    r = run("-i", kind, "-I", str(fa_all), "-O", str(out), "--add", "-t", str(bb), *extra)
+    assert r.returncode == 0, r.stderr
+    # oracle mirror
+    st, leaf_names = _util.backbone_state(orc, bb.read_text(), n)
+    assert len(leaf_names) == m
+    order_names = list(leaf_names) + [names[i] for i in perm if names[i] not in set(leaf_names)]
+    by_name = dict(zip(names, seqs))
+    M = _api_matrix(kind, [by_name[x] for x in order_names], L)
+    orc.place_init_lists(n, m, st)
+    st = orc.place_run(M, first=m, state=st)
+    assert out.read_text() == _util.newick_from_placement(order_names, st["head"], st["e"], st["nxt"], st["len"], n)
