@@ -158,6 +158,7 @@ def main():
         return res
 
     phase = []
+    prune = None
     if args.probe_only:
         args.steps = args.warmup = 0
     for _ in range(args.warmup):
@@ -167,6 +168,12 @@ def main():
     for _ in range(args.steps):
         step()
         phase.append(dip.timing())
+        try:
+            sc, full = dip.prune_stats()
+            prune = {"units_scanned": sc, "units_per_full_scan": full, "iterations": n - 2,
+                     "scanned_fraction_of_full_scans": sc / (full * (n - 2.0))}
+        except Exception:
+            prune = None
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -202,6 +209,8 @@ def main():
         "phase_ms": {"dist": float(np.mean([p[0] for p in phase])) if phase else None,
                      "nj": float(np.mean([p[1] for p in phase])) if phase else None},
         "roofline": roofline,
+        "nj_algorithm": "exact pruned scan (njp.hip)" if prune else "full streaming scan (nj.hip)",
+        "prune": prune,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

@@ -57,6 +57,10 @@ def load_library():
     L.dpr_comm_unique_id.argtypes = [C.c_void_p]
     L.dpr_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.dpr_comm_selftest.argtypes = [C.c_void_p]
+    L.dpr_scan_tune.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.dpr_set_nj_mode.argtypes = [C.c_int]
+    L.dpr_get_prune_stats.argtypes = [C.c_void_p, c_u64p, c_u64p]
+    L.dpr_bw_probe.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.dpr_set_msa.argtypes = [C.c_void_p, c_u64p, C.c_int64, C.c_int64]
     L.dpr_set_reads.argtypes = [C.c_void_p, c_u64p, c_u64p, c_u64p, C.c_int64]
     L.dpr_set_matrix_lower.argtypes = [C.c_void_p, c_f64p, C.c_int64]
@@ -79,6 +83,12 @@ def load_library():
                                 c_i32p, c_i32p, c_i32p, c_i32p, c_f64p]
     _LIB = L
     return L
+
+
+def set_nj_mode(mode):
+    """0 = full streaming scan every iteration, 1 = exact pruned scan (default)."""
+    L = load_library()
+    _chk(L, L.dpr_set_nj_mode(mode))
 
 
 def _chk(L, rc):
@@ -265,6 +275,12 @@ class Dipper:
         m = np.zeros(max(row, 1), dtype=np.int32)
         _chk(self.L, self.L.dpr_get_msa_counts(self.h, row, _p(u, c_i32p), _p(m, c_i32p)))
         return u[:row], m[:row]
+
+    def prune_stats(self):
+        a = C.c_uint64()
+        b = C.c_uint64()
+        _chk(self.L, self.L.dpr_get_prune_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def timing(self):
         a = C.c_double()

@@ -4,6 +4,7 @@
 #include "dpr_internal.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
 
@@ -73,6 +74,17 @@ struct dpr_ctx {
 
 using namespace dpr;
 
+// NJ algorithm on a single GPU: 1 = exact pruned scan (njp.hip, default), 0 = full streaming scan
+static int g_nj_mode = -1;
+static bool want_pruned()
+{
+    if (g_nj_mode < 0) {
+        const char* e = std::getenv("DPR_NJ_MODE");
+        g_nj_mode = (e && std::strcmp(e, "stream") == 0) ? 0 : 1;
+    }
+    return g_nj_mode == 1;
+}
+
 // ---- exchange step of the sharded path: RCCL all-gather, or device copies between virtual ranks --
 enum ExKind { EX_RECS, EX_SLICES, EX_U };
 static const int kNcclUint8 = 1, kNcclFloat64 = 8;
@@ -116,30 +128,29 @@ static NjBuffers* owner_buffers(dpr_ctx* c, int64_t row)
     return o == c->rank ? &c->nj[0] : nullptr;
 }
 
-// one NJ iteration on every rank held by this context
-static int nj_iteration(dpr_ctx* c)
+// one NJ iteration (active size n, iteration index it) on every rank held by this context
+static int nj_iteration(dpr_ctx* c, int64_t n, int64_t it)
 {
     if (c->world == 1) {
         NjBuffers& b = c->nj[0];
-        if (int rc = nj_launch_scan(b, false, c->stream)) return rc;
-        if (int rc = nj_launch_select(b, true, c->stream)) return rc;
-        if (int rc = nj_launch_update(b, c->stream)) return rc;
-        return nj_launch_finalize(b, c->stream);
+        if (b.pr.active) {
+            if (int rc = njp_launch_scan(b, false, c->stream)) return rc;
+            if (int rc = njp_launch_post(b, n, it, c->stream)) return rc;
+            return njp_launch_bounds(b, n - 1, it + 1, c->stream);
+        }
+        if (int rc = nj_launch_scan(b, false, n, it, c->stream)) return rc;
+        return nj_launch_post(b, n, it, c->stream);
     }
     for (auto& b : c->nj) {
-        if (int rc = nj_launch_scan(b, false, c->stream)) return rc;
-        if (int rc = nj_launch_select(b, false, c->stream)) return rc;
+        if (int rc = nj_launch_scan(b, false, n, it, c->stream)) return rc;
+        if (int rc = nj_launch_select_local(b, nj_scan_grid(), c->stream)) return rc;
     }
     if (int rc = exchange(c, EX_RECS)) return rc;
-    for (auto& b : c->nj) {
-        if (int rc = nj_launch_commit(b, c->stream)) return rc;
-        if (int rc = nj_launch_extract(b, c->stream)) return rc;
-    }
+    for (auto& b : c->nj)
+        if (int rc = nj_launch_commit_extract(b, n, it, c->stream)) return rc;
     if (int rc = exchange(c, EX_SLICES)) return rc;
-    for (auto& b : c->nj) {
-        if (int rc = nj_launch_update(b, c->stream)) return rc;
-        if (int rc = nj_launch_finalize(b, c->stream)) return rc;
-    }
+    for (auto& b : c->nj)
+        if (int rc = nj_launch_update_sharded(b, n, c->stream)) return rc;
     return DPR_OK;
 }
 
@@ -437,6 +448,10 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
     }
     for (auto& b : c->nj)
         if (int rc = nj_prepare(b, c->stream)) return rc;
+    if (c->world == 1 && want_pruned() && n >= 3) {
+        if (int rc = njp_build(c->nj[0], c->stream)) return rc;
+        if (int rc = njp_launch_bounds(c->nj[0], n, 0, c->stream)) return rc;
+    }
     DPR_HIP(hipEventRecord(c->ev[1], c->stream));
     DPR_HIP(hipStreamSynchronize(c->stream));
     float ms = 0;
@@ -468,7 +483,10 @@ int64_t dpr_nj_run(dpr_ctx* c, int64_t max_iters, int32_t* merge_x, int32_t* mer
     const int64_t it0 = st.it;
     DPR_HIP(hipEventRecord(c->ev[2], c->stream));
     for (int64_t k = 0; k < todo; ++k)
-        if (int rc = nj_iteration(c)) return rc;
+        if (int rc = nj_iteration(c, st.n - k, it0 + k)) return rc;
+    for (auto& b : c->nj)
+        if (!b.pr.active)
+            if (int rc = nj_launch_finish(b, st.n - todo, it0 + todo, c->stream)) return rc;
     DPR_HIP(hipEventRecord(c->ev[3], c->stream));
     if (int rc = fetch_state(c, &st)) return rc;
     float ms = 0;
@@ -488,7 +506,11 @@ int64_t dpr_nj_run(dpr_ctx* c, int64_t max_iters, int32_t* merge_x, int32_t* mer
     if (last_d && st.n == 2) {
         // D[0][1] of the final pair (src/neighborJoining.cu:245-249); row 1 lives on rank 0
         NjBuffers& b0 = c->nj[0];
-        if (c->world == 1 || c->vworld > 0) {
+        if (b0.pr.active) {
+            int32_t pos01[2];
+            DPR_HIP(hipMemcpy(pos01, b0.pr.pos_of_slot, sizeof(pos01), hipMemcpyDeviceToHost));
+            DPR_HIP(hipMemcpy(last_d, b0.pr.D + (int64_t)pos01[1] * b0.pr.ld + pos01[0], sizeof(double), hipMemcpyDeviceToHost));
+        } else if (c->world == 1 || c->vworld > 0) {
             DPR_HIP(hipMemcpy(last_d, b0.D + 1 * b0.ld + 0, sizeof(double), hipMemcpyDeviceToHost));
         } else {
             NjRecord rec{ 0.0, 0ull, 0.0, 0ull };
@@ -508,15 +530,20 @@ int dpr_argmin_once(dpr_ctx* c, int reps, int32_t* out_i, int32_t* out_j, double
     if (!c || !c->have_matrix) { set_error("dpr_argmin_once: call dpr_dist_matrix first"); return DPR_ERR_STATE; }
     DPR_HIP(hipSetDevice(c->device));
     if (reps < 1) reps = 1;
+    NjState st0;
+    if (int rc = fetch_state(c, &st0)) return rc;
+    auto probe = [&](NjBuffers& b) -> int {
+        return b.pr.active ? njp_launch_scan(b, true, c->stream) : nj_launch_scan(b, true, st0.n, st0.it, c->stream);
+    };
     for (auto& b : c->nj)
-        if (int rc = nj_launch_scan(b, true, c->stream)) return rc;  // warm
+        if (int rc = probe(b)) return rc;  // warm
     DPR_HIP(hipEventRecord(c->ev[2], c->stream));
     for (int r = 0; r < reps; ++r)
         for (auto& b : c->nj)
-            if (int rc = nj_launch_scan(b, true, c->stream)) return rc;
+            if (int rc = probe(b)) return rc;
     DPR_HIP(hipEventRecord(c->ev[3], c->stream));
     for (auto& b : c->nj)
-        if (int rc = nj_launch_select(b, false, c->stream)) return rc;
+        if (int rc = nj_launch_select_local(b, b.pr.active ? njp_scan_grid() : nj_scan_grid(), c->stream)) return rc;
     if (int rc = exchange(c, EX_RECS)) return rc;
     std::vector<NjRecord> recs((size_t)c->world);
     DPR_HIP(hipMemcpyAsync(recs.data(), c->nj[0].recs, sizeof(NjRecord) * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
@@ -533,6 +560,39 @@ int dpr_argmin_once(dpr_ctx* c, int reps, int32_t* out_i, int32_t* out_j, double
     return DPR_OK;
 }
 
+// 0 = full streaming scan every iteration, 1 = exact pruned scan (default; single GPU only)
+int dpr_set_nj_mode(int mode)
+{
+    if (mode != 0 && mode != 1) { set_error("dpr_set_nj_mode: mode must be 0 or 1"); return DPR_ERR_ARG; }
+    g_nj_mode = mode;
+    return DPR_OK;
+}
+
+// units scanned by the pruned path since the matrix was built, and units per full scan
+int dpr_get_prune_stats(dpr_ctx* c, uint64_t* units_scanned, uint64_t* units_per_full_scan)
+{
+    if (!c || !c->have_matrix || !c->nj[0].pr.active) { set_error("dpr_get_prune_stats: pruned path not active"); return DPR_ERR_STATE; }
+    if (units_scanned) DPR_HIP(hipMemcpy(units_scanned, c->nj[0].pr.counters, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (units_per_full_scan) *units_per_full_scan = (uint64_t)c->nj[0].pr.utot;
+    return DPR_OK;
+}
+
+// tuning hook: row-group size (16/32/64), non-temporal loads (0/1), scan grid (<= 2048; 0 = default)
+int dpr_scan_tune(int rg, int nt, int grid)
+{
+    if (((rg & 127) != 16 && (rg & 127) != 64) || grid < 0 || grid > kScanBlocks) { set_error("dpr_scan_tune: bad argument"); return DPR_ERR_ARG; }
+    nj_scan_config(rg, nt, grid);
+    return DPR_OK;
+}
+
+// calibration: average ms of a plain streaming read of `bytes` of the matrix buffer
+int dpr_bw_probe(dpr_ctx* c, int64_t bytes, int nt, int grid, int reps, float* out_ms)
+{
+    if (!c || !c->have_matrix || !out_ms || grid < 1 || reps < 1) { set_error("dpr_bw_probe: bad argument"); return DPR_ERR_ARG; }
+    DPR_HIP(hipSetDevice(c->device));
+    return nj_bw_probe(c->nj[0], bytes, nt, grid, reps, c->stream, c->ev[2], c->ev[3], out_ms);
+}
+
 // ---- test hooks ---------------------------------------------------------------------------------------------
 int64_t dpr_n_active(dpr_ctx* c)
 {
@@ -547,6 +607,17 @@ int64_t dpr_n_total(dpr_ctx* c) { return c ? c->nj[0].N : DPR_ERR_ARG; }
 int dpr_get_matrix_row(dpr_ctx* c, int64_t i, double* out)
 {
     if (!c || !c->have_matrix || !out || i < 0 || i >= c->nj[0].N) { set_error("dpr_get_matrix_row: bad argument"); return DPR_ERR_ARG; }
+    if (c->nj[0].pr.active) {
+        // position space: row of slot i, columns gathered through pos_of_slot (dead slots read +inf)
+        NjPruned& q = c->nj[0].pr;
+        const int64_t N = c->nj[0].N;
+        std::vector<int32_t> pos((size_t)N);
+        std::vector<double> row((size_t)q.P);
+        DPR_HIP(hipMemcpy(pos.data(), q.pos_of_slot, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
+        DPR_HIP(hipMemcpy(row.data(), q.D + (int64_t)pos[(size_t)i] * q.ld, sizeof(double) * (size_t)q.P, hipMemcpyDeviceToHost));
+        for (int64_t j = 0; j < N; ++j) out[j] = row[(size_t)pos[(size_t)j]];
+        return DPR_OK;
+    }
     NjBuffers* b = owner_buffers(c, i);
     if (!b) { set_error("dpr_get_matrix_row: row not owned by this rank"); return DPR_ERR_ARG; }
     DPR_HIP(hipMemcpy(out, b->D + shard_local_row(i, c->world) * b->ld, sizeof(double) * (size_t)b->N, hipMemcpyDeviceToHost));
@@ -556,6 +627,16 @@ int dpr_get_matrix_row(dpr_ctx* c, int64_t i, double* out)
 int dpr_get_row_sums(dpr_ctx* c, double* out)
 {
     if (!c || !c->have_matrix || !out) { set_error("dpr_get_row_sums: bad argument"); return DPR_ERR_ARG; }
+    if (c->nj[0].pr.active) {
+        NjPruned& q = c->nj[0].pr;
+        const int64_t N = c->nj[0].N;
+        std::vector<int32_t> pos((size_t)N);
+        std::vector<double> u((size_t)q.P);
+        DPR_HIP(hipMemcpy(pos.data(), q.pos_of_slot, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
+        DPR_HIP(hipMemcpy(u.data(), q.U, sizeof(double) * (size_t)q.P, hipMemcpyDeviceToHost));
+        for (int64_t j = 0; j < N; ++j) out[j] = u[(size_t)pos[(size_t)j]];
+        return DPR_OK;
+    }
     DPR_HIP(hipMemcpy(out, c->nj[0].U, sizeof(double) * (size_t)c->nj[0].N, hipMemcpyDeviceToHost));
     return DPR_OK;
 }

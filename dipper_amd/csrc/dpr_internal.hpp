@@ -11,7 +11,7 @@ namespace dpr {
 
 constexpr int kRowBlock = DPR_ROW_BLOCK;  // rows per ownership block == rows per scan tile
 constexpr int kTileCols = 512;            // columns per scan tile (256 lanes x 2 doubles)
-constexpr int kScanBlocks = 2048;         // persistent scan grid: 256 CUs x 8 blocks
+constexpr int kScanBlocks = 8192;         // capacity of the partials array (scan grid <= this)
 constexpr int kThreads = 256;
 
 void set_error(const std::string& msg);
@@ -78,6 +78,20 @@ struct NjState {
     int32_t pad;
 };
 
+// position-space state of the pruned path (njp.hip)
+struct NjPruned {
+    bool active = false;
+    int64_t P = 0, ld = 0;      // positions of this epoch, row stride
+    double* D = nullptr;        // [P][ld] position space
+    double *U = nullptr, *Ur = nullptr;   // by position; Ur = NaN for dead positions
+    uint64_t *KA = nullptr, *KB = nullptr;  // key parts from the reference slot of each position
+    int32_t *slot_of_pos = nullptr, *pos_of_slot = nullptr, *perm = nullptr;
+    uint64_t* umin = nullptr;   // [strips][groups] order-encoded lower bound of D per unit
+    int64_t nunits_alloc = 0, utot = 0;
+    double *gmax = nullptr, *bmax = nullptr;   // max Ur per 16 / 256 positions
+    uint64_t *seed = nullptr, *counters = nullptr;
+};
+
 struct NjBuffers {
     double* D = nullptr;       // [rows_local_max][ld] (+ tail pad)
     int64_t ld = 0;
@@ -100,6 +114,7 @@ struct NjBuffers {
     double* log_bx = nullptr;
     double* log_by = nullptr;
     int rank = 0, world = 1;
+    NjPruned pr;
 };
 
 // nj.hip
@@ -108,13 +123,24 @@ void nj_free(NjBuffers& b);
 int nj_expand_lower(NjBuffers& b, const double* d_packed_lower, hipStream_t s);
 int nj_init_sums(NjBuffers& b, hipStream_t s);          // U (local rows), diag, state
 int nj_prepare(NjBuffers& b, hipStream_t s);            // Ur, KA for n = st->n
-int nj_launch_scan(NjBuffers& b, bool probe, hipStream_t s);
-int nj_launch_select(NjBuffers& b, bool commit, hipStream_t s);   // world == 1
-int nj_launch_update(NjBuffers& b, hipStream_t s);
-int nj_launch_commit(NjBuffers& b, hipStream_t s);    // world > 1: reduce b.recs[world] + commit
-int nj_launch_extract(NjBuffers& b, hipStream_t s);   // world > 1: column slices of x, y, n-1
-int nj_launch_unpack_u(NjBuffers& b, hipStream_t s);  // world > 1: gathered row sums -> U
-int nj_launch_finalize(NjBuffers& b, hipStream_t s);
+int nj_launch_scan(NjBuffers& b, bool probe, int64_t n, int64_t it, hipStream_t s);
+void nj_scan_config(int rg, int nt, int grid);  // tuning knobs (dpr_scan_tune)
+int nj_scan_grid();
+int nj_bw_probe(NjBuffers& b, int64_t bytes, int nt, int grid, int reps, hipStream_t s, hipEvent_t e0, hipEvent_t e1, float* ms);
+int nj_launch_post(NjBuffers& b, int64_t n, int64_t it, hipStream_t s);            // world == 1
+int nj_launch_select_local(NjBuffers& b, int nparts, hipStream_t s);                            // -> b.recs[b.rank]
+int nj_launch_commit_extract(NjBuffers& b, int64_t n, int64_t it, hipStream_t s);   // world > 1
+int nj_launch_update_sharded(NjBuffers& b, int64_t n, hipStream_t s);               // world > 1
+int nj_launch_unpack_u(NjBuffers& b, hipStream_t s);                                // world > 1: gathered row sums -> U
+int nj_launch_finish(NjBuffers& b, int64_t n, int64_t it, hipStream_t s);           // materialise U[x] after the loop
+
+// njp.hip: exact pruned NJ (world == 1)
+int njp_build(NjBuffers& b, hipStream_t s);   // permute the tip-order matrix by ascending row sum; frees b.D
+void njp_free(NjPruned& q);
+int njp_scan_grid();
+int njp_launch_bounds(NjBuffers& b, int64_t n, int64_t it, hipStream_t s);
+int njp_launch_scan(NjBuffers& b, bool full, hipStream_t s);
+int njp_launch_post(NjBuffers& b, int64_t n, int64_t it, hipStream_t s);
 
 // msa.hip
 struct MsaBuffers {

@@ -9,57 +9,9 @@
 //
 // All fp64 expressions are written exactly as the reference associates them; this TU is compiled
 // with -ffp-contract=off.
-#include "dpr_internal.hpp"
+#include "nj_dev.hpp"
 
 namespace dpr {
-
-// ------------------------------------------------------------------------------------------------
-// helpers
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void best_update(double& bq, uint64_t& bk, double q, uint64_t k)
-{
-    // strict '<' on q (NaN never wins), ties resolved by the reference's visiting order (key)
-    const bool take = (q < bq) | ((q == bq) & (k < bk));
-    bq = take ? q : bq;
-    bk = take ? k : bk;
-}
-
-__device__ __forceinline__ void wave_best(double& bq, uint64_t& bk)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double oq = __shfl_down(bq, off, 64);
-        const uint64_t ok = __shfl_down((unsigned long long)bk, off, 64);
-        best_update(bq, bk, oq, ok);
-    }
-}
-
-// block-wide (256 threads) lexicographic minimum; result valid in thread 0
-__device__ __forceinline__ void block_best(double& bq, uint64_t& bk, double* sq, uint64_t* sk)
-{
-    wave_best(bq, bk);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) { sq[w] = bq; sk[w] = bk; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 1; i < kThreads / 64; ++i) best_update(bq, bk, sq[i], sk[i]);
-    }
-}
-
-// pairwise tree over 256 values, c[t] += c[t+s] for s = 128..1 (canonical order)
-__device__ __forceinline__ double block_tree256(double v, double* s)
-{
-    const int t = threadIdx.x;
-    s[t] = v;
-    __syncthreads();
-#pragma unroll
-    for (int st = 128; st > 0; st >>= 1) {
-        if (t < st) s[t] = s[t] + s[t + st];
-        __syncthreads();
-    }
-    return s[0];
-}
 
 // ------------------------------------------------------------------------------------------------
 // matrix source: packed lower triangle (MatrixReader, src/matrix_reader.cu:23-45 + fillDismatrix
@@ -129,37 +81,43 @@ __global__ __launch_bounds__(kThreads) void nj_prepare_kernel(const NjState* __r
 
 // ------------------------------------------------------------------------------------------------
 // Q-argmin scan (findMinDist, src/neighborJoining.cu:117-148).
-// Work unit = tile of 64 owned rows x 512 columns of the strict lower triangle; a lane owns two
-// adjacent columns (one 16-byte load per row), eight rows in flight.  Each loaded D[a][b] (b<a)
-// yields both ordered candidates of the reference:
+// Work unit = RG owned rows x 512 columns of the strict lower triangle, enumerated strip-major
+// (column strip cb, then row groups downwards); every block takes a CONTIGUOUS, equal share of the
+// units, so it keeps its two columns' Ur/KA/KB in registers while it walks down a strip and all
+// blocks finish together.  A lane owns two adjacent columns (one 16-byte non-temporal load per row),
+// eight rows in flight; row parameters come through scalar loads.  Each loaded D[a][b] (b<a) yields
+// both ordered candidates of the reference:
 //   (i=a,j=b): q = (D - Ur[a]) - Ur[b], key = KA[a] | KB[b]
 //   (i=b,j=a): q = (D - Ur[b]) - Ur[a], key = KA[b] | KB[a]
+// Prologue (it > 0): the row sum of the node created in the previous iteration, U[x] = canonical sum
+// of the 256-chunk partials left by the update kernel, is finished here by every block for itself
+// (block 0 also stores it), which saves a kernel per iteration.
 // ------------------------------------------------------------------------------------------------
-template <bool DIAG>
-__device__ __forceinline__ void scan_tile(const double* __restrict__ D, int64_t ld,
+template <bool DIAG, bool NT, bool FILT>
+__device__ __forceinline__ void scan_rows(const double* __restrict__ D, int64_t ld,
                                           const double* __restrict__ Ur,
-                                          const uint64_t* __restrict__ KA, int64_t g0, int64_t l0,
-                                          int nrows, int64_t c0, double& bq, uint64_t& bk)
+                                          const uint64_t* __restrict__ KA, int64_t a0, int64_t l0,
+                                          int nrows, int64_t c0, int64_t xprev, double urx, double ub0,
+                                          double ub1, uint64_t ka0, uint64_t ka1, uint64_t kb0,
+                                          uint64_t kb1, double& bq, uint64_t& bk)
 {
     const int tid = threadIdx.x;
     const int64_t b0 = c0 + 2 * tid, b1 = b0 + 1;
-    const double ub0 = Ur[b0], ub1 = Ur[b1];
-    const uint64_t ka0 = KA[b0], ka1 = KA[b1];
-    const uint64_t kb0 = nj_key_b(b0), kb1 = nj_key_b(b1);
-    const double2* base = reinterpret_cast<const double2*>(D + l0 * ld + c0) + tid;
+    const v2d* base = reinterpret_cast<const v2d*>(D + l0 * ld + c0) + tid;
     const int64_t ld2 = ld >> 1;
-
     for (int r = 0; r < nrows; r += 8) {
-        double2 v[8];
+        v2d v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int rr = min(r + u, nrows - 1);  // clamp: duplicates are idempotent
-            v[u] = base[(int64_t)rr * ld2];
+            const v2d* p = base + (int64_t)rr * ld2;
+            if (DIAG) p = (b0 < a0 + rr) ? p : p - tid;  // masked lanes share one line
+            v[u] = NT ? __builtin_nontemporal_load(p) : *p;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int64_t a = g0 + min(r + u, nrows - 1);
-            const double ua = Ur[a];
+            const int64_t a = a0 + min(r + u, nrows - 1);
+            const double ua = (a == xprev) ? urx : Ur[a];
             const uint64_t kaa = KA[a];
             const uint64_t kba = nj_key_b(a);
             double d0 = v[u].x, d1 = v[u].y;
@@ -167,140 +125,193 @@ __device__ __forceinline__ void scan_tile(const double* __restrict__ D, int64_t 
                 d0 = (b0 < a) ? d0 : __builtin_nan("");
                 d1 = (b1 < a) ? d1 : __builtin_nan("");
             }
-            best_update(bq, bk, (d0 - ua) - ub0, kaa | kb0);
-            best_update(bq, bk, (d0 - ub0) - ua, ka0 | kba);
-            best_update(bq, bk, (d1 - ua) - ub1, kaa | kb1);
-            best_update(bq, bk, (d1 - ub1) - ua, ka1 | kba);
+            const double q0a = (d0 - ua) - ub0, q0b = (d0 - ub0) - ua;
+            const double q1a = (d1 - ua) - ub1, q1b = (d1 - ub1) - ua;
+            if (FILT) {
+                // a lane's best improves O(log m) times over m elements: test once per row, update rarely
+                const double m = fmin(fmin(q0a, q0b), fmin(q1a, q1b));  // fmin drops NaN (masked / invalid)
+                if (!(m <= bq)) continue;
+            }
+            best_update(bq, bk, q0a, kaa | kb0);
+            best_update(bq, bk, q0b, ka0 | kba);
+            best_update(bq, bk, q1a, kaa | kb1);
+            best_update(bq, bk, q1b, ka1 | kba);
         }
     }
 }
 
-template <bool PROBE>
+// strip geometry for active size n on (rank, world): first owned local row that can see column c0,
+// rounded down to a row group, and the number of row groups below it
+template <int RG>
+__device__ __forceinline__ void strip_geom(int64_t cb, int64_t n, int64_t nloc, int rank, int world,
+                                           int64_t& lstart, int& cnt)
+{
+    const int64_t c0 = cb * kTileCols;
+    const int64_t lmin = shard_rows(min(c0 + 1, n), rank, world);  // owned rows with global index <= c0
+    lstart = lmin / RG * RG;
+    cnt = nloc > lstart ? (int)((nloc - lstart + RG - 1) / RG) : 0;
+}
+
+template <bool PROBE, int RG, bool NT, bool FILT>
 __global__ __launch_bounds__(kThreads) void nj_scan_kernel(
-    const double* __restrict__ D, int64_t ld, const NjState* __restrict__ st,
-    const double* __restrict__ Ur, const uint64_t* __restrict__ KA,
-    const int32_t* __restrict__ tile_start, int nlrb, int rank, int world,
+    const double* __restrict__ D, int64_t ld, const NjState* __restrict__ st, double* __restrict__ U_w,
+    double* __restrict__ Ur_w, const double* __restrict__ Ur, const uint64_t* __restrict__ KA,
+    const double* __restrict__ xpart, int64_t n, int64_t it, int rank, int world,
     NjRecord* __restrict__ partials)
 {
+    // Ur_w aliases Ur: block 0 stores the single element Ur[xprev] through it, and no block ever USES
+    // Ur[xprev] read through the const pointer (every use substitutes urx), so the scan can keep
+    // scalar loads for the row parameters.
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int32_t* ts = reinterpret_cast<int32_t*>(smem);
+    int32_t* pref = reinterpret_cast<int32_t*>(smem);  // [nstrips + 1] exclusive prefix of unit counts
+    __shared__ int32_t ssum[kThreads];
+    __shared__ double sd[kThreads];
     __shared__ double sq[kThreads / 64];
     __shared__ uint64_t sk[kThreads / 64];
 
     const int tid = threadIdx.x;
-    const int64_t n = st->n;
     double bq = 10000.0;  // the reference's init value (src/neighborJoining.cu:134)
     uint64_t bk = ~0ull;
+    const bool dead = st->status != 0;
 
-    const int64_t nrb_glob = (n + kRowBlock - 1) / kRowBlock;
-    int nact = nrb_glob > rank ? (int)((nrb_glob - rank + world - 1) / world) : 0;
-    if (nact > nlrb) nact = nlrb;
-    if (st->status != 0) nact = 0;
-    for (int i = tid; i < nact; i += kThreads) ts[i] = tile_start[i];
-    __syncthreads();
-
-    int ntiles = 0;
-    if (nact > 0) {
-        const int64_t g0L = ((int64_t)(nact - 1) * world + rank) * kRowBlock;
-        const int64_t gEndL = min(g0L + (int64_t)kRowBlock, n);
-        ntiles = ts[nact - 1] + (int)((gEndL - 1 + kTileCols - 1) / kTileCols);
+    int64_t xprev = -1;
+    double urx = 0.0;
+    if (it > 0 && !dead) {
+        xprev = st->x;
+        const double ux = finish_ux(xpart, n + 1, sd);
+        urx = ux / (double)(n - 2);
+        if (blockIdx.x == 0 && tid == 0) { U_w[xprev] = ux; Ur_w[xprev] = urx; }
     }
 
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        int lo = 0, hi = nact - 1;
+    const int64_t nloc = shard_rows(n, rank, world);
+    int nstrips = n > 1 ? (int)((n - 1 + kTileCols - 1) / kTileCols) : 0;
+    if (dead) nstrips = 0;
+
+    // unit counts per strip -> exclusive prefix in LDS (thread t owns strips [t*per, t*per+per))
+    const int per = (nstrips + kThreads - 1) / kThreads;
+    int mysum = 0;
+    for (int k = 0; k < per; ++k) {
+        const int cb = tid * per + k;
+        if (cb < nstrips) { int64_t ls; int c; strip_geom<RG>(cb, n, nloc, rank, world, ls, c); mysum += c; }
+    }
+    ssum[tid] = mysum;
+    __syncthreads();
+    for (int off = 1; off < kThreads; off <<= 1) {
+        const int v = tid >= off ? ssum[tid - off] : 0;
+        __syncthreads();
+        ssum[tid] += v;
+        __syncthreads();
+    }
+    {
+        int run = ssum[tid] - mysum;
+        for (int k = 0; k < per; ++k) {
+            const int cb = tid * per + k;
+            if (cb < nstrips) { int64_t ls; int c; strip_geom<RG>(cb, n, nloc, rank, world, ls, c); pref[cb] = run; run += c; }
+        }
+        if (tid == kThreads - 1) pref[nstrips] = ssum[tid];
+    }
+    __syncthreads();
+    const int64_t utot = nstrips > 0 ? pref[nstrips] : 0;
+    const int64_t ub = utot * blockIdx.x / gridDim.x, ue = utot * (blockIdx.x + 1) / gridDim.x;
+
+    if (ub < ue) {
+        int lo = 0, hi = nstrips - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if (ts[mid] <= t) lo = mid; else hi = mid - 1;
+            if (pref[mid] <= (int)ub) lo = mid; else hi = mid - 1;
         }
-        const int lrb = __builtin_amdgcn_readfirstlane(lo);
-        const int cb = __builtin_amdgcn_readfirstlane(t - ts[lo]);
-        const int64_t g0 = ((int64_t)lrb * world + rank) * kRowBlock;
-        const int64_t l0 = (int64_t)lrb * kRowBlock;
-        const int nrows = (int)min((int64_t)kRowBlock, n - g0);
-        const int64_t c0 = (int64_t)cb * kTileCols;
-        if (c0 + kTileCols > g0)
-            scan_tile<true>(D, ld, Ur, KA, g0, l0, nrows, c0, bq, bk);
-        else
-            scan_tile<false>(D, ld, Ur, KA, g0, l0, nrows, c0, bq, bk);
+        int cb = __builtin_amdgcn_readfirstlane(lo);
+        int g = __builtin_amdgcn_readfirstlane((int)ub - pref[lo]);
+        int64_t lstart; int cnt;
+        strip_geom<RG>(cb, n, nloc, rank, world, lstart, cnt);
+        bool fresh = true;
+        double ub0 = 0, ub1 = 0; uint64_t ka0 = 0, ka1 = 0, kb0 = 0, kb1 = 0;
+        for (int64_t u = ub; u < ue; ++u) {
+            while (g >= cnt) { ++cb; g = 0; strip_geom<RG>(cb, n, nloc, rank, world, lstart, cnt); fresh = true; }
+            const int64_t c0 = (int64_t)cb * kTileCols;
+            if (fresh) {
+                const int64_t b0 = c0 + 2 * tid;
+                ub0 = (b0 == xprev) ? urx : Ur[b0];
+                ub1 = (b0 + 1 == xprev) ? urx : Ur[b0 + 1];
+                ka0 = KA[b0]; ka1 = KA[b0 + 1];
+                kb0 = nj_key_b(b0); kb1 = nj_key_b(b0 + 1);
+                fresh = false;
+            }
+            const int64_t l0 = lstart + (int64_t)g * RG;
+            const int nrows = (int)min((int64_t)RG, nloc - l0);
+            const int64_t a0 = shard_global_row(l0, rank, world);
+            if (a0 < c0 + kTileCols)
+                scan_rows<true, NT, FILT>(D, ld, Ur, KA, a0, l0, nrows, c0, xprev, urx, ub0, ub1, ka0, ka1, kb0, kb1, bq, bk);
+            else
+                scan_rows<false, NT, FILT>(D, ld, Ur, KA, a0, l0, nrows, c0, xprev, urx, ub0, ub1, ka0, ka1, kb0, kb1, bq, bk);
+            ++g;
+        }
     }
 
     block_best(bq, bk, sq, sk);
     if (tid == 0) {
         NjRecord rec;
         rec.q = bq; rec.key = bk; rec.d = 0.0; rec.pad = 0;
+        if (bk != ~0ull) {
+            // d = D[max][min]: the block only visited owned rows a > b, so the row is local
+            const int64_t i = (int64_t)(bk & 0xFFFFFFull), j = (int64_t)((bk >> 24) & 0xFFFFFFull);
+            const int64_t x = i < j ? i : j, y = i < j ? j : i;
+            rec.d = D[shard_local_row(y, world) * ld + x];
+        }
         partials[blockIdx.x] = rec;
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// select: reduce the per-block partials (thrust::min_element, src/neighborJoining.cu:214), fetch
-// d = D[x][y] from the owned row, and (COMMIT) do the host part of the reference's loop
-// (:219-239): branch lengths, merge log, state.
-// ------------------------------------------------------------------------------------------------
-template <bool COMMIT>
-__global__ __launch_bounds__(kThreads) void nj_select_kernel(
-    const double* __restrict__ D, int64_t ld, NjState* __restrict__ st,
-    const double* __restrict__ U, const NjRecord* __restrict__ partials, int nparts, int rank,
-    int world, int32_t* __restrict__ log_x, int32_t* __restrict__ log_y,
-    double* __restrict__ log_bx, double* __restrict__ log_by, NjRecord* __restrict__ out)
+// local winner of this rank -> recs[rank] (all-gathered when world > 1; read by the host for probes)
+__global__ __launch_bounds__(kThreads) void nj_select_local_kernel(const NjState* __restrict__ st,
+                                                                   const NjRecord* __restrict__ partials,
+                                                                   int nparts, NjRecord* __restrict__ out)
 {
-    __shared__ double sq[kThreads / 64];
+    __shared__ double sq[kThreads / 64], sdd[kThreads / 64];
     __shared__ uint64_t sk[kThreads / 64];
-    double bq = 10000.0;
-    uint64_t bk = ~0ull;
-    for (int i = threadIdx.x; i < nparts; i += kThreads) best_update(bq, bk, partials[i].q, partials[i].key);
-    block_best(bq, bk, sq, sk);
+    double bq, bd; uint64_t bk;
+    reduce_records(partials, nparts, bq, bk, bd, sq, sk, sdd);
     if (threadIdx.x != 0) return;
-    if (st->status != 0) {
-        if (out) { out->q = 10000.0; out->key = ~0ull; out->d = 0.0; out->pad = 0; }
-        return;
-    }
-    if (bk == ~0ull) {
-        if (COMMIT) st->status = 1;
-        if (out) { out->q = bq; out->key = bk; out->d = 0.0; out->pad = 0; }
-        return;
-    }
-    const int64_t i = (int64_t)(bk & 0xFFFFFFull), j = (int64_t)((bk >> 24) & 0xFFFFFFull);
-    const int64_t x = i < j ? i : j, y = i < j ? j : i;
-    // the scan only visits owned rows a > b, so row y is local
-    const double d = D[shard_local_row(y, world) * ld + x];
-    if (out) { out->q = bq; out->key = bk; out->d = d; out->pad = 0; }
-    if (COMMIT) {
-        const int64_t n = st->n;
-        const double r = (double)(n - 2);
-        double blX = (d + U[x] / r - U[y] / r) * 0.5;
-        double blY = d - blX;
-        if (blX < 0) { blY += blX; blX = 0; }
-        if (blY < 0) { blX += blY; blY = 0; }
-        const int64_t it = st->it;
-        log_x[it] = (int32_t)x; log_y[it] = (int32_t)y; log_bx[it] = blX; log_by[it] = blY;
-        st->x = (int32_t)x; st->y = (int32_t)y; st->d = d; st->q = bq;
-    }
+    if (st->status != 0) { bq = 10000.0; bk = ~0ull; bd = 0.0; }
+    out->q = bq; out->key = bk; out->d = bd; out->pad = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
-// updateDisMatrix (src/neighborJoining.cu:161-194), one thread per active slot i.
-// world == 1: the three source vectors are rows x, y, n-1 of D.
-// Also prepares Ur/KA of the next iteration (n' = n-1) and the 256-chunk partial sums of U[x].
+// world == 1: select (thrust::min_element, src/neighborJoining.cu:214) + host bookkeeping (:219-239)
+// + updateDisMatrix (:161-194) in ONE kernel.  Every block reduces the scan partials for itself;
+// thread i handles slot i; the thread of the last slot also plays the reference's thread (0,0) tail
+// and is the single writer of the merge log and of the state.  Prepares Ur/KA for n' = n-1 and the
+// 256-chunk partial sums of U[x].
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void nj_update_kernel(double* __restrict__ D, int64_t ld,
-                                                             const NjState* __restrict__ st,
-                                                             double* __restrict__ U,
-                                                             double* __restrict__ Ur,
-                                                             uint64_t* __restrict__ KA,
-                                                             double* __restrict__ xpart)
+__global__ __launch_bounds__(kThreads) void nj_post_kernel(double* __restrict__ D, int64_t ld,
+                                                           NjState* __restrict__ st, double* __restrict__ U,
+                                                           double* __restrict__ Ur, uint64_t* __restrict__ KA,
+                                                           double* __restrict__ xpart,
+                                                           const NjRecord* __restrict__ partials, int nparts,
+                                                           int64_t n, int64_t it, int32_t* __restrict__ log_x,
+                                                           int32_t* __restrict__ log_y, double* __restrict__ log_bx,
+                                                           double* __restrict__ log_by)
 {
     __shared__ double s[kThreads];
-    const int64_t n = st->n;
+    __shared__ double sq[kThreads / 64], sdd[kThreads / 64];
+    __shared__ uint64_t sk[kThreads / 64];
     if (st->status != 0) return;
-    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if ((int64_t)blockIdx.x * kThreads >= n) return;  // whole block idle
-    const int64_t x = st->x, y = st->y, last = n - 1;
-    const double d = st->d;
+    double bq, d; uint64_t bk;
+    reduce_records(partials, nparts, bq, bk, d, sq, sk, sdd);
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t last = n - 1;
+    if (bk == ~0ull) {
+        if (i == last) st->status = 1;
+        return;
+    }
+    const int64_t ki = (int64_t)(bk & 0xFFFFFFull), kj = (int64_t)((bk >> 24) & 0xFFFFFFull);
+    const int64_t x = ki < kj ? ki : kj, y = ki < kj ? kj : ki;
     const int64_t n1 = n - 1;
     const double r1 = (double)(n1 - 2);
 
     double val = 0.0;
+    if (i == last) commit_merge(st, U, n, it, x, y, d, bq, log_x, log_y, log_bx, log_by);  // reads U[y] before the tail rewrites it
     if (i < n && i != x && i != y) {
         const double dxi = D[x * ld + i], dyi = D[y * ld + i];
         val = (dxi + dyi - d) * 0.5;
@@ -328,15 +339,16 @@ __global__ __launch_bounds__(kThreads) void nj_update_kernel(double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// world > 1.  Per iteration: local record -> all-gather -> commit (identical on every rank) ->
-// column slices of x, y, n-1 for the owned rows -> all-gather -> update.
+// world > 1.  Per iteration: scan -> local record -> all-gather -> commit (identical on every rank)
+// + column slices of x, y, n-1 for the owned rows -> all-gather -> sharded update.
 // ------------------------------------------------------------------------------------------------
-__global__ void nj_commit_kernel(NjState* __restrict__ st, const double* __restrict__ U,
-                                 const NjRecord* __restrict__ recs, int world,
-                                 int32_t* __restrict__ log_x, int32_t* __restrict__ log_y,
-                                 double* __restrict__ log_bx, double* __restrict__ log_by)
+// slice[v][li] = D[li][c_v] for c = (x, y, n-1), owned rows with global index < n
+__global__ __launch_bounds__(kThreads) void nj_commit_extract_kernel(
+    const double* __restrict__ D, int64_t ld, NjState* __restrict__ st, const double* __restrict__ U,
+    const NjRecord* __restrict__ recs, double* __restrict__ slice, int64_t slice_len, int64_t rows_local,
+    int64_t n, int64_t it, int rank, int world, int32_t* __restrict__ log_x, int32_t* __restrict__ log_y,
+    double* __restrict__ log_bx, double* __restrict__ log_by)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (st->status != 0) return;
     double bq = 10000.0, d = 0.0;
     uint64_t bk = ~0ull;
@@ -345,47 +357,28 @@ __global__ void nj_commit_kernel(NjState* __restrict__ st, const double* __restr
         const uint64_t k = recs[r].key;
         if ((q < bq) | ((q == bq) & (k < bk))) { bq = q; bk = k; d = recs[r].d; }
     }
-    if (bk == ~0ull) { st->status = 1; return; }
-    const int64_t i = (int64_t)(bk & 0xFFFFFFull), j = (int64_t)((bk >> 24) & 0xFFFFFFull);
-    const int64_t x = i < j ? i : j, y = i < j ? j : i;
-    const int64_t n = st->n;
-    const double r = (double)(n - 2);
-    double blX = (d + U[x] / r - U[y] / r) * 0.5;
-    double blY = d - blX;
-    if (blX < 0) { blY += blX; blX = 0; }
-    if (blY < 0) { blX += blY; blY = 0; }
-    const int64_t it = st->it;
-    log_x[it] = (int32_t)x; log_y[it] = (int32_t)y; log_bx[it] = blX; log_by[it] = blY;
-    st->x = (int32_t)x; st->y = (int32_t)y; st->d = d; st->q = bq;
-}
-
-// slice[v][li] = D[li][c_v] for c = (x, y, n-1), owned rows with global index < n
-__global__ __launch_bounds__(kThreads) void nj_extract_kernel(const double* __restrict__ D, int64_t ld,
-                                                              const NjState* __restrict__ st,
-                                                              double* __restrict__ slice,
-                                                              int64_t slice_len, int64_t rows_local,
-                                                              int rank, int world)
-{
-    if (st->status != 0) return;
+    const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+    if (bk == ~0ull) { if (writer) st->status = 1; return; }
+    const int64_t ki = (int64_t)(bk & 0xFFFFFFull), kj = (int64_t)((bk >> 24) & 0xFFFFFFull);
+    const int64_t x = ki < kj ? ki : kj, y = ki < kj ? kj : ki;
+    if (writer) commit_merge(st, U, n, it, x, y, d, bq, log_x, log_y, log_bx, log_by);
     const int64_t li = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (li >= rows_local) return;
-    const int64_t n = st->n;
     const int64_t i = shard_global_row(li, rank, world);
     if (i >= n) return;
     const double* row = D + li * ld;
-    slice[0 * slice_len + li] = row[st->x];
-    slice[1 * slice_len + li] = row[st->y];
+    slice[0 * slice_len + li] = row[x];
+    slice[1 * slice_len + li] = row[y];
     slice[2 * slice_len + li] = row[n - 1];
 }
 
-// gathered layout: gath[(r*3 + v)*slice_len + li]
+// gathered layout: gath[(r*3 + v)*slice_len + li]; x, y, d come from the state the commit wrote
 __global__ __launch_bounds__(kThreads) void nj_update_sharded_kernel(
     double* __restrict__ D, int64_t ld, const NjState* __restrict__ st, double* __restrict__ U,
     double* __restrict__ Ur, uint64_t* __restrict__ KA, double* __restrict__ xpart,
-    const double* __restrict__ gath, int64_t slice_len, int rank, int world)
+    const double* __restrict__ gath, int64_t slice_len, int64_t n, int rank, int world)
 {
     __shared__ double s[kThreads];
-    const int64_t n = st->n;
     if (st->status != 0) return;
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if ((int64_t)blockIdx.x * kThreads >= n) return;
@@ -434,27 +427,58 @@ __global__ __launch_bounds__(kThreads) void nj_unpack_u_kernel(const double* __r
     U[i] = gathU[(int64_t)shard_owner(i, world) * slice_len + shard_local_row(i, world)];
 }
 
-// U[x] = canonical sum of the chunk sums; advance the state to n-1.
-__global__ __launch_bounds__(kThreads) void nj_finalize_kernel(NjState* __restrict__ st,
-                                                               double* __restrict__ U,
-                                                               double* __restrict__ Ur,
-                                                               const double* __restrict__ xpart)
+// after the last enqueued iteration: materialise U[x], Ur[x] (what the next scan's prologue would do),
+// so that hooks and a resumed run see a consistent state
+__global__ __launch_bounds__(kThreads) void nj_finish_kernel(const NjState* __restrict__ st,
+                                                             double* __restrict__ U, double* __restrict__ Ur,
+                                                             const double* __restrict__ xpart, int64_t n, int64_t it)
 {
     __shared__ double s[kThreads];
-    if (st->status != 0) return;
-    const int64_t n = st->n;
-    const int64_t nchunk = (n + kThreads - 1) / kThreads;
-    double acc = 0.0;
-    for (int64_t c = threadIdx.x; c < nchunk; c += kThreads) acc += xpart[c];
-    const double ux = block_tree256(acc, s);
+    if (st->status != 0 || it <= 0) return;
+    const double ux = finish_ux(xpart, n + 1, s);
     if (threadIdx.x == 0) {
         const int64_t x = st->x;
-        const int64_t n1 = n - 1;
         U[x] = ux;
-        Ur[x] = ux / (double)(n1 - 2);
-        st->n = n1;
-        st->it = st->it + 1;
+        Ur[x] = ux / (double)(n - 2);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// calibration: plain streaming read of the matrix allocation (16 B per lane, min-reduce), to know
+// what a pure HBM read reaches on the same buffer the scan streams
+// ------------------------------------------------------------------------------------------------
+template <bool NT>
+__global__ __launch_bounds__(kThreads) void bw_read_kernel(const v2d* __restrict__ p, int64_t nvec, double* __restrict__ out)
+{
+    double m = 1e300;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    for (; i + 7 * stride < nvec; i += 8 * stride) {
+        v2d v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = NT ? __builtin_nontemporal_load(p + i + u * stride) : p[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = fmin(m, fmin(v[u].x, v[u].y));
+    }
+    for (; i < nvec; i += stride) { const v2d v = p[i]; m = fmin(m, fmin(v.x, v.y)); }
+    if (m == -1.2345e300) out[0] = m;  // never true: keeps the loads alive
+}
+
+int nj_bw_probe(NjBuffers& b, int64_t bytes, int nt, int grid, int reps, hipStream_t s, hipEvent_t e0, hipEvent_t e1, float* ms)
+{
+    const int64_t cap = (int64_t)b.rows_local * b.ld * (int64_t)sizeof(double);
+    if (bytes <= 0 || bytes > cap) bytes = cap;
+    const int64_t nvec = bytes / 16;
+    for (int r = -1; r < reps; ++r) {
+        if (r == 0) DPR_HIP(hipEventRecord(e0, s));
+        if (nt) hipLaunchKernelGGL(bw_read_kernel<true>, dim3(grid), dim3(kThreads), 0, s, reinterpret_cast<const v2d*>(b.D), nvec, b.xpart);
+        else hipLaunchKernelGGL(bw_read_kernel<false>, dim3(grid), dim3(kThreads), 0, s, reinterpret_cast<const v2d*>(b.D), nvec, b.xpart);
+    }
+    DPR_HIP(hipEventRecord(e1, s));
+    DPR_HIP(hipStreamSynchronize(s));
+    DPR_HIP(hipEventElapsedTime(ms, e0, e1));
+    *ms /= (float)reps;
+    return DPR_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -480,6 +504,7 @@ int nj_alloc(NjBuffers& b, int64_t N, int rank, int world)
     DPR_HIP(hipMemset(b.Ur, 0, vec * sizeof(double)));
     DPR_HIP(hipMemset(b.KA, 0, vec * sizeof(uint64_t)));
     DPR_HIP(hipMalloc(&b.partials, sizeof(NjRecord) * kScanBlocks));
+    DPR_HIP(hipMemset(b.partials, 0xff, sizeof(NjRecord) * kScanBlocks));  // key = ~0: "no candidate"
     DPR_HIP(hipMalloc(&b.recs, sizeof(NjRecord) * (size_t)(world > 1 ? world : 1)));
     DPR_HIP(hipMalloc(&b.xpart, sizeof(double) * (size_t)((N + kThreads - 1) / kThreads + 1)));
     {
@@ -515,6 +540,7 @@ int nj_alloc(NjBuffers& b, int64_t N, int rank, int world)
 
 void nj_free(NjBuffers& b)
 {
+    njp_free(b.pr);
     void* ptrs[] = { b.D, b.U, b.Ur, b.KA, b.partials, b.recs, b.xpart, b.gath, b.slice, b.st,
                      b.tile_start, b.log_x, b.log_y, b.log_bx, b.log_by };
     for (void* p : ptrs)
@@ -555,31 +581,53 @@ int nj_prepare(NjBuffers& b, hipStream_t s)
     return DPR_OK;
 }
 
-int nj_launch_scan(NjBuffers& b, bool probe, hipStream_t s)
+// scan tuning knobs (dpr_scan_tune): row-group size, non-temporal loads, grid size
+static int g_scan_rg = 16, g_scan_nt = 1, g_scan_grid = 2048;
+void nj_scan_config(int rg, int nt, int grid) { g_scan_rg = rg; g_scan_nt = nt; g_scan_grid = grid; }
+int nj_scan_grid() { return g_scan_grid > 0 ? g_scan_grid : 2048; }
+
+template <bool PROBE>
+static void scan_dispatch(NjBuffers& b, int64_t n, int64_t it, hipStream_t s)
 {
-    const size_t lds = sizeof(int32_t) * (size_t)(b.nlrb + 1);
-    if (probe)
-        hipLaunchKernelGGL(nj_scan_kernel<true>, dim3(kScanBlocks), dim3(kThreads), lds, s, b.D, b.ld,
-                           b.st, b.Ur, b.KA, b.tile_start, b.nlrb, b.rank, b.world, b.partials);
-    else
-        hipLaunchKernelGGL(nj_scan_kernel<false>, dim3(kScanBlocks), dim3(kThreads), lds, s, b.D, b.ld,
-                           b.st, b.Ur, b.KA, b.tile_start, b.nlrb, b.rank, b.world, b.partials);
+    const int grid = nj_scan_grid();
+    const size_t lds = sizeof(int32_t) * (size_t)((b.N + kTileCols - 1) / kTileCols + 2);
+#define DPR_SCAN(RG, NT, FILT)                                                                                     \
+    hipLaunchKernelGGL((nj_scan_kernel<PROBE, RG, NT, FILT>), dim3(grid), dim3(kThreads), lds, s, b.D, b.ld, b.st, \
+                       b.U, b.Ur, b.Ur, b.KA, b.xpart, n, it, b.rank, b.world, b.partials)
+    const int rg = g_scan_rg & 127;
+    const bool filt = (g_scan_rg & 128) != 0;   // bit 7 of the row-group knob selects the filtered update
+    if (filt) {
+        if (g_scan_nt) { if (rg == 64) DPR_SCAN(64, true, true); else DPR_SCAN(16, true, true); }
+        else { if (rg == 64) DPR_SCAN(64, false, true); else DPR_SCAN(16, false, true); }
+    } else {
+        if (g_scan_nt) { if (rg == 64) DPR_SCAN(64, true, false); else DPR_SCAN(16, true, false); }
+        else { if (rg == 64) DPR_SCAN(64, false, false); else DPR_SCAN(16, false, false); }
+    }
+#undef DPR_SCAN
+}
+
+int nj_launch_scan(NjBuffers& b, bool probe, int64_t n, int64_t it, hipStream_t s)
+{
+    if (probe) scan_dispatch<true>(b, n, it, s); else scan_dispatch<false>(b, n, it, s);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
 
-// commit = true: world == 1, reduce + commit.  commit = false: local record only, written to
-// b.recs[b.rank] (all-gathered in place by the caller when world > 1).
-int nj_launch_select(NjBuffers& b, bool commit, hipStream_t s)
+// world == 1: select + commit + update in one kernel
+int nj_launch_post(NjBuffers& b, int64_t n, int64_t it, hipStream_t s)
 {
-    if (commit)
-        hipLaunchKernelGGL(nj_select_kernel<true>, dim3(1), dim3(kThreads), 0, s, b.D, b.ld, b.st, b.U,
-                           b.partials, kScanBlocks, b.rank, b.world, b.log_x, b.log_y, b.log_bx,
-                           b.log_by, b.recs + b.rank);
-    else
-        hipLaunchKernelGGL(nj_select_kernel<false>, dim3(1), dim3(kThreads), 0, s, b.D, b.ld, b.st, b.U,
-                           b.partials, kScanBlocks, b.rank, b.world, b.log_x, b.log_y, b.log_bx,
-                           b.log_by, b.recs + b.rank);
+    const unsigned grid = (unsigned)((n + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(nj_post_kernel, dim3(grid), dim3(kThreads), 0, s, b.D, b.ld, b.st, b.U, b.Ur, b.KA, b.xpart,
+                       b.partials, nj_scan_grid(), n, it, b.log_x, b.log_y, b.log_bx, b.log_by);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+// local record of this rank -> b.recs[b.rank]
+int nj_launch_select_local(NjBuffers& b, int nparts, hipStream_t s)
+{
+    hipLaunchKernelGGL(nj_select_local_kernel, dim3(1), dim3(kThreads), 0, s, b.st, b.partials, nparts,
+                       b.recs + b.rank);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
@@ -592,42 +640,29 @@ int nj_launch_unpack_u(NjBuffers& b, hipStream_t s)
     return DPR_OK;
 }
 
-int nj_launch_commit(NjBuffers& b, hipStream_t s)
+// world > 1: reduce b.recs[world], commit, extract the column slices of x, y, n-1
+int nj_launch_commit_extract(NjBuffers& b, int64_t n, int64_t it, hipStream_t s)
 {
-    hipLaunchKernelGGL(nj_commit_kernel, dim3(1), dim3(64), 0, s, b.st, b.U, b.recs, b.world, b.log_x, b.log_y,
-                       b.log_bx, b.log_by);
+    const int64_t rows = b.rows_local > 0 ? b.rows_local : 1;
+    const unsigned grid = (unsigned)((rows + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(nj_commit_extract_kernel, dim3(grid), dim3(kThreads), 0, s, b.D, b.ld, b.st, b.U, b.recs,
+                       b.slice, b.slice_len, b.rows_local, n, it, b.rank, b.world, b.log_x, b.log_y, b.log_bx, b.log_by);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
 
-int nj_launch_extract(NjBuffers& b, hipStream_t s)
+int nj_launch_update_sharded(NjBuffers& b, int64_t n, hipStream_t s)
 {
-    if (b.rows_local == 0) return DPR_OK;
-    const unsigned grid = (unsigned)((b.rows_local + kThreads - 1) / kThreads);
-    hipLaunchKernelGGL(nj_extract_kernel, dim3(grid), dim3(kThreads), 0, s, b.D, b.ld, b.st, b.slice, b.slice_len,
-                       b.rows_local, b.rank, b.world);
+    const unsigned grid = (unsigned)((n + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(nj_update_sharded_kernel, dim3(grid), dim3(kThreads), 0, s, b.D, b.ld, b.st, b.U, b.Ur, b.KA,
+                       b.xpart, b.gath, b.slice_len, n, b.rank, b.world);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
 
-int nj_launch_update(NjBuffers& b, hipStream_t s)
+int nj_launch_finish(NjBuffers& b, int64_t n, int64_t it, hipStream_t s)
 {
-    const unsigned grid = (unsigned)((b.N + kThreads - 1) / kThreads);
-    if (b.world > 1) {
-        hipLaunchKernelGGL(nj_update_sharded_kernel, dim3(grid), dim3(kThreads), 0, s, b.D, b.ld, b.st, b.U, b.Ur,
-                           b.KA, b.xpart, b.gath, b.slice_len, b.rank, b.world);
-        DPR_HIP(hipGetLastError());
-        return DPR_OK;
-    }
-    hipLaunchKernelGGL(nj_update_kernel, dim3(grid), dim3(kThreads), 0, s, b.D, b.ld, b.st, b.U, b.Ur,
-                       b.KA, b.xpart);
-    DPR_HIP(hipGetLastError());
-    return DPR_OK;
-}
-
-int nj_launch_finalize(NjBuffers& b, hipStream_t s)
-{
-    hipLaunchKernelGGL(nj_finalize_kernel, dim3(1), dim3(kThreads), 0, s, b.st, b.U, b.Ur, b.xpart);
+    hipLaunchKernelGGL(nj_finish_kernel, dim3(1), dim3(kThreads), 0, s, b.st, b.U, b.Ur, b.xpart, n, it);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }

@@ -1,0 +1,111 @@
+// Device helpers shared by the NJ translation units (nj.hip: streaming path, njp.hip: pruned path).
+#pragma once
+#include "dpr_internal.hpp"
+
+namespace dpr {
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void best_update(double& bq, uint64_t& bk, double q, uint64_t k)
+{
+    // strict '<' on q (NaN never wins), ties resolved by the reference's visiting order (key)
+    const bool take = (q < bq) | ((q == bq) & (k < bk));
+    bq = take ? q : bq;
+    bk = take ? k : bk;
+}
+
+__device__ __forceinline__ void wave_best(double& bq, uint64_t& bk)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oq = __shfl_down(bq, off, 64);
+        const uint64_t ok = __shfl_down((unsigned long long)bk, off, 64);
+        best_update(bq, bk, oq, ok);
+    }
+}
+
+// block-wide (256 threads) lexicographic minimum; result valid in thread 0
+__device__ __forceinline__ void block_best(double& bq, uint64_t& bk, double* sq, uint64_t* sk)
+{
+    wave_best(bq, bk);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sq[w] = bq; sk[w] = bk; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 1; i < kThreads / 64; ++i) best_update(bq, bk, sq[i], sk[i]);
+    }
+}
+
+// pairwise tree over 256 values, c[t] += c[t+s] for s = 128..1 (canonical order)
+__device__ __forceinline__ double block_tree256(double v, double* s)
+{
+    const int t = threadIdx.x;
+    s[t] = v;
+    __syncthreads();
+#pragma unroll
+    for (int st = 128; st > 0; st >>= 1) {
+        if (t < st) s[t] = s[t] + s[t + st];
+        __syncthreads();
+    }
+    return s[0];
+}
+
+// canonical U[x] from the chunk partials of the previous update (n_prev = n + 1 slots)
+__device__ __forceinline__ double finish_ux(const double* __restrict__ xpart, int64_t n_prev, double* s)
+{
+    const int64_t nchunk = (n_prev + kThreads - 1) / kThreads;
+    double acc = 0.0;
+    for (int64_t c = threadIdx.x; c < nchunk; c += kThreads) acc += xpart[c];
+    return block_tree256(acc, s);
+}
+
+// block-wide reduction of `cnt` records to the winner (q, key, d); result in every thread
+__device__ __forceinline__ void reduce_records(const NjRecord* __restrict__ recs, int cnt, double& bq,
+                                               uint64_t& bk, double& bd, double* sq, uint64_t* sk,
+                                               double* sdd)
+{
+    bq = 10000.0; bk = ~0ull; bd = 0.0;
+    for (int i = threadIdx.x; i < cnt; i += kThreads) {
+        const double q = recs[i].q;
+        const uint64_t k = recs[i].key;
+        if ((q < bq) | ((q == bq) & (k < bk))) { bq = q; bk = k; bd = recs[i].d; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oq = __shfl_down(bq, off, 64);
+        const uint64_t ok = __shfl_down((unsigned long long)bk, off, 64);
+        const double od = __shfl_down(bd, off, 64);
+        if ((oq < bq) | ((oq == bq) & (ok < bk))) { bq = oq; bk = ok; bd = od; }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sq[w] = bq; sk[w] = bk; sdd[w] = bd; }
+    __syncthreads();
+    bq = sq[0]; bk = sk[0]; bd = sdd[0];
+#pragma unroll
+    for (int i = 1; i < kThreads / 64; ++i)
+        if ((sq[i] < bq) | ((sq[i] == bq) & (sk[i] < bk))) { bq = sq[i]; bk = sk[i]; bd = sdd[i]; }
+    __syncthreads();
+}
+
+// host part of the reference's loop (src/neighborJoining.cu:219-239): branch lengths, merge log, state
+__device__ __forceinline__ void commit_merge(NjState* __restrict__ st, const double* __restrict__ U,
+                                             int64_t n, int64_t it, int64_t x, int64_t y, double d, double q,
+                                             int32_t* __restrict__ log_x, int32_t* __restrict__ log_y,
+                                             double* __restrict__ log_bx, double* __restrict__ log_by)
+{
+    const double r = (double)(n - 2);
+    double blX = (d + U[x] / r - U[y] / r) * 0.5;
+    double blY = d - blX;
+    if (blX < 0) { blY += blX; blX = 0; }
+    if (blY < 0) { blX += blY; blY = 0; }
+    log_x[it] = (int32_t)x; log_y[it] = (int32_t)y; log_bx[it] = blX; log_by[it] = blY;
+    st->x = (int32_t)x; st->y = (int32_t)y; st->d = d; st->q = q;
+    st->n = n - 1; st->it = it + 1;
+}
+
+
+}  // namespace dpr

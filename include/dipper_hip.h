@@ -131,6 +131,21 @@ int64_t dpr_nj_run(dpr_ctx *ctx, int64_t max_iters, int32_t *merge_x, int32_t *m
 int dpr_argmin_once(dpr_ctx *ctx, int reps, int32_t *out_i, int32_t *out_j, double *out_q,
                     float *out_ms_per_scan);
 
+/* NJ algorithm on a single GPU: 1 = exact pruned scan (default), 0 = full streaming scan every
+ * iteration.  Both produce the same merge log bit for bit (tests run both); takes effect at the next
+ * dpr_dist_matrix.  Environment DPR_NJ_MODE=stream selects 0 for the CLI. */
+int dpr_set_nj_mode(int mode);
+/* pruned path: 16x512 units scanned since dpr_dist_matrix, and units of one full scan */
+int dpr_get_prune_stats(dpr_ctx *ctx, uint64_t *units_scanned, uint64_t *units_per_full_scan);
+
+/* tuning knobs of the Q-argmin scan (process-wide): rows per work unit (16/32/64), non-temporal
+ * loads (0/1), grid size (0 = default, <= 2048).  Results never depend on them. */
+int dpr_scan_tune(int rows_per_unit, int nontemporal, int grid);
+
+/* calibration: plain streaming read (16 B/lane, optional non-temporal) of `bytes` of the matrix
+ * buffer; average milliseconds per pass.  Gives the read ceiling the scan is compared with. */
+int dpr_bw_probe(dpr_ctx *ctx, int64_t bytes, int nontemporal, int grid, int reps, float *out_ms);
+
 /* ---- test hooks ------------------------------------------------------------------------------*/
 int64_t dpr_n_active(dpr_ctx *ctx);
 int64_t dpr_n_total(dpr_ctx *ctx);

@@ -7,12 +7,16 @@ from tests import _util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def gpu():
+@pytest.fixture(scope="module", params=[1, 0], ids=["pruned", "stream"])
+def gpu(request):
+    """Every test runs on both single-GPU NJ algorithms: exact pruned scan and full streaming scan."""
     import dipper_amd
+    from dipper_amd import capi
+    capi.set_nj_mode(request.param)
     d = dipper_amd.Dipper(0)
     yield d
     d.close()
+    capi.set_nj_mode(1)
 
 
 def _check_nj(gpu, orc, D):
