@@ -133,11 +133,6 @@ static int nj_iteration(dpr_ctx* c, int64_t n, int64_t it)
 {
     if (c->world == 1) {
         NjBuffers& b = c->nj[0];
-        if (b.pr.active) {
-            if (int rc = njp_launch_scan(b, false, c->stream)) return rc;
-            if (int rc = njp_launch_post(b, n, it, c->stream)) return rc;
-            return njp_launch_bounds(b, n - 1, it + 1, c->stream);
-        }
         if (int rc = nj_launch_scan(b, false, n, it, c->stream)) return rc;
         return nj_launch_post(b, n, it, c->stream);
     }
@@ -450,7 +445,6 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
         if (int rc = nj_prepare(b, c->stream)) return rc;
     if (c->world == 1 && want_pruned() && n >= 3) {
         if (int rc = njp_build(c->nj[0], c->stream)) return rc;
-        if (int rc = njp_launch_bounds(c->nj[0], n, 0, c->stream)) return rc;
     }
     DPR_HIP(hipEventRecord(c->ev[1], c->stream));
     DPR_HIP(hipStreamSynchronize(c->stream));
@@ -482,8 +476,12 @@ int64_t dpr_nj_run(dpr_ctx* c, int64_t max_iters, int32_t* merge_x, int32_t* mer
     if (max_iters >= 0 && max_iters < todo) todo = max_iters;
     const int64_t it0 = st.it;
     DPR_HIP(hipEventRecord(c->ev[2], c->stream));
-    for (int64_t k = 0; k < todo; ++k)
-        if (int rc = nj_iteration(c, st.n - k, it0 + k)) return rc;
+    if (c->world == 1 && c->nj[0].pr.active) {
+        if (int rc = njp_run(c->nj[0], it0, todo, c->stream)) return rc;
+    } else {
+        for (int64_t k = 0; k < todo; ++k)
+            if (int rc = nj_iteration(c, st.n - k, it0 + k)) return rc;
+    }
     for (auto& b : c->nj)
         if (!b.pr.active)
             if (int rc = nj_launch_finish(b, st.n - todo, it0 + todo, c->stream)) return rc;
@@ -532,8 +530,10 @@ int dpr_argmin_once(dpr_ctx* c, int reps, int32_t* out_i, int32_t* out_j, double
     if (reps < 1) reps = 1;
     NjState st0;
     if (int rc = fetch_state(c, &st0)) return rc;
+    // pruned mode: the streaming kernel runs over the position-space matrix (all P positions, dead
+    // ones carry NaN row sums); it = 0 because the bounds kernel already finished U[x]
     auto probe = [&](NjBuffers& b) -> int {
-        return b.pr.active ? njp_launch_scan(b, true, c->stream) : nj_launch_scan(b, true, st0.n, st0.it, c->stream);
+        return b.pr.active ? nj_launch_scan(b, true, b.pr.P, 0, c->stream) : nj_launch_scan(b, true, st0.n, st0.it, c->stream);
     };
     for (auto& b : c->nj)
         if (int rc = probe(b)) return rc;  // warm
@@ -543,7 +543,7 @@ int dpr_argmin_once(dpr_ctx* c, int reps, int32_t* out_i, int32_t* out_j, double
             if (int rc = probe(b)) return rc;
     DPR_HIP(hipEventRecord(c->ev[3], c->stream));
     for (auto& b : c->nj)
-        if (int rc = nj_launch_select_local(b, b.pr.active ? njp_scan_grid() : nj_scan_grid(), c->stream)) return rc;
+        if (int rc = nj_launch_select_local(b, nj_scan_grid(), c->stream)) return rc;
     if (int rc = exchange(c, EX_RECS)) return rc;
     std::vector<NjRecord> recs((size_t)c->world);
     DPR_HIP(hipMemcpyAsync(recs.data(), c->nj[0].recs, sizeof(NjRecord) * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
@@ -572,8 +572,53 @@ int dpr_set_nj_mode(int mode)
 int dpr_get_prune_stats(dpr_ctx* c, uint64_t* units_scanned, uint64_t* units_per_full_scan)
 {
     if (!c || !c->have_matrix || !c->nj[0].pr.active) { set_error("dpr_get_prune_stats: pruned path not active"); return DPR_ERR_STATE; }
-    if (units_scanned) DPR_HIP(hipMemcpy(units_scanned, c->nj[0].pr.counters, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    NjState st;
+    if (int rc = fetch_state(c, &st)) return rc;
+    if (units_scanned) *units_scanned = st.units_scanned;
     if (units_per_full_scan) *units_per_full_scan = (uint64_t)c->nj[0].pr.utot;
+    return DPR_OK;
+}
+
+// debug (DPR_NJ_ITERSTATS=1): per iteration [units scanned, max units of one block]
+int dpr_get_iterstats(dpr_ctx* c, uint64_t* out, int64_t iters)
+{
+    if (!c || !c->have_matrix || !c->nj[0].pr.iterstats) { set_error("dpr_get_iterstats: not enabled"); return DPR_ERR_STATE; }
+    DPR_HIP(hipMemcpy(out, c->nj[0].pr.iterstats, sizeof(uint64_t) * (size_t)(2 * iters), hipMemcpyDeviceToHost));
+    return DPR_OK;
+}
+
+// microbenchmark: wall time per launch of a chain of trivial dependent kernels (eager or graph replay)
+__global__ void dpr_nop_kernel(unsigned long long* p) { if (threadIdx.x == 0 && blockIdx.x == 0 && p[7] == 12345) p[6] = 1; }
+
+int dpr_launch_bench(dpr_ctx* c, int nlaunch, int grid, int use_graph, float* us_per_launch)
+{
+    if (!c || nlaunch < 1 || grid < 1 || !us_per_launch) { set_error("dpr_launch_bench: bad argument"); return DPR_ERR_ARG; }
+    DPR_HIP(hipSetDevice(c->device));
+    unsigned long long* buf = nullptr;
+    DPR_HIP(hipMalloc(&buf, 64));
+    DPR_HIP(hipMemset(buf, 0, 64));
+    hipGraphExec_t ge = nullptr;
+    const int per = 128;
+    if (use_graph) {
+        hipGraph_t g = nullptr;
+        DPR_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        for (int k = 0; k < per; ++k) hipLaunchKernelGGL(dpr_nop_kernel, dim3(grid), dim3(256), 0, c->stream, buf);
+        DPR_HIP(hipStreamEndCapture(c->stream, &g));
+        DPR_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        DPR_HIP(hipGraphDestroy(g));
+    }
+    DPR_HIP(hipStreamSynchronize(c->stream));
+    DPR_HIP(hipEventRecord(c->ev[2], c->stream));
+    int done = 0;
+    if (use_graph) for (; done + per <= nlaunch; done += per) DPR_HIP(hipGraphLaunch(ge, c->stream));
+    for (; done < nlaunch; ++done) hipLaunchKernelGGL(dpr_nop_kernel, dim3(grid), dim3(256), 0, c->stream, buf);
+    DPR_HIP(hipEventRecord(c->ev[3], c->stream));
+    DPR_HIP(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    DPR_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+    *us_per_launch = ms * 1e3f / (float)nlaunch;
+    if (ge) (void)hipGraphExecDestroy(ge);
+    (void)hipFree(buf);
     return DPR_OK;
 }
 

@@ -75,7 +75,14 @@ struct NjState {
     double d;        // D[x][y]
     double q;        // winning Q value
     int32_t status;  // 0 ok, 1 = no candidate (DPR_ERR_NOCAND)
-    int32_t pad;
+    int32_t pad;     // pruned path: position of the node created by the last merge
+    // pruned path (graph-replayed kernels read their iteration from memory): `it` is advanced by the
+    // post kernel, `itb` by the bounds kernel; a kernel only reads the counter that is stable while it runs
+    int64_t itb;
+    int64_t it_limit;  // iterations >= it_limit are no-ops
+    int64_t N;         // tips
+    unsigned long long cnt_list[2];   // units listed for the scan of parity it & 1
+    unsigned long long units_scanned; // statistics
 };
 
 // position-space state of the pruned path (njp.hip)
@@ -90,6 +97,11 @@ struct NjPruned {
     int64_t nunits_alloc = 0, utot = 0;
     double *gmax = nullptr, *bmax = nullptr;   // max Ur per 16 / 256 positions
     uint64_t *seed = nullptr, *counters = nullptr;
+    hipGraphExec_t graph = nullptr;   // kGraphIters iterations of (test, scan, post, bounds)
+    int32_t* list = nullptr;         // units selected by the prep kernel (strip << 20 | group)
+    int32_t *blk_cb = nullptr, *blk_g0 = nullptr;   // prep block -> (strip, first group)
+    int nprep = 0;
+    uint64_t* iterstats = nullptr;   // optional (DPR_NJ_ITERSTATS): per iteration units scanned, max per block
 };
 
 struct NjBuffers {
@@ -138,9 +150,7 @@ int nj_launch_finish(NjBuffers& b, int64_t n, int64_t it, hipStream_t s);       
 int njp_build(NjBuffers& b, hipStream_t s);   // permute the tip-order matrix by ascending row sum; frees b.D
 void njp_free(NjPruned& q);
 int njp_scan_grid();
-int njp_launch_bounds(NjBuffers& b, int64_t n, int64_t it, hipStream_t s);
-int njp_launch_scan(NjBuffers& b, bool full, hipStream_t s);
-int njp_launch_post(NjBuffers& b, int64_t n, int64_t it, hipStream_t s);
+int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s);   // enqueue `todo` iterations (hipGraph replays)
 
 // msa.hip
 struct MsaBuffers {

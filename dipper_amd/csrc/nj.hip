@@ -62,6 +62,8 @@ __global__ __launch_bounds__(kThreads) void nj_row_sums_kernel(const double* __r
 __global__ void nj_state_init_kernel(NjState* st, int64_t N)
 {
     st->n = N; st->it = 0; st->x = 0; st->y = 0; st->d = 0.0; st->q = 0.0; st->status = 0; st->pad = 0;
+    st->itb = 0; st->it_limit = 0; st->N = N;
+    st->cnt_list[0] = 0; st->cnt_list[1] = 0; st->units_scanned = 0;
 }
 
 // Ur[i] = U[i]/(n-2) (plain division, src/neighborJoining.cu:130,137) and the i-part of the key
@@ -96,7 +98,8 @@ __global__ __launch_bounds__(kThreads) void nj_prepare_kernel(const NjState* __r
 template <bool DIAG, bool NT, bool FILT>
 __device__ __forceinline__ void scan_rows(const double* __restrict__ D, int64_t ld,
                                           const double* __restrict__ Ur,
-                                          const uint64_t* __restrict__ KA, int64_t a0, int64_t l0,
+                                          const uint64_t* __restrict__ KA, const uint64_t* __restrict__ KB,
+                                          int64_t a0, int64_t l0,
                                           int nrows, int64_t c0, int64_t xprev, double urx, double ub0,
                                           double ub1, uint64_t ka0, uint64_t ka1, uint64_t kb0,
                                           uint64_t kb1, double& bq, uint64_t& bk)
@@ -119,7 +122,7 @@ __device__ __forceinline__ void scan_rows(const double* __restrict__ D, int64_t 
             const int64_t a = a0 + min(r + u, nrows - 1);
             const double ua = (a == xprev) ? urx : Ur[a];
             const uint64_t kaa = KA[a];
-            const uint64_t kba = nj_key_b(a);
+            const uint64_t kba = KB ? KB[a] : nj_key_b(a);   // position-space matrices carry their slot keys
             double d0 = v[u].x, d1 = v[u].y;
             if (DIAG) {
                 d0 = (b0 < a) ? d0 : __builtin_nan("");
@@ -156,6 +159,7 @@ template <bool PROBE, int RG, bool NT, bool FILT>
 __global__ __launch_bounds__(kThreads) void nj_scan_kernel(
     const double* __restrict__ D, int64_t ld, const NjState* __restrict__ st, double* __restrict__ U_w,
     double* __restrict__ Ur_w, const double* __restrict__ Ur, const uint64_t* __restrict__ KA,
+    const uint64_t* __restrict__ KB, const int32_t* __restrict__ pos_of_slot,
     const double* __restrict__ xpart, int64_t n, int64_t it, int rank, int world,
     NjRecord* __restrict__ partials)
 {
@@ -234,16 +238,17 @@ __global__ __launch_bounds__(kThreads) void nj_scan_kernel(
                 ub0 = (b0 == xprev) ? urx : Ur[b0];
                 ub1 = (b0 + 1 == xprev) ? urx : Ur[b0 + 1];
                 ka0 = KA[b0]; ka1 = KA[b0 + 1];
-                kb0 = nj_key_b(b0); kb1 = nj_key_b(b0 + 1);
+                kb0 = KB ? KB[b0] : nj_key_b(b0);
+                kb1 = KB ? KB[b0 + 1] : nj_key_b(b0 + 1);
                 fresh = false;
             }
             const int64_t l0 = lstart + (int64_t)g * RG;
             const int nrows = (int)min((int64_t)RG, nloc - l0);
             const int64_t a0 = shard_global_row(l0, rank, world);
             if (a0 < c0 + kTileCols)
-                scan_rows<true, NT, FILT>(D, ld, Ur, KA, a0, l0, nrows, c0, xprev, urx, ub0, ub1, ka0, ka1, kb0, kb1, bq, bk);
+                scan_rows<true, NT, FILT>(D, ld, Ur, KA, KB, a0, l0, nrows, c0, xprev, urx, ub0, ub1, ka0, ka1, kb0, kb1, bq, bk);
             else
-                scan_rows<false, NT, FILT>(D, ld, Ur, KA, a0, l0, nrows, c0, xprev, urx, ub0, ub1, ka0, ka1, kb0, kb1, bq, bk);
+                scan_rows<false, NT, FILT>(D, ld, Ur, KA, KB, a0, l0, nrows, c0, xprev, urx, ub0, ub1, ka0, ka1, kb0, kb1, bq, bk);
             ++g;
         }
     }
@@ -255,7 +260,12 @@ __global__ __launch_bounds__(kThreads) void nj_scan_kernel(
         if (bk != ~0ull) {
             // d = D[max][min]: the block only visited owned rows a > b, so the row is local
             const int64_t i = (int64_t)(bk & 0xFFFFFFull), j = (int64_t)((bk >> 24) & 0xFFFFFFull);
-            const int64_t x = i < j ? i : j, y = i < j ? j : i;
+            int64_t x = i < j ? i : j, y = i < j ? j : i;
+            if (pos_of_slot) {   // position space (single GPU): keys hold slots, the matrix is indexed by position
+                const int64_t pi = pos_of_slot[i], pj = pos_of_slot[j];
+                x = pi < pj ? pi : pj; y = pi < pj ? pj : pi;
+                rec.pad = (uint64_t)y | ((uint64_t)x << 32);
+            }
             rec.d = D[shard_local_row(y, world) * ld + x];
         }
         partials[blockIdx.x] = rec;
@@ -265,8 +275,10 @@ __global__ __launch_bounds__(kThreads) void nj_scan_kernel(
 // local winner of this rank -> recs[rank] (all-gathered when world > 1; read by the host for probes)
 __global__ __launch_bounds__(kThreads) void nj_select_local_kernel(const NjState* __restrict__ st,
                                                                    const NjRecord* __restrict__ partials,
-                                                                   int nparts, NjRecord* __restrict__ out)
+                                                                   int nparts, const unsigned long long* __restrict__ nparts_dev,
+                                                                   NjRecord* __restrict__ out)
 {
+    if (nparts < 0) nparts = (int)nparts_dev[st->it & 1];   // pruned path: records published by the last scan
     __shared__ double sq[kThreads / 64], sdd[kThreads / 64];
     __shared__ uint64_t sk[kThreads / 64];
     double bq, bd; uint64_t bk;
@@ -591,9 +603,16 @@ static void scan_dispatch(NjBuffers& b, int64_t n, int64_t it, hipStream_t s)
 {
     const int grid = nj_scan_grid();
     const size_t lds = sizeof(int32_t) * (size_t)((b.N + kTileCols - 1) / kTileCols + 2);
+    // pruned mode keeps the matrix in position space with explicit slot keys (probe only)
+    const NjPruned& q = b.pr;
+    const double* D = q.active ? q.D : b.D;
+    const int64_t ld = q.active ? q.ld : b.ld;
+    double *U = q.active ? q.U : b.U, *Ur = q.active ? q.Ur : b.Ur;
+    const uint64_t *KA = q.active ? q.KA : b.KA, *KB = q.active ? q.KB : nullptr;
+    const int32_t* pos = q.active ? q.pos_of_slot : nullptr;
 #define DPR_SCAN(RG, NT, FILT)                                                                                     \
-    hipLaunchKernelGGL((nj_scan_kernel<PROBE, RG, NT, FILT>), dim3(grid), dim3(kThreads), lds, s, b.D, b.ld, b.st, \
-                       b.U, b.Ur, b.Ur, b.KA, b.xpart, n, it, b.rank, b.world, b.partials)
+    hipLaunchKernelGGL((nj_scan_kernel<PROBE, RG, NT, FILT>), dim3(grid), dim3(kThreads), lds, s, D, ld, b.st,     \
+                       U, Ur, Ur, KA, KB, pos, b.xpart, n, it, b.rank, b.world, b.partials)
     const int rg = g_scan_rg & 127;
     const bool filt = (g_scan_rg & 128) != 0;   // bit 7 of the row-group knob selects the filtered update
     if (filt) {
@@ -627,7 +646,7 @@ int nj_launch_post(NjBuffers& b, int64_t n, int64_t it, hipStream_t s)
 int nj_launch_select_local(NjBuffers& b, int nparts, hipStream_t s)
 {
     hipLaunchKernelGGL(nj_select_local_kernel, dim3(1), dim3(kThreads), 0, s, b.st, b.partials, nparts,
-                       b.recs + b.rank);
+                       (const unsigned long long*)(b.pr.counters ? b.pr.counters + 1 : nullptr), b.recs + b.rank);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }

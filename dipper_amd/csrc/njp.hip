@@ -15,12 +15,15 @@
 //    skipped.  Sorting by row sum makes Ur homogeneous inside units, which is what makes the bound
 //    tight.
 //
-// Per iteration: njp_post_kernel (select + merge + update, indexed by reference slot so that the
-// canonical U[x] summation order is unchanged) -> njp_bounds_kernel (finish U[x], group maxima,
-// seed bound) -> njp_scan_kernel (test all units, scan survivors, refresh their umin).
+// Per iteration: njp_scan_kernel (scan the listed units, refresh their umin) -> njp_post_kernel
+// (select + merge + update, indexed by reference slot so that the canonical U[x] summation order is
+// unchanged) -> njp_prep_kernel (finish U[x], seed bound, test every unit, list the survivors).
+// The kernels take no per-iteration arguments (they read the iteration index from the device
+// state), so 32 iterations are captured into one hipGraph and replayed.
 #include "nj_dev.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 
 namespace dpr {
@@ -96,66 +99,7 @@ __global__ void njp_fill_u64_kernel(uint64_t* __restrict__ a, int64_t cnt, uint6
 }
 
 // ------------------------------------------------------------------------------------------------
-// bounds: finish U[px] (canonical sum of the chunk partials), per-16-row and per-256 maxima of Ur,
-// seed bound = best current q among the previous iteration's per-block winners (positions in pad)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void njp_bounds_kernel(const double* __restrict__ D, int64_t ld,
-                                                              const NjState* __restrict__ st, double* __restrict__ U,
-                                                              double* __restrict__ Ur, const double* __restrict__ xpart,
-                                                              const NjRecord* __restrict__ partials, int nparts,
-                                                              int64_t P, int64_t n, int64_t it,
-                                                              double* __restrict__ gmax, double* __restrict__ bmax,
-                                                              unsigned long long* __restrict__ seed)
-{
-    __shared__ double s[kThreads];
-    __shared__ double smx[kThreads / 64];
-    if (st->status != 0) return;
-    int64_t px = -1;
-    double ux = 0.0, urx = 0.0;
-    if (it > 0) {
-        px = st->pad;  // position of the node created by the previous merge
-        ux = finish_ux(xpart, n + 1, s);
-        urx = ux / (double)(n - 2);
-    }
-    const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    double ur = -__builtin_inf();
-    if (p < P) {
-        double v = (p == px) ? urx : Ur[p];
-        if (p == px) { U[p] = ux; Ur[p] = urx; }
-        if (v == v) ur = v;  // dead positions carry NaN
-    }
-    double m = ur;
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 15) == 0 && p < P) gmax[p / kUR] = m;
-#pragma unroll
-    for (int off = 32; off >= 16; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0) smx[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) bmax[blockIdx.x] = fmax(fmax(smx[0], smx[1]), fmax(smx[2], smx[3]));
-
-    // seed: one candidate per thread
-    const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    double q = __builtin_inf();
-    if (t < nparts && partials[t].key != ~0ull) {
-        const uint64_t pp = partials[t].pad;
-        const int64_t pa = (int64_t)(pp & 0xffffffffull), pb = (int64_t)(pp >> 32);  // pa > pb
-        if (pa < P && pb < pa) {
-        const double ua = (pa == px) ? urx : Ur[pa], ub = (pb == px) ? urx : Ur[pb];
-        const double d = D[pa * ld + pb];
-        const double q1 = (d - ua) - ub, q2 = (d - ub) - ua;
-        q = fmin(q1, q2);        // NaN (dead) and inf drop out
-        if (!(q == q)) q = __builtin_inf();
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) q = fmin(q, __shfl_xor(q, off, 64));
-    if ((threadIdx.x & 63) == 0 && q < __builtin_inf()) atomicMin(seed, (unsigned long long)enc_f64(q));
-}
-
-// ------------------------------------------------------------------------------------------------
-// pruned scan.  Linear valid-unit index t -> (strip cb, group g); block b handles t = b, b+G, ...
-// (interleaved, so that clustered survivors spread over the grid).
+// Linear valid-unit index t -> (strip cb, group g)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void unit_of(int64_t t, int64_t G16, int& cb, int64_t& g)
 {
@@ -169,122 +113,226 @@ __device__ __forceinline__ void unit_of(int64_t t, int64_t G16, int& cb, int64_t
     g = 32 * (int64_t)lo + (t - unit_prefix(lo, G16));
 }
 
-template <bool FULL>
-__global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __restrict__ D, int64_t ld,
-                                                            const NjState* __restrict__ st,
-                                                            const double* __restrict__ Ur,
-                                                            const uint64_t* __restrict__ KA,
-                                                            const uint64_t* __restrict__ KB,
-                                                            const int32_t* __restrict__ pos_of_slot,
-                                                            unsigned long long* __restrict__ umin,
-                                                            const double* __restrict__ gmax,
-                                                            const double* __restrict__ bmax,
-                                                            const unsigned long long* __restrict__ seed,
-                                                            int64_t P, int64_t utot,
-                                                            NjRecord* __restrict__ partials,
-                                                            unsigned long long* __restrict__ counters)
+// Latency is what matters in these three kernels (a few hundred KB of data per iteration): every
+// kernel issues all of its global loads up front, in as few dependent hops as possible.
+//
+// prep = finish U[px] + seed bound + unit tests, one lane per valid unit.  Every block derives what
+// it needs -- the new node's row sum, the bound, the maxima of Ur over its units' rows and strips --
+// directly from Ur, so no cross-block hand-off is needed.  Runs after post(it-1); `it` = st->it is
+// stable while it runs.  It publishes st->itb = it, the iteration index the following scan/post
+// kernels read (they must not read st->it, which the post kernel advances while it runs).
+// For it >= it_limit only U[px] is materialised (no list).
+__global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __restrict__ D, int64_t ld,
+                                                            NjState* __restrict__ st, double* __restrict__ U_w,
+                                                            double* __restrict__ Ur_w, const double* __restrict__ Ur,
+                                                            const double* __restrict__ xpart,
+                                                            const NjRecord* __restrict__ partials,
+                                                            const unsigned long long* __restrict__ umin,
+                                                            int64_t P, const int32_t* __restrict__ blk_cb,
+                                                            const int32_t* __restrict__ blk_g0, int scan_grid,
+                                                            int32_t* __restrict__ list)
 {
-    __shared__ int32_t s_list[kThreads];
-    __shared__ int32_t s_cnt;
-    __shared__ double sq[kThreads / 64];
-    __shared__ uint64_t sk[kThreads / 64];
-    __shared__ double smin[kThreads / 64];
-
+    __shared__ double s[kThreads];
+    __shared__ double sseed[kThreads / 64];
+    __shared__ double scm[kThreads / 64];
     const int tid = threadIdx.x;
-    const int64_t G16 = (P + kUR - 1) / kUR;
-    const int64_t nb256 = (P + kThreads - 1) / kThreads;
-    double bq = 10000.0;  // the reference's init value
-    uint64_t bk = ~0ull;
-    const bool dead = st->status != 0;
-    const unsigned long long seedv = *seed;
-    const double bound = (FULL || seedv == ~0ull) ? __builtin_inf() : dec_f64(seedv);
-    unsigned long long scanned = 0;
+    // hop 1: the state line and this block's (strip, first group): blocks never span strips
+    const int cb = blk_cb[blockIdx.x];
+    const int64_t g = (int64_t)blk_g0[blockIdx.x] + tid;
+    const int64_t it = st->it, limit = st->it_limit, N = st->N;
+    const int64_t px = it > 0 ? (int64_t)st->pad : -1;
+    const unsigned long long nlist_prev = it > 0 ? st->cnt_list[(it - 1) & 1] : 0ull;
+    if (st->status != 0) return;
+    const bool beyond = it >= limit;
+    if (blockIdx.x == 0 && tid == 0) st->itb = it;            // never read by this kernel
+    if (beyond && (blockIdx.x != 0 || it == 0)) return;       // only block 0 materialises U[px]
+    const int64_t n = N - it;
+    const double NINF = -__builtin_inf(), PINF = __builtin_inf();
 
-    for (int64_t base = blockIdx.x; base < utot && !dead; base += (int64_t)gridDim.x * kThreads) {
-        // ---- test up to 256 units of this block, one per lane
-        const int64_t t = base + (int64_t)tid * gridDim.x;
-        bool keep = false;
-        if (t < utot) {
-            int cb; int64_t g;
-            unit_of(t, G16, cb, g);
-            const double u = dec_f64(umin[(int64_t)cb * G16 + g]);
-            const double rm = gmax[g];
-            const int64_t b2 = 2 * (int64_t)cb;
-            const double cm = fmax(bmax[b2], b2 + 1 < nb256 ? bmax[b2 + 1] : -__builtin_inf());
-            const double lb = fmin((u - rm) - cm, (u - cm) - rm);
-            keep = FULL ? (rm > -__builtin_inf() && cm > -__builtin_inf()) : (lb <= bound);
+    // hop 2: every independent load of this block
+    const int64_t nchunk = it > 0 ? (n + 1 + kThreads - 1) / kThreads : 0;
+    double acc = 0.0;
+    for (int64_t c = tid; c < nchunk; c += kThreads) acc += xpart[c];       // chunk sums of U[px]
+    const int64_t nrec = (int64_t)(nlist_prev < (unsigned long long)scan_grid ? nlist_prev : (unsigned long long)scan_grid);
+    NjRecord cand; cand.key = ~0ull; cand.pad = 0; cand.q = 0; cand.d = 0;
+    if (!beyond && tid < nrec) cand = partials[tid];                         // seed candidates (first 256)
+    const int64_t G16 = (P + kUR - 1) / kUR;
+    const bool have = !beyond && g < G16;
+    double uenc_d = PINF;
+    double rmax = NINF; bool px_in_group = false;
+    if (have) {
+        uenc_d = dec_f64(umin[(int64_t)cb * G16 + g]);
+        const int64_t a0 = g * kUR;
+#pragma unroll
+        for (int r = 0; r < kUR; ++r) {
+            const int64_t p = a0 + r;
+            if (p == px) px_in_group = true;
+            else if (p < P) { const double v = Ur[p]; if (v == v) rmax = fmax(rmax, v); }
         }
-        if (tid == 0) s_cnt = 0;
-        __syncthreads();
-        if (keep) { const int slot = atomicAdd(&s_cnt, 1); s_list[slot] = tid; }
-        __syncthreads();
-        const int cnt = s_cnt;
-        scanned += (unsigned long long)cnt;
-        // ---- scan the survivors (order inside the block is irrelevant for the result)
-        for (int e = 0; e < cnt; ++e) {
-            const int64_t tu = base + (int64_t)s_list[e] * gridDim.x;
-            int cb; int64_t g;
-            unit_of(tu, G16, cb, g);
-            cb = __builtin_amdgcn_readfirstlane(cb);
-            const int64_t g_s = (int64_t)__builtin_amdgcn_readfirstlane((int)g);
-            const int64_t c0 = (int64_t)cb * kTileCols, a0 = g_s * kUR;
-            const int nrows = (int)min((int64_t)kUR, P - a0);
-            const int64_t b0 = c0 + 2 * tid, b1 = b0 + 1;
-            const double ub0 = Ur[b0], ub1 = Ur[b1];
-            const uint64_t ka0 = KA[b0], ka1 = KA[b1], kb0 = KB[b0], kb1 = KB[b1];
-            const v2d* basep = reinterpret_cast<const v2d*>(D + a0 * ld + c0) + tid;
-            const int64_t ld2 = ld >> 1;
-            const bool diag = a0 < c0 + kTileCols;
-            double m = __builtin_inf();
-            for (int r = 0; r < nrows; r += 8) {
-                v2d v[8];
-#pragma unroll
-                for (int u8 = 0; u8 < 8; ++u8) {
-                    const int rr = min(r + u8, nrows - 1);
-                    const v2d* pp = basep + (int64_t)rr * ld2;
-                    if (diag) pp = (b0 < a0 + rr) ? pp : pp - tid;
-                    v[u8] = __builtin_nontemporal_load(pp);
-                }
-#pragma unroll
-                for (int u8 = 0; u8 < 8; ++u8) {
-                    const int64_t a = a0 + min(r + u8, nrows - 1);
-                    const double ua = Ur[a];
-                    const uint64_t kaa = KA[a], kba = KB[a];
-                    double d0 = v[u8].x, d1 = v[u8].y;
-                    if (diag) {
-                        d0 = (b0 < a) ? d0 : __builtin_nan("");
-                        d1 = (b1 < a) ? d1 : __builtin_nan("");
-                    }
-                    m = fmin(m, fmin(d0, d1));  // fmin drops the NaN of masked entries; dead entries hold +inf
-                    best_update(bq, bk, (d0 - ua) - ub0, kaa | kb0);
-                    best_update(bq, bk, (d0 - ub0) - ua, ka0 | kba);
-                    best_update(bq, bk, (d1 - ua) - ub1, kaa | kb1);
-                    best_update(bq, bk, (d1 - ub1) - ua, ka1 | kba);
-                }
-            }
-            // exact unit minimum -> umin
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_xor(m, off, 64));
-            if ((tid & 63) == 0) smin[tid >> 6] = m;
-            __syncthreads();
-            if (tid == 0) umin[(int64_t)cb * G16 + g_s] = enc_f64(fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3])));
-            __syncthreads();
+    }
+    // column maximum of this block's strip, px excluded for now
+    double cm_part = NINF;
+    if (!beyond)
+        for (int e = tid; e < kTileCols; e += kThreads) {
+            const int64_t p = (int64_t)cb * kTileCols + e;
+            if (p < P && p != px) { const double v = Ur[p]; if (v == v) cm_part = fmax(cm_part, v); }
+        }
+    // hop 3: candidate gathers
+    double qc = PINF;
+    bool cand_px = false;
+    double cd = 0, cua = 0, cub = 0;
+    if (cand.key != ~0ull) {
+        const int64_t pi = (int64_t)(cand.pad & 0xffffffffull), pj = (int64_t)(cand.pad >> 32);
+        const int64_t pa = pi > pj ? pi : pj, pb = pi > pj ? pj : pi;
+        if (pa < P && pb < pa) {
+            cd = D[pa * ld + pb];
+            cua = pa == px ? 0.0 : Ur[pa];
+            cub = pb == px ? 0.0 : Ur[pb];
+            cand_px = (pa == px) || (pb == px);
+            if (!cand_px && cua == cua && cub == cub) qc = fmin((cd - cua) - cub, (cd - cub) - cua);
         }
     }
 
-    block_best(bq, bk, sq, sk);
-    if (tid == 0) {
-        NjRecord rec;
-        rec.q = bq; rec.key = bk; rec.d = 0.0; rec.pad = 0;
-        if (bk != ~0ull) {
-            const int64_t i = (int64_t)(bk & 0xFFFFFFull), j = (int64_t)((bk >> 24) & 0xFFFFFFull);
-            const int64_t pi = pos_of_slot[i], pj = pos_of_slot[j];
-            const int64_t pa = pi > pj ? pi : pj, pb = pi > pj ? pj : pi;
-            rec.d = D[pa * ld + pb];
-            rec.pad = (uint64_t)pa | ((uint64_t)pb << 32);
+    // ---- reductions
+    double urx = 0.0;
+    if (it > 0) {
+        const double ux = block_tree256(acc, s);
+        urx = ux / (double)(n - 2);
+        if (blockIdx.x == 0 && tid == 0) { U_w[px] = ux; Ur_w[px] = urx; }
+    }
+    if (beyond) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        qc = fmin(qc, __shfl_xor(qc, off, 64));
+        cm_part = fmax(cm_part, __shfl_xor(cm_part, off, 64));
+    }
+    if ((tid & 63) == 0) { sseed[tid >> 6] = qc; scm[tid >> 6] = cm_part; }
+    __syncthreads();
+    const double bound = fmin(fmin(sseed[0], sseed[1]), fmin(sseed[2], sseed[3]));
+    double cm = fmax(fmax(scm[0], scm[1]), fmax(scm[2], scm[3]));
+    // the new node's Ur joins the maxima of its group and its strip
+    if (px >= 0) {
+        if (px / kTileCols == cb) cm = fmax(cm, urx);
+        if (px_in_group) rmax = fmax(rmax, urx);
+    }
+    bool keep = false;
+    if (have) {
+        const double lb = fmin((uenc_d - rmax) - cm, (uenc_d - cm) - rmax);
+        keep = (rmax > NINF) && (cm > NINF) && (lb <= bound);
+    }
+    const int par = (int)(it & 1);
+    const unsigned long long mask = __ballot(keep);
+    const int lane = tid & 63;
+    unsigned long long base = 0;
+    if (lane == 0 && mask) base = atomicAdd(&st->cnt_list[par], (unsigned long long)__popcll(mask));
+    base = __shfl(base, 0, 64);
+    if (keep) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)((cb << 20) | (int)g);   // strip | group
+}
+
+// scan the listed units: block b takes entries b, b+G, ... and always writes partials[b] when it had
+// work, so the records of a scan are partials[0 .. min(cnt, grid)).  The lane-level best carries the
+// positions of the pair and its distance, so nothing is looked up after the reduction.
+__device__ __forceinline__ void best_update4(double& bq, uint64_t& bk, uint64_t& bp, double& bd, double q, uint64_t k,
+                                             uint64_t pp, double d)
+{
+    const bool take = (q < bq) | ((q == bq) & (k < bk));
+    bq = take ? q : bq; bk = take ? k : bk; bp = take ? pp : bp; bd = take ? d : bd;
+}
+
+__global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __restrict__ D, int64_t ld,
+                                                            NjState* __restrict__ st,
+                                                            const double* __restrict__ Ur,
+                                                            const uint64_t* __restrict__ KA,
+                                                            const uint64_t* __restrict__ KB,
+                                                            unsigned long long* __restrict__ umin,
+                                                            int64_t P, const int32_t* __restrict__ list,
+                                                            NjRecord* __restrict__ partials,
+                                                            unsigned long long* __restrict__ iterstats)
+{
+    __shared__ double sq[kThreads / 64], sd[kThreads / 64];
+    __shared__ uint64_t sk[kThreads / 64], sp[kThreads / 64];
+    __shared__ double smin[2][kThreads / 64];
+
+    const int tid = threadIdx.x;
+    // hop 1: state line and (speculatively) this block's first list entry
+    const int64_t it = st->itb, limit = st->it_limit;
+    const int32_t first = list[blockIdx.x];
+    if (it >= limit || st->status != 0) return;
+    const int64_t cnt = (int64_t)st->cnt_list[it & 1];
+    if ((int64_t)blockIdx.x >= cnt) return;
+    const int64_t G16 = (P + kUR - 1) / kUR;
+    double bq = 10000.0, bd = 0.0;  // the reference's init value
+    uint64_t bk = ~0ull, bp = 0;
+    int64_t scanned = 0;
+    int flip = 0;
+
+    for (int64_t e = blockIdx.x; e < cnt; e += gridDim.x, ++scanned, flip ^= 1) {
+        const int code = __builtin_amdgcn_readfirstlane(e == (int64_t)blockIdx.x ? first : list[e]);
+        const int cb = code >> 20;
+        const int64_t g_s = (int64_t)(code & 0xFFFFF);
+        const int64_t c0 = (int64_t)cb * kTileCols, a0 = g_s * kUR;
+        const int nrows = (int)min((int64_t)kUR, P - a0);
+        const int64_t b0 = c0 + 2 * tid, b1 = b0 + 1;
+        const double ub0 = Ur[b0], ub1 = Ur[b1];
+        const uint64_t ka0 = KA[b0], ka1 = KA[b1], kb0 = KB[b0], kb1 = KB[b1];
+        const v2d* basep = reinterpret_cast<const v2d*>(D + a0 * ld + c0) + tid;
+        const int64_t ld2 = ld >> 1;
+        const bool diag = a0 < c0 + kTileCols;
+        const bool live0 = ub0 == ub0, live1 = ub1 == ub1;   // dead columns carry NaN row sums
+        double m = __builtin_inf();
+        v2d v[kUR];
+#pragma unroll
+        for (int u8 = 0; u8 < kUR; ++u8) {
+            const int rr = min(u8, nrows - 1);
+            const v2d* pp = basep + (int64_t)rr * ld2;
+            if (diag) pp = (b0 < a0 + rr) ? pp : pp - tid;
+            v[u8] = __builtin_nontemporal_load(pp);
         }
+#pragma unroll
+        for (int u8 = 0; u8 < kUR; ++u8) {
+            const int64_t a = a0 + min(u8, nrows - 1);
+            const double ua = Ur[a];
+            if (!(ua == ua)) continue;                        // dead row (wave-uniform)
+            const uint64_t kaa = KA[a], kba = KB[a];
+            double d0 = v[u8].x, d1 = v[u8].y;
+            if (diag) {
+                d0 = (b0 < a) ? d0 : __builtin_nan("");
+                d1 = (b1 < a) ? d1 : __builtin_nan("");
+            }
+            // exact unit minimum over live pairs (fmin drops the NaN of masked entries)
+            m = fmin(m, fmin(live0 ? d0 : __builtin_nan(""), live1 ? d1 : __builtin_nan("")));
+            const uint64_t pa = (uint64_t)a;
+            best_update4(bq, bk, bp, bd, (d0 - ua) - ub0, kaa | kb0, pa | ((uint64_t)b0 << 32), d0);   // (i=a, j=b0)
+            best_update4(bq, bk, bp, bd, (d0 - ub0) - ua, ka0 | kba, (uint64_t)b0 | (pa << 32), d0);   // (i=b0, j=a)
+            best_update4(bq, bk, bp, bd, (d1 - ua) - ub1, kaa | kb1, pa | ((uint64_t)b1 << 32), d1);
+            best_update4(bq, bk, bp, bd, (d1 - ub1) - ua, ka1 | kba, (uint64_t)b1 | (pa << 32), d1);
+        }
+        // exact unit minimum -> umin (double-buffered LDS: one barrier per unit)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_xor(m, off, 64));
+        if ((tid & 63) == 0) smin[flip][tid >> 6] = m;
+        __syncthreads();
+        if (tid == 0)
+            umin[(int64_t)cb * G16 + g_s] = enc_f64(fmin(fmin(smin[flip][0], smin[flip][1]), fmin(smin[flip][2], smin[flip][3])));
+    }
+
+    // block winner (q, key, positions, d)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oq = __shfl_down(bq, off, 64), od = __shfl_down(bd, off, 64);
+        const uint64_t ok = __shfl_down((unsigned long long)bk, off, 64), op = __shfl_down((unsigned long long)bp, off, 64);
+        best_update4(bq, bk, bp, bd, oq, ok, op, od);
+    }
+    if ((tid & 63) == 0) { sq[tid >> 6] = bq; sk[tid >> 6] = bk; sp[tid >> 6] = bp; sd[tid >> 6] = bd; }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int w = 1; w < kThreads / 64; ++w) best_update4(bq, bk, bp, bd, sq[w], sk[w], sp[w], sd[w]);
+        NjRecord rec;
+        rec.q = bq; rec.key = bk; rec.d = bd; rec.pad = bp;   // pad = pos_i | pos_j << 32
         partials[blockIdx.x] = rec;
-        if (counters && scanned) atomicAdd(counters, scanned);
+        if (iterstats) { atomicAdd(&iterstats[2 * it], (unsigned long long)scanned); atomicMax(&iterstats[2 * it + 1], (unsigned long long)scanned); }
+        if (blockIdx.x == 0) st->units_scanned += (unsigned long long)cnt;   // single writer
     }
 }
 
@@ -299,38 +347,71 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
                                                             int32_t* __restrict__ slot_of_pos,
                                                             int32_t* __restrict__ pos_of_slot,
                                                             unsigned long long* __restrict__ umin,
-                                                            unsigned long long* __restrict__ seed,
                                                             double* __restrict__ xpart,
-                                                            const NjRecord* __restrict__ partials, int nparts,
-                                                            int64_t P, int64_t n, int64_t it,
+                                                            const NjRecord* __restrict__ partials, int scan_grid,
+                                                            int64_t P,
                                                             int32_t* __restrict__ log_x, int32_t* __restrict__ log_y,
                                                             double* __restrict__ log_bx, double* __restrict__ log_by)
 {
     __shared__ double s[kThreads];
     __shared__ double sq[kThreads / 64], sdd[kThreads / 64];
-    __shared__ uint64_t sk[kThreads / 64];
-    if (st->status != 0) return;
-    double bq, d; uint64_t bk;
-    reduce_records(partials, nparts, bq, bk, d, sq, sk, sdd);
+    __shared__ uint64_t sk[kThreads / 64], spp[kThreads / 64];
+    // hop 1: state line, this thread's slot -> position, and (speculatively) the scan records
+    const int64_t it = st->itb;   // stable: the writer below only advances st->it / st->n
+    const int64_t limit = st->it_limit, N = st->N;
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t p = i < N ? (int64_t)pos_of_slot[i] : -1;
+    NjRecord r0; r0.q = 10000.0; r0.key = ~0ull; r0.d = 0; r0.pad = 0;
+    NjRecord mine[4] = { r0, r0, r0, r0 };
+    const unsigned long long cnt_raw = st->cnt_list[it & 1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = threadIdx.x + k * kThreads;
+        if (idx < scan_grid && (unsigned long long)idx < cnt_raw) mine[k] = partials[idx];
+    }
+    if (st->status != 0 || it >= limit) return;
+    const int64_t n = N - it;
+    if (n < 3 || (int64_t)blockIdx.x * kThreads >= n) return;
+    const int par = (int)(it & 1);
+
+    // select: reduce the records (thrust::min_element, src/neighborJoining.cu:214)
+    double bq = 10000.0, d = 0.0; uint64_t bk = ~0ull, bp = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) best_update4(bq, bk, bp, d, mine[k].q, mine[k].key, mine[k].pad, mine[k].d);
+    {
+        const int64_t nrec = (int64_t)(cnt_raw < (unsigned long long)scan_grid ? cnt_raw : (unsigned long long)scan_grid);
+        for (int64_t idx = threadIdx.x + 4 * kThreads; idx < nrec; idx += kThreads)
+            best_update4(bq, bk, bp, d, partials[idx].q, partials[idx].key, partials[idx].pad, partials[idx].d);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oq = __shfl_down(bq, off, 64), od = __shfl_down(d, off, 64);
+        const uint64_t ok = __shfl_down((unsigned long long)bk, off, 64), op = __shfl_down((unsigned long long)bp, off, 64);
+        best_update4(bq, bk, bp, d, oq, ok, op, od);
+    }
+    if ((threadIdx.x & 63) == 0) { sq[threadIdx.x >> 6] = bq; sk[threadIdx.x >> 6] = bk; spp[threadIdx.x >> 6] = bp; sdd[threadIdx.x >> 6] = d; }
+    __syncthreads();
+    bq = sq[0]; bk = sk[0]; bp = spp[0]; d = sdd[0];
+#pragma unroll
+    for (int w = 1; w < kThreads / 64; ++w) best_update4(bq, bk, bp, d, sq[w], sk[w], spp[w], sdd[w]);
+
     const int64_t last = n - 1;
     if (bk == ~0ull) {
         if (i == last) st->status = 1;
         return;
     }
     const int64_t ki = (int64_t)(bk & 0xFFFFFFull), kj = (int64_t)((bk >> 24) & 0xFFFFFFull);
+    const int64_t pi = (int64_t)(bp & 0xffffffffull), pj = (int64_t)(bp >> 32);
     const int64_t x = ki < kj ? ki : kj, y = ki < kj ? kj : ki;
-    const int64_t px = pos_of_slot[x], py = pos_of_slot[y];
+    const int64_t px = ki < kj ? pi : pj, py = ki < kj ? pj : pi;
     const int64_t n1 = n - 1;
     const double r1 = (double)(n1 - 2);
     const int64_t G16 = (P + kUR - 1) / kUR;
-    const double INF = __builtin_inf();
 
     double val = 0.0;
     if (i < n) {
-        const int64_t p = pos_of_slot[i];
         if (i == last) {
-            // single writer of the log and the state (reads U[px], U[py] before anything rewrites them)
+            // single writer of the log and the state (reads U[px], U[py]; nobody rewrites them here)
             const double r = (double)(n - 2);
             double blX = (d + U[px] / r - U[py] / r) * 0.5;
             double blY = d - blX;
@@ -339,7 +420,7 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
             log_x[it] = (int32_t)x; log_y[it] = (int32_t)y; log_bx[it] = blX; log_by[it] = blY;
             st->x = (int32_t)x; st->y = (int32_t)y; st->d = d; st->q = bq;
             st->n = n1; st->it = it + 1; st->pad = (int32_t)px;
-            *seed = ~0ull;  // +inf-most encoding: no bound until njp_bounds_kernel finds one
+            st->cnt_list[1 - par] = 0ull;   // list counter of the NEXT scan (nobody reads it in this launch)
         }
         int64_t new_slot = i;
         if (i != x && i != y) {
@@ -350,8 +431,6 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
             Ur[p] = u / r1;
             D[px * ld + p] = val;
             D[p * ld + px] = val;
-            D[py * ld + p] = INF;
-            D[p * ld + py] = INF;
             // the unit holding the pair (px, p) may have a new minimum
             const int64_t pa = p > px ? p : px, pb = p > px ? px : p;
             atomicMin(&umin[(pb / kTileCols) * G16 + pa / kUR], (unsigned long long)enc_f64(val));
@@ -361,9 +440,7 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
                 pos_of_slot[y] = (int32_t)p;
             }
         } else if (i == y) {
-            Ur[p] = __builtin_nan("");   // dead; U[p] is left alone (the writer thread may still be reading it)
-            D[px * ld + py] = INF;
-            D[py * ld + px] = INF;
+            Ur[p] = __builtin_nan("");   // dead: every q it takes part in is NaN, every unit minimum skips it
             if (y != last) slot_of_pos[p] = -1;
             new_slot = -1;
         }
@@ -376,7 +453,7 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static int g_njp_grid = 2048;
+static int g_njp_grid = 1024;
 int njp_scan_grid() { return g_njp_grid; }
 
 static int64_t round_up16(int64_t v) { return (v + 15) / 16 * 16; }
@@ -421,11 +498,31 @@ int njp_build(NjBuffers& b, hipStream_t s)
     DPR_HIP(hipMalloc(&q.umin, sizeof(uint64_t) * (size_t)q.nunits_alloc));
     DPR_HIP(hipMalloc(&q.gmax, sizeof(double) * (size_t)(G16 + 16)));
     DPR_HIP(hipMalloc(&q.bmax, sizeof(double) * (size_t)((N + kThreads - 1) / kThreads + 2)));
-    DPR_HIP(hipMalloc(&q.seed, sizeof(uint64_t) * 2));
-    q.counters = q.seed + 1;
-    const uint64_t init_seed[2] = { ~0ull, 0ull };
+    DPR_HIP(hipMalloc(&q.seed, sizeof(uint64_t) * 8));
+    q.counters = q.seed + 1;   // [0] units scanned, [1+par] partial records, [3+par] listed units of the scan with parity par
+    const uint64_t init_seed[8] = { ~0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull };
     DPR_HIP(hipMemcpyAsync(q.seed, init_seed, sizeof(init_seed), hipMemcpyHostToDevice, s));
     q.utot = unit_total(N);
+    {
+        // prep blocks: one strip and up to 256 consecutive row groups each (groups >= 32*cb see the strip)
+        std::vector<int32_t> hcb, hg0;
+        const int64_t G = (N + kUR - 1) / kUR;
+        for (int64_t c = 0; 32 * c < G && c * kTileCols < N - 1; ++c)
+            for (int64_t g0 = 32 * c; g0 < G; g0 += kThreads) { hcb.push_back((int32_t)c); hg0.push_back((int32_t)g0); }
+        if (hcb.empty()) { hcb.push_back(0); hg0.push_back(0); }
+        q.nprep = (int)hcb.size();
+        DPR_HIP(hipMalloc(&q.blk_cb, sizeof(int32_t) * hcb.size()));
+        DPR_HIP(hipMalloc(&q.blk_g0, sizeof(int32_t) * hg0.size()));
+        DPR_HIP(hipMemcpyAsync(q.blk_cb, hcb.data(), sizeof(int32_t) * hcb.size(), hipMemcpyHostToDevice, s));
+        DPR_HIP(hipMemcpyAsync(q.blk_g0, hg0.data(), sizeof(int32_t) * hg0.size(), hipMemcpyHostToDevice, s));
+        DPR_HIP(hipStreamSynchronize(s));   // the host vectors go out of scope
+    }
+    DPR_HIP(hipMalloc(&q.list, sizeof(int32_t) * (size_t)(q.utot + kScanBlocks + 64)));
+    DPR_HIP(hipMemsetAsync(q.list, 0, sizeof(int32_t) * (size_t)(q.utot + kScanBlocks + 64), s));
+    if (std::getenv("DPR_NJ_ITERSTATS")) {
+        DPR_HIP(hipMalloc(&q.iterstats, sizeof(uint64_t) * (size_t)(2 * N + 2)));
+        DPR_HIP(hipMemsetAsync(q.iterstats, 0, sizeof(uint64_t) * (size_t)(2 * N + 2), s));
+    }
 
     dim3 grid((unsigned)((N + kThreads - 1) / kThreads > 64 ? 64 : (N + kThreads - 1) / kThreads), (unsigned)(N < 32768 ? N : 32768));
     hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, b.D, b.ld, q.D, q.ld, q.perm, N);
@@ -444,46 +541,65 @@ int njp_build(NjBuffers& b, hipStream_t s)
 
 void njp_free(NjPruned& q)
 {
-    void* ptrs[] = { q.D, q.U, q.Ur, q.KA, q.KB, q.slot_of_pos, q.pos_of_slot, q.perm, q.umin, q.gmax, q.bmax, q.seed };
+    if (q.graph) { (void)hipGraphExecDestroy(q.graph); q.graph = nullptr; }
+    void* ptrs[] = { q.D, q.U, q.Ur, q.KA, q.KB, q.slot_of_pos, q.pos_of_slot, q.perm, q.umin, q.gmax, q.bmax, q.seed, q.iterstats, q.list, q.blk_cb, q.blk_g0 };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     q = NjPruned();
 }
 
-int njp_launch_bounds(NjBuffers& b, int64_t n, int64_t it, hipStream_t s)
+static int njp_launch_prep(NjBuffers& b, hipStream_t s)
 {
     NjPruned& q = b.pr;
-    const unsigned grid = (unsigned)((q.P + kThreads - 1) / kThreads);
-    hipLaunchKernelGGL(njp_bounds_kernel, dim3(grid), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.U, q.Ur, b.xpart,
-                       b.partials, njp_scan_grid(), q.P, n, it, q.gmax, q.bmax, (unsigned long long*)q.seed);
+    hipLaunchKernelGGL(njp_prep_kernel, dim3((unsigned)q.nprep), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.U, q.Ur, q.Ur,
+                       b.xpart, b.partials, (const unsigned long long*)q.umin, q.P, q.blk_cb, q.blk_g0, g_njp_grid, q.list);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
 
-
-int njp_launch_scan(NjBuffers& b, bool full, hipStream_t s)
+// one iteration: scan -> post -> prep(next); every kernel reads its iteration index from the device state
+static int njp_enqueue_iteration(NjBuffers& b, hipStream_t s)
 {
     NjPruned& q = b.pr;
-    if (full)
-        hipLaunchKernelGGL(njp_scan_kernel<true>, dim3(g_njp_grid), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.Ur, q.KA,
-                           q.KB, q.pos_of_slot, (unsigned long long*)q.umin, q.gmax, q.bmax,
-                           (const unsigned long long*)q.seed, q.P, q.utot, b.partials, (unsigned long long*)q.counters);
-    else
-        hipLaunchKernelGGL(njp_scan_kernel<false>, dim3(g_njp_grid), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.Ur, q.KA,
-                           q.KB, q.pos_of_slot, (unsigned long long*)q.umin, q.gmax, q.bmax,
-                           (const unsigned long long*)q.seed, q.P, q.utot, b.partials, (unsigned long long*)q.counters);
-    DPR_HIP(hipGetLastError());
-    return DPR_OK;
+    hipLaunchKernelGGL(njp_scan_kernel, dim3(g_njp_grid), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.Ur, q.KA, q.KB,
+                       (unsigned long long*)q.umin, q.P, q.list, b.partials, (unsigned long long*)q.iterstats);
+    const unsigned pgrid = (unsigned)((b.N + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(njp_post_kernel, dim3(pgrid), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.U, q.Ur, q.KA, q.KB,
+                       q.slot_of_pos, q.pos_of_slot, (unsigned long long*)q.umin, b.xpart, b.partials, g_njp_grid, q.P,
+                       b.log_x, b.log_y, b.log_bx, b.log_by);
+    return njp_launch_prep(b, s);
 }
 
-int njp_launch_post(NjBuffers& b, int64_t n, int64_t it, hipStream_t s)
+// enqueue `todo` iterations starting at iteration it0.  The four kernels of an iteration take no
+// per-iteration arguments, so kGraphIters iterations are captured once into a hipGraph and replayed;
+// iterations beyond it_limit are no-ops.
+constexpr int kGraphIters = 32;
+
+int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
 {
     NjPruned& q = b.pr;
-    const unsigned grid = (unsigned)((n + kThreads - 1) / kThreads);
-    hipLaunchKernelGGL(njp_post_kernel, dim3(grid), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.U, q.Ur, q.KA, q.KB,
-                       q.slot_of_pos, q.pos_of_slot, (unsigned long long*)q.umin, (unsigned long long*)q.seed, b.xpart,
-                       b.partials, njp_scan_grid(), q.P, n, it, b.log_x, b.log_y, b.log_bx, b.log_by);
-    DPR_HIP(hipGetLastError());
+    const int64_t limit = it0 + todo;
+    DPR_HIP(hipMemcpyAsync(&b.st->it_limit, &limit, sizeof(int64_t), hipMemcpyHostToDevice, s));
+    DPR_HIP(hipStreamSynchronize(s));   // `limit` is a stack variable
+    if (todo <= 0) return DPR_OK;
+    if (int rc = njp_launch_prep(b, s)) return rc;   // list + bound for iteration it0
+    const bool use_graph = todo >= kGraphIters && !std::getenv("DPR_NJ_NOGRAPH");
+    if (use_graph && !q.graph) {
+        hipGraph_t g = nullptr;
+        DPR_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int rc = DPR_OK;
+        for (int k = 0; k < kGraphIters && rc == DPR_OK; ++k) rc = njp_enqueue_iteration(b, s);
+        hipError_t e = hipStreamEndCapture(s, &g);
+        if (rc != DPR_OK) return rc;
+        if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
+        DPR_HIP(hipGraphInstantiate(&q.graph, g, nullptr, nullptr, 0));
+        DPR_HIP(hipGraphDestroy(g));
+    }
+    int64_t done = 0;
+    if (use_graph)
+        for (; done + kGraphIters <= todo; done += kGraphIters) DPR_HIP(hipGraphLaunch(q.graph, s));
+    for (; done < todo; ++done)
+        if (int rc = njp_enqueue_iteration(b, s)) return rc;
     return DPR_OK;
 }
 

@@ -138,6 +138,12 @@ int dpr_set_nj_mode(int mode);
 /* pruned path: 16x512 units scanned since dpr_dist_matrix, and units of one full scan */
 int dpr_get_prune_stats(dpr_ctx *ctx, uint64_t *units_scanned, uint64_t *units_per_full_scan);
 
+/* microbenchmark: microseconds per launch of a chain of `nlaunch` trivial dependent kernels of `grid`
+ * blocks on the context's stream, eager (0) or hipGraph replay of 128-node chains (1) */
+int dpr_launch_bench(dpr_ctx *ctx, int nlaunch, int grid, int use_graph, float *us_per_launch);
+/* debug, needs DPR_NJ_ITERSTATS=1: per iteration {units scanned, most units scanned by one block} */
+int dpr_get_iterstats(dpr_ctx *ctx, uint64_t *out, int64_t iters);
+
 /* tuning knobs of the Q-argmin scan (process-wide): rows per work unit (16/32/64), non-temporal
  * loads (0/1), grid size (0 = default, <= 2048).  Results never depend on them. */
 int dpr_scan_tune(int rows_per_unit, int nontemporal, int grid);
