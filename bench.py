@@ -190,7 +190,7 @@ def main():
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, world),
-                "kernel": "nj_scan_kernel<true> (probe instantiation of the Q-argmin scan)",
+                "kernel": "nj_scan_kernel<PROBE=true,...> (probe instantiation of the full Q-argmin scan)",
                 "n_active": n, "algorithmic_bytes": alg_bytes, "ms": scan_ms, "rows_local": int(rows_local)}
 
     out = {
