@@ -62,8 +62,10 @@ __global__ __launch_bounds__(kThreads) void msa_dist_kernel(const uint32_t* __re
                                                             int64_t rows_local, int rank, int world,
                                                             int64_t row0)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t sA[3][kKC][kPT];
-    __shared__ __attribute__((aligned(16))) uint32_t sB[3][kKC][kPT];
+    // rows padded to 68 words: the staging writes (consecutive lanes = consecutive k) then hit 8 banks
+    // two ways instead of one bank sixteen ways; 68*4 B keeps the 16-byte reads aligned
+    __shared__ __attribute__((aligned(16))) uint32_t sA[3][kKC][kPT + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t sB[3][kKC][kPT + 4];
 
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
@@ -71,6 +73,9 @@ __global__ __launch_bounds__(kThreads) void msa_dist_kernel(const uint32_t* __re
     const int64_t c0 = (int64_t)blockIdx.x * kPT;   // global column block
     // world > 0: rows are the owned rows of (rank, world); world == 0: plain tip ids row0 + l
     const int64_t g0 = world > 0 ? shard_global_row(l0, rank, world) : row0 + l0;
+    // single GPU, whole matrix: tiles strictly above the diagonal are produced by their mirror tile
+    const bool mirror = (world == 1);
+    if (mirror && c0 > g0 + kPT - 1) return;
 
     int useful[4][4], match[4][4];
 #pragma unroll
@@ -128,7 +133,9 @@ __global__ __launch_bounds__(kThreads) void msa_dist_kernel(const uint32_t* __re
         for (int c = 0; c < 4; ++c) {
             const int64_t gj = c0 + tx * 4 + c;
             if (gj >= n) continue;
-            D[li * ld + gj] = (gi == gj) ? 0.0 : msa_epilogue(useful[r][c], match[r][c], dist_type);
+            const double d = (gi == gj) ? 0.0 : msa_epilogue(useful[r][c], match[r][c], dist_type);
+            D[li * ld + gj] = d;
+            if (mirror && c0 + kPT - 1 < g0) D[gj * ld + gi] = d;   // counts are symmetric (src/MSA.cu:121-122)
         }
     }
 }
