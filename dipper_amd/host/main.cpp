@@ -224,6 +224,45 @@ int main(int argc, char** argv)
         return 0;
     }
 
+    if ((params.in == "m" || params.in == "r") && params.out == "d") {
+        // -o d: distance matrix in PHYLIP format (lower-triangular, tab separated -- the layout the
+        // reader of -i d consumes).  "coming soon" in the reference (src/tree_generation.cu:55-58).
+        const bool aligned = params.in == "m";
+        std::vector<std::string> seqs, names_, names;
+        readSequences(inputFile, seqs, names_);
+        const size_t numSequences = seqs.size();
+        if (numSequences < 2) die("ERROR: need at least two sequences in " + inputFile);
+        names.resize(numSequences);
+        const std::vector<int> ids = shuffledIds(numSequences, -1);   // input order
+        for (size_t i = 0; i < numSequences; ++i) names[(size_t)ids[i]] = names_[i];
+        auto output_ = open_out();
+        DeviceContext dev(device);
+        dpr_set_nj_mode(0);   // plain matrix layout, no NJ structures
+        NJDeviceArrays njDeviceArrays;
+        if (aligned) {
+            MSADeviceArrays msaDeviceArrays;
+            msaDeviceArrays.allocateDeviceArrays(dev, seqs, ids);
+        } else {
+            MashDeviceArrays mashDeviceArrays;
+            mashDeviceArrays.allocateDeviceArrays(dev, seqs, ids);
+            mashDeviceArrays.sketchConstructionOnGpu(dev, params);
+        }
+        njDeviceArrays.getDismatrix(dev, (int)numSequences, params, nullptr);
+        std::vector<double> row(numSequences);
+        char buf[64];
+        *output_ << numSequences << "\n";
+        for (size_t i = 0; i < numSequences; ++i) {
+            gpuCheck(dpr_get_matrix_row(dev.ctx, (int64_t)i, row.data()), "dpr_get_matrix_row");
+            *output_ << names[i];
+            for (size_t j = 0; j < i; ++j) {
+                std::snprintf(buf, sizeof(buf), "\t%.9g", row[j]);
+                *output_ << buf;
+            }
+            *output_ << "\n";
+        }
+        return 0;
+    }
+
     if ((params.in == "m" || params.in == "r") && params.out == "t") {
         const bool aligned = params.in == "m";
         std::vector<std::string> seqs, names_, names;

@@ -172,3 +172,30 @@ def test_add_queries_to_backbone(tmp_path, orc, kind):
     orc.place_init_lists(n, m, st)
     st = orc.place_run(M, first=m, state=st)
     assert out.read_text() == _util.newick_from_placement(order_names, st["head"], st["e"], st["nxt"], st["len"], n)
+
+
+def test_output_distance_matrix(tmp_path, orc):
+    """-o d writes the lower-triangular PHYLIP matrix that -i d consumes; feeding it back gives the
+    NJ tree of the float-rounded matrix."""
+    rng = np.random.default_rng(41)
+    n, L = 60, 800
+    seqs = _util.synth_alignment(rng, n, L, mean_bl=1e-2, lo=1e-3, hi=5e-2)
+    names = [f"T{i+1}" for i in range(n)]
+    fa = tmp_path / "a.fa"
+    _util.write_fasta(str(fa), names, seqs)
+    phy = tmp_path / "d.phy"
+    assert run("-i", "m", "-o", "d", "-I", str(fa), "-O", str(phy), "-d", "1").returncode == 0
+    lines = phy.read_text().strip().split("\n")
+    assert int(lines[0]) == n and [ln.split("\t")[0] for ln in lines[1:]] == names
+    D = orc.msa_dist_lower(orc.pack4_many(seqs), L, 1)
+    for i in range(n):
+        vals = [float(v) for v in lines[1 + i].split("\t")[1:]]
+        assert len(vals) == i and np.allclose(vals, D[i, :i], rtol=1e-8, atol=0)
+    out = tmp_path / "t.nwk"
+    assert run("-i", "d", "-I", str(phy), "-O", str(out)).returncode == 0
+    Dr = np.zeros((n, n))
+    for i in range(n):
+        for j, v in enumerate(lines[1 + i].split("\t")[1:]):
+            Dr[i, j] = orc.phylip_value(v)
+    ref = orc.nj_run(Dr)
+    assert out.read_text() == _util.newick_from_merges(names, ref["merge_x"], ref["merge_y"], ref["bl_x"], ref["bl_y"], ref["last_d"])
