@@ -13,6 +13,8 @@
 // one-row-per-launch kernel).
 #include "dpr_internal.hpp"
 
+#include <cstdlib>
+
 namespace dpr {
 
 constexpr int kSketchThreads = 1024;
@@ -185,6 +187,163 @@ __global__ __launch_bounds__(kThreads) void mash_dist_rows_kernel(const uint64_t
 }
 
 // ------------------------------------------------------------------------------------------------
+// Lookup formulation of the same distance (S <= 1024, pairs with column index < row index).
+// The sequential merge is equivalent to: events in value order, B before A on ties; every A element
+// and every B element whose value is not in A advances `uni`; B elements equal to an A value advance
+// `inter`; stop at the S-th advance.  Hence, iterating over the DISTINCT values v of A (outer list =
+// the lower-index tip) that also occur in B (inner list):
+//     inter = sum of mult_B(v) over those v with   first_A(v) + #{b < v} - #{matching b < v}  <  S
+// and uni = S.  So B is never walked: per row tip the block keeps its sketch in LDS with a bucket
+// index (bucket[k] = first t with b_t >> shift >= k, 1024 buckets), a wave holds one column sketch in
+// registers (16 values per lane) and resolves each value with one bucket read and ~1 sketch read;
+// a wave prefix sum supplies the matches of the lanes before it.  A block keeps 12 row tips
+// resident (146 KiB of LDS) and streams the columns, 8 at a time (one per wave).
+// ------------------------------------------------------------------------------------------------
+constexpr int kLS = 1024;            // largest sketch this kernel handles
+constexpr int kLRows = 12;           // row tips resident per block
+constexpr int kLThreads = 512;       // 8 waves
+constexpr int kLColsPerBlock = 512;
+constexpr int kLBuckets = 1024;
+
+__global__ __launch_bounds__(kLThreads) void mash_dist_lookup_kernel(const uint64_t* __restrict__ sk, int S, int k,
+                                                                     int64_t n, int64_t r0, int64_t nr, int world,
+                                                                     int64_t ncols, double* __restrict__ out,
+                                                                     int64_t ld, int mirror)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* vals = reinterpret_cast<uint64_t*>(smem);                              // [kLRows][kLS]
+    uint32_t* bucket = reinterpret_cast<uint32_t*>(vals + kLRows * kLS);             // [kLRows][kLBuckets + 1]
+    __shared__ int s_shift[kLRows];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t t0 = (int64_t)blockIdx.y * kLRows;
+    const int64_t cbeg = (int64_t)blockIdx.x * kLColsPerBlock;
+    const int64_t cend = min(ncols, cbeg + kLColsPerBlock);
+    int64_t irow[kLRows];
+    int64_t imax = -1;
+#pragma unroll
+    for (int r = 0; r < kLRows; ++r) {
+        const int64_t tt = t0 + r;
+        int64_t i = -1;
+        if (tt < nr) { i = r0 + tt; if (i >= n) i = -1; }
+        irow[r] = i;
+        imax = max(imax, i);
+    }
+    (void)world;
+    if (imax < 0 || cbeg >= imax) return;   // nothing below the diagonal in this column range
+
+    // ---- resident row structures
+    for (int e = tid; e < kLRows * kLS; e += kLThreads) {
+        const int r = e / kLS, sidx = e % kLS;
+        vals[e] = (irow[r] >= 0 && sidx < S) ? sk[irow[r] * S + sidx] : ~0ull;
+    }
+    __syncthreads();
+    if (tid < kLRows) {
+        const uint64_t mx = vals[tid * kLS + (S - 1)];
+        const int bits = mx ? 64 - __clzll((long long)mx) : 1;
+        s_shift[tid] = bits > 10 ? bits - 10 : 0;
+    }
+    __syncthreads();
+    for (int e = tid; e < kLRows * (kLBuckets + 1); e += kLThreads) {
+        const int r = e / (kLBuckets + 1), kb = e % (kLBuckets + 1);
+        const uint64_t* v = vals + r * kLS;
+        const int sh = s_shift[r];
+        int lo = 0, hi = S;                      // first t with (v[t] >> sh) >= kb
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((v[mid] >> sh) < (uint64_t)kb) lo = mid + 1; else hi = mid;
+        }
+        bucket[e] = (uint32_t)lo;
+    }
+    __syncthreads();
+
+    // ---- stream the columns: wave w takes column c0 + w
+    for (int64_t c0 = cbeg; c0 < cend && c0 < imax; c0 += kLThreads / 64) {
+        const int64_t j = c0 + w;
+        if (j >= cend || j >= imax) continue;
+        uint64_t a[16];
+        const uint64_t* col = sk + j * S + 16 * lane;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a[u] = (16 * lane + u < S) ? col[u] : ~0ull;
+        uint64_t aprev = __shfl_up((unsigned long long)a[15], 1, 64);
+        const bool has_prev = lane > 0;
+#pragma unroll 1
+        for (int r = 0; r < kLRows; ++r) {
+            const int64_t i = irow[r];
+            if (i < 0 || j >= i) continue;                       // wave-uniform
+            const uint64_t* v = vals + r * kLS;
+            const uint32_t* bk = bucket + r * (kLBuckets + 1);
+            const int sh = s_shift[r];
+            // phase 1-2: bucket and first probe of all 16 values (independent LDS reads overlap)
+            int t[16];
+            uint64_t bv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                uint64_t kb = a[u] >> sh;
+                if (kb > (uint64_t)kLBuckets) kb = kLBuckets;
+                t[u] = (int)bk[kb];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) bv[u] = v[t[u] < S ? t[u] : S - 1];
+            // phase 3: advance to #{b < a} (rarely more than one or two rounds)
+            for (;;) {
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const bool adv = t[u] < S && bv[u] < a[u];
+                    t[u] += adv ? 1 : 0;
+                    any |= adv;
+                }
+                if (!__any(any)) break;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) bv[u] = v[t[u] < S ? t[u] : S - 1];
+            }
+            // phase 4: matches, multiplicities (the next slot is read for every value: no branch)
+            uint64_t nx[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) nx[u] = v[t[u] + 1 < S ? t[u] + 1 : S - 1];
+            int cu[16], mu[16];
+            int msum = 0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                cu[u] = 1 << 30; mu[u] = 0;
+                const int sidx = 16 * lane + u;
+                const uint64_t av = a[u];
+                const bool first = (u == 0) ? (!has_prev || aprev != av) : (a[u > 0 ? u - 1 : 0] != av);
+                const bool match = sidx < S && first && t[u] < S && bv[u] == av;
+                if (match) {
+                    int mult = 1;
+                    if (t[u] + 1 < S && nx[u] == av) {           // duplicates in B: rare, walk them
+                        mult = 2;
+                        while (t[u] + mult < S && v[t[u] + mult] == av) ++mult;
+                    }
+                    cu[u] = sidx + t[u] - msum;                  // rank before the lanes' prefix is subtracted
+                    mu[u] = mult;
+                    msum += mult;
+                }
+            }
+            int incl = msum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int x = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += x;
+            }
+            const int thr = S + (incl - msum);                   // rank - prefix < S
+            int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) cnt += (cu[u] < thr) ? mu[u] : 0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+            if (lane == 0) {
+                const double jac = fmax((double)cnt, 1.0) / S;
+                const double d = fmin(1.0, fabs(log(2.0 * jac / (1.0 + jac)) / (double)k));
+                out[(t0 + r) * ld + j] = d;
+                if (mirror) out[j * ld + (r0 + t0 + r)] = d;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 int mash_upload(MashBuffers& m, const uint64_t* packed2, const uint64_t* word_off, const uint64_t* len,
@@ -241,6 +400,22 @@ int mash_dist_rows(const MashBuffers& m, int64_t r0, int64_t nr, int rank, int w
                    int64_t ncols, double* out, int64_t ld, hipStream_t s)
 {
     if (nr <= 0 || ncols <= 0) return DPR_OK;
+    // lower-triangle pairs (placement batches; single-GPU NJ with a mirror write): lookup kernel
+    const bool mirror = full && world == 1 && r0 == 0;
+    if (m.S <= kLS && (!full || mirror) && world <= 1 && !std::getenv("DPR_MASH_SIMPLE")) {
+        static bool attr_set = false;
+        const size_t tlds = sizeof(uint64_t) * kLRows * kLS + sizeof(uint32_t) * kLRows * (kLBuckets + 1);
+        if (!attr_set) {
+            DPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mash_dist_lookup_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+            attr_set = true;
+        }
+        dim3 tgrid((unsigned)((ncols + kLColsPerBlock - 1) / kLColsPerBlock), (unsigned)((nr + kLRows - 1) / kLRows));
+        hipLaunchKernelGGL(mash_dist_lookup_kernel, tgrid, dim3(kLThreads), tlds, s, m.sketches, m.S, m.k, m.n, r0, nr,
+                           world, ncols, out, ld, mirror ? 1 : 0);
+        DPR_HIP(hipGetLastError());
+        return DPR_OK;
+    }
     dim3 grid((unsigned)((ncols + kThreads - 1) / kThreads), (unsigned)nr);
     const size_t lds = sizeof(uint64_t) * (size_t)m.S;
     if (full)

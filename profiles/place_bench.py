@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Mash sketch + k-closest placement timing: python profiles/place_bench.py [tips] [sites] [kind m|r]"""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").environ.get("GRAFT_REPO_ROOT", "."))
 import numpy as np
 import bench, dipper_amd
 from dipper_amd import capi
