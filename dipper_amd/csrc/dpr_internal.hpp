@@ -95,8 +95,6 @@ struct NjPruned {
     int32_t *slot_of_pos = nullptr, *pos_of_slot = nullptr, *perm = nullptr;
     uint64_t* umin = nullptr;   // [strips][groups] order-encoded lower bound of D per unit
     int64_t nunits_alloc = 0, utot = 0;
-    double *gmax = nullptr, *bmax = nullptr;   // max Ur per 16 / 256 positions
-    uint64_t *seed = nullptr, *counters = nullptr;
     hipGraphExec_t graph = nullptr;   // kGraphIters iterations of (test, scan, post, bounds)
     int32_t* list = nullptr;         // units selected by the prep kernel (strip << 20 | group)
     int32_t *blk_cb = nullptr, *blk_g0 = nullptr;   // prep block -> (strip, first group)
@@ -119,8 +117,6 @@ struct NjBuffers {
     double* slice = nullptr;   // [3][slice] local column slices (world > 1)
     int64_t slice_len = 0;
     NjState* st = nullptr;
-    int32_t* tile_start = nullptr;  // [nlrb+1]
-    int32_t nlrb = 0;
     int32_t* log_x = nullptr;  // [N]
     int32_t* log_y = nullptr;
     double* log_bx = nullptr;

@@ -275,10 +275,8 @@ __global__ __launch_bounds__(kThreads) void nj_scan_kernel(
 // local winner of this rank -> recs[rank] (all-gathered when world > 1; read by the host for probes)
 __global__ __launch_bounds__(kThreads) void nj_select_local_kernel(const NjState* __restrict__ st,
                                                                    const NjRecord* __restrict__ partials,
-                                                                   int nparts, const unsigned long long* __restrict__ nparts_dev,
-                                                                   NjRecord* __restrict__ out)
+                                                                   int nparts, NjRecord* __restrict__ out)
 {
-    if (nparts < 0) nparts = (int)nparts_dev[st->it & 1];   // pruned path: records published by the last scan
     __shared__ double sq[kThreads / 64], sdd[kThreads / 64];
     __shared__ uint64_t sk[kThreads / 64];
     double bq, bd; uint64_t bk;
@@ -536,17 +534,6 @@ int nj_alloc(NjBuffers& b, int64_t N, int rank, int world)
     DPR_HIP(hipMalloc(&b.log_bx, sizeof(double) * (size_t)(N + 1)));
     DPR_HIP(hipMalloc(&b.log_by, sizeof(double) * (size_t)(N + 1)));
 
-    // tile prefix over owned row blocks (full, unclipped blocks)
-    const int64_t nrb_glob = (N + kRowBlock - 1) / kRowBlock;
-    b.nlrb = nrb_glob > rank ? (int32_t)((nrb_glob - rank + world - 1) / world) : 0;
-    std::vector<int32_t> ts((size_t)b.nlrb + 1, 0);
-    for (int l = 0; l < b.nlrb; ++l) {
-        const int64_t g0 = ((int64_t)l * world + rank) * kRowBlock;
-        const int64_t gEnd = g0 + kRowBlock < N ? g0 + kRowBlock : N;
-        ts[(size_t)l + 1] = ts[(size_t)l] + (int32_t)((gEnd - 1 + kTileCols - 1) / kTileCols);
-    }
-    DPR_HIP(hipMalloc(&b.tile_start, sizeof(int32_t) * ts.size()));
-    DPR_HIP(hipMemcpy(b.tile_start, ts.data(), sizeof(int32_t) * ts.size(), hipMemcpyHostToDevice));
     return DPR_OK;
 }
 
@@ -554,7 +541,7 @@ void nj_free(NjBuffers& b)
 {
     njp_free(b.pr);
     void* ptrs[] = { b.D, b.U, b.Ur, b.KA, b.partials, b.recs, b.xpart, b.gath, b.slice, b.st,
-                     b.tile_start, b.log_x, b.log_y, b.log_bx, b.log_by };
+                     b.log_x, b.log_y, b.log_bx, b.log_by };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     b = NjBuffers();
@@ -646,7 +633,7 @@ int nj_launch_post(NjBuffers& b, int64_t n, int64_t it, hipStream_t s)
 int nj_launch_select_local(NjBuffers& b, int nparts, hipStream_t s)
 {
     hipLaunchKernelGGL(nj_select_local_kernel, dim3(1), dim3(kThreads), 0, s, b.st, b.partials, nparts,
-                       (const unsigned long long*)(b.pr.counters ? b.pr.counters + 1 : nullptr), b.recs + b.rank);
+                       b.recs + b.rank);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }

@@ -98,21 +98,6 @@ __global__ void njp_fill_u64_kernel(uint64_t* __restrict__ a, int64_t cnt, uint6
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x) a[i] = v;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Linear valid-unit index t -> (strip cb, group g)
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void unit_of(int64_t t, int64_t G16, int& cb, int64_t& g)
-{
-    // largest cb with unit_prefix(cb) <= t; prefix is concave increasing while counts stay positive
-    int lo = 0, hi = (int)((G16 + 31) / 32);
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (unit_prefix(mid, G16) <= t && G16 - 32 * (int64_t)(mid - 1) > 0) lo = mid; else hi = mid - 1;
-    }
-    cb = lo;
-    g = 32 * (int64_t)lo + (t - unit_prefix(lo, G16));
-}
-
 // Latency is what matters in these three kernels (a few hundred KB of data per iteration): every
 // kernel issues all of its global loads up front, in as few dependent hops as possible.
 //
@@ -496,12 +481,6 @@ int njp_build(NjBuffers& b, hipStream_t s)
     const int64_t G16 = (N + kUR - 1) / kUR, S = (N + kTileCols - 1) / kTileCols + 1;
     q.nunits_alloc = S * G16;
     DPR_HIP(hipMalloc(&q.umin, sizeof(uint64_t) * (size_t)q.nunits_alloc));
-    DPR_HIP(hipMalloc(&q.gmax, sizeof(double) * (size_t)(G16 + 16)));
-    DPR_HIP(hipMalloc(&q.bmax, sizeof(double) * (size_t)((N + kThreads - 1) / kThreads + 2)));
-    DPR_HIP(hipMalloc(&q.seed, sizeof(uint64_t) * 8));
-    q.counters = q.seed + 1;   // [0] units scanned, [1+par] partial records, [3+par] listed units of the scan with parity par
-    const uint64_t init_seed[8] = { ~0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull };
-    DPR_HIP(hipMemcpyAsync(q.seed, init_seed, sizeof(init_seed), hipMemcpyHostToDevice, s));
     q.utot = unit_total(N);
     {
         // prep blocks: one strip and up to 256 consecutive row groups each (groups >= 32*cb see the strip)
@@ -542,7 +521,7 @@ int njp_build(NjBuffers& b, hipStream_t s)
 void njp_free(NjPruned& q)
 {
     if (q.graph) { (void)hipGraphExecDestroy(q.graph); q.graph = nullptr; }
-    void* ptrs[] = { q.D, q.U, q.Ur, q.KA, q.KB, q.slot_of_pos, q.pos_of_slot, q.perm, q.umin, q.gmax, q.bmax, q.seed, q.iterstats, q.list, q.blk_cb, q.blk_g0 };
+    void* ptrs[] = { q.D, q.U, q.Ur, q.KA, q.KB, q.slot_of_pos, q.pos_of_slot, q.perm, q.umin, q.iterstats, q.list, q.blk_cb, q.blk_g0 };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     q = NjPruned();
