@@ -81,8 +81,14 @@ def load_library():
     L.dpr_get_timing.argtypes = [C.c_void_p, c_f64p, c_f64p]
     L.dpr_place_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                 c_i32p, c_i32p, c_i32p, c_i32p, c_f64p]
+    L.dpr_dc_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int,
+                             c_i32p, c_i32p, c_i32p, c_i32p, c_f64p, c_i32p]
+    L.dpr_get_dc_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), c_f64p]
     _LIB = L
     return L
+
+
+DC_EXACT_LAST = 1
 
 
 def set_nj_mode(mode):
@@ -222,6 +228,28 @@ class Dipper:
         trace = np.zeros(3 * n, np.float64)
         _chk(self.L, self.L.dpr_get_place_state(self.h, _p(cid, c_i32p), _p(cdis, c_f64p), _p(trace, c_f64p)))
         st.update(cid=cid, cdis=cdis, trace=trace.reshape(n, 3))
+        return st
+
+    def dc_run(self, source, n, backbone, dist_type=1, k=15, flags=0):
+        """Divide-and-conquer mode (dpr_dc_run); returns the adjacency, closest lists, trace, cluster ids."""
+        st = dict(head=np.full(2 * n, -1, np.int32), e=np.full(8 * n, -1, np.int32),
+                  nxt=np.full(8 * n, -1, np.int32), belong=np.full(8 * n, -1, np.int32),
+                  len=np.full(8 * n, 2.0, np.float64))
+        cl = np.full(n, -1, np.int32)
+        _chk(self.L, self.L.dpr_dc_run(self.h, source, dist_type, k, n, backbone, flags, _p(st["head"], c_i32p),
+                                       _p(st["e"], c_i32p), _p(st["nxt"], c_i32p), _p(st["belong"], c_i32p),
+                                       _p(st["len"], c_f64p), _p(cl, c_i32p)))
+        cid = np.zeros(40 * n, np.int32)
+        cdis = np.zeros(40 * n, np.float64)
+        trace = np.zeros(3 * n, np.float64)
+        _chk(self.L, self.L.dpr_get_place_state(self.h, _p(cid, c_i32p), _p(cdis, c_f64p), _p(trace, c_f64p)))
+        counts = np.zeros(5, np.int64)
+        ms = np.zeros(3, np.float64)
+        _chk(self.L, self.L.dpr_get_dc_stats(self.h, counts.ctypes.data_as(C.POINTER(C.c_int64)), _p(ms, c_f64p)))
+        st.update(cid=cid, cdis=cdis, trace=trace.reshape(n, 3), cluster_id=cl,
+                  stats=dict(clusters=int(counts[0]), max_cluster=int(counts[1]), pairs=int(counts[2]),
+                             groups=int(counts[3]), jobs=int(counts[4]), backbone_ms=float(ms[0]),
+                             assign_ms=float(ms[1]), cluster_ms=float(ms[2])))
         return st
 
     def dist_matrix(self, source, dist_type=1, k=15):

@@ -70,6 +70,8 @@ struct dpr_ctx {
     int64_t n_input = 0;
     int have_matrix = 0;
     double dist_ms = 0, nj_ms = 0;
+    dpr::DcStats dc_stats;
+    double dc_ms[3] = { 0, 0, 0 };   // backbone, cluster assignment, cluster trees
 };
 
 using namespace dpr;
@@ -711,6 +713,45 @@ int dpr_get_timing(dpr_ctx* c, double* dist_ms, double* nj_ms)
     return DPR_OK;
 }
 
+// k-closest placement of tips [first, last) into c->place (findPlacementTree / addQuery loop,
+// src/placement_close_k.cu:756-851,888-987; findBackboneTreeDC, src/divide_and_conquer/
+// placement_close_k.cu:832-925): distance rows in batches of 256 from the row providers.
+// first == 2 starts from the two-tip tree, otherwise the imported backbone is already in the arrays.
+static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int64_t last)
+{
+    PlaceBuffers& p = c->place;
+    const int64_t R = 256;                       // distance rows per batch
+    const int64_t ldb = (last + 15) / 16 * 16;
+    double* rows = nullptr;
+    if (source != DPR_SRC_MATRIX) DPR_HIP(hipMalloc(&rows, sizeof(double) * (size_t)(R * ldb)));
+    auto row_ptr = [&](int64_t i, int64_t i0) -> const double* {
+        return source == DPR_SRC_MATRIX ? c->packed_lower + i * (i - 1) / 2 : rows + (i - i0) * ldb;
+    };
+    auto fill_rows = [&](int64_t i0, int64_t nr) -> int {
+        if (source == DPR_SRC_MSA) return msa_dist_block_rows(c->msa, i0, nr, 0, 0, i0 + nr, dist_type, rows, ldb, c->stream);
+        if (source == DPR_SRC_MASH) return mash_dist_rows(c->mash, i0, nr, 0, 0, false, i0 + nr, rows, ldb, c->stream);
+        return DPR_OK;
+    };
+    int rc = DPR_OK;
+    if (first == 2) {
+        rc = place_init_fresh(p, c->stream);
+        if (!rc) rc = fill_rows(1, 1);
+        if (!rc) rc = place_initial_tree(p, row_ptr(1, 1), c->stream);
+    } else {
+        rc = place_import_backbone(p, first, c->stream);
+    }
+    for (int64_t i0 = first; !rc && i0 < last; i0 += R) {
+        const int64_t nr = last - i0 < R ? last - i0 : R;
+        rc = fill_rows(i0, nr);
+        for (int64_t i = i0; !rc && i < i0 + nr; ++i) rc = place_tip(p, row_ptr(i, i0), i, c->place_trace, c->stream);
+    }
+    if (rows) {
+        if (!rc) (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(rows);
+    }
+    return rc;
+}
+
 int dpr_place_run(dpr_ctx* c, int source, int dist_type, int k, int64_t first, int64_t n, int32_t* head,
                   int32_t* e, int32_t* nxt, int32_t* belong, double* len)
 {
@@ -729,38 +770,15 @@ int dpr_place_run(dpr_ctx* c, int source, int dist_type, int k, int64_t first, i
     if (c->place_trace) { (void)hipFree(c->place_trace); c->place_trace = nullptr; }
     DPR_HIP(hipMalloc(&c->place_trace, sizeof(double) * (size_t)(3 * n)));
     DPR_HIP(hipMemsetAsync(c->place_trace, 0, sizeof(double) * (size_t)(3 * n), c->stream));
-    const int64_t R = 256;                       // distance rows per batch
-    const int64_t ldb = (n + 15) / 16 * 16;
-    double* rows = nullptr;
-    if (source != DPR_SRC_MATRIX) DPR_HIP(hipMalloc(&rows, sizeof(double) * (size_t)(R * ldb)));
-    auto row_ptr = [&](int64_t i, int64_t i0) -> const double* {
-        return source == DPR_SRC_MATRIX ? c->packed_lower + i * (i - 1) / 2 : rows + (i - i0) * ldb;
-    };
-    auto fill_rows = [&](int64_t i0, int64_t nr) -> int {
-        if (source == DPR_SRC_MSA) return msa_dist_block_rows(c->msa, i0, nr, 0, 0, i0 + nr, dist_type, rows, ldb, c->stream);
-        if (source == DPR_SRC_MASH) return mash_dist_rows(c->mash, i0, nr, 0, 0, false, i0 + nr, rows, ldb, c->stream);
-        return DPR_OK;
-    };
-    DPR_HIP(hipEventRecord(c->ev[2], c->stream));
-    int64_t start = first;
-    if (first == 2) {
-        if (int rc = place_init_fresh(p, c->stream)) return rc;
-        if (int rc = fill_rows(1, 1)) return rc;
-        if (int rc = place_initial_tree(p, row_ptr(1, 1), c->stream)) return rc;
-    } else {
+    if (first > 2) {
         DPR_HIP(hipMemcpyAsync(p.head, head, sizeof(int32_t) * (size_t)(2 * n), hipMemcpyHostToDevice, c->stream));
         DPR_HIP(hipMemcpyAsync(p.e, e, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyHostToDevice, c->stream));
         DPR_HIP(hipMemcpyAsync(p.nxt, nxt, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyHostToDevice, c->stream));
         DPR_HIP(hipMemcpyAsync(p.belong, belong, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyHostToDevice, c->stream));
         DPR_HIP(hipMemcpyAsync(p.len, len, sizeof(double) * (size_t)(8 * n), hipMemcpyHostToDevice, c->stream));
-        if (int rc = place_import_backbone(p, first, c->stream)) return rc;
     }
-    for (int64_t i0 = start; i0 < n; i0 += R) {
-        const int64_t nr = n - i0 < R ? n - i0 : R;
-        if (int rc = fill_rows(i0, nr)) return rc;
-        for (int64_t i = i0; i < i0 + nr; ++i)
-            if (int rc = place_tip(p, row_ptr(i, i0), i, c->place_trace, c->stream)) return rc;
-    }
+    DPR_HIP(hipEventRecord(c->ev[2], c->stream));
+    if (int rc = place_range(c, source, dist_type, first, n)) return rc;
     DPR_HIP(hipEventRecord(c->ev[3], c->stream));
     DPR_HIP(hipMemcpyAsync(head, p.head, sizeof(int32_t) * (size_t)(2 * n), hipMemcpyDeviceToHost, c->stream));
     DPR_HIP(hipMemcpyAsync(e, p.e, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
@@ -771,7 +789,108 @@ int dpr_place_run(dpr_ctx* c, int source, int dist_type, int k, int64_t first, i
     float ms = 0;
     DPR_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
     c->nj_ms = ms;
-    if (rows) (void)hipFree(rows);
+    return DPR_OK;
+}
+
+// ---- divide-and-conquer mode ------------------------------------------------------------------------
+int dpr_dc_run(dpr_ctx* c, int source, int dist_type, int k, int64_t n, int64_t backbone, int flags, int32_t* head,
+               int32_t* e, int32_t* nxt, int32_t* belong, double* len, int32_t* cluster_id)
+{
+    if (!c || !head || !e || !nxt || !belong || !len || n < 4) { set_error("dpr_dc_run: bad argument"); return DPR_ERR_ARG; }
+    if (backbone < 3 || backbone >= n) { set_error("dpr_dc_run: backbone size must be in [3, n)"); return DPR_ERR_ARG; }
+    DPR_HIP(hipSetDevice(c->device));
+    if (source == DPR_SRC_MSA) {
+        if (!c->msa.planes || c->msa.n != n) { set_error("dpr_dc_run: call dpr_set_msa with n sequences first"); return DPR_ERR_STATE; }
+    } else if (source == DPR_SRC_MASH) {
+        if (!c->mash.sketches || c->mash.n != n) { set_error("dpr_dc_run: call dpr_set_reads and dpr_sketch first"); return DPR_ERR_STATE; }
+        if (k != c->mash.k) { set_error("dpr_dc_run: k differs from the sketch k"); return DPR_ERR_ARG; }
+    } else {
+        // src/divide_and_conquer/placement_close_k.cu:969-972
+        set_error("dpr_dc_run: input must be unaligned or aligned sequences for the clustering based approach");
+        return DPR_ERR_ARG;
+    }
+    const int64_t B = backbone;
+    if (int rc = place_alloc(c->place, n, B)) return rc;
+    PlaceBuffers& p = c->place;
+    if (c->place_trace) { (void)hipFree(c->place_trace); c->place_trace = nullptr; }
+    DPR_HIP(hipMalloc(&c->place_trace, sizeof(double) * (size_t)(3 * n)));
+    DPR_HIP(hipMemsetAsync(c->place_trace, 0, sizeof(double) * (size_t)(3 * n), c->stream));
+    hipEvent_t ev[4];
+    for (auto& x : ev) DPR_HIP(hipEventCreate(&x));
+    int32_t* d_cl = nullptr;
+    double* dT = nullptr;
+    DcTable tab;
+    std::vector<int32_t> h_cl((size_t)n, -1);
+    auto run = [&]() -> int {
+        // ---- backbone tree: tips [0, B) (findBackboneTreeDC)
+        DPR_HIP(hipEventRecord(ev[0], c->stream));
+        if (int rc = place_range(c, source, dist_type, 2, B)) return rc;
+        DPR_HIP(hipEventRecord(ev[1], c->stream));
+        // ---- cluster assignment of tips [B, n) (findClustersDC)
+        if (int rc = dc_table_build(p, B, tab, c->stream)) return rc;
+        int64_t Q = ((int64_t)1 << 31) / (8 * B) / 256 * 256;
+        if (Q < 256) Q = 256;
+        if (Q > 8192) Q = 8192;
+        const int64_t nq = n - B;
+        if (Q > (nq + 255) / 256 * 256) Q = (nq + 255) / 256 * 256;
+        DPR_HIP(hipMalloc(&dT, sizeof(double) * (size_t)(B * Q)));
+        DPR_HIP(hipMalloc(&d_cl, sizeof(int32_t) * (size_t)n));
+        DPR_HIP(hipMemsetAsync(d_cl, 0xff, sizeof(int32_t) * (size_t)n, c->stream));
+        // the reference's aligned-input kernel never writes the distance to backbone tip B-1
+        // (src/divide_and_conquer/msa.cu:331 `idx>=ed-st`) and scans the 0.0 of a fresh allocation
+        const bool skip_last = source == DPR_SRC_MSA && !(flags & DPR_DC_EXACT_LAST);
+        for (int64_t i0 = B; i0 < n; i0 += Q) {
+            const int64_t nr = n - i0 < Q ? n - i0 : Q;
+            int rc;
+            if (source == DPR_SRC_MSA) rc = msa_dist_block_rows(c->msa, i0, nr, 0, 0, B, dist_type, dT, Q, c->stream, true);
+            else rc = mash_dist_rows(c->mash, i0, nr, 0, 0, false, B, dT, Q, c->stream, true);
+            if (rc) return rc;
+            if (skip_last) DPR_HIP(hipMemsetAsync(dT + (B - 1) * Q, 0, sizeof(double) * (size_t)Q, c->stream));
+            if (int rc2 = dc_assign(tab, dT, Q, (int)nr, d_cl + i0, c->stream)) return rc2;
+        }
+        DPR_HIP(hipMemcpyAsync(h_cl.data(), d_cl, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        DPR_HIP(hipEventRecord(ev[2], c->stream));
+        DPR_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(dT); dT = nullptr;
+        // trace column 0 of a query = its cluster
+        // ---- cluster trees (findClusterTreeDC)
+        size_t free_b = 0, total_b = 0;
+        DPR_HIP(hipMemGetInfo(&free_b, &total_b));
+        size_t budget = free_b / 2;
+        if (const char* env = std::getenv("DPR_DC_BUDGET_MB")) budget = (size_t)std::atoll(env) << 20;
+        if (int rc = dc_cluster_phase(p, h_cl.data(), n, B, source, dist_type, &c->msa, &c->mash, c->place_trace, budget,
+                                      &c->dc_stats, c->stream)) return rc;
+        DPR_HIP(hipEventRecord(ev[3], c->stream));
+        DPR_HIP(hipMemcpyAsync(head, p.head, sizeof(int32_t) * (size_t)(2 * n), hipMemcpyDeviceToHost, c->stream));
+        DPR_HIP(hipMemcpyAsync(e, p.e, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
+        DPR_HIP(hipMemcpyAsync(nxt, p.nxt, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
+        DPR_HIP(hipMemcpyAsync(belong, p.belong, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
+        DPR_HIP(hipMemcpyAsync(len, p.len, sizeof(double) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
+        DPR_HIP(hipStreamSynchronize(c->stream));
+        float ms = 0;
+        DPR_HIP(hipEventElapsedTime(&ms, ev[0], ev[1])); c->dc_ms[0] = ms;
+        DPR_HIP(hipEventElapsedTime(&ms, ev[1], ev[2])); c->dc_ms[1] = ms;
+        DPR_HIP(hipEventElapsedTime(&ms, ev[2], ev[3])); c->dc_ms[2] = ms;
+        c->nj_ms = c->dc_ms[0] + c->dc_ms[1] + c->dc_ms[2];
+        if (cluster_id) std::copy(h_cl.begin(), h_cl.end(), cluster_id);
+        return DPR_OK;
+    };
+    const int rc = run();
+    if (dT) (void)hipFree(dT);
+    if (d_cl) (void)hipFree(d_cl);
+    dc_table_free(tab);
+    for (auto& x : ev) (void)hipEventDestroy(x);
+    return rc;
+}
+
+int dpr_get_dc_stats(dpr_ctx* c, int64_t* counts5, double* phase_ms3)
+{
+    if (!c) { set_error("dpr_get_dc_stats: null ctx"); return DPR_ERR_ARG; }
+    if (counts5) {
+        counts5[0] = c->dc_stats.clusters; counts5[1] = c->dc_stats.max_cluster; counts5[2] = c->dc_stats.pairs;
+        counts5[3] = c->dc_stats.groups; counts5[4] = c->dc_stats.jobs;
+    }
+    if (phase_ms3) for (int i = 0; i < 3; ++i) phase_ms3[i] = c->dc_ms[i];
     return DPR_OK;
 }
 

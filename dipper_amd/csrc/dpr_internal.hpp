@@ -148,6 +148,24 @@ void njp_free(NjPruned& q);
 int njp_scan_grid();
 int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s);   // enqueue `todo` iterations (hipGraph replays)
 
+// Divide-and-conquer cluster distances (dc.hip builds the jobs; msa.hip / mash.hip run them).
+// Cluster ci has cl_m[ci] members (tip ids members[cl_moff[ci] + t], ascending) and a leaf list
+// cols[cl_coff[ci] + u], u < kDcLeaves + m: the 2 x 5 closest leaves of the cluster edge and of its
+// reverse (-1 = empty list entry), then the members.  Element (t, u), u < kDcLeaves + t, of its
+// distance block is out[cl_out[ci] + t * cl_ld[ci] + u] = distance(row tip members[t], column tip cols[u]).
+constexpr int kDcLeaves = 10;
+struct PairJobs {
+    const int4* jobs;          // (cluster, first row t0, first column u0, -)
+    const int32_t* members;
+    const int32_t* cols;
+    const int64_t* cl_moff;
+    const int32_t* cl_m;
+    const int64_t* cl_coff;
+    const int64_t* cl_out;
+    const int32_t* cl_ld;
+    double* out;
+};
+
 // msa.hip
 struct MsaBuffers {
     uint32_t* planes = nullptr;  // [3][n][W32]: valid, lo, hi bit planes, 32 bases per word
@@ -156,6 +174,7 @@ struct MsaBuffers {
 int msa_upload(MsaBuffers& m, const uint64_t* packed4, int64_t n, int64_t L, hipStream_t s);
 void msa_free(MsaBuffers& m);
 int msa_dist_rows(const MsaBuffers& m, NjBuffers& b, int dist_type, hipStream_t s);
+int msa_dist_tile_edge(int dist_type);   // rows/columns per job tile of msa_dist_jobs
 int msa_counts_row(const MsaBuffers& m, int64_t row, int32_t* d_useful, int32_t* d_match, hipStream_t s);
 
 // mash.hip
@@ -175,17 +194,23 @@ int mash_sketch(MashBuffers& m, int k, int S, hipStream_t s);
 // rows r0..r0+nr (world > 0: owned local rows of (rank,world); world == 0: plain tip ids) x columns
 // [0,ncols) -> out[t*ld + j]; full = also j >= i
 int mash_dist_rows(const MashBuffers& m, int64_t r0, int64_t nr, int rank, int world, bool full,
-                   int64_t ncols, double* out, int64_t ld, hipStream_t s);
+                   int64_t ncols, double* out, int64_t ld, hipStream_t s, bool transposed = false);
+int mash_dist_jobs(const MashBuffers& m, const PairJobs& J, int njobs, hipStream_t s);
+int mash_jobs_rows();   // members per job
+int mash_jobs_cols();   // leaf-list positions per job
 int mash_hash_positions(const MashBuffers& m, int64_t seq, int k, uint64_t* d_out, uint64_t len, uint64_t word_off,
                         hipStream_t s);
 
 // msa.hip: same row-provider shape as mash_dist_rows
+// transposed: out[j * ld + t] instead of out[t * ld + j]
 int msa_dist_block_rows(const MsaBuffers& m, int64_t r0, int64_t nr, int rank, int world, int64_t ncols,
-                        int dist_type, double* out, int64_t ld, hipStream_t s);
+                        int dist_type, double* out, int64_t ld, hipStream_t s, bool transposed = false);
+int msa_dist_jobs(const MsaBuffers& m, int dist_type, const PairJobs& J, int njobs, hipStream_t s);
 
 // place.hip
 struct PlaceBuffers {
-    int64_t N = 0;
+    int64_t N = 0;   // tips the arrays are sized for; internal node ids start at N
+    int64_t M = 0;   // tips of the edge scan's slot range (4M-4 slots): N, or the backbone size in DC mode
     int32_t *head = nullptr, *e = nullptr, *nxt = nullptr, *belong = nullptr, *rev = nullptr, *cid = nullptr;
     double *len = nullptr, *cdis = nullptr;
     int32_t *q_id = nullptr, *q_from = nullptr;
@@ -193,11 +218,31 @@ struct PlaceBuffers {
     void* partials = nullptr;
     int nparts_max = 0;
 };
-int place_alloc(PlaceBuffers& p, int64_t N);
+int place_alloc(PlaceBuffers& p, int64_t N, int64_t M = 0);   // M = 0: M = N
 void place_free(PlaceBuffers& p);
 int place_init_fresh(PlaceBuffers& p, hipStream_t s);
 int place_initial_tree(PlaceBuffers& p, const double* d_dis_row1, hipStream_t s);
 int place_import_backbone(PlaceBuffers& p, int64_t m, hipStream_t s);
 int place_tip(PlaceBuffers& p, const double* d_dis, int64_t tip, double* d_trace, hipStream_t s);
+
+// dc.hip: divide-and-conquer mode (cluster assignment + concurrent cluster trees)
+struct DcTable {
+    int nv = 0;                    // eligible backbone slots (belong >= e), ascending
+    int32_t* vslots = nullptr;
+    int32_t* et_cid = nullptr;     // [nv][10] closest ids: own list, reverse list
+    double* et_cdis = nullptr;     // [nv][10]
+    double* et_len = nullptr;      // [nv]
+    double* part_add = nullptr;    // [chunks][ldq] per-chunk first minima
+    int32_t* part_pos = nullptr;
+    size_t part_cap = 0;
+};
+struct DcStats { int64_t clusters = 0, max_cluster = 0, pairs = 0, groups = 0, jobs = 0; };
+int dc_table_build(PlaceBuffers& p, int64_t B, DcTable& t, hipStream_t s);
+void dc_table_free(DcTable& t);
+// dT[c * ldq + q] = distance(query q of the batch, backbone tip c); d_cluster_id[q] = chosen slot
+int dc_assign(DcTable& t, const double* dT, int64_t ldq, int Q, int32_t* d_cluster_id, hipStream_t s);
+int dc_cluster_phase(PlaceBuffers& p, const int32_t* h_cluster_id, int64_t N, int64_t B, int source, int dist_type,
+                     const MsaBuffers* msa, const MashBuffers* mash, double* d_trace, size_t budget_bytes,
+                     DcStats* stats, hipStream_t s);
 
 }  // namespace dpr

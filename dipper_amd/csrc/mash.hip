@@ -205,31 +205,56 @@ constexpr int kLThreads = 512;       // 8 waves
 constexpr int kLColsPerBlock = 512;
 constexpr int kLBuckets = 1024;
 
+// JOBS = false: rows r0 + [0, nr) (tip ids) x columns [0, ncols), pairs with column id < row id;
+//   out[t * ld + j], transposed: out[j * ld + t] (t = row - r0); mirror: also out[j * ld + row].
+// JOBS = true: divide-and-conquer cluster blocks (PairJobs, dpr_internal.hpp): job = (cluster, first
+//   member t0, first leaf-list position u0); pair (t, u) with u < kDcLeaves + t.
+template <bool JOBS>
 __global__ __launch_bounds__(kLThreads) void mash_dist_lookup_kernel(const uint64_t* __restrict__ sk, int S, int k,
-                                                                     int64_t n, int64_t r0, int64_t nr, int world,
+                                                                     int64_t n, int64_t r0, int64_t nr,
                                                                      int64_t ncols, double* __restrict__ out,
-                                                                     int64_t ld, int mirror)
+                                                                     int64_t ld, int mirror, int transposed,
+                                                                     PairJobs J)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* vals = reinterpret_cast<uint64_t*>(smem);                              // [kLRows][kLS]
     uint32_t* bucket = reinterpret_cast<uint32_t*>(vals + kLRows * kLS);             // [kLRows][kLBuckets + 1]
     __shared__ int s_shift[kLRows];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int64_t t0 = (int64_t)blockIdx.y * kLRows;
-    const int64_t cbeg = (int64_t)blockIdx.x * kLColsPerBlock;
-    const int64_t cend = min(ncols, cbeg + kLColsPerBlock);
-    int64_t irow[kLRows];
-    int64_t imax = -1;
+    int64_t t0, cbeg, cend;
+    int64_t irow[kLRows];     // tip id of the resident rows (-1: none)
+    int64_t rlim[kLRows];     // row r takes column positions < rlim[r]
+    int64_t imax = -1;        // largest rlim
+    const int32_t* colids = nullptr;
+    if (JOBS) {
+        const int4 job = J.jobs[blockIdx.x];
+        const int ci = job.x, m = J.cl_m[ci];
+        t0 = job.y; cbeg = job.z;
+        colids = J.cols + J.cl_coff[ci];
+        out = J.out + J.cl_out[ci];
+        ld = J.cl_ld[ci];
 #pragma unroll
-    for (int r = 0; r < kLRows; ++r) {
-        const int64_t tt = t0 + r;
-        int64_t i = -1;
-        if (tt < nr) { i = r0 + tt; if (i >= n) i = -1; }
-        irow[r] = i;
-        imax = max(imax, i);
+        for (int r = 0; r < kLRows; ++r) {
+            const int64_t tt = t0 + r;
+            irow[r] = tt < m ? J.members[J.cl_moff[ci] + tt] : -1;
+            rlim[r] = tt < m ? kDcLeaves + tt : -1;
+            imax = max(imax, rlim[r]);
+        }
+        cend = min(imax, cbeg + kLColsPerBlock);
+    } else {
+        t0 = (int64_t)blockIdx.y * kLRows;
+        cbeg = (int64_t)blockIdx.x * kLColsPerBlock;
+        cend = min(ncols, cbeg + kLColsPerBlock);
+#pragma unroll
+        for (int r = 0; r < kLRows; ++r) {
+            const int64_t tt = t0 + r;
+            int64_t i = -1;
+            if (tt < nr) { i = r0 + tt; if (i >= n) i = -1; }
+            irow[r] = i; rlim[r] = i;
+            imax = max(imax, i);
+        }
     }
-    (void)world;
-    if (imax < 0 || cbeg >= imax) return;   // nothing below the diagonal in this column range
+    if (imax < 0 || cbeg >= imax) return;   // nothing to do in this column range
 
     // ---- resident row structures
     for (int e = tid; e < kLRows * kLS; e += kLThreads) {
@@ -256,10 +281,12 @@ __global__ __launch_bounds__(kLThreads) void mash_dist_lookup_kernel(const uint6
     }
     __syncthreads();
 
-    // ---- stream the columns: wave w takes column c0 + w
+    // ---- stream the columns: wave w takes column position c0 + w
     for (int64_t c0 = cbeg; c0 < cend && c0 < imax; c0 += kLThreads / 64) {
-        const int64_t j = c0 + w;
-        if (j >= cend || j >= imax) continue;
+        const int64_t jpos = c0 + w;
+        if (jpos >= cend || jpos >= imax) continue;
+        const int64_t j = JOBS ? (int64_t)colids[jpos] : jpos;
+        if (j < 0) continue;                                     // empty leaf-list entry (wave-uniform)
         uint64_t a[16];
         const uint64_t* col = sk + j * S + 16 * lane;
 #pragma unroll
@@ -268,8 +295,7 @@ __global__ __launch_bounds__(kLThreads) void mash_dist_lookup_kernel(const uint6
         const bool has_prev = lane > 0;
 #pragma unroll 1
         for (int r = 0; r < kLRows; ++r) {
-            const int64_t i = irow[r];
-            if (i < 0 || j >= i) continue;                       // wave-uniform
+            if (irow[r] < 0 || jpos >= rlim[r]) continue;        // wave-uniform
             const uint64_t* v = vals + r * kLS;
             const uint32_t* bk = bucket + r * (kLBuckets + 1);
             const int sh = s_shift[r];
@@ -336,8 +362,11 @@ __global__ __launch_bounds__(kLThreads) void mash_dist_lookup_kernel(const uint6
             if (lane == 0) {
                 const double jac = fmax((double)cnt, 1.0) / S;
                 const double d = fmin(1.0, fabs(log(2.0 * jac / (1.0 + jac)) / (double)k));
-                out[(t0 + r) * ld + j] = d;
-                if (mirror) out[j * ld + (r0 + t0 + r)] = d;
+                if (JOBS) out[(t0 + r) * ld + jpos] = d;
+                else {
+                    if (transposed) out[j * ld + (t0 + r)] = d; else out[(t0 + r) * ld + j] = d;
+                    if (mirror) out[j * ld + (r0 + t0 + r)] = d;
+                }
             }
         }
     }
@@ -396,23 +425,48 @@ int mash_sketch(MashBuffers& m, int k, int S, hipStream_t s)
     return DPR_OK;
 }
 
+static int lookup_attr()
+{
+    static bool attr_set = false;
+    const size_t tlds = sizeof(uint64_t) * kLRows * kLS + sizeof(uint32_t) * kLRows * (kLBuckets + 1);
+    if (!attr_set) {
+        DPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mash_dist_lookup_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+        DPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mash_dist_lookup_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+        attr_set = true;
+    }
+    return DPR_OK;
+}
+
+int mash_jobs_rows() { return kLRows; }
+int mash_jobs_cols() { return kLColsPerBlock; }
+
+int mash_dist_jobs(const MashBuffers& m, const PairJobs& J, int njobs, hipStream_t s)
+{
+    if (njobs <= 0) return DPR_OK;
+    if (m.S > kLS) { set_error("divide-and-conquer mode needs a sketch size <= 1024"); return DPR_ERR_ARG; }
+    if (int rc = lookup_attr()) return rc;
+    const size_t tlds = sizeof(uint64_t) * kLRows * kLS + sizeof(uint32_t) * kLRows * (kLBuckets + 1);
+    hipLaunchKernelGGL(mash_dist_lookup_kernel<true>, dim3((unsigned)njobs), dim3(kLThreads), tlds, s, m.sketches, m.S,
+                       m.k, m.n, (int64_t)0, (int64_t)0, (int64_t)0, (double*)nullptr, (int64_t)0, 0, 0, J);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
 int mash_dist_rows(const MashBuffers& m, int64_t r0, int64_t nr, int rank, int world, bool full,
-                   int64_t ncols, double* out, int64_t ld, hipStream_t s)
+                   int64_t ncols, double* out, int64_t ld, hipStream_t s, bool transposed)
 {
     if (nr <= 0 || ncols <= 0) return DPR_OK;
+    if (transposed && (full || world > 1 || m.S > kLS)) { set_error("mash_dist_rows: transposed output needs the lookup kernel"); return DPR_ERR_ARG; }
     // lower-triangle pairs (placement batches; single-GPU NJ with a mirror write): lookup kernel
     const bool mirror = full && world == 1 && r0 == 0;
-    if (m.S <= kLS && (!full || mirror) && world <= 1 && !std::getenv("DPR_MASH_SIMPLE")) {
-        static bool attr_set = false;
+    if (m.S <= kLS && (!full || mirror) && world <= 1 && (transposed || !std::getenv("DPR_MASH_SIMPLE"))) {
+        if (int rc = lookup_attr()) return rc;
         const size_t tlds = sizeof(uint64_t) * kLRows * kLS + sizeof(uint32_t) * kLRows * (kLBuckets + 1);
-        if (!attr_set) {
-            DPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mash_dist_lookup_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
-            attr_set = true;
-        }
         dim3 tgrid((unsigned)((ncols + kLColsPerBlock - 1) / kLColsPerBlock), (unsigned)((nr + kLRows - 1) / kLRows));
-        hipLaunchKernelGGL(mash_dist_lookup_kernel, tgrid, dim3(kLThreads), tlds, s, m.sketches, m.S, m.k, m.n, r0, nr,
-                           world, ncols, out, ld, mirror ? 1 : 0);
+        hipLaunchKernelGGL(mash_dist_lookup_kernel<false>, tgrid, dim3(kLThreads), tlds, s, m.sketches, m.S, m.k, m.n, r0,
+                           nr, ncols, out, ld, mirror ? 1 : 0, transposed ? 1 : 0, PairJobs());
         DPR_HIP(hipGetLastError());
         return DPR_OK;
     }

@@ -13,7 +13,6 @@
 
 namespace dpr {
 
-constexpr int kPT = 64;   // pairs tile edge (64 rows x 64 cols per block)
 constexpr int kKC = 16;   // plane words (32 bases each) staged per step
 
 __global__ __launch_bounds__(kThreads) void msa_planes_kernel(const uint64_t* __restrict__ packed4,
@@ -54,47 +53,129 @@ __device__ __forceinline__ double msa_epilogue(int useful, int match, int dist_t
     return -0.75 * log(1.0 - uncor / 0.75);
 }
 
-// Block = 64 owned rows x 64 columns; thread (ty,tx) of 16x16 owns rows ty*4.., cols tx*4..
-// LDS: [side][plane][k][64 sequences] so that four consecutive sequences are one 16-byte read.
-__global__ __launch_bounds__(kThreads) void msa_dist_kernel(const uint32_t* __restrict__ planes,
-                                                            int64_t n, int64_t W32, int dist_type,
-                                                            double* __restrict__ D, int64_t ld,
-                                                            int64_t rows_local, int rank, int world,
-                                                            int64_t row0)
-{
-    // rows padded to 68 words: the staging writes (consecutive lanes = consecutive k) then hit 8 banks
-    // two ways instead of one bank sixteen ways; 68*4 B keeps the 16-byte reads aligned
-    __shared__ __attribute__((aligned(16))) uint32_t sA[3][kKC][kPT + 4];
-    __shared__ __attribute__((aligned(16))) uint32_t sB[3][kKC][kPT + 4];
+// ------------------------------------------------------------------------------------------------
+// Pair counters.  Types 1-2: useful / match (above).  Types 3-6 (Tajima-Nei, K2P, Tamura,
+// Jin-Nei): formulas and counters of src/divide_and_conquer/msa.cu:107-217 (counts), :238-265
+// (epilogues); the copies in src/MSA.cu index with the wrong variable.  Only sites valid
+// in BOTH sequences count.  With the planes (code = 2*HI + LO; A,C,G,T = 0..3), per 32 bases of a
+// (row r, column c) pair:
+//   both = Vr & Vc                      tot   += popc(both)
+//   eq   = both & ~((LOr^LOc)|(HIr^HIc))          (match)
+//   transitions  p: mismatch & ~(LOr^LOc)   (same parity), transversions q: mismatch & (LOr^LOc)
+//   C or G       : HI ^ LO               (Tamura's gc1 = row, gc2 = column, mismatching sites only)
+//   Tajima-Nei pair classes {A,G},{A,T},{C,G},{C,T} and base counts over both sequences.
+// ------------------------------------------------------------------------------------------------
+template <int TYPE>
+struct PairCounts {
+    int tot = 0, eq = 0, p = 0, q = 0, gc1 = 0, gc2 = 0;
+    int fA = 0, fC = 0, fG = 0;   // base counts over both sequences (T = 2*tot - others)
+    int pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0;
+    __device__ __forceinline__ void add(uint32_t vr, uint32_t lr, uint32_t hr, uint32_t vc, uint32_t lc, uint32_t hc)
+    {
+        const uint32_t both = vr & vc;
+        const uint32_t dl = lr ^ lc, dh = hr ^ hc;
+        const uint32_t e = both & ~(dl | dh);
+        const uint32_t mis = both & ~e;
+        tot += __popc(both);
+        if (TYPE == DPR_DIST_TAJIMANEI) {
+            eq += __popc(e);
+            fA += __popc(both & ~hr & ~lr) + __popc(both & ~hc & ~lc);
+            fC += __popc(both & ~hr & lr) + __popc(both & ~hc & lc);
+            fG += __popc(both & hr & ~lr) + __popc(both & hc & ~lc);
+            pr0 += __popc(both & ~lr & ~lc & dh);          // {A,G}
+            pr1 += __popc(both & dh & dl & ~(hr ^ lr));    // {A,T}
+            pr2 += __popc(both & dh & dl & (hr ^ lr));     // {C,G}
+            pr3 += __popc(both & lr & lc & dh);            // {C,T}
+        } else {
+            p += __popc(mis & ~dl);
+            q += __popc(mis & dl);
+            if (TYPE == DPR_DIST_TAMURA) {
+                gc1 += __popc(mis & (hr ^ lr));
+                gc2 += __popc(mis & (hc ^ lc));
+            }
+        }
+    }
+    __device__ __forceinline__ double value(int) const
+    {
+        if (TYPE == DPR_DIST_TAJIMANEI) {
+            const int frac[4] = { fA, fC, fG, 2 * tot - fA - fC - fG };
+            double fr[4];
+            for (int i = 0; i < 4; ++i) fr[i] = double(frac[i]) / tot / 2.0;
+            double h = 0;
+            h += 0.5 * pr0 * fr[0] * fr[2];
+            h += 0.5 * pr1 * fr[0] * fr[3];
+            h += 0.5 * pr2 * fr[1] * fr[2];
+            h += 0.5 * pr3 * fr[1] * fr[3];
+            const double D = double(tot - eq) / tot;
+            const double b = 0.5 * (1.0 - fr[0] * fr[0] - fr[2] * fr[2] + D * D / h);
+            return -b * log(1.0 - D / b);
+        }
+        const double pp = double(p) / tot, qq = double(q) / tot;
+        if (TYPE == DPR_DIST_K2P) return -0.5 * log((1 - 2 * pp - qq) * sqrt(1 - 2 * qq));
+        if (TYPE == DPR_DIST_JINNEI) return 0.5 * (1.0 / (1 - 2 * pp - qq) + 0.5 / (1 - qq * 2) - 1.5);
+        const double c = double(gc1) / tot + double(gc2) / tot - 2 * double(gc1) * double(gc2) / tot / tot;
+        return -c * log(1 - pp / c - qq) - 0.5 * (1 - c) * log(1 - 2 * qq);
+    }
+};
+// types 1 and 2 share one instantiation (TYPE = DPR_DIST_JC), the formula is picked at run time
+template <>
+struct PairCounts<DPR_DIST_JC> {
+    int useful = 0, match = 0;
+    __device__ __forceinline__ void add(uint32_t vr, uint32_t lr, uint32_t hr, uint32_t vc, uint32_t lc, uint32_t hc)
+    {
+        useful += __popc(vr | vc);
+        const uint32_t diff = (lr ^ lc) | (hr ^ hc);
+        match += __popc(vr & vc & ~diff);
+    }
+    __device__ __forceinline__ double value(int dist_type) const { return msa_epilogue(useful, match, dist_type); }
+};
 
+template <int TYPE> struct TileOf { static constexpr int SUB = 2; };              // 32 x 32 pairs, 2 x 2 per thread
+template <> struct TileOf<DPR_DIST_JC> { static constexpr int SUB = 4; };         // 64 x 64 pairs, 4 x 4 per thread
+
+// What a block computes: up to PT row sequences x PT column sequences (ids in LDS, -1 = none) and
+// where the PT x PT tile of distances goes.
+constexpr int64_t kNoDiag = (int64_t)1 << 40;
+struct TileOut {
+    double* out;        // element (r, c) of the tile -> out[r * ld + c]            (row-major target)
+    int64_t ld;
+    int nr, nc;         // valid rows / columns of the tile
+    int lower_base;     // >= 0: keep only c_pos < lower_base + r_pos (tile-local positions + tile origins below)
+    int r_org, c_org;   // positions of the tile origin inside its job (for lower_base)
+    double* mir;        // != nullptr: also element (r, c) -> mir[c * mir_ld + r]  (mirror / transposed target)
+    int64_t mir_ld;
+    bool skip_main;     // only the transposed target is written
+    int64_t diag;       // element (r, c) with r + diag == c is a tip against itself -> 0 (kNoDiag: none)
+};
+
+// Block of 256 threads = 16 x 16; thread (ty,tx) owns rows ty*SUB.., cols tx*SUB..
+// LDS: [side][plane][k][PT (+4) sequences] so that SUB consecutive sequences are one 16/8-byte read;
+// rows padded by 4 words: the staging writes (consecutive lanes = consecutive k) then hit 8 banks two
+// ways instead of one bank sixteen ways.  The same memory is reused for the PT x PT tile of
+// distances, which is then written with full-row coalescing in both orientations.
+template <int TYPE>
+__device__ __forceinline__ void msa_tile(const uint32_t* __restrict__ planes, int64_t n, int64_t W32, int dist_type,
+                                         const int32_t* s_rid, const int32_t* s_cid, const TileOut& o, char* smem)
+{
+    constexpr int SUB = TileOf<TYPE>::SUB, PT = 16 * SUB, LDP = PT + 4;
+    typedef uint32_t (*Stage)[kKC][LDP];
+    Stage sA = reinterpret_cast<Stage>(smem);
+    Stage sB = reinterpret_cast<Stage>(smem + sizeof(uint32_t) * 3 * kKC * LDP);
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
-    const int64_t l0 = (int64_t)blockIdx.y * kPT;   // local row block (== ownership block)
-    const int64_t c0 = (int64_t)blockIdx.x * kPT;   // global column block
-    // world > 0: rows are the owned rows of (rank, world); world == 0: plain tip ids row0 + l
-    const int64_t g0 = world > 0 ? shard_global_row(l0, rank, world) : row0 + l0;
-    // single GPU, whole matrix: tiles strictly above the diagonal are produced by their mirror tile
-    const bool mirror = (world == 1);
-    if (mirror && c0 > g0 + kPT - 1) return;
-
-    int useful[4][4], match[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { useful[r][c] = 0; match[r][c] = 0; }
-
+    PairCounts<TYPE> acc[SUB][SUB];
     for (int64_t k0 = 0; k0 < W32; k0 += kKC) {
-        // stage: 2 sides x 3 planes x 64 seqs x 16 words = 6144 words, 24 per thread.
-        // consecutive lanes read consecutive words of one sequence (64-byte runs).
-        for (int e = tid; e < 3 * kPT * kKC; e += kThreads) {
-            const int p = e / (kPT * kKC), rem = e % (kPT * kKC);
+        // stage: 2 sides x 3 planes x PT seqs x 16 words; consecutive lanes read consecutive words of
+        // one sequence (64-byte runs)
+        for (int e = tid; e < 3 * PT * kKC; e += kThreads) {
+            const int p = e / (PT * kKC), rem = e % (PT * kKC);
             const int sq = rem / kKC, kk = rem % kKC;
             const int64_t k = k0 + kk;
-            const int64_t ga = g0 + sq, gb = c0 + sq;
+            const int64_t ga = s_rid[sq], gb = s_cid[sq];
             uint32_t va = 0, vb = 0;
             if (k < W32) {
-                if (ga < n && l0 + sq < rows_local) va = planes[((int64_t)p * n + ga) * W32 + k];
-                if (gb < n) vb = planes[((int64_t)p * n + gb) * W32 + k];
+                if (ga >= 0) va = planes[((int64_t)p * n + ga) * W32 + k];
+                if (gb >= 0) vb = planes[((int64_t)p * n + gb) * W32 + k];
             }
             sA[p][kk][sq] = va;
             sB[p][kk][sq] = vb;
@@ -102,180 +183,178 @@ __global__ __launch_bounds__(kThreads) void msa_dist_kernel(const uint32_t* __re
         __syncthreads();
 #pragma unroll 4
         for (int kk = 0; kk < kKC; ++kk) {
-            const uint4 aV = *reinterpret_cast<const uint4*>(&sA[0][kk][ty * 4]);
-            const uint4 aL = *reinterpret_cast<const uint4*>(&sA[1][kk][ty * 4]);
-            const uint4 aH = *reinterpret_cast<const uint4*>(&sA[2][kk][ty * 4]);
-            const uint4 bV = *reinterpret_cast<const uint4*>(&sB[0][kk][tx * 4]);
-            const uint4 bL = *reinterpret_cast<const uint4*>(&sB[1][kk][tx * 4]);
-            const uint4 bH = *reinterpret_cast<const uint4*>(&sB[2][kk][tx * 4]);
-            const uint32_t av[4] = { aV.x, aV.y, aV.z, aV.w }, al[4] = { aL.x, aL.y, aL.z, aL.w },
-                           ah[4] = { aH.x, aH.y, aH.z, aH.w };
-            const uint32_t bv[4] = { bV.x, bV.y, bV.z, bV.w }, bl[4] = { bL.x, bL.y, bL.z, bL.w },
-                           bh[4] = { bH.x, bH.y, bH.z, bH.w };
+            uint32_t av[SUB], al[SUB], ah[SUB], bv[SUB], bl[SUB], bh[SUB];
+            if (SUB == 4) {
+                const uint4 aV = *reinterpret_cast<const uint4*>(&sA[0][kk][ty * 4]);
+                const uint4 aL = *reinterpret_cast<const uint4*>(&sA[1][kk][ty * 4]);
+                const uint4 aH = *reinterpret_cast<const uint4*>(&sA[2][kk][ty * 4]);
+                const uint4 bV = *reinterpret_cast<const uint4*>(&sB[0][kk][tx * 4]);
+                const uint4 bL = *reinterpret_cast<const uint4*>(&sB[1][kk][tx * 4]);
+                const uint4 bH = *reinterpret_cast<const uint4*>(&sB[2][kk][tx * 4]);
+                av[0] = aV.x; av[1] = aV.y; av[SUB - 2] = aV.z; av[SUB - 1] = aV.w;
+                al[0] = aL.x; al[1] = aL.y; al[SUB - 2] = aL.z; al[SUB - 1] = aL.w;
+                ah[0] = aH.x; ah[1] = aH.y; ah[SUB - 2] = aH.z; ah[SUB - 1] = aH.w;
+                bv[0] = bV.x; bv[1] = bV.y; bv[SUB - 2] = bV.z; bv[SUB - 1] = bV.w;
+                bl[0] = bL.x; bl[1] = bL.y; bl[SUB - 2] = bL.z; bl[SUB - 1] = bL.w;
+                bh[0] = bH.x; bh[1] = bH.y; bh[SUB - 2] = bH.z; bh[SUB - 1] = bH.w;
+            } else {
+                const uint2 aV = *reinterpret_cast<const uint2*>(&sA[0][kk][ty * 2]);
+                const uint2 aL = *reinterpret_cast<const uint2*>(&sA[1][kk][ty * 2]);
+                const uint2 aH = *reinterpret_cast<const uint2*>(&sA[2][kk][ty * 2]);
+                const uint2 bV = *reinterpret_cast<const uint2*>(&sB[0][kk][tx * 2]);
+                const uint2 bL = *reinterpret_cast<const uint2*>(&sB[1][kk][tx * 2]);
+                const uint2 bH = *reinterpret_cast<const uint2*>(&sB[2][kk][tx * 2]);
+                av[0] = aV.x; av[1] = aV.y; al[0] = aL.x; al[1] = aL.y; ah[0] = aH.x; ah[1] = aH.y;
+                bv[0] = bV.x; bv[1] = bV.y; bl[0] = bL.x; bl[1] = bL.y; bh[0] = bH.x; bh[1] = bH.y;
+            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < SUB; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    useful[r][c] += __popc(av[r] | bv[c]);
-                    const uint32_t diff = (al[r] ^ bl[c]) | (ah[r] ^ bh[c]);
-                    match[r][c] += __popc(av[r] & bv[c] & ~diff);
-                }
+                for (int c = 0; c < SUB; ++c) acc[r][c].add(av[r], al[r], ah[r], bv[c], bl[c], bh[c]);
         }
         __syncthreads();
     }
-
+    // distances into the LDS tile (row stride PT+1 doubles), then coalesced rows in both orientations
+    double* T = reinterpret_cast<double*>(smem);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int64_t li = l0 + ty * 4 + r;
-        const int64_t gi = g0 + ty * 4 + r;
-        if (li >= rows_local || gi >= n) continue;
+    for (int r = 0; r < SUB; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int64_t gj = c0 + tx * 4 + c;
-            if (gj >= n) continue;
-            const double d = (gi == gj) ? 0.0 : msa_epilogue(useful[r][c], match[r][c], dist_type);
-            D[li * ld + gj] = d;
-            if (mirror && c0 + kPT - 1 < g0) D[gj * ld + gi] = d;   // counts are symmetric (src/MSA.cu:121-122)
+        for (int c = 0; c < SUB; ++c) {
+            const int rr = ty * SUB + r, cc = tx * SUB + c;
+            double d = 0.0;
+            if (rr < o.nr && cc < o.nc && rr + o.diag != cc) d = acc[r][c].value(dist_type);
+            T[rr * (PT + 1) + cc] = d;
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Distance types 3-6 (Tajima-Nei, K2P, Tamura, Jin-Nei): formulas and counters of
-// src/divide_and_conquer/msa.cu:107-217 (counts), :238-265 (epilogues); the copies in src/MSA.cu
-// index with the wrong variable.  Only sites valid in BOTH sequences count.
-// With the planes (code = 2*HI + LO; A,C,G,T = 0..3), per 32 bases of a (row r, column c) pair:
-//   both = Vr & Vc                      tot   += popc(both)
-//   eq   = both & ~((LOr^LOc)|(HIr^HIc))          (match)
-//   transitions  p: mismatch & ~(LOr^LOc)   (same parity), transversions q: mismatch & (LOr^LOc)
-//   C or G       : HI ^ LO               (Tamura's gc1 = row, gc2 = column, mismatching sites only)
-//   Tajima-Nei pair classes {A,G},{A,T},{C,G},{C,T} and base counts over both sequences.
-// Block = 32 x 32 pairs, thread (ty,tx) of 16 x 16 owns a 2 x 2 sub-tile.
-// ------------------------------------------------------------------------------------------------
-constexpr int kET = 32;
-
-template <int TYPE>
-struct ExtCounts {
-    int tot = 0, eq = 0, p = 0, q = 0, gc1 = 0, gc2 = 0;
-    int fA = 0, fC = 0, fG = 0;   // base counts over both sequences (T = 2*tot - others)
-    int pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0;
-};
-
-template <int TYPE>
-__device__ __forceinline__ void ext_accum(ExtCounts<TYPE>& k, uint32_t vr, uint32_t lr, uint32_t hr, uint32_t vc,
-                                          uint32_t lc, uint32_t hc)
-{
-    const uint32_t both = vr & vc;
-    const uint32_t dl = lr ^ lc, dh = hr ^ hc;
-    const uint32_t eq = both & ~(dl | dh);
-    const uint32_t mis = both & ~eq;
-    k.tot += __popc(both);
-    if (TYPE == DPR_DIST_TAJIMANEI) {
-        k.eq += __popc(eq);
-        k.fA += __popc(both & ~hr & ~lr) + __popc(both & ~hc & ~lc);
-        k.fC += __popc(both & ~hr & lr) + __popc(both & ~hc & lc);
-        k.fG += __popc(both & hr & ~lr) + __popc(both & hc & ~lc);
-        k.pr0 += __popc(both & ~lr & ~lc & dh);          // {A,G}
-        k.pr1 += __popc(both & dh & dl & ~(hr ^ lr));    // {A,T}
-        k.pr2 += __popc(both & dh & dl & (hr ^ lr));     // {C,G}
-        k.pr3 += __popc(both & lr & lc & dh);            // {C,T}
-    } else {
-        k.p += __popc(mis & ~dl);
-        k.q += __popc(mis & dl);
-        if (TYPE == DPR_DIST_TAMURA) {
-            k.gc1 += __popc(mis & (hr ^ lr));
-            k.gc2 += __popc(mis & (hc ^ lc));
+    __syncthreads();
+    if (!o.skip_main)
+        for (int e = tid; e < PT * PT; e += kThreads) {
+            const int rr = e / PT, cc = e % PT;
+            if (rr < o.nr && cc < o.nc && (o.lower_base < 0 || o.c_org + cc < o.lower_base + o.r_org + rr))
+                o.out[(int64_t)rr * o.ld + cc] = T[rr * (PT + 1) + cc];
         }
-    }
+    if (o.mir)
+        for (int e = tid; e < PT * PT; e += kThreads) {
+            const int cc = e / PT, rr = e % PT;
+            if (rr < o.nr && cc < o.nc) o.mir[(int64_t)cc * o.mir_ld + rr] = T[rr * (PT + 1) + cc];
+        }
 }
 
-template <int TYPE>
-__device__ __forceinline__ double ext_epilogue(const ExtCounts<TYPE>& k)
+template <int TYPE> constexpr size_t msa_tile_lds()
 {
-    const int tot = k.tot;
-    if (TYPE == DPR_DIST_TAJIMANEI) {
-        const int frac[4] = { k.fA, k.fC, k.fG, 2 * tot - k.fA - k.fC - k.fG };
-        double fr[4];
-        for (int i = 0; i < 4; ++i) fr[i] = double(frac[i]) / tot / 2.0;
-        double h = 0;
-        h += 0.5 * k.pr0 * fr[0] * fr[2];
-        h += 0.5 * k.pr1 * fr[0] * fr[3];
-        h += 0.5 * k.pr2 * fr[1] * fr[2];
-        h += 0.5 * k.pr3 * fr[1] * fr[3];
-        const double D = double(tot - k.eq) / tot;
-        const double b = 0.5 * (1.0 - fr[0] * fr[0] - fr[2] * fr[2] + D * D / h);
-        return -b * log(1.0 - D / b);
-    }
-    const double pp = double(k.p) / tot, qq = double(k.q) / tot;
-    if (TYPE == DPR_DIST_K2P) return -0.5 * log((1 - 2 * pp - qq) * sqrt(1 - 2 * qq));
-    if (TYPE == DPR_DIST_JINNEI) return 0.5 * (1.0 / (1 - 2 * pp - qq) + 0.5 / (1 - qq * 2) - 1.5);
-    const double c = double(k.gc1) / tot + double(k.gc2) / tot - 2 * double(k.gc1) * double(k.gc2) / tot / tot;
-    return -c * log(1 - pp / c - qq) - 0.5 * (1 - c) * log(1 - 2 * qq);
+    constexpr int PT = 16 * TileOf<TYPE>::SUB;
+    constexpr size_t stage = sizeof(uint32_t) * 2 * 3 * kKC * (PT + 4), tile = sizeof(double) * PT * (PT + 1);
+    return stage > tile ? stage : tile;
 }
 
+// Matrix front-end: local rows l0.. of (rank, world) (world > 0) or tips row0 + l (world == 0)
+// against columns col0 + [0, ncols).  world == 1: only tiles on or below the diagonal are computed and
+// mirrored (counts are symmetric, src/MSA.cu:121-122).  transposed: out[(c - col0) * ld + l].
 template <int TYPE>
-__global__ __launch_bounds__(kThreads) void msa_dist_ext_kernel(const uint32_t* __restrict__ planes, int64_t n,
-                                                                int64_t W32, double* __restrict__ D, int64_t ld,
-                                                                int64_t rows_local, int rank, int world, int64_t row0)
+__global__ __launch_bounds__(kThreads) void msa_dist_kernel(const uint32_t* __restrict__ planes, int64_t n, int64_t W32,
+                                                            int dist_type, double* __restrict__ D, int64_t ld,
+                                                            int64_t rows_local, int rank, int world, int64_t row0,
+                                                            int64_t col0, int64_t ncols, int transposed)
 {
-    __shared__ uint32_t sA[3][kKC][kET + 1];
-    __shared__ uint32_t sB[3][kKC][kET + 1];
-    const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
-    const int64_t l0 = (int64_t)blockIdx.y * kET;
-    const int64_t c0 = (int64_t)blockIdx.x * kET;
-    // kET divides the ownership block, so a row tile never straddles two owners
+    constexpr int PT = 16 * TileOf<TYPE>::SUB;
+    __shared__ __attribute__((aligned(16))) char smem[msa_tile_lds<TYPE>()];
+    __shared__ int32_t s_rid[PT], s_cid[PT];
+    const int64_t l0 = (int64_t)blockIdx.y * PT;   // PT divides the ownership block: one owner per row tile
+    const int64_t c0 = col0 + (int64_t)blockIdx.x * PT;
     const int64_t g0 = world > 0 ? shard_global_row(l0, rank, world) : row0 + l0;
     const bool mirror = (world == 1);
-    if (mirror && c0 > g0 + kET - 1) return;
-    ExtCounts<TYPE> k[2][2];
-    for (int64_t k0 = 0; k0 < W32; k0 += kKC) {
-        for (int e = tid; e < 3 * kET * kKC; e += kThreads) {
-            const int p = e / (kET * kKC), rem = e % (kET * kKC);
-            const int sq = rem / kKC, kk = rem % kKC;
-            const int64_t w = k0 + kk;
-            const int64_t ga = g0 + sq, gb = c0 + sq;
-            uint32_t va = 0, vb = 0;
-            if (w < W32) {
-                if (ga < n && l0 + sq < rows_local) va = planes[((int64_t)p * n + ga) * W32 + w];
-                if (gb < n) vb = planes[((int64_t)p * n + gb) * W32 + w];
-            }
-            sA[p][kk][sq] = va;
-            sB[p][kk][sq] = vb;
-        }
-        __syncthreads();
-        for (int kk = 0; kk < kKC; ++kk)
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-                    ext_accum<TYPE>(k[r][c], sA[0][kk][ty * 2 + r], sA[1][kk][ty * 2 + r], sA[2][kk][ty * 2 + r],
-                                    sB[0][kk][tx * 2 + c], sB[1][kk][tx * 2 + c], sB[2][kk][tx * 2 + c]);
-        __syncthreads();
+    if (mirror && c0 > g0 + PT - 1) return;
+    if (threadIdx.x < PT) {
+        const int64_t ga = g0 + threadIdx.x, gb = c0 + threadIdx.x;
+        s_rid[threadIdx.x] = (ga < n && l0 + threadIdx.x < rows_local) ? (int32_t)ga : -1;
+        s_cid[threadIdx.x] = (gb < n && gb < col0 + ncols) ? (int32_t)gb : -1;
     }
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int64_t li = l0 + ty * 2 + r, gi = g0 + ty * 2 + r;
-        if (li >= rows_local || gi >= n) continue;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int64_t gj = c0 + tx * 2 + c;
-            if (gj >= n) continue;
-            const double d = (gi == gj) ? 0.0 : ext_epilogue<TYPE>(k[r][c]);
-            D[li * ld + gj] = d;
-            if (mirror && c0 + kET - 1 < g0) D[gj * ld + gi] = d;
-        }
+    __syncthreads();
+    TileOut o;
+    const int64_t nr = rows_local - l0 < n - g0 ? rows_local - l0 : n - g0;
+    const int64_t ncl = col0 + ncols < n ? col0 + ncols : n;
+    o.nr = (int)(nr < PT ? nr : PT);
+    o.nc = (int)(ncl - c0 < PT ? ncl - c0 : PT);
+    o.lower_base = -1; o.r_org = 0; o.c_org = 0;
+    o.diag = g0 - c0;
+    if (transposed) {
+        o.skip_main = true; o.out = nullptr; o.ld = 0;
+        o.mir = D + (c0 - col0) * ld + l0; o.mir_ld = ld;
+    } else {
+        o.skip_main = false; o.out = D + l0 * ld + c0; o.ld = ld;
+        const bool below = mirror && c0 + PT - 1 < g0;
+        o.mir = below ? D + c0 * ld + g0 : nullptr; o.mir_ld = ld;
+    }
+    msa_tile<TYPE>(planes, n, W32, dist_type, s_rid, s_cid, o, smem);
+}
+
+// Job front-end (divide-and-conquer cluster distances): job -> (cluster, row tile, column tile);
+// rows = the cluster's members, columns = its leaf list (ids, -1 = empty); element (t, u) with
+// u < 10 + t goes to out[cl_out + t * cl_ld + u].
+template <int TYPE>
+__global__ __launch_bounds__(kThreads) void msa_dist_jobs_kernel(const uint32_t* __restrict__ planes, int64_t n,
+                                                                 int64_t W32, int dist_type, PairJobs J)
+{
+    constexpr int PT = 16 * TileOf<TYPE>::SUB;
+    __shared__ __attribute__((aligned(16))) char smem[msa_tile_lds<TYPE>()];
+    __shared__ int32_t s_rid[PT], s_cid[PT];
+    const int4 job = J.jobs[blockIdx.x];             // cluster, first row, first column, unused
+    const int ci = job.x, t0 = job.y, u0 = job.z;
+    const int m = J.cl_m[ci], ncols = m + kDcLeaves;
+    if (threadIdx.x < PT) {
+        const int t = t0 + threadIdx.x, u = u0 + threadIdx.x;
+        s_rid[threadIdx.x] = t < m ? J.members[J.cl_moff[ci] + t] : -1;
+        s_cid[threadIdx.x] = u < ncols ? J.cols[J.cl_coff[ci] + u] : -1;
+    }
+    __syncthreads();
+    TileOut o;
+    o.nr = m - t0 < PT ? m - t0 : PT;
+    o.nc = ncols - u0 < PT ? ncols - u0 : PT;
+    o.lower_base = kDcLeaves; o.r_org = t0; o.c_org = u0;
+    o.diag = kNoDiag; o.skip_main = false;
+    o.out = J.out + J.cl_out[ci] + (int64_t)t0 * J.cl_ld[ci] + u0; o.ld = J.cl_ld[ci];
+    o.mir = nullptr; o.mir_ld = 0;
+    msa_tile<TYPE>(planes, n, W32, dist_type, s_rid, s_cid, o, smem);
+}
+
+template <int TYPE>
+static int launch_matrix(dim3 grid, hipStream_t s, const uint32_t* planes, int64_t n, int64_t W32, int dist_type,
+                         double* D, int64_t ld, int64_t rows, int rank, int world, int64_t row0, int64_t col0,
+                         int64_t ncols, int transposed)
+{
+    hipLaunchKernelGGL(msa_dist_kernel<TYPE>, grid, dim3(kThreads), 0, s, planes, n, W32, dist_type, D, ld, rows, rank,
+                       world, row0, col0, ncols, transposed);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+static int msa_launch(int dist_type, hipStream_t s, const MsaBuffers& m, double* D, int64_t ld, int64_t rows, int rank,
+                      int world, int64_t row0, int64_t col0, int64_t ncols, int transposed)
+{
+    const int pt = (dist_type == DPR_DIST_UNCORRECTED || dist_type == DPR_DIST_JC) ? 64 : 32;
+    dim3 g((unsigned)((ncols + pt - 1) / pt), (unsigned)((rows + pt - 1) / pt));
+    switch (dist_type) {
+    case DPR_DIST_UNCORRECTED:
+    case DPR_DIST_JC:        return launch_matrix<DPR_DIST_JC>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed);
+    case DPR_DIST_TAJIMANEI: return launch_matrix<DPR_DIST_TAJIMANEI>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed);
+    case DPR_DIST_K2P:       return launch_matrix<DPR_DIST_K2P>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed);
+    case DPR_DIST_TAMURA:    return launch_matrix<DPR_DIST_TAMURA>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed);
+    case DPR_DIST_JINNEI:    return launch_matrix<DPR_DIST_JINNEI>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed);
+    default: set_error("unknown distance type (valid: 1-6)"); return DPR_ERR_ARG;
     }
 }
 
-static int launch_ext(int dist_type, dim3 grid, hipStream_t s, const uint32_t* planes, int64_t n, int64_t W32,
-                      double* D, int64_t ld, int64_t rows, int rank, int world, int64_t row0)
+int msa_dist_tile_edge(int dist_type) { return (dist_type == DPR_DIST_UNCORRECTED || dist_type == DPR_DIST_JC) ? 64 : 32; }
+
+int msa_dist_jobs(const MsaBuffers& m, int dist_type, const PairJobs& J, int njobs, hipStream_t s)
 {
+    if (njobs <= 0) return DPR_OK;
     switch (dist_type) {
-    case DPR_DIST_TAJIMANEI: hipLaunchKernelGGL(msa_dist_ext_kernel<DPR_DIST_TAJIMANEI>, grid, dim3(kThreads), 0, s, planes, n, W32, D, ld, rows, rank, world, row0); break;
-    case DPR_DIST_K2P:       hipLaunchKernelGGL(msa_dist_ext_kernel<DPR_DIST_K2P>, grid, dim3(kThreads), 0, s, planes, n, W32, D, ld, rows, rank, world, row0); break;
-    case DPR_DIST_TAMURA:    hipLaunchKernelGGL(msa_dist_ext_kernel<DPR_DIST_TAMURA>, grid, dim3(kThreads), 0, s, planes, n, W32, D, ld, rows, rank, world, row0); break;
-    case DPR_DIST_JINNEI:    hipLaunchKernelGGL(msa_dist_ext_kernel<DPR_DIST_JINNEI>, grid, dim3(kThreads), 0, s, planes, n, W32, D, ld, rows, rank, world, row0); break;
+    case DPR_DIST_UNCORRECTED:
+    case DPR_DIST_JC:        hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_JC>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J); break;
+    case DPR_DIST_TAJIMANEI: hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_TAJIMANEI>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J); break;
+    case DPR_DIST_K2P:       hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_K2P>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J); break;
+    case DPR_DIST_TAMURA:    hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_TAMURA>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J); break;
+    case DPR_DIST_JINNEI:    hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_JINNEI>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J); break;
     default: set_error("unknown distance type (valid: 1-6)"); return DPR_ERR_ARG;
     }
     DPR_HIP(hipGetLastError());
@@ -331,31 +410,15 @@ void msa_free(MsaBuffers& m)
 int msa_dist_rows(const MsaBuffers& m, NjBuffers& b, int dist_type, hipStream_t s)
 {
     if (b.rows_local == 0) return DPR_OK;
-    if (dist_type != DPR_DIST_UNCORRECTED && dist_type != DPR_DIST_JC) {
-        dim3 g((unsigned)((m.n + kET - 1) / kET), (unsigned)((b.rows_local + kET - 1) / kET));
-        return launch_ext(dist_type, g, s, m.planes, m.n, m.W32, b.D, b.ld, b.rows_local, b.rank, b.world, 0);
-    }
-    dim3 grid((unsigned)((m.n + kPT - 1) / kPT), (unsigned)((b.rows_local + kPT - 1) / kPT));
-    hipLaunchKernelGGL(msa_dist_kernel, grid, dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, b.D,
-                       b.ld, b.rows_local, b.rank, b.world, (int64_t)0);
-    DPR_HIP(hipGetLastError());
-    return DPR_OK;
+    return msa_launch(dist_type, s, m, b.D, b.ld, b.rows_local, b.rank, b.world, 0, 0, m.n, 0);
 }
 
 int msa_dist_block_rows(const MsaBuffers& m, int64_t r0, int64_t nr, int rank, int world, int64_t ncols,
-                        int dist_type, double* out, int64_t ld, hipStream_t s)
+                        int dist_type, double* out, int64_t ld, hipStream_t s, bool transposed)
 {
     if (nr <= 0 || ncols <= 0) return DPR_OK;
     (void)rank;
-    if (dist_type != DPR_DIST_UNCORRECTED && dist_type != DPR_DIST_JC) {
-        dim3 g((unsigned)((ncols + kET - 1) / kET), (unsigned)((nr + kET - 1) / kET));
-        return launch_ext(dist_type, g, s, m.planes, m.n, m.W32, out, ld, nr, 0, world, r0);
-    }
-    dim3 grid((unsigned)((ncols + kPT - 1) / kPT), (unsigned)((nr + kPT - 1) / kPT));
-    hipLaunchKernelGGL(msa_dist_kernel, grid, dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, out, ld, nr,
-                       0, world, r0);
-    DPR_HIP(hipGetLastError());
-    return DPR_OK;
+    return msa_launch(dist_type, s, m, out, ld, nr, 0, world, r0, 0, ncols, transposed ? 1 : 0);
 }
 
 int msa_counts_row(const MsaBuffers& m, int64_t row, int32_t* d_useful, int32_t* d_match, hipStream_t s)

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(64) void place_update_kernel(PlaceBuffers p, const 
         if (pp.add < badd || (pp.add == badd && pp.idx < bidx)) { badd = pp.add; bidx = pp.idx; beid = pp.eid; bfrac = pp.frac; }
     }
     // slots >= 4*num-4 (and < 4N-4) all carry the tuple (0,0,2): the first of them competes
-    const int64_t live = 4 * num - 4, lim = 4 * p.N - 4;
+    const int64_t live = 4 * num - 4, lim = 4 * p.M - 4;
     if (lane == 0 && live < lim) {
         if (2.0 < badd || (2.0 == badd && (int)live < bidx)) { badd = 2.0; bidx = (int)live; beid = 0; bfrac = 0; }
     }
@@ -293,10 +293,11 @@ __global__ __launch_bounds__(64) void place_update_kernel(PlaceBuffers p, const 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-int place_alloc(PlaceBuffers& p, int64_t N)
+int place_alloc(PlaceBuffers& p, int64_t N, int64_t M)
 {
     place_free(p);
     p.N = N;
+    p.M = M > 0 ? M : N;
     DPR_HIP(hipMalloc(&p.head, sizeof(int32_t) * (size_t)(2 * N)));
     DPR_HIP(hipMalloc(&p.e, sizeof(int32_t) * (size_t)(8 * N)));
     DPR_HIP(hipMalloc(&p.nxt, sizeof(int32_t) * (size_t)(8 * N)));

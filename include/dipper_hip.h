@@ -174,6 +174,25 @@ int dpr_get_timing(dpr_ctx *ctx, double *dist_ms, double *nj_ms);
 int dpr_place_run(dpr_ctx *ctx, int source, int dist_type, int k, int64_t first, int64_t n,
                   int32_t *head, int32_t *e, int32_t *nxt, int32_t *belong, double *len);
 
+/* ---- divide-and-conquer mode: KPlacementDeviceArraysDC::{findBackboneTreeDC, findClustersDC,
+ * findClusterTreeDC} (src/divide_and_conquer/placement_close_k.cu:731-935, 937-1113, 1251-1535) with the
+ * DC row providers MashDeviceArraysDC / MSADeviceArraysDC (src/divide_and_conquer/mash.cu:453-755,
+ * msa.cu:219-504); dispatch at src/tree_generation.cu:422-449,541-575 (`-m 3` or n >= 1 000 000).
+ * Tips [0, backbone) form the backbone (the CLI passes n/20, src/tree_generation.cu:425,545), every
+ * other tip is assigned to a backbone edge and placed inside that edge's cluster.  Unlike the
+ * reference nothing is staged through host memory: all planes / sketches stay in HBM.
+ * Adjacency outputs as dpr_place_run (internal node ids start at n; root-side node n);
+ * cluster_id (optional, n entries): -1 for backbone tips, else the backbone slot of the tip's cluster.
+ * flags: DPR_DC_EXACT_LAST computes the distance of a query to the LAST backbone tip also for aligned
+ * input (the reference's kernel stops one short, src/divide_and_conquer/msa.cu:331, and scans a 0.0;
+ * that behaviour is the default so that results match the reference). */
+#define DPR_DC_EXACT_LAST 1
+int dpr_dc_run(dpr_ctx *ctx, int source, int dist_type, int k, int64_t n, int64_t backbone, int flags,
+               int32_t *head, int32_t *e, int32_t *nxt, int32_t *belong, double *len, int32_t *cluster_id);
+/* counts: clusters, largest cluster, in-cluster pair distances, memory groups, pair jobs;
+ * phase_ms: backbone tree, cluster assignment, cluster trees (HIP events) */
+int dpr_get_dc_stats(dpr_ctx *ctx, int64_t *counts5, double *phase_ms3);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

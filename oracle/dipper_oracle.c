@@ -575,10 +575,10 @@ static void orc_list_merge_into(orc_ptree *T, int dst, int src)
     }
 }
 
-static void orc_split_edge(orc_ptree *T, int eid, double fracLen, double addLen, int placeId, int ec)
+static void orc_split_edge_mid(orc_ptree *T, int eid, double fracLen, double addLen, int placeId, int ec,
+                               int middle)
 {
-    int N = (int)T->N;
-    int middle = placeId + N - 1, outside = placeId;
+    int outside = placeId;
     int x = T->belong[eid], y = T->e[eid];
     double originalDis = T->len[eid];
     int xe = -1, ye = -1;
@@ -609,6 +609,11 @@ static void orc_split_edge(orc_ptree *T, int eid, double fracLen, double addLen,
     T->e[ec] = outside; T->len[ec] = addLen; T->nxt[ec] = T->head[middle]; T->head[middle] = ec; T->belong[ec] = middle;
     orc_list_merge_into(T, ec, ec - 2);
     orc_list_merge_into(T, ec, ec - 3);
+}
+
+static void orc_split_edge(orc_ptree *T, int eid, double fracLen, double addLen, int placeId, int ec)
+{
+    orc_split_edge_mid(T, eid, fracLen, addLen, placeId, ec, placeId + (int)T->N - 1);
 }
 
 /* one tip scan: slots [0,lim) are written like the reference's minPos array; returns the index of
@@ -715,6 +720,209 @@ ORC_API void orc_place_init_lists(int64_t N, int64_t m, int32_t *head, int32_t *
         for (int k = 0; k < 5; ++k) { cdis[i * 5 + k] = 2; cid[i * 5 + k] = -1; }
     for (int64_t i = 0; i < m; ++i) orc_closest_update(&T, (int)i);
     free(T.q_id); free(T.q_from); free(T.q_dis);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * f-1  divide-and-conquer mode.  src/divide_and_conquer/placement_close_k.cu:
+ * findBackboneTreeDC :731-935, findClustersDC :937-1113, findClusterTreeDC :1251-1535 with the
+ * kernels initializeDC :86-110, calculateBranchLengthDC :128-181,
+ * calculateBranchLengthSpecialIDDC :184-240, updateClosestNodesDC :243-277,
+ * updateClosestNodesInClusterDC :313-357, updateTreeStructureDC :359-441,
+ * updateTreeStructureInClusterDC :443-527, buildInitialTreeDC :529-553, updateClusterInfoDC
+ * :555-575, initializeClusterDC :611-646.  Parity unpinned by the reference (CUDA only; the CPU
+ * twins in placement_close_k.cpp need TBB headers the image lacks).
+ *
+ * Tips 0..B-1 are the backbone (B = N/20 at the CLI, src/tree_generation.cu:425,545), placed
+ * with the k-closest algorithm but with node ids offset by the TOTAL tip count N
+ * (middle = tip + N - 1, root-side node N) and the edge scan limited to 4B-4 slots.
+ * Every other tip j gets cluster_id[j] = slot of the backbone edge chosen by the same scan on the
+ * frozen backbone (no tree update).  Then, cluster by cluster (ascending slot), members in
+ * ascending tip order are placed seeing only the cluster's edges (edge j, its reverse, and the 4
+ * new slots of every earlier member, scanned in the order of the reference's edgeMask: j, reverse,
+ * then per earlier member its slots in DESCENDING order) and only the cluster's leaves (the 2x5
+ * closest leaves of edge j and its reverse + earlier members).
+ *
+ * dist: row-major [N][ld], entry (i,j), j < i = distance with tip i as the row ("B" list of the
+ * Mash merge / tarRow of the MSA counts) and tip j as the column; only j < i is read (backbone
+ * leaves < B <= member; earlier members < later members).
+ *
+ * Reference defects and the canonical choice (DESIGN.md "DC quirks"):
+ *  - MSADistConstructionRangeForClusteringDC (msa.cu:331) returns for idx >= ed-st, so with the
+ *    call (l=0, r=B-1) the distance of a query to backbone tip B-1 is never written and the scan
+ *    reads the never-written d_dist[B-1] of a fresh allocation: skip_last_backbone != 0
+ *    reproduces that with 0.0 (the Mash twin, mash.cu:500, computes it: pass 0).
+ *  - ...SpecialIDDC (msa.cu:394, mash.cu:575) test `idx > backboneSize` where `>=` is meant; for
+ *    the single tip id == B that reads out of bounds.  Restated with `>=` (intended).
+ *  - updateClosestNodesInClusterDC reads dis[0]/from[0] of an uninitialised scratch; restated
+ *    with (0, -1) as SURVEY 9.11.
+ *  - a cluster with exactly B members makes the reference's batching loop spin forever and one
+ *    with more exits (:1339-1346); both return -2 here.
+ * Returns the next free slot (4N-4 when every tip was placed) or <0.
+ * ------------------------------------------------------------------------------------------ */
+static int orc_in_cluster(const int32_t *mask_index, int slot) { return mask_index[slot] == slot; }
+
+static void orc_closest_update_in_cluster(orc_ptree *T, int x, int cluster_eid, const int32_t *mask_index)
+{
+    int l = 0, r = -1;
+    T->q_id[++r] = x; T->q_dis[0] = 0; T->q_from[0] = -1;
+    int ed1 = T->e[cluster_eid], ed2 = T->belong[cluster_eid];
+    while (l <= r) {
+        int node = T->q_id[l], fb = T->q_from[l];
+        double d = T->q_dis[l];
+        l++;
+        if (node == ed1 || node == ed2) continue;
+        for (int i = T->head[node]; i != -1; i = T->nxt[i]) {
+            if (!orc_in_cluster(mask_index, i)) continue;
+            if (T->e[i] == fb) continue;
+            for (int j = 0; j < 5; ++j) {
+                double nowd = T->cdis[i * 5 + j];
+                if (nowd > d) {
+                    for (int k = 4; k > j; --k) {
+                        T->cdis[i * 5 + k] = T->cdis[i * 5 + k - 1];
+                        T->cid[i * 5 + k] = T->cid[i * 5 + k - 1];
+                    }
+                    T->cdis[i * 5 + j] = d;
+                    T->cid[i * 5 + j] = x;
+                    ++r; T->q_id[r] = T->e[i]; T->q_dis[r] = d + T->len[i]; T->q_from[r] = node;
+                    break;
+                }
+            }
+        }
+    }
+}
+
+/* calculateBranchLengthSpecialIDDC + min_element over positions [0,edgeCount) of the edge mask */
+static int orc_edge_scan_masked(const orc_ptree *T, const double *dis, const int32_t *edge_mask, int edge_count,
+                                double *out_frac, double *out_add)
+{
+    int best = -1; double best_add = 0, best_frac = 0; int best_eid = 0;
+    for (int pos = 0; pos < edge_count; ++pos) {
+        int idx = edge_mask[pos];
+        int eid; double d1, add;
+        if (T->belong[idx] < T->e[idx]) { eid = 0; d1 = 0; add = 2; }
+        else {
+            int x = T->belong[idx], oth = T->e[idx];
+            double dis1 = 0, dis2 = 0, val;
+            eid = idx;
+            for (int i = 0; i < 5; ++i)
+                if (T->cid[eid * 5 + i] != -1) {
+                    val = dis[T->cid[eid * 5 + i]] - T->cdis[eid * 5 + i];
+                    if (val > dis1) dis1 = val;
+                }
+            int oe = T->head[oth];
+            while (T->e[oe] != x) oe = T->nxt[oe];
+            for (int i = 0; i < 5; ++i)
+                if (T->cid[oe * 5 + i] != -1) {
+                    val = dis[T->cid[oe * 5 + i]] - T->cdis[oe * 5 + i];
+                    if (val > dis2) dis2 = val;
+                }
+            double L = T->len[eid];
+            add = (dis1 + dis2 - L) / 2;
+            if (add < 0) add = 0;
+            dis1 -= add; dis2 -= add;
+            if (dis1 < 0) dis1 = 0;
+            if (dis2 < 0) dis2 = 0;
+            if (dis1 > L) { add += dis1 - L; dis1 = L; }
+            if (dis2 > L) { add += dis2 - L; dis2 = L; }
+            double rest = L - dis1 - dis2;
+            dis1 += rest / 2; dis2 += rest / 2;
+            d1 = dis1;
+        }
+        if (best < 0 || add < best_add) { best = pos; best_add = add; best_frac = d1; best_eid = eid; }
+    }
+    *out_frac = best_frac; *out_add = best_add;
+    return best_eid;
+}
+
+ORC_API int orc_dc_run(int64_t N, int64_t B, const double *dist, int64_t ld, int skip_last_backbone,
+                       int32_t *head, int32_t *e, int32_t *nxt, int32_t *belong, double *len,
+                       int32_t *cid, double *cdis, int32_t *cluster_id, double *trace)
+{
+    if (B < 3 || B > N) return -1;
+    orc_ptree T;
+    T.N = N; T.head = head; T.e = e; T.nxt = nxt; T.belong = belong; T.len = len; T.cid = cid; T.cdis = cdis;
+    T.q_id = (int32_t *)malloc(sizeof(int32_t) * (size_t)(2 * N));
+    T.q_from = (int32_t *)malloc(sizeof(int32_t) * (size_t)(2 * N));
+    T.q_dis = (double *)malloc(sizeof(double) * (size_t)(2 * N));
+    double *dis = (double *)calloc((size_t)N, sizeof(double));        /* d_dist: fresh allocation = 0 */
+    int32_t *edge_mask = (int32_t *)malloc(sizeof(int32_t) * (size_t)(4 * N));
+    int32_t *mask_index = (int32_t *)malloc(sizeof(int32_t) * (size_t)(4 * N));
+    int32_t *leaf_mask = (int32_t *)malloc(sizeof(int32_t) * (size_t)(2 * N));
+    int rc = 0;
+    /* ---- backbone (findBackboneTreeDC) */
+    const int lim_all = (int)(4 * N - 4), lim_bb = (int)(4 * B - 4);
+    for (int i = 0; i < lim_all; ++i) {
+        for (int k = 0; k < 5; ++k) { cdis[i * 5 + k] = 2; cid[i * 5 + k] = -1; }
+        nxt[i] = -1; e[i] = -1; belong[i] = -1;
+    }
+    for (int64_t i = 0; i < 2 * N; ++i) head[i] = -1;
+    {
+        double d = dist[1 * ld + 0];
+        int nv = (int)N;
+        e[0] = nv; len[0] = d / 2; nxt[0] = head[0]; head[0] = 0; belong[0] = 0;
+        e[1] = nv; len[1] = d / 2; nxt[1] = head[1]; head[1] = 1; belong[1] = 1;
+        e[2] = 0;  len[2] = d / 2; nxt[2] = head[nv]; head[nv] = 2; belong[2] = nv;
+        e[3] = 1;  len[3] = d / 2; nxt[3] = head[nv]; head[nv] = 3; belong[3] = nv;
+    }
+    int next = 4;
+    orc_closest_update(&T, 0);
+    orc_closest_update(&T, 1);
+    for (int64_t i = 2; i < B; ++i) {
+        double frac, add;
+        for (int64_t c = 0; c < i; ++c) dis[c] = dist[i * ld + c];
+        int eid = orc_edge_scan(&T, dis, (int)i, lim_bb, &frac, &add);
+        if (trace) { trace[3 * i] = eid; trace[3 * i + 1] = frac; trace[3 * i + 2] = add; }
+        orc_split_edge(&T, eid, frac, add, (int)i, next);
+        next += 4;
+        orc_closest_update(&T, (int)i);
+    }
+    /* ---- cluster assignment (findClustersDC): scan only, no tree update */
+    for (int64_t j = 0; j < B; ++j) cluster_id[j] = -1;
+    for (int64_t j = B; j < N; ++j) {
+        double frac, add;
+        const int64_t ncol = skip_last_backbone ? B - 1 : B;
+        for (int64_t c = 0; c < ncol; ++c) dis[c] = dist[j * ld + c];
+        cluster_id[j] = orc_edge_scan(&T, dis, (int)j, lim_bb, &frac, &add);
+        if (trace) { trace[3 * j] = cluster_id[j]; trace[3 * j + 1] = frac; trace[3 * j + 2] = add; }
+    }
+    /* ---- cluster trees (findClusterTreeDC) */
+    int insert_leaf_count = (int)B;
+    for (int j = 0; j < lim_bb && rc == 0; ++j) {
+        int64_t members = 0;
+        for (int64_t t = B; t < N; ++t) members += (cluster_id[t] == j);
+        if (members == 0) continue;
+        if (members >= B) { rc = -2; break; }
+        for (int64_t s = 0; s < 4 * N; ++s) mask_index[s] = -1;
+        /* initializeClusterDC */
+        int x = belong[j], y = e[j];
+        int oth = head[y];
+        while (e[oth] != x) oth = nxt[oth];
+        int leaf_count = 0, edge_count = 0;
+        for (int i = 0; i < 5; ++i) leaf_mask[leaf_count++] = cid[j * 5 + i];
+        for (int i = 0; i < 5; ++i) leaf_mask[leaf_count++] = cid[oth * 5 + i];
+        edge_mask[edge_count++] = j; edge_mask[edge_count++] = oth;
+        mask_index[j] = j; mask_index[oth] = oth;
+        for (int64_t leaf = B; leaf < N; ++leaf) {
+            if (cluster_id[leaf] != j) continue;
+            /* dist...SpecialIDDC: dis[id] for the cluster's leaves (ids == -1 skipped) */
+            for (int t = 0; t < leaf_count; ++t) {
+                int id = leaf_mask[t];
+                if (id == -1) continue;
+                dis[id] = dist[leaf * ld + id];
+            }
+            double frac, add;
+            int eid = orc_edge_scan_masked(&T, dis, edge_mask, edge_count, &frac, &add);
+            if (trace) { trace[3 * leaf + 1] = frac; trace[3 * leaf + 2] = add; }
+            orc_split_edge_mid(&T, eid, frac, add, (int)leaf, next, insert_leaf_count + (int)N - 1);
+            next += 4; insert_leaf_count++;
+            /* updateClusterInfoDC */
+            leaf_mask[leaf_count++] = (int)leaf;
+            for (int i = 1; i <= 4; ++i) { edge_mask[edge_count++] = next - i; mask_index[next - i] = next - i; }
+            orc_closest_update_in_cluster(&T, (int)leaf, j, mask_index);
+        }
+    }
+    free(T.q_id); free(T.q_from); free(T.q_dis); free(dis); free(edge_mask); free(mask_index); free(leaf_mask);
+    return rc ? rc : next;
 }
 
 /* ------------------------------------------------------------------------------------------
