@@ -251,6 +251,28 @@ void KPlacementDeviceArrays::addQuery(DeviceContext& dev, Param& params)
     std::cerr << "Distance + Tree Operation Time " << (long long)tree_ms << " ms\n";
 }
 
+void KPlacementDeviceArraysDC::allocateDeviceArraysDC(size_t num, size_t totalNum)
+{
+    allocateDeviceArrays(totalNum);          // arrays sized by the total tip count, node ids start there
+    backboneSize = (int)num;
+    totalNumSequences = (int)totalNum;
+    clusterID.assign(totalNum, -1);
+}
+
+void KPlacementDeviceArraysDC::findTreeDC(DeviceContext& dev, Param& params)
+{
+    gpuCheck(dpr_dc_run(dev.ctx, sourceOf(params), (int)params.distanceType, (int)params.kmerSize, totalNumSequences,
+                        backboneSize, 0, h_head.data(), h_e.data(), h_nxt.data(), h_belong.data(), h_len.data(),
+                        clusterID.data()), "dpr_dc_run");
+    int64_t counts[5] = { 0, 0, 0, 0, 0 };
+    double ms[3] = { 0, 0, 0 };
+    dpr_get_dc_stats(dev.ctx, counts, ms);
+    std::cerr << "Finished backbone construction in: " << (long long)ms[0] << " ms\n";
+    std::cerr << "Finished clustering in: " << (long long)ms[1] << " ms\n";
+    std::cerr << "Finished cluster trees in: " << (long long)ms[2] << " ms (" << counts[0] << " clusters, largest "
+              << counts[1] << ")\n";
+}
+
 // printTree (src/placement_close_k.cu:568-643), iterative: root = node numSequences+bd-2, children in
 // adjacency-list order, the edge back to the parent skipped; a node with a single adjacency entry is a leaf.
 void KPlacementDeviceArrays::printTree(const std::vector<std::string>& name, std::ostream& output_)

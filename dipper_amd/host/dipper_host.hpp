@@ -97,6 +97,17 @@ struct KPlacementDeviceArrays {  // src/mash_placement.cuh:167-197
     void printTree(const std::vector<std::string>& name, std::ostream& output_);
 };
 
+// Divide-and-conquer mode (src/mash_placement.cuh KPlacementDeviceArraysDC; findBackboneTreeDC /
+// findClustersDC / findClusterTreeDC / printTreeDC, src/divide_and_conquer/placement_close_k.cu:731-1535,
+// 651-711).  One call of the C ABI runs the three phases; the tree is printed from node totalNumSequences.
+struct KPlacementDeviceArraysDC : KPlacementDeviceArrays {
+    int totalNumSequences = 0;
+    std::vector<int32_t> clusterID;
+    void allocateDeviceArraysDC(size_t num, size_t totalNum);
+    void findTreeDC(DeviceContext& dev, Param& params);
+    void printTreeDC(const std::vector<std::string>& name, std::ostream& output_) { printTree(name, output_); }
+};
+
 // Newick text of an NJ merge log (bookkeeping + print of src/neighborJoining.cu:233-270), iterative.
 void writeNewickFromMerges(std::ostream& os, const std::vector<std::string>& name, const std::vector<int32_t>& mx,
                            const std::vector<int32_t>& my, const std::vector<double>& bx,

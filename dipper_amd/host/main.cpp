@@ -280,7 +280,6 @@ int main(int argc, char** argv)
         if (aligned) msaDeviceArrays.allocateDeviceArrays(dev, seqs, ids);
         else mashDeviceArrays.allocateDeviceArrays(dev, seqs, ids);
         std::cerr << "Input in: " << ms_since(inputStart) << " ms\n";
-        if (mode == 3) die("divide-and-conquer mode is not built yet (rank 1 of the 'next' rows, DESIGN.md); use -m 1 or -m 2");
         auto createArrayStart = std::chrono::high_resolution_clock::now();
         if (!aligned) {
             // the reference sketches only in placement/DC mode (-i r + NJ reads unsketched
@@ -290,7 +289,21 @@ int main(int argc, char** argv)
             mashDeviceArrays.sketchConstructionOnGpu(dev, params);
             std::cerr << "Sketch Created in: " << ms_since(t0) << " ms\n";
         }
-        if (mode == 1) {
+        if (mode == 3) {
+            // src/tree_generation.cu:422-449 (aligned), :541-575 (unaligned): backbone = batch = N/20
+            std::cerr << "Using divide-and-conquer mode\n";
+            const size_t backboneSize = numSequences / 20;
+            if (backboneSize < 3) die("ERROR: divide-and-conquer mode needs at least 60 sequences (backbone = N/20)");
+            params.batchSize = params.backboneSize = backboneSize;
+            KPlacementDeviceArraysDC kplacementDeviceArraysDC;
+            kplacementDeviceArraysDC.allocateDeviceArraysDC(backboneSize, numSequences);
+            if (aligned) std::cerr << "Allocated in: " << ms_since(createArrayStart) << " ms\n";
+            auto t0 = std::chrono::high_resolution_clock::now();
+            kplacementDeviceArraysDC.findTreeDC(dev, params);
+            const long long tree_ms = ms_since(t0);
+            kplacementDeviceArraysDC.printTreeDC(names, *output_);
+            std::cerr << "Tree Created in: " << tree_ms << " ms\n";
+        } else if (mode == 1) {
             std::cerr << (aligned ? "Using k-closest placement mode\n" : "Using k-closest placement mode\n");
             note_exact();
             KPlacementDeviceArrays kplacementDeviceArrays;

@@ -144,6 +144,28 @@ def test_placement_modes_end_to_end(tmp_path, orc):
     assert out.read_text() == _util.newick_from_placement(nm, st["head"], st["e"], st["nxt"], st["len"], 150)
 
 
+def test_divide_and_conquer_end_to_end(tmp_path, orc):
+    """-m 3 (src/tree_generation.cu:422-449,541-575): backbone = N/20, cluster assignment, cluster
+    trees, printTreeDC; Newick text equal to the oracle's sequential restatement on the same distances."""
+    rng = np.random.default_rng(51)
+    n, L = 1400, 1200
+    seqs = _util.synth_alignment(rng, n, L, mean_bl=5e-3, lo=1e-4, hi=5e-2)
+    names = [f"T{i+1}" for i in range(n)]
+    fa = tmp_path / "a.fa"
+    _util.write_fasta(str(fa), names, seqs)
+    for kind, extra, skip in (("m", ["-d", "2"], 1), ("r", [], 0)):
+        out = tmp_path / f"dc_{kind}.nwk"
+        r = run("-i", kind, "-I", str(fa), "-O", str(out), "-m", "3", "--seed", "-1", *extra)
+        M = _api_matrix(kind, seqs, L)
+        st = orc.dc_run(M, n // 20, skip_last_backbone=skip)
+        if st["next_slot"] == -2:      # a cluster as large as the backbone: the reference stops, so do we
+            assert r.returncode == 1 and "not fewer than the backbone size" in r.stderr
+            continue
+        assert r.returncode == 0, r.stderr
+        assert "Using divide-and-conquer mode" in r.stderr and "Finished clustering in" in r.stderr
+        assert out.read_text() == _util.newick_from_placement(names, st["head"], st["e"], st["nxt"], st["len"], n)
+
+
 @pytest.mark.parametrize("kind", ["m", "r"])
 def test_add_queries_to_backbone(tmp_path, orc, kind):
     """--add (src/tree_generation.cu:252-332, addQuery src/placement_close_k.cu:858-990)."""
