@@ -81,6 +81,9 @@ def load_library():
     L.dpr_get_timing.argtypes = [C.c_void_p, c_f64p, c_f64p]
     L.dpr_place_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                 c_i32p, c_i32p, c_i32p, c_i32p, c_f64p]
+    L.dpr_place_exact_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                      c_i32p, c_i32p, c_i32p, c_i32p, c_f64p]
+    L.dpr_get_exact_state.argtypes = [C.c_void_p, c_i32p, c_i32p]
     L.dpr_dc_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int,
                              c_i32p, c_i32p, c_i32p, c_i32p, c_f64p, c_i32p]
     L.dpr_get_dc_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), c_f64p]
@@ -228,6 +231,22 @@ class Dipper:
         trace = np.zeros(3 * n, np.float64)
         _chk(self.L, self.L.dpr_get_place_state(self.h, _p(cid, c_i32p), _p(cdis, c_f64p), _p(trace, c_f64p)))
         st.update(cid=cid, cdis=cdis, trace=trace.reshape(n, 3))
+        return st
+
+    def place_exact_run(self, source, n, dist_type=1, k=15):
+        """Exact placement mode (dpr_place_exact_run); returns adjacency, rev, dep, trace."""
+        st = dict(head=np.full(2 * n, -1, np.int32), e=np.full(8 * n, -1, np.int32),
+                  nxt=np.full(8 * n, -1, np.int32), belong=np.full(8 * n, -1, np.int32),
+                  len=np.full(8 * n, 2.0, np.float64))
+        _chk(self.L, self.L.dpr_place_exact_run(self.h, source, dist_type, k, n, _p(st["head"], c_i32p),
+                                                _p(st["e"], c_i32p), _p(st["nxt"], c_i32p),
+                                                _p(st["belong"], c_i32p), _p(st["len"], c_f64p)))
+        rev = np.zeros(8 * n, np.int32)
+        dep = np.zeros(2 * n, np.int32)
+        trace = np.zeros(3 * n, np.float64)
+        _chk(self.L, self.L.dpr_get_exact_state(self.h, _p(rev, c_i32p), _p(dep, c_i32p)))
+        _chk(self.L, self.L.dpr_get_place_state(self.h, None, None, _p(trace, c_f64p)))
+        st.update(rev=rev, dep=dep, trace=trace.reshape(n, 3))
         return st
 
     def dc_run(self, source, n, backbone, dist_type=1, k=15, flags=0):

@@ -65,6 +65,7 @@ struct dpr_ctx {
     dpr::MsaBuffers msa;
     dpr::MashBuffers mash;
     dpr::PlaceBuffers place;
+    dpr::ExactBuffers exact;
     double* place_trace = nullptr;   // [3N] (eid, frac, add) per placed tip
     double* packed_lower = nullptr;  // MATRIX source, device
     int64_t n_input = 0;
@@ -250,6 +251,7 @@ int dpr_destroy(dpr_ctx* c)
     msa_free(c->msa);
     mash_free(c->mash);
     place_free(c->place);
+    exact_free(c->exact);
     if (c->place_trace) (void)hipFree(c->place_trace);
     if (c->packed_lower) (void)hipFree(c->packed_lower);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -789,6 +791,80 @@ int dpr_place_run(dpr_ctx* c, int source, int dist_type, int k, int64_t first, i
     float ms = 0;
     DPR_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
     c->nj_ms = ms;
+    return DPR_OK;
+}
+
+// ---- exact placement mode -----------------------------------------------------------------------------
+int dpr_place_exact_run(dpr_ctx* c, int source, int dist_type, int k, int64_t n, int32_t* head, int32_t* e,
+                        int32_t* nxt, int32_t* belong, double* len)
+{
+    if (!c || !head || !e || !nxt || !belong || !len || n < 3) { set_error("dpr_place_exact_run: bad argument"); return DPR_ERR_ARG; }
+    DPR_HIP(hipSetDevice(c->device));
+    if (source == DPR_SRC_MSA) {
+        if (!c->msa.planes || c->msa.n != n) { set_error("dpr_place_exact_run: call dpr_set_msa with n sequences first"); return DPR_ERR_STATE; }
+    } else if (source == DPR_SRC_MASH) {
+        if (!c->mash.sketches || c->mash.n != n) { set_error("dpr_place_exact_run: call dpr_set_reads and dpr_sketch first"); return DPR_ERR_STATE; }
+        if (k != c->mash.k) { set_error("dpr_place_exact_run: k differs from the sketch k"); return DPR_ERR_ARG; }
+    } else if (source == DPR_SRC_MATRIX) {
+        if (!c->packed_lower || c->n_input != n) { set_error("dpr_place_exact_run: call dpr_set_matrix_lower first"); return DPR_ERR_STATE; }
+    } else { set_error("dpr_place_exact_run: unknown source"); return DPR_ERR_ARG; }
+    if (int rc = place_alloc(c->place, n)) return rc;
+    if (int rc = exact_alloc(c->exact, n)) return rc;
+    PlaceBuffers& p = c->place;
+    ExactBuffers& x = c->exact;
+    if (c->place_trace) { (void)hipFree(c->place_trace); c->place_trace = nullptr; }
+    DPR_HIP(hipMalloc(&c->place_trace, sizeof(double) * (size_t)(3 * n)));
+    DPR_HIP(hipMemsetAsync(c->place_trace, 0, sizeof(double) * (size_t)(3 * n), c->stream));
+    // distance rows in batches of R+1: the step of tip i also runs the passes of tip i+1, so a batch
+    // shares its last row with the next one
+    const int64_t R = 256;
+    const int64_t ldb = (n + 15) / 16 * 16;
+    double* rows = nullptr;
+    if (source != DPR_SRC_MATRIX) DPR_HIP(hipMalloc(&rows, sizeof(double) * (size_t)((R + 1) * ldb)));
+    int64_t r0 = 1;
+    auto row_ptr = [&](int64_t i) -> const double* {
+        return source == DPR_SRC_MATRIX ? c->packed_lower + i * (i - 1) / 2 : rows + (i - r0) * ldb;
+    };
+    auto fill_rows = [&](int64_t i0, int64_t nr) -> int {
+        if (source == DPR_SRC_MSA) return msa_dist_block_rows(c->msa, i0, nr, 0, 0, i0 + nr, dist_type, rows, ldb, c->stream);
+        if (source == DPR_SRC_MASH) return mash_dist_rows(c->mash, i0, nr, 0, 0, false, i0 + nr, rows, ldb, c->stream);
+        return DPR_OK;
+    };
+    DPR_HIP(hipEventRecord(c->ev[2], c->stream));
+    int rc = DPR_OK;
+    while (!rc) {
+        const int64_t nr = n - r0 < R + 1 ? n - r0 : R + 1;
+        rc = fill_rows(r0, nr);
+        if (!rc && r0 == 1) rc = exact_init(p, x, row_ptr(1), nr > 1 ? row_ptr(2) : nullptr, nr > 1, c->stream);
+        for (int64_t i = r0 < 2 ? 2 : r0; !rc && i < r0 + nr - 1; ++i) rc = exact_tip(p, x, i, row_ptr(i + 1), true, c->place_trace, c->stream);
+        if (rc) break;
+        if (r0 + nr == n) { rc = exact_tip(p, x, n - 1, nullptr, false, c->place_trace, c->stream); break; }
+        r0 = r0 + nr - 1;
+    }
+    if (!rc) {
+        DPR_HIP(hipEventRecord(c->ev[3], c->stream));
+        DPR_HIP(hipMemcpyAsync(head, p.head, sizeof(int32_t) * (size_t)(2 * n), hipMemcpyDeviceToHost, c->stream));
+        DPR_HIP(hipMemcpyAsync(e, p.e, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
+        DPR_HIP(hipMemcpyAsync(nxt, p.nxt, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
+        DPR_HIP(hipMemcpyAsync(belong, p.belong, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
+        DPR_HIP(hipMemcpyAsync(len, p.len, sizeof(double) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
+    }
+    const hipError_t se = hipStreamSynchronize(c->stream);
+    if (rows) (void)hipFree(rows);
+    if (rc) return rc;
+    DPR_HIP(se);
+    float ms = 0;
+    DPR_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+    c->nj_ms = ms;
+    return DPR_OK;
+}
+
+int dpr_get_exact_state(dpr_ctx* c, int32_t* rev, int32_t* dep)
+{
+    if (!c || !c->exact.dep || !c->place.rev) { set_error("dpr_get_exact_state: no exact placement state"); return DPR_ERR_STATE; }
+    const int64_t n = c->place.N;
+    if (rev) DPR_HIP(hipMemcpy(rev, c->place.rev, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost));
+    if (dep) DPR_HIP(hipMemcpy(dep, c->exact.dep, sizeof(int32_t) * (size_t)(2 * n), hipMemcpyDeviceToHost));
     return DPR_OK;
 }
 

@@ -225,6 +225,23 @@ int place_initial_tree(PlaceBuffers& p, const double* d_dis_row1, hipStream_t s)
 int place_import_backbone(PlaceBuffers& p, int64_t m, hipStream_t s);
 int place_tip(PlaceBuffers& p, const double* d_dis, int64_t tip, double* d_trace, hipStream_t s);
 
+// exact.hip: exact placement mode (src/placement.cu)
+struct ExactBuffers {
+    double* lim = nullptr;       // [8N] per directed slot
+    int32_t* dep = nullptr;      // [2N] depth below node N
+    int32_t* dfsrk = nullptr;    // [2N] DFS pre-order rank
+    int32_t* order = nullptr;    // [2N] placed nodes grouped by depth
+    int32_t* lvoff = nullptr;    // [2N+2] first index of every level in order[]
+    int32_t* hist = nullptr;     // [2N+2]
+    void* partials = nullptr;
+};
+int exact_alloc(ExactBuffers& x, int64_t N);
+void exact_free(ExactBuffers& x);
+int exact_init(PlaceBuffers& p, ExactBuffers& x, const double* d_dis_row1, const double* d_dis_row2, bool has_tip2,
+               hipStream_t s);
+int exact_tip(PlaceBuffers& p, ExactBuffers& x, int64_t tip, const double* d_dis_next, bool has_next, double* d_trace,
+              hipStream_t s);
+
 // dc.hip: divide-and-conquer mode (cluster assignment + concurrent cluster trees)
 struct DcTable {
     int nv = 0;                    // eligible backbone slots (belong >= e), ascending

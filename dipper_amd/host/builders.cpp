@@ -234,6 +234,15 @@ static int sourceOf(const Param& params)
 
 void KPlacementDeviceArrays::findPlacementTree(DeviceContext& dev, Param& params)
 {
+    if (exact) {
+        gpuCheck(dpr_place_exact_run(dev.ctx, sourceOf(params), (int)params.distanceType, (int)params.kmerSize, numSequences,
+                                     h_head.data(), h_e.data(), h_nxt.data(), h_belong.data(), h_len.data()),
+                 "dpr_place_exact_run");
+        double dist_ms = 0, tree_ms = 0;
+        dpr_get_timing(dev.ctx, &dist_ms, &tree_ms);
+        std::cerr << "Distance + Tree Operation Time " << (long long)tree_ms << " ms\n";
+        return;
+    }
     gpuCheck(dpr_place_run(dev.ctx, sourceOf(params), (int)params.distanceType, (int)params.kmerSize, 2, numSequences,
                            h_head.data(), h_e.data(), h_nxt.data(), h_belong.data(), h_len.data()), "dpr_place_run");
     double dist_ms = 0, tree_ms = 0;

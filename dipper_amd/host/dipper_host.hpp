@@ -86,8 +86,12 @@ struct Tree {
     int findLeaf(const std::string& name) const;   // node index or -1
 };
 
-struct KPlacementDeviceArrays {  // src/mash_placement.cuh:167-197
+// k-closest placement (src/mash_placement.cuh:167-197); with exact = true the same host object drives
+// the exact mode of PlacementDeviceArrays (src/mash_placement.cuh:137-165, src/placement.cu): identical
+// adjacency arrays and printTree (src/placement.cu:454-505 == src/placement_close_k.cu:568-643)
+struct KPlacementDeviceArrays {
     int numSequences = 0, backboneSize = -1, bd = 2;
+    bool exact = false;
     std::vector<int32_t> h_head, h_e, h_nxt, h_belong;
     std::vector<double> h_len;
     void allocateDeviceArrays(size_t num, int backboneSize = -1);

@@ -171,9 +171,9 @@ int main(int argc, char** argv)
         if (algo == "3" || (algo == "0" && n >= dc_thr)) return 3;
         return 2;
     };
-    auto note_exact = [&]() {
-        if (placemode == "0") std::cerr << "Note: exact placement mode is not built; using k-closest placement\n";
-    };
+    // exact placement mode: `-p 0`, or -- the reference's effective behaviour, which reads the placement mode
+    // from --algorithm (src/tree_generation.cu:222-224) -- an explicit `-m 0` that lands in placement
+    const bool exact_mode = placemode == "0" || (vm.count("algorithm") && algo == "0");
 
     if (add) {
         // src/tree_generation.cu:252-332
@@ -304,9 +304,10 @@ int main(int argc, char** argv)
             kplacementDeviceArraysDC.printTreeDC(names, *output_);
             std::cerr << "Tree Created in: " << tree_ms << " ms\n";
         } else if (mode == 1) {
-            std::cerr << (aligned ? "Using k-closest placement mode\n" : "Using k-closest placement mode\n");
-            note_exact();
+            std::cerr << "Using ";
+            std::cerr << (exact_mode ? " exact placement mode\n" : "k-closest placement mode\n");   // src/tree_generation.cu:378-402
             KPlacementDeviceArrays kplacementDeviceArrays;
+            kplacementDeviceArrays.exact = exact_mode;
             kplacementDeviceArrays.allocateDeviceArrays(numSequences);
             if (aligned) std::cerr << "Allocated in: " << ms_since(createArrayStart) << " ms\n";
             auto t0 = std::chrono::high_resolution_clock::now();
@@ -334,10 +335,10 @@ int main(int argc, char** argv)
         if (mode == 3) { std::cerr << "Divide-and-conquer mode not supported with input matrix\n"; return 1; }
         DeviceContext dev(device);
         if (mode == 1) {
-            std::cerr << "Using k-closest placement mode\n";
-            note_exact();
+            std::cerr << "Using " << (exact_mode ? " exact placement mode\n" : "k-closest placement mode\n");
             gpuCheck(dpr_set_matrix_lower(dev.ctx, matrixReader.lower.data(), numSequences), "dpr_set_matrix_lower");
             KPlacementDeviceArrays kplacementDeviceArrays;
+            kplacementDeviceArrays.exact = exact_mode;
             kplacementDeviceArrays.allocateDeviceArrays((size_t)numSequences);
             kplacementDeviceArrays.findPlacementTree(dev, params);
             kplacementDeviceArrays.printTree(matrixReader.name, *output_);

@@ -174,6 +174,15 @@ int dpr_get_timing(dpr_ctx *ctx, double *dist_ms, double *nj_ms);
 int dpr_place_run(dpr_ctx *ctx, int source, int dist_type, int k, int64_t first, int64_t n,
                   int32_t *head, int32_t *e, int32_t *nxt, int32_t *belong, double *len);
 
+/* ---- exact placement mode: PlacementDeviceArrays::{allocateDeviceArrays,findPlacementTree}
+ * (src/placement.cu:17-117,508-789), reached in the reference through `-m 0` with 30000 <= n < 1000000
+ * (SURVEY 9.2).  Same inputs/outputs as dpr_place_run with first = 2; per tip the per-slot bounds come
+ * from an exact bottom-up / top-down pass over the whole tree instead of the K = 5 closest lists. */
+int dpr_place_exact_run(dpr_ctx *ctx, int source, int dist_type, int k, int64_t n, int32_t *head, int32_t *e,
+                        int32_t *nxt, int32_t *belong, double *len);
+/* test hook: reverse-slot array (8n) and node depths below node n (2n) of the last dpr_place_exact_run */
+int dpr_get_exact_state(dpr_ctx *ctx, int32_t *rev, int32_t *dep);
+
 /* ---- divide-and-conquer mode: KPlacementDeviceArraysDC::{findBackboneTreeDC, findClustersDC,
  * findClusterTreeDC} (src/divide_and_conquer/placement_close_k.cu:731-935, 937-1113, 1251-1535) with the
  * DC row providers MashDeviceArraysDC / MSADeviceArraysDC (src/divide_and_conquer/mash.cu:453-755,

@@ -926,6 +926,180 @@ ORC_API int orc_dc_run(int64_t N, int64_t B, const double *dist, int64_t ld, int
 }
 
 /* ------------------------------------------------------------------------------------------
+ * f-3  exact placement mode.  src/placement.cu: initialize :119-140, buildInitialTree :245-293,
+ * updateFromBottomToTop :296-329, updateFromTopToBottom :331-364, calculateBranchLength :158-197
+ * + thrust::min_element :688 (first occurrence over all 4N-4 tuples), updateTreeStructure
+ * :199-243, updateDfsRk :366-379, findEndRk :382-398 + thrust::reduce(minimum, init N+i-1) :746,
+ * updateDepth :400-416, stable_sort_by_key on depth :766, updateLevelStEd :419-434; driver loop
+ * findPlacementTree :508-789.  Parity unpinned by the reference (CUDA only).
+ *
+ * Per tip i: lim[slot x->y] = the largest (distance to a leaf behind x) - (path from x to it),
+ * clamped at 0, by a level-by-level bottom-up then top-down pass over the tree rooted at node N;
+ * candidates are the parent->child slots (dep[belong] <= dep[e]), pendant length and split position
+ * from lim[slot], lim[reverse]; first minimum in slot order; the edge is split and the DFS ranks,
+ * depths and level lists are patched.  Restated literally, including updateTreeStructure's
+ * ineffective swap (:236-239; never taken because the winner is a parent->child slot) and the
+ * identity fill of bfsorder before the stable sort.
+ * dist: row-major [N][ld], (i,j) j<i read.  Outputs the adjacency (+rev, dep) and per tip
+ * (eid, frac, add) in trace.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { int key; int val; } orc_kv;
+static void orc_stable_sort_by_key(int *keys, int *vals, int n, orc_kv *tmp, int *cnt, int maxkey)
+{
+    /* counting sort = stable; keys in [0, maxkey] */
+    for (int k = 0; k <= maxkey + 1; ++k) cnt[k] = 0;
+    for (int i = 0; i < n; ++i) cnt[keys[i] + 1]++;
+    for (int k = 0; k <= maxkey; ++k) cnt[k + 1] += cnt[k];
+    for (int i = 0; i < n; ++i) { int pos = cnt[keys[i]]++; tmp[pos].key = keys[i]; tmp[pos].val = vals[i]; }
+    for (int i = 0; i < n; ++i) { keys[i] = tmp[i].key; vals[i] = tmp[i].val; }
+}
+
+ORC_API int orc_place_exact_run(int64_t N64, const double *dist_rows, int64_t ld, int32_t *head, int32_t *e,
+                                int32_t *nxt, int32_t *belong, double *len, int32_t *rev, int32_t *dep,
+                                double *trace)
+{
+    const int N = (int)N64;
+    const int lim_slots = 4 * N - 4, nodes = 2 * N - 1;
+    double *lim = (double *)calloc((size_t)(8 * N), sizeof(double));
+    int *bfsorder = (int *)calloc((size_t)(2 * N), sizeof(int));
+    int *dfsrk = (int *)malloc(sizeof(int) * (size_t)(2 * N));
+    int *levelst = (int *)malloc(sizeof(int) * (size_t)(2 * N));
+    int *leveled = (int *)malloc(sizeof(int) * (size_t)(2 * N));
+    int *temp = (int *)malloc(sizeof(int) * (size_t)(2 * N));
+    const int maxkey = nodes * 10;
+    orc_kv *kv = (orc_kv *)malloc(sizeof(orc_kv) * (size_t)(2 * N));
+    int *cnt = (int *)malloc(sizeof(int) * (size_t)(maxkey + 3));
+    /* initialize */
+    for (int i = 0; i < lim_slots; ++i) { nxt[i] = -1; e[i] = -1; belong[i] = -1; }
+    for (int i = 0; i < nodes; ++i) { head[i] = -1; dep[i] = nodes * 10; dfsrk[i] = levelst[i] = leveled[i] = -1; }
+    /* buildInitialTree */
+    {
+        const int nv = N;
+        const double d = dist_rows[1 * ld + 0];
+        e[0] = nv; len[0] = d / 2; nxt[0] = head[0]; head[0] = 0; belong[0] = 0;
+        e[1] = nv; len[1] = d / 2; nxt[1] = head[1]; head[1] = 1; belong[1] = 1;
+        e[2] = 0;  len[2] = d / 2; nxt[2] = head[nv]; head[nv] = 2; belong[2] = nv;
+        e[3] = 1;  len[3] = d / 2; nxt[3] = head[nv]; head[nv] = 3; belong[3] = nv;
+        bfsorder[0] = nv; bfsorder[1] = 0; bfsorder[2] = 1;
+        dep[nv] = 0; dep[0] = dep[1] = 1;
+        dfsrk[nv] = 0; dfsrk[0] = 1; dfsrk[1] = 2;
+        levelst[0] = leveled[0] = 0; levelst[1] = 1; leveled[1] = 2;
+        rev[0] = 2; rev[2] = 0; rev[1] = 3; rev[3] = 1;
+    }
+    int next = 4;
+    for (int i = 2; i < N; ++i) {
+        const double *dist = dist_rows + (int64_t)i * ld;
+        const int id = bfsorder[i * 2 - 2];
+        const int mx = dep[id];
+        for (int j = mx; j >= 0; --j)                       /* updateFromBottomToTop */
+            for (int t = levelst[j]; t <= leveled[j]; ++t) {
+                const int idx = bfsorder[t];
+                double m = 0;
+                if (idx < N) m = dist[idx];
+                for (int k = head[idx]; k != -1; k = nxt[k])
+                    if (dep[e[k]] > dep[idx]) { double req = lim[rev[k]] - len[k]; if (req > m) m = req; }
+                for (int k = head[idx]; k != -1; k = nxt[k])
+                    if (dep[e[k]] < dep[idx]) lim[k] = m;
+            }
+        for (int j = 0; j <= mx; ++j)                       /* updateFromTopToBottom */
+            for (int t = levelst[j]; t <= leveled[j]; ++t) {
+                const int idx = bfsorder[t];
+                for (int k = head[idx]; k != -1; k = nxt[k])
+                    if (dep[e[k]] > dep[idx]) {
+                        double m = 0;
+                        for (int q = head[idx]; q != -1; q = nxt[q])
+                            if (e[q] != e[k]) { double req = lim[rev[q]] - len[q]; if (req > m) m = req; }
+                        lim[k] = m;
+                    }
+            }
+        /* calculateBranchLength + min_element over all 4N-4 tuples */
+        int best = -1, best_eid = 0; double best_add = 0, best_frac = 0;
+        for (int idx = 0; idx < lim_slots; ++idx) {
+            int eid; double d1, add;
+            if (idx >= i * 4 - 4 || dep[belong[idx]] > dep[e[idx]]) { eid = 0; d1 = 0; add = 2; }
+            else {
+                const int x = belong[idx], oth = e[idx];
+                eid = idx;
+                double dis1 = lim[eid];
+                int oe = head[oth];
+                while (e[oe] != x) oe = nxt[oe];
+                double dis2 = lim[oe];
+                const double L = len[eid];
+                add = (dis1 + dis2 - L) / 2;
+                if (add < 0) add = 0;
+                dis1 -= add; dis2 -= add;
+                if (dis1 < 0) dis1 = 0;
+                if (dis2 < 0) dis2 = 0;
+                if (dis1 > L) { add += dis1 - L; dis1 = L; }
+                if (dis2 > L) { add += dis2 - L; dis2 = L; }
+                const double rest = L - dis1 - dis2;
+                dis1 += rest / 2; dis2 += rest / 2;
+                d1 = dis1;
+            }
+            if (best < 0 || add < best_add) { best = idx; best_add = add; best_frac = d1; best_eid = eid; }
+        }
+        const int eid = best_eid; const double fracLen = best_frac, addLen = best_add;
+        if (trace) { trace[3 * i] = eid; trace[3 * i + 1] = fracLen; trace[3 * i + 2] = addLen; }
+        /* updateTreeStructure */
+        {
+            int ec = next;
+            const int middle = i + N - 1, outside = i;
+            int x = belong[eid], y = e[eid];
+            const double originalDis = len[eid];
+            int xe = -1, ye = -1;
+            for (int k = head[x]; k != -1; k = nxt[k])
+                if (e[k] == y) { e[k] = middle; len[k] = fracLen; xe = k; rev[xe] = ec; break; }
+            for (int k = head[y]; k != -1; k = nxt[k])
+                if (e[k] == x) { e[k] = middle; len[k] -= fracLen; ye = k; rev[ye] = ec + 1; break; }
+            e[ec] = x; len[ec] = fracLen; nxt[ec] = head[middle]; head[middle] = ec; belong[ec] = middle; rev[ec] = xe; ec++;
+            e[ec] = y; len[ec] = originalDis - fracLen; nxt[ec] = head[middle]; head[middle] = ec; belong[ec] = middle; rev[ec] = ye; ec++;
+            e[ec] = middle; len[ec] = addLen; nxt[ec] = head[outside]; head[outside] = ec; belong[ec] = outside; rev[ec] = ec + 1; ec++;
+            e[ec] = outside; len[ec] = addLen; nxt[ec] = head[middle]; head[middle] = ec; belong[ec] = middle; rev[ec] = ec - 1; ec++;
+            if (dfsrk[x] > dfsrk[y]) { int t2 = x; y = x; x = t2; }   /* the reference's (ineffective) swap */
+            dfsrk[middle] = dfsrk[y];
+            dfsrk[outside] = dfsrk[middle] + 1;
+            dep[middle] = dep[x]; dep[outside] = dep[middle] + 1;
+            next += 4;
+        }
+        const int tot = N + i, ref = N + i - 1;
+        /* updateDfsRk */
+        {
+            const int r1 = dfsrk[ref];
+            for (int idx = 0; idx < tot; ++idx) {
+                if (idx > i && idx < N) continue;
+                if (idx == ref || idx == i) continue;
+                if (dfsrk[idx] >= r1) dfsrk[idx] += 2;
+            }
+        }
+        /* findEndRk + reduce(min, init N+i-1) */
+        int small = N + i - 1;
+        for (int idx = 0; idx < tot; ++idx) {
+            int t2;
+            if (idx > i && idx < N) t2 = 1000000000;
+            else if (dfsrk[idx] <= dfsrk[ref] + 2 || dep[idx] > dep[ref] + 1) t2 = 1000000000;
+            else t2 = dfsrk[idx] - 1;
+            if (t2 < small) small = t2;
+        }
+        /* updateDepth */
+        for (int idx = 0; idx < tot; ++idx) {
+            if (idx > i && idx < N) continue;
+            bfsorder[idx] = idx;
+            if (dfsrk[idx] <= small && dfsrk[idx] >= dfsrk[ref]) dep[idx]++;
+        }
+        /* stable sort of node ids by depth */
+        for (int idx = 0; idx < tot; ++idx) temp[idx] = dep[idx];
+        orc_stable_sort_by_key(temp, bfsorder, tot, kv, cnt, maxkey);
+        /* updateLevelStEd */
+        for (int idx = 0; idx < i * 2 + 1; ++idx) {
+            if (idx == 0 || dep[bfsorder[idx - 1]] != dep[bfsorder[idx]]) levelst[dep[bfsorder[idx]]] = idx;
+            if (idx + 1 == i * 2 + 1 || dep[bfsorder[idx + 1]] != dep[bfsorder[idx]]) leveled[dep[bfsorder[idx]]] = idx;
+        }
+    }
+    free(lim); free(bfsorder); free(dfsrk); free(levelst); free(leveled); free(temp); free(kv); free(cnt);
+    return next;
+}
+
+/* ------------------------------------------------------------------------------------------
  * a-12  PHYLIP token -> double.  src/matrix_reader.cu:42 parses with stof (float precision).
  * ------------------------------------------------------------------------------------------ */
 ORC_API double orc_phylip_value(const char *tok) { return (double)strtof(tok, NULL); }

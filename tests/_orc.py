@@ -49,6 +49,9 @@ class Oracle:
         L.orc_dc_run.argtypes = [C.c_int64, C.c_int64, c_f64p, C.c_int64, C.c_int, c_i32p, c_i32p, c_i32p,
                                  c_i32p, c_f64p, c_i32p, c_f64p, c_i32p, c_f64p]
         L.orc_dc_run.restype = C.c_int
+        L.orc_place_exact_run.argtypes = [C.c_int64, c_f64p, C.c_int64, c_i32p, c_i32p, c_i32p, c_i32p, c_f64p,
+                                          c_i32p, c_i32p, c_f64p]
+        L.orc_place_exact_run.restype = C.c_int
         L.orc_phylip_value.argtypes = [C.c_char_p]
         L.orc_phylip_value.restype = C.c_double
 
@@ -187,6 +190,22 @@ class Oracle:
                                  _p(cl, c_i32p), _p(trace, c_f64p))
         st["next_slot"] = rc
         st["cluster_id"] = cl
+        st["trace"] = trace.reshape(N, 3)
+        return st
+
+    def place_exact_run(self, dist_rows):
+        """Exact placement mode (src/placement.cu) on a dense matrix (entry (i,j), j<i, read)."""
+        D = np.ascontiguousarray(dist_rows, dtype=np.float64)
+        N, ld = D.shape
+        st = self.place_alloc(N)
+        st["rev"] = np.full(8 * N, -1, dtype=np.int32)
+        st["dep"] = np.full(2 * N, -1, dtype=np.int32)
+        trace = np.zeros(3 * N, dtype=np.float64)
+        st["next_slot"] = self.lib.orc_place_exact_run(N, _p(D, c_f64p), ld, _p(st["head"], c_i32p),
+                                                       _p(st["e"], c_i32p), _p(st["nxt"], c_i32p),
+                                                       _p(st["belong"], c_i32p), _p(st["len"], c_f64p),
+                                                       _p(st["rev"], c_i32p), _p(st["dep"], c_i32p),
+                                                       _p(trace, c_f64p))
         st["trace"] = trace.reshape(N, 3)
         return st
 

@@ -144,6 +144,22 @@ def test_placement_modes_end_to_end(tmp_path, orc):
     assert out.read_text() == _util.newick_from_placement(nm, st["head"], st["e"], st["nxt"], st["len"], 150)
 
 
+def test_exact_placement_end_to_end(tmp_path, orc):
+    """-m 1 -p 0: exact placement mode (src/placement.cu); Newick text equal to the oracle's."""
+    rng = np.random.default_rng(61)
+    n, L = 260, 1200
+    seqs = _util.synth_alignment(rng, n, L, mean_bl=5e-3, lo=1e-4, hi=5e-2)
+    names = [f"T{i+1}" for i in range(n)]
+    fa = tmp_path / "a.fa"
+    _util.write_fasta(str(fa), names, seqs)
+    out = tmp_path / "x.nwk"
+    r = run("-i", "m", "-I", str(fa), "-O", str(out), "-m", "1", "-p", "0", "-d", "2", "--seed", "-1")
+    assert r.returncode == 0, r.stderr
+    assert "exact placement mode" in r.stderr
+    st = orc.place_exact_run(_api_matrix("m", seqs, L))
+    assert out.read_text() == _util.newick_from_placement(names, st["head"], st["e"], st["nxt"], st["len"], n)
+
+
 def test_divide_and_conquer_end_to_end(tmp_path, orc):
     """-m 3 (src/tree_generation.cu:422-449,541-575): backbone = N/20, cluster assignment, cluster
     trees, printTreeDC; Newick text equal to the oracle's sequential restatement on the same distances."""

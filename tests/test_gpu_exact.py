@@ -1,0 +1,86 @@
+"""GPU parity of the exact placement mode (src/placement.cu) through the C ABI:
+tree state, reverse slots, node depths and per-tip (eid, frac, add) against the oracle's literal
+restatement (bit-exact)."""
+import numpy as np
+import pytest
+
+from tests import _util
+from tests.test_gpu_mash_place import _reads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import dipper_amd
+    d = dipper_amd.Dipper(0)
+    yield d
+    d.close()
+
+
+def _same_exact_state(got, ref, n):
+    live = 4 * n - 4
+    assert ref["next_slot"] == live
+    assert np.array_equal(got["trace"][2:], ref["trace"][2:])
+    for key in ("head", "e", "nxt", "belong", "len", "rev"):
+        m = 2 * n - 1 if key == "head" else live      # initialize covers 2N-1 nodes (src/placement.cu:521-527)
+        assert np.array_equal(got[key][:m], ref[key][:m]), key
+    assert np.array_equal(got["dep"][:2 * n - 1], ref["dep"][:2 * n - 1])
+
+
+@pytest.mark.parametrize("n", [3, 4, 9, 64, 300, 1100, 2600])
+def test_exact_matrix_source(gpu, orc, n):
+    from dipper_amd import capi
+    rng = np.random.default_rng(n)
+    D = _util.random_additive_matrix(rng, n, zero_frac=0.3 if n > 9 else 0.0)
+    D *= 0.9 / D.max()
+    gpu.set_matrix_full(D)
+    got = gpu.place_exact_run(capi.SRC_MATRIX, n)
+    ref = orc.place_exact_run(D)
+    _same_exact_state(got, ref, n)
+    names = [f"T{i}" for i in range(n)]
+    nw = _util.newick_from_placement(names, got["head"], got["e"], got["nxt"], got["len"], n, fmt=repr)
+    assert np.abs(_util.patristic(nw, names) - D).max() < 1e-12 * n
+
+
+def test_exact_noisy_and_caterpillar(gpu, orc):
+    """non-additive input (clamps, ties, the (0,0,2) tuples) and a ladder-shaped metric (depth ~ n:
+    one tree level per workgroup barrier, level lists longer than the workgroup)"""
+    from dipper_amd import capi
+    rng = np.random.default_rng(99)
+    n = 500
+    D = np.round(rng.random((n, n)) * 0.5, 2)
+    D = np.tril(D, -1) + np.tril(D, -1).T
+    gpu.set_matrix_full(D)
+    _same_exact_state(gpu.place_exact_run(capi.SRC_MATRIX, n), orc.place_exact_run(D), n)
+    n = 700
+    pos = np.cumsum(rng.uniform(0.0005, 0.001, size=n))        # caterpillar: tips hang off a path
+    pend = rng.uniform(0.0005, 0.001, size=n)
+    D = np.abs(pos[:, None] - pos[None, :]) + pend[:, None] + pend[None, :]
+    np.fill_diagonal(D, 0.0)
+    order = np.argsort(pos)                                     # insertion along the path -> deep tree
+    D = D[order][:, order]
+    gpu.set_matrix_full(D)
+    ref = orc.place_exact_run(D)
+    assert ref["dep"][:2 * n - 1].max() > 300
+    _same_exact_state(gpu.place_exact_run(capi.SRC_MATRIX, n), ref, n)
+
+
+def test_exact_msa_and_mash_sources(gpu, orc):
+    from dipper_amd import capi
+    rng = np.random.default_rng(123)
+    n, L = 700, 2000         # more than two row batches of 256
+    seqs = _util.synth_alignment(rng, n, L, mean_bl=5e-3, lo=1e-4, hi=5e-2)
+    gpu.set_msa(capi.pack4_many(seqs), L)
+    gpu.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+    M = gpu.matrix()
+    got = gpu.place_exact_run(capi.SRC_MSA, n, dist_type=capi.DIST_JC)
+    _same_exact_state(got, orc.place_exact_run(M), n)
+
+    reads = _reads(rng, 300, 3000, 6000)
+    gpu.set_reads(reads)
+    gpu.sketch(k=15, S=1000, fetch=False)
+    gpu.dist_matrix(capi.SRC_MASH, 0, 15)
+    M = gpu.matrix()
+    got = gpu.place_exact_run(capi.SRC_MASH, len(reads), k=15)
+    _same_exact_state(got, orc.place_exact_run(M), len(reads))

@@ -150,6 +150,66 @@ def test_placement_recovers_additive_tree(orc, n):
     assert np.abs(_util.patristic(nw, names) - D).max() < 1e-12 * n
 
 
+@pytest.mark.parametrize("n,B", [(60, 25), (400, 100), (1000, 150)])
+def test_dc_recovers_additive_tree(orc, n, B):
+    """divide-and-conquer restatement (orc_dc_run): with every query-to-backbone distance computed
+    (the Mash twin's behaviour) a tree metric is recovered exactly; every tip is placed once; clusters
+    are eligible backbone slots."""
+    rng = np.random.default_rng(n)
+    D = _util.random_additive_matrix(rng, n)
+    D *= 0.9 / D.max()
+    st = orc.dc_run(D, B, skip_last_backbone=0)
+    assert st["next_slot"] == 4 * n - 4
+    cl = st["cluster_id"]
+    assert np.all(cl[:B] == -1) and np.all(cl[B:] >= 0) and np.all(cl[B:] < 4 * B - 4)
+    names = [f"T{i}" for i in range(n)]
+    nw = _util.newick_from_placement(names, st["head"], st["e"], st["nxt"], st["len"], n, fmt=repr)
+    assert np.abs(_util.patristic(nw, names) - D).max() < 1e-12 * n
+    # the reference's aligned-input defect (distance to the last backbone tip never written) only moves
+    # queries whose true edge is next to that tip: same tip set, valid tree
+    st2 = orc.dc_run(D, B, skip_last_backbone=1)
+    assert st2["next_slot"] == 4 * n - 4
+    nw2 = _util.newick_from_placement(names, st2["head"], st2["e"], st2["nxt"], st2["len"], n, fmt=repr)
+    assert sorted(_util.parse_newick(nw2)[2].values()) == sorted(names)
+
+
+def test_dc_rejects_cluster_as_large_as_backbone(orc):
+    """src/divide_and_conquer/placement_close_k.cu:1339-1346: exit above B, endless loop at B"""
+    rng = np.random.default_rng(60)
+    D = _util.random_additive_matrix(rng, 60)
+    D *= 0.9 / D.max()
+    assert orc.dc_run(D, 10)["next_slot"] == -2
+
+
+@pytest.mark.parametrize("n", [8, 60, 300])
+def test_exact_placement_recovers_additive_tree_and_depths(orc, n):
+    """exact placement restatement (orc_place_exact_run): additive input recovered; the incrementally
+    patched depths (DFS-rank scheme of src/placement.cu:366-416) equal the true depths below node N."""
+    rng = np.random.default_rng(70 + n)
+    D = _util.random_additive_matrix(rng, n, zero_frac=0.2)
+    D *= 0.9 / D.max()
+    st = orc.place_exact_run(D)
+    assert st["next_slot"] == 4 * n - 4
+    names = [f"T{i}" for i in range(n)]
+    nw = _util.newick_from_placement(names, st["head"], st["e"], st["nxt"], st["len"], n, fmt=repr)
+    assert np.abs(_util.patristic(nw, names) - D).max() < 1e-12 * n
+    dep = {n: 0}
+    todo = [n]
+    while todo:
+        v = todo.pop()
+        i = st["head"][v]
+        while i != -1:
+            w = int(st["e"][i])
+            if w not in dep:
+                dep[w] = dep[v] + 1
+                todo.append(w)
+            i = st["nxt"][i]
+    assert len(dep) == 2 * n - 1
+    assert all(st["dep"][v] == d for v, d in dep.items())
+    live = 4 * n - 4
+    assert np.array_equal(st["rev"][st["rev"][:live]], np.arange(live))
+
+
 def test_phylip_value_is_float_rounded(orc):
     assert orc.phylip_value("0.1") == float(np.float32(0.1))
     assert orc.phylip_value("1e-3") == float(np.float32(1e-3))
