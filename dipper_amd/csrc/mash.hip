@@ -187,23 +187,62 @@ __global__ __launch_bounds__(kThreads) void mash_dist_rows_kernel(const uint64_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// Lookup formulation of the same distance (S <= 1024, pairs with column index < row index).
+// Table formulation of the same distance (S <= 1024).
 // The sequential merge is equivalent to: events in value order, B before A on ties; every A element
 // and every B element whose value is not in A advances `uni`; B elements equal to an A value advance
-// `inter`; stop at the S-th advance.  Hence, iterating over the DISTINCT values v of A (outer list =
-// the lower-index tip) that also occur in B (inner list):
-//     inter = sum of mult_B(v) over those v with   first_A(v) + #{b < v} - #{matching b < v}  <  S
-// and uni = S.  So B is never walked: per row tip the block keeps its sketch in LDS with a bucket
-// index (bucket[k] = first t with b_t >> shift >= k, 1024 buckets), a wave holds one column sketch in
-// registers (16 values per lane) and resolves each value with one bucket read and ~1 sketch read;
-// a wave prefix sum supplies the matches of the lanes before it.  A block keeps 12 row tips
-// resident (146 KiB of LDS) and streams the columns, 8 at a time (one per wave).
+// `inter`; stop at the S-th advance.  Hence, iterating over the DISTINCT values v of A (outer list)
+// that also occur in B (inner list):
+//     inter = sum of mult_B(v) over those v with   first_A(v) + #{b < v} - #{matched b < v}  <  S
+// and uni = S: B is never walked, every A value only needs  rank_B(v) = #{b < v}  and  mult_B(v).
+// Per resident row tip (the B list) the block keeps in LDS the sorted sketch and an ORDERED bucket
+// table on the leading 9 significant bits: base[bucket] = number of values in lower buckets, and
+// 8 x 15-bit tags per bucket (the next 15 bits of each value, ascending, in 16-bit fields).  One
+// 16-byte read of the bucket of an A value gives rank_B(v) = base + #(tags below v's tag); the
+// sketch entry at that rank decides the match (64-bit compare; equal tags of different values and
+// duplicates are walked, buckets with more than 8 values are flagged and binary-searched -- all rare).
+// A wave holds one column sketch (the A list) in registers, strided: step u covers the 64 consecutive
+// values a[64u .. 64u+63], so (i) the lanes of one LDS instruction read ~33 consecutive buckets and
+// ~64 consecutive sketch entries (near conflict-free, unlike random probing, which is what bounds a
+// hash-probe formulation), (ii) the prefix of matches inside a step is a ballot/popcount and the
+// running totals are wave-uniform.  Union ranks grow with v, so the wave stops at the first step whose
+// smallest rank is already >= S (about half of the 16 steps).  16 waves share 8 resident rows.
 // ------------------------------------------------------------------------------------------------
-constexpr int kLS = 1024;            // largest sketch this kernel handles
-constexpr int kLRows = 12;           // row tips resident per block
-constexpr int kLThreads = 512;       // 8 waves
+constexpr int kLS = 1024;             // largest sketch this kernel handles
+constexpr int kTB = 512;              // ordered buckets per row (+1 catch-all above the row's maximum)
+constexpr int kLRows = 8;             // row tips resident per block
+constexpr int kLThreads = 1024;       // 16 waves
 constexpr int kLColsPerBlock = 512;
-constexpr int kLBuckets = 1024;
+constexpr int kTValsStride = kLS + 2;                              // u64 per row (2 pad entries = ~0)
+constexpr int kTBaseStride = (kTB + 1 + 7) / 8 * 8;                // u16 per row
+constexpr size_t kTLds = (size_t)kLRows * (sizeof(uint64_t) * kTValsStride + sizeof(uint4) * (kTB + 1) +
+                                            sizeof(uint16_t) * kTBaseStride);
+
+// 15 tag bits below the 9 bucket bits.  An empty entry is stored as tag 0x7FFF: like a real tag of that
+// value it is never "below" anything, and equal tags are always told apart by the values themselves.
+__device__ __forceinline__ uint32_t mash_tag15(uint64_t v, int tsh) { return (uint32_t)(v >> tsh) & 0x7FFFu; }
+
+__device__ __forceinline__ int lds_lower_bound(const uint64_t* v, int S, uint64_t key)
+{
+    int lo = 0, hi = S;                      // first t with v[t] >= key
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (v[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// Tags are 15 bits, stored with bit 15 set (0xFFFF = empty).  For m2 = the 15-bit tag of the A value in
+// both halves, (stored - m2) never borrows across the halves and keeps bit 15 of a half exactly when
+// that tag is >= m: eight tags are compared with 4 x (sub, and, bcnt).
+__device__ __forceinline__ int tags_below(uint4 tg, uint32_t m2)
+{
+    const uint32_t H = 0x80008000u;
+    int ge = __popc((tg.x - m2) & H);
+    ge += __popc((tg.y - m2) & H);
+    ge += __popc((tg.z - m2) & H);
+    ge += __popc((tg.w - m2) & H);
+    return 8 - ge;
+}
 
 // JOBS = false: rows r0 + [0, nr) (tip ids) x columns [0, ncols), pairs with column id < row id;
 //   out[t * ld + j], transposed: out[j * ld + t] (t = row - r0); mirror: also out[j * ld + row].
@@ -217,15 +256,16 @@ __global__ __launch_bounds__(kLThreads) void mash_dist_lookup_kernel(const uint6
                                                                      PairJobs J)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* vals = reinterpret_cast<uint64_t*>(smem);                              // [kLRows][kLS]
-    uint32_t* bucket = reinterpret_cast<uint32_t*>(vals + kLRows * kLS);             // [kLRows][kLBuckets + 1]
-    __shared__ int s_shift[kLRows];
+    uint64_t* vals = reinterpret_cast<uint64_t*>(smem);                              // [kLRows][kTValsStride]
+    uint4* tags = reinterpret_cast<uint4*>(vals + kLRows * kTValsStride);            // [kLRows][kTB + 1]
+    uint16_t* base = reinterpret_cast<uint16_t*>(tags + kLRows * (kTB + 1));         // [kLRows][kTBaseStride]
+    __shared__ int s_shift[kLRows], s_dups[kLRows];
+    __shared__ int64_t s_irow[kLRows], s_rlim[kLRows];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     int64_t t0, cbeg, cend;
-    int64_t irow[kLRows];     // tip id of the resident rows (-1: none)
-    int64_t rlim[kLRows];     // row r takes column positions < rlim[r]
-    int64_t imax = -1;        // largest rlim
+    int64_t imax = -1;        // largest column bound of the resident rows
     const int32_t* colids = nullptr;
+    // ---- resident rows: tip id (-1: none) and the bound on the column position (row r takes positions < rlim)
     if (JOBS) {
         const int4 job = J.jobs[blockIdx.x];
         const int ci = job.x, m = J.cl_m[ci];
@@ -233,51 +273,60 @@ __global__ __launch_bounds__(kLThreads) void mash_dist_lookup_kernel(const uint6
         colids = J.cols + J.cl_coff[ci];
         out = J.out + J.cl_out[ci];
         ld = J.cl_ld[ci];
-#pragma unroll
         for (int r = 0; r < kLRows; ++r) {
             const int64_t tt = t0 + r;
-            irow[r] = tt < m ? J.members[J.cl_moff[ci] + tt] : -1;
-            rlim[r] = tt < m ? kDcLeaves + tt : -1;
-            imax = max(imax, rlim[r]);
+            const int64_t rl = tt < m ? kDcLeaves + tt : -1;
+            if (tid == 0) { s_irow[r] = tt < m ? J.members[J.cl_moff[ci] + tt] : -1; s_rlim[r] = rl; }
+            imax = max(imax, rl);
         }
         cend = min(imax, cbeg + kLColsPerBlock);
     } else {
         t0 = (int64_t)blockIdx.y * kLRows;
         cbeg = (int64_t)blockIdx.x * kLColsPerBlock;
         cend = min(ncols, cbeg + kLColsPerBlock);
-#pragma unroll
         for (int r = 0; r < kLRows; ++r) {
             const int64_t tt = t0 + r;
             int64_t i = -1;
             if (tt < nr) { i = r0 + tt; if (i >= n) i = -1; }
-            irow[r] = i; rlim[r] = i;
+            if (tid == 0) { s_irow[r] = i; s_rlim[r] = i; }
             imax = max(imax, i);
         }
     }
-    if (imax < 0 || cbeg >= imax) return;   // nothing to do in this column range
+    if (imax < 0 || cbeg >= imax) return;   // nothing to do in this column range (block-uniform)
+    __syncthreads();
 
     // ---- resident row structures
-    for (int e = tid; e < kLRows * kLS; e += kLThreads) {
-        const int r = e / kLS, sidx = e % kLS;
-        vals[e] = (irow[r] >= 0 && sidx < S) ? sk[irow[r] * S + sidx] : ~0ull;
+    for (int e = tid; e < kLRows * kTValsStride; e += kLThreads) {
+        const int r = e / kTValsStride, sidx = e % kTValsStride;
+        const int64_t i = s_irow[r];
+        vals[e] = (i >= 0 && sidx < S) ? sk[i * S + sidx] : ~0ull;
     }
     __syncthreads();
     if (tid < kLRows) {
-        const uint64_t mx = vals[tid * kLS + (S - 1)];
+        const uint64_t mx = vals[tid * kTValsStride + (S - 1)];
         const int bits = mx ? 64 - __clzll((long long)mx) : 1;
-        s_shift[tid] = bits > 10 ? bits - 10 : 0;
+        s_shift[tid] = bits > 24 ? bits - 9 : 15;     // >= 15 so that the tag shift is never negative
+        s_dups[tid] = 0;
     }
     __syncthreads();
-    for (int e = tid; e < kLRows * (kLBuckets + 1); e += kLThreads) {
-        const int r = e / (kLBuckets + 1), kb = e % (kLBuckets + 1);
-        const uint64_t* v = vals + r * kLS;
-        const int sh = s_shift[r];
-        int lo = 0, hi = S;                      // first t with (v[t] >> sh) >= kb
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if ((v[mid] >> sh) < (uint64_t)kb) lo = mid + 1; else hi = mid;
+    for (int e = tid; e < kLRows * kLS; e += kLThreads) {        // does the row hold a value twice?
+        const int r = e / kLS, sidx = e % kLS;
+        if (sidx + 1 < S && vals[r * kTValsStride + sidx] == vals[r * kTValsStride + sidx + 1]) s_dups[r] = 1;
+    }
+    for (int e = tid; e < kLRows * (kTB + 1); e += kLThreads) {
+        const int r = e / (kTB + 1), kb = e % (kTB + 1);
+        const uint64_t* v = vals + r * kTValsStride;
+        const int sh = s_shift[r], tsh = sh - 15;
+        int lo = S, hi = S;
+        if (kb < kTB) {
+            lo = lds_lower_bound(v, S, (uint64_t)kb << sh);
+            hi = kb == kTB - 1 ? S : lds_lower_bound(v, S, (uint64_t)(kb + 1) << sh);
         }
-        bucket[e] = (uint32_t)lo;
+        uint32_t t8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t8[q] = 0x8000u | (lo + q < hi ? mash_tag15(v[lo + q], tsh) : 0x7FFFu);
+        tags[r * (kTB + 1) + kb] = make_uint4(t8[0] | (t8[1] << 16), t8[2] | (t8[3] << 16), t8[4] | (t8[5] << 16), t8[6] | (t8[7] << 16));
+        base[r * kTBaseStride + kb] = (uint16_t)(lo | (hi - lo > 8 ? 0x8000 : 0));
     }
     __syncthreads();
 
@@ -288,85 +337,91 @@ __global__ __launch_bounds__(kLThreads) void mash_dist_lookup_kernel(const uint6
         const int64_t j = JOBS ? (int64_t)colids[jpos] : jpos;
         if (j < 0) continue;                                     // empty leaf-list entry (wave-uniform)
         uint64_t a[16];
-        const uint64_t* col = sk + j * S + 16 * lane;
+        const uint64_t* col = sk + j * S + lane;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) a[u] = (16 * lane + u < S) ? col[u] : ~0ull;
-        uint64_t aprev = __shfl_up((unsigned long long)a[15], 1, 64);
-        const bool has_prev = lane > 0;
+        for (int u = 0; u < 16; ++u) a[u] = (64 * u + lane < S) ? col[64 * u] : ~0ull;
+        // bit u of firstmask: a[64u + lane] exists and differs from its predecessor -- only the first
+        // occurrence of a value in A can match (later copies find B exhausted)
+        uint32_t firstmask = 0;
+        {
+            uint64_t carry = ~0ull;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                uint64_t prev = __shfl_up((unsigned long long)a[u], 1, 64);
+                if (lane == 0) prev = carry;
+                const bool first = (64 * u + lane < S) && ((64 * u + lane == 0) || prev != a[u]);
+                firstmask |= (first ? 1u : 0u) << u;
+                carry = __shfl((unsigned long long)a[u], 63, 64);
+            }
+        }
+        int mycnt = 0;                                           // lane r keeps the count of row r
 #pragma unroll 1
         for (int r = 0; r < kLRows; ++r) {
-            if (irow[r] < 0 || jpos >= rlim[r]) continue;        // wave-uniform
-            const uint64_t* v = vals + r * kLS;
-            const uint32_t* bk = bucket + r * (kLBuckets + 1);
-            const int sh = s_shift[r];
-            // phase 1-2: bucket and first probe of all 16 values (independent LDS reads overlap)
-            int t[16];
-            uint64_t bv[16];
+            if (s_irow[r] < 0 || jpos >= s_rlim[r]) continue;    // wave-uniform
+            const uint64_t* v = vals + r * kTValsStride;
+            const uint4* tg_r = tags + r * (kTB + 1);
+            const uint16_t* base_r = base + r * kTBaseStride;
+            const int sh = s_shift[r], tsh = sh - 15;
+            const bool row_dups = s_dups[r] != 0;                // wave-uniform
+            int cnt = 0, mtotal = 0;                             // wave-uniform running totals
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                uint64_t kb = a[u] >> sh;
-                if (kb > (uint64_t)kLBuckets) kb = kLBuckets;
-                t[u] = (int)bk[kb];
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) bv[u] = v[t[u] < S ? t[u] : S - 1];
-            // phase 3: advance to #{b < a} (rarely more than one or two rounds)
-            for (;;) {
-                bool any = false;
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const bool adv = t[u] < S && bv[u] < a[u];
-                    t[u] += adv ? 1 : 0;
-                    any |= adv;
-                }
-                if (!__any(any)) break;
-#pragma unroll
-                for (int u = 0; u < 16; ++u) bv[u] = v[t[u] < S ? t[u] : S - 1];
-            }
-            // phase 4: matches, multiplicities (the next slot is read for every value: no branch)
-            uint64_t nx[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) nx[u] = v[t[u] + 1 < S ? t[u] + 1 : S - 1];
-            int cu[16], mu[16];
-            int msum = 0;
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                cu[u] = 1 << 30; mu[u] = 0;
-                const int sidx = 16 * lane + u;
+                const int pos = 64 * u + lane;
                 const uint64_t av = a[u];
-                const bool first = (u == 0) ? (!has_prev || aprev != av) : (a[u > 0 ? u - 1 : 0] != av);
-                const bool match = sidx < S && first && t[u] < S && bv[u] == av;
-                if (match) {
-                    int mult = 1;
-                    if (t[u] + 1 < S && nx[u] == av) {           // duplicates in B: rare, walk them
-                        mult = 2;
-                        while (t[u] + mult < S && v[t[u] + mult] == av) ++mult;
+                // bucket = leading 9 significant bits (catch-all kTB above the row's range), tag = next 15 bits
+                const uint64_t x = av >> tsh;
+                const uint32_t xlo = (uint32_t)x;
+                const int kb = ((uint32_t)(x >> 32) != 0u || xlo >= ((uint32_t)kTB << 15)) ? kTB : (int)(xlo >> 15);
+                const uint4 tg = tg_r[kb];
+                const uint32_t bs = base_r[kb];
+                const uint32_t mt = xlo & 0x7FFFu;
+                int rankb = (int)(bs & 0x7FFFu) + tags_below(tg, mt | (mt << 16));
+                if (__any((bs & 0x8000u) != 0u)) {               // a crowded bucket in this step (rare)
+                    if (bs & 0x8000u) rankb = lds_lower_bound(v, S, av);
+                }
+                uint64_t b0 = v[rankb];
+                if (__any(b0 < av)) {                            // equal tags of different values (rare)
+                    while (b0 < av) b0 = v[++rankb];
+                }
+                const bool match = ((firstmask >> u) & 1u) && b0 == av;
+                const unsigned long long mb = __ballot(match);
+                int madd;
+                if (row_dups) {                                  // multiplicities in B: full prefix sum
+                    int mult = 0;
+                    if (match) { mult = 1; while (rankb + mult < S && v[rankb + mult] == av) ++mult; }
+                    int incl = mult;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const int x = __shfl_up(incl, off, 64);
+                        if (lane >= off) incl += x;
                     }
-                    cu[u] = sidx + t[u] - msum;                  // rank before the lanes' prefix is subtracted
-                    mu[u] = mult;
-                    msum += mult;
+                    madd = __shfl(incl, 63, 64);
+                    const bool ok = match && (pos + rankb - (mtotal + incl - mult) < S);
+                    int c = ok ? mult : 0;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+                    cnt += c;
+                } else {
+                    madd = __popcll(mb);
+                    const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u));
+                    const bool ok = match && (pos + rankb - (mtotal + below) < S);
+                    cnt += __popcll(__ballot(ok));
                 }
+                mtotal += madd;
+                // ranks grow with the value: the next step starts at rank >= 64(u+1) + #{b < a[64u+63]} - mtotal
+                const int rb63 = __builtin_amdgcn_readlane(rankb, 63);
+                if (64 * (u + 1) >= S || 64 * (u + 1) + rb63 - mtotal >= S) break;
             }
-            int incl = msum;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int x = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += x;
-            }
-            const int thr = S + (incl - msum);                   // rank - prefix < S
-            int cnt = 0;
-#pragma unroll
-            for (int u = 0; u < 16; ++u) cnt += (cu[u] < thr) ? mu[u] : 0;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-            if (lane == 0) {
-                const double jac = fmax((double)cnt, 1.0) / S;
-                const double d = fmin(1.0, fabs(log(2.0 * jac / (1.0 + jac)) / (double)k));
-                if (JOBS) out[(t0 + r) * ld + jpos] = d;
-                else {
-                    if (transposed) out[j * ld + (t0 + r)] = d; else out[(t0 + r) * ld + j] = d;
-                    if (mirror) out[j * ld + (r0 + t0 + r)] = d;
-                }
+            if (lane == r) mycnt = cnt;
+        }
+        if (lane < kLRows && s_irow[lane] >= 0 && jpos < s_rlim[lane]) {
+            const double jac = fmax((double)mycnt, 1.0) / S;
+            const double d = fmin(1.0, fabs(log(2.0 * jac / (1.0 + jac)) / (double)k));
+            const int64_t t = t0 + lane;
+            if (JOBS) out[t * ld + jpos] = d;
+            else {
+                if (transposed) out[j * ld + t] = d; else out[t * ld + j] = d;
+                if (mirror) out[j * ld + (r0 + t)] = d;
             }
         }
     }
@@ -428,7 +483,7 @@ int mash_sketch(MashBuffers& m, int k, int S, hipStream_t s)
 static int lookup_attr()
 {
     static bool attr_set = false;
-    const size_t tlds = sizeof(uint64_t) * kLRows * kLS + sizeof(uint32_t) * kLRows * (kLBuckets + 1);
+    const size_t tlds = kTLds;
     if (!attr_set) {
         DPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mash_dist_lookup_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
@@ -447,7 +502,7 @@ int mash_dist_jobs(const MashBuffers& m, const PairJobs& J, int njobs, hipStream
     if (njobs <= 0) return DPR_OK;
     if (m.S > kLS) { set_error("divide-and-conquer mode needs a sketch size <= 1024"); return DPR_ERR_ARG; }
     if (int rc = lookup_attr()) return rc;
-    const size_t tlds = sizeof(uint64_t) * kLRows * kLS + sizeof(uint32_t) * kLRows * (kLBuckets + 1);
+    const size_t tlds = kTLds;
     hipLaunchKernelGGL(mash_dist_lookup_kernel<true>, dim3((unsigned)njobs), dim3(kLThreads), tlds, s, m.sketches, m.S,
                        m.k, m.n, (int64_t)0, (int64_t)0, (int64_t)0, (double*)nullptr, (int64_t)0, 0, 0, J);
     DPR_HIP(hipGetLastError());
@@ -463,7 +518,7 @@ int mash_dist_rows(const MashBuffers& m, int64_t r0, int64_t nr, int rank, int w
     const bool mirror = full && world == 1 && r0 == 0;
     if (m.S <= kLS && (!full || mirror) && world <= 1 && (transposed || !std::getenv("DPR_MASH_SIMPLE"))) {
         if (int rc = lookup_attr()) return rc;
-        const size_t tlds = sizeof(uint64_t) * kLRows * kLS + sizeof(uint32_t) * kLRows * (kLBuckets + 1);
+        const size_t tlds = kTLds;
         dim3 tgrid((unsigned)((ncols + kLColsPerBlock - 1) / kLColsPerBlock), (unsigned)((nr + kLRows - 1) / kLRows));
         hipLaunchKernelGGL(mash_dist_lookup_kernel<false>, tgrid, dim3(kLThreads), tlds, s, m.sketches, m.S, m.k, m.n, r0,
                            nr, ncols, out, ld, mirror ? 1 : 0, transposed ? 1 : 0, PairJobs());
