@@ -12,6 +12,8 @@
 // State layout mirrors the reference (forward-star adjacency head/e/nxt/belong/len, K=5 sorted
 // closest lists per directed edge) plus rev[slot] = reverse slot, which replaces the list walk of
 // src/placement_close_k.cu:339-340.
+#include <cstdlib>
+
 #include "dpr_internal.hpp"
 
 namespace dpr {
@@ -63,23 +65,62 @@ __device__ __forceinline__ void list_insert(double* cdis, int32_t* cid, int slot
     }
 }
 
-// updateClosestNodes, one wave: frontier entries l..r processed 64 at a time.
-__device__ void closest_update_wave(const PlaceBuffers& p, int x)
+// updateClosestNodes, one wave: frontier entries l..r processed 64 at a time.  Per round a lane makes
+// three dependent memory hops (queue entry -> the node's slot triple adj[] -> everything about those
+// slots: target, length, both 5-entry lists, all loads in flight together) instead of walking the
+// head/nxt list with one hop per field.  adj[3*node] == -2 marks a node of degree > 3 (possible only in
+// an imported backbone), which falls back to the list walk.
+__device__ __forceinline__ void closest_update_wave(const PlaceBuffers& p, int x)
 {
     const int lane = threadIdx.x & 63;
     int l = 0, r = 1;  // queue [l, r)
     if (lane == 0) { p.q_id[0] = x; p.q_dis[0] = 0.0; p.q_from[0] = -1; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     while (l < r) {
         const int cnt = min(64, r - l);
         int node = -1, fb = -1;
         double d = 0.0;
         if (lane < cnt) { node = p.q_id[l + lane]; fb = p.q_from[l + lane]; d = p.q_dis[l + lane]; }
-        // each lane walks the out-edges of its node (pass 1: insert, remember which edges took it)
+        int s3[3] = { -1, -1, -1 };
+        if (lane < cnt) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s3[k] = p.adj[3 * node + k];
+        }
+        const bool walk = s3[0] == -2;
+        int en[3] = { -1, -1, -1 };
+        double ln[3] = { 0, 0, 0 };
         int nnew = 0;
         unsigned long long took = 0ull;
-        if (lane < cnt) {
+        if (!walk) {
+            double cd[3][K5];
+            int ci[3][K5];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (s3[k] >= 0) {
+                    const int sl = s3[k];
+                    en[k] = p.e[sl]; ln[k] = p.len[sl];
+#pragma unroll
+                    for (int j = 0; j < K5; ++j) { cd[k][j] = p.cdis[sl * K5 + j]; ci[k][j] = p.cid[sl * K5 + j]; }
+                }
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (s3[k] >= 0 && en[k] != fb) {
+                    const int sl = s3[k];
+                    int j = K5;
+#pragma unroll
+                    for (int t = K5 - 1; t >= 0; --t)
+                        if (cd[k][t] > d) j = t;              // first entry farther than d
+                    if (j < K5) {
+#pragma unroll
+                        for (int t = K5 - 1; t > 0; --t)
+                            if (t > j) { p.cdis[sl * K5 + t] = cd[k][t - 1]; p.cid[sl * K5 + t] = ci[k][t - 1]; }
+                        p.cdis[sl * K5 + j] = d;
+                        p.cid[sl * K5 + j] = x;
+                        took |= 1ull << k; nnew++;
+                    }
+                }
+        } else {
             int pos = 0;
             for (int i = p.head[node]; i != -1; i = p.nxt[i], ++pos) {
                 if (p.e[i] == fb) continue;
@@ -97,16 +138,20 @@ __device__ void closest_update_wave(const PlaceBuffers& p, int x)
         }
         const int total = __shfl(incl, 63, 64);
         if (nnew) {
-            int w = r + incl - nnew, pos = 0;
-            for (int i = p.head[node]; i != -1; i = p.nxt[i], ++pos)
-                if (pos < 64 && ((took >> pos) & 1ull)) {
-                    p.q_id[w] = p.e[i]; p.q_dis[w] = d + p.len[i]; p.q_from[w] = node; ++w;
-                }
+            int w = r + incl - nnew;
+            if (!walk) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if ((took >> k) & 1ull) { p.q_id[w] = en[k]; p.q_dis[w] = d + ln[k]; p.q_from[w] = node; ++w; }
+            } else {
+                int pos = 0;
+                for (int i = p.head[node]; i != -1; i = p.nxt[i], ++pos)
+                    if (pos < 64 && ((took >> pos) & 1ull)) { p.q_id[w] = p.e[i]; p.q_dis[w] = d + p.len[i]; p.q_from[w] = node; ++w; }
+            }
         }
         l += cnt;
         r += total;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 }
@@ -122,12 +167,26 @@ __global__ __launch_bounds__(64) void place_initial_tree_kernel(PlaceBuffers p, 
         p.e[ec] = nv; p.len[ec] = d / 2; p.nxt[ec] = p.head[1]; p.head[1] = ec; p.belong[ec] = 1; p.rev[ec] = 3; ec++;
         p.e[ec] = 0;  p.len[ec] = d / 2; p.nxt[ec] = p.head[nv]; p.head[nv] = ec; p.belong[ec] = nv; p.rev[ec] = 0; ec++;
         p.e[ec] = 1;  p.len[ec] = d / 2; p.nxt[ec] = p.head[nv]; p.head[nv] = ec; p.belong[ec] = nv; p.rev[ec] = 1; ec++;
+        p.adj[0] = 0; p.adj[1] = -1; p.adj[2] = -1;
+        p.adj[3] = 1; p.adj[4] = -1; p.adj[5] = -1;
+        p.adj[3 * nv] = 2; p.adj[3 * nv + 1] = 3; p.adj[3 * nv + 2] = -1;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     closest_update_wave(p, 0);
     closest_update_wave(p, 1);
+}
+
+// slot triples of an imported backbone (degree > 3 -> -2: list walk)
+__global__ __launch_bounds__(kThreads) void place_build_adj_kernel(PlaceBuffers p, int64_t nodes)
+{
+    const int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (v >= nodes) return;
+    int s3[3] = { -1, -1, -1 }, cnt = 0;
+    for (int i = p.head[v]; i != -1; i = p.nxt[i], ++cnt)
+        if (cnt < 3) s3[cnt] = i;
+    if (cnt > 3) { s3[0] = -2; s3[1] = -2; s3[2] = -2; }
+    p.adj[3 * v] = s3[0]; p.adj[3 * v + 1] = s3[1]; p.adj[3 * v + 2] = s3[2];
 }
 
 // closest lists of an imported backbone: leaves 0..m-1 in order (src/placement_close_k.cu:247-260)
@@ -136,31 +195,143 @@ __global__ __launch_bounds__(64) void place_backbone_lists_kernel(PlaceBuffers p
     for (int64_t t = t0; t < t1; ++t) closest_update_wave(p, (int)t);
 }
 
-// calculateBranchLength for live slots idx < 4*num-4 and block-level first-minimum
-__global__ __launch_bounds__(kThreads) void place_scan_kernel(PlaceBuffers p, const double* __restrict__ dis,
-                                                              int64_t num, PlacePartial* __restrict__ partials)
+// Per tip two kernels: place_tip_kernel (calculateBranchLength for the live slots idx < 4*num-4 and the
+// block-level first minimum) and the single-wavefront place_update_kernel, which finishes the argmin,
+// splits the edge (updateTreeStructure) and runs the closest-list update (updateClosestNodes) -- the
+// reference's Thrust reduction, device->host copy and two single-thread kernels.  (Fusing the two with a
+// last-block-done ticket was measured 1.5-2x SLOWER: every block then needs a device-scope release
+// fence, i.e. an L2 write-back, which costs more than the kernel boundary it saves.)
+__device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, const PlacePartial* partials, int nparts,
+                                                        int64_t num, int64_t edge_count, double* __restrict__ trace)
 {
-    __shared__ double sadd[kThreads / 64];
-    __shared__ int sidx[kThreads / 64];
+    const int lane = threadIdx.x & 63;
+    double badd = __builtin_inf(), bfrac = 0;
+    int bidx = 0x7fffffff, beid = 0;
+    for (int i = lane; i < nparts; i += 64) {
+        const PlacePartial pp = partials[i];
+        if (pp.add < badd || (pp.add == badd && pp.idx < bidx)) { badd = pp.add; bidx = pp.idx; beid = pp.eid; bfrac = pp.frac; }
+    }
+    // slots >= 4*num-4 (and < 4M-4) all carry the tuple (0,0,2): the first of them competes
+    const int64_t live = 4 * num - 4, lim = 4 * p.M - 4;
+    if (lane == 0 && live < lim) {
+        if (2.0 < badd || (2.0 == badd && (int)live < bidx)) { badd = 2.0; bidx = (int)live; beid = 0; bfrac = 0; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oa = __shfl_down(badd, off, 64);
+        const int oi = __shfl_down(bidx, off, 64);
+        const int oe = __shfl_down(beid, off, 64);
+        const double of = __shfl_down(bfrac, off, 64);
+        if (oa < badd || (oa == badd && oi < bidx)) { badd = oa; bidx = oi; beid = oe; bfrac = of; }
+    }
+    const int eid = __shfl(beid, 0, 64);
+    const double fracLen = __shfl(bfrac, 0, 64), addLen = __shfl(badd, 0, 64);
+    const int placeId = (int)num;
+    if (lane == 0) {
+        if (trace) { trace[3 * num] = eid; trace[3 * num + 1] = fracLen; trace[3 * num + 2] = addLen; }
+        int ec = (int)edge_count;
+        const int N = (int)p.N;
+        const int middle = placeId + N - 1, outside = placeId;
+        const int xe = eid, ye = p.rev[eid];   // the reference finds them by walking head[x] / head[y]
+        const int x = p.belong[eid], y = p.e[eid];
+        const double originalDis = p.len[eid];
+        // both lists up front (independent loads)
+        double cdx[K5], cdy[K5];
+        int cix[K5], ciy[K5];
+#pragma unroll
+        for (int i = 0; i < K5; ++i) { cdx[i] = p.cdis[xe * K5 + i]; cix[i] = p.cid[xe * K5 + i]; cdy[i] = p.cdis[ye * K5 + i]; ciy[i] = p.cid[ye * K5 + i]; }
+        const double lenye = p.len[ye];
+        p.e[xe] = middle; p.len[xe] = fracLen;
+        p.e[ye] = middle; p.len[ye] = lenye - fracLen;
+        // middle -> x: inherits the list of y -> x (slots untouched by the reference keep the init values 2 / -1)
+        double n0d[K5], n1d[K5];
+        int n0i[K5], n1i[K5];
+        p.e[ec] = x; p.len[ec] = fracLen; p.nxt[ec] = -1; p.belong[ec] = middle;
+#pragma unroll
+        for (int i = 0; i < K5; ++i) {
+            const bool has = ciy[i] != -1;
+            n0i[i] = has ? ciy[i] : p.cid[ec * K5 + i];
+            n0d[i] = has ? cdy[i] + originalDis - fracLen : p.cdis[ec * K5 + i];
+            if (has) { p.cid[ec * K5 + i] = n0i[i]; p.cdis[ec * K5 + i] = n0d[i]; }
+        }
+        p.rev[ec] = xe; p.rev[xe] = ec;
+        ec++;
+        // middle -> y: inherits the list of x -> y
+        p.e[ec] = y; p.len[ec] = originalDis - fracLen; p.nxt[ec] = ec - 1; p.belong[ec] = middle;
+#pragma unroll
+        for (int i = 0; i < K5; ++i) {
+            const bool has = cix[i] != -1;
+            n1i[i] = has ? cix[i] : p.cid[ec * K5 + i];
+            n1d[i] = has ? cdx[i] + fracLen : p.cdis[ec * K5 + i];
+            if (has) { p.cid[ec * K5 + i] = n1i[i]; p.cdis[ec * K5 + i] = n1d[i]; }
+        }
+        p.rev[ec] = ye; p.rev[ye] = ec;
+        ec++;
+        // outside -> middle
+        p.e[ec] = middle; p.len[ec] = addLen; p.nxt[ec] = -1; p.head[outside] = ec; p.belong[ec] = outside;
+        p.rev[ec] = ec + 1;
+        ec++;
+        // middle -> outside: merge of the two inherited lists (src/placement_close_k.cu:506-527), in registers
+        p.e[ec] = outside; p.len[ec] = addLen; p.nxt[ec] = ec - 2; p.head[middle] = ec; p.belong[ec] = middle;
+        p.rev[ec] = ec - 1;
+        double md[K5];
+        int mi[K5];
+#pragma unroll
+        for (int i = 0; i < K5; ++i) { md[i] = p.cdis[ec * K5 + i]; mi[i] = p.cid[ec * K5 + i]; }
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int i = 0; i < K5; ++i) {
+                const int si = pass == 0 ? n1i[i] : n0i[i];      // e1 = middle->y first, then e2 = middle->x
+                const double sd = pass == 0 ? n1d[i] : n0d[i];
+                if (si == -1) break;
+                for (int j = 0; j < K5; ++j)
+                    if (md[j] > sd) {
+                        for (int k = K5 - 1; k > j; --k) { md[k] = md[k - 1]; mi[k] = mi[k - 1]; }
+                        md[j] = sd; mi[j] = si;
+                        break;
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < K5; ++i) { p.cdis[ec * K5 + i] = md[i]; p.cid[ec * K5 + i] = mi[i]; }
+        // slot triples of the two new nodes (existing nodes keep theirs: a split only retargets slots)
+        p.adj[3 * middle] = ec - 3; p.adj[3 * middle + 1] = ec - 2; p.adj[3 * middle + 2] = ec;
+        p.adj[3 * outside] = ec - 1; p.adj[3 * outside + 1] = -1; p.adj[3 * outside + 2] = -1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    closest_update_wave(p, placeId);
+}
+
+constexpr int kTipThreads = 256;
+__global__ __launch_bounds__(kTipThreads) void place_tip_kernel(PlaceBuffers p, const double* __restrict__ dis,
+                                                             int64_t num, PlacePartial* __restrict__ partials)
+{
+    __shared__ double sadd[kTipThreads / 64];
+    __shared__ int sidx[kTipThreads / 64];
     const int64_t live = 4 * num - 4;
-    const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t idx = (int64_t)blockIdx.x * kTipThreads + threadIdx.x;
     double add = 2.0, d1 = 0.0;
     int eid = 0;
     bool have = idx < live;
     if (have && p.belong[idx] >= p.e[idx]) {
-        const int x = p.belong[idx];
-        (void)x;
         eid = (int)idx;
         const int oe = p.rev[idx];
+        double cd[2 * K5];
+        int ci[2 * K5];
+#pragma unroll
+        for (int i = 0; i < K5; ++i) { ci[i] = p.cid[eid * K5 + i]; cd[i] = p.cdis[eid * K5 + i]; }
+#pragma unroll
+        for (int i = 0; i < K5; ++i) { ci[K5 + i] = p.cid[oe * K5 + i]; cd[K5 + i] = p.cdis[oe * K5 + i]; }
+        double dv[2 * K5];
+#pragma unroll
+        for (int i = 0; i < 2 * K5; ++i) dv[i] = ci[i] != -1 ? dis[ci[i]] : 0.0;
         double dis1 = 0, dis2 = 0, val;
-        for (int i = 0; i < K5; ++i) {
-            const int c = p.cid[eid * K5 + i];
-            if (c != -1) { val = dis[c] - p.cdis[eid * K5 + i]; if (val > dis1) dis1 = val; }
-        }
-        for (int i = 0; i < K5; ++i) {
-            const int c = p.cid[oe * K5 + i];
-            if (c != -1) { val = dis[c] - p.cdis[oe * K5 + i]; if (val > dis2) dis2 = val; }
-        }
+#pragma unroll
+        for (int i = 0; i < K5; ++i)
+            if (ci[i] != -1) { val = dv[i] - cd[i]; if (val > dis1) dis1 = val; }
+#pragma unroll
+        for (int i = 0; i < K5; ++i)
+            if (ci[K5 + i] != -1) { val = dv[K5 + i] - cd[K5 + i]; if (val > dis2) dis2 = val; }
         const double L = p.len[eid];
         double a = (dis1 + dis2 - L) / 2;
         if (a < 0) a = 0;
@@ -187,7 +358,7 @@ __global__ __launch_bounds__(kThreads) void place_scan_kernel(PlaceBuffers p, co
     if (lane == 0) { sadd[w] = badd; sidx[w] = bidx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < kThreads / 64; ++i)
+        for (int i = 1; i < kTipThreads / 64; ++i)
             if (sadd[i] < badd || (sadd[i] == badd && sidx[i] < bidx)) { badd = sadd[i]; bidx = sidx[i]; }
         sadd[0] = badd; sidx[0] = bidx;
     }
@@ -203,91 +374,10 @@ __global__ __launch_bounds__(kThreads) void place_scan_kernel(PlaceBuffers p, co
     }
 }
 
-// finish the argmin, updateTreeStructure, updateClosestNodes -- one wave
-__global__ __launch_bounds__(64) void place_update_kernel(PlaceBuffers p, const PlacePartial* __restrict__ partials,
-                                                          int nparts, int64_t num, int64_t edge_count,
-                                                          double* __restrict__ trace)
+__global__ __launch_bounds__(64) void place_update_kernel(PlaceBuffers p, const PlacePartial* partials, int nparts,
+                                                          int64_t num, double* __restrict__ trace)
 {
-    const int lane = threadIdx.x;
-    double badd = __builtin_inf(), bfrac = 0;
-    int bidx = 0x7fffffff, beid = 0;
-    for (int i = lane; i < nparts; i += 64) {
-        const PlacePartial pp = partials[i];
-        if (pp.add < badd || (pp.add == badd && pp.idx < bidx)) { badd = pp.add; bidx = pp.idx; beid = pp.eid; bfrac = pp.frac; }
-    }
-    // slots >= 4*num-4 (and < 4N-4) all carry the tuple (0,0,2): the first of them competes
-    const int64_t live = 4 * num - 4, lim = 4 * p.M - 4;
-    if (lane == 0 && live < lim) {
-        if (2.0 < badd || (2.0 == badd && (int)live < bidx)) { badd = 2.0; bidx = (int)live; beid = 0; bfrac = 0; }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double oa = __shfl_down(badd, off, 64);
-        const int oi = __shfl_down(bidx, off, 64);
-        const int oe = __shfl_down(beid, off, 64);
-        const double of = __shfl_down(bfrac, off, 64);
-        if (oa < badd || (oa == badd && oi < bidx)) { badd = oa; bidx = oi; beid = oe; bfrac = of; }
-    }
-    const int eid = __shfl(beid, 0, 64);
-    const double fracLen = __shfl(bfrac, 0, 64), addLen = __shfl(badd, 0, 64);
-    const int placeId = (int)num;
-    if (lane == 0) {
-        if (trace) { trace[3 * num] = eid; trace[3 * num + 1] = fracLen; trace[3 * num + 2] = addLen; }
-        int ec = (int)edge_count;
-        const int N = (int)p.N;
-        const int middle = placeId + N - 1, outside = placeId;
-        const int x = p.belong[eid], y = p.e[eid];
-        const double originalDis = p.len[eid];
-        const int xe = eid, ye = p.rev[eid];   // the reference finds them by walking head[x] / head[y]
-        p.e[xe] = middle; p.len[xe] = fracLen;
-        p.e[ye] = middle; p.len[ye] -= fracLen;
-        // middle -> x
-        p.e[ec] = x; p.len[ec] = fracLen; p.nxt[ec] = p.head[middle]; p.head[middle] = ec; p.belong[ec] = middle;
-        for (int i = 0; i < K5; ++i)
-            if (p.cid[ye * K5 + i] != -1) {
-                p.cid[ec * K5 + i] = p.cid[ye * K5 + i];
-                p.cdis[ec * K5 + i] = p.cdis[ye * K5 + i] + originalDis - fracLen;
-            }
-        p.rev[ec] = xe; p.rev[xe] = ec;
-        ec++;
-        // middle -> y
-        p.e[ec] = y; p.len[ec] = originalDis - fracLen; p.nxt[ec] = p.head[middle]; p.head[middle] = ec; p.belong[ec] = middle;
-        for (int i = 0; i < K5; ++i)
-            if (p.cid[xe * K5 + i] != -1) {
-                p.cid[ec * K5 + i] = p.cid[xe * K5 + i];
-                p.cdis[ec * K5 + i] = p.cdis[xe * K5 + i] + fracLen;
-            }
-        p.rev[ec] = ye; p.rev[ye] = ec;
-        ec++;
-        // outside -> middle
-        p.e[ec] = middle; p.len[ec] = addLen; p.nxt[ec] = p.head[outside]; p.head[outside] = ec; p.belong[ec] = outside;
-        p.rev[ec] = ec + 1;
-        ec++;
-        // middle -> outside
-        p.e[ec] = outside; p.len[ec] = addLen; p.nxt[ec] = p.head[middle]; p.head[middle] = ec; p.belong[ec] = middle;
-        p.rev[ec] = ec - 1;
-        const int e1 = ec - 2, e2 = ec - 3;
-        for (int pass = 0; pass < 2; ++pass) {
-            const int src = pass == 0 ? e1 : e2;
-            for (int i = 0; i < K5; ++i) {
-                if (p.cid[src * K5 + i] == -1) break;
-                for (int j = 0; j < K5; ++j)
-                    if (p.cdis[ec * K5 + j] > p.cdis[src * K5 + i]) {
-                        for (int k = K5 - 1; k > j; --k) {
-                            p.cdis[ec * K5 + k] = p.cdis[ec * K5 + k - 1];
-                            p.cid[ec * K5 + k] = p.cid[ec * K5 + k - 1];
-                        }
-                        p.cdis[ec * K5 + j] = p.cdis[src * K5 + i];
-                        p.cid[ec * K5 + j] = p.cid[src * K5 + i];
-                        break;
-                    }
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    closest_update_wave(p, placeId);
+    place_finish_and_update(p, partials, nparts, num, 4 * num - 4, trace);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -304,6 +394,7 @@ int place_alloc(PlaceBuffers& p, int64_t N, int64_t M)
     DPR_HIP(hipMalloc(&p.belong, sizeof(int32_t) * (size_t)(8 * N)));
     DPR_HIP(hipMalloc(&p.rev, sizeof(int32_t) * (size_t)(8 * N)));
     DPR_HIP(hipMalloc(&p.len, sizeof(double) * (size_t)(8 * N)));
+    DPR_HIP(hipMalloc(&p.adj, sizeof(int32_t) * (size_t)(6 * N)));
     DPR_HIP(hipMalloc(&p.cid, sizeof(int32_t) * (size_t)(40 * N)));
     DPR_HIP(hipMalloc(&p.cdis, sizeof(double) * (size_t)(40 * N)));
     DPR_HIP(hipMalloc(&p.q_id, sizeof(int32_t) * (size_t)(2 * N + 64)));
@@ -316,7 +407,7 @@ int place_alloc(PlaceBuffers& p, int64_t N, int64_t M)
 
 void place_free(PlaceBuffers& p)
 {
-    void* ptrs[] = { p.head, p.e, p.nxt, p.belong, p.rev, p.len, p.cid, p.cdis, p.q_id, p.q_from, p.q_dis, p.partials };
+    void* ptrs[] = { p.head, p.e, p.nxt, p.belong, p.rev, p.len, p.cid, p.cdis, p.q_id, p.q_from, p.q_dis, p.partials, p.adj };
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     p = PlaceBuffers();
@@ -344,6 +435,7 @@ int place_import_backbone(PlaceBuffers& p, int64_t m, hipStream_t s)
     hipLaunchKernelGGL(place_init_lists_kernel, dim3((unsigned)((lim + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, lim);
     const int64_t nslots = 4 * m - 4;
     hipLaunchKernelGGL(place_pair_rev_kernel, dim3((unsigned)((nslots + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, nslots);
+    hipLaunchKernelGGL(place_build_adj_kernel, dim3((unsigned)((2 * p.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, 2 * p.N);
     // sequential over the backbone leaves (ties in the lists depend on this order); chunked so that no
     // single launch runs for too long
     const int64_t chunk = 4096;
@@ -358,11 +450,10 @@ int place_import_backbone(PlaceBuffers& p, int64_t m, hipStream_t s)
 int place_tip(PlaceBuffers& p, const double* d_dis, int64_t tip, double* d_trace, hipStream_t s)
 {
     const int64_t live = 4 * tip - 4;
-    const int nblk = (int)((live + kThreads - 1) / kThreads);
-    hipLaunchKernelGGL(place_scan_kernel, dim3((unsigned)nblk), dim3(kThreads), 0, s, p, d_dis, tip,
-                       reinterpret_cast<PlacePartial*>(p.partials));
-    hipLaunchKernelGGL(place_update_kernel, dim3(1), dim3(64), 0, s, p, reinterpret_cast<const PlacePartial*>(p.partials),
-                       nblk, tip, live, d_trace);
+    const int nblk = (int)((live + kTipThreads - 1) / kTipThreads);
+    PlacePartial* parts = reinterpret_cast<PlacePartial*>(p.partials);
+    hipLaunchKernelGGL(place_tip_kernel, dim3((unsigned)nblk), dim3(kTipThreads), 0, s, p, d_dis, tip, parts);
+    hipLaunchKernelGGL(place_update_kernel, dim3(1), dim3(64), 0, s, p, (const PlacePartial*)parts, nblk, tip, d_trace);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
