@@ -234,6 +234,7 @@ struct ExactBuffers {
     int32_t* order = nullptr;    // [2N] placed nodes grouped by depth
     int32_t* lvoff = nullptr;    // [2N+2] first index of every level in order[]
     int32_t* hist = nullptr;     // [2N+2]
+    int32_t* nd = nullptr;       // [2N][12] node records: slot[3], reverse slot[3], target node[3], pad
     void* partials = nullptr;
 };
 int exact_alloc(ExactBuffers& x, int64_t N);

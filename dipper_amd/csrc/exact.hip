@@ -13,6 +13,8 @@
 //       level does not influence any result), then run the level-synchronous bottom-up / top-down
 //       pass for the NEXT tip with workgroup barriers between levels instead of kernel launches.
 // lim[], depths and level lists live in HBM/L2 (O(N) per tip); nothing returns to the host.
+#include <cstdlib>
+
 #include "dpr_internal.hpp"
 
 namespace dpr {
@@ -23,47 +25,118 @@ struct PlacePartialX { double add; int32_t idx; int32_t eid; double frac; };
 
 __device__ __forceinline__ bool px_placed(int idx, int i, int N) { return !(idx > i && idx < N); }
 
-// level-synchronous passes for tip `tip` (its distance row `dis`): lim[slot x->y] = max(0 | dist[x] for a
+// node record: (slot, reverse slot, target node) x 3, laid out slot[3], rslot[3], nb[3], pad[3]
+__device__ __forceinline__ void px_set_node(const ExactBuffers& x, int node, int s0, int r0, int n0, int s1, int r1, int n1,
+                                            int s2, int r2, int n2)
+{
+    int32_t* q = x.nd + 12 * (int64_t)node;
+    q[0] = s0; q[1] = s1; q[2] = s2; q[3] = r0; q[4] = r1; q[5] = r2; q[6] = n0; q[7] = n1; q[8] = n2;
+}
+__device__ __forceinline__ void px_retarget(const ExactBuffers& x, int node, int slot, int new_rev, int new_nb)
+{
+    int32_t* q = x.nd + 12 * (int64_t)node;
+    for (int k = 0; k < 3; ++k)
+        if (q[k] == slot) { q[3 + k] = new_rev; q[6 + k] = new_nb; }
+}
+
+// Node record (12 ints): the node's up to three slots, their reverse slots and their target nodes.  Slots
+// are write-once per node (a split only retargets them), so a record changes only where the split
+// happens.  With it a level step needs ONE dependent memory hop: everything that does not depend on the
+// previous level (record, depths, lengths, the leaf's distance) is loaded one level ahead.
+struct NodeCtx {
+    int idx;            // -1: none
+    int slot[3], rslot[3];
+    bool down[3];       // edge leads to a deeper node (src/placement.cu:320,346: dep[e[i]] > dep[idx])
+    double len[3];
+    double init;        // 0, or the distance for a leaf (src/placement.cu:317-318)
+};
+
+__device__ __forceinline__ NodeCtx px_load_ctx(const ExactBuffers& x, const PlaceBuffers& p, const double* __restrict__ dis,
+                                               int t, int t1)
+{
+    NodeCtx c;
+    c.idx = -1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { c.slot[k] = -1; c.rslot[k] = -1; c.down[k] = false; c.len[k] = 0; }
+    c.init = 0;
+    if (t < t1) {
+        const int idx = x.order[t];
+        c.idx = idx;
+        const int4 a = reinterpret_cast<const int4*>(x.nd + 12 * (int64_t)idx)[0];
+        const int4 b = reinterpret_cast<const int4*>(x.nd + 12 * (int64_t)idx)[1];
+        const int4 cc = reinterpret_cast<const int4*>(x.nd + 12 * (int64_t)idx)[2];
+        c.slot[0] = a.x; c.slot[1] = a.y; c.slot[2] = a.z;
+        c.rslot[0] = a.w; c.rslot[1] = b.x; c.rslot[2] = b.y;
+        const int nb[3] = { b.z, b.w, cc.x };
+        const int dd = x.dep[idx];
+        if (idx < (int)p.N) c.init = dis[idx];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (c.slot[k] >= 0) { c.down[k] = x.dep[nb[k]] > dd; c.len[k] = p.len[c.slot[k]]; }
+    }
+    return c;
+}
+
+// bottom-up: lim[slot to the parent] = max(init, lim[child -> node] - len) over the child edges
+__device__ __forceinline__ void px_up(const ExactBuffers& x, const NodeCtx& c)
+{
+    if (c.idx < 0) return;
+    double mx = c.init;
+    int up = -1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (c.slot[k] >= 0) {
+            if (c.down[k]) { const double req = x.lim[c.rslot[k]] - c.len[k]; if (req > mx) mx = req; }
+            else up = c.slot[k];
+        }
+    if (up >= 0) x.lim[up] = mx;
+}
+
+// top-down: lim[slot to a child] = max(0, lim[other -> node] - len) over the node's other edges
+__device__ __forceinline__ void px_down(const ExactBuffers& x, const NodeCtx& c)
+{
+    if (c.idx < 0) return;
+    double rq[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rq[k] = c.slot[k] >= 0 ? x.lim[c.rslot[k]] - c.len[k] : 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        if (c.slot[a] >= 0 && c.down[a]) {
+            double mx = 0;
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                if (b != a && c.slot[b] >= 0 && rq[b] > mx) mx = rq[b];
+            x.lim[c.slot[a]] = mx;
+        }
+}
+
+// level-synchronous passes for one tip (its distance row `dis`): lim[slot x->y] = max(0 | dist[x] for a
 // leaf, max over the other edges (x,z) of lim[z->x] - len) -- bottom-up fills child->parent slots,
-// top-down parent->child slots (src/placement.cu:296-364)
+// top-down parent->child slots (src/placement.cu:296-364); one workgroup barrier per level
 __device__ void px_dp(const ExactBuffers& x, const PlaceBuffers& p, const double* __restrict__ dis, int maxdep)
 {
-    const int N = (int)p.N;
+    const int tid = threadIdx.x;
+    NodeCtx cur = px_load_ctx(x, p, dis, x.lvoff[maxdep] + tid, x.lvoff[maxdep + 1]);
     for (int j = maxdep; j >= 0; --j) {
         const int t0 = x.lvoff[j], t1 = x.lvoff[j + 1];
-        for (int t = t0 + (int)threadIdx.x; t < t1; t += kXT) {
-            const int idx = x.order[t];
-            const int dd = x.dep[idx];
-            double mx = 0;
-            if (idx < N) mx = dis[idx];
-            int up = -1;
-            for (int i = p.head[idx]; i != -1; i = p.nxt[i]) {
-                if (x.dep[p.e[i]] > dd) { const double req = x.lim[p.rev[i]] - p.len[i]; if (req > mx) mx = req; }
-                else up = i;
-            }
-            if (up >= 0) x.lim[up] = mx;
-        }
+        NodeCtx nxt;
+        nxt.idx = -1;
+        if (j > 0) nxt = px_load_ctx(x, p, dis, x.lvoff[j - 1] + tid, t0);       // one level ahead
+        px_up(x, cur);
+        for (int t = t0 + tid + kXT; t < t1; t += kXT) px_up(x, px_load_ctx(x, p, dis, t, t1));
         __syncthreads();
+        cur = nxt;
     }
+    cur = px_load_ctx(x, p, dis, x.lvoff[0] + tid, x.lvoff[1]);
     for (int j = 0; j <= maxdep; ++j) {
         const int t0 = x.lvoff[j], t1 = x.lvoff[j + 1];
-        for (int t = t0 + (int)threadIdx.x; t < t1; t += kXT) {
-            const int idx = x.order[t];
-            const int dd = x.dep[idx];
-            // at most three edges: values of lim[rev] - len for each, then "max over the others"
-            int sl[3]; double rq[3]; bool down[3]; int cnt = 0;
-            for (int i = p.head[idx]; i != -1 && cnt < 3; i = p.nxt[i], ++cnt) {
-                sl[cnt] = i; rq[cnt] = x.lim[p.rev[i]] - p.len[i]; down[cnt] = x.dep[p.e[i]] > dd;
-            }
-            for (int a = 0; a < cnt; ++a)
-                if (down[a]) {
-                    double mx = 0;
-                    for (int b = 0; b < cnt; ++b)
-                        if (b != a && rq[b] > mx) mx = rq[b];
-                    x.lim[sl[a]] = mx;
-                }
-        }
+        NodeCtx nxt;
+        nxt.idx = -1;
+        if (j < maxdep) nxt = px_load_ctx(x, p, dis, t1 + tid, x.lvoff[j + 2]);
+        px_down(x, cur);
+        for (int t = t0 + tid + kXT; t < t1; t += kXT) px_down(x, px_load_ctx(x, p, dis, t, t1));
         __syncthreads();
+        cur = nxt;
     }
 }
 
@@ -147,6 +220,9 @@ __global__ __launch_bounds__(kXT) void px_step_kernel(PlaceBuffers p, ExactBuffe
             p.rev[0] = 2; p.rev[2] = 0; p.rev[1] = 3; p.rev[3] = 1;
             x.dep[nv] = 0; x.dep[0] = 1; x.dep[1] = 1;
             x.dfsrk[nv] = 0; x.dfsrk[0] = 1; x.dfsrk[1] = 2;
+            px_set_node(x, 0, 0, 2, nv, -1, -1, -1, -1, -1, -1);
+            px_set_node(x, 1, 1, 3, nv, -1, -1, -1, -1, -1, -1);
+            px_set_node(x, nv, 2, 0, 0, 3, 1, 1, -1, -1, -1);
         }
         i = 1;
         __syncthreads();
@@ -188,6 +264,11 @@ __global__ __launch_bounds__(kXT) void px_step_kernel(PlaceBuffers p, ExactBuffe
             p.e[ec] = yn; p.len[ec] = originalDis - fracLen; p.nxt[ec] = p.head[middle]; p.head[middle] = ec; p.belong[ec] = middle; p.rev[ec] = ye; ec++;
             p.e[ec] = middle; p.len[ec] = addLen; p.nxt[ec] = p.head[outside]; p.head[outside] = ec; p.belong[ec] = outside; p.rev[ec] = ec + 1; ec++;
             p.e[ec] = outside; p.len[ec] = addLen; p.nxt[ec] = p.head[middle]; p.head[middle] = ec; p.belong[ec] = middle; p.rev[ec] = ec - 1; ec++;
+            // node records: x and y keep their slots, which now lead to `middle`
+            px_retarget(x, xn, xe, ec - 4, middle);
+            px_retarget(x, yn, ye, ec - 3, middle);
+            px_set_node(x, middle, ec - 4, xe, xn, ec - 3, ye, yn, ec - 1, ec - 2, outside);
+            px_set_node(x, outside, ec - 2, ec - 1, middle, -1, -1, -1, -1, -1, -1);
             if (x.dfsrk[xn] > x.dfsrk[yn]) { const int t2 = xn; yn = xn; xn = t2; }   // the reference's (ineffective) swap, :236-239
             x.dfsrk[middle] = x.dfsrk[yn];
             x.dfsrk[outside] = x.dfsrk[middle] + 1;
@@ -291,13 +372,14 @@ int exact_alloc(ExactBuffers& x, int64_t N)
     DPR_HIP(hipMalloc(&x.order, sizeof(int32_t) * (size_t)(2 * N)));
     DPR_HIP(hipMalloc(&x.lvoff, sizeof(int32_t) * (size_t)(2 * N + 2)));
     DPR_HIP(hipMalloc(&x.hist, sizeof(int32_t) * (size_t)(2 * N + 2)));
+    DPR_HIP(hipMalloc(&x.nd, sizeof(int32_t) * (size_t)(12 * 2 * N)));
     DPR_HIP(hipMalloc(&x.partials, sizeof(PlacePartialX) * (size_t)((4 * N + kThreads - 1) / kThreads + 1)));
     return DPR_OK;
 }
 
 void exact_free(ExactBuffers& x)
 {
-    void* ptrs[] = { x.lim, x.dep, x.dfsrk, x.order, x.lvoff, x.hist, x.partials };
+    void* ptrs[] = { x.lim, x.dep, x.dfsrk, x.order, x.lvoff, x.hist, x.partials, x.nd };
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     x = ExactBuffers();
