@@ -94,6 +94,11 @@ def load_library():
 DC_EXACT_LAST = 1
 
 
+def dc_virtual_ranks(w):
+    """flags value emulating w ranks of the multi-GPU divide-and-conquer path on one GPU"""
+    return (w & 0xff) << 8
+
+
 def set_nj_mode(mode):
     """0 = full streaming scan every iteration, 1 = exact pruned scan (default)."""
     L = load_library()

@@ -27,6 +27,7 @@ struct Rccl {
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, Id128, int) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
@@ -44,6 +45,7 @@ static int rccl_load()
     g_rccl.GetUniqueId = (int (*)(void*))dlsym(g_rccl.lib, "ncclGetUniqueId");
     g_rccl.CommInitRank = (int (*)(void**, int, Id128, int))dlsym(g_rccl.lib, "ncclCommInitRank");
     g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(g_rccl.lib, "ncclAllGather");
+    g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
     g_rccl.CommDestroy = (int (*)(void*))dlsym(g_rccl.lib, "ncclCommDestroy");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
@@ -90,7 +92,7 @@ static bool want_pruned()
 
 // ---- exchange step of the sharded path: RCCL all-gather, or device copies between virtual ranks --
 enum ExKind { EX_RECS, EX_SLICES, EX_U };
-static const int kNcclUint8 = 1, kNcclFloat64 = 8;
+static const int kNcclUint8 = 1, kNcclFloat64 = 8, kNcclInt32 = 2, kNcclUint64 = 5, kNcclSum = 0;
 
 static int exchange(dpr_ctx* c, ExKind kind)
 {
@@ -331,13 +333,19 @@ int dpr_comm_selftest(dpr_ctx* c)
     DPR_HIP(hipMemcpy(ds, hs.data(), sizeof(double) * 192, hipMemcpyHostToDevice));
     r = g_rccl.AllGather(d, d, sizeof(NjRecord), kNcclUint8, comm, c->stream);          // in place
     if (r == 0) r = g_rccl.AllGather(ds, dg, 192, kNcclFloat64, comm, c->stream);
+    // the all-reduces of the multi-GPU divide-and-conquer path: in place, uint64 / int32 sums
+    if (r == 0 && g_rccl.AllReduce) r = g_rccl.AllReduce(ds, ds, 192, kNcclUint64, kNcclSum, comm, c->stream);
+    if (r == 0 && g_rccl.AllReduce) r = g_rccl.AllReduce(ds, ds, 384, kNcclInt32, kNcclSum, comm, c->stream);
+    if (r == 0 && !g_rccl.AllReduce) r = -1;
     DPR_HIP(hipStreamSynchronize(c->stream));
+    std::vector<double> hr(192, -1.0);
+    DPR_HIP(hipMemcpy(hr.data(), ds, sizeof(double) * 192, hipMemcpyDeviceToHost));
     DPR_HIP(hipMemcpy(&back, d, sizeof(NjRecord), hipMemcpyDeviceToHost));
     DPR_HIP(hipMemcpy(hg.data(), dg, sizeof(double) * 192, hipMemcpyDeviceToHost));
     (void)hipFree(d); (void)hipFree(ds); (void)hipFree(dg);
     g_rccl.CommDestroy(comm);
-    if (r != 0) { set_error("ncclAllGather failed"); return DPR_ERR_COMM; }
-    if (back.q != h.q || back.key != h.key || back.d != h.d || hg != hs) { set_error("dpr_comm_selftest: data mismatch"); return DPR_ERR_COMM; }
+    if (r != 0) { set_error("ncclAllGather / ncclAllReduce failed"); return DPR_ERR_COMM; }
+    if (back.q != h.q || back.key != h.key || back.d != h.d || hg != hs || hr != hs) { set_error("dpr_comm_selftest: data mismatch"); return DPR_ERR_COMM; }
     return DPR_OK;
 }
 
@@ -895,14 +903,20 @@ int dpr_dc_run(dpr_ctx* c, int source, int dist_type, int k, int64_t n, int64_t 
     for (auto& x : ev) DPR_HIP(hipEventCreate(&x));
     int32_t* d_cl = nullptr;
     double* dT = nullptr;
+    uint64_t *snap_old = nullptr, *snap_acc = nullptr;
     DcTable tab;
+    // ranks: RCCL ranks of dpr_comm_init, or -- validation on one GPU -- DPR_DC_VIRTUAL_RANKS(w) emulated in turn
+    const bool real = c->world > 1 && c->vworld == 0 && c->comm != nullptr;
+    const int W = real ? c->world : (((flags >> 8) & 0xff) > 1 ? ((flags >> 8) & 0xff) : 1);
     std::vector<int32_t> h_cl((size_t)n, -1);
     auto run = [&]() -> int {
         // ---- backbone tree: tips [0, B) (findBackboneTreeDC)
         DPR_HIP(hipEventRecord(ev[0], c->stream));
         if (int rc = place_range(c, source, dist_type, 2, B)) return rc;
         DPR_HIP(hipEventRecord(ev[1], c->stream));
-        // ---- cluster assignment of tips [B, n) (findClustersDC)
+        // ---- cluster assignment of tips [B, n) (findClustersDC).  Multi-GPU: the backbone above is built
+        // identically on every rank (same inputs, deterministic kernels); the queries are independent, so each
+        // rank assigns a contiguous share and the ids are summed (zeros elsewhere) over RCCL.
         if (int rc = dc_table_build(p, B, tab, c->stream)) return rc;
         int64_t Q = ((int64_t)1 << 31) / (8 * B) / 256 * 256;
         if (Q < 256) Q = 256;
@@ -910,32 +924,80 @@ int dpr_dc_run(dpr_ctx* c, int source, int dist_type, int k, int64_t n, int64_t 
         const int64_t nq = n - B;
         if (Q > (nq + 255) / 256 * 256) Q = (nq + 255) / 256 * 256;
         DPR_HIP(hipMalloc(&dT, sizeof(double) * (size_t)(B * Q)));
-        DPR_HIP(hipMalloc(&d_cl, sizeof(int32_t) * (size_t)n));
-        DPR_HIP(hipMemsetAsync(d_cl, 0xff, sizeof(int32_t) * (size_t)n, c->stream));
+        DPR_HIP(hipMalloc(&d_cl, sizeof(int32_t) * (size_t)(n + 1)));
+        DPR_HIP(hipMemsetAsync(d_cl, 0, sizeof(int32_t) * (size_t)(n + 1), c->stream));
         // the reference's aligned-input kernel never writes the distance to backbone tip B-1
         // (src/divide_and_conquer/msa.cu:331 `idx>=ed-st`) and scans the 0.0 of a fresh allocation
         const bool skip_last = source == DPR_SRC_MSA && !(flags & DPR_DC_EXACT_LAST);
-        for (int64_t i0 = B; i0 < n; i0 += Q) {
-            const int64_t nr = n - i0 < Q ? n - i0 : Q;
-            int rc;
-            if (source == DPR_SRC_MSA) rc = msa_dist_block_rows(c->msa, i0, nr, 0, 0, B, dist_type, dT, Q, c->stream, true);
-            else rc = mash_dist_rows(c->mash, i0, nr, 0, 0, false, B, dT, Q, c->stream, true);
-            if (rc) return rc;
-            if (skip_last) DPR_HIP(hipMemsetAsync(dT + (B - 1) * Q, 0, sizeof(double) * (size_t)Q, c->stream));
-            if (int rc2 = dc_assign(tab, dT, Q, (int)nr, d_cl + i0, c->stream)) return rc2;
+        const int64_t share = ((nq + W - 1) / W + 255) / 256 * 256;
+        for (int v = 0; v < W; ++v) {
+            if (real && v != c->rank) continue;     // virtual ranks: every share is processed here, one after the other
+            const int64_t q0 = B + (int64_t)v * share, q1 = q0 + share < n ? q0 + share : n;
+            for (int64_t i0 = q0; i0 < q1; i0 += Q) {
+                const int64_t nr = q1 - i0 < Q ? q1 - i0 : Q;
+                int rc;
+                if (source == DPR_SRC_MSA) rc = msa_dist_block_rows(c->msa, i0, nr, 0, 0, B, dist_type, dT, Q, c->stream, true);
+                else rc = mash_dist_rows(c->mash, i0, nr, 0, 0, false, B, dT, Q, c->stream, true);
+                if (rc) return rc;
+                if (skip_last) DPR_HIP(hipMemsetAsync(dT + (B - 1) * Q, 0, sizeof(double) * (size_t)Q, c->stream));
+                if (int rc2 = dc_assign(tab, dT, Q, (int)nr, d_cl + i0, c->stream)) return rc2;
+            }
+        }
+        if (real) {
+            if (!g_rccl.AllReduce) { set_error("dpr_dc_run: librccl.so lacks ncclAllReduce"); return DPR_ERR_COMM; }
+            if (g_rccl.AllReduce(d_cl, d_cl, (size_t)n, kNcclInt32, kNcclSum, c->comm, c->stream) != 0) { set_error("ncclAllReduce(cluster ids) failed"); return DPR_ERR_COMM; }
         }
         DPR_HIP(hipMemcpyAsync(h_cl.data(), d_cl, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
         DPR_HIP(hipEventRecord(ev[2], c->stream));
         DPR_HIP(hipStreamSynchronize(c->stream));
+        for (int64_t t = 0; t < B; ++t) h_cl[(size_t)t] = -1;
         (void)hipFree(dT); dT = nullptr;
-        // trace column 0 of a query = its cluster
-        // ---- cluster trees (findClusterTreeDC)
+        // ---- cluster trees (findClusterTreeDC).  Multi-GPU: clusters are dealt to the ranks; an array element
+        // is changed by at most one rank, so the states are merged as old + sum of (new - old) (dc_delta_*).
         size_t free_b = 0, total_b = 0;
         DPR_HIP(hipMemGetInfo(&free_b, &total_b));
         size_t budget = free_b / 2;
         if (const char* env = std::getenv("DPR_DC_BUDGET_MB")) budget = (size_t)std::atoll(env) << 20;
-        if (int rc = dc_cluster_phase(p, h_cl.data(), n, B, source, dist_type, &c->msa, &c->mash, c->place_trace, budget,
-                                      &c->dc_stats, c->stream)) return rc;
+        if (W == 1) {
+            if (int rc = dc_cluster_phase(p, h_cl.data(), n, B, source, dist_type, &c->msa, &c->mash, c->place_trace, budget,
+                                          &c->dc_stats, 0, 1, c->stream)) return rc;
+        } else {
+            struct Arr { void* cur; int64_t words; };
+            const Arr arrs[] = { { p.head, n }, { p.e, 4 * n }, { p.nxt, 4 * n }, { p.belong, 4 * n }, { p.rev, 4 * n },
+                                 { p.len, 8 * n }, { p.cid, 20 * n }, { p.cdis, 40 * n }, { c->place_trace, 3 * n } };
+            int64_t tot = 0;
+            for (const Arr& a : arrs) tot += a.words;
+            DPR_HIP(hipMalloc(&snap_old, sizeof(uint64_t) * (size_t)tot));
+            if (!real) { DPR_HIP(hipMalloc(&snap_acc, sizeof(uint64_t) * (size_t)tot)); DPR_HIP(hipMemsetAsync(snap_acc, 0, sizeof(uint64_t) * (size_t)tot, c->stream)); }
+            int64_t off = 0;
+            for (const Arr& a : arrs) { DPR_HIP(hipMemcpyAsync(snap_old + off, a.cur, sizeof(uint64_t) * (size_t)a.words, hipMemcpyDeviceToDevice, c->stream)); off += a.words; }
+            if (budget > sizeof(uint64_t) * (size_t)tot * 2) budget -= sizeof(uint64_t) * (size_t)tot * 2;
+            for (int v = 0; v < W; ++v) {
+                if (real && v != c->rank) continue;
+                if (!real && v > 0) {                // next virtual rank starts from the backbone state again
+                    off = 0;
+                    for (const Arr& a : arrs) { DPR_HIP(hipMemcpyAsync(a.cur, snap_old + off, sizeof(uint64_t) * (size_t)a.words, hipMemcpyDeviceToDevice, c->stream)); off += a.words; }
+                }
+                if (int rc = dc_cluster_phase(p, h_cl.data(), n, B, source, dist_type, &c->msa, &c->mash, c->place_trace, budget,
+                                              &c->dc_stats, v, W, c->stream)) return rc;
+                off = 0;
+                for (const Arr& a : arrs) {
+                    if (int rc = dc_delta_sub(a.cur, snap_old + off, a.words, c->stream)) return rc;
+                    if (!real) { if (int rc = dc_delta_add(snap_acc + off, a.cur, a.words, c->stream)) return rc; }
+                    off += a.words;
+                }
+            }
+            off = 0;
+            for (const Arr& a : arrs) {
+                if (real) {
+                    if (g_rccl.AllReduce(a.cur, a.cur, (size_t)a.words, kNcclUint64, kNcclSum, c->comm, c->stream) != 0) { set_error("ncclAllReduce(state delta) failed"); return DPR_ERR_COMM; }
+                } else {
+                    DPR_HIP(hipMemcpyAsync(a.cur, snap_acc + off, sizeof(uint64_t) * (size_t)a.words, hipMemcpyDeviceToDevice, c->stream));
+                }
+                if (int rc = dc_delta_add(a.cur, snap_old + off, a.words, c->stream)) return rc;
+                off += a.words;
+            }
+        }
         DPR_HIP(hipEventRecord(ev[3], c->stream));
         DPR_HIP(hipMemcpyAsync(head, p.head, sizeof(int32_t) * (size_t)(2 * n), hipMemcpyDeviceToHost, c->stream));
         DPR_HIP(hipMemcpyAsync(e, p.e, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
@@ -954,6 +1016,8 @@ int dpr_dc_run(dpr_ctx* c, int source, int dist_type, int k, int64_t n, int64_t 
     const int rc = run();
     if (dT) (void)hipFree(dT);
     if (d_cl) (void)hipFree(d_cl);
+    if (snap_old) (void)hipFree(snap_old);
+    if (snap_acc) (void)hipFree(snap_acc);
     dc_table_free(tab);
     for (auto& x : ev) (void)hipEventDestroy(x);
     return rc;

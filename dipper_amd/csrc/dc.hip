@@ -369,10 +369,33 @@ __global__ __launch_bounds__(64) void dc_cluster_kernel(PlaceBuffers p, int32_t*
     }
 }
 
+__global__ __launch_bounds__(kThreads) void dc_delta_kernel(unsigned long long* __restrict__ cur,
+                                                            const unsigned long long* __restrict__ old, int64_t n, int add)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads)
+        cur[i] = add ? cur[i] + old[i] : cur[i] - old[i];
+}
+// 32-bit arrays are processed as pairs in one 64-bit word: a borrow/carry between the halves cancels in
+// old + ((new - old) summed over ranks), because at most one rank contributes a non-zero difference
+int dc_delta_sub(void* cur, const void* old, int64_t words64, hipStream_t s)
+{
+    if (words64 <= 0) return DPR_OK;
+    hipLaunchKernelGGL(dc_delta_kernel, dim3(2048), dim3(kThreads), 0, s, (unsigned long long*)cur, (const unsigned long long*)old, words64, 0);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+int dc_delta_add(void* cur, const void* old, int64_t words64, hipStream_t s)
+{
+    if (words64 <= 0) return DPR_OK;
+    hipLaunchKernelGGL(dc_delta_kernel, dim3(2048), dim3(kThreads), 0, s, (unsigned long long*)cur, (const unsigned long long*)old, words64, 1);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
 // host: group the query tips by cluster, lay out the per-cluster blocks, run cols -> pair jobs -> trees
 int dc_cluster_phase(PlaceBuffers& p, const int32_t* h_cluster_id, int64_t N, int64_t B, int source, int dist_type,
                      const MsaBuffers* msa, const MashBuffers* mash, double* d_trace, size_t budget_bytes,
-                     DcStats* stats, hipStream_t s)
+                     DcStats* stats, int rank, int world, hipStream_t s)
 {
     const int64_t lim = 4 * B - 4, nq = N - B;
     if (nq <= 0) return DPR_OK;
@@ -411,13 +434,29 @@ int dc_cluster_phase(PlaceBuffers& p, const int32_t* h_cluster_id, int64_t N, in
     }
     // largest clusters first: their serial member loops bound the phase
     std::stable_sort(cl.begin(), cl.end(), [](const DcCluster& a, const DcCluster& b) { return a.m > b.m; });
+    if (stats) { stats->clusters = (int64_t)cl.size(); stats->max_cluster = maxm; stats->pairs = 0; stats->groups = 0; stats->jobs = 0; }
+    if (world > 1) {
+        // clusters are independent: deal them to the ranks, largest first onto the least loaded rank
+        // (cost ~ members^2; identical on every rank), and keep this rank's share.  Slots and node ids of a
+        // cluster do not depend on who builds it.
+        std::vector<double> load((size_t)world, 0.0);
+        std::vector<DcCluster> mine;
+        for (const DcCluster& C : cl) {
+            int best = 0;
+            for (int r = 1; r < world; ++r)
+                if (load[(size_t)r] < load[(size_t)best]) best = r;
+            load[(size_t)best] += (double)C.m * (double)(C.m + 2 * kDcLeaves);
+            if (best == rank) mine.push_back(C);
+        }
+        cl.swap(mine);
+    }
     const int64_t ncl = (int64_t)cl.size();
     int64_t coff = 0, qoff = 0;
     for (auto& C : cl) {
         C.coff = coff; coff += kDcLeaves + C.m;
         C.qoff = qoff; qoff += 2 * (int64_t)C.m + 8 + 64;
     }
-    if (stats) { stats->clusters = ncl; stats->max_cluster = maxm; stats->pairs = 0; stats->groups = 0; stats->jobs = 0; }
+    if (ncl == 0) return DPR_OK;
 
     int32_t *d_members = nullptr, *d_cols = nullptr, *d_clx = nullptr, *d_qid = nullptr, *d_qfrom = nullptr, *d_status = nullptr;
     double* d_qdis = nullptr;

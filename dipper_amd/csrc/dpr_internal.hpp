@@ -262,6 +262,10 @@ void dc_table_free(DcTable& t);
 int dc_assign(DcTable& t, const double* dT, int64_t ldq, int Q, int32_t* d_cluster_id, hipStream_t s);
 int dc_cluster_phase(PlaceBuffers& p, const int32_t* h_cluster_id, int64_t N, int64_t B, int source, int dist_type,
                      const MsaBuffers* msa, const MashBuffers* mash, double* d_trace, size_t budget_bytes,
-                     DcStats* stats, hipStream_t s);
+                     DcStats* stats, int rank, int world, hipStream_t s);
+// multi-rank merge of the cluster phase: every array element is changed by at most one rank, so
+// new = old + sum over ranks of (new - old) in wrap-around integer arithmetic (doubles as their bit patterns)
+int dc_delta_sub(void* cur, const void* old, int64_t words64, hipStream_t s);   // cur -= old (64-bit words)
+int dc_delta_add(void* cur, const void* old, int64_t words64, hipStream_t s);   // cur += old
 
 }  // namespace dpr

@@ -196,6 +196,12 @@ int dpr_get_exact_state(dpr_ctx *ctx, int32_t *rev, int32_t *dep);
  * input (the reference's kernel stops one short, src/divide_and_conquer/msa.cu:331, and scans a 0.0;
  * that behaviour is the default so that results match the reference). */
 #define DPR_DC_EXACT_LAST 1
+/* Multi-GPU: after dpr_comm_init every rank calls dpr_dc_run with the same (replicated) inputs; the
+ * backbone is built identically on every rank, the query tips and the clusters are shared out, cluster ids
+ * and the state changes are summed over RCCL (two all-reduces per run), and every rank returns the full
+ * tree.  DPR_DC_VIRTUAL_RANKS(w) emulates w ranks one after the other on a single GPU (validation of the
+ * sharding and of the merge; same result as w = 1, bit for bit). */
+#define DPR_DC_VIRTUAL_RANKS(w) (((w) & 0xff) << 8)
 int dpr_dc_run(dpr_ctx *ctx, int source, int dist_type, int k, int64_t n, int64_t backbone, int flags,
                int32_t *head, int32_t *e, int32_t *nxt, int32_t *belong, double *len, int32_t *cluster_id);
 /* counts: clusters, largest cluster, in-cluster pair distances, memory groups, pair jobs;

@@ -18,7 +18,16 @@ rng = np.random.default_rng(7)
 perm = rng.permutation(n)          # the CLI shuffles the input order (src/tree_generation.cu:341-344)
 seqs = [seqs[i] for i in perm]
 print(f"input {n} x {L} generated in {time.perf_counter()-t0:.1f}s", flush=True)
-d = dipper_amd.Dipper(0)
+# multi-GPU: python -m torch.distributed.run --nnodes=1 --nproc-per-node G --master-addr 127.0.0.1 profiles/dc_bench.py ...
+rank, world, local_rank = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
+d = dipper_amd.Dipper(local_rank)
+if world > 1:
+    import torch, torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    uid = [d.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    d.comm_init(rank, world, uid[0])
 t0 = time.perf_counter()
 if kind == "r":
     d.set_reads(seqs)
@@ -37,4 +46,9 @@ sizes = sizes[sizes > 0]
 out = dict(kind=kind, mean_bl=mean_bl, tips=n, sites=L, backbone=B, upload_s=t1 - t0, sketch_s=t2 - t1, dc_s=t3 - t2,
            tips_per_s=n / (t3 - t1), stats=st["stats"],
            cluster_size_quantiles={q: float(np.quantile(sizes, q)) for q in (0.5, 0.9, 0.99, 1.0)})
-print(json.dumps(out), flush=True)
+out["n_gpus"] = world
+if rank == 0:
+    print(json.dumps(out), flush=True)
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()

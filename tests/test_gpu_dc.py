@@ -94,6 +94,30 @@ def test_dc_memory_groups(gpu, orc, monkeypatch):
     _same_dc_state(got, orc.dc_run(M, B, skip_last_backbone=1), n, B)
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_dc_sharded_virtual_ranks(gpu, orc, world):
+    """multi-GPU path of dpr_dc_run on one GPU: query shares per rank, clusters dealt to the ranks,
+    states merged as old + sum(new - old) -- bit-identical to the single-rank run and to the oracle"""
+    from dipper_amd import capi
+    rng = np.random.default_rng(31)
+    n, B, L = 900, 150, 1000
+    seqs = _clone_heavy_alignment(rng, n, L, clones=60)
+    gpu.set_msa(capi.pack4_many(seqs), L)
+    gpu.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+    M = gpu.matrix()
+    ref = orc.dc_run(M, B, skip_last_backbone=1)
+    got = gpu.dc_run(capi.SRC_MSA, n, B, dist_type=capi.DIST_JC, flags=capi.dc_virtual_ranks(world))
+    _same_dc_state(got, ref, n, B)
+    if world == 3:
+        reads = _reads(rng, 300, 3000, 5000)
+        gpu.set_reads(reads)
+        gpu.sketch(k=15, S=1000, fetch=False)
+        gpu.dist_matrix(capi.SRC_MASH, 0, 15)
+        M = gpu.matrix()
+        got = gpu.dc_run(capi.SRC_MASH, len(reads), 80, k=15, flags=capi.dc_virtual_ranks(world))
+        _same_dc_state(got, orc.dc_run(M, 80, skip_last_backbone=0), len(reads), 80)
+
+
 def test_dc_mash(gpu, orc):
     from dipper_amd import capi
     rng = np.random.default_rng(321)
