@@ -12,6 +12,27 @@ namespace dipper {
 DeviceContext::DeviceContext(int device) { gpuCheck(dpr_create(&ctx, device), "dpr_create"); }
 DeviceContext::~DeviceContext() { if (ctx) dpr_destroy(ctx); }
 
+struct AsyncDeviceContext::Impl {
+    std::thread th;
+    DeviceContext* dev = nullptr;
+};
+AsyncDeviceContext::AsyncDeviceContext(int device) : impl(new Impl)
+{
+    Impl* q = impl;
+    impl->th = std::thread([q, device] { q->dev = new DeviceContext(device); });
+}
+DeviceContext& AsyncDeviceContext::get()
+{
+    if (impl->th.joinable()) impl->th.join();
+    return *impl->dev;
+}
+AsyncDeviceContext::~AsyncDeviceContext()
+{
+    if (impl->th.joinable()) impl->th.join();
+    delete impl->dev;
+    delete impl;
+}
+
 // replaces the tbb::parallel_for packing loop (src/tree_generation.cu:352-362) + MSADeviceArrays::
 // allocateDeviceArrays (src/MSA.cu:14-72)
 void MSADeviceArrays::allocateDeviceArrays(DeviceContext& dev, const std::vector<std::string>& seqs,

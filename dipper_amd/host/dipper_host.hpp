@@ -47,6 +47,16 @@ struct DeviceContext {  // replaces cudaSetDevice (src/tree_generation.cu:240-24
     explicit DeviceContext(int device);
     ~DeviceContext();
 };
+// The HIP runtime start-up (~0.2 s) overlaps the reading of the input: the context is created on a
+// helper thread and joined by get().
+struct AsyncDeviceContext {
+    explicit AsyncDeviceContext(int device);
+    ~AsyncDeviceContext();
+    DeviceContext& get();
+private:
+    struct Impl;
+    Impl* impl;
+};
 
 struct MSADeviceArrays {  // src/mash_placement.cuh:87-98
     size_t numSequences = 0;

@@ -1,9 +1,14 @@
 // Readers and writers of the dipper host side.
 #include "dipper_host.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <thread>
 #include <cctype>
 #include <cstdlib>
 #include <cstring>
@@ -42,10 +47,9 @@ static std::string slurp_gz(const std::string& path)
     return data;
 }
 
-void readSequences(const std::string& path, std::vector<std::string>& seqs, std::vector<std::string>& names)
+// serial record parser with klib-kseq semantics (FASTA and FASTQ)
+static void parseRecords(const char* data, size_t n, std::vector<std::string>& seqs, std::vector<std::string>& names)
 {
-    const std::string data = slurp_gz(path);
-    const size_t n = data.size();
     size_t p = 0;
     // jump to the first header
     while (p < n && data[p] != '>' && data[p] != '@') ++p;
@@ -53,7 +57,7 @@ void readSequences(const std::string& path, std::vector<std::string>& seqs, std:
         ++p;  // header char
         size_t e = p;
         while (e < n && !std::isspace((unsigned char)data[e])) ++e;
-        names.emplace_back(data, p, e - p);
+        names.emplace_back(data + p, e - p);
         // rest of the header line is the comment
         while (e < n && data[e] != '\n') ++e;
         p = e < n ? e + 1 : n;
@@ -66,7 +70,7 @@ void readSequences(const std::string& path, std::vector<std::string>& seqs, std:
             if (c == '\n') { ++p; continue; }
             size_t le = p;
             while (le < n && data[le] != '\n') ++le;
-            seq.append(data, p, le - p);
+            seq.append(data + p, le - p);
             if (seq.size() > 1 && seq.back() == '\r') seq.pop_back();
             p = le < n ? le + 1 : n;
         }
@@ -86,6 +90,99 @@ void readSequences(const std::string& path, std::vector<std::string>& seqs, std:
         }
         seqs.push_back(std::move(seq));
     }
+}
+
+// Plain FASTA: the records are found and copied out by all host threads (same result as the serial
+// parser).  Returns false when the text needs the serial parser (FASTQ: a line starting with '+').
+static bool parseFastaParallel(const char* data, size_t n, std::vector<std::string>& seqs, std::vector<std::string>& names)
+{
+    const unsigned nt = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    if (n < (size_t)(1 << 22) || nt < 2) return false;
+    size_t first = 0;
+    while (first < n && data[first] != '>' && data[first] != '@') ++first;
+    if (first >= n) return false;
+    // record starts: a '>' or '@' at the beginning of a line (the serial parser's rule) after the first header
+    std::vector<std::vector<size_t>> starts(nt);
+    std::vector<char> plus(nt, 0);
+    const size_t chunk = (n - first + nt - 1) / nt;
+    {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nt; ++t)
+            pool.emplace_back([&, t] {
+                const size_t lo = first + (size_t)t * chunk, hi = std::min(n, lo + chunk);
+                if (lo >= hi) return;
+                if (t == 0) starts[0].push_back(first);
+                const char* q = data + lo;
+                const char* end = data + hi;
+                while (q < end) {
+                    q = static_cast<const char*>(std::memchr(q, '\n', (size_t)(end - q)));
+                    if (!q) break;
+                    ++q;
+                    if (q < data + n) {
+                        if (*q == '>' || *q == '@') starts[t].push_back((size_t)(q - data));
+                        else if (*q == '+') plus[t] = 1;
+                    }
+                }
+            });
+        for (auto& th : pool) th.join();
+    }
+    for (char c : plus) if (c) return false;
+    std::vector<size_t> st;
+    for (auto& v : starts) st.insert(st.end(), v.begin(), v.end());
+    const size_t nrec = st.size();
+    st.push_back(n);
+    const size_t base = seqs.size();
+    seqs.resize(base + nrec);
+    names.resize(base + nrec);
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; ++t)
+        pool.emplace_back([&, t] {
+            for (size_t r = t; r < nrec; r += nt) {
+                size_t p = st[r] + 1;
+                const size_t end = st[r + 1];
+                size_t e = p;
+                while (e < end && !std::isspace((unsigned char)data[e])) ++e;
+                names[base + r].assign(data + p, e - p);
+                while (e < end && data[e] != '\n') ++e;
+                p = e < end ? e + 1 : end;
+                std::string& seq = seqs[base + r];
+                seq.reserve(end - p);
+                while (p < end) {
+                    if (data[p] == '\n') { ++p; continue; }
+                    const char* nl = static_cast<const char*>(std::memchr(data + p, '\n', end - p));
+                    const size_t le = nl ? (size_t)(nl - data) : end;
+                    seq.append(data + p, le - p);
+                    if (seq.size() > 1 && seq.back() == '\r') seq.pop_back();
+                    p = le < end ? le + 1 : end;
+                }
+            }
+        });
+    for (auto& th : pool) th.join();
+    return true;
+}
+
+void readSequences(const std::string& path, std::vector<std::string>& seqs, std::vector<std::string>& names)
+{
+    // uncompressed input: map the file (no copy); gzip (magic 1f 8b): inflate into memory
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd >= 0) {
+        struct stat sb;
+        unsigned char magic[2] = { 0, 0 };
+        if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 2 && pread(fd, magic, 2, 0) == 2 &&
+            !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+            void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            if (m != MAP_FAILED) {
+                const char* data = static_cast<const char*>(m);
+                if (!parseFastaParallel(data, (size_t)sb.st_size, seqs, names)) parseRecords(data, (size_t)sb.st_size, seqs, names);
+                munmap(m, (size_t)sb.st_size);
+                close(fd);
+                return;
+            }
+        }
+        close(fd);
+    }
+    const std::string data = slurp_gz(path);
+    if (!parseFastaParallel(data.data(), data.size(), seqs, names)) parseRecords(data.data(), data.size(), seqs, names);
 }
 
 std::vector<int> shuffledIds(size_t n, long long seed)

@@ -3,6 +3,8 @@
 // (src/tree_generation.cu:33-99,159-646); host orchestration is plain C++ over the C ABI.
 #include "dipper_host.hpp"
 
+#include <unistd.h>
+
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -61,7 +63,7 @@ static const Opt kOpts[] = {
     { "output-format", 'o', true }, { "algorithm", 'm', true }, { "placement-mode", 'p', true },
     { "kmer-size", 'k', true }, { "sketch-size", 's', true }, { "distance-type", 'd', true },
     { "add", 'a', false }, { "input-tree", 't', true }, { "help", 'h', false },
-    { "seed", 0, true }, { "device", 0, true }, { "dump-tree", 0, true },
+    { "seed", 0, true }, { "device", 0, true }, { "dump-tree", 0, true }, { "dump-fasta", 0, false },
 };
 
 static void usageError(const std::string& what)
@@ -135,6 +137,18 @@ int main(int argc, char** argv)
         for (const Node& nd : t.nodes)
             std::printf("%d %d %.17g %d %s\n", nd.idx, nd.parent >= 0 ? t.nodes[(size_t)nd.parent].idx : -1, nd.bl,
                         nd.children.empty() ? 1 : 0, nd.name.c_str());
+        return 0;
+    }
+    if (vm.count("dump-fasta")) {
+        // developer aid (no GPU): read --input-file and print name, length and FNV-1a of every record
+        std::vector<std::string> seqs, names;
+        readSequences(strOr(vm, "input-file", ""), seqs, names);
+        std::printf("%zu\n", seqs.size());
+        for (size_t i = 0; i < seqs.size(); ++i) {
+            uint64_t h = 1469598103934665603ull;
+            for (unsigned char ch : seqs[i]) { h ^= ch; h *= 1099511628211ull; }
+            std::printf("%s %zu %016llx\n", names[i].c_str(), seqs[i].size(), (unsigned long long)h);
+        }
         return 0;
     }
     for (const char* req : { "input-format", "input-file", "output-file" })
@@ -266,6 +280,7 @@ int main(int argc, char** argv)
     if ((params.in == "m" || params.in == "r") && params.out == "t") {
         const bool aligned = params.in == "m";
         std::vector<std::string> seqs, names_, names;
+        AsyncDeviceContext adev(device);          // HIP start-up runs while the input is read
         readSequences(inputFile, seqs, names_);
         const size_t numSequences = seqs.size();
         if (numSequences < 3) die("ERROR: need at least three sequences in " + inputFile);
@@ -273,7 +288,7 @@ int main(int argc, char** argv)
         const std::vector<int> ids = shuffledIds(numSequences, seed);
         for (size_t i = 0; i < numSequences; ++i) names[(size_t)ids[i]] = names_[i];
         auto output_ = open_out();
-        DeviceContext dev(device);
+        DeviceContext& dev = adev.get();
         MSADeviceArrays msaDeviceArrays;
         MashDeviceArrays mashDeviceArrays;
         const int mode = pick_mode((long long)numSequences);
@@ -325,6 +340,12 @@ int main(int argc, char** argv)
             njDeviceArrays.findNeighbourJoiningTree(dev, names, *output_);
             std::cerr << "Tree Created in: " << ms_since(t0) << " ms\n";
         }
+        // the tree is written: close the output and leave without tearing down ~15 GB of device buffers
+        // and the HIP runtime one by one (the driver reclaims them with the process)
+        output_.reset();
+        std::cerr.flush();
+        std::fflush(nullptr);
+        _exit(0);
     } else if (params.in == "d" && params.out == "t") {
         MatrixReader matrixReader;
         matrixReader.read(inputFile);
