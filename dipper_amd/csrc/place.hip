@@ -207,9 +207,17 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
     const int lane = threadIdx.x & 63;
     double badd = __builtin_inf(), bfrac = 0;
     int bidx = 0x7fffffff, beid = 0;
-    for (int i = lane; i < nparts; i += 64) {
-        const PlacePartial pp = partials[i];
-        if (pp.add < badd || (pp.add == badd && pp.idx < bidx)) { badd = pp.add; bidx = pp.idx; beid = pp.eid; bfrac = pp.frac; }
+    for (int i0 = lane; i0 < nparts; i0 += 256) {      // four independent loads in flight per lane
+        PlacePartial pp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 64 * u;
+            if (i < nparts) pp[u] = partials[i];
+            else { pp[u].add = __builtin_inf(); pp[u].idx = 0x7fffffff; pp[u].eid = 0; pp[u].frac = 0; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (pp[u].add < badd || (pp[u].add == badd && pp[u].idx < bidx)) { badd = pp[u].add; bidx = pp[u].idx; beid = pp[u].eid; bfrac = pp[u].frac; }
     }
     // slots >= 4*num-4 (and < 4M-4) all carry the tuple (0,0,2): the first of them competes
     const int64_t live = 4 * num - 4, lim = 4 * p.M - 4;
