@@ -929,10 +929,10 @@ int dpr_dc_run(dpr_ctx* c, int source, int dist_type, int k, int64_t n, int64_t 
         // the reference's aligned-input kernel never writes the distance to backbone tip B-1
         // (src/divide_and_conquer/msa.cu:331 `idx>=ed-st`) and scans the 0.0 of a fresh allocation
         const bool skip_last = source == DPR_SRC_MSA && !(flags & DPR_DC_EXACT_LAST);
-        const int64_t share = ((nq + W - 1) / W + 255) / 256 * 256;
         for (int v = 0; v < W; ++v) {
             if (real && v != c->rank) continue;     // virtual ranks: every share is processed here, one after the other
-            const int64_t q0 = B + (int64_t)v * share, q1 = q0 + share < n ? q0 + share : n;
+            int64_t q0 = 0, q1 = 0;
+            dc_query_share(n, B, v, W, &q0, &q1);
             for (int64_t i0 = q0; i0 < q1; i0 += Q) {
                 const int64_t nr = q1 - i0 < Q ? q1 - i0 : Q;
                 int rc;
@@ -1021,6 +1021,20 @@ int dpr_dc_run(dpr_ctx* c, int source, int dist_type, int k, int64_t n, int64_t 
     dc_table_free(tab);
     for (auto& x : ev) (void)hipEventDestroy(x);
     return rc;
+}
+
+int dpr_dc_query_share(int64_t n, int64_t backbone, int rank, int world, int64_t* q0, int64_t* q1)
+{
+    if (!q0 || !q1 || world < 1 || rank < 0 || rank >= world || backbone < 0 || backbone > n) { set_error("dpr_dc_query_share: bad argument"); return DPR_ERR_ARG; }
+    dc_query_share(n, backbone, rank, world, q0, q1);
+    return DPR_OK;
+}
+
+int dpr_dc_deal_clusters(const int64_t* sizes_desc, int64_t count, int world, int32_t* owner)
+{
+    if (!sizes_desc || !owner || count < 0 || world < 1) { set_error("dpr_dc_deal_clusters: bad argument"); return DPR_ERR_ARG; }
+    dc_deal_clusters(sizes_desc, count, world, owner);
+    return DPR_OK;
 }
 
 int dpr_get_dc_stats(dpr_ctx* c, int64_t* counts5, double* phase_ms3)

@@ -369,6 +369,28 @@ __global__ __launch_bounds__(64) void dc_cluster_kernel(PlaceBuffers p, int32_t*
     }
 }
 
+void dc_deal_clusters(const int64_t* sizes_desc, int64_t count, int world, int32_t* owner)
+{
+    std::vector<double> load((size_t)world, 0.0);
+    for (int64_t i = 0; i < count; ++i) {
+        int best = 0;
+        for (int r = 1; r < world; ++r)
+            if (load[(size_t)r] < load[(size_t)best]) best = r;
+        load[(size_t)best] += (double)sizes_desc[i] * (double)(sizes_desc[i] + 2 * kDcLeaves);
+        owner[i] = best;
+    }
+}
+
+void dc_query_share(int64_t n, int64_t B, int rank, int world, int64_t* q0, int64_t* q1)
+{
+    const int64_t nq = n - B;
+    const int64_t share = ((nq + world - 1) / world + 255) / 256 * 256;
+    int64_t a = B + (int64_t)rank * share, b = a + share;
+    if (a > n) a = n;
+    if (b > n) b = n;
+    *q0 = a; *q1 = b;
+}
+
 __global__ __launch_bounds__(kThreads) void dc_delta_kernel(unsigned long long* __restrict__ cur,
                                                             const unsigned long long* __restrict__ old, int64_t n, int add)
 {
@@ -439,15 +461,13 @@ int dc_cluster_phase(PlaceBuffers& p, const int32_t* h_cluster_id, int64_t N, in
         // clusters are independent: deal them to the ranks, largest first onto the least loaded rank
         // (cost ~ members^2; identical on every rank), and keep this rank's share.  Slots and node ids of a
         // cluster do not depend on who builds it.
-        std::vector<double> load((size_t)world, 0.0);
+        std::vector<int64_t> sizes(cl.size());
+        std::vector<int32_t> owner(cl.size());
+        for (size_t i = 0; i < cl.size(); ++i) sizes[i] = cl[i].m;
+        dc_deal_clusters(sizes.data(), (int64_t)sizes.size(), world, owner.data());
         std::vector<DcCluster> mine;
-        for (const DcCluster& C : cl) {
-            int best = 0;
-            for (int r = 1; r < world; ++r)
-                if (load[(size_t)r] < load[(size_t)best]) best = r;
-            load[(size_t)best] += (double)C.m * (double)(C.m + 2 * kDcLeaves);
-            if (best == rank) mine.push_back(C);
-        }
+        for (size_t i = 0; i < cl.size(); ++i)
+            if (owner[i] == rank) mine.push_back(cl[i]);
         cl.swap(mine);
     }
     const int64_t ncl = (int64_t)cl.size();

@@ -265,6 +265,8 @@ int dc_cluster_phase(PlaceBuffers& p, const int32_t* h_cluster_id, int64_t N, in
                      DcStats* stats, int rank, int world, hipStream_t s);
 // multi-rank merge of the cluster phase: every array element is changed by at most one rank, so
 // new = old + sum over ranks of (new - old) in wrap-around integer arithmetic (doubles as their bit patterns)
+void dc_deal_clusters(const int64_t* sizes_desc, int64_t count, int world, int32_t* owner);
+void dc_query_share(int64_t n, int64_t B, int rank, int world, int64_t* q0, int64_t* q1);
 int dc_delta_sub(void* cur, const void* old, int64_t words64, hipStream_t s);   // cur -= old (64-bit words)
 int dc_delta_add(void* cur, const void* old, int64_t words64, hipStream_t s);   // cur += old
 

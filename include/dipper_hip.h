@@ -204,6 +204,12 @@ int dpr_get_exact_state(dpr_ctx *ctx, int32_t *rev, int32_t *dep);
 #define DPR_DC_VIRTUAL_RANKS(w) (((w) & 0xff) << 8)
 int dpr_dc_run(dpr_ctx *ctx, int source, int dist_type, int k, int64_t n, int64_t backbone, int flags,
                int32_t *head, int32_t *e, int32_t *nxt, int32_t *belong, double *len, int32_t *cluster_id);
+/* host-only helpers of the multi-GPU split (pure functions; used by dpr_dc_run itself and by the CPU tests):
+ * share of the query tips [backbone, n) of `rank` (contiguous, multiples of 256 tips) ... */
+int dpr_dc_query_share(int64_t n, int64_t backbone, int rank, int world, int64_t *q0, int64_t *q1);
+/* ... and the owner of every cluster: sizes[] in the order dpr_dc_run builds them (descending, ties by
+ * ascending slot); largest first onto the least-loaded rank (load = m * (m + 20)), ties to the lowest rank */
+int dpr_dc_deal_clusters(const int64_t *sizes_desc, int64_t count, int world, int32_t *owner);
 /* counts: clusters, largest cluster, in-cluster pair distances, memory groups, pair jobs;
  * phase_ms: backbone tree, cluster assignment, cluster trees (HIP events) */
 int dpr_get_dc_stats(dpr_ctx *ctx, int64_t *counts5, double *phase_ms3);

@@ -834,9 +834,28 @@ static int orc_edge_scan_masked(const orc_ptree *T, const double *dis, const int
     return best_eid;
 }
 
+static int orc_dc_run_phases(int64_t N, int64_t B, const double *dist, int64_t ld, int skip_last_backbone,
+                             int32_t *head, int32_t *e, int32_t *nxt, int32_t *belong, double *len,
+                             int32_t *cid, double *cdis, int32_t *cluster_id, double *trace, int phases);
+
 ORC_API int orc_dc_run(int64_t N, int64_t B, const double *dist, int64_t ld, int skip_last_backbone,
                        int32_t *head, int32_t *e, int32_t *nxt, int32_t *belong, double *len,
                        int32_t *cid, double *cdis, int32_t *cluster_id, double *trace)
+{
+    return orc_dc_run_phases(N, B, dist, ld, skip_last_backbone, head, e, nxt, belong, len, cid, cdis, cluster_id, trace, 3);
+}
+
+/* phases = 2: stop after the backbone tree and the cluster assignment (state of the backbone, cluster ids) */
+ORC_API int orc_dc_run_backbone(int64_t N, int64_t B, const double *dist, int64_t ld, int skip_last_backbone,
+                                int32_t *head, int32_t *e, int32_t *nxt, int32_t *belong, double *len,
+                                int32_t *cid, double *cdis, int32_t *cluster_id, double *trace)
+{
+    return orc_dc_run_phases(N, B, dist, ld, skip_last_backbone, head, e, nxt, belong, len, cid, cdis, cluster_id, trace, 2);
+}
+
+static int orc_dc_run_phases(int64_t N, int64_t B, const double *dist, int64_t ld, int skip_last_backbone,
+                             int32_t *head, int32_t *e, int32_t *nxt, int32_t *belong, double *len,
+                             int32_t *cid, double *cdis, int32_t *cluster_id, double *trace, int phases)
 {
     if (B < 3 || B > N) return -1;
     orc_ptree T;
@@ -887,7 +906,7 @@ ORC_API int orc_dc_run(int64_t N, int64_t B, const double *dist, int64_t ld, int
     }
     /* ---- cluster trees (findClusterTreeDC) */
     int insert_leaf_count = (int)B;
-    for (int j = 0; j < lim_bb && rc == 0; ++j) {
+    for (int j = 0; j < lim_bb && rc == 0 && phases > 2; ++j) {
         int64_t members = 0;
         for (int64_t t = B; t < N; ++t) members += (cluster_id[t] == j);
         if (members == 0) continue;

@@ -49,6 +49,8 @@ class Oracle:
         L.orc_dc_run.argtypes = [C.c_int64, C.c_int64, c_f64p, C.c_int64, C.c_int, c_i32p, c_i32p, c_i32p,
                                  c_i32p, c_f64p, c_i32p, c_f64p, c_i32p, c_f64p]
         L.orc_dc_run.restype = C.c_int
+        L.orc_dc_run_backbone.argtypes = L.orc_dc_run.argtypes
+        L.orc_dc_run_backbone.restype = C.c_int
         L.orc_place_exact_run.argtypes = [C.c_int64, c_f64p, C.c_int64, c_i32p, c_i32p, c_i32p, c_i32p, c_f64p,
                                           c_i32p, c_i32p, c_f64p]
         L.orc_place_exact_run.restype = C.c_int
@@ -177,14 +179,16 @@ class Oracle:
                                       _p(st["len"], c_f64p), _p(st["cid"], c_i32p),
                                       _p(st["cdis"], c_f64p))
 
-    def dc_run(self, dist_rows, B, skip_last_backbone=0):
-        """Divide-and-conquer mode on a dense distance matrix (entry (i,j), j<i, read)."""
+    def dc_run(self, dist_rows, B, skip_last_backbone=0, backbone_only=False):
+        """Divide-and-conquer mode on a dense distance matrix (entry (i,j), j<i, read).
+        backbone_only: stop after the backbone tree and the cluster assignment."""
         D = np.ascontiguousarray(dist_rows, dtype=np.float64)
         N, ld = D.shape
         st = self.place_alloc(N)
         trace = np.zeros(3 * N, dtype=np.float64)
         cl = np.full(N, -1, dtype=np.int32)
-        rc = self.lib.orc_dc_run(N, B, _p(D, c_f64p), ld, skip_last_backbone, _p(st["head"], c_i32p),
+        fn = self.lib.orc_dc_run_backbone if backbone_only else self.lib.orc_dc_run
+        rc = fn(N, B, _p(D, c_f64p), ld, skip_last_backbone, _p(st["head"], c_i32p),
                                  _p(st["e"], c_i32p), _p(st["nxt"], c_i32p), _p(st["belong"], c_i32p),
                                  _p(st["len"], c_f64p), _p(st["cid"], c_i32p), _p(st["cdis"], c_f64p),
                                  _p(cl, c_i32p), _p(trace, c_f64p))
