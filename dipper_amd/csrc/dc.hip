@@ -16,7 +16,6 @@
 //    the cluster sizes), so all cluster trees are built concurrently, one wavefront per cluster, from
 //    per-cluster distance blocks computed beforehand by the tiled pair kernels.
 #include <algorithm>
-#include <numeric>
 
 #include "dpr_internal.hpp"
 
