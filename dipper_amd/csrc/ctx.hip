@@ -587,7 +587,7 @@ int dpr_get_prune_stats(dpr_ctx* c, uint64_t* units_scanned, uint64_t* units_per
     NjState st;
     if (int rc = fetch_state(c, &st)) return rc;
     if (units_scanned) *units_scanned = st.units_scanned;
-    if (units_per_full_scan) *units_per_full_scan = (uint64_t)c->nj[0].pr.utot;
+    if (units_per_full_scan) *units_per_full_scan = (uint64_t)c->nj[0].pr.utot0;
     return DPR_OK;
 }
 
@@ -671,8 +671,13 @@ int dpr_get_matrix_row(dpr_ctx* c, int64_t i, double* out)
         std::vector<int32_t> pos((size_t)N);
         std::vector<double> row((size_t)q.P);
         DPR_HIP(hipMemcpy(pos.data(), q.pos_of_slot, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
-        DPR_HIP(hipMemcpy(row.data(), q.D + (int64_t)pos[(size_t)i] * q.ld, sizeof(double) * (size_t)q.P, hipMemcpyDeviceToHost));
-        for (int64_t j = 0; j < N; ++j) out[j] = row[(size_t)pos[(size_t)j]];
+        if (pos[(size_t)i] >= 0 && pos[(size_t)i] < q.P)
+            DPR_HIP(hipMemcpy(row.data(), q.D + (int64_t)pos[(size_t)i] * q.ld, sizeof(double) * (size_t)q.P, hipMemcpyDeviceToHost));
+        if (pos[(size_t)i] < 0 || pos[(size_t)i] >= q.P) {      // slot not alive any more
+            for (int64_t j = 0; j < N; ++j) out[j] = __builtin_inf();
+            return DPR_OK;
+        }
+        for (int64_t j = 0; j < N; ++j) out[j] = (pos[(size_t)j] >= 0 && pos[(size_t)j] < q.P) ? row[(size_t)pos[(size_t)j]] : __builtin_inf();
         return DPR_OK;
     }
     NjBuffers* b = owner_buffers(c, i);
@@ -691,7 +696,7 @@ int dpr_get_row_sums(dpr_ctx* c, double* out)
         std::vector<double> u((size_t)q.P);
         DPR_HIP(hipMemcpy(pos.data(), q.pos_of_slot, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
         DPR_HIP(hipMemcpy(u.data(), q.U, sizeof(double) * (size_t)q.P, hipMemcpyDeviceToHost));
-        for (int64_t j = 0; j < N; ++j) out[j] = u[(size_t)pos[(size_t)j]];
+        for (int64_t j = 0; j < N; ++j) out[j] = (pos[(size_t)j] >= 0 && pos[(size_t)j] < q.P) ? u[(size_t)pos[(size_t)j]] : 0.0;
         return DPR_OK;
     }
     DPR_HIP(hipMemcpy(out, c->nj[0].U, sizeof(double) * (size_t)c->nj[0].N, hipMemcpyDeviceToHost));

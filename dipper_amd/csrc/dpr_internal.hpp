@@ -95,6 +95,7 @@ struct NjPruned {
     int32_t *slot_of_pos = nullptr, *pos_of_slot = nullptr, *perm = nullptr;
     uint64_t* umin = nullptr;   // [strips][groups] order-encoded lower bound of D per unit
     int64_t nunits_alloc = 0, utot = 0;
+    int64_t utot0 = 0;          // units of one full scan at the first epoch (statistics)
     hipGraphExec_t graph = nullptr;   // kGraphIters iterations of (test, scan, post, bounds)
     int32_t* list = nullptr;         // units selected by the prep kernel (strip << 20 | group)
     int32_t *blk_cb = nullptr, *blk_g0 = nullptr;   // prep block -> (strip, first group)

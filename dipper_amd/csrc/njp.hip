@@ -23,6 +23,8 @@
 #include "nj_dev.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <numeric>
 
@@ -443,25 +445,12 @@ int njp_scan_grid() { return g_njp_grid; }
 
 static int64_t round_up16(int64_t v) { return (v + 15) / 16 * 16; }
 
-int njp_build(NjBuffers& b, hipStream_t s)
+// allocate the position-space structures of an epoch with P positions (N = total tips: slot arrays)
+static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, hipStream_t s)
 {
-    // b.D / b.U hold the matrix and the row sums in tip order (world == 1).  Sort by U ascending.
-    const int64_t N = b.N;
-    std::vector<double> hU((size_t)N);
-    DPR_HIP(hipMemcpyAsync(hU.data(), b.U, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, s));
-    DPR_HIP(hipStreamSynchronize(s));
-    std::vector<int32_t> perm((size_t)N);
-    std::iota(perm.begin(), perm.end(), 0);
-    std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t c) {
-        const double ua = hU[(size_t)a], uc = hU[(size_t)c];
-        if (ua != ua) return false;      // NaN last
-        if (uc != uc) return true;
-        return ua < uc;
-    });
-    NjPruned& q = b.pr;
-    q.P = N;
-    q.ld = round_up16(N);
-    const int64_t rows_alloc = (N + kUR - 1) / kUR * kUR + kUR;
+    q.P = P;
+    q.ld = round_up16(P);
+    const int64_t rows_alloc = (P + kUR - 1) / kUR * kUR + kUR;
     const size_t dbytes = (size_t)(rows_alloc * q.ld + kTileCols + 16) * sizeof(double);
     DPR_HIP(hipMalloc(&q.D, dbytes));
     DPR_HIP(hipMemsetAsync(q.D, 0, dbytes, s));
@@ -477,17 +466,17 @@ int njp_build(NjBuffers& b, hipStream_t s)
     DPR_HIP(hipMalloc(&q.slot_of_pos, sizeof(int32_t) * vec));
     DPR_HIP(hipMalloc(&q.pos_of_slot, sizeof(int32_t) * vec));
     DPR_HIP(hipMalloc(&q.perm, sizeof(int32_t) * vec));
-    DPR_HIP(hipMemcpyAsync(q.perm, perm.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, s));
-    const int64_t G16 = (N + kUR - 1) / kUR, S = (N + kTileCols - 1) / kTileCols + 1;
+    DPR_HIP(hipMemsetAsync(q.slot_of_pos, 0xff, sizeof(int32_t) * vec, s));
+    DPR_HIP(hipMemsetAsync(q.pos_of_slot, 0xff, sizeof(int32_t) * vec, s));   // -1: slot not alive
+    const int64_t G16 = (P + kUR - 1) / kUR, S = (P + kTileCols - 1) / kTileCols + 1;
     q.nunits_alloc = S * G16;
     DPR_HIP(hipMalloc(&q.umin, sizeof(uint64_t) * (size_t)q.nunits_alloc));
-    q.utot = unit_total(N);
+    q.utot = unit_total(P);
     {
         // prep blocks: one strip and up to 256 consecutive row groups each (groups >= 32*cb see the strip)
         std::vector<int32_t> hcb, hg0;
-        const int64_t G = (N + kUR - 1) / kUR;
-        for (int64_t c = 0; 32 * c < G && c * kTileCols < N - 1; ++c)
-            for (int64_t g0 = 32 * c; g0 < G; g0 += kThreads) { hcb.push_back((int32_t)c); hg0.push_back((int32_t)g0); }
+        for (int64_t c = 0; 32 * c < G16 && c * kTileCols < P - 1; ++c)
+            for (int64_t g0 = 32 * c; g0 < G16; g0 += kThreads) { hcb.push_back((int32_t)c); hg0.push_back((int32_t)g0); }
         if (hcb.empty()) { hcb.push_back(0); hg0.push_back(0); }
         q.nprep = (int)hcb.size();
         DPR_HIP(hipMalloc(&q.blk_cb, sizeof(int32_t) * hcb.size()));
@@ -498,22 +487,94 @@ int njp_build(NjBuffers& b, hipStream_t s)
     }
     DPR_HIP(hipMalloc(&q.list, sizeof(int32_t) * (size_t)(q.utot + kScanBlocks + 64)));
     DPR_HIP(hipMemsetAsync(q.list, 0, sizeof(int32_t) * (size_t)(q.utot + kScanBlocks + 64), s));
+    hipLaunchKernelGGL(njp_fill_u64_kernel, dim3(256), dim3(256), 0, s, (uint64_t*)q.umin, q.nunits_alloc,
+                       enc_f64_host(-__builtin_inf()));
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+static void sort_by_row_sum(std::vector<int32_t>& perm, const std::vector<double>& hU)
+{
+    std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t c) {
+        const double ua = hU[(size_t)a], uc = hU[(size_t)c];
+        if (ua != ua) return false;      // NaN last
+        if (uc != uc) return true;
+        return ua < uc;
+    });
+}
+
+int njp_build(NjBuffers& b, hipStream_t s)
+{
+    // b.D / b.U hold the matrix and the row sums in tip order (world == 1).  Sort by U ascending.
+    const int64_t N = b.N;
+    std::vector<double> hU((size_t)N);
+    DPR_HIP(hipMemcpyAsync(hU.data(), b.U, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, s));
+    DPR_HIP(hipStreamSynchronize(s));
+    std::vector<int32_t> perm((size_t)N);
+    std::iota(perm.begin(), perm.end(), 0);
+    sort_by_row_sum(perm, hU);
+    NjPruned& q = b.pr;
+    if (int rc = njp_alloc_epoch(q, N, N, s)) return rc;
+    q.utot0 = q.utot;
+    DPR_HIP(hipMemcpyAsync(q.perm, perm.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, s));
     if (std::getenv("DPR_NJ_ITERSTATS")) {
         DPR_HIP(hipMalloc(&q.iterstats, sizeof(uint64_t) * (size_t)(2 * N + 2)));
         DPR_HIP(hipMemsetAsync(q.iterstats, 0, sizeof(uint64_t) * (size_t)(2 * N + 2), s));
     }
-
     dim3 grid((unsigned)((N + kThreads - 1) / kThreads > 64 ? 64 : (N + kThreads - 1) / kThreads), (unsigned)(N < 32768 ? N : 32768));
     hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, b.D, b.ld, q.D, q.ld, q.perm, N);
     hipLaunchKernelGGL(njp_init_vectors_kernel, dim3((unsigned)((N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                        b.U, q.perm, (const int32_t*)nullptr, N, N, q.U, q.Ur, q.KA, q.KB, q.slot_of_pos, q.pos_of_slot);
-    hipLaunchKernelGGL(njp_fill_u64_kernel, dim3(256), dim3(256), 0, s, (uint64_t*)q.umin, q.nunits_alloc,
-                       enc_f64_host(-__builtin_inf()));
     DPR_HIP(hipGetLastError());
     DPR_HIP(hipStreamSynchronize(s));
     // the tip-order matrix is no longer needed
     (void)hipFree(b.D);
     b.D = nullptr;
+    q.active = true;
+    return DPR_OK;
+}
+
+// New epoch: the live positions (n of them), re-sorted by their CURRENT row sums, become a dense n x n
+// position space.  Merges put new nodes into the positions of merged ones, so the order by row sum -- which
+// is what keeps the unit bounds tight -- decays, and dead positions still occupy scanned units; late in a
+// run most units were scanned every iteration.  Costs one n^2 copy; the first scan of the epoch is a full
+// one (bounds start at -inf, no seed).  Called between iterations with the stream idle.
+static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s)
+{
+    NjPruned& q = b.pr;
+    NjState st;
+    DPR_HIP(hipMemcpy(&st, b.st, sizeof(NjState), hipMemcpyDeviceToHost));
+    const int64_t n = st.n, Pold = q.P;
+    if (st.status != 0 || n < 3) return DPR_OK;
+    std::vector<double> hU((size_t)Pold), hUr((size_t)Pold);
+    DPR_HIP(hipMemcpy(hU.data(), q.U, sizeof(double) * (size_t)Pold, hipMemcpyDeviceToHost));
+    DPR_HIP(hipMemcpy(hUr.data(), q.Ur, sizeof(double) * (size_t)Pold, hipMemcpyDeviceToHost));
+    std::vector<int32_t> perm;
+    perm.reserve((size_t)n);
+    for (int64_t p = 0; p < Pold; ++p)
+        if (hUr[(size_t)p] == hUr[(size_t)p]) perm.push_back((int32_t)p);      // dead positions carry NaN
+    if ((int64_t)perm.size() != n) { set_error("njp_rebuild_epoch: live positions do not match the active size"); return DPR_ERR_STATE; }
+    sort_by_row_sum(perm, hU);
+    int32_t new_px = -1;
+    for (int64_t a = 0; a < n; ++a)
+        if (perm[(size_t)a] == st.pad) new_px = (int32_t)a;
+    NjPruned qn;
+    if (int rc = njp_alloc_epoch(qn, n, b.N, s)) return rc;
+    qn.utot0 = q.utot0;
+    qn.iterstats = q.iterstats; q.iterstats = nullptr;
+    DPR_HIP(hipMemcpyAsync(qn.perm, perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
+    dim3 grid((unsigned)((n + kThreads - 1) / kThreads > 64 ? 64 : (n + kThreads - 1) / kThreads), (unsigned)(n < 32768 ? n : 32768));
+    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, q.D, q.ld, qn.D, qn.ld, qn.perm, n);
+    hipLaunchKernelGGL(njp_init_vectors_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                       q.U, qn.perm, (const int32_t*)q.slot_of_pos, n, n, qn.U, qn.Ur, qn.KA, qn.KB, qn.slot_of_pos, qn.pos_of_slot);
+    DPR_HIP(hipGetLastError());
+    // iteration state: position of the last new node in the new space; no seed records, empty lists
+    st.pad = new_px;
+    st.cnt_list[0] = 0ull; st.cnt_list[1] = 0ull;
+    DPR_HIP(hipMemcpyAsync(b.st, &st, sizeof(NjState), hipMemcpyHostToDevice, s));
+    DPR_HIP(hipStreamSynchronize(s));
+    njp_free(q);
+    q = qn;
     q.active = true;
     return DPR_OK;
 }
@@ -554,7 +615,7 @@ static int njp_enqueue_iteration(NjBuffers& b, hipStream_t s)
 // iterations beyond it_limit are no-ops.
 constexpr int kGraphIters = 32;
 
-int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
+static int njp_run_segment(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
 {
     NjPruned& q = b.pr;
     const int64_t limit = it0 + todo;
@@ -579,6 +640,38 @@ int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
         for (; done + kGraphIters <= todo; done += kGraphIters) DPR_HIP(hipGraphLaunch(q.graph, s));
     for (; done < todo; ++done)
         if (int rc = njp_enqueue_iteration(b, s)) return rc;
+    return DPR_OK;
+}
+
+// enqueue `todo` iterations starting at iteration it0, in epochs: whenever the active size has dropped to
+// half of the epoch's positions (and the epoch is large enough to matter) the position space is rebuilt
+int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
+{
+    const char* e_min = std::getenv("DPR_NJ_EPOCH_MIN");
+    const int64_t epoch_min = e_min ? std::atoll(e_min) : 2048;   // epochs smaller than this are not rebuilt
+    const char* e_pct = std::getenv("DPR_NJ_EPOCH_PCT");
+    const int64_t pct = e_pct ? std::atoll(e_pct) : 70;           // rebuild once n <= pct% of the epoch's positions
+    int64_t it = it0, left = todo;
+    if (left <= 0) return njp_run_segment(b, it0, 0, s);
+    while (left > 0) {
+        const int64_t n = b.N - it, P = b.pr.P;
+        int64_t seg = left;
+        if (epoch_min > 0 && P >= epoch_min) {
+            const int64_t target = P * pct / 100;
+            if (n <= target && n >= 3) {
+                DPR_HIP(hipStreamSynchronize(s));
+                const auto t0 = std::chrono::steady_clock::now();
+                if (int rc = njp_rebuild_epoch(b, s)) return rc;
+                if (std::getenv("DPR_NJ_EPOCH_LOG"))
+                    std::fprintf(stderr, "[njp] epoch rebuild at n=%lld: %.2f ms\n", (long long)n,
+                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+                continue;
+            }
+            if (n - target < seg) seg = n - target;
+        }
+        if (int rc = njp_run_segment(b, it, seg, s)) return rc;
+        it += seg; left -= seg;
+    }
     return DPR_OK;
 }
 

@@ -124,3 +124,49 @@ def test_msa_dist_and_nj(gpu, orc, n, L, inv):
             res = gpu.nj_run()
             assert np.array_equal(res["merge_x"], ref["merge_x"]) and np.array_equal(res["merge_y"], ref["merge_y"])
             assert np.array_equal(res["bl_x"], ref["bl_x"]) and np.array_equal(res["bl_y"], ref["bl_y"])
+
+
+@pytest.mark.parametrize("n,kind", [(700, "additive"), (1500, "additive"), (777, "ties"), (900, "noisy")])
+def test_nj_epoch_rebuilds(orc, monkeypatch, n, kind):
+    """pruned path with the position space rebuilt (compacted + re-sorted by the current row sums) every
+    time the active size halves (DPR_NJ_EPOCH_MIN lowers the size threshold so that small inputs go
+    through several epochs): same merge log as the oracle, also for runs interrupted between iterations,
+    and U stays the active row sums."""
+    import dipper_amd
+    from dipper_amd import capi
+    monkeypatch.setenv("DPR_NJ_EPOCH_MIN", "48")
+    rng = np.random.default_rng(n)
+    if kind == "additive":
+        D = _util.random_additive_matrix(rng, n)
+    elif kind == "ties":
+        D = _util.random_additive_matrix(rng, n, zero_frac=0.4)
+        D = np.round(D, 1)
+    else:
+        D = np.round(rng.random((n, n)), 3)
+        D = np.tril(D, -1) + np.tril(D, -1).T
+    capi.set_nj_mode(1)
+    d = dipper_amd.Dipper(0)
+    try:
+        d.set_matrix_full(D)
+        d.dist_matrix(capi.SRC_MATRIX)
+        ref = orc.nj_run(np.tril(D, -1))
+        # interrupted run: the pieces cross several epoch boundaries
+        parts = [d.nj_run(max_iters=k) for k in (n // 2 + 7, n // 4, 5, -1)]
+        for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
+            assert np.array_equal(np.concatenate([p[key] for p in parts]), ref[key]), key
+        assert parts[-1]["last_d"] == ref["last_d"]
+    finally:
+        d.close()
+    d = dipper_amd.Dipper(0)
+    try:
+        d.set_matrix_full(D)
+        d.dist_matrix(capi.SRC_MATRIX)
+        k = n // 2 + 30
+        d.nj_run(max_iters=k)
+        na = n - k
+        part = orc.nj_run(np.tril(D, -1), max_iters=k)
+        assert np.array_equal(d.row_sums()[:na], part["U"][:na])
+        M = d.matrix()[:na, :na]
+        assert np.array_equal(M, part["D"][:na, :na])
+    finally:
+        d.close()
