@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""--add timing (BASELINE configs[4] shape, scaled): python profiles/add_bench.py [backbone tips] [queries] [sites] [kind m|r]
+Backbone tree = divide-and-conquer tree of the first m tips (built here), imported like Tree::Tree +
+initializeDeviceArrays, then the queries are placed with addQuery (dpr_place_run first = m)."""
+import json, os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+sys.setrecursionlimit(1000000)
+import numpy as np
+import dipper_amd
+from dipper_amd import capi
+from tests import _util, _orc
+m = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+nq = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+L = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
+kind = sys.argv[4] if len(sys.argv) > 4 else "m"
+n = m + nq
+seqs = _util.synth_alignment(np.random.default_rng(1), n, L, mean_bl=1e-3, lo=1e-4, hi=1e-2)
+seqs = [seqs[i] for i in np.random.default_rng(7).permutation(n)]
+d = dipper_amd.Dipper(0)
+def load(ss):
+    if kind == "r":
+        d.set_reads(ss); d.sketch(15, 1000, fetch=False)
+    else:
+        d.set_msa(capi.pack4_many(ss), L)
+src = capi.SRC_MASH if kind == "r" else capi.SRC_MSA
+load(seqs[:m])
+t0 = time.perf_counter()
+bb = d.dc_run(src, m, max(m // 20, 3), dist_type=2, k=15)
+t1 = time.perf_counter()
+names = [f"T{i}" for i in range(n)]
+nwk = _util.newick_from_placement(names[:m], bb["head"], bb["e"], bb["nxt"], bb["len"], m)
+t2 = time.perf_counter()
+st, leaf_names = _util.backbone_state(_orc.load(), nwk, n)      # Tree::Tree ids + adjacency (host, Python mirror)
+order = [int(x[1:]) for x in leaf_names]                           # backbone tips in import order, then the queries
+seq_order = [seqs[i] for i in order] + seqs[m:]
+t3 = time.perf_counter()
+load(seq_order)
+t4 = time.perf_counter()
+res = d.place_run(src, n, first=m, dist_type=2, k=15, state={k: st[k] for k in ("head", "e", "nxt", "belong", "len")})
+t5 = time.perf_counter()
+print(json.dumps(dict(kind=kind, backbone=m, queries=nq, sites=L, backbone_tree_s=t1 - t0, newick_host_s=t3 - t1,
+                      upload_s=t4 - t3, add_s=t5 - t4, add_device_ms=d.timing()[1], queries_per_s=nq / (t5 - t4))))
