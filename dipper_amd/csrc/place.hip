@@ -189,6 +189,63 @@ __global__ __launch_bounds__(kThreads) void place_build_adj_kernel(PlaceBuffers 
     p.adj[3 * v] = s3[0]; p.adj[3 * v + 1] = s3[1]; p.adj[3 * v + 2] = s3[2];
 }
 
+// Closest lists of an imported backbone, all slots in parallel.  The reference inserts the leaves one
+// after the other (m single-thread BFS launches, src/placement_close_k.cu:247-260); the lists it ends with
+// are, for every slot u->v, the five leaves x behind u with the smallest path length d_u(x) < 2 (the lists
+// start at the sentinel 2 and take x only while `entry > d`), ties by leaf id (= insertion order), where
+// d is accumulated from the leaf outwards: d_u(x) = d_w(x) + len[slot w->u].  A leaf that misses a list
+// cannot be in any list farther along (the leaves ahead of it are also ahead there), so the BFS pruning
+// does not change that set.  Hence one relaxation round recomputes every list from the lists of the slots
+// entering u (plus the leaf u itself), double-buffered, until nothing changes: #rounds = tree diameter in
+// edges instead of m dependent launches.
+__global__ __launch_bounds__(kThreads) void place_lists_round_kernel(PlaceBuffers p, const int32_t* __restrict__ cid_in,
+                                                                     const double* __restrict__ cdis_in,
+                                                                     int32_t* __restrict__ cid_out,
+                                                                     double* __restrict__ cdis_out, int64_t nslots,
+                                                                     int64_t m, int* __restrict__ changed)
+{
+    const int64_t s = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (s >= nslots) return;
+    const int u = p.belong[s];
+    double bd[K5];
+    int bi[K5];
+#pragma unroll
+    for (int j = 0; j < K5; ++j) { bd[j] = 2.0; bi[j] = -1; }
+    auto offer = [&](int x, double d) {
+        if (!(2.0 > d)) return;                                   // the sentinel 2 never gives way to d >= 2
+        int pos = K5;
+#pragma unroll
+        for (int j = K5 - 1; j >= 0; --j)
+            if (bd[j] > d || (bd[j] == d && (bi[j] == -1 || bi[j] > x))) pos = j;
+        if (pos == K5) return;
+#pragma unroll
+        for (int j = K5 - 1; j > 0; --j)
+            if (j > pos) { bd[j] = bd[j - 1]; bi[j] = bi[j - 1]; }
+#pragma unroll
+        for (int j = 0; j < K5; ++j)
+            if (j == pos) { bd[j] = d; bi[j] = x; }
+    };
+    if (u < m) offer(u, 0.0);                                     // u is a backbone leaf
+    for (int o = p.head[u]; o != -1; o = p.nxt[o]) {
+        if (o == (int)s) continue;
+        const int in = p.rev[o];                                  // slot w -> u
+        const double L = p.len[in];
+        for (int j = 0; j < K5; ++j) {
+            const int x = cid_in[in * K5 + j];
+            if (x == -1) break;
+            offer(x, cdis_in[in * K5 + j] + L);
+        }
+    }
+    bool diff = false;
+#pragma unroll
+    for (int j = 0; j < K5; ++j) {
+        diff |= (cid_in[s * K5 + j] != bi[j]) || (cdis_in[s * K5 + j] != bd[j]);
+        cid_out[s * K5 + j] = bi[j];
+        cdis_out[s * K5 + j] = bd[j];
+    }
+    if (diff) *changed = 1;
+}
+
 // closest lists of an imported backbone: leaves 0..m-1 in order (src/placement_close_k.cu:247-260)
 __global__ __launch_bounds__(64) void place_backbone_lists_kernel(PlaceBuffers p, int64_t t0, int64_t t1)
 {
@@ -444,12 +501,42 @@ int place_import_backbone(PlaceBuffers& p, int64_t m, hipStream_t s)
     const int64_t nslots = 4 * m - 4;
     hipLaunchKernelGGL(place_pair_rev_kernel, dim3((unsigned)((nslots + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, nslots);
     hipLaunchKernelGGL(place_build_adj_kernel, dim3((unsigned)((2 * p.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, 2 * p.N);
-    // sequential over the backbone leaves (ties in the lists depend on this order); chunked so that no
-    // single launch runs for too long
-    const int64_t chunk = 4096;
-    for (int64_t t0 = 0; t0 < m; t0 += chunk) {
-        const int64_t t1 = t0 + chunk < m ? t0 + chunk : m;
-        hipLaunchKernelGGL(place_backbone_lists_kernel, dim3(1), dim3(64), 0, s, p, t0, t1);
+    DPR_HIP(hipGetLastError());
+    // parallel relaxation rounds (see place_lists_round_kernel), double-buffered; the flag is read every 16 rounds
+    const bool serial = std::getenv("DPR_IMPORT_SERIAL") != nullptr;
+    bool converged = false;
+    if (!serial) {
+        int32_t* cid2 = nullptr; double* cdis2 = nullptr; int* d_changed = nullptr;
+        DPR_HIP(hipMalloc(&cid2, sizeof(int32_t) * (size_t)(nslots * K5)));
+        DPR_HIP(hipMalloc(&cdis2, sizeof(double) * (size_t)(nslots * K5)));
+        DPR_HIP(hipMalloc(&d_changed, sizeof(int)));
+        const unsigned grid = (unsigned)((nslots + kThreads - 1) / kThreads);
+        const int max_rounds = 4096;
+        int rounds = 0, rc = DPR_OK;
+        while (rounds < max_rounds && !converged) {
+            DPR_HIP(hipMemsetAsync(d_changed, 0, sizeof(int), s));
+            for (int k = 0; k < 16; ++k, ++rounds) {     // even number: the result of a batch is in p.cid / p.cdis
+                const bool fwd = (k & 1) == 0;
+                hipLaunchKernelGGL(place_lists_round_kernel, dim3(grid), dim3(kThreads), 0, s, p,
+                                   fwd ? (const int32_t*)p.cid : (const int32_t*)cid2, fwd ? (const double*)p.cdis : (const double*)cdis2,
+                                   fwd ? cid2 : p.cid, fwd ? cdis2 : p.cdis, nslots, m, d_changed);
+            }
+            int h = 1;
+            if (hipMemcpyAsync(&h, d_changed, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rc = DPR_ERR_HIP; break; }
+            // no change in the last batch: fixed point (a batch whose first rounds still changed lists sets the flag)
+            converged = (h == 0);
+        }
+        (void)hipFree(cid2); (void)hipFree(cdis2); (void)hipFree(d_changed);
+        if (rc) { set_error("place_import_backbone: relaxation rounds failed"); return rc; }
+    }
+    if (!converged) {
+        // very deep trees (diameter > 4096 edges) or DPR_IMPORT_SERIAL: the reference's order, leaf by leaf
+        hipLaunchKernelGGL(place_init_lists_kernel, dim3((unsigned)((lim + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, lim);
+        const int64_t chunk = 4096;
+        for (int64_t t0 = 0; t0 < m; t0 += chunk) {
+            const int64_t t1 = t0 + chunk < m ? t0 + chunk : m;
+            hipLaunchKernelGGL(place_backbone_lists_kernel, dim3(1), dim3(64), 0, s, p, t0, t1);
+        }
     }
     DPR_HIP(hipGetLastError());
     return DPR_OK;

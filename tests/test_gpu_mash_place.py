@@ -125,3 +125,41 @@ def test_placement_msa_and_mash_sources(gpu, orc):
     M = gpu.matrix()
     got = gpu.place_run(capi.SRC_MASH, len(reads), k=15)
     _same_state(got, orc.place_run(M), len(reads))
+
+
+@pytest.mark.parametrize("serial", [False, True], ids=["rounds", "serial"])
+def test_backbone_import_lists(gpu, orc, monkeypatch, serial):
+    """initializeDeviceArrays (src/placement_close_k.cu:126-264): closest lists of an imported backbone.
+    The parallel relaxation rounds and the reference's leaf-by-leaf order (DPR_IMPORT_SERIAL) must both give
+    the oracle's lists bit for bit -- on the reference's own t2 backbone (1000 tips, many zero lengths =
+    ties) and on a caterpillar (diameter ~ m: many rounds)."""
+    import os
+    from dipper_amd import capi
+    if serial:
+        monkeypatch.setenv("DPR_IMPORT_SERIAL", "1")
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    t2 = open(os.path.join(gold, "t2.backbone.nwk")).readline()
+    m = 300
+    cat = "(" * (m - 1) + "L0:0.01"
+    for i in range(1, m):
+        cat += f",L{i}:{0.01 + 0.001 * (i % 7)}):{0.002 * (i % 3)}"
+    cat = cat[:cat.rfind(":")] + ";"
+    for nwk in (t2, cat):
+        kids = _util.parse_newick(nwk)[0]
+        mm = sum(1 for v in kids if not kids[v])
+        n = mm + 1
+        st, _ = _util.backbone_state(orc, nwk, n)
+        ref = {k: v.copy() for k, v in st.items()}
+        orc.place_init_lists(n, mm, ref)
+        # one query (tip mm) is placed after the import: its row of a random matrix
+        D = np.round(np.random.default_rng(mm).random((n, n)) * 0.3, 3)
+        D = np.tril(D, -1) + np.tril(D, -1).T
+        ref = orc.place_run(D, first=mm, state=ref)
+        gpu.set_matrix_full(D)
+        got = gpu.place_run(capi.SRC_MATRIX, n, first=mm, state={k: st[k].copy() for k in ("head", "e", "nxt", "belong", "len")})
+        live = 4 * n - 4
+        for key in ("head", "e", "nxt", "belong", "len"):
+            assert np.array_equal(got[key][:(2 * n if key == "head" else live)], ref[key][:(2 * n if key == "head" else live)]), key
+        assert np.array_equal(got["cid"][:5 * live], ref["cid"][:5 * live])
+        assert np.array_equal(got["cdis"][:5 * live], ref["cdis"][:5 * live])
+        assert np.array_equal(got["trace"][mm:], ref["trace"][mm:])
