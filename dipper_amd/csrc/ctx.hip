@@ -737,20 +737,37 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
     PlaceBuffers& p = c->place;
     const int64_t R = 256;                       // distance rows per batch
     const int64_t ldb = (last + 15) / 16 * 16;
+    // Multi-GPU (dpr_comm_init done, inputs replicated): the distance rows of a batch do not depend on the
+    // placements, so every rank computes R/world of them and one all-gather per batch completes the block;
+    // the tree kernels then run identically on every rank (deterministic), so no tree state is exchanged.
+    const bool sharded = c->world > 1 && c->vworld == 0 && c->comm != nullptr && source != DPR_SRC_MATRIX;
+    const int W = sharded ? c->world : 1;
+    const int64_t per = (R + W - 1) / W;         // rows per rank and batch
     double* rows = nullptr;
-    if (source != DPR_SRC_MATRIX) DPR_HIP(hipMalloc(&rows, sizeof(double) * (size_t)(R * ldb)));
+    if (source != DPR_SRC_MATRIX) DPR_HIP(hipMalloc(&rows, sizeof(double) * (size_t)(per * W * ldb)));
     auto row_ptr = [&](int64_t i, int64_t i0) -> const double* {
         return source == DPR_SRC_MATRIX ? c->packed_lower + i * (i - 1) / 2 : rows + (i - i0) * ldb;
     };
+    auto fill_some = [&](int64_t i0, int64_t nr, double* out) -> int {
+        if (nr <= 0) return DPR_OK;
+        if (source == DPR_SRC_MSA) return msa_dist_block_rows(c->msa, i0, nr, 0, 0, i0 + nr, dist_type, out, ldb, c->stream);
+        if (source == DPR_SRC_MASH) return mash_dist_rows(c->mash, i0, nr, 0, 0, false, i0 + nr, out, ldb, c->stream);
+        return DPR_OK;
+    };
     auto fill_rows = [&](int64_t i0, int64_t nr) -> int {
-        if (source == DPR_SRC_MSA) return msa_dist_block_rows(c->msa, i0, nr, 0, 0, i0 + nr, dist_type, rows, ldb, c->stream);
-        if (source == DPR_SRC_MASH) return mash_dist_rows(c->mash, i0, nr, 0, 0, false, i0 + nr, rows, ldb, c->stream);
+        if (!sharded) return fill_some(i0, nr, rows);
+        const int64_t a = (int64_t)c->rank * per, b = a + per < nr ? a + per : nr;     // this rank's rows of the batch
+        if (int rc = fill_some(i0 + a, b - a, rows + a * ldb)) return rc;
+        if (g_rccl.AllGather(rows + a * ldb, rows, (size_t)(per * ldb), kNcclFloat64, c->comm, c->stream) != 0) {
+            set_error("ncclAllGather(distance rows) failed");
+            return DPR_ERR_COMM;
+        }
         return DPR_OK;
     };
     int rc = DPR_OK;
     if (first == 2) {
         rc = place_init_fresh(p, c->stream);
-        if (!rc) rc = fill_rows(1, 1);
+        if (!rc) rc = fill_some(1, 1, rows);
         if (!rc) rc = place_initial_tree(p, row_ptr(1, 1), c->stream);
     } else {
         rc = place_import_backbone(p, first, c->stream);

@@ -16,7 +16,8 @@ kind = sys.argv[4] if len(sys.argv) > 4 else "m"
 n = m + nq
 seqs = _util.synth_alignment(np.random.default_rng(1), n, L, mean_bl=1e-3, lo=1e-4, hi=1e-2)
 seqs = [seqs[i] for i in np.random.default_rng(7).permutation(n)]
-d = dipper_amd.Dipper(0)
+from profiles import _mgpu
+d, rank, world, dist = _mgpu.open_dipper()      # multi-GPU: see profiles/_mgpu.py
 def load(ss):
     if kind == "r":
         d.set_reads(ss); d.sketch(15, 1000, fetch=False)
@@ -38,5 +39,7 @@ load(seq_order)
 t4 = time.perf_counter()
 res = d.place_run(src, n, first=m, dist_type=2, k=15, state={k: st[k] for k in ("head", "e", "nxt", "belong", "len")})
 t5 = time.perf_counter()
-print(json.dumps(dict(kind=kind, backbone=m, queries=nq, sites=L, backbone_tree_s=t1 - t0, newick_host_s=t3 - t1,
+if rank == 0:
+  print(json.dumps(dict(n_gpus=world, kind=kind, backbone=m, queries=nq, sites=L, backbone_tree_s=t1 - t0, newick_host_s=t3 - t1,
                       upload_s=t4 - t3, add_s=t5 - t4, add_device_ms=d.timing()[1], queries_per_s=nq / (t5 - t4))))
+_mgpu.finish(dist)

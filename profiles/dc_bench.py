@@ -18,16 +18,8 @@ rng = np.random.default_rng(7)
 perm = rng.permutation(n)          # the CLI shuffles the input order (src/tree_generation.cu:341-344)
 seqs = [seqs[i] for i in perm]
 print(f"input {n} x {L} generated in {time.perf_counter()-t0:.1f}s", flush=True)
-# multi-GPU: python -m torch.distributed.run --nnodes=1 --nproc-per-node G --master-addr 127.0.0.1 profiles/dc_bench.py ...
-rank, world, local_rank = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
-d = dipper_amd.Dipper(local_rank)
-if world > 1:
-    import torch, torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    uid = [d.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(uid, src=0)
-    d.comm_init(rank, world, uid[0])
+from profiles import _mgpu
+d, rank, world, dist = _mgpu.open_dipper()      # multi-GPU: see profiles/_mgpu.py
 t0 = time.perf_counter()
 if kind == "r":
     d.set_reads(seqs)
@@ -49,6 +41,4 @@ out = dict(kind=kind, mean_bl=mean_bl, tips=n, sites=L, backbone=B, upload_s=t1 
 out["n_gpus"] = world
 if rank == 0:
     print(json.dumps(out), flush=True)
-if world > 1:
-    dist.barrier()
-    dist.destroy_process_group()
+_mgpu.finish(dist)

@@ -9,7 +9,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 kind = sys.argv[3] if len(sys.argv) > 3 else "r"
 seqs = bench.make_input(n, L, 1)
-d = dipper_amd.Dipper(0)
+from profiles import _mgpu
+d, rank, world, dist = _mgpu.open_dipper()      # multi-GPU: see profiles/_mgpu.py
 t0 = time.perf_counter()
 if kind == "r":
     d.set_reads(seqs)
@@ -22,4 +23,6 @@ else:
     t1 = t2 = time.perf_counter()
     st = d.place_run(capi.SRC_MSA, n, dist_type=2)
 t3 = time.perf_counter()
-print(f"{kind} n={n} L={L}: upload {t1-t0:.2f}s sketch {t2-t1:.3f}s placement {t3-t2:.2f}s ({d.timing()[1]:.0f} ms on device) -> {n/(t3-t1):.0f} tips/s")
+if rank == 0:
+    print(f"{world} GPU(s) {kind} n={n} L={L}: upload {t1-t0:.2f}s sketch {t2-t1:.3f}s placement {t3-t2:.2f}s ({d.timing()[1]:.0f} ms on device) -> {n/(t3-t1):.0f} tips/s")
+_mgpu.finish(dist)
