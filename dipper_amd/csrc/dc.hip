@@ -49,7 +49,8 @@ __global__ __launch_bounds__(kThreads) void dc_edge_table_kernel(PlaceBuffers p,
 // dT[c * ldq + q] = distance(query q, backbone tip c).  Writes the chunk's first minimum per query.
 __global__ __launch_bounds__(kThreads) void dc_assign_scan_kernel(const int32_t* __restrict__ et_cid,
                                                                   const double* __restrict__ et_cdis,
-                                                                  const double* __restrict__ et_len, int nv,
+                                                                  const double* __restrict__ et_len,
+                                                                  const int32_t* __restrict__ vslots, int nv,
                                                                   const double* __restrict__ dT, int64_t ldq, int Q,
                                                                   double* __restrict__ part_add,
                                                                   int32_t* __restrict__ part_pos)
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(kThreads) void dc_assign_scan_kernel(const int32_t*
     const int e0 = blockIdx.x * kAE, e1 = min(nv, e0 + kAE);
     const double* col = dT + qq;
     double best = __builtin_inf();
-    int bpos = 0x7fffffff;
+    int bpos = 0x7fffffff;      // the SLOT of the best edge: the table is in tree order, ties go to the lowest slot
     for (int e = e0; e < e1; ++e) {
         double dis1 = 0, dis2 = 0, val;
 #pragma unroll
@@ -80,7 +81,8 @@ __global__ __launch_bounds__(kThreads) void dc_assign_scan_kernel(const int32_t*
         if (dis2 < 0) dis2 = 0;
         if (dis1 > L) { a += dis1 - L; dis1 = L; }
         if (dis2 > L) { a += dis2 - L; dis2 = L; }
-        if (a < best) { best = a; bpos = e; }
+        const int slot = vslots[e];
+        if (a < best || (a == best && slot < bpos)) { best = a; bpos = slot; }
     }
     if (q < Q) {
         part_add[(int64_t)blockIdx.x * ldq + q] = best;
@@ -92,8 +94,7 @@ __global__ __launch_bounds__(kThreads) void dc_assign_scan_kernel(const int32_t*
 // of them (belong 0 < e), so the winner is the first eligible minimum if it is < 2, else tuple eid 0.
 __global__ __launch_bounds__(kThreads) void dc_assign_reduce_kernel(const double* __restrict__ part_add,
                                                                     const int32_t* __restrict__ part_pos, int nchunks,
-                                                                    int64_t ldq, int Q, const int32_t* __restrict__ vslots,
-                                                                    int32_t* __restrict__ cluster_id)
+                                                                    int64_t ldq, int Q, int32_t* __restrict__ cluster_id)
 {
     const int q = blockIdx.x * kThreads + threadIdx.x;
     if (q >= Q) return;
@@ -101,23 +102,45 @@ __global__ __launch_bounds__(kThreads) void dc_assign_reduce_kernel(const double
     int bpos = 0x7fffffff;
     for (int c = 0; c < nchunks; ++c) {
         const double a = part_add[(int64_t)c * ldq + q];
-        if (a < best) { best = a; bpos = part_pos[(int64_t)c * ldq + q]; }
+        const int sl = part_pos[(int64_t)c * ldq + q];
+        if (a < best || (a == best && sl < bpos)) { best = a; bpos = sl; }
     }
-    cluster_id[q] = (best < 2.0) ? vslots[bpos] : 0;
+    cluster_id[q] = (best < 2.0) ? bpos : 0;
 }
 
 int dc_table_build(PlaceBuffers& p, int64_t B, DcTable& t, hipStream_t s)
 {
     dc_table_free(t);
     const int64_t lim = 4 * B - 4;
-    std::vector<int32_t> hb((size_t)lim), he((size_t)lim);
+    std::vector<int32_t> hb((size_t)lim), he((size_t)lim), hn((size_t)lim), hh((size_t)(2 * p.N));
     DPR_HIP(hipMemcpyAsync(hb.data(), p.belong, sizeof(int32_t) * (size_t)lim, hipMemcpyDeviceToHost, s));
     DPR_HIP(hipMemcpyAsync(he.data(), p.e, sizeof(int32_t) * (size_t)lim, hipMemcpyDeviceToHost, s));
+    DPR_HIP(hipMemcpyAsync(hn.data(), p.nxt, sizeof(int32_t) * (size_t)lim, hipMemcpyDeviceToHost, s));
+    DPR_HIP(hipMemcpyAsync(hh.data(), p.head, sizeof(int32_t) * (size_t)(2 * p.N), hipMemcpyDeviceToHost, s));
     DPR_HIP(hipStreamSynchronize(s));
+    // eligible slots (belong >= e) in TREE order (depth-first from node N): edges that are neighbours in
+    // the backbone share most of their closest leaves, so a scan block's 256 edges touch a few hundred
+    // distance rows instead of ~2500 and they stay in L2.  The minimum is order-independent (ties by slot).
     std::vector<int32_t> vs;
     vs.reserve((size_t)lim / 2 + 1);
-    for (int64_t i = 0; i < lim; ++i)
-        if (hb[(size_t)i] >= he[(size_t)i]) vs.push_back((int32_t)i);
+    {
+        std::vector<std::pair<int32_t, int32_t>> st;   // (node, slot we came through or -1)
+        st.emplace_back((int32_t)p.N, -1);
+        while (!st.empty()) {
+            const auto [node, via] = st.back();
+            st.pop_back();
+            for (int32_t i = hh[(size_t)node]; i != -1; i = hn[(size_t)i]) {
+                if (via >= 0 && he[(size_t)i] == hb[(size_t)via]) continue;      // the edge back to where we came from
+                // undirected edge {node, e[i]}: its eligible direction is slot i or its reverse
+                const int32_t to = he[(size_t)i];
+                int32_t r = hh[(size_t)to];
+                while (r != -1 && he[(size_t)r] != node) r = hn[(size_t)r];
+                vs.push_back(hb[(size_t)i] >= he[(size_t)i] ? i : r);
+                st.emplace_back(to, i);
+            }
+        }
+    }
+    if ((int64_t)vs.size() != lim / 2) { set_error("divide-and-conquer: backbone is not a tree over its slots"); return DPR_ERR_STATE; }
     t.nv = (int)vs.size();
     if (t.nv == 0) { set_error("divide-and-conquer: backbone has no eligible edge"); return DPR_ERR_STATE; }
     DPR_HIP(hipMalloc(&t.vslots, sizeof(int32_t) * vs.size()));
@@ -155,10 +178,10 @@ int dc_assign(DcTable& t, const double* dT, int64_t ldq, int Q, int32_t* d_clust
     // edge chunks are the fast grid index: the blocks in flight share few query groups, whose
     // distance columns then stay in L2 / Infinity Cache while all chunks sweep them
     dim3 grid((unsigned)nchunks, (unsigned)((Q + kThreads - 1) / kThreads));
-    hipLaunchKernelGGL(dc_assign_scan_kernel, grid, dim3(kThreads), 0, s, t.et_cid, t.et_cdis, t.et_len, t.nv, dT, ldq, Q,
+    hipLaunchKernelGGL(dc_assign_scan_kernel, grid, dim3(kThreads), 0, s, t.et_cid, t.et_cdis, t.et_len, t.vslots, t.nv, dT, ldq, Q,
                        t.part_add, t.part_pos);
     hipLaunchKernelGGL(dc_assign_reduce_kernel, dim3((unsigned)((Q + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
-                       t.part_add, t.part_pos, nchunks, ldq, Q, t.vslots, d_cluster_id);
+                       t.part_add, t.part_pos, nchunks, ldq, Q, d_cluster_id);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
