@@ -213,7 +213,7 @@ struct PlaceBuffers {
     int64_t N = 0;   // tips the arrays are sized for; internal node ids start at N
     int64_t M = 0;   // tips of the edge scan's slot range (4M-4 slots): N, or the backbone size in DC mode
     int32_t *head = nullptr, *e = nullptr, *nxt = nullptr, *belong = nullptr, *rev = nullptr, *cid = nullptr;
-    int32_t* adj = nullptr;      // [6N] up to three slots per node (-1 none; -2,-2,-2: degree > 3, walk the list)
+    int32_t* cont = nullptr;     // [16N] per slot u->v: the (up to two) slots leaving v other than v->u (-1 none; -2: v has degree > 3, walk its list)
     double *len = nullptr, *cdis = nullptr;
     int32_t *q_id = nullptr, *q_from = nullptr;
     double* q_dis = nullptr;

@@ -65,68 +65,54 @@ __device__ __forceinline__ void list_insert(double* cdis, int32_t* cid, int slot
     }
 }
 
-// updateClosestNodes, one wave: frontier entries l..r processed 64 at a time.  Per round a lane makes
-// three dependent memory hops (queue entry -> the node's slot triple adj[] -> everything about those
-// slots: target, length, both 5-entry lists, all loads in flight together) instead of walking the
-// head/nxt list with one hop per field.  adj[3*node] == -2 marks a node of degree > 3 (possible only in
-// an imported backbone), which falls back to the list walk.
-__device__ __forceinline__ void closest_update_wave(const PlaceBuffers& p, int x)
+// updateClosestNodes, one wave: frontier entries l..r processed 64 at a time.  The frontier holds SLOTS:
+// reaching slot i = (u -> v) with the distance d of u inserts the new leaf into list[i]; if it entered, the
+// slots leaving v other than the reverse of i (cont[2i], cont[2i+1]; write-once except at a split) follow
+// with d + len[i].  That is the reference's node BFS with the adjacency walk folded into the queue entry,
+// so a round costs two dependent memory hops (queue entry -> everything about the slot, all loads in flight
+// together).  cont[2i] == -2 marks a target node of degree > 3 (possible only in an imported backbone),
+// which falls back to walking that node's list.
+__device__ __forceinline__ void closest_update_wave(const PlaceBuffers& p, int x, int start_slot)
 {
     const int lane = threadIdx.x & 63;
     int l = 0, r = 1;  // queue [l, r)
-    if (lane == 0) { p.q_id[0] = x; p.q_dis[0] = 0.0; p.q_from[0] = -1; }
+    if (lane == 0) { p.q_id[0] = start_slot; p.q_dis[0] = 0.0; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     while (l < r) {
         const int cnt = min(64, r - l);
-        int node = -1, fb = -1;
+        int sl = -1;
         double d = 0.0;
-        if (lane < cnt) { node = p.q_id[l + lane]; fb = p.q_from[l + lane]; d = p.q_dis[l + lane]; }
-        int s3[3] = { -1, -1, -1 };
-        if (lane < cnt) {
+        if (lane < cnt) { sl = p.q_id[l + lane]; d = p.q_dis[l + lane]; }
+        int c0 = -1, c1 = -1, nnew = 0;
+        double dn = 0.0;
+        bool walk = false;
+        if (sl >= 0) {
+            double cd[K5];
+            int ci[K5];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) s3[k] = p.adj[3 * node + k];
-        }
-        const bool walk = s3[0] == -2;
-        int en[3] = { -1, -1, -1 };
-        double ln[3] = { 0, 0, 0 };
-        int nnew = 0;
-        unsigned long long took = 0ull;
-        if (!walk) {
-            double cd[3][K5];
-            int ci[3][K5];
+            for (int j = 0; j < K5; ++j) { cd[j] = p.cdis[sl * K5 + j]; ci[j] = p.cid[sl * K5 + j]; }
+            const double ln = p.len[sl];
+            const int k0 = p.cont[2 * sl], k1 = p.cont[2 * sl + 1];
+            int j = K5;
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-                if (s3[k] >= 0) {
-                    const int sl = s3[k];
-                    en[k] = p.e[sl]; ln[k] = p.len[sl];
+            for (int t = K5 - 1; t >= 0; --t)
+                if (cd[t] > d) j = t;                  // first entry farther than d
+            if (j < K5) {
 #pragma unroll
-                    for (int j = 0; j < K5; ++j) { cd[k][j] = p.cdis[sl * K5 + j]; ci[k][j] = p.cid[sl * K5 + j]; }
+                for (int t = K5 - 1; t > 0; --t)
+                    if (t > j) { p.cdis[sl * K5 + t] = cd[t - 1]; p.cid[sl * K5 + t] = ci[t - 1]; }
+                p.cdis[sl * K5 + j] = d;
+                p.cid[sl * K5 + j] = x;
+                dn = d + ln;
+                if (k0 == -2) {                        // high-degree target: count its other slots
+                    walk = true;
+                    const int back = p.rev[sl];
+                    for (int i = p.head[p.e[sl]]; i != -1; i = p.nxt[i]) nnew += (i != back) ? 1 : 0;
+                } else {
+                    c0 = k0; c1 = k1;
+                    nnew = (c0 >= 0 ? 1 : 0) + (c1 >= 0 ? 1 : 0);
                 }
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                if (s3[k] >= 0 && en[k] != fb) {
-                    const int sl = s3[k];
-                    int j = K5;
-#pragma unroll
-                    for (int t = K5 - 1; t >= 0; --t)
-                        if (cd[k][t] > d) j = t;              // first entry farther than d
-                    if (j < K5) {
-#pragma unroll
-                        for (int t = K5 - 1; t > 0; --t)
-                            if (t > j) { p.cdis[sl * K5 + t] = cd[k][t - 1]; p.cid[sl * K5 + t] = ci[k][t - 1]; }
-                        p.cdis[sl * K5 + j] = d;
-                        p.cid[sl * K5 + j] = x;
-                        took |= 1ull << k; nnew++;
-                    }
-                }
-        } else {
-            int pos = 0;
-            for (int i = p.head[node]; i != -1; i = p.nxt[i], ++pos) {
-                if (p.e[i] == fb) continue;
-                bool ins;
-                list_insert(p.cdis, p.cid, i, x, d, ins);
-                if (ins && pos < 64) { took |= 1ull << pos; nnew++; }
             }
         }
         // append in lane order (order is irrelevant for the result, kept deterministic anyway)
@@ -140,13 +126,12 @@ __device__ __forceinline__ void closest_update_wave(const PlaceBuffers& p, int x
         if (nnew) {
             int w = r + incl - nnew;
             if (!walk) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    if ((took >> k) & 1ull) { p.q_id[w] = en[k]; p.q_dis[w] = d + ln[k]; p.q_from[w] = node; ++w; }
+                if (c0 >= 0) { p.q_id[w] = c0; p.q_dis[w] = dn; ++w; }
+                if (c1 >= 0) { p.q_id[w] = c1; p.q_dis[w] = dn; ++w; }
             } else {
-                int pos = 0;
-                for (int i = p.head[node]; i != -1; i = p.nxt[i], ++pos)
-                    if (pos < 64 && ((took >> pos) & 1ull)) { p.q_id[w] = p.e[i]; p.q_dis[w] = d + p.len[i]; p.q_from[w] = node; ++w; }
+                const int back = p.rev[sl];
+                for (int i = p.head[p.e[sl]]; i != -1; i = p.nxt[i])
+                    if (i != back) { p.q_id[w] = i; p.q_dis[w] = dn; ++w; }
             }
         }
         l += cnt;
@@ -167,26 +152,30 @@ __global__ __launch_bounds__(64) void place_initial_tree_kernel(PlaceBuffers p, 
         p.e[ec] = nv; p.len[ec] = d / 2; p.nxt[ec] = p.head[1]; p.head[1] = ec; p.belong[ec] = 1; p.rev[ec] = 3; ec++;
         p.e[ec] = 0;  p.len[ec] = d / 2; p.nxt[ec] = p.head[nv]; p.head[nv] = ec; p.belong[ec] = nv; p.rev[ec] = 0; ec++;
         p.e[ec] = 1;  p.len[ec] = d / 2; p.nxt[ec] = p.head[nv]; p.head[nv] = ec; p.belong[ec] = nv; p.rev[ec] = 1; ec++;
-        p.adj[0] = 0; p.adj[1] = -1; p.adj[2] = -1;
-        p.adj[3] = 1; p.adj[4] = -1; p.adj[5] = -1;
-        p.adj[3 * nv] = 2; p.adj[3 * nv + 1] = 3; p.adj[3 * nv + 2] = -1;
+        // continuation slots: beyond 0 -> nv lies nv -> 1, beyond 1 -> nv lies nv -> 0, leaves end the walk
+        p.cont[0] = 3; p.cont[1] = -1; p.cont[2] = 2; p.cont[3] = -1;
+        p.cont[4] = -1; p.cont[5] = -1; p.cont[6] = -1; p.cont[7] = -1;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    closest_update_wave(p, 0);
-    closest_update_wave(p, 1);
+    closest_update_wave(p, 0, 0);
+    closest_update_wave(p, 1, 1);
 }
 
-// slot triples of an imported backbone (degree > 3 -> -2: list walk)
-__global__ __launch_bounds__(kThreads) void place_build_adj_kernel(PlaceBuffers p, int64_t nodes)
+// continuation slots of an imported backbone (target node of degree > 3 -> -2: list walk)
+__global__ __launch_bounds__(kThreads) void place_build_cont_kernel(PlaceBuffers p, int64_t nslots)
 {
-    const int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (v >= nodes) return;
-    int s3[3] = { -1, -1, -1 }, cnt = 0;
-    for (int i = p.head[v]; i != -1; i = p.nxt[i], ++cnt)
-        if (cnt < 3) s3[cnt] = i;
-    if (cnt > 3) { s3[0] = -2; s3[1] = -2; s3[2] = -2; }
-    p.adj[3 * v] = s3[0]; p.adj[3 * v + 1] = s3[1]; p.adj[3 * v + 2] = s3[2];
+    const int64_t sl = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (sl >= nslots) return;
+    const int back = p.rev[sl];
+    int c[2] = { -1, -1 }, cnt = 0;
+    for (int i = p.head[p.e[sl]]; i != -1; i = p.nxt[i]) {
+        if (i == back) continue;
+        if (cnt < 2) c[cnt] = i;
+        ++cnt;
+    }
+    if (cnt > 2) { c[0] = -2; c[1] = -2; }
+    p.cont[2 * sl] = c[0]; p.cont[2 * sl + 1] = c[1];
 }
 
 // Closest lists of an imported backbone, all slots in parallel.  The reference inserts the leaves one
@@ -249,7 +238,7 @@ __global__ __launch_bounds__(kThreads) void place_lists_round_kernel(PlaceBuffer
 // closest lists of an imported backbone: leaves 0..m-1 in order (src/placement_close_k.cu:247-260)
 __global__ __launch_bounds__(64) void place_backbone_lists_kernel(PlaceBuffers p, int64_t t0, int64_t t1)
 {
-    for (int64_t t = t0; t < t1; ++t) closest_update_wave(p, (int)t);
+    for (int64_t t = t0; t < t1; ++t) closest_update_wave(p, (int)t, p.head[t]);   // a leaf has one slot
 }
 
 // Per tip two kernels: place_tip_kernel (calculateBranchLength for the live slots idx < 4*num-4 and the
@@ -358,13 +347,20 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
         }
 #pragma unroll
         for (int i = 0; i < K5; ++i) { p.cdis[ec * K5 + i] = md[i]; p.cid[ec * K5 + i] = mi[i]; }
-        // slot triples of the two new nodes (existing nodes keep theirs: a split only retargets slots)
-        p.adj[3 * middle] = ec - 3; p.adj[3 * middle + 1] = ec - 2; p.adj[3 * middle + 2] = ec;
-        p.adj[3 * outside] = ec - 1; p.adj[3 * outside + 1] = -1; p.adj[3 * outside + 2] = -1;
+        // continuation slots: the new slots towards x / y inherit what lay beyond y -> x / x -> y; xe and ye now
+        // end in `middle`; slots entering x or y from elsewhere keep theirs (slot ids do not change)
+        const int e0 = ec - 3, e1 = ec - 2, e2 = ec - 1, e3 = ec;
+        const int ox0 = p.cont[2 * xe], ox1 = p.cont[2 * xe + 1], oy0 = p.cont[2 * ye], oy1 = p.cont[2 * ye + 1];
+        p.cont[2 * e0] = oy0; p.cont[2 * e0 + 1] = oy1;
+        p.cont[2 * e1] = ox0; p.cont[2 * e1 + 1] = ox1;
+        p.cont[2 * xe] = e1; p.cont[2 * xe + 1] = e3;
+        p.cont[2 * ye] = e0; p.cont[2 * ye + 1] = e3;
+        p.cont[2 * e2] = e0; p.cont[2 * e2 + 1] = e1;
+        p.cont[2 * e3] = -1; p.cont[2 * e3 + 1] = -1;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    closest_update_wave(p, placeId);
+    closest_update_wave(p, placeId, (int)edge_count + 2);   // the new leaf's only slot: outside -> middle
 }
 
 constexpr int kTipThreads = 256;
@@ -459,12 +455,12 @@ int place_alloc(PlaceBuffers& p, int64_t N, int64_t M)
     DPR_HIP(hipMalloc(&p.belong, sizeof(int32_t) * (size_t)(8 * N)));
     DPR_HIP(hipMalloc(&p.rev, sizeof(int32_t) * (size_t)(8 * N)));
     DPR_HIP(hipMalloc(&p.len, sizeof(double) * (size_t)(8 * N)));
-    DPR_HIP(hipMalloc(&p.adj, sizeof(int32_t) * (size_t)(6 * N)));
+    DPR_HIP(hipMalloc(&p.cont, sizeof(int32_t) * (size_t)(16 * N)));
     DPR_HIP(hipMalloc(&p.cid, sizeof(int32_t) * (size_t)(40 * N)));
     DPR_HIP(hipMalloc(&p.cdis, sizeof(double) * (size_t)(40 * N)));
-    DPR_HIP(hipMalloc(&p.q_id, sizeof(int32_t) * (size_t)(2 * N + 64)));
+    DPR_HIP(hipMalloc(&p.q_id, sizeof(int32_t) * (size_t)(4 * N + 64)));      // BFS frontier: every slot at most once
     DPR_HIP(hipMalloc(&p.q_from, sizeof(int32_t) * (size_t)(2 * N + 64)));
-    DPR_HIP(hipMalloc(&p.q_dis, sizeof(double) * (size_t)(2 * N + 64)));
+    DPR_HIP(hipMalloc(&p.q_dis, sizeof(double) * (size_t)(4 * N + 64)));
     p.nparts_max = (int)((4 * N + kThreads - 1) / kThreads + 1);
     DPR_HIP(hipMalloc(&p.partials, sizeof(PlacePartial) * (size_t)p.nparts_max));
     return DPR_OK;
@@ -472,7 +468,7 @@ int place_alloc(PlaceBuffers& p, int64_t N, int64_t M)
 
 void place_free(PlaceBuffers& p)
 {
-    void* ptrs[] = { p.head, p.e, p.nxt, p.belong, p.rev, p.len, p.cid, p.cdis, p.q_id, p.q_from, p.q_dis, p.partials, p.adj };
+    void* ptrs[] = { p.head, p.e, p.nxt, p.belong, p.rev, p.len, p.cid, p.cdis, p.q_id, p.q_from, p.q_dis, p.partials, p.cont };
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     p = PlaceBuffers();
@@ -500,7 +496,7 @@ int place_import_backbone(PlaceBuffers& p, int64_t m, hipStream_t s)
     hipLaunchKernelGGL(place_init_lists_kernel, dim3((unsigned)((lim + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, lim);
     const int64_t nslots = 4 * m - 4;
     hipLaunchKernelGGL(place_pair_rev_kernel, dim3((unsigned)((nslots + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, nslots);
-    hipLaunchKernelGGL(place_build_adj_kernel, dim3((unsigned)((2 * p.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, 2 * p.N);
+    hipLaunchKernelGGL(place_build_cont_kernel, dim3((unsigned)((nslots + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, nslots);
     DPR_HIP(hipGetLastError());
     // parallel relaxation rounds (see place_lists_round_kernel), double-buffered; the flag is read every 16 rounds
     const bool serial = std::getenv("DPR_IMPORT_SERIAL") != nullptr;
