@@ -20,7 +20,7 @@ namespace dpr {
 
 constexpr int K5 = 5;
 
-struct PlacePartial { double add; int32_t idx; int32_t eid; double frac; };
+struct PlacePartial { double add; int32_t idx; int32_t eid; double frac; int32_t rev; int32_t pad; };   // rev = reverse slot of eid (-1: look it up)
 
 __global__ __launch_bounds__(kThreads) void place_init_kernel(PlaceBuffers p, int64_t lim, int64_t nodes)
 {
@@ -252,31 +252,32 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
 {
     const int lane = threadIdx.x & 63;
     double badd = __builtin_inf(), bfrac = 0;
-    int bidx = 0x7fffffff, beid = 0;
+    int bidx = 0x7fffffff, beid = 0, brev = -1;
     for (int i0 = lane; i0 < nparts; i0 += 256) {      // four independent loads in flight per lane
         PlacePartial pp[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + 64 * u;
             if (i < nparts) pp[u] = partials[i];
-            else { pp[u].add = __builtin_inf(); pp[u].idx = 0x7fffffff; pp[u].eid = 0; pp[u].frac = 0; }
+            else { pp[u].add = __builtin_inf(); pp[u].idx = 0x7fffffff; pp[u].eid = 0; pp[u].frac = 0; pp[u].rev = -1; }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (pp[u].add < badd || (pp[u].add == badd && pp[u].idx < bidx)) { badd = pp[u].add; bidx = pp[u].idx; beid = pp[u].eid; bfrac = pp[u].frac; }
+            if (pp[u].add < badd || (pp[u].add == badd && pp[u].idx < bidx)) { badd = pp[u].add; bidx = pp[u].idx; beid = pp[u].eid; bfrac = pp[u].frac; brev = pp[u].rev; }
     }
     // slots >= 4*num-4 (and < 4M-4) all carry the tuple (0,0,2): the first of them competes
     const int64_t live = 4 * num - 4, lim = 4 * p.M - 4;
     if (lane == 0 && live < lim) {
-        if (2.0 < badd || (2.0 == badd && (int)live < bidx)) { badd = 2.0; bidx = (int)live; beid = 0; bfrac = 0; }
+        if (2.0 < badd || (2.0 == badd && (int)live < bidx)) { badd = 2.0; bidx = (int)live; beid = 0; bfrac = 0; brev = -1; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const double oa = __shfl_down(badd, off, 64);
         const int oi = __shfl_down(bidx, off, 64);
         const int oe = __shfl_down(beid, off, 64);
+        const int orv = __shfl_down(brev, off, 64);
         const double of = __shfl_down(bfrac, off, 64);
-        if (oa < badd || (oa == badd && oi < bidx)) { badd = oa; bidx = oi; beid = oe; bfrac = of; }
+        if (oa < badd || (oa == badd && oi < bidx)) { badd = oa; bidx = oi; beid = oe; bfrac = of; brev = orv; }
     }
     const int eid = __shfl(beid, 0, 64);
     const double fracLen = __shfl(bfrac, 0, 64), addLen = __shfl(badd, 0, 64);
@@ -286,7 +287,7 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
         int ec = (int)edge_count;
         const int N = (int)p.N;
         const int middle = placeId + N - 1, outside = placeId;
-        const int xe = eid, ye = p.rev[eid];   // the reference finds them by walking head[x] / head[y]
+        const int xe = eid, ye = brev >= 0 ? brev : p.rev[eid];   // the reference finds them by walking head[x] / head[y]
         const int x = p.belong[eid], y = p.e[eid];
         const double originalDis = p.len[eid];
         // both lists up front (independent loads)
@@ -426,11 +427,11 @@ __global__ __launch_bounds__(kTipThreads) void place_tip_kernel(PlaceBuffers p, 
     __syncthreads();
     // the winner of the block publishes its tuple
     if (have && (int)idx == sidx[0]) {
-        PlacePartial pp; pp.add = add; pp.idx = (int)idx; pp.eid = eid; pp.frac = d1;
+        PlacePartial pp; pp.add = add; pp.idx = (int)idx; pp.eid = eid; pp.frac = d1; pp.rev = eid ? p.rev[eid] : -1; pp.pad = 0;
         partials[blockIdx.x] = pp;
     }
     if (threadIdx.x == 0 && sidx[0] == 0x7fffffff) {
-        PlacePartial pp; pp.add = __builtin_inf(); pp.idx = 0x7fffffff; pp.eid = 0; pp.frac = 0;
+        PlacePartial pp; pp.add = __builtin_inf(); pp.idx = 0x7fffffff; pp.eid = 0; pp.frac = 0; pp.rev = -1; pp.pad = 0;
         partials[blockIdx.x] = pp;
     }
 }
