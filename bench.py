@@ -27,6 +27,23 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def host_cores():
+    """Threads the CPU baselines may use: the smallest of os.cpu_count(), the affinity mask and the cgroup CPU
+    quota (a GPU box exposes 256 logical CPUs but grants 16; oversubscribed OpenMP teams run many times slower)."""
+    c = os.cpu_count() or 1
+    try:
+        c = min(c, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            c = min(c, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, c)
+
+
 def make_input(n, L, seed):
     """Seeded stand-in for `iqtree2 --alisim` (scripts/alisim.sh:14): Yule-Harding tree, JC69,
     branch lengths exponential(2e-5) clipped to [2e-6, 2e-4], no indels."""
@@ -56,7 +73,8 @@ def cpu_baseline(dip, n, budget_s=20.0):
     import psutil
     from tests import _orc
     orc = _orc.load()
-    cores = os.cpu_count() or 1
+    cores = host_cores()
+    log(f"[cpu_baseline] oracle NJ on {cores} host threads ...")
     need = n * n * 8 * 1.15
     avail = psutil.virtual_memory().available
     ns = n
@@ -97,6 +115,57 @@ def cpu_baseline(dip, n, budget_s=20.0):
                   f"(leading {ns} tips): init + first {k} iterations timed ({tk:.1f} s), "
                   f"extrapolated to all {n-2} iterations of N={n} by sum(n^2); distance stage excluded",
     }
+
+
+def cpu_baseline_rapidnj(dip, n, budget_s=20.0):
+    """Stronger CPU baseline next to the oracle's: a from-scratch RapidNJ-style exact NJ (sorted rows +
+    q_min pruning, OpenMP; oracle/rapidnj_baseline.c -- north_star names RapidNJ, which is not installed and
+    cannot be fetched).  Whole NJ run on the GPU's distance matrix when it fits the time budget (calibrated on
+    the leading 6 000 tips), else on the largest leading block that does, extrapolated with the measured
+    exponent.  Distances excluded, as for the oracle baseline."""
+    import psutil
+    from tests import _orc
+    orc = _orc.load()
+    cores = host_cores()
+    log(f"[cpu_baseline_rapidnj] RapidNJ-style NJ on {cores} host threads ...")
+
+    def block(m):
+        D = np.zeros((m, m), dtype=np.float64)
+        for i in range(m):
+            D[i, :] = dip.matrix_row(i)[:m]
+        return D
+
+    def run(D):
+        t0 = time.perf_counter()
+        r = orc.rapidnj_run(D, threads=cores)
+        dt = time.perf_counter() - t0
+        assert r["joins"] == D.shape[0] - 2
+        log(f"[cpu_baseline_rapidnj] {D.shape[0]} tips: {dt:.2f} s")
+        return dt
+
+    m0 = min(n, 3000)
+    m1 = min(n, 6000)
+    D1 = block(m1)
+    t0 = run(D1[:m0, :m0])
+    t1 = run(D1) if m1 > m0 else t0
+    expo = max(1.5, min(3.0, np.log(max(t1, 1e-3) / max(t0, 1e-3)) / np.log(m1 / m0))) if m1 > m0 else 2.0
+    est_full = t1 * (n / m1) ** expo
+    avail = psutil.virtual_memory().available
+    m = n
+    if est_full > budget_s:
+        m = int(m1 * (budget_s / max(t1, 1e-3)) ** (1.0 / expo))
+    m = min(m, int((0.4 * avail / 14.0) ** 0.5))       # matrix copy + working copy + sorted rows
+    m = max(m1, min(m, n))
+    if m > m1:
+        del D1
+        tm = run(block(m))
+    else:
+        tm = t1
+    t_full = tm * (n / m) ** expo
+    return {"value": n / t_full, "unit": "tips/s", "cores": cores, "kind": "rapidnj-style reimplementation (not the oracle)",
+            "sample": f"exact NJ with RapidNJ's sorted-row search on the same matrix, leading {m} of {n} tips in {tm:.1f} s "
+                      + ("(whole run)" if m == n else f"extrapolated by (N/m)^{expo:.2f} (exponent measured between {m0} and {m1} tips)")
+                      + "; distance stage excluded"}
 
 
 def e2e_cli(seqs, n, L):
@@ -245,8 +314,12 @@ def main():
         try:
             out["cpu_baseline"] = cpu_baseline(dip, n)
         except Exception as e:  # the baseline must never take the bench line down
-            out["cpu_baseline"] = {"value": None, "unit": "tips/s", "cores": os.cpu_count(), "kind": "port",
+            out["cpu_baseline"] = {"value": None, "unit": "tips/s", "cores": host_cores(), "kind": "port",
                                    "sample": f"failed: {e!r}"}
+        try:
+            out["cpu_baseline_rapidnj"] = cpu_baseline_rapidnj(dip, n)
+        except Exception as e:
+            out["cpu_baseline_rapidnj"] = {"value": None, "unit": "tips/s", "cores": host_cores(), "sample": f"failed: {e!r}"}
     dip.close()
     if want_e2e:
         try:

@@ -54,6 +54,9 @@ class Oracle:
         L.orc_place_exact_run.argtypes = [C.c_int64, c_f64p, C.c_int64, c_i32p, c_i32p, c_i32p, c_i32p, c_f64p,
                                           c_i32p, c_i32p, c_f64p]
         L.orc_place_exact_run.restype = C.c_int
+        L.orc_rapidnj_run.argtypes = [c_f64p, C.c_int64, C.c_int64, C.c_int, c_i32p, c_i32p, c_f64p, c_f64p,
+                                      c_i32p, c_f64p]
+        L.orc_rapidnj_run.restype = C.c_int64
         L.orc_phylip_value.argtypes = [C.c_char_p]
         L.orc_phylip_value.restype = C.c_double
 
@@ -213,6 +216,19 @@ class Oracle:
         st["trace"] = trace.reshape(N, 3)
         return st
 
+    def rapidnj_run(self, D_full, threads=0):
+        """CPU baseline (oracle/rapidnj_baseline.c): RapidNJ-style exact NJ on a full symmetric matrix.
+        Returns the join log in node ids (tips 0..N-1, join t creates node N+t)."""
+        D = np.array(D_full, dtype=np.float64, order="C", copy=True)
+        N, ld = D.shape
+        ca = np.zeros(N, np.int32); cb = np.zeros(N, np.int32)
+        la = np.zeros(N); lb = np.zeros(N)
+        last = np.zeros(2, np.int32); last_d = C.c_double()
+        joins = self.lib.orc_rapidnj_run(_p(D, c_f64p), N, ld, threads, _p(ca, c_i32p), _p(cb, c_i32p),
+                                         _p(la, c_f64p), _p(lb, c_f64p), _p(last, c_i32p), C.byref(last_d))
+        return dict(joins=joins, child_a=ca[:max(joins, 0)], child_b=cb[:max(joins, 0)], bl_a=la[:max(joins, 0)],
+                    bl_b=lb[:max(joins, 0)], last_pair=last, last_d=last_d.value)
+
     def phylip_value(self, tok: str):
         return self.lib.orc_phylip_value(tok.encode())
 
@@ -225,8 +241,8 @@ def load():
     global _LIB
     if _LIB is None:
         path = os.path.join(ORACLE_DIR, "liboracle.so")
-        src = os.path.join(ORACLE_DIR, "dipper_oracle.c")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        srcs = [os.path.join(ORACLE_DIR, f) for f in ("dipper_oracle.c", "rapidnj_baseline.c")]
+        if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in srcs):
             build()
         _LIB = Oracle(C.CDLL(path))
     return _LIB

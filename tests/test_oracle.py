@@ -213,3 +213,24 @@ def test_exact_placement_recovers_additive_tree_and_depths(orc, n):
 def test_phylip_value_is_float_rounded(orc):
     assert orc.phylip_value("0.1") == float(np.float32(0.1))
     assert orc.phylip_value("1e-3") == float(np.float32(1e-3))
+
+
+@pytest.mark.parametrize("n", [8, 200, 1500])
+def test_rapidnj_style_baseline_is_exact_nj(orc, n):
+    """oracle/rapidnj_baseline.c is only the CPU baseline bench.py times, but it must be a correct NJ: on an
+    additive matrix it recovers the tree and produces the splits of the oracle's NJ."""
+    rng = np.random.default_rng(n)
+    D = _util.random_additive_matrix(rng, n)
+    r = orc.rapidnj_run(D, threads=4)
+    assert r["joins"] == n - 2
+    names = [f"T{i}" for i in range(n)]
+    sub = {i: names[i] for i in range(n)}
+    for t in range(r["joins"]):
+        a, b = int(r["child_a"][t]), int(r["child_b"][t])
+        sub[n + t] = "(%s:%r,%s:%r)" % (sub.pop(a), float(r["bl_a"][t]), sub.pop(b), float(r["bl_b"][t]))
+    p0, p1 = int(r["last_pair"][0]), int(r["last_pair"][1])
+    nw = "(%s:%r,%s:%r);" % (sub[p0], r["last_d"] / 2, sub[p1], r["last_d"] / 2)
+    assert np.abs(_util.patristic(nw, names) - D).max() < 1e-9
+    ref = orc.nj_run(np.tril(D, -1))
+    nw2 = _util.newick_from_merges(names, ref["merge_x"], ref["merge_y"], ref["bl_x"], ref["bl_y"], ref["last_d"], fmt=repr)
+    assert _util.splits(nw, names) == _util.splits(nw2, names)
