@@ -169,7 +169,7 @@ struct PairJobs {
 
 // msa.hip
 struct MsaBuffers {
-    uint32_t* planes = nullptr;  // [3][n][W32]: valid, lo, hi bit planes, 32 bases per word
+    uint32_t* planes = nullptr;  // [4][n][W32]: X (not a base), LO, HI, LX = LO | X bit planes, 32 bases per word
     int64_t n = 0, L = 0, W32 = 0;
 };
 int msa_upload(MsaBuffers& m, const uint64_t* packed4, int64_t n, int64_t L, hipStream_t s);
