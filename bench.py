@@ -284,7 +284,12 @@ def main():
     dip.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
     _, _, _, scan_ms = dip.argmin_once(reps=args.probe_reps)
     rows_local = capi.load_library().dpr_shard_rows(n, rank, world)
-    alg_bytes = 4.0 * n * n / world + 4.0 * n   # strict lower triangle of this rank's rows + U once
+    # pruned NJ on several GPUs keeps the whole matrix on every rank (the ranks share the unit tests and scans of
+    # an iteration), so the probe streams the whole triangle; the streaming algorithm is row-sharded
+    replicated = prune is not None and world > 1
+    if replicated:
+        rows_local = n
+    alg_bytes = (4.0 * n * n if replicated else 4.0 * n * n / world) + 4.0 * n   # strict lower triangle (of this rank's rows) + U once
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, world),
@@ -303,7 +308,8 @@ def main():
         "dtype": "f64",
         "data": "synthetic (seeded Yule-Harding tree, JC69, L=%d, no indels)" % L,
         "config": {"workload": "configs[1]: %d aligned tips, -d 2 (JC69), conventional NJ" % n,
-                   "tips": n, "sites": L, "parallelism": "rows%d" % world},
+                   "tips": n, "sites": L,
+                   "parallelism": ("units%d (matrix replicated, unit tests and scans shared)" if replicated else "rows%d") % world},
         "phase_ms": {"dist": float(np.mean([p[0] for p in phase])) if phase else None,
                      "nj": float(np.mean([p[1] for p in phase])) if phase else None},
         "roofline": roofline,

@@ -101,6 +101,12 @@ def dc_virtual_ranks(w):
     return (w & 0xff) << 8
 
 
+def set_nj_virtual_shards(w):
+    """the next dist_matrix of a single-rank context emulates w unit-sharded ranks of the pruned NJ"""
+    L = load_library()
+    _chk(L, L.dpr_set_nj_virtual_shards(w))
+
+
 def set_nj_mode(mode):
     """0 = full streaming scan every iteration, 1 = exact pruned scan (default)."""
     L = load_library()

@@ -72,6 +72,7 @@ struct dpr_ctx {
     double* packed_lower = nullptr;  // MATRIX source, device
     int64_t n_input = 0;
     int have_matrix = 0;
+    bool nj_replicated = false;      // several ranks, each holding the whole matrix (unit-sharded pruned NJ)
     double dist_ms = 0, nj_ms = 0;
     dpr::DcStats dc_stats;
     double dc_ms[3] = { 0, 0, 0 };   // backbone, cluster assignment, cluster trees
@@ -81,6 +82,18 @@ using namespace dpr;
 
 // NJ algorithm on a single GPU: 1 = exact pruned scan (njp.hip, default), 0 = full streaming scan
 static int g_nj_mode = -1;
+static int g_nj_vshards = 1;   // > 1: a single-rank context emulates that many unit-sharded ranks (validation)
+
+// in-place all-gather of the block records of the unit-sharded pruned NJ
+static int njp_gather_cb(void* ctx, void* buf, size_t bytes_per_rank, hipStream_t s)
+{
+    dpr_ctx* c = static_cast<dpr_ctx*>(ctx);
+    if (g_rccl.AllGather(static_cast<char*>(buf) + (size_t)c->rank * bytes_per_rank, buf, bytes_per_rank, 1 /* ncclUint8 */, c->comm, s) != 0) {
+        set_error("ncclAllGather(block records) failed");
+        return DPR_ERR_COMM;
+    }
+    return DPR_OK;
+}
 static bool want_pruned()
 {
     if (g_nj_mode < 0) {
@@ -96,7 +109,7 @@ static const int kNcclUint8 = 1, kNcclFloat64 = 8, kNcclInt32 = 2, kNcclUint64 =
 
 static int exchange(dpr_ctx* c, ExKind kind)
 {
-    if (c->world == 1) return DPR_OK;
+    if (c->world == 1 || c->nj_replicated) return DPR_OK;
     if (c->vworld > 0) {
         for (int r = 0; r < c->vworld; ++r) {
             NjBuffers& src = c->nj[(size_t)r];
@@ -432,8 +445,13 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
         return DPR_ERR_ARG;
     }
     c->have_matrix = 0;
+    // Several real ranks + pruned NJ: every rank builds and keeps the WHOLE matrix (7.2 GB at 30 000 tips, 80 GB at
+    // 100 000) and the ranks share the per-iteration unit tests and scans (njp.hip, unit-sharded mode).  The
+    // streaming algorithm (DPR_NJ_MODE=stream) keeps the row-sharded layout.
+    const bool repl = c->world > 1 && c->vworld == 0 && want_pruned() && n >= 3;
+    c->nj_replicated = repl;
     for (size_t r = 0; r < c->nj.size(); ++r)
-        if (int rc = nj_alloc(c->nj[r], n, c->vworld > 0 ? (int)r : c->rank, c->world)) return rc;
+        if (int rc = nj_alloc(c->nj[r], n, repl ? 0 : (c->vworld > 0 ? (int)r : c->rank), repl ? 1 : c->world)) return rc;
     DPR_HIP(hipEventRecord(c->ev[0], c->stream));
     for (auto& b : c->nj) {
         if (source == DPR_SRC_MSA) {
@@ -448,14 +466,17 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
         }
         if (int rc = nj_init_sums(b, c->stream)) return rc;
     }
-    if (c->world > 1) {
+    if (c->world > 1 && !repl) {
         if (int rc = exchange(c, EX_U)) return rc;
         for (auto& b : c->nj)
             if (int rc = nj_launch_unpack_u(b, c->stream)) return rc;
     }
     for (auto& b : c->nj)
         if (int rc = nj_prepare(b, c->stream)) return rc;
-    if (c->world == 1 && want_pruned() && n >= 3) {
+    if ((c->world == 1 || repl) && want_pruned() && n >= 3) {
+        NjPruned& q = c->nj[0].pr;
+        if (repl) { q.sh_world = c->world; q.sh_rank = c->rank; q.sh_virtual = false; q.gather = njp_gather_cb; q.gather_ctx = c; }
+        else if (g_nj_vshards > 1) { q.sh_world = g_nj_vshards; q.sh_rank = 0; q.sh_virtual = true; }
         if (int rc = njp_build(c->nj[0], c->stream)) return rc;
     }
     DPR_HIP(hipEventRecord(c->ev[1], c->stream));
@@ -488,7 +509,7 @@ int64_t dpr_nj_run(dpr_ctx* c, int64_t max_iters, int32_t* merge_x, int32_t* mer
     if (max_iters >= 0 && max_iters < todo) todo = max_iters;
     const int64_t it0 = st.it;
     DPR_HIP(hipEventRecord(c->ev[2], c->stream));
-    if (c->world == 1 && c->nj[0].pr.active) {
+    if (c->nj[0].pr.active) {
         if (int rc = njp_run(c->nj[0], it0, todo, c->stream)) return rc;
     } else {
         for (int64_t k = 0; k < todo; ++k)
@@ -557,13 +578,14 @@ int dpr_argmin_once(dpr_ctx* c, int reps, int32_t* out_i, int32_t* out_j, double
     for (auto& b : c->nj)
         if (int rc = nj_launch_select_local(b, nj_scan_grid(), c->stream)) return rc;
     if (int rc = exchange(c, EX_RECS)) return rc;
-    std::vector<NjRecord> recs((size_t)c->world);
-    DPR_HIP(hipMemcpyAsync(recs.data(), c->nj[0].recs, sizeof(NjRecord) * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
+    const int ew = c->nj_replicated ? 1 : c->world;      // ranks whose records differ
+    std::vector<NjRecord> recs((size_t)ew);
+    DPR_HIP(hipMemcpyAsync(recs.data(), c->nj[0].recs, sizeof(NjRecord) * (size_t)ew, hipMemcpyDeviceToHost, c->stream));
     DPR_HIP(hipStreamSynchronize(c->stream));
     float ms = 0;
     DPR_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
     if (out_ms) *out_ms = ms / (float)reps;
-    const int w = dpr_record_reduce(recs.data(), c->world);
+    const int w = dpr_record_reduce(recs.data(), ew);
     if (w < 0) { set_error("dpr_argmin_once: no Q candidate below 10000"); return DPR_ERR_NOCAND; }
     const NjRecord& rec = recs[(size_t)w];
     if (out_i) *out_i = (int32_t)(rec.key & 0xFFFFFFull);
@@ -572,7 +594,15 @@ int dpr_argmin_once(dpr_ctx* c, int reps, int32_t* out_i, int32_t* out_j, double
     return DPR_OK;
 }
 
-// 0 = full streaming scan every iteration, 1 = exact pruned scan (default; single GPU only)
+// validation knob: the next dpr_dist_matrix on a single-rank context sets up `w` emulated unit-sharded ranks
+int dpr_set_nj_virtual_shards(int w)
+{
+    if (w < 1 || w > 64) { set_error("dpr_set_nj_virtual_shards: 1 <= w <= 64"); return DPR_ERR_ARG; }
+    g_nj_vshards = w;
+    return DPR_OK;
+}
+
+// 0 = full streaming scan every iteration, 1 = exact pruned scan (default)
 int dpr_set_nj_mode(int mode)
 {
     if (mode != 0 && mode != 1) { set_error("dpr_set_nj_mode: mode must be 0 or 1"); return DPR_ERR_ARG; }

@@ -96,6 +96,14 @@ struct NjPruned {
     uint64_t* umin = nullptr;   // [strips][groups] order-encoded lower bound of D per unit
     int64_t nunits_alloc = 0, utot = 0;
     int64_t utot0 = 0;          // units of one full scan at the first epoch (statistics)
+    // unit-sharded mode (several GPUs, each holding the whole position-space matrix): unit ownership by
+    // (strip * G16 + group) % sh_world; sh_virtual: all ranks are emulated in this process (validation)
+    int sh_world = 1, sh_rank = 0;
+    bool sh_virtual = false;
+    int (*gather)(void* ctx, void* buf, size_t bytes_per_rank, hipStream_t s) = nullptr;   // in-place all-gather of the block records
+    void* gather_ctx = nullptr;
+    unsigned long long* cnt_all = nullptr;   // [local ranks][2] list counters
+    int64_t list_stride = 0;
     hipGraphExec_t graph = nullptr;   // kGraphIters iterations of (test, scan, post, bounds)
     int32_t* list = nullptr;         // units selected by the prep kernel (strip << 20 | group)
     int32_t *blk_cb = nullptr, *blk_g0 = nullptr;   // prep block -> (strip, first group)

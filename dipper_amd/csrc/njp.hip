@@ -117,7 +117,8 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
                                                             const unsigned long long* __restrict__ umin,
                                                             int64_t P, const int32_t* __restrict__ blk_cb,
                                                             const int32_t* __restrict__ blk_g0, int scan_grid,
-                                                            int32_t* __restrict__ list)
+                                                            int32_t* __restrict__ list, int sh_rank, int sh_world,
+                                                            unsigned long long* __restrict__ cnt_rank, int nrec_fixed)
 {
     __shared__ double s[kThreads];
     __shared__ double sseed[kThreads / 64];
@@ -128,7 +129,10 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
     const int64_t g = (int64_t)blk_g0[blockIdx.x] + tid;
     const int64_t it = st->it, limit = st->it_limit, N = st->N;
     const int64_t px = it > 0 ? (int64_t)st->pad : -1;
-    const unsigned long long nlist_prev = it > 0 ? st->cnt_list[(it - 1) & 1] : 0ull;
+    // unit-sharded mode (sh_world > 1): this launch tests only the units it owns and appends to its own list /
+    // counter; the seed records are the gathered records of ALL ranks, nrec_fixed of them, each written
+    unsigned long long* cntp = cnt_rank ? cnt_rank : st->cnt_list;
+    const unsigned long long nlist_prev = it > 0 ? (nrec_fixed >= 0 ? (unsigned long long)nrec_fixed : cntp[(it - 1) & 1]) : 0ull;
     if (st->status != 0) return;
     const bool beyond = it >= limit;
     if (blockIdx.x == 0 && tid == 0) st->itb = it;            // never read by this kernel
@@ -142,7 +146,10 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
     for (int64_t c = tid; c < nchunk; c += kThreads) acc += xpart[c];       // chunk sums of U[px]
     const int64_t nrec = (int64_t)(nlist_prev < (unsigned long long)scan_grid ? nlist_prev : (unsigned long long)scan_grid);
     NjRecord cand; cand.key = ~0ull; cand.pad = 0; cand.q = 0; cand.d = 0;
-    if (!beyond && tid < nrec) cand = partials[tid];                         // seed candidates (first 256)
+    {   // seed candidates: the first 256 records, or -- gathered records of several ranks -- every (nrec/256)-th
+        const int64_t stride = nrec_fixed >= 0 && nrec >= 2 * kThreads ? nrec / kThreads : 1;
+        if (!beyond && (int64_t)tid * stride < nrec) cand = partials[(int64_t)tid * stride];
+    }
     const int64_t G16 = (P + kUR - 1) / kUR;
     const bool have = !beyond && g < G16;
     double uenc_d = PINF;
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
         if (px_in_group) rmax = fmax(rmax, urx);
     }
     bool keep = false;
-    if (have) {
+    if (have && (sh_world <= 1 || (int)(((int64_t)cb * G16 + g) % sh_world) == sh_rank)) {
         const double lb = fmin((uenc_d - rmax) - cm, (uenc_d - cm) - rmax);
         keep = (rmax > NINF) && (cm > NINF) && (lb <= bound);
     }
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
     const unsigned long long mask = __ballot(keep);
     const int lane = tid & 63;
     unsigned long long base = 0;
-    if (lane == 0 && mask) base = atomicAdd(&st->cnt_list[par], (unsigned long long)__popcll(mask));
+    if (lane == 0 && mask) base = atomicAdd(&cntp[par], (unsigned long long)__popcll(mask));
     base = __shfl(base, 0, 64);
     if (keep) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)((cb << 20) | (int)g);   // strip | group
 }
@@ -234,7 +241,8 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __rest
                                                             unsigned long long* __restrict__ umin,
                                                             int64_t P, const int32_t* __restrict__ list,
                                                             NjRecord* __restrict__ partials,
-                                                            unsigned long long* __restrict__ iterstats)
+                                                            unsigned long long* __restrict__ iterstats,
+                                                            const unsigned long long* __restrict__ cnt_rank, int write_null)
 {
     __shared__ double sq[kThreads / 64], sd[kThreads / 64];
     __shared__ uint64_t sk[kThreads / 64], sp[kThreads / 64];
@@ -245,8 +253,14 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __rest
     const int64_t it = st->itb, limit = st->it_limit;
     const int32_t first = list[blockIdx.x];
     if (it >= limit || st->status != 0) return;
-    const int64_t cnt = (int64_t)st->cnt_list[it & 1];
-    if ((int64_t)blockIdx.x >= cnt) return;
+    const int64_t cnt = (int64_t)(cnt_rank ? cnt_rank[it & 1] : st->cnt_list[it & 1]);
+    if ((int64_t)blockIdx.x >= cnt) {
+        if (write_null && tid == 0) {      // unit-sharded mode: every record of the gathered array is defined
+            NjRecord rec; rec.q = 10000.0; rec.key = ~0ull; rec.d = 0.0; rec.pad = 0ull;
+            partials[blockIdx.x] = rec;
+        }
+        return;
+    }
     const int64_t G16 = (P + kUR - 1) / kUR;
     double bq = 10000.0, bd = 0.0;  // the reference's init value
     uint64_t bk = ~0ull, bp = 0;
@@ -338,7 +352,9 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
                                                             const NjRecord* __restrict__ partials, int scan_grid,
                                                             int64_t P,
                                                             int32_t* __restrict__ log_x, int32_t* __restrict__ log_y,
-                                                            double* __restrict__ log_bx, double* __restrict__ log_by)
+                                                            double* __restrict__ log_bx, double* __restrict__ log_by,
+                                                            int nrec_fixed, unsigned long long* __restrict__ cnt_all,
+                                                            int cnt_ranks)
 {
     __shared__ double s[kThreads];
     __shared__ double sq[kThreads / 64], sdd[kThreads / 64];
@@ -350,7 +366,7 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
     const int64_t p = i < N ? (int64_t)pos_of_slot[i] : -1;
     NjRecord r0; r0.q = 10000.0; r0.key = ~0ull; r0.d = 0; r0.pad = 0;
     NjRecord mine[4] = { r0, r0, r0, r0 };
-    const unsigned long long cnt_raw = st->cnt_list[it & 1];
+    const unsigned long long cnt_raw = nrec_fixed >= 0 ? (unsigned long long)nrec_fixed : st->cnt_list[it & 1];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int idx = threadIdx.x + k * kThreads;
@@ -408,6 +424,7 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
             st->x = (int32_t)x; st->y = (int32_t)y; st->d = d; st->q = bq;
             st->n = n1; st->it = it + 1; st->pad = (int32_t)px;
             st->cnt_list[1 - par] = 0ull;   // list counter of the NEXT scan (nobody reads it in this launch)
+            for (int v = 0; v < cnt_ranks; ++v) cnt_all[2 * v + (1 - par)] = 0ull;
         }
         int64_t new_slot = i;
         if (i != x && i != y) {
@@ -485,8 +502,13 @@ static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, hipStream_t s)
         DPR_HIP(hipMemcpyAsync(q.blk_g0, hg0.data(), sizeof(int32_t) * hg0.size(), hipMemcpyHostToDevice, s));
         DPR_HIP(hipStreamSynchronize(s));   // the host vectors go out of scope
     }
-    DPR_HIP(hipMalloc(&q.list, sizeof(int32_t) * (size_t)(q.utot + kScanBlocks + 64)));
-    DPR_HIP(hipMemsetAsync(q.list, 0, sizeof(int32_t) * (size_t)(q.utot + kScanBlocks + 64), s));
+    // unit-sharded mode: one list and one counter pair per rank held here (all of them for virtual ranks)
+    const int local_ranks = q.sh_world > 1 && q.sh_virtual ? q.sh_world : 1;
+    q.list_stride = q.utot + kScanBlocks + 64;
+    DPR_HIP(hipMalloc(&q.list, sizeof(int32_t) * (size_t)(q.list_stride * local_ranks)));
+    DPR_HIP(hipMemsetAsync(q.list, 0, sizeof(int32_t) * (size_t)(q.list_stride * local_ranks), s));
+    DPR_HIP(hipMalloc(&q.cnt_all, sizeof(unsigned long long) * (size_t)(2 * local_ranks)));
+    DPR_HIP(hipMemsetAsync(q.cnt_all, 0, sizeof(unsigned long long) * (size_t)(2 * local_ranks), s));
     hipLaunchKernelGGL(njp_fill_u64_kernel, dim3(256), dim3(256), 0, s, (uint64_t*)q.umin, q.nunits_alloc,
                        enc_f64_host(-__builtin_inf()));
     DPR_HIP(hipGetLastError());
@@ -559,6 +581,7 @@ static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s)
     for (int64_t a = 0; a < n; ++a)
         if (perm[(size_t)a] == st.pad) new_px = (int32_t)a;
     NjPruned qn;
+    qn.sh_world = q.sh_world; qn.sh_rank = q.sh_rank; qn.sh_virtual = q.sh_virtual; qn.gather = q.gather; qn.gather_ctx = q.gather_ctx;
     if (int rc = njp_alloc_epoch(qn, n, b.N, s)) return rc;
     qn.utot0 = q.utot0;
     qn.iterstats = q.iterstats; q.iterstats = nullptr;
@@ -572,6 +595,12 @@ static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s)
     st.pad = new_px;
     st.cnt_list[0] = 0ull; st.cnt_list[1] = 0ull;
     DPR_HIP(hipMemcpyAsync(b.st, &st, sizeof(NjState), hipMemcpyHostToDevice, s));
+    if (q.sh_world > 1) {   // gathered records refer to old positions: make them null (key = ~0)
+        std::vector<NjRecord> nul((size_t)kScanBlocks);
+        for (auto& r : nul) { r.q = 10000.0; r.key = ~0ull; r.d = 0.0; r.pad = 0ull; }
+        DPR_HIP(hipMemcpyAsync(b.partials, nul.data(), sizeof(NjRecord) * nul.size(), hipMemcpyHostToDevice, s));
+        DPR_HIP(hipStreamSynchronize(s));
+    }
     DPR_HIP(hipStreamSynchronize(s));
     njp_free(q);
     q = qn;
@@ -582,17 +611,39 @@ static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s)
 void njp_free(NjPruned& q)
 {
     if (q.graph) { (void)hipGraphExecDestroy(q.graph); q.graph = nullptr; }
-    void* ptrs[] = { q.D, q.U, q.Ur, q.KA, q.KB, q.slot_of_pos, q.pos_of_slot, q.perm, q.umin, q.iterstats, q.list, q.blk_cb, q.blk_g0 };
+    void* ptrs[] = { q.D, q.U, q.Ur, q.KA, q.KB, q.slot_of_pos, q.pos_of_slot, q.perm, q.umin, q.iterstats, q.list, q.blk_cb, q.blk_g0, q.cnt_all };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     q = NjPruned();
 }
 
-static int njp_launch_prep(NjBuffers& b, hipStream_t s)
+// unit-sharded mode: records per rank and in total
+static int njp_grid_rank(const NjPruned& q) { return q.sh_world > 1 ? (g_njp_grid / q.sh_world > 0 ? g_njp_grid / q.sh_world : 1) : g_njp_grid; }
+static int njp_grid_total(const NjPruned& q) { return q.sh_world > 1 ? njp_grid_rank(q) * q.sh_world : g_njp_grid; }
+
+// prep of rank v (its own units, list and counters); v is ignored outside the unit-sharded mode
+static int njp_launch_prep(NjBuffers& b, hipStream_t s, int v = 0)
 {
     NjPruned& q = b.pr;
+    const bool sh = q.sh_world > 1;
+    const int slot = sh && q.sh_virtual ? v : 0;             // local storage index of this rank
     hipLaunchKernelGGL(njp_prep_kernel, dim3((unsigned)q.nprep), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.U, q.Ur, q.Ur,
-                       b.xpart, b.partials, (const unsigned long long*)q.umin, q.P, q.blk_cb, q.blk_g0, g_njp_grid, q.list);
+                       b.xpart, b.partials, (const unsigned long long*)q.umin, q.P, q.blk_cb, q.blk_g0, njp_grid_total(q),
+                       q.list + (int64_t)slot * q.list_stride, sh ? v : 0, sh ? q.sh_world : 1,
+                       sh ? q.cnt_all + 2 * slot : (unsigned long long*)nullptr, sh ? njp_grid_total(q) : -1);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+static int njp_launch_post(NjBuffers& b, hipStream_t s)
+{
+    NjPruned& q = b.pr;
+    const bool sh = q.sh_world > 1;
+    const unsigned pgrid = (unsigned)((b.N + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(njp_post_kernel, dim3(pgrid), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.U, q.Ur, q.KA, q.KB,
+                       q.slot_of_pos, q.pos_of_slot, (unsigned long long*)q.umin, b.xpart, b.partials, njp_grid_total(q), q.P,
+                       b.log_x, b.log_y, b.log_bx, b.log_by, sh ? njp_grid_total(q) : -1,
+                       sh ? q.cnt_all : (unsigned long long*)nullptr, sh ? (q.sh_virtual ? q.sh_world : 1) : 0);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
@@ -601,13 +652,35 @@ static int njp_launch_prep(NjBuffers& b, hipStream_t s)
 static int njp_enqueue_iteration(NjBuffers& b, hipStream_t s)
 {
     NjPruned& q = b.pr;
-    hipLaunchKernelGGL(njp_scan_kernel, dim3(g_njp_grid), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.Ur, q.KA, q.KB,
-                       (unsigned long long*)q.umin, q.P, q.list, b.partials, (unsigned long long*)q.iterstats);
-    const unsigned pgrid = (unsigned)((b.N + kThreads - 1) / kThreads);
-    hipLaunchKernelGGL(njp_post_kernel, dim3(pgrid), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.U, q.Ur, q.KA, q.KB,
-                       q.slot_of_pos, q.pos_of_slot, (unsigned long long*)q.umin, b.xpart, b.partials, g_njp_grid, q.P,
-                       b.log_x, b.log_y, b.log_bx, b.log_by);
-    return njp_launch_prep(b, s);
+    if (q.sh_world <= 1) {
+        hipLaunchKernelGGL(njp_scan_kernel, dim3(g_njp_grid), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.Ur, q.KA, q.KB,
+                           (unsigned long long*)q.umin, q.P, q.list, b.partials, (unsigned long long*)q.iterstats,
+                           (const unsigned long long*)nullptr, 0);
+        if (int rc = njp_launch_post(b, s)) return rc;
+        return njp_launch_prep(b, s);
+    }
+    // Unit-sharded mode (every rank holds the whole position-space matrix): a unit belongs to rank
+    // (strip * G16 + group) mod world for good.  Each rank tests and scans only its own units -- a unit that
+    // holds the winner always survives its owner's test, whatever the other ranks' bounds are -- so the unit
+    // bounds stay private to their owner and ONE small all-gather per iteration (the block records) is the
+    // only exchange; select + merge + update run replicated.
+    const int gr = njp_grid_rank(q);
+    const int v0 = q.sh_virtual ? 0 : q.sh_rank, v1 = q.sh_virtual ? q.sh_world : q.sh_rank + 1;
+    for (int v = v0; v < v1; ++v) {
+        const int slot = q.sh_virtual ? v : 0;
+        hipLaunchKernelGGL(njp_scan_kernel, dim3((unsigned)gr), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.Ur, q.KA, q.KB,
+                           (unsigned long long*)q.umin, q.P, q.list + (int64_t)slot * q.list_stride, b.partials + (int64_t)v * gr,
+                           (unsigned long long*)q.iterstats, (const unsigned long long*)(q.cnt_all + 2 * slot), 1);
+    }
+    DPR_HIP(hipGetLastError());
+    if (!q.sh_virtual) {
+        if (!q.gather) { set_error("njp: unit-sharded mode without a gather callback"); return DPR_ERR_STATE; }
+        if (int rc = q.gather(q.gather_ctx, b.partials, sizeof(NjRecord) * (size_t)gr, s)) return rc;
+    }
+    if (int rc = njp_launch_post(b, s)) return rc;
+    for (int v = v0; v < v1; ++v)
+        if (int rc = njp_launch_prep(b, s, v)) return rc;
+    return DPR_OK;
 }
 
 // enqueue `todo` iterations starting at iteration it0.  The four kernels of an iteration take no
@@ -622,8 +695,13 @@ static int njp_run_segment(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t 
     DPR_HIP(hipMemcpyAsync(&b.st->it_limit, &limit, sizeof(int64_t), hipMemcpyHostToDevice, s));
     DPR_HIP(hipStreamSynchronize(s));   // `limit` is a stack variable
     if (todo <= 0) return DPR_OK;
-    if (int rc = njp_launch_prep(b, s)) return rc;   // list + bound for iteration it0
-    const bool use_graph = todo >= kGraphIters && !std::getenv("DPR_NJ_NOGRAPH");
+    {   // list + bound for iteration it0
+        const int v0 = q.sh_world > 1 && !q.sh_virtual ? q.sh_rank : 0;
+        const int v1 = q.sh_world > 1 ? (q.sh_virtual ? q.sh_world : q.sh_rank + 1) : 1;
+        for (int v = v0; v < v1; ++v)
+            if (int rc = njp_launch_prep(b, s, v)) return rc;
+    }
+    const bool use_graph = q.sh_world <= 1 && todo >= kGraphIters && !std::getenv("DPR_NJ_NOGRAPH");
     if (use_graph && !q.graph) {
         hipGraph_t g = nullptr;
         DPR_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));

@@ -135,6 +135,11 @@ int dpr_argmin_once(dpr_ctx *ctx, int reps, int32_t *out_i, int32_t *out_j, doub
  * iteration.  Both produce the same merge log bit for bit (tests run both); takes effect at the next
  * dpr_dist_matrix.  Environment DPR_NJ_MODE=stream selects 0 for the CLI. */
 int dpr_set_nj_mode(int mode);
+/* Several GPUs + pruned scan: every rank keeps the whole matrix and the ranks share the per-iteration unit tests
+ * and scans (a unit belongs to one rank for good; one small all-gather of block records per iteration).
+ * dpr_set_nj_virtual_shards(w) makes the next dpr_dist_matrix of a single-rank context emulate w such ranks
+ * (validation on one GPU; same merge log bit for bit). */
+int dpr_set_nj_virtual_shards(int w);
 /* pruned path: 16x512 units scanned since dpr_dist_matrix, and units of one full scan */
 int dpr_get_prune_stats(dpr_ctx *ctx, uint64_t *units_scanned, uint64_t *units_per_full_scan);
 

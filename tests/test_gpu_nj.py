@@ -170,3 +170,34 @@ def test_nj_epoch_rebuilds(orc, monkeypatch, n, kind):
         assert np.array_equal(M, part["D"][:na, :na])
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_nj_unit_sharded_virtual_ranks(orc, monkeypatch, world):
+    """multi-GPU pruned NJ (every rank holds the matrix, the unit tests / scans are shared, one all-gather of
+    block records per iteration) emulated on one GPU: each emulated rank tests and scans only the units it
+    owns with its own list and counters; same merge log as the oracle, with epoch rebuilds in between."""
+    import dipper_amd
+    from dipper_amd import capi
+    monkeypatch.setenv("DPR_NJ_EPOCH_MIN", "200")
+    capi.set_nj_mode(1)
+    capi.set_nj_virtual_shards(world)
+    try:
+        for n, kind in ((900, "additive"), (777, "ties"), (40, "additive")):
+            rng = np.random.default_rng(n + world)
+            D = _util.random_additive_matrix(rng, n, zero_frac=0.4 if kind == "ties" else 0.0)
+            if kind == "ties":
+                D = np.round(D, 1)
+            d = dipper_amd.Dipper(0)
+            try:
+                d.set_matrix_full(D)
+                d.dist_matrix(capi.SRC_MATRIX)
+                ref = orc.nj_run(np.tril(D, -1))
+                parts = [d.nj_run(max_iters=k) for k in (n // 3, 7, -1)]
+                for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
+                    assert np.array_equal(np.concatenate([p[key] for p in parts]), ref[key]), (key, n, kind)
+                assert parts[-1]["last_d"] == ref["last_d"]
+            finally:
+                d.close()
+    finally:
+        capi.set_nj_virtual_shards(1)
