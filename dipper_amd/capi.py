@@ -86,6 +86,7 @@ def load_library():
     L.dpr_get_exact_state.argtypes = [C.c_void_p, c_i32p, c_i32p]
     L.dpr_dc_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int,
                              c_i32p, c_i32p, c_i32p, c_i32p, c_f64p, c_i32p]
+    L.dpr_njp_unit_owner.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int]
     L.dpr_dc_query_share.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.dpr_dc_deal_clusters.argtypes = [C.POINTER(C.c_int64), C.c_int64, C.c_int, c_i32p]
     L.dpr_get_dc_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), c_f64p]

@@ -594,6 +594,8 @@ int dpr_argmin_once(dpr_ctx* c, int reps, int32_t* out_i, int32_t* out_j, double
     return DPR_OK;
 }
 
+int dpr_njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world) { return njp_unit_owner(strip, group, P, world); }
+
 // validation knob: the next dpr_dist_matrix on a single-rank context sets up `w` emulated unit-sharded ranks
 int dpr_set_nj_virtual_shards(int w)
 {

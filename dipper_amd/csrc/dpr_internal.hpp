@@ -155,6 +155,7 @@ int nj_launch_finish(NjBuffers& b, int64_t n, int64_t it, hipStream_t s);       
 int njp_build(NjBuffers& b, hipStream_t s);   // permute the tip-order matrix by ascending row sum; frees b.D
 void njp_free(NjPruned& q);
 int njp_scan_grid();
+int njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world);
 int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s);   // enqueue `todo` iterations (hipGraph replays)
 
 // Divide-and-conquer cluster distances (dc.hip builds the jobs; msa.hip / mash.hip run them).

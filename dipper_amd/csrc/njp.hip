@@ -59,6 +59,14 @@ __host__ __device__ inline int64_t unit_total(int64_t P)
     return S > 0 ? unit_prefix(S, G16) : 0;
 }
 
+// unit ownership of the unit-sharded mode (also exported for the CPU tests of the N > 1 logic)
+int njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world)
+{
+    const int64_t G16 = (P + kUR - 1) / kUR;
+    if (strip < 0 || group < 0 || group >= G16 || group < 32 * strip || strip * kTileCols >= P - 1 || world < 1) return -1;
+    return (int)((strip * G16 + group) % world);
+}
+
 // ------------------------------------------------------------------------------------------------
 // epoch build: B[a][b] = A[perm[a]][perm[b]]
 // ------------------------------------------------------------------------------------------------

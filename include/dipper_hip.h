@@ -140,6 +140,9 @@ int dpr_set_nj_mode(int mode);
  * dpr_set_nj_virtual_shards(w) makes the next dpr_dist_matrix of a single-rank context emulate w such ranks
  * (validation on one GPU; same merge log bit for bit). */
 int dpr_set_nj_virtual_shards(int w);
+/* host-only: owner of the 16-row x 512-column unit (strip = column block, group = row group) among `world` ranks
+ * when the position space has P positions; -1 if the unit holds no pair of the strict lower triangle */
+int dpr_njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world);
 /* pruned path: 16x512 units scanned since dpr_dist_matrix, and units of one full scan */
 int dpr_get_prune_stats(dpr_ctx *ctx, uint64_t *units_scanned, uint64_t *units_per_full_scan);
 
