@@ -40,6 +40,74 @@ __device__ __forceinline__ void block_best(double& bq, uint64_t& bk, double* sq,
     }
 }
 
+// ---- wave-wide reductions on the DPP path --------------------------------------------------------
+// The latency-bound kernels of the pruned path reduce a handful of values per launch; a butterfly of
+// __shfl (ds_bpermute, ~100+ cycles per dependent step) was a visible part of their critical path.
+// Here: two quad permutes + two mirrors (VALU latency) give every lane its row-of-16 result, four
+// v_readlane combine the rows.  Results are wave-uniform.
+template <int CTRL> __device__ __forceinline__ uint64_t dpp_u64(uint64_t x)
+{
+    const int lo = (int)(uint32_t)x, hi = (int)(uint32_t)(x >> 32);
+    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return ((uint64_t)(uint32_t)hi2 << 32) | (uint64_t)(uint32_t)lo2;
+}
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double x)
+{
+    return __longlong_as_double((long long)dpp_u64<CTRL>((uint64_t)__double_as_longlong(x)));
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t x, int lane)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double readlane_f64(double x, int lane)
+{
+    return __longlong_as_double((long long)readlane_u64((uint64_t)__double_as_longlong(x), lane));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+
+// minimum / maximum over the wave, NaN operands ignored (fmin / fmax semantics)
+__device__ __forceinline__ double wave_fmin(double x)
+{
+    x = fmin(x, dpp_f64<kDppXor1>(x));
+    x = fmin(x, dpp_f64<kDppXor2>(x));
+    x = fmin(x, dpp_f64<kDppHalfMirror>(x));
+    x = fmin(x, dpp_f64<kDppMirror>(x));
+    return fmin(fmin(readlane_f64(x, 0), readlane_f64(x, 16)), fmin(readlane_f64(x, 32), readlane_f64(x, 48)));
+}
+__device__ __forceinline__ double wave_fmax(double x)
+{
+    x = fmax(x, dpp_f64<kDppXor1>(x));
+    x = fmax(x, dpp_f64<kDppXor2>(x));
+    x = fmax(x, dpp_f64<kDppHalfMirror>(x));
+    x = fmax(x, dpp_f64<kDppMirror>(x));
+    return fmax(fmax(readlane_f64(x, 0), readlane_f64(x, 16)), fmax(readlane_f64(x, 32), readlane_f64(x, 48)));
+}
+__device__ __forceinline__ uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint64_t wave_umin64(uint64_t x)
+{
+    x = umin64(x, dpp_u64<kDppXor1>(x));
+    x = umin64(x, dpp_u64<kDppXor2>(x));
+    x = umin64(x, dpp_u64<kDppHalfMirror>(x));
+    x = umin64(x, dpp_u64<kDppMirror>(x));
+    return umin64(umin64(readlane_u64(x, 0), readlane_u64(x, 16)), umin64(readlane_u64(x, 32), readlane_u64(x, 48)));
+}
+
+// wave-wide winner of (q, key, positions, d) under "smaller q, then smaller key" (the lanes' q are never NaN:
+// they start at the reference's 10000 and only take smaller values); result wave-uniform
+__device__ __forceinline__ void wave_best4(double& bq, uint64_t& bk, uint64_t& bp, double& bd)
+{
+    const double wq = wave_fmin(bq);
+    const uint64_t wk = wave_umin64(bq == wq ? bk : ~0ull);
+    const unsigned long long own = __builtin_amdgcn_ballot_w64((bq == wq) & (bk == wk));
+    const int src = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(own));   // own != 0: the lane holding wq has bk >= wk
+    bp = readlane_u64(bp, src);
+    bd = readlane_f64(bd, src);
+    bq = wq; bk = wk;
+}
+
 // pairwise tree over 256 values, c[t] += c[t+s] for s = 128..1 (canonical order)
 __device__ __forceinline__ double block_tree256(double v, double* s)
 {

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
                                                             double* __restrict__ Ur_w, const double* __restrict__ Ur,
                                                             const double* __restrict__ xpart,
                                                             const NjRecord* __restrict__ partials,
-                                                            const unsigned long long* __restrict__ umin,
+                                                            unsigned long long* umin,
                                                             int64_t P, const int32_t* __restrict__ blk_cb,
                                                             const int32_t* __restrict__ blk_g0, int scan_grid,
                                                             int32_t* __restrict__ list, int sh_rank, int sh_world,
@@ -131,8 +131,13 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
     __shared__ double s[kThreads];
     __shared__ double sseed[kThreads / 64];
     __shared__ double scm[kThreads / 64];
+    __shared__ double snew[kThreads / 64];
     const int tid = threadIdx.x;
-    // hop 1: the state line and this block's (strip, first group): blocks never span strips
+    // hop 1: the state line, this block's (strip, first group) -- blocks never span strips -- and, speculatively,
+    // this thread's seed record (its index depends on the launch arguments only)
+    const int64_t nrec_arg = nrec_fixed >= 0 ? (int64_t)(nrec_fixed < scan_grid ? nrec_fixed : scan_grid) : -1;
+    const int64_t stride = nrec_arg >= 2 * kThreads ? nrec_arg / kThreads : 1;   // gathered records of several ranks: every (nrec/256)-th
+    NjRecord cand = partials[(int64_t)tid * stride];
     const int cb = blk_cb[blockIdx.x];
     const int64_t g = (int64_t)blk_g0[blockIdx.x] + tid;
     const int64_t it = st->it, limit = st->it_limit, N = st->N;
@@ -148,20 +153,24 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
     const int64_t n = N - it;
     const double NINF = -__builtin_inf(), PINF = __builtin_inf();
 
-    // hop 2: every independent load of this block
+    // hop 2: every other load of this block
     const int64_t nchunk = it > 0 ? (n + 1 + kThreads - 1) / kThreads : 0;
     double acc = 0.0;
     for (int64_t c = tid; c < nchunk; c += kThreads) acc += xpart[c];       // chunk sums of U[px]
     const int64_t nrec = (int64_t)(nlist_prev < (unsigned long long)scan_grid ? nlist_prev : (unsigned long long)scan_grid);
-    NjRecord cand; cand.key = ~0ull; cand.pad = 0; cand.q = 0; cand.d = 0;
-    {   // seed candidates: the first 256 records, or -- gathered records of several ranks -- every (nrec/256)-th
-        const int64_t stride = nrec_fixed >= 0 && nrec >= 2 * kThreads ? nrec / kThreads : 1;
-        if (!beyond && (int64_t)tid * stride < nrec) cand = partials[(int64_t)tid * stride];
-    }
+    if (beyond || (int64_t)tid * stride >= nrec) cand.key = ~0ull;   // stale or absent record
     const int64_t G16 = (P + kUR - 1) / kUR;
     const bool have = !beyond && g < G16;
+    // The new node's row (written by the post kernel) may lower the bound of the units it crosses: the units
+    // (strip of px, groups behind px) through their 16 rows, the units (strips before px, group of px) through
+    // their 512 columns.  The lane that tests a unit folds that minimum into umin itself (no atomics in post).
+    const bool px_strip = px >= 0 && px / kTileCols == cb;                       // block-uniform
+    const int64_t gx = px >= 0 ? px / kUR : -1;
+    const bool gx_here = px >= 0 && gx >= (int64_t)blk_g0[blockIdx.x] && gx < (int64_t)blk_g0[blockIdx.x] + kThreads;   // block-uniform
+    const double* __restrict__ rowx = D + (px >= 0 ? px : 0) * ld;
     double uenc_d = PINF;
     double rmax = NINF; bool px_in_group = false;
+    double newmin = PINF;
     if (have) {
         uenc_d = dec_f64(umin[(int64_t)cb * G16 + g]);
         const int64_t a0 = g * kUR;
@@ -169,29 +178,33 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
         for (int r = 0; r < kUR; ++r) {
             const int64_t p = a0 + r;
             if (p == px) px_in_group = true;
-            else if (p < P) { const double v = Ur[p]; if (v == v) rmax = fmax(rmax, v); }
+            else if (p < P) {
+                const double v = Ur[p];
+                const double dv = px_strip ? rowx[p] : PINF;      // block-uniform; both loads issue together
+                if (v == v) { rmax = fmax(rmax, v); if (p > px) newmin = fmin(newmin, dv); }
+            }
         }
     }
-    // column maximum of this block's strip, px excluded for now
-    double cm_part = NINF;
+    // column maximum of this block's strip, px excluded for now; minimum of the new row over the strip's live columns
+    double cm_part = NINF, colmin = PINF;
     if (!beyond)
         for (int e = tid; e < kTileCols; e += kThreads) {
             const int64_t p = (int64_t)cb * kTileCols + e;
-            if (p < P && p != px) { const double v = Ur[p]; if (v == v) cm_part = fmax(cm_part, v); }
+            if (p < P && p != px) {
+                const double v = Ur[p];
+                const double dv = gx_here ? rowx[p] : PINF;
+                if (v == v) { cm_part = fmax(cm_part, v); if (p < px) colmin = fmin(colmin, dv); }
+            }
         }
-    // hop 3: candidate gathers
+    // candidate gathers (same hop: the records were loaded up front)
     double qc = PINF;
-    bool cand_px = false;
-    double cd = 0, cua = 0, cub = 0;
     if (cand.key != ~0ull) {
         const int64_t pi = (int64_t)(cand.pad & 0xffffffffull), pj = (int64_t)(cand.pad >> 32);
         const int64_t pa = pi > pj ? pi : pj, pb = pi > pj ? pj : pi;
-        if (pa < P && pb < pa) {
-            cd = D[pa * ld + pb];
-            cua = pa == px ? 0.0 : Ur[pa];
-            cub = pb == px ? 0.0 : Ur[pb];
-            cand_px = (pa == px) || (pb == px);
-            if (!cand_px && cua == cua && cub == cub) qc = fmin((cd - cua) - cub, (cd - cub) - cua);
+        if (pa < P && pb < pa && pa != px && pb != px) {
+            const double cd = D[pa * ld + pb];
+            const double cua = Ur[pa], cub = Ur[pb];
+            if (cua == cua && cub == cub) qc = fmin((cd - cua) - cub, (cd - cub) - cua);
         }
     }
 
@@ -203,22 +216,26 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
         if (blockIdx.x == 0 && tid == 0) { U_w[px] = ux; Ur_w[px] = urx; }
     }
     if (beyond) return;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        qc = fmin(qc, __shfl_xor(qc, off, 64));
-        cm_part = fmax(cm_part, __shfl_xor(cm_part, off, 64));
-    }
-    if ((tid & 63) == 0) { sseed[tid >> 6] = qc; scm[tid >> 6] = cm_part; }
+    qc = wave_fmin(qc);
+    cm_part = wave_fmax(cm_part);
+    if (gx_here) colmin = wave_fmin(colmin);
+    if ((tid & 63) == 0) { sseed[tid >> 6] = qc; scm[tid >> 6] = cm_part; snew[tid >> 6] = colmin; }
     __syncthreads();
     const double bound = fmin(fmin(sseed[0], sseed[1]), fmin(sseed[2], sseed[3]));
     double cm = fmax(fmax(scm[0], scm[1]), fmax(scm[2], scm[3]));
+    if (gx_here && g == gx) newmin = fmin(newmin, fmin(fmin(snew[0], snew[1]), fmin(snew[2], snew[3])));   // the unit (this strip, group of px)
     // the new node's Ur joins the maxima of its group and its strip
     if (px >= 0) {
-        if (px / kTileCols == cb) cm = fmax(cm, urx);
+        if (px_strip) cm = fmax(cm, urx);
         if (px_in_group) rmax = fmax(rmax, urx);
     }
+    const bool mine = have && (sh_world <= 1 || (int)(((int64_t)cb * G16 + g) % sh_world) == sh_rank);
     bool keep = false;
-    if (have && (sh_world <= 1 || (int)(((int64_t)cb * G16 + g) % sh_world) == sh_rank)) {
+    if (mine) {
+        if (newmin < uenc_d) {                     // persist the lowered bound (this lane is the unit's only writer here)
+            uenc_d = newmin;
+            umin[(int64_t)cb * G16 + g] = enc_f64(newmin);
+        }
         const double lb = fmin((uenc_d - rmax) - cm, (uenc_d - cm) - rmax);
         keep = (rmax > NINF) && (cm > NINF) && (lb <= bound);
     }
@@ -270,6 +287,11 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __rest
         return;
     }
     const int64_t G16 = (P + kUR - 1) / kUR;
+    // Two passes per unit instead of a (q, key, positions, d) compare-and-select per candidate (64 candidates
+    // per lane and unit, ~20 VALU instructions each, were 2 us of this kernel's critical path): pass 1 computes
+    // the candidates' q and their minimum over the WAVE; pass 2 -- only when that minimum reaches the wave's
+    // best so far -- looks for the candidates equal to it (rare, wave-uniform branch) and keeps the smallest key.
+    // bq is wave-uniform; (bk, bp, bd) is this lane's best candidate AT q == bq (bk == ~0: none).
     double bq = 10000.0, bd = 0.0;  // the reference's init value
     uint64_t bk = ~0ull, bp = 0;
     int64_t scanned = 0;
@@ -280,57 +302,89 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __rest
         const int cb = code >> 20;
         const int64_t g_s = (int64_t)(code & 0xFFFFF);
         const int64_t c0 = (int64_t)cb * kTileCols, a0 = g_s * kUR;
-        const int nrows = (int)min((int64_t)kUR, P - a0);
+        // Rows a0 .. a0+15 are always read: the matrix has a zeroed group of rows behind position P and the
+        // vectors carry NaN row sums there (njp_alloc_epoch), so rows >= P behave like dead rows.
         const int64_t b0 = c0 + 2 * tid, b1 = b0 + 1;
-        const double ub0 = Ur[b0], ub1 = Ur[b1];
-        const uint64_t ka0 = KA[b0], ka1 = KA[b1], kb0 = KB[b0], kb1 = KB[b1];
+        const v2d ubv = *reinterpret_cast<const v2d*>(Ur + b0);
+        const ulonglong2 kav = *reinterpret_cast<const ulonglong2*>(KA + b0), kbv = *reinterpret_cast<const ulonglong2*>(KB + b0);
+        const double ub0 = ubv.x, ub1 = ubv.y;
+        const uint64_t ka0 = kav.x, ka1 = kav.y, kb0 = kbv.x, kb1 = kbv.y;
         const v2d* basep = reinterpret_cast<const v2d*>(D + a0 * ld + c0) + tid;
         const int64_t ld2 = ld >> 1;
         const bool diag = a0 < c0 + kTileCols;
         const bool live0 = ub0 == ub0, live1 = ub1 == ub1;   // dead columns carry NaN row sums
-        double m = __builtin_inf();
         v2d v[kUR];
 #pragma unroll
-        for (int u8 = 0; u8 < kUR; ++u8) {
-            const int rr = min(u8, nrows - 1);
-            const v2d* pp = basep + (int64_t)rr * ld2;
-            if (diag) pp = (b0 < a0 + rr) ? pp : pp - tid;
-            v[u8] = __builtin_nontemporal_load(pp);
+        for (int u8 = 0; u8 < kUR; ++u8) v[u8] = __builtin_nontemporal_load(basep + (int64_t)u8 * ld2);
+        // the 16 rows' row sums and keys: lane l holds row a0 + (l & 15) (three coalesced loads, no scalar-register
+        // pressure); v_readlane hands them out -- the keys only in the rare branch of pass 2
+        const double ua_l = Ur[a0 + (tid & 15)];
+        const uint64_t kaa_l = KA[a0 + (tid & 15)], kba_l = KB[a0 + (tid & 15)];
+        double ua[kUR];
+#pragma unroll
+        for (int u8 = 0; u8 < kUR; ++u8) ua[u8] = readlane_f64(ua_l, u8);
+        if (diag) {   // block-uniform and rare (units on the diagonal): mask the entries with column >= row
+            const int ib0 = (int)b0, ia0 = (int)a0;
+#pragma unroll
+            for (int u8 = 0; u8 < kUR; ++u8) {
+                const int a = ia0 + u8;
+                v[u8].x = (ib0 < a) ? v[u8].x : __builtin_nan("");
+                v[u8].y = (ib0 + 1 < a) ? v[u8].y : __builtin_nan("");
+            }
         }
+        // pass 1: q of the four ordered candidates of every loaded pair; a dead row or column (NaN row sum) and a
+        // masked entry (NaN distance) give a NaN q, which fmin drops and no comparison selects.  m0 / m1: the
+        // exact minimum over the live rows of this lane's two columns (dead rows add NaN, which fmin drops).
+        double q[kUR][4];
+        double lm = __builtin_inf(), m0 = __builtin_inf(), m1 = __builtin_inf();
 #pragma unroll
         for (int u8 = 0; u8 < kUR; ++u8) {
-            const int64_t a = a0 + min(u8, nrows - 1);
-            const double ua = Ur[a];
-            if (!(ua == ua)) continue;                        // dead row (wave-uniform)
-            const uint64_t kaa = KA[a], kba = KB[a];
-            double d0 = v[u8].x, d1 = v[u8].y;
-            if (diag) {
-                d0 = (b0 < a) ? d0 : __builtin_nan("");
-                d1 = (b1 < a) ? d1 : __builtin_nan("");
+            const double d0 = v[u8].x, d1 = v[u8].y;
+            const double rn = ua[u8] == ua[u8] ? 0.0 : __builtin_nan("");   // wave-uniform
+            m0 = fmin(m0, d0 + rn);
+            m1 = fmin(m1, d1 + rn);
+            q[u8][0] = (d0 - ua[u8]) - ub0;   // (i=a,  j=b0)
+            q[u8][1] = (d0 - ub0) - ua[u8];   // (i=b0, j=a)
+            q[u8][2] = (d1 - ua[u8]) - ub1;
+            q[u8][3] = (d1 - ub1) - ua[u8];
+            lm = fmin(lm, fmin(fmin(q[u8][0], q[u8][1]), fmin(q[u8][2], q[u8][3])));
+        }
+        double m = fmin(fmin(live0 ? m0 : __builtin_nan(""), live1 ? m1 : __builtin_nan("")), __builtin_inf());   // +inf: no live pair
+        const double wm = wave_fmin(lm);          // +inf when the wave saw no valid candidate
+        if (wm <= bq) {                           // wave-uniform
+            if (wm < bq) { bq = wm; bk = ~0ull; }
+#pragma unroll
+            for (int u8 = 0; u8 < kUR; ++u8) {
+                const bool e0 = q[u8][0] == wm, e1 = q[u8][1] == wm, e2 = q[u8][2] == wm, e3 = q[u8][3] == wm;
+                if (__builtin_amdgcn_ballot_w64(e0 | e1 | e2 | e3) != 0ull) {
+                    const uint64_t pa = (uint64_t)(a0 + u8);
+                    const uint64_t kaa = readlane_u64(kaa_l, u8), kba = readlane_u64(kba_l, u8);
+                    const uint64_t k0 = kaa | kb0, k1 = ka0 | kba, k2 = kaa | kb1, k3 = ka1 | kba;
+                    if (e0 & (k0 < bk)) { bk = k0; bp = pa | ((uint64_t)b0 << 32); bd = v[u8].x; }
+                    if (e1 & (k1 < bk)) { bk = k1; bp = (uint64_t)b0 | (pa << 32); bd = v[u8].x; }
+                    if (e2 & (k2 < bk)) { bk = k2; bp = pa | ((uint64_t)b1 << 32); bd = v[u8].y; }
+                    if (e3 & (k3 < bk)) { bk = k3; bp = (uint64_t)b1 | (pa << 32); bd = v[u8].y; }
+                }
             }
-            // exact unit minimum over live pairs (fmin drops the NaN of masked entries)
-            m = fmin(m, fmin(live0 ? d0 : __builtin_nan(""), live1 ? d1 : __builtin_nan("")));
-            const uint64_t pa = (uint64_t)a;
-            best_update4(bq, bk, bp, bd, (d0 - ua) - ub0, kaa | kb0, pa | ((uint64_t)b0 << 32), d0);   // (i=a, j=b0)
-            best_update4(bq, bk, bp, bd, (d0 - ub0) - ua, ka0 | kba, (uint64_t)b0 | (pa << 32), d0);   // (i=b0, j=a)
-            best_update4(bq, bk, bp, bd, (d1 - ua) - ub1, kaa | kb1, pa | ((uint64_t)b1 << 32), d1);
-            best_update4(bq, bk, bp, bd, (d1 - ub1) - ua, ka1 | kba, (uint64_t)b1 | (pa << 32), d1);
         }
         // exact unit minimum -> umin (double-buffered LDS: one barrier per unit)
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_xor(m, off, 64));
+        m = wave_fmin(m);
         if ((tid & 63) == 0) smin[flip][tid >> 6] = m;
         __syncthreads();
         if (tid == 0)
             umin[(int64_t)cb * G16 + g_s] = enc_f64(fmin(fmin(smin[flip][0], smin[flip][1]), fmin(smin[flip][2], smin[flip][3])));
     }
 
-    // block winner (q, key, positions, d)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double oq = __shfl_down(bq, off, 64), od = __shfl_down(bd, off, 64);
-        const uint64_t ok = __shfl_down((unsigned long long)bk, off, 64), op = __shfl_down((unsigned long long)bp, off, 64);
-        best_update4(bq, bk, bp, bd, oq, ok, op, od);
+    // wave winner: the smallest key among the lanes' candidates at bq, then that lane's positions and distance
+    {
+        const uint64_t wk = wave_umin64(bk);
+        if (wk != ~0ull) {
+            const unsigned long long own = __builtin_amdgcn_ballot_w64(bk == wk);
+            const int src = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(own));
+            bp = readlane_u64(bp, src);
+            bd = readlane_f64(bd, src);
+        }
+        bk = wk;
     }
     if ((tid & 63) == 0) { sq[tid >> 6] = bq; sk[tid >> 6] = bk; sp[tid >> 6] = bp; sd[tid >> 6] = bd; }
     __syncthreads();
@@ -394,12 +448,7 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
         for (int64_t idx = threadIdx.x + 4 * kThreads; idx < nrec; idx += kThreads)
             best_update4(bq, bk, bp, d, partials[idx].q, partials[idx].key, partials[idx].pad, partials[idx].d);
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double oq = __shfl_down(bq, off, 64), od = __shfl_down(d, off, 64);
-        const uint64_t ok = __shfl_down((unsigned long long)bk, off, 64), op = __shfl_down((unsigned long long)bp, off, 64);
-        best_update4(bq, bk, bp, d, oq, ok, op, od);
-    }
+    wave_best4(bq, bk, bp, d);
     if ((threadIdx.x & 63) == 0) { sq[threadIdx.x >> 6] = bq; sk[threadIdx.x >> 6] = bk; spp[threadIdx.x >> 6] = bp; sdd[threadIdx.x >> 6] = d; }
     __syncthreads();
     bq = sq[0]; bk = sk[0]; bp = spp[0]; d = sdd[0];
@@ -417,7 +466,6 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
     const int64_t px = ki < kj ? pi : pj, py = ki < kj ? pj : pi;
     const int64_t n1 = n - 1;
     const double r1 = (double)(n1 - 2);
-    const int64_t G16 = (P + kUR - 1) / kUR;
 
     double val = 0.0;
     if (i < n) {
@@ -443,9 +491,7 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
             Ur[p] = u / r1;
             D[px * ld + p] = val;
             D[p * ld + px] = val;
-            // the unit holding the pair (px, p) may have a new minimum
-            const int64_t pa = p > px ? p : px, pb = p > px ? px : p;
-            atomicMin(&umin[(pb / kTileCols) * G16 + pa / kUR], (unsigned long long)enc_f64(val));
+            // (the bounds of the units this pair belongs to are lowered by the prep kernel that follows)
             if (i == last) {           // relabel: the node of the last slot now lives in slot y
                 new_slot = y;
                 slot_of_pos[p] = (int32_t)y;
@@ -636,7 +682,7 @@ static int njp_launch_prep(NjBuffers& b, hipStream_t s, int v = 0)
     const bool sh = q.sh_world > 1;
     const int slot = sh && q.sh_virtual ? v : 0;             // local storage index of this rank
     hipLaunchKernelGGL(njp_prep_kernel, dim3((unsigned)q.nprep), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.U, q.Ur, q.Ur,
-                       b.xpart, b.partials, (const unsigned long long*)q.umin, q.P, q.blk_cb, q.blk_g0, njp_grid_total(q),
+                       b.xpart, b.partials, (unsigned long long*)q.umin, q.P, q.blk_cb, q.blk_g0, njp_grid_total(q),
                        q.list + (int64_t)slot * q.list_stride, sh ? v : 0, sh ? q.sh_world : 1,
                        sh ? q.cnt_all + 2 * slot : (unsigned long long*)nullptr, sh ? njp_grid_total(q) : -1);
     DPR_HIP(hipGetLastError());
