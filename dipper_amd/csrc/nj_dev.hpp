@@ -122,6 +122,30 @@ __device__ __forceinline__ double block_tree256(double v, double* s)
     return s[0];
 }
 
+// The same tree (same operand pairs at every level, so the same bits) with three barriers instead of nine: the
+// levels 128 and 64 go through LDS, the levels 32 .. 1 stay inside wave 0 (lane t adds lane t + st).  All 256
+// threads must call it; the sum is valid in thread 0 only.
+constexpr int kDppRowShl1 = 0x101, kDppRowShl2 = 0x102, kDppRowShl4 = 0x104, kDppRowShl8 = 0x108;
+__device__ __forceinline__ double block_tree256_lane0(double v, double* s)
+{
+    const int t = threadIdx.x;
+    s[t] = v;
+    __syncthreads();
+    if (t < 128) s[t] = s[t] + s[t + 128];
+    __syncthreads();
+    double r = 0.0;
+    if (t < 64) {                                   // wave 0, all lanes active
+        r = s[t] + s[t + 64];
+        r = r + __shfl_down(r, 32, 64);
+        r = r + __shfl_down(r, 16, 64);
+        r = r + dpp_f64<kDppRowShl8>(r);            // lane t of a row reads lane t + 8 of the same row
+        r = r + dpp_f64<kDppRowShl4>(r);
+        r = r + dpp_f64<kDppRowShl2>(r);
+        r = r + dpp_f64<kDppRowShl1>(r);
+    }
+    return r;
+}
+
 // canonical U[x] from the chunk partials of the previous update (n_prev = n + 1 slots)
 __device__ __forceinline__ double finish_ux(const double* __restrict__ xpart, int64_t n_prev, double* s)
 {

@@ -211,7 +211,10 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
     // ---- reductions
     double urx = 0.0;
     if (it > 0) {
-        const double ux = block_tree256(acc, s);
+        double ux = block_tree256_lane0(acc, s);
+        if (tid == 0) s[0] = ux;
+        __syncthreads();
+        ux = s[0];
         urx = ux / (double)(n - 2);
         if (blockIdx.x == 0 && tid == 0) { U_w[px] = ux; Ur_w[px] = urx; }
     }
@@ -425,15 +428,22 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
     const int64_t it = st->itb;   // stable: the writer below only advances st->it / st->n
     const int64_t limit = st->it_limit, N = st->N;
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    const int64_t p = i < N ? (int64_t)pos_of_slot[i] : -1;
+    // (none of these addresses depends on a loaded value: the slot arrays are padded past N, the record array holds
+    // scan_grid entries; what a load was worth is decided afterwards)
+    const int64_t p = (int64_t)pos_of_slot[i];
     NjRecord r0; r0.q = 10000.0; r0.key = ~0ull; r0.d = 0; r0.pad = 0;
     NjRecord mine[4] = { r0, r0, r0, r0 };
-    const unsigned long long cnt_raw = nrec_fixed >= 0 ? (unsigned long long)nrec_fixed : st->cnt_list[it & 1];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int idx = threadIdx.x + k * kThreads;
-        if (idx < scan_grid && (unsigned long long)idx < cnt_raw) mine[k] = partials[idx];
+        if (idx < scan_grid) mine[k] = partials[idx];
     }
+    const unsigned long long cnt_raw = nrec_fixed >= 0 ? (unsigned long long)nrec_fixed : st->cnt_list[it & 1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if ((unsigned long long)(threadIdx.x + k * kThreads) >= cnt_raw) mine[k] = r0;   // not written by this iteration's scan
+    // hop 1b: this position's row sum (its address needs the position only; in flight during the record reduction)
+    const double up = (i < N && p >= 0) ? U[p] : 0.0;
     if (st->status != 0 || it >= limit) return;
     const int64_t n = N - it;
     if (n < 3 || (int64_t)blockIdx.x * kThreads >= n) return;
@@ -486,7 +496,7 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
         if (i != x && i != y) {
             const double dxi = D[px * ld + p], dyi = D[py * ld + p];
             val = (dxi + dyi - d) * 0.5;
-            const double u = U[p] + (-dxi - dyi + val);   // i == last: "U[y] = U[last] + ..." of the reference's tail
+            const double u = up + (-dxi - dyi + val);   // i == last: "U[y] = U[last] + ..." of the reference's tail
             U[p] = u;
             Ur[p] = u / r1;
             D[px * ld + p] = val;
@@ -498,13 +508,14 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
                 pos_of_slot[y] = (int32_t)p;
             }
         } else if (i == y) {
-            Ur[p] = __builtin_nan("");   // dead: every q it takes part in is NaN, every unit minimum skips it
-            if (y != last) slot_of_pos[p] = -1;
+            // (py from the winning record, not this thread's pos_of_slot[y]: the thread of the last slot rewrites that entry)
+            Ur[py] = __builtin_nan("");   // dead: every q it takes part in is NaN, every unit minimum skips it
+            if (y != last) slot_of_pos[py] = -1;
             new_slot = -1;
         }
         if (new_slot >= 0) { KA[p] = nj_key_a(new_slot, n1); KB[p] = nj_key_b(new_slot); }
     }
-    const double cs = block_tree256(val, s);
+    const double cs = block_tree256_lane0(val, s);
     if (threadIdx.x == 0) xpart[blockIdx.x] = cs;
 }
 
