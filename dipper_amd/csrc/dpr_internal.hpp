@@ -228,6 +228,7 @@ struct PlaceBuffers {
     double* q_dis = nullptr;
     void* partials = nullptr;
     int nparts_max = 0;
+    int dbg = 0;   // 4: place_update_kernel writes its phase clocks into the trace (DPR_PLACE_CLOCKS, profiling only)
 };
 int place_alloc(PlaceBuffers& p, int64_t N, int64_t M = 0);   // M = 0: M = N
 void place_free(PlaceBuffers& p);

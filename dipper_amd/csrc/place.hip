@@ -14,7 +14,7 @@
 // src/placement_close_k.cu:339-340.
 #include <cstdlib>
 
-#include "dpr_internal.hpp"
+#include "nj_dev.hpp"
 
 namespace dpr {
 
@@ -68,22 +68,32 @@ __device__ __forceinline__ void list_insert(double* cdis, int32_t* cid, int slot
 // updateClosestNodes, one wave: frontier entries l..r processed 64 at a time.  The frontier holds SLOTS:
 // reaching slot i = (u -> v) with the distance d of u inserts the new leaf into list[i]; if it entered, the
 // slots leaving v other than the reverse of i (cont[2i], cont[2i+1]; write-once except at a split) follow
-// with d + len[i].  That is the reference's node BFS with the adjacency walk folded into the queue entry,
-// so a round costs two dependent memory hops (queue entry -> everything about the slot, all loads in flight
-// together).  cont[2i] == -2 marks a target node of degree > 3 (possible only in an imported backbone),
+// with d + len[i].  That is the reference's node BFS with the adjacency walk folded into the queue entry.
+// A round costs ONE global-memory hop (everything about the slot, all loads in flight together): the
+// frontier lives in LDS (entries beyond kQueueLds spill to the global queue), its append offsets come from
+// two ballots (a slot contributes 0, 1 or 2 entries), and -- every directed edge being reached at most once
+// per BFS -- no list is read after it was written, so the rounds need no memory fence beyond the wave's own
+// program order.  cont[2i] == -2 marks a target node of degree > 3 (possible only in an imported backbone),
 // which falls back to walking that node's list.
+constexpr int kQueueLds = 2048;
 __device__ __forceinline__ void closest_update_wave(const PlaceBuffers& p, int x, int start_slot)
 {
+    __shared__ int32_t sq_id[kQueueLds];
+    __shared__ double sq_dis[kQueueLds];
     const int lane = threadIdx.x & 63;
     int l = 0, r = 1;  // queue [l, r)
-    if (lane == 0) { p.q_id[0] = start_slot; p.q_dis[0] = 0.0; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane == 0) { sq_id[0] = start_slot; sq_dis[0] = 0.0; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     while (l < r) {
         const int cnt = min(64, r - l);
         int sl = -1;
         double d = 0.0;
-        if (lane < cnt) { sl = p.q_id[l + lane]; d = p.q_dis[l + lane]; }
+        if (lane < cnt) {
+            const int qi = l + lane;
+            if (qi < kQueueLds) { sl = sq_id[qi]; d = sq_dis[qi]; }
+            else { sl = p.q_id[qi]; d = p.q_dis[qi]; }
+        }
         int c0 = -1, c1 = -1, nnew = 0;
         double dn = 0.0;
         bool walk = false;
@@ -116,28 +126,48 @@ __device__ __forceinline__ void closest_update_wave(const PlaceBuffers& p, int x
             }
         }
         // append in lane order (order is irrelevant for the result, kept deterministic anyway)
-        int incl = nnew;
+        int excl, total;
+        if (__builtin_amdgcn_ballot_w64(walk) == 0ull) {       // wave-uniform: every lane adds 0, 1 or 2 entries
+            const unsigned long long m1 = __builtin_amdgcn_ballot_w64(nnew >= 1), m2 = __builtin_amdgcn_ballot_w64(nnew >= 2);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            excl = __popcll(m1 & below) + __popcll(m2 & below);
+            total = __popcll(m1) + __popcll(m2);
+        } else {
+            int incl = nnew;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += v;
+            }
+            total = __shfl(incl, 63, 64);
+            excl = incl - nnew;
         }
-        const int total = __shfl(incl, 63, 64);
+        const bool spill = r + total > kQueueLds;               // wave-uniform
         if (nnew) {
-            int w = r + incl - nnew;
+            int w = r + excl;
+            auto push = [&](int slot) {
+                if (w < kQueueLds) { sq_id[w] = slot; sq_dis[w] = dn; }
+                else { p.q_id[w] = slot; p.q_dis[w] = dn; }
+                ++w;
+            };
             if (!walk) {
-                if (c0 >= 0) { p.q_id[w] = c0; p.q_dis[w] = dn; ++w; }
-                if (c1 >= 0) { p.q_id[w] = c1; p.q_dis[w] = dn; ++w; }
+                if (c0 >= 0) push(c0);
+                if (c1 >= 0) push(c1);
             } else {
                 const int back = p.rev[sl];
                 for (int i = p.head[p.e[sl]]; i != -1; i = p.nxt[i])
-                    if (i != back) { p.q_id[w] = i; p.q_dis[w] = dn; ++w; }
+                    if (i != back) push(i);
             }
         }
         l += cnt;
         r += total;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (spill) {                                            // entries went to the global queue
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
     }
 }
 
@@ -247,55 +277,79 @@ __global__ __launch_bounds__(64) void place_backbone_lists_kernel(PlaceBuffers p
 // reference's Thrust reduction, device->host copy and two single-thread kernels.  (Fusing the two with a
 // last-block-done ticket was measured 1.5-2x SLOWER: every block then needs a device-scope release
 // fence, i.e. an L2 write-back, which costs more than the kernel boundary it saves.)
+constexpr int kUpdThreads = 256;
 __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, const PlacePartial* partials, int nparts,
                                                         int64_t num, int64_t edge_count, double* __restrict__ trace)
 {
-    const int lane = threadIdx.x & 63;
+    __shared__ double s_add[kUpdThreads / 64], s_frac[kUpdThreads / 64];
+    __shared__ int s_idx[kUpdThreads / 64], s_eid[kUpdThreads / 64], s_rev[kUpdThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    int ec = (int)edge_count;
+    const unsigned long long tk0 = wall_clock64();
+    // (a) loads that do not depend on the winner: the (initial) lists of the new slots ec, ec+1, ec+3 -- slots the
+    // reference never touched keep the init values 2 / -1, which it reads back at the split; in flight during (b)
+    double i0d[K5], i1d[K5], i3d[K5];
+    int i0i[K5], i1i[K5], i3i[K5];
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < K5; ++i) {
+            i0d[i] = p.cdis[ec * K5 + i]; i0i[i] = p.cid[ec * K5 + i];
+            i1d[i] = p.cdis[(ec + 1) * K5 + i]; i1i[i] = p.cid[(ec + 1) * K5 + i];
+            i3d[i] = p.cdis[(ec + 3) * K5 + i]; i3i[i] = p.cid[(ec + 3) * K5 + i];
+        }
+    }
+    // (b) first minimum over the block partials of the scan: four waves, eight loads in flight per thread
     double badd = __builtin_inf(), bfrac = 0;
     int bidx = 0x7fffffff, beid = 0, brev = -1;
-    for (int i0 = lane; i0 < nparts; i0 += 256) {      // four independent loads in flight per lane
-        PlacePartial pp[4];
+    const int nthr = (int)blockDim.x;
+    for (int i0 = tid; i0 < nparts; i0 += 8 * nthr) {
+        PlacePartial pp[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + 64 * u;
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + nthr * u;
             if (i < nparts) pp[u] = partials[i];
             else { pp[u].add = __builtin_inf(); pp[u].idx = 0x7fffffff; pp[u].eid = 0; pp[u].frac = 0; pp[u].rev = -1; }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 8; ++u)
             if (pp[u].add < badd || (pp[u].add == badd && pp[u].idx < bidx)) { badd = pp[u].add; bidx = pp[u].idx; beid = pp[u].eid; bfrac = pp[u].frac; brev = pp[u].rev; }
     }
     // slots >= 4*num-4 (and < 4M-4) all carry the tuple (0,0,2): the first of them competes
     const int64_t live = 4 * num - 4, lim = 4 * p.M - 4;
-    if (lane == 0 && live < lim) {
+    if (tid == 0 && live < lim) {
         if (2.0 < badd || (2.0 == badd && (int)live < bidx)) { badd = 2.0; bidx = (int)live; beid = 0; bfrac = 0; brev = -1; }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double oa = __shfl_down(badd, off, 64);
-        const int oi = __shfl_down(bidx, off, 64);
-        const int oe = __shfl_down(beid, off, 64);
-        const int orv = __shfl_down(brev, off, 64);
-        const double of = __shfl_down(bfrac, off, 64);
-        if (oa < badd || (oa == badd && oi < bidx)) { badd = oa; bidx = oi; beid = oe; bfrac = of; brev = orv; }
+    {   // wave winner (smallest add, then smallest idx; add is never NaN here), then the four wave winners through LDS
+        const double wa = wave_fmin(badd);
+        const uint64_t wi = wave_umin64(badd == wa ? (uint64_t)(uint32_t)bidx : ~0ull);
+        const unsigned long long own = __builtin_amdgcn_ballot_w64((badd == wa) & ((uint64_t)(uint32_t)bidx == wi));
+        const int src = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(own));
+        if (lane == src) { s_add[tid >> 6] = badd; s_idx[tid >> 6] = bidx; s_eid[tid >> 6] = beid; s_frac[tid >> 6] = bfrac; s_rev[tid >> 6] = brev; }
     }
-    const int eid = __shfl(beid, 0, 64);
-    const double fracLen = __shfl(bfrac, 0, 64), addLen = __shfl(badd, 0, 64);
+    __syncthreads();
+    if (tid >= 64) return;                    // wave 0 goes on alone
+    badd = s_add[0]; bidx = s_idx[0]; beid = s_eid[0]; bfrac = s_frac[0]; brev = s_rev[0];
+#pragma unroll
+    for (int w = 1; w < nthr / 64; ++w)
+        if (s_add[w] < badd || (s_add[w] == badd && s_idx[w] < bidx)) { badd = s_add[w]; bidx = s_idx[w]; beid = s_eid[w]; bfrac = s_frac[w]; brev = s_rev[w]; }
+    const int eid = beid;
+    const double fracLen = bfrac, addLen = badd;
+    const unsigned long long tk1 = wall_clock64();
     const int placeId = (int)num;
     if (lane == 0) {
         if (trace) { trace[3 * num] = eid; trace[3 * num + 1] = fracLen; trace[3 * num + 2] = addLen; }
-        int ec = (int)edge_count;
         const int N = (int)p.N;
         const int middle = placeId + N - 1, outside = placeId;
         const int xe = eid, ye = brev >= 0 ? brev : p.rev[eid];   // the reference finds them by walking head[x] / head[y]
+        // (c) every load of the split in one round trip, before the first store
         const int x = p.belong[eid], y = p.e[eid];
         const double originalDis = p.len[eid];
-        // both lists up front (independent loads)
         double cdx[K5], cdy[K5];
         int cix[K5], ciy[K5];
 #pragma unroll
         for (int i = 0; i < K5; ++i) { cdx[i] = p.cdis[xe * K5 + i]; cix[i] = p.cid[xe * K5 + i]; cdy[i] = p.cdis[ye * K5 + i]; ciy[i] = p.cid[ye * K5 + i]; }
         const double lenye = p.len[ye];
+        const int ox0 = p.cont[2 * xe], ox1 = p.cont[2 * xe + 1], oy0 = p.cont[2 * ye], oy1 = p.cont[2 * ye + 1];
         p.e[xe] = middle; p.len[xe] = fracLen;
         p.e[ye] = middle; p.len[ye] = lenye - fracLen;
         // middle -> x: inherits the list of y -> x (slots untouched by the reference keep the init values 2 / -1)
@@ -305,8 +359,8 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
 #pragma unroll
         for (int i = 0; i < K5; ++i) {
             const bool has = ciy[i] != -1;
-            n0i[i] = has ? ciy[i] : p.cid[ec * K5 + i];
-            n0d[i] = has ? cdy[i] + originalDis - fracLen : p.cdis[ec * K5 + i];
+            n0i[i] = has ? ciy[i] : i0i[i];
+            n0d[i] = has ? cdy[i] + originalDis - fracLen : i0d[i];
             if (has) { p.cid[ec * K5 + i] = n0i[i]; p.cdis[ec * K5 + i] = n0d[i]; }
         }
         p.rev[ec] = xe; p.rev[xe] = ec;
@@ -316,8 +370,8 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
 #pragma unroll
         for (int i = 0; i < K5; ++i) {
             const bool has = cix[i] != -1;
-            n1i[i] = has ? cix[i] : p.cid[ec * K5 + i];
-            n1d[i] = has ? cdx[i] + fracLen : p.cdis[ec * K5 + i];
+            n1i[i] = has ? cix[i] : i1i[i];
+            n1d[i] = has ? cdx[i] + fracLen : i1d[i];
             if (has) { p.cid[ec * K5 + i] = n1i[i]; p.cdis[ec * K5 + i] = n1d[i]; }
         }
         p.rev[ec] = ye; p.rev[ye] = ec;
@@ -332,18 +386,27 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
         double md[K5];
         int mi[K5];
 #pragma unroll
-        for (int i = 0; i < K5; ++i) { md[i] = p.cdis[ec * K5 + i]; mi[i] = p.cid[ec * K5 + i]; }
+        for (int i = 0; i < K5; ++i) { md[i] = i3d[i]; mi[i] = i3i[i]; }
+#pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
+            bool open = true;                                    // the reference stops a list at its first empty entry
+#pragma unroll
             for (int i = 0; i < K5; ++i) {
                 const int si = pass == 0 ? n1i[i] : n0i[i];      // e1 = middle->y first, then e2 = middle->x
                 const double sd = pass == 0 ? n1d[i] : n0d[i];
-                if (si == -1) break;
-                for (int j = 0; j < K5; ++j)
-                    if (md[j] > sd) {
-                        for (int k = K5 - 1; k > j; --k) { md[k] = md[k - 1]; mi[k] = mi[k - 1]; }
-                        md[j] = sd; mi[j] = si;
-                        break;
-                    }
+                open = open && si != -1;
+                int j = K5;
+#pragma unroll
+                for (int t = K5 - 1; t >= 0; --t)
+                    if (md[t] > sd) j = t;                       // first entry farther than sd
+                if (open && j < K5) {
+#pragma unroll
+                    for (int k = K5 - 1; k > 0; --k)
+                        if (k > j) { md[k] = md[k - 1]; mi[k] = mi[k - 1]; }
+#pragma unroll
+                    for (int k = 0; k < K5; ++k)
+                        if (k == j) { md[k] = sd; mi[k] = si; }
+                }
             }
         }
 #pragma unroll
@@ -351,7 +414,6 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
         // continuation slots: the new slots towards x / y inherit what lay beyond y -> x / x -> y; xe and ye now
         // end in `middle`; slots entering x or y from elsewhere keep theirs (slot ids do not change)
         const int e0 = ec - 3, e1 = ec - 2, e2 = ec - 1, e3 = ec;
-        const int ox0 = p.cont[2 * xe], ox1 = p.cont[2 * xe + 1], oy0 = p.cont[2 * ye], oy1 = p.cont[2 * ye + 1];
         p.cont[2 * e0] = oy0; p.cont[2 * e0 + 1] = oy1;
         p.cont[2 * e1] = ox0; p.cont[2 * e1 + 1] = ox1;
         p.cont[2 * xe] = e1; p.cont[2 * xe + 1] = e3;
@@ -359,9 +421,16 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
         p.cont[2 * e2] = e0; p.cont[2 * e2 + 1] = e1;
         p.cont[2 * e3] = -1; p.cont[2 * e3 + 1] = -1;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // the wave reads what its lane 0 just stored: program order within the wavefront
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned long long tk2 = wall_clock64();
     closest_update_wave(p, placeId, (int)edge_count + 2);   // the new leaf's only slot: outside -> middle
+    if ((p.dbg & 4) && trace && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long tk3 = wall_clock64();
+        trace[3 * num] = (double)(tk1 - tk0); trace[3 * num + 1] = (double)(tk2 - tk1); trace[3 * num + 2] = (double)(tk3 - tk2);
+    }
 }
 
 constexpr int kTipThreads = 256;
@@ -436,7 +505,7 @@ __global__ __launch_bounds__(kTipThreads) void place_tip_kernel(PlaceBuffers p, 
     }
 }
 
-__global__ __launch_bounds__(64) void place_update_kernel(PlaceBuffers p, const PlacePartial* partials, int nparts,
+__global__ __launch_bounds__(kUpdThreads) void place_update_kernel(PlaceBuffers p, const PlacePartial* partials, int nparts,
                                                           int64_t num, double* __restrict__ trace)
 {
     place_finish_and_update(p, partials, nparts, num, 4 * num - 4, trace);
@@ -449,6 +518,7 @@ int place_alloc(PlaceBuffers& p, int64_t N, int64_t M)
 {
     place_free(p);
     p.N = N;
+    if (const char* e = std::getenv("DPR_PLACE_CLOCKS")) p.dbg = std::atoi(e) ? 4 : 0;   // profiles/place_phases.py
     p.M = M > 0 ? M : N;
     DPR_HIP(hipMalloc(&p.head, sizeof(int32_t) * (size_t)(2 * N)));
     DPR_HIP(hipMalloc(&p.e, sizeof(int32_t) * (size_t)(8 * N)));
@@ -545,7 +615,7 @@ int place_tip(PlaceBuffers& p, const double* d_dis, int64_t tip, double* d_trace
     const int nblk = (int)((live + kTipThreads - 1) / kTipThreads);
     PlacePartial* parts = reinterpret_cast<PlacePartial*>(p.partials);
     hipLaunchKernelGGL(place_tip_kernel, dim3((unsigned)nblk), dim3(kTipThreads), 0, s, p, d_dis, tip, parts);
-    hipLaunchKernelGGL(place_update_kernel, dim3(1), dim3(64), 0, s, p, (const PlacePartial*)parts, nblk, tip, d_trace);
+    hipLaunchKernelGGL(place_update_kernel, dim3(1), dim3(kUpdThreads), 0, s, p, (const PlacePartial*)parts, nblk, tip, d_trace);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
