@@ -257,6 +257,7 @@ def main():
 
     phase = []
     prune = None
+    last_res = None
     if args.probe_only:
         args.steps = args.warmup = 0
     for _ in range(args.warmup):
@@ -264,7 +265,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        last_res = step()
         phase.append(dip.timing())
         try:
             sc, full = dip.prune_stats()
@@ -279,6 +280,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / max(args.steps, 1) * 1e3 if args.steps else float("nan")
+
+    # ---- several GPUs: the ranks must hold the same merge log, and it must be the one a single GPU produces ----
+    mgpu_check = None
+    if world > 1 and last_res is not None:
+        import hashlib
+        h = hashlib.sha256()
+        for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
+            h.update(np.ascontiguousarray(last_res[key]).tobytes())
+        digest = int.from_bytes(h.digest()[:7], "little")
+        mine = torch.tensor([digest], dtype=torch.int64, device="cuda")
+        allh = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allh, mine)
+        agree = all(int(t.item()) == digest for t in allh)
+        mgpu_check = {"ranks_agree": bool(agree)}
+        if rank == 0:
+            try:   # untimed replay of the same step on this rank's GPU alone (no communicator)
+                solo = dipper_amd.Dipper(local_rank)
+                solo.set_msa(packed, L)
+                solo.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+                ref = solo.nj_run()
+                solo.close()
+                mgpu_check["matches_single_gpu"] = bool(
+                    all(np.array_equal(ref[k], last_res[k]) for k in ("merge_x", "merge_y", "bl_x", "bl_y")))
+            except Exception as e:
+                mgpu_check["matches_single_gpu"] = None
+                mgpu_check["error"] = repr(e)
+        dist.barrier()
 
     # ---- roofline of the dominant kernel: Q-argmin scan at n = N on a fresh matrix ----------------
     dip.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
@@ -316,6 +344,8 @@ def main():
         "nj_algorithm": "exact pruned scan (njp.hip)" if prune else "full streaming scan (nj.hip)",
         "prune": prune,
     }
+    if mgpu_check is not None:
+        out["multi_gpu_check"] = mgpu_check
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(dip, n)

@@ -451,7 +451,7 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
     const bool repl = c->world > 1 && c->vworld == 0 && want_pruned() && n >= 3;
     c->nj_replicated = repl;
     for (size_t r = 0; r < c->nj.size(); ++r)
-        if (int rc = nj_alloc(c->nj[r], n, repl ? 0 : (c->vworld > 0 ? (int)r : c->rank), repl ? 1 : c->world)) return rc;
+        if (int rc = nj_alloc(c->nj[r], n, repl ? 0 : (c->vworld > 0 ? (int)r : c->rank), repl ? 1 : c->world, c->stream)) return rc;
     DPR_HIP(hipEventRecord(c->ev[0], c->stream));
     for (auto& b : c->nj) {
         if (source == DPR_SRC_MSA) {
@@ -627,6 +627,7 @@ int dpr_get_prune_stats(dpr_ctx* c, uint64_t* units_scanned, uint64_t* units_per
 int dpr_get_iterstats(dpr_ctx* c, uint64_t* out, int64_t iters)
 {
     if (!c || !c->have_matrix || !c->nj[0].pr.iterstats) { set_error("dpr_get_iterstats: not enabled"); return DPR_ERR_STATE; }
+    DPR_HIP(hipStreamSynchronize(c->stream));   // the plain copies below run on the null stream, which does not wait for c->stream
     DPR_HIP(hipMemcpy(out, c->nj[0].pr.iterstats, sizeof(uint64_t) * (size_t)(2 * iters), hipMemcpyDeviceToHost));
     return DPR_OK;
 }
@@ -696,6 +697,7 @@ int64_t dpr_n_total(dpr_ctx* c) { return c ? c->nj[0].N : DPR_ERR_ARG; }
 int dpr_get_matrix_row(dpr_ctx* c, int64_t i, double* out)
 {
     if (!c || !c->have_matrix || !out || i < 0 || i >= c->nj[0].N) { set_error("dpr_get_matrix_row: bad argument"); return DPR_ERR_ARG; }
+    DPR_HIP(hipStreamSynchronize(c->stream));   // the plain copies below run on the null stream, which does not wait for c->stream
     if (c->nj[0].pr.active) {
         // position space: row of slot i, columns gathered through pos_of_slot (dead slots read +inf)
         NjPruned& q = c->nj[0].pr;
@@ -721,6 +723,7 @@ int dpr_get_matrix_row(dpr_ctx* c, int64_t i, double* out)
 int dpr_get_row_sums(dpr_ctx* c, double* out)
 {
     if (!c || !c->have_matrix || !out) { set_error("dpr_get_row_sums: bad argument"); return DPR_ERR_ARG; }
+    DPR_HIP(hipStreamSynchronize(c->stream));   // the plain copies below run on the null stream, which does not wait for c->stream
     if (c->nj[0].pr.active) {
         NjPruned& q = c->nj[0].pr;
         const int64_t N = c->nj[0].N;
@@ -924,6 +927,7 @@ int dpr_place_exact_run(dpr_ctx* c, int source, int dist_type, int k, int64_t n,
 int dpr_get_exact_state(dpr_ctx* c, int32_t* rev, int32_t* dep)
 {
     if (!c || !c->exact.dep || !c->place.rev) { set_error("dpr_get_exact_state: no exact placement state"); return DPR_ERR_STATE; }
+    DPR_HIP(hipStreamSynchronize(c->stream));   // the plain copies below run on the null stream, which does not wait for c->stream
     const int64_t n = c->place.N;
     if (rev) DPR_HIP(hipMemcpy(rev, c->place.rev, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost));
     if (dep) DPR_HIP(hipMemcpy(dep, c->exact.dep, sizeof(int32_t) * (size_t)(2 * n), hipMemcpyDeviceToHost));
@@ -1105,6 +1109,7 @@ int dpr_get_dc_stats(dpr_ctx* c, int64_t* counts5, double* phase_ms3)
 int dpr_get_place_state(dpr_ctx* c, int32_t* cid, double* cdis, double* trace)
 {
     if (!c || !c->place.cid) { set_error("dpr_get_place_state: no placement state"); return DPR_ERR_STATE; }
+    DPR_HIP(hipStreamSynchronize(c->stream));   // the plain copies below run on the null stream, which does not wait for c->stream
     const int64_t n = c->place.N;
     if (cid) DPR_HIP(hipMemcpy(cid, c->place.cid, sizeof(int32_t) * (size_t)(40 * n), hipMemcpyDeviceToHost));
     if (cdis) DPR_HIP(hipMemcpy(cdis, c->place.cdis, sizeof(double) * (size_t)(40 * n), hipMemcpyDeviceToHost));

@@ -135,7 +135,7 @@ struct NjBuffers {
 };
 
 // nj.hip
-int nj_alloc(NjBuffers& b, int64_t N, int rank, int world);
+int nj_alloc(NjBuffers& b, int64_t N, int rank, int world, hipStream_t s);   // fills ordered on s
 void nj_free(NjBuffers& b);
 int nj_expand_lower(NjBuffers& b, const double* d_packed_lower, hipStream_t s);
 int nj_init_sums(NjBuffers& b, hipStream_t s);          // U (local rows), diag, state

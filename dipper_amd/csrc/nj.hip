@@ -496,7 +496,9 @@ int nj_bw_probe(NjBuffers& b, int64_t bytes, int nt, int grid, int reps, hipStre
 // ------------------------------------------------------------------------------------------------
 static int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
-int nj_alloc(NjBuffers& b, int64_t N, int rank, int world)
+// (all fills are ordered on the caller's stream: a plain hipMemset runs on the null stream, which a non-blocking
+// stream does not wait for -- the fill of a 7 GB matrix would still be running when the first distance tiles land)
+int nj_alloc(NjBuffers& b, int64_t N, int rank, int world, hipStream_t s)
 {
     nj_free(b);
     b.N = N; b.rank = rank; b.world = world;
@@ -505,16 +507,16 @@ int nj_alloc(NjBuffers& b, int64_t N, int rank, int world)
     const int64_t rows_alloc = round_up(b.rows_local > 0 ? b.rows_local : 1, kRowBlock);
     const size_t dbytes = (size_t)(rows_alloc * b.ld + kTileCols + 16) * sizeof(double);
     DPR_HIP(hipMalloc(&b.D, dbytes));
-    DPR_HIP(hipMemset(b.D, 0, dbytes));
+    DPR_HIP(hipMemsetAsync(b.D, 0, dbytes, s));
     const size_t vec = (size_t)(N + kTileCols + 16);
     DPR_HIP(hipMalloc(&b.U, vec * sizeof(double)));
     DPR_HIP(hipMalloc(&b.Ur, vec * sizeof(double)));
     DPR_HIP(hipMalloc(&b.KA, vec * sizeof(uint64_t)));
-    DPR_HIP(hipMemset(b.U, 0, vec * sizeof(double)));
-    DPR_HIP(hipMemset(b.Ur, 0, vec * sizeof(double)));
-    DPR_HIP(hipMemset(b.KA, 0, vec * sizeof(uint64_t)));
+    DPR_HIP(hipMemsetAsync(b.U, 0, vec * sizeof(double), s));
+    DPR_HIP(hipMemsetAsync(b.Ur, 0, vec * sizeof(double), s));
+    DPR_HIP(hipMemsetAsync(b.KA, 0, vec * sizeof(uint64_t), s));
     DPR_HIP(hipMalloc(&b.partials, sizeof(NjRecord) * kScanBlocks));
-    DPR_HIP(hipMemset(b.partials, 0xff, sizeof(NjRecord) * kScanBlocks));  // key = ~0: "no candidate"
+    DPR_HIP(hipMemsetAsync(b.partials, 0xff, sizeof(NjRecord) * kScanBlocks, s));  // key = ~0: "no candidate"
     DPR_HIP(hipMalloc(&b.recs, sizeof(NjRecord) * (size_t)(world > 1 ? world : 1)));
     DPR_HIP(hipMalloc(&b.xpart, sizeof(double) * (size_t)((N + kThreads - 1) / kThreads + 1)));
     {
@@ -524,8 +526,8 @@ int nj_alloc(NjBuffers& b, int64_t N, int rank, int world)
         if (world > 1) {
             DPR_HIP(hipMalloc(&b.slice, sizeof(double) * (size_t)(3 * b.slice_len)));
             DPR_HIP(hipMalloc(&b.gath, sizeof(double) * (size_t)(3 * b.slice_len * world)));
-            DPR_HIP(hipMemset(b.slice, 0, sizeof(double) * (size_t)(3 * b.slice_len)));
-            DPR_HIP(hipMemset(b.gath, 0, sizeof(double) * (size_t)(3 * b.slice_len * world)));
+            DPR_HIP(hipMemsetAsync(b.slice, 0, sizeof(double) * (size_t)(3 * b.slice_len), s));
+            DPR_HIP(hipMemsetAsync(b.gath, 0, sizeof(double) * (size_t)(3 * b.slice_len * world), s));
         }
     }
     DPR_HIP(hipMalloc(&b.st, sizeof(NjState)));

@@ -111,3 +111,51 @@ def test_config3_divide_and_conquer_1m():
     sizes = np.bincount(cl[B:])
     assert sizes.sum() == n - B and sizes.max() < B
     assert full["stats"]["clusters"] == int((sizes > 0).sum())
+
+
+def _dirty_device_memory(total_bytes, byte=0xFF, chunk=2 << 30):
+    """Fill `total_bytes` of device memory with a byte pattern (0xFF = NaN as fp64) and free it again, through the
+    HIP runtime the library already loaded: what the next hipMalloc hands out is then visibly not zero."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    ptrs = []
+    for _ in range(int(total_bytes // chunk)):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), chunk) == 0
+        assert hip.hipMemset(p, byte, chunk) == 0
+        ptrs.append(p)
+    assert hip.hipDeviceSynchronize() == 0
+    for p in ptrs:
+        assert hip.hipFree(p) == 0
+
+
+def test_config1_matrix_build_is_stream_ordered():
+    """Regression: the 7 GB zero fill of a fresh 30 000-tip matrix ran on the null stream, which the context's
+    non-blocking stream does not wait for, and wiped distance tiles that had already been written (zero blocks
+    in rows 2 000-2 700, hence different trees from run to run).  Three builds -- on memory that held zeros, NaN
+    patterns and 0x40 patterns before -- must give the same row sums bit for bit, and no row sum may be NaN."""
+    import dipper_amd
+    from dipper_amd import capi
+    n, L = 30000, 1000
+    seqs = _util.synth_alignment(np.random.default_rng(1), n, L, mean_bl=2e-4, lo=2e-5, hi=2e-3)
+    packed = capi.pack4_many(seqs)
+    del seqs
+    capi.set_nj_mode(0)
+    try:
+        sums = []
+        for fill in (0x00, 0xFF, 0x40):
+            d = dipper_amd.Dipper(0)          # (the context first: it loads the HIP runtime)
+            try:
+                _dirty_device_memory(24 << 30, fill)
+                d.set_msa(packed, L)
+                d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+                sums.append(d.row_sums().view(np.uint64).copy())
+            finally:
+                d.close()
+    finally:
+        capi.set_nj_mode(1)
+    assert not np.any(np.isnan(sums[0].view(np.float64)))
+    assert np.array_equal(sums[0], sums[1]) and np.array_equal(sums[0], sums[2])
