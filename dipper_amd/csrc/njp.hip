@@ -338,7 +338,6 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __rest
         // pass 1: q of the four ordered candidates of every loaded pair; a dead row or column (NaN row sum) and a
         // masked entry (NaN distance) give a NaN q, which fmin drops and no comparison selects.  m0 / m1: the
         // exact minimum over the live rows of this lane's two columns (dead rows add NaN, which fmin drops).
-        double q[kUR][4];
         double lm = __builtin_inf(), m0 = __builtin_inf(), m1 = __builtin_inf();
 #pragma unroll
         for (int u8 = 0; u8 < kUR; ++u8) {
@@ -346,27 +345,30 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __rest
             const double rn = ua[u8] == ua[u8] ? 0.0 : __builtin_nan("");   // wave-uniform
             m0 = fmin(m0, d0 + rn);
             m1 = fmin(m1, d1 + rn);
-            q[u8][0] = (d0 - ua[u8]) - ub0;   // (i=a,  j=b0)
-            q[u8][1] = (d0 - ub0) - ua[u8];   // (i=b0, j=a)
-            q[u8][2] = (d1 - ua[u8]) - ub1;
-            q[u8][3] = (d1 - ub1) - ua[u8];
-            lm = fmin(lm, fmin(fmin(q[u8][0], q[u8][1]), fmin(q[u8][2], q[u8][3])));
+            const double q0 = (d0 - ua[u8]) - ub0;   // (i=a,  j=b0)
+            const double q1 = (d0 - ub0) - ua[u8];   // (i=b0, j=a)
+            const double q2 = (d1 - ua[u8]) - ub1;
+            const double q3 = (d1 - ub1) - ua[u8];
+            lm = fmin(lm, fmin(fmin(q0, q1), fmin(q2, q3)));
         }
         double m = fmin(fmin(live0 ? m0 : __builtin_nan(""), live1 ? m1 : __builtin_nan("")), __builtin_inf());   // +inf: no live pair
         const double wm = wave_fmin(lm);          // +inf when the wave saw no valid candidate
-        if (wm <= bq) {                           // wave-uniform
-            if (wm < bq) { bq = wm; bk = ~0ull; }
+        if (wm <= bq) {                           // wave-uniform; the q are recomputed (same operations, same bits)
+            if (wm < bq) { bq = wm; bk = ~0ull; }   // rather than kept: 128 registers less, twice the blocks per CU
 #pragma unroll
             for (int u8 = 0; u8 < kUR; ++u8) {
-                const bool e0 = q[u8][0] == wm, e1 = q[u8][1] == wm, e2 = q[u8][2] == wm, e3 = q[u8][3] == wm;
+                double d0 = v[u8].x, d1 = v[u8].y;
+                asm volatile("" : "+v"(d0), "+v"(d1));    // opaque: keeps the compiler from holding pass 1's 64 q alive
+                const bool e0 = (d0 - ua[u8]) - ub0 == wm, e1 = (d0 - ub0) - ua[u8] == wm;
+                const bool e2 = (d1 - ua[u8]) - ub1 == wm, e3 = (d1 - ub1) - ua[u8] == wm;
                 if (__builtin_amdgcn_ballot_w64(e0 | e1 | e2 | e3) != 0ull) {
                     const uint64_t pa = (uint64_t)(a0 + u8);
                     const uint64_t kaa = readlane_u64(kaa_l, u8), kba = readlane_u64(kba_l, u8);
                     const uint64_t k0 = kaa | kb0, k1 = ka0 | kba, k2 = kaa | kb1, k3 = ka1 | kba;
-                    if (e0 & (k0 < bk)) { bk = k0; bp = pa | ((uint64_t)b0 << 32); bd = v[u8].x; }
-                    if (e1 & (k1 < bk)) { bk = k1; bp = (uint64_t)b0 | (pa << 32); bd = v[u8].x; }
-                    if (e2 & (k2 < bk)) { bk = k2; bp = pa | ((uint64_t)b1 << 32); bd = v[u8].y; }
-                    if (e3 & (k3 < bk)) { bk = k3; bp = (uint64_t)b1 | (pa << 32); bd = v[u8].y; }
+                    if (e0 & (k0 < bk)) { bk = k0; bp = pa | ((uint64_t)b0 << 32); bd = d0; }
+                    if (e1 & (k1 < bk)) { bk = k1; bp = (uint64_t)b0 | (pa << 32); bd = d0; }
+                    if (e2 & (k2 < bk)) { bk = k2; bp = pa | ((uint64_t)b1 << 32); bd = d1; }
+                    if (e3 & (k3 < bk)) { bk = k3; bp = (uint64_t)b1 | (pa << 32); bd = d1; }
                 }
             }
         }
