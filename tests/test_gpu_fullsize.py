@@ -113,23 +113,7 @@ def test_config3_divide_and_conquer_1m():
     assert full["stats"]["clusters"] == int((sizes > 0).sum())
 
 
-def _dirty_device_memory(total_bytes, byte=0xFF, chunk=2 << 30):
-    """Fill `total_bytes` of device memory with a byte pattern (0xFF = NaN as fp64) and free it again, through the
-    HIP runtime the library already loaded: what the next hipMalloc hands out is then visibly not zero."""
-    import ctypes as C
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
-    hip.hipFree.argtypes = [C.c_void_p]
-    ptrs = []
-    for _ in range(int(total_bytes // chunk)):
-        p = C.c_void_p()
-        assert hip.hipMalloc(C.byref(p), chunk) == 0
-        assert hip.hipMemset(p, byte, chunk) == 0
-        ptrs.append(p)
-    assert hip.hipDeviceSynchronize() == 0
-    for p in ptrs:
-        assert hip.hipFree(p) == 0
+from tests.conftest import dirty_device_memory as _dirty_device_memory
 
 
 def test_config1_matrix_build_is_stream_ordered():
