@@ -795,7 +795,7 @@ int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
     const char* e_min = std::getenv("DPR_NJ_EPOCH_MIN");
     const int64_t epoch_min = e_min ? std::atoll(e_min) : 2048;   // epochs smaller than this are not rebuilt
     const char* e_pct = std::getenv("DPR_NJ_EPOCH_PCT");
-    const int64_t pct = e_pct ? std::atoll(e_pct) : 70;           // rebuild once n <= pct% of the epoch's positions
+    const int64_t pct = e_pct ? std::atoll(e_pct) : 80;           // rebuild once n <= pct% of the epoch's positions (sweep: profiles/epoch_sweep2.sh)
     int64_t it = it0, left = todo;
     if (left <= 0) return njp_run_segment(b, it0, 0, s);
     while (left > 0) {
