@@ -168,11 +168,17 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
     const int64_t gx = px >= 0 ? px / kUR : -1;
     const bool gx_here = px >= 0 && gx >= (int64_t)blk_g0[blockIdx.x] && gx < (int64_t)blk_g0[blockIdx.x] + kThreads;   // block-uniform
     const double* __restrict__ rowx = D + (px >= 0 ? px : 0) * ld;
-    double uenc_d = PINF;
+    // Every unit carries FOUR bounds, one per 128-column sub-strip (the columns of one wave of the scan kernel):
+    // the test keeps a unit if any sub-unit survives and hands the scan a 4-bit mask, so a wave whose sub-unit
+    // cannot hold the winner neither loads nor evaluates its 16 x 128 block.
+    const int wpx = px >= 0 ? (int)((px % kTileCols) / (kTileCols / 4)) : -1;    // sub-strip of the new node's column
+    double u4[4] = { PINF, PINF, PINF, PINF };
     double rmax = NINF; bool px_in_group = false;
-    double newmin = PINF;
+    double newminA = PINF;                                  // new row x this group's rows (sub-strip wpx of px's strip)
+    unsigned long long* up4 = umin + ((int64_t)cb * G16 + (have ? g : 0)) * 4;
     if (have) {
-        uenc_d = dec_f64(umin[(int64_t)cb * G16 + g]);
+        const ulonglong2 ua = *reinterpret_cast<const ulonglong2*>(up4), ub = *reinterpret_cast<const ulonglong2*>(up4 + 2);
+        u4[0] = dec_f64(ua.x); u4[1] = dec_f64(ua.y); u4[2] = dec_f64(ub.x); u4[3] = dec_f64(ub.y);
         const int64_t a0 = g * kUR;
 #pragma unroll
         for (int r = 0; r < kUR; ++r) {
@@ -181,21 +187,24 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
             else if (p < P) {
                 const double v = Ur[p];
                 const double dv = px_strip ? rowx[p] : PINF;      // block-uniform; both loads issue together
-                if (v == v) { rmax = fmax(rmax, v); if (p > px) newmin = fmin(newmin, dv); }
+                if (v == v) { rmax = fmax(rmax, v); if (p > px) newminA = fmin(newminA, dv); }
             }
         }
     }
-    // column maximum of this block's strip, px excluded for now; minimum of the new row over the strip's live columns
+    // column maximum of each sub-strip (wave w reads columns 128w .. 128w+127 of the strip), px excluded for now;
+    // minimum of the new row over the sub-strip's live columns
     double cm_part = NINF, colmin = PINF;
-    if (!beyond)
-        for (int e = tid; e < kTileCols; e += kThreads) {
-            const int64_t p = (int64_t)cb * kTileCols + e;
+    if (!beyond) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int64_t p = (int64_t)cb * kTileCols + 2 * tid + k;
             if (p < P && p != px) {
                 const double v = Ur[p];
                 const double dv = gx_here ? rowx[p] : PINF;
                 if (v == v) { cm_part = fmax(cm_part, v); if (p < px) colmin = fmin(colmin, dv); }
             }
         }
+    }
     // candidate gathers (same hop: the records were loaded up front)
     double qc = PINF;
     if (cand.key != ~0ull) {
@@ -225,30 +234,33 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
     if ((tid & 63) == 0) { sseed[tid >> 6] = qc; scm[tid >> 6] = cm_part; snew[tid >> 6] = colmin; }
     __syncthreads();
     const double bound = fmin(fmin(sseed[0], sseed[1]), fmin(sseed[2], sseed[3]));
-    double cm = fmax(fmax(scm[0], scm[1]), fmax(scm[2], scm[3]));
-    if (gx_here && g == gx) newmin = fmin(newmin, fmin(fmin(snew[0], snew[1]), fmin(snew[2], snew[3])));   // the unit (this strip, group of px)
-    // the new node's Ur joins the maxima of its group and its strip
-    if (px >= 0) {
-        if (px_strip) cm = fmax(cm, urx);
-        if (px_in_group) rmax = fmax(rmax, urx);
-    }
+    // the new node's Ur joins the maxima of its group and of its sub-strip
+    if (px_in_group) rmax = fmax(rmax, urx);
     const bool mine = have && (sh_world <= 1 || (int)(((int64_t)cb * G16 + g) % sh_world) == sh_rank);
-    bool keep = false;
+    int submask = 0;
     if (mine) {
-        if (newmin < uenc_d) {                     // persist the lowered bound (this lane is the unit's only writer here)
-            uenc_d = newmin;
-            umin[(int64_t)cb * G16 + g] = enc_f64(newmin);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            double cmw = scm[w];
+            if (px_strip && w == wpx) cmw = fmax(cmw, urx);
+            double nm = (gx_here && g == gx) ? snew[w] : PINF;            // the unit (this strip, group of px)
+            if (px_strip && w == wpx) nm = fmin(nm, newminA);
+            if (nm < u4[w]) {                          // persist the lowered bound (this lane is the unit's only writer here)
+                u4[w] = nm;
+                up4[w] = enc_f64(nm);
+            }
+            const double lb = fmin((u4[w] - rmax) - cmw, (u4[w] - cmw) - rmax);
+            if ((cmw > NINF) && (lb <= bound)) submask |= 1 << w;
         }
-        const double lb = fmin((uenc_d - rmax) - cm, (uenc_d - cm) - rmax);
-        keep = (rmax > NINF) && (cm > NINF) && (lb <= bound);
     }
+    const bool keep = mine && (rmax > NINF) && submask != 0;
     const int par = (int)(it & 1);
     const unsigned long long mask = __ballot(keep);
     const int lane = tid & 63;
     unsigned long long base = 0;
     if (lane == 0 && mask) base = atomicAdd(&cntp[par], (unsigned long long)__popcll(mask));
     base = __shfl(base, 0, 64);
-    if (keep) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)((cb << 20) | (int)g);   // strip | group
+    if (keep) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)(((uint32_t)submask << 28) | ((uint32_t)cb << 18) | (uint32_t)g);   // sub-unit mask | strip | group
 }
 
 // scan the listed units: block b takes entries b, b+G, ... and always writes partials[b] when it had
@@ -274,7 +286,6 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __rest
 {
     __shared__ double sq[kThreads / 64], sd[kThreads / 64];
     __shared__ uint64_t sk[kThreads / 64], sp[kThreads / 64];
-    __shared__ double smin[2][kThreads / 64];
 
     const int tid = threadIdx.x;
     // hop 1: state line and (speculatively) this block's first list entry
@@ -298,12 +309,13 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __rest
     double bq = 10000.0, bd = 0.0;  // the reference's init value
     uint64_t bk = ~0ull, bp = 0;
     int64_t scanned = 0;
-    int flip = 0;
 
-    for (int64_t e = blockIdx.x; e < cnt; e += gridDim.x, ++scanned, flip ^= 1) {
-        const int code = __builtin_amdgcn_readfirstlane(e == (int64_t)blockIdx.x ? first : list[e]);
-        const int cb = code >> 20;
-        const int64_t g_s = (int64_t)(code & 0xFFFFF);
+    const int wv = tid >> 6;                         // this wave's sub-strip of every unit
+    for (int64_t e = blockIdx.x; e < cnt; e += gridDim.x, ++scanned) {
+        const uint32_t code = (uint32_t)__builtin_amdgcn_readfirstlane(e == (int64_t)blockIdx.x ? first : list[e]);
+        if (!((code >> (28 + wv)) & 1u)) continue;   // the bound of this wave's sub-unit rules it out (wave-uniform)
+        const int cb = (int)((code >> 18) & 1023u);
+        const int64_t g_s = (int64_t)(code & 0x3FFFFu);
         const int64_t c0 = (int64_t)cb * kTileCols, a0 = g_s * kUR;
         // Rows a0 .. a0+15 are always read: the matrix has a zeroed group of rows behind position P and the
         // vectors carry NaN row sums there (njp_alloc_epoch), so rows >= P behave like dead rows.
@@ -372,12 +384,9 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __rest
                 }
             }
         }
-        // exact unit minimum -> umin (double-buffered LDS: one barrier per unit)
+        // exact minimum of this wave's sub-unit -> its bound (no cross-wave step any more)
         m = wave_fmin(m);
-        if ((tid & 63) == 0) smin[flip][tid >> 6] = m;
-        __syncthreads();
-        if (tid == 0)
-            umin[(int64_t)cb * G16 + g_s] = enc_f64(fmin(fmin(smin[flip][0], smin[flip][1]), fmin(smin[flip][2], smin[flip][3])));
+        if ((tid & 63) == 0) umin[((int64_t)cb * G16 + g_s) * 4 + wv] = enc_f64(m);
     }
 
     // wave winner: the smallest key among the lanes' candidates at bq, then that lane's positions and distance
@@ -532,6 +541,7 @@ static int64_t round_up16(int64_t v) { return (v + 15) / 16 * 16; }
 // allocate the position-space structures of an epoch with P positions (N = total tips: slot arrays)
 static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, hipStream_t s)
 {
+    if (P >= (int64_t)kTileCols * 1024) { set_error("pruned NJ: the list encoding holds fewer than 524288 positions"); return DPR_ERR_ARG; }
     q.P = P;
     q.ld = round_up16(P);
     const int64_t rows_alloc = (P + kUR - 1) / kUR * kUR + kUR;
@@ -553,7 +563,7 @@ static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, hipStream_t s)
     DPR_HIP(hipMemsetAsync(q.slot_of_pos, 0xff, sizeof(int32_t) * vec, s));
     DPR_HIP(hipMemsetAsync(q.pos_of_slot, 0xff, sizeof(int32_t) * vec, s));   // -1: slot not alive
     const int64_t G16 = (P + kUR - 1) / kUR, S = (P + kTileCols - 1) / kTileCols + 1;
-    q.nunits_alloc = S * G16;
+    q.nunits_alloc = S * G16 * 4;      // four sub-strip bounds per unit
     DPR_HIP(hipMalloc(&q.umin, sizeof(uint64_t) * (size_t)q.nunits_alloc));
     q.utot = unit_total(P);
     {
