@@ -604,6 +604,11 @@ static void sort_by_row_sum(std::vector<int32_t>& perm, const std::vector<double
 
 int njp_build(NjBuffers& b, hipStream_t s)
 {
+    {   // blocks of the unit scan (tests shrink it so that every block walks several units and cnt > grid)
+        const char* e = std::getenv("DPR_NJP_GRID");
+        const int g = e ? std::atoi(e) : 1024;
+        g_njp_grid = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+    }
     // b.D / b.U hold the matrix and the row sums in tip order (world == 1).  Sort by U ascending.
     const int64_t N = b.N;
     std::vector<double> hU((size_t)N);

@@ -172,6 +172,37 @@ def test_nj_epoch_rebuilds(orc, monkeypatch, n, kind):
         d.close()
 
 
+@pytest.mark.parametrize("grid,n,kind", [(3, 1500, "additive"), (1, 900, "ties"), (7, 2100, "ties"), (5, 1200, "noisy")])
+def test_nj_pruned_small_scan_grid(orc, monkeypatch, grid, n, kind):
+    """The unit scan with very few blocks (DPR_NJP_GRID): every block walks many listed units (the wave keeps its
+    best across units, pass 2 runs only for units that reach it), the number of listed units exceeds the grid,
+    and the seed records are the first `grid` ones -- same merge log as the oracle."""
+    import dipper_amd
+    from dipper_amd import capi
+    monkeypatch.setenv("DPR_NJP_GRID", str(grid))
+    monkeypatch.setenv("DPR_NJ_EPOCH_MIN", "256")
+    rng = np.random.default_rng(1000 + n)
+    if kind == "additive":
+        D = _util.random_additive_matrix(rng, n)
+    elif kind == "ties":
+        D = np.round(_util.random_additive_matrix(rng, n, zero_frac=0.4), 1)
+    else:
+        D = np.round(rng.random((n, n)), 3)
+        D = np.tril(D, -1) + np.tril(D, -1).T
+    capi.set_nj_mode(1)
+    d = dipper_amd.Dipper(0)
+    try:
+        d.set_matrix_full(D)
+        d.dist_matrix(capi.SRC_MATRIX)
+        ref = orc.nj_run(np.tril(D, -1))
+        res = d.nj_run()
+        for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
+            assert np.array_equal(res[key], ref[key]), key
+        assert res["last_d"] == ref["last_d"]
+    finally:
+        d.close()
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_nj_unit_sharded_virtual_ranks(orc, monkeypatch, world):
     """multi-GPU pruned NJ (every rank holds the matrix, the unit tests / scans are shared, one all-gather of
