@@ -444,36 +444,45 @@ __global__ __launch_bounds__(kTipThreads) void place_tip_kernel(PlaceBuffers p, 
     double add = 2.0, d1 = 0.0;
     int eid = 0;
     bool have = idx < live;
-    if (have && p.belong[idx] >= p.e[idx]) {
-        eid = (int)idx;
-        const int oe = p.rev[idx];
+    // Three dependent round trips instead of four: everything whose address follows from the slot number is loaded
+    // up front (eligibility, reverse slot, length, the slot's own list) and the eligibility test comes afterwards;
+    // then the reverse slot's list together with the distance gathers of the own list; then the remaining gathers.
+    int myrev = -1;
+    if (have) {
+        const int sl = (int)idx;
+        const int bel = p.belong[sl], tgt = p.e[sl];
+        const int oe = p.rev[sl];
+        const double L = p.len[sl];
         double cd[2 * K5];
         int ci[2 * K5];
 #pragma unroll
-        for (int i = 0; i < K5; ++i) { ci[i] = p.cid[eid * K5 + i]; cd[i] = p.cdis[eid * K5 + i]; }
+        for (int i = 0; i < K5; ++i) { ci[i] = p.cid[sl * K5 + i]; cd[i] = p.cdis[sl * K5 + i]; }
+        if (bel >= tgt) {
+            eid = sl;
+            myrev = oe;
 #pragma unroll
-        for (int i = 0; i < K5; ++i) { ci[K5 + i] = p.cid[oe * K5 + i]; cd[K5 + i] = p.cdis[oe * K5 + i]; }
-        double dv[2 * K5];
+            for (int i = 0; i < K5; ++i) { ci[K5 + i] = p.cid[oe * K5 + i]; cd[K5 + i] = p.cdis[oe * K5 + i]; }
+            double dv[2 * K5];
 #pragma unroll
-        for (int i = 0; i < 2 * K5; ++i) dv[i] = ci[i] != -1 ? dis[ci[i]] : 0.0;
-        double dis1 = 0, dis2 = 0, val;
+            for (int i = 0; i < 2 * K5; ++i) dv[i] = ci[i] != -1 ? dis[ci[i]] : 0.0;
+            double dis1 = 0, dis2 = 0, val;
 #pragma unroll
-        for (int i = 0; i < K5; ++i)
-            if (ci[i] != -1) { val = dv[i] - cd[i]; if (val > dis1) dis1 = val; }
+            for (int i = 0; i < K5; ++i)
+                if (ci[i] != -1) { val = dv[i] - cd[i]; if (val > dis1) dis1 = val; }
 #pragma unroll
-        for (int i = 0; i < K5; ++i)
-            if (ci[K5 + i] != -1) { val = dv[K5 + i] - cd[K5 + i]; if (val > dis2) dis2 = val; }
-        const double L = p.len[eid];
-        double a = (dis1 + dis2 - L) / 2;
-        if (a < 0) a = 0;
-        dis1 -= a; dis2 -= a;
-        if (dis1 < 0) dis1 = 0;
-        if (dis2 < 0) dis2 = 0;
-        if (dis1 > L) { a += dis1 - L; dis1 = L; }
-        if (dis2 > L) { a += dis2 - L; dis2 = L; }
-        const double rest = L - dis1 - dis2;
-        dis1 += rest / 2; dis2 += rest / 2;
-        add = a; d1 = dis1;
+            for (int i = 0; i < K5; ++i)
+                if (ci[K5 + i] != -1) { val = dv[K5 + i] - cd[K5 + i]; if (val > dis2) dis2 = val; }
+            double a = (dis1 + dis2 - L) / 2;
+            if (a < 0) a = 0;
+            dis1 -= a; dis2 -= a;
+            if (dis1 < 0) dis1 = 0;
+            if (dis2 < 0) dis2 = 0;
+            if (dis1 > L) { a += dis1 - L; dis1 = L; }
+            if (dis2 > L) { a += dis2 - L; dis2 = L; }
+            const double rest = L - dis1 - dis2;
+            dis1 += rest / 2; dis2 += rest / 2;
+            add = a; d1 = dis1;
+        }
     }
     // first minimum of add over idx (thrust::min_element): key (add, idx); NaN never wins
     double badd = have ? add : __builtin_inf();
@@ -496,7 +505,7 @@ __global__ __launch_bounds__(kTipThreads) void place_tip_kernel(PlaceBuffers p, 
     __syncthreads();
     // the winner of the block publishes its tuple
     if (have && (int)idx == sidx[0]) {
-        PlacePartial pp; pp.add = add; pp.idx = (int)idx; pp.eid = eid; pp.frac = d1; pp.rev = eid ? p.rev[eid] : -1; pp.pad = 0;
+        PlacePartial pp; pp.add = add; pp.idx = (int)idx; pp.eid = eid; pp.frac = d1; pp.rev = eid ? myrev : -1; pp.pad = 0;
         partials[blockIdx.x] = pp;
     }
     if (threadIdx.x == 0 && sidx[0] == 0x7fffffff) {
