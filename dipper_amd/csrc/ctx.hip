@@ -628,6 +628,7 @@ int dpr_get_iterstats(dpr_ctx* c, uint64_t* out, int64_t iters)
 {
     if (!c || !c->have_matrix || !c->nj[0].pr.iterstats) { set_error("dpr_get_iterstats: not enabled"); return DPR_ERR_STATE; }
     DPR_HIP(hipStreamSynchronize(c->stream));   // the plain copies below run on the null stream, which does not wait for c->stream
+    // iters > N - 2 reads on into the tail (iters = N + 33 returns the 64 phase-clock words behind the 2N + 2 counters)
     DPR_HIP(hipMemcpy(out, c->nj[0].pr.iterstats, sizeof(uint64_t) * (size_t)(2 * iters), hipMemcpyDeviceToHost));
     return DPR_OK;
 }

@@ -126,13 +126,18 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
                                                             int64_t P, const int32_t* __restrict__ blk_cb,
                                                             const int32_t* __restrict__ blk_g0, int scan_grid,
                                                             int32_t* __restrict__ list, int sh_rank, int sh_world,
-                                                            unsigned long long* __restrict__ cnt_rank, int nrec_fixed)
+                                                            unsigned long long* __restrict__ cnt_rank, int nrec_fixed,
+                                                            unsigned long long* __restrict__ clk)
 {
     __shared__ double s[kThreads];
     __shared__ double sseed[kThreads / 64];
     __shared__ double scm[kThreads / 64];
     __shared__ double snew[kThreads / 64];
     const int tid = threadIdx.x;
+    // optional phase clocks (DPR_NJ_ITERSTATS; profiles/nj_clocks.py): thread 0 of block 0 and of the middle block
+    const bool clocked = clk != nullptr && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2);
+    unsigned long long ck[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    if (clocked) ck[0] = wall_clock64();
     // hop 1: the state line, this block's (strip, first group) -- blocks never span strips -- and, speculatively,
     // this thread's seed record (its index depends on the launch arguments only)
     const int64_t nrec_arg = nrec_fixed >= 0 ? (int64_t)(nrec_fixed < scan_grid ? nrec_fixed : scan_grid) : -1;
@@ -152,6 +157,7 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
     if (beyond && (blockIdx.x != 0 || it == 0)) return;       // only block 0 materialises U[px]
     const int64_t n = N - it;
     const double NINF = -__builtin_inf(), PINF = __builtin_inf();
+    if (clocked) { __builtin_amdgcn_s_waitcnt(0); ck[1] = wall_clock64(); }
 
     // hop 2: every other load of this block
     const int64_t nchunk = it > 0 ? (n + 1 + kThreads - 1) / kThreads : 0;
@@ -176,19 +182,46 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
     double rmax = NINF; bool px_in_group = false;
     double newminA = PINF;                                  // new row x this group's rows (sub-strip wpx of px's strip)
     unsigned long long* up4 = umin + ((int64_t)cb * G16 + (have ? g : 0)) * 4;
+    // All loads of this round trip are issued before the first use, without data-dependent branches in between
+    // (measured with the phase clocks: as a loop of "load, test, use" the sixteen row sums of a lane arrived one
+    // after the other, 4.3 us; the vectors are padded with NaN behind P, so every address is valid).
+    v2d urow[kUR / 2], drow[kUR / 2];
+    ulonglong2 um0 = make_ulonglong2(0ull, 0ull), um1 = um0;
+    const int64_t a0 = (have ? g : 0) * kUR;                       // 128-byte aligned: eight 16-byte loads
+    const int64_t pc0 = (int64_t)cb * kTileCols + 2 * tid;         // this thread's two strip columns (< P + 512)
+    if (have) { um0 = *reinterpret_cast<const ulonglong2*>(up4); um1 = *reinterpret_cast<const ulonglong2*>(up4 + 2); }
+#pragma unroll
+    for (int r = 0; r < kUR / 2; ++r) urow[r] = *reinterpret_cast<const v2d*>(Ur + a0 + 2 * r);
+    const v2d ucol = *reinterpret_cast<const v2d*>(Ur + pc0);
+    v2d dcol; dcol.x = PINF; dcol.y = PINF;
+    if (px_strip) {                                                // block-uniform
+#pragma unroll
+        for (int r = 0; r < kUR / 2; ++r) drow[r] = *reinterpret_cast<const v2d*>(rowx + a0 + 2 * r);
+    } else {
+#pragma unroll
+        for (int r = 0; r < kUR / 2; ++r) { drow[r].x = PINF; drow[r].y = PINF; }
+    }
+    if (gx_here) dcol = *reinterpret_cast<const v2d*>(rowx + pc0);  // block-uniform; row px is readable up to its padded end
+    // candidate gathers (same round trip: the records were loaded up front)
+    double cd = 0.0, cua = __builtin_nan(""), cub = __builtin_nan("");
+    if (cand.key != ~0ull) {
+        const int64_t pi = (int64_t)(cand.pad & 0xffffffffull), pj = (int64_t)(cand.pad >> 32);
+        const int64_t pa = pi > pj ? pi : pj, pb = pi > pj ? pj : pi;
+        // the record carries D[pa][pb]; the entry is unchanged since the scan (neither end is the new node, and a
+        // dead end gives a NaN row sum) -- no gather into the 7 GB matrix (a cold TLB walk per launch)
+        if (pa < P && pb < pa && pa != px && pb != px) { cd = cand.d; cua = Ur[pa]; cub = Ur[pb]; }
+    }
     if (have) {
-        const ulonglong2 ua = *reinterpret_cast<const ulonglong2*>(up4), ub = *reinterpret_cast<const ulonglong2*>(up4 + 2);
-        u4[0] = dec_f64(ua.x); u4[1] = dec_f64(ua.y); u4[2] = dec_f64(ub.x); u4[3] = dec_f64(ub.y);
-        const int64_t a0 = g * kUR;
+        u4[0] = dec_f64(um0.x); u4[1] = dec_f64(um0.y); u4[2] = dec_f64(um1.x); u4[3] = dec_f64(um1.y);
 #pragma unroll
         for (int r = 0; r < kUR; ++r) {
             const int64_t p = a0 + r;
-            if (p == px) px_in_group = true;
-            else if (p < P) {
-                const double v = Ur[p];
-                const double dv = px_strip ? rowx[p] : PINF;      // block-uniform; both loads issue together
-                if (v == v) { rmax = fmax(rmax, v); if (p > px) newminA = fmin(newminA, dv); }
-            }
+            const double v = (r & 1) ? urow[r >> 1].y : urow[r >> 1].x;
+            const double dv = (r & 1) ? drow[r >> 1].y : drow[r >> 1].x;
+            px_in_group |= p == px;
+            const bool live = (v == v) & (p != px);                // dead positions and the padding behind P carry NaN
+            rmax = live ? fmax(rmax, v) : rmax;
+            newminA = (live & (p > px)) ? fmin(newminA, dv) : newminA;
         }
     }
     // column maximum of each sub-strip (wave w reads columns 128w .. 128w+127 of the strip), px excluded for now;
@@ -197,26 +230,17 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
     if (!beyond) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int64_t p = (int64_t)cb * kTileCols + 2 * tid + k;
-            if (p < P && p != px) {
-                const double v = Ur[p];
-                const double dv = gx_here ? rowx[p] : PINF;
-                if (v == v) { cm_part = fmax(cm_part, v); if (p < px) colmin = fmin(colmin, dv); }
-            }
+            const int64_t p = pc0 + k;
+            const double v = k ? ucol.y : ucol.x;
+            const double dv = k ? dcol.y : dcol.x;
+            const bool live = (v == v) & (p != px);
+            cm_part = live ? fmax(cm_part, v) : cm_part;
+            colmin = (live & (p < px)) ? fmin(colmin, dv) : colmin;
         }
     }
-    // candidate gathers (same hop: the records were loaded up front)
     double qc = PINF;
-    if (cand.key != ~0ull) {
-        const int64_t pi = (int64_t)(cand.pad & 0xffffffffull), pj = (int64_t)(cand.pad >> 32);
-        const int64_t pa = pi > pj ? pi : pj, pb = pi > pj ? pj : pi;
-        if (pa < P && pb < pa && pa != px && pb != px) {
-            const double cd = D[pa * ld + pb];
-            const double cua = Ur[pa], cub = Ur[pb];
-            if (cua == cua && cub == cub) qc = fmin((cd - cua) - cub, (cd - cub) - cua);
-        }
-    }
-
+    if (cua == cua && cub == cub) qc = fmin((cd - cua) - cub, (cd - cub) - cua);
+    if (clocked) { __builtin_amdgcn_s_waitcnt(0); ck[2] = wall_clock64(); }
     // ---- reductions
     double urx = 0.0;
     if (it > 0) {
@@ -228,6 +252,7 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
         if (blockIdx.x == 0 && tid == 0) { U_w[px] = ux; Ur_w[px] = urx; }
     }
     if (beyond) return;
+    if (clocked) ck[3] = wall_clock64();
     qc = wave_fmin(qc);
     cm_part = wave_fmax(cm_part);
     if (gx_here) colmin = wave_fmin(colmin);
@@ -254,13 +279,22 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
         }
     }
     const bool keep = mine && (rmax > NINF) && submask != 0;
+    if (clocked) ck[4] = wall_clock64();
     const int par = (int)(it & 1);
     const unsigned long long mask = __ballot(keep);
     const int lane = tid & 63;
     unsigned long long base = 0;
     if (lane == 0 && mask) base = atomicAdd(&cntp[par], (unsigned long long)__popcll(mask));
     base = __shfl(base, 0, 64);
+    if (clocked) { __builtin_amdgcn_s_waitcnt(0); ck[5] = wall_clock64(); }
     if (keep) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)(((uint32_t)submask << 28) | ((uint32_t)cb << 18) | (uint32_t)g);   // sub-unit mask | strip | group
+    if (clocked) {
+        __builtin_amdgcn_s_waitcnt(0);
+        ck[6] = wall_clock64();
+        unsigned long long* o = clk + (blockIdx.x == 0 ? 0 : 8);
+        atomicAdd(&o[0], 1ull);
+        for (int k = 1; k < 7; ++k) atomicAdd(&o[k], ck[k] - ck[k - 1]);
+    }
 }
 
 // scan the listed units: block b takes entries b, b+G, ... and always writes partials[b] when it had
@@ -622,8 +656,8 @@ int njp_build(NjBuffers& b, hipStream_t s)
     q.utot0 = q.utot;
     DPR_HIP(hipMemcpyAsync(q.perm, perm.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, s));
     if (std::getenv("DPR_NJ_ITERSTATS")) {
-        DPR_HIP(hipMalloc(&q.iterstats, sizeof(uint64_t) * (size_t)(2 * N + 2)));
-        DPR_HIP(hipMemsetAsync(q.iterstats, 0, sizeof(uint64_t) * (size_t)(2 * N + 2), s));
+        DPR_HIP(hipMalloc(&q.iterstats, sizeof(uint64_t) * (size_t)(2 * N + 2 + 64)));      // + phase clocks of the prep kernel
+        DPR_HIP(hipMemsetAsync(q.iterstats, 0, sizeof(uint64_t) * (size_t)(2 * N + 2 + 64), s));
     }
     dim3 grid((unsigned)((N + kThreads - 1) / kThreads > 64 ? 64 : (N + kThreads - 1) / kThreads), (unsigned)(N < 32768 ? N : 32768));
     hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, b.D, b.ld, q.D, q.ld, q.perm, N);
@@ -712,7 +746,8 @@ static int njp_launch_prep(NjBuffers& b, hipStream_t s, int v = 0)
     hipLaunchKernelGGL(njp_prep_kernel, dim3((unsigned)q.nprep), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.U, q.Ur, q.Ur,
                        b.xpart, b.partials, (unsigned long long*)q.umin, q.P, q.blk_cb, q.blk_g0, njp_grid_total(q),
                        q.list + (int64_t)slot * q.list_stride, sh ? v : 0, sh ? q.sh_world : 1,
-                       sh ? q.cnt_all + 2 * slot : (unsigned long long*)nullptr, sh ? njp_grid_total(q) : -1);
+                       sh ? q.cnt_all + 2 * slot : (unsigned long long*)nullptr, sh ? njp_grid_total(q) : -1,
+                       q.iterstats ? (unsigned long long*)q.iterstats + 2 * b.N + 2 : (unsigned long long*)nullptr);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
