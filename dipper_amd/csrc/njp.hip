@@ -241,7 +241,13 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
     double qc = PINF;
     if (cua == cua && cub == cub) qc = fmin((cd - cua) - cub, (cd - cub) - cua);
     if (clocked) { __builtin_amdgcn_s_waitcnt(0); ck[2] = wall_clock64(); }
-    // ---- reductions
+    // ---- reductions: the wave results go to LDS before the tree, whose barriers publish them as well
+    if (!beyond) {
+        qc = wave_fmin(qc);
+        cm_part = wave_fmax(cm_part);
+        if (gx_here) colmin = wave_fmin(colmin);
+        if ((tid & 63) == 0) { sseed[tid >> 6] = qc; scm[tid >> 6] = cm_part; snew[tid >> 6] = colmin; }
+    }
     double urx = 0.0;
     if (it > 0) {
         double ux = block_tree256_lane0(acc, s);
@@ -250,14 +256,11 @@ __global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __rest
         ux = s[0];
         urx = ux / (double)(n - 2);
         if (blockIdx.x == 0 && tid == 0) { U_w[px] = ux; Ur_w[px] = urx; }
+    } else {
+        __syncthreads();
     }
     if (beyond) return;
     if (clocked) ck[3] = wall_clock64();
-    qc = wave_fmin(qc);
-    cm_part = wave_fmax(cm_part);
-    if (gx_here) colmin = wave_fmin(colmin);
-    if ((tid & 63) == 0) { sseed[tid >> 6] = qc; scm[tid >> 6] = cm_part; snew[tid >> 6] = colmin; }
-    __syncthreads();
     const double bound = fmin(fmin(sseed[0], sseed[1]), fmin(sseed[2], sseed[3]));
     // the new node's Ur joins the maxima of its group and of its sub-strip
     if (px_in_group) rmax = fmax(rmax, urx);
@@ -322,6 +325,9 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __rest
     __shared__ uint64_t sk[kThreads / 64], sp[kThreads / 64];
 
     const int tid = threadIdx.x;
+    const bool clocked = iterstats != nullptr && tid == 0 && blockIdx.x == 0;     // phase clocks (profiles/nj_clocks.py)
+    unsigned long long ck[5] = { 0, 0, 0, 0, 0 };
+    if (clocked) ck[0] = wall_clock64();
     // hop 1: state line and (speculatively) this block's first list entry
     const int64_t it = st->itb, limit = st->it_limit;
     const int32_t first = list[blockIdx.x];
@@ -335,6 +341,7 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __rest
         return;
     }
     const int64_t G16 = (P + kUR - 1) / kUR;
+    if (clocked) { __builtin_amdgcn_s_waitcnt(0); ck[1] = wall_clock64(); }
     // Two passes per unit instead of a (q, key, positions, d) compare-and-select per candidate (64 candidates
     // per lane and unit, ~20 VALU instructions each, were 2 us of this kernel's critical path): pass 1 computes
     // the candidates' q and their minimum over the WAVE; pass 2 -- only when that minimum reaches the wave's
@@ -372,6 +379,7 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __rest
         double ua[kUR];
 #pragma unroll
         for (int u8 = 0; u8 < kUR; ++u8) ua[u8] = readlane_f64(ua_l, u8);
+        if (clocked && ck[2] == 0) { __builtin_amdgcn_s_waitcnt(0); ck[2] = wall_clock64(); }
         if (diag) {   // block-uniform and rare (units on the diagonal): mask the entries with column >= row
             const int ib0 = (int)b0, ia0 = (int)a0;
 #pragma unroll
@@ -423,6 +431,7 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __rest
         if ((tid & 63) == 0) umin[((int64_t)cb * G16 + g_s) * 4 + wv] = enc_f64(m);
     }
 
+    if (clocked) ck[3] = wall_clock64();
     // wave winner: the smallest key among the lanes' candidates at bq, then that lane's positions and distance
     {
         const uint64_t wk = wave_umin64(bk);
@@ -443,7 +452,15 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __rest
         rec.q = bq; rec.key = bk; rec.d = bd; rec.pad = bp;   // pad = pos_i | pos_j << 32
         partials[blockIdx.x] = rec;
         if (iterstats) { atomicAdd(&iterstats[2 * it], (unsigned long long)scanned); atomicMax(&iterstats[2 * it + 1], (unsigned long long)scanned); }
-        if (blockIdx.x == 0) st->units_scanned += (unsigned long long)cnt;   // single writer
+        if (blockIdx.x == 0) atomicAdd(&st->units_scanned, (unsigned long long)cnt);   // statistics; no load on this block's tail
+        if (clocked) {
+            __builtin_amdgcn_s_waitcnt(0);
+            ck[4] = wall_clock64();
+            unsigned long long* o = iterstats + 2 * st->N + 2 + 16;
+            atomicAdd(&o[0], 1ull);
+            if (ck[2] == 0) ck[2] = ck[1];
+            for (int k = 1; k < 5; ++k) atomicAdd(&o[k], ck[k] - ck[k - 1]);
+        }
     }
 }
 
@@ -464,11 +481,14 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
                                                             int32_t* __restrict__ log_x, int32_t* __restrict__ log_y,
                                                             double* __restrict__ log_bx, double* __restrict__ log_by,
                                                             int nrec_fixed, unsigned long long* __restrict__ cnt_all,
-                                                            int cnt_ranks)
+                                                            int cnt_ranks, unsigned long long* __restrict__ clk)
 {
     __shared__ double s[kThreads];
     __shared__ double sq[kThreads / 64], sdd[kThreads / 64];
     __shared__ uint64_t sk[kThreads / 64], spp[kThreads / 64];
+    const bool clocked = clk != nullptr && threadIdx.x == 0 && blockIdx.x == 0;   // phase clocks (profiles/nj_clocks.py)
+    unsigned long long ck[6] = { 0, 0, 0, 0, 0, 0 };
+    if (clocked) ck[0] = wall_clock64();
     // hop 1: state line, this thread's slot -> position, and (speculatively) the scan records
     const int64_t it = st->itb;   // stable: the writer below only advances st->it / st->n
     const int64_t limit = st->it_limit, N = st->N;
@@ -494,10 +514,14 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
     if (n < 3 || (int64_t)blockIdx.x * kThreads >= n) return;
     const int par = (int)(it & 1);
 
+    if (clocked) { __builtin_amdgcn_s_waitcnt(0); ck[1] = wall_clock64(); }
     // select: reduce the records (thrust::min_element, src/neighborJoining.cu:214)
     double bq = 10000.0, d = 0.0; uint64_t bk = ~0ull, bp = 0;
+    best_update4(bq, bk, bp, d, mine[0].q, mine[0].key, mine[0].pad, mine[0].d);
+    if (cnt_raw > (unsigned long long)kThreads) {      // block-uniform; mostly false: a scan rarely lists more than 256 units
 #pragma unroll
-    for (int k = 0; k < 4; ++k) best_update4(bq, bk, bp, d, mine[k].q, mine[k].key, mine[k].pad, mine[k].d);
+        for (int k = 1; k < 4; ++k) best_update4(bq, bk, bp, d, mine[k].q, mine[k].key, mine[k].pad, mine[k].d);
+    }
     {
         const int64_t nrec = (int64_t)(cnt_raw < (unsigned long long)scan_grid ? cnt_raw : (unsigned long long)scan_grid);
         for (int64_t idx = threadIdx.x + 4 * kThreads; idx < nrec; idx += kThreads)
@@ -510,6 +534,7 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
 #pragma unroll
     for (int w = 1; w < kThreads / 64; ++w) best_update4(bq, bk, bp, d, sq[w], sk[w], spp[w], sdd[w]);
 
+    if (clocked) ck[2] = wall_clock64();
     const int64_t last = n - 1;
     if (bk == ~0ull) {
         if (i == last) st->status = 1;
@@ -540,6 +565,7 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
         int64_t new_slot = i;
         if (i != x && i != y) {
             const double dxi = D[px * ld + p], dyi = D[py * ld + p];
+            if (clocked) { __builtin_amdgcn_s_waitcnt(0); ck[3] = wall_clock64(); }
             val = (dxi + dyi - d) * 0.5;
             const double u = up + (-dxi - dyi + val);   // i == last: "U[y] = U[last] + ..." of the reference's tail
             U[p] = u;
@@ -560,8 +586,17 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
         }
         if (new_slot >= 0) { KA[p] = nj_key_a(new_slot, n1); KB[p] = nj_key_b(new_slot); }
     }
+    if (clocked) ck[4] = wall_clock64();
     const double cs = block_tree256_lane0(val, s);
     if (threadIdx.x == 0) xpart[blockIdx.x] = cs;
+    if (clocked) {
+        __builtin_amdgcn_s_waitcnt(0);
+        ck[5] = wall_clock64();
+        unsigned long long* o = clk + 32;
+        atomicAdd(&o[0], 1ull);
+        if (ck[3] == 0) ck[3] = ck[2];
+        for (int k = 1; k < 6; ++k) atomicAdd(&o[k], ck[k] - ck[k - 1]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -760,7 +795,8 @@ static int njp_launch_post(NjBuffers& b, hipStream_t s)
     hipLaunchKernelGGL(njp_post_kernel, dim3(pgrid), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.U, q.Ur, q.KA, q.KB,
                        q.slot_of_pos, q.pos_of_slot, (unsigned long long*)q.umin, b.xpart, b.partials, njp_grid_total(q), q.P,
                        b.log_x, b.log_y, b.log_bx, b.log_by, sh ? njp_grid_total(q) : -1,
-                       sh ? q.cnt_all : (unsigned long long*)nullptr, sh ? (q.sh_virtual ? q.sh_world : 1) : 0);
+                       sh ? q.cnt_all : (unsigned long long*)nullptr, sh ? (q.sh_virtual ? q.sh_world : 1) : 0,
+                       q.iterstats ? (unsigned long long*)q.iterstats + 2 * b.N + 2 : (unsigned long long*)nullptr);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }

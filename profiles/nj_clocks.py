@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase clocks of njp_prep_kernel (wall_clock64, 10 ns units; block 0 and the middle block), averaged over a run."""
+"""Phase clocks of the three pruned-NJ kernels (wall_clock64, 10 ns units; thread 0 of block 0, prep also the middle block), averaged over a run."""
 import ctypes as C, os, sys
 import numpy as np
 os.environ["DPR_NJ_ITERSTATS"] = "1"
@@ -23,3 +23,8 @@ for blk, o in (("block 0", 0), ("middle block", 8)):
     cnt = clk[o]
     if cnt:
         print(blk, "launches %d:" % cnt, "; ".join("%s %.2f us" % (nm, clk[o + 1 + k] / cnt / 100.0) for k, nm in enumerate(names)))
+for name, o, names in (("scan block 0", 16, ["hop 1 (state, list)", "hop 2 (unit data)", "passes + reductions", "block winner + record"]),
+                       ("post block 0", 32, ["hop 1 (state, slots, records)", "record reduction", "hop 2 (rows px, py)", "update + stores", "tree + chunk sum"])):
+    cnt = clk[o]
+    if cnt:
+        print(name, "launches %d:" % cnt, "; ".join("%s %.2f us" % (nm, clk[o + 1 + k] / cnt / 100.0) for k, nm in enumerate(names)))
