@@ -232,3 +232,32 @@ def test_nj_unit_sharded_virtual_ranks(orc, monkeypatch, world):
                 d.close()
     finally:
         capi.set_nj_virtual_shards(1)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_nj_unit_sharded_virtual_ranks_many_units(world):
+    """The same emulation at 6 000 tips (≈ 2 300 units in 12 strips, several epochs, zero-length branches and
+    therefore tie-heavy Q values): the unit-sharded run must reproduce the single-rank pruned run bit for bit."""
+    import dipper_amd
+    from dipper_amd import capi
+    n, L = 6000, 400
+    seqs = _util.synth_alignment(np.random.default_rng(7), n, L, mean_bl=1e-3, lo=1e-4, hi=1e-2)
+    packed = capi.pack4_many(seqs)
+    capi.set_nj_mode(1)
+    res = {}
+    try:
+        for w in (1, world):
+            capi.set_nj_virtual_shards(w)
+            d = dipper_amd.Dipper(0)
+            try:
+                d.set_msa(packed, L)
+                d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+                res[w] = d.nj_run()
+            finally:
+                d.close()
+    finally:
+        capi.set_nj_virtual_shards(1)
+    assert res[1]["iters"] == res[world]["iters"] == n - 2
+    for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
+        assert np.array_equal(res[1][key], res[world][key]), key
+    assert res[1]["last_d"] == res[world]["last_d"]
