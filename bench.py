@@ -210,6 +210,12 @@ def main():
                          "(used for the rocprofv3 --pmc passes)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON record: everything else that writes to file descriptor 1 (RCCL prints
+    # a version banner there when a communicator is created) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -238,10 +244,30 @@ def main():
     log(f"[bench r{rank}] synthetic input {n} x {L} generated+packed in {time.perf_counter()-t0:.1f}s")
 
     dip = dipper_amd.Dipper(local_rank)
+    comm_note = None
     if world > 1:
-        uid = [dip.comm_unique_id() if rank == 0 else None]
+        # the library's own RCCL communicator; if any rank cannot create it, every rank falls back to the
+        # single-GPU plan on its own GPU (same result, no exchange) and the bench line says so
+        ok, err = 1, ""
+        try:
+            uid = [dip.comm_unique_id() if rank == 0 else None]
+        except Exception as e:
+            uid, ok, err = [None], 0, repr(e)
         dist.broadcast_object_list(uid, src=0)
-        dip.comm_init(rank, world, uid[0])
+        if ok and uid[0] is not None:
+            try:
+                dip.comm_init(rank, world, uid[0])
+            except Exception as e:
+                ok, err = 0, repr(e)
+        else:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            comm_note = "replicated: the library's RCCL communicator could not be created on every rank (%s)" % (err or "another rank failed")
+            log(f"[bench r{rank}] {comm_note}")
+            dip.close()
+            dip = dipper_amd.Dipper(local_rank)
     dip.set_msa(packed, L)          # H2D + bit-plane conversion: inputs now resident in HBM
     if rank == 0:
         log(f"[bench] device: {dip.device_name()}")
@@ -316,10 +342,11 @@ def main():
     rows_local = capi.load_library().dpr_shard_rows(n, rank, world)
     # pruned NJ on several GPUs keeps the whole matrix on every rank (the ranks share the unit tests and scans of
     # an iteration), so the probe streams the whole triangle; the streaming algorithm is row-sharded
-    replicated = prune is not None and world > 1
-    if replicated:
+    replicated = prune is not None and world > 1 and comm_note is None
+    whole = world == 1 or replicated or comm_note is not None      # this rank holds (and the probe streams) the whole triangle
+    if whole:
         rows_local = n
-    alg_bytes = (4.0 * n * n if replicated else 4.0 * n * n / world) + 4.0 * n   # strict lower triangle (of this rank's rows) + U once
+    alg_bytes = (4.0 * n * n if whole else 4.0 * n * n / world) + 4.0 * n   # strict lower triangle (of this rank's rows) + U once
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, world),
@@ -339,7 +366,7 @@ def main():
         "data": "synthetic (seeded Yule-Harding tree, JC69, L=%d, no indels)" % L,
         "config": {"workload": "configs[1]: %d aligned tips, -d 2 (JC69), conventional NJ" % n,
                    "tips": n, "sites": L,
-                   "parallelism": ("units%d (matrix replicated, unit tests and scans shared)" if replicated else "rows%d") % world},
+                   "parallelism": comm_note or (("units%d (matrix replicated, unit tests and scans shared)" if replicated else "rows%d") % world)},
         "phase_ms": {"dist": float(np.mean([p[0] for p in phase])) if phase else None,
                      "nj": float(np.mean([p[1] for p in phase])) if phase else None},
         "roofline": roofline,
@@ -365,7 +392,8 @@ def main():
         except Exception as e:  # never take the bench line down
             out["e2e_cli"] = {"error": repr(e)}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
