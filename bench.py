@@ -303,6 +303,7 @@ def main():
             prune = None
     barrier()
     dt = time.perf_counter() - t0
+    sharded_timed = world > 1 and dip.nj_is_unit_sharded()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -322,6 +323,26 @@ def main():
         dist.all_gather(allh, mine)
         agree = all(int(t.item()) == digest for t in allh)
         mgpu_check = {"ranks_agree": bool(agree)}
+        if world > 1 and comm_note is None and not dip.nj_is_unit_sharded():
+            # the timed steps ran the single-GPU plan on every rank (N below the sharding threshold): run the
+            # unit-sharded plan (one RCCL all-gather per iteration) once, untimed, and compare
+            try:
+                capi.set_nj_multi_plan(1)
+                barrier()
+                ts = time.perf_counter()
+                dip.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+                sh = dip.nj_run()
+                barrier()
+                sh_ms = (time.perf_counter() - ts) * 1e3
+                same = all(np.array_equal(sh[k], last_res[k]) for k in ("merge_x", "merge_y", "bl_x", "bl_y"))
+                okt = torch.tensor([1 if same else 0], dtype=torch.int32, device="cuda")
+                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+                mgpu_check["unit_sharded_plan"] = {"matches": bool(int(okt.item())), "ms_per_step": sh_ms,
+                                                   "nj_ms": dip.timing()[1]}
+            except Exception as e:
+                mgpu_check["unit_sharded_plan"] = {"error": repr(e)}
+            finally:
+                capi.set_nj_multi_plan(0)
         if rank == 0:
             try:   # untimed replay of the same step on this rank's GPU alone (no communicator)
                 solo = dipper_amd.Dipper(local_rank)
@@ -343,6 +364,7 @@ def main():
     # pruned NJ on several GPUs keeps the whole matrix on every rank (the ranks share the unit tests and scans of
     # an iteration), so the probe streams the whole triangle; the streaming algorithm is row-sharded
     replicated = prune is not None and world > 1 and comm_note is None
+    sharded = replicated and sharded_timed
     whole = world == 1 or replicated or comm_note is not None      # this rank holds (and the probe streams) the whole triangle
     if whole:
         rows_local = n
@@ -366,7 +388,10 @@ def main():
         "data": "synthetic (seeded Yule-Harding tree, JC69, L=%d, no indels)" % L,
         "config": {"workload": "configs[1]: %d aligned tips, -d 2 (JC69), conventional NJ" % n,
                    "tips": n, "sites": L,
-                   "parallelism": comm_note or (("units%d (matrix replicated, unit tests and scans shared)" if replicated else "rows%d") % world)},
+                   "parallelism": comm_note or (("units%d (matrix replicated, unit tests and scans shared, one all-gather per iteration)" % world) if sharded
+                                                else ("replicas%d (every rank runs the single-GPU plan: N is below the unit-sharding threshold of 65536 tips, "
+                                                      "where an iteration is ~20 us of dependent latency; the unit-sharded plan runs once untimed, see multi_gpu_check)" % world) if replicated
+                                                else "rows%d" % world)},
         "phase_ms": {"dist": float(np.mean([p[0] for p in phase])) if phase else None,
                      "nj": float(np.mean([p[1] for p in phase])) if phase else None},
         "roofline": roofline,

@@ -59,6 +59,8 @@ def load_library():
     L.dpr_comm_selftest.argtypes = [C.c_void_p]
     L.dpr_scan_tune.argtypes = [C.c_int, C.c_int, C.c_int]
     L.dpr_set_nj_mode.argtypes = [C.c_int]
+    L.dpr_set_nj_multi_plan.argtypes = [C.c_int]
+    L.dpr_nj_is_unit_sharded.argtypes = [C.c_void_p]
     L.dpr_get_prune_stats.argtypes = [C.c_void_p, c_u64p, c_u64p]
     L.dpr_bw_probe.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.dpr_set_msa.argtypes = [C.c_void_p, c_u64p, C.c_int64, C.c_int64]
@@ -112,6 +114,13 @@ def set_nj_mode(mode):
     """0 = full streaming scan every iteration, 1 = exact pruned scan (default)."""
     L = load_library()
     _chk(L, L.dpr_set_nj_mode(mode))
+
+
+def set_nj_multi_plan(plan):
+    """Several ranks, pruned NJ: 0 = auto (unit-sharded from 65 536 tips on), 1 = always unit-sharded, 2 = every rank
+    runs the single-GPU plan."""
+    L = load_library()
+    _chk(L, L.dpr_set_nj_multi_plan(plan))
 
 
 def _chk(L, rc):
@@ -301,6 +310,9 @@ class Dipper:
                                               _p(bx, c_f64p), _p(by, c_f64p), C.byref(last)))
         return dict(iters=done, merge_x=mx[:done], merge_y=my[:done], bl_x=bx[:done], bl_y=by[:done],
                     last_d=last.value)
+
+    def nj_is_unit_sharded(self):
+        return bool(self.L.dpr_nj_is_unit_sharded(self.h))
 
     def argmin_once(self, reps=1):
         i = C.c_int32()

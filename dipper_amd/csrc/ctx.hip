@@ -72,7 +72,8 @@ struct dpr_ctx {
     double* packed_lower = nullptr;  // MATRIX source, device
     int64_t n_input = 0;
     int have_matrix = 0;
-    bool nj_replicated = false;      // several ranks, each holding the whole matrix (unit-sharded pruned NJ)
+    bool nj_replicated = false;      // several ranks, each holding the whole matrix (pruned NJ)
+    bool nj_unit_sharded = false;    // ... and sharing the unit tests / scans of an iteration (else: every rank runs the single-GPU plan)
     double dist_ms = 0, nj_ms = 0;
     dpr::DcStats dc_stats;
     double dc_ms[3] = { 0, 0, 0 };   // backbone, cluster assignment, cluster trees
@@ -83,6 +84,19 @@ using namespace dpr;
 // NJ algorithm on a single GPU: 1 = exact pruned scan (njp.hip, default), 0 = full streaming scan
 static int g_nj_mode = -1;
 static int g_nj_vshards = 1;   // > 1: a single-rank context emulates that many unit-sharded ranks (validation)
+// Several ranks, pruned NJ: 0 = auto (unit-sharded scans from kNjShardTips tips on, below that every rank runs the
+// single-GPU plan on its own copy: an iteration is then ~20 us of dependent latency and a collective per iteration
+// would only add to it), 1 = always unit-sharded, 2 = never (dpr_set_nj_multi_plan / DPR_NJ_MULTI=auto|shard|solo)
+static int g_nj_multi_plan = -1;
+constexpr int64_t kNjShardTips = 65536;
+static int nj_multi_plan()
+{
+    if (g_nj_multi_plan < 0) {
+        const char* e = std::getenv("DPR_NJ_MULTI");
+        g_nj_multi_plan = (e && std::strcmp(e, "shard") == 0) ? 1 : (e && std::strcmp(e, "solo") == 0) ? 2 : 0;
+    }
+    return g_nj_multi_plan;
+}
 
 // in-place all-gather of the block records of the unit-sharded pruned NJ
 static int njp_gather_cb(void* ctx, void* buf, size_t bytes_per_rank, hipStream_t s)
@@ -475,7 +489,9 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
         if (int rc = nj_prepare(b, c->stream)) return rc;
     if ((c->world == 1 || repl) && want_pruned() && n >= 3) {
         NjPruned& q = c->nj[0].pr;
-        if (repl) { q.sh_world = c->world; q.sh_rank = c->rank; q.sh_virtual = false; q.gather = njp_gather_cb; q.gather_ctx = c; }
+        const bool shard = repl && (nj_multi_plan() == 1 || (nj_multi_plan() == 0 && n >= kNjShardTips));
+        c->nj_unit_sharded = shard;
+        if (shard) { q.sh_world = c->world; q.sh_rank = c->rank; q.sh_virtual = false; q.gather = njp_gather_cb; q.gather_ctx = c; }
         else if (g_nj_vshards > 1) { q.sh_world = g_nj_vshards; q.sh_rank = 0; q.sh_virtual = true; }
         if (int rc = njp_build(c->nj[0], c->stream)) return rc;
     }
@@ -603,6 +619,14 @@ int dpr_set_nj_virtual_shards(int w)
     g_nj_vshards = w;
     return DPR_OK;
 }
+
+int dpr_set_nj_multi_plan(int plan)
+{
+    if (plan < 0 || plan > 2) { set_error("dpr_set_nj_multi_plan: 0 auto, 1 unit-sharded, 2 single-GPU plan on every rank"); return DPR_ERR_ARG; }
+    g_nj_multi_plan = plan;
+    return DPR_OK;
+}
+int dpr_nj_is_unit_sharded(dpr_ctx* c) { return c && c->nj_unit_sharded ? 1 : 0; }
 
 // 0 = full streaming scan every iteration, 1 = exact pruned scan (default)
 int dpr_set_nj_mode(int mode)

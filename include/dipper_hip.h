@@ -140,6 +140,13 @@ int dpr_set_nj_mode(int mode);
  * dpr_set_nj_virtual_shards(w) makes the next dpr_dist_matrix of a single-rank context emulate w such ranks
  * (validation on one GPU; same merge log bit for bit). */
 int dpr_set_nj_virtual_shards(int w);
+/* Several ranks (dpr_comm_init), pruned NJ: plan 0 = auto (unit-sharded scans + one all-gather per iteration from
+ * 65 536 tips on; below that every rank runs the single-GPU plan on its own copy of the matrix -- an iteration is then
+ * ~20 us of dependent latency, which a collective per iteration would only lengthen), 1 = always unit-sharded,
+ * 2 = never.  Also DPR_NJ_MULTI=auto|shard|solo.  No counterpart in the reference (single GPU,
+ * src/tree_generation.cu:240-245).  dpr_nj_is_unit_sharded: what the last dpr_dist_matrix chose. */
+int dpr_set_nj_multi_plan(int plan);
+int dpr_nj_is_unit_sharded(dpr_ctx *ctx);
 /* host-only: owner of the 16-row x 512-column unit (strip = column block, group = row group) among `world` ranks
  * when the position space has P positions; -1 if the unit holds no pair of the strict lower triangle */
 int dpr_njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world);
