@@ -312,6 +312,7 @@ def main():
 
     # ---- several GPUs: the ranks must hold the same merge log, and it must be the one a single GPU produces ----
     mgpu_check = None
+    run_sharded_check = False
     if (world > 1 or force_check) and last_res is not None:
         import hashlib
         h = hashlib.sha256()
@@ -323,26 +324,7 @@ def main():
         dist.all_gather(allh, mine)
         agree = all(int(t.item()) == digest for t in allh)
         mgpu_check = {"ranks_agree": bool(agree)}
-        if world > 1 and comm_note is None and not dip.nj_is_unit_sharded():
-            # the timed steps ran the single-GPU plan on every rank (N below the sharding threshold): run the
-            # unit-sharded plan (one RCCL all-gather per iteration) once, untimed, and compare
-            try:
-                capi.set_nj_multi_plan(1)
-                barrier()
-                ts = time.perf_counter()
-                dip.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
-                sh = dip.nj_run()
-                barrier()
-                sh_ms = (time.perf_counter() - ts) * 1e3
-                same = all(np.array_equal(sh[k], last_res[k]) for k in ("merge_x", "merge_y", "bl_x", "bl_y"))
-                okt = torch.tensor([1 if same else 0], dtype=torch.int32, device="cuda")
-                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-                mgpu_check["unit_sharded_plan"] = {"matches": bool(int(okt.item())), "ms_per_step": sh_ms,
-                                                   "nj_ms": dip.timing()[1]}
-            except Exception as e:
-                mgpu_check["unit_sharded_plan"] = {"error": repr(e)}
-            finally:
-                capi.set_nj_multi_plan(0)
+        run_sharded_check = comm_note is None and not dip.nj_is_unit_sharded()   # (also in the one-rank rehearsal)
         if rank == 0:
             try:   # untimed replay of the same step on this rank's GPU alone (no communicator)
                 solo = dipper_amd.Dipper(local_rank)
@@ -410,6 +392,39 @@ def main():
             out["cpu_baseline_rapidnj"] = cpu_baseline_rapidnj(dip, n)
         except Exception as e:
             out["cpu_baseline_rapidnj"] = {"value": None, "unit": "tips/s", "cores": host_cores(), "sample": f"failed: {e!r}"}
+    if run_sharded_check:
+        # The timed steps ran the single-GPU plan on every rank (N below the sharding threshold).  Last of all, with
+        # the record complete: run the unit-sharded plan (one RCCL all-gather per iteration) once, untimed, and compare.
+        # A watchdog ends every rank with the record printed if that path does not come back.
+        import threading
+
+        def give_up():
+            out.setdefault("multi_gpu_check", {})["unit_sharded_plan"] = {"error": "no result within 300 s"}
+            if rank == 0:
+                os.write(json_fd, (json.dumps(out) + "\n").encode())
+            os._exit(0)
+
+        dog = threading.Timer(300.0, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            capi.set_nj_multi_plan(1)
+            barrier()
+            ts = time.perf_counter()
+            dip.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+            sh = dip.nj_run()
+            barrier()
+            sh_ms = (time.perf_counter() - ts) * 1e3
+            same = all(np.array_equal(sh[k], last_res[k]) for k in ("merge_x", "merge_y", "bl_x", "bl_y"))
+            okt = torch.tensor([1 if same else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            out["multi_gpu_check"]["unit_sharded_plan"] = {"matches": bool(int(okt.item())), "ms_per_step": sh_ms,
+                                                           "nj_ms": dip.timing()[1]}
+        except Exception as e:
+            out["multi_gpu_check"]["unit_sharded_plan"] = {"error": repr(e)}
+        finally:
+            dog.cancel()
+            capi.set_nj_multi_plan(0)
     dip.close()
     if want_e2e:
         try:
