@@ -393,6 +393,7 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __rest
         // masked entry (NaN distance) give a NaN q, which fmin drops and no comparison selects.  m0 / m1: the
         // exact minimum over the live rows of this lane's two columns (dead rows add NaN, which fmin drops).
         double lm = __builtin_inf(), m0 = __builtin_inf(), m1 = __builtin_inf();
+        double rowq[kUR];                          // this lane's smallest q per row: pass 2 looks only at rows that reach wm
 #pragma unroll
         for (int u8 = 0; u8 < kUR; ++u8) {
             const double d0 = v[u8].x, d1 = v[u8].y;
@@ -403,7 +404,8 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __rest
             const double q1 = (d0 - ub0) - ua[u8];   // (i=b0, j=a)
             const double q2 = (d1 - ua[u8]) - ub1;
             const double q3 = (d1 - ub1) - ua[u8];
-            lm = fmin(lm, fmin(fmin(q0, q1), fmin(q2, q3)));
+            rowq[u8] = fmin(fmin(q0, q1), fmin(q2, q3));
+            lm = fmin(lm, rowq[u8]);
         }
         double m = fmin(fmin(live0 ? m0 : __builtin_nan(""), live1 ? m1 : __builtin_nan("")), __builtin_inf());   // +inf: no live pair
         const double wm = wave_fmin(lm);          // +inf when the wave saw no valid candidate
@@ -411,11 +413,11 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __rest
             if (wm < bq) { bq = wm; bk = ~0ull; }   // rather than kept: 128 registers less, twice the blocks per CU
 #pragma unroll
             for (int u8 = 0; u8 < kUR; ++u8) {
-                double d0 = v[u8].x, d1 = v[u8].y;
-                asm volatile("" : "+v"(d0), "+v"(d1));    // opaque: keeps the compiler from holding pass 1's 64 q alive
-                const bool e0 = (d0 - ua[u8]) - ub0 == wm, e1 = (d0 - ub0) - ua[u8] == wm;
-                const bool e2 = (d1 - ua[u8]) - ub1 == wm, e3 = (d1 - ub1) - ua[u8] == wm;
-                if (__builtin_amdgcn_ballot_w64(e0 | e1 | e2 | e3) != 0ull) {
+                if (__builtin_amdgcn_ballot_w64(rowq[u8] == wm) != 0ull) {      // rare; the four q are recomputed (same bits)
+                    double d0 = v[u8].x, d1 = v[u8].y;
+                    asm volatile("" : "+v"(d0), "+v"(d1));    // opaque: keeps the compiler from holding pass 1's 64 q alive
+                    const bool e0 = (d0 - ua[u8]) - ub0 == wm, e1 = (d0 - ub0) - ua[u8] == wm;
+                    const bool e2 = (d1 - ua[u8]) - ub1 == wm, e3 = (d1 - ub1) - ua[u8] == wm;
                     const uint64_t pa = (uint64_t)(a0 + u8);
                     const uint64_t kaa = readlane_u64(kaa_l, u8), kba = readlane_u64(kba_l, u8);
                     const uint64_t k0 = kaa | kb0, k1 = ka0 | kba, k2 = kaa | kb1, k3 = ka1 | kba;
