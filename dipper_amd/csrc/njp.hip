@@ -858,6 +858,7 @@ static int njp_run_segment(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t 
     }
     const bool use_graph = q.sh_world <= 1 && todo >= kGraphIters && !std::getenv("DPR_NJ_NOGRAPH");
     if (use_graph && !q.graph) {
+        const auto tg0 = std::chrono::steady_clock::now();
         hipGraph_t g = nullptr;
         DPR_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         int rc = DPR_OK;
@@ -867,6 +868,9 @@ static int njp_run_segment(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t 
         if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
         DPR_HIP(hipGraphInstantiate(&q.graph, g, nullptr, nullptr, 0));
         DPR_HIP(hipGraphDestroy(g));
+        if (std::getenv("DPR_NJ_EPOCH_LOG"))
+            std::fprintf(stderr, "[njp] graph capture + instantiate (P=%lld): %.2f ms\n", (long long)q.P,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg0).count());
     }
     int64_t done = 0;
     if (use_graph)
