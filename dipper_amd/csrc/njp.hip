@@ -5,9 +5,10 @@
 //  * the matrix lives in POSITION space: tips are permuted by ascending initial row sum, rows never
 //    move afterwards (the reference's "last slot moves into y" becomes a relabel of slot_of_pos /
 //    pos_of_slot); every key uses the reference's slot numbers, so ties resolve as in the reference;
-//  * the triangle is cut into units of 16 rows x 512 columns with a lazily maintained lower bound
-//    umin[unit] <= min D over the unit (exact whenever the unit is scanned, min-updated when the new
-//    node's row/column is written);
+//  * the triangle is cut into units of 16 rows x 512 columns, each with four 128-column sub-units (the columns of
+//    one wave of the scan kernel) that carry a lazily maintained lower bound umin[unit][w] <= min D over the
+//    sub-unit (exact whenever it is scanned; lowered by the prep lane that tests the unit when the new node's
+//    row / column crosses it);
 //  * for a unit, every candidate obeys  q = fl(fl(D - Ur_a) - Ur_b) >= fl(fl(umin - rmax) - cmax)
 //    (and the other association order) because fl(x - y) is monotone in x and -y; units whose bound
 //    exceeds a known upper bound of the optimum (the best of the previous iteration's per-block
@@ -15,7 +16,7 @@
 //    skipped.  Sorting by row sum makes Ur homogeneous inside units, which is what makes the bound
 //    tight.
 //
-// Per iteration: njp_scan_kernel (scan the listed units, refresh their umin) -> njp_post_kernel
+// Per iteration: njp_scan_kernel (scan the surviving sub-units of the listed units, refresh their bounds) -> njp_post_kernel
 // (select + merge + update, indexed by reference slot so that the canonical U[x] summation order is
 // unchanged) -> njp_prep_kernel (finish U[x], seed bound, test every unit, list the survivors).
 // The kernels take no per-iteration arguments (they read the iteration index from the device
@@ -476,7 +477,6 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
                                                             uint64_t* __restrict__ KB,
                                                             int32_t* __restrict__ slot_of_pos,
                                                             int32_t* __restrict__ pos_of_slot,
-                                                            unsigned long long* __restrict__ umin,
                                                             double* __restrict__ xpart,
                                                             const NjRecord* __restrict__ partials, int scan_grid,
                                                             int64_t P,
@@ -795,7 +795,7 @@ static int njp_launch_post(NjBuffers& b, hipStream_t s)
     const bool sh = q.sh_world > 1;
     const unsigned pgrid = (unsigned)((b.N + kThreads - 1) / kThreads);
     hipLaunchKernelGGL(njp_post_kernel, dim3(pgrid), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.U, q.Ur, q.KA, q.KB,
-                       q.slot_of_pos, q.pos_of_slot, (unsigned long long*)q.umin, b.xpart, b.partials, njp_grid_total(q), q.P,
+                       q.slot_of_pos, q.pos_of_slot, b.xpart, b.partials, njp_grid_total(q), q.P,
                        b.log_x, b.log_y, b.log_bx, b.log_by, sh ? njp_grid_total(q) : -1,
                        sh ? q.cnt_all : (unsigned long long*)nullptr, sh ? (q.sh_virtual ? q.sh_world : 1) : 0,
                        q.iterstats ? (unsigned long long*)q.iterstats + 2 * b.N + 2 : (unsigned long long*)nullptr);
