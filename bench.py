@@ -1,17 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the hot path (BASELINE.json):
-tips/sec for packed aligned tips -> JC distances -> conventional NJ -> merge log at N = 30k on
-MI355X, plus the Q-argmin HBM roofline and a CPU NJ baseline timed on the host cores.
+"""bench.py -- headline benchmark (BASELINE.json): tips/sec FASTA -> Newick at N = 30k on MI355X, with the
+Q-argmin HBM roofline, the hot path's own kernel record, a self-check of the timed result and CPU NJ baselines
+timed on the host cores.
 
-One "step" = one pass of the hot path over one batch of synthetic input that is already resident
-in HBM (bit-plane sequences): all-pairs JC69 distance matrix + row sums + all N-2 NJ iterations.
-Run as `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches it under
-torch.distributed.run (one rank per GPU, RCCL).
+One "step" = one pass of the whole path over one batch of synthetic input: the `dipper` command line (FASTA
+parse, pack, H2D, all-pairs JC69 distances, all N-2 NJ iterations, Newick write) on this rank's GPU.  `value`
+is BASELINE.json's metric measured over exactly K such steps.  The hot path alone (packed tips resident in HBM
+-> distances -> NJ merge log, in process through the C ABI) is timed over the same K/W next to it (`hot_path`).
+Run as `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it under
+torch.distributed.run (one rank per GPU, RCCL): a 30k-tip tree is ~15-20 us of dependent latency per NJ iteration,
+which sharding only lengthens, so the ranks build independent trees (replicas, `scaling: weak`); the sharded NJ
+plan is measured where it can win, at 100 000 tips (`sharded_100k`).
 """
 import argparse
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 import numpy as np
@@ -21,6 +30,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+UNIT_BYTES = 16 * 512 * 8      # one unit of the pruned scan: 16 rows x 512 columns of fp64
+EXE = os.path.join(ROOT, "dipper_amd", "bin", "dipper")
 
 
 def log(*a):
@@ -46,10 +57,17 @@ def host_cores():
 
 def make_input(n, L, seed):
     """Seeded stand-in for `iqtree2 --alisim` (scripts/alisim.sh:14): Yule-Harding tree, JC69,
-    branch lengths exponential(2e-5) clipped to [2e-6, 2e-4], no indels."""
+    branch lengths exponential(2e-5) clipped to [2e-6, 2e-4], no indels (aligned input)."""
     from tests import _util
     rng = np.random.default_rng(seed)
     return _util.synth_alignment(rng, n, L, mean_bl=2e-5, lo=2e-6, hi=2e-4)
+
+
+def stats_ms(xs):
+    xs = [float(x) for x in xs]
+    if not xs:
+        return None
+    return {"min": min(xs), "median": float(np.median(xs)), "max": max(xs), "mean": float(np.mean(xs))}
 
 
 def pmc_traffic(n, world):
@@ -66,28 +84,44 @@ def pmc_traffic(n, world):
     return None
 
 
-def cpu_baseline(dip, n, budget_s=20.0):
+def merge_digest(res):
+    h = hashlib.sha256()
+    for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
+        h.update(np.ascontiguousarray(res[key]).tobytes())
+    return h.hexdigest()[:16]
+
+
+def same_log(a, b):
+    return bool(all(np.array_equal(a[k], b[k]) for k in ("merge_x", "merge_y", "bl_x", "bl_y")) and a["last_d"] == b["last_d"])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1 only; bounded samples)
+# ---------------------------------------------------------------------------------------------------------
+def gpu_matrix_block(dip, m):
+    D = np.zeros((m, m), dtype=np.float64)
+    for i in range(m):
+        D[i, :] = dip.matrix_row(i)[:m]
+    return D
+
+
+def cpu_baseline(dip, n, cores, budget_s=15.0):
     """CPU NJ (the oracle's restatement of the reference's arithmetic, OpenMP over row bands) on a
-    bounded sample: the first k iterations at full size on the same matrix, extrapolated to the
-    whole run by the sum of n^2.  Distances are NOT included (the matrix is copied from the GPU)."""
+    bounded sample: init + the first k iterations at full size on the GPU's own matrix, scaled to the
+    whole run by the sum of n^2 (every iteration is one full scan).  Distances are NOT included."""
+    import ctypes as C
     import psutil
     from tests import _orc
+    from tests._orc import _p, c_f64p, c_i32p
     orc = _orc.load()
-    cores = host_cores()
-    log(f"[cpu_baseline] oracle NJ on {cores} host threads ...")
+    log(f"[cpu_baseline] oracle NJ on {cores} host thread(s) ...")
     need = n * n * 8 * 1.15
     avail = psutil.virtual_memory().available
     ns = n
     if need > 0.5 * avail:
         ns = int((0.5 * avail / 9.2) ** 0.5)
         log(f"[cpu_baseline] host memory {avail/2**30:.0f} GiB: sampling the leading {ns} tips")
-    D = np.zeros((ns, ns), dtype=np.float64)
-    for i in range(ns):
-        D[i, :] = dip.matrix_row(i)[:ns]
-    D = np.tril(D, -1)
-    # calibrate: 2 iterations, then as many as fit the budget
-    import ctypes as C
-    from tests._orc import _p, c_f64p, c_i32p
+    D = np.tril(gpu_matrix_block(dip, ns), -1)
     k_max = 64
     mx = np.zeros(k_max, np.int32); my = np.zeros(k_max, np.int32)
     bx = np.zeros(k_max); by = np.zeros(k_max)
@@ -111,29 +145,21 @@ def cpu_baseline(dip, n, budget_s=20.0):
     t_full = t0 * (n / ns) ** 2 + per_it * k * s_full / s_sample
     return {
         "value": n / t_full, "unit": "tips/s", "cores": cores, "kind": "port",
-        "sample": f"oracle NJ (reference arithmetic, OpenMP {cores} threads) on the same matrix "
-                  f"(leading {ns} tips): init + first {k} iterations timed ({tk:.1f} s), "
-                  f"extrapolated to all {n-2} iterations of N={n} by sum(n^2); distance stage excluded",
+        "sample": f"oracle NJ (reference arithmetic, OpenMP {cores} thread(s)) on the GPU's matrix "
+                  f"(leading {ns} tips): init + first {k} of {n-2} iterations timed ({tk:.1f} s), scaled to the "
+                  f"whole run by sum(n^2) (every iteration is one full O(n^2) scan); distance stage excluded",
     }
 
 
-def cpu_baseline_rapidnj(dip, n, budget_s=20.0):
-    """Stronger CPU baseline next to the oracle's: a from-scratch RapidNJ-style exact NJ (sorted rows +
-    q_min pruning, OpenMP; oracle/rapidnj_baseline.c -- north_star names RapidNJ, which is not installed and
-    cannot be fetched).  Whole NJ run on the GPU's distance matrix when it fits the time budget (calibrated on
-    the leading 6 000 tips), else on the largest leading block that does, extrapolated with the measured
-    exponent.  Distances excluded, as for the oracle baseline."""
+def cpu_baseline_rapidnj(dip, n, cores, budget_s=20.0):
+    """Stronger CPU baseline: a from-scratch RapidNJ-style exact NJ (sorted rows + q_min pruning, OpenMP;
+    oracle/rapidnj_baseline.c -- north_star names RapidNJ, which is not installed and cannot be fetched).
+    Whole NJ run on the leading m tips of the GPU's matrix, m sized to the time budget; scaled to N with the
+    exponent measured between two smaller blocks.  Distances excluded."""
     import psutil
     from tests import _orc
     orc = _orc.load()
-    cores = host_cores()
     log(f"[cpu_baseline_rapidnj] RapidNJ-style NJ on {cores} host threads ...")
-
-    def block(m):
-        D = np.zeros((m, m), dtype=np.float64)
-        for i in range(m):
-            D[i, :] = dip.matrix_row(i)[:m]
-        return D
 
     def run(D):
         t0 = time.perf_counter()
@@ -145,7 +171,7 @@ def cpu_baseline_rapidnj(dip, n, budget_s=20.0):
 
     m0 = min(n, 3000)
     m1 = min(n, 6000)
-    D1 = block(m1)
+    D1 = gpu_matrix_block(dip, m1)
     t0 = run(D1[:m0, :m0])
     t1 = run(D1) if m1 > m0 else t0
     expo = max(1.5, min(3.0, np.log(max(t1, 1e-3) / max(t0, 1e-3)) / np.log(m1 / m0))) if m1 > m0 else 2.0
@@ -158,53 +184,73 @@ def cpu_baseline_rapidnj(dip, n, budget_s=20.0):
     m = max(m1, min(m, n))
     if m > m1:
         del D1
-        tm = run(block(m))
+        tm = run(gpu_matrix_block(dip, m))
     else:
         tm = t1
     t_full = tm * (n / m) ** expo
     return {"value": n / t_full, "unit": "tips/s", "cores": cores, "kind": "rapidnj-style reimplementation (not the oracle)",
-            "sample": f"exact NJ with RapidNJ's sorted-row search on the same matrix, leading {m} of {n} tips in {tm:.1f} s "
-                      + ("(whole run)" if m == n else f"extrapolated by (N/m)^{expo:.2f} (exponent measured between {m0} and {m1} tips)")
+            "sample": f"exact NJ with RapidNJ's sorted-row search on the GPU's matrix, leading {m} of {n} tips in {tm:.1f} s "
+                      + ("(whole run)" if m == n else f"scaled by (N/m)^{expo:.2f} (exponent measured between {m0} and {m1} tips)")
                       + "; distance stage excluded"}
 
 
-def e2e_cli(seqs, n, L):
-    """BASELINE.json's literal headline: wall time of the whole `dipper` command (FASTA parse, pack, H2D,
-    distances, NJ, Newick write) on the same synthetic alignment, written to a scratch FASTA first.
-    Reported next to `value` (which by contract excludes host I/O), never as `value`."""
-    import subprocess
-    import tempfile
+def rapidnj_probe(dip, n, cores, tmp, budget_s=30.0):
+    """The reference authors' own baseline command (scripts/experiment.sh:123: `rapidnj <phylip> -i pd -c $(nproc)`),
+    if a `rapidnj` binary is on PATH of this box; otherwise say so."""
+    exe = shutil.which("rapidnj")
+    if not exe:
+        return {"found": False, "note": "no `rapidnj` on PATH (not installable here: no network); "
+                                        "see cpu_baseline_rapidnj for the from-scratch stand-in"}
     from tests import _util
-    exe = os.path.join(ROOT, "dipper_amd", "bin", "dipper")
-    if not os.path.exists(exe):
-        return {"error": "dipper_amd/bin/dipper not built"}
-    with tempfile.TemporaryDirectory() as tmp:
-        fa, out = os.path.join(tmp, "in.fa"), os.path.join(tmp, "out.nwk")
-        _util.write_fasta(fa, ["T%d" % (i + 1) for i in range(n)], seqs, width=0)
-        best = None
-        for _ in range(2):
-            t0 = time.perf_counter()
-            r = subprocess.run([exe, "-i", "m", "-I", fa, "-O", out, "-m", "2", "-d", "2"], capture_output=True, text=True)
-            dt = time.perf_counter() - t0
-            if r.returncode != 0:
-                return {"error": r.stderr[-300:]}
-            best = dt if best is None else min(best, dt)
-        return {"metric": "tips/sec FASTA -> Newick, whole CLI run", "wall_s": best, "tips_per_s": n / best,
-                "fasta_bytes": os.path.getsize(fa), "newick_bytes": os.path.getsize(out),
-                "command": "dipper -i m -I in.fa -O out.nwk -m 2 -d 2", "runs": 2}
+    m = min(n, 4000)
+    D = gpu_matrix_block(dip, m)
+    path = os.path.join(tmp, "rapidnj_in.phy")
+    _util.write_phylip_lower(path, ["T%d" % (i + 1) for i in range(m)], D)
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([exe, path, "-i", "pd", "-c", str(cores)], capture_output=True, text=True, timeout=budget_s * 4)
+    except Exception as e:
+        return {"found": True, "path": exe, "error": repr(e)}
+    dt = time.perf_counter() - t0
+    return {"found": True, "path": exe, "rc": r.returncode, "tips": m, "wall_s": dt, "tips_per_s": m / dt,
+            "command": f"rapidnj in.phy -i pd -c {cores}", "note": "PHYLIP parse included; leading block of the GPU's matrix"}
+
+
+# ---------------------------------------------------------------------------------------------------------
+def cli_step(fa, out, device):
+    t0 = time.perf_counter()
+    r = subprocess.run([EXE, "-i", "m", "-I", fa, "-O", out, "-m", "2", "-d", "2", "--device", str(device)],
+                       capture_output=True, text=True)
+    dt = time.perf_counter() - t0
+    if r.returncode != 0:
+        raise RuntimeError("dipper failed: " + r.stderr[-400:])
+    phases = {}
+    for line in r.stderr.splitlines():          # the CLI's own progress lines (the reference prints the same ones)
+        for key, tag in (("input", "Input in:"), ("tree", "Tree Created in:")):
+            if line.startswith(tag):
+                try:
+                    phases[key] = float(line.split(":")[1].split()[0])
+                except Exception:
+                    pass
+    return dt, phases
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tips", type=int, default=30000)
     ap.add_argument("--sites", type=int, default=10000)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--probe-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI timing (FASTA -> Newick)")
+    ap.add_argument("--no-cli", action="store_true",
+                    help="skip the command-line steps: `value` is then the in-process hot path (used when profiling the kernels)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the untimed self-check of the timed result")
+    ap.add_argument("--no-sharded", action="store_true", help="several GPUs: skip the 100 000-tip unit-sharded sub-record")
+    ap.add_argument("--sharded-tips", type=int, default=100000)
+    ap.add_argument("--sharded-sites", type=int, default=2000)
     ap.add_argument("--probe-only", action="store_true",
                     help="skip the timed steps; only build the matrix and run the roofline probe "
                          "(used for the rocprofv3 --pmc passes)")
@@ -225,217 +271,396 @@ def main():
     import torch
     import dipper_amd
     from dipper_amd import capi
+    from tests import _util
 
     dist = None
-    # DPR_BENCH_CHECK=1 under `torch.distributed.run --nproc-per-node 1` rehearses the multi-GPU self-check on one GPU
+    # DPR_BENCH_CHECK=1 under `torch.distributed.run --nproc-per-node 1` rehearses the multi-GPU legs on one GPU
     force_check = os.environ.get("DPR_BENCH_CHECK") == "1" and "RANK" in os.environ
     if world > 1 or force_check:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     n, L = args.tips, args.sites
     t0 = time.perf_counter()
     seqs = make_input(n, L, args.seed)
     packed = capi.pack4_many(seqs)
-    want_e2e = rank == 0 and world == 1 and not args.no_e2e and not args.probe_only
-    if not want_e2e:
-        del seqs
     log(f"[bench r{rank}] synthetic input {n} x {L} generated+packed in {time.perf_counter()-t0:.1f}s")
+    names = ["T%d" % (i + 1) for i in range(n)]
 
-    dip = dipper_amd.Dipper(local_rank)
-    comm_note = None
-    if world > 1:
-        # the library's own RCCL communicator; if any rank cannot create it, every rank falls back to the
-        # single-GPU plan on its own GPU (same result, no exchange) and the bench line says so
-        ok, err = 1, ""
-        try:
-            uid = [dip.comm_unique_id() if rank == 0 else None]
-        except Exception as e:
-            uid, ok, err = [None], 0, repr(e)
-        dist.broadcast_object_list(uid, src=0)
-        if ok and uid[0] is not None:
-            try:
-                dip.comm_init(rank, world, uid[0])
-            except Exception as e:
-                ok, err = 0, repr(e)
-        else:
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            comm_note = "replicated: the library's RCCL communicator could not be created on every rank (%s)" % (err or "another rank failed")
-            log(f"[bench r{rank}] {comm_note}")
-            dip.close()
-            dip = dipper_amd.Dipper(local_rank)
-    dip.set_msa(packed, L)          # H2D + bit-plane conversion: inputs now resident in HBM
-    if rank == 0:
-        log(f"[bench] device: {dip.device_name()}")
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def step():
-        dip.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
-        res = dip.nj_run()
-        assert res["iters"] == n - 2
-        return res
-
-    phase = []
-    prune = None
-    last_res = None
+    want_cli = not args.no_cli and not args.probe_only and os.path.exists(EXE)
+    tmp = tempfile.mkdtemp(prefix="dipper_bench_r%d_" % rank)
+    fa, nwk = os.path.join(tmp, "in.fa"), os.path.join(tmp, "out.nwk")
+    if want_cli:
+        _util.write_fasta(fa, names, seqs, width=0)
+    del seqs
     if args.probe_only:
         args.steps = args.warmup = 0
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last_res = step()
-        phase.append(dip.timing())
-        try:
-            sc, full = dip.prune_stats()
-            prune = {"units_scanned": sc, "units_per_full_scan": full, "iterations": n - 2,
-                     "scanned_fraction_of_full_scans": sc / (full * (n - 2.0))}
-        except Exception:
-            prune = None
-    barrier()
-    dt = time.perf_counter() - t0
-    sharded_timed = world > 1 and dip.nj_is_unit_sharded()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = dt / max(args.steps, 1) * 1e3 if args.steps else float("nan")
 
-    # ---- several GPUs: the ranks must hold the same merge log, and it must be the one a single GPU produces ----
-    mgpu_check = None
-    run_sharded_check = False
-    if (world > 1 or force_check) and last_res is not None:
-        import hashlib
-        h = hashlib.sha256()
-        for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
-            h.update(np.ascontiguousarray(last_res[key]).tobytes())
-        digest = int.from_bytes(h.digest()[:7], "little")
-        mine = torch.tensor([digest], dtype=torch.int64, device="cuda")
-        allh = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allh, mine)
-        agree = all(int(t.item()) == digest for t in allh)
-        mgpu_check = {"ranks_agree": bool(agree)}
-        run_sharded_check = comm_note is None and not dip.nj_is_unit_sharded()   # (also in the one-rank rehearsal)
-        if rank == 0:
-            try:   # untimed replay of the same step on this rank's GPU alone (no communicator)
-                solo = dipper_amd.Dipper(local_rank)
-                solo.set_msa(packed, L)
-                solo.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
-                ref = solo.nj_run()
-                solo.close()
-                mgpu_check["matches_single_gpu"] = bool(
-                    all(np.array_equal(ref[k], last_res[k]) for k in ("merge_x", "merge_y", "bl_x", "bl_y")))
+    out = {}
+    try:
+        # =====================================================================================================
+        # A. BASELINE.json's metric: FASTA -> Newick, the whole `dipper` command, K timed steps after W warm-ups
+        # =====================================================================================================
+        cli = None
+        if want_cli:
+            for _ in range(args.warmup):
+                cli_step(fa, nwk, local_rank)
+            barrier()
+            t0 = time.perf_counter()
+            walls, inputs, trees = [], [], []
+            for _ in range(args.steps):
+                dt, ph = cli_step(fa, nwk, local_rank)
+                walls.append(dt * 1e3)
+                inputs.append(ph.get("input", float("nan")))
+                trees.append(ph.get("tree", float("nan")))
+            barrier()
+            dt_cli = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([dt_cli], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_cli = float(t.item())
+            cli = {"metric": "tips/sec FASTA -> Newick, whole CLI run (process start, FASTA parse, pack, H2D, JC69 distances, NJ, Newick write)",
+                   "command": "dipper -i m -I in.fa -O out.nwk -m 2 -d 2 --device <local rank>",
+                   "steps": args.steps, "warmup": args.warmup,
+                   "wall_ms": stats_ms(walls), "input_ms": stats_ms(inputs), "tree_ms": stats_ms(trees),
+                   "tips_per_s_median": n / (float(np.median(walls)) * 1e-3) if walls else None,
+                   "fasta_bytes": os.path.getsize(fa), "newick_bytes": os.path.getsize(nwk) if os.path.exists(nwk) else None}
+            log(f"[bench r{rank}] CLI steps: {cli['wall_ms']}")
+
+        # =====================================================================================================
+        # B. the hot path alone, in process through the C ABI: inputs resident in HBM -> distances -> NJ merge log
+        # =====================================================================================================
+        dip = dipper_amd.Dipper(local_rank)
+        dip.set_nj_multi_plan(2)        # timed steps: every rank builds its own tree (no collective at 30k tips)
+        comm_note = None
+        have_comm = False
+        if world > 1:
+            # the library's own RCCL communicator (used by the sharded 100k leg); if any rank cannot create it the
+            # bench line says so
+            ok, err = 1, ""
+            try:
+                uid = [dip.comm_unique_id() if rank == 0 else None]
             except Exception as e:
-                mgpu_check["matches_single_gpu"] = None
-                mgpu_check["error"] = repr(e)
-        dist.barrier()
+                uid, ok, err = [None], 0, repr(e)
+            dist.broadcast_object_list(uid, src=0)
+            if ok and uid[0] is not None:
+                try:
+                    dip.comm_init(rank, world, uid[0])
+                except Exception as e:
+                    ok, err = 0, repr(e)
+            else:
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                comm_note = "the library's RCCL communicator could not be created on every rank (%s)" % (err or "another rank failed")
+                log(f"[bench r{rank}] {comm_note}")
+                dip.close()
+                dip = dipper_amd.Dipper(local_rank)
+                dip.set_nj_multi_plan(2)
+            else:
+                have_comm = True
+        dip.set_msa(packed, L)          # H2D + bit-plane conversion: inputs now resident in HBM
+        if rank == 0:
+            log(f"[bench] device: {dip.device_name()}")
 
-    # ---- roofline of the dominant kernel: Q-argmin scan at n = N on a fresh matrix ----------------
-    dip.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
-    _, _, _, scan_ms = dip.argmin_once(reps=args.probe_reps)
-    rows_local = capi.load_library().dpr_shard_rows(n, rank, world)
-    # pruned NJ on several GPUs keeps the whole matrix on every rank (the ranks share the unit tests and scans of
-    # an iteration), so the probe streams the whole triangle; the streaming algorithm is row-sharded
-    replicated = prune is not None and world > 1 and comm_note is None
-    sharded = replicated and sharded_timed
-    whole = world == 1 or replicated or comm_note is not None      # this rank holds (and the probe streams) the whole triangle
-    if whole:
-        rows_local = n
-    alg_bytes = (4.0 * n * n if whole else 4.0 * n * n / world) + 4.0 * n   # strict lower triangle (of this rank's rows) + U once
-    achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, world),
-                "kernel": "nj_scan_kernel<PROBE=true,...> (probe instantiation of the full Q-argmin scan)",
-                "n_active": n, "algorithmic_bytes": alg_bytes, "ms": scan_ms, "rows_local": int(rows_local)}
-
-    out = {
-        "metric": "tips/sec packed aligned tips -> JC distances -> NJ merge log at N=%d" % n,
-        "value": n / (ms_per_step * 1e-3),
-        "unit": "tips/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
-        "higher_is_better": True,
-        "scaling": "strong",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic (seeded Yule-Harding tree, JC69, L=%d, no indels)" % L,
-        "config": {"workload": "configs[1]: %d aligned tips, -d 2 (JC69), conventional NJ" % n,
-                   "tips": n, "sites": L,
-                   "parallelism": comm_note or (("units%d (matrix replicated, unit tests and scans shared, one all-gather per iteration)" % world) if sharded
-                                                else ("replicas%d (every rank runs the single-GPU plan: N is below the unit-sharding threshold of 65536 tips, "
-                                                      "where an iteration is ~20 us of dependent latency; the unit-sharded plan runs once untimed, see multi_gpu_check)" % world) if replicated
-                                                else "rows%d" % world)},
-        "phase_ms": {"dist": float(np.mean([p[0] for p in phase])) if phase else None,
-                     "nj": float(np.mean([p[1] for p in phase])) if phase else None},
-        "roofline": roofline,
-        "nj_algorithm": "exact pruned scan (njp.hip)" if prune else "full streaming scan (nj.hip)",
-        "prune": prune,
-    }
-    if mgpu_check is not None:
-        out["multi_gpu_check"] = mgpu_check
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            out["cpu_baseline"] = cpu_baseline(dip, n)
-        except Exception as e:  # the baseline must never take the bench line down
-            out["cpu_baseline"] = {"value": None, "unit": "tips/s", "cores": host_cores(), "kind": "port",
-                                   "sample": f"failed: {e!r}"}
-        try:
-            out["cpu_baseline_rapidnj"] = cpu_baseline_rapidnj(dip, n)
-        except Exception as e:
-            out["cpu_baseline_rapidnj"] = {"value": None, "unit": "tips/s", "cores": host_cores(), "sample": f"failed: {e!r}"}
-    if run_sharded_check:
-        # The timed steps ran the single-GPU plan on every rank (N below the sharding threshold).  Last of all, with
-        # the record complete: run the unit-sharded plan (one RCCL all-gather per iteration) once, untimed, and compare.
-        # A watchdog ends every rank with the record printed if that path does not come back.
-        import threading
-
-        def give_up():
-            out.setdefault("multi_gpu_check", {})["unit_sharded_plan"] = {"error": "no result within 300 s"}
-            if rank == 0:
-                os.write(json_fd, (json.dumps(out) + "\n").encode())
-            os._exit(0)
-
-        dog = threading.Timer(300.0, give_up)
-        dog.daemon = True
-        dog.start()
-        try:
-            capi.set_nj_multi_plan(1)
-            barrier()
-            ts = time.perf_counter()
+        def step():
             dip.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
-            sh = dip.nj_run()
-            barrier()
-            sh_ms = (time.perf_counter() - ts) * 1e3
-            same = all(np.array_equal(sh[k], last_res[k]) for k in ("merge_x", "merge_y", "bl_x", "bl_y"))
-            okt = torch.tensor([1 if same else 0], dtype=torch.int32, device="cuda")
-            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-            out["multi_gpu_check"]["unit_sharded_plan"] = {"matches": bool(int(okt.item())), "ms_per_step": sh_ms,
-                                                           "nj_ms": dip.timing()[1]}
-        except Exception as e:
-            out["multi_gpu_check"]["unit_sharded_plan"] = {"error": repr(e)}
-        finally:
-            dog.cancel()
-            capi.set_nj_multi_plan(0)
-    dip.close()
-    if want_e2e:
-        try:
-            out["e2e_cli"] = e2e_cli(seqs, n, L)
-        except Exception as e:  # never take the bench line down
-            out["e2e_cli"] = {"error": repr(e)}
+            res = dip.nj_run()
+            assert res["iters"] == n - 2
+            return res
+
+        phase, walls_hp = [], []
+        prune = None
+        last_res = None
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ts = time.perf_counter()
+            last_res = step()
+            walls_hp.append((time.perf_counter() - ts) * 1e3)
+            phase.append(dip.timing())
+            try:
+                sc, full = dip.prune_stats()
+                prune = {"units_scanned": sc, "units_per_full_scan": full, "iterations": n - 2,
+                         "scanned_fraction_of_full_scans": sc / (full * (n - 2.0))}
+            except Exception:
+                prune = None
+        barrier()
+        dt_hp = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt_hp], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_hp = float(t.item())
+        ms_hp = dt_hp / max(args.steps, 1) * 1e3 if args.steps else float("nan")
+        nj_ms = [p[1] for p in phase]
+        hot = {"metric": "tips/sec packed aligned tips resident in HBM -> JC69 distances -> NJ merge log (C ABI, in process)",
+               "value": world * n / (ms_hp * 1e-3) if args.steps else None, "unit": "tips/s", "ms_per_step": ms_hp,
+               "steps": args.steps, "warmup": args.warmup,
+               "step_ms": stats_ms(walls_hp),
+               "phase_ms": {"dist": stats_ms([p[0] for p in phase]), "nj": stats_ms(nj_ms)},
+               "nj_us_per_iteration": (float(np.median(nj_ms)) * 1e3 / (n - 2)) if nj_ms else None,
+               "nj_iterations_per_s": (world * (n - 2) / (float(np.median(nj_ms)) * 1e-3)) if nj_ms else None,
+               "nj_algorithm": "exact pruned scan (njp.hip)" if prune else "full streaming scan (nj.hip)",
+               "prune": prune}
+        log(f"[bench r{rank}] hot path steps: {hot['step_ms']} phases {hot['phase_ms']}")
+
+        # ---- the timed kernels' own record: what the pruned scan read, and how fast ---------------------------
+        if prune and nj_ms and not args.probe_only:
+            try:
+                # one more NJ run, eager, HIP events on the library's stream around every 16th iteration's launches
+                dip.set_nj_kernel_timing(16)
+                dip.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+                dip.nj_run()
+                kt = dip.nj_kernel_timing()
+            except Exception as e:
+                kt = {"error": repr(e)}
+            finally:
+                dip.set_nj_kernel_timing(0)
+            bytes_scanned = prune["units_scanned"] * float(UNIT_BYTES)
+            rec = {"kernels_per_iteration": kt.get("kernels_per_iteration"),
+                   "units_scanned_per_iteration": prune["units_scanned"] / (n - 2.0),
+                   "bytes_scanned_per_run_upper": bytes_scanned,
+                   "note": "bytes = listed units x 64 KiB (an upper bound: a listed unit's sub-units whose own bound rules "
+                           "them out are not loaded); kernel times: HIP events on the library's stream around every "
+                           "16th iteration's launches in one extra eager (not graph-replayed) run"}
+            rec.update({k: v for k, v in kt.items() if k != "kernels_per_iteration"})
+            if kt.get("scan_us_avg"):
+                t_scan = kt["scan_us_avg"] * 1e-6 * (n - 2)
+                ach = bytes_scanned / t_scan / 1e9
+                rec["roofline_timed"] = {"bound": "hbm (latency-limited: ~100 units = 7 MB per launch)", "kernel": kt.get("scan_kernel"),
+                                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                         "bytes_per_launch": bytes_scanned / (n - 2.0), "us_per_launch": kt["scan_us_avg"]}
+            hot["timed_kernels"] = rec
+
+        # =====================================================================================================
+        # C. self-check of the timed result (untimed)
+        # =====================================================================================================
+        parity = None
+        if last_res is not None and not args.no_parity and rank == 0:
+            parity = {"merge_log_digest": merge_digest(last_res)}
+            try:
+                # (1) the streaming algorithm (the reference's: one full Q scan per iteration) on the bench's own input
+                chk = dipper_amd.Dipper(local_rank)
+                chk.set_nj_mode(0)
+                chk.set_msa(packed, L)
+                ts = time.perf_counter()
+                chk.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+                ref = chk.nj_run()
+                parity["stream_equals_pruned"] = same_log(ref, last_res)
+                parity["stream_run_s"] = time.perf_counter() - ts
+                chk.close()
+                del ref
+            except Exception as e:
+                parity["stream_equals_pruned"] = None
+                parity["stream_error"] = repr(e)
+            try:
+                # (2) the CPU oracle on the leading tips of the same alignment: GPU distances -> oracle NJ vs GPU NJ
+                from tests import _orc
+                orc = _orc.load()
+                m = min(n, 1500)
+                chk = dipper_amd.Dipper(local_rank)
+                chk.set_msa(packed[:m], L)
+                chk.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+                Dm = chk.matrix()
+                got = chk.nj_run()
+                want = orc.nj_run(np.tril(Dm, -1), threads=host_cores())
+                parity["oracle_prefix_equal"] = same_log(want, got)
+                parity["oracle_prefix_tips"] = m
+                Dref = orc.msa_dist_lower(np.ascontiguousarray(packed[:m]), L, 2)
+                lo = np.tril_indices(m, -1)
+                parity["oracle_prefix_dist_max_rel"] = float(np.max(np.abs(Dm[lo] - Dref[lo]) / np.maximum(np.abs(Dref[lo]), 1e-300))) if m > 1 else 0.0
+                chk.close()
+            except Exception as e:
+                parity["oracle_prefix_equal"] = None
+                parity["oracle_error"] = repr(e)
+            if cli is not None:
+                try:
+                    # (3) the Newick text the CLI writes for the unshuffled input (--seed -1; the timed runs shuffle the input
+                    # order like the reference) == the Newick assembled from the in-process merge log
+                    r = subprocess.run([EXE, "-i", "m", "-I", fa, "-O", nwk, "-m", "2", "-d", "2", "--device", str(local_rank),
+                                        "--seed", "-1"], capture_output=True, text=True)
+                    txt = open(nwk).read()
+                    mine = _util.newick_from_merges(names, last_res["merge_x"], last_res["merge_y"], last_res["bl_x"],
+                                                    last_res["bl_y"], last_res["last_d"])
+                    parity["cli_newick_equals_merge_log"] = bool(r.returncode == 0 and txt.strip() == mine.strip())
+                except Exception as e:
+                    parity["cli_newick_equals_merge_log"] = None
+                    parity["cli_error"] = repr(e)
+            log(f"[bench] parity_check: {parity}")
+
+        # ---- several ranks: same merge log everywhere (every rank built the same tree from the same input) ----
+        mgpu_check = None
+        if dist is not None and last_res is not None:
+            digest = int(merge_digest(last_res)[:14], 16)
+            mine = torch.tensor([digest], dtype=torch.int64, device="cuda")
+            allh = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allh, mine)
+            mgpu_check = {"ranks_agree": bool(all(int(t.item()) == digest for t in allh))}
+
+        # =====================================================================================================
+        # D. roofline of the Q-argmin (BASELINE metric 2): full streaming scan at n = N on a fresh matrix
+        # =====================================================================================================
+        dip.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+        _, _, _, scan_ms = dip.argmin_once(reps=args.probe_reps)
+        alg_bytes = 4.0 * n * n + 4.0 * n       # strict lower triangle + U once (this rank holds the whole matrix)
+        achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, 1),
+                    "kernel": "nj_scan_kernel<PROBE=true,...>: the full Q-argmin scan (SURVEY 8d's unit of work; the streaming NJ "
+                              "path runs it every iteration, the default pruned path does not -- see hot_path.timed_kernels)",
+                    "n_active": n, "algorithmic_bytes": alg_bytes, "ms": scan_ms}
+
+        primary = cli is not None
+        ms_per_step = (dt_cli / max(args.steps, 1) * 1e3) if primary else ms_hp
+        out = {
+            "metric": "tips/sec FASTA->Newick at N=%d" % n if primary else hot["metric"],
+            "value": world * n / (ms_per_step * 1e-3) if args.steps else None,
+            "unit": "tips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (seeded Yule-Harding tree, JC69, L=%d, no indels; own generator: no alisim in the image)" % L,
+            "config": {"workload": "configs[1]: %d aligned tips, -d 2 (JC69), conventional NJ (-m 2)" % n,
+                       "tips": n, "sites": L,
+                       "step": "one whole `dipper` command per rank (FASTA -> Newick)" if primary else "in-process hot path (HBM-resident input -> merge log)",
+                       "parallelism": "1 GPU" if world == 1 else
+                                      ("replicas%d: every rank builds its own %d-tip tree on its own GPU, no collective "
+                                       "(an NJ iteration at this size is dependent latency, not bandwidth); value = %d x tips / step time. "
+                                       "The sharded NJ plan is measured at %d tips: sharded_100k" % (world, n, world, args.sharded_tips))},
+            "step_ms": cli["wall_ms"] if primary else hot["step_ms"],
+            "e2e_cli": cli,
+            "hot_path": hot,
+            "phase_ms": {"dist": hot["phase_ms"]["dist"]["mean"] if hot["phase_ms"]["dist"] else None,
+                         "nj": hot["phase_ms"]["nj"]["mean"] if hot["phase_ms"]["nj"] else None},
+            "roofline": roofline,
+            "parity_check": parity,
+        }
+        if comm_note:
+            out["comm_note"] = comm_note
+        if mgpu_check is not None:
+            out["multi_gpu_check"] = mgpu_check
+
+        # =====================================================================================================
+        # E. CPU baselines (rank 0, one GPU): bounded samples on the GPU's own matrix
+        # =====================================================================================================
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.probe_only:
+            cores = host_cores()
+            for key, fn, kw in (("cpu_baseline", cpu_baseline, {"cores": cores}),
+                                ("cpu_baseline_1core", cpu_baseline, {"cores": 1, "budget_s": 10.0}),
+                                ("cpu_baseline_rapidnj", cpu_baseline_rapidnj, {"cores": cores})):
+                try:
+                    out[key] = fn(dip, n, **kw)
+                except Exception as e:  # a baseline must never take the bench line down
+                    out[key] = {"value": None, "unit": "tips/s", "cores": kw.get("cores"), "kind": "port", "sample": f"failed: {e!r}"}
+            try:
+                out["rapidnj_path_probe"] = rapidnj_probe(dip, n, cores, tmp)
+            except Exception as e:
+                out["rapidnj_path_probe"] = {"found": None, "error": repr(e)}
+        dip.close()
+        dip = None
+
+        # =====================================================================================================
+        # F. several GPUs: the unit-sharded NJ plan where it can pay -- N = 100 000 (80 GB matrix per rank), one step
+        # =====================================================================================================
+        run_sharded = (world > 1 and have_comm) or force_check
+        if run_sharded and not args.no_sharded and not args.probe_only:
+            # last of all, with the record complete, under a watchdog: a hung RCCL path must not take the line down --
+            # the record is printed and the process ends NON-ZERO so that the launcher tears the job down
+            def give_up():
+                out["sharded_100k"] = {"error": "no result within the time limit"}
+                if rank == 0:
+                    os.write(json_fd, (json.dumps(out) + "\n").encode())
+                os._exit(3)
+
+            dog = threading.Timer(900.0, give_up)
+            dog.daemon = True
+            dog.start()
+            try:
+                out["sharded_100k"] = sharded_leg(args, rank, world, local_rank, dist, torch, barrier, force_check)
+            except Exception as e:
+                out["sharded_100k"] = {"error": repr(e)}
+            finally:
+                dog.cancel()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
+
+
+def sharded_leg(args, rank, world, local_rank, dist, torch, barrier, rehearsal):
+    """N = 100 000 x 2 000 sites, one NJ run with the unit-sharded plan over the library's RCCL communicator (matrix
+    replicated, unit tests and scans owned by rank, one all-gather of block records per iteration), next to the
+    single-GPU plan on rank 0's GPU alone.  Reports NJ iterations/s for both and whether the merge logs agree."""
+    import dipper_amd
+    from dipper_amd import capi
+    ns, Ls = args.sharded_tips, args.sharded_sites
+    t0 = time.perf_counter()
+    rng = np.random.default_rng(args.seed + 7)
+    from tests import _util
+    seqs = _util.synth_alignment(rng, ns, Ls, mean_bl=2e-5 * 10000 / Ls, lo=2e-6 * 10000 / Ls, hi=2e-4 * 10000 / Ls)
+    packed = capi.pack4_many(seqs)
+    del seqs
+    log(f"[bench r{rank}] sharded leg: input {ns} x {Ls} in {time.perf_counter()-t0:.1f}s")
+    rec = {"tips": ns, "sites": Ls, "world": world}
+    d = dipper_amd.Dipper(local_rank)
+    if world > 1:
+        uid = [d.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        d.comm_init(rank, world, uid[0])
+    d.set_nj_multi_plan(1)
+    d.set_msa(packed, Ls)
+    barrier()
+    ts = time.perf_counter()
+    d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+    res = d.nj_run()
+    barrier()
+    wall = time.perf_counter() - ts
+    dist_ms, nj_ms = d.timing()
+    rec["unit_sharded_plan"] = {"is_unit_sharded": d.nj_is_unit_sharded(), "rccl_ranks": world, "wall_s": wall, "dist_ms": dist_ms, "nj_ms": nj_ms,
+                                "nj_iterations_per_s": (ns - 2) / (nj_ms * 1e-3), "merge_log_digest": merge_digest(res)}
+    try:
+        sc, full = d.prune_stats()
+        rec["unit_sharded_plan"]["units_scanned_this_rank"] = sc
+    except Exception:
+        pass
+    d.close()
+    digest = int(merge_digest(res)[:14], 16)
+    if dist is not None:
+        mine = torch.tensor([digest], dtype=torch.int64, device="cuda")
+        allh = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allh, mine)
+        rec["ranks_agree"] = bool(all(int(t.item()) == digest for t in allh))
+    if rank == 0:       # the single-GPU plan on one GPU, for the 1-GPU denominator (the other ranks wait)
+        s = dipper_amd.Dipper(local_rank)
+        s.set_nj_multi_plan(2)
+        s.set_msa(packed, Ls)
+        ts = time.perf_counter()
+        s.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+        ref = s.nj_run()
+        wall1 = time.perf_counter() - ts
+        d1, n1 = s.timing()
+        rec["single_gpu_plan"] = {"wall_s": wall1, "dist_ms": d1, "nj_ms": n1, "nj_iterations_per_s": (ns - 2) / (n1 * 1e-3)}
+        rec["matches_single_gpu"] = same_log(ref, res)
+        rec["nj_speedup_vs_single_gpu"] = n1 / nj_ms
+        s.close()
+    if dist is not None:
+        dist.barrier()
+    return rec
 
 
 if __name__ == "__main__":

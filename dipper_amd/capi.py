@@ -61,6 +61,14 @@ def load_library():
     L.dpr_set_nj_mode.argtypes = [C.c_int]
     L.dpr_set_nj_multi_plan.argtypes = [C.c_int]
     L.dpr_nj_is_unit_sharded.argtypes = [C.c_void_p]
+    L.dpr_ctx_set_nj_mode.argtypes = [C.c_void_p, C.c_int]
+    L.dpr_ctx_set_nj_multi_plan.argtypes = [C.c_void_p, C.c_int]
+    L.dpr_ctx_set_nj_virtual_shards.argtypes = [C.c_void_p, C.c_int]
+    L.dpr_ctx_set_nj_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+    L.dpr_get_nj_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_int), c_f64p, C.POINTER(C.c_int64)]
+    L.dpr_nj_kernel_name.argtypes = [C.c_int]
+    L.dpr_nj_kernel_name.restype = C.c_char_p
+    L.dpr_get_place_timing.argtypes = [C.c_void_p, c_f64p, c_f64p]
     L.dpr_get_prune_stats.argtypes = [C.c_void_p, c_u64p, c_u64p]
     L.dpr_bw_probe.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.dpr_set_msa.argtypes = [C.c_void_p, c_u64p, C.c_int64, C.c_int64]
@@ -314,6 +322,16 @@ class Dipper:
     def nj_is_unit_sharded(self):
         return bool(self.L.dpr_nj_is_unit_sharded(self.h))
 
+    # plan knobs of THIS context (-1 = follow the process-wide default); effective at the next dist_matrix
+    def set_nj_mode(self, mode):
+        _chk(self.L, self.L.dpr_ctx_set_nj_mode(self.h, mode))
+
+    def set_nj_multi_plan(self, plan):
+        _chk(self.L, self.L.dpr_ctx_set_nj_multi_plan(self.h, plan))
+
+    def set_nj_virtual_shards(self, w):
+        _chk(self.L, self.L.dpr_ctx_set_nj_virtual_shards(self.h, w))
+
     def argmin_once(self, reps=1):
         i = C.c_int32()
         j = C.c_int32()
@@ -321,6 +339,29 @@ class Dipper:
         ms = C.c_float()
         _chk(self.L, self.L.dpr_argmin_once(self.h, reps, C.byref(i), C.byref(j), C.byref(q), C.byref(ms)))
         return i.value, j.value, q.value, ms.value
+
+    def set_nj_kernel_timing(self, stride):
+        _chk(self.L, self.L.dpr_ctx_set_nj_kernel_timing(self.h, stride))
+
+    def nj_kernel_timing(self):
+        """per-kernel averages of the last timed NJ run (set_nj_kernel_timing): launch order, microseconds"""
+        nk = C.c_int()
+        ns = C.c_int64()
+        us = np.zeros(4, np.float64)
+        _chk(self.L, self.L.dpr_get_nj_kernel_timing(self.h, C.byref(nk), _p(us, c_f64p), C.byref(ns)))
+        names = [(self.L.dpr_nj_kernel_name(i) or b"").decode() for i in range(nk.value)]
+        rec = {"kernels_per_iteration": nk.value, "sampled_iterations": int(ns.value),
+               "kernel_us_avg": {nm: float(us[i]) for i, nm in enumerate(names)}}
+        for i, nm in enumerate(names):
+            if "scan" in nm:
+                rec["scan_kernel"], rec["scan_us_avg"] = nm, float(us[i])
+        return rec
+
+    def place_timing(self):
+        a = C.c_double()
+        b = C.c_double()
+        _chk(self.L, self.L.dpr_get_place_timing(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     # ---- hooks ------------------------------------------------------------------------------------
     def n_active(self):

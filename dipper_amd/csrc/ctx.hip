@@ -75,8 +75,13 @@ struct dpr_ctx {
     bool nj_replicated = false;      // several ranks, each holding the whole matrix (pruned NJ)
     bool nj_unit_sharded = false;    // ... and sharing the unit tests / scans of an iteration (else: every rank runs the single-GPU plan)
     double dist_ms = 0, nj_ms = 0;
+    double place_dist_ms = 0;        // distance rows of the last placement run (the rest of nj_ms is tree work)
+    std::vector<hipEvent_t> place_ev;   // event pairs around the distance batches of the current placement run
     dpr::DcStats dc_stats;
     double dc_ms[3] = { 0, 0, 0 };   // backbone, cluster assignment, cluster trees
+    // plan knobs of THIS context (dpr_ctx_set_*); -1 = follow the process-wide default (dpr_set_* / environment)
+    int nj_mode = -1, nj_vshards = -1, nj_multi_plan = -1;
+    dpr::NjKernelTiming nj_kt;
 };
 
 using namespace dpr;
@@ -108,14 +113,17 @@ static int njp_gather_cb(void* ctx, void* buf, size_t bytes_per_rank, hipStream_
     }
     return DPR_OK;
 }
-static bool want_pruned()
+static bool want_pruned(const dpr_ctx* c)
 {
+    if (c->nj_mode >= 0) return c->nj_mode == 1;
     if (g_nj_mode < 0) {
         const char* e = std::getenv("DPR_NJ_MODE");
         g_nj_mode = (e && std::strcmp(e, "stream") == 0) ? 0 : 1;
     }
     return g_nj_mode == 1;
 }
+static int ctx_multi_plan(const dpr_ctx* c) { return c->nj_multi_plan >= 0 ? c->nj_multi_plan : nj_multi_plan(); }
+static int ctx_vshards(const dpr_ctx* c) { return c->nj_vshards >= 1 ? c->nj_vshards : g_nj_vshards; }
 
 // ---- exchange step of the sharded path: RCCL all-gather, or device copies between virtual ranks --
 enum ExKind { EX_RECS, EX_SLICES, EX_U };
@@ -266,8 +274,15 @@ int dpr_create(dpr_ctx** out, int device)
     }
     dpr_ctx* c = new dpr_ctx();
     c->device = device;
-    DPR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (auto& ev : c->ev) DPR_HIP(hipEventCreate(&ev));
+    hipError_t ce = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (auto& ev : c->ev)
+        if (ce == hipSuccess) ce = hipEventCreate(&ev);
+    if (ce != hipSuccess) {          // nothing of a half-built context is left behind
+        for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return hip_fail(ce, "dpr_create: stream / event creation");
+    }
     // first launch of the library: the runtime loads the whole gfx950 code object now, i.e. inside context creation
     // (which the CLI overlaps with reading the input) instead of in front of the first distance kernel
     hipLaunchKernelGGL(dpr_warm_kernel, dim3(1), dim3(64), 0, c->stream, 0);
@@ -282,6 +297,8 @@ int dpr_destroy(dpr_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    for (hipEvent_t e : c->place_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->nj_kt.ev) (void)hipEventDestroy(e);
     for (auto& b : c->nj) nj_free(b);
     msa_free(c->msa);
     mash_free(c->mash);
@@ -468,7 +485,7 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
     // Several real ranks + pruned NJ: every rank builds and keeps the WHOLE matrix (7.2 GB at 30 000 tips, 80 GB at
     // 100 000) and the ranks share the per-iteration unit tests and scans (njp.hip, unit-sharded mode).  The
     // streaming algorithm (DPR_NJ_MODE=stream) keeps the row-sharded layout.
-    const bool repl = c->world > 1 && c->vworld == 0 && want_pruned() && n >= 3;
+    const bool repl = c->world > 1 && c->vworld == 0 && want_pruned(c) && n >= 3;
     c->nj_replicated = repl;
     for (size_t r = 0; r < c->nj.size(); ++r)
         if (int rc = nj_alloc(c->nj[r], n, repl ? 0 : (c->vworld > 0 ? (int)r : c->rank), repl ? 1 : c->world, c->stream)) return rc;
@@ -493,12 +510,13 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
     }
     for (auto& b : c->nj)
         if (int rc = nj_prepare(b, c->stream)) return rc;
-    if ((c->world == 1 || repl) && want_pruned() && n >= 3) {
+    if ((c->world == 1 || repl) && want_pruned(c) && n >= 3) {
         NjPruned& q = c->nj[0].pr;
-        const bool shard = repl && (nj_multi_plan() == 1 || (nj_multi_plan() == 0 && n >= kNjShardTips));
+        const int plan = ctx_multi_plan(c);
+        const bool shard = repl && (plan == 1 || (plan == 0 && n >= kNjShardTips));
         c->nj_unit_sharded = shard;
         if (shard) { q.sh_world = c->world; q.sh_rank = c->rank; q.sh_virtual = false; q.gather = njp_gather_cb; q.gather_ctx = c; }
-        else if (g_nj_vshards > 1) { q.sh_world = g_nj_vshards; q.sh_rank = 0; q.sh_virtual = true; }
+        else if (ctx_vshards(c) > 1) { q.sh_world = ctx_vshards(c); q.sh_rank = 0; q.sh_virtual = true; }
         if (int rc = njp_build(c->nj[0], c->stream)) return rc;
     }
     DPR_HIP(hipEventRecord(c->ev[1], c->stream));
@@ -506,8 +524,7 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
     float ms = 0;
     DPR_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->dist_ms = ms;
-    if (source == DPR_SRC_MATRIX) { (void)hipFree(c->packed_lower); c->packed_lower = nullptr; }
-    c->have_matrix = 1;
+    c->have_matrix = 1;   // (the packed triangle of a MATRIX source stays until dpr_set_matrix_lower / dpr_destroy)
     return DPR_OK;
 }
 
@@ -530,6 +547,8 @@ int64_t dpr_nj_run(dpr_ctx* c, int64_t max_iters, int32_t* merge_x, int32_t* mer
     if (todo < 0) todo = 0;
     if (max_iters >= 0 && max_iters < todo) todo = max_iters;
     const int64_t it0 = st.it;
+    c->nj[0].kt = &c->nj_kt;
+    if (c->nj_kt.stride > 0 && it0 == 0) { c->nj_kt.samples = 0; for (double& v : c->nj_kt.us_sum) v = 0; }
     DPR_HIP(hipEventRecord(c->ev[2], c->stream));
     if (c->nj[0].pr.active) {
         if (int rc = njp_run(c->nj[0], it0, todo, c->stream)) return rc;
@@ -545,6 +564,19 @@ int64_t dpr_nj_run(dpr_ctx* c, int64_t max_iters, int32_t* merge_x, int32_t* mer
     float ms = 0;
     DPR_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
     c->nj_ms = ms;
+    if (!c->nj_kt.ev.empty()) {       // per-kernel timing samples of this run (stream idle)
+        NjKernelTiming& kt = c->nj_kt;
+        const size_t grp = (size_t)kt.nk + 1;
+        for (size_t g0 = 0; kt.nk > 0 && g0 + grp <= kt.ev.size(); g0 += grp) {
+            for (int k = 0; k < kt.nk; ++k) {
+                float us = 0;
+                if (hipEventElapsedTime(&us, kt.ev[g0 + (size_t)k], kt.ev[g0 + (size_t)k + 1]) == hipSuccess) kt.us_sum[k] += (double)us * 1e3;
+            }
+            ++kt.samples;
+        }
+        for (hipEvent_t e : kt.ev) (void)hipEventDestroy(e);
+        kt.ev.clear();
+    }
     const int64_t done = st.it - it0;
     if (done > 0) {
         if (merge_x) DPR_HIP(hipMemcpy(merge_x, c->nj[0].log_x + it0, sizeof(int32_t) * (size_t)done, hipMemcpyDeviceToHost));
@@ -634,6 +666,45 @@ int dpr_set_nj_multi_plan(int plan)
 }
 int dpr_nj_is_unit_sharded(dpr_ctx* c) { return c && c->nj_unit_sharded ? 1 : 0; }
 
+// the same three knobs for ONE context (two contexts in one process may run different plans); value -1 = follow
+// the process-wide default again.  Take effect at the context's next dpr_dist_matrix.
+int dpr_ctx_set_nj_mode(dpr_ctx* c, int mode)
+{
+    if (!c || mode < -1 || mode > 1) { set_error("dpr_ctx_set_nj_mode: mode must be -1, 0 or 1"); return DPR_ERR_ARG; }
+    c->nj_mode = mode;
+    return DPR_OK;
+}
+int dpr_ctx_set_nj_multi_plan(dpr_ctx* c, int plan)
+{
+    if (!c || plan < -1 || plan > 2) { set_error("dpr_ctx_set_nj_multi_plan: -1 default, 0 auto, 1 unit-sharded, 2 single-GPU plan on every rank"); return DPR_ERR_ARG; }
+    c->nj_multi_plan = plan;
+    return DPR_OK;
+}
+// Per-kernel timing of the pruned NJ loop: stride > 0 makes the following dpr_nj_run calls enqueue their iterations
+// eagerly (no hipGraph replay) with HIP events on the library's stream around the launches of every stride-th iteration.
+int dpr_ctx_set_nj_kernel_timing(dpr_ctx* c, int stride)
+{
+    if (!c || stride < 0) { set_error("dpr_ctx_set_nj_kernel_timing: stride >= 0"); return DPR_ERR_ARG; }
+    c->nj_kt.stride = stride;
+    return DPR_OK;
+}
+int dpr_get_nj_kernel_timing(dpr_ctx* c, int* kernels, double* us_avg, int64_t* samples)
+{
+    if (!c) { set_error("dpr_get_nj_kernel_timing: null ctx"); return DPR_ERR_ARG; }
+    if (kernels) *kernels = c->nj_kt.nk;
+    if (samples) *samples = c->nj_kt.samples;
+    if (us_avg) for (int k = 0; k < kNjKernelsMax; ++k) us_avg[k] = c->nj_kt.samples > 0 ? c->nj_kt.us_sum[k] / (double)c->nj_kt.samples : 0.0;
+    return DPR_OK;
+}
+const char* dpr_nj_kernel_name(int idx) { return njp_kernel_name(idx); }
+
+int dpr_ctx_set_nj_virtual_shards(dpr_ctx* c, int w)
+{
+    if (!c || w < -1 || w == 0 || w > 64) { set_error("dpr_ctx_set_nj_virtual_shards: -1 or 1 <= w <= 64"); return DPR_ERR_ARG; }
+    c->nj_vshards = w;
+    return DPR_OK;
+}
+
 // 0 = full streaming scan every iteration, 1 = exact pruned scan (default)
 int dpr_set_nj_mode(int mode)
 {
@@ -711,7 +782,13 @@ int dpr_bw_probe(dpr_ctx* c, int64_t bytes, int nt, int grid, int reps, float* o
 {
     if (!c || !c->have_matrix || !out_ms || grid < 1 || reps < 1) { set_error("dpr_bw_probe: bad argument"); return DPR_ERR_ARG; }
     DPR_HIP(hipSetDevice(c->device));
-    return nj_bw_probe(c->nj[0], bytes, nt, grid, reps, c->stream, c->ev[2], c->ev[3], out_ms);
+    // the buffer the Q-argmin scans: the position-space matrix of the pruned path (whose tip-order matrix is dead
+    // once the first epoch is built), else this rank's rows
+    NjBuffers& b = c->nj[0];
+    const double* buf = b.pr.active ? b.pr.D : b.D;
+    const int64_t cap = b.pr.active ? b.pr.P * b.pr.ld * (int64_t)sizeof(double) : b.rows_local * b.ld * (int64_t)sizeof(double);
+    if (!buf || cap <= 0) { set_error("dpr_bw_probe: no matrix buffer"); return DPR_ERR_STATE; }
+    return nj_bw_probe(buf, cap, b.xpart, bytes, nt, grid, reps, c->stream, c->ev[2], c->ev[3], out_ms);
 }
 
 // ---- test hooks ---------------------------------------------------------------------------------------------
@@ -820,7 +897,7 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
         if (source == DPR_SRC_MASH) return mash_dist_rows(c->mash, i0, nr, 0, 0, false, i0 + nr, out, ldb, c->stream);
         return DPR_OK;
     };
-    auto fill_rows = [&](int64_t i0, int64_t nr) -> int {
+    auto fill_rows_inner = [&](int64_t i0, int64_t nr) -> int {
         if (!sharded) return fill_some(i0, nr, rows);
         const int64_t a = (int64_t)c->rank * per, b = a + per < nr ? a + per : nr;     // this rank's rows of the batch
         if (int rc = fill_some(i0 + a, b - a, rows + a * ldb)) return rc;
@@ -829,6 +906,19 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
             return DPR_ERR_COMM;
         }
         return DPR_OK;
+    };
+    // the reference reports the distance and the tree part of a placement run separately
+    // (src/placement_close_k.cu:852-853,985-986): an event pair around every distance batch, summed by the caller
+    auto fill_rows = [&](int64_t i0, int64_t nr) -> int {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (source != DPR_SRC_MATRIX) {
+            DPR_HIP(hipEventCreate(&e0)); DPR_HIP(hipEventCreate(&e1));
+            c->place_ev.push_back(e0); c->place_ev.push_back(e1);
+            DPR_HIP(hipEventRecord(e0, c->stream));
+        }
+        const int rc = fill_rows_inner(i0, nr);
+        if (e1) DPR_HIP(hipEventRecord(e1, c->stream));
+        return rc;
     };
     int rc = DPR_OK;
     if (first == 2) {
@@ -848,6 +938,27 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
         (void)hipFree(rows);
     }
     return rc;
+}
+
+// sum of the distance-batch event pairs of the run that just finished (stream idle); the events are released
+static void place_collect_dist_ms(dpr_ctx* c)
+{
+    double tot = 0;
+    for (size_t i = 0; i + 1 < c->place_ev.size(); i += 2) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->place_ev[i], c->place_ev[i + 1]) == hipSuccess) tot += ms;
+    }
+    for (hipEvent_t e : c->place_ev) (void)hipEventDestroy(e);
+    c->place_ev.clear();
+    c->place_dist_ms = tot;
+}
+
+int dpr_get_place_timing(dpr_ctx* c, double* dist_ms, double* tree_ms)
+{
+    if (!c) { set_error("dpr_get_place_timing: null ctx"); return DPR_ERR_ARG; }
+    if (dist_ms) *dist_ms = c->place_dist_ms;
+    if (tree_ms) *tree_ms = c->nj_ms > c->place_dist_ms ? c->nj_ms - c->place_dist_ms : 0.0;
+    return DPR_OK;
 }
 
 int dpr_place_run(dpr_ctx* c, int source, int dist_type, int k, int64_t first, int64_t n, int32_t* head,
@@ -876,7 +987,7 @@ int dpr_place_run(dpr_ctx* c, int source, int dist_type, int k, int64_t first, i
         DPR_HIP(hipMemcpyAsync(p.len, len, sizeof(double) * (size_t)(8 * n), hipMemcpyHostToDevice, c->stream));
     }
     DPR_HIP(hipEventRecord(c->ev[2], c->stream));
-    if (int rc = place_range(c, source, dist_type, first, n)) return rc;
+    if (int rc = place_range(c, source, dist_type, first, n)) { place_collect_dist_ms(c); return rc; }
     DPR_HIP(hipEventRecord(c->ev[3], c->stream));
     DPR_HIP(hipMemcpyAsync(head, p.head, sizeof(int32_t) * (size_t)(2 * n), hipMemcpyDeviceToHost, c->stream));
     DPR_HIP(hipMemcpyAsync(e, p.e, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
@@ -887,6 +998,7 @@ int dpr_place_run(dpr_ctx* c, int source, int dist_type, int k, int64_t first, i
     float ms = 0;
     DPR_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
     c->nj_ms = ms;
+    place_collect_dist_ms(c);
     return DPR_OK;
 }
 
@@ -1103,6 +1215,7 @@ int dpr_dc_run(dpr_ctx* c, int source, int dist_type, int k, int64_t n, int64_t 
         return DPR_OK;
     };
     const int rc = run();
+    place_collect_dist_ms(c);     // (backbone placement batches; the events must not outlive the run)
     if (dT) (void)hipFree(dT);
     if (d_cl) (void)hipFree(d_cl);
     if (snap_old) (void)hipFree(snap_old);

@@ -104,6 +104,15 @@ struct NjPruned {
     void* gather_ctx = nullptr;
     unsigned long long* cnt_all = nullptr;   // [local ranks][2] list counters
     int64_t list_stride = 0;
+    // Arena, kept until nj_free (a context that builds a matrix of the same size again allocates nothing):
+    // one matrix buffer of the pruned path's own -- the epochs alternate between it and NjBuffers::D, whose tip-order
+    // contents are dead once epoch 0 is built -- and two slabs for the per-epoch vectors (an epoch rebuild reads the
+    // old epoch's vectors while it writes the new one's).
+    double* arena_D = nullptr;
+    char* arena_slab[2] = { nullptr, nullptr };
+    size_t arena_slab_bytes = 0;
+    int64_t arena_N = 0;
+    int epoch_index = 0;             // epoch e uses slab e & 1; its matrix lives in arena_D for even e, in NjBuffers::D for odd e
     hipGraphExec_t graph = nullptr;   // kGraphIters iterations of (test, scan, post, bounds)
     int32_t* list = nullptr;         // units selected by the prep kernel (strip << 20 | group)
     int32_t *blk_cb = nullptr, *blk_g0 = nullptr;   // prep block -> (strip, first group)
@@ -111,7 +120,19 @@ struct NjPruned {
     uint64_t* iterstats = nullptr;   // optional (DPR_NJ_ITERSTATS): per iteration units scanned, max per block
 };
 
+// optional per-kernel timing of the pruned NJ loop (dpr_ctx_set_nj_kernel_timing): the run is enqueued eagerly and every
+// stride-th iteration's launches are bracketed by HIP events on the library's stream
+constexpr int kNjKernelsMax = 4;
+struct NjKernelTiming {
+    int stride = 0;                    // 0 = off
+    int nk = 0;                        // kernels per iteration of the last timed run
+    std::vector<hipEvent_t> ev;        // (nk + 1) events per sampled iteration
+    double us_sum[kNjKernelsMax] = { 0, 0, 0, 0 };
+    int64_t samples = 0;
+};
+
 struct NjBuffers {
+    NjKernelTiming* kt = nullptr;   // owned by the context
     double* D = nullptr;       // [rows_local_max][ld] (+ tail pad)
     int64_t ld = 0;
     int64_t N = 0;             // total tips
@@ -135,7 +156,8 @@ struct NjBuffers {
 };
 
 // nj.hip
-int nj_alloc(NjBuffers& b, int64_t N, int rank, int world, hipStream_t s);   // fills ordered on s
+int nj_alloc(NjBuffers& b, int64_t N, int rank, int world, hipStream_t s);   // fills ordered on s; same shape again: buffers kept
+int nj_fill_pads(double* D, int64_t ld, int64_t nrows, int64_t ncols, int64_t rows_alloc, int64_t tail, bool diag, hipStream_t s);
 void nj_free(NjBuffers& b);
 int nj_expand_lower(NjBuffers& b, const double* d_packed_lower, hipStream_t s);
 int nj_init_sums(NjBuffers& b, hipStream_t s);          // U (local rows), diag, state
@@ -143,7 +165,8 @@ int nj_prepare(NjBuffers& b, hipStream_t s);            // Ur, KA for n = st->n
 int nj_launch_scan(NjBuffers& b, bool probe, int64_t n, int64_t it, hipStream_t s);
 void nj_scan_config(int rg, int nt, int grid);  // tuning knobs (dpr_scan_tune)
 int nj_scan_grid();
-int nj_bw_probe(NjBuffers& b, int64_t bytes, int nt, int grid, int reps, hipStream_t s, hipEvent_t e0, hipEvent_t e1, float* ms);
+int nj_bw_probe(const double* buf, int64_t cap_bytes, double* sink, int64_t bytes, int nt, int grid, int reps, hipStream_t s, hipEvent_t e0,
+                hipEvent_t e1, float* ms);
 int nj_launch_post(NjBuffers& b, int64_t n, int64_t it, hipStream_t s);            // world == 1
 int nj_launch_select_local(NjBuffers& b, int nparts, hipStream_t s);                            // -> b.recs[b.rank]
 int nj_launch_commit_extract(NjBuffers& b, int64_t n, int64_t it, hipStream_t s);   // world > 1
@@ -152,11 +175,13 @@ int nj_launch_unpack_u(NjBuffers& b, hipStream_t s);                            
 int nj_launch_finish(NjBuffers& b, int64_t n, int64_t it, hipStream_t s);           // materialise U[x] after the loop
 
 // njp.hip: exact pruned NJ (world == 1)
-int njp_build(NjBuffers& b, hipStream_t s);   // permute the tip-order matrix by ascending row sum; frees b.D
-void njp_free(NjPruned& q);
+int njp_build(NjBuffers& b, hipStream_t s);   // permute the tip-order matrix by ascending row sum into the pruned path's own buffer
+void njp_free(NjPruned& q);                   // everything, the arena included
+void njp_reset(NjPruned& q);                  // epoch state only (graph, pointers); the arena stays for the next build
 int njp_scan_grid();
 int njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world);
 int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s);   // enqueue `todo` iterations (hipGraph replays)
+const char* njp_kernel_name(int idx);   // kernels of one iteration, in launch order
 
 // Divide-and-conquer cluster distances (dc.hip builds the jobs; msa.hip / mash.hip run them).
 // Cluster ci has cl_m[ci] members (tip ids members[cl_moff[ci] + t], ascending) and a leaf list

@@ -474,15 +474,16 @@ __global__ __launch_bounds__(kThreads) void bw_read_kernel(const v2d* __restrict
     if (m == -1.2345e300) out[0] = m;  // never true: keeps the loads alive
 }
 
-int nj_bw_probe(NjBuffers& b, int64_t bytes, int nt, int grid, int reps, hipStream_t s, hipEvent_t e0, hipEvent_t e1, float* ms)
+int nj_bw_probe(const double* buf, int64_t cap, double* sink, int64_t bytes, int nt, int grid, int reps, hipStream_t s, hipEvent_t e0,
+                hipEvent_t e1, float* ms)
 {
-    const int64_t cap = (int64_t)b.rows_local * b.ld * (int64_t)sizeof(double);
+    if (!buf || cap <= 0) { set_error("nj_bw_probe: no buffer"); return DPR_ERR_STATE; }
     if (bytes <= 0 || bytes > cap) bytes = cap;
     const int64_t nvec = bytes / 16;
     for (int r = -1; r < reps; ++r) {
         if (r == 0) DPR_HIP(hipEventRecord(e0, s));
-        if (nt) hipLaunchKernelGGL(bw_read_kernel<true>, dim3(grid), dim3(kThreads), 0, s, reinterpret_cast<const v2d*>(b.D), nvec, b.xpart);
-        else hipLaunchKernelGGL(bw_read_kernel<false>, dim3(grid), dim3(kThreads), 0, s, reinterpret_cast<const v2d*>(b.D), nvec, b.xpart);
+        if (nt) hipLaunchKernelGGL(bw_read_kernel<true>, dim3(grid), dim3(kThreads), 0, s, reinterpret_cast<const v2d*>(buf), nvec, sink);
+        else hipLaunchKernelGGL(bw_read_kernel<false>, dim3(grid), dim3(kThreads), 0, s, reinterpret_cast<const v2d*>(buf), nvec, sink);
     }
     DPR_HIP(hipEventRecord(e1, s));
     DPR_HIP(hipStreamSynchronize(s));
@@ -496,46 +497,82 @@ int nj_bw_probe(NjBuffers& b, int64_t bytes, int nt, int grid, int reps, hipStre
 // ------------------------------------------------------------------------------------------------
 static int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+// zero the parts of a [rows_alloc][ld] matrix buffer that the producers of the nrows x ncols block do not write: the
+// columns [ncols, ld) of the rows below nrows, the rows [nrows, rows_alloc) and the tail pad behind the last row (the scan tiles may
+// read them; what they hold never reaches a result -- the rows / columns are masked by index or by a NaN row sum --
+// but a reused buffer then holds exactly what a fresh, zero-filled one does)
+__global__ __launch_bounds__(kThreads) void nj_fill_pads_kernel(double* __restrict__ D, int64_t ld, int64_t nrows,
+                                                                int64_t ncols, int64_t rows_alloc, int64_t tail, int diag)
+{
+    for (int64_t r = blockIdx.x; r < rows_alloc + 1; r += gridDim.x) {
+        double* row = D + r * ld;
+        const int64_t c0 = r < nrows ? ncols : 0, c1 = r < rows_alloc ? ld : tail;
+        for (int64_t c = c0 + threadIdx.x; c < c1; c += kThreads) row[c] = 0.0;
+        if (diag && r < nrows && r < ncols && threadIdx.x == 0) row[r] = 0.0;   // (the Mash pair kernel writes j < i and its mirror only)
+    }
+}
+
+int nj_fill_pads(double* D, int64_t ld, int64_t nrows, int64_t ncols, int64_t rows_alloc, int64_t tail, bool diag, hipStream_t s)
+{
+    const int64_t g = rows_alloc + 1 < 4096 ? rows_alloc + 1 : 4096;
+    hipLaunchKernelGGL(nj_fill_pads_kernel, dim3((unsigned)g), dim3(kThreads), 0, s, D, ld, nrows, ncols, rows_alloc, tail, diag ? 1 : 0);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
 // (all fills are ordered on the caller's stream: a plain hipMemset runs on the null stream, which a non-blocking
 // stream does not wait for -- the fill of a 7 GB matrix would still be running when the first distance tiles land)
+//
+// A context that builds a matrix of the same shape again (bench.py's steps, a second dpr_dist_matrix) keeps every
+// buffer: freeing and re-allocating 2 x 7.2 GB per call at 30 000 tips cost more than the distance kernel itself.
+// Only the pads are zeroed then -- every element of the n x n block is overwritten by the distance kernels.
 int nj_alloc(NjBuffers& b, int64_t N, int rank, int world, hipStream_t s)
 {
-    nj_free(b);
-    b.N = N; b.rank = rank; b.world = world;
-    b.ld = round_up(N, 16);
-    b.rows_local = shard_rows(N, rank, world);
-    const int64_t rows_alloc = round_up(b.rows_local > 0 ? b.rows_local : 1, kRowBlock);
+    const bool reuse = b.D != nullptr && b.N == N && b.rank == rank && b.world == world;
+    if (!reuse) {
+        nj_free(b);
+        b.N = N; b.rank = rank; b.world = world;
+        b.ld = round_up(N, 16);
+        b.rows_local = shard_rows(N, rank, world);
+    }
+    // (+32 rows: the pruned path reuses this buffer for its odd epochs, whose row groups end up to 31 rows behind N)
+    const int64_t rows_alloc = round_up(b.rows_local > 0 ? b.rows_local : 1, kRowBlock) + 32;
     const size_t dbytes = (size_t)(rows_alloc * b.ld + kTileCols + 16) * sizeof(double);
-    DPR_HIP(hipMalloc(&b.D, dbytes));
-    DPR_HIP(hipMemsetAsync(b.D, 0, dbytes, s));
     const size_t vec = (size_t)(N + kTileCols + 16);
-    DPR_HIP(hipMalloc(&b.U, vec * sizeof(double)));
-    DPR_HIP(hipMalloc(&b.Ur, vec * sizeof(double)));
-    DPR_HIP(hipMalloc(&b.KA, vec * sizeof(uint64_t)));
-    DPR_HIP(hipMemsetAsync(b.U, 0, vec * sizeof(double), s));
-    DPR_HIP(hipMemsetAsync(b.Ur, 0, vec * sizeof(double), s));
-    DPR_HIP(hipMemsetAsync(b.KA, 0, vec * sizeof(uint64_t), s));
-    DPR_HIP(hipMalloc(&b.partials, sizeof(NjRecord) * kScanBlocks));
-    DPR_HIP(hipMemsetAsync(b.partials, 0xff, sizeof(NjRecord) * kScanBlocks, s));  // key = ~0: "no candidate"
-    DPR_HIP(hipMalloc(&b.recs, sizeof(NjRecord) * (size_t)(world > 1 ? world : 1)));
-    DPR_HIP(hipMalloc(&b.xpart, sizeof(double) * (size_t)((N + kThreads - 1) / kThreads + 1)));
-    {
+    const int64_t nblk = (N + kRowBlock - 1) / kRowBlock;
+    if (!reuse) {
+        DPR_HIP(hipMalloc(&b.D, dbytes));
+        DPR_HIP(hipMemsetAsync(b.D, 0, dbytes, s));
+        DPR_HIP(hipMalloc(&b.U, vec * sizeof(double)));
+        DPR_HIP(hipMalloc(&b.Ur, vec * sizeof(double)));
+        DPR_HIP(hipMalloc(&b.KA, vec * sizeof(uint64_t)));
+        DPR_HIP(hipMalloc(&b.partials, sizeof(NjRecord) * kScanBlocks));
+        DPR_HIP(hipMalloc(&b.recs, sizeof(NjRecord) * (size_t)(world > 1 ? world : 1)));
+        DPR_HIP(hipMalloc(&b.xpart, sizeof(double) * (size_t)((N + kThreads - 1) / kThreads + 1)));
         // uniform slice length: local rows of rank 0 at n = N, padded to whole ownership blocks
-        const int64_t nblk = (N + kRowBlock - 1) / kRowBlock;
         b.slice_len = ((nblk + world - 1) / world) * kRowBlock;
         if (world > 1) {
             DPR_HIP(hipMalloc(&b.slice, sizeof(double) * (size_t)(3 * b.slice_len)));
             DPR_HIP(hipMalloc(&b.gath, sizeof(double) * (size_t)(3 * b.slice_len * world)));
-            DPR_HIP(hipMemsetAsync(b.slice, 0, sizeof(double) * (size_t)(3 * b.slice_len), s));
-            DPR_HIP(hipMemsetAsync(b.gath, 0, sizeof(double) * (size_t)(3 * b.slice_len * world), s));
         }
+        DPR_HIP(hipMalloc(&b.st, sizeof(NjState)));
+        DPR_HIP(hipMalloc(&b.log_x, sizeof(int32_t) * (size_t)(N + 1)));
+        DPR_HIP(hipMalloc(&b.log_y, sizeof(int32_t) * (size_t)(N + 1)));
+        DPR_HIP(hipMalloc(&b.log_bx, sizeof(double) * (size_t)(N + 1)));
+        DPR_HIP(hipMalloc(&b.log_by, sizeof(double) * (size_t)(N + 1)));
+    } else {
+        njp_reset(b.pr);       // the pruned path's arena stays, its epoch state goes
+        // the rows [0, rows_local) x [0, N) are rewritten by the producers; zero what they leave alone
+        if (int rc = nj_fill_pads(b.D, b.ld, b.rows_local, N, rows_alloc, kTileCols + 16, world == 1, s)) return rc;
     }
-    DPR_HIP(hipMalloc(&b.st, sizeof(NjState)));
-    DPR_HIP(hipMalloc(&b.log_x, sizeof(int32_t) * (size_t)(N + 1)));
-    DPR_HIP(hipMalloc(&b.log_y, sizeof(int32_t) * (size_t)(N + 1)));
-    DPR_HIP(hipMalloc(&b.log_bx, sizeof(double) * (size_t)(N + 1)));
-    DPR_HIP(hipMalloc(&b.log_by, sizeof(double) * (size_t)(N + 1)));
-
+    DPR_HIP(hipMemsetAsync(b.U, 0, vec * sizeof(double), s));
+    DPR_HIP(hipMemsetAsync(b.Ur, 0, vec * sizeof(double), s));
+    DPR_HIP(hipMemsetAsync(b.KA, 0, vec * sizeof(uint64_t), s));
+    DPR_HIP(hipMemsetAsync(b.partials, 0xff, sizeof(NjRecord) * kScanBlocks, s));  // key = ~0: "no candidate"
+    if (world > 1) {
+        DPR_HIP(hipMemsetAsync(b.slice, 0, sizeof(double) * (size_t)(3 * b.slice_len), s));
+        DPR_HIP(hipMemsetAsync(b.gath, 0, sizeof(double) * (size_t)(3 * b.slice_len * world), s));
+    }
     return DPR_OK;
 }
 

@@ -604,58 +604,119 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+static int64_t round_up16(int64_t v) { return (v + 15) / 16 * 16; }
 static int g_njp_grid = 1024;
 int njp_scan_grid() { return g_njp_grid; }
 
-static int64_t round_up16(int64_t v) { return (v + 15) / 16 * 16; }
 
-// allocate the position-space structures of an epoch with P positions (N = total tips: slot arrays)
-static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, hipStream_t s)
+// ---- arena -------------------------------------------------------------------------------------------------------
+// Everything the pruned path needs is allocated once per (tips, local ranks) and kept until nj_free: hipMalloc /
+// hipFree of the 7.2 GB matrices (and of ~15 vectors per epoch, 8 epochs per run) serialise with the device and
+// cost more than the distance kernel when a context builds its matrix again (bench.py's steps).
+struct SlabPlan {
+    size_t U, Ur, KA, KB, slot_of_pos, pos_of_slot, perm, umin, list, blk_cb, blk_g0, cnt_all, total;
+    int64_t list_stride;
+};
+static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+static int64_t prep_blocks(int64_t P, std::vector<int32_t>* hcb, std::vector<int32_t>* hg0)
+{
+    const int64_t G16 = (P + kUR - 1) / kUR;
+    int64_t cnt = 0;
+    for (int64_t c = 0; 32 * c < G16 && c * kTileCols < P - 1; ++c)
+        for (int64_t g0 = 32 * c; g0 < G16; g0 += kThreads) {
+            if (hcb) { hcb->push_back((int32_t)c); hg0->push_back((int32_t)g0); }
+            ++cnt;
+        }
+    if (cnt == 0) { if (hcb) { hcb->push_back(0); hg0->push_back(0); } cnt = 1; }
+    return cnt;
+}
+static SlabPlan slab_plan(int64_t P, int64_t N, int local_ranks)
+{
+    SlabPlan p;
+    const size_t vec = (size_t)(N + kTileCols + 16);
+    const int64_t G16 = (P + kUR - 1) / kUR, S = (P + kTileCols - 1) / kTileCols + 1;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
+    p.U = take(vec * 8); p.Ur = take(vec * 8); p.KA = take(vec * 8); p.KB = take(vec * 8);
+    p.slot_of_pos = take(vec * 4); p.pos_of_slot = take(vec * 4); p.perm = take(vec * 4);
+    p.umin = take((size_t)(S * G16 * 4) * 8);
+    p.list_stride = unit_total(P) + kScanBlocks + 64;
+    p.list = take((size_t)(p.list_stride * local_ranks) * 4);
+    const size_t nprep = (size_t)prep_blocks(P, nullptr, nullptr);
+    p.blk_cb = take(nprep * 4); p.blk_g0 = take(nprep * 4);
+    p.cnt_all = take((size_t)(2 * local_ranks) * 8);
+    p.total = off;
+    return p;
+}
+static size_t matrix_bytes(int64_t P)
+{
+    const int64_t rows_alloc = (P + kUR - 1) / kUR * kUR + kUR;
+    return (size_t)(rows_alloc * round_up16(P) + kTileCols + 16) * sizeof(double);
+}
+
+static int njp_arena(NjPruned& q, int64_t N, hipStream_t s)
+{
+    const int local_ranks = q.sh_world > 1 && q.sh_virtual ? q.sh_world : 1;
+    const SlabPlan plan = slab_plan(N, N, local_ranks);
+    if (q.arena_D && q.arena_N == N && q.arena_slab_bytes >= plan.total) return DPR_OK;
+    void* old[] = { q.arena_D, q.arena_slab[0], q.arena_slab[1] };
+    for (void* p : old)
+        if (p) (void)hipFree(p);
+    q.arena_D = nullptr; q.arena_slab[0] = q.arena_slab[1] = nullptr;
+    DPR_HIP(hipMalloc(&q.arena_D, matrix_bytes(N)));
+    DPR_HIP(hipMemsetAsync(q.arena_D, 0, matrix_bytes(N), s));
+    for (int k = 0; k < 2; ++k) DPR_HIP(hipMalloc(&q.arena_slab[k], plan.total));
+    q.arena_slab_bytes = plan.total;
+    q.arena_N = N;
+    return DPR_OK;
+}
+
+// point q at the position-space structures of an epoch with P positions (N = total tips: slot arrays) inside
+// matrix buffer `Dbuf` and slab `slab`, and initialise them (all fills ordered on s)
+static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, char* slab, hipStream_t s)
 {
     if (P >= (int64_t)kTileCols * 1024) { set_error("pruned NJ: the list encoding holds fewer than 524288 positions"); return DPR_ERR_ARG; }
+    const int local_ranks = q.sh_world > 1 && q.sh_virtual ? q.sh_world : 1;
+    const SlabPlan plan = slab_plan(P, N, local_ranks);
     q.P = P;
     q.ld = round_up16(P);
+    q.D = Dbuf;
     const int64_t rows_alloc = (P + kUR - 1) / kUR * kUR + kUR;
-    const size_t dbytes = (size_t)(rows_alloc * q.ld + kTileCols + 16) * sizeof(double);
-    DPR_HIP(hipMalloc(&q.D, dbytes));
-    DPR_HIP(hipMemsetAsync(q.D, 0, dbytes, s));
+    // what the permute kernel does not write: columns [P, ld), the group of rows behind position P, the tail pad
+    if (int rc = nj_fill_pads(q.D, q.ld, P, P, rows_alloc, kTileCols + 16, false, s)) return rc;
     const size_t vec = (size_t)(N + kTileCols + 16);
-    DPR_HIP(hipMalloc(&q.U, vec * sizeof(double)));
-    DPR_HIP(hipMalloc(&q.Ur, vec * sizeof(double)));
-    DPR_HIP(hipMalloc(&q.KA, vec * sizeof(uint64_t)));
-    DPR_HIP(hipMalloc(&q.KB, vec * sizeof(uint64_t)));
+    q.U = reinterpret_cast<double*>(slab + plan.U);
+    q.Ur = reinterpret_cast<double*>(slab + plan.Ur);
+    q.KA = reinterpret_cast<uint64_t*>(slab + plan.KA);
+    q.KB = reinterpret_cast<uint64_t*>(slab + plan.KB);
+    q.slot_of_pos = reinterpret_cast<int32_t*>(slab + plan.slot_of_pos);
+    q.pos_of_slot = reinterpret_cast<int32_t*>(slab + plan.pos_of_slot);
+    q.perm = reinterpret_cast<int32_t*>(slab + plan.perm);
+    q.umin = reinterpret_cast<uint64_t*>(slab + plan.umin);
+    q.list = reinterpret_cast<int32_t*>(slab + plan.list);
+    q.blk_cb = reinterpret_cast<int32_t*>(slab + plan.blk_cb);
+    q.blk_g0 = reinterpret_cast<int32_t*>(slab + plan.blk_g0);
+    q.cnt_all = reinterpret_cast<unsigned long long*>(slab + plan.cnt_all);
     DPR_HIP(hipMemsetAsync(q.U, 0, vec * sizeof(double), s));
     DPR_HIP(hipMemsetAsync(q.Ur, 0xff, vec * sizeof(double), s));   // NaN beyond P
     DPR_HIP(hipMemsetAsync(q.KA, 0, vec * sizeof(uint64_t), s));
     DPR_HIP(hipMemsetAsync(q.KB, 0, vec * sizeof(uint64_t), s));
-    DPR_HIP(hipMalloc(&q.slot_of_pos, sizeof(int32_t) * vec));
-    DPR_HIP(hipMalloc(&q.pos_of_slot, sizeof(int32_t) * vec));
-    DPR_HIP(hipMalloc(&q.perm, sizeof(int32_t) * vec));
     DPR_HIP(hipMemsetAsync(q.slot_of_pos, 0xff, sizeof(int32_t) * vec, s));
     DPR_HIP(hipMemsetAsync(q.pos_of_slot, 0xff, sizeof(int32_t) * vec, s));   // -1: slot not alive
     const int64_t G16 = (P + kUR - 1) / kUR, S = (P + kTileCols - 1) / kTileCols + 1;
     q.nunits_alloc = S * G16 * 4;      // four sub-strip bounds per unit
-    DPR_HIP(hipMalloc(&q.umin, sizeof(uint64_t) * (size_t)q.nunits_alloc));
     q.utot = unit_total(P);
     {
         // prep blocks: one strip and up to 256 consecutive row groups each (groups >= 32*cb see the strip)
         std::vector<int32_t> hcb, hg0;
-        for (int64_t c = 0; 32 * c < G16 && c * kTileCols < P - 1; ++c)
-            for (int64_t g0 = 32 * c; g0 < G16; g0 += kThreads) { hcb.push_back((int32_t)c); hg0.push_back((int32_t)g0); }
-        if (hcb.empty()) { hcb.push_back(0); hg0.push_back(0); }
-        q.nprep = (int)hcb.size();
-        DPR_HIP(hipMalloc(&q.blk_cb, sizeof(int32_t) * hcb.size()));
-        DPR_HIP(hipMalloc(&q.blk_g0, sizeof(int32_t) * hg0.size()));
+        q.nprep = (int)prep_blocks(P, &hcb, &hg0);
         DPR_HIP(hipMemcpyAsync(q.blk_cb, hcb.data(), sizeof(int32_t) * hcb.size(), hipMemcpyHostToDevice, s));
         DPR_HIP(hipMemcpyAsync(q.blk_g0, hg0.data(), sizeof(int32_t) * hg0.size(), hipMemcpyHostToDevice, s));
         DPR_HIP(hipStreamSynchronize(s));   // the host vectors go out of scope
     }
     // unit-sharded mode: one list and one counter pair per rank held here (all of them for virtual ranks)
-    const int local_ranks = q.sh_world > 1 && q.sh_virtual ? q.sh_world : 1;
-    q.list_stride = q.utot + kScanBlocks + 64;
-    DPR_HIP(hipMalloc(&q.list, sizeof(int32_t) * (size_t)(q.list_stride * local_ranks)));
+    q.list_stride = plan.list_stride;
     DPR_HIP(hipMemsetAsync(q.list, 0, sizeof(int32_t) * (size_t)(q.list_stride * local_ranks), s));
-    DPR_HIP(hipMalloc(&q.cnt_all, sizeof(unsigned long long) * (size_t)(2 * local_ranks)));
     DPR_HIP(hipMemsetAsync(q.cnt_all, 0, sizeof(unsigned long long) * (size_t)(2 * local_ranks), s));
     hipLaunchKernelGGL(njp_fill_u64_kernel, dim3(256), dim3(256), 0, s, (uint64_t*)q.umin, q.nunits_alloc,
                        enc_f64_host(-__builtin_inf()));
@@ -689,7 +750,9 @@ int njp_build(NjBuffers& b, hipStream_t s)
     std::iota(perm.begin(), perm.end(), 0);
     sort_by_row_sum(perm, hU);
     NjPruned& q = b.pr;
-    if (int rc = njp_alloc_epoch(q, N, N, s)) return rc;
+    if (int rc = njp_arena(q, N, s)) return rc;
+    q.epoch_index = 0;
+    if (int rc = njp_alloc_epoch(q, N, N, q.arena_D, q.arena_slab[0], s)) return rc;
     q.utot0 = q.utot;
     DPR_HIP(hipMemcpyAsync(q.perm, perm.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, s));
     if (std::getenv("DPR_NJ_ITERSTATS")) {
@@ -701,10 +764,8 @@ int njp_build(NjBuffers& b, hipStream_t s)
     hipLaunchKernelGGL(njp_init_vectors_kernel, dim3((unsigned)((N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                        b.U, q.perm, (const int32_t*)nullptr, N, N, q.U, q.Ur, q.KA, q.KB, q.slot_of_pos, q.pos_of_slot);
     DPR_HIP(hipGetLastError());
-    DPR_HIP(hipStreamSynchronize(s));
-    // the tip-order matrix is no longer needed
-    (void)hipFree(b.D);
-    b.D = nullptr;
+    DPR_HIP(hipStreamSynchronize(s));   // `perm` goes out of scope
+    // (the tip-order matrix in b.D is dead from here on: the odd epochs use its storage)
     q.active = true;
     return DPR_OK;
 }
@@ -714,9 +775,11 @@ int njp_build(NjBuffers& b, hipStream_t s)
 // is what keeps the unit bounds tight -- decays, and dead positions still occupy scanned units; late in a
 // run most units were scanned every iteration.  Costs one n^2 copy; the first scan of the epoch is a full
 // one (bounds start at -inf, no seed).  Called between iterations with the stream idle.
-static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s)
+// *rebuilt = false: nothing was done (no candidate left, or fewer than three active nodes).
+static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s, bool* rebuilt)
 {
     NjPruned& q = b.pr;
+    *rebuilt = false;
     NjState st;
     DPR_HIP(hipMemcpy(&st, b.st, sizeof(NjState), hipMemcpyDeviceToHost));
     const int64_t n = st.n, Pold = q.P;
@@ -733,16 +796,16 @@ static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s)
     int32_t new_px = -1;
     for (int64_t a = 0; a < n; ++a)
         if (perm[(size_t)a] == st.pad) new_px = (int32_t)a;
-    NjPruned qn;
-    qn.sh_world = q.sh_world; qn.sh_rank = q.sh_rank; qn.sh_virtual = q.sh_virtual; qn.gather = q.gather; qn.gather_ctx = q.gather_ctx;
-    if (int rc = njp_alloc_epoch(qn, n, b.N, s)) return rc;
-    qn.utot0 = q.utot0;
-    qn.iterstats = q.iterstats; q.iterstats = nullptr;
-    DPR_HIP(hipMemcpyAsync(qn.perm, perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
+    if (q.graph) { (void)hipGraphExecDestroy(q.graph); q.graph = nullptr; }
+    const NjPruned old = q;              // the old epoch's pointers (read by the permute / init kernels below)
+    const int e = old.epoch_index + 1;
+    q.epoch_index = e;
+    if (int rc = njp_alloc_epoch(q, n, b.N, (e & 1) ? b.D : q.arena_D, q.arena_slab[e & 1], s)) return rc;
+    DPR_HIP(hipMemcpyAsync(q.perm, perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
     dim3 grid((unsigned)((n + kThreads - 1) / kThreads > 64 ? 64 : (n + kThreads - 1) / kThreads), (unsigned)(n < 32768 ? n : 32768));
-    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, q.D, q.ld, qn.D, qn.ld, qn.perm, n);
+    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, old.D, old.ld, q.D, q.ld, q.perm, n);
     hipLaunchKernelGGL(njp_init_vectors_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
-                       q.U, qn.perm, (const int32_t*)q.slot_of_pos, n, n, qn.U, qn.Ur, qn.KA, qn.KB, qn.slot_of_pos, qn.pos_of_slot);
+                       old.U, q.perm, (const int32_t*)old.slot_of_pos, n, n, q.U, q.Ur, q.KA, q.KB, q.slot_of_pos, q.pos_of_slot);
     DPR_HIP(hipGetLastError());
     // iteration state: position of the last new node in the new space; no seed records, empty lists
     st.pad = new_px;
@@ -755,16 +818,25 @@ static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s)
         DPR_HIP(hipStreamSynchronize(s));
     }
     DPR_HIP(hipStreamSynchronize(s));
-    njp_free(q);
-    q = qn;
-    q.active = true;
+    *rebuilt = true;
     return DPR_OK;
+}
+
+// epoch state only: the next njp_build finds the arena in place
+void njp_reset(NjPruned& q)
+{
+    if (q.graph) { (void)hipGraphExecDestroy(q.graph); q.graph = nullptr; }
+    if (q.iterstats) { (void)hipFree(q.iterstats); q.iterstats = nullptr; }
+    NjPruned fresh;
+    fresh.arena_D = q.arena_D; fresh.arena_slab[0] = q.arena_slab[0]; fresh.arena_slab[1] = q.arena_slab[1];
+    fresh.arena_slab_bytes = q.arena_slab_bytes; fresh.arena_N = q.arena_N;
+    q = fresh;
 }
 
 void njp_free(NjPruned& q)
 {
-    if (q.graph) { (void)hipGraphExecDestroy(q.graph); q.graph = nullptr; }
-    void* ptrs[] = { q.D, q.U, q.Ur, q.KA, q.KB, q.slot_of_pos, q.pos_of_slot, q.perm, q.umin, q.iterstats, q.list, q.blk_cb, q.blk_g0, q.cnt_all };
+    njp_reset(q);
+    void* ptrs[] = { q.arena_D, q.arena_slab[0], q.arena_slab[1] };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     q = NjPruned();
@@ -803,16 +875,30 @@ static int njp_launch_post(NjBuffers& b, hipStream_t s)
     return DPR_OK;
 }
 
-// one iteration: scan -> post -> prep(next); every kernel reads its iteration index from the device state
-static int njp_enqueue_iteration(NjBuffers& b, hipStream_t s)
+// one iteration: scan -> post -> prep(next); every kernel reads its iteration index from the device state.
+// sample: bracket the launches by HIP events (NjKernelTiming; eager runs only)
+static int njp_enqueue_iteration(NjBuffers& b, hipStream_t s, bool sample = false)
 {
     NjPruned& q = b.pr;
     if (q.sh_world <= 1) {
+        auto mark = [&]() -> int {
+            if (!sample) return DPR_OK;
+            hipEvent_t e = nullptr;
+            DPR_HIP(hipEventCreate(&e));
+            b.kt->ev.push_back(e);
+            DPR_HIP(hipEventRecord(e, s));
+            return DPR_OK;
+        };
+        if (sample) b.kt->nk = 3;
+        if (int rc = mark()) return rc;
         hipLaunchKernelGGL(njp_scan_kernel, dim3(g_njp_grid), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.Ur, q.KA, q.KB,
                            (unsigned long long*)q.umin, q.P, q.list, b.partials, (unsigned long long*)q.iterstats,
                            (const unsigned long long*)nullptr, 0);
+        if (int rc = mark()) return rc;
         if (int rc = njp_launch_post(b, s)) return rc;
-        return njp_launch_prep(b, s);
+        if (int rc = mark()) return rc;
+        if (int rc = njp_launch_prep(b, s)) return rc;
+        return mark();
     }
     // Unit-sharded mode (every rank holds the whole position-space matrix): a unit belongs to rank
     // (strip * G16 + group) mod world for good.  Each rank tests and scans only its own units -- a unit that
@@ -856,7 +942,8 @@ static int njp_run_segment(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t 
         for (int v = v0; v < v1; ++v)
             if (int rc = njp_launch_prep(b, s, v)) return rc;
     }
-    const bool use_graph = q.sh_world <= 1 && todo >= kGraphIters && !std::getenv("DPR_NJ_NOGRAPH");
+    const bool timing = b.kt && b.kt->stride > 0 && q.sh_world <= 1;
+    const bool use_graph = q.sh_world <= 1 && todo >= kGraphIters && !timing && !std::getenv("DPR_NJ_NOGRAPH");
     if (use_graph && !q.graph) {
         const auto tg0 = std::chrono::steady_clock::now();
         hipGraph_t g = nullptr;
@@ -876,8 +963,14 @@ static int njp_run_segment(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t 
     if (use_graph)
         for (; done + kGraphIters <= todo; done += kGraphIters) DPR_HIP(hipGraphLaunch(q.graph, s));
     for (; done < todo; ++done)
-        if (int rc = njp_enqueue_iteration(b, s)) return rc;
+        if (int rc = njp_enqueue_iteration(b, s, timing && (it0 + done) % b.kt->stride == 0)) return rc;
     return DPR_OK;
+}
+
+const char* njp_kernel_name(int idx)
+{
+    static const char* names[] = { "njp_scan_kernel", "njp_post_kernel", "njp_prep_kernel" };
+    return idx >= 0 && idx < 3 ? names[idx] : "";
 }
 
 // enqueue `todo` iterations starting at iteration it0, in epochs: whenever the active size has dropped to
@@ -898,7 +991,11 @@ int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
             if (n <= target && n >= 3) {
                 DPR_HIP(hipStreamSynchronize(s));
                 const auto t0 = std::chrono::steady_clock::now();
-                if (int rc = njp_rebuild_epoch(b, s)) return rc;
+                bool rebuilt = false;
+                if (int rc = njp_rebuild_epoch(b, s, &rebuilt)) return rc;
+                // not rebuilt: the run has no candidate left (status != 0: any NaN / inf distance at iteration 0 makes every
+                // row sum NaN) and every queued kernel is a no-op -- stop here, dpr_nj_run reports DPR_ERR_NOCAND
+                if (!rebuilt) return DPR_OK;
                 if (std::getenv("DPR_NJ_EPOCH_LOG"))
                     std::fprintf(stderr, "[njp] epoch rebuild at n=%lld: %.2f ms\n", (long long)n,
                                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());

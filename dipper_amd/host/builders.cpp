@@ -260,15 +260,16 @@ void KPlacementDeviceArrays::findPlacementTree(DeviceContext& dev, Param& params
                                      h_head.data(), h_e.data(), h_nxt.data(), h_belong.data(), h_len.data()),
                  "dpr_place_exact_run");
         double dist_ms = 0, tree_ms = 0;
-        dpr_get_timing(dev.ctx, &dist_ms, &tree_ms);
+        dpr_get_timing(dev.ctx, &dist_ms, &tree_ms);    // (the exact mode's distance rows are produced inside its per-tip loop)
         std::cerr << "Distance + Tree Operation Time " << (long long)tree_ms << " ms\n";
         return;
     }
     gpuCheck(dpr_place_run(dev.ctx, sourceOf(params), (int)params.distanceType, (int)params.kmerSize, 2, numSequences,
                            h_head.data(), h_e.data(), h_nxt.data(), h_belong.data(), h_len.data()), "dpr_place_run");
     double dist_ms = 0, tree_ms = 0;
-    dpr_get_timing(dev.ctx, &dist_ms, &tree_ms);
-    std::cerr << "Distance + Tree Operation Time " << (long long)tree_ms << " ms\n";
+    dpr_get_place_timing(dev.ctx, &dist_ms, &tree_ms);
+    std::cerr << "Distance Operation Time " << (long long)dist_ms << " ms\n";    // src/placement_close_k.cu:852-853,985-986
+    std::cerr << "Tree Operation Time " << (long long)tree_ms << " ms\n";
 }
 
 void KPlacementDeviceArrays::addQuery(DeviceContext& dev, Param& params)
@@ -277,8 +278,9 @@ void KPlacementDeviceArrays::addQuery(DeviceContext& dev, Param& params)
                            numSequences, h_head.data(), h_e.data(), h_nxt.data(), h_belong.data(), h_len.data()),
              "dpr_place_run");
     double dist_ms = 0, tree_ms = 0;
-    dpr_get_timing(dev.ctx, &dist_ms, &tree_ms);
-    std::cerr << "Distance + Tree Operation Time " << (long long)tree_ms << " ms\n";
+    dpr_get_place_timing(dev.ctx, &dist_ms, &tree_ms);
+    std::cerr << "Distance Operation Time " << (long long)dist_ms << " ms\n";    // src/placement_close_k.cu:852-853,985-986
+    std::cerr << "Tree Operation Time " << (long long)tree_ms << " ms\n";
 }
 
 void KPlacementDeviceArraysDC::allocateDeviceArraysDC(size_t num, size_t totalNum)
@@ -326,7 +328,7 @@ void KPlacementDeviceArrays::printTree(const std::vector<std::string>& name, std
             st.pop_back();
             if (st.empty()) break;
             Frame& up = st.back();
-            output_ << ":" << h_len[(size_t)up.pos[up.next - 1]] << (up.next == up.pos.size() ? ')' : ',');
+            output_ << ":"; putLength(output_, h_len[(size_t)up.pos[up.next - 1]]); output_ << (up.next == up.pos.size() ? ')' : ',');
             continue;
         }
         const int slot = f.pos[f.next++];
@@ -335,7 +337,7 @@ void KPlacementDeviceArrays::printTree(const std::vector<std::string>& name, std
             output_ << "(";
             st.push_back(make(child, f.node));
         } else {
-            output_ << name[(size_t)child] << ":" << h_len[(size_t)slot] << (f.next == f.pos.size() ? ')' : ',');
+            output_ << name[(size_t)child] << ":"; putLength(output_, h_len[(size_t)slot]); output_ << (f.next == f.pos.size() ? ')' : ',');
         }
     }
     output_ << ";\n";

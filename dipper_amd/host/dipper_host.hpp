@@ -6,6 +6,7 @@
 // the reference finds the same vocabulary; the granularity differs (whole matrix / whole run per
 // call instead of one row per call), see INTEGRATION.md.
 #pragma once
+#include <ostream>
 #include <cstdint>
 #include <cstdio>
 #include <iosfwd>
@@ -121,6 +122,10 @@ struct KPlacementDeviceArraysDC : KPlacementDeviceArrays {
     void findTreeDC(DeviceContext& dev, Param& params);
     void printTreeDC(const std::vector<std::string>& name, std::ostream& output_) { printTree(name, output_); }
 };
+
+// THE number formatter of every Newick writer of this build: the reference streams its doubles with the default
+// ostream settings (6 significant digits, %g style; src/neighborJoining.cu:252-270, src/placement_close_k.cu:568-643)
+inline void putLength(std::ostream& os, double v) { os << v; }
 
 // Newick text of an NJ merge log (bookkeeping + print of src/neighborJoining.cu:233-270), iterative.
 void writeNewickFromMerges(std::ostream& os, const std::vector<std::string>& name, const std::vector<int32_t>& mx,

@@ -274,7 +274,7 @@ void writeNewickFromMerges(std::ostream& os, const std::vector<std::string>& nam
             if (st.empty()) break;
             Frame& up = st.back();
             const Child& c = kids[(size_t)up.node * 2 + (size_t)(up.next - 1)];
-            os << ":" << c.len << (up.next == 2 ? ')' : ',');
+            os << ":"; putLength(os, c.len); os << (up.next == 2 ? ')' : ',');
             continue;
         }
         const Child& c = kids[(size_t)f.node * 2 + (size_t)f.next];
@@ -283,7 +283,7 @@ void writeNewickFromMerges(std::ostream& os, const std::vector<std::string>& nam
             os << "(";
             st.push_back(Frame{ c.node, 0 });
         } else {
-            os << name[(size_t)c.node] << ":" << c.len << (f.next == 2 ? ')' : ',');
+            os << name[(size_t)c.node] << ":"; putLength(os, c.len); os << (f.next == 2 ? ')' : ',');
         }
     }
     os << ";\n";

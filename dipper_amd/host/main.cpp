@@ -63,7 +63,7 @@ static const Opt kOpts[] = {
     { "output-format", 'o', true }, { "algorithm", 'm', true }, { "placement-mode", 'p', true },
     { "kmer-size", 'k', true }, { "sketch-size", 's', true }, { "distance-type", 'd', true },
     { "add", 'a', false }, { "input-tree", 't', true }, { "help", 'h', false },
-    { "seed", 0, true }, { "device", 0, true }, { "dump-tree", 0, true }, { "dump-fasta", 0, false },
+    { "seed", 0, true }, { "device", 0, true }, { "dump-tree", 0, true }, { "dump-fasta", 0, false }, { "dump-lengths", 0, false },
 };
 
 static void usageError(const std::string& what)
@@ -137,6 +137,22 @@ int main(int argc, char** argv)
         for (const Node& nd : t.nodes)
             std::printf("%d %d %.17g %d %s\n", nd.idx, nd.parent >= 0 ? t.nodes[(size_t)nd.parent].idx : -1, nd.bl,
                         nd.children.empty() ? 1 : 0, nd.name.c_str());
+        return 0;
+    }
+    if (vm.count("dump-lengths")) {
+        // developer aid (no GPU): every branch-length token of --input-tree, parsed as a double and written back
+        // through the number formatter of this build's Newick writers, one per line
+        std::ifstream tf(strOr(vm, "input-tree", ""));
+        if (!tf) { std::cerr << "ERROR: Unable to open input tree file: " << strOr(vm, "input-tree", "") << "\n"; return 1; }
+        std::string nwk;
+        std::getline(tf, nwk);
+        for (size_t i = 0; i < nwk.size(); ++i) {
+            if (nwk[i] != ':') continue;
+            char* e = nullptr;
+            const double v = std::strtod(nwk.c_str() + i + 1, &e);
+            putLength(std::cout, v);
+            std::cout << "\n";
+        }
         return 0;
     }
     if (vm.count("dump-fasta")) {

@@ -102,7 +102,8 @@ int dpr_set_msa(dpr_ctx *ctx, const uint64_t *packed4, int64_t n, int64_t L);
 int dpr_set_reads(dpr_ctx *ctx, const uint64_t *packed2, const uint64_t *word_off,
                   const uint64_t *len, int64_t n);
 /* MatrixReader (src/matrix_reader.cu:15-45): rows concatenated, row i has i entries (i=0..n-1),
- * already parsed with the reference's float rounding by the host reader. */
+ * already parsed with the reference's float rounding by the host reader.  The device copy stays until the next
+ * dpr_set_matrix_lower / dpr_destroy, so dpr_dist_matrix(DPR_SRC_MATRIX) and dpr_place_run may be called repeatedly. */
 int dpr_set_matrix_lower(dpr_ctx *ctx, const double *rows, int64_t n);
 
 /* ---- Mash sketches: MashDeviceArrays::sketchConstructionOnGpu (src/mash.cu:386-424).
@@ -147,6 +148,19 @@ int dpr_set_nj_virtual_shards(int w);
  * src/tree_generation.cu:240-245).  dpr_nj_is_unit_sharded: what the last dpr_dist_matrix chose. */
 int dpr_set_nj_multi_plan(int plan);
 int dpr_nj_is_unit_sharded(dpr_ctx *ctx);
+/* The three plan knobs above are process-wide DEFAULTS.  Per context (two contexts of one process may run different
+ * plans): same meaning, value -1 = follow the process-wide default again; effective at that context's next
+ * dpr_dist_matrix. */
+int dpr_ctx_set_nj_mode(dpr_ctx *ctx, int mode);
+int dpr_ctx_set_nj_multi_plan(dpr_ctx *ctx, int plan);
+int dpr_ctx_set_nj_virtual_shards(dpr_ctx *ctx, int w);
+/* Measurement aid of the pruned NJ loop (bench.py's `timed_kernels` record): stride > 0 makes the following dpr_nj_run
+ * calls enqueue their iterations eagerly (no hipGraph replay) with HIP events on the library's stream around the launches
+ * of every stride-th iteration; dpr_get_nj_kernel_timing returns the kernels per iteration, the average microseconds per
+ * kernel (launch order, up to 4 entries) and the number of sampled iterations; dpr_nj_kernel_name(i) names kernel i. */
+int dpr_ctx_set_nj_kernel_timing(dpr_ctx *ctx, int stride);
+int dpr_get_nj_kernel_timing(dpr_ctx *ctx, int *kernels, double *us_avg4, int64_t *samples);
+const char *dpr_nj_kernel_name(int idx);
 /* host-only: owner of the 16-row x 512-column unit (strip = column block, group = row group) among `world` ranks
  * when the position space has P positions; -1 if the unit holds no pair of the strict lower triangle */
 int dpr_njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world);
@@ -159,12 +173,14 @@ int dpr_launch_bench(dpr_ctx *ctx, int nlaunch, int grid, int use_graph, float *
 /* debug, needs DPR_NJ_ITERSTATS=1: per iteration {units scanned, most units scanned by one block} */
 int dpr_get_iterstats(dpr_ctx *ctx, uint64_t *out, int64_t iters);
 
-/* tuning knobs of the Q-argmin scan (process-wide): rows per work unit (16/32/64), non-temporal
- * loads (0/1), grid size (0 = default, <= 2048).  Results never depend on them. */
+/* tuning knobs of the streaming Q-argmin scan (process-wide): rows per work unit (16 or 64; +128 selects the
+ * filtered candidate update), non-temporal loads (0/1), grid size (0 = default 2048, <= 8192).  Results never
+ * depend on them. */
 int dpr_scan_tune(int rows_per_unit, int nontemporal, int grid);
 
 /* calibration: plain streaming read (16 B/lane, optional non-temporal) of `bytes` of the matrix
- * buffer; average milliseconds per pass.  Gives the read ceiling the scan is compared with. */
+ * buffer the Q-argmin scans (the position-space matrix in pruned mode); average milliseconds per pass.  Gives the
+ * read ceiling the scan is compared with. */
 int dpr_bw_probe(dpr_ctx *ctx, int64_t bytes, int nontemporal, int grid, int reps, float *out_ms);
 
 /* ---- test hooks ------------------------------------------------------------------------------*/
@@ -188,6 +204,11 @@ int dpr_get_timing(dpr_ctx *ctx, double *dist_ms, double *nj_ms);
  * expects the imported backbone (initializeDeviceArrays :126-264) in the arrays. */
 int dpr_place_run(dpr_ctx *ctx, int source, int dist_type, int k, int64_t first, int64_t n,
                   int32_t *head, int32_t *e, int32_t *nxt, int32_t *belong, double *len);
+
+/* distance and tree part of the last dpr_place_run in milliseconds (the reference prints them as "Distance Operation
+ * Time" / "Tree Operation Time", src/placement_close_k.cu:852-853,985-986): HIP-event time of the distance batches,
+ * and the rest of the run */
+int dpr_get_place_timing(dpr_ctx *ctx, double *dist_ms, double *tree_ms);
 
 /* ---- exact placement mode: PlacementDeviceArrays::{allocateDeviceArrays,findPlacementTree}
  * (src/placement.cu:17-117,508-789), reached in the reference through `-m 0` with 30000 <= n < 1000000

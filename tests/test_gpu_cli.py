@@ -125,6 +125,11 @@ def test_placement_modes_end_to_end(tmp_path, orc):
         r = run("-i", kind, "-I", str(fa), "-O", str(out), "-m", "1", "--seed", "-1", *extra)
         assert r.returncode == 0, r.stderr
         assert "k-closest placement mode" in r.stderr
+        # the reference's two progress lines of a placement run (src/placement_close_k.cu:852-853)
+        lines = r.stderr.splitlines()
+        di = [i for i, ln in enumerate(lines) if ln.startswith("Distance Operation Time ") and ln.endswith(" ms")]
+        ti = [i for i, ln in enumerate(lines) if ln.startswith("Tree Operation Time ") and ln.endswith(" ms")]
+        assert len(di) == 1 and len(ti) == 1 and ti[0] == di[0] + 1, r.stderr
         M = _api_matrix(kind, seqs, L)
         st = orc.place_run(M)
         assert out.read_text() == _util.newick_from_placement(names, st["head"], st["e"], st["nxt"], st["len"], n)

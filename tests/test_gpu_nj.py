@@ -261,3 +261,106 @@ def test_nj_unit_sharded_virtual_ranks_many_units(world):
     for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
         assert np.array_equal(res[1][key], res[world][key]), key
     assert res[1]["last_d"] == res[world]["last_d"]
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("mode", [1, 0], ids=["pruned", "stream"])
+def test_nj_no_candidate_with_epochs_terminates(monkeypatch, mode):
+    """A NaN distance makes every row sum NaN: no Q candidate at iteration 0.  The reference's behaviour is
+    undefined there; the library must return DPR_ERR_NOCAND -- also when the run is long enough to reach an
+    epoch boundary of the pruned path (the host loop used to spin there forever)."""
+    import dipper_amd
+    from dipper_amd import capi, DipperError
+    monkeypatch.setenv("DPR_NJ_EPOCH_MIN", "48")
+    n = 300
+    rng = np.random.default_rng(3)
+    D = rng.random((n, n))
+    D = np.tril(D, -1) + np.tril(D, -1).T
+    D[7, 3] = D[3, 7] = np.nan
+    D[:, 11] = np.nan
+    D[11, :] = np.nan
+    d = dipper_amd.Dipper(0)
+    try:
+        d.set_nj_mode(mode)
+        d.set_matrix_full(D)
+        d.dist_matrix(capi.SRC_MATRIX)
+        with pytest.raises(DipperError) as ei:
+            d.nj_run()
+        assert ei.value.code == -4
+    finally:
+        d.close()
+
+
+def test_context_reuse_same_shape_and_per_context_plans(orc):
+    """A context that builds a matrix of the same shape again keeps all its device buffers (no hipFree / hipMalloc of
+    the N x N matrices): the second and third build must be as clean as the first -- every NJ result bit-identical to
+    the oracle, for both algorithms chosen PER CONTEXT while another context of the process runs the other one."""
+    import dipper_amd
+    from dipper_amd import capi
+    rng = np.random.default_rng(77)
+    n = 700
+    mats = [_util.random_additive_matrix(rng, n, zero_frac=z) for z in (0.0, 0.4, 0.0)]
+    mats[2] = np.round(mats[2], 1)
+    refs = [orc.nj_run(np.tril(D, -1)) for D in mats]
+    a, b = dipper_amd.Dipper(0), dipper_amd.Dipper(0)
+    try:
+        a.set_nj_mode(1)
+        b.set_nj_mode(0)
+        for rnd in range(2):
+            for D, ref in zip(mats, refs):
+                for d in (a, b):
+                    d.set_matrix_full(D)
+                    d.dist_matrix(capi.SRC_MATRIX)
+                    if rnd == 1:
+                        d.dist_matrix(capi.SRC_MATRIX)      # twice on the same input (the packed triangle stays)
+                    assert np.array_equal(d.matrix(), np.tril(D, -1) + np.tril(D, -1).T)
+                    res = d.nj_run()
+                    for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
+                        assert np.array_equal(res[key], ref[key]), key
+                    assert res["last_d"] == ref["last_d"]
+        # the pruned context really ran the pruned path, the other one did not
+        a.dist_matrix(capi.SRC_MATRIX)
+        a.nj_run(max_iters=5)
+        assert a.prune_stats()[1] > 0
+        b.dist_matrix(capi.SRC_MATRIX)
+        with pytest.raises(dipper_amd.DipperError):
+            b.prune_stats()
+    finally:
+        a.close()
+        b.close()
+
+
+def test_context_reuse_msa_and_mash_sources(orc):
+    """Reuse across sources: the Mash pair kernel writes only j < i and its mirror, so the diagonal of a reused
+    buffer must be cleared by the library; an MSA build of the same shape in between leaves other data behind."""
+    import dipper_amd
+    from dipper_amd import capi
+    rng = np.random.default_rng(5)
+    n, L = 260, 1500
+    seqs = _util.synth_alignment(rng, n, L, mean_bl=5e-3, lo=1e-4, hi=5e-2)
+    packed = capi.pack4_many(seqs)
+    d = dipper_amd.Dipper(0)
+    fresh = dipper_amd.Dipper(0)
+    try:
+        d.set_msa(packed, L)
+        d.set_reads(seqs)
+        d.sketch(k=15, S=1000, fetch=False)
+        fresh.set_reads(seqs)
+        fresh.sketch(k=15, S=1000, fetch=False)
+        fresh.dist_matrix(capi.SRC_MASH, 1, 15)
+        M_fresh = fresh.matrix()
+        for _ in range(2):
+            d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+            M1 = d.matrix()
+            d.nj_run()                                   # the pruned path's epochs overwrite both matrix buffers
+            d.dist_matrix(capi.SRC_MASH, 1, 15)
+            M2 = d.matrix()
+            assert np.array_equal(M2, M_fresh) and np.all(np.diag(M2) == 0)
+            res = d.nj_run()
+            ref = orc.nj_run(np.tril(M2, -1))
+            for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
+                assert np.array_equal(res[key], ref[key]), key
+            assert np.all(np.diag(M1) == 0)
+    finally:
+        d.close()
+        fresh.close()
