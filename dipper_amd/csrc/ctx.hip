@@ -837,8 +837,10 @@ int dpr_get_row_sums(dpr_ctx* c, double* out)
         const int64_t N = c->nj[0].N;
         std::vector<int32_t> pos((size_t)N);
         std::vector<double> u((size_t)q.P);
+        NjState st;
+        if (int rc = fetch_state(c, &st)) return rc;
         DPR_HIP(hipMemcpy(pos.data(), q.pos_of_slot, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
-        DPR_HIP(hipMemcpy(u.data(), q.U, sizeof(double) * (size_t)q.P, hipMemcpyDeviceToHost));
+        DPR_HIP(hipMemcpy(u.data(), njp_current_u(q, st.it), sizeof(double) * (size_t)q.P, hipMemcpyDeviceToHost));
         for (int64_t j = 0; j < N; ++j) out[j] = (pos[(size_t)j] >= 0 && pos[(size_t)j] < q.P) ? u[(size_t)pos[(size_t)j]] : 0.0;
         return DPR_OK;
     }

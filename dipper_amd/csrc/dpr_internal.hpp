@@ -75,14 +75,18 @@ struct NjState {
     double d;        // D[x][y]
     double q;        // winning Q value
     int32_t status;  // 0 ok, 1 = no candidate (DPR_ERR_NOCAND)
-    int32_t pad;     // pruned path: position of the node created by the last merge
-    // pruned path (graph-replayed kernels read their iteration from memory): `it` is advanced by the
-    // post kernel, `itb` by the bounds kernel; a kernel only reads the counter that is stable while it runs
+    int32_t pad;
+    // pruned path (graph-replayed kernels read their iteration from memory): `it` is advanced by the post kernel while
+    // it runs, so the post kernel reads `itb`, which the scan kernel (that reads `it`) publishes for it
     int64_t itb;
     int64_t it_limit;  // iterations >= it_limit are no-ops
     int64_t N;         // tips
-    unsigned long long cnt_list[2];   // units listed for the scan of parity it & 1
+    unsigned long long cnt_list[4];   // units listed for the scan of iteration it: cnt_list[it % 3]
     unsigned long long units_scanned; // statistics
+    // pnew[it & 1]: position of the node created by merge it-1 (-1: none).  During iteration it that node is in
+    // QUARANTINE: its row sum is not materialised yet (Ur = NaN, so the unit scans skip it), its pairs are evaluated
+    // by the scan kernel's new-row blocks from the row buffer R[(it - 1) & 1]
+    int32_t pnew[2];
 };
 
 // position-space state of the pruned path (njp.hip)
@@ -90,19 +94,23 @@ struct NjPruned {
     bool active = false;
     int64_t P = 0, ld = 0;      // positions of this epoch, row stride
     double* D = nullptr;        // [P][ld] position space
-    double *U = nullptr, *Ur = nullptr;   // by position; Ur = NaN for dead positions
+    double* U = nullptr;        // [2][vstride] by position, double-buffered: iteration it reads U + (it & 1) * vstride
+    double* Ur = nullptr;       // by position; NaN for dead positions and for the node in quarantine
+    double* R = nullptr;        // [2][vstride] row of the node created by merge it: R + (it & 1) * vstride
+    int64_t vstride = 0;
     uint64_t *KA = nullptr, *KB = nullptr;  // key parts from the reference slot of each position
-    int32_t *slot_of_pos = nullptr, *pos_of_slot = nullptr, *perm = nullptr;
-    uint64_t* umin = nullptr;   // [strips][groups] order-encoded lower bound of D per unit
+    int32_t *slot_of_pos = nullptr, *pos_of_slot = nullptr, *perm = nullptr;   // slot_of_pos < 0: dead position
+    uint64_t* umin = nullptr;   // [strips][groups][4] order-encoded lower bound of D per sub-unit
     int64_t nunits_alloc = 0, utot = 0;
     int64_t utot0 = 0;          // units of one full scan at the first epoch (statistics)
+    bool fresh = false;         // epoch just built: the first scan is a full one (njp_list_all_kernel), nothing in quarantine
     // unit-sharded mode (several GPUs, each holding the whole position-space matrix): unit ownership by
     // (strip * G16 + group) % sh_world; sh_virtual: all ranks are emulated in this process (validation)
     int sh_world = 1, sh_rank = 0;
     bool sh_virtual = false;
     int (*gather)(void* ctx, void* buf, size_t bytes_per_rank, hipStream_t s) = nullptr;   // in-place all-gather of the block records
     void* gather_ctx = nullptr;
-    unsigned long long* cnt_all = nullptr;   // [local ranks][2] list counters
+    unsigned long long* cnt_all = nullptr;   // [local ranks][4] list counters (index it % 3)
     int64_t list_stride = 0;
     // Arena, kept until nj_free (a context that builds a matrix of the same size again allocates nothing):
     // one matrix buffer of the pruned path's own -- the epochs alternate between it and NjBuffers::D, whose tip-order
@@ -112,10 +120,11 @@ struct NjPruned {
     char* arena_slab[2] = { nullptr, nullptr };
     size_t arena_slab_bytes = 0;
     int64_t arena_N = 0;
+    int arena_ranks = 0;
     int epoch_index = 0;             // epoch e uses slab e & 1; its matrix lives in arena_D for even e, in NjBuffers::D for odd e
-    hipGraphExec_t graph = nullptr;   // kGraphIters iterations of (test, scan, post, bounds)
-    int32_t* list = nullptr;         // units selected by the prep kernel (strip << 20 | group)
-    int32_t *blk_cb = nullptr, *blk_g0 = nullptr;   // prep block -> (strip, first group)
+    hipGraphExec_t graph = nullptr;   // kGraphIters iterations of (scan, post)
+    int32_t* list = nullptr;         // units selected by the tests (sub-unit mask << 28 | strip << 18 | group)
+    int32_t *blk_cb = nullptr, *blk_g0 = nullptr;   // test block -> (strip, first group)
     int nprep = 0;
     uint64_t* iterstats = nullptr;   // optional (DPR_NJ_ITERSTATS): per iteration units scanned, max per block
 };
@@ -182,6 +191,7 @@ int njp_scan_grid();
 int njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world);
 int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s);   // enqueue `todo` iterations (hipGraph replays)
 const char* njp_kernel_name(int idx);   // kernels of one iteration, in launch order
+const double* njp_current_u(const NjPruned& q, int64_t it);   // row sums by position after `it` iterations
 
 // Divide-and-conquer cluster distances (dc.hip builds the jobs; msa.hip / mash.hip run them).
 // Cluster ci has cl_m[ci] members (tip ids members[cl_moff[ci] + t], ascending) and a leaf list

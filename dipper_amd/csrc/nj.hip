@@ -63,7 +63,8 @@ __global__ void nj_state_init_kernel(NjState* st, int64_t N)
 {
     st->n = N; st->it = 0; st->x = 0; st->y = 0; st->d = 0.0; st->q = 0.0; st->status = 0; st->pad = 0;
     st->itb = 0; st->it_limit = 0; st->N = N;
-    st->cnt_list[0] = 0; st->cnt_list[1] = 0; st->units_scanned = 0;
+    st->cnt_list[0] = 0; st->cnt_list[1] = 0; st->cnt_list[2] = 0; st->cnt_list[3] = 0; st->units_scanned = 0;
+    st->pnew[0] = -1; st->pnew[1] = -1;
 }
 
 // Ur[i] = U[i]/(n-2) (plain division, src/neighborJoining.cu:130,137) and the i-part of the key
@@ -548,7 +549,10 @@ int nj_alloc(NjBuffers& b, int64_t N, int rank, int world, hipStream_t s)
         DPR_HIP(hipMalloc(&b.KA, vec * sizeof(uint64_t)));
         DPR_HIP(hipMalloc(&b.partials, sizeof(NjRecord) * kScanBlocks));
         DPR_HIP(hipMalloc(&b.recs, sizeof(NjRecord) * (size_t)(world > 1 ? world : 1)));
-        DPR_HIP(hipMalloc(&b.xpart, sizeof(double) * (size_t)((N + kThreads - 1) / kThreads + 1)));
+        // (at least 512 entries: the pruned scan's new-row blocks load entry threadIdx.x before they know the chunk count)
+        const size_t xcnt = (size_t)((N + kThreads - 1) / kThreads + 1);
+        DPR_HIP(hipMalloc(&b.xpart, sizeof(double) * (xcnt < 512 ? 512 : xcnt)));
+        DPR_HIP(hipMemsetAsync(b.xpart, 0, sizeof(double) * (xcnt < 512 ? 512 : xcnt), s));
         // uniform slice length: local rows of rank 0 at n = N, padded to whole ownership blocks
         b.slice_len = ((nblk + world - 1) / world) * kRowBlock;
         if (world > 1) {

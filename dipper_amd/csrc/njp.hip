@@ -16,11 +16,19 @@
 //    skipped.  Sorting by row sum makes Ur homogeneous inside units, which is what makes the bound
 //    tight.
 //
-// Per iteration: njp_scan_kernel (scan the surviving sub-units of the listed units, refresh their bounds) -> njp_post_kernel
-// (select + merge + update, indexed by reference slot so that the canonical U[x] summation order is
-// unchanged) -> njp_prep_kernel (finish U[x], seed bound, test every unit, list the survivors).
-// The kernels take no per-iteration arguments (they read the iteration index from the device
-// state), so 32 iterations are captured into one hipGraph and replayed.
+// Per iteration TWO kernels (three until round 2; what an iteration costs is its chain of dependent memory round
+// trips plus one kernel boundary per launch):
+//   SCAN(it): the surviving sub-units of the listed units (exact bounds refreshed) + the NEW ROW: the node created by
+//             merge it-1 is in QUARANTINE during iteration it -- its row sum (a canonical sum over all slots) is only
+//             finished here, by dedicated blocks that also evaluate its pairs from a row buffer and move that buffer
+//             into the matrix;
+//   POST(it): select + merge + update (indexed by reference slot so that the canonical U[x] summation order is
+//             unchanged) fused with the unit tests of iteration it+1: the test lanes need the row sums AFTER the
+//             merge, which other blocks of the same launch are still storing, so they recompute them for their own
+//             16 rows / 2 columns from the (double-buffered) current row sums and rows x, y -- which is why the update
+//             writes the new node's row to a buffer instead of over row x.
+// The kernels take no per-iteration arguments (they read the iteration index from the device state), so 32
+// iterations are captured into one hipGraph and replayed.
 #include "nj_dev.hpp"
 
 #include <algorithm>
@@ -109,201 +117,35 @@ __global__ void njp_fill_u64_kernel(uint64_t* __restrict__ a, int64_t cnt, uint6
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x) a[i] = v;
 }
 
-// Latency is what matters in these three kernels (a few hundred KB of data per iteration): every
-// kernel issues all of its global loads up front, in as few dependent hops as possible.
-//
-// prep = finish U[px] + seed bound + unit tests, one lane per valid unit.  Every block derives what
-// it needs -- the new node's row sum, the bound, the maxima of Ur over its units' rows and strips --
-// directly from Ur, so no cross-block hand-off is needed.  Runs after post(it-1); `it` = st->it is
-// stable while it runs.  It publishes st->itb = it, the iteration index the following scan/post
-// kernels read (they must not read st->it, which the post kernel advances while it runs).
-// For it >= it_limit only U[px] is materialised (no list).
-__global__ __launch_bounds__(kThreads) void njp_prep_kernel(const double* __restrict__ D, int64_t ld,
-                                                            NjState* __restrict__ st, double* __restrict__ U_w,
-                                                            double* __restrict__ Ur_w, const double* __restrict__ Ur,
-                                                            const double* __restrict__ xpart,
-                                                            const NjRecord* __restrict__ partials,
-                                                            unsigned long long* umin,
-                                                            int64_t P, const int32_t* __restrict__ blk_cb,
-                                                            const int32_t* __restrict__ blk_g0, int scan_grid,
-                                                            int32_t* __restrict__ list, int sh_rank, int sh_world,
-                                                            unsigned long long* __restrict__ cnt_rank, int nrec_fixed,
-                                                            unsigned long long* __restrict__ clk)
-{
-    __shared__ double s[kThreads];
-    __shared__ double sseed[kThreads / 64];
-    __shared__ double scm[kThreads / 64];
-    __shared__ double snew[kThreads / 64];
-    const int tid = threadIdx.x;
-    // optional phase clocks (DPR_NJ_ITERSTATS; profiles/nj_clocks.py): thread 0 of block 0 and of the middle block
-    const bool clocked = clk != nullptr && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2);
-    unsigned long long ck[7] = { 0, 0, 0, 0, 0, 0, 0 };
-    if (clocked) ck[0] = wall_clock64();
-    // hop 1: the state line, this block's (strip, first group) -- blocks never span strips -- and, speculatively,
-    // this thread's seed record (its index depends on the launch arguments only)
-    const int64_t nrec_arg = nrec_fixed >= 0 ? (int64_t)(nrec_fixed < scan_grid ? nrec_fixed : scan_grid) : -1;
-    const int64_t stride = nrec_arg >= 2 * kThreads ? nrec_arg / kThreads : 1;   // gathered records of several ranks: every (nrec/256)-th
-    NjRecord cand = partials[(int64_t)tid * stride];
-    const int cb = blk_cb[blockIdx.x];
-    const int64_t g = (int64_t)blk_g0[blockIdx.x] + tid;
-    const int64_t it = st->it, limit = st->it_limit, N = st->N;
-    const int64_t px = it > 0 ? (int64_t)st->pad : -1;
-    // unit-sharded mode (sh_world > 1): this launch tests only the units it owns and appends to its own list /
-    // counter; the seed records are the gathered records of ALL ranks, nrec_fixed of them, each written
-    unsigned long long* cntp = cnt_rank ? cnt_rank : st->cnt_list;
-    const unsigned long long nlist_prev = it > 0 ? (nrec_fixed >= 0 ? (unsigned long long)nrec_fixed : cntp[(it - 1) & 1]) : 0ull;
-    if (st->status != 0) return;
-    const bool beyond = it >= limit;
-    if (blockIdx.x == 0 && tid == 0) st->itb = it;            // never read by this kernel
-    if (beyond && (blockIdx.x != 0 || it == 0)) return;       // only block 0 materialises U[px]
-    const int64_t n = N - it;
-    const double NINF = -__builtin_inf(), PINF = __builtin_inf();
-    if (clocked) { __builtin_amdgcn_s_waitcnt(0); ck[1] = wall_clock64(); }
+// Latency is what matters in the kernels of the loop (a few hundred KB of data per iteration): every kernel issues
+// all of its global loads in as few dependent hops as possible.
 
-    // hop 2: every other load of this block
-    const int64_t nchunk = it > 0 ? (n + 1 + kThreads - 1) / kThreads : 0;
-    double acc = 0.0;
-    for (int64_t c = tid; c < nchunk; c += kThreads) acc += xpart[c];       // chunk sums of U[px]
-    const int64_t nrec = (int64_t)(nlist_prev < (unsigned long long)scan_grid ? nlist_prev : (unsigned long long)scan_grid);
-    if (beyond || (int64_t)tid * stride >= nrec) cand.key = ~0ull;   // stale or absent record
-    const int64_t G16 = (P + kUR - 1) / kUR;
-    const bool have = !beyond && g < G16;
-    // The new node's row (written by the post kernel) may lower the bound of the units it crosses: the units
-    // (strip of px, groups behind px) through their 16 rows, the units (strips before px, group of px) through
-    // their 512 columns.  The lane that tests a unit folds that minimum into umin itself (no atomics in post).
-    const bool px_strip = px >= 0 && px / kTileCols == cb;                       // block-uniform
-    const int64_t gx = px >= 0 ? px / kUR : -1;
-    const bool gx_here = px >= 0 && gx >= (int64_t)blk_g0[blockIdx.x] && gx < (int64_t)blk_g0[blockIdx.x] + kThreads;   // block-uniform
-    const double* __restrict__ rowx = D + (px >= 0 ? px : 0) * ld;
-    // Every unit carries FOUR bounds, one per 128-column sub-strip (the columns of one wave of the scan kernel):
-    // the test keeps a unit if any sub-unit survives and hands the scan a 4-bit mask, so a wave whose sub-unit
-    // cannot hold the winner neither loads nor evaluates its 16 x 128 block.
-    const int wpx = px >= 0 ? (int)((px % kTileCols) / (kTileCols / 4)) : -1;    // sub-strip of the new node's column
-    double u4[4] = { PINF, PINF, PINF, PINF };
-    double rmax = NINF; bool px_in_group = false;
-    double newminA = PINF;                                  // new row x this group's rows (sub-strip wpx of px's strip)
-    unsigned long long* up4 = umin + ((int64_t)cb * G16 + (have ? g : 0)) * 4;
-    // All loads of this round trip are issued before the first use, without data-dependent branches in between
-    // (measured with the phase clocks: as a loop of "load, test, use" the sixteen row sums of a lane arrived one
-    // after the other, 4.3 us; the vectors are padded with NaN behind P, so every address is valid).
-    v2d urow[kUR / 2], drow[kUR / 2];
-    ulonglong2 um0 = make_ulonglong2(0ull, 0ull), um1 = um0;
-    const int64_t a0 = (have ? g : 0) * kUR;                       // 128-byte aligned: eight 16-byte loads
-    const int64_t pc0 = (int64_t)cb * kTileCols + 2 * tid;         // this thread's two strip columns (< P + 512)
-    if (have) { um0 = *reinterpret_cast<const ulonglong2*>(up4); um1 = *reinterpret_cast<const ulonglong2*>(up4 + 2); }
-#pragma unroll
-    for (int r = 0; r < kUR / 2; ++r) urow[r] = *reinterpret_cast<const v2d*>(Ur + a0 + 2 * r);
-    const v2d ucol = *reinterpret_cast<const v2d*>(Ur + pc0);
-    v2d dcol; dcol.x = PINF; dcol.y = PINF;
-    if (px_strip) {                                                // block-uniform
-#pragma unroll
-        for (int r = 0; r < kUR / 2; ++r) drow[r] = *reinterpret_cast<const v2d*>(rowx + a0 + 2 * r);
-    } else {
-#pragma unroll
-        for (int r = 0; r < kUR / 2; ++r) { drow[r].x = PINF; drow[r].y = PINF; }
-    }
-    if (gx_here) dcol = *reinterpret_cast<const v2d*>(rowx + pc0);  // block-uniform; row px is readable up to its padded end
-    // candidate gathers (same round trip: the records were loaded up front)
-    double cd = 0.0, cua = __builtin_nan(""), cub = __builtin_nan("");
-    if (cand.key != ~0ull) {
-        const int64_t pi = (int64_t)(cand.pad & 0xffffffffull), pj = (int64_t)(cand.pad >> 32);
-        const int64_t pa = pi > pj ? pi : pj, pb = pi > pj ? pj : pi;
-        // the record carries D[pa][pb]; the entry is unchanged since the scan (neither end is the new node, and a
-        // dead end gives a NaN row sum) -- no gather into the 7 GB matrix (a cold TLB walk per launch)
-        if (pa < P && pb < pa && pa != px && pb != px) { cd = cand.d; cua = Ur[pa]; cub = Ur[pb]; }
-    }
-    if (have) {
-        u4[0] = dec_f64(um0.x); u4[1] = dec_f64(um0.y); u4[2] = dec_f64(um1.x); u4[3] = dec_f64(um1.y);
-#pragma unroll
-        for (int r = 0; r < kUR; ++r) {
-            const int64_t p = a0 + r;
-            const double v = (r & 1) ? urow[r >> 1].y : urow[r >> 1].x;
-            const double dv = (r & 1) ? drow[r >> 1].y : drow[r >> 1].x;
-            px_in_group |= p == px;
-            const bool live = (v == v) & (p != px);                // dead positions and the padding behind P carry NaN
-            rmax = live ? fmax(rmax, v) : rmax;
-            newminA = (live & (p > px)) ? fmin(newminA, dv) : newminA;
-        }
-    }
-    // column maximum of each sub-strip (wave w reads columns 128w .. 128w+127 of the strip), px excluded for now;
-    // minimum of the new row over the sub-strip's live columns
-    double cm_part = NINF, colmin = PINF;
-    if (!beyond) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int64_t p = pc0 + k;
-            const double v = k ? ucol.y : ucol.x;
-            const double dv = k ? dcol.y : dcol.x;
-            const bool live = (v == v) & (p != px);
-            cm_part = live ? fmax(cm_part, v) : cm_part;
-            colmin = (live & (p < px)) ? fmin(colmin, dv) : colmin;
-        }
-    }
-    double qc = PINF;
-    if (cua == cua && cub == cub) qc = fmin((cd - cua) - cub, (cd - cub) - cua);
-    if (clocked) { __builtin_amdgcn_s_waitcnt(0); ck[2] = wall_clock64(); }
-    // ---- reductions: the wave results go to LDS before the tree, whose barriers publish them as well
-    if (!beyond) {
-        qc = wave_fmin(qc);
-        cm_part = wave_fmax(cm_part);
-        if (gx_here) colmin = wave_fmin(colmin);
-        if ((tid & 63) == 0) { sseed[tid >> 6] = qc; scm[tid >> 6] = cm_part; snew[tid >> 6] = colmin; }
-    }
-    double urx = 0.0;
-    if (it > 0) {
-        double ux = block_tree256_lane0(acc, s);
-        if (tid == 0) s[0] = ux;
-        __syncthreads();
-        ux = s[0];
-        urx = ux / (double)(n - 2);
-        if (blockIdx.x == 0 && tid == 0) { U_w[px] = ux; Ur_w[px] = urx; }
-    } else {
-        __syncthreads();
-    }
-    if (beyond) return;
-    if (clocked) ck[3] = wall_clock64();
-    const double bound = fmin(fmin(sseed[0], sseed[1]), fmin(sseed[2], sseed[3]));
-    // the new node's Ur joins the maxima of its group and of its sub-strip
-    if (px_in_group) rmax = fmax(rmax, urx);
-    const bool mine = have && (sh_world <= 1 || (int)(((int64_t)cb * G16 + g) % sh_world) == sh_rank);
-    int submask = 0;
-    if (mine) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            double cmw = scm[w];
-            if (px_strip && w == wpx) cmw = fmax(cmw, urx);
-            double nm = (gx_here && g == gx) ? snew[w] : PINF;            // the unit (this strip, group of px)
-            if (px_strip && w == wpx) nm = fmin(nm, newminA);
-            if (nm < u4[w]) {                          // persist the lowered bound (this lane is the unit's only writer here)
-                u4[w] = nm;
-                up4[w] = enc_f64(nm);
-            }
-            const double lb = fmin((u4[w] - rmax) - cmw, (u4[w] - cmw) - rmax);
-            if ((cmw > NINF) && (lb <= bound)) submask |= 1 << w;
-        }
-    }
-    const bool keep = mine && (rmax > NINF) && submask != 0;
-    if (clocked) ck[4] = wall_clock64();
-    const int par = (int)(it & 1);
-    const unsigned long long mask = __ballot(keep);
-    const int lane = tid & 63;
-    unsigned long long base = 0;
-    if (lane == 0 && mask) base = atomicAdd(&cntp[par], (unsigned long long)__popcll(mask));
-    base = __shfl(base, 0, 64);
-    if (clocked) { __builtin_amdgcn_s_waitcnt(0); ck[5] = wall_clock64(); }
-    if (keep) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)(((uint32_t)submask << 28) | ((uint32_t)cb << 18) | (uint32_t)g);   // sub-unit mask | strip | group
-    if (clocked) {
-        __builtin_amdgcn_s_waitcnt(0);
-        ck[6] = wall_clock64();
-        unsigned long long* o = clk + (blockIdx.x == 0 ? 0 : 8);
-        atomicAdd(&o[0], 1ull);
-        for (int k = 1; k < 7; ++k) atomicAdd(&o[k], ck[k] - ck[k - 1]);
-    }
-}
+// arguments shared by the kernels of the loop (by value: one kernarg block)
+struct NjpArgs {
+    double* D; int64_t ld; NjState* st;
+    double* U; double* R; int64_t vstride;      // U, R: [2][vstride]
+    double* Ur; uint64_t* KA; uint64_t* KB; int32_t* slot_of_pos; int32_t* pos_of_slot;
+    double* xpart; NjRecord* partials; unsigned long long* umin;
+    int64_t P;
+    const int32_t* blk_cb; const int32_t* blk_g0; int ntest;     // test blocks: (strip, first group), up to 256 groups each
+    int32_t* list; unsigned long long* cnt;     // the list of THIS launch's rank and its counters cnt[0..2]
+    int ugrid;        // unit-scan blocks per rank
+    int urecs;        // unit records in partials (ugrid x ranks); the new-row records follow them
+    int nrb;          // new-row blocks = ceil(P / 512)
+    int rec_off;      // first unit record of this launch's rank
+    int all_defined;  // unit-sharded mode: every unit record is written by every scan
+    int sh_rank, sh_world;
+    unsigned long long* cnt_all; int cnt_ranks;     // all local counter quadruples (the update role zeroes the next ones)
+    int do_update, do_tests, do_rows;
+    int32_t* log_x; int32_t* log_y; double* log_bx; double* log_by;
+    unsigned long long* iterstats;
+};
 
-// scan the listed units: block b takes entries b, b+G, ... and always writes partials[b] when it had
-// work, so the records of a scan are partials[0 .. min(cnt, grid)).  The lane-level best carries the
-// positions of the pair and its distance, so nothing is looked up after the reduction.
+// the reference's update arithmetic (src/neighborJoining.cu:171-176), one place for the update role and for the
+// test role that needs the same row sums before they are stored
+__device__ __forceinline__ double nj_val(double dxi, double dyi, double d) { return (dxi + dyi - d) * 0.5; }
+__device__ __forceinline__ double nj_unew(double up, double dxi, double dyi, double val) { return up + (-dxi - dyi + val); }
+
 __device__ __forceinline__ void best_update4(double& bq, uint64_t& bk, uint64_t& bp, double& bd, double q, uint64_t k,
                                              uint64_t pp, double d)
 {
@@ -311,140 +153,206 @@ __device__ __forceinline__ void best_update4(double& bq, uint64_t& bk, uint64_t&
     bq = take ? q : bq; bk = take ? k : bk; bp = take ? pp : bp; bd = take ? d : bd;
 }
 
-__global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __restrict__ D, int64_t ld,
-                                                            NjState* __restrict__ st,
-                                                            const double* __restrict__ Ur,
-                                                            const uint64_t* __restrict__ KA,
-                                                            const uint64_t* __restrict__ KB,
-                                                            unsigned long long* __restrict__ umin,
-                                                            int64_t P, const int32_t* __restrict__ list,
-                                                            NjRecord* __restrict__ partials,
-                                                            unsigned long long* __restrict__ iterstats,
-                                                            const unsigned long long* __restrict__ cnt_rank, int write_null)
+// ------------------------------------------------------------------------------------------------
+// epoch start: every unit is listed with all four sub-units (the bounds start at -inf and there is no
+// seed, so no test could rule anything out); nothing is in quarantine
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void njp_list_all_kernel(NjpArgs a)
+{
+    const int tid = threadIdx.x;
+    const int64_t it = a.st->it;
+    if (a.st->status != 0) return;
+    const int cb = a.blk_cb[blockIdx.x];
+    const int64_t g = (int64_t)a.blk_g0[blockIdx.x] + tid;
+    const int64_t G16 = (a.P + kUR - 1) / kUR;
+    const bool keep = g < G16 && (a.sh_world <= 1 || (int)(((int64_t)cb * G16 + g) % a.sh_world) == a.sh_rank);
+    const unsigned long long mask = __ballot(keep);
+    const int lane = tid & 63;
+    unsigned long long base = 0;
+    if (lane == 0 && mask) base = atomicAdd(&a.cnt[it % 3], (unsigned long long)__popcll(mask));
+    base = __shfl(base, 0, 64);
+    if (keep) a.list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)((0xFu << 28) | ((uint32_t)cb << 18) | (uint32_t)g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// SCAN(it).  Blocks [0, ugrid): the listed units -- block b takes entries b, b+G, ... and always writes
+// partials[b] when it had work, so the unit records of a scan are partials[0 .. min(cnt, grid)).  The
+// lane-level best carries the positions of the pair and its distance, so nothing is looked up after the
+// reduction.  The node in quarantine has a NaN row sum: the unit scans skip its row and column (and the
+// exact sub-unit minima they store leave it out).
+// Blocks [ugrid, ugrid + nrb): the NEW ROW.  They finish the row sum U[x] of the node created by the
+// previous merge from the chunk partials (canonical order), evaluate its pairs against every live
+// position from the row buffer, and move the buffered row into the matrix (nobody reads that row validly
+// during this launch); the first of them stores U[x].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjpArgs a)
 {
     __shared__ double sq[kThreads / 64], sd[kThreads / 64];
     __shared__ uint64_t sk[kThreads / 64], sp[kThreads / 64];
+    __shared__ double stree[kThreads];
 
     const int tid = threadIdx.x;
-    const bool clocked = iterstats != nullptr && tid == 0 && blockIdx.x == 0;     // phase clocks (profiles/nj_clocks.py)
-    unsigned long long ck[5] = { 0, 0, 0, 0, 0 };
-    if (clocked) ck[0] = wall_clock64();
-    // hop 1: state line and (speculatively) this block's first list entry
-    const int64_t it = st->itb, limit = st->it_limit;
-    const int32_t first = list[blockIdx.x];
-    if (it >= limit || st->status != 0) return;
-    const int64_t cnt = (int64_t)(cnt_rank ? cnt_rank[it & 1] : st->cnt_list[it & 1]);
-    if ((int64_t)blockIdx.x >= cnt) {
-        if (write_null && tid == 0) {      // unit-sharded mode: every record of the gathered array is defined
-            NjRecord rec; rec.q = 10000.0; rec.key = ~0ull; rec.d = 0.0; rec.pad = 0ull;
-            partials[blockIdx.x] = rec;
-        }
-        return;
-    }
-    const int64_t G16 = (P + kUR - 1) / kUR;
-    if (clocked) { __builtin_amdgcn_s_waitcnt(0); ck[1] = wall_clock64(); }
-    // Two passes per unit instead of a (q, key, positions, d) compare-and-select per candidate (64 candidates
-    // per lane and unit, ~20 VALU instructions each, were 2 us of this kernel's critical path): pass 1 computes
-    // the candidates' q and their minimum over the WAVE; pass 2 -- only when that minimum reaches the wave's
-    // best so far -- looks for the candidates equal to it (rare, wave-uniform branch) and keeps the smallest key.
-    // bq is wave-uniform; (bk, bp, bd) is this lane's best candidate AT q == bq (bk == ~0: none).
+    // hop 1: state line and (speculatively) this block's first list entry / chunk partial
+    const int64_t it = a.st->it, limit = a.st->it_limit, N = a.st->N;
+    const bool unit_block = (int)blockIdx.x < a.ugrid;
+    const int32_t first = unit_block ? a.list[blockIdx.x] : 0;
+    const double xp0 = unit_block ? 0.0 : a.xpart[tid];          // (the array is padded to a multiple of 256 entries)
+    const int64_t pz = (int64_t)a.st->pnew[it & 1];
+    if (blockIdx.x == 0 && tid == 0) a.st->itb = it;             // the post kernel's iteration index (it advances `it` itself); also beyond the limit
+    if (it >= limit || a.st->status != 0) return;
+    const int64_t P = a.P;
     double bq = 10000.0, bd = 0.0;  // the reference's init value
     uint64_t bk = ~0ull, bp = 0;
-    int64_t scanned = 0;
+    NjRecord* rec_out;
 
-    const int wv = tid >> 6;                         // this wave's sub-strip of every unit
-    for (int64_t e = blockIdx.x; e < cnt; e += gridDim.x, ++scanned) {
-        const uint32_t code = (uint32_t)__builtin_amdgcn_readfirstlane(e == (int64_t)blockIdx.x ? first : list[e]);
-        if (!((code >> (28 + wv)) & 1u)) continue;   // the bound of this wave's sub-unit rules it out (wave-uniform)
-        const int cb = (int)((code >> 18) & 1023u);
-        const int64_t g_s = (int64_t)(code & 0x3FFFFu);
-        const int64_t c0 = (int64_t)cb * kTileCols, a0 = g_s * kUR;
-        // Rows a0 .. a0+15 are always read: the matrix has a zeroed group of rows behind position P and the
-        // vectors carry NaN row sums there (njp_alloc_epoch), so rows >= P behave like dead rows.
-        const int64_t b0 = c0 + 2 * tid, b1 = b0 + 1;
-        const v2d ubv = *reinterpret_cast<const v2d*>(Ur + b0);
-        const ulonglong2 kav = *reinterpret_cast<const ulonglong2*>(KA + b0), kbv = *reinterpret_cast<const ulonglong2*>(KB + b0);
-        const double ub0 = ubv.x, ub1 = ubv.y;
-        const uint64_t ka0 = kav.x, ka1 = kav.y, kb0 = kbv.x, kb1 = kbv.y;
-        const v2d* basep = reinterpret_cast<const v2d*>(D + a0 * ld + c0) + tid;
-        const int64_t ld2 = ld >> 1;
-        const bool diag = a0 < c0 + kTileCols;
-        const bool live0 = ub0 == ub0, live1 = ub1 == ub1;   // dead columns carry NaN row sums
-        v2d v[kUR];
+    if (!unit_block) {
+        // ---------------------------------------------------------------- new-row block
+        const int r = (int)blockIdx.x - a.ugrid;
+        rec_out = a.partials + a.urecs + r;
+        if (pz < 0 || !a.do_rows) {
+            if (tid == 0) { NjRecord rec; rec.q = 10000.0; rec.key = ~0ull; rec.d = 0.0; rec.pad = 0ull; *rec_out = rec; }
+            return;
+        }
+        const int64_t n = N - it;
+        const int64_t nchunk = (n + 1 + kThreads - 1) / kThreads;        // chunks of the previous update (n + 1 slots)
+        double acc = tid < nchunk ? xp0 : 0.0;
+        for (int64_t c = tid + kThreads; c < nchunk; c += kThreads) acc += a.xpart[c];
+        // hop 2 (independent of the sum): this thread's two positions of the buffered row and their vectors
+        const double* __restrict__ Rz = a.R + ((it + 1) & 1) * a.vstride;     // written by POST(it - 1)
+        const int64_t j0 = (int64_t)r * kTileCols + 2 * tid;
+        const v2d dv = *reinterpret_cast<const v2d*>(Rz + j0);
+        const v2d uv = *reinterpret_cast<const v2d*>(a.Ur + j0);
+        const ulonglong2 kav = *reinterpret_cast<const ulonglong2*>(a.KA + j0), kbv = *reinterpret_cast<const ulonglong2*>(a.KB + j0);
+        const uint64_t kax = a.KA[pz], kbx = a.KB[pz];
+        double ux = block_tree256_lane0(acc, stree);
+        if (tid == 0) stree[0] = ux;
+        __syncthreads();
+        ux = stree[0];
+        const double urx = ux / (double)(n - 2);
+        if (r == 0 && tid == 0) a.U[(it & 1) * a.vstride + pz] = ux;
+        if (j0 < P) *reinterpret_cast<v2d*>(a.D + pz * a.ld + j0) = dv;        // (R[pz] = 0: the diagonal stays 0)
 #pragma unroll
-        for (int u8 = 0; u8 < kUR; ++u8) v[u8] = __builtin_nontemporal_load(basep + (int64_t)u8 * ld2);
-        // the 16 rows' row sums and keys: lane l holds row a0 + (l & 15) (three coalesced loads, no scalar-register
-        // pressure); v_readlane hands them out -- the keys only in the rare branch of pass 2
-        const double ua_l = Ur[a0 + (tid & 15)];
-        const uint64_t kaa_l = KA[a0 + (tid & 15)], kba_l = KB[a0 + (tid & 15)];
-        double ua[kUR];
-#pragma unroll
-        for (int u8 = 0; u8 < kUR; ++u8) ua[u8] = readlane_f64(ua_l, u8);
-        if (clocked && ck[2] == 0) { __builtin_amdgcn_s_waitcnt(0); ck[2] = wall_clock64(); }
-        if (diag) {   // block-uniform and rare (units on the diagonal): mask the entries with column >= row
-            const int ib0 = (int)b0, ia0 = (int)a0;
-#pragma unroll
-            for (int u8 = 0; u8 < kUR; ++u8) {
-                const int a = ia0 + u8;
-                v[u8].x = (ib0 < a) ? v[u8].x : __builtin_nan("");
-                v[u8].y = (ib0 + 1 < a) ? v[u8].y : __builtin_nan("");
+        for (int k = 0; k < 2; ++k) {
+            const double d = k ? dv.y : dv.x, uj = k ? uv.y : uv.x;       // dead / padding / pz itself: NaN row sum -> NaN q
+            const uint64_t kaj = k ? kav.y : kav.x, kbj = k ? kbv.y : kbv.x;
+            const uint64_t pj = (uint64_t)(j0 + k);
+            best_update4(bq, bk, bp, bd, (d - urx) - uj, kax | kbj, (uint64_t)pz | (pj << 32), d);   // (i = x, j)
+            best_update4(bq, bk, bp, bd, (d - uj) - urx, kaj | kbx, pj | ((uint64_t)pz << 32), d);   // (i = j, j = x)
+        }
+        wave_best4(bq, bk, bp, bd);
+    } else {
+        // ---------------------------------------------------------------- unit block
+        rec_out = a.partials + a.rec_off + blockIdx.x;
+        const int64_t cnt = (int64_t)a.cnt[it % 3];
+        if ((int64_t)blockIdx.x >= cnt) {
+            if (a.all_defined && tid == 0) {      // unit-sharded mode: every record of the gathered array is defined
+                NjRecord rec; rec.q = 10000.0; rec.key = ~0ull; rec.d = 0.0; rec.pad = 0ull;
+                *rec_out = rec;
             }
+            return;
         }
-        // pass 1: q of the four ordered candidates of every loaded pair; a dead row or column (NaN row sum) and a
-        // masked entry (NaN distance) give a NaN q, which fmin drops and no comparison selects.  m0 / m1: the
-        // exact minimum over the live rows of this lane's two columns (dead rows add NaN, which fmin drops).
-        double lm = __builtin_inf(), m0 = __builtin_inf(), m1 = __builtin_inf();
-        double rowq[kUR];                          // this lane's smallest q per row: pass 2 looks only at rows that reach wm
+        const int64_t G16 = (P + kUR - 1) / kUR;
+        // Two passes per unit instead of a (q, key, positions, d) compare-and-select per candidate (64 candidates
+        // per lane and unit, ~20 VALU instructions each, were 2 us of this kernel's critical path): pass 1 computes
+        // the candidates' q and their minimum over the WAVE; pass 2 -- only when that minimum reaches the wave's
+        // best so far -- looks for the candidates equal to it (rare, wave-uniform branch) and keeps the smallest key.
+        // bq is wave-uniform; (bk, bp, bd) is this lane's best candidate AT q == bq (bk == ~0: none).
+        int64_t scanned = 0;
+        const int wv = tid >> 6;                         // this wave's sub-strip of every unit
+        for (int64_t e = blockIdx.x; e < cnt; e += a.ugrid, ++scanned) {
+            const uint32_t code = (uint32_t)__builtin_amdgcn_readfirstlane(e == (int64_t)blockIdx.x ? first : a.list[e]);
+            if (!((code >> (28 + wv)) & 1u)) continue;   // the bound of this wave's sub-unit rules it out (wave-uniform)
+            const int cb = (int)((code >> 18) & 1023u);
+            const int64_t g_s = (int64_t)(code & 0x3FFFFu);
+            const int64_t c0 = (int64_t)cb * kTileCols, a0 = g_s * kUR;
+            // Rows a0 .. a0+15 are always read: the matrix has a group of rows behind position P and the
+            // vectors carry NaN row sums there (njp_alloc_epoch), so rows >= P behave like dead rows.
+            const int64_t b0 = c0 + 2 * tid, b1 = b0 + 1;
+            const v2d ubv = *reinterpret_cast<const v2d*>(a.Ur + b0);
+            const ulonglong2 kav = *reinterpret_cast<const ulonglong2*>(a.KA + b0), kbv = *reinterpret_cast<const ulonglong2*>(a.KB + b0);
+            const double ub0 = ubv.x, ub1 = ubv.y;
+            const uint64_t ka0 = kav.x, ka1 = kav.y, kb0 = kbv.x, kb1 = kbv.y;
+            const v2d* basep = reinterpret_cast<const v2d*>(a.D + a0 * a.ld + c0) + tid;
+            const int64_t ld2 = a.ld >> 1;
+            const bool diag = a0 < c0 + kTileCols;
+            const bool live0 = ub0 == ub0, live1 = ub1 == ub1;   // dead columns carry NaN row sums
+            v2d v[kUR];
 #pragma unroll
-        for (int u8 = 0; u8 < kUR; ++u8) {
-            const double d0 = v[u8].x, d1 = v[u8].y;
-            const double rn = ua[u8] == ua[u8] ? 0.0 : __builtin_nan("");   // wave-uniform
-            m0 = fmin(m0, d0 + rn);
-            m1 = fmin(m1, d1 + rn);
-            const double q0 = (d0 - ua[u8]) - ub0;   // (i=a,  j=b0)
-            const double q1 = (d0 - ub0) - ua[u8];   // (i=b0, j=a)
-            const double q2 = (d1 - ua[u8]) - ub1;
-            const double q3 = (d1 - ub1) - ua[u8];
-            rowq[u8] = fmin(fmin(q0, q1), fmin(q2, q3));
-            lm = fmin(lm, rowq[u8]);
-        }
-        double m = fmin(fmin(live0 ? m0 : __builtin_nan(""), live1 ? m1 : __builtin_nan("")), __builtin_inf());   // +inf: no live pair
-        const double wm = wave_fmin(lm);          // +inf when the wave saw no valid candidate
-        if (wm <= bq) {                           // wave-uniform; the q are recomputed (same operations, same bits)
-            if (wm < bq) { bq = wm; bk = ~0ull; }   // rather than kept: 128 registers less, twice the blocks per CU
+            for (int u8 = 0; u8 < kUR; ++u8) v[u8] = __builtin_nontemporal_load(basep + (int64_t)u8 * ld2);
+            // the 16 rows' row sums and keys: lane l holds row a0 + (l & 15) (three coalesced loads, no scalar-register
+            // pressure); v_readlane hands them out -- the keys only in the rare branch of pass 2
+            const double ua_l = a.Ur[a0 + (tid & 15)];
+            const uint64_t kaa_l = a.KA[a0 + (tid & 15)], kba_l = a.KB[a0 + (tid & 15)];
+            double ua[kUR];
 #pragma unroll
-            for (int u8 = 0; u8 < kUR; ++u8) {
-                if (__builtin_amdgcn_ballot_w64(rowq[u8] == wm) != 0ull) {      // rare; the four q are recomputed (same bits)
-                    double d0 = v[u8].x, d1 = v[u8].y;
-                    asm volatile("" : "+v"(d0), "+v"(d1));    // opaque: keeps the compiler from holding pass 1's 64 q alive
-                    const bool e0 = (d0 - ua[u8]) - ub0 == wm, e1 = (d0 - ub0) - ua[u8] == wm;
-                    const bool e2 = (d1 - ua[u8]) - ub1 == wm, e3 = (d1 - ub1) - ua[u8] == wm;
-                    const uint64_t pa = (uint64_t)(a0 + u8);
-                    const uint64_t kaa = readlane_u64(kaa_l, u8), kba = readlane_u64(kba_l, u8);
-                    const uint64_t k0 = kaa | kb0, k1 = ka0 | kba, k2 = kaa | kb1, k3 = ka1 | kba;
-                    if (e0 & (k0 < bk)) { bk = k0; bp = pa | ((uint64_t)b0 << 32); bd = d0; }
-                    if (e1 & (k1 < bk)) { bk = k1; bp = (uint64_t)b0 | (pa << 32); bd = d0; }
-                    if (e2 & (k2 < bk)) { bk = k2; bp = pa | ((uint64_t)b1 << 32); bd = d1; }
-                    if (e3 & (k3 < bk)) { bk = k3; bp = (uint64_t)b1 | (pa << 32); bd = d1; }
+            for (int u8 = 0; u8 < kUR; ++u8) ua[u8] = readlane_f64(ua_l, u8);
+            if (diag) {   // block-uniform and rare (units on the diagonal): mask the entries with column >= row
+                const int ib0 = (int)b0, ia0 = (int)a0;
+#pragma unroll
+                for (int u8 = 0; u8 < kUR; ++u8) {
+                    const int ar = ia0 + u8;
+                    v[u8].x = (ib0 < ar) ? v[u8].x : __builtin_nan("");
+                    v[u8].y = (ib0 + 1 < ar) ? v[u8].y : __builtin_nan("");
                 }
             }
+            // pass 1: q of the four ordered candidates of every loaded pair; a dead row or column (NaN row sum) and a
+            // masked entry (NaN distance) give a NaN q, which fmin drops and no comparison selects.  m0 / m1: the
+            // exact minimum over the live rows of this lane's two columns (dead rows add NaN, which fmin drops).
+            double lm = __builtin_inf(), m0 = __builtin_inf(), m1 = __builtin_inf();
+            double rowq[kUR];                          // this lane's smallest q per row: pass 2 looks only at rows that reach wm
+#pragma unroll
+            for (int u8 = 0; u8 < kUR; ++u8) {
+                const double d0 = v[u8].x, d1 = v[u8].y;
+                const double rn = ua[u8] == ua[u8] ? 0.0 : __builtin_nan("");   // wave-uniform
+                m0 = fmin(m0, d0 + rn);
+                m1 = fmin(m1, d1 + rn);
+                const double q0 = (d0 - ua[u8]) - ub0;   // (i=a,  j=b0)
+                const double q1 = (d0 - ub0) - ua[u8];   // (i=b0, j=a)
+                const double q2 = (d1 - ua[u8]) - ub1;
+                const double q3 = (d1 - ub1) - ua[u8];
+                rowq[u8] = fmin(fmin(q0, q1), fmin(q2, q3));
+                lm = fmin(lm, rowq[u8]);
+            }
+            double m = fmin(fmin(live0 ? m0 : __builtin_nan(""), live1 ? m1 : __builtin_nan("")), __builtin_inf());   // +inf: no live pair
+            const double wm = wave_fmin(lm);          // +inf when the wave saw no valid candidate
+            if (wm <= bq) {                           // wave-uniform; the q are recomputed (same operations, same bits)
+                if (wm < bq) { bq = wm; bk = ~0ull; }   // rather than kept: 128 registers less, twice the blocks per CU
+#pragma unroll
+                for (int u8 = 0; u8 < kUR; ++u8) {
+                    if (__builtin_amdgcn_ballot_w64(rowq[u8] == wm) != 0ull) {      // rare; the four q are recomputed (same bits)
+                        double d0 = v[u8].x, d1 = v[u8].y;
+                        asm volatile("" : "+v"(d0), "+v"(d1));    // opaque: keeps the compiler from holding pass 1's 64 q alive
+                        const bool e0 = (d0 - ua[u8]) - ub0 == wm, e1 = (d0 - ub0) - ua[u8] == wm;
+                        const bool e2 = (d1 - ua[u8]) - ub1 == wm, e3 = (d1 - ub1) - ua[u8] == wm;
+                        const uint64_t pa = (uint64_t)(a0 + u8);
+                        const uint64_t kaa = readlane_u64(kaa_l, u8), kba = readlane_u64(kba_l, u8);
+                        const uint64_t k0 = kaa | kb0, k1 = ka0 | kba, k2 = kaa | kb1, k3 = ka1 | kba;
+                        if (e0 & (k0 < bk)) { bk = k0; bp = pa | ((uint64_t)b0 << 32); bd = d0; }
+                        if (e1 & (k1 < bk)) { bk = k1; bp = (uint64_t)b0 | (pa << 32); bd = d0; }
+                        if (e2 & (k2 < bk)) { bk = k2; bp = pa | ((uint64_t)b1 << 32); bd = d1; }
+                        if (e3 & (k3 < bk)) { bk = k3; bp = (uint64_t)b1 | (pa << 32); bd = d1; }
+                    }
+                }
+            }
+            // exact minimum of this wave's sub-unit -> its bound (no cross-wave step)
+            m = wave_fmin(m);
+            if ((tid & 63) == 0) a.umin[((int64_t)cb * G16 + g_s) * 4 + wv] = enc_f64(m);
         }
-        // exact minimum of this wave's sub-unit -> its bound (no cross-wave step any more)
-        m = wave_fmin(m);
-        if ((tid & 63) == 0) umin[((int64_t)cb * G16 + g_s) * 4 + wv] = enc_f64(m);
-    }
-
-    if (clocked) ck[3] = wall_clock64();
-    // wave winner: the smallest key among the lanes' candidates at bq, then that lane's positions and distance
-    {
-        const uint64_t wk = wave_umin64(bk);
-        if (wk != ~0ull) {
-            const unsigned long long own = __builtin_amdgcn_ballot_w64(bk == wk);
-            const int src = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(own));
-            bp = readlane_u64(bp, src);
-            bd = readlane_f64(bd, src);
+        // wave winner: the smallest key among the lanes' candidates at bq, then that lane's positions and distance
+        {
+            const uint64_t wk = wave_umin64(bk);
+            if (wk != ~0ull) {
+                const unsigned long long own = __builtin_amdgcn_ballot_w64(bk == wk);
+                const int src = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(own));
+                bp = readlane_u64(bp, src);
+                bd = readlane_f64(bd, src);
+            }
+            bk = wk;
         }
-        bk = wk;
+        if (tid == 0) {
+            if (a.iterstats) { atomicAdd(&a.iterstats[2 * it], (unsigned long long)scanned); atomicMax(&a.iterstats[2 * it + 1], (unsigned long long)scanned); }
+            if (blockIdx.x == 0) atomicAdd(&a.st->units_scanned, (unsigned long long)cnt);   // statistics
+        }
     }
     if ((tid & 63) == 0) { sq[tid >> 6] = bq; sk[tid >> 6] = bk; sp[tid >> 6] = bp; sd[tid >> 6] = bd; }
     __syncthreads();
@@ -453,93 +361,139 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(const double* __rest
         for (int w = 1; w < kThreads / 64; ++w) best_update4(bq, bk, bp, bd, sq[w], sk[w], sp[w], sd[w]);
         NjRecord rec;
         rec.q = bq; rec.key = bk; rec.d = bd; rec.pad = bp;   // pad = pos_i | pos_j << 32
-        partials[blockIdx.x] = rec;
-        if (iterstats) { atomicAdd(&iterstats[2 * it], (unsigned long long)scanned); atomicMax(&iterstats[2 * it + 1], (unsigned long long)scanned); }
-        if (blockIdx.x == 0) atomicAdd(&st->units_scanned, (unsigned long long)cnt);   // statistics; no load on this block's tail
-        if (clocked) {
-            __builtin_amdgcn_s_waitcnt(0);
-            ck[4] = wall_clock64();
-            unsigned long long* o = iterstats + 2 * st->N + 2 + 16;
-            atomicAdd(&o[0], 1ull);
-            if (ck[2] == 0) ck[2] = ck[1];
-            for (int k = 1; k < 5; ++k) atomicAdd(&o[k], ck[k] - ck[k - 1]);
-        }
+        *rec_out = rec;
     }
 }
 
+// after the last enqueued iteration: what the next scan's new-row blocks would materialise (row sum of the node in
+// quarantine, its row in the matrix), so that hooks, epoch rebuilds and a resumed run find them in memory.  The node
+// stays in quarantine (Ur = NaN): the next scan repeats the two stores with the same values.
+__global__ __launch_bounds__(kThreads) void njp_finish_kernel(NjpArgs a)
+{
+    __shared__ double stree[kThreads];
+    const int tid = threadIdx.x;
+    const int64_t it = a.st->it, N = a.st->N;
+    const int64_t pz = (int64_t)a.st->pnew[it & 1];
+    if (a.st->status != 0 || pz < 0) return;
+    const int64_t n = N - it;
+    const int64_t nchunk = (n + 1 + kThreads - 1) / kThreads;
+    double acc = 0.0;
+    for (int64_t c = tid; c < nchunk; c += kThreads) acc += a.xpart[c];
+    const double* __restrict__ Rz = a.R + ((it + 1) & 1) * a.vstride;
+    const int64_t j0 = (int64_t)blockIdx.x * kTileCols + 2 * tid;
+    const v2d dv = *reinterpret_cast<const v2d*>(Rz + j0);
+    const double ux = block_tree256_lane0(acc, stree);
+    if (blockIdx.x == 0 && tid == 0) a.U[(it & 1) * a.vstride + pz] = ux;
+    if (j0 < a.P) *reinterpret_cast<v2d*>(a.D + pz * a.ld + j0) = dv;
+}
+
 // ------------------------------------------------------------------------------------------------
-// select + merge + update, indexed by REFERENCE slot i (so the chunk sums of U[x] keep the canonical
-// order).  Position space: rows never move; the node of slot n-1 is relabelled to slot y.
+// POST(it) = select + merge + update + the unit tests of iteration it + 1.
+// Every block reduces the scan records to the winner for itself.  Then
+//  * update role (blocks [ntest, ntest + ceil(N / 256))), indexed by REFERENCE slot i so that the chunk sums
+//    of U[x] keep the canonical order: new row sums into the OTHER U buffer (the test role of this launch
+//    reads the current one), the new node's row into the row buffer R[it & 1] and its column into the matrix
+//    (rows x and y themselves stay untouched in this launch: the test role reads them), the new node goes
+//    into quarantine (Ur = NaN), the node of the last slot is relabelled to slot y;
+//  * test role (blocks [0, ntest): one strip, one lane per unit): it needs the row sums AFTER this merge,
+//    which other blocks are only just storing, so it recomputes them for its 16 rows and 2 columns from the
+//    current buffer and rows x, y (same arithmetic, same bits); seed bound = the scan records re-evaluated
+//    the same way; the row of the node that LEAVES quarantine (merge it - 1, row buffer R[(it - 1) & 1]) is
+//    folded into the bounds of the sub-units it crosses; survivors are appended to the list of scan it + 1.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__ D, int64_t ld,
-                                                            NjState* __restrict__ st, double* __restrict__ U,
-                                                            double* __restrict__ Ur, uint64_t* __restrict__ KA,
-                                                            uint64_t* __restrict__ KB,
-                                                            int32_t* __restrict__ slot_of_pos,
-                                                            int32_t* __restrict__ pos_of_slot,
-                                                            double* __restrict__ xpart,
-                                                            const NjRecord* __restrict__ partials, int scan_grid,
-                                                            int64_t P,
-                                                            int32_t* __restrict__ log_x, int32_t* __restrict__ log_y,
-                                                            double* __restrict__ log_bx, double* __restrict__ log_by,
-                                                            int nrec_fixed, unsigned long long* __restrict__ cnt_all,
-                                                            int cnt_ranks, unsigned long long* __restrict__ clk)
+__global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
 {
     __shared__ double s[kThreads];
     __shared__ double sq[kThreads / 64], sdd[kThreads / 64];
     __shared__ uint64_t sk[kThreads / 64], spp[kThreads / 64];
-    const bool clocked = clk != nullptr && threadIdx.x == 0 && blockIdx.x == 0;   // phase clocks (profiles/nj_clocks.py)
-    unsigned long long ck[6] = { 0, 0, 0, 0, 0, 0 };
-    if (clocked) ck[0] = wall_clock64();
-    // hop 1: state line, this thread's slot -> position, and (speculatively) the scan records
-    const int64_t it = st->itb;   // stable: the writer below only advances st->it / st->n
-    const int64_t limit = st->it_limit, N = st->N;
-    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    // (none of these addresses depends on a loaded value: the slot arrays are padded past N, the record array holds
-    // scan_grid entries; what a load was worth is decided afterwards)
-    const int64_t p = (int64_t)pos_of_slot[i];
+    __shared__ double sseed[kThreads / 64], scm[kThreads / 64], snew[kThreads / 64];
+    const int tid = threadIdx.x;
+    const bool test_block = (int)blockIdx.x < a.ntest;
+    // hop 1: state line, scan records, and what each role can address without knowing the winner
+    const int64_t it = a.st->itb;   // stable: the writer below only advances st->it
+    const int64_t limit = a.st->it_limit, N = a.st->N;
+    const int64_t pz = (int64_t)a.st->pnew[it & 1];        // node leaving quarantine (its U was stored by SCAN(it))
+    const int nrec_all = a.urecs + a.nrb;
     NjRecord r0; r0.q = 10000.0; r0.key = ~0ull; r0.d = 0; r0.pad = 0;
     NjRecord mine[4] = { r0, r0, r0, r0 };
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int idx = threadIdx.x + k * kThreads;
-        if (idx < scan_grid) mine[k] = partials[idx];
+        const int idx = tid + k * kThreads;
+        if (idx < nrec_all) mine[k] = a.partials[idx];
     }
-    const unsigned long long cnt_raw = nrec_fixed >= 0 ? (unsigned long long)nrec_fixed : st->cnt_list[it & 1];
+    // seed candidates of the test role: one unit record (every (urecs / 256)-th when all of them are defined) and one
+    // new-row record per thread
+    const int64_t sstride = a.all_defined && a.urecs >= 2 * kThreads ? a.urecs / kThreads : 1;
+    NjRecord candA = r0, candB = r0;
+    if (test_block) {
+        if ((int64_t)tid * sstride < a.urecs) candA = a.partials[(int64_t)tid * sstride];
+        if (tid < a.nrb) candB = a.partials[a.urecs + tid];
+    }
+    const unsigned long long cnt_raw = a.all_defined ? (unsigned long long)a.urecs : a.cnt[it % 3];
+    const int64_t uvalid = (int64_t)(cnt_raw < (unsigned long long)a.urecs ? cnt_raw : (unsigned long long)a.urecs);   // unit records written by SCAN(it)
+    const double* __restrict__ Uc = a.U + (it & 1) * a.vstride;
+    double* __restrict__ Un = a.U + ((it + 1) & 1) * a.vstride;
+    const int64_t P = a.P;
+    const int64_t G16 = (P + kUR - 1) / kUR;
+    // update role
+    const int64_t i = (int64_t)((int)blockIdx.x - a.ntest) * kThreads + tid;     // reference slot
+    int64_t p = -1;
+    double up = 0.0;
+    // test role
+    int cb = 0;
+    int64_t g = 0, a0 = 0, pc0 = 0;
+    bool have = false;
+    int4 sprow[kUR / 4];
+    v2d urow[kUR / 2];
+    int2 spcol = make_int2(-1, -1);
+    v2d ucol; ucol.x = 0.0; ucol.y = 0.0;
+    ulonglong2 um0 = make_ulonglong2(0ull, 0ull), um1 = um0;
+    unsigned long long* up4 = a.umin;
+    if (test_block) {
+        cb = a.blk_cb[blockIdx.x];
+        g = (int64_t)a.blk_g0[blockIdx.x] + tid;
+        have = g < G16;
+        a0 = (have ? g : 0) * kUR;                                    // 128-byte aligned
+        pc0 = (int64_t)cb * kTileCols + 2 * tid;                      // this thread's two strip columns (< P + 512)
+        up4 = a.umin + ((int64_t)cb * G16 + (have ? g : 0)) * 4;
+        if (have) { um0 = *reinterpret_cast<const ulonglong2*>(up4); um1 = *reinterpret_cast<const ulonglong2*>(up4 + 2); }
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if ((unsigned long long)(threadIdx.x + k * kThreads) >= cnt_raw) mine[k] = r0;   // not written by this iteration's scan
-    // hop 1b: this position's row sum (its address needs the position only; in flight during the record reduction)
-    const double up = (i < N && p >= 0) ? U[p] : 0.0;
-    if (st->status != 0 || it >= limit) return;
+        for (int r = 0; r < kUR / 4; ++r) sprow[r] = *reinterpret_cast<const int4*>(a.slot_of_pos + a0 + 4 * r);
+#pragma unroll
+        for (int r = 0; r < kUR / 2; ++r) urow[r] = *reinterpret_cast<const v2d*>(Uc + a0 + 2 * r);
+        spcol = *reinterpret_cast<const int2*>(a.slot_of_pos + pc0);
+        ucol = *reinterpret_cast<const v2d*>(Uc + pc0);
+    } else {
+        p = (int64_t)a.pos_of_slot[i];                 // (the slot arrays are padded past N)
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + k * kThreads;
+        if (idx >= uvalid && idx < a.urecs) mine[k] = r0;   // not written by this iteration's scan
+    }
+    if (!test_block) up = (i < N && p >= 0) ? Uc[p] : 0.0;      // hop 1b (address needs the position only)
+    if (a.st->status != 0 || it >= limit) return;
     const int64_t n = N - it;
-    if (n < 3 || (int64_t)blockIdx.x * kThreads >= n) return;
-    const int par = (int)(it & 1);
+    if (n < 3) return;
+    if (!test_block && (!a.do_update || (int64_t)((int)blockIdx.x - a.ntest) * kThreads >= n)) return;
+    if (test_block && !a.do_tests) return;
 
-    if (clocked) { __builtin_amdgcn_s_waitcnt(0); ck[1] = wall_clock64(); }
-    // select: reduce the records (thrust::min_element, src/neighborJoining.cu:214)
+    // ---- select: reduce the records (thrust::min_element, src/neighborJoining.cu:214)
     double bq = 10000.0, d = 0.0; uint64_t bk = ~0ull, bp = 0;
-    best_update4(bq, bk, bp, d, mine[0].q, mine[0].key, mine[0].pad, mine[0].d);
-    if (cnt_raw > (unsigned long long)kThreads) {      // block-uniform; mostly false: a scan rarely lists more than 256 units
 #pragma unroll
-        for (int k = 1; k < 4; ++k) best_update4(bq, bk, bp, d, mine[k].q, mine[k].key, mine[k].pad, mine[k].d);
-    }
-    {
-        const int64_t nrec = (int64_t)(cnt_raw < (unsigned long long)scan_grid ? cnt_raw : (unsigned long long)scan_grid);
-        for (int64_t idx = threadIdx.x + 4 * kThreads; idx < nrec; idx += kThreads)
-            best_update4(bq, bk, bp, d, partials[idx].q, partials[idx].key, partials[idx].pad, partials[idx].d);
-    }
+    for (int k = 0; k < 4; ++k) best_update4(bq, bk, bp, d, mine[k].q, mine[k].key, mine[k].pad, mine[k].d);
+    for (int64_t idx = tid + 4 * kThreads; idx < nrec_all; idx += kThreads)
+        if (idx < uvalid || idx >= a.urecs) best_update4(bq, bk, bp, d, a.partials[idx].q, a.partials[idx].key, a.partials[idx].pad, a.partials[idx].d);
     wave_best4(bq, bk, bp, d);
-    if ((threadIdx.x & 63) == 0) { sq[threadIdx.x >> 6] = bq; sk[threadIdx.x >> 6] = bk; spp[threadIdx.x >> 6] = bp; sdd[threadIdx.x >> 6] = d; }
+    if ((tid & 63) == 0) { sq[tid >> 6] = bq; sk[tid >> 6] = bk; spp[tid >> 6] = bp; sdd[tid >> 6] = d; }
     __syncthreads();
     bq = sq[0]; bk = sk[0]; bp = spp[0]; d = sdd[0];
 #pragma unroll
     for (int w = 1; w < kThreads / 64; ++w) best_update4(bq, bk, bp, d, sq[w], sk[w], spp[w], sdd[w]);
 
-    if (clocked) ck[2] = wall_clock64();
     const int64_t last = n - 1;
     if (bk == ~0ull) {
-        if (i == last) st->status = 1;
+        if (!test_block && i == last) a.st->status = 1;
         return;
     }
     const int64_t ki = (int64_t)(bk & 0xFFFFFFull), kj = (int64_t)((bk >> 24) & 0xFFFFFFull);
@@ -548,57 +502,165 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(double* __restrict__
     const int64_t px = ki < kj ? pi : pj, py = ki < kj ? pj : pi;
     const int64_t n1 = n - 1;
     const double r1 = (double)(n1 - 2);
+    const double* __restrict__ rowx = a.D + px * a.ld;
+    const double* __restrict__ rowy = a.D + py * a.ld;
 
-    double val = 0.0;
-    if (i < n) {
-        if (i == last) {
-            // single writer of the log and the state (reads U[px], U[py]; nobody rewrites them here)
-            const double r = (double)(n - 2);
-            double blX = (d + U[px] / r - U[py] / r) * 0.5;
-            double blY = d - blX;
-            if (blX < 0) { blY += blX; blX = 0; }
-            if (blY < 0) { blX += blY; blY = 0; }
-            log_x[it] = (int32_t)x; log_y[it] = (int32_t)y; log_bx[it] = blX; log_by[it] = blY;
-            st->x = (int32_t)x; st->y = (int32_t)y; st->d = d; st->q = bq;
-            st->n = n1; st->it = it + 1; st->pad = (int32_t)px;
-            st->cnt_list[1 - par] = 0ull;   // list counter of the NEXT scan (nobody reads it in this launch)
-            for (int v = 0; v < cnt_ranks; ++v) cnt_all[2 * v + (1 - par)] = 0ull;
-        }
-        int64_t new_slot = i;
-        if (i != x && i != y) {
-            const double dxi = D[px * ld + p], dyi = D[py * ld + p];
-            if (clocked) { __builtin_amdgcn_s_waitcnt(0); ck[3] = wall_clock64(); }
-            val = (dxi + dyi - d) * 0.5;
-            const double u = up + (-dxi - dyi + val);   // i == last: "U[y] = U[last] + ..." of the reference's tail
-            U[p] = u;
-            Ur[p] = u / r1;
-            D[px * ld + p] = val;
-            D[p * ld + px] = val;
-            // (the bounds of the units this pair belongs to are lowered by the prep kernel that follows)
-            if (i == last) {           // relabel: the node of the last slot now lives in slot y
-                new_slot = y;
-                slot_of_pos[p] = (int32_t)y;
-                pos_of_slot[y] = (int32_t)p;
+    if (!test_block) {
+        // ------------------------------------------------------------------------------ update role
+        double* __restrict__ Rw = a.R + (it & 1) * a.vstride;
+        double val = 0.0;
+        if (i < n) {
+            if (i == last) {
+                // single writer of the log and the state (reads U[px], U[py] of the current buffer)
+                const double r = (double)(n - 2);
+                double blX = (d + Uc[px] / r - Uc[py] / r) * 0.5;
+                double blY = d - blX;
+                if (blX < 0) { blY += blX; blX = 0; }
+                if (blY < 0) { blX += blY; blY = 0; }
+                a.log_x[it] = (int32_t)x; a.log_y[it] = (int32_t)y; a.log_bx[it] = blX; a.log_by[it] = blY;
+                a.st->x = (int32_t)x; a.st->y = (int32_t)y; a.st->d = d; a.st->q = bq;
+                a.st->n = n1; a.st->it = it + 1;
+                a.st->pnew[(it + 1) & 1] = (int32_t)px;
+                // list counters of the scan after next (nobody reads or appends to them in this launch)
+                a.st->cnt_list[(it + 2) % 3] = 0ull;
+                for (int v = 0; v < a.cnt_ranks; ++v) a.cnt_all[4 * v + (it + 2) % 3] = 0ull;
             }
-        } else if (i == y) {
-            // (py from the winning record, not this thread's pos_of_slot[y]: the thread of the last slot rewrites that entry)
-            Ur[py] = __builtin_nan("");   // dead: every q it takes part in is NaN, every unit minimum skips it
-            if (y != last) slot_of_pos[py] = -1;
-            new_slot = -1;
+            int64_t new_slot = i;
+            if (i != x && i != y) {
+                const double dxi = rowx[p], dyi = rowy[p];
+                val = nj_val(dxi, dyi, d);
+                const double u = nj_unew(up, dxi, dyi, val);   // i == last: "U[y] = U[last] + ..." of the reference's tail
+                Un[p] = u;
+                a.Ur[p] = u / r1;
+                Rw[p] = val;                   // row of the new node: into the matrix by the next scan's new-row blocks
+                a.D[p * a.ld + px] = val;      // its column
+                if (i == last) {           // relabel: the node of the last slot now lives in slot y
+                    new_slot = y;
+                    a.slot_of_pos[p] = (int32_t)y;
+                    a.pos_of_slot[y] = (int32_t)p;
+                }
+            } else if (i == y) {
+                // (py from the winning record, not this thread's pos_of_slot[y]: the thread of the last slot rewrites that entry)
+                a.Ur[py] = __builtin_nan("");   // dead: every q it takes part in is NaN, every unit minimum skips it
+                a.slot_of_pos[py] = -1;
+                Rw[py] = 0.0;
+                new_slot = -1;
+            } else {
+                a.Ur[px] = __builtin_nan("");   // quarantine until SCAN(it + 1) has finished its row sum
+                Rw[px] = 0.0;                  // diagonal
+            }
+            if (new_slot >= 0) { a.KA[p] = nj_key_a(new_slot, n1); a.KB[p] = nj_key_b(new_slot); }
         }
-        if (new_slot >= 0) { KA[p] = nj_key_a(new_slot, n1); KB[p] = nj_key_b(new_slot); }
+        const double cs = block_tree256_lane0(val, s);
+        if (tid == 0) a.xpart[(int)blockIdx.x - a.ntest] = cs;
+        return;
     }
-    if (clocked) ck[4] = wall_clock64();
-    const double cs = block_tree256_lane0(val, s);
-    if (threadIdx.x == 0) xpart[blockIdx.x] = cs;
-    if (clocked) {
-        __builtin_amdgcn_s_waitcnt(0);
-        ck[5] = wall_clock64();
-        unsigned long long* o = clk + 32;
-        atomicAdd(&o[0], 1ull);
-        if (ck[3] == 0) ck[3] = ck[2];
-        for (int k = 1; k < 6; ++k) atomicAdd(&o[k], ck[k] - ck[k - 1]);
+
+    // ---------------------------------------------------------------------------------- test role
+    const double NINF = -__builtin_inf(), PINF = __builtin_inf();
+    // hop 2: rows x and y over this lane's 16 rows and 2 columns; the row buffer of the node leaving quarantine where
+    // it crosses this block's units; the seed candidates' row sums
+    const bool fold = pz >= 0 && pz != px && pz != py;                       // block-uniform
+    const double* __restrict__ Rz = a.R + ((it + 1) & 1) * a.vstride;        // written by POST(it - 1)
+    const bool pz_strip = fold && pz / kTileCols == cb;                      // block-uniform
+    const int64_t gz = fold ? pz / kUR : -1;
+    const bool gz_here = fold && gz >= (int64_t)a.blk_g0[blockIdx.x] && gz < (int64_t)a.blk_g0[blockIdx.x] + kThreads;   // block-uniform
+    const int wpz = fold ? (int)((pz % kTileCols) / (kTileCols / 4)) : -1;   // sub-strip of that node's column
+    v2d dxr[kUR / 2], dyr[kUR / 2], rzr[kUR / 2];
+#pragma unroll
+    for (int r = 0; r < kUR / 2; ++r) { dxr[r] = *reinterpret_cast<const v2d*>(rowx + a0 + 2 * r); dyr[r] = *reinterpret_cast<const v2d*>(rowy + a0 + 2 * r); }
+    const v2d dxc = *reinterpret_cast<const v2d*>(rowx + pc0), dyc = *reinterpret_cast<const v2d*>(rowy + pc0);
+    if (pz_strip) {
+#pragma unroll
+        for (int r = 0; r < kUR / 2; ++r) rzr[r] = *reinterpret_cast<const v2d*>(Rz + a0 + 2 * r);
+    } else {
+#pragma unroll
+        for (int r = 0; r < kUR / 2; ++r) { rzr[r].x = PINF; rzr[r].y = PINF; }
     }
+    v2d rzc; rzc.x = PINF; rzc.y = PINF;
+    if (gz_here) rzc = *reinterpret_cast<const v2d*>(Rz + pc0);
+    // seed candidates re-evaluated with the row sums after this merge
+    double qc = PINF;
+    if ((int64_t)tid * sstride >= uvalid) candA.key = ~0ull;          // not written by this iteration's scan
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const NjRecord cand = k ? candB : candA;
+        if (cand.key != ~0ull) {
+            const int64_t ci = (int64_t)(cand.pad & 0xffffffffull), cj = (int64_t)(cand.pad >> 32);
+            // the record carries D of the pair; the entry is unchanged by this merge unless one end is x or y
+            if (ci < P && cj < P && ci != px && cj != px && ci != py && cj != py) {
+                const double uia = Uc[ci], uib = Uc[cj];
+                const double xa = rowx[ci], ya = rowy[ci], xb = rowx[cj], yb = rowy[cj];
+                const double ua = nj_unew(uia, xa, ya, nj_val(xa, ya, d)) / r1;
+                const double ub = nj_unew(uib, xb, yb, nj_val(xb, yb, d)) / r1;
+                const double qk = fmin((cand.d - ua) - ub, (cand.d - ub) - ua);
+                qc = qk == qk ? fmin(qc, qk) : qc;
+            }
+        }
+    }
+    double u4[4] = { PINF, PINF, PINF, PINF };
+    double rmax = NINF, newminA = PINF;
+    if (have) {
+        u4[0] = dec_f64(um0.x); u4[1] = dec_f64(um0.y); u4[2] = dec_f64(um1.x); u4[3] = dec_f64(um1.y);
+#pragma unroll
+        for (int r = 0; r < kUR; ++r) {
+            const int64_t pp = a0 + r;
+            const int sl = (r & 3) == 0 ? sprow[r >> 2].x : (r & 3) == 1 ? sprow[r >> 2].y : (r & 3) == 2 ? sprow[r >> 2].z : sprow[r >> 2].w;
+            const double uo = (r & 1) ? urow[r >> 1].y : urow[r >> 1].x;
+            const double dx = (r & 1) ? dxr[r >> 1].y : dxr[r >> 1].x;
+            const double dy = (r & 1) ? dyr[r >> 1].y : dyr[r >> 1].x;
+            const double rz = (r & 1) ? rzr[r >> 1].y : rzr[r >> 1].x;
+            const bool live = (sl >= 0) & (pp != px) & (pp != py);     // the new node (px) is in quarantine during scan it + 1
+            const double un = nj_unew(uo, dx, dy, nj_val(dx, dy, d)) / r1;
+            rmax = live ? fmax(rmax, un) : rmax;
+            newminA = (live & (pp > pz)) ? fmin(newminA, rz) : newminA;
+        }
+    }
+    // column maximum of each sub-strip (wave w holds columns 128w .. 128w+127 of the strip); minimum of the row of the
+    // node leaving quarantine over the sub-strip's live columns
+    double cm_part = NINF, colmin = PINF;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int64_t pp = pc0 + k;
+        const int sl = k ? spcol.y : spcol.x;
+        const double uo = k ? ucol.y : ucol.x;
+        const double dx = k ? dxc.y : dxc.x, dy = k ? dyc.y : dyc.x;
+        const double rz = k ? rzc.y : rzc.x;
+        const bool live = (sl >= 0) & (pp != px) & (pp != py) & (pp < P);
+        const double un = nj_unew(uo, dx, dy, nj_val(dx, dy, d)) / r1;
+        cm_part = live ? fmax(cm_part, un) : cm_part;
+        colmin = (live & (pp < pz)) ? fmin(colmin, rz) : colmin;
+    }
+    qc = wave_fmin(qc);
+    cm_part = wave_fmax(cm_part);
+    if (gz_here) colmin = wave_fmin(colmin);
+    __syncthreads();               // (the select above read sq .. sdd; sseed / scm / snew are separate arrays, but keep the phases apart)
+    if ((tid & 63) == 0) { sseed[tid >> 6] = qc; scm[tid >> 6] = cm_part; snew[tid >> 6] = colmin; }
+    __syncthreads();
+    const double bound = fmin(fmin(sseed[0], sseed[1]), fmin(sseed[2], sseed[3]));
+    const bool own = have && (a.sh_world <= 1 || (int)(((int64_t)cb * G16 + g) % a.sh_world) == a.sh_rank);
+    int submask = 0;
+    if (own) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const double cmw = scm[w];
+            double nm = (gz_here && g == gz) ? snew[w] : PINF;            // the unit (this strip, group of pz)
+            if (pz_strip && w == wpz) nm = fmin(nm, newminA);
+            if (nm < u4[w]) {                          // persist the lowered bound (this lane is the unit's only writer here)
+                u4[w] = nm;
+                up4[w] = enc_f64(nm);
+            }
+            const double lb = fmin((u4[w] - rmax) - cmw, (u4[w] - cmw) - rmax);
+            if ((cmw > NINF) && (lb <= bound)) submask |= 1 << w;
+        }
+    }
+    const bool keep = own && (rmax > NINF) && submask != 0;
+    const unsigned long long mask = __ballot(keep);
+    const int lane = tid & 63;
+    unsigned long long base = 0;
+    if (lane == 0 && mask) base = atomicAdd(&a.cnt[(it + 1) % 3], (unsigned long long)__popcll(mask));
+    base = __shfl(base, 0, 64);
+    if (keep) a.list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)(((uint32_t)submask << 28) | ((uint32_t)cb << 18) | (uint32_t)g);   // sub-unit mask | strip | group
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -608,13 +670,12 @@ static int64_t round_up16(int64_t v) { return (v + 15) / 16 * 16; }
 static int g_njp_grid = 1024;
 int njp_scan_grid() { return g_njp_grid; }
 
-
 // ---- arena -------------------------------------------------------------------------------------------------------
 // Everything the pruned path needs is allocated once per (tips, local ranks) and kept until nj_free: hipMalloc /
 // hipFree of the 7.2 GB matrices (and of ~15 vectors per epoch, 8 epochs per run) serialise with the device and
 // cost more than the distance kernel when a context builds its matrix again (bench.py's steps).
 struct SlabPlan {
-    size_t U, Ur, KA, KB, slot_of_pos, pos_of_slot, perm, umin, list, blk_cb, blk_g0, cnt_all, total;
+    size_t U, R, Ur, KA, KB, slot_of_pos, pos_of_slot, perm, umin, list, blk_cb, blk_g0, cnt_all, total;
     int64_t list_stride;
 };
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -630,21 +691,23 @@ static int64_t prep_blocks(int64_t P, std::vector<int32_t>* hcb, std::vector<int
     if (cnt == 0) { if (hcb) { hcb->push_back(0); hg0->push_back(0); } cnt = 1; }
     return cnt;
 }
+static int64_t vec_len(int64_t N) { return (N + kTileCols + 16 + 31) / 32 * 32; }    // 256-byte multiple per vector
 static SlabPlan slab_plan(int64_t P, int64_t N, int local_ranks)
 {
     SlabPlan p;
-    const size_t vec = (size_t)(N + kTileCols + 16);
+    const size_t vec = (size_t)vec_len(N);
     const int64_t G16 = (P + kUR - 1) / kUR, S = (P + kTileCols - 1) / kTileCols + 1;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
-    p.U = take(vec * 8); p.Ur = take(vec * 8); p.KA = take(vec * 8); p.KB = take(vec * 8);
+    p.U = take(2 * vec * 8); p.R = take(2 * vec * 8);
+    p.Ur = take(vec * 8); p.KA = take(vec * 8); p.KB = take(vec * 8);
     p.slot_of_pos = take(vec * 4); p.pos_of_slot = take(vec * 4); p.perm = take(vec * 4);
     p.umin = take((size_t)(S * G16 * 4) * 8);
     p.list_stride = unit_total(P) + kScanBlocks + 64;
     p.list = take((size_t)(p.list_stride * local_ranks) * 4);
     const size_t nprep = (size_t)prep_blocks(P, nullptr, nullptr);
     p.blk_cb = take(nprep * 4); p.blk_g0 = take(nprep * 4);
-    p.cnt_all = take((size_t)(2 * local_ranks) * 8);
+    p.cnt_all = take((size_t)(4 * local_ranks) * 8);
     p.total = off;
     return p;
 }
@@ -658,7 +721,7 @@ static int njp_arena(NjPruned& q, int64_t N, hipStream_t s)
 {
     const int local_ranks = q.sh_world > 1 && q.sh_virtual ? q.sh_world : 1;
     const SlabPlan plan = slab_plan(N, N, local_ranks);
-    if (q.arena_D && q.arena_N == N && q.arena_slab_bytes >= plan.total) return DPR_OK;
+    if (q.arena_D && q.arena_N == N && q.arena_ranks >= local_ranks && q.arena_slab_bytes >= plan.total) return DPR_OK;
     void* old[] = { q.arena_D, q.arena_slab[0], q.arena_slab[1] };
     for (void* p : old)
         if (p) (void)hipFree(p);
@@ -668,6 +731,7 @@ static int njp_arena(NjPruned& q, int64_t N, hipStream_t s)
     for (int k = 0; k < 2; ++k) DPR_HIP(hipMalloc(&q.arena_slab[k], plan.total));
     q.arena_slab_bytes = plan.total;
     q.arena_N = N;
+    q.arena_ranks = local_ranks;
     return DPR_OK;
 }
 
@@ -684,8 +748,10 @@ static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, char
     const int64_t rows_alloc = (P + kUR - 1) / kUR * kUR + kUR;
     // what the permute kernel does not write: columns [P, ld), the group of rows behind position P, the tail pad
     if (int rc = nj_fill_pads(q.D, q.ld, P, P, rows_alloc, kTileCols + 16, false, s)) return rc;
-    const size_t vec = (size_t)(N + kTileCols + 16);
+    const size_t vec = (size_t)vec_len(N);
+    q.vstride = (int64_t)vec;
     q.U = reinterpret_cast<double*>(slab + plan.U);
+    q.R = reinterpret_cast<double*>(slab + plan.R);
     q.Ur = reinterpret_cast<double*>(slab + plan.Ur);
     q.KA = reinterpret_cast<uint64_t*>(slab + plan.KA);
     q.KB = reinterpret_cast<uint64_t*>(slab + plan.KB);
@@ -697,30 +763,32 @@ static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, char
     q.blk_cb = reinterpret_cast<int32_t*>(slab + plan.blk_cb);
     q.blk_g0 = reinterpret_cast<int32_t*>(slab + plan.blk_g0);
     q.cnt_all = reinterpret_cast<unsigned long long*>(slab + plan.cnt_all);
-    DPR_HIP(hipMemsetAsync(q.U, 0, vec * sizeof(double), s));
+    DPR_HIP(hipMemsetAsync(q.U, 0, 2 * vec * sizeof(double), s));
+    DPR_HIP(hipMemsetAsync(q.R, 0, 2 * vec * sizeof(double), s));
     DPR_HIP(hipMemsetAsync(q.Ur, 0xff, vec * sizeof(double), s));   // NaN beyond P
     DPR_HIP(hipMemsetAsync(q.KA, 0, vec * sizeof(uint64_t), s));
     DPR_HIP(hipMemsetAsync(q.KB, 0, vec * sizeof(uint64_t), s));
-    DPR_HIP(hipMemsetAsync(q.slot_of_pos, 0xff, sizeof(int32_t) * vec, s));
+    DPR_HIP(hipMemsetAsync(q.slot_of_pos, 0xff, sizeof(int32_t) * vec, s));   // -1: dead / padding
     DPR_HIP(hipMemsetAsync(q.pos_of_slot, 0xff, sizeof(int32_t) * vec, s));   // -1: slot not alive
     const int64_t G16 = (P + kUR - 1) / kUR, S = (P + kTileCols - 1) / kTileCols + 1;
     q.nunits_alloc = S * G16 * 4;      // four sub-strip bounds per unit
     q.utot = unit_total(P);
     {
-        // prep blocks: one strip and up to 256 consecutive row groups each (groups >= 32*cb see the strip)
+        // test blocks: one strip and up to 256 consecutive row groups each (groups >= 32*cb see the strip)
         std::vector<int32_t> hcb, hg0;
         q.nprep = (int)prep_blocks(P, &hcb, &hg0);
         DPR_HIP(hipMemcpyAsync(q.blk_cb, hcb.data(), sizeof(int32_t) * hcb.size(), hipMemcpyHostToDevice, s));
         DPR_HIP(hipMemcpyAsync(q.blk_g0, hg0.data(), sizeof(int32_t) * hg0.size(), hipMemcpyHostToDevice, s));
         DPR_HIP(hipStreamSynchronize(s));   // the host vectors go out of scope
     }
-    // unit-sharded mode: one list and one counter pair per rank held here (all of them for virtual ranks)
+    // unit-sharded mode: one list and one counter quadruple per rank held here (all of them for virtual ranks)
     q.list_stride = plan.list_stride;
     DPR_HIP(hipMemsetAsync(q.list, 0, sizeof(int32_t) * (size_t)(q.list_stride * local_ranks), s));
-    DPR_HIP(hipMemsetAsync(q.cnt_all, 0, sizeof(unsigned long long) * (size_t)(2 * local_ranks), s));
+    DPR_HIP(hipMemsetAsync(q.cnt_all, 0, sizeof(unsigned long long) * (size_t)(4 * local_ranks), s));
     hipLaunchKernelGGL(njp_fill_u64_kernel, dim3(256), dim3(256), 0, s, (uint64_t*)q.umin, q.nunits_alloc,
                        enc_f64_host(-__builtin_inf()));
     DPR_HIP(hipGetLastError());
+    q.fresh = true;
     return DPR_OK;
 }
 
@@ -756,11 +824,12 @@ int njp_build(NjBuffers& b, hipStream_t s)
     q.utot0 = q.utot;
     DPR_HIP(hipMemcpyAsync(q.perm, perm.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, s));
     if (std::getenv("DPR_NJ_ITERSTATS")) {
-        DPR_HIP(hipMalloc(&q.iterstats, sizeof(uint64_t) * (size_t)(2 * N + 2 + 64)));      // + phase clocks of the prep kernel
-        DPR_HIP(hipMemsetAsync(q.iterstats, 0, sizeof(uint64_t) * (size_t)(2 * N + 2 + 64), s));
+        DPR_HIP(hipMalloc(&q.iterstats, sizeof(uint64_t) * (size_t)(2 * N + 2)));
+        DPR_HIP(hipMemsetAsync(q.iterstats, 0, sizeof(uint64_t) * (size_t)(2 * N + 2), s));
     }
     dim3 grid((unsigned)((N + kThreads - 1) / kThreads > 64 ? 64 : (N + kThreads - 1) / kThreads), (unsigned)(N < 32768 ? N : 32768));
     hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, b.D, b.ld, q.D, q.ld, q.perm, N);
+    // (iteration 0 reads U buffer 0)
     hipLaunchKernelGGL(njp_init_vectors_kernel, dim3((unsigned)((N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                        b.U, q.perm, (const int32_t*)nullptr, N, N, q.U, q.Ur, q.KA, q.KB, q.slot_of_pos, q.pos_of_slot);
     DPR_HIP(hipGetLastError());
@@ -774,7 +843,8 @@ int njp_build(NjBuffers& b, hipStream_t s)
 // position space.  Merges put new nodes into the positions of merged ones, so the order by row sum -- which
 // is what keeps the unit bounds tight -- decays, and dead positions still occupy scanned units; late in a
 // run most units were scanned every iteration.  Costs one n^2 copy; the first scan of the epoch is a full
-// one (bounds start at -inf, no seed).  Called between iterations with the stream idle.
+// one (bounds start at -inf, no seed).  Called between iterations with the stream idle and the node in
+// quarantine materialised (njp_finish_kernel).
 // *rebuilt = false: nothing was done (no candidate left, or fewer than three active nodes).
 static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s, bool* rebuilt)
 {
@@ -784,18 +854,17 @@ static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s, bool* rebuilt)
     DPR_HIP(hipMemcpy(&st, b.st, sizeof(NjState), hipMemcpyDeviceToHost));
     const int64_t n = st.n, Pold = q.P;
     if (st.status != 0 || n < 3) return DPR_OK;
-    std::vector<double> hU((size_t)Pold), hUr((size_t)Pold);
-    DPR_HIP(hipMemcpy(hU.data(), q.U, sizeof(double) * (size_t)Pold, hipMemcpyDeviceToHost));
-    DPR_HIP(hipMemcpy(hUr.data(), q.Ur, sizeof(double) * (size_t)Pold, hipMemcpyDeviceToHost));
+    std::vector<double> hU((size_t)Pold);
+    std::vector<int32_t> hslot((size_t)Pold);
+    const double* Ucur = q.U + (st.it & 1) * q.vstride;
+    DPR_HIP(hipMemcpy(hU.data(), Ucur, sizeof(double) * (size_t)Pold, hipMemcpyDeviceToHost));
+    DPR_HIP(hipMemcpy(hslot.data(), q.slot_of_pos, sizeof(int32_t) * (size_t)Pold, hipMemcpyDeviceToHost));
     std::vector<int32_t> perm;
     perm.reserve((size_t)n);
     for (int64_t p = 0; p < Pold; ++p)
-        if (hUr[(size_t)p] == hUr[(size_t)p]) perm.push_back((int32_t)p);      // dead positions carry NaN
+        if (hslot[(size_t)p] >= 0) perm.push_back((int32_t)p);      // (Ur does not tell: the node in quarantine carries NaN there)
     if ((int64_t)perm.size() != n) { set_error("njp_rebuild_epoch: live positions do not match the active size"); return DPR_ERR_STATE; }
     sort_by_row_sum(perm, hU);
-    int32_t new_px = -1;
-    for (int64_t a = 0; a < n; ++a)
-        if (perm[(size_t)a] == st.pad) new_px = (int32_t)a;
     if (q.graph) { (void)hipGraphExecDestroy(q.graph); q.graph = nullptr; }
     const NjPruned old = q;              // the old epoch's pointers (read by the permute / init kernels below)
     const int e = old.epoch_index + 1;
@@ -805,19 +874,14 @@ static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s, bool* rebuilt)
     dim3 grid((unsigned)((n + kThreads - 1) / kThreads > 64 ? 64 : (n + kThreads - 1) / kThreads), (unsigned)(n < 32768 ? n : 32768));
     hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, old.D, old.ld, q.D, q.ld, q.perm, n);
     hipLaunchKernelGGL(njp_init_vectors_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
-                       old.U, q.perm, (const int32_t*)old.slot_of_pos, n, n, q.U, q.Ur, q.KA, q.KB, q.slot_of_pos, q.pos_of_slot);
+                       Ucur, q.perm, (const int32_t*)old.slot_of_pos, n, n, q.U + (st.it & 1) * q.vstride, q.Ur, q.KA, q.KB,
+                       q.slot_of_pos, q.pos_of_slot);
     DPR_HIP(hipGetLastError());
-    // iteration state: position of the last new node in the new space; no seed records, empty lists
-    st.pad = new_px;
-    st.cnt_list[0] = 0ull; st.cnt_list[1] = 0ull;
+    // iteration state: nothing in quarantine (every row sum is in memory), empty lists
+    st.pnew[0] = -1; st.pnew[1] = -1;
+    for (auto& c : st.cnt_list) c = 0ull;
     DPR_HIP(hipMemcpyAsync(b.st, &st, sizeof(NjState), hipMemcpyHostToDevice, s));
-    if (q.sh_world > 1) {   // gathered records refer to old positions: make them null (key = ~0)
-        std::vector<NjRecord> nul((size_t)kScanBlocks);
-        for (auto& r : nul) { r.q = 10000.0; r.key = ~0ull; r.d = 0.0; r.pad = 0ull; }
-        DPR_HIP(hipMemcpyAsync(b.partials, nul.data(), sizeof(NjRecord) * nul.size(), hipMemcpyHostToDevice, s));
-        DPR_HIP(hipStreamSynchronize(s));
-    }
-    DPR_HIP(hipStreamSynchronize(s));
+    DPR_HIP(hipStreamSynchronize(s));    // `st`, `perm` are host objects
     *rebuilt = true;
     return DPR_OK;
 }
@@ -829,7 +893,7 @@ void njp_reset(NjPruned& q)
     if (q.iterstats) { (void)hipFree(q.iterstats); q.iterstats = nullptr; }
     NjPruned fresh;
     fresh.arena_D = q.arena_D; fresh.arena_slab[0] = q.arena_slab[0]; fresh.arena_slab[1] = q.arena_slab[1];
-    fresh.arena_slab_bytes = q.arena_slab_bytes; fresh.arena_N = q.arena_N;
+    fresh.arena_slab_bytes = q.arena_slab_bytes; fresh.arena_N = q.arena_N; fresh.arena_ranks = q.arena_ranks;
     q = fresh;
 }
 
@@ -842,40 +906,59 @@ void njp_free(NjPruned& q)
     q = NjPruned();
 }
 
-// unit-sharded mode: records per rank and in total
+// unit-sharded mode: unit-scan blocks per rank and unit records in total
 static int njp_grid_rank(const NjPruned& q) { return q.sh_world > 1 ? (g_njp_grid / q.sh_world > 0 ? g_njp_grid / q.sh_world : 1) : g_njp_grid; }
 static int njp_grid_total(const NjPruned& q) { return q.sh_world > 1 ? njp_grid_rank(q) * q.sh_world : g_njp_grid; }
 
-// prep of rank v (its own units, list and counters); v is ignored outside the unit-sharded mode
-static int njp_launch_prep(NjBuffers& b, hipStream_t s, int v = 0)
+// kernel arguments of rank v (its own list and counters; v is ignored outside the unit-sharded mode)
+static NjpArgs njp_args(NjBuffers& b, int v)
 {
     NjPruned& q = b.pr;
     const bool sh = q.sh_world > 1;
     const int slot = sh && q.sh_virtual ? v : 0;             // local storage index of this rank
-    hipLaunchKernelGGL(njp_prep_kernel, dim3((unsigned)q.nprep), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.U, q.Ur, q.Ur,
-                       b.xpart, b.partials, (unsigned long long*)q.umin, q.P, q.blk_cb, q.blk_g0, njp_grid_total(q),
-                       q.list + (int64_t)slot * q.list_stride, sh ? v : 0, sh ? q.sh_world : 1,
-                       sh ? q.cnt_all + 2 * slot : (unsigned long long*)nullptr, sh ? njp_grid_total(q) : -1,
-                       q.iterstats ? (unsigned long long*)q.iterstats + 2 * b.N + 2 : (unsigned long long*)nullptr);
-    DPR_HIP(hipGetLastError());
-    return DPR_OK;
+    NjpArgs a;
+    a.D = q.D; a.ld = q.ld; a.st = b.st;
+    a.U = q.U; a.R = q.R; a.vstride = q.vstride;
+    a.Ur = q.Ur; a.KA = q.KA; a.KB = q.KB; a.slot_of_pos = q.slot_of_pos; a.pos_of_slot = q.pos_of_slot;
+    a.xpart = b.xpart; a.partials = b.partials; a.umin = (unsigned long long*)q.umin;
+    a.P = q.P;
+    a.blk_cb = q.blk_cb; a.blk_g0 = q.blk_g0; a.ntest = q.nprep;
+    a.list = q.list + (int64_t)slot * q.list_stride;
+    a.cnt = sh ? q.cnt_all + 4 * slot : b.st->cnt_list;
+    a.ugrid = njp_grid_rank(q);
+    a.urecs = njp_grid_total(q);
+    a.nrb = (int)((q.P + kTileCols - 1) / kTileCols);
+    a.rec_off = sh ? v * a.ugrid : 0;
+    a.all_defined = sh ? 1 : 0;
+    a.sh_rank = sh ? v : 0; a.sh_world = sh ? q.sh_world : 1;
+    a.cnt_all = sh ? q.cnt_all : nullptr;
+    a.cnt_ranks = sh ? (q.sh_virtual ? q.sh_world : 1) : 0;
+    a.do_update = 1; a.do_tests = 1; a.do_rows = 1;
+    a.log_x = b.log_x; a.log_y = b.log_y; a.log_bx = b.log_bx; a.log_by = b.log_by;
+    a.iterstats = (unsigned long long*)q.iterstats;
+    return a;
 }
 
-static int njp_launch_post(NjBuffers& b, hipStream_t s)
+static int njp_launch_scan(NjBuffers& b, hipStream_t s, int v, bool rows)
 {
-    NjPruned& q = b.pr;
-    const bool sh = q.sh_world > 1;
-    const unsigned pgrid = (unsigned)((b.N + kThreads - 1) / kThreads);
-    hipLaunchKernelGGL(njp_post_kernel, dim3(pgrid), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.U, q.Ur, q.KA, q.KB,
-                       q.slot_of_pos, q.pos_of_slot, b.xpart, b.partials, njp_grid_total(q), q.P,
-                       b.log_x, b.log_y, b.log_bx, b.log_by, sh ? njp_grid_total(q) : -1,
-                       sh ? q.cnt_all : (unsigned long long*)nullptr, sh ? (q.sh_virtual ? q.sh_world : 1) : 0,
-                       q.iterstats ? (unsigned long long*)q.iterstats + 2 * b.N + 2 : (unsigned long long*)nullptr);
+    NjpArgs a = njp_args(b, v);
+    a.do_rows = rows ? 1 : 0;
+    hipLaunchKernelGGL(njp_scan_kernel, dim3((unsigned)(a.ugrid + (rows ? a.nrb : 0))), dim3(kThreads), 0, s, a);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
 
-// one iteration: scan -> post -> prep(next); every kernel reads its iteration index from the device state.
+static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
+{
+    NjpArgs a = njp_args(b, v);
+    a.do_update = update ? 1 : 0;
+    const unsigned ublocks = update ? (unsigned)((b.N + kThreads - 1) / kThreads) : 0u;
+    hipLaunchKernelGGL(njp_post_kernel, dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+// one iteration: SCAN -> POST; every kernel reads its iteration index from the device state.
 // sample: bracket the launches by HIP events (NjKernelTiming; eager runs only)
 static int njp_enqueue_iteration(NjBuffers& b, hipStream_t s, bool sample = false)
 {
@@ -889,44 +972,37 @@ static int njp_enqueue_iteration(NjBuffers& b, hipStream_t s, bool sample = fals
             DPR_HIP(hipEventRecord(e, s));
             return DPR_OK;
         };
-        if (sample) b.kt->nk = 3;
+        if (sample) b.kt->nk = 3;      // the third interval holds nothing: what an event pair itself costs
         if (int rc = mark()) return rc;
-        hipLaunchKernelGGL(njp_scan_kernel, dim3(g_njp_grid), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.Ur, q.KA, q.KB,
-                           (unsigned long long*)q.umin, q.P, q.list, b.partials, (unsigned long long*)q.iterstats,
-                           (const unsigned long long*)nullptr, 0);
+        if (int rc = njp_launch_scan(b, s, 0, true)) return rc;
         if (int rc = mark()) return rc;
-        if (int rc = njp_launch_post(b, s)) return rc;
+        if (int rc = njp_launch_post(b, s, 0, true)) return rc;
         if (int rc = mark()) return rc;
-        if (int rc = njp_launch_prep(b, s)) return rc;
         return mark();
     }
     // Unit-sharded mode (every rank holds the whole position-space matrix): a unit belongs to rank
     // (strip * G16 + group) mod world for good.  Each rank tests and scans only its own units -- a unit that
     // holds the winner always survives its owner's test, whatever the other ranks' bounds are -- so the unit
-    // bounds stay private to their owner and ONE small all-gather per iteration (the block records) is the
-    // only exchange; select + merge + update run replicated.
+    // bounds stay private to their owner and ONE small all-gather per iteration (the unit records) is the
+    // only exchange; the new-row blocks, select + merge + update run replicated.
     const int gr = njp_grid_rank(q);
     const int v0 = q.sh_virtual ? 0 : q.sh_rank, v1 = q.sh_virtual ? q.sh_world : q.sh_rank + 1;
-    for (int v = v0; v < v1; ++v) {
-        const int slot = q.sh_virtual ? v : 0;
-        hipLaunchKernelGGL(njp_scan_kernel, dim3((unsigned)gr), dim3(kThreads), 0, s, q.D, q.ld, b.st, q.Ur, q.KA, q.KB,
-                           (unsigned long long*)q.umin, q.P, q.list + (int64_t)slot * q.list_stride, b.partials + (int64_t)v * gr,
-                           (unsigned long long*)q.iterstats, (const unsigned long long*)(q.cnt_all + 2 * slot), 1);
-    }
-    DPR_HIP(hipGetLastError());
+    for (int v = v0; v < v1; ++v)
+        if (int rc = njp_launch_scan(b, s, v, v == v0)) return rc;
     if (!q.sh_virtual) {
         if (!q.gather) { set_error("njp: unit-sharded mode without a gather callback"); return DPR_ERR_STATE; }
         if (int rc = q.gather(q.gather_ctx, b.partials, sizeof(NjRecord) * (size_t)gr, s)) return rc;
     }
-    if (int rc = njp_launch_post(b, s)) return rc;
+    // (virtual ranks: the update runs once, with the first rank's tests; the other ranks' tests follow in launches of
+    // their own -- they read only what the update leaves alone: the current U buffer, rows x and y, the scan records)
     for (int v = v0; v < v1; ++v)
-        if (int rc = njp_launch_prep(b, s, v)) return rc;
+        if (int rc = njp_launch_post(b, s, v, v == v0)) return rc;
     return DPR_OK;
 }
 
-// enqueue `todo` iterations starting at iteration it0.  The four kernels of an iteration take no
-// per-iteration arguments, so kGraphIters iterations are captured once into a hipGraph and replayed;
-// iterations beyond it_limit are no-ops.
+// enqueue `todo` iterations starting at iteration it0.  The kernels of an iteration take no per-iteration
+// arguments, so kGraphIters iterations are captured once into a hipGraph and replayed; iterations beyond
+// it_limit are no-ops.  Afterwards the node in quarantine is materialised (row sum, matrix row).
 constexpr int kGraphIters = 32;
 
 static int njp_run_segment(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
@@ -936,11 +1012,15 @@ static int njp_run_segment(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t 
     DPR_HIP(hipMemcpyAsync(&b.st->it_limit, &limit, sizeof(int64_t), hipMemcpyHostToDevice, s));
     DPR_HIP(hipStreamSynchronize(s));   // `limit` is a stack variable
     if (todo <= 0) return DPR_OK;
-    {   // list + bound for iteration it0
-        const int v0 = q.sh_world > 1 && !q.sh_virtual ? q.sh_rank : 0;
-        const int v1 = q.sh_world > 1 ? (q.sh_virtual ? q.sh_world : q.sh_rank + 1) : 1;
-        for (int v = v0; v < v1; ++v)
-            if (int rc = njp_launch_prep(b, s, v)) return rc;
+    const int v0 = q.sh_world > 1 && !q.sh_virtual ? q.sh_rank : 0;
+    const int v1 = q.sh_world > 1 ? (q.sh_virtual ? q.sh_world : q.sh_rank + 1) : 1;
+    if (q.fresh) {      // first scan of an epoch: every unit
+        for (int v = v0; v < v1; ++v) {
+            NjpArgs a = njp_args(b, v);
+            hipLaunchKernelGGL(njp_list_all_kernel, dim3((unsigned)a.ntest), dim3(kThreads), 0, s, a);
+        }
+        DPR_HIP(hipGetLastError());
+        q.fresh = false;
     }
     const bool timing = b.kt && b.kt->stride > 0 && q.sh_world <= 1;
     const bool use_graph = q.sh_world <= 1 && todo >= kGraphIters && !timing && !std::getenv("DPR_NJ_NOGRAPH");
@@ -964,23 +1044,31 @@ static int njp_run_segment(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t 
         for (; done + kGraphIters <= todo; done += kGraphIters) DPR_HIP(hipGraphLaunch(q.graph, s));
     for (; done < todo; ++done)
         if (int rc = njp_enqueue_iteration(b, s, timing && (it0 + done) % b.kt->stride == 0)) return rc;
+    {
+        NjpArgs a = njp_args(b, v0);
+        hipLaunchKernelGGL(njp_finish_kernel, dim3((unsigned)a.nrb), dim3(kThreads), 0, s, a);
+        DPR_HIP(hipGetLastError());
+    }
     return DPR_OK;
 }
 
 const char* njp_kernel_name(int idx)
 {
-    static const char* names[] = { "njp_scan_kernel", "njp_post_kernel", "njp_prep_kernel" };
+    static const char* names[] = { "njp_scan_kernel", "njp_post_kernel", "(empty event pair)" };
     return idx >= 0 && idx < 3 ? names[idx] : "";
 }
 
+// current U buffer of the pruned path (row sums by position) after `it` iterations
+const double* njp_current_u(const NjPruned& q, int64_t it) { return q.U + (it & 1) * q.vstride; }
+
 // enqueue `todo` iterations starting at iteration it0, in epochs: whenever the active size has dropped to
-// half of the epoch's positions (and the epoch is large enough to matter) the position space is rebuilt
+// pct % of the epoch's positions (and the epoch is large enough to matter) the position space is rebuilt
 int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
 {
     const char* e_min = std::getenv("DPR_NJ_EPOCH_MIN");
     const int64_t epoch_min = e_min ? std::atoll(e_min) : 2048;   // epochs smaller than this are not rebuilt
     const char* e_pct = std::getenv("DPR_NJ_EPOCH_PCT");
-    const int64_t pct = e_pct ? std::atoll(e_pct) : 80;           // rebuild once n <= pct% of the epoch's positions (sweep: profiles/epoch_sweep2.sh)
+    const int64_t pct = e_pct ? std::atoll(e_pct) : 80;           // rebuild once n <= pct% of the epoch's positions
     int64_t it = it0, left = todo;
     if (left <= 0) return njp_run_segment(b, it0, 0, s);
     while (left > 0) {
