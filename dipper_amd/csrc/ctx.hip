@@ -528,6 +528,25 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
     return DPR_OK;
 }
 
+// Allocate the N x N matrix buffers of a following dpr_dist_matrix(n tips) now (single-rank contexts; a no-op
+// otherwise): dpr_dist_matrix finds them in place.  The CLI calls it from its device thread as soon as the number of
+// input sequences is known, while the host threads are still packing them.
+int dpr_reserve_nj(dpr_ctx* c, int64_t n)
+{
+    if (!c || n < 2 || n >= (1 << 24)) { set_error("dpr_reserve_nj: bad argument"); return DPR_ERR_ARG; }
+    if (c->world != 1 || c->vworld > 0) return DPR_OK;
+    DPR_HIP(hipSetDevice(c->device));
+    c->have_matrix = 0;
+    if (int rc = nj_alloc(c->nj[0], n, 0, 1, c->stream)) return rc;
+    if (want_pruned(c) && n >= 3) {
+        NjPruned& q = c->nj[0].pr;
+        if (ctx_vshards(c) > 1) { q.sh_world = ctx_vshards(c); q.sh_rank = 0; q.sh_virtual = true; }
+        if (int rc = njp_reserve(q, n, c->stream)) return rc;
+    }
+    DPR_HIP(hipStreamSynchronize(c->stream));
+    return DPR_OK;
+}
+
 // ---- NJ -------------------------------------------------------------------------------------------------
 static int fetch_state(dpr_ctx* c, NjState* st)
 {
@@ -697,6 +716,7 @@ int dpr_get_nj_kernel_timing(dpr_ctx* c, int* kernels, double* us_avg, int64_t* 
     return DPR_OK;
 }
 const char* dpr_nj_kernel_name(int idx) { return njp_kernel_name(idx); }
+int dpr_get_nj_phase_stamps(uint64_t* out) { return njp_phase_stamps((unsigned long long*)out); }
 
 int dpr_ctx_set_nj_virtual_shards(dpr_ctx* c, int w)
 {

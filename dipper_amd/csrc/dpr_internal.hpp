@@ -186,11 +186,13 @@ int nj_launch_finish(NjBuffers& b, int64_t n, int64_t it, hipStream_t s);       
 // njp.hip: exact pruned NJ (world == 1)
 int njp_build(NjBuffers& b, hipStream_t s);   // permute the tip-order matrix by ascending row sum into the pruned path's own buffer
 void njp_free(NjPruned& q);                   // everything, the arena included
+int njp_reserve(NjPruned& q, int64_t N, hipStream_t s);   // allocate the arena for N tips ahead of njp_build
 void njp_reset(NjPruned& q);                  // epoch state only (graph, pointers); the arena stays for the next build
 int njp_scan_grid();
 int njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world);
 int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s);   // enqueue `todo` iterations (hipGraph replays)
 const char* njp_kernel_name(int idx);   // kernels of one iteration, in launch order
+int njp_phase_stamps(unsigned long long* out);   // debug (DPR_NJ_PHASES)
 const double* njp_current_u(const NjPruned& q, int64_t it);   // row sums by position after `it` iterations
 
 // Divide-and-conquer cluster distances (dc.hip builds the jobs; msa.hip / mash.hip run them).

@@ -139,7 +139,18 @@ struct NjpArgs {
     int do_update, do_tests, do_rows;
     int32_t* log_x; int32_t* log_y; double* log_bx; double* log_by;
     unsigned long long* iterstats;
+    int flags;        // experiments (DPR_NJP_FLAGS): 1 = column of the new node stored with plain stores instead of write-through (sc1)
+    unsigned long long* dbg; int64_t dbg_it;     // DPR_NJ_PHASES=<iteration>: per-block phase stamps of that iteration (profiles/nj_phases.py)
 };
+
+// phase stamps (debug; 100 MHz wall clock): thread 0 of every block, kernel k (0 scan, 1 post), slot j
+#define NJP_STAMP(k, j, drain)                                                                             \
+    do {                                                                                                   \
+        if (a.dbg != nullptr && it == a.dbg_it && threadIdx.x == 0) {                                      \
+            if (drain) __builtin_amdgcn_s_waitcnt(0);                                                      \
+            a.dbg[((k) * 2048 + (int)blockIdx.x) * 8 + (j)] = wall_clock64();                              \
+        }                                                                                                  \
+    } while (0)
 
 // the reference's update arithmetic (src/neighborJoining.cu:171-176), one place for the update role and for the
 // test role that needs the same row sums before they are stored
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(kThreads) void njp_list_all_kernel(NjpArgs a)
 // lane-level best carries the positions of the pair and its distance, so nothing is looked up after the
 // reduction.  The node in quarantine has a NaN row sum: the unit scans skip its row and column (and the
 // exact sub-unit minima they store leave it out).
-// Blocks [ugrid, ugrid + nrb): the NEW ROW.  They finish the row sum U[x] of the node created by the
+// Blocks [0, nrb): the NEW ROW.  They finish the row sum U[x] of the node created by the
 // previous merge from the chunk partials (canonical order), evaluate its pairs against every live
 // position from the row buffer, and move the buffered row into the matrix (nobody reads that row validly
 // during this launch); the first of them stores U[x].
@@ -194,12 +205,17 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjpArgs a)
     const int tid = threadIdx.x;
     // hop 1: state line and (speculatively) this block's first list entry / chunk partial
     const int64_t it = a.st->it, limit = a.st->it_limit, N = a.st->N;
-    const bool unit_block = (int)blockIdx.x < a.ugrid;
-    const int32_t first = unit_block ? a.list[blockIdx.x] : 0;
+    // (the new-row blocks come FIRST in the grid: a 1000-block grid takes ~1.5 us to start, and their chain -- chunk
+    // partials, canonical tree, division, candidates -- is the longer one)
+    const int nrl = a.do_rows ? a.nrb : 0;
+    const bool unit_block = (int)blockIdx.x >= nrl;
+    const int ub = (int)blockIdx.x - nrl;                        // unit block index
+    const int32_t first = unit_block ? a.list[ub] : 0;
     const double xp0 = unit_block ? 0.0 : a.xpart[tid];          // (the array is padded to a multiple of 256 entries)
     const int64_t pz = (int64_t)a.st->pnew[it & 1];
     if (blockIdx.x == 0 && tid == 0) a.st->itb = it;             // the post kernel's iteration index (it advances `it` itself); also beyond the limit
     if (it >= limit || a.st->status != 0) return;
+    NJP_STAMP(0, 0, true);
     const int64_t P = a.P;
     double bq = 10000.0, bd = 0.0;  // the reference's init value
     uint64_t bk = ~0ull, bp = 0;
@@ -207,9 +223,9 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjpArgs a)
 
     if (!unit_block) {
         // ---------------------------------------------------------------- new-row block
-        const int r = (int)blockIdx.x - a.ugrid;
+        const int r = (int)blockIdx.x;
         rec_out = a.partials + a.urecs + r;
-        if (pz < 0 || !a.do_rows) {
+        if (pz < 0) {
             if (tid == 0) { NjRecord rec; rec.q = 10000.0; rec.key = ~0ull; rec.d = 0.0; rec.pad = 0ull; *rec_out = rec; }
             return;
         }
@@ -224,10 +240,12 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjpArgs a)
         const v2d uv = *reinterpret_cast<const v2d*>(a.Ur + j0);
         const ulonglong2 kav = *reinterpret_cast<const ulonglong2*>(a.KA + j0), kbv = *reinterpret_cast<const ulonglong2*>(a.KB + j0);
         const uint64_t kax = a.KA[pz], kbx = a.KB[pz];
+        NJP_STAMP(0, 1, true);
         double ux = block_tree256_lane0(acc, stree);
         if (tid == 0) stree[0] = ux;
         __syncthreads();
         ux = stree[0];
+        NJP_STAMP(0, 2, false);
         const double urx = ux / (double)(n - 2);
         if (r == 0 && tid == 0) a.U[(it & 1) * a.vstride + pz] = ux;
         if (j0 < P) *reinterpret_cast<v2d*>(a.D + pz * a.ld + j0) = dv;        // (R[pz] = 0: the diagonal stays 0)
@@ -242,9 +260,9 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjpArgs a)
         wave_best4(bq, bk, bp, bd);
     } else {
         // ---------------------------------------------------------------- unit block
-        rec_out = a.partials + a.rec_off + blockIdx.x;
+        rec_out = a.partials + a.rec_off + ub;
         const int64_t cnt = (int64_t)a.cnt[it % 3];
-        if ((int64_t)blockIdx.x >= cnt) {
+        if ((int64_t)ub >= cnt) {
             if (a.all_defined && tid == 0) {      // unit-sharded mode: every record of the gathered array is defined
                 NjRecord rec; rec.q = 10000.0; rec.key = ~0ull; rec.d = 0.0; rec.pad = 0ull;
                 *rec_out = rec;
@@ -259,8 +277,8 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjpArgs a)
         // bq is wave-uniform; (bk, bp, bd) is this lane's best candidate AT q == bq (bk == ~0: none).
         int64_t scanned = 0;
         const int wv = tid >> 6;                         // this wave's sub-strip of every unit
-        for (int64_t e = blockIdx.x; e < cnt; e += a.ugrid, ++scanned) {
-            const uint32_t code = (uint32_t)__builtin_amdgcn_readfirstlane(e == (int64_t)blockIdx.x ? first : a.list[e]);
+        for (int64_t e = ub; e < cnt; e += a.ugrid, ++scanned) {
+            const uint32_t code = (uint32_t)__builtin_amdgcn_readfirstlane(e == (int64_t)ub ? first : a.list[e]);
             if (!((code >> (28 + wv)) & 1u)) continue;   // the bound of this wave's sub-unit rules it out (wave-uniform)
             const int cb = (int)((code >> 18) & 1023u);
             const int64_t g_s = (int64_t)(code & 0x3FFFFu);
@@ -286,6 +304,7 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjpArgs a)
             double ua[kUR];
 #pragma unroll
             for (int u8 = 0; u8 < kUR; ++u8) ua[u8] = readlane_f64(ua_l, u8);
+            NJP_STAMP(0, 1, true);
             if (diag) {   // block-uniform and rare (units on the diagonal): mask the entries with column >= row
                 const int ib0 = (int)b0, ia0 = (int)a0;
 #pragma unroll
@@ -315,11 +334,14 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjpArgs a)
             }
             double m = fmin(fmin(live0 ? m0 : __builtin_nan(""), live1 ? m1 : __builtin_nan("")), __builtin_inf());   // +inf: no live pair
             const double wm = wave_fmin(lm);          // +inf when the wave saw no valid candidate
+            NJP_STAMP(0, 2, false);
             if (wm <= bq) {                           // wave-uniform; the q are recomputed (same operations, same bits)
                 if (wm < bq) { bq = wm; bk = ~0ull; }   // rather than kept: 128 registers less, twice the blocks per CU
+                if (a.dbg != nullptr && it == a.dbg_it && (tid & 63) == 0) atomicAdd(&a.dbg[(int)blockIdx.x * 8 + 6], 1ull);
 #pragma unroll
                 for (int u8 = 0; u8 < kUR; ++u8) {
                     if (__builtin_amdgcn_ballot_w64(rowq[u8] == wm) != 0ull) {      // rare; the four q are recomputed (same bits)
+                        if (a.dbg != nullptr && it == a.dbg_it && (tid & 63) == 0) atomicAdd(&a.dbg[(int)blockIdx.x * 8 + 5], 1ull);
                         double d0 = v[u8].x, d1 = v[u8].y;
                         asm volatile("" : "+v"(d0), "+v"(d1));    // opaque: keeps the compiler from holding pass 1's 64 q alive
                         const bool e0 = (d0 - ua[u8]) - ub0 == wm, e1 = (d0 - ub0) - ua[u8] == wm;
@@ -334,6 +356,7 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjpArgs a)
                     }
                 }
             }
+            NJP_STAMP(0, 7, false);
             // exact minimum of this wave's sub-unit -> its bound (no cross-wave step)
             m = wave_fmin(m);
             if ((tid & 63) == 0) a.umin[((int64_t)cb * G16 + g_s) * 4 + wv] = enc_f64(m);
@@ -351,9 +374,10 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjpArgs a)
         }
         if (tid == 0) {
             if (a.iterstats) { atomicAdd(&a.iterstats[2 * it], (unsigned long long)scanned); atomicMax(&a.iterstats[2 * it + 1], (unsigned long long)scanned); }
-            if (blockIdx.x == 0) atomicAdd(&a.st->units_scanned, (unsigned long long)cnt);   // statistics
+            if (ub == 0) atomicAdd(&a.st->units_scanned, (unsigned long long)cnt);   // statistics
         }
     }
+    NJP_STAMP(0, 3, false);
     if ((tid & 63) == 0) { sq[tid >> 6] = bq; sk[tid >> 6] = bk; sp[tid >> 6] = bp; sd[tid >> 6] = bd; }
     __syncthreads();
     if (tid == 0) {
@@ -363,6 +387,7 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjpArgs a)
         rec.q = bq; rec.key = bk; rec.d = bd; rec.pad = bp;   // pad = pos_i | pos_j << 32
         *rec_out = rec;
     }
+    NJP_STAMP(0, 4, true);
 }
 
 // after the last enqueued iteration: what the next scan's new-row blocks would materialise (row sum of the node in
@@ -415,9 +440,10 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
     const int64_t pz = (int64_t)a.st->pnew[it & 1];        // node leaving quarantine (its U was stored by SCAN(it))
     const int nrec_all = a.urecs + a.nrb;
     NjRecord r0; r0.q = 10000.0; r0.key = ~0ull; r0.d = 0; r0.pad = 0;
-    NjRecord mine[4] = { r0, r0, r0, r0 };
+    constexpr int kMine = 5;           // records per thread loaded up front (1280: the default 1024 unit records + 256 new-row records)
+    NjRecord mine[kMine] = { r0, r0, r0, r0, r0 };
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kMine; ++k) {
         const int idx = tid + k * kThreads;
         if (idx < nrec_all) mine[k] = a.partials[idx];
     }
@@ -435,17 +461,18 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
     double* __restrict__ Un = a.U + ((it + 1) & 1) * a.vstride;
     const int64_t P = a.P;
     const int64_t G16 = (P + kUR - 1) / kUR;
+    const int64_t pclamp = (P + 1) & ~(int64_t)1;     // an even index behind the last position (16-byte aligned pair loads)
     // update role
     const int64_t i = (int64_t)((int)blockIdx.x - a.ntest) * kThreads + tid;     // reference slot
     int64_t p = -1;
     double up = 0.0;
-    // test role
+    // test role: the block's 256 row groups are 4096 consecutive positions, read COALESCED in 8 chunks of 512 (thread t:
+    // positions rbase + 512 c + 2 t, + 1) -- one lane per group with 16 consecutive values each would touch 64 lines per
+    // wave instruction and push 8 x the bytes through L1
     int cb = 0;
-    int64_t g = 0, a0 = 0, pc0 = 0;
+    int64_t g = 0, rbase = 0, pc0 = 0;
     bool have = false;
-    int4 sprow[kUR / 4];
-    v2d urow[kUR / 2];
-    int2 spcol = make_int2(-1, -1);
+    v2d urow[8];
     v2d ucol; ucol.x = 0.0; ucol.y = 0.0;
     ulonglong2 um0 = make_ulonglong2(0ull, 0ull), um1 = um0;
     unsigned long long* up4 = a.umin;
@@ -453,21 +480,21 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
         cb = a.blk_cb[blockIdx.x];
         g = (int64_t)a.blk_g0[blockIdx.x] + tid;
         have = g < G16;
-        a0 = (have ? g : 0) * kUR;                                    // 128-byte aligned
+        rbase = (int64_t)a.blk_g0[blockIdx.x] * kUR;
         pc0 = (int64_t)cb * kTileCols + 2 * tid;                      // this thread's two strip columns (< P + 512)
         up4 = a.umin + ((int64_t)cb * G16 + (have ? g : 0)) * 4;
         if (have) { um0 = *reinterpret_cast<const ulonglong2*>(up4); um1 = *reinterpret_cast<const ulonglong2*>(up4 + 2); }
 #pragma unroll
-        for (int r = 0; r < kUR / 4; ++r) sprow[r] = *reinterpret_cast<const int4*>(a.slot_of_pos + a0 + 4 * r);
-#pragma unroll
-        for (int r = 0; r < kUR / 2; ++r) urow[r] = *reinterpret_cast<const v2d*>(Uc + a0 + 2 * r);
-        spcol = *reinterpret_cast<const int2*>(a.slot_of_pos + pc0);
+        for (int c = 0; c < 8; ++c) {
+            const int64_t pp = rbase + c * kTileCols + 2 * tid;
+            urow[c] = *reinterpret_cast<const v2d*>(Uc + (pp < P ? pp : pclamp));      // behind P: padding (NaN = dead)
+        }
         ucol = *reinterpret_cast<const v2d*>(Uc + pc0);
     } else {
         p = (int64_t)a.pos_of_slot[i];                 // (the slot arrays are padded past N)
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kMine; ++k) {
         const int idx = tid + k * kThreads;
         if (idx >= uvalid && idx < a.urecs) mine[k] = r0;   // not written by this iteration's scan
     }
@@ -477,12 +504,14 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
     if (n < 3) return;
     if (!test_block && (!a.do_update || (int64_t)((int)blockIdx.x - a.ntest) * kThreads >= n)) return;
     if (test_block && !a.do_tests) return;
+    NJP_STAMP(1, 0, false);
+    NJP_STAMP(1, 1, true);
 
     // ---- select: reduce the records (thrust::min_element, src/neighborJoining.cu:214)
     double bq = 10000.0, d = 0.0; uint64_t bk = ~0ull, bp = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) best_update4(bq, bk, bp, d, mine[k].q, mine[k].key, mine[k].pad, mine[k].d);
-    for (int64_t idx = tid + 4 * kThreads; idx < nrec_all; idx += kThreads)
+    for (int k = 0; k < kMine; ++k) best_update4(bq, bk, bp, d, mine[k].q, mine[k].key, mine[k].pad, mine[k].d);
+    for (int64_t idx = tid + kMine * kThreads; idx < nrec_all; idx += kThreads)
         if (idx < uvalid || idx >= a.urecs) best_update4(bq, bk, bp, d, a.partials[idx].q, a.partials[idx].key, a.partials[idx].pad, a.partials[idx].d);
     wave_best4(bq, bk, bp, d);
     if ((tid & 63) == 0) { sq[tid >> 6] = bq; sk[tid >> 6] = bk; spp[tid >> 6] = bp; sdd[tid >> 6] = d; }
@@ -491,6 +520,7 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
 #pragma unroll
     for (int w = 1; w < kThreads / 64; ++w) best_update4(bq, bk, bp, d, sq[w], sk[w], spp[w], sdd[w]);
 
+    NJP_STAMP(1, 2, false);
     const int64_t last = n - 1;
     if (bk == ~0ull) {
         if (!test_block && i == last) a.st->status = 1;
@@ -533,7 +563,10 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
                 Un[p] = u;
                 a.Ur[p] = u / r1;
                 Rw[p] = val;                   // row of the new node: into the matrix by the next scan's new-row blocks
-                a.D[p * a.ld + px] = val;      // its column
+                // its column: 8 bytes into n different lines.  Stored write-through (sc1): as plain stores they leave n dirty
+                // 128-byte lines in L2 that the end-of-kernel write-back has to flush (NJ 515 -> 508 ms at 30 000 tips)
+                if (a.flags & 1) a.D[p * a.ld + px] = val;
+                else __hip_atomic_store(a.D + p * a.ld + px, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (i == last) {           // relabel: the node of the last slot now lives in slot y
                     new_slot = y;
                     a.slot_of_pos[p] = (int32_t)y;
@@ -542,6 +575,8 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
             } else if (i == y) {
                 // (py from the winning record, not this thread's pos_of_slot[y]: the thread of the last slot rewrites that entry)
                 a.Ur[py] = __builtin_nan("");   // dead: every q it takes part in is NaN, every unit minimum skips it
+                Un[py] = __builtin_nan("");     // ... and NaN in BOTH row-sum buffers (a dead position is never written again;
+                a.U[(it & 1) * a.vstride + py] = __builtin_nan("");   //  the test role of this launch leaves py out by index)
                 a.slot_of_pos[py] = -1;
                 Rw[py] = 0.0;
                 new_slot = -1;
@@ -551,8 +586,10 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
             }
             if (new_slot >= 0) { a.KA[p] = nj_key_a(new_slot, n1); a.KB[p] = nj_key_b(new_slot); }
         }
+        NJP_STAMP(1, 3, false);
         const double cs = block_tree256_lane0(val, s);
         if (tid == 0) a.xpart[(int)blockIdx.x - a.ntest] = cs;
+        NJP_STAMP(1, 6, true);
         return;
     }
 
@@ -566,17 +603,15 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
     const int64_t gz = fold ? pz / kUR : -1;
     const bool gz_here = fold && gz >= (int64_t)a.blk_g0[blockIdx.x] && gz < (int64_t)a.blk_g0[blockIdx.x] + kThreads;   // block-uniform
     const int wpz = fold ? (int)((pz % kTileCols) / (kTileCols / 4)) : -1;   // sub-strip of that node's column
-    v2d dxr[kUR / 2], dyr[kUR / 2], rzr[kUR / 2];
+    v2d dxr[8], dyr[8];
 #pragma unroll
-    for (int r = 0; r < kUR / 2; ++r) { dxr[r] = *reinterpret_cast<const v2d*>(rowx + a0 + 2 * r); dyr[r] = *reinterpret_cast<const v2d*>(rowy + a0 + 2 * r); }
-    const v2d dxc = *reinterpret_cast<const v2d*>(rowx + pc0), dyc = *reinterpret_cast<const v2d*>(rowy + pc0);
-    if (pz_strip) {
-#pragma unroll
-        for (int r = 0; r < kUR / 2; ++r) rzr[r] = *reinterpret_cast<const v2d*>(Rz + a0 + 2 * r);
-    } else {
-#pragma unroll
-        for (int r = 0; r < kUR / 2; ++r) { rzr[r].x = PINF; rzr[r].y = PINF; }
+    for (int c = 0; c < 8; ++c) {
+        const int64_t pp = rbase + c * kTileCols + 2 * tid;
+        const int64_t po = pp < P ? pp : pclamp;
+        dxr[c] = *reinterpret_cast<const v2d*>(rowx + po);
+        dyr[c] = *reinterpret_cast<const v2d*>(rowy + po);
     }
+    const v2d dxc = *reinterpret_cast<const v2d*>(rowx + pc0), dyc = *reinterpret_cast<const v2d*>(rowy + pc0);
     v2d rzc; rzc.x = PINF; rzc.y = PINF;
     if (gz_here) rzc = *reinterpret_cast<const v2d*>(Rz + pc0);
     // seed candidates re-evaluated with the row sums after this merge
@@ -598,46 +633,73 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
             }
         }
     }
-    double u4[4] = { PINF, PINF, PINF, PINF };
-    double rmax = NINF, newminA = PINF;
-    if (have) {
-        u4[0] = dec_f64(um0.x); u4[1] = dec_f64(um0.y); u4[2] = dec_f64(um1.x); u4[3] = dec_f64(um1.y);
+    NJP_STAMP(1, 3, true);
+    // Row sums after this merge for the block's 4096 row positions (U, not U / (n - 3): the division is monotone, so it is
+    // done once per group afterwards -- fl(max U / r) == max fl(U / r) bit for bit, and an fp64 division is ~40
+    // instructions).  They go through LDS, 16 values + 1 pad per group (both the pairwise writes and the group-wise reads
+    // are then conflict-free), and the test lane of a group takes the maximum of its 16.  Dead positions and the padding
+    // behind P carry NaN in U; the merged pair is left out by (32-bit, block-local) index.
+    __shared__ double s_un[4096 + 256];
+    const int lxp = (int)(px - rbase), lyp = (int)(py - rbase), lzp = (int)((fold ? pz : -1) - rbase);
 #pragma unroll
-        for (int r = 0; r < kUR; ++r) {
-            const int64_t pp = a0 + r;
-            const int sl = (r & 3) == 0 ? sprow[r >> 2].x : (r & 3) == 1 ? sprow[r >> 2].y : (r & 3) == 2 ? sprow[r >> 2].z : sprow[r >> 2].w;
-            const double uo = (r & 1) ? urow[r >> 1].y : urow[r >> 1].x;
-            const double dx = (r & 1) ? dxr[r >> 1].y : dxr[r >> 1].x;
-            const double dy = (r & 1) ? dyr[r >> 1].y : dyr[r >> 1].x;
-            const double rz = (r & 1) ? rzr[r >> 1].y : rzr[r >> 1].x;
-            const bool live = (sl >= 0) & (pp != px) & (pp != py);     // the new node (px) is in quarantine during scan it + 1
-            const double un = nj_unew(uo, dx, dy, nj_val(dx, dy, d)) / r1;
-            rmax = live ? fmax(rmax, un) : rmax;
-            newminA = (live & (pp > pz)) ? fmin(newminA, rz) : newminA;
-        }
+    for (int c = 0; c < 8; ++c) {
+        const int lp = c * kTileCols + 2 * tid;
+        const double u0 = urow[c].x, u1 = urow[c].y;
+        const bool live0 = (u0 == u0) & (lp != lxp) & (lp != lyp);          // (the new node is in quarantine during scan it + 1)
+        const bool live1 = (u1 == u1) & (lp + 1 != lxp) & (lp + 1 != lyp);
+        const double n0 = nj_unew(u0, dxr[c].x, dyr[c].x, nj_val(dxr[c].x, dyr[c].x, d));
+        const double n1v = nj_unew(u1, dxr[c].y, dyr[c].y, nj_val(dxr[c].y, dyr[c].y, d));
+        const int li = lp + (lp >> 4);
+        s_un[li] = live0 ? n0 : NINF;
+        s_un[li + 1] = live1 ? n1v : NINF;
     }
+    double u4[4] = { PINF, PINF, PINF, PINF };
+    if (have) { u4[0] = dec_f64(um0.x); u4[1] = dec_f64(um0.y); u4[2] = dec_f64(um1.x); u4[3] = dec_f64(um1.y); }
     // column maximum of each sub-strip (wave w holds columns 128w .. 128w+127 of the strip); minimum of the row of the
     // node leaving quarantine over the sub-strip's live columns
     double cm_part = NINF, colmin = PINF;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int64_t pp = pc0 + k;
-        const int sl = k ? spcol.y : spcol.x;
         const double uo = k ? ucol.y : ucol.x;
         const double dx = k ? dxc.y : dxc.x, dy = k ? dyc.y : dyc.x;
         const double rz = k ? rzc.y : rzc.x;
-        const bool live = (sl >= 0) & (pp != px) & (pp != py) & (pp < P);
-        const double un = nj_unew(uo, dx, dy, nj_val(dx, dy, d)) / r1;
+        const bool live = (uo == uo) & (pp != px) & (pp != py) & (pp < P);
+        const double un = nj_unew(uo, dx, dy, nj_val(dx, dy, d));      // divided after the wave maximum
         cm_part = live ? fmax(cm_part, un) : cm_part;
         colmin = (live & (pp < pz)) ? fmin(colmin, rz) : colmin;
     }
     qc = wave_fmin(qc);
-    cm_part = wave_fmax(cm_part);
+    cm_part = wave_fmax(cm_part) / r1;            // (-inf stays -inf)
     if (gz_here) colmin = wave_fmin(colmin);
-    __syncthreads();               // (the select above read sq .. sdd; sseed / scm / snew are separate arrays, but keep the phases apart)
     if ((tid & 63) == 0) { sseed[tid >> 6] = qc; scm[tid >> 6] = cm_part; snew[tid >> 6] = colmin; }
     __syncthreads();
+    NJP_STAMP(1, 4, false);
     const double bound = fmin(fmin(sseed[0], sseed[1]), fmin(sseed[2], sseed[3]));
+    double rmax = NINF, newminA = PINF;                             // group g = blk_g0 + tid
+#pragma unroll
+    for (int k = 0; k < kUR; ++k) rmax = fmax(rmax, s_un[17 * tid + k]);
+    rmax = rmax / r1;                                               // (-inf stays -inf)
+    if (pz_strip) {
+        // block-uniform and rare (the strip of the node leaving quarantine): minimum of its buffered row over each
+        // group's live rows behind it, same route through LDS
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int lp = c * kTileCols + 2 * tid;
+            const int64_t pp = rbase + lp;
+            const v2d rz = *reinterpret_cast<const v2d*>(Rz + (pp < P ? pp : pclamp));
+            const double u0 = urow[c].x, u1 = urow[c].y;
+            const bool live0 = (u0 == u0) & (lp != lxp) & (lp != lyp) & (lp > lzp);
+            const bool live1 = (u1 == u1) & (lp + 1 != lxp) & (lp + 1 != lyp) & (lp + 1 > lzp);
+            const int li = lp + (lp >> 4);
+            s_un[li] = live0 ? rz.x : PINF;
+            s_un[li + 1] = live1 ? rz.y : PINF;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kUR; ++k) newminA = fmin(newminA, s_un[17 * tid + k]);
+    }
     const bool own = have && (a.sh_world <= 1 || (int)(((int64_t)cb * G16 + g) % a.sh_world) == a.sh_rank);
     int submask = 0;
     if (own) {
@@ -660,7 +722,9 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
     unsigned long long base = 0;
     if (lane == 0 && mask) base = atomicAdd(&a.cnt[(it + 1) % 3], (unsigned long long)__popcll(mask));
     base = __shfl(base, 0, 64);
+    NJP_STAMP(1, 5, true);
     if (keep) a.list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)(((uint32_t)submask << 28) | ((uint32_t)cb << 18) | (uint32_t)g);   // sub-unit mask | strip | group
+    NJP_STAMP(1, 6, true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -668,6 +732,8 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
 // ------------------------------------------------------------------------------------------------
 static int64_t round_up16(int64_t v) { return (v + 15) / 16 * 16; }
 static int g_njp_grid = 1024;
+static unsigned long long* g_njp_dbg = nullptr;     // DPR_NJ_PHASES: [2 kernels][2048 blocks][8 stamps]
+static int64_t g_njp_dbg_it = -1;
 int njp_scan_grid() { return g_njp_grid; }
 
 // ---- arena -------------------------------------------------------------------------------------------------------
@@ -735,6 +801,8 @@ static int njp_arena(NjPruned& q, int64_t N, hipStream_t s)
     return DPR_OK;
 }
 
+int njp_reserve(NjPruned& q, int64_t N, hipStream_t s) { return njp_arena(q, N, s); }
+
 // point q at the position-space structures of an epoch with P positions (N = total tips: slot arrays) inside
 // matrix buffer `Dbuf` and slab `slab`, and initialise them (all fills ordered on s)
 static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, char* slab, hipStream_t s)
@@ -763,7 +831,7 @@ static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, char
     q.blk_cb = reinterpret_cast<int32_t*>(slab + plan.blk_cb);
     q.blk_g0 = reinterpret_cast<int32_t*>(slab + plan.blk_g0);
     q.cnt_all = reinterpret_cast<unsigned long long*>(slab + plan.cnt_all);
-    DPR_HIP(hipMemsetAsync(q.U, 0, 2 * vec * sizeof(double), s));
+    DPR_HIP(hipMemsetAsync(q.U, 0xff, 2 * vec * sizeof(double), s));   // NaN = dead / padding, in both buffers
     DPR_HIP(hipMemsetAsync(q.R, 0, 2 * vec * sizeof(double), s));
     DPR_HIP(hipMemsetAsync(q.Ur, 0xff, vec * sizeof(double), s));   // NaN beyond P
     DPR_HIP(hipMemsetAsync(q.KA, 0, vec * sizeof(uint64_t), s));
@@ -805,9 +873,16 @@ static void sort_by_row_sum(std::vector<int32_t>& perm, const std::vector<double
 int njp_build(NjBuffers& b, hipStream_t s)
 {
     {   // blocks of the unit scan (tests shrink it so that every block walks several units and cnt > grid)
+        // default: 256 blocks while an iteration lists ~100 units (a 1000-block grid takes ~1.5 us just to start; NJ 515 ->
+        // 512 ms at 30 000 tips), 1024 where the scans are bandwidth-bound (thousands of units per iteration at 100 000 tips)
         const char* e = std::getenv("DPR_NJP_GRID");
-        const int g = e ? std::atoi(e) : 1024;
+        const int g = e ? std::atoi(e) : (b.N < 50000 ? 256 : 1024);
         g_njp_grid = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+    }
+    if (const char* e = std::getenv("DPR_NJ_PHASES")) {
+        g_njp_dbg_it = std::atoll(e);
+        if (!g_njp_dbg) DPR_HIP(hipMalloc(&g_njp_dbg, sizeof(unsigned long long) * 2 * 2048 * 8));
+        DPR_HIP(hipMemsetAsync(g_njp_dbg, 0, sizeof(unsigned long long) * 2 * 2048 * 8, s));
     }
     // b.D / b.U hold the matrix and the row sums in tip order (world == 1).  Sort by U ascending.
     const int64_t N = b.N;
@@ -936,6 +1011,8 @@ static NjpArgs njp_args(NjBuffers& b, int v)
     a.do_update = 1; a.do_tests = 1; a.do_rows = 1;
     a.log_x = b.log_x; a.log_y = b.log_y; a.log_bx = b.log_bx; a.log_by = b.log_by;
     a.iterstats = (unsigned long long*)q.iterstats;
+    a.dbg = g_njp_dbg; a.dbg_it = g_njp_dbg_it;
+    { static const int fl = std::getenv("DPR_NJP_FLAGS") ? std::atoi(std::getenv("DPR_NJP_FLAGS")) : 0; a.flags = fl; }
     return a;
 }
 
@@ -1056,6 +1133,15 @@ const char* njp_kernel_name(int idx)
 {
     static const char* names[] = { "njp_scan_kernel", "njp_post_kernel", "(empty event pair)" };
     return idx >= 0 && idx < 3 ? names[idx] : "";
+}
+
+// debug: the phase stamps of iteration DPR_NJ_PHASES (2 x 2048 x 8 words), 0 = not stamped
+int njp_phase_stamps(unsigned long long* out)
+{
+    if (!g_njp_dbg) { set_error("DPR_NJ_PHASES not set"); return DPR_ERR_STATE; }
+    DPR_HIP(hipDeviceSynchronize());
+    DPR_HIP(hipMemcpy(out, g_njp_dbg, sizeof(unsigned long long) * 2 * 2048 * 8, hipMemcpyDeviceToHost));
+    return DPR_OK;
 }
 
 // current U buffer of the pruned path (row sums by position) after `it` iterations

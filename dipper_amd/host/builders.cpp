@@ -5,6 +5,9 @@
 #include <cctype>
 #include <cstdlib>
 #include <iostream>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 namespace dipper {
@@ -15,38 +18,69 @@ DeviceContext::~DeviceContext() { if (ctx) dpr_destroy(ctx); }
 struct AsyncDeviceContext::Impl {
     std::thread th;
     DeviceContext* dev = nullptr;
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t reserve_n = 0;
+    bool closing = false;
 };
 AsyncDeviceContext::AsyncDeviceContext(int device) : impl(new Impl)
 {
     Impl* q = impl;
-    impl->th = std::thread([q, device] { q->dev = new DeviceContext(device); });
+    impl->th = std::thread([q, device] {
+        q->dev = new DeviceContext(device);
+        std::unique_lock<std::mutex> lk(q->mu);
+        q->cv.wait(lk, [q] { return q->reserve_n != 0 || q->closing; });
+        const size_t n = q->reserve_n;
+        lk.unlock();
+        if (n) (void)dpr_reserve_nj(q->dev->ctx, (int64_t)n);      // best effort: dpr_dist_matrix allocates what is missing
+    });
+}
+void AsyncDeviceContext::reserveNJ(size_t n)
+{
+    { std::lock_guard<std::mutex> lk(impl->mu); impl->reserve_n = n; }
+    impl->cv.notify_all();
 }
 DeviceContext& AsyncDeviceContext::get()
 {
+    { std::lock_guard<std::mutex> lk(impl->mu); impl->closing = true; }
+    impl->cv.notify_all();
     if (impl->th.joinable()) impl->th.join();
     return *impl->dev;
 }
 AsyncDeviceContext::~AsyncDeviceContext()
 {
+    { std::lock_guard<std::mutex> lk(impl->mu); impl->closing = true; }
+    impl->cv.notify_all();
     if (impl->th.joinable()) impl->th.join();
     delete impl->dev;
     delete impl;
 }
 
-// replaces the tbb::parallel_for packing loop (src/tree_generation.cu:352-362) + MSADeviceArrays::
-// allocateDeviceArrays (src/MSA.cu:14-72)
-void MSADeviceArrays::allocateDeviceArrays(DeviceContext& dev, const std::vector<std::string>& seqs,
-                                           const std::vector<int>& ids)
+void MSADeviceArrays::allocateDeviceArrays(DeviceContext& dev, const PackedSequences& packed)
 {
-    numSequences = seqs.size();
+    numSequences = packed.numSequences;
     if (numSequences < 2) die("ERROR: need at least two sequences");
+    seqLen = packed.seqLen;
+    gpuCheck(dpr_set_msa(dev.ctx, packed.flat.data(), (int64_t)numSequences, (int64_t)seqLen), "dpr_set_msa");
+}
+
+void MashDeviceArrays::allocateDeviceArrays(DeviceContext& dev, const PackedSequences& packed)
+{
+    numSequences = packed.numSequences;
+    if (numSequences < 2) die("ERROR: need at least two sequences");
+    gpuCheck(dpr_set_reads(dev.ctx, packed.flat.data(), packed.off.data(), packed.lens.data(), (int64_t)numSequences), "dpr_set_reads");
+}
+
+void packAligned(const std::vector<std::string>& seqs, const std::vector<int>& ids, std::vector<uint64_t>& flat, int& seqLen)
+{
+    const size_t numSequences = seqs.size();
     // seqLen = length of the sequence in slot 0 (src/MSA.cu:19)
     size_t slot0 = 0;
     for (size_t i = 0; i < numSequences; ++i) if (ids[i] == 0) slot0 = i;
     seqLen = (int)seqs[slot0].size();
     const size_t W = ((size_t)seqLen + 15) / 16;
-    std::vector<uint64_t> flat(numSequences * W, 0);
-    unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    flat.assign(numSequences * W, 0);
+    unsigned nt = hostThreads(32);
     std::vector<std::thread> pool;
     for (unsigned t = 0; t < nt; ++t)
         pool.emplace_back([&, t] {
@@ -68,6 +102,17 @@ void MSADeviceArrays::allocateDeviceArrays(DeviceContext& dev, const std::vector
             }
         });
     for (auto& th : pool) th.join();
+}
+
+// replaces the tbb::parallel_for packing loop (src/tree_generation.cu:352-362) + MSADeviceArrays::
+// allocateDeviceArrays (src/MSA.cu:14-72)
+void MSADeviceArrays::allocateDeviceArrays(DeviceContext& dev, const std::vector<std::string>& seqs,
+                                           const std::vector<int>& ids)
+{
+    numSequences = seqs.size();
+    if (numSequences < 2) die("ERROR: need at least two sequences");
+    std::vector<uint64_t> flat;
+    packAligned(seqs, ids, flat, seqLen);
     gpuCheck(dpr_set_msa(dev.ctx, flat.data(), (int64_t)numSequences, (int64_t)seqLen), "dpr_set_msa");
 }
 
@@ -90,25 +135,34 @@ void NJDeviceArrays::findNeighbourJoiningTree(DeviceContext& dev, std::vector<st
     std::vector<int32_t> mx((size_t)std::max(N - 2, 1)), my((size_t)std::max(N - 2, 1));
     std::vector<double> bx((size_t)std::max(N - 2, 1)), by((size_t)std::max(N - 2, 1));
     double last = 0.0;
+    const auto t0 = std::chrono::steady_clock::now();
     const int64_t done = dpr_nj_run(dev.ctx, -1, mx.data(), my.data(), bx.data(), by.data(), &last);
     if (done < 0) gpuCheck((int)done, "dpr_nj_run");
+    const auto t1 = std::chrono::steady_clock::now();
     writeNewickFromMerges(output_, name, mx, my, bx, by, last);
+    if (std::getenv("DPR_CLI_TIMING")) {
+        double dist_ms = 0, nj_ms = 0;
+        dpr_get_timing(dev.ctx, &dist_ms, &nj_ms);
+        std::cerr << "  device: distances " << dist_ms << " ms, NJ " << nj_ms << " ms; dpr_nj_run call "
+                  << std::chrono::duration<double, std::milli>(t1 - t0).count() << " ms; Newick text "
+                  << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count() << " ms\n";
+    }
 }
 
-void MashDeviceArrays::allocateDeviceArrays(DeviceContext& dev, const std::vector<std::string>& seqs,
-                                            const std::vector<int>& ids)
+void packUnaligned(const std::vector<std::string>& seqs, const std::vector<int>& ids, std::vector<uint64_t>& flat,
+                   std::vector<uint64_t>& off, std::vector<uint64_t>& lens)
 {
-    numSequences = seqs.size();
-    if (numSequences < 2) die("ERROR: need at least two sequences");
-    std::vector<uint64_t> lens(numSequences), off(numSequences), nw(numSequences);
+    const size_t numSequences = seqs.size();
+    lens.assign(numSequences, 0); off.assign(numSequences, 0);
+    std::vector<uint64_t> nw(numSequences);
     for (size_t i = 0; i < numSequences; ++i) {
         lens[(size_t)ids[i]] = seqs[i].size();
         nw[(size_t)ids[i]] = (seqs[i].size() + 31) / 32;
     }
     uint64_t total = 0;
     for (size_t s = 0; s < numSequences; ++s) { off[s] = total; total += nw[s]; }  // exclusive scan (src/mash.cu:109-119)
-    std::vector<uint64_t> flat(total + 1, 0);
-    unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    flat.assign(total + 1, 0);
+    unsigned nt = hostThreads(32);
     std::vector<std::thread> pool;
     for (unsigned t = 0; t < nt; ++t)
         pool.emplace_back([&, t] {
@@ -116,6 +170,15 @@ void MashDeviceArrays::allocateDeviceArrays(DeviceContext& dev, const std::vecto
                 if (!seqs[i].empty()) dpr_pack2(seqs[i].data(), seqs[i].size(), flat.data() + off[(size_t)ids[i]]);
         });
     for (auto& th : pool) th.join();
+}
+
+void MashDeviceArrays::allocateDeviceArrays(DeviceContext& dev, const std::vector<std::string>& seqs,
+                                            const std::vector<int>& ids)
+{
+    numSequences = seqs.size();
+    if (numSequences < 2) die("ERROR: need at least two sequences");
+    std::vector<uint64_t> lens, off, flat;
+    packUnaligned(seqs, ids, flat, off, lens);
     gpuCheck(dpr_set_reads(dev.ctx, flat.data(), off.data(), lens.data(), (int64_t)numSequences), "dpr_set_reads");
 }
 

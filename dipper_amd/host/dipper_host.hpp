@@ -30,6 +30,33 @@ void gpuCheck(int rc, const char* what);         // "Gpu_ERROR"-style exit on rc
 // (src/tree_generation.cu:132-154, src/kseq.h).
 void readSequences(const std::string& path, std::vector<std::string>& seqs, std::vector<std::string>& names);
 
+// Host threads this process may really use: min(hardware_concurrency, affinity mask, cgroup cpu.max quota).  A GPU box
+// reports 256 logical CPUs but grants 16: a pool sized by hardware_concurrency burns the quota of a scheduling period
+// in a quarter of it and is then throttled as a whole.
+unsigned hostThreads(unsigned cap = 64);
+
+// Fast path of the sequence inputs (-i m / -i r without --add): the records are indexed in the mapped (or inflated)
+// text by all host threads and packed straight into the flat 4-bit / 2-bit arrays of the device interface -- no
+// per-sequence std::string copies.  Same records, names and codes as readSequences + dpr_pack4 / dpr_pack2
+// (klib-kseq semantics); ok = false: the text needs the serial parser (FASTQ), use readSequences.
+struct PackedSequences {
+    bool ok = false;
+    size_t numSequences = 0;
+    std::vector<std::string> names;     // by SLOT (ids applied)
+    // aligned (4-bit): flat [n][W], seqLen = length of the sequence in slot 0 (src/MSA.cu:19)
+    int seqLen = 0;
+    // unaligned (2-bit): flat words at off[slot], lens[slot] bases
+    std::vector<uint64_t> flat, off, lens;
+};
+// on_count(n) is called as soon as the number of records is known (the device thread reserves its matrices then)
+void readSequencesPacked(const std::string& path, bool aligned, long long seed, PackedSequences& out,
+                         void (*on_count)(size_t n, void* user) = nullptr, void* user = nullptr);
+
+// the per-sequence encoders of the general path (seqs[i] goes to slot ids[i]); the fast path must produce the same arrays
+void packAligned(const std::vector<std::string>& seqs, const std::vector<int>& ids, std::vector<uint64_t>& flat, int& seqLen);
+void packUnaligned(const std::vector<std::string>& seqs, const std::vector<int>& ids, std::vector<uint64_t>& flat,
+                   std::vector<uint64_t>& off, std::vector<uint64_t>& lens);
+
 // Input-order shuffle of the reference (src/tree_generation.cu:341-344,470-473): ids[i] = slot of
 // input sequence i.  seed < 0 keeps the input order.
 std::vector<int> shuffledIds(size_t n, long long seed);
@@ -54,6 +81,8 @@ struct AsyncDeviceContext {
     explicit AsyncDeviceContext(int device);
     ~AsyncDeviceContext();
     DeviceContext& get();
+    // ask the helper thread to allocate the NJ matrices for n tips (dpr_reserve_nj) once the context exists; returns at once
+    void reserveNJ(size_t n);
 private:
     struct Impl;
     Impl* impl;
@@ -64,6 +93,7 @@ struct MSADeviceArrays {  // src/mash_placement.cuh:87-98
     int seqLen = 0;
     // seqs[i] goes to slot ids[i]; packs with the 4-bit encoder in parallel and uploads
     void allocateDeviceArrays(DeviceContext& dev, const std::vector<std::string>& seqs, const std::vector<int>& ids);
+    void allocateDeviceArrays(DeviceContext& dev, const PackedSequences& packed);      // already packed by readSequencesPacked
 };
 
 struct NJDeviceArrays {  // src/mash_placement.cuh:199-212
@@ -76,6 +106,7 @@ struct MashDeviceArrays {  // src/mash_placement.cuh:34-50
     size_t numSequences = 0;
     // 2-bit packing in parallel (src/tree_generation.cu:480-490) + upload; seqs[i] goes to slot ids[i]
     void allocateDeviceArrays(DeviceContext& dev, const std::vector<std::string>& seqs, const std::vector<int>& ids);
+    void allocateDeviceArrays(DeviceContext& dev, const PackedSequences& packed);
     void sketchConstructionOnGpu(DeviceContext& dev, Param& params);
 };
 

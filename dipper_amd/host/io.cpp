@@ -2,6 +2,7 @@
 #include "dipper_host.hpp"
 
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -29,6 +30,28 @@ void gpuCheck(int rc, const char* what)
         std::fprintf(stderr, "Gpu_ERROR: %s failed: %s\n", what, dpr_last_error());
         std::exit(1);
     }
+}
+
+unsigned hostThreads(unsigned cap)
+{
+    unsigned n = std::thread::hardware_concurrency();
+    if (n == 0) n = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+        const unsigned a = (unsigned)CPU_COUNT(&set);
+        if (a > 0 && a < n) n = a;
+    }
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {      // cgroup v2: "<quota> <period>" or "max <period>"
+        char q[64] = { 0 };
+        long long period = 0;
+        if (std::fscanf(f, "%63s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) {
+            const long long quota = std::atoll(q);
+            const unsigned c = (unsigned)std::max(1LL, quota / period);
+            if (c < n) n = c;
+        }
+        std::fclose(f);
+    }
+    return std::max(1u, std::min(cap, n));
 }
 
 static std::string slurp_gz(const std::string& path)
@@ -96,7 +119,7 @@ static void parseRecords(const char* data, size_t n, std::vector<std::string>& s
 // parser).  Returns false when the text needs the serial parser (FASTQ: a line starting with '+').
 static bool parseFastaParallel(const char* data, size_t n, std::vector<std::string>& seqs, std::vector<std::string>& names)
 {
-    const unsigned nt = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    const unsigned nt = hostThreads(64);
     if (n < (size_t)(1 << 22) || nt < 2) return false;
     size_t first = 0;
     while (first < n && data[first] != '>' && data[first] != '@') ++first;
@@ -183,6 +206,182 @@ void readSequences(const std::string& path, std::vector<std::string>& seqs, std:
     }
     const std::string data = slurp_gz(path);
     if (!parseFastaParallel(data.data(), data.size(), seqs, names)) parseRecords(data.data(), data.size(), seqs, names);
+}
+
+// ---- fast path: index + pack straight from the text -------------------------------------------------------------
+namespace {
+struct TextSource {      // mapped file or inflated gzip
+    const char* data = nullptr;
+    size_t n = 0;
+    void* map = nullptr;
+    size_t map_len = 0;
+    std::string owned;
+    ~TextSource() { if (map) munmap(map, map_len); }
+    void open(const std::string& path)
+    {
+        int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd >= 0) {
+            struct stat sb;
+            unsigned char magic[2] = { 0, 0 };
+            if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 2 && pread(fd, magic, 2, 0) == 2 &&
+                !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+                // (no MAP_POPULATE: the worker threads fault the page-cache pages in, in parallel)
+                void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) {
+                    (void)madvise(m, (size_t)sb.st_size, MADV_WILLNEED);
+                    map = m; map_len = (size_t)sb.st_size;
+                    data = static_cast<const char*>(m); n = map_len;
+                    ::close(fd);
+                    return;
+                }
+            }
+            ::close(fd);
+        }
+        owned = slurp_gz(path);
+        data = owned.data(); n = owned.size();
+    }
+};
+
+template <class F> void parallelFor(size_t count, unsigned nt, F&& f)
+{
+    if (nt < 2 || count < 2) { for (size_t i = 0; i < count; ++i) f(i, 0u); return; }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; ++t)
+        pool.emplace_back([&, t] { for (size_t i = t; i < count; i += nt) f(i, t); });
+    for (auto& th : pool) th.join();
+}
+
+// the sequence text of a record [p, end): calls seg(ptr, len) for every line's bases in order, with the serial
+// parser's carriage-return rule (a trailing CR is dropped when the sequence so far is longer than one character)
+template <class F> inline void forEachSegment(const char* data, size_t p, size_t end, F&& seg)
+{
+    size_t total = 0;
+    while (p < end) {
+        if (data[p] == '\n') { ++p; continue; }
+        const char* nl = static_cast<const char*>(std::memchr(data + p, '\n', end - p));
+        const size_t le = nl ? (size_t)(nl - data) : end;
+        size_t len = le - p;
+        if (len > 0 && data[le - 1] == '\r' && total + len > 1) --len;
+        if (len) seg(data + p, len);
+        total += len;
+        p = le < end ? le + 1 : end;
+    }
+}
+
+struct CodeLut {
+    uint8_t c4[256], c2[256];
+    CodeLut()
+    {
+        for (int i = 0; i < 256; ++i) { c4[i] = 4; c2[i] = 0; }      // fourBitCompressor: anything else -> 4; twoBitCompressor: -> 0 ('A')
+        const char* b = "ACGT";
+        for (int k = 0; k < 4; ++k) { c4[(unsigned char)b[k]] = (uint8_t)k; c2[(unsigned char)b[k]] = (uint8_t)k; }
+        c4[(unsigned char)'U'] = 3; c2[(unsigned char)'U'] = 3;
+    }
+};
+const CodeLut kLut;
+}  // namespace
+
+void readSequencesPacked(const std::string& path, bool aligned, long long seed, PackedSequences& out,
+                         void (*on_count)(size_t n, void* user), void* user)
+{
+    out = PackedSequences();
+    TextSource src;
+    src.open(path);
+    const char* data = src.data;
+    const size_t n = src.n;
+    const unsigned nt = hostThreads(64);
+    size_t first = 0;
+    while (first < n && data[first] != '>' && data[first] != '@') ++first;
+    if (first >= n) { out.ok = true; return; }
+    // ---- record starts: '>' or '@' at the beginning of a line; a line starting with '+' means FASTQ -> serial parser
+    std::vector<std::vector<size_t>> starts(nt);
+    std::vector<char> plus(nt, 0);
+    const size_t chunk = (n - first + nt - 1) / nt;
+    parallelFor(nt, nt, [&](size_t t, unsigned) {
+        const size_t lo = first + t * chunk, hi = std::min(n, lo + chunk);
+        if (lo >= hi) return;
+        if (t == 0) starts[0].push_back(first);
+        const char* q = data + lo;
+        const char* end = data + hi;
+        while (q < end) {
+            q = static_cast<const char*>(std::memchr(q, '\n', (size_t)(end - q)));
+            if (!q) break;
+            ++q;
+            if (q < data + n) {
+                if (*q == '>' || *q == '@') starts[t].push_back((size_t)(q - data));
+                else if (*q == '+') plus[t] = 1;
+            }
+        }
+    });
+    for (char c : plus) if (c) return;      // ok stays false
+    std::vector<size_t> st;
+    for (auto& v : starts) st.insert(st.end(), v.begin(), v.end());
+    const size_t nrec = st.size();
+    st.push_back(n);
+    out.numSequences = nrec;
+    if (on_count) on_count(nrec, user);
+    const std::vector<int> ids = shuffledIds(nrec, seed);
+    // ---- names, body offsets and lengths
+    out.names.assign(nrec, std::string());
+    std::vector<size_t> body(nrec), len(nrec);
+    parallelFor(nrec, nt, [&](size_t r, unsigned) {
+        size_t p = st[r] + 1;
+        const size_t end = st[r + 1];
+        size_t e = p;
+        while (e < end && !std::isspace((unsigned char)data[e])) ++e;
+        out.names[(size_t)ids[r]].assign(data + p, e - p);
+        while (e < end && data[e] != '\n') ++e;
+        body[r] = e < end ? e + 1 : end;
+        size_t l = 0;
+        forEachSegment(data, body[r], end, [&](const char*, size_t k) { l += k; });
+        len[r] = l;
+    });
+    if (aligned) {
+        size_t slot0 = 0;
+        for (size_t r = 0; r < nrec; ++r) if (ids[r] == 0) slot0 = r;
+        out.seqLen = (int)len[slot0];
+        const size_t W = ((size_t)out.seqLen + 15) / 16;
+        out.flat.resize(nrec * W);            // (every word is written below)
+        parallelFor(nrec, nt, [&](size_t r, unsigned) {
+            uint64_t* dst = out.flat.data() + (size_t)ids[r] * W;
+            const size_t have = (len[r] + 15) / 16;
+            size_t w = 0, j = 0;              // word index, base index inside the word
+            uint64_t v = 0;
+            forEachSegment(data, body[r], st[r + 1], [&](const char* s, size_t k) {
+                for (size_t i = 0; i < k && w < W; ++i) {
+                    v |= (uint64_t)kLut.c4[(unsigned char)s[i]] << (4 * j);
+                    if (++j == 16) { dst[w++] = v; v = 0; j = 0; }
+                }
+            });
+            if (j && w < W) dst[w++] = v;     // last, partly filled word of the sequence (tail zero as dpr_pack4 leaves it)
+            // a sequence shorter than the one in slot 0: the missing bases are marked invalid (code 4)
+            for (; w < W; ++w) dst[w] = 0x4444444444444444ull;
+            if (len[r] < (size_t)out.seqLen && have > 0 && have <= W) {
+                const size_t rr = len[r] % 16;
+                if (rr) dst[have - 1] |= 0x4444444444444444ull << (4 * rr);
+            }
+        });
+    } else {
+        out.lens.assign(nrec, 0); out.off.assign(nrec, 0);
+        std::vector<uint64_t> nw(nrec);
+        for (size_t r = 0; r < nrec; ++r) { out.lens[(size_t)ids[r]] = len[r]; nw[(size_t)ids[r]] = (len[r] + 31) / 32; }
+        uint64_t total = 0;
+        for (size_t s2 = 0; s2 < nrec; ++s2) { out.off[s2] = total; total += nw[s2]; }  // exclusive scan (src/mash.cu:109-119)
+        out.flat.assign(total + 1, 0);
+        parallelFor(nrec, nt, [&](size_t r, unsigned) {
+            uint64_t* dst = out.flat.data() + out.off[(size_t)ids[r]];
+            size_t w = 0, j = 0;
+            uint64_t v = 0;
+            forEachSegment(data, body[r], st[r + 1], [&](const char* s, size_t k) {
+                for (size_t i = 0; i < k; ++i) {
+                    v |= (uint64_t)kLut.c2[(unsigned char)s[i]] << (2 * j);
+                    if (++j == 32) { dst[w++] = v; v = 0; j = 0; }
+                }
+            });
+            if (j) dst[w++] = v;
+        });
+    }
+    out.ok = true;
 }
 
 std::vector<int> shuffledIds(size_t n, long long seed)

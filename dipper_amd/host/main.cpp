@@ -63,7 +63,7 @@ static const Opt kOpts[] = {
     { "output-format", 'o', true }, { "algorithm", 'm', true }, { "placement-mode", 'p', true },
     { "kmer-size", 'k', true }, { "sketch-size", 's', true }, { "distance-type", 'd', true },
     { "add", 'a', false }, { "input-tree", 't', true }, { "help", 'h', false },
-    { "seed", 0, true }, { "device", 0, true }, { "dump-tree", 0, true }, { "dump-fasta", 0, false }, { "dump-lengths", 0, false },
+    { "seed", 0, true }, { "device", 0, true }, { "dump-tree", 0, true }, { "dump-fasta", 0, false }, { "dump-lengths", 0, false }, { "dump-packed", 0, true },
 };
 
 static void usageError(const std::string& what)
@@ -154,6 +154,35 @@ int main(int argc, char** argv)
             std::cout << "\n";
         }
         return 0;
+    }
+    if (vm.count("dump-packed")) {
+        // developer aid (no GPU): --dump-packed m|r compares the fast input path (records indexed in the mapped text and
+        // packed straight into the flat arrays) with the general one (readSequences + per-sequence encoders)
+        const bool aligned = vm["dump-packed"] == "m";
+        long long sd = 1;
+        try { if (vm.count("seed")) sd = std::stoll(vm["seed"]); } catch (...) {}
+        PackedSequences fast;
+        readSequencesPacked(strOr(vm, "input-file", ""), aligned, sd, fast);
+        if (!fast.ok) { std::printf("SERIAL-ONLY\n"); return 0; }
+        std::vector<std::string> seqs, names_;
+        readSequences(strOr(vm, "input-file", ""), seqs, names_);
+        const std::vector<int> ids = shuffledIds(seqs.size(), sd);
+        std::vector<std::string> names(seqs.size());
+        for (size_t i = 0; i < seqs.size(); ++i) names[(size_t)ids[i]] = names_[i];
+        bool same = fast.numSequences == seqs.size() && fast.names == names;
+        if (aligned) {
+            std::vector<uint64_t> flat; int seqLen = 0;
+            packAligned(seqs, ids, flat, seqLen);
+            same = same && seqLen == fast.seqLen && flat == fast.flat;
+            std::printf("%zu %d %zu\n", seqs.size(), seqLen, flat.size());
+        } else {
+            std::vector<uint64_t> flat, off, lens;
+            packUnaligned(seqs, ids, flat, off, lens);
+            same = same && flat == fast.flat && off == fast.off && lens == fast.lens;
+            std::printf("%zu %zu\n", seqs.size(), flat.size());
+        }
+        std::printf(same ? "IDENTICAL\n" : "DIFFERENT\n");
+        return same ? 0 : 2;
     }
     if (vm.count("dump-fasta")) {
         // developer aid (no GPU): read --input-file and print name, length and FNV-1a of every record
@@ -295,21 +324,41 @@ int main(int argc, char** argv)
 
     if ((params.in == "m" || params.in == "r") && params.out == "t") {
         const bool aligned = params.in == "m";
-        std::vector<std::string> seqs, names_, names;
+        std::vector<std::string> names;
         AsyncDeviceContext adev(device);          // HIP start-up runs while the input is read
-        readSequences(inputFile, seqs, names_);
-        const size_t numSequences = seqs.size();
+        // fast path: records indexed in the mapped text and packed straight into the device interface's flat arrays;
+        // as soon as the number of records is known the device thread allocates the NJ matrices (when NJ is the mode)
+        struct Hook { AsyncDeviceContext* adev; decltype(pick_mode)* pick; } hook{ &adev, &pick_mode };
+        PackedSequences packed;
+        readSequencesPacked(inputFile, aligned, seed, packed, [](size_t n, void* u) {
+            Hook* h = static_cast<Hook*>(u);
+            if (n >= 3 && (*h->pick)((long long)n) == 2) h->adev->reserveNJ(n);
+        }, &hook);
+        std::vector<std::string> seqs;
+        std::vector<int> ids;
+        if (!packed.ok) {                         // FASTQ: serial parser + the per-sequence encoders
+            std::vector<std::string> names_;
+            readSequences(inputFile, seqs, names_);
+            ids = shuffledIds(seqs.size(), seed);
+            names.resize(seqs.size());
+            for (size_t i = 0; i < seqs.size(); ++i) names[(size_t)ids[i]] = names_[i];
+        } else {
+            names = std::move(packed.names);
+        }
+        const size_t numSequences = packed.ok ? packed.numSequences : seqs.size();
         if (numSequences < 3) die("ERROR: need at least three sequences in " + inputFile);
-        names.resize(numSequences);
-        const std::vector<int> ids = shuffledIds(numSequences, seed);
-        for (size_t i = 0; i < numSequences; ++i) names[(size_t)ids[i]] = names_[i];
         auto output_ = open_out();
         DeviceContext& dev = adev.get();
         MSADeviceArrays msaDeviceArrays;
         MashDeviceArrays mashDeviceArrays;
         const int mode = pick_mode((long long)numSequences);
-        if (aligned) msaDeviceArrays.allocateDeviceArrays(dev, seqs, ids);
-        else mashDeviceArrays.allocateDeviceArrays(dev, seqs, ids);
+        if (packed.ok) {
+            if (aligned) msaDeviceArrays.allocateDeviceArrays(dev, packed);
+            else mashDeviceArrays.allocateDeviceArrays(dev, packed);
+        } else {
+            if (aligned) msaDeviceArrays.allocateDeviceArrays(dev, seqs, ids);
+            else mashDeviceArrays.allocateDeviceArrays(dev, seqs, ids);
+        }
         std::cerr << "Input in: " << ms_since(inputStart) << " ms\n";
         auto createArrayStart = std::chrono::high_resolution_clock::now();
         if (!aligned) {
@@ -353,12 +402,14 @@ int main(int argc, char** argv)
             auto t0 = std::chrono::high_resolution_clock::now();
             NJDeviceArrays njDeviceArrays;
             njDeviceArrays.getDismatrix(dev, (int)numSequences, params, nullptr);
+            if (std::getenv("DPR_CLI_TIMING")) std::cerr << "  getDismatrix call " << ms_since(t0) << " ms\n";
             njDeviceArrays.findNeighbourJoiningTree(dev, names, *output_);
             std::cerr << "Tree Created in: " << ms_since(t0) << " ms\n";
         }
         // the tree is written: close the output and leave without tearing down ~15 GB of device buffers
         // and the HIP runtime one by one (the driver reclaims them with the process)
         output_.reset();
+        if (std::getenv("DPR_CLI_TIMING")) std::cerr << "Main in: " << ms_since(inputStart) << " ms\n";
         std::cerr.flush();
         std::fflush(nullptr);
         _exit(0);

@@ -117,6 +117,11 @@ int dpr_sketch(dpr_ctx *ctx, int k, int S, uint64_t *host_sketches);
  * and calculateU (:94-115).  Builds the (sharded) symmetric fp64 matrix and the row sums U. */
 int dpr_dist_matrix(dpr_ctx *ctx, int source, int dist_type, int k);
 
+/* Optional: allocate the matrix buffers of a following dpr_dist_matrix over n tips now (cudaMalloc of the n x n matrix
+ * in NJDeviceArrays::getDismatrix, src/neighborJoining.cu:41-56); dpr_dist_matrix then finds them in place.  Lets the
+ * CLI overlap the allocation with the packing of the input. */
+int dpr_reserve_nj(dpr_ctx *ctx, int64_t n);
+
 /* ---- neighbor joining: NJDeviceArrays::findNeighbourJoiningTree (src/neighborJoining.cu:197-249)
  * without the Newick print.  Outputs (host, N-2 entries each): merged matrix slots x<y and the two
  * branch lengths per iteration; *last_d = D[0][1] of the final pair.  max_iters<0 runs all N-2
@@ -161,6 +166,9 @@ int dpr_ctx_set_nj_virtual_shards(dpr_ctx *ctx, int w);
 int dpr_ctx_set_nj_kernel_timing(dpr_ctx *ctx, int stride);
 int dpr_get_nj_kernel_timing(dpr_ctx *ctx, int *kernels, double *us_avg4, int64_t *samples);
 const char *dpr_nj_kernel_name(int idx);
+/* debug, needs DPR_NJ_PHASES=<iteration>: 2 kernels x 2048 blocks x 8 phase stamps (100 MHz ticks, 0 = none) of that
+ * iteration of the last pruned NJ run (profiles/nj_phases.py) */
+int dpr_get_nj_phase_stamps(uint64_t *out32768);
 /* host-only: owner of the 16-row x 512-column unit (strip = column block, group = row group) among `world` ranks
  * when the position space has P positions; -1 if the unit holds no pair of the strict lower triangle */
 int dpr_njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world);
