@@ -68,12 +68,17 @@ __host__ __device__ inline int64_t unit_total(int64_t P)
     return S > 0 ? unit_prefix(S, G16) : 0;
 }
 
-// unit ownership of the unit-sharded mode (also exported for the CPU tests of the N > 1 logic)
+// Unit ownership of the unit-sharded mode (also exported for the CPU tests of the N > 1 logic).  Units are tested in
+// blocks of one strip x 256 consecutive row groups (strip-major); test block t belongs to rank t mod world, and with it
+// its units -- so a rank launches (and pays for) only its own share of the test blocks.
 int njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world)
 {
     const int64_t G16 = (P + kUR - 1) / kUR;
     if (strip < 0 || group < 0 || group >= G16 || group < 32 * strip || strip * kTileCols >= P - 1 || world < 1) return -1;
-    return (int)((strip * G16 + group) % world);
+    int64_t t = 0;
+    for (int64_t c = 0; c < strip; ++c) t += (G16 - 32 * c + kThreads - 1) / kThreads;     // test blocks of the strips before
+    t += (group - 32 * strip) / kThreads;
+    return (int)(t % world);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -173,10 +178,11 @@ __global__ __launch_bounds__(kThreads) void njp_list_all_kernel(NjpArgs a)
     const int tid = threadIdx.x;
     const int64_t it = a.st->it;
     if (a.st->status != 0) return;
-    const int cb = a.blk_cb[blockIdx.x];
-    const int64_t g = (int64_t)a.blk_g0[blockIdx.x] + tid;
+    const int tb = a.sh_rank + (int)blockIdx.x * a.sh_world;      // this rank's blockIdx.x-th test block
+    const int cb = a.blk_cb[tb];
+    const int64_t g = (int64_t)a.blk_g0[tb] + tid;
     const int64_t G16 = (a.P + kUR - 1) / kUR;
-    const bool keep = g < G16 && (a.sh_world <= 1 || (int)(((int64_t)cb * G16 + g) % a.sh_world) == a.sh_rank);
+    const bool keep = g < G16;
     const unsigned long long mask = __ballot(keep);
     const int lane = tid & 63;
     unsigned long long base = 0;
@@ -434,6 +440,7 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
     __shared__ double sseed[kThreads / 64], scm[kThreads / 64], snew[kThreads / 64];
     const int tid = threadIdx.x;
     const bool test_block = (int)blockIdx.x < a.ntest;
+    const int tb = test_block ? a.sh_rank + (int)blockIdx.x * a.sh_world : 0;      // this rank's blockIdx.x-th test block
     // hop 1: state line, scan records, and what each role can address without knowing the winner
     const int64_t it = a.st->itb;   // stable: the writer below only advances st->it
     const int64_t limit = a.st->it_limit, N = a.st->N;
@@ -477,10 +484,10 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
     ulonglong2 um0 = make_ulonglong2(0ull, 0ull), um1 = um0;
     unsigned long long* up4 = a.umin;
     if (test_block) {
-        cb = a.blk_cb[blockIdx.x];
-        g = (int64_t)a.blk_g0[blockIdx.x] + tid;
+        cb = a.blk_cb[tb];
+        g = (int64_t)a.blk_g0[tb] + tid;
         have = g < G16;
-        rbase = (int64_t)a.blk_g0[blockIdx.x] * kUR;
+        rbase = (int64_t)a.blk_g0[tb] * kUR;
         pc0 = (int64_t)cb * kTileCols + 2 * tid;                      // this thread's two strip columns (< P + 512)
         up4 = a.umin + ((int64_t)cb * G16 + (have ? g : 0)) * 4;
         if (have) { um0 = *reinterpret_cast<const ulonglong2*>(up4); um1 = *reinterpret_cast<const ulonglong2*>(up4 + 2); }
@@ -601,7 +608,7 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
     const double* __restrict__ Rz = a.R + ((it + 1) & 1) * a.vstride;        // written by POST(it - 1)
     const bool pz_strip = fold && pz / kTileCols == cb;                      // block-uniform
     const int64_t gz = fold ? pz / kUR : -1;
-    const bool gz_here = fold && gz >= (int64_t)a.blk_g0[blockIdx.x] && gz < (int64_t)a.blk_g0[blockIdx.x] + kThreads;   // block-uniform
+    const bool gz_here = fold && gz >= (int64_t)a.blk_g0[tb] && gz < (int64_t)a.blk_g0[tb] + kThreads;   // block-uniform
     const int wpz = fold ? (int)((pz % kTileCols) / (kTileCols / 4)) : -1;   // sub-strip of that node's column
     v2d dxr[8], dyr[8];
 #pragma unroll
@@ -700,7 +707,7 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
 #pragma unroll
         for (int k = 0; k < kUR; ++k) newminA = fmin(newminA, s_un[17 * tid + k]);
     }
-    const bool own = have && (a.sh_world <= 1 || (int)(((int64_t)cb * G16 + g) % a.sh_world) == a.sh_rank);
+    const bool own = have;      // (a rank launches only its own test blocks)
     int submask = 0;
     if (own) {
 #pragma unroll
@@ -997,7 +1004,8 @@ static NjpArgs njp_args(NjBuffers& b, int v)
     a.Ur = q.Ur; a.KA = q.KA; a.KB = q.KB; a.slot_of_pos = q.slot_of_pos; a.pos_of_slot = q.pos_of_slot;
     a.xpart = b.xpart; a.partials = b.partials; a.umin = (unsigned long long*)q.umin;
     a.P = q.P;
-    a.blk_cb = q.blk_cb; a.blk_g0 = q.blk_g0; a.ntest = q.nprep;
+    a.blk_cb = q.blk_cb; a.blk_g0 = q.blk_g0;
+    a.ntest = sh ? (q.nprep - v + q.sh_world - 1) / q.sh_world : q.nprep;     // test blocks v, v + world, ... are this rank's
     a.list = q.list + (int64_t)slot * q.list_stride;
     a.cnt = sh ? q.cnt_all + 4 * slot : b.st->cnt_list;
     a.ugrid = njp_grid_rank(q);
@@ -1030,6 +1038,7 @@ static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
     NjpArgs a = njp_args(b, v);
     a.do_update = update ? 1 : 0;
     const unsigned ublocks = update ? (unsigned)((b.N + kThreads - 1) / kThreads) : 0u;
+    if ((unsigned)a.ntest + ublocks == 0u) return DPR_OK;      // (a rank without test blocks in a tests-only launch)
     hipLaunchKernelGGL(njp_post_kernel, dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
@@ -1094,7 +1103,7 @@ static int njp_run_segment(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t 
     if (q.fresh) {      // first scan of an epoch: every unit
         for (int v = v0; v < v1; ++v) {
             NjpArgs a = njp_args(b, v);
-            hipLaunchKernelGGL(njp_list_all_kernel, dim3((unsigned)a.ntest), dim3(kThreads), 0, s, a);
+            if (a.ntest > 0) hipLaunchKernelGGL(njp_list_all_kernel, dim3((unsigned)a.ntest), dim3(kThreads), 0, s, a);
         }
         DPR_HIP(hipGetLastError());
         q.fresh = false;

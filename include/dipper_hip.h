@@ -170,7 +170,9 @@ const char *dpr_nj_kernel_name(int idx);
  * iteration of the last pruned NJ run (profiles/nj_phases.py) */
 int dpr_get_nj_phase_stamps(uint64_t *out32768);
 /* host-only: owner of the 16-row x 512-column unit (strip = column block, group = row group) among `world` ranks
- * when the position space has P positions; -1 if the unit holds no pair of the strict lower triangle */
+ * when the position space has P positions (units are tested in blocks of one strip x 256 consecutive row groups,
+ * strip-major; test block t and its units belong to rank t mod world); -1 if the unit holds no pair of the strict
+ * lower triangle */
 int dpr_njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world);
 /* pruned path: 16x512 units scanned since dpr_dist_matrix, and units of one full scan */
 int dpr_get_prune_stats(dpr_ctx *ctx, uint64_t *units_scanned, uint64_t *units_per_full_scan);

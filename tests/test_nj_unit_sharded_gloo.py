@@ -60,13 +60,30 @@ def _worker(rank, world, port, D, out_q):
         Ur = U / float(n - 2)
         best = (10000.0, 2**64 - 1, 0.0)
         for (strip, group) in mine:
-            for a in range(16 * group, min(16 * group + 16, n)):
-                for b in range(512 * strip, min(512 * strip + 512, a)):
-                    d = M[a, b]
-                    for (i, j, q) in ((a, b, (d - Ur[a]) - Ur[b]), (b, a, (d - Ur[b]) - Ur[a])):
-                        k = L.dpr_nj_key(i, j, n)
-                        if q < best[0] or (q == best[0] and k < best[1]):
-                            best = (q, k, d)
+            a0, a1 = 16 * group, min(16 * group + 16, n)
+            b0, b1 = 512 * strip, min(512 * strip + 512, n)
+            if a0 >= a1 or b0 >= b1 or b0 >= a1 - 1 + 1:
+                continue
+            A = np.arange(a0, a1)[:, None]
+            B = np.arange(b0, b1)[None, :]
+            valid = B < A
+            if not valid.any():
+                continue
+            d = M[a0:a1, b0:b1]
+            q1 = (d - Ur[a0:a1, None]) - Ur[None, b0:b1]          # (i = a, j = b)
+            q2 = (d - Ur[None, b0:b1]) - Ur[a0:a1, None]          # (i = b, j = a)
+            q1 = np.where(valid, q1, np.inf)
+            q2 = np.where(valid, q2, np.inf)
+            m = min(q1.min(), q2.min())
+            if m > best[0]:
+                continue
+            for qq, swap in ((q1, False), (q2, True)):
+                for ia, ib in zip(*np.nonzero(qq == m)):
+                    a, b = a0 + int(ia), b0 + int(ib)
+                    i, j = (b, a) if swap else (a, b)
+                    k = L.dpr_nj_key(i, j, n)
+                    if m < best[0] or (m == best[0] and k < best[1]):
+                        best = (float(m), k, float(d[ia, ib]))
         rec = np.zeros(1, dtype=rec_t)
         rec["q"], rec["key"], rec["d"] = best
         t = torch.from_numpy(np.frombuffer(rec.tobytes(), dtype=np.uint8).copy())
@@ -119,7 +136,7 @@ def _worker(rank, world, port, D, out_q):
 
 def test_unit_sharded_nj_two_ranks_gloo(orc):
     rng = np.random.default_rng(23)
-    n = 70
+    n = 530           # two column strips -> two test blocks of the product's ownership rule, one per rank
     D = _util.random_additive_matrix(rng, n, zero_frac=0.3)
     D = np.round(D, 2)                      # ties: the key order decides
     ref = orc.nj_run(np.tril(D, -1))
