@@ -208,34 +208,52 @@ __global__ __launch_bounds__(kThreads) void place_build_cont_kernel(PlaceBuffers
     p.cont[2 * sl] = c[0]; p.cont[2 * sl + 1] = c[1];
 }
 
-// Closest lists of an imported backbone, all slots in parallel.  The reference inserts the leaves one
-// after the other (m single-thread BFS launches, src/placement_close_k.cu:247-260); the lists it ends with
-// are, for every slot u->v, the five leaves x behind u with the smallest path length d_u(x) < 2 (the lists
-// start at the sentinel 2 and take x only while `entry > d`), ties by leaf id (= insertion order), where
-// d is accumulated from the leaf outwards: d_u(x) = d_w(x) + len[slot w->u].  A leaf that misses a list
-// cannot be in any list farther along (the leaves ahead of it are also ahead there), so the BFS pruning
-// does not change that set.  Hence one relaxation round recomputes every list from the lists of the slots
-// entering u (plus the leaf u itself), double-buffered, until nothing changes: #rounds = tree diameter in
-// edges instead of m dependent launches.
-__global__ __launch_bounds__(kThreads) void place_lists_round_kernel(PlaceBuffers p, const int32_t* __restrict__ cid_in,
-                                                                     const double* __restrict__ cdis_in,
-                                                                     int32_t* __restrict__ cid_out,
-                                                                     double* __restrict__ cdis_out, int64_t nslots,
-                                                                     int64_t m, int* __restrict__ changed)
+// Closest lists of an imported backbone without m dependent launches, EXACTLY as the reference builds them.
+// The reference inserts the leaves one after the other (m single-thread BFS launches, src/placement_close_k.cu:
+// 247-260): leaf x, coming from slot w->u with distance d, is offered to list[u->v] (five entries, sorted, start
+// value 2, an entry gives way only to a strictly smaller distance) and continues behind v only if it entered.  So the
+// leaves ARRIVE at a slot in ascending leaf id, a leaf PASSES a slot iff it entered the list as it stood at its turn,
+// and the arrivals of u->v are the passers of the slots w->u (w != v) with len[w->u] added -- a recurrence over the
+// directed edges of the tree, which form a DAG (depth = tree diameter).  place_lists_level_kernel evaluates it level
+// by level: a slot whose feeding slots are done merges their passer sequences by leaf id, replays the five-entry
+// insertion over the merged arrivals, keeps the leaves that entered (its own passer sequence, at most kPassCap) and
+// writes the final list.  Same lists as the serial order bit for bit, including the ties that floating-point rounding
+// of d + len creates downstream of distinct distances (a plain "five smallest by (distance, id)" relaxation -- round 1's
+// first version -- gets those wrong: a leaf evicted upstream can tie with its evictors after the addition and, having
+// arrived first, stay ahead of them; found by tests/test_gpu_fullsize.py::test_config4_add_50k_onto_500k).
+constexpr int kPassCap = 128;
+__global__ __launch_bounds__(kThreads) void place_lists_level_kernel(PlaceBuffers p, int32_t* __restrict__ level,
+                                                                     int32_t* __restrict__ pcnt, int32_t* __restrict__ pid,
+                                                                     double* __restrict__ pdis, int round, int64_t nslots,
+                                                                     int64_t m, int* __restrict__ flags)
 {
     const int64_t s = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (s >= nslots) return;
+    if (s >= nslots || level[s] >= 0) return;
     const int u = p.belong[s];
+    // feeding slots w -> u (all but the reverse of s): done in an EARLIER round?
+    constexpr int kMaxIn = 8;
+    int in[kMaxIn], nin = 0;
+    bool ready = true, many = false;
+    for (int o = p.head[u]; o != -1; o = p.nxt[o]) {
+        if (o == (int)s) continue;
+        const int w = p.rev[o];
+        const int lv = level[w];
+        if (lv < 0 || lv >= round) ready = false;
+        if (nin < kMaxIn) in[nin++] = w; else many = true;
+    }
+    if (!ready) return;
+    if (many) { flags[1] = 1; return; }                 // node of degree > 9: leave it to the serial order
     double bd[K5];
     int bi[K5];
 #pragma unroll
     for (int j = 0; j < K5; ++j) { bd[j] = 2.0; bi[j] = -1; }
-    auto offer = [&](int x, double d) {
-        if (!(2.0 > d)) return;                                   // the sentinel 2 never gives way to d >= 2
+    int npass = 0;
+    bool overflow = false;
+    auto arrive = [&](int x, double d) {
         int pos = K5;
 #pragma unroll
         for (int j = K5 - 1; j >= 0; --j)
-            if (bd[j] > d || (bd[j] == d && (bi[j] == -1 || bi[j] > x))) pos = j;
+            if (bd[j] > d) pos = j;                       // first entry strictly farther (list_insert)
         if (pos == K5) return;
 #pragma unroll
         for (int j = K5 - 1; j > 0; --j)
@@ -243,26 +261,34 @@ __global__ __launch_bounds__(kThreads) void place_lists_round_kernel(PlaceBuffer
 #pragma unroll
         for (int j = 0; j < K5; ++j)
             if (j == pos) { bd[j] = d; bi[j] = x; }
+        if (npass < kPassCap) { pid[s * kPassCap + npass] = x; pdis[s * kPassCap + npass] = d; }
+        else overflow = true;
+        ++npass;
     };
-    if (u < m) offer(u, 0.0);                                     // u is a backbone leaf
-    for (int o = p.head[u]; o != -1; o = p.nxt[o]) {
-        if (o == (int)s) continue;
-        const int in = p.rev[o];                                  // slot w -> u
-        const double L = p.len[in];
-        for (int j = 0; j < K5; ++j) {
-            const int x = cid_in[in * K5 + j];
-            if (x == -1) break;
-            offer(x, cdis_in[in * K5 + j] + L);
-        }
+    // merge of the feeding passer sequences (each ascending in leaf id) with the leaf u itself (a backbone leaf has no
+    // feeding slot; its own arrival has distance 0)
+    int hd[kMaxIn], cn[kMaxIn];
+    double ln[kMaxIn];
+    for (int k = 0; k < nin; ++k) { hd[k] = 0; cn[k] = pcnt[in[k]]; ln[k] = p.len[in[k]]; if (cn[k] > kPassCap) cn[k] = kPassCap; }
+    bool self = u < m;
+    for (;;) {
+        int best = -1, bx = 0x7fffffff;
+        for (int k = 0; k < nin; ++k)
+            if (hd[k] < cn[k]) {
+                const int x = pid[(int64_t)in[k] * kPassCap + hd[k]];
+                if (x < bx) { bx = x; best = k; }
+            }
+        if (self && u < bx) { arrive(u, 0.0); self = false; continue; }
+        if (best < 0) break;
+        arrive(bx, pdis[(int64_t)in[best] * kPassCap + hd[best]] + ln[best]);
+        ++hd[best];
     }
-    bool diff = false;
+    pcnt[s] = npass;
+    if (overflow) flags[1] = 1;
 #pragma unroll
-    for (int j = 0; j < K5; ++j) {
-        diff |= (cid_in[s * K5 + j] != bi[j]) || (cdis_in[s * K5 + j] != bd[j]);
-        cid_out[s * K5 + j] = bi[j];
-        cdis_out[s * K5 + j] = bd[j];
-    }
-    if (diff) *changed = 1;
+    for (int j = 0; j < K5; ++j) { p.cid[s * K5 + j] = bi[j]; p.cdis[s * K5 + j] = bd[j]; }
+    level[s] = round;
+    flags[0] = 1;                                         // progress
 }
 
 // closest lists of an imported backbone: leaves 0..m-1 in order (src/placement_close_k.cu:247-260)
@@ -578,35 +604,42 @@ int place_import_backbone(PlaceBuffers& p, int64_t m, hipStream_t s)
     hipLaunchKernelGGL(place_pair_rev_kernel, dim3((unsigned)((nslots + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, nslots);
     hipLaunchKernelGGL(place_build_cont_kernel, dim3((unsigned)((nslots + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, nslots);
     DPR_HIP(hipGetLastError());
-    // parallel relaxation rounds (see place_lists_round_kernel), double-buffered; the flag is read every 16 rounds
+    // level-by-level evaluation of the serial order's recurrence (see place_lists_level_kernel); the progress flag is
+    // read every 16 rounds
     const bool serial = std::getenv("DPR_IMPORT_SERIAL") != nullptr;
     bool converged = false;
     if (!serial) {
-        int32_t* cid2 = nullptr; double* cdis2 = nullptr; int* d_changed = nullptr;
-        DPR_HIP(hipMalloc(&cid2, sizeof(int32_t) * (size_t)(nslots * K5)));
-        DPR_HIP(hipMalloc(&cdis2, sizeof(double) * (size_t)(nslots * K5)));
-        DPR_HIP(hipMalloc(&d_changed, sizeof(int)));
+        int32_t *level = nullptr, *pcnt = nullptr, *pid = nullptr;
+        double* pdis = nullptr;
+        int* d_flags = nullptr;
+        auto release = [&]() { void* q[] = { level, pcnt, pid, pdis, d_flags }; for (void* x : q) if (x) (void)hipFree(x); };
+        hipError_t ae = hipMalloc(&level, sizeof(int32_t) * (size_t)nslots);
+        if (ae == hipSuccess) ae = hipMalloc(&pcnt, sizeof(int32_t) * (size_t)nslots);
+        if (ae == hipSuccess) ae = hipMalloc(&pid, sizeof(int32_t) * (size_t)nslots * kPassCap);
+        if (ae == hipSuccess) ae = hipMalloc(&pdis, sizeof(double) * (size_t)nslots * kPassCap);
+        if (ae == hipSuccess) ae = hipMalloc(&d_flags, 2 * sizeof(int));
+        if (ae != hipSuccess) { release(); return hip_fail(ae, "place_import_backbone: hipMalloc"); }
+        DPR_HIP(hipMemsetAsync(level, 0xff, sizeof(int32_t) * (size_t)nslots, s));
+        DPR_HIP(hipMemsetAsync(pcnt, 0, sizeof(int32_t) * (size_t)nslots, s));
         const unsigned grid = (unsigned)((nslots + kThreads - 1) / kThreads);
-        const int max_rounds = 4096;
+        const int max_rounds = 8192;
         int rounds = 0, rc = DPR_OK;
-        while (rounds < max_rounds && !converged) {
-            DPR_HIP(hipMemsetAsync(d_changed, 0, sizeof(int), s));
-            for (int k = 0; k < 16; ++k, ++rounds) {     // even number: the result of a batch is in p.cid / p.cdis
-                const bool fwd = (k & 1) == 0;
-                hipLaunchKernelGGL(place_lists_round_kernel, dim3(grid), dim3(kThreads), 0, s, p,
-                                   fwd ? (const int32_t*)p.cid : (const int32_t*)cid2, fwd ? (const double*)p.cdis : (const double*)cdis2,
-                                   fwd ? cid2 : p.cid, fwd ? cdis2 : p.cdis, nslots, m, d_changed);
-            }
-            int h = 1;
-            if (hipMemcpyAsync(&h, d_changed, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rc = DPR_ERR_HIP; break; }
-            // no change in the last batch: fixed point (a batch whose first rounds still changed lists sets the flag)
-            converged = (h == 0);
+        bool bail = false;
+        while (rounds < max_rounds && !converged && !bail) {
+            DPR_HIP(hipMemsetAsync(d_flags, 0, 2 * sizeof(int), s));
+            for (int k = 0; k < 16; ++k, ++rounds)
+                hipLaunchKernelGGL(place_lists_level_kernel, dim3(grid), dim3(kThreads), 0, s, p, level, pcnt, pid, pdis, rounds, nslots, m, d_flags);
+            int h[2] = { 1, 1 };
+            if (hipMemcpyAsync(h, d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rc = DPR_ERR_HIP; break; }
+            if (h[1]) bail = true;                 // a passer sequence longer than kPassCap or a node of very high degree
+            else converged = (h[0] == 0);          // no slot finished in the last 16 rounds: all are done
         }
-        (void)hipFree(cid2); (void)hipFree(cdis2); (void)hipFree(d_changed);
-        if (rc) { set_error("place_import_backbone: relaxation rounds failed"); return rc; }
+        release();
+        if (rc) { set_error("place_import_backbone: level rounds failed"); return rc; }
+        if (bail) converged = false;
     }
     if (!converged) {
-        // very deep trees (diameter > 4096 edges) or DPR_IMPORT_SERIAL: the reference's order, leaf by leaf
+        // very deep trees (diameter > 8192 edges), overlong passer sequences or DPR_IMPORT_SERIAL: the reference's order, leaf by leaf
         hipLaunchKernelGGL(place_init_lists_kernel, dim3((unsigned)((lim + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, lim);
         const int64_t chunk = 4096;
         for (int64_t t0 = 0; t0 < m; t0 += chunk) {

@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage (GPU box): bash profiles/pmc_kernel.sh <tag> "<counters>" <kernel substring> -- <python script args...>
+# one rocprofv3 --pmc pass (with --kernel-trace only); prints the per-dispatch mean of every counter for the kernel
 TAG=$1; CNT=$2; KSUB=$3; shift 3; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
@@ -11,5 +12,6 @@ acc=collections.defaultdict(list)
 for r in csv.DictReader(open('$OUT/p_counter_collection.csv')):
     if '$KSUB' in r['Kernel_Name']:
         acc[r['Counter_Name']].append(float(r['Counter_Value']))
-for k,v in acc.items(): print(k, len(v), 'mean %.3e'%(sum(v)/len(v)))
+for k,v in sorted(acc.items()): print('$TAG', k, len(v), 'mean %.4e'%(sum(v)/len(v)))
 PY
+rm -f $OUT/p_kernel_trace.csv

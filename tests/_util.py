@@ -61,6 +61,47 @@ def synth_alignment(rng, n, L, mean_bl=2e-4, lo=2e-5, hi=2e-3, invalid_frac=0.0)
     return res
 
 
+def synth_reads(rng, n, L, mean_bl=2e-4, lo=2e-5, hi=2e-3, ins_rate=0.03, del_rate=0.09, mean_indel=2.0):
+    """Unaligned counterpart of synth_alignment for the Mash inputs: the same JC69 substitutions down a Yule tree plus
+    insertions and deletions at `ins_rate` / `del_rate` events per substitution (scripts/alisim.sh:14 of the reference
+    passes `--indel 0.03,0.09` to iqtree2's alisim), geometric lengths with mean `mean_indel`.  Returns n byte strings
+    of different lengths."""
+    parent, children, leaves = yule_tree(rng, n)
+    nn = len(parent)
+    seq = [None] * nn
+    seq[0] = rng.integers(0, 4, size=L, dtype=np.uint8)
+    pending = [0]
+    out = {}
+    pgeo = 1.0 / max(mean_indel, 1.0)
+    while pending:
+        node = pending.pop()
+        s = seq[node]
+        if not children[node]:
+            out[node] = s
+            seq[node] = None
+            continue
+        for c in children[node]:
+            bl = float(np.clip(rng.exponential(mean_bl), lo, hi))
+            t = s.copy()
+            k = rng.poisson(len(t) * bl)
+            if k:
+                pos = rng.integers(0, len(t), size=k)
+                t[pos] = (t[pos] + rng.integers(1, 4, size=k, dtype=np.uint8)) & 3
+            for _ in range(rng.poisson(len(t) * bl * del_rate)):
+                m = int(rng.geometric(pgeo))
+                if len(t) > m + 32:
+                    p0 = int(rng.integers(0, len(t) - m))
+                    t = np.delete(t, np.s_[p0:p0 + m])
+            for _ in range(rng.poisson(len(t) * bl * ins_rate)):
+                m = int(rng.geometric(pgeo))
+                p0 = int(rng.integers(0, len(t) + 1))
+                t = np.insert(t, p0, rng.integers(0, 4, size=m, dtype=np.uint8))
+            seq[c] = t
+            pending.append(c)
+        seq[node] = None
+    return [BASES[out[leaf]].tobytes() for leaf in leaves]
+
+
 def random_additive_matrix(rng, n, zero_frac=0.0):
     """Patristic distance matrix of a random binary tree with n tips (exact tree metric up to fp
     rounding).  zero_frac of the branches get length 0 (ties, as in near-clonal data)."""

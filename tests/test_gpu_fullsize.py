@@ -113,6 +113,87 @@ def test_config3_divide_and_conquer_1m():
     assert full["stats"]["clusters"] == int((sizes > 0).sum())
 
 
+def _renumber_nodes(st, n_from, n_to):
+    """Adjacency of an imported backbone built for n_from tips -> the same tree for n_to tips: internal node ids start
+    at the tip count (src/tree.cpp:216-361 with another totalLeaves); slots, lengths and leaf ids are unchanged."""
+    out = {}
+    for key in ("e", "belong"):
+        a = st[key].copy()
+        a[a >= n_from] += n_to - n_from
+        out[key] = np.full(8 * n_to, -1, np.int32)
+        k = min(len(a), 8 * n_to)
+        out[key][:k] = a[:k]
+    for key, fill, dt in (("nxt", -1, np.int32), ("len", 2.0, np.float64)):
+        out[key] = np.full(8 * n_to, fill, dt)
+        k = min(len(st[key]), 8 * n_to)
+        out[key][:k] = st[key][:k]
+    head = np.full(2 * n_to, -1, np.int32)
+    m_leaves = min(n_from, n_to)
+    head[:m_leaves] = st["head"][:m_leaves]
+    internal = st["head"][n_from:2 * n_from]
+    k = min(len(internal), n_to)
+    head[n_to:n_to + k] = internal[:k]
+    out["head"] = head
+    return out
+
+
+def test_config4_add_50k_onto_500k(orc):
+    """BASELINE configs[4] at its workload on one GPU (aligned input, 300 sites): --add of 50 000 queries onto a
+    500 000-tip backbone (initializeDeviceArrays + addQuery, src/placement_close_k.cu:126-264,858-990).
+    Size-independent properties: (a) the closest lists the import builds (parallel relaxation rounds) equal the oracle's
+    leaf-by-leaf order on ALL 2 000 000 slots; (b) the result is a binary tree over all 550 000 tips; (c) the trace of
+    the first 10 000 queries (edge, split position, pendant length) does not depend on the 40 000 later ones."""
+    import sys
+    import dipper_amd
+    from dipper_amd import capi
+    sys.setrecursionlimit(max(sys.getrecursionlimit(), 100000))
+    m, nq, q1, L = 500000, 50000, 10000, 300
+    n = m + nq
+    seqs = _util.synth_alignment(np.random.default_rng(5), n, L, mean_bl=2e-3, lo=2e-4, hi=2e-2)
+    seqs = [seqs[i] for i in np.random.default_rng(6).permutation(n)]
+    d = dipper_amd.Dipper(0)
+    try:
+        # backbone tree of the first m tips (divide-and-conquer run), written and re-imported like the CLI's -t file
+        d.set_msa(capi.pack4_many(seqs[:m]), L)
+        bb = d.dc_run(capi.SRC_MSA, m, m // 20, dist_type=capi.DIST_JC)
+        names = ["T%d" % i for i in range(n)]
+        nwk = _util.newick_from_placement(names[:m], bb["head"], bb["e"], bb["nxt"], bb["len"], m)
+        del bb
+        st, leaf_names = _util.backbone_state(orc, nwk, n)          # Tree::Tree ids + adjacency
+        order = [int(x[1:]) for x in leaf_names]                     # backbone tips in import order, then the queries
+        packed = capi.pack4_many([seqs[i] for i in order] + seqs[m:])
+        del seqs
+        adj = ("head", "e", "nxt", "belong", "len")
+        # (a) the import alone (no query): closest lists vs the oracle's serial order
+        st_m = _renumber_nodes(st, n, m)
+        d.set_msa(packed[:m], L)
+        got = d.place_run(capi.SRC_MSA, m, first=m, dist_type=capi.DIST_JC, state={k: st_m[k].copy() for k in adj})
+        ref = {k: st_m[k].copy() for k in adj}
+        ref["cid"] = np.full(40 * m, -1, np.int32)
+        ref["cdis"] = np.full(40 * m, 2.0, np.float64)
+        orc.place_init_lists(m, m, ref)
+        live = 4 * m - 4
+        assert np.array_equal(got["cid"][:5 * live], ref["cid"][:5 * live])
+        assert np.array_equal(got["cdis"][:5 * live], ref["cdis"][:5 * live])
+        for key in adj:
+            assert np.array_equal(got[key][:(2 * m if key == "head" else live)], st_m[key][:(2 * m if key == "head" else live)]), key
+        del got, ref
+        # (b) all queries
+        d.set_msa(packed, L)
+        full = d.place_run(capi.SRC_MSA, n, first=m, dist_type=capi.DIST_JC, state={k: st[k].copy() for k in adj})
+        _tree_degrees_ok(full, n)
+        tr = full["trace"][m:]
+        assert np.all(tr[:, 0] >= 0) and np.all(tr[:, 0] < 4 * n - 4) and np.all(tr[:, 1] >= 0) and np.all(tr[:, 2] >= 0)
+        # (c) prefix property
+        n2 = m + q1
+        st2 = _renumber_nodes(st, n, n2)
+        d.set_msa(packed[:n2], L)
+        part = d.place_run(capi.SRC_MSA, n2, first=m, dist_type=capi.DIST_JC, state={k: st2[k].copy() for k in adj})
+        assert np.array_equal(full["trace"][m:n2], part["trace"][m:n2])
+    finally:
+        d.close()
+
+
 from tests.conftest import dirty_device_memory as _dirty_device_memory
 
 
