@@ -12,7 +12,9 @@
 // State layout mirrors the reference (forward-star adjacency head/e/nxt/belong/len, K=5 sorted
 // closest lists per directed edge) plus rev[slot] = reverse slot, which replaces the list walk of
 // src/placement_close_k.cu:339-340.
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "nj_dev.hpp"
 
@@ -216,15 +218,18 @@ __global__ __launch_bounds__(kThreads) void place_build_cont_kernel(PlaceBuffers
 // and the arrivals of u->v are the passers of the slots w->u (w != v) with len[w->u] added -- a recurrence over the
 // directed edges of the tree, which form a DAG (depth = tree diameter).  place_lists_level_kernel evaluates it level
 // by level: a slot whose feeding slots are done merges their passer sequences by leaf id, replays the five-entry
-// insertion over the merged arrivals, keeps the leaves that entered (its own passer sequence, at most kPassCap) and
-// writes the final list.  Same lists as the serial order bit for bit, including the ties that floating-point rounding
+// insertion over the merged arrivals, keeps the leaves that entered (its own passer sequence) and writes the final list.  Same lists as the serial order bit for bit, including the ties that floating-point rounding
 // of d + len creates downstream of distinct distances (a plain "five smallest by (distance, id)" relaxation -- round 1's
 // first version -- gets those wrong: a leaf evicted upstream can tie with its evictors after the addition and, having
 // arrived first, stay ahead of them; found by tests/test_gpu_fullsize.py::test_config4_add_50k_onto_500k).
-constexpr int kPassCap = 128;
+// Passer sequences have very different lengths (a handful near the leaves, a few hundred for slots that have most of the
+// tree behind them), so they live in one pool: a slot replays its arrivals twice, first to count, then -- after reserving its range with one
+// atomic add -- to store.
 __global__ __launch_bounds__(kThreads) void place_lists_level_kernel(PlaceBuffers p, int32_t* __restrict__ level,
-                                                                     int32_t* __restrict__ pcnt, int32_t* __restrict__ pid,
-                                                                     double* __restrict__ pdis, int round, int64_t nslots,
+                                                                     int32_t* __restrict__ pcnt, long long* __restrict__ poff,
+                                                                     int32_t* __restrict__ pid, double* __restrict__ pdis,
+                                                                     unsigned long long* __restrict__ pool_top,
+                                                                     unsigned long long pool_cap, int round, int64_t nslots,
                                                                      int64_t m, int* __restrict__ flags)
 {
     const int64_t s = (int64_t)blockIdx.x * kThreads + threadIdx.x;
@@ -243,48 +248,55 @@ __global__ __launch_bounds__(kThreads) void place_lists_level_kernel(PlaceBuffer
     }
     if (!ready) return;
     if (many) { flags[1] = 1; return; }                 // node of degree > 9: leave it to the serial order
+    int cn[kMaxIn];
+    long long of[kMaxIn];
+    double ln[kMaxIn];
+    for (int k = 0; k < nin; ++k) { cn[k] = pcnt[in[k]]; of[k] = poff[in[k]]; ln[k] = p.len[in[k]]; }
     double bd[K5];
     int bi[K5];
-#pragma unroll
-    for (int j = 0; j < K5; ++j) { bd[j] = 2.0; bi[j] = -1; }
-    int npass = 0;
-    bool overflow = false;
-    auto arrive = [&](int x, double d) {
-        int pos = K5;
-#pragma unroll
-        for (int j = K5 - 1; j >= 0; --j)
-            if (bd[j] > d) pos = j;                       // first entry strictly farther (list_insert)
-        if (pos == K5) return;
-#pragma unroll
-        for (int j = K5 - 1; j > 0; --j)
-            if (j > pos) { bd[j] = bd[j - 1]; bi[j] = bi[j - 1]; }
-#pragma unroll
-        for (int j = 0; j < K5; ++j)
-            if (j == pos) { bd[j] = d; bi[j] = x; }
-        if (npass < kPassCap) { pid[s * kPassCap + npass] = x; pdis[s * kPassCap + npass] = d; }
-        else overflow = true;
-        ++npass;
-    };
     // merge of the feeding passer sequences (each ascending in leaf id) with the leaf u itself (a backbone leaf has no
-    // feeding slot; its own arrival has distance 0)
-    int hd[kMaxIn], cn[kMaxIn];
-    double ln[kMaxIn];
-    for (int k = 0; k < nin; ++k) { hd[k] = 0; cn[k] = pcnt[in[k]]; ln[k] = p.len[in[k]]; if (cn[k] > kPassCap) cn[k] = kPassCap; }
-    bool self = u < m;
-    for (;;) {
-        int best = -1, bx = 0x7fffffff;
-        for (int k = 0; k < nin; ++k)
-            if (hd[k] < cn[k]) {
-                const int x = pid[(int64_t)in[k] * kPassCap + hd[k]];
-                if (x < bx) { bx = x; best = k; }
-            }
-        if (self && u < bx) { arrive(u, 0.0); self = false; continue; }
-        if (best < 0) break;
-        arrive(bx, pdis[(int64_t)in[best] * kPassCap + hd[best]] + ln[best]);
-        ++hd[best];
-    }
+    // feeding slot; its own arrival has distance 0), replaying list_insert; out != nullptr: the passers are stored
+    auto replay = [&](int32_t* out_id, double* out_d) -> int {
+#pragma unroll
+        for (int j = 0; j < K5; ++j) { bd[j] = 2.0; bi[j] = -1; }
+        int npass = 0;
+        int hd[kMaxIn];
+        for (int k = 0; k < nin; ++k) hd[k] = 0;
+        bool self = u < m;
+        for (;;) {
+            int best = -1, bx = 0x7fffffff;
+            for (int k = 0; k < nin; ++k)
+                if (hd[k] < cn[k]) {
+                    const int x = pid[of[k] + hd[k]];
+                    if (x < bx) { bx = x; best = k; }
+                }
+            int x;
+            double d;
+            if (self && u < bx) { x = u; d = 0.0; self = false; }
+            else if (best < 0) break;
+            else { x = bx; d = pdis[of[best] + hd[best]] + ln[best]; ++hd[best]; }
+            int pos = K5;
+#pragma unroll
+            for (int j = K5 - 1; j >= 0; --j)
+                if (bd[j] > d) pos = j;                   // first entry strictly farther (list_insert)
+            if (pos == K5) continue;
+#pragma unroll
+            for (int j = K5 - 1; j > 0; --j)
+                if (j > pos) { bd[j] = bd[j - 1]; bi[j] = bi[j - 1]; }
+#pragma unroll
+            for (int j = 0; j < K5; ++j)
+                if (j == pos) { bd[j] = d; bi[j] = x; }
+            if (out_id) { out_id[npass] = x; out_d[npass] = d; }
+            ++npass;
+        }
+        return npass;
+    };
+    const int npass = replay(nullptr, nullptr);
+    const unsigned long long off = atomicAdd(pool_top, (unsigned long long)npass);
+    if (off + (unsigned long long)npass > pool_cap) { flags[1] = 1; return; }      // pool exhausted: the serial order takes over
+    (void)replay(pid + off, pdis + off);
     pcnt[s] = npass;
-    if (overflow) flags[1] = 1;
+    poff[s] = (long long)off;
 #pragma unroll
     for (int j = 0; j < K5; ++j) { p.cid[s * K5 + j] = bi[j]; p.cdis[s * K5 + j] = bd[j]; }
     level[s] = round;
@@ -610,17 +622,25 @@ int place_import_backbone(PlaceBuffers& p, int64_t m, hipStream_t s)
     bool converged = false;
     if (!serial) {
         int32_t *level = nullptr, *pcnt = nullptr, *pid = nullptr;
+        long long* poff = nullptr;
         double* pdis = nullptr;
         int* d_flags = nullptr;
-        auto release = [&]() { void* q[] = { level, pcnt, pid, pdis, d_flags }; for (void* x : q) if (x) (void)hipFree(x); };
+        unsigned long long* pool_top = nullptr;
+        // (a slot pointing away from the root has nearly all leaves behind it: its passers are the 5-records of their
+        // distances in id order, O(5 ln m); measured mean over all slots of a 500 000-tip backbone: see DPR_IMPORT_LOG)
+        const unsigned long long pool_cap = (unsigned long long)nslots * 192ull;
+        auto release = [&]() { void* q[] = { level, pcnt, poff, pid, pdis, d_flags, pool_top }; for (void* x : q) if (x) (void)hipFree(x); };
         hipError_t ae = hipMalloc(&level, sizeof(int32_t) * (size_t)nslots);
         if (ae == hipSuccess) ae = hipMalloc(&pcnt, sizeof(int32_t) * (size_t)nslots);
-        if (ae == hipSuccess) ae = hipMalloc(&pid, sizeof(int32_t) * (size_t)nslots * kPassCap);
-        if (ae == hipSuccess) ae = hipMalloc(&pdis, sizeof(double) * (size_t)nslots * kPassCap);
+        if (ae == hipSuccess) ae = hipMalloc(&poff, sizeof(long long) * (size_t)nslots);
+        if (ae == hipSuccess) ae = hipMalloc(&pid, sizeof(int32_t) * (size_t)pool_cap);
+        if (ae == hipSuccess) ae = hipMalloc(&pdis, sizeof(double) * (size_t)pool_cap);
         if (ae == hipSuccess) ae = hipMalloc(&d_flags, 2 * sizeof(int));
+        if (ae == hipSuccess) ae = hipMalloc(&pool_top, sizeof(unsigned long long));
         if (ae != hipSuccess) { release(); return hip_fail(ae, "place_import_backbone: hipMalloc"); }
         DPR_HIP(hipMemsetAsync(level, 0xff, sizeof(int32_t) * (size_t)nslots, s));
         DPR_HIP(hipMemsetAsync(pcnt, 0, sizeof(int32_t) * (size_t)nslots, s));
+        DPR_HIP(hipMemsetAsync(pool_top, 0, sizeof(unsigned long long), s));
         const unsigned grid = (unsigned)((nslots + kThreads - 1) / kThreads);
         const int max_rounds = 8192;
         int rounds = 0, rc = DPR_OK;
@@ -628,18 +648,26 @@ int place_import_backbone(PlaceBuffers& p, int64_t m, hipStream_t s)
         while (rounds < max_rounds && !converged && !bail) {
             DPR_HIP(hipMemsetAsync(d_flags, 0, 2 * sizeof(int), s));
             for (int k = 0; k < 16; ++k, ++rounds)
-                hipLaunchKernelGGL(place_lists_level_kernel, dim3(grid), dim3(kThreads), 0, s, p, level, pcnt, pid, pdis, rounds, nslots, m, d_flags);
+                hipLaunchKernelGGL(place_lists_level_kernel, dim3(grid), dim3(kThreads), 0, s, p, level, pcnt, poff, pid, pdis, pool_top,
+                                   pool_cap, rounds, nslots, m, d_flags);
             int h[2] = { 1, 1 };
             if (hipMemcpyAsync(h, d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rc = DPR_ERR_HIP; break; }
-            if (h[1]) bail = true;                 // a passer sequence longer than kPassCap or a node of very high degree
+            if (h[1]) bail = true;                 // passer pool exhausted or a node of very high degree
             else converged = (h[0] == 0);          // no slot finished in the last 16 rounds: all are done
+        }
+        if (std::getenv("DPR_IMPORT_LOG")) {
+            std::vector<int32_t> hc((size_t)nslots);
+            (void)hipMemcpy(hc.data(), pcnt, sizeof(int32_t) * (size_t)nslots, hipMemcpyDeviceToHost);
+            int mx = 0; double sum = 0;
+            for (int32_t v : hc) { mx = v > mx ? v : mx; sum += v; }
+            std::fprintf(stderr, "[import] %d level rounds, bail %d, passer sequences: longest %d, mean %.1f\n", rounds, (int)bail, mx, sum / (double)nslots);
         }
         release();
         if (rc) { set_error("place_import_backbone: level rounds failed"); return rc; }
         if (bail) converged = false;
     }
     if (!converged) {
-        // very deep trees (diameter > 8192 edges), overlong passer sequences or DPR_IMPORT_SERIAL: the reference's order, leaf by leaf
+        // very deep trees (diameter > 8192 edges), an exhausted passer pool or DPR_IMPORT_SERIAL: the reference's order, leaf by leaf
         hipLaunchKernelGGL(place_init_lists_kernel, dim3((unsigned)((lim + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, lim);
         const int64_t chunk = 4096;
         for (int64_t t0 = 0; t0 < m; t0 += chunk) {
