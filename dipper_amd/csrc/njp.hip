@@ -454,13 +454,16 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
         const int idx = tid + k * kThreads;
         if (idx < nrec_all) mine[k] = a.partials[idx];
     }
-    // seed candidates of the test role: one unit record (every (urecs / 256)-th when all of them are defined) and one
-    // new-row record per thread
-    const int64_t sstride = a.all_defined && a.urecs >= 2 * kThreads ? a.urecs / kThreads : 1;
-    NjRecord candA = r0, candB = r0;
+    // seed candidate of the test role, ONE per thread (two fp64 divisions each): the last threads take the new-row
+    // records, the others a unit record (every sstride-th when all of them are defined)
+    const int nseed_rows = a.nrb < kThreads / 2 ? a.nrb : kThreads / 2;
+    const int nseed_units = kThreads - nseed_rows;
+    const int64_t sstride = a.all_defined && a.urecs >= 2 * nseed_units ? a.urecs / nseed_units : 1;
+    const bool seed_is_unit = tid < nseed_units;
+    NjRecord cand = r0;
     if (test_block) {
-        if ((int64_t)tid * sstride < a.urecs) candA = a.partials[(int64_t)tid * sstride];
-        if (tid < a.nrb) candB = a.partials[a.urecs + tid];
+        if (!seed_is_unit) cand = a.partials[a.urecs + (tid - nseed_units)];
+        else if ((int64_t)tid * sstride < a.urecs) cand = a.partials[(int64_t)tid * sstride];
     }
     const unsigned long long cnt_raw = a.all_defined ? (unsigned long long)a.urecs : a.cnt[it % 3];
     const int64_t uvalid = (int64_t)(cnt_raw < (unsigned long long)a.urecs ? cnt_raw : (unsigned long long)a.urecs);   // unit records written by SCAN(it)
@@ -516,8 +519,10 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
 
     // ---- select: reduce the records (thrust::min_element, src/neighborJoining.cu:214)
     double bq = 10000.0, d = 0.0; uint64_t bk = ~0ull, bp = 0;
+    const int nmine = (nrec_all + kThreads - 1) / kThreads;       // block-uniform: records per thread that exist at all
 #pragma unroll
-    for (int k = 0; k < kMine; ++k) best_update4(bq, bk, bp, d, mine[k].q, mine[k].key, mine[k].pad, mine[k].d);
+    for (int k = 0; k < kMine; ++k)
+        if (k < nmine) best_update4(bq, bk, bp, d, mine[k].q, mine[k].key, mine[k].pad, mine[k].d);
     for (int64_t idx = tid + kMine * kThreads; idx < nrec_all; idx += kThreads)
         if (idx < uvalid || idx >= a.urecs) best_update4(bq, bk, bp, d, a.partials[idx].q, a.partials[idx].key, a.partials[idx].pad, a.partials[idx].d);
     wave_best4(bq, bk, bp, d);
@@ -621,23 +626,19 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
     const v2d dxc = *reinterpret_cast<const v2d*>(rowx + pc0), dyc = *reinterpret_cast<const v2d*>(rowy + pc0);
     v2d rzc; rzc.x = PINF; rzc.y = PINF;
     if (gz_here) rzc = *reinterpret_cast<const v2d*>(Rz + pc0);
-    // seed candidates re-evaluated with the row sums after this merge
+    // seed candidate re-evaluated with the row sums after this merge
     double qc = PINF;
-    if ((int64_t)tid * sstride >= uvalid) candA.key = ~0ull;          // not written by this iteration's scan
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const NjRecord cand = k ? candB : candA;
-        if (cand.key != ~0ull) {
-            const int64_t ci = (int64_t)(cand.pad & 0xffffffffull), cj = (int64_t)(cand.pad >> 32);
-            // the record carries D of the pair; the entry is unchanged by this merge unless one end is x or y
-            if (ci < P && cj < P && ci != px && cj != px && ci != py && cj != py) {
-                const double uia = Uc[ci], uib = Uc[cj];
-                const double xa = rowx[ci], ya = rowy[ci], xb = rowx[cj], yb = rowy[cj];
-                const double ua = nj_unew(uia, xa, ya, nj_val(xa, ya, d)) / r1;
-                const double ub = nj_unew(uib, xb, yb, nj_val(xb, yb, d)) / r1;
-                const double qk = fmin((cand.d - ua) - ub, (cand.d - ub) - ua);
-                qc = qk == qk ? fmin(qc, qk) : qc;
-            }
+    if (seed_is_unit && (int64_t)tid * sstride >= uvalid) cand.key = ~0ull;          // not written by this iteration's scan
+    if (cand.key != ~0ull) {
+        const int64_t ci = (int64_t)(cand.pad & 0xffffffffull), cj = (int64_t)(cand.pad >> 32);
+        // the record carries D of the pair; the entry is unchanged by this merge unless one end is x or y
+        if (ci < P && cj < P && ci != px && cj != px && ci != py && cj != py) {
+            const double uia = Uc[ci], uib = Uc[cj];
+            const double xa = rowx[ci], ya = rowy[ci], xb = rowx[cj], yb = rowy[cj];
+            const double ua = nj_unew(uia, xa, ya, nj_val(xa, ya, d)) / r1;
+            const double ub = nj_unew(uib, xb, yb, nj_val(xb, yb, d)) / r1;
+            const double qk = fmin((cand.d - ua) - ub, (cand.d - ub) - ua);
+            qc = qk == qk ? qk : qc;
         }
     }
     NJP_STAMP(1, 3, true);
