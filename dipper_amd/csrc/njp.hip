@@ -40,6 +40,10 @@
 namespace dpr {
 
 constexpr int kUR = 16;  // rows per unit
+// row groups (= units of one strip) per test block of the post kernel: 64 below 50 000 positions (1024 row positions per
+// block: the row phase of a block is short, NJ 500 -> 482 ms at 30 000 tips), 256 above (fewer blocks, less repeated
+// column and record work where the kernel is throughput-bound: 26.7 vs 36.7 us per launch at 100 000 tips)
+__host__ __device__ inline int njp_tg(int64_t P) { return P < 50000 ? 64 : 256; }
 
 __device__ __forceinline__ uint64_t enc_f64(double x)
 {
@@ -69,15 +73,16 @@ __host__ __device__ inline int64_t unit_total(int64_t P)
 }
 
 // Unit ownership of the unit-sharded mode (also exported for the CPU tests of the N > 1 logic).  Units are tested in
-// blocks of one strip x 256 consecutive row groups (strip-major); test block t belongs to rank t mod world, and with it
+// blocks of one strip x njp_tg(P) consecutive row groups (strip-major); test block t belongs to rank t mod world, and with it
 // its units -- so a rank launches (and pays for) only its own share of the test blocks.
 int njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world)
 {
     const int64_t G16 = (P + kUR - 1) / kUR;
     if (strip < 0 || group < 0 || group >= G16 || group < 32 * strip || strip * kTileCols >= P - 1 || world < 1) return -1;
     int64_t t = 0;
-    for (int64_t c = 0; c < strip; ++c) t += (G16 - 32 * c + kThreads - 1) / kThreads;     // test blocks of the strips before
-    t += (group - 32 * strip) / kThreads;
+    const int64_t tg = njp_tg(P);
+    for (int64_t c = 0; c < strip; ++c) t += (G16 - 32 * c + tg - 1) / tg;     // test blocks of the strips before
+    t += (group - 32 * strip) / tg;
     return (int)(t % world);
 }
 
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(kThreads) void njp_list_all_kernel(NjpArgs a)
     const int cb = a.blk_cb[tb];
     const int64_t g = (int64_t)a.blk_g0[tb] + tid;
     const int64_t G16 = (a.P + kUR - 1) / kUR;
-    const bool keep = g < G16;
+    const bool keep = g < G16 && tid < njp_tg(a.P);
     const unsigned long long mask = __ballot(keep);
     const int lane = tid & 63;
     unsigned long long base = 0;
@@ -432,6 +437,7 @@ __global__ __launch_bounds__(kThreads) void njp_finish_kernel(NjpArgs a)
 //    the same way; the row of the node that LEAVES quarantine (merge it - 1, row buffer R[(it - 1) & 1]) is
 //    folded into the bounds of the sub-units it crosses; survivors are appended to the list of scan it + 1.
 // ------------------------------------------------------------------------------------------------
+template <int kTG>
 __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
 {
     __shared__ double s[kThreads];
@@ -476,26 +482,27 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
     const int64_t i = (int64_t)((int)blockIdx.x - a.ntest) * kThreads + tid;     // reference slot
     int64_t p = -1;
     double up = 0.0;
-    // test role: the block's 256 row groups are 4096 consecutive positions, read COALESCED in 8 chunks of 512 (thread t:
+    // test role: the block's kTG row groups are 2048 consecutive positions, read COALESCED in chunks of 512 (thread t:
     // positions rbase + 512 c + 2 t, + 1) -- one lane per group with 16 consecutive values each would touch 64 lines per
     // wave instruction and push 8 x the bytes through L1
     int cb = 0;
     int64_t g = 0, rbase = 0, pc0 = 0;
     bool have = false;
-    v2d urow[8];
+    constexpr int kRC = kTG * kUR / kTileCols;     // 512-position chunks of the block's row range
+    v2d urow[kRC];
     v2d ucol; ucol.x = 0.0; ucol.y = 0.0;
     ulonglong2 um0 = make_ulonglong2(0ull, 0ull), um1 = um0;
     unsigned long long* up4 = a.umin;
     if (test_block) {
         cb = a.blk_cb[tb];
         g = (int64_t)a.blk_g0[tb] + tid;
-        have = g < G16;
+        have = g < G16 && tid < kTG;
         rbase = (int64_t)a.blk_g0[tb] * kUR;
         pc0 = (int64_t)cb * kTileCols + 2 * tid;                      // this thread's two strip columns (< P + 512)
         up4 = a.umin + ((int64_t)cb * G16 + (have ? g : 0)) * 4;
         if (have) { um0 = *reinterpret_cast<const ulonglong2*>(up4); um1 = *reinterpret_cast<const ulonglong2*>(up4 + 2); }
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < kRC; ++c) {
             const int64_t pp = rbase + c * kTileCols + 2 * tid;
             urow[c] = *reinterpret_cast<const v2d*>(Uc + (pp < P ? pp : pclamp));      // behind P: padding (NaN = dead)
         }
@@ -613,11 +620,11 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
     const double* __restrict__ Rz = a.R + ((it + 1) & 1) * a.vstride;        // written by POST(it - 1)
     const bool pz_strip = fold && pz / kTileCols == cb;                      // block-uniform
     const int64_t gz = fold ? pz / kUR : -1;
-    const bool gz_here = fold && gz >= (int64_t)a.blk_g0[tb] && gz < (int64_t)a.blk_g0[tb] + kThreads;   // block-uniform
+    const bool gz_here = fold && gz >= (int64_t)a.blk_g0[tb] && gz < (int64_t)a.blk_g0[tb] + kTG;   // block-uniform
     const int wpz = fold ? (int)((pz % kTileCols) / (kTileCols / 4)) : -1;   // sub-strip of that node's column
-    v2d dxr[8], dyr[8];
+    v2d dxr[kRC], dyr[kRC];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < kRC; ++c) {
         const int64_t pp = rbase + c * kTileCols + 2 * tid;
         const int64_t po = pp < P ? pp : pclamp;
         dxr[c] = *reinterpret_cast<const v2d*>(rowx + po);
@@ -642,15 +649,15 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
         }
     }
     NJP_STAMP(1, 3, true);
-    // Row sums after this merge for the block's 4096 row positions (U, not U / (n - 3): the division is monotone, so it is
+    // Row sums after this merge for the row positions of the block (U, not U / (n - 3): the division is monotone, so it is
     // done once per group afterwards -- fl(max U / r) == max fl(U / r) bit for bit, and an fp64 division is ~40
     // instructions).  They go through LDS, 16 values + 1 pad per group (both the pairwise writes and the group-wise reads
     // are then conflict-free), and the test lane of a group takes the maximum of its 16.  Dead positions and the padding
     // behind P carry NaN in U; the merged pair is left out by (32-bit, block-local) index.
-    __shared__ double s_un[4096 + 256];
+    __shared__ double s_un[kTG * (kUR + 1)];
     const int lxp = (int)(px - rbase), lyp = (int)(py - rbase), lzp = (int)((fold ? pz : -1) - rbase);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < kRC; ++c) {
         const int lp = c * kTileCols + 2 * tid;
         const double u0 = urow[c].x, u1 = urow[c].y;
         const bool live0 = (u0 == u0) & (lp != lxp) & (lp != lyp);          // (the new node is in quarantine during scan it + 1)
@@ -685,15 +692,16 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
     NJP_STAMP(1, 4, false);
     const double bound = fmin(fmin(sseed[0], sseed[1]), fmin(sseed[2], sseed[3]));
     double rmax = NINF, newminA = PINF;                             // group g = blk_g0 + tid
+    const int tg = tid < kTG ? tid : 0;
 #pragma unroll
-    for (int k = 0; k < kUR; ++k) rmax = fmax(rmax, s_un[17 * tid + k]);
+    for (int k = 0; k < kUR; ++k) rmax = fmax(rmax, s_un[17 * tg + k]);
     rmax = rmax / r1;                                               // (-inf stays -inf)
     if (pz_strip) {
         // block-uniform and rare (the strip of the node leaving quarantine): minimum of its buffered row over each
         // group's live rows behind it, same route through LDS
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < kRC; ++c) {
             const int lp = c * kTileCols + 2 * tid;
             const int64_t pp = rbase + lp;
             const v2d rz = *reinterpret_cast<const v2d*>(Rz + (pp < P ? pp : pclamp));
@@ -706,7 +714,7 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < kUR; ++k) newminA = fmin(newminA, s_un[17 * tid + k]);
+        for (int k = 0; k < kUR; ++k) newminA = fmin(newminA, s_un[17 * tg + k]);
     }
     const bool own = have;      // (a rank launches only its own test blocks)
     int submask = 0;
@@ -758,7 +766,7 @@ static int64_t prep_blocks(int64_t P, std::vector<int32_t>* hcb, std::vector<int
     const int64_t G16 = (P + kUR - 1) / kUR;
     int64_t cnt = 0;
     for (int64_t c = 0; 32 * c < G16 && c * kTileCols < P - 1; ++c)
-        for (int64_t g0 = 32 * c; g0 < G16; g0 += kThreads) {
+        for (int64_t g0 = 32 * c; g0 < G16; g0 += njp_tg(P)) {
             if (hcb) { hcb->push_back((int32_t)c); hg0->push_back((int32_t)g0); }
             ++cnt;
         }
@@ -779,7 +787,12 @@ static SlabPlan slab_plan(int64_t P, int64_t N, int local_ranks)
     p.umin = take((size_t)(S * G16 * 4) * 8);
     p.list_stride = unit_total(P) + kScanBlocks + 64;
     p.list = take((size_t)(p.list_stride * local_ranks) * 4);
-    const size_t nprep = (size_t)prep_blocks(P, nullptr, nullptr);
+    // (capacity for the finest test-block size: a later, smaller epoch of the same arena may use it)
+    size_t nprep = 1;
+    {
+        const int64_t G16c = (P + kUR - 1) / kUR;
+        for (int64_t c = 0; 32 * c < G16c && c * kTileCols < P - 1; ++c) nprep += (size_t)((G16c - 32 * c + 63) / 64);
+    }
     p.blk_cb = take(nprep * 4); p.blk_g0 = take(nprep * 4);
     p.cnt_all = take((size_t)(4 * local_ranks) * 8);
     p.total = off;
@@ -1040,7 +1053,8 @@ static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
     a.do_update = update ? 1 : 0;
     const unsigned ublocks = update ? (unsigned)((b.N + kThreads - 1) / kThreads) : 0u;
     if ((unsigned)a.ntest + ublocks == 0u) return DPR_OK;      // (a rank without test blocks in a tests-only launch)
-    hipLaunchKernelGGL(njp_post_kernel, dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
+    if (njp_tg(b.pr.P) == 64) hipLaunchKernelGGL(njp_post_kernel<64>, dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL(njp_post_kernel<256>, dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
