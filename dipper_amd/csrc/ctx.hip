@@ -59,6 +59,7 @@ static int rccl_load()
 struct dpr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // distance rows of the next placement batch (created on first use)
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
     int rank = 0, world = 1;  // RCCL rank/world, or world = number of virtual ranks
     int vworld = 0;           // > 0: all ranks live in this context on one device (validation mode)
@@ -307,6 +308,7 @@ int dpr_destroy(dpr_ctx* c)
     if (c->place_trace) (void)hipFree(c->place_trace);
     if (c->packed_lower) (void)hipFree(c->packed_lower);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return DPR_OK;
@@ -908,22 +910,36 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
     const bool sharded = c->world > 1 && c->vworld == 0 && c->comm != nullptr && source != DPR_SRC_MATRIX;
     const int W = sharded ? c->world : 1;
     const int64_t per = (R + W - 1) / W;         // rows per rank and batch
-    double* rows = nullptr;
-    if (source != DPR_SRC_MATRIX) DPR_HIP(hipMalloc(&rows, sizeof(double) * (size_t)(per * W * ldb)));
-    auto row_ptr = [&](int64_t i, int64_t i0) -> const double* {
+    // The distance rows of the NEXT batch are produced on a second stream while the tree kernels of the current batch
+    // run (they are latency-bound and occupy two workgroups; the pair kernels fill the rest of the chip): two row
+    // buffers, the producer waits for the batch that last read the buffer it overwrites.
+    // (Mash input only: 5 000 000 000 pair distances against 1.8 s of tree kernels at 100 000 tips -- 5.02 -> 3.81 s; with
+    // aligned input the distance part is 4 % of the run and the contention costs more than it hides: 1.63 -> 1.82 s)
+    const bool overlap = source == DPR_SRC_MASH && !std::getenv("DPR_PLACE_NO_OVERLAP");
+    double* rows_buf[2] = { nullptr, nullptr };
+    const size_t row_bytes = sizeof(double) * (size_t)(per * W * ldb);
+    if (source != DPR_SRC_MATRIX) {
+        DPR_HIP(hipMalloc(&rows_buf[0], row_bytes));
+        if (overlap) DPR_HIP(hipMalloc(&rows_buf[1], row_bytes));
+    }
+    if (overlap && !c->stream2) DPR_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    hipStream_t ds = overlap ? c->stream2 : c->stream;          // stream of the distance kernels
+    std::vector<hipEvent_t> sync_ev;                             // fill-done / tree-done events of this run
+    auto new_event = [&](hipEvent_t* e) -> int { DPR_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming)); sync_ev.push_back(*e); return DPR_OK; };
+    auto row_ptr = [&](int64_t i, int64_t i0, const double* rows) -> const double* {
         return source == DPR_SRC_MATRIX ? c->packed_lower + i * (i - 1) / 2 : rows + (i - i0) * ldb;
     };
-    auto fill_some = [&](int64_t i0, int64_t nr, double* out) -> int {
+    auto fill_some = [&](int64_t i0, int64_t nr, double* out, hipStream_t st) -> int {
         if (nr <= 0) return DPR_OK;
-        if (source == DPR_SRC_MSA) return msa_dist_block_rows(c->msa, i0, nr, 0, 0, i0 + nr, dist_type, out, ldb, c->stream);
-        if (source == DPR_SRC_MASH) return mash_dist_rows(c->mash, i0, nr, 0, 0, false, i0 + nr, out, ldb, c->stream);
+        if (source == DPR_SRC_MSA) return msa_dist_block_rows(c->msa, i0, nr, 0, 0, i0 + nr, dist_type, out, ldb, st);
+        if (source == DPR_SRC_MASH) return mash_dist_rows(c->mash, i0, nr, 0, 0, false, i0 + nr, out, ldb, st);
         return DPR_OK;
     };
-    auto fill_rows_inner = [&](int64_t i0, int64_t nr) -> int {
-        if (!sharded) return fill_some(i0, nr, rows);
+    auto fill_rows_inner = [&](int64_t i0, int64_t nr, double* rows) -> int {
+        if (!sharded) return fill_some(i0, nr, rows, ds);
         const int64_t a = (int64_t)c->rank * per, b = a + per < nr ? a + per : nr;     // this rank's rows of the batch
-        if (int rc = fill_some(i0 + a, b - a, rows + a * ldb)) return rc;
-        if (g_rccl.AllGather(rows + a * ldb, rows, (size_t)(per * ldb), kNcclFloat64, c->comm, c->stream) != 0) {
+        if (int rc = fill_some(i0 + a, b - a, rows + a * ldb, ds)) return rc;
+        if (g_rccl.AllGather(rows + a * ldb, rows, (size_t)(per * ldb), kNcclFloat64, c->comm, ds) != 0) {
             set_error("ncclAllGather(distance rows) failed");
             return DPR_ERR_COMM;
         }
@@ -931,34 +947,68 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
     };
     // the reference reports the distance and the tree part of a placement run separately
     // (src/placement_close_k.cu:852-853,985-986): an event pair around every distance batch, summed by the caller
-    auto fill_rows = [&](int64_t i0, int64_t nr) -> int {
+    auto fill_rows = [&](int64_t i0, int64_t nr, double* rows) -> int {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (source != DPR_SRC_MATRIX) {
             DPR_HIP(hipEventCreate(&e0)); DPR_HIP(hipEventCreate(&e1));
             c->place_ev.push_back(e0); c->place_ev.push_back(e1);
-            DPR_HIP(hipEventRecord(e0, c->stream));
+            DPR_HIP(hipEventRecord(e0, ds));
         }
-        const int rc = fill_rows_inner(i0, nr);
-        if (e1) DPR_HIP(hipEventRecord(e1, c->stream));
+        const int rc = fill_rows_inner(i0, nr, rows);
+        if (e1) DPR_HIP(hipEventRecord(e1, ds));
         return rc;
     };
-    int rc = DPR_OK;
-    if (first == 2) {
-        rc = place_init_fresh(p, c->stream);
-        if (!rc) rc = fill_some(1, 1, rows);
-        if (!rc) rc = place_initial_tree(p, row_ptr(1, 1), c->stream);
-    } else {
-        rc = place_import_backbone(p, first, c->stream);
+    auto run = [&]() -> int {
+        if (first == 2) {
+            if (int rc = place_init_fresh(p, c->stream)) return rc;
+            if (int rc = fill_some(1, 1, rows_buf[0], c->stream)) return rc;
+            if (int rc = place_initial_tree(p, row_ptr(1, 1, rows_buf[0]), c->stream)) return rc;
+        } else {
+            if (int rc = place_import_backbone(p, first, c->stream)) return rc;
+        }
+        if (first >= last) return DPR_OK;
+        hipEvent_t filled[2] = { nullptr, nullptr }, consumed[2] = { nullptr, nullptr };
+        if (overlap) {
+            // the first batch overwrites buffer 0, which the initial tree just read on the main stream
+            hipEvent_t e;
+            if (int rc = new_event(&e)) return rc;
+            DPR_HIP(hipEventRecord(e, c->stream));
+            DPR_HIP(hipStreamWaitEvent(ds, e, 0));
+        }
+        int64_t i0 = first;
+        int cur = 0;
+        {
+            const int64_t nr = last - i0 < R ? last - i0 : R;
+            if (int rc = fill_rows(i0, nr, rows_buf[0])) return rc;
+            if (overlap) { if (int rc = new_event(&filled[0])) return rc; DPR_HIP(hipEventRecord(filled[0], ds)); }
+        }
+        for (; i0 < last; i0 += R, cur ^= 1) {
+            const int64_t nr = last - i0 < R ? last - i0 : R;
+            const int64_t j0 = i0 + R;
+            if (overlap && j0 < last) {          // next batch into the other buffer, once its last reader is done
+                const int nb = cur ^ 1;
+                if (consumed[nb]) DPR_HIP(hipStreamWaitEvent(ds, consumed[nb], 0));
+                const int64_t nr2 = last - j0 < R ? last - j0 : R;
+                if (int rc = fill_rows(j0, nr2, rows_buf[nb])) return rc;
+                if (int rc = new_event(&filled[nb])) return rc;
+                DPR_HIP(hipEventRecord(filled[nb], ds));
+            }
+            double* rows = rows_buf[overlap ? cur : 0];
+            if (overlap) DPR_HIP(hipStreamWaitEvent(c->stream, filled[cur], 0));
+            else if (i0 > first) { if (int rc = fill_rows(i0, nr, rows)) return rc; }
+            for (int64_t i = i0; i < i0 + nr; ++i)
+                if (int rc = place_tip(p, row_ptr(i, i0, rows), i, c->place_trace, c->stream)) return rc;
+            if (overlap) { if (int rc = new_event(&consumed[cur])) return rc; DPR_HIP(hipEventRecord(consumed[cur], c->stream)); }
+        }
+        return DPR_OK;
+    };
+    const int rc = run();
+    if (rows_buf[0] || rows_buf[1]) {
+        (void)hipStreamSynchronize(c->stream);
+        if (overlap) (void)hipStreamSynchronize(c->stream2);
+        for (double* q : rows_buf) if (q) (void)hipFree(q);
     }
-    for (int64_t i0 = first; !rc && i0 < last; i0 += R) {
-        const int64_t nr = last - i0 < R ? last - i0 : R;
-        rc = fill_rows(i0, nr);
-        for (int64_t i = i0; !rc && i < i0 + nr; ++i) rc = place_tip(p, row_ptr(i, i0), i, c->place_trace, c->stream);
-    }
-    if (rows) {
-        if (!rc) (void)hipStreamSynchronize(c->stream);
-        (void)hipFree(rows);
-    }
+    for (hipEvent_t e : sync_ev) (void)hipEventDestroy(e);
     return rc;
 }
 

@@ -230,6 +230,13 @@ struct MashBuffers {
     uint64_t* word_off = nullptr;  // [n]
     uint64_t* len = nullptr;       // [n] bases
     uint64_t* sketches = nullptr;  // [n][S] ascending
+    // run encoding of every sketch against ONE reference list (mash_encode, see mash.hip): tokens [n][S] of 16 bytes,
+    // tok_cnt[n]; ref = the reference's distinct values (ref_n of them)
+    uint4* tokens = nullptr;
+    int32_t* tok_cnt = nullptr;
+    uint64_t* ref = nullptr;
+    int ref_n = 0;
+    double tok_mean = 0.0;         // tokens per sketch (sampled): the token kernel is used while this stays small
     uint64_t total_words = 0;
     int64_t n = 0;
     int S = 0, k = 0;

@@ -12,6 +12,8 @@
 // Layout: sketches row-major [n][S] u64 in HBM (the reference transposes to [S][n] for its
 // one-row-per-launch kernel).
 #include "dpr_internal.hpp"
+#include <cstdio>
+#include <vector>
 
 #include <cstdlib>
 
@@ -428,6 +430,177 @@ __global__ __launch_bounds__(kLThreads) void mash_dist_lookup_kernel(const uint6
 }
 
 // ------------------------------------------------------------------------------------------------
+// Run-encoded pair kernel (round 2; default while sketches resemble each other).
+// On the inputs the reference is run on (near-clonal alignments, scripts/alisim.sh) two sketches share
+// almost all of their 1000 values, and the reference's loop spends its 2000 steps finding that out again
+// for every pair.  Here every sketch is encoded ONCE against a common reference list R (the distinct values
+// of one of the sketches, picked for short encodings) as a sequence of tokens:
+//     RUN(p, len)   the next len values are R[p], R[p+1], ... (first copies only)
+//     LIT(v, rk, eq) one value v that does not continue a run; rk = #{r in R : r < v}, eq = (R[rk] == v,
+//                   i.e. an extra copy of a reference value)
+// and the pair loop -- the reference's own event loop (src/mash.cu:437-454: consume b while b <= a, count
+// uni / inter, stop at uni == S) -- runs over tokens: two runs at the same reference index are L matching
+// pairs at once (inter += L, uni += L), runs at different indices skip to the later index with uni += gap,
+// a literal against a run compares rk with the run's index.  Every comparison of two run elements or of a
+// run element with a literal is an integer comparison in reference-index space (only two literals compare
+// their 64-bit values), and the cut-off is exact because every bulk step is capped at S - uni.  Same
+// counts as the literal loop bit for bit -- duplicates, padding values and S of any size included -- in
+// ~(tokens of A + tokens of B) steps instead of ~2 S.
+// A lane owns one pair: 64 consecutive row tips against one column tip at a time, the token arrays of the
+// rows (a few hundred bytes each on clonal data) stay cache-resident over the column loop.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kTokLit = 1u, kTokEq = 2u;
+constexpr int kTWaves = 4;               // waves (64-row tiles) per block
+
+// one thread per sketch
+// (output slot q holds sketch q * stride: stride > 1 encodes a sample)
+__global__ __launch_bounds__(kThreads) void mash_encode_kernel(const uint64_t* __restrict__ sk, int S, int64_t n, int64_t stride,
+                                                               const uint64_t* __restrict__ R, int nR,
+                                                               uint4* __restrict__ tokens, int32_t* __restrict__ tok_cnt)
+{
+    const int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (q >= n) return;
+    const uint64_t* X = sk + q * stride * S;
+    uint4* out = tokens + q * S;
+    int nt = 0, i = 0;
+    while (i < S) {
+        const uint64_t x = X[i];
+        int lo = 0, hi = nR;                          // rk = #{r < x}
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (R[mid] < x) lo = mid + 1; else hi = mid; }
+        const int rk = lo;
+        const bool inR = rk < nR && R[rk] == x;
+        if (inR && (i == 0 || X[i - 1] != x)) {       // first copy of a reference value: a run starts
+            int len = 1;
+            while (i + len < S && rk + len < nR && X[i + len] == R[rk + len]) ++len;
+            out[nt++] = make_uint4((uint32_t)rk, 0u, (uint32_t)len, 0u);
+            i += len;
+        } else {
+            out[nt++] = make_uint4((uint32_t)x, (uint32_t)(x >> 32), (uint32_t)rk, kTokLit | (inR ? kTokEq : 0u));
+            ++i;
+        }
+    }
+    tok_cnt[q] = nt;
+}
+
+// distinct values of a sorted list (one block; nR via counter)
+__global__ void mash_dedup_kernel(const uint64_t* __restrict__ x, int S, uint64_t* __restrict__ R, int* __restrict__ nR)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int k = 0;
+    for (int i = 0; i < S; ++i)
+        if (i == 0 || x[i] != x[i - 1]) R[k++] = x[i];
+    *nR = k;
+}
+
+// Cursor over a token sequence.  The head element is described in REFERENCE-INDEX space by an integer key:
+// run element R[p] -> 2p + 1; literal with rank rk -> 2 rk + 1 if it equals R[rk] (an extra copy), else 2 rk (strictly
+// between R[rk-1] and R[rk]).  Keys order the values; equal odd keys are equal values; only two literals with the same
+// even key have to compare their 64-bit values.
+struct TokCursor {
+    const uint4* p;        // next token to fetch
+    int left;              // tokens not fetched yet
+    uint4 nxt;             // prefetched token
+    int key, rem;          // key of the head element, elements left in the segment
+    bool run, done;
+    uint64_t val;          // literal value
+    __device__ __forceinline__ void fetch()
+    {
+        if (left > 0) { nxt = *p; ++p; --left; } else { nxt = make_uint4(0u, 0u, 0u, 0xffffffffu); }
+    }
+    __device__ __forceinline__ void advance_segment()      // make the prefetched token current
+    {
+        const uint4 t = nxt;
+        done = t.w == 0xffffffffu;
+        const bool lit = (t.w & kTokLit) != 0u;
+        run = !lit;
+        val = ((uint64_t)t.y << 32) | t.x;
+        key = lit ? 2 * (int)t.z + ((t.w & kTokEq) ? 1 : 0) : 2 * (int)t.x + 1;
+        rem = lit ? 1 : (int)t.z;
+        fetch();
+    }
+    __device__ __forceinline__ void init(const uint4* tok, int cnt)
+    {
+        p = tok; left = cnt;
+        fetch();
+        advance_segment();
+    }
+    __device__ __forceinline__ void consume(int L)          // 0 <= L <= rem
+    {
+        rem -= L;
+        key += run ? 2 * L : 0;
+        if (L > 0 && rem == 0) advance_segment();
+    }
+};
+
+__global__ __launch_bounds__(kTWaves * 64) void mash_dist_tokens_kernel(const uint4* __restrict__ tokens, const int32_t* __restrict__ tok_cnt,
+                                                                        int S, int k, int64_t n, int64_t r0, int64_t nr, int64_t ncols,
+                                                                        double* __restrict__ out, int64_t ld, int mirror, int transposed,
+                                                                        int cols_per_block)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t t = ((int64_t)blockIdx.y * kTWaves + w) * 64 + lane;      // row index inside the batch
+    const int64_t i = r0 + t;                                                // row tip id
+    const bool row_ok = t < nr && i < n;
+    const int64_t tile_last = r0 + ((int64_t)blockIdx.y * kTWaves + w) * 64 + 63;   // wave-uniform
+    const int64_t cbeg = (int64_t)blockIdx.x * cols_per_block;
+    int64_t cend = cbeg + cols_per_block;
+    if (cend > ncols) cend = ncols;
+    if (cend > tile_last) cend = tile_last;                                  // columns below the tile's last row only
+    const uint4* tokB = tokens + (row_ok ? i : 0) * S;
+    const int cntB = row_ok ? tok_cnt[i] : 0;
+    TokCursor B0;                                                            // this lane's row at its first element (same for every column)
+    B0.init(tokB, cntB);
+    for (int64_t j = cbeg; j < cend; ++j) {
+        const bool pair_ok = row_ok && j < i;
+        TokCursor A, B = B0;                                                 // A: column j (the outer list), B: this lane's row
+        A.init(tokens + j * S, tok_cnt[j]);
+        int uni = 0, inter = 0;
+        bool alive = pair_ok;
+        int guard = 4 * S + 64;                                              // every step consumes an element: never reached
+        while (__builtin_amdgcn_ballot_w64(alive) && --guard > 0) {
+            // one step of the reference's loop per lane, written without branches on the token kinds (the lanes of a wave
+            // are in different states; a branch per kind made every step cost the sum of all of them)
+            const int cap = S - uni;                                         // > 0 for a live lane
+            const int kA = A.key, kB = B.key;
+            const bool bdone = B.done;
+            const bool eqk = !bdone & (kB == kA);
+            const bool odd = (kA & 1) != 0;
+            const bool vlt = B.val < A.val, veq = B.val == A.val;           // decide only between two literals of one even key
+            const bool b_less = (!bdone & (kB < kA)) | (eqk & !odd & vlt);
+            const bool equal = eqk & (odd | veq);
+            const bool a_less = !(b_less | equal);                           // b > a, or no b left
+            const bool pairs = equal & A.run & B.run;
+            const int Lb = B.run ? (kA - kB + 1) >> 1 : 1;                   // B elements below a
+            const int La = bdone ? A.rem : (A.run ? (kB - kA + 1) >> 1 : 1); // A elements below b (all of them if B is exhausted)
+            int L = pairs ? (A.rem < B.rem ? A.rem : B.rem) : b_less ? (Lb < B.rem ? Lb : B.rem) : a_less ? (La < A.rem ? La : A.rem) : 1;
+            L = L < cap ? L : cap;
+            // (b == a, then a) pairs: the a of a pair may only go once the NEXT b is known to be larger -- inside B's run it
+            // is (the next reference value), behind the run's last element it is not (an extra copy of that value may follow)
+            const bool bend = pairs & (L == B.rem);
+            const int Lp = L - (bend ? 1 : 0);
+            int cA = 0, cB = 0, du = 0, di = 0;
+            if (pairs) {
+                di = Lp; du = Lp; cA = Lp; cB = Lp;
+                if (bend & (uni + Lp < S)) { di += 1; cB += 1; }
+            } else if (b_less) { du = L; cB = L; }
+            else if (a_less) { du = L; cA = L; }
+            else { di = 1; cB = 1; }                                         // b == a with a literal involved: the b goes, a stays
+            if (!alive) { cA = 0; cB = 0; du = 0; di = 0; }                  // a finished lane keeps its counts
+            uni += du; inter += di;
+            A.consume(cA);
+            B.consume(cB);
+            if (alive) alive = uni < S && !A.done;
+        }
+        if (pair_ok) {
+            const double jac = fmax((double)inter, 1.0) / (double)uni;
+            const double d = fmin(1.0, fabs(log(2.0 * jac / (1.0 + jac)) / (double)k));
+            if (transposed) out[j * ld + t] = d; else out[t * ld + j] = d;
+            if (mirror) out[j * ld + i] = d;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 int mash_upload(MashBuffers& m, const uint64_t* packed2, const uint64_t* word_off, const uint64_t* len,
@@ -454,17 +627,84 @@ int mash_upload(MashBuffers& m, const uint64_t* packed2, const uint64_t* word_of
 
 void mash_free(MashBuffers& m)
 {
-    void* ptrs[] = { m.packed2, m.word_off, m.len, m.sketches };
+    void* ptrs[] = { m.packed2, m.word_off, m.len, m.sketches, m.tokens, m.tok_cnt, m.ref };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     m = MashBuffers();
+}
+
+// run encoding of all sketches against the distinct values of sketch 0 (see mash_dist_tokens_kernel)
+static int mash_encode(MashBuffers& m, hipStream_t s)
+{
+    if (std::getenv("DPR_MASH_LOOKUP")) return DPR_OK;            // A/B: the table kernel of round 1 everywhere
+    const int S = m.S;
+    DPR_HIP(hipMalloc(&m.tokens, sizeof(uint4) * (size_t)(m.n * S)));
+    DPR_HIP(hipMalloc(&m.tok_cnt, sizeof(int32_t) * (size_t)m.n));
+    DPR_HIP(hipMalloc(&m.ref, sizeof(uint64_t) * (size_t)(S + 1)));
+    int* d_nr = nullptr;
+    DPR_HIP(hipMalloc(&d_nr, sizeof(int)));
+    // The reference list: any sketch gives exact results, one in the middle of the data gives short encodings.  A few
+    // candidates (evenly spaced tips) are tried on a sample of the sketches; the one with the fewest tokens is kept.
+    int64_t best_tip = 0;
+    {
+        const int64_t neval = m.n < 256 ? m.n : 256, ncand = m.n < 16 ? m.n : 16;
+        const int64_t estride = m.n / neval;
+        std::vector<int32_t> cnt((size_t)neval);
+        double best = 1e300;
+        for (int64_t c = 0; c < ncand; ++c) {
+            const int64_t tip = c * (m.n / ncand) + (c ? (m.n / ncand) / 2 : 0);          // tip 0 first (the only candidate of tiny inputs)
+            hipLaunchKernelGGL(mash_dedup_kernel, dim3(1), dim3(64), 0, s, m.sketches + tip * S, S, m.ref, d_nr);
+            int nRc = 0;
+            DPR_HIP(hipMemcpyAsync(&nRc, d_nr, sizeof(int), hipMemcpyDeviceToHost, s));
+            DPR_HIP(hipStreamSynchronize(s));
+            hipLaunchKernelGGL(mash_encode_kernel, dim3((unsigned)((neval + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, m.sketches, S, neval,
+                               estride, m.ref, nRc, m.tokens, m.tok_cnt);
+            DPR_HIP(hipMemcpyAsync(cnt.data(), m.tok_cnt, sizeof(int32_t) * (size_t)neval, hipMemcpyDeviceToHost, s));
+            DPR_HIP(hipStreamSynchronize(s));
+            double sum = 0;
+            for (int32_t v : cnt) sum += v;
+            if (sum < best) { best = sum; best_tip = tip; }
+        }
+    }
+    hipLaunchKernelGGL(mash_dedup_kernel, dim3(1), dim3(64), 0, s, m.sketches + best_tip * S, S, m.ref, d_nr);
+    int nR = 0;
+    DPR_HIP(hipMemcpyAsync(&nR, d_nr, sizeof(int), hipMemcpyDeviceToHost, s));
+    DPR_HIP(hipStreamSynchronize(s));
+    (void)hipFree(d_nr);
+    m.ref_n = nR;
+    hipLaunchKernelGGL(mash_encode_kernel, dim3((unsigned)((m.n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, m.sketches, S, m.n,
+                       (int64_t)1, m.ref, nR, m.tokens, m.tok_cnt);
+    DPR_HIP(hipGetLastError());
+    // tokens per sketch over a sample: the token kernel pays while the sketches resemble the reference
+    const int64_t ns = m.n < 4096 ? m.n : 4096;
+    std::vector<int32_t> cnt((size_t)ns);
+    const int64_t step = m.n / ns;
+    if (step <= 1) {
+        DPR_HIP(hipMemcpyAsync(cnt.data(), m.tok_cnt, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost, s));
+    } else {
+        DPR_HIP(hipMemcpy2DAsync(cnt.data(), sizeof(int32_t), m.tok_cnt, sizeof(int32_t) * (size_t)step, sizeof(int32_t), (size_t)ns,
+                                 hipMemcpyDeviceToHost, s));
+    }
+    DPR_HIP(hipStreamSynchronize(s));
+    double sum = 0;
+    for (int32_t c : cnt) sum += c;
+    m.tok_mean = sum / (double)ns;
+    if (std::getenv("DPR_MASH_LOG")) {
+        int32_t mx = 0;
+        for (int32_t c : cnt) mx = c > mx ? c : mx;
+        std::fprintf(stderr, "[mash] run encoding against the sketch of tip %lld (%d distinct values): %.1f tokens per sketch (sample of %lld, most %d)\n",
+                     (long long)best_tip, nR, m.tok_mean, (long long)ns, mx);
+    }
+    return DPR_OK;
 }
 
 int mash_sketch(MashBuffers& m, int k, int S, hipStream_t s)
 {
     if (k < 2 || k > 15) { set_error("kmer size must be in [2,15]"); return DPR_ERR_ARG; }
     if (S < 1 || S > 4096) { set_error("sketch size must be in [1,4096]"); return DPR_ERR_ARG; }
-    if (m.sketches) { (void)hipFree(m.sketches); m.sketches = nullptr; }
+    void* olds[] = { m.sketches, m.tokens, m.tok_cnt, m.ref };
+    for (void* q : olds) if (q) (void)hipFree(q);
+    m.sketches = nullptr; m.tokens = nullptr; m.tok_cnt = nullptr; m.ref = nullptr; m.tok_mean = 0.0;
     DPR_HIP(hipMalloc(&m.sketches, sizeof(uint64_t) * (size_t)(m.n * S)));
     m.S = S; m.k = k;
     static bool attr_set = false;
@@ -477,7 +717,7 @@ int mash_sketch(MashBuffers& m, int k, int S, hipStream_t s)
     hipLaunchKernelGGL(mash_sketch_kernel, dim3(grid), dim3(kSketchThreads), kSortCap * sizeof(uint64_t), s,
                        m.packed2, m.word_off, m.len, m.n, k, S, m.sketches);
     DPR_HIP(hipGetLastError());
-    return DPR_OK;
+    return mash_encode(m, s);
 }
 
 static int lookup_attr()
@@ -513,9 +753,23 @@ int mash_dist_rows(const MashBuffers& m, int64_t r0, int64_t nr, int rank, int w
                    int64_t ncols, double* out, int64_t ld, hipStream_t s, bool transposed)
 {
     if (nr <= 0 || ncols <= 0) return DPR_OK;
-    if (transposed && (full || world > 1 || m.S > kLS)) { set_error("mash_dist_rows: transposed output needs the lookup kernel"); return DPR_ERR_ARG; }
-    // lower-triangle pairs (placement batches; single-GPU NJ with a mirror write): lookup kernel
+    if (transposed && (full || world > 1 || (m.S > kLS && !m.tokens))) { set_error("mash_dist_rows: transposed output needs the token or the lookup kernel"); return DPR_ERR_ARG; }
+    // lower-triangle pairs (placement batches; single-GPU NJ with a mirror write): token kernel while the sketches
+    // resemble each other (at most DPR_MASH_TOKENS_MAX tokens per sketch on average, default 150 of up to S: measured break-even with the table kernel), else the table kernel
     const bool mirror = full && world == 1 && r0 == 0;
+    static const double tok_max = std::getenv("DPR_MASH_TOKENS_MAX") ? std::atof(std::getenv("DPR_MASH_TOKENS_MAX")) : 150.0;
+    if (m.tokens && m.tok_mean <= tok_max && (!full || mirror) && world <= 1) {
+        // columns a wave walks through: 128 for a whole matrix, fewer when the launch has few row tiles (placement batches
+        // of 256 rows), so that it still fills the chip (>= ~4096 waves) and no wave runs long after the others
+        const int64_t tiles = (nr + 63) / 64;
+        int64_t cpb = ncols * tiles / 4096;
+        cpb = cpb < 8 ? 8 : (cpb > 128 ? 128 : cpb);
+        dim3 tgrid((unsigned)((ncols + cpb - 1) / cpb), (unsigned)((nr + kTWaves * 64 - 1) / (kTWaves * 64)));
+        hipLaunchKernelGGL(mash_dist_tokens_kernel, tgrid, dim3(kTWaves * 64), 0, s, m.tokens, m.tok_cnt, m.S, m.k, m.n, r0, nr, ncols,
+                           out, ld, mirror ? 1 : 0, transposed ? 1 : 0, (int)cpb);
+        DPR_HIP(hipGetLastError());
+        return DPR_OK;
+    }
     if (m.S <= kLS && (!full || mirror) && world <= 1 && (transposed || !std::getenv("DPR_MASH_SIMPLE"))) {
         if (int rc = lookup_attr()) return rc;
         const size_t tlds = kTLds;

@@ -24,5 +24,6 @@ else:
     st = d.place_run(capi.SRC_MSA, n, dist_type=2)
 t3 = time.perf_counter()
 if rank == 0:
+    print("distance / tree part of the run: %.0f / %.0f ms" % d.place_timing())
     print(f"{world} GPU(s) {kind} n={n} L={L}: upload {t1-t0:.2f}s sketch {t2-t1:.3f}s placement {t3-t2:.2f}s ({d.timing()[1]:.0f} ms on device) -> {n/(t3-t1):.0f} tips/s")
 _mgpu.finish(dist)

@@ -69,6 +69,48 @@ def test_mash_dist_matrix_and_nj(gpu, orc):
         assert np.array_equal(res[key], ref[key]), key
 
 
+@pytest.mark.parametrize("S,k", [(1000, 15), (64, 15), (257, 8), (2000, 15), (5, 4)])
+def test_mash_dist_token_kernel_cases(orc, monkeypatch, S, k):
+    """The run-encoded pair kernel (every sketch as runs of a reference list + literals) against the oracle's literal
+    loop on the cases its rules have to get right: near-identical reads (long runs, a handful of literals), exact copies,
+    reads with repeats (duplicate values: extra copies behind a run, in the reference itself, as literals), short reads
+    (padding values = duplicates of the largest value), unrelated reads (all literals) and a reference (sketch 0) that is
+    itself an outlier.  Integer intersection counts are exact, so the distances agree to the last bits of log()."""
+    import dipper_amd
+    from dipper_amd import capi
+    monkeypatch.setenv("DPR_MASH_TOKENS_MAX", "1e9")           # the token kernel whatever the token counts are
+    rng = np.random.default_rng(S * 31 + k)
+    L = 2500
+    clonal = _util.synth_reads(rng, 60, L, mean_bl=3e-4, lo=3e-5, hi=3e-3)
+    rep = (b"ACGTTGCA" * 40 + clonal[3][:1200]) * 2                      # every k-mer twice -> duplicate sketch values
+    base = clonal[5]
+    seqs = []
+    for first in (clonal[0], rep, _reads(rng, 1, L, L, related=False)[0]):     # three different references
+        seqs = [first] + clonal[1:] + [base, base, rep, rep[: len(rep) // 2], b"ACGT" * 30, b"A" * 40, b"AC", base[:300]]
+        seqs += _reads(rng, 6, 300, 3000, related=False)
+        n = len(seqs)
+        d = dipper_amd.Dipper(0)
+        try:
+            d.set_nj_mode(0)
+            d.set_reads(seqs)
+            sk = d.sketch(k=k, S=S)
+            for q in (0, 1, n // 2, n - 1):
+                assert np.array_equal(sk[q], orc.sketch(orc.pack2(seqs[q]), len(seqs[q]), k=k, S=S))
+            d.dist_matrix(capi.SRC_MASH, 0, k)
+            M = d.matrix()
+            assert np.array_equal(M, M.T) and np.all(np.diag(M) == 0)
+            for i in range(1, n):
+                ref = orc.mash_dist_row(sk, k, i, i)
+                assert np.allclose(M[i, :i], ref, rtol=1e-12, atol=0), (i, np.nonzero(~np.isclose(M[i, :i], ref, rtol=1e-12, atol=0))[0][:5])
+            # placement batches and the transposed (divide-and-conquer assignment) output use the same kernel
+            st = d.place_run(capi.SRC_MASH, n, k=k)
+            Dm = np.tril(M, -1) + np.tril(M, -1).T
+            ref_st = orc.place_run(Dm)
+            assert np.array_equal(st["trace"][2:], ref_st["trace"][2:])
+        finally:
+            d.close()
+
+
 def _same_state(a, b, n):
     live = 4 * n - 4
     for key in ("head", "e", "nxt", "belong", "len"):
