@@ -3,6 +3,7 @@
 // gfx950 device.
 #include "dpr_internal.hpp"
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -259,8 +260,14 @@ int dpr_create(dpr_ctx** out, int device)
 {
     if (!out) { set_error("dpr_create: null out"); return DPR_ERR_ARG; }
     *out = nullptr;
+    const bool tlog = std::getenv("DPR_CLI_TIMING") != nullptr;
+    const auto tc0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (tlog) std::fprintf(stderr, "  dpr_create: %s at %.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
+    };
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
+    lap("hipGetDeviceCount (runtime start-up)");
     if (e != hipSuccess || count <= 0) {
         set_error("Gpu_ERROR: no HIP device available (this library has no CPU fallback)");
         return DPR_ERR_HIP;
@@ -273,6 +280,7 @@ int dpr_create(dpr_ctx** out, int device)
         set_error(std::string("Gpu_ERROR: device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
         return DPR_ERR_HIP;
     }
+    lap("hipSetDevice + properties");
     dpr_ctx* c = new dpr_ctx();
     c->device = device;
     hipError_t ce = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -286,8 +294,10 @@ int dpr_create(dpr_ctx** out, int device)
     }
     // first launch of the library: the runtime loads the whole gfx950 code object now, i.e. inside context creation
     // (which the CLI overlaps with reading the input) instead of in front of the first distance kernel
+    lap("stream + events");
     hipLaunchKernelGGL(dpr_warm_kernel, dim3(1), dim3(64), 0, c->stream, 0);
     (void)hipGetLastError();
+    if (tlog) { (void)hipStreamSynchronize(c->stream); lap("first kernel (code object load) done"); }
     *out = c;
     return DPR_OK;
 }
