@@ -249,6 +249,8 @@ def main():
                     help="skip the command-line steps: `value` is then the in-process hot path (used when profiling the kernels)")
     ap.add_argument("--no-parity", action="store_true", help="skip the untimed self-check of the timed result")
     ap.add_argument("--no-sharded", action="store_true", help="several GPUs: skip the 100 000-tip unit-sharded sub-record")
+    ap.add_argument("--no-stream-leg", action="store_true", help="skip the row-sharded streaming-NJ sub-record")
+    ap.add_argument("--stream-iters", type=int, default=256)
     ap.add_argument("--sharded-tips", type=int, default=100000)
     ap.add_argument("--sharded-sites", type=int, default=10000)
     ap.add_argument("--probe-only", action="store_true",
@@ -579,6 +581,30 @@ def main():
         dip = None
 
         # =====================================================================================================
+        # E2. north_star's partitioning on this run's GPUs: matrix row-sharded over the ranks, one full Q scan per
+        #     iteration (streaming NJ), the block winners exchanged with RCCL -- NJ iterations/s and aggregate GB/s
+        # =====================================================================================================
+        if not args.probe_only and not args.no_stream_leg and (world == 1 or have_comm):
+            dog = None
+            if world > 1:
+                def give_up_stream():
+                    out["streaming_row_sharded"] = {"error": "no result within the time limit"}
+                    if rank == 0:
+                        os.write(json_fd, (json.dumps(out) + "\n").encode())
+                    os._exit(3)
+                dog = threading.Timer(300.0, give_up_stream)
+                dog.daemon = True
+                dog.start()
+            try:
+                out["streaming_row_sharded"] = streaming_leg(rank, world, local_rank, dist, torch, barrier, packed, n, L,
+                                                             args.stream_iters, solo_denominator=True)
+            except Exception as e:
+                out["streaming_row_sharded"] = {"error": repr(e)}
+            finally:
+                if dog is not None:
+                    dog.cancel()
+
+        # =====================================================================================================
         # F. several GPUs: the unit-sharded NJ plan where it can pay -- N = 100 000 (80 GB matrix per rank), one step
         # =====================================================================================================
         run_sharded = (world > 1 and have_comm) or force_check
@@ -607,6 +633,78 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
+
+
+def streaming_leg(rank, world, local_rank, dist, torch, barrier, packed, n, L, iters, solo_denominator=False):
+    """The streaming NJ (the reference's algorithm: one full Q-argmin scan per iteration, src/neighborJoining.cu:211-243)
+    with the matrix row-sharded block-cyclically over the ranks: `iters` iterations on the given input.  Every rank
+    scans its rows; the per-rank winners and the two merged rows travel in RCCL all-gathers (ctx.hip, exchange()).
+    With one rank this is the single-GPU streaming loop -- the denominator of the scaling figure; with
+    solo_denominator rank 0 also runs that loop alone so that the record carries its own 1-GPU figure."""
+    import dipper_amd
+    from dipper_amd import capi
+    iters = max(1, min(iters, n - 2))
+
+    def run(d, timed_world):
+        d.set_nj_mode(0)
+        d.set_msa(packed, L)
+        d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+        d.nj_run(max_iters=8)           # warm-up: first launches / communicator channels
+        d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+        if timed_world > 1:
+            barrier()
+        else:
+            torch.cuda.synchronize()
+        ts = time.perf_counter()
+        res = d.nj_run(max_iters=iters)
+        if timed_world > 1:
+            barrier()
+        wall = time.perf_counter() - ts
+        if timed_world > 1:
+            t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        # algorithmic bytes of iteration k: strict lower triangle of the n-k active rows, 8 bytes per element, read
+        # once, + the row sums -- what the single-GPU roofline record counts (4 n^2 + 4 n)
+        by = sum(4.0 * (n - k) * (n - k) + 4.0 * (n - k) for k in range(res["iters"]))
+        return res, {"iterations": int(res["iters"]), "wall_s": wall,
+                     "us_per_iteration": wall / max(res["iters"], 1) * 1e6,
+                     "nj_iterations_per_s": res["iters"] / wall,
+                     "aggregate_GBps": by / wall / 1e9, "peak_GBps": HBM_PEAK_GBS * timed_world,
+                     "frac_of_aggregate_peak": by / wall / 1e9 / (HBM_PEAK_GBS * timed_world),
+                     "merge_log_digest": merge_digest(res)}
+
+    rec = {"tips": n, "sites": L, "world": world,
+           "layout": "rows block-cyclic over the ranks (dpr_shard_owner), one full Q scan per iteration, all-gather of "
+                     "the per-rank winners + of the two merged rows; nj_run(max_iters) -- the first iterations of the run"}
+    d = dipper_amd.Dipper(local_rank)
+    try:
+        if world > 1:
+            uid = [d.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            d.comm_init(rank, world, uid[0])
+        res, r = run(d, world)
+        rec.update(r)
+    finally:
+        d.close()
+    if world > 1:
+        digest = int(merge_digest(res)[:14], 16)
+        mine = torch.tensor([digest], dtype=torch.int64, device="cuda")
+        allh = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allh, mine)
+        rec["ranks_agree"] = bool(all(int(t.item()) == digest for t in allh))
+        if solo_denominator:
+            if rank == 0:
+                s1 = dipper_amd.Dipper(local_rank)
+                try:
+                    ref, r1 = run(s1, 1)
+                finally:
+                    s1.close()
+                rec["single_gpu"] = r1
+                rec["matches_single_gpu"] = same_log(ref, res)
+                rec["iteration_speedup_vs_single_gpu"] = r1["wall_s"] / rec["wall_s"]
+            dist.barrier()
+    return rec
 
 
 def sharded_leg(args, rank, world, local_rank, dist, torch, barrier, rehearsal):
@@ -667,6 +765,13 @@ def sharded_leg(args, rank, world, local_rank, dist, torch, barrier, rehearsal):
         s.close()
     if dist is not None:
         dist.barrier()
+    # the row-sharded streaming plan at this size too (scan = 40 GB per iteration: the size where the exchange is small
+    # beside the scan)
+    try:
+        rec["streaming_row_sharded"] = streaming_leg(rank, world, local_rank, dist if world > 1 else None, torch, barrier, packed, ns, Ls,
+                                                     max(8, args.stream_iters // 4), solo_denominator=True)
+    except Exception as e:
+        rec["streaming_row_sharded"] = {"error": repr(e)}
     return rec
 
 

@@ -348,11 +348,11 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjpArgs a)
             NJP_STAMP(0, 2, false);
             if (wm <= bq) {                           // wave-uniform; the q are recomputed (same operations, same bits)
                 if (wm < bq) { bq = wm; bk = ~0ull; }   // rather than kept: 128 registers less, twice the blocks per CU
-                if (a.dbg != nullptr && it == a.dbg_it && (tid & 63) == 0) atomicAdd(&a.dbg[(int)blockIdx.x * 8 + 6], 1ull);
+                if (a.dbg != nullptr && (it == a.dbg_it || a.dbg_it == -2) && (tid & 63) == 0) atomicAdd(&a.dbg[(a.dbg_it == -2 ? 0 : (int)blockIdx.x) * 8 + 6], 1ull);
 #pragma unroll
                 for (int u8 = 0; u8 < kUR; ++u8) {
                     if (__builtin_amdgcn_ballot_w64(rowq[u8] == wm) != 0ull) {      // rare; the four q are recomputed (same bits)
-                        if (a.dbg != nullptr && it == a.dbg_it && (tid & 63) == 0) atomicAdd(&a.dbg[(int)blockIdx.x * 8 + 5], 1ull);
+                        if (a.dbg != nullptr && (it == a.dbg_it || a.dbg_it == -2) && (tid & 63) == 0) atomicAdd(&a.dbg[(a.dbg_it == -2 ? 0 : (int)blockIdx.x) * 8 + 5], 1ull);
                         double d0 = v[u8].x, d1 = v[u8].y;
                         asm volatile("" : "+v"(d0), "+v"(d1));    // opaque: keeps the compiler from holding pass 1's 64 q alive
                         const bool e0 = (d0 - ua[u8]) - ub0 == wm, e1 = (d0 - ub0) - ua[u8] == wm;
