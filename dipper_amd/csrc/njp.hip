@@ -738,6 +738,14 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
     unsigned long long base = 0;
     if (lane == 0 && mask) base = atomicAdd(&a.cnt[(it + 1) % 3], (unsigned long long)__popcll(mask));
     base = __shfl(base, 0, 64);
+    if (a.dbg != nullptr && a.dbg_it == -2 && mask) {       // DPR_NJ_PHASES=-2: per iteration the largest number of (sub-)units one test block lists
+        int subs = keep ? __popc(submask) : 0;
+        for (int off = 32; off > 0; off >>= 1) subs += __shfl_xor(subs, off, 64);
+        if (lane == 0 && it < 32768) {
+            atomicMax(&a.dbg[32768 + it], ((unsigned long long)__popcll(mask) << 32) | (unsigned long long)subs);
+            atomicAdd(&a.dbg[7], (unsigned long long)subs);
+        }
+    }
     NJP_STAMP(1, 5, true);
     if (keep) a.list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)(((uint32_t)submask << 28) | ((uint32_t)cb << 18) | (uint32_t)g);   // sub-unit mask | strip | group
     NJP_STAMP(1, 6, true);
@@ -748,7 +756,7 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
 // ------------------------------------------------------------------------------------------------
 static int64_t round_up16(int64_t v) { return (v + 15) / 16 * 16; }
 static int g_njp_grid = 1024;
-static unsigned long long* g_njp_dbg = nullptr;     // DPR_NJ_PHASES: [2 kernels][2048 blocks][8 stamps]
+static unsigned long long* g_njp_dbg = nullptr;     // DPR_NJ_PHASES: [2 kernels][2048 blocks][8 stamps], then 32768 words of accumulate-mode statistics
 static int64_t g_njp_dbg_it = -1;
 int njp_scan_grid() { return g_njp_grid; }
 
@@ -902,8 +910,8 @@ int njp_build(NjBuffers& b, hipStream_t s)
     }
     if (const char* e = std::getenv("DPR_NJ_PHASES")) {
         g_njp_dbg_it = std::atoll(e);
-        if (!g_njp_dbg) DPR_HIP(hipMalloc(&g_njp_dbg, sizeof(unsigned long long) * 2 * 2048 * 8));
-        DPR_HIP(hipMemsetAsync(g_njp_dbg, 0, sizeof(unsigned long long) * 2 * 2048 * 8, s));
+        if (!g_njp_dbg) DPR_HIP(hipMalloc(&g_njp_dbg, sizeof(unsigned long long) * 4 * 2048 * 8));
+        DPR_HIP(hipMemsetAsync(g_njp_dbg, 0, sizeof(unsigned long long) * 4 * 2048 * 8, s));
     }
     // b.D / b.U hold the matrix and the row sums in tip order (world == 1).  Sort by U ascending.
     const int64_t N = b.N;
@@ -1164,7 +1172,7 @@ int njp_phase_stamps(unsigned long long* out)
 {
     if (!g_njp_dbg) { set_error("DPR_NJ_PHASES not set"); return DPR_ERR_STATE; }
     DPR_HIP(hipDeviceSynchronize());
-    DPR_HIP(hipMemcpy(out, g_njp_dbg, sizeof(unsigned long long) * 2 * 2048 * 8, hipMemcpyDeviceToHost));
+    DPR_HIP(hipMemcpy(out, g_njp_dbg, sizeof(unsigned long long) * 4 * 2048 * 8, hipMemcpyDeviceToHost));
     return DPR_OK;
 }
 

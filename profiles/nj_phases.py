@@ -23,7 +23,7 @@ d.set_msa(capi.pack4_many(seqs), L)
 d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
 d.nj_run()
 print("nj_ms", d.timing()[1])
-buf = np.zeros(2 * 2048 * 8, np.uint64)
+buf = np.zeros(4 * 2048 * 8, np.uint64)
 L_ = capi.load_library()
 L_.dpr_get_nj_phase_stamps.argtypes = [C.c_void_p]
 assert L_.dpr_get_nj_phase_stamps(buf.ctypes.data) == 0
