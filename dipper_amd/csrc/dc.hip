@@ -16,6 +16,7 @@
 //    the cluster sizes), so all cluster trees are built concurrently, one wavefront per cluster, from
 //    per-cluster distance blocks computed beforehand by the tiled pair kernels.
 #include <algorithm>
+#include <cstdlib>
 
 #include "dpr_internal.hpp"
 
@@ -237,15 +238,22 @@ __device__ __forceinline__ bool dc_list_insert(double* cdis, int32_t* cid, int32
 // One wavefront per cluster: members in ascending tip order; per member the masked edge scan
 // (positions in the reference's edgeMask order), the edge split and the in-cluster closest update.
 // clx mirrors cid with the column of the leaf inside the cluster's distance block.
-__global__ __launch_bounds__(64) void dc_cluster_kernel(PlaceBuffers p, int32_t* __restrict__ clx,
-                                                        const DcCluster* __restrict__ cl,
-                                                        const int32_t* __restrict__ members,
-                                                        const double* __restrict__ Dc, int32_t* __restrict__ qid,
-                                                        int32_t* __restrict__ qfrom, double* __restrict__ qdis,
-                                                        int32_t* __restrict__ status, double* __restrict__ trace)
+// kW wavefronts per cluster: the masked edge scan of a member (2 + 4t positions, the part that grows with the cluster)
+// is shared by all of them, the split and the in-cluster closest update stay with wavefront 0.  kW = 1 for the many
+// small clusters (one wavefront each, thousands resident), kW = 16 for the few large ones, whose serial member loops
+// would otherwise bound the phase (cost ~ m^2 / lanes).
+template <int kW>
+__global__ __launch_bounds__(64 * kW) void dc_cluster_kernel(PlaceBuffers p, int32_t* __restrict__ clx,
+                                                             const DcCluster* __restrict__ cl,
+                                                             const int32_t* __restrict__ members,
+                                                             const double* __restrict__ Dc, int32_t* __restrict__ qid,
+                                                             int32_t* __restrict__ qfrom, double* __restrict__ qdis,
+                                                             int32_t* __restrict__ status, double* __restrict__ trace)
 {
+    __shared__ double s_add[kW], s_frac[kW];
+    __shared__ int s_pos[kW], s_eid[kW];
     const DcCluster C = cl[blockIdx.x];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = C.slot, oth = p.rev[j];
     const int N = (int)p.N;
     int32_t* q_id = qid + C.qoff; int32_t* q_from = qfrom + C.qoff; double* q_dis = qdis + C.qoff;
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(64) void dc_cluster_kernel(PlaceBuffers p, int32_t*
         // ---- calculateBranchLengthSpecialIDDC + first minimum over mask positions
         double badd = __builtin_inf(), bfrac = 0;
         int bpos = 0x7fffffff, beid = 0;
-        for (int pos = lane; pos < edge_count; pos += 64) {
+        for (int pos = tid; pos < edge_count; pos += 64 * kW) {
             const int slot = pos == 0 ? j : pos == 1 ? oth : C.base_slot + 4 * ((pos - 2) >> 2) + (3 - ((pos - 2) & 3));
             double add = 2.0, d1 = 0.0;
             int eid = 0;
@@ -290,17 +298,25 @@ __global__ __launch_bounds__(64) void dc_cluster_kernel(PlaceBuffers p, int32_t*
             const double of = __shfl_down(bfrac, off, 64);
             if (oa < badd || (oa == badd && op < bpos)) { badd = oa; bpos = op; beid = oe; bfrac = of; }
         }
-        const int eid = __shfl(beid, 0, 64);
-        const int wpos = __shfl(bpos, 0, 64);
-        const double fracLen = __shfl(bfrac, 0, 64), addLen = __shfl(badd, 0, 64);
+        if (kW > 1) {     // wave winners -> block winner (smallest add, then smallest position), the same in every thread
+            if (lane == 0) { s_add[wave] = badd; s_pos[wave] = bpos; s_eid[wave] = beid; s_frac[wave] = bfrac; }
+            __syncthreads();
+            badd = s_add[0]; bpos = s_pos[0]; beid = s_eid[0]; bfrac = s_frac[0];
+#pragma unroll
+            for (int w = 1; w < kW; ++w)
+                if (s_add[w] < badd || (s_add[w] == badd && s_pos[w] < bpos)) { badd = s_add[w]; bpos = s_pos[w]; beid = s_eid[w]; bfrac = s_frac[w]; }
+        }
+        const int eid = kW > 1 ? beid : __shfl(beid, 0, 64);
+        const int wpos = kW > 1 ? bpos : __shfl(bpos, 0, 64);
+        const double fracLen = kW > 1 ? bfrac : __shfl(bfrac, 0, 64), addLen = kW > 1 ? badd : __shfl(badd, 0, 64);
         // an ineligible tuple (eid 0, add 2) or nothing comparable won: the reference would split slot 0,
         // which belongs to another cluster; reported instead (needs distances >= 2)
-        if (wpos == 0x7fffffff || !(addLen < 2.0)) {
-            if (lane == 0) atomicExch(status, 1 + blockIdx.x);
+        if (wpos == 0x7fffffff || !(addLen < 2.0)) {     // block-uniform
+            if (tid == 0) atomicExch(status, 1 + blockIdx.x);
             return;
         }
         const int ec0 = C.base_slot + 4 * t;
-        if (lane == 0) {
+        if (tid == 0) {
             if (trace) { trace[3 * leaf + 1] = fracLen; trace[3 * leaf + 2] = addLen; }   // [3*leaf] keeps the cluster id
             int ec = ec0;
             const int middle = C.base_leaf + t + N - 1, outside = leaf;
@@ -347,14 +363,14 @@ __global__ __launch_bounds__(64) void dc_cluster_kernel(PlaceBuffers p, int32_t*
             q_id[0] = leaf; q_dis[0] = 0.0; q_from[0] = -1;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_barrier();
+        if (kW == 1) __builtin_amdgcn_s_barrier();      // (kW > 1: wavefront 0 goes on alone, program order + the fences)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         // ---- updateClosestNodesInClusterDC, frontier-parallel (every directed edge of a tree is reached at
         // most once, so the insertions do not depend on the visiting order)
         const int ed1 = p.e[j], ed2 = p.belong[j];
         const int hi_slot = ec0 + 4;   // cluster slots: j, oth, [base_slot, hi_slot)
         int l = 0, r = 1;
-        while (l < r) {
+        while (wave == 0 && l < r) {
             const int cnt = min(64, r - l);
             int node = -1, fb = -1;
             double d = 0.0;
@@ -385,7 +401,12 @@ __global__ __launch_bounds__(64) void dc_cluster_kernel(PlaceBuffers p, int32_t*
             l += cnt;
             r += total;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_s_barrier();
+            if (kW == 1) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        if (kW > 1) {     // the other wavefronts scan the next member against what wavefront 0 has just stored
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
     }
@@ -529,6 +550,8 @@ int dc_cluster_phase(PlaceBuffers& p, const int32_t* h_cluster_id, int64_t N, in
         if (d_out) (void)hipFree(d_out);
         d_i32 = nullptr; d_i64 = nullptr; d_jobs = nullptr; d_out = nullptr;
     };
+    int64_t big_m = 64;         // clusters above this size get a whole workgroup (DPR_DC_BIG_CLUSTER: validation / tuning)
+    if (const char* e = std::getenv("DPR_DC_BIG_CLUSTER")) big_m = std::atoll(e);
     auto run = [&]() -> int {
         while (g0 < ncl) {
             // ---- a group of clusters whose distance blocks fit the budget
@@ -571,9 +594,19 @@ int dc_cluster_phase(PlaceBuffers& p, const int32_t* h_cluster_id, int64_t N, in
             J.cl_m = d_i32; J.cl_ld = d_i32 + gn; J.out = d_out;
             if (source == DPR_SRC_MSA) { if (int r2 = msa_dist_jobs(*msa, dist_type, J, (int)jobs.size(), s)) return r2; }
             else { if (int r2 = mash_dist_jobs(*mash, J, (int)jobs.size(), s)) return r2; }
-            hipLaunchKernelGGL(dc_cluster_kernel, dim3((unsigned)gn), dim3(64), 0, s, p, d_clx, d_cl + g0, d_members, d_out,
-                               d_qid, d_qfrom, d_qdis, d_status, d_trace);
-            DPR_HIP(hipGetLastError());
+            // clusters are sorted by size: the large ones of the group first, a workgroup of 16 wavefronts each
+            int64_t nbig = 0;
+            while (nbig < gn && cl[(size_t)(g0 + nbig)].m > big_m) ++nbig;
+            if (nbig > 0) {
+                hipLaunchKernelGGL(dc_cluster_kernel<16>, dim3((unsigned)nbig), dim3(1024), 0, s, p, d_clx, d_cl + g0, d_members, d_out,
+                                   d_qid, d_qfrom, d_qdis, d_status, d_trace);
+                DPR_HIP(hipGetLastError());
+            }
+            if (gn > nbig) {
+                hipLaunchKernelGGL(dc_cluster_kernel<1>, dim3((unsigned)(gn - nbig)), dim3(64), 0, s, p, d_clx, d_cl + g0 + nbig, d_members, d_out,
+                                   d_qid, d_qfrom, d_qdis, d_status, d_trace);
+                DPR_HIP(hipGetLastError());
+            }
             DPR_HIP(hipStreamSynchronize(s));   // host vectors and group buffers are reused
             cleanup_group();
             g0 = g1;
