@@ -1112,7 +1112,8 @@ static int njp_enqueue_iteration(NjBuffers& b, hipStream_t s, bool sample = fals
 // enqueue `todo` iterations starting at iteration it0.  The kernels of an iteration take no per-iteration
 // arguments, so kGraphIters iterations are captured once into a hipGraph and replayed; iterations beyond
 // it_limit are no-ops.  Afterwards the node in quarantine is materialised (row sum, matrix row).
-constexpr int kGraphIters = 32;
+static int g_graph_iters = 32;      // DPR_NJ_GRAPH_ITERS
+#define kGraphIters g_graph_iters
 
 static int njp_run_segment(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
 {
@@ -1132,6 +1133,7 @@ static int njp_run_segment(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t 
         q.fresh = false;
     }
     const bool timing = b.kt && b.kt->stride > 0 && q.sh_world <= 1;
+    if (const char* e = std::getenv("DPR_NJ_GRAPH_ITERS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096 && v != g_graph_iters) { g_graph_iters = v; if (q.graph) { (void)hipGraphExecDestroy(q.graph); q.graph = nullptr; } } }
     const bool use_graph = q.sh_world <= 1 && todo >= kGraphIters && !timing && !std::getenv("DPR_NJ_NOGRAPH");
     if (use_graph && !q.graph) {
         const auto tg0 = std::chrono::steady_clock::now();
