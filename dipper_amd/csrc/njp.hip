@@ -40,10 +40,39 @@
 namespace dpr {
 
 constexpr int kUR = 16;  // rows per unit
-// row groups (= units of one strip) per test block of the post kernel: 64 below 50 000 positions (1024 row positions per
+// Row groups (= units of one strip) per test block of the post kernel: 64 below 40 000 positions (1024 row positions per
 // block: the row phase of a block is short, NJ 500 -> 482 ms at 30 000 tips), 256 above (fewer blocks, less repeated
-// column and record work where the kernel is throughput-bound: 26.7 vs 36.7 us per launch at 100 000 tips)
-__host__ __device__ inline int njp_tg(int64_t P) { return P < 50000 ? 64 : 256; }
+// column and record work where the kernel is throughput-bound).  The switch: 38 000-50 000 positions measured within
+// 1.5 % of each other at 100 000 tips, 24 000 costs 8 % at 30 000 tips; DPR_NJ_BIG_P moves it (the tests run both shapes).
+static int64_t njp_big_p()
+{
+    static const int64_t v = std::getenv("DPR_NJ_BIG_P") ? std::atoll(std::getenv("DPR_NJ_BIG_P")) : 40000;
+    return v;
+}
+static int njp_tg(int64_t P) { return P < njp_big_p() ? 64 : 256; }
+// Strips per test block.  In the small shape a test block is one strip x 64 row groups (the post kernel is a chain of
+// dependent round trips there and all blocks are resident at once).  In the large shape one strip x 256 groups left
+// ~2 900 blocks of ~160 registers per thread, i.e. several rounds of resident blocks, each paying the whole chain (select,
+// rows x / y, row sums): 33 us per launch at 100 000 tips.  So a block keeps its 256 row groups and handles kBigNS strips
+// with them, all strips' loads in flight together: 23 us per launch (2 strips: +9 %, 8 strips one load ahead: +4 %, 16: +29 %;
+// the block that owns 256 row groups then needs 247 registers, two blocks per CU, and the grid still takes two rounds).
+constexpr int kBigNS = 4;
+static int njp_big_ns()
+{
+    static const int v = std::getenv("DPR_NJ_BIG_NS") ? std::atoi(std::getenv("DPR_NJ_BIG_NS")) : kBigNS;
+    return v == 2 ? v : kBigNS;
+}
+static int njp_ns(int64_t P) { return njp_tg(P) == 64 ? 1 : njp_big_ns(); }
+// strips that hold a valid unit for some group of the row block [g0, g0 + tg)
+__host__ __device__ inline int64_t njp_strips_of_rows(int64_t g0, int64_t tg, int64_t P)
+{
+    const int64_t G16 = (P + 16 - 1) / 16;
+    const int64_t glast = (g0 + tg < G16 ? g0 + tg : G16) - 1;
+    if (glast < 0) return 0;
+    int64_t c = glast / 32 + 1;                       // strips with 32 c <= glast
+    const int64_t cp = (P - 2) / 512 + 1;             // strips with 512 c < P - 1
+    return P >= 2 ? (c < cp ? c : cp) : 0;
+}
 
 __device__ __forceinline__ uint64_t enc_f64(double x)
 {
@@ -73,16 +102,23 @@ __host__ __device__ inline int64_t unit_total(int64_t P)
 }
 
 // Unit ownership of the unit-sharded mode (also exported for the CPU tests of the N > 1 logic).  Units are tested in
-// blocks of one strip x njp_tg(P) consecutive row groups (strip-major); test block t belongs to rank t mod world, and with it
-// its units -- so a rank launches (and pays for) only its own share of the test blocks.
+// blocks of njp_ns(P) strips x njp_tg(P) consecutive row groups (one strip, strip-major, in the small shape; row-block
+// major above); test block t belongs to rank t mod world, and with it its units -- so a rank launches (and pays for) only
+// its own share of the test blocks.
 int njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world)
 {
     const int64_t G16 = (P + kUR - 1) / kUR;
     if (strip < 0 || group < 0 || group >= G16 || group < 32 * strip || strip * kTileCols >= P - 1 || world < 1) return -1;
     int64_t t = 0;
-    const int64_t tg = njp_tg(P);
-    for (int64_t c = 0; c < strip; ++c) t += (G16 - 32 * c + tg - 1) / tg;     // test blocks of the strips before
-    t += (group - 32 * strip) / tg;
+    const int64_t tg = njp_tg(P), ns = njp_ns(P);
+    if (ns == 1) {
+        for (int64_t c = 0; c < strip; ++c) t += (G16 - 32 * c + tg - 1) / tg;     // test blocks of the strips before
+        t += (group - 32 * strip) / tg;
+    } else {                                                                        // row-block major, ns strips per block
+        const int64_t k = group / tg;
+        for (int64_t kk = 0; kk < k; ++kk) t += (njp_strips_of_rows(kk * tg, tg, P) + ns - 1) / ns;
+        t += strip / ns;
+    }
     return (int)(t % world);
 }
 
@@ -137,7 +173,9 @@ struct NjpArgs {
     double* Ur; uint64_t* KA; uint64_t* KB; int32_t* slot_of_pos; int32_t* pos_of_slot;
     double* xpart; NjRecord* partials; unsigned long long* umin;
     int64_t P;
-    const int32_t* blk_cb; const int32_t* blk_g0; int ntest;     // test blocks: (strip, first group), up to 256 groups each
+    const int32_t* blk_cb; const int32_t* blk_g0; int ntest;     // test blocks: (first strip, first group), up to 256 groups each
+    int tg, ns;                                                  // ... of tg row groups x up to ns strips
+    int nupd;                                                    // update blocks of this post launch
     int32_t* list; unsigned long long* cnt;     // the list of THIS launch's rank and its counters cnt[0..2]
     int ugrid;        // unit-scan blocks per rank
     int urecs;        // unit records in partials (ugrid x ranks); the new-row records follow them
@@ -184,16 +222,22 @@ __global__ __launch_bounds__(kThreads) void njp_list_all_kernel(NjpArgs a)
     const int64_t it = a.st->it;
     if (a.st->status != 0) return;
     const int tb = a.sh_rank + (int)blockIdx.x * a.sh_world;      // this rank's blockIdx.x-th test block
-    const int cb = a.blk_cb[tb];
+    const int cb0 = a.blk_cb[tb];
     const int64_t g = (int64_t)a.blk_g0[tb] + tid;
     const int64_t G16 = (a.P + kUR - 1) / kUR;
-    const bool keep = g < G16 && tid < njp_tg(a.P);
-    const unsigned long long mask = __ballot(keep);
+    const int tg = a.tg;
+    int64_t send = njp_strips_of_rows((int64_t)a.blk_g0[tb], tg, a.P);
+    if (a.ns == 1) send = cb0 + 1;
+    else if (send > cb0 + a.ns) send = cb0 + a.ns;
     const int lane = tid & 63;
-    unsigned long long base = 0;
-    if (lane == 0 && mask) base = atomicAdd(&a.cnt[it % 3], (unsigned long long)__popcll(mask));
-    base = __shfl(base, 0, 64);
-    if (keep) a.list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)((0xFu << 28) | ((uint32_t)cb << 18) | (uint32_t)g);
+    for (int cb = cb0; cb < (int)send; ++cb) {
+        const bool keep = g < G16 && g >= 32 * (int64_t)cb && tid < tg;
+        const unsigned long long mask = __ballot(keep);
+        unsigned long long base = 0;
+        if (lane == 0 && mask) base = atomicAdd(&a.cnt[it % 3], (unsigned long long)__popcll(mask));
+        base = __shfl(base, 0, 64);
+        if (keep) a.list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)((0xFu << 28) | ((uint32_t)cb << 18) | (uint32_t)g);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -437,16 +481,21 @@ __global__ __launch_bounds__(kThreads) void njp_finish_kernel(NjpArgs a)
 //    the same way; the row of the node that LEAVES quarantine (merge it - 1, row buffer R[(it - 1) & 1]) is
 //    folded into the bounds of the sub-units it crosses; survivors are appended to the list of scan it + 1.
 // ------------------------------------------------------------------------------------------------
-template <int kTG>
+template <int kTG, int kNS>
 __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
 {
     __shared__ double s[kThreads];
     __shared__ double sq[kThreads / 64], sdd[kThreads / 64];
     __shared__ uint64_t sk[kThreads / 64], spp[kThreads / 64];
-    __shared__ double sseed[kThreads / 64], scm[kThreads / 64], snew[kThreads / 64];
+    __shared__ double sseed[kThreads / 64];
     const int tid = threadIdx.x;
-    const bool test_block = (int)blockIdx.x < a.ntest;
-    const int tb = test_block ? a.sh_rank + (int)blockIdx.x * a.sh_world : 0;      // this rank's blockIdx.x-th test block
+    // block roles: test blocks first, then the update blocks (the other way round -- the short update blocks ahead of the
+    // test blocks when the grid does not fit on the chip at once -- measured 5 % slower at 100 000 tips)
+    const int bx = (int)blockIdx.x;
+    const bool upd_first = (a.flags & 2) != 0;
+    const bool test_block = upd_first ? bx >= a.nupd : bx < a.ntest;
+    const int tbi = upd_first ? bx - a.nupd : bx, ubi = upd_first ? bx : bx - a.ntest;
+    const int tb = test_block ? a.sh_rank + tbi * a.sh_world : 0;      // this rank's tbi-th test block
     // hop 1: state line, scan records, and what each role can address without knowing the winner
     const int64_t it = a.st->itb;   // stable: the writer below only advances st->it
     const int64_t limit = a.st->it_limit, N = a.st->N;
@@ -479,34 +528,52 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
     const int64_t G16 = (P + kUR - 1) / kUR;
     const int64_t pclamp = (P + 1) & ~(int64_t)1;     // an even index behind the last position (16-byte aligned pair loads)
     // update role
-    const int64_t i = (int64_t)((int)blockIdx.x - a.ntest) * kThreads + tid;     // reference slot
+    const int64_t i = (int64_t)ubi * kThreads + tid;     // reference slot
     int64_t p = -1;
     double up = 0.0;
-    // test role: the block's kTG row groups are 2048 consecutive positions, read COALESCED in chunks of 512 (thread t:
+    // test role: the block's kTG row groups are 16 kTG consecutive positions, read COALESCED in chunks of 512 (thread t:
     // positions rbase + 512 c + 2 t, + 1) -- one lane per group with 16 consecutive values each would touch 64 lines per
-    // wave instruction and push 8 x the bytes through L1
-    int cb = 0;
-    int64_t g = 0, rbase = 0, pc0 = 0;
-    bool have = false;
+    // wave instruction and push 8 x the bytes through L1.  The block walks nsb <= kNS strips with these rows; what a
+    // strip needs (its columns' row sums, rows x / y over its columns, the bounds of its units) is loaded up front.
+    struct ColData { v2d ucol, dxc, dyc, rzc; ulonglong2 um0, um1; };
+    int cb0 = 0, nsb = 0;
+    int64_t g = 0, rbase = 0;
+    bool have_g = false;
     constexpr int kRC = kTG * kUR / kTileCols;     // 512-position chunks of the block's row range
     v2d urow[kRC];
-    v2d ucol; ucol.x = 0.0; ucol.y = 0.0;
-    ulonglong2 um0 = make_ulonglong2(0ull, 0ull), um1 = um0;
-    unsigned long long* up4 = a.umin;
+    ColData cd[kNS];          // every strip of the block in flight at once (walking them one load ahead cost ~1.5 us per strip)
+#pragma unroll
+    for (int k = 0; k < kNS; ++k) {
+        cd[k].ucol.x = 0.0; cd[k].ucol.y = 0.0; cd[k].dxc = cd[k].ucol; cd[k].dyc = cd[k].ucol; cd[k].rzc = cd[k].ucol;
+        cd[k].um0 = make_ulonglong2(0ull, 0ull); cd[k].um1 = cd[k].um0;
+    }
+    // hop-1 part of a strip: nothing here depends on the winner
+    auto load_a = [&](int cb, ColData& c) {
+        const int64_t pc0 = (int64_t)cb * kTileCols + 2 * tid;                      // this thread's two strip columns (< P + 512)
+        c.ucol = *reinterpret_cast<const v2d*>(Uc + pc0);
+        if (have_g && g >= 32 * (int64_t)cb) {
+            const unsigned long long* up = a.umin + ((int64_t)cb * G16 + g) * 4;
+            c.um0 = *reinterpret_cast<const ulonglong2*>(up); c.um1 = *reinterpret_cast<const ulonglong2*>(up + 2);
+        }
+    };
     if (test_block) {
-        cb = a.blk_cb[tb];
+        cb0 = a.blk_cb[tb];
         g = (int64_t)a.blk_g0[tb] + tid;
-        have = g < G16 && tid < kTG;
+        have_g = g < G16 && tid < kTG;
         rbase = (int64_t)a.blk_g0[tb] * kUR;
-        pc0 = (int64_t)cb * kTileCols + 2 * tid;                      // this thread's two strip columns (< P + 512)
-        up4 = a.umin + ((int64_t)cb * G16 + (have ? g : 0)) * 4;
-        if (have) { um0 = *reinterpret_cast<const ulonglong2*>(up4); um1 = *reinterpret_cast<const ulonglong2*>(up4 + 2); }
+        if (kNS == 1) nsb = 1;
+        else {
+            const int64_t send = njp_strips_of_rows((int64_t)a.blk_g0[tb], kTG, P);
+            nsb = (int)(send - cb0 < kNS ? send - cb0 : kNS);
+        }
+#pragma unroll
+        for (int k = 0; k < kNS; ++k)
+            if (k < nsb) load_a(cb0 + k, cd[k]);
 #pragma unroll
         for (int c = 0; c < kRC; ++c) {
             const int64_t pp = rbase + c * kTileCols + 2 * tid;
             urow[c] = *reinterpret_cast<const v2d*>(Uc + (pp < P ? pp : pclamp));      // behind P: padding (NaN = dead)
         }
-        ucol = *reinterpret_cast<const v2d*>(Uc + pc0);
     } else {
         p = (int64_t)a.pos_of_slot[i];                 // (the slot arrays are padded past N)
     }
@@ -519,7 +586,7 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
     if (a.st->status != 0 || it >= limit) return;
     const int64_t n = N - it;
     if (n < 3) return;
-    if (!test_block && (!a.do_update || (int64_t)((int)blockIdx.x - a.ntest) * kThreads >= n)) return;
+    if (!test_block && (!a.do_update || (int64_t)ubi * kThreads >= n)) return;
     if (test_block && !a.do_tests) return;
     NJP_STAMP(1, 0, false);
     NJP_STAMP(1, 1, true);
@@ -607,21 +674,28 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
         }
         NJP_STAMP(1, 3, false);
         const double cs = block_tree256_lane0(val, s);
-        if (tid == 0) a.xpart[(int)blockIdx.x - a.ntest] = cs;
+        if (tid == 0) a.xpart[ubi] = cs;
         NJP_STAMP(1, 6, true);
         return;
     }
 
     // ---------------------------------------------------------------------------------- test role
     const double NINF = -__builtin_inf(), PINF = __builtin_inf();
-    // hop 2: rows x and y over this lane's 16 rows and 2 columns; the row buffer of the node leaving quarantine where
-    // it crosses this block's units; the seed candidates' row sums
+    // hop 2: rows x and y over this block's rows and the first strip's columns; the row buffer of the node leaving
+    // quarantine where it crosses this block's units; the seed candidates' row sums
     const bool fold = pz >= 0 && pz != px && pz != py;                       // block-uniform
     const double* __restrict__ Rz = a.R + ((it + 1) & 1) * a.vstride;        // written by POST(it - 1)
-    const bool pz_strip = fold && pz / kTileCols == cb;                      // block-uniform
     const int64_t gz = fold ? pz / kUR : -1;
     const bool gz_here = fold && gz >= (int64_t)a.blk_g0[tb] && gz < (int64_t)a.blk_g0[tb] + kTG;   // block-uniform
     const int wpz = fold ? (int)((pz % kTileCols) / (kTileCols / 4)) : -1;   // sub-strip of that node's column
+    // winner-dependent part of a strip
+    auto load_b = [&](int cb, ColData& c) {
+        const int64_t pc0 = (int64_t)cb * kTileCols + 2 * tid;
+        c.dxc = *reinterpret_cast<const v2d*>(rowx + pc0);
+        c.dyc = *reinterpret_cast<const v2d*>(rowy + pc0);
+        c.rzc.x = PINF; c.rzc.y = PINF;
+        if (gz_here) c.rzc = *reinterpret_cast<const v2d*>(Rz + pc0);
+    };
     v2d dxr[kRC], dyr[kRC];
 #pragma unroll
     for (int c = 0; c < kRC; ++c) {
@@ -630,9 +704,9 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
         dxr[c] = *reinterpret_cast<const v2d*>(rowx + po);
         dyr[c] = *reinterpret_cast<const v2d*>(rowy + po);
     }
-    const v2d dxc = *reinterpret_cast<const v2d*>(rowx + pc0), dyc = *reinterpret_cast<const v2d*>(rowy + pc0);
-    v2d rzc; rzc.x = PINF; rzc.y = PINF;
-    if (gz_here) rzc = *reinterpret_cast<const v2d*>(Rz + pc0);
+#pragma unroll
+    for (int k = 0; k < kNS; ++k)
+        if (k < nsb) load_b(cb0 + k, cd[k]);
     // seed candidate re-evaluated with the row sums after this merge
     double qc = PINF;
     if (seed_is_unit && (int64_t)tid * sstride >= uvalid) cand.key = ~0ull;          // not written by this iteration's scan
@@ -655,6 +729,7 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
     // are then conflict-free), and the test lane of a group takes the maximum of its 16.  Dead positions and the padding
     // behind P carry NaN in U; the merged pair is left out by (32-bit, block-local) index.
     __shared__ double s_un[kTG * (kUR + 1)];
+    __shared__ double scm2[2][kThreads / 64], snew2[2][kThreads / 64];
     const int lxp = (int)(px - rbase), lyp = (int)(py - rbase), lzp = (int)((fold ? pz : -1) - rbase);
 #pragma unroll
     for (int c = 0; c < kRC; ++c) {
@@ -668,86 +743,99 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
         s_un[li] = live0 ? n0 : NINF;
         s_un[li + 1] = live1 ? n1v : NINF;
     }
-    double u4[4] = { PINF, PINF, PINF, PINF };
-    if (have) { u4[0] = dec_f64(um0.x); u4[1] = dec_f64(um0.y); u4[2] = dec_f64(um1.x); u4[3] = dec_f64(um1.y); }
-    // column maximum of each sub-strip (wave w holds columns 128w .. 128w+127 of the strip); minimum of the row of the
-    // node leaving quarantine over the sub-strip's live columns
-    double cm_part = NINF, colmin = PINF;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int64_t pp = pc0 + k;
-        const double uo = k ? ucol.y : ucol.x;
-        const double dx = k ? dxc.y : dxc.x, dy = k ? dyc.y : dyc.x;
-        const double rz = k ? rzc.y : rzc.x;
-        const bool live = (uo == uo) & (pp != px) & (pp != py) & (pp < P);
-        const double un = nj_unew(uo, dx, dy, nj_val(dx, dy, d));      // divided after the wave maximum
-        cm_part = live ? fmax(cm_part, un) : cm_part;
-        colmin = (live & (pp < pz)) ? fmin(colmin, rz) : colmin;
-    }
     qc = wave_fmin(qc);
-    cm_part = wave_fmax(cm_part) / r1;            // (-inf stays -inf)
-    if (gz_here) colmin = wave_fmin(colmin);
-    if ((tid & 63) == 0) { sseed[tid >> 6] = qc; scm[tid >> 6] = cm_part; snew[tid >> 6] = colmin; }
-    __syncthreads();
-    NJP_STAMP(1, 4, false);
-    const double bound = fmin(fmin(sseed[0], sseed[1]), fmin(sseed[2], sseed[3]));
-    double rmax = NINF, newminA = PINF;                             // group g = blk_g0 + tid
+    if ((tid & 63) == 0) sseed[tid >> 6] = qc;
+    double bound = PINF, rmax = NINF;                               // both set behind the first strip's barrier
     const int tg = tid < kTG ? tid : 0;
-#pragma unroll
-    for (int k = 0; k < kUR; ++k) rmax = fmax(rmax, s_un[17 * tg + k]);
-    rmax = rmax / r1;                                               // (-inf stays -inf)
-    if (pz_strip) {
-        // block-uniform and rare (the strip of the node leaving quarantine): minimum of its buffered row over each
-        // group's live rows behind it, same route through LDS
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < kRC; ++c) {
-            const int lp = c * kTileCols + 2 * tid;
-            const int64_t pp = rbase + lp;
-            const v2d rz = *reinterpret_cast<const v2d*>(Rz + (pp < P ? pp : pclamp));
-            const double u0 = urow[c].x, u1 = urow[c].y;
-            const bool live0 = (u0 == u0) & (lp != lxp) & (lp != lyp) & (lp > lzp);
-            const bool live1 = (u1 == u1) & (lp + 1 != lxp) & (lp + 1 != lyp) & (lp + 1 > lzp);
-            const int li = lp + (lp >> 4);
-            s_un[li] = live0 ? rz.x : PINF;
-            s_un[li + 1] = live1 ? rz.y : PINF;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kUR; ++k) newminA = fmin(newminA, s_un[17 * tg + k]);
-    }
-    const bool own = have;      // (a rank launches only its own test blocks)
-    int submask = 0;
-    if (own) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const double cmw = scm[w];
-            double nm = (gz_here && g == gz) ? snew[w] : PINF;            // the unit (this strip, group of pz)
-            if (pz_strip && w == wpz) nm = fmin(nm, newminA);
-            if (nm < u4[w]) {                          // persist the lowered bound (this lane is the unit's only writer here)
-                u4[w] = nm;
-                up4[w] = enc_f64(nm);
-            }
-            const double lb = fmin((u4[w] - rmax) - cmw, (u4[w] - cmw) - rmax);
-            if ((cmw > NINF) && (lb <= bound)) submask |= 1 << w;
-        }
-    }
-    const bool keep = own && (rmax > NINF) && submask != 0;
-    const unsigned long long mask = __ballot(keep);
     const int lane = tid & 63;
-    unsigned long long base = 0;
-    if (lane == 0 && mask) base = atomicAdd(&a.cnt[(it + 1) % 3], (unsigned long long)__popcll(mask));
-    base = __shfl(base, 0, 64);
-    if (a.dbg != nullptr && a.dbg_it == -2 && mask) {       // DPR_NJ_PHASES=-2: per iteration the largest number of (sub-)units one test block lists
-        int subs = keep ? __popc(submask) : 0;
-        for (int off = 32; off > 0; off >>= 1) subs += __shfl_xor(subs, off, 64);
-        if (lane == 0 && it < 32768) {
-            atomicMax(&a.dbg[32768 + it], ((unsigned long long)__popcll(mask) << 32) | (unsigned long long)subs);
-            atomicAdd(&a.dbg[7], (unsigned long long)subs);
+#pragma unroll
+    for (int sidx = 0; sidx < kNS; ++sidx) {
+        if (sidx >= nsb) break;                       // block-uniform
+        const int cb = cb0 + sidx, par = sidx & 1;
+        const ColData& cur = cd[sidx];
+        const int64_t pc0 = (int64_t)cb * kTileCols + 2 * tid;
+        const bool pz_strip = fold && pz / kTileCols == cb;                      // block-uniform
+        const bool have = have_g && g >= 32 * (int64_t)cb;
+        unsigned long long* up4 = a.umin + ((int64_t)cb * G16 + (have ? g : 0)) * 4;
+        double u4[4] = { PINF, PINF, PINF, PINF };
+        if (have) { u4[0] = dec_f64(cur.um0.x); u4[1] = dec_f64(cur.um0.y); u4[2] = dec_f64(cur.um1.x); u4[3] = dec_f64(cur.um1.y); }
+        // column maximum of each sub-strip (wave w holds columns 128w .. 128w+127 of the strip); minimum of the row of the
+        // node leaving quarantine over the sub-strip's live columns
+        double cm_part = NINF, colmin = PINF;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int64_t pp = pc0 + k;
+            const double uo = k ? cur.ucol.y : cur.ucol.x;
+            const double dx = k ? cur.dxc.y : cur.dxc.x, dy = k ? cur.dyc.y : cur.dyc.x;
+            const double rz = k ? cur.rzc.y : cur.rzc.x;
+            const bool live = (uo == uo) & (pp != px) & (pp != py) & (pp < P);
+            const double un = nj_unew(uo, dx, dy, nj_val(dx, dy, d));      // divided after the wave maximum
+            cm_part = live ? fmax(cm_part, un) : cm_part;
+            colmin = (live & (pp < pz)) ? fmin(colmin, rz) : colmin;
         }
+        cm_part = wave_fmax(cm_part) / r1;            // (-inf stays -inf)
+        if (gz_here) colmin = wave_fmin(colmin);
+        if (lane == 0) { scm2[par][tid >> 6] = cm_part; snew2[par][tid >> 6] = colmin; }
+        __syncthreads();      // (one barrier per strip: the parity keeps a fast wave's next stores off the values still being read)
+        NJP_STAMP(1, 4, false);
+        if (sidx == 0) {
+            bound = fmin(fmin(sseed[0], sseed[1]), fmin(sseed[2], sseed[3]));
+#pragma unroll
+            for (int k = 0; k < kUR; ++k) rmax = fmax(rmax, s_un[17 * tg + k]);      // group g = blk_g0 + tid
+            rmax = rmax / r1;                                                       // (-inf stays -inf)
+        }
+        double newminA = PINF;
+        if (pz_strip) {
+            // block-uniform and rare (the strip of the node leaving quarantine): minimum of its buffered row over each
+            // group's live rows behind it, same route through LDS
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < kRC; ++c) {
+                const int lp = c * kTileCols + 2 * tid;
+                const int64_t pp = rbase + lp;
+                const v2d rz = *reinterpret_cast<const v2d*>(Rz + (pp < P ? pp : pclamp));
+                const double u0 = urow[c].x, u1 = urow[c].y;
+                const bool live0 = (u0 == u0) & (lp != lxp) & (lp != lyp) & (lp > lzp);
+                const bool live1 = (u1 == u1) & (lp + 1 != lxp) & (lp + 1 != lyp) & (lp + 1 > lzp);
+                const int li = lp + (lp >> 4);
+                s_un[li] = live0 ? rz.x : PINF;
+                s_un[li + 1] = live1 ? rz.y : PINF;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kUR; ++k) newminA = fmin(newminA, s_un[17 * tg + k]);
+        }
+        int submask = 0;
+        if (have) {      // (a rank launches only its own test blocks)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const double cmw = scm2[par][w];
+                double nm = (gz_here && g == gz) ? snew2[par][w] : PINF;      // the unit (this strip, group of pz)
+                if (pz_strip && w == wpz) nm = fmin(nm, newminA);
+                if (nm < u4[w]) {                          // persist the lowered bound (this lane is the unit's only writer here)
+                    u4[w] = nm;
+                    up4[w] = enc_f64(nm);
+                }
+                const double lb = fmin((u4[w] - rmax) - cmw, (u4[w] - cmw) - rmax);
+                if ((cmw > NINF) && (lb <= bound)) submask |= 1 << w;
+            }
+        }
+        const bool keep = have && (rmax > NINF) && submask != 0;
+        const unsigned long long mask = __ballot(keep);
+        unsigned long long base = 0;
+        if (lane == 0 && mask) base = atomicAdd(&a.cnt[(it + 1) % 3], (unsigned long long)__popcll(mask));
+        base = __shfl(base, 0, 64);
+        if (a.dbg != nullptr && a.dbg_it == -2 && mask) {       // DPR_NJ_PHASES=-2: per iteration the largest number of (sub-)units one test block lists
+            int subs = keep ? __popc(submask) : 0;
+            for (int off = 32; off > 0; off >>= 1) subs += __shfl_xor(subs, off, 64);
+            if (lane == 0 && it < 32768) {
+                atomicMax(&a.dbg[32768 + it], ((unsigned long long)__popcll(mask) << 32) | (unsigned long long)subs);
+                atomicAdd(&a.dbg[7], (unsigned long long)subs);
+            }
+        }
+        NJP_STAMP(1, 5, true);
+        if (keep) a.list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)(((uint32_t)submask << 28) | ((uint32_t)cb << 18) | (uint32_t)g);   // sub-unit mask | strip | group
     }
-    NJP_STAMP(1, 5, true);
-    if (keep) a.list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)(((uint32_t)submask << 28) | ((uint32_t)cb << 18) | (uint32_t)g);   // sub-unit mask | strip | group
     NJP_STAMP(1, 6, true);
 }
 
@@ -773,11 +861,19 @@ static int64_t prep_blocks(int64_t P, std::vector<int32_t>* hcb, std::vector<int
 {
     const int64_t G16 = (P + kUR - 1) / kUR;
     int64_t cnt = 0;
-    for (int64_t c = 0; 32 * c < G16 && c * kTileCols < P - 1; ++c)
-        for (int64_t g0 = 32 * c; g0 < G16; g0 += njp_tg(P)) {
-            if (hcb) { hcb->push_back((int32_t)c); hg0->push_back((int32_t)g0); }
-            ++cnt;
-        }
+    if (njp_ns(P) == 1) {
+        for (int64_t c = 0; 32 * c < G16 && c * kTileCols < P - 1; ++c)
+            for (int64_t g0 = 32 * c; g0 < G16; g0 += njp_tg(P)) {
+                if (hcb) { hcb->push_back((int32_t)c); hg0->push_back((int32_t)g0); }
+                ++cnt;
+            }
+    } else {
+        for (int64_t g0 = 0; g0 < G16; g0 += njp_tg(P))
+            for (int64_t c0 = 0; c0 < njp_strips_of_rows(g0, njp_tg(P), P); c0 += njp_ns(P)) {
+                if (hcb) { hcb->push_back((int32_t)c0); hg0->push_back((int32_t)g0); }
+                ++cnt;
+            }
+    }
     if (cnt == 0) { if (hcb) { hcb->push_back(0); hg0->push_back(0); } cnt = 1; }
     return cnt;
 }
@@ -1027,6 +1123,7 @@ static NjpArgs njp_args(NjBuffers& b, int v)
     a.xpart = b.xpart; a.partials = b.partials; a.umin = (unsigned long long*)q.umin;
     a.P = q.P;
     a.blk_cb = q.blk_cb; a.blk_g0 = q.blk_g0;
+    a.tg = njp_tg(q.P); a.ns = njp_ns(q.P); a.nupd = 0;
     a.ntest = sh ? (q.nprep - v + q.sh_world - 1) / q.sh_world : q.nprep;     // test blocks v, v + world, ... are this rank's
     a.list = q.list + (int64_t)slot * q.list_stride;
     a.cnt = sh ? q.cnt_all + 4 * slot : b.st->cnt_list;
@@ -1060,9 +1157,11 @@ static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
     NjpArgs a = njp_args(b, v);
     a.do_update = update ? 1 : 0;
     const unsigned ublocks = update ? (unsigned)((b.N + kThreads - 1) / kThreads) : 0u;
+    a.nupd = (int)ublocks;
     if ((unsigned)a.ntest + ublocks == 0u) return DPR_OK;      // (a rank without test blocks in a tests-only launch)
-    if (njp_tg(b.pr.P) == 64) hipLaunchKernelGGL(njp_post_kernel<64>, dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
-    else hipLaunchKernelGGL(njp_post_kernel<256>, dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
+    if (njp_tg(b.pr.P) == 64) hipLaunchKernelGGL((njp_post_kernel<64, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
+    else if (a.ns == 2) hipLaunchKernelGGL((njp_post_kernel<256, 2>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL((njp_post_kernel<256, kBigNS>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }

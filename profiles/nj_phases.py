@@ -27,7 +27,7 @@ buf = np.zeros(4 * 2048 * 8, np.uint64)
 L_ = capi.load_library()
 L_.dpr_get_nj_phase_stamps.argtypes = [C.c_void_p]
 assert L_.dpr_get_nj_phase_stamps(buf.ctypes.data) == 0
-buf = buf.reshape(2, 2048, 8).astype(np.int64)
+buf = buf[:2 * 2048 * 8].reshape(2, 2048, 8).astype(np.int64)
 t_scan0 = buf[0][buf[0] > 0].min()
 for k, name in ((0, "scan"), (1, "post")):
     b = buf[k]
