@@ -157,3 +157,39 @@ def test_unit_sharded_nj_two_ranks_gloo(orc):
         assert [m[1] for m in merges] == ref["merge_y"].tolist()
         assert np.array_equal(np.array([m[2] for m in merges]), ref["bl_x"])
         assert np.array_equal(np.array([m[3] for m in merges]), ref["bl_y"])
+
+
+_OWNER_CHECK = r"""
+import sys
+from dipper_amd import capi
+L = capi.load_library()
+P, world = int(sys.argv[1]), int(sys.argv[2])
+G16, S = (P + 15) // 16, (P + 511) // 512
+owners, per_rank = {}, [0] * world
+for strip in range(S + 1):
+    for group in range(G16 + 2):
+        o = L.dpr_njp_unit_owner(strip, group, P, world)
+        valid = group < G16 and group >= 32 * strip and strip * 512 < P - 1
+        assert (o >= 0) == valid, (strip, group, o)
+        if valid:
+            assert 0 <= o < world
+            owners[(strip, group)] = o
+            per_rank[o] += 1
+assert sum(per_rank) == len(owners) and min(per_rank) > 0, per_rank
+print(len(owners), max(per_rank) / (sum(per_rank) / world))
+"""
+
+
+def test_unit_owner_rule_both_shapes():
+    """dpr_njp_unit_owner covers every valid unit of the lower triangle exactly once in both test-block shapes (the large
+    one -- four strips x 256 row groups per block -- forced through DPR_NJ_BIG_P), nothing outside it, no idle rank."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for big_p in ("1000000000", "1"):
+        for P, world in ((5000, 2), (20000, 8), (9001, 3)):
+            env = dict(os.environ, DPR_NJ_BIG_P=big_p, PYTHONPATH=root)
+            r = subprocess.run([sys.executable, "-c", _OWNER_CHECK, str(P), str(world)], env=env, capture_output=True, text=True, cwd=root)
+            assert r.returncode == 0, r.stderr[-2000:]
+            units, imbalance = r.stdout.split()
+            assert int(units) > 0 and float(imbalance) < 1.6, (big_p, P, world, r.stdout)
