@@ -225,6 +225,21 @@ int msa_dist_tile_edge(int dist_type);   // rows/columns per job tile of msa_dis
 int msa_counts_row(const MsaBuffers& m, int64_t row, int32_t* d_useful, int32_t* d_match, hipStream_t s);
 
 // mash.hip
+// inverted index over the sketches (mash_index.hip): per chunk of 512 tips the (value -> tips, positions) postings
+struct MashIndex {
+    uint32_t* post = nullptr;    // [n*S] per chunk sorted by value: (tip mod 512) << 11 | position; 0xFFFFFFFF = not a first copy
+    uint64_t* uniq = nullptr;    // [nu] distinct values, chunk after chunk
+    uint32_t* off = nullptr;     // [nu + 1] first posting of each distinct value
+    uint32_t* bkt = nullptr;     // [chunks][65537] directory on the leading bits: first distinct value of each bucket
+    uint32_t* ubase = nullptr;   // [chunks + 1] first distinct value of each chunk
+    int32_t* shift = nullptr;    // [chunks] bucket = value >> shift
+    uint64_t* vmax = nullptr;    // [chunks] largest value
+    uint16_t* mult = nullptr;    // [n*S] copies of the value at its first position in a sketch, 0 elsewhere
+    double* dtab = nullptr;      // [S + 1] distance of every count
+    int64_t chunks = 0;
+    uint32_t nu = 0;
+};
+
 struct MashBuffers {
     uint64_t* packed2 = nullptr;   // flat 2-bit packed reads
     uint64_t* word_off = nullptr;  // [n]
@@ -237,6 +252,7 @@ struct MashBuffers {
     uint64_t* ref = nullptr;
     int ref_n = 0;
     double tok_mean = 0.0;         // tokens per sketch (sampled): the token kernel is used while this stays small
+    MashIndex index;               // built when the sketches do not resemble each other (or DPR_MASH_INDEX=1)
     uint64_t total_words = 0;
     int64_t n = 0;
     int S = 0, k = 0;
@@ -250,6 +266,11 @@ int mash_sketch(MashBuffers& m, int k, int S, hipStream_t s);
 int mash_dist_rows(const MashBuffers& m, int64_t r0, int64_t nr, int rank, int world, bool full,
                    int64_t ncols, double* out, int64_t ld, hipStream_t s, bool transposed = false);
 int mash_dist_jobs(const MashBuffers& m, const PairJobs& J, int njobs, hipStream_t s);
+// mash_index.hip
+int mash_index_build(MashBuffers& m, hipStream_t s);
+void mash_index_free(MashIndex& ix);
+int mash_dist_index(const MashBuffers& m, int64_t r0, int64_t nr, int64_t ncols, double* out, int64_t ld, bool mirror,
+                    bool transposed, hipStream_t s);
 int mash_jobs_rows();   // members per job
 int mash_jobs_cols();   // leaf-list positions per job
 int mash_hash_positions(const MashBuffers& m, int64_t seq, int k, uint64_t* d_out, uint64_t len, uint64_t word_off,

@@ -630,7 +630,20 @@ void mash_free(MashBuffers& m)
     void* ptrs[] = { m.packed2, m.word_off, m.len, m.sketches, m.tokens, m.tok_cnt, m.ref };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    mash_index_free(m.index);
     m = MashBuffers();
+}
+
+// kernel choice (read at every call: the tests switch kernels inside one process)
+static double mash_tok_max()
+{
+    const char* e = std::getenv("DPR_MASH_TOKENS_MAX");
+    return e ? std::atof(e) : 150.0;
+}
+static int mash_index_policy()      // 1 always, 0 never, -1 automatic
+{
+    const char* e = std::getenv("DPR_MASH_INDEX");
+    return e ? std::atoi(e) : -1;
 }
 
 // run encoding of all sketches against the distinct values of sketch 0 (see mash_dist_tokens_kernel)
@@ -705,6 +718,7 @@ int mash_sketch(MashBuffers& m, int k, int S, hipStream_t s)
     void* olds[] = { m.sketches, m.tokens, m.tok_cnt, m.ref };
     for (void* q : olds) if (q) (void)hipFree(q);
     m.sketches = nullptr; m.tokens = nullptr; m.tok_cnt = nullptr; m.ref = nullptr; m.tok_mean = 0.0;
+    mash_index_free(m.index);
     DPR_HIP(hipMalloc(&m.sketches, sizeof(uint64_t) * (size_t)(m.n * S)));
     m.S = S; m.k = k;
     static bool attr_set = false;
@@ -717,7 +731,13 @@ int mash_sketch(MashBuffers& m, int k, int S, hipStream_t s)
     hipLaunchKernelGGL(mash_sketch_kernel, dim3(grid), dim3(kSketchThreads), kSortCap * sizeof(uint64_t), s,
                        m.packed2, m.word_off, m.len, m.n, k, S, m.sketches);
     DPR_HIP(hipGetLastError());
-    return mash_encode(m, s);
+    if (int rc = mash_encode(m, s)) return rc;
+    // The inverted index (mash_index.hip) serves the row-against-columns shapes when the token kernel does not apply
+    // (DPR_MASH_INDEX=1: always, 0: never)
+    const int want = mash_index_policy();
+    if (want == 1 || (want < 0 && !(m.tokens && m.tok_mean <= mash_tok_max())))
+        if (int rc = mash_index_build(m, s)) return rc;
+    return DPR_OK;
 }
 
 static int lookup_attr()
@@ -757,7 +777,9 @@ int mash_dist_rows(const MashBuffers& m, int64_t r0, int64_t nr, int rank, int w
     // lower-triangle pairs (placement batches; single-GPU NJ with a mirror write): token kernel while the sketches
     // resemble each other (at most DPR_MASH_TOKENS_MAX tokens per sketch on average, default 150 of up to S: measured break-even with the table kernel), else the table kernel
     const bool mirror = full && world == 1 && r0 == 0;
-    static const double tok_max = std::getenv("DPR_MASH_TOKENS_MAX") ? std::atof(std::getenv("DPR_MASH_TOKENS_MAX")) : 150.0;
+    const double tok_max = mash_tok_max();
+    if (m.index.post && (!full || mirror) && world <= 1 && (mash_index_policy() == 1 || !(m.tokens && m.tok_mean <= tok_max)))
+        return mash_dist_index(m, r0, nr, ncols, out, ld, mirror, transposed, s);
     if (m.tokens && m.tok_mean <= tok_max && (!full || mirror) && world <= 1) {
         // columns a wave walks through: 128 for a whole matrix, fewer when the launch has few row tiles (placement batches
         // of 256 rows), so that it still fills the chip (>= ~4096 waves) and no wave runs long after the others

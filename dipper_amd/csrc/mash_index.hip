@@ -1,0 +1,332 @@
+// Mash distances through an inverted index (round 2).  Replaces mashDistConstruction (src/mash.cu:426-455) for the
+// row-against-many-columns shapes (NJ matrix, placement batches, divide-and-conquer query x backbone blocks) when the
+// sketches do NOT resemble each other enough for the run-encoded token kernel.
+//
+// The reference's merge of column sketch A (outer list) and row sketch B (inner list) counts, for the DISTINCT values
+// v of A that also occur in B,    inter += mult_B(v)   as long as   first_A(v) + #{b < v} - #{matched b < v} < S
+// (and uni = S at the end; mash.hip).  So a pair needs nothing but its SHARED values, in
+// ascending order, with three small integers each: the position of v in A, the position of v in B, the multiplicity
+// of v in B -- and one counter.  That is a join, not a merge:
+//   * index (once per sketch set): the tips are cut into chunks of 512; a chunk's (value, tip, position) triples --
+//     first occurrences only -- are sorted by value (rocPRIM segmented radix sort: preprocessing, not the hot path);
+//     per chunk the distinct values, the start of each value's posting list, and a 65 536-bucket directory on the
+//     leading bits;
+//   * query: ONE WAVEFRONT per (row, chunk).  It walks the row's distinct values in ascending order (64 directory
+//     look-ups at a time, one per lane), and for every value found it streams the posting list: lane = posting =
+//     one column tip; counter c[tip] (16 bits, LDS, 1 KiB per wavefront) is read, the reference's condition
+//     pos_A + pos_B - c < S tested, c += mult_B stored.  Tips of one posting list are distinct, lists are applied in
+//     value order, so every counter sees its shared values in the reference's order.  At the end c[tip] IS inter.
+// Work per pair = its shared values (550 of 1 000 at 4 % divergence, ~20 for unrelated reads) instead of the ~1 500
+// wave instructions of the table kernel's rank look-ups, and the chunk's postings (2 MB) stay in L2 while all
+// wavefronts of the moment work on the same chunk (tasks are chunk-major).
+#include "dpr_internal.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+#include <rocprim/functional.hpp>
+
+namespace dpr {
+
+constexpr int kIC = 512;             // tips per chunk (9 bits in a posting)
+constexpr int kIPosBits = 11;        // sketch position in a posting: S <= 2047
+constexpr int kIBktLog = 16;
+constexpr int kINB = 1 << kIBktLog;  // directory buckets per chunk
+constexpr int kIThreads = 256;
+// not a first copy: tip 511, position 2047 -- with S <= 2047 the reference's condition never holds for it (no special case in the kernel)
+constexpr uint32_t kINone = ((uint32_t)(kIC - 1) << kIPosBits) | ((1u << kIPosBits) - 1u);
+
+// payload of every sketch entry: (tip mod 512) << 11 | position for the first occurrence of a value in its sketch,
+// none for further copies; mult = copies of the value at first occurrences, 0 elsewhere
+__global__ __launch_bounds__(kIThreads) void mi_payload_kernel(const uint64_t* __restrict__ sk, int S, int64_t total,
+                                                               uint32_t* __restrict__ pay, uint16_t* __restrict__ mult)
+{
+    const int64_t idx = (int64_t)blockIdx.x * kIThreads + threadIdx.x;
+    if (idx >= total) return;
+    const int64_t t = idx / S;
+    const int p = (int)(idx - t * S);
+    const uint64_t v = sk[idx];
+    const bool first = p == 0 || sk[idx - 1] != v;
+    int m = 0;
+    if (first) {
+        m = 1;
+        while (p + m < S && sk[idx + m] == v) ++m;
+    }
+    mult[idx] = (uint16_t)m;
+    pay[idx] = first ? (((uint32_t)(t & (kIC - 1)) << kIPosBits) | (uint32_t)p) : kINone;
+}
+
+// head flags of the sorted keys (chunks are fixed segments of 512 S entries)
+__global__ __launch_bounds__(kIThreads) void mi_heads_kernel(const uint64_t* __restrict__ ks, int64_t total, int64_t seg,
+                                                             uint32_t* __restrict__ flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * kIThreads + threadIdx.x;
+    if (i >= total) return;
+    flag[i] = (i % seg == 0 || ks[i] != ks[i - 1]) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(kIThreads) void mi_compact_kernel(const uint64_t* __restrict__ ks, const uint32_t* __restrict__ flag,
+                                                               const uint32_t* __restrict__ g, int64_t total,
+                                                               uint64_t* __restrict__ uniq, uint32_t* __restrict__ off)
+{
+    const int64_t i = (int64_t)blockIdx.x * kIThreads + threadIdx.x;
+    if (i >= total) return;
+    if (flag[i]) { uniq[g[i] - 1] = ks[i]; off[g[i] - 1] = (uint32_t)i; }
+    if (i == total - 1) off[g[i]] = (uint32_t)total;
+}
+
+// per chunk: first / one-past-last distinct value (global indices), directory shift
+__global__ __launch_bounds__(kIThreads) void mi_chunks_kernel(const uint64_t* __restrict__ ks, const uint32_t* __restrict__ g,
+                                                              int64_t total, int64_t seg, int64_t chunks,
+                                                              uint32_t* __restrict__ ubase, int32_t* __restrict__ shift,
+                                                              uint64_t* __restrict__ vmax)
+{
+    const int64_t c = (int64_t)blockIdx.x * kIThreads + threadIdx.x;
+    if (c > chunks) return;
+    if (c == chunks) { ubase[c] = g[total - 1]; return; }
+    const int64_t start = c * seg, end = start + seg < total ? start + seg : total;
+    ubase[c] = start ? g[start - 1] : 0u;
+    const uint64_t vm = ks[end - 1];
+    vmax[c] = vm;
+    const int bits = 64 - __builtin_clzll(vm | 1ull);
+    shift[c] = bits > kIBktLog ? bits - kIBktLog : 0;
+}
+
+// directory: bkt[c][b] = first distinct value (global index) of chunk c whose bucket is >= b; bkt[c][kINB] = end
+__global__ __launch_bounds__(kIThreads) void mi_buckets_kernel(const uint64_t* __restrict__ uniq, const uint32_t* __restrict__ off,
+                                                               const uint32_t* __restrict__ ubase, const int32_t* __restrict__ shift,
+                                                               int64_t nu, int64_t seg, uint32_t* __restrict__ bkt)
+{
+    const int64_t u = (int64_t)blockIdx.x * kIThreads + threadIdx.x;
+    if (u >= nu) return;
+    const int64_t c = (int64_t)off[u] / seg;
+    const int sh = shift[c];
+    uint32_t* row = bkt + c * (int64_t)(kINB + 1);
+    const int b = (int)(uniq[u] >> sh);
+    const int bprev = (uint32_t)u == ubase[c] ? -1 : (int)(uniq[u - 1] >> sh);
+    for (int bb = bprev + 1; bb <= b; ++bb) row[bb] = (uint32_t)u;
+    if ((uint32_t)(u + 1) == ubase[c + 1])
+        for (int bb = b + 1; bb <= kINB; ++bb) row[bb] = (uint32_t)(u + 1);
+}
+
+// the distance of every possible count: same expression as the pair kernels of mash.hip (uni = S at the end of the merge)
+__global__ void mi_dtab_kernel(int S, int k, double* __restrict__ dtab)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x > S) return;
+    const double jac = fmax((double)x, 1.0) / (double)S;
+    dtab[x] = fmin(1.0, fabs(log(2.0 * jac / (1.0 + jac)) / (double)k));
+}
+
+// ------------------------------------------------------------------------------------------------
+// one wavefront per (chunk, row): tasks chunk-major
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kIThreads) void mash_dist_index_kernel(MashIndex ix, const uint64_t* __restrict__ sk, int S,
+                                                                    int64_t n, int64_t r0, int64_t nr, int64_t ncols,
+                                                                    int64_t cchunks, double* __restrict__ out, int64_t ld,
+                                                                    int mirror, int transposed)
+{
+    __shared__ uint16_t s_cnt[kIThreads / 64][kIC];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t task = (int64_t)blockIdx.x * (kIThreads / 64) + w;
+    const int64_t c = task / nr, t = task - c * nr;
+    if (c >= cchunks) return;                       // (no block-wide barrier below: wavefronts are independent)
+    const int64_t i = r0 + t;                       // row tip
+    if (i >= n) return;
+    const int64_t lim = ncols < i ? ncols : i;      // columns j < lim
+    const int64_t j0 = c * kIC;
+    if (j0 >= lim) return;
+    uint16_t* cnt = s_cnt[w];
+#pragma unroll
+    for (int m = 0; m < kIC / 64; ++m) cnt[lane + 64 * m] = 0;
+    const uint64_t vm = ix.vmax[c];
+    const int sh = ix.shift[c];
+    const uint32_t* __restrict__ bkt = ix.bkt + c * (int64_t)(kINB + 1);
+    const uint64_t* __restrict__ row = sk + i * S;
+    const uint16_t* __restrict__ rmult = ix.mult + i * S;
+    for (int b0 = 0; b0 < S; b0 += 64) {
+        const int p = b0 + lane;
+        const uint64_t v = p < S ? row[p] : 0ull;
+        const int mu = p < S ? (int)rmult[p] : 0;
+        uint32_t start = 0, len = 0;
+        if (mu > 0 && v <= vm) {                    // directory look-up of this lane's value
+            const uint32_t bb = (uint32_t)(v >> sh);
+            uint32_t lo = bkt[bb];
+            const uint32_t hi0 = bkt[bb + 1];
+            uint32_t hi = hi0;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (ix.uniq[mid] < v) lo = mid + 1; else hi = mid;
+            }
+            if (lo < hi0 && ix.uniq[lo] == v) { start = ix.off[lo]; len = ix.off[lo + 1] - start; }
+        }
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(len > 0);
+        // the row's values in ascending order; the first 64 postings of the NEXT value are loaded while this one is applied
+        uint32_t pre = kINone;
+        if (todo) {
+            const int l = (int)__builtin_ctzll(todo);
+            const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)start, l), ln = (uint32_t)__builtin_amdgcn_readlane((int)len, l);
+            pre = (uint32_t)lane < ln ? ix.post[st + lane] : kINone;
+        }
+        while (todo) {
+            const int l = (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)start, l);
+            const uint32_t ln = (uint32_t)__builtin_amdgcn_readlane((int)len, l);
+            const int m = __builtin_amdgcn_readlane(mu, l);
+            const int nb = b0 + l;                  // position of the value's first copy in the row sketch
+            const uint32_t ent0 = pre;
+            if (todo) {
+                const int l2 = (int)__builtin_ctzll(todo);
+                const uint32_t st2 = (uint32_t)__builtin_amdgcn_readlane((int)start, l2), ln2 = (uint32_t)__builtin_amdgcn_readlane((int)len, l2);
+                pre = (uint32_t)lane < ln2 ? ix.post[st2 + lane] : kINone;
+            }
+            auto apply = [&](uint32_t ent) {
+                const uint32_t tip = ent >> kIPosBits;
+                const int pos = (int)(ent & ((1u << kIPosBits) - 1u));
+                const int c0 = (int)cnt[tip];
+                if (pos + nb - c0 < S) cnt[tip] = (uint16_t)(c0 + m);      // (tips of one posting list are distinct)
+            };
+            apply(ent0);
+            for (uint32_t e0 = 64; e0 < ln; e0 += 192) {       // three more groups in flight at a time
+                uint32_t ent[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const uint32_t e = e0 + 64u * (uint32_t)q + (uint32_t)lane;
+                    ent[q] = e < ln ? ix.post[st + e] : kINone;
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (e0 + 64u * (uint32_t)q < ln) apply(ent[q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < kIC / 64; ++m) {
+        const int64_t j = j0 + lane + 64 * m;
+        if (j < lim) {
+            const int x = (int)cnt[lane + 64 * m];
+            const double d = ix.dtab[x > 1 ? x : 1];
+            if (transposed) out[j * ld + t] = d; else out[t * ld + j] = d;
+            if (mirror) out[j * ld + i] = d;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+void mash_index_free(MashIndex& ix)
+{
+    void* ptrs[] = { ix.post, ix.uniq, ix.off, ix.bkt, ix.ubase, ix.shift, ix.vmax, ix.mult, ix.dtab };
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    ix = MashIndex();
+}
+
+int mash_index_build(MashBuffers& m, hipStream_t s)
+{
+    mash_index_free(m.index);
+    const int S = m.S;
+    const int64_t n = m.n, total = n * S;
+    if (S >= (1 << kIPosBits) || total >= (int64_t)0xFFFF0000ll || n < 2) return DPR_OK;      // not indexable: the other kernels take over
+    MashIndex& ix = m.index;
+    const int64_t seg = (int64_t)kIC * S, chunks = (n + kIC - 1) / kIC;
+    const unsigned gt = (unsigned)((total + kIThreads - 1) / kIThreads);
+    uint64_t* ks = nullptr;
+    uint32_t *pay = nullptr, *flag = nullptr, *g = nullptr, *segoff = nullptr;
+    void* tmp = nullptr;
+    auto cleanup = [&]() {
+        void* ptrs[] = { ks, pay, flag, g, segoff, tmp };
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+    };
+    auto fail = [&](int rc) { cleanup(); mash_index_free(ix); return rc; };
+#define MI_HIP(x)                                                       \
+    do {                                                                \
+        hipError_t e_ = (x);                                            \
+        if (e_ != hipSuccess) return fail(hip_fail(e_, #x));            \
+    } while (0)
+    MI_HIP(hipMalloc(&ix.mult, sizeof(uint16_t) * (size_t)total));
+    MI_HIP(hipMalloc(&ix.post, sizeof(uint32_t) * (size_t)total));
+    MI_HIP(hipMalloc(&pay, sizeof(uint32_t) * (size_t)total));
+    MI_HIP(hipMalloc(&ks, sizeof(uint64_t) * (size_t)total));
+    hipLaunchKernelGGL(mi_payload_kernel, dim3(gt), dim3(kIThreads), 0, s, m.sketches, S, total, pay, ix.mult);
+    MI_HIP(hipGetLastError());
+    // sort every chunk's entries by value
+    std::vector<uint32_t> hseg((size_t)chunks + 1);
+    for (int64_t c = 0; c <= chunks; ++c) hseg[(size_t)c] = (uint32_t)(c * seg < total ? c * seg : total);
+    MI_HIP(hipMalloc(&segoff, sizeof(uint32_t) * (size_t)(chunks + 1)));
+    MI_HIP(hipMemcpyAsync(segoff, hseg.data(), sizeof(uint32_t) * (size_t)(chunks + 1), hipMemcpyHostToDevice, s));
+    size_t tb = 0;
+    MI_HIP(rocprim::segmented_radix_sort_pairs(nullptr, tb, (const uint64_t*)m.sketches, ks, (const uint32_t*)pay, ix.post, (unsigned)total,
+                                               (unsigned)chunks, (const uint32_t*)segoff, (const uint32_t*)segoff + 1, 0u, 64u, s));
+    MI_HIP(hipMalloc(&tmp, tb ? tb : 16));
+    MI_HIP(rocprim::segmented_radix_sort_pairs(tmp, tb, (const uint64_t*)m.sketches, ks, (const uint32_t*)pay, ix.post, (unsigned)total,
+                                               (unsigned)chunks, (const uint32_t*)segoff, (const uint32_t*)segoff + 1, 0u, 64u, s));
+    MI_HIP(hipStreamSynchronize(s));      // (hseg leaves scope; temporary storage is reused)
+    (void)hipFree(tmp); tmp = nullptr;
+    (void)hipFree(pay); pay = nullptr;
+    // distinct values of every chunk and the start of their posting lists
+    MI_HIP(hipMalloc(&flag, sizeof(uint32_t) * (size_t)total));
+    MI_HIP(hipMalloc(&g, sizeof(uint32_t) * (size_t)total));
+    hipLaunchKernelGGL(mi_heads_kernel, dim3(gt), dim3(kIThreads), 0, s, ks, total, seg, flag);
+    MI_HIP(hipGetLastError());
+    tb = 0;
+    MI_HIP(rocprim::inclusive_scan(nullptr, tb, (const uint32_t*)flag, g, (size_t)total, rocprim::plus<uint32_t>(), s));
+    MI_HIP(hipMalloc(&tmp, tb ? tb : 16));
+    MI_HIP(rocprim::inclusive_scan(tmp, tb, (const uint32_t*)flag, g, (size_t)total, rocprim::plus<uint32_t>(), s));
+    uint32_t nu = 0;
+    MI_HIP(hipMemcpyAsync(&nu, g + (total - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    ix.nu = nu;
+    MI_HIP(hipMalloc(&ix.uniq, sizeof(uint64_t) * (size_t)nu));
+    MI_HIP(hipMalloc(&ix.off, sizeof(uint32_t) * ((size_t)nu + 1)));
+    hipLaunchKernelGGL(mi_compact_kernel, dim3(gt), dim3(kIThreads), 0, s, ks, flag, g, total, ix.uniq, ix.off);
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipMalloc(&ix.ubase, sizeof(uint32_t) * (size_t)(chunks + 1)));
+    MI_HIP(hipMalloc(&ix.shift, sizeof(int32_t) * (size_t)chunks));
+    MI_HIP(hipMalloc(&ix.vmax, sizeof(uint64_t) * (size_t)chunks));
+    hipLaunchKernelGGL(mi_chunks_kernel, dim3((unsigned)((chunks + 1 + kIThreads - 1) / kIThreads)), dim3(kIThreads), 0, s, ks, g, total, seg,
+                       chunks, ix.ubase, ix.shift, ix.vmax);
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipMalloc(&ix.bkt, sizeof(uint32_t) * (size_t)(chunks * (kINB + 1))));
+    hipLaunchKernelGGL(mi_buckets_kernel, dim3((unsigned)((nu + kIThreads - 1) / kIThreads)), dim3(kIThreads), 0, s, ix.uniq, ix.off, ix.ubase,
+                       ix.shift, (int64_t)nu, seg, ix.bkt);
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipMalloc(&ix.dtab, sizeof(double) * (size_t)(S + 1)));
+    hipLaunchKernelGGL(mi_dtab_kernel, dim3((unsigned)((S + 1 + 255) / 256)), dim3(256), 0, s, S, m.k, ix.dtab);
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipStreamSynchronize(s));
+#undef MI_HIP
+    cleanup();
+    ix.chunks = chunks;
+    if (std::getenv("DPR_MASH_LOG"))
+        std::fprintf(stderr, "[mash] inverted index: %lld chunks of %d tips, %u distinct (chunk, value) pairs of %lld entries\n",
+                     (long long)chunks, kIC, nu, (long long)total);
+    return DPR_OK;
+}
+
+// rows r0 .. r0+nr x columns j < min(ncols, row): out[t*ld + j] (transposed: out[j*ld + t]); mirror: also out[j*ld + row]
+int mash_dist_index(const MashBuffers& m, int64_t r0, int64_t nr, int64_t ncols, double* out, int64_t ld, bool mirror,
+                    bool transposed, hipStream_t s)
+{
+    const MashIndex& ix = m.index;
+    if (!ix.post) { set_error("mash_dist_index: no index"); return DPR_ERR_STATE; }
+    int64_t top = r0 + nr - 1 < ncols ? r0 + nr - 1 : ncols;       // columns any row of the batch can need: j < top
+    if (top <= 0) return DPR_OK;
+    const int64_t cchunks = (top + kIC - 1) / kIC;
+    const int64_t tasks = cchunks * nr, per = kIThreads / 64;
+    const int64_t blocks = (tasks + per - 1) / per;
+    if (blocks >= (int64_t)0x7FFFFFFF) { set_error("mash_dist_index: batch too large"); return DPR_ERR_ARG; }
+    hipLaunchKernelGGL(mash_dist_index_kernel, dim3((unsigned)blocks), dim3(kIThreads), 0, s, ix, m.sketches, m.S, m.n, r0, nr, ncols, cchunks,
+                       out, ld, mirror ? 1 : 0, transposed ? 1 : 0);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+}  // namespace dpr

@@ -69,16 +69,20 @@ def test_mash_dist_matrix_and_nj(gpu, orc):
         assert np.array_equal(res[key], ref[key]), key
 
 
+@pytest.mark.parametrize("kernel", ["tokens", "index", "table"])
 @pytest.mark.parametrize("S,k", [(1000, 15), (64, 15), (257, 8), (2000, 15), (5, 4)])
-def test_mash_dist_token_kernel_cases(orc, monkeypatch, S, k):
-    """The run-encoded pair kernel (every sketch as runs of a reference list + literals) against the oracle's literal
-    loop on the cases its rules have to get right: near-identical reads (long runs, a handful of literals), exact copies,
+def test_mash_dist_token_kernel_cases(orc, monkeypatch, S, k, kernel):
+    """The three pair kernels -- run-encoded tokens (every sketch as runs of a reference list + literals), inverted
+    index (one wavefront per row x 512 columns, posting lists in value order), bucket tables -- against the oracle's literal
+    loop on the cases their rules have to get right: near-identical reads (long runs, a handful of literals), exact copies,
     reads with repeats (duplicate values: extra copies behind a run, in the reference itself, as literals), short reads
     (padding values = duplicates of the largest value), unrelated reads (all literals) and a reference (sketch 0) that is
     itself an outlier.  Integer intersection counts are exact, so the distances agree to the last bits of log()."""
     import dipper_amd
     from dipper_amd import capi
-    monkeypatch.setenv("DPR_MASH_TOKENS_MAX", "1e9")           # the token kernel whatever the token counts are
+    # (the library reads these at every sketch / distance call)
+    monkeypatch.setenv("DPR_MASH_INDEX", "1" if kernel == "index" else "0")
+    monkeypatch.setenv("DPR_MASH_TOKENS_MAX", "1e9" if kernel == "tokens" else "-1")   # the token kernel whatever the token counts are / never
     rng = np.random.default_rng(S * 31 + k)
     L = 2500
     clonal = _util.synth_reads(rng, 60, L, mean_bl=3e-4, lo=3e-5, hi=3e-3)
