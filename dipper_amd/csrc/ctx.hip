@@ -932,8 +932,22 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
         DPR_HIP(hipMalloc(&rows_buf[0], row_bytes));
         if (overlap) DPR_HIP(hipMalloc(&rows_buf[1], row_bytes));
     }
-    if (overlap && !c->stream2) DPR_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    if (overlap && !c->stream2) {
+        // lowest priority: the distance kernels fill the chip, the tree kernels of the current batch (one wavefront or a few
+        // blocks each, on the context's stream) must not queue behind them
+        int least = 0, greatest = 0;
+        DPR_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        if (const char* e = std::getenv("DPR_PLACE_DIST_CUMASK")) {      // experiment: keep some CUs free of distance kernels
+            const uint32_t pat = (uint32_t)std::strtoul(e, nullptr, 16);
+            uint32_t mask[8];
+            for (uint32_t& w : mask) w = pat;
+            DPR_HIP(hipExtStreamCreateWithCUMask(&c->stream2, 8, mask));
+        } else {
+            DPR_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, least));
+        }
+    }
     hipStream_t ds = overlap ? c->stream2 : c->stream;          // stream of the distance kernels
+    c->mash.share_chip = overlap;
     std::vector<hipEvent_t> sync_ev;                             // fill-done / tree-done events of this run
     auto new_event = [&](hipEvent_t* e) -> int { DPR_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming)); sync_ev.push_back(*e); return DPR_OK; };
     auto row_ptr = [&](int64_t i, int64_t i0, const double* rows) -> const double* {
@@ -1013,6 +1027,7 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
         return DPR_OK;
     };
     const int rc = run();
+    c->mash.share_chip = false;
     if (rows_buf[0] || rows_buf[1]) {
         (void)hipStreamSynchronize(c->stream);
         if (overlap) (void)hipStreamSynchronize(c->stream2);

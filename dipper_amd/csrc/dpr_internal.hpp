@@ -253,6 +253,7 @@ struct MashBuffers {
     int ref_n = 0;
     double tok_mean = 0.0;         // tokens per sketch (sampled): the token kernel is used while this stays small
     MashIndex index;               // built when the sketches do not resemble each other (or DPR_MASH_INDEX=1)
+    bool share_chip = false;       // the next distance launches run beside tree kernels of another stream: leave wave slots free
     uint64_t total_words = 0;
     int64_t n = 0;
     int S = 0, k = 0;

@@ -634,17 +634,22 @@ void mash_free(MashBuffers& m)
     m = MashBuffers();
 }
 
-// kernel choice (read at every call: the tests switch kernels inside one process)
-static double mash_tok_max()
+// Kernel choice for the row-against-columns shapes (read at every call: the tests switch kernels inside one process).
+// Tokens while the sketches resemble the reference list (measured at 20 000 reads x 3 kb: 3.4 G pairs/s at 13 tokens per
+// sketch, 0.8 G at 97), the inverted index otherwise (2.5-3.9 G pairs/s at any divergence, 9.8 G for unrelated reads), the
+// bucket-table kernel where neither exists (sketches of 2048 values and more) and for the cluster jobs.
+// DPR_MASH_TOKENS_MAX overrides the threshold, DPR_MASH_INDEX=1 / 0 forces / forbids the index.
+static double mash_tok_max(bool index_possible)
 {
     const char* e = std::getenv("DPR_MASH_TOKENS_MAX");
-    return e ? std::atof(e) : 150.0;
+    return e ? std::atof(e) : (index_possible ? 24.0 : 150.0);
 }
 static int mash_index_policy()      // 1 always, 0 never, -1 automatic
 {
     const char* e = std::getenv("DPR_MASH_INDEX");
     return e ? std::atoi(e) : -1;
 }
+static bool mash_indexable(const MashBuffers& m) { return m.S < 2048 && m.n >= 2 && m.n * (int64_t)m.S < (int64_t)0xFFFF0000ll; }
 
 // run encoding of all sketches against the distinct values of sketch 0 (see mash_dist_tokens_kernel)
 static int mash_encode(MashBuffers& m, hipStream_t s)
@@ -735,8 +740,11 @@ int mash_sketch(MashBuffers& m, int k, int S, hipStream_t s)
     // The inverted index (mash_index.hip) serves the row-against-columns shapes when the token kernel does not apply
     // (DPR_MASH_INDEX=1: always, 0: never)
     const int want = mash_index_policy();
-    if (want == 1 || (want < 0 && !(m.tokens && m.tok_mean <= mash_tok_max())))
-        if (int rc = mash_index_build(m, s)) return rc;
+    if (want == 1 || (want < 0 && mash_indexable(m) && !(m.tokens && m.tok_mean <= mash_tok_max(true)))) {
+        const int rc = mash_index_build(m, s);
+        if (rc != DPR_OK && want == 1) return rc;
+        if (rc != DPR_OK) (void)hipGetLastError();      // (no memory for the index: the table kernel takes over)
+    }
     return DPR_OK;
 }
 
@@ -777,8 +785,8 @@ int mash_dist_rows(const MashBuffers& m, int64_t r0, int64_t nr, int rank, int w
     // lower-triangle pairs (placement batches; single-GPU NJ with a mirror write): token kernel while the sketches
     // resemble each other (at most DPR_MASH_TOKENS_MAX tokens per sketch on average, default 150 of up to S: measured break-even with the table kernel), else the table kernel
     const bool mirror = full && world == 1 && r0 == 0;
-    const double tok_max = mash_tok_max();
-    if (m.index.post && (!full || mirror) && world <= 1 && (mash_index_policy() == 1 || !(m.tokens && m.tok_mean <= tok_max)))
+    const double tok_max = mash_tok_max(mash_index_policy() != 0 && m.index.post != nullptr);
+    if (m.index.post && mash_index_policy() != 0 && (!full || mirror) && world <= 1 && (mash_index_policy() == 1 || !(m.tokens && m.tok_mean <= tok_max)))
         return mash_dist_index(m, r0, nr, ncols, out, ld, mirror, transposed, s);
     if (m.tokens && m.tok_mean <= tok_max && (!full || mirror) && world <= 1) {
         // columns a wave walks through: 128 for a whole matrix, fewer when the launch has few row tiles (placement batches

@@ -132,15 +132,15 @@ __global__ __launch_bounds__(kIThreads) void mash_dist_index_kernel(MashIndex ix
 {
     __shared__ uint16_t s_cnt[kIThreads / 64][kIC];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t task = (int64_t)blockIdx.x * (kIThreads / 64) + w;
+    uint16_t* cnt = s_cnt[w];
+    // (no block-wide barrier below: wavefronts are independent; a wavefront takes tasks grid-stride, chunk-major)
+    for (int64_t task = (int64_t)blockIdx.x * (kIThreads / 64) + w; task < cchunks * nr; task += (int64_t)gridDim.x * (kIThreads / 64)) {
     const int64_t c = task / nr, t = task - c * nr;
-    if (c >= cchunks) return;                       // (no block-wide barrier below: wavefronts are independent)
     const int64_t i = r0 + t;                       // row tip
-    if (i >= n) return;
+    if (i >= n) continue;
     const int64_t lim = ncols < i ? ncols : i;      // columns j < lim
     const int64_t j0 = c * kIC;
-    if (j0 >= lim) return;
-    uint16_t* cnt = s_cnt[w];
+    if (j0 >= lim) continue;
 #pragma unroll
     for (int m = 0; m < kIC / 64; ++m) cnt[lane + 64 * m] = 0;
     const uint64_t vm = ix.vmax[c];
@@ -214,6 +214,7 @@ __global__ __launch_bounds__(kIThreads) void mash_dist_index_kernel(MashIndex ix
             if (transposed) out[j * ld + t] = d; else out[t * ld + j] = d;
             if (mirror) out[j * ld + i] = d;
         }
+    }
     }
 }
 
@@ -321,9 +322,15 @@ int mash_dist_index(const MashBuffers& m, int64_t r0, int64_t nr, int64_t ncols,
     if (top <= 0) return DPR_OK;
     const int64_t cchunks = (top + kIC - 1) / kIC;
     const int64_t tasks = cchunks * nr, per = kIThreads / 64;
-    const int64_t blocks = (tasks + per - 1) / per;
-    if (blocks >= (int64_t)0x7FFFFFFF) { set_error("mash_dist_index: batch too large"); return DPR_ERR_ARG; }
-    hipLaunchKernelGGL(mash_dist_index_kernel, dim3((unsigned)blocks), dim3(kIThreads), 0, s, ix, m.sketches, m.S, m.n, r0, nr, ncols, cchunks,
+    int64_t blocks = (tasks + per - 1) / per;       // one task per wavefront (a bounded grid walking the tasks: 25 % slower, uneven tasks)
+    if (blocks > (int64_t)0x3FFFFFFF) blocks = 0x3FFFFFFF;
+    // When tree kernels of a placement batch run beside this launch on another stream (share_chip), unused dynamic LDS
+    // caps this kernel at six blocks = 24 of the 32 wavefronts of a CU, so that their launches find wave slots at once
+    // instead of queueing behind an oversubscribed grid (100 000-tip placement: 3.98 s uncapped, 3.75 s with 22 KiB,
+    // 4.48 s with 29 KiB = 16 wavefronts).
+    static const int pad_kb = std::getenv("DPR_MASH_INDEX_PAD_KB") ? std::atoi(std::getenv("DPR_MASH_INDEX_PAD_KB")) : 22;
+    const size_t pad = m.share_chip ? (size_t)pad_kb * 1024 : 0;
+    hipLaunchKernelGGL(mash_dist_index_kernel, dim3((unsigned)blocks), dim3(kIThreads), pad, s, ix, m.sketches, m.S, m.n, r0, nr, ncols, cchunks,
                        out, ld, mirror ? 1 : 0, transposed ? 1 : 0);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
