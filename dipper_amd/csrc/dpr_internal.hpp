@@ -227,7 +227,7 @@ int msa_counts_row(const MsaBuffers& m, int64_t row, int32_t* d_useful, int32_t*
 // mash.hip
 // inverted index over the sketches (mash_index.hip): per chunk of 512 tips the (value -> tips, positions) postings
 struct MashIndex {
-    uint32_t* post = nullptr;    // [n*S] per chunk sorted by value: (tip mod 512) << 11 | position; 0xFFFFFFFF = not a first copy
+    uint32_t* post = nullptr;    // [n*S] per chunk sorted by value: 2 * (tip mod 512) << 16 | position; tip 511 + position 65535 = not a first copy
     uint64_t* uniq = nullptr;    // [nu] distinct values, chunk after chunk
     uint32_t* off = nullptr;     // [nu + 1] first posting of each distinct value
     uint32_t* bkt = nullptr;     // [chunks][65537] directory on the leading bits: first distinct value of each bucket

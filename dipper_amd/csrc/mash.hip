@@ -649,7 +649,7 @@ static int mash_index_policy()      // 1 always, 0 never, -1 automatic
     const char* e = std::getenv("DPR_MASH_INDEX");
     return e ? std::atoi(e) : -1;
 }
-static bool mash_indexable(const MashBuffers& m) { return m.S < 2048 && m.n >= 2 && m.n * (int64_t)m.S < (int64_t)0xFFFF0000ll; }
+static bool mash_indexable(const MashBuffers& m) { return m.S <= 4096 && m.n >= 2 && m.n * (int64_t)m.S < (int64_t)0xFFFF0000ll; }
 
 // run encoding of all sketches against the distinct values of sketch 0 (see mash_dist_tokens_kernel)
 static int mash_encode(MashBuffers& m, hipStream_t s)

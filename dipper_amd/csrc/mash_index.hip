@@ -32,15 +32,16 @@
 
 namespace dpr {
 
-constexpr int kIC = 512;             // tips per chunk (9 bits in a posting)
-constexpr int kIPosBits = 11;        // sketch position in a posting: S <= 2047
+constexpr int kIC = 512;             // tips per chunk
+// a posting: byte offset of the tip's 16-bit counter (2 * (tip mod 512)) in the high half, sketch position in the low half
 constexpr int kIBktLog = 16;
 constexpr int kINB = 1 << kIBktLog;  // directory buckets per chunk
-constexpr int kIThreads = 256;
-// not a first copy: tip 511, position 2047 -- with S <= 2047 the reference's condition never holds for it (no special case in the kernel)
-constexpr uint32_t kINone = ((uint32_t)(kIC - 1) << kIPosBits) | ((1u << kIPosBits) - 1u);
+constexpr int kIThreads = 256;       // (index build kernels)
+// not a first copy: counter of tip 511, position 65535 -- the reference's condition never holds for it (S <= 4096), so the
+// kernel needs no special case
+constexpr uint32_t kINone = ((uint32_t)(2 * (kIC - 1)) << 16) | 0xFFFFu;
 
-// payload of every sketch entry: (tip mod 512) << 11 | position for the first occurrence of a value in its sketch,
+// payload of every sketch entry: 2 * (tip mod 512) << 16 | position for the first occurrence of a value in its sketch,
 // none for further copies; mult = copies of the value at first occurrences, 0 elsewhere
 __global__ __launch_bounds__(kIThreads) void mi_payload_kernel(const uint64_t* __restrict__ sk, int S, int64_t total,
                                                                uint32_t* __restrict__ pay, uint16_t* __restrict__ mult)
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(kIThreads) void mi_payload_kernel(const uint64_t* _
         while (p + m < S && sk[idx + m] == v) ++m;
     }
     mult[idx] = (uint16_t)m;
-    pay[idx] = first ? (((uint32_t)(t & (kIC - 1)) << kIPosBits) | (uint32_t)p) : kINone;
+    pay[idx] = first ? (((uint32_t)(2 * (t & (kIC - 1))) << 16) | (uint32_t)p) : kINone;
 }
 
 // head flags of the sorted keys (chunks are fixed segments of 512 S entries)
@@ -123,18 +124,16 @@ __global__ void mi_dtab_kernel(int S, int k, double* __restrict__ dtab)
 }
 
 // ------------------------------------------------------------------------------------------------
-// one wavefront per (chunk, row): tasks chunk-major
+// one wavefront (= one workgroup: the counters sit at a fixed LDS address) per (chunk, row): tasks chunk-major
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kIThreads) void mash_dist_index_kernel(MashIndex ix, const uint64_t* __restrict__ sk, int S,
-                                                                    int64_t n, int64_t r0, int64_t nr, int64_t ncols,
-                                                                    int64_t cchunks, double* __restrict__ out, int64_t ld,
-                                                                    int mirror, int transposed)
+__global__ __launch_bounds__(64) void mash_dist_index_kernel(MashIndex ix, const uint64_t* __restrict__ sk, int S,
+                                                             int64_t n, int64_t r0, int64_t nr, int64_t ncols,
+                                                             int64_t cchunks, double* __restrict__ out, int64_t ld,
+                                                             int mirror, int transposed)
 {
-    __shared__ uint16_t s_cnt[kIThreads / 64][kIC];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint16_t* cnt = s_cnt[w];
-    // (no block-wide barrier below: wavefronts are independent; a wavefront takes tasks grid-stride, chunk-major)
-    for (int64_t task = (int64_t)blockIdx.x * (kIThreads / 64) + w; task < cchunks * nr; task += (int64_t)gridDim.x * (kIThreads / 64)) {
+    __shared__ uint16_t cnt[kIC];
+    const int lane = threadIdx.x;
+    for (int64_t task = (int64_t)blockIdx.x; task < cchunks * nr; task += (int64_t)gridDim.x) {
     const int64_t c = task / nr, t = task - c * nr;
     const int64_t i = r0 + t;                       // row tip
     if (i >= n) continue;
@@ -185,19 +184,26 @@ __global__ __launch_bounds__(kIThreads) void mash_dist_index_kernel(MashIndex ix
                 const uint32_t st2 = (uint32_t)__builtin_amdgcn_readlane((int)start, l2), ln2 = (uint32_t)__builtin_amdgcn_readlane((int)len, l2);
                 pre = (uint32_t)lane < ln2 ? ix.post[st2 + lane] : kINone;
             }
+            // reference's condition first_A(v) + nb - c < S  <=>  c - first_A(v) > nb - S
+            const int K = nb - S;
             auto apply = [&](uint32_t ent) {
-                const uint32_t tip = ent >> kIPosBits;
-                const int pos = (int)(ent & ((1u << kIPosBits) - 1u));
-                const int c0 = (int)cnt[tip];
-                if (pos + nb - c0 < S) cnt[tip] = (uint16_t)(c0 + m);      // (tips of one posting list are distinct)
+                uint16_t* pc = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(cnt) + (ent >> 16));
+                const int c0 = (int)*pc;
+                if (c0 - (int)(ent & 0xFFFFu) > K) *pc = (uint16_t)(c0 + m);      // (tips of one posting list are distinct)
             };
             apply(ent0);
-            for (uint32_t e0 = 64; e0 < ln; e0 += 192) {       // three more groups in flight at a time
+            const uint32_t* __restrict__ pl = ix.post + st;
+            uint32_t e0 = 64;
+            for (; e0 + 192 <= ln; e0 += 192) {                 // whole groups, three in flight: no bounds to check
+                const uint32_t a0 = pl[e0 + (uint32_t)lane], a1 = pl[e0 + 64u + (uint32_t)lane], a2 = pl[e0 + 128u + (uint32_t)lane];
+                apply(a0); apply(a1); apply(a2);
+            }
+            if (e0 < ln) {                                      // the rest: up to three groups, the last one partial
                 uint32_t ent[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const uint32_t e = e0 + 64u * (uint32_t)q + (uint32_t)lane;
-                    ent[q] = e < ln ? ix.post[st + e] : kINone;
+                    ent[q] = e < ln ? pl[e] : kINone;
                 }
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
@@ -234,7 +240,7 @@ int mash_index_build(MashBuffers& m, hipStream_t s)
     mash_index_free(m.index);
     const int S = m.S;
     const int64_t n = m.n, total = n * S;
-    if (S >= (1 << kIPosBits) || total >= (int64_t)0xFFFF0000ll || n < 2) return DPR_OK;      // not indexable: the other kernels take over
+    if (S > 4096 || total >= (int64_t)0xFFFF0000ll || n < 2) return DPR_OK;      // not indexable: the other kernels take over
     MashIndex& ix = m.index;
     const int64_t seg = (int64_t)kIC * S, chunks = (n + kIC - 1) / kIC;
     const unsigned gt = (unsigned)((total + kIThreads - 1) / kIThreads);
@@ -321,16 +327,14 @@ int mash_dist_index(const MashBuffers& m, int64_t r0, int64_t nr, int64_t ncols,
     int64_t top = r0 + nr - 1 < ncols ? r0 + nr - 1 : ncols;       // columns any row of the batch can need: j < top
     if (top <= 0) return DPR_OK;
     const int64_t cchunks = (top + kIC - 1) / kIC;
-    const int64_t tasks = cchunks * nr, per = kIThreads / 64;
-    int64_t blocks = (tasks + per - 1) / per;       // one task per wavefront (a bounded grid walking the tasks: 25 % slower, uneven tasks)
+    int64_t blocks = cchunks * nr;                  // one task per wavefront (a bounded grid walking the tasks: 25 % slower, uneven tasks)
     if (blocks > (int64_t)0x3FFFFFFF) blocks = 0x3FFFFFFF;
     // When tree kernels of a placement batch run beside this launch on another stream (share_chip), unused dynamic LDS
-    // caps this kernel at six blocks = 24 of the 32 wavefronts of a CU, so that their launches find wave slots at once
-    // instead of queueing behind an oversubscribed grid (100 000-tip placement: 3.98 s uncapped, 3.75 s with 22 KiB,
-    // 4.48 s with 29 KiB = 16 wavefronts).
-    static const int pad_kb = std::getenv("DPR_MASH_INDEX_PAD_KB") ? std::atoi(std::getenv("DPR_MASH_INDEX_PAD_KB")) : 22;
-    const size_t pad = m.share_chip ? (size_t)pad_kb * 1024 : 0;
-    hipLaunchKernelGGL(mash_dist_index_kernel, dim3((unsigned)blocks), dim3(kIThreads), pad, s, ix, m.sketches, m.S, m.n, r0, nr, ncols, cchunks,
+    // caps this kernel at 24 of the 32 wavefronts of a CU, so that their launches find wave slots at once instead of
+    // queueing behind an oversubscribed grid (100 000-tip placement: 3.98 s uncapped, 3.75 s at 24, 4.48 s at 16 wavefronts).
+    static const int pad_b = std::getenv("DPR_MASH_INDEX_PAD") ? std::atoi(std::getenv("DPR_MASH_INDEX_PAD")) : 5632;
+    const size_t pad = m.share_chip ? (size_t)pad_b : 0;
+    hipLaunchKernelGGL(mash_dist_index_kernel, dim3((unsigned)blocks), dim3(64), pad, s, ix, m.sketches, m.S, m.n, r0, nr, ncols, cchunks,
                        out, ld, mirror ? 1 : 0, transposed ? 1 : 0);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
