@@ -637,6 +637,10 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
                 a.st->x = (int32_t)x; a.st->y = (int32_t)y; a.st->d = d; a.st->q = bq;
                 a.st->n = n1; a.st->it = it + 1;
                 a.st->pnew[(it + 1) & 1] = (int32_t)px;
+                // the dead position carries NaN in BOTH row-sum buffers from now on (it is never written again).  The
+                // store into the CURRENT buffer is this thread's, behind its own read of U[py] above: any other thread
+                // storing it could overtake that read (seen once in 30 000 iterations as a NaN branch length)
+                a.U[(it & 1) * a.vstride + py] = __builtin_nan("");
                 // list counters of the scan after next (nobody reads or appends to them in this launch)
                 a.st->cnt_list[(it + 2) % 3] = 0ull;
                 for (int v = 0; v < a.cnt_ranks; ++v) a.cnt_all[4 * v + (it + 2) % 3] = 0ull;
@@ -661,8 +665,7 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
             } else if (i == y) {
                 // (py from the winning record, not this thread's pos_of_slot[y]: the thread of the last slot rewrites that entry)
                 a.Ur[py] = __builtin_nan("");   // dead: every q it takes part in is NaN, every unit minimum skips it
-                Un[py] = __builtin_nan("");     // ... and NaN in BOTH row-sum buffers (a dead position is never written again;
-                a.U[(it & 1) * a.vstride + py] = __builtin_nan("");   //  the test role of this launch leaves py out by index)
+                Un[py] = __builtin_nan("");     // (the current buffer's entry: the log writer above; the test role of this launch leaves py out by index)
                 a.slot_of_pos[py] = -1;
                 Rw[py] = 0.0;
                 new_slot = -1;
