@@ -32,7 +32,7 @@
 
 namespace dpr {
 
-constexpr int kIC = 512;             // tips per chunk
+constexpr int kIC = 512;             // tips per chunk (1024: -3 ... -12 % at mean branch 2e-5 ... 1e-3, +29 % for unrelated reads)
 // a posting: byte offset of the tip's 16-bit counter (2 * (tip mod 512)) in the high half, sketch position in the low half
 constexpr int kIBktLog = 16;
 constexpr int kINB = 1 << kIBktLog;  // directory buckets per chunk
