@@ -354,7 +354,7 @@ class Dipper:
         us = np.zeros(4, np.float64)
         _chk(self.L, self.L.dpr_get_nj_kernel_timing(self.h, C.byref(nk), _p(us, c_f64p), C.byref(ns)))
         names = [(self.L.dpr_nj_kernel_name(i) or b"").decode() for i in range(nk.value)]
-        rec = {"kernels_per_iteration": nk.value, "sampled_iterations": int(ns.value),
+        rec = {"kernels_per_iteration": sum(1 for nm in names if not nm.startswith("(")), "sampled_iterations": int(ns.value),
                "kernel_us_avg": {nm: float(us[i]) for i, nm in enumerate(names)}}
         for i, nm in enumerate(names):
             if "scan" in nm:
