@@ -51,6 +51,10 @@ unsigned hostThreads(unsigned cap)
         }
         std::fclose(f);
     }
+    if (const char* e = std::getenv("DPR_HOST_THREADS")) {           // experiments: fewer reader threads
+        const unsigned v = (unsigned)std::atoi(e);
+        if (v >= 1 && v < n) n = v;
+    }
     return std::max(1u, std::min(cap, n));
 }
 
