@@ -250,6 +250,9 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the untimed self-check of the timed result")
     ap.add_argument("--no-sharded", action="store_true", help="several GPUs: skip the 100 000-tip unit-sharded sub-record")
     ap.add_argument("--no-stream-leg", action="store_true", help="skip the row-sharded streaming-NJ sub-record")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="one GPU: skip the single runs of the other BASELINE sizes (NJ at 100 000 tips, placement of 100 000 unaligned tips, "
+                         "divide-and-conquer of 1 000 000 tips)")
     ap.add_argument("--stream-iters", type=int, default=256)
     ap.add_argument("--sharded-tips", type=int, default=100000)
     ap.add_argument("--sharded-sites", type=int, default=10000)
@@ -605,6 +608,17 @@ def main():
                     dog.cancel()
 
         # =====================================================================================================
+        # E3. north_star's other sizes, one run each on this GPU (rank 0 of a single-GPU run; no warm-up: first-touch of
+        #     the buffers is inside the figures): NJ at 100 000 tips, k-closest placement of 100 000 unaligned tips (Mash),
+        #     divide-and-conquer of 1 000 000 aligned tips
+        # =====================================================================================================
+        if world == 1 and rank == 0 and not args.no_other_configs and not args.probe_only:
+            try:
+                out["other_configs"] = other_configs(args, local_rank)
+            except Exception as e:
+                out["other_configs"] = {"error": repr(e)}
+
+        # =====================================================================================================
         # F. several GPUs: the unit-sharded NJ plan where it can pay -- N = 100 000 (80 GB matrix per rank), one step
         # =====================================================================================================
         run_sharded = (world > 1 and have_comm) or force_check
@@ -633,6 +647,88 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
+
+
+def other_configs(args, local_rank):
+    """BASELINE.json configs[2] / configs[3] and north_star's N = 100 000 NJ, one run each (synthetic inputs as everywhere:
+    seeded Yule tree, JC69; unaligned reads with seeded indels).  Every record: tips, seconds of the timed part, tips/s."""
+    import dipper_amd
+    from dipper_amd import capi
+    from tests import _util
+    rec = {}
+
+    def leg(name, fn):
+        t0 = time.perf_counter()
+        try:
+            rec[name] = fn()
+        except Exception as e:       # one failing leg must not take the others (or the line) down
+            rec[name] = {"error": repr(e)}
+        rec[name]["leg_wall_s"] = time.perf_counter() - t0
+        log(f"[bench] other_configs.{name}: {rec[name]}")
+
+    def nj_100k():
+        n, L = 100000, 10000
+        seqs = _util.synth_alignment(np.random.default_rng(args.seed + 7), n, L, mean_bl=2e-5, lo=2e-6, hi=2e-4)
+        packed = capi.pack4_many(seqs)
+        del seqs
+        d = dipper_amd.Dipper(local_rank)
+        try:
+            d.reserve_nj(n)          # the two 80 GB buffers (the CLI allocates them on its device thread while it parses the input)
+            d.set_msa(packed, L)
+            t0 = time.perf_counter()
+            d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+            res = d.nj_run()
+            wall = time.perf_counter() - t0
+            dist_ms, nj_ms = d.timing()
+            sc, _ = d.prune_stats()
+            return {"workload": "conventional NJ, %d aligned tips x %d sites, JC69 (80 GB matrix on one GPU), packed tips in HBM -> merge log" % (n, L),
+                    "tips": n, "seconds": wall, "tips_per_s": n / wall, "dist_ms": dist_ms, "nj_ms": nj_ms,
+                    "nj_iterations_per_s": res["iters"] / (nj_ms * 1e-3), "units_scanned": sc, "merge_log_digest": merge_digest(res)}
+        finally:
+            d.close()
+
+    def place_100k_unaligned():
+        n, L = 100000, 3000
+        seqs = _util.synth_reads(np.random.default_rng(args.seed + 8), n, L, mean_bl=2e-5, lo=2e-6, hi=2e-4)
+        d = dipper_amd.Dipper(local_rank)
+        try:
+            d.set_reads(seqs)
+            t0 = time.perf_counter()
+            d.sketch(15, 1000, fetch=False)
+            t1 = time.perf_counter()
+            st = d.place_run(capi.SRC_MASH, n, k=15)
+            wall = time.perf_counter() - t0
+            dist_ms, tree_ms = d.place_timing()
+            return {"workload": "configs[2]: %d unaligned tips x ~%d bases, Mash sketches (k 15, 1000 values) + k-closest placement, reads in HBM -> tree arrays" % (n, L),
+                    "tips": n, "seconds": wall, "tips_per_s": n / wall, "sketch_s": t1 - t0, "distance_part_ms": dist_ms, "tree_part_ms": tree_ms,
+                    "trace_digest": hashlib.sha256(np.ascontiguousarray(st["trace"]).tobytes()).hexdigest()[:16]}
+        finally:
+            d.close()
+
+    def dc_1m():
+        n, L = 1000000, 400
+        seqs = _util.synth_alignment(np.random.default_rng(args.seed + 9), n, L, mean_bl=2e-3, lo=2e-4, hi=2e-2)
+        order = np.random.default_rng(7).permutation(n)      # the CLI shuffles its input (src/tree_generation.cu:341-344)
+        packed = capi.pack4_many([seqs[i] for i in order])
+        del seqs
+        d = dipper_amd.Dipper(local_rank)
+        try:
+            d.set_msa(packed, L)
+            t0 = time.perf_counter()
+            st = d.dc_run(capi.SRC_MSA, n, n // 20, dist_type=capi.DIST_JC)
+            wall = time.perf_counter() - t0
+            return {"workload": "configs[3] on one GPU: divide-and-conquer, %d aligned tips x %d sites, backbone %d, packed tips in HBM -> tree arrays" % (n, L, n // 20),
+                    "tips": n, "seconds": wall, "tips_per_s": n / wall,
+                    "device_s": (st["stats"]["backbone_ms"] + st["stats"]["assign_ms"] + st["stats"]["cluster_ms"]) * 1e-3,
+                    "note": "seconds includes copying the tree arrays and closest lists (0.5 GB) back to the host",
+                    "stats": {k: (float(v) if isinstance(v, float) else int(v)) for k, v in st["stats"].items()}}
+        finally:
+            d.close()
+
+    leg("nj_100k", nj_100k)
+    leg("place_100k_unaligned", place_100k_unaligned)
+    leg("dc_1m", dc_1m)
+    return rec
 
 
 def streaming_leg(rank, world, local_rank, dist, torch, barrier, packed, n, L, iters, solo_denominator=False):
