@@ -785,7 +785,10 @@ int mash_dist_rows(const MashBuffers& m, int64_t r0, int64_t nr, int rank, int w
     // lower-triangle pairs (placement batches; single-GPU NJ with a mirror write): token kernel while the sketches
     // resemble each other (at most DPR_MASH_TOKENS_MAX tokens per sketch on average, default 150 of up to S: measured break-even with the table kernel), else the table kernel
     const bool mirror = full && world == 1 && r0 == 0;
-    const double tok_max = mash_tok_max(mash_index_policy() != 0 && m.index.post != nullptr);
+    // (beside the tree kernels of a placement batch the token kernel keeps its lead longer: it leaves wave slots free, the
+    //  index kernel has to be throttled there -- 100 000 tips at 32 tokens per sketch: 3.8 s against 4.5 s)
+    const bool have_index = mash_index_policy() != 0 && m.index.post != nullptr;
+    const double tok_max = (have_index && m.share_chip && !std::getenv("DPR_MASH_TOKENS_MAX")) ? 48.0 : mash_tok_max(have_index);
     if (m.index.post && mash_index_policy() != 0 && (!full || mirror) && world <= 1 && (mash_index_policy() == 1 || !(m.tokens && m.tok_mean <= tok_max)))
         return mash_dist_index(m, r0, nr, ncols, out, ld, mirror, transposed, s);
     if (m.tokens && m.tok_mean <= tok_max && (!full || mirror) && world <= 1) {
