@@ -5,7 +5,7 @@ TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o b -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cli --no-parity --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o b -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cli --no-parity --no-cpu-baseline --no-other-configs --no-stream-leg "$@" > $OUT/bench.json 2> $OUT/bench.err
 rm -f $OUT/*kernel_trace.csv
 python3 - <<PY
 import csv

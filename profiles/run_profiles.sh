@@ -11,10 +11,10 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cli --no-parity --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o probe -- python3 $REPO/bench.py --probe-only --no-cli --no-parity --no-cpu-baseline > $OUT/probe_fetch.json 2> $OUT/probe_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o probe -- python3 $REPO/bench.py --probe-only --no-cli --no-parity --no-cpu-baseline > $OUT/probe_write.json 2> $OUT/probe_write.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats100k -o bench -- python3 $REPO/bench.py --tips 100000 --sites 10000 --steps 1 --warmup 0 --no-cli --no-parity --no-cpu-baseline > $OUT/bench100k_under_rocprof.json 2> $OUT/bench100k_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cli --no-parity --no-cpu-baseline --no-other-configs --no-stream-leg > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o probe -- python3 $REPO/bench.py --probe-only --no-cli --no-parity --no-cpu-baseline --no-other-configs --no-stream-leg > $OUT/probe_fetch.json 2> $OUT/probe_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o probe -- python3 $REPO/bench.py --probe-only --no-cli --no-parity --no-cpu-baseline --no-other-configs --no-stream-leg > $OUT/probe_write.json 2> $OUT/probe_write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats100k -o bench -- python3 $REPO/bench.py --tips 100000 --sites 10000 --steps 1 --warmup 0 --no-cli --no-parity --no-cpu-baseline --no-other-configs --no-stream-leg > $OUT/bench100k_under_rocprof.json 2> $OUT/bench100k_under_rocprof.err
 find $OUT -name "*kernel_trace.csv" -delete
 python3 - <<PY
 import csv, glob
