@@ -49,7 +49,12 @@ static int64_t njp_big_p()
     static const int64_t v = std::getenv("DPR_NJ_BIG_P") ? std::atoll(std::getenv("DPR_NJ_BIG_P")) : 40000;
     return v;
 }
-static int njp_tg(int64_t P) { return P < njp_big_p() ? 64 : 256; }
+static int njp_tg_small()
+{
+    static const int v = std::getenv("DPR_NJ_TG_SMALL") ? std::atoi(std::getenv("DPR_NJ_TG_SMALL")) : 64;
+    return v == 32 || v == 128 ? v : 64;
+}
+static int njp_tg(int64_t P) { return P < njp_big_p() ? njp_tg_small() : 256; }
 // Strips per test block.  In the small shape a test block is one strip x 64 row groups (the post kernel is a chain of
 // dependent round trips there and all blocks are resident at once).  In the large shape one strip x 256 groups left
 // ~2 900 blocks of ~160 registers per thread, i.e. several rounds of resident blocks, each paying the whole chain (select,
@@ -62,7 +67,7 @@ static int njp_big_ns()
     static const int v = std::getenv("DPR_NJ_BIG_NS") ? std::atoi(std::getenv("DPR_NJ_BIG_NS")) : kBigNS;
     return v == 2 ? v : kBigNS;
 }
-static int njp_ns(int64_t P) { return njp_tg(P) == 64 ? 1 : njp_big_ns(); }
+static int njp_ns(int64_t P) { return njp_tg(P) != 256 ? 1 : njp_big_ns(); }
 // strips that hold a valid unit for some group of the row block [g0, g0 + tg)
 __host__ __device__ inline int64_t njp_strips_of_rows(int64_t g0, int64_t tg, int64_t P)
 {
@@ -898,7 +903,7 @@ static SlabPlan slab_plan(int64_t P, int64_t N, int local_ranks)
     size_t nprep = 1;
     {
         const int64_t G16c = (P + kUR - 1) / kUR;
-        for (int64_t c = 0; 32 * c < G16c && c * kTileCols < P - 1; ++c) nprep += (size_t)((G16c - 32 * c + 63) / 64);
+        for (int64_t c = 0; 32 * c < G16c && c * kTileCols < P - 1; ++c) nprep += (size_t)((G16c - 32 * c + 31) / 32);
     }
     p.blk_cb = take(nprep * 4); p.blk_g0 = take(nprep * 4);
     p.cnt_all = take((size_t)(4 * local_ranks) * 8);
@@ -1162,7 +1167,9 @@ static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
     const unsigned ublocks = update ? (unsigned)((b.N + kThreads - 1) / kThreads) : 0u;
     a.nupd = (int)ublocks;
     if ((unsigned)a.ntest + ublocks == 0u) return DPR_OK;      // (a rank without test blocks in a tests-only launch)
-    if (njp_tg(b.pr.P) == 64) hipLaunchKernelGGL((njp_post_kernel<64, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
+    if (a.tg == 64) hipLaunchKernelGGL((njp_post_kernel<64, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
+    else if (a.tg == 32) hipLaunchKernelGGL((njp_post_kernel<32, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
+    else if (a.tg == 128) hipLaunchKernelGGL((njp_post_kernel<128, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
     else if (a.ns == 2) hipLaunchKernelGGL((njp_post_kernel<256, 2>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
     else hipLaunchKernelGGL((njp_post_kernel<256, kBigNS>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
     DPR_HIP(hipGetLastError());

@@ -232,3 +232,42 @@ def test_mash_other_sketch_sizes(gpu, orc, S):
     # placement rows (lower-triangle batches, no mirror) give the same distances
     got = gpu.place_run(capi.SRC_MASH, n, k=12)
     _same_state(got, orc.place_run(M), n)
+
+
+@pytest.mark.parametrize("S,k", [(300, 15), (1000, 11)])
+def test_mash_index_kernel_several_chunks(orc, monkeypatch, S, k):
+    """The inverted-index kernel over several 512-tip chunks (the last one partial): a clonal clade, a divergent clade,
+    unrelated reads, short reads (padding values) and repeats, in shuffled order; the whole matrix against the oracle's
+    literal loop on a sample of rows that covers every chunk, plus the transposed block of the divide-and-conquer
+    assignment through dc_run's own test elsewhere."""
+    import dipper_amd
+    from dipper_amd import capi
+    monkeypatch.setenv("DPR_MASH_INDEX", "1")
+    rng = np.random.default_rng(S + k)
+    L = 1500
+    seqs = _util.synth_reads(rng, 700, L, mean_bl=5e-5, lo=5e-6, hi=5e-4)
+    seqs += _util.synth_reads(rng, 500, L, mean_bl=2e-3, lo=2e-4, hi=2e-2)
+    seqs += _reads(rng, 60, 200, 2500, related=False)
+    seqs += [seqs[3][:120], b"ACGT" * 12, b"A" * 30, (b"ACGTTGCA" * 30 + seqs[5][:600]) * 2, seqs[10], seqs[10]]
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    n = len(seqs)
+    assert n > 2 * 512 and n % 512 != 0
+    d = dipper_amd.Dipper(0)
+    try:
+        d.set_nj_mode(0)
+        d.set_reads(seqs)
+        sk = d.sketch(k=k, S=S)
+        d.dist_matrix(capi.SRC_MASH, 0, k)
+        M = d.matrix()
+        assert np.array_equal(M, M.T) and np.all(np.diag(M) == 0)
+        rows = sorted(set([1, 2, 63, 64, 511, 512, 513, 1023, 1024, 1025, n - 2, n - 1] + list(rng.integers(1, n, size=30))))
+        for i in rows:
+            ref = orc.mash_dist_row(sk, k, i, i)
+            assert np.allclose(M[i, :i], ref, rtol=1e-12, atol=0), (i, np.nonzero(~np.isclose(M[i, :i], ref, rtol=1e-12, atol=0))[0][:5])
+        # placement batches (rows i0 .. against columns below them) use the same kernel
+        st = d.place_run(capi.SRC_MASH, n, k=k)
+        Dm = np.tril(M, -1) + np.tril(M, -1).T
+        assert np.array_equal(st["trace"][2:], orc.place_run(Dm)["trace"][2:])
+    finally:
+        d.close()
