@@ -254,6 +254,7 @@ def main():
                     help="one GPU: skip the single runs of the other BASELINE sizes (NJ at 100 000 tips, placement of 100 000 unaligned tips, "
                          "divide-and-conquer of 1 000 000 tips)")
     ap.add_argument("--stream-iters", type=int, default=256)
+    ap.add_argument("--dc-tips", type=int, default=1000000, help="several GPUs: size of the divide-and-conquer sub-record")
     ap.add_argument("--sharded-tips", type=int, default=100000)
     ap.add_argument("--sharded-sites", type=int, default=10000)
     ap.add_argument("--probe-only", action="store_true",
@@ -868,6 +869,70 @@ def sharded_leg(args, rank, world, local_rank, dist, torch, barrier, rehearsal):
                                                      max(8, args.stream_iters // 4), solo_denominator=True)
     except Exception as e:
         rec["streaming_row_sharded"] = {"error": repr(e)}
+    del packed
+    # configs[3]: divide-and-conquer of 1 000 000 tips over the ranks (query shares of the assignment and the clusters dealt
+    # to the ranks, backbone distance rows sharded; dpr_dc_run after dpr_comm_init), with rank 0's single-GPU run beside it
+    try:
+        rec["dc_1m"] = dc_leg(args, rank, world, local_rank, dist if world > 1 else None, torch, barrier)
+    except Exception as e:
+        rec["dc_1m"] = {"error": repr(e)}
+    return rec
+
+
+def dc_leg(args, rank, world, local_rank, dist, torch, barrier):
+    import dipper_amd
+    from dipper_amd import capi
+    from tests import _util
+    n, L = args.dc_tips, 400
+    seqs = _util.synth_alignment(np.random.default_rng(args.seed + 9), n, L, mean_bl=2e-3, lo=2e-4, hi=2e-2)
+    order = np.random.default_rng(7).permutation(n)      # the CLI shuffles its input (src/tree_generation.cu:341-344)
+    packed = capi.pack4_many([seqs[i] for i in order])
+    del seqs
+    rec = {"tips": n, "sites": L, "backbone": n // 20, "world": world}
+
+    def run(d):
+        d.set_msa(packed, L)
+        if world > 1 and d is not solo:
+            barrier()
+        t0 = time.perf_counter()
+        st = d.dc_run(capi.SRC_MSA, n, n // 20, dist_type=capi.DIST_JC)
+        wall = time.perf_counter() - t0
+        h = hashlib.sha256()
+        for key in ("head", "e", "nxt", "belong", "len"):
+            h.update(np.ascontiguousarray(st[key]).tobytes())
+        return wall, st["stats"], h.hexdigest()[:16]
+
+    solo = None
+    d = dipper_amd.Dipper(local_rank)
+    try:
+        if world > 1:
+            uid = [d.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            d.comm_init(rank, world, uid[0])
+        wall, stats, digest = run(d)
+    finally:
+        d.close()
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+        mine = torch.tensor([int(digest[:14], 16)], dtype=torch.int64, device="cuda")
+        allh = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allh, mine)
+        rec["ranks_agree"] = bool(all(int(x.item()) == int(digest[:14], 16) for x in allh))
+    rec.update({"seconds": wall, "tips_per_s": n / wall, "tree_digest": digest,
+                "stats_rank0": {k: (float(v) if isinstance(v, float) else int(v)) for k, v in stats.items()}})
+    if world > 1:
+        if rank == 0:
+            solo = dipper_amd.Dipper(local_rank)
+            try:
+                w1, st1, dg1 = run(solo)
+            finally:
+                solo.close()
+            rec["single_gpu"] = {"seconds": w1, "tips_per_s": n / w1}
+            rec["matches_single_gpu"] = dg1 == digest
+            rec["speedup_vs_single_gpu"] = w1 / wall
+        dist.barrier()
     return rec
 
 
