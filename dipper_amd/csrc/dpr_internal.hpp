@@ -236,8 +236,10 @@ struct MashIndex {
     uint64_t* vmax = nullptr;    // [chunks] largest value
     uint16_t* mult = nullptr;    // [n*S] copies of the value at its first position in a sketch, 0 elsewhere
     double* dtab = nullptr;      // [S + 1] distance of every count
+    int32_t* dblk = nullptr;     // [nu] dense block of the value or -1
+    uint16_t* dense = nullptr;   // [ndense][512] position of the value in every tip of the chunk, 65535 = absent
     int64_t chunks = 0;
-    uint32_t nu = 0;
+    uint32_t nu = 0, ndense = 0;
 };
 
 struct MashBuffers {

@@ -114,6 +114,37 @@ __global__ __launch_bounds__(kIThreads) void mi_buckets_kernel(const uint64_t* _
         for (int bb = b + 1; bb <= kINB; ++bb) row[bb] = (uint32_t)(u + 1);
 }
 
+// Dense values: a value held by at least kIDenseMin tips of a chunk gets, besides its posting list, a block of 512 positions
+// indexed by tip (65535 = absent) -- no larger than the list it replaces in the kernel's inner loop, read in tip order, and the
+// counters are then touched in tip order too (conflict-free, no address arithmetic).
+constexpr uint32_t kIDenseMin = 192;
+__global__ __launch_bounds__(kIThreads) void mi_dense_flag_kernel(const uint32_t* __restrict__ off, int64_t nu, uint32_t* __restrict__ dflag)
+{
+    const int64_t u = (int64_t)blockIdx.x * kIThreads + threadIdx.x;
+    if (u >= nu) return;
+    dflag[u] = off[u + 1] - off[u] >= kIDenseMin ? 1u : 0u;
+}
+// dblk[u] = index of u's dense block or -1; posting i of a dense value stores its position into the block
+__global__ __launch_bounds__(kIThreads) void mi_dense_index_kernel(const uint32_t* __restrict__ dflag, const uint32_t* __restrict__ dscan,
+                                                                   int64_t nu, int32_t* __restrict__ dblk)
+{
+    const int64_t u = (int64_t)blockIdx.x * kIThreads + threadIdx.x;
+    if (u >= nu) return;
+    dblk[u] = dflag[u] ? (int32_t)(dscan[u] - 1u) : -1;
+}
+__global__ __launch_bounds__(kIThreads) void mi_dense_fill_kernel(const uint32_t* __restrict__ post, const uint32_t* __restrict__ g,
+                                                                  const int32_t* __restrict__ dblk, int64_t total,
+                                                                  uint16_t* __restrict__ dense)
+{
+    const int64_t i = (int64_t)blockIdx.x * kIThreads + threadIdx.x;
+    if (i >= total) return;
+    const int32_t b = dblk[g[i] - 1u];
+    if (b < 0) return;
+    const uint32_t ent = post[i];
+    if (ent == kINone) return;
+    dense[(int64_t)b * kIC + (ent >> 17)] = (uint16_t)(ent & 0xFFFFu);
+}
+
 // the distance of every possible count: same expression as the pair kernels of mash.hip (uni = S at the end of the merge)
 __global__ void mi_dtab_kernel(int S, int k, double* __restrict__ dtab)
 {
@@ -152,6 +183,7 @@ __global__ __launch_bounds__(64) void mash_dist_index_kernel(MashIndex ix, const
         const uint64_t v = p < S ? row[p] : 0ull;
         const int mu = p < S ? (int)rmult[p] : 0;
         uint32_t start = 0, len = 0;
+        int dense = -1;
         if (mu > 0 && v <= vm) {                    // directory look-up of this lane's value
             const uint32_t bb = (uint32_t)(v >> sh);
             uint32_t lo = bkt[bb];
@@ -161,31 +193,44 @@ __global__ __launch_bounds__(64) void mash_dist_index_kernel(MashIndex ix, const
                 const uint32_t mid = (lo + hi) >> 1;
                 if (ix.uniq[mid] < v) lo = mid + 1; else hi = mid;
             }
-            if (lo < hi0 && ix.uniq[lo] == v) { start = ix.off[lo]; len = ix.off[lo + 1] - start; }
+            if (lo < hi0 && ix.uniq[lo] == v) { start = ix.off[lo]; len = ix.off[lo + 1] - start; dense = ix.dblk[lo]; }
         }
         unsigned long long todo = __builtin_amdgcn_ballot_w64(len > 0);
         // the row's values in ascending order; the first 64 postings of the NEXT value are loaded while this one is applied
-        uint32_t pre = kINone;
-        if (todo) {
-            const int l = (int)__builtin_ctzll(todo);
+        // the first load of a value (64 postings, or tips 0..63 of its dense block) is issued while the previous value is applied
+        auto first_load = [&](int l) -> uint32_t {
+            const int dn = __builtin_amdgcn_readlane(dense, l);
+            if (dn >= 0) return (uint32_t)ix.dense[(int64_t)dn * kIC + lane];
             const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)start, l), ln = (uint32_t)__builtin_amdgcn_readlane((int)len, l);
-            pre = (uint32_t)lane < ln ? ix.post[st + lane] : kINone;
-        }
+            return (uint32_t)lane < ln ? ix.post[st + lane] : kINone;
+        };
+        uint32_t pre = kINone;
+        if (todo) pre = first_load((int)__builtin_ctzll(todo));
         while (todo) {
             const int l = (int)__builtin_ctzll(todo);
             todo &= todo - 1;
             const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)start, l);
             const uint32_t ln = (uint32_t)__builtin_amdgcn_readlane((int)len, l);
             const int m = __builtin_amdgcn_readlane(mu, l);
+            const int dn = __builtin_amdgcn_readlane(dense, l);
             const int nb = b0 + l;                  // position of the value's first copy in the row sketch
             const uint32_t ent0 = pre;
-            if (todo) {
-                const int l2 = (int)__builtin_ctzll(todo);
-                const uint32_t st2 = (uint32_t)__builtin_amdgcn_readlane((int)start, l2), ln2 = (uint32_t)__builtin_amdgcn_readlane((int)len, l2);
-                pre = (uint32_t)lane < ln2 ? ix.post[st2 + lane] : kINone;
-            }
+            if (todo) pre = first_load((int)__builtin_ctzll(todo));
             // reference's condition first_A(v) + nb - c < S  <=>  c - first_A(v) > nb - S
             const int K = nb - S;
+            if (dn >= 0) {                          // dense value: positions by tip, counters in tip order
+                const uint16_t* __restrict__ db = ix.dense + (int64_t)dn * kIC;
+                uint32_t ps[kIC / 64];
+                ps[0] = ent0;
+#pragma unroll
+                for (int q = 1; q < kIC / 64; ++q) ps[q] = (uint32_t)db[64 * q + lane];
+#pragma unroll
+                for (int q = 0; q < kIC / 64; ++q) {
+                    const int c0 = (int)cnt[64 * q + lane];
+                    if (c0 - (int)ps[q] > K) cnt[64 * q + lane] = (uint16_t)(c0 + m);      // absent: position 65535, never true
+                }
+                continue;
+            }
             auto apply = [&](uint32_t ent) {
                 uint16_t* pc = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(cnt) + (ent >> 16));
                 const int c0 = (int)*pc;
@@ -229,7 +274,7 @@ __global__ __launch_bounds__(64) void mash_dist_index_kernel(MashIndex ix, const
 // ------------------------------------------------------------------------------------------------
 void mash_index_free(MashIndex& ix)
 {
-    void* ptrs[] = { ix.post, ix.uniq, ix.off, ix.bkt, ix.ubase, ix.shift, ix.vmax, ix.mult, ix.dtab };
+    void* ptrs[] = { ix.post, ix.uniq, ix.off, ix.bkt, ix.ubase, ix.shift, ix.vmax, ix.mult, ix.dtab, ix.dblk, ix.dense };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     ix = MashIndex();
@@ -305,6 +350,34 @@ int mash_index_build(MashBuffers& m, hipStream_t s)
     hipLaunchKernelGGL(mi_buckets_kernel, dim3((unsigned)((nu + kIThreads - 1) / kIThreads)), dim3(kIThreads), 0, s, ix.uniq, ix.off, ix.ubase,
                        ix.shift, (int64_t)nu, seg, ix.bkt);
     MI_HIP(hipGetLastError());
+    // dense blocks (flag and scan reuse the head-flag buffers: nu <= total)
+    {
+        const unsigned gu = (unsigned)((nu + kIThreads - 1) / kIThreads);
+        hipLaunchKernelGGL(mi_dense_flag_kernel, dim3(gu), dim3(kIThreads), 0, s, ix.off, (int64_t)nu, flag);
+        MI_HIP(hipGetLastError());
+        uint32_t* dscan = nullptr;
+        MI_HIP(hipMalloc(&dscan, sizeof(uint32_t) * (size_t)nu));
+        (void)hipFree(tmp); tmp = nullptr;
+        tb = 0;
+        hipError_t e1 = rocprim::inclusive_scan(nullptr, tb, (const uint32_t*)flag, dscan, (size_t)nu, rocprim::plus<uint32_t>(), s);
+        if (e1 == hipSuccess) e1 = hipMalloc(&tmp, tb ? tb : 16);
+        if (e1 == hipSuccess) e1 = rocprim::inclusive_scan(tmp, tb, (const uint32_t*)flag, dscan, (size_t)nu, rocprim::plus<uint32_t>(), s);
+        uint32_t nd = 0;
+        if (e1 == hipSuccess) e1 = hipMemcpyAsync(&nd, dscan + (nu - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);
+        if (e1 == hipSuccess) e1 = hipMalloc(&ix.dblk, sizeof(int32_t) * (size_t)nu);
+        if (e1 == hipSuccess) e1 = hipMalloc(&ix.dense, sizeof(uint16_t) * ((size_t)nd * kIC + 64));
+        if (e1 == hipSuccess) e1 = hipMemsetAsync(ix.dense, 0xff, sizeof(uint16_t) * ((size_t)nd * kIC + 64), s);
+        if (e1 == hipSuccess) {
+            hipLaunchKernelGGL(mi_dense_index_kernel, dim3(gu), dim3(kIThreads), 0, s, flag, dscan, (int64_t)nu, ix.dblk);
+            hipLaunchKernelGGL(mi_dense_fill_kernel, dim3(gt), dim3(kIThreads), 0, s, ix.post, g, ix.dblk, total, ix.dense);
+            e1 = hipGetLastError();
+        }
+        if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);
+        (void)hipFree(dscan);
+        if (e1 != hipSuccess) return fail(hip_fail(e1, "mash_index_build: dense blocks"));
+        ix.ndense = nd;
+    }
     MI_HIP(hipMalloc(&ix.dtab, sizeof(double) * (size_t)(S + 1)));
     hipLaunchKernelGGL(mi_dtab_kernel, dim3((unsigned)((S + 1 + 255) / 256)), dim3(256), 0, s, S, m.k, ix.dtab);
     MI_HIP(hipGetLastError());
@@ -313,8 +386,8 @@ int mash_index_build(MashBuffers& m, hipStream_t s)
     cleanup();
     ix.chunks = chunks;
     if (std::getenv("DPR_MASH_LOG"))
-        std::fprintf(stderr, "[mash] inverted index: %lld chunks of %d tips, %u distinct (chunk, value) pairs of %lld entries\n",
-                     (long long)chunks, kIC, nu, (long long)total);
+        std::fprintf(stderr, "[mash] inverted index: %lld chunks of %d tips, %u distinct (chunk, value) pairs of %lld entries, %u of them dense\n",
+                     (long long)chunks, kIC, nu, (long long)total, ix.ndense);
     return DPR_OK;
 }
 
