@@ -635,14 +635,16 @@ void mash_free(MashBuffers& m)
 }
 
 // Kernel choice for the row-against-columns shapes (read at every call: the tests switch kernels inside one process).
-// Tokens while the sketches resemble the reference list (measured at 20 000 reads x 3 kb: 3.4 G pairs/s at 13 tokens per
-// sketch, 0.8 G at 97), the inverted index otherwise (2.5-3.9 G pairs/s at any divergence, 9.8 G for unrelated reads), the
-// bucket-table kernel where neither exists (sketches of 2048 values and more) and for the cluster jobs.
-// DPR_MASH_TOKENS_MAX overrides the threshold, DPR_MASH_INDEX=1 / 0 forces / forbids the index.
-static double mash_tok_max(bool index_possible)
+// The inverted index (mash_index.hip) wherever it can be built: 4.4-10 G pairs/s at any divergence (20 000 reads x 3 kb);
+// without it (no memory, more than 2^32 sketch values, DPR_MASH_INDEX=0) the run-encoded tokens while the sketches resemble the
+// reference list (3.4 G pairs/s at 13 tokens per sketch, 0.8 G at 97; up to 150 tokens), else the bucket tables (0.4-0.7 G),
+// which also serve the cluster jobs.  DPR_MASH_INDEX=1 / 0 forces / forbids the index; DPR_MASH_TOKENS_MAX, when set, gives
+// the token kernel every sketch set with at most that many tokens per sketch (ahead of the index).
+static bool mash_tok_forced() { return std::getenv("DPR_MASH_TOKENS_MAX") != nullptr; }
+static double mash_tok_max()
 {
     const char* e = std::getenv("DPR_MASH_TOKENS_MAX");
-    return e ? std::atof(e) : (index_possible ? 24.0 : 150.0);
+    return e ? std::atof(e) : 150.0;
 }
 static int mash_index_policy()      // 1 always, 0 never, -1 automatic
 {
@@ -736,15 +738,15 @@ int mash_sketch(MashBuffers& m, int k, int S, hipStream_t s)
     hipLaunchKernelGGL(mash_sketch_kernel, dim3(grid), dim3(kSketchThreads), kSortCap * sizeof(uint64_t), s,
                        m.packed2, m.word_off, m.len, m.n, k, S, m.sketches);
     DPR_HIP(hipGetLastError());
-    if (int rc = mash_encode(m, s)) return rc;
-    // The inverted index (mash_index.hip) serves the row-against-columns shapes when the token kernel does not apply
-    // (DPR_MASH_INDEX=1: always, 0: never)
     const int want = mash_index_policy();
-    if (want == 1 || (want < 0 && mash_indexable(m) && !(m.tokens && m.tok_mean <= mash_tok_max(true)))) {
+    if (want == 1 || (want < 0 && mash_indexable(m))) {
         const int rc = mash_index_build(m, s);
         if (rc != DPR_OK && want == 1) return rc;
-        if (rc != DPR_OK) (void)hipGetLastError();      // (no memory for the index: the table kernel takes over)
+        if (rc != DPR_OK) (void)hipGetLastError();      // (no memory for the index: tokens / tables take over)
     }
+    // token encoding only where it can be used: no index, or a threshold given explicitly
+    if (!m.index.post || mash_tok_forced())
+        if (int rc = mash_encode(m, s)) return rc;
     return DPR_OK;
 }
 
@@ -781,17 +783,15 @@ int mash_dist_rows(const MashBuffers& m, int64_t r0, int64_t nr, int rank, int w
                    int64_t ncols, double* out, int64_t ld, hipStream_t s, bool transposed)
 {
     if (nr <= 0 || ncols <= 0) return DPR_OK;
-    if (transposed && (full || world > 1 || (m.S > kLS && !m.tokens))) { set_error("mash_dist_rows: transposed output needs the token or the lookup kernel"); return DPR_ERR_ARG; }
+    if (transposed && (full || world > 1 || (m.S > kLS && !m.tokens && !m.index.post))) { set_error("mash_dist_rows: transposed output needs the index, the token or the lookup kernel"); return DPR_ERR_ARG; }
     // lower-triangle pairs (placement batches; single-GPU NJ with a mirror write): token kernel while the sketches
     // resemble each other (at most DPR_MASH_TOKENS_MAX tokens per sketch on average, default 150 of up to S: measured break-even with the table kernel), else the table kernel
     const bool mirror = full && world == 1 && r0 == 0;
-    // (beside the tree kernels of a placement batch the token kernel keeps its lead longer: it leaves wave slots free, the
-    //  index kernel has to be throttled there -- 100 000 tips at 32 tokens per sketch: 3.8 s against 4.5 s)
-    const bool have_index = mash_index_policy() != 0 && m.index.post != nullptr;
-    const double tok_max = (have_index && m.share_chip && !std::getenv("DPR_MASH_TOKENS_MAX")) ? 48.0 : mash_tok_max(have_index);
-    if (m.index.post && mash_index_policy() != 0 && (!full || mirror) && world <= 1 && (mash_index_policy() == 1 || !(m.tokens && m.tok_mean <= tok_max)))
+    const bool tokens_ok = m.tokens && m.tok_mean <= mash_tok_max();
+    const bool use_index = m.index.post && mash_index_policy() != 0 && (mash_index_policy() == 1 || !(mash_tok_forced() && tokens_ok));
+    if (use_index && (!full || mirror) && world <= 1)
         return mash_dist_index(m, r0, nr, ncols, out, ld, mirror, transposed, s);
-    if (m.tokens && m.tok_mean <= tok_max && (!full || mirror) && world <= 1) {
+    if (tokens_ok && (!full || mirror) && world <= 1) {
         // columns a wave walks through: 128 for a whole matrix, fewer when the launch has few row tiles (placement batches
         // of 256 rows), so that it still fills the chip (>= ~4096 waves) and no wave runs long after the others
         const int64_t tiles = (nr + 63) / 64;

@@ -402,11 +402,13 @@ int mash_dist_index(const MashBuffers& m, int64_t r0, int64_t nr, int64_t ncols,
     const int64_t cchunks = (top + kIC - 1) / kIC;
     int64_t blocks = cchunks * nr;                  // one task per wavefront (a bounded grid walking the tasks: 25 % slower, uneven tasks)
     if (blocks > (int64_t)0x3FFFFFFF) blocks = 0x3FFFFFFF;
-    // When tree kernels of a placement batch run beside this launch on another stream (share_chip), unused dynamic LDS
-    // caps this kernel at 24 of the 32 wavefronts of a CU, so that their launches find wave slots at once instead of
-    // queueing behind an oversubscribed grid (100 000-tip placement: 3.98 s uncapped, 3.75 s at 24, 4.48 s at 16 wavefronts).
-    static const int pad_b = std::getenv("DPR_MASH_INDEX_PAD") ? std::atoi(std::getenv("DPR_MASH_INDEX_PAD")) : 5632;
-    const size_t pad = m.share_chip ? (size_t)pad_b : 0;
+    // When tree kernels of a placement batch run beside this launch on another stream (share_chip), the grid is bounded instead:
+    // 16 wavefronts per CU walk the tasks.  A grid of 100 000 small workgroups keeps the dispatcher busy and every wave slot
+    // taken, and the tree kernels -- 2 launches per tip, up to 1 500 workgroups each -- then make NO progress beside it
+    // (100 000 tips: distance 1.2 s + tree 2.0 s = 3.2 s, nothing hidden).
+    static const int share_waves = std::getenv("DPR_MASH_INDEX_SHARE_WAVES") ? std::atoi(std::getenv("DPR_MASH_INDEX_SHARE_WAVES")) : 20;
+    if (m.share_chip && share_waves > 0 && blocks > 256ll * share_waves) blocks = 256ll * share_waves;
+    const size_t pad = 0;
     hipLaunchKernelGGL(mash_dist_index_kernel, dim3((unsigned)blocks), dim3(64), pad, s, ix, m.sketches, m.S, m.n, r0, nr, ncols, cchunks,
                        out, ld, mirror ? 1 : 0, transposed ? 1 : 0);
     DPR_HIP(hipGetLastError());
