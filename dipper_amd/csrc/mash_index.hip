@@ -1,6 +1,6 @@
 // Mash distances through an inverted index (round 2).  Replaces mashDistConstruction (src/mash.cu:426-455) for the
-// row-against-many-columns shapes (NJ matrix, placement batches, divide-and-conquer query x backbone blocks) when the
-// sketches do NOT resemble each other enough for the run-encoded token kernel.
+// row-against-many-columns shapes (NJ matrix, placement batches, divide-and-conquer query x backbone blocks): the default
+// pair kernel wherever the index can be built (mash.hip: kernel choice).
 //
 // The reference's merge of column sketch A (outer list) and row sketch B (inner list) counts, for the DISTINCT values
 // v of A that also occur in B,    inter += mult_B(v)   as long as   first_A(v) + #{b < v} - #{matched b < v} < S
@@ -16,9 +16,12 @@
 //     one column tip; counter c[tip] (16 bits, LDS, 1 KiB per wavefront) is read, the reference's condition
 //     pos_A + pos_B - c < S tested, c += mult_B stored.  Tips of one posting list are distinct, lists are applied in
 //     value order, so every counter sees its shared values in the reference's order.  At the end c[tip] IS inter.
+//     A value held by most tips of the chunk (every value of a clonal data set) also has a block of 512 positions indexed
+//     by tip: lanes then read positions and counters in tip order (no address arithmetic, conflict-free LDS).
 // Work per pair = its shared values (550 of 1 000 at 4 % divergence, ~20 for unrelated reads) instead of the ~1 500
-// wave instructions of the table kernel's rank look-ups, and the chunk's postings (2 MB) stay in L2 while all
-// wavefronts of the moment work on the same chunk (tasks are chunk-major).
+// wave instructions of the table kernel's rank look-ups (68 VALU + 32 LDS wave instructions per pair on clonal reads by
+// rocprofv3), and the chunk's postings (2 MB) stay in L2 while all wavefronts of the moment work on the same chunk (tasks
+// are chunk-major): 4.4-10 G pairs/s at 20 000 reads x 3 kb, against 0.4-0.7 G of the table kernel.
 #include "dpr_internal.hpp"
 
 #include <cstdio>
