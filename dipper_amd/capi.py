@@ -77,6 +77,7 @@ def load_library():
     L.dpr_sketch.argtypes = [C.c_void_p, C.c_int, C.c_int, c_u64p]
     L.dpr_dist_matrix.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.dpr_reserve_nj.argtypes = [C.c_void_p, C.c_int64]
+    L.dpr_warm_graphs.argtypes = [C.c_void_p]
     L.dpr_nj_run.argtypes = [C.c_void_p, C.c_int64, c_i32p, c_i32p, c_f64p, c_f64p, c_f64p]
     L.dpr_nj_run.restype = C.c_int64
     L.dpr_argmin_once.argtypes = [C.c_void_p, C.c_int, c_i32p, c_i32p, c_f64p, C.POINTER(C.c_float)]
@@ -302,6 +303,9 @@ class Dipper:
                              groups=int(counts[3]), jobs=int(counts[4]), backbone_ms=float(ms[0]),
                              assign_ms=float(ms[1]), cluster_ms=float(ms[2])))
         return st
+
+    def warm_graphs(self):
+        _chk(self.L, self.L.dpr_warm_graphs(self.h))
 
     def reserve_nj(self, n):
         _chk(self.L, self.L.dpr_reserve_nj(self.h, n))

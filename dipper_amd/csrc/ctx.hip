@@ -298,6 +298,7 @@ int dpr_create(dpr_ctx** out, int device)
     hipLaunchKernelGGL(dpr_warm_kernel, dim3(1), dim3(64), 0, c->stream, 0);
     (void)hipGetLastError();
     if (tlog) { (void)hipStreamSynchronize(c->stream); lap("first kernel (code object load) done"); }
+
     *out = c;
     return DPR_OK;
 }
@@ -556,6 +557,33 @@ int dpr_reserve_nj(dpr_ctx* c, int64_t n)
         if (int rc = njp_reserve(q, n, c->stream)) return rc;
     }
     DPR_HIP(hipStreamSynchronize(c->stream));
+    return DPR_OK;
+}
+
+// The first hipGraph of a process costs ~30 ms to instantiate (the next ones 0.2 ms); the pruned NJ replays graphs, so that
+// cost would sit in front of its first 32 iterations with the GPU idle.  The CLI calls this from a helper thread while it
+// reads its input (a private stream: nothing of the context's stream is touched).  Safe to call any number of times.
+int dpr_warm_graphs(dpr_ctx* c)
+{
+    if (!c) { set_error("dpr_warm_graphs: null ctx"); return DPR_ERR_ARG; }
+    DPR_HIP(hipSetDevice(c->device));
+    hipStream_t st = nullptr;
+    DPR_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        hipLaunchKernelGGL(dpr_warm_kernel, dim3(1), dim3(64), 0, st, 0);
+        if (hipStreamEndCapture(st, &g) == hipSuccess && g) {
+            if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess && ge) {
+                (void)hipGraphLaunch(ge, st);
+                (void)hipStreamSynchronize(st);
+                (void)hipGraphExecDestroy(ge);
+            }
+            (void)hipGraphDestroy(g);
+        }
+    }
+    (void)hipGetLastError();
+    (void)hipStreamDestroy(st);
     return DPR_OK;
 }
 

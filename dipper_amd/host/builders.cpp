@@ -16,7 +16,7 @@ DeviceContext::DeviceContext(int device) { gpuCheck(dpr_create(&ctx, device), "d
 DeviceContext::~DeviceContext() { if (ctx) dpr_destroy(ctx); }
 
 struct AsyncDeviceContext::Impl {
-    std::thread th;
+    std::thread th, warm;
     DeviceContext* dev = nullptr;
     std::mutex mu;
     std::condition_variable cv;
@@ -28,6 +28,9 @@ AsyncDeviceContext::AsyncDeviceContext(int device) : impl(new Impl)
     Impl* q = impl;
     impl->th = std::thread([q, device] {
         q->dev = new DeviceContext(device);
+        // (helper of the helper: the one-time graph set-up of the HIP runtime runs beside the allocation below, the uploads
+        //  and the distance kernels; joined when the context goes away)
+        q->warm = std::thread([ctx = q->dev->ctx] { (void)dpr_warm_graphs(ctx); });
         std::unique_lock<std::mutex> lk(q->mu);
         q->cv.wait(lk, [q] { return q->reserve_n != 0 || q->closing; });
         const size_t n = q->reserve_n;
@@ -52,6 +55,7 @@ AsyncDeviceContext::~AsyncDeviceContext()
     { std::lock_guard<std::mutex> lk(impl->mu); impl->closing = true; }
     impl->cv.notify_all();
     if (impl->th.joinable()) impl->th.join();
+    if (impl->warm.joinable()) impl->warm.join();
     delete impl->dev;
     delete impl;
 }

@@ -117,6 +117,10 @@ int dpr_sketch(dpr_ctx *ctx, int k, int S, uint64_t *host_sketches);
  * and calculateU (:94-115).  Builds the (sharded) symmetric fp64 matrix and the row sums U. */
 int dpr_dist_matrix(dpr_ctx *ctx, int source, int dist_type, int k);
 
+/* Pay the one-time cost of the process's first hipGraph instantiation (~30 ms; dpr_nj_run replays graphs) now, on a
+ * private stream -- the CLI calls it from a helper thread while it reads its input.  No reference counterpart. */
+int dpr_warm_graphs(dpr_ctx *ctx);
+
 /* Optional: allocate the matrix buffers of a following dpr_dist_matrix over n tips now (cudaMalloc of the n x n matrix
  * in NJDeviceArrays::getDismatrix, src/neighborJoining.cu:41-56); dpr_dist_matrix then finds them in place.  Lets the
  * CLI overlap the allocation with the packing of the input. */
