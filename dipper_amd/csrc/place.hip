@@ -579,6 +579,13 @@ int place_alloc(PlaceBuffers& p, int64_t N, int64_t M)
     DPR_HIP(hipMalloc(&p.q_id, sizeof(int32_t) * (size_t)(4 * N + 64)));      // BFS frontier: every slot at most once
     DPR_HIP(hipMalloc(&p.q_from, sizeof(int32_t) * (size_t)(2 * N + 64)));
     DPR_HIP(hipMalloc(&p.q_dis, sizeof(double) * (size_t)(4 * N + 64)));
+    // the arrays hold 8N slots, placement uses 4N - 4 of them: the rest is defined too (what dpr_place_run copies back)
+    DPR_HIP(hipMemset(p.e, 0xff, sizeof(int32_t) * (size_t)(8 * N)));
+    DPR_HIP(hipMemset(p.nxt, 0xff, sizeof(int32_t) * (size_t)(8 * N)));
+    DPR_HIP(hipMemset(p.belong, 0xff, sizeof(int32_t) * (size_t)(8 * N)));
+    DPR_HIP(hipMemset(p.rev, 0xff, sizeof(int32_t) * (size_t)(8 * N)));
+    DPR_HIP(hipMemset(p.len, 0, sizeof(double) * (size_t)(8 * N)));
+    DPR_HIP(hipDeviceSynchronize());      // (null-stream fills: the context's stream does not wait for them)
     p.nparts_max = (int)((4 * N + kThreads - 1) / kThreads + 1);
     DPR_HIP(hipMalloc(&p.partials, sizeof(PlacePartial) * (size_t)p.nparts_max));
     return DPR_OK;
