@@ -271,3 +271,30 @@ def test_mash_index_kernel_several_chunks(orc, monkeypatch, S, k):
         assert np.array_equal(st["trace"][2:], orc.place_run(Dm)["trace"][2:])
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("n,S,k", [(2, 1, 2), (3, 2, 3), (511, 7, 6), (512, 64, 4), (513, 5, 2), (1025, 33, 5)])
+def test_mash_index_kernel_edges(orc, monkeypatch, n, S, k):
+    """Chunk boundaries (one tip short of a chunk, exactly one chunk, one tip over, two chunks + 1), tiny sketches and small
+    k (few distinct hash values: almost every sketch value is a duplicate or a padding value): inverted-index kernel
+    against the oracle's literal loop."""
+    import dipper_amd
+    from dipper_amd import capi
+    monkeypatch.setenv("DPR_MASH_INDEX", "1")
+    rng = np.random.default_rng(n * 131 + S * 7 + k)
+    seqs = _reads(rng, n, 12, 220, related=(n % 2 == 1))
+    seqs[0] = b"AC"                                   # shorter than k for k > 2: an all-padding sketch
+    d = dipper_amd.Dipper(0)
+    try:
+        d.set_nj_mode(0)
+        d.set_reads(seqs)
+        sk = d.sketch(k=k, S=S)
+        d.dist_matrix(capi.SRC_MASH, 0, k)
+        M = d.matrix()
+        assert np.array_equal(M, M.T) and np.all(np.diag(M) == 0)
+        rows = range(1, n) if n <= 513 else sorted(set([1, 511, 512, 513, 1023, 1024] + list(rng.integers(1, n, size=40))))
+        for i in rows:
+            ref = orc.mash_dist_row(sk, k, i, i)
+            assert np.allclose(M[i, :i], ref, rtol=1e-12, atol=0), (i, np.nonzero(~np.isclose(M[i, :i], ref, rtol=1e-12, atol=0))[0][:5])
+    finally:
+        d.close()
