@@ -1051,8 +1051,12 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
             double* rows = rows_buf[overlap ? cur : 0];
             if (overlap) DPR_HIP(hipStreamWaitEvent(c->stream, filled[cur], 0));
             else if (i0 > first) { if (int rc = fill_rows(i0, nr, rows)) return rc; }
-            for (int64_t i = i0; i < i0 + nr; ++i)
-                if (int rc = place_tip(p, row_ptr(i, i0, rows), i, c->place_trace, c->stream)) return rc;
+            if (source == DPR_SRC_MATRIX) {      // packed triangle: rows are not evenly spaced
+                for (int64_t i = i0; i < i0 + nr; ++i)
+                    if (int rc = place_tip(p, row_ptr(i, i0, rows), i, c->place_trace, c->stream)) return rc;
+            } else {
+                if (int rc = place_tips(p, rows, ldb, i0, nr, c->place_trace, c->stream)) return rc;
+            }
             if (overlap) { if (int rc = new_event(&consumed[cur])) return rc; DPR_HIP(hipEventRecord(consumed[cur], c->stream)); }
         }
         return DPR_OK;

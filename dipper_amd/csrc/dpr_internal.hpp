@@ -296,6 +296,8 @@ struct PlaceBuffers {
     double* q_dis = nullptr;
     void* partials = nullptr;
     int nparts_max = 0;
+    void* partials_multi = nullptr;   // block minima of a scan launch that serves several tips (place_tips)
+    int64_t nparts_multi = 0;
     int dbg = 0;   // 4: place_update_kernel writes its phase clocks into the trace (DPR_PLACE_CLOCKS, profiling only)
 };
 int place_alloc(PlaceBuffers& p, int64_t N, int64_t M = 0);   // M = 0: M = N
@@ -304,6 +306,7 @@ int place_init_fresh(PlaceBuffers& p, hipStream_t s);
 int place_initial_tree(PlaceBuffers& p, const double* d_dis_row1, hipStream_t s);
 int place_import_backbone(PlaceBuffers& p, int64_t m, hipStream_t s);
 int place_tip(PlaceBuffers& p, const double* d_dis, int64_t tip, double* d_trace, hipStream_t s);
+int place_tips(PlaceBuffers& p, const double* d_dis0, int64_t ldb, int64_t tip0, int64_t count, double* d_trace, hipStream_t s);
 
 // exact.hip: exact placement mode (src/placement.cu)
 struct ExactBuffers {

@@ -559,6 +559,463 @@ __global__ __launch_bounds__(kUpdThreads) void place_update_kernel(PlaceBuffers 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Several tips per launch (round 2).  The per-tip pair of launches costs ~7 us of scan + ~12 us of update, most of it
+// launch ramp, kernel boundary and dependent round trips.  Here ONE scan launch evaluates every live slot for kMultiB
+// consecutive tips against the state BEFORE the first of them (the slot's lists are loaded once), and ONE update launch
+// places the tips one after the other.  For the 2nd..Bth tip the speculative block minima stay valid except where an
+// earlier placement of the same launch changed an input of the evaluation: the lists of the slots the new leaf entered
+// (and, since a slot's evaluation reads its reverse's list, their reverse slots), the split edge's two slots and the four
+// new slots.  Those "dirty" slots (50-100 per placement) are re-evaluated with the current state; a block whose
+// speculative winner is dirty is re-scanned; everything else keeps its speculative value, which is what a sequential
+// scan would compute (same inputs, same arithmetic).  First minimum by (pendant length, slot) as before, so adjacency,
+// lists and trace are those of the tip-by-tip schedule bit for bit (tests/test_gpu_mash_place.py, test_gpu_fullsize.py).
+// ------------------------------------------------------------------------------------------------
+constexpr int kMultiB = 4;
+constexpr int kDirtyHash = 4096, kDirtyCap = 2048, kRescanCap = 128;
+
+// calculateBranchLength for one slot (the arithmetic of place_tip_kernel)
+__device__ __forceinline__ void place_eval_slot(const PlaceBuffers& p, const double* __restrict__ dis, int sl, double& add, double& d1,
+                                                int& eid, int& myrev)
+{
+    add = 2.0; d1 = 0.0; eid = 0; myrev = -1;
+    const int bel = p.belong[sl], tgt = p.e[sl];
+    const int oe = p.rev[sl];
+    const double L = p.len[sl];
+    if (bel >= tgt) {
+        double cd[2 * K5];
+        int ci[2 * K5];
+#pragma unroll
+        for (int i = 0; i < K5; ++i) { ci[i] = p.cid[sl * K5 + i]; cd[i] = p.cdis[sl * K5 + i]; }
+#pragma unroll
+        for (int i = 0; i < K5; ++i) { ci[K5 + i] = p.cid[oe * K5 + i]; cd[K5 + i] = p.cdis[oe * K5 + i]; }
+        eid = sl;
+        myrev = oe;
+        double dv[2 * K5];
+#pragma unroll
+        for (int i = 0; i < 2 * K5; ++i) dv[i] = ci[i] != -1 ? dis[ci[i]] : 0.0;
+        double dis1 = 0, dis2 = 0, val;
+#pragma unroll
+        for (int i = 0; i < K5; ++i)
+            if (ci[i] != -1) { val = dv[i] - cd[i]; if (val > dis1) dis1 = val; }
+#pragma unroll
+        for (int i = 0; i < K5; ++i)
+            if (ci[K5 + i] != -1) { val = dv[K5 + i] - cd[K5 + i]; if (val > dis2) dis2 = val; }
+        double a = (dis1 + dis2 - L) / 2;
+        if (a < 0) a = 0;
+        dis1 -= a; dis2 -= a;
+        if (dis1 < 0) dis1 = 0;
+        if (dis2 < 0) dis2 = 0;
+        if (dis1 > L) { a += dis1 - L; dis1 = L; }
+        if (dis2 > L) { a += dis2 - L; dis2 = L; }
+        const double rest = L - dis1 - dis2;
+        dis1 += rest / 2; dis2 += rest / 2;
+        add = a; d1 = dis1;
+    }
+}
+
+// scan of the slots [0, 4 num0 - 4) for the tips num0 .. num0 + nb - 1 (rows dis0 + j ldb): partials[j * nblk + block]
+__global__ __launch_bounds__(kTipThreads) void place_tip_multi_kernel(PlaceBuffers p, const double* __restrict__ dis0, int64_t ldb,
+                                                                   int64_t num0, int nb, PlacePartial* __restrict__ partials, int nblk)
+{
+    __shared__ double sadd[kMultiB][kTipThreads / 64];
+    __shared__ int sidx[kMultiB][kTipThreads / 64];
+    const int64_t live = 4 * num0 - 4;
+    const int64_t idx = (int64_t)blockIdx.x * kTipThreads + threadIdx.x;
+    const bool have = idx < live;
+    double add[kMultiB], d1[kMultiB];
+    int eid = 0, myrev = -1;
+#pragma unroll
+    for (int j = 0; j < kMultiB; ++j) { add[j] = 2.0; d1[j] = 0.0; }
+    if (have) {
+        const int sl = (int)idx;
+        const int bel = p.belong[sl], tgt = p.e[sl];
+        const int oe = p.rev[sl];
+        const double L = p.len[sl];
+        if (bel >= tgt) {
+            double cd[2 * K5];
+            int ci[2 * K5];
+#pragma unroll
+            for (int i = 0; i < K5; ++i) { ci[i] = p.cid[sl * K5 + i]; cd[i] = p.cdis[sl * K5 + i]; }
+#pragma unroll
+            for (int i = 0; i < K5; ++i) { ci[K5 + i] = p.cid[oe * K5 + i]; cd[K5 + i] = p.cdis[oe * K5 + i]; }
+            eid = sl;
+            myrev = oe;
+#pragma unroll
+            for (int j = 0; j < kMultiB; ++j) {
+                if (j >= nb) break;
+                const double* __restrict__ dis = dis0 + (int64_t)j * ldb;
+                double dv[2 * K5];
+#pragma unroll
+                for (int i = 0; i < 2 * K5; ++i) dv[i] = ci[i] != -1 ? dis[ci[i]] : 0.0;
+                double dis1 = 0, dis2 = 0, val;
+#pragma unroll
+                for (int i = 0; i < K5; ++i)
+                    if (ci[i] != -1) { val = dv[i] - cd[i]; if (val > dis1) dis1 = val; }
+#pragma unroll
+                for (int i = 0; i < K5; ++i)
+                    if (ci[K5 + i] != -1) { val = dv[K5 + i] - cd[K5 + i]; if (val > dis2) dis2 = val; }
+                double a = (dis1 + dis2 - L) / 2;
+                if (a < 0) a = 0;
+                dis1 -= a; dis2 -= a;
+                if (dis1 < 0) dis1 = 0;
+                if (dis2 < 0) dis2 = 0;
+                if (dis1 > L) { a += dis1 - L; dis1 = L; }
+                if (dis2 > L) { a += dis2 - L; dis2 = L; }
+                const double rest = L - dis1 - dis2;
+                dis1 += rest / 2; dis2 += rest / 2;
+                add[j] = a; d1[j] = dis1;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double badd[kMultiB];
+    int bidx[kMultiB];
+#pragma unroll
+    for (int j = 0; j < kMultiB; ++j) {
+        badd[j] = (have && add[j] == add[j]) ? add[j] : __builtin_inf();      // NaN never wins
+        bidx[j] = have ? (int)idx : 0x7fffffff;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double oa = __shfl_down(badd[j], off, 64);
+            const int oi = __shfl_down(bidx[j], off, 64);
+            if (oa < badd[j] || (oa == badd[j] && oi < bidx[j])) { badd[j] = oa; bidx[j] = oi; }
+        }
+        if (lane == 0) { sadd[j][w] = badd[j]; sidx[j][w] = bidx[j]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kMultiB; ++j) {
+        if (j >= nb) break;
+        double ba = sadd[j][0];
+        int bi = sidx[j][0];
+#pragma unroll
+        for (int i = 1; i < kTipThreads / 64; ++i)
+            if (sadd[j][i] < ba || (sadd[j][i] == ba && sidx[j][i] < bi)) { ba = sadd[j][i]; bi = sidx[j][i]; }
+        if (have && (int)idx == bi) {
+            PlacePartial pp; pp.add = add[j]; pp.idx = (int)idx; pp.eid = eid; pp.frac = d1[j]; pp.rev = eid ? myrev : -1; pp.pad = 0;
+            partials[(int64_t)j * nblk + blockIdx.x] = pp;
+        }
+        if (threadIdx.x == 0 && bi == 0x7fffffff) {
+            PlacePartial pp; pp.add = __builtin_inf(); pp.idx = 0x7fffffff; pp.eid = 0; pp.frac = 0; pp.rev = -1; pp.pad = 0;
+            partials[(int64_t)j * nblk + blockIdx.x] = pp;
+        }
+    }
+}
+
+struct DirtySet {          // slots whose evaluation inputs changed since the scan launch (LDS)
+    int* hash;             // [kDirtyHash] open addressing, -1 = empty
+    int* list;             // [kDirtyCap]
+    int* count;            // entries in list (may run past kDirtyCap: overflow)
+};
+__device__ __forceinline__ void dirty_add(const DirtySet& ds, int slot)
+{
+    if (*ds.count >= kDirtyCap) { atomicAdd(ds.count, 1); return; }      // overflow: the caller falls back to a full scan
+    unsigned h = ((unsigned)slot * 2654435761u) >> 20;
+    for (int probe = 0; probe < kDirtyHash; ++probe) {
+        const int old = atomicCAS(&ds.hash[h], -1, slot);
+        if (old == slot) return;
+        if (old == -1) {
+            const int k = atomicAdd(ds.count, 1);
+            if (k < kDirtyCap) ds.list[k] = slot;
+            return;
+        }
+        h = (h + 1) & (kDirtyHash - 1);
+    }
+}
+__device__ __forceinline__ bool dirty_has(const DirtySet& ds, int slot)
+{
+    unsigned h = ((unsigned)slot * 2654435761u) >> 20;
+    for (int probe = 0; probe < kDirtyHash; ++probe) {
+        const int v = ds.hash[h];
+        if (v == slot) return true;
+        if (v == -1) return false;
+        h = (h + 1) & (kDirtyHash - 1);
+    }
+    return false;
+}
+
+// updateClosestNodes as closest_update_wave, additionally recording every slot whose list changed (and its reverse)
+__device__ __forceinline__ void closest_update_wave_rec(const PlaceBuffers& p, int x, int start_slot, const DirtySet& ds,
+                                                        int32_t* sq_id, double* sq_dis)
+{
+    const int lane = threadIdx.x & 63;
+    int l = 0, r = 1;
+    if (lane == 0) { sq_id[0] = start_slot; sq_dis[0] = 0.0; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    while (l < r) {
+        const int cnt = min(64, r - l);
+        int sl = -1;
+        double d = 0.0;
+        if (lane < cnt) {
+            const int qi = l + lane;
+            if (qi < kQueueLds) { sl = sq_id[qi]; d = sq_dis[qi]; }
+            else { sl = p.q_id[qi]; d = p.q_dis[qi]; }
+        }
+        int c0 = -1, c1 = -1, nnew = 0;
+        double dn = 0.0;
+        bool walk = false;
+        if (sl >= 0) {
+            double cd[K5];
+            int ci[K5];
+#pragma unroll
+            for (int j = 0; j < K5; ++j) { cd[j] = p.cdis[sl * K5 + j]; ci[j] = p.cid[sl * K5 + j]; }
+            const double ln = p.len[sl];
+            const int k0 = p.cont[2 * sl], k1 = p.cont[2 * sl + 1];
+            const int back = p.rev[sl];
+            int j = K5;
+#pragma unroll
+            for (int t = K5 - 1; t >= 0; --t)
+                if (cd[t] > d) j = t;                  // first entry farther than d
+            if (j < K5) {
+#pragma unroll
+                for (int t = K5 - 1; t > 0; --t)
+                    if (t > j) { p.cdis[sl * K5 + t] = cd[t - 1]; p.cid[sl * K5 + t] = ci[t - 1]; }
+                p.cdis[sl * K5 + j] = d;
+                p.cid[sl * K5 + j] = x;
+                dirty_add(ds, sl);
+                dirty_add(ds, back);
+                dn = d + ln;
+                if (k0 == -2) {                        // high-degree target: count its other slots
+                    walk = true;
+                    for (int i = p.head[p.e[sl]]; i != -1; i = p.nxt[i]) nnew += (i != back) ? 1 : 0;
+                } else {
+                    c0 = k0; c1 = k1;
+                    nnew = (c0 >= 0 ? 1 : 0) + (c1 >= 0 ? 1 : 0);
+                }
+            }
+        }
+        int incl = nnew;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        const int total = __shfl(incl, 63, 64);
+        const int excl = incl - nnew;
+        const bool spill = r + total > kQueueLds;               // wave-uniform
+        if (nnew) {
+            int w = r + excl;
+            auto push = [&](int slot) {
+                if (w < kQueueLds) { sq_id[w] = slot; sq_dis[w] = dn; }
+                else { p.q_id[w] = slot; p.q_dis[w] = dn; }
+                ++w;
+            };
+            if (!walk) {
+                if (c0 >= 0) push(c0);
+                if (c1 >= 0) push(c1);
+            } else {
+                const int back = p.rev[sl];
+                for (int i = p.head[p.e[sl]]; i != -1; i = p.nxt[i])
+                    if (i != back) push(i);
+            }
+        }
+        l += cnt;
+        r += total;
+        if (spill) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+constexpr int kMultiMaxThreads = 1024;      // (launched with 256 threads, or 1024 when there are many block minima to go through)
+__global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(PlaceBuffers p, const PlacePartial* __restrict__ partials, int nblk,
+                                                                         int64_t num0, int nb, const double* __restrict__ dis0, int64_t ldb,
+                                                                         double* __restrict__ trace)
+{
+    __shared__ int s_hash[kDirtyHash];
+    __shared__ int s_list[kDirtyCap];
+    __shared__ int s_count, s_nrescan;
+    __shared__ int s_rescan[kRescanCap];
+    __shared__ int32_t sq_id[kQueueLds];
+    __shared__ double sq_dis[kQueueLds];
+    __shared__ double s_add[kMultiMaxThreads / 64], s_frac[kMultiMaxThreads / 64];
+    __shared__ int s_idx[kMultiMaxThreads / 64], s_eid[kMultiMaxThreads / 64], s_rev[kMultiMaxThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, nthr = (int)blockDim.x;
+    for (int i = tid; i < kDirtyHash; i += nthr) s_hash[i] = -1;
+    if (tid == 0) { s_count = 0; s_nrescan = 0; }
+    __syncthreads();
+    DirtySet ds{ s_hash, s_list, &s_count };
+    const int64_t live0 = 4 * num0 - 4;                 // slots the scan launch covered
+    for (int jt = 0; jt < nb; ++jt) {
+        const int64_t num = num0 + jt;
+        const int ec0 = (int)(4 * num - 4);             // live slots of this tip = slot id of its first new slot
+        const double* __restrict__ dis = dis0 + (int64_t)jt * ldb;
+        const PlacePartial* __restrict__ part = partials + (int64_t)jt * nblk;
+        double badd = __builtin_inf(), bfrac = 0;
+        int bidx = 0x7fffffff, beid = 0, brev = -1;
+        auto consider = [&](double a, int idx, int eid, double frac, int rv) {
+            const double aa = a == a ? a : __builtin_inf();
+            if (aa < badd || (aa == badd && idx < bidx)) { badd = aa; bidx = idx; beid = eid; bfrac = frac; brev = rv; }
+        };
+        const int ndirty = s_count;                      // (stable: written before the last barrier)
+        const bool overflow = ndirty > kDirtyCap;
+        if (!overflow) {
+            // (A) speculative block minima whose winner is untouched
+            for (int b = tid; b < nblk; b += nthr) {
+                const PlacePartial pp = part[b];
+                if (jt > 0 && pp.idx != 0x7fffffff && dirty_has(ds, pp.idx)) {
+                    const int k = atomicAdd(&s_nrescan, 1);
+                    if (k < kRescanCap) s_rescan[k] = b;
+                } else {
+                    consider(pp.add, pp.idx, pp.eid, pp.frac, pp.rev);
+                }
+            }
+            // (B) the dirty slots with the current state (new slots included)
+            for (int k = tid; k < ndirty; k += nthr) {
+                const int sl = s_list[k];
+                if (sl < ec0) {
+                    double a, f; int e2, rv;
+                    place_eval_slot(p, dis, sl, a, f, e2, rv);
+                    consider(a, sl, e2, f, e2 ? rv : -1);
+                }
+            }
+        }
+        __syncthreads();
+        const int nres = s_nrescan;
+        if (overflow || nres > kRescanCap) {
+            // too much changed for the bookkeeping (small trees: every list still has room): scan everything here
+            badd = __builtin_inf(); bfrac = 0; bidx = 0x7fffffff; beid = 0; brev = -1;
+            for (int sl = tid; sl < ec0; sl += nthr) {
+                double a, f; int e2, rv;
+                place_eval_slot(p, dis, sl, a, f, e2, rv);
+                consider(a, sl, e2, f, e2 ? rv : -1);
+            }
+        } else {
+            // (C) blocks whose speculative winner is dirty: all their slots again
+            for (int k = 0; k < nres; ++k) {
+                const int64_t sl = (int64_t)s_rescan[k] * kTipThreads + tid;
+                if (tid < kTipThreads && sl < live0) {
+                    double a, f; int e2, rv;
+                    place_eval_slot(p, dis, (int)sl, a, f, e2, rv);
+                    consider(a, (int)sl, e2, f, e2 ? rv : -1);
+                }
+            }
+        }
+        // slots >= 4*num-4 (and < 4M-4) all carry the tuple (0,0,2): the first of them competes
+        if (tid == 0 && (int64_t)ec0 < 4 * p.M - 4) consider(2.0, ec0, 0, 0.0, -1);
+        {
+            const double wa = wave_fmin(badd);
+            const uint64_t wi = wave_umin64(badd == wa ? (uint64_t)(uint32_t)bidx : ~0ull);
+            const unsigned long long own = __builtin_amdgcn_ballot_w64((badd == wa) & ((uint64_t)(uint32_t)bidx == wi));
+            const int src = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(own));
+            if (lane == src) { s_add[tid >> 6] = badd; s_idx[tid >> 6] = bidx; s_eid[tid >> 6] = beid; s_frac[tid >> 6] = bfrac; s_rev[tid >> 6] = brev; }
+        }
+        __syncthreads();
+        if (tid < 64) {                      // wavefront 0: split + closest-list update, as place_finish_and_update
+            badd = s_add[0]; bidx = s_idx[0]; beid = s_eid[0]; bfrac = s_frac[0]; brev = s_rev[0];
+            for (int w = 1; w < nthr / 64; ++w)
+                if (s_add[w] < badd || (s_add[w] == badd && s_idx[w] < bidx)) { badd = s_add[w]; bidx = s_idx[w]; beid = s_eid[w]; bfrac = s_frac[w]; brev = s_rev[w]; }
+            const int eid = beid;
+            const double fracLen = bfrac, addLen = badd;
+            const int placeId = (int)num;
+            int ec = ec0;
+            if (lane == 0) {
+                if (trace) { trace[3 * num] = eid; trace[3 * num + 1] = fracLen; trace[3 * num + 2] = addLen; }
+                s_nrescan = 0;
+                const int N = (int)p.N;
+                const int middle = placeId + N - 1, outside = placeId;
+                const int xe = eid, ye = brev >= 0 ? brev : p.rev[eid];
+                double i0d[K5], i1d[K5], i3d[K5];
+                int i0i[K5], i1i[K5], i3i[K5];
+#pragma unroll
+                for (int i = 0; i < K5; ++i) {
+                    i0d[i] = p.cdis[ec * K5 + i]; i0i[i] = p.cid[ec * K5 + i];
+                    i1d[i] = p.cdis[(ec + 1) * K5 + i]; i1i[i] = p.cid[(ec + 1) * K5 + i];
+                    i3d[i] = p.cdis[(ec + 3) * K5 + i]; i3i[i] = p.cid[(ec + 3) * K5 + i];
+                }
+                const int x = p.belong[eid], y = p.e[eid];
+                const double originalDis = p.len[eid];
+                double cdx[K5], cdy[K5];
+                int cix[K5], ciy[K5];
+#pragma unroll
+                for (int i = 0; i < K5; ++i) { cdx[i] = p.cdis[xe * K5 + i]; cix[i] = p.cid[xe * K5 + i]; cdy[i] = p.cdis[ye * K5 + i]; ciy[i] = p.cid[ye * K5 + i]; }
+                const double lenye = p.len[ye];
+                const int ox0 = p.cont[2 * xe], ox1 = p.cont[2 * xe + 1], oy0 = p.cont[2 * ye], oy1 = p.cont[2 * ye + 1];
+                p.e[xe] = middle; p.len[xe] = fracLen;
+                p.e[ye] = middle; p.len[ye] = lenye - fracLen;
+                double n0d[K5], n1d[K5];
+                int n0i[K5], n1i[K5];
+                p.e[ec] = x; p.len[ec] = fracLen; p.nxt[ec] = -1; p.belong[ec] = middle;
+#pragma unroll
+                for (int i = 0; i < K5; ++i) {
+                    const bool has = ciy[i] != -1;
+                    n0i[i] = has ? ciy[i] : i0i[i];
+                    n0d[i] = has ? cdy[i] + originalDis - fracLen : i0d[i];
+                    if (has) { p.cid[ec * K5 + i] = n0i[i]; p.cdis[ec * K5 + i] = n0d[i]; }
+                }
+                p.rev[ec] = xe; p.rev[xe] = ec;
+                ec++;
+                p.e[ec] = y; p.len[ec] = originalDis - fracLen; p.nxt[ec] = ec - 1; p.belong[ec] = middle;
+#pragma unroll
+                for (int i = 0; i < K5; ++i) {
+                    const bool has = cix[i] != -1;
+                    n1i[i] = has ? cix[i] : i1i[i];
+                    n1d[i] = has ? cdx[i] + fracLen : i1d[i];
+                    if (has) { p.cid[ec * K5 + i] = n1i[i]; p.cdis[ec * K5 + i] = n1d[i]; }
+                }
+                p.rev[ec] = ye; p.rev[ye] = ec;
+                ec++;
+                p.e[ec] = middle; p.len[ec] = addLen; p.nxt[ec] = -1; p.head[outside] = ec; p.belong[ec] = outside;
+                p.rev[ec] = ec + 1;
+                ec++;
+                p.e[ec] = outside; p.len[ec] = addLen; p.nxt[ec] = ec - 2; p.head[middle] = ec; p.belong[ec] = middle;
+                p.rev[ec] = ec - 1;
+                double md[K5];
+                int mi[K5];
+#pragma unroll
+                for (int i = 0; i < K5; ++i) { md[i] = i3d[i]; mi[i] = i3i[i]; }
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    bool open = true;
+#pragma unroll
+                    for (int i = 0; i < K5; ++i) {
+                        const int si = pass == 0 ? n1i[i] : n0i[i];
+                        const double sd = pass == 0 ? n1d[i] : n0d[i];
+                        open = open && si != -1;
+                        int j = K5;
+#pragma unroll
+                        for (int t = K5 - 1; t >= 0; --t)
+                            if (md[t] > sd) j = t;
+                        if (open && j < K5) {
+#pragma unroll
+                            for (int k = K5 - 1; k > 0; --k)
+                                if (k > j) { md[k] = md[k - 1]; mi[k] = mi[k - 1]; }
+#pragma unroll
+                            for (int k = 0; k < K5; ++k)
+                                if (k == j) { md[k] = sd; mi[k] = si; }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < K5; ++i) { p.cdis[ec * K5 + i] = md[i]; p.cid[ec * K5 + i] = mi[i]; }
+                const int e0 = ec - 3, e1 = ec - 2, e2 = ec - 1, e3 = ec;
+                p.cont[2 * e0] = oy0; p.cont[2 * e0 + 1] = oy1;
+                p.cont[2 * e1] = ox0; p.cont[2 * e1 + 1] = ox1;
+                p.cont[2 * xe] = e1; p.cont[2 * xe + 1] = e3;
+                p.cont[2 * ye] = e0; p.cont[2 * ye + 1] = e3;
+                p.cont[2 * e2] = e0; p.cont[2 * e2 + 1] = e1;
+                p.cont[2 * e3] = -1; p.cont[2 * e3 + 1] = -1;
+                // what the split changed for later evaluations: the edge's two slots and the four new ones
+                dirty_add(ds, xe); dirty_add(ds, ye);
+                dirty_add(ds, e0); dirty_add(ds, e1); dirty_add(ds, e2); dirty_add(ds, e3);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            closest_update_wave_rec(p, placeId, ec0 + 2, ds, sq_id, sq_dis);   // the new leaf's only slot: outside -> middle
+        }
+        // the other wavefronts evaluate the next tip against what wavefront 0 has just stored
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 int place_alloc(PlaceBuffers& p, int64_t N, int64_t M)
@@ -588,12 +1045,14 @@ int place_alloc(PlaceBuffers& p, int64_t N, int64_t M)
     DPR_HIP(hipDeviceSynchronize());      // (null-stream fills: the context's stream does not wait for them)
     p.nparts_max = (int)((4 * N + kThreads - 1) / kThreads + 1);
     DPR_HIP(hipMalloc(&p.partials, sizeof(PlacePartial) * (size_t)p.nparts_max));
+    p.nparts_multi = (int64_t)p.nparts_max * kMultiB;
+    DPR_HIP(hipMalloc(&p.partials_multi, sizeof(PlacePartial) * (size_t)p.nparts_multi));
     return DPR_OK;
 }
 
 void place_free(PlaceBuffers& p)
 {
-    void* ptrs[] = { p.head, p.e, p.nxt, p.belong, p.rev, p.len, p.cid, p.cdis, p.q_id, p.q_from, p.q_dis, p.partials, p.cont };
+    void* ptrs[] = { p.head, p.e, p.nxt, p.belong, p.rev, p.len, p.cid, p.cdis, p.q_id, p.q_from, p.q_dis, p.partials, p.partials_multi, p.cont };
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     p = PlaceBuffers();
@@ -683,6 +1142,37 @@ int place_import_backbone(PlaceBuffers& p, int64_t m, hipStream_t s)
         }
     }
     DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+// tips tip0 .. tip0 + count - 1, distance rows at d_dis0 + k * ldb: kMultiB tips per pair of launches once the tree is large
+// enough for the shared scan to outweigh the fix-up chain of the update launch (measured: 100 000 tips 1.61 -> 1.91 s, i.e. NOT
+// there; 300 000 tips 7.00 -> 6.76 s; 50 000 queries onto a 500 000-tip backbone 2.85 -> 2.59 s).  DPR_PLACE_MULTI_MIN moves the
+// switch (the tests run the multi-tip path from the third tip on), DPR_PLACE_SINGLE turns it off.
+int place_tips(PlaceBuffers& p, const double* d_dis0, int64_t ldb, int64_t tip0, int64_t count, double* d_trace, hipStream_t s)
+{
+    // (read per call: the tests switch inside one process)
+    const int64_t min_tip = std::getenv("DPR_PLACE_MULTI_MIN") ? std::atoll(std::getenv("DPR_PLACE_MULTI_MIN")) : 150000;
+    const bool off = std::getenv("DPR_PLACE_SINGLE") != nullptr;
+    const bool big_block = std::getenv("DPR_PLACE_MULTI_BIG") != nullptr;      // tests: the 1024-thread update workgroup at any size
+    int64_t k = 0;
+    while (k < count) {
+        const int64_t tip = tip0 + k;
+        const int64_t live = 4 * tip - 4;
+        const int nblk = (int)((live + kTipThreads - 1) / kTipThreads);
+        const int nb = (int)(count - k < kMultiB ? count - k : kMultiB);
+        if (off || tip < min_tip || nb < 2 || (int64_t)nblk * kMultiB > p.nparts_multi) {
+            if (int rc = place_tip(p, d_dis0 + k * ldb, tip, d_trace, s)) return rc;
+            k += 1;
+            continue;
+        }
+        PlacePartial* parts = reinterpret_cast<PlacePartial*>(p.partials_multi);
+        hipLaunchKernelGGL(place_tip_multi_kernel, dim3((unsigned)nblk), dim3(kTipThreads), 0, s, p, d_dis0 + k * ldb, ldb, tip, nb, parts, nblk);
+        hipLaunchKernelGGL(place_update_multi_kernel, dim3(1), dim3((nblk > 2048 || big_block) ? kMultiMaxThreads : kUpdThreads), 0, s, p, (const PlacePartial*)parts, nblk, tip, nb,
+                           d_dis0 + k * ldb, ldb, d_trace);
+        DPR_HIP(hipGetLastError());
+        k += nb;
+    }
     return DPR_OK;
 }
 

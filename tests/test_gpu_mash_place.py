@@ -153,8 +153,16 @@ def test_placement_noisy_matrix(gpu, orc):
     _same_state(got, orc.place_run(D), n)
 
 
-def test_placement_msa_and_mash_sources(gpu, orc):
+@pytest.mark.parametrize("multi", ["default", "multi", "multi-1024"])
+def test_placement_msa_and_mash_sources(gpu, orc, monkeypatch, multi):
+    """default: one scan + one update launch per tip at this size; multi: four tips per pair of launches from the third tip on
+    (dirty-slot bookkeeping, block re-scans and -- on trees this small -- the overflow path that re-scans everything), with the
+    256-thread and the 1024-thread update workgroup: same adjacency, lists and trace as the oracle's tip-by-tip order."""
     from dipper_amd import capi
+    if multi != "default":
+        monkeypatch.setenv("DPR_PLACE_MULTI_MIN", "3")
+    if multi == "multi-1024":
+        monkeypatch.setenv("DPR_PLACE_MULTI_BIG", "1")
     rng = np.random.default_rng(123)
     n, L = 400, 2000
     seqs = _util.synth_alignment(rng, n, L, mean_bl=5e-3, lo=1e-4, hi=5e-2)
