@@ -69,6 +69,7 @@ def load_library():
     L.dpr_nj_kernel_name.argtypes = [C.c_int]
     L.dpr_nj_kernel_name.restype = C.c_char_p
     L.dpr_get_place_timing.argtypes = [C.c_void_p, c_f64p, c_f64p]
+    L.dpr_get_place_overlap.argtypes = [C.c_void_p, C.POINTER(C.c_int), c_f64p]
     L.dpr_get_prune_stats.argtypes = [C.c_void_p, c_u64p, c_u64p]
     L.dpr_bw_probe.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.dpr_set_msa.argtypes = [C.c_void_p, c_u64p, C.c_int64, C.c_int64]
@@ -370,6 +371,14 @@ class Dipper:
         b = C.c_double()
         _chk(self.L, self.L.dpr_get_place_timing(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def place_overlap(self):
+        """(overlapped, dist_busy_ms): whether the last placement run computed its distance rows beside the tree kernels,
+        and for how long those batches were in flight (not a summand of the wall time)"""
+        o = C.c_int()
+        b = C.c_double()
+        _chk(self.L, self.L.dpr_get_place_overlap(self.h, C.byref(o), C.byref(b)))
+        return bool(o.value), b.value
 
     # ---- hooks ------------------------------------------------------------------------------------
     def n_active(self):

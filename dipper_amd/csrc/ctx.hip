@@ -78,7 +78,10 @@ struct dpr_ctx {
     bool nj_unit_sharded = false;    // ... and sharing the unit tests / scans of an iteration (else: every rank runs the single-GPU plan)
     double dist_ms = 0, nj_ms = 0;
     double place_dist_ms = 0;        // distance rows of the last placement run (the rest of nj_ms is tree work)
-    std::vector<hipEvent_t> place_ev;   // event pairs around the distance batches of the current placement run
+    std::vector<hipEvent_t> place_ev;   // event pairs whose sum is the reported distance part of the current placement run
+    std::vector<hipEvent_t> place_ev_busy;   // overlap mode: event pairs around the distance batches on the second stream
+    double place_dist_busy_ms = 0;      // overlap mode: time the distance batches were in flight beside the tree kernels
+    bool place_overlapped = false;
     dpr::DcStats dc_stats;
     double dc_ms[3] = { 0, 0, 0 };   // backbone, cluster assignment, cluster trees
     // plan knobs of THIS context (dpr_ctx_set_*); -1 = follow the process-wide default (dpr_set_* / environment)
@@ -310,6 +313,7 @@ int dpr_destroy(dpr_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     for (hipEvent_t e : c->place_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->place_ev_busy) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->nj_kt.ev) (void)hipEventDestroy(e);
     for (auto& b : c->nj) nj_free(b);
     msa_free(c->msa);
@@ -961,7 +965,10 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
     const size_t row_bytes = sizeof(double) * (size_t)(per * W * ldb);
     if (source != DPR_SRC_MATRIX) {
         DPR_HIP(hipMalloc(&rows_buf[0], row_bytes));
-        if (overlap) DPR_HIP(hipMalloc(&rows_buf[1], row_bytes));
+        if (overlap) {
+            const hipError_t me = hipMalloc(&rows_buf[1], row_bytes);
+            if (me != hipSuccess) { (void)hipFree(rows_buf[0]); return hip_fail(me, "hipMalloc(second row buffer)"); }
+        }
     }
     if (overlap && !c->stream2) {
         // lowest priority: the distance kernels fill the chip, the tree kernels of the current batch (one wavefront or a few
@@ -1002,11 +1009,17 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
     };
     // the reference reports the distance and the tree part of a placement run separately
     // (src/placement_close_k.cu:852-853,985-986): an event pair around every distance batch, summed by the caller
+    // Overlap mode: the batches run on the second stream BESIDE the tree kernels, so their own intervals overlap the tree
+    // work in wall time (and stretch while they share the chip) -- they are kept as `busy` time; what is reported as the
+    // distance part is the time the tree stream actually WAITED for a batch (event pairs around its waits below), so
+    // distance + tree = the run's wall time again.
+    c->place_overlapped = overlap;
     auto fill_rows = [&](int64_t i0, int64_t nr, double* rows) -> int {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (source != DPR_SRC_MATRIX) {
             DPR_HIP(hipEventCreate(&e0)); DPR_HIP(hipEventCreate(&e1));
-            c->place_ev.push_back(e0); c->place_ev.push_back(e1);
+            std::vector<hipEvent_t>& dst = overlap ? c->place_ev_busy : c->place_ev;
+            dst.push_back(e0); dst.push_back(e1);
             DPR_HIP(hipEventRecord(e0, ds));
         }
         const int rc = fill_rows_inner(i0, nr, rows);
@@ -1049,7 +1062,14 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
                 DPR_HIP(hipEventRecord(filled[nb], ds));
             }
             double* rows = rows_buf[overlap ? cur : 0];
-            if (overlap) DPR_HIP(hipStreamWaitEvent(c->stream, filled[cur], 0));
+            if (overlap) {
+                hipEvent_t w0 = nullptr, w1 = nullptr;
+                DPR_HIP(hipEventCreate(&w0)); DPR_HIP(hipEventCreate(&w1));
+                c->place_ev.push_back(w0); c->place_ev.push_back(w1);
+                DPR_HIP(hipEventRecord(w0, c->stream));
+                DPR_HIP(hipStreamWaitEvent(c->stream, filled[cur], 0));
+                DPR_HIP(hipEventRecord(w1, c->stream));
+            }
             else if (i0 > first) { if (int rc = fill_rows(i0, nr, rows)) return rc; }
             if (source == DPR_SRC_MATRIX) {      // packed triangle: rows are not evenly spaced
                 for (int64_t i = i0; i < i0 + nr; ++i)
@@ -1075,21 +1095,37 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
 // sum of the distance-batch event pairs of the run that just finished (stream idle); the events are released
 static void place_collect_dist_ms(dpr_ctx* c)
 {
-    double tot = 0;
-    for (size_t i = 0; i + 1 < c->place_ev.size(); i += 2) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, c->place_ev[i], c->place_ev[i + 1]) == hipSuccess) tot += ms;
-    }
-    for (hipEvent_t e : c->place_ev) (void)hipEventDestroy(e);
-    c->place_ev.clear();
-    c->place_dist_ms = tot;
+    auto sum = [](std::vector<hipEvent_t>& evs) {
+        double tot = 0;
+        for (size_t i = 0; i + 1 < evs.size(); i += 2) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, evs[i], evs[i + 1]) == hipSuccess) tot += ms;
+        }
+        for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+        evs.clear();
+        return tot;
+    };
+    c->place_dist_ms = sum(c->place_ev);
+    c->place_dist_busy_ms = sum(c->place_ev_busy);
 }
 
+// dist_ms: the part of the run the tree kernels could not proceed for want of distance rows (without overlap: the
+// distance batches themselves; with overlap: the tree stream's waits for them); tree_ms: the rest of the run.
 int dpr_get_place_timing(dpr_ctx* c, double* dist_ms, double* tree_ms)
 {
     if (!c) { set_error("dpr_get_place_timing: null ctx"); return DPR_ERR_ARG; }
     if (dist_ms) *dist_ms = c->place_dist_ms;
     if (tree_ms) *tree_ms = c->nj_ms > c->place_dist_ms ? c->nj_ms - c->place_dist_ms : 0.0;
+    return DPR_OK;
+}
+
+// overlap mode of the last placement run: *overlapped = 1 and *dist_busy_ms = time the distance batches were in flight on
+// the second stream (concurrent with the tree kernels, so NOT a summand of the run's wall time); else 0 / 0
+int dpr_get_place_overlap(dpr_ctx* c, int* overlapped, double* dist_busy_ms)
+{
+    if (!c) { set_error("dpr_get_place_overlap: null ctx"); return DPR_ERR_ARG; }
+    if (overlapped) *overlapped = c->place_overlapped ? 1 : 0;
+    if (dist_busy_ms) *dist_busy_ms = c->place_overlapped ? c->place_dist_busy_ms : 0.0;
     return DPR_OK;
 }
 

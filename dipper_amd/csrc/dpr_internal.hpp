@@ -122,7 +122,12 @@ struct NjPruned {
     int64_t arena_N = 0;
     int arena_ranks = 0;
     int epoch_index = 0;             // epoch e uses slab e & 1; its matrix lives in arena_D for even e, in NjBuffers::D for odd e
-    hipGraphExec_t graph = nullptr;   // kGraphIters iterations of (scan, post)
+    hipGraphExec_t graph = nullptr;   // graph_iters iterations of (scan, post)
+    // plan of THIS context (set by njp_build; two contexts of one process may differ and run on different host threads)
+    int scan_grid = 1024;             // blocks of the unit scan (256 below 50 000 tips; DPR_NJP_GRID)
+    int graph_iters = 32;             // iterations per captured hipGraph (DPR_NJ_GRAPH_ITERS)
+    unsigned long long* dbg = nullptr;   // DPR_NJ_PHASES: [2 kernels][2048 blocks][8 stamps], then 32768 words of accumulate-mode statistics
+    int64_t dbg_it = -1;
     int32_t* list = nullptr;         // units selected by the tests (sub-unit mask << 28 | strip << 18 | group)
     int32_t *blk_cb = nullptr, *blk_g0 = nullptr;   // test block -> (strip, first group)
     int nprep = 0;
@@ -188,7 +193,6 @@ int njp_build(NjBuffers& b, hipStream_t s);   // permute the tip-order matrix by
 void njp_free(NjPruned& q);                   // everything, the arena included
 int njp_reserve(NjPruned& q, int64_t N, hipStream_t s);   // allocate the arena for N tips ahead of njp_build
 void njp_reset(NjPruned& q);                  // epoch state only (graph, pointers); the arena stays for the next build
-int njp_scan_grid();
 int njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world);
 int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s);   // enqueue `todo` iterations (hipGraph replays)
 const char* njp_kernel_name(int idx);   // kernels of one iteration, in launch order

@@ -783,12 +783,19 @@ int mash_dist_rows(const MashBuffers& m, int64_t r0, int64_t nr, int rank, int w
                    int64_t ncols, double* out, int64_t ld, hipStream_t s, bool transposed)
 {
     if (nr <= 0 || ncols <= 0) return DPR_OK;
-    if (transposed && (full || world > 1 || (m.S > kLS && !m.tokens && !m.index.post))) { set_error("mash_dist_rows: transposed output needs the index, the token or the lookup kernel"); return DPR_ERR_ARG; }
     // lower-triangle pairs (placement batches; single-GPU NJ with a mirror write): token kernel while the sketches
     // resemble each other (at most DPR_MASH_TOKENS_MAX tokens per sketch on average, default 150 of up to S: measured break-even with the table kernel), else the table kernel
     const bool mirror = full && world == 1 && r0 == 0;
     const bool tokens_ok = m.tokens && m.tok_mean <= mash_tok_max();
     const bool use_index = m.index.post && mash_index_policy() != 0 && (mash_index_policy() == 1 || !(mash_tok_forced() && tokens_ok));
+    // transposed output exists in the index, token and lookup kernels only: reject the call unless one of them WILL be
+    // selected below (the literal row kernel at the end ignores `transposed`; a sketch size above the lookup tables with
+    // the index switched off and divergent reads used to fall through to it and lay the block out row-major)
+    if (transposed && (full || world > 1 || !(use_index || tokens_ok || m.S <= kLS))) {
+        set_error("mash_dist_rows: transposed output needs the index, the token or the lookup kernel (sketch size above 1024 with "
+                  "the index unavailable and dissimilar sketches)");
+        return DPR_ERR_ARG;
+    }
     if (use_index && (!full || mirror) && world <= 1)
         return mash_dist_index(m, r0, nr, ncols, out, ld, mirror, transposed, s);
     if (tokens_ok && (!full || mirror) && world <= 1) {

@@ -527,7 +527,16 @@ int nj_fill_pads(double* D, int64_t ld, int64_t nrows, int64_t ncols, int64_t ro
 // A context that builds a matrix of the same shape again (bench.py's steps, a second dpr_dist_matrix) keeps every
 // buffer: freeing and re-allocating 2 x 7.2 GB per call at 30 000 tips cost more than the distance kernel itself.
 // Only the pads are zeroed then -- every element of the n x n block is overwritten by the distance kernels.
+static int nj_alloc_inner(NjBuffers& b, int64_t N, int rank, int world, hipStream_t s);
 int nj_alloc(NjBuffers& b, int64_t N, int rank, int world, hipStream_t s)
+{
+    // a failure part-way (out of memory after the matrix) must not leave a half-built NjBuffers behind: the reuse test
+    // of the next call looks at b.D only (dpr_reserve_nj is called best-effort by the CLI, its return code ignored)
+    const int rc = nj_alloc_inner(b, N, rank, world, s);
+    if (rc != DPR_OK) nj_free(b);
+    return rc;
+}
+static int nj_alloc_inner(NjBuffers& b, int64_t N, int rank, int world, hipStream_t s)
 {
     const bool reuse = b.D != nullptr && b.N == N && b.rank == rank && b.world == world;
     if (!reuse) {

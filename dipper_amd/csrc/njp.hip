@@ -851,10 +851,11 @@ __global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
 // host side
 // ------------------------------------------------------------------------------------------------
 static int64_t round_up16(int64_t v) { return (v + 15) / 16 * 16; }
-static int g_njp_grid = 1024;
-static unsigned long long* g_njp_dbg = nullptr;     // DPR_NJ_PHASES: [2 kernels][2048 blocks][8 stamps], then 32768 words of accumulate-mode statistics
-static int64_t g_njp_dbg_it = -1;
-int njp_scan_grid() { return g_njp_grid; }
+// (the scan grid, the graph length and the debug buffer are per-context state of NjPruned: two contexts of one process
+// may run different plans, from different host threads)
+// the stamps of the last context that ran with DPR_NJ_PHASES (debug hook njp_phase_stamps; a process-wide pointer to a
+// per-context buffer that stays allocated until the process ends)
+static unsigned long long* g_njp_dbg_last = nullptr;
 
 // ---- arena -------------------------------------------------------------------------------------------------------
 // Everything the pruned path needs is allocated once per (tips, local ranks) and kept until nj_free: hipMalloc /
@@ -1010,12 +1011,14 @@ int njp_build(NjBuffers& b, hipStream_t s)
         // 512 ms at 30 000 tips), 1024 where the scans are bandwidth-bound (thousands of units per iteration at 100 000 tips)
         const char* e = std::getenv("DPR_NJP_GRID");
         const int g = e ? std::atoi(e) : (b.N < 50000 ? 256 : 1024);
-        g_njp_grid = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+        b.pr.scan_grid = g < 1 ? 1 : (g > 1024 ? 1024 : g);
     }
+    if (const char* e = std::getenv("DPR_NJ_GRAPH_ITERS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) b.pr.graph_iters = v; }
     if (const char* e = std::getenv("DPR_NJ_PHASES")) {
-        g_njp_dbg_it = std::atoll(e);
-        if (!g_njp_dbg) DPR_HIP(hipMalloc(&g_njp_dbg, sizeof(unsigned long long) * 4 * 2048 * 8));
-        DPR_HIP(hipMemsetAsync(g_njp_dbg, 0, sizeof(unsigned long long) * 4 * 2048 * 8, s));
+        b.pr.dbg_it = std::atoll(e);
+        if (!b.pr.dbg) DPR_HIP(hipMalloc(&b.pr.dbg, sizeof(unsigned long long) * 4 * 2048 * 8));
+        DPR_HIP(hipMemsetAsync(b.pr.dbg, 0, sizeof(unsigned long long) * 4 * 2048 * 8, s));
+        g_njp_dbg_last = b.pr.dbg;
     }
     // b.D / b.U hold the matrix and the row sums in tip order (world == 1).  Sort by U ascending.
     const int64_t N = b.N;
@@ -1102,12 +1105,14 @@ void njp_reset(NjPruned& q)
     NjPruned fresh;
     fresh.arena_D = q.arena_D; fresh.arena_slab[0] = q.arena_slab[0]; fresh.arena_slab[1] = q.arena_slab[1];
     fresh.arena_slab_bytes = q.arena_slab_bytes; fresh.arena_N = q.arena_N; fresh.arena_ranks = q.arena_ranks;
+    fresh.dbg = q.dbg;      // (debug buffer: kept for njp_phase_stamps, a few hundred KB, DPR_NJ_PHASES runs only)
     q = fresh;
 }
 
 void njp_free(NjPruned& q)
 {
     njp_reset(q);
+    if (q.dbg) { if (g_njp_dbg_last == q.dbg) g_njp_dbg_last = nullptr; (void)hipFree(q.dbg); q.dbg = nullptr; }
     void* ptrs[] = { q.arena_D, q.arena_slab[0], q.arena_slab[1] };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -1115,8 +1120,8 @@ void njp_free(NjPruned& q)
 }
 
 // unit-sharded mode: unit-scan blocks per rank and unit records in total
-static int njp_grid_rank(const NjPruned& q) { return q.sh_world > 1 ? (g_njp_grid / q.sh_world > 0 ? g_njp_grid / q.sh_world : 1) : g_njp_grid; }
-static int njp_grid_total(const NjPruned& q) { return q.sh_world > 1 ? njp_grid_rank(q) * q.sh_world : g_njp_grid; }
+static int njp_grid_rank(const NjPruned& q) { return q.sh_world > 1 ? (q.scan_grid / q.sh_world > 0 ? q.scan_grid / q.sh_world : 1) : q.scan_grid; }
+static int njp_grid_total(const NjPruned& q) { return q.sh_world > 1 ? njp_grid_rank(q) * q.sh_world : q.scan_grid; }
 
 // kernel arguments of rank v (its own list and counters; v is ignored outside the unit-sharded mode)
 static NjpArgs njp_args(NjBuffers& b, int v)
@@ -1146,7 +1151,7 @@ static NjpArgs njp_args(NjBuffers& b, int v)
     a.do_update = 1; a.do_tests = 1; a.do_rows = 1;
     a.log_x = b.log_x; a.log_y = b.log_y; a.log_bx = b.log_bx; a.log_by = b.log_by;
     a.iterstats = (unsigned long long*)q.iterstats;
-    a.dbg = g_njp_dbg; a.dbg_it = g_njp_dbg_it;
+    a.dbg = q.dbg; a.dbg_it = q.dbg_it;
     { static const int fl = std::getenv("DPR_NJP_FLAGS") ? std::atoi(std::getenv("DPR_NJP_FLAGS")) : 0; a.flags = fl; }
     return a;
 }
@@ -1221,8 +1226,7 @@ static int njp_enqueue_iteration(NjBuffers& b, hipStream_t s, bool sample = fals
 // enqueue `todo` iterations starting at iteration it0.  The kernels of an iteration take no per-iteration
 // arguments, so kGraphIters iterations are captured once into a hipGraph and replayed; iterations beyond
 // it_limit are no-ops.  Afterwards the node in quarantine is materialised (row sum, matrix row).
-static int g_graph_iters = 32;      // DPR_NJ_GRAPH_ITERS
-#define kGraphIters g_graph_iters
+// (NjPruned::graph_iters, default 32; DPR_NJ_GRAPH_ITERS at njp_build)
 
 static int njp_run_segment(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
 {
@@ -1242,7 +1246,7 @@ static int njp_run_segment(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t 
         q.fresh = false;
     }
     const bool timing = b.kt && b.kt->stride > 0 && q.sh_world <= 1;
-    if (const char* e = std::getenv("DPR_NJ_GRAPH_ITERS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096 && v != g_graph_iters) { g_graph_iters = v; if (q.graph) { (void)hipGraphExecDestroy(q.graph); q.graph = nullptr; } } }
+    const int kGraphIters = q.graph_iters;
     const bool use_graph = q.sh_world <= 1 && todo >= kGraphIters && !timing && !std::getenv("DPR_NJ_NOGRAPH");
     if (use_graph && !q.graph) {
         const auto tg0 = std::chrono::steady_clock::now();
@@ -1281,9 +1285,9 @@ const char* njp_kernel_name(int idx)
 // debug: the phase stamps of iteration DPR_NJ_PHASES (2 x 2048 x 8 words), 0 = not stamped
 int njp_phase_stamps(unsigned long long* out)
 {
-    if (!g_njp_dbg) { set_error("DPR_NJ_PHASES not set"); return DPR_ERR_STATE; }
+    if (!g_njp_dbg_last) { set_error("DPR_NJ_PHASES not set"); return DPR_ERR_STATE; }
     DPR_HIP(hipDeviceSynchronize());
-    DPR_HIP(hipMemcpy(out, g_njp_dbg, sizeof(unsigned long long) * 4 * 2048 * 8, hipMemcpyDeviceToHost));
+    DPR_HIP(hipMemcpy(out, g_njp_dbg_last, sizeof(unsigned long long) * 4 * 2048 * 8, hipMemcpyDeviceToHost));
     return DPR_OK;
 }
 

@@ -48,6 +48,10 @@ DeviceContext& AsyncDeviceContext::get()
     { std::lock_guard<std::mutex> lk(impl->mu); impl->closing = true; }
     impl->cv.notify_all();
     if (impl->th.joinable()) impl->th.join();
+    // the graph warm-up (~30 ms, started when the context came up) is long over when the input has been read; joined here so
+    // that every dpr_* call that follows is the only one on this context (dpr_warm_graphs is the one entry point that may
+    // run beside others -- it touches a private stream only -- and here it ran beside dpr_reserve_nj alone)
+    if (impl->warm.joinable()) impl->warm.join();
     return *impl->dev;
 }
 AsyncDeviceContext::~AsyncDeviceContext()
@@ -320,6 +324,20 @@ static int sourceOf(const Param& params)
     return params.in == "r" ? DPR_SRC_MASH : (params.in == "m" ? DPR_SRC_MSA : DPR_SRC_MATRIX);
 }
 
+// the reference's two timing lines (src/placement_close_k.cu:852-853,985-986).  With Mash input the distance rows of the
+// next batch are computed beside the tree kernels: the first line is then the time the tree kernels waited for rows
+// (the two lines still add up to the run) and a third line gives the batches' own, overlapped duration.
+static void printPlaceTiming(DeviceContext& dev)
+{
+    double dist_ms = 0, tree_ms = 0, busy_ms = 0;
+    int overlapped = 0;
+    dpr_get_place_timing(dev.ctx, &dist_ms, &tree_ms);
+    dpr_get_place_overlap(dev.ctx, &overlapped, &busy_ms);
+    std::cerr << "Distance Operation Time " << (long long)dist_ms << " ms\n";
+    std::cerr << "Tree Operation Time " << (long long)tree_ms << " ms\n";
+    if (overlapped) std::cerr << "Distance batches overlapped with tree operations: " << (long long)busy_ms << " ms in flight\n";
+}
+
 void KPlacementDeviceArrays::findPlacementTree(DeviceContext& dev, Param& params)
 {
     if (exact) {
@@ -333,10 +351,7 @@ void KPlacementDeviceArrays::findPlacementTree(DeviceContext& dev, Param& params
     }
     gpuCheck(dpr_place_run(dev.ctx, sourceOf(params), (int)params.distanceType, (int)params.kmerSize, 2, numSequences,
                            h_head.data(), h_e.data(), h_nxt.data(), h_belong.data(), h_len.data()), "dpr_place_run");
-    double dist_ms = 0, tree_ms = 0;
-    dpr_get_place_timing(dev.ctx, &dist_ms, &tree_ms);
-    std::cerr << "Distance Operation Time " << (long long)dist_ms << " ms\n";    // src/placement_close_k.cu:852-853,985-986
-    std::cerr << "Tree Operation Time " << (long long)tree_ms << " ms\n";
+    printPlaceTiming(dev);
 }
 
 void KPlacementDeviceArrays::addQuery(DeviceContext& dev, Param& params)
@@ -344,10 +359,7 @@ void KPlacementDeviceArrays::addQuery(DeviceContext& dev, Param& params)
     gpuCheck(dpr_place_run(dev.ctx, sourceOf(params), (int)params.distanceType, (int)params.kmerSize, backboneSize,
                            numSequences, h_head.data(), h_e.data(), h_nxt.data(), h_belong.data(), h_len.data()),
              "dpr_place_run");
-    double dist_ms = 0, tree_ms = 0;
-    dpr_get_place_timing(dev.ctx, &dist_ms, &tree_ms);
-    std::cerr << "Distance Operation Time " << (long long)dist_ms << " ms\n";    // src/placement_close_k.cu:852-853,985-986
-    std::cerr << "Tree Operation Time " << (long long)tree_ms << " ms\n";
+    printPlaceTiming(dev);
 }
 
 void KPlacementDeviceArraysDC::allocateDeviceArraysDC(size_t num, size_t totalNum)

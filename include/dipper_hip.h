@@ -118,7 +118,10 @@ int dpr_sketch(dpr_ctx *ctx, int k, int S, uint64_t *host_sketches);
 int dpr_dist_matrix(dpr_ctx *ctx, int source, int dist_type, int k);
 
 /* Pay the one-time cost of the process's first hipGraph instantiation (~30 ms; dpr_nj_run replays graphs) now, on a
- * private stream -- the CLI calls it from a helper thread while it reads its input.  No reference counterpart. */
+ * private stream -- the CLI calls it from a helper thread while it reads its input.  No reference counterpart.
+ * Threading: this is the ONE entry point that may run concurrently with other dpr_* calls on the same context (it
+ * touches nothing of the context but its device index; thread-local stream capture, thread-local error string);
+ * join the helper thread before dpr_destroy. */
 int dpr_warm_graphs(dpr_ctx *ctx);
 
 /* Optional: allocate the matrix buffers of a following dpr_dist_matrix over n tips now (cudaMalloc of the n x n matrix
@@ -220,9 +223,14 @@ int dpr_place_run(dpr_ctx *ctx, int source, int dist_type, int k, int64_t first,
                   int32_t *head, int32_t *e, int32_t *nxt, int32_t *belong, double *len);
 
 /* distance and tree part of the last dpr_place_run in milliseconds (the reference prints them as "Distance Operation
- * Time" / "Tree Operation Time", src/placement_close_k.cu:852-853,985-986): HIP-event time of the distance batches,
- * and the rest of the run */
+ * Time" / "Tree Operation Time", src/placement_close_k.cu:852-853,985-986).  The two add up to the run.  Without
+ * overlap dist_ms is the HIP-event time of the distance batches.  Mash input computes the rows of the next batch on a
+ * second stream beside the tree kernels: dist_ms is then the time the tree stream WAITED for distance rows (the
+ * non-overlapped remainder), not the batches' own duration -- that one is dpr_get_place_overlap's dist_busy_ms */
 int dpr_get_place_timing(dpr_ctx *ctx, double *dist_ms, double *tree_ms);
+/* *overlapped = 1 if the last placement run computed its distance rows beside the tree kernels; *dist_busy_ms = time the
+ * distance batches were in flight then (concurrent with tree work: not a summand of the wall time); 0 / 0.0 otherwise */
+int dpr_get_place_overlap(dpr_ctx *ctx, int *overlapped, double *dist_busy_ms);
 
 /* ---- exact placement mode: PlacementDeviceArrays::{allocateDeviceArrays,findPlacementTree}
  * (src/placement.cu:17-117,508-789), reached in the reference through `-m 0` with 30000 <= n < 1000000

@@ -133,6 +133,27 @@ def test_dc_mash(gpu, orc):
     assert np.bincount(ref["cluster_id"][B:]).max() > 12       # more than one 12-row group in a cluster
 
 
+def test_dc_mash_large_sketch_without_index_is_rejected(monkeypatch):
+    """Sketch size above the lookup tables (1024) with the inverted index switched off and divergent reads: none of
+    the three kernels that can write the query-minor distance block of the assignment phase is available.  The call
+    must fail loudly (it used to fall through to the literal row kernel, which ignores the layout flag, and assign
+    clusters from a mis-laid block without any error)."""
+    import dipper_amd
+    from dipper_amd import capi
+    monkeypatch.setenv("DPR_MASH_INDEX", "0")
+    rng = np.random.default_rng(77)
+    reads = [rng.choice(_util.BASES, size=2500).tobytes() for _ in range(300)]      # unrelated reads: ~S tokens per sketch
+    d = dipper_amd.Dipper(0)
+    try:
+        d.set_reads(reads)
+        d.sketch(k=15, S=2000, fetch=False)
+        with pytest.raises(capi.DipperError) as ei:
+            d.dc_run(capi.SRC_MASH, len(reads), 60, k=15)
+        assert "transposed" in str(ei.value) or "sketch size" in str(ei.value)
+    finally:
+        d.close()
+
+
 def test_dc_additive_recovery_at_size(gpu):
     """size-independent property: with the distance to the last backbone tip computed
     (DPR_DC_EXACT_LAST) a tree metric is recovered exactly; here through sequences, so check that

@@ -77,18 +77,29 @@ def test_nj_random_nonadditive(gpu, orc):
     _check_nj(gpu, orc, D)
 
 
-def test_nj_no_candidate(gpu):
-    """All Q >= 10000: the reference's init value wins (undefined there); we return an error."""
+def test_nj_all_zero_matrix(gpu, orc):
+    """All distances 0: every Q is 0, i.e. one global tie that the key (band, j mod 256, j, i) alone resolves, for all
+    n - 2 iterations -- same merge log as the oracle."""
+    n = 40
+    _check_nj(gpu, orc, np.zeros((n, n)))
+
+
+def test_nj_no_candidate(gpu, orc):
+    """All Q >= 10000 from the first iteration on: with every distance -c the criterion is q = c n / (n - 2) > 0, so
+    c = 1e5 leaves the reference's init tuple (0, 0, 10000) as the winner (it then merges slot 0 with itself:
+    undefined, src/neighborJoining.cu:134-141,214).  The library returns DPR_ERR_NOCAND; the oracle agrees that the
+    first scan finds nothing."""
     from dipper_amd import capi, DipperError
     n = 8
-    D = np.full((n, n), 1e6)
-    np.fill_diagonal(D, 0)
-    # q = d - (U_i+U_j)/(n-2) = 1e6 - 2*7e6/6 < 0 -> fine; force positive q with a far outlier
-    D = np.zeros((n, n))
-    gpu.set_matrix_full(D + 0.0)
+    D = np.full((n, n), -1.0e5)
+    np.fill_diagonal(D, 0.0)
+    rc, _, _, _ = orc.nj_argmin(np.ascontiguousarray(D), n, orc.row_sums(np.ascontiguousarray(D)))
+    assert rc != 0
+    gpu.set_matrix_full(D)
     gpu.dist_matrix(capi.SRC_MATRIX)
-    res = gpu.nj_run()   # all-zero matrix: q = 0 everywhere, valid
-    assert res["iters"] == n - 2
+    with pytest.raises(DipperError) as ei:
+        gpu.nj_run()
+    assert ei.value.code == -4
 
 
 @pytest.mark.parametrize("n,L,inv", [(40, 100, 0.0), (130, 1000, 0.05), (300, 2500, 0.0), (257, 33, 0.2)])
