@@ -240,6 +240,14 @@ class Dipper:
         self._reads = (np.ascontiguousarray(flat), off, lens)
         _chk(self.L, self.L.dpr_set_reads(self.h, _p(self._reads[0], c_u64p), _p(off, c_u64p), _p(lens, c_u64p), len(seqs)))
 
+    def set_reads_packed(self, flat, off, lens):
+        """already 2-bit packed reads: the three arrays of dpr_set_reads (twoBitCompressor layout)"""
+        flat = np.ascontiguousarray(flat, dtype=np.uint64)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint64)
+        self._reads = (flat, off, lens)
+        _chk(self.L, self.L.dpr_set_reads(self.h, _p(flat, c_u64p), _p(off, c_u64p), _p(lens, c_u64p), len(lens)))
+
     def sketch(self, k=15, S=1000, fetch=True):
         n = len(self._reads[2])
         out = np.zeros((n, S), dtype=np.uint64) if fetch else None

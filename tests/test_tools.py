@@ -1,0 +1,133 @@
+"""CPU tests of the bench / test infrastructure under tools/: the native synthetic-input generator (gen_synth: seeded
+Yule tree, JC69, optional indels, true tree) and the normalised-RF tool (nrf), which implements the reference authors'
+accuracy measure (scripts/nrf.sh:26,36-60)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import _util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GEN = os.path.join(ROOT, "tools", "bin", "gen_synth")
+NRF = os.path.join(ROOT, "tools", "bin", "nrf")
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(GEN) and os.path.exists(NRF)), reason="tools not built (python __graft_entry__.py)")
+
+
+def _fasta(path):
+    names, seqs = [], []
+    for line in open(path, "rb").read().split(b"\n"):
+        if line.startswith(b">"):
+            names.append(line[1:].split()[0].decode())
+        elif line:
+            seqs.append(line)
+    return names, seqs
+
+
+def _nrf(a, b):
+    return json.loads(subprocess.run([NRF, a, b], check=True, capture_output=True, text=True).stdout)
+
+
+def test_gen_synth_outputs_agree_and_do_not_depend_on_threads(tmp_path, orc):
+    n, L = 500, 1000
+    out = {}
+    for tag, threads in (("a", 1), ("b", 5)):
+        base = str(tmp_path / tag)
+        subprocess.run([GEN, "--tips", str(n), "--sites", str(L), "--seed", "3", "--mean-bl", "1e-2", "--lo", "1e-3", "--hi", "1e-1",
+                        "--shuffle", "11", "--threads", str(threads), "--fasta", base + ".fa", "--packed4", base + ".p4",
+                        "--tree", base + ".nwk", "--order", base + ".ord"], check=True)
+        out[tag] = {k: open(base + k, "rb").read() for k in (".fa", ".p4", ".nwk", ".ord")}
+    assert out["a"] == out["b"]
+    names, seqs = _fasta(str(tmp_path / "a.fa"))
+    order = np.frombuffer(out["a"][".ord"], dtype=np.int32)
+    assert sorted(order.tolist()) == list(range(n)) and not np.array_equal(order, np.arange(n))
+    assert names == ["T%d" % (k + 1) for k in order]
+    assert all(len(s) == L and set(s) <= set(b"ACGT") for s in seqs)
+    # --packed4 is fourBitCompressor's encoding of the FASTA rows (the oracle's restatement, src/fourBitCompressor.cpp:5-41)
+    packed = np.frombuffer(out["a"][".p4"], dtype=np.uint64).reshape(n, (L + 15) // 16)
+    assert np.array_equal(packed, orc.pack4_many(seqs))
+    # the true tree is over the same names
+    kids, length, name, root = _util.parse_newick(out["a"][".nwk"].decode())
+    assert sorted(name[v] for v in name if not kids[v]) == sorted(names)
+    assert all(1e-3 <= length[v] <= 1e-1 for v in length)
+
+
+def test_gen_synth_reads_with_indels(tmp_path, orc):
+    n, L = 200, 2000
+    base = str(tmp_path / "r")
+    subprocess.run([GEN, "--tips", str(n), "--sites", str(L), "--seed", "5", "--mean-bl", "2e-2", "--lo", "2e-3", "--hi", "2e-1",
+                    "--indel", "0.03,0.09", "--fasta", base + ".fa", "--packed2", base, "--tree", base + ".nwk"], check=True)
+    names, seqs = _fasta(base + ".fa")
+    assert names == ["T%d" % (k + 1) for k in range(n)]
+    lens = np.fromfile(base + ".len", dtype=np.uint64)
+    off = np.fromfile(base + ".off", dtype=np.uint64)
+    flat = np.fromfile(base + ".flat", dtype=np.uint64)
+    assert np.array_equal(lens, np.array([len(s) for s in seqs], dtype=np.uint64))
+    assert len(set(lens.tolist())) > 1                      # indels change the lengths
+    for i in (0, 1, n // 2, n - 1):                         # twoBitCompressor's words (src/twoBitCompressor.cpp:5-41)
+        w = orc.pack2(seqs[i])
+        assert np.array_equal(flat[int(off[i]):int(off[i]) + len(w)], w)
+
+
+def _random_newick(rng, names, fmt="%.6g"):
+    items = [(nm, None) for nm in names]
+    rng.shuffle(items)
+    items = [nm for nm, _ in items]
+    while len(items) > 1:
+        i, j = sorted(rng.choice(len(items), size=2, replace=False).tolist())
+        b = items.pop(j)
+        a = items.pop(i)
+        items.append("(%s:%s,%s:%s)" % (a, fmt % rng.uniform(0, 1), b, fmt % rng.uniform(0, 1)))
+    return items[0] + ";\n"
+
+
+@pytest.mark.parametrize("n", [4, 5, 12, 60, 300])
+def test_nrf_tool_equals_bipartition_sets(tmp_path, n):
+    """the tool's hashed bipartitions against plain Python sets (tests/_util.splits) on random trees, incl. a tree
+    compared with a few-leaf rearrangement of itself and with its own rerooting"""
+    rng = np.random.default_rng(n)
+    names = ["T%d" % (i + 1) for i in range(n)]
+    trees = [_random_newick(rng, names) for _ in range(3)]
+    for k, t in enumerate(trees):
+        open(tmp_path / ("t%d.nwk" % k), "w").write(t)
+    for a in range(3):
+        for b in range(3):
+            got = _nrf(str(tmp_path / ("t%d.nwk" % a)), str(tmp_path / ("t%d.nwk" % b)))
+            sa, sb = _util.splits(trees[a], names), _util.splits(trees[b], names)
+            assert got["tips"] == n and got["splits_a"] == len(sa) and got["splits_b"] == len(sb)
+            assert got["rf"] == len(sa ^ sb) and got["common"] == len(sa & sb)
+            assert got["nrf"] == pytest.approx(len(sa ^ sb) / max(len(sa) + len(sb), 1))
+    assert _nrf(str(tmp_path / "t0.nwk"), str(tmp_path / "t0.nwk"))["nrf"] == 0.0
+
+
+def test_generated_alignment_carries_its_tree(tmp_path, orc):
+    """JC69 distances of a long, divergent generated alignment + the oracle's NJ recover the generating tree almost
+    completely (nRF small) -- the generator's sequences really evolve down the tree it writes."""
+    n, L = 120, 20000
+    base = str(tmp_path / "g")
+    subprocess.run([GEN, "--tips", str(n), "--sites", str(L), "--seed", "2", "--mean-bl", "2e-2", "--lo", "5e-3", "--hi", "1e-1",
+                    "--fasta", base + ".fa", "--tree", base + ".nwk"], check=True)
+    names, seqs = _fasta(base + ".fa")
+    D = orc.msa_dist_lower(orc.pack4_many(seqs), L, 2)
+    res = orc.nj_run(np.tril(D, -1))
+    nwk = _util.newick_from_merges(names, res["merge_x"], res["merge_y"], res["bl_x"], res["bl_y"], res["last_d"], fmt=repr)
+    open(base + ".nj.nwk", "w").write(nwk)
+    got = _nrf(base + ".nwk", base + ".nj.nwk")
+    assert got["tips"] == n and got["nrf"] < 0.05
+
+
+def test_nrf_ignores_the_root(tmp_path):
+    """the same unrooted tree written with three different roots (degree-2 root, trifurcation, root next to a tip)"""
+    forms = ["((A:1,B:1):1,((C:1,D:1):1,E:1):1);", "((A:1,B:1):2,(C:1,D:1):1,E:1);", "(A:1,(B:1,((C:1,D:1):1,E:1):2):0);"]
+    for k, t in enumerate(forms):
+        open(tmp_path / ("f%d.nwk" % k), "w").write(t + "\n")
+    for a in range(3):
+        for b in range(3):
+            got = _nrf(str(tmp_path / ("f%d.nwk" % a)), str(tmp_path / ("f%d.nwk" % b)))
+            assert got["rf"] == 0 and got["splits_a"] == 2 and got["splits_b"] == 2
+    open(tmp_path / "other.nwk", "w").write("((A:1,C:1):1,((B:1,D:1):1,E:1):1);\n")
+    got = _nrf(str(tmp_path / "f0.nwk"), str(tmp_path / "other.nwk"))
+    assert got["rf"] == 4 and got["nrf"] == 1.0
