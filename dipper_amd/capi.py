@@ -57,6 +57,13 @@ def load_library():
     L.dpr_comm_unique_id.argtypes = [C.c_void_p]
     L.dpr_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.dpr_comm_selftest.argtypes = [C.c_void_p]
+    L.dpr_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.dpr_comm_init_local.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.dpr_peer_export.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    L.dpr_peer_attach.argtypes = [C.c_void_p, C.c_void_p]
+    L.dpr_ctx_set_nj_exchange.argtypes = [C.c_void_p, C.c_int]
+    L.dpr_get_nj_exchange_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_char_p, C.c_int]
+    L.dpr_ctx_set_poll_limit_ms.argtypes = [C.c_void_p, C.c_int]
     L.dpr_scan_tune.argtypes = [C.c_int, C.c_int, C.c_int]
     L.dpr_set_nj_mode.argtypes = [C.c_int]
     L.dpr_set_nj_multi_plan.argtypes = [C.c_int]
@@ -209,6 +216,42 @@ class Dipper:
 
     def comm_selftest(self):
         _chk(self.L, self.L.dpr_comm_selftest(self.h))
+
+    def comm_init_local(self, rank, world):
+        _chk(self.L, self.L.dpr_comm_init_local(self.h, rank, world))
+
+    def peer_export(self, n_tips):
+        buf = (C.c_char * 192)()
+        _chk(self.L, self.L.dpr_peer_export(self.h, n_tips, buf))
+        return bytes(buf)
+
+    def peer_attach(self, blobs):
+        data = b"".join(blobs)
+        buf = (C.c_char * len(data)).from_buffer_copy(data)
+        _chk(self.L, self.L.dpr_peer_attach(self.h, buf))
+
+    def set_nj_exchange(self, plan):
+        """row-sharded NJ loop: 0 legacy, 1 peer, 2 mailbox, -1 default"""
+        _chk(self.L, self.L.dpr_ctx_set_nj_exchange(self.h, plan))
+
+    def nj_exchange_info(self):
+        p = C.c_int()
+        nl = C.c_int64()
+        nc = C.c_int64()
+        note = C.create_string_buffer(256)
+        _chk(self.L, self.L.dpr_get_nj_exchange_info(self.h, C.byref(p), C.byref(nl), C.byref(nc), note, 256))
+        return {"plan": {0: "legacy", 1: "peer", 2: "mailbox"}.get(p.value, str(p.value)), "launches": int(nl.value),
+                "collectives": int(nc.value), "note": note.value.decode()}
+
+    def set_poll_limit_ms(self, ms):
+        _chk(self.L, self.L.dpr_ctx_set_poll_limit_ms(self.h, ms))
+
+    def comm_info(self):
+        """(rank, ranks) as the RCCL communicator of this context reports them; (0, 1) without one"""
+        r = C.c_int()
+        n = C.c_int()
+        _chk(self.L, self.L.dpr_comm_info(self.h, C.byref(r), C.byref(n)))
+        return r.value, n.value
 
     # ---- inputs -----------------------------------------------------------------------------------
     def set_msa(self, packed4, L):

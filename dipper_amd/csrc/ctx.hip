@@ -30,6 +30,8 @@ struct Rccl {
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    int (*CommUserRank)(void*, int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 
@@ -49,6 +51,8 @@ static int rccl_load()
     g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
     g_rccl.CommDestroy = (int (*)(void*))dlsym(g_rccl.lib, "ncclCommDestroy");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
+    g_rccl.CommCount = (int (*)(void*, int*))dlsym(g_rccl.lib, "ncclCommCount");
+    g_rccl.CommUserRank = (int (*)(void*, int*))dlsym(g_rccl.lib, "ncclCommUserRank");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
         set_error("librccl.so lacks a required symbol");
         return DPR_ERR_COMM;
@@ -86,6 +90,14 @@ struct dpr_ctx {
     double dc_ms[3] = { 0, 0, 0 };   // backbone, cluster assignment, cluster trees
     // plan knobs of THIS context (dpr_ctx_set_*); -1 = follow the process-wide default (dpr_set_* / environment)
     int nj_mode = -1, nj_vshards = -1, nj_multi_plan = -1;
+    // row-sharded streaming NJ: exchange plan of the loop (-1 = DPR_NJ_EXCHANGE, default peer; see njs.hip) and what the
+    // last dpr_dist_matrix actually set up (a failed peer set-up falls back to the legacy loop and says why)
+    int nj_exchange = -1;
+    int nj_exchange_active = dpr::kNjsLegacy;
+    std::string nj_exchange_note;
+    bool local_comm = false;         // ranks joined by dpr_comm_init_local: no RCCL, windows attached by the launcher
+    bool njs_pending = false;        // the rows of the last merge still live in the row buffers
+    int64_t nj_launches = 0, nj_collectives = 0;     // of the last dpr_nj_run (per rank)
     dpr::NjKernelTiming nj_kt;
 };
 
@@ -127,6 +139,17 @@ static bool want_pruned(const dpr_ctx* c)
     }
     return g_nj_mode == 1;
 }
+static int g_nj_exchange = -1;
+static int ctx_exchange_plan(const dpr_ctx* c)
+{
+    if (c->local_comm) return kNjsMailbox;
+    if (c->nj_exchange >= 0) return c->nj_exchange;
+    if (g_nj_exchange < 0) {
+        const char* e = std::getenv("DPR_NJ_EXCHANGE");
+        g_nj_exchange = (e && std::strcmp(e, "legacy") == 0) ? kNjsLegacy : (e && std::strcmp(e, "mailbox") == 0) ? kNjsMailbox : kNjsPeer;
+    }
+    return g_nj_exchange;
+}
 static int ctx_multi_plan(const dpr_ctx* c) { return c->nj_multi_plan >= 0 ? c->nj_multi_plan : nj_multi_plan(); }
 static int ctx_vshards(const dpr_ctx* c) { return c->nj_vshards >= 1 ? c->nj_vshards : g_nj_vshards; }
 
@@ -155,6 +178,8 @@ static int exchange(dpr_ctx* c, ExKind kind)
     }
     NjBuffers& b = c->nj[0];
     int rc;
+    if (!c->comm) { set_error("exchange: no RCCL communicator on this context"); return DPR_ERR_COMM; }
+    ++c->nj_collectives;
     if (kind == EX_RECS)
         rc = g_rccl.AllGather(b.recs + c->rank, b.recs, sizeof(NjRecord), kNcclUint8, c->comm, c->stream);
     else
@@ -164,6 +189,135 @@ static int exchange(dpr_ctx* c, ExKind kind)
         return DPR_ERR_COMM;
     }
     return DPR_OK;
+}
+
+// ---- peer windows of the one-exchange sharded loop (njs.hip) -----------------------------------------------------
+struct PeerBlob {                  // what a rank tells the others about its buffers (192 bytes)
+    uint64_t ok;                   // 1: both handles valid
+    uint64_t n_tips;
+    hipIpcMemHandle_t d, w;        // matrix rows, window
+    uint64_t pad[6];
+};
+static_assert(sizeof(PeerBlob) == 192, "PeerBlob layout");
+
+static int peer_blob_of(dpr_ctx* c, PeerBlob* out)
+{
+    NjBuffers& b = c->nj[0];
+    std::memset(out, 0, sizeof(PeerBlob));
+    out->n_tips = (uint64_t)b.N;
+    if (!b.D || !b.peer.win) return DPR_OK;
+    if (hipIpcGetMemHandle(&out->d, b.D) != hipSuccess || hipIpcGetMemHandle(&out->w, b.peer.win) != hipSuccess) { (void)hipGetLastError(); return DPR_OK; }
+    out->ok = 1;
+    return DPR_OK;
+}
+
+// map the other ranks' buffers; all[r] for r = 0 .. world-1.  *ok = 0 when any blob is unusable or a mapping fails.
+static int peer_attach_blobs(dpr_ctx* c, const PeerBlob* all, int* ok)
+{
+    NjBuffers& b = c->nj[0];
+    *ok = 1;
+    for (int r = 0; r < c->world; ++r)
+        if (!all[r].ok || all[r].n_tips != (uint64_t)b.N) *ok = 0;
+    if (!*ok) return DPR_OK;
+    std::vector<char*> wins((size_t)c->world, nullptr);
+    std::vector<double*> Ds((size_t)c->world, nullptr);
+    for (int r = 0; r < c->world && *ok; ++r) {
+        if (r == c->rank) { wins[(size_t)r] = b.peer.win; Ds[(size_t)r] = b.D; continue; }
+        void *pd = nullptr, *pw = nullptr;
+        if (hipIpcOpenMemHandle(&pd, all[r].d, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); *ok = 0; break; }
+        b.peer.opened.push_back(pd);
+        if (hipIpcOpenMemHandle(&pw, all[r].w, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); *ok = 0; break; }
+        b.peer.opened.push_back(pw);
+        Ds[(size_t)r] = static_cast<double*>(pd);
+        wins[(size_t)r] = static_cast<char*>(pw);
+    }
+    if (!*ok) {
+        for (void* m : b.peer.opened) (void)hipIpcCloseMemHandle(m);
+        b.peer.opened.clear();
+        return DPR_OK;
+    }
+    return njs_set_peers(b, wins.data(), Ds.data(), c->stream);
+}
+
+// all-gather of `bytes` per rank through the staging buffer b.gath (RCCL); host arrays in / out
+static int rccl_gather_bytes(dpr_ctx* c, const void* mine, void* all, size_t bytes)
+{
+    NjBuffers& b = c->nj[0];
+    char* stage = reinterpret_cast<char*>(b.gath);
+    if (!stage || bytes * (size_t)c->world > sizeof(double) * (size_t)(3 * b.slice_len * c->world)) { set_error("rccl_gather_bytes: staging buffer too small"); return DPR_ERR_STATE; }
+    DPR_HIP(hipMemcpyAsync(stage + (size_t)c->rank * bytes, mine, bytes, hipMemcpyHostToDevice, c->stream));
+    if (g_rccl.AllGather(stage + (size_t)c->rank * bytes, stage, bytes, kNcclUint8, c->comm, c->stream) != 0) { set_error("ncclAllGather(peer handles) failed"); return DPR_ERR_COMM; }
+    DPR_HIP(hipMemcpyAsync(all, stage, bytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
+    DPR_HIP(hipStreamSynchronize(c->stream));
+    return DPR_OK;
+}
+
+// Set up the exchange plan of the row-sharded loop for the buffers nj_alloc just provided.  A plan that cannot be set up
+// on EVERY rank (no fine-grained window, IPC handles refused, a mapping fails) falls back to the legacy loop on all
+// ranks together -- the decision is taken on gathered flags, so the ranks cannot disagree -- and says why in
+// nj_exchange_note.  Ranks joined without RCCL (dpr_comm_init_local) have nothing to fall back to: error.
+static int njs_setup(dpr_ctx* c)
+{
+    const int plan = ctx_exchange_plan(c);
+    c->nj_exchange_active = kNjsLegacy;
+    c->nj_exchange_note.clear();
+    c->njs_pending = false;
+    if (plan == kNjsLegacy) return DPR_OK;
+    if (c->world > kNjsMaxWorld) { c->nj_exchange_note = "more ranks than mailbox slots"; return DPR_OK; }
+    int ok = 1;
+    for (auto& b : c->nj) {
+        b.peer.plan = plan;
+        if (njs_alloc_window(b, c->stream) != DPR_OK) { ok = 0; (void)hipGetLastError(); }
+    }
+    if (c->vworld > 0) {
+        if (!ok) { c->nj_exchange_note = "window allocation failed: " + g_err; for (auto& b : c->nj) b.peer.plan = kNjsLegacy; return DPR_OK; }
+        std::vector<char*> wins((size_t)c->vworld);
+        std::vector<double*> Ds((size_t)c->vworld);
+        for (int r = 0; r < c->vworld; ++r) { wins[(size_t)r] = c->nj[(size_t)r].peer.win; Ds[(size_t)r] = c->nj[(size_t)r].D; }
+        for (auto& b : c->nj)
+            if (int rc = njs_set_peers(b, wins.data(), Ds.data(), c->stream)) return rc;
+        c->nj_exchange_active = plan;
+        return DPR_OK;
+    }
+    NjBuffers& b = c->nj[0];
+    if (c->local_comm) {
+        if (!ok) return DPR_ERR_HIP;
+        if (!b.peer.attached) { set_error("dpr_dist_matrix: ranks joined by dpr_comm_init_local need dpr_peer_export / dpr_peer_attach for this tip count first"); return DPR_ERR_STATE; }
+        c->nj_exchange_active = kNjsMailbox;
+        return DPR_OK;
+    }
+    if (!b.peer.attached) {
+        PeerBlob mine;
+        std::vector<PeerBlob> all((size_t)c->world);
+        if (ok) peer_blob_of(c, &mine); else std::memset(&mine, 0, sizeof mine);
+        if (int rc = rccl_gather_bytes(c, &mine, all.data(), sizeof(PeerBlob))) return rc;
+        int mapped = 0;
+        if (int rc = peer_attach_blobs(c, all.data(), &mapped)) return rc;
+        // second round: did every rank map every peer?
+        std::vector<uint64_t> flags((size_t)c->world, 0);
+        const uint64_t mf = mapped ? 1 : 0;
+        if (int rc = rccl_gather_bytes(c, &mf, flags.data(), sizeof(uint64_t))) return rc;
+        bool all_ok = true;
+        for (uint64_t f : flags) all_ok = all_ok && f == 1;
+        if (!all_ok) {
+            for (void* m : b.peer.opened) (void)hipIpcCloseMemHandle(m);
+            b.peer.opened.clear();
+            b.peer.attached = false;
+            b.peer.plan = kNjsLegacy;
+            c->nj_exchange_note = "peer windows could not be mapped on every rank (hipIpc): legacy two-exchange loop";
+            return DPR_OK;
+        }
+    }
+    c->nj_exchange_active = plan;
+    return DPR_OK;
+}
+
+// barrier over the ranks of the sharded loop, enqueued on the context's stream
+static int njs_barrier(dpr_ctx* c)
+{
+    if (c->vworld > 0 || c->world == 1) return DPR_OK;       // one stream: already ordered
+    if (c->comm) return exchange(c, EX_RECS);                // (the gathered records are dead between iterations)
+    return njs_launch_barrier(c->nj[0], c->stream);
 }
 
 static NjBuffers* owner_buffers(dpr_ctx* c, int64_t row)
@@ -181,6 +335,19 @@ static int nj_iteration(dpr_ctx* c, int64_t n, int64_t it)
         if (int rc = nj_launch_scan(b, false, n, it, c->stream)) return rc;
         return nj_launch_post(b, n, it, c->stream);
     }
+    if (c->nj_exchange_active != kNjsLegacy) {
+        // one exchange, two launches (njs.hip): scan + record, [all-gather of the records | nothing: mailboxes], update
+        for (auto& b : c->nj)
+            if (int rc = njs_launch_scan(b, n, it, c->njs_pending, c->stream)) return rc;
+        if (c->nj_exchange_active == kNjsPeer)
+            if (int rc = exchange(c, EX_RECS)) return rc;
+        for (auto& b : c->nj)
+            if (int rc = njs_launch_post(b, n, it, c->njs_pending, c->stream)) return rc;
+        c->njs_pending = true;
+        c->nj_launches += 2;
+        return DPR_OK;
+    }
+    c->nj_launches += 4;
     for (auto& b : c->nj) {
         if (int rc = nj_launch_scan(b, false, n, it, c->stream)) return rc;
         if (int rc = nj_launch_select_local(b, nj_scan_grid(), c->stream)) return rc;
@@ -375,6 +542,96 @@ int dpr_comm_init(dpr_ctx* c, int rank, int world, const void* id128)
     return DPR_OK;
 }
 
+// Ranks WITHOUT RCCL (several processes whose GPUs -- or one shared GPU -- can map each other's memory): the row-sharded
+// NJ then runs its mailbox plan, and the launcher carries the 192-byte blobs of dpr_peer_export between the processes
+// (tests/test_gpu_multiproc.py does it with pipes on ONE GPU, which RCCL refuses: "duplicate GPU").
+int dpr_comm_init_local(dpr_ctx* c, int rank, int world)
+{
+    if (!c || world < 1 || world > kNjsMaxWorld || rank < 0 || rank >= world) { set_error("dpr_comm_init_local: bad argument"); return DPR_ERR_ARG; }
+    if (c->vworld > 0 || c->comm) { set_error("dpr_comm_init_local: context already holds ranks"); return DPR_ERR_STATE; }
+    c->rank = rank; c->world = world;
+    c->local_comm = world > 1;
+    return DPR_OK;
+}
+
+// allocate the NJ buffers and the window for n_tips on this rank and describe them (192 bytes) for the other ranks
+int dpr_peer_export(dpr_ctx* c, int64_t n_tips, void* out192)
+{
+    if (!c || !out192 || n_tips < 2 || n_tips >= (1 << 24)) { set_error("dpr_peer_export: bad argument"); return DPR_ERR_ARG; }
+    if (c->world < 2 || c->vworld > 0) { set_error("dpr_peer_export: needs a multi-rank context"); return DPR_ERR_STATE; }
+    DPR_HIP(hipSetDevice(c->device));
+    c->have_matrix = 0;
+    NjBuffers& b = c->nj[0];
+    if (int rc = nj_alloc(b, n_tips, c->rank, c->world, c->stream)) return rc;
+    b.peer.plan = kNjsMailbox;
+    if (int rc = njs_alloc_window(b, c->stream)) return rc;
+    --b.peer.run_id;          // (dpr_dist_matrix's own njs_alloc_window call counts the run)
+    DPR_HIP(hipStreamSynchronize(c->stream));
+    PeerBlob blob;
+    peer_blob_of(c, &blob);
+    if (!blob.ok) { set_error("dpr_peer_export: hipIpcGetMemHandle failed"); return DPR_ERR_HIP; }
+    std::memcpy(out192, &blob, sizeof blob);
+    return DPR_OK;
+}
+
+// all192: the blobs of all ranks in rank order (this rank's own one is ignored)
+int dpr_peer_attach(dpr_ctx* c, const void* all192)
+{
+    if (!c || !all192) { set_error("dpr_peer_attach: bad argument"); return DPR_ERR_ARG; }
+    if (c->world < 2 || c->vworld > 0 || !c->nj[0].peer.win) { set_error("dpr_peer_attach: call dpr_peer_export first"); return DPR_ERR_STATE; }
+    DPR_HIP(hipSetDevice(c->device));
+    NjBuffers& b = c->nj[0];
+    for (void* m : b.peer.opened) (void)hipIpcCloseMemHandle(m);
+    b.peer.opened.clear();
+    b.peer.attached = false;
+    int ok = 0;
+    if (int rc = peer_attach_blobs(c, static_cast<const PeerBlob*>(all192), &ok)) return rc;
+    if (!ok) { set_error("dpr_peer_attach: a peer's buffers could not be mapped (hipIpcOpenMemHandle) or describe another tip count"); return DPR_ERR_HIP; }
+    return DPR_OK;
+}
+
+// exchange plan of the row-sharded NJ loop: 0 legacy (4 launches + 2 all-gathers), 1 peer (2 launches + 1 all-gather,
+// rows pulled from their owners), 2 mailbox (2 launches, no collective); -1 = DPR_NJ_EXCHANGE / default (peer)
+int dpr_ctx_set_nj_exchange(dpr_ctx* c, int plan)
+{
+    if (!c || plan < -1 || plan > 2) { set_error("dpr_ctx_set_nj_exchange: -1 default, 0 legacy, 1 peer, 2 mailbox"); return DPR_ERR_ARG; }
+    c->nj_exchange = plan;
+    return DPR_OK;
+}
+// what the last dpr_dist_matrix set up and what the last dpr_nj_run enqueued on this rank
+int dpr_get_nj_exchange_info(dpr_ctx* c, int* active_plan, int64_t* launches, int64_t* collectives, char* note, int cap)
+{
+    if (!c) { set_error("dpr_get_nj_exchange_info: null ctx"); return DPR_ERR_ARG; }
+    if (active_plan) *active_plan = c->nj_exchange_active;
+    if (launches) *launches = c->nj_launches;
+    if (collectives) *collectives = c->nj_collectives;
+    if (note && cap > 0) std::snprintf(note, (size_t)cap, "%s", c->nj_exchange_note.c_str());
+    return DPR_OK;
+}
+// bound of one mailbox poll in milliseconds (default 2000): a rank whose record does not arrive ends the run with DPR_ERR_COMM
+int dpr_ctx_set_poll_limit_ms(dpr_ctx* c, int ms)
+{
+    if (!c || ms < 1) { set_error("dpr_ctx_set_poll_limit_ms: ms >= 1"); return DPR_ERR_ARG; }
+    for (auto& b : c->nj) b.peer.poll_ticks = (unsigned long long)ms * 100000ull;
+    return DPR_OK;
+}
+
+// what the communicator itself says (ncclCommCount / ncclCommUserRank), not what the caller passed to dpr_comm_init:
+// bench.py reports these per leg, so that a record claiming G ranks has RCCL's word for it
+int dpr_comm_info(dpr_ctx* c, int* rank, int* nranks)
+{
+    if (!c) { set_error("dpr_comm_info: null ctx"); return DPR_ERR_ARG; }
+    if (rank) *rank = 0;
+    if (nranks) *nranks = 1;
+    if (!c->comm) return DPR_OK;                 // no communicator: one rank
+    if (!g_rccl.CommCount || !g_rccl.CommUserRank) { set_error("librccl.so lacks ncclCommCount / ncclCommUserRank"); return DPR_ERR_COMM; }
+    int r = 0, n = 0;
+    if (g_rccl.CommCount(c->comm, &n) != 0 || g_rccl.CommUserRank(c->comm, &r) != 0) { set_error("ncclCommCount / ncclCommUserRank failed"); return DPR_ERR_COMM; }
+    if (rank) *rank = r;
+    if (nranks) *nranks = n;
+    return DPR_OK;
+}
+
 // RCCL plumbing self-test on ONE GPU: 1-rank communicator + all-gather of one record.  Exercises the
 // dlopen'ed entry points, the by-value ncclUniqueId ABI and the datatype constants used by exchange().
 int dpr_comm_selftest(dpr_ctx* c)
@@ -482,7 +739,7 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
 {
     if (!c) { set_error("dpr_dist_matrix: null ctx"); return DPR_ERR_ARG; }
     DPR_HIP(hipSetDevice(c->device));
-    if (c->world > 1 && c->vworld == 0 && !c->comm) { set_error("dpr_dist_matrix: dpr_comm_init was not called"); return DPR_ERR_STATE; }
+    if (c->world > 1 && c->vworld == 0 && !c->comm && !c->local_comm) { set_error("dpr_dist_matrix: dpr_comm_init was not called"); return DPR_ERR_STATE; }
     int64_t n = 0;
     if (source == DPR_SRC_MSA) {
         if (!c->msa.planes) { set_error("dpr_dist_matrix: call dpr_set_msa first"); return DPR_ERR_STATE; }
@@ -506,6 +763,10 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
     c->nj_replicated = repl;
     for (size_t r = 0; r < c->nj.size(); ++r)
         if (int rc = nj_alloc(c->nj[r], n, repl ? 0 : (c->vworld > 0 ? (int)r : c->rank), repl ? 1 : c->world, c->stream)) return rc;
+    const bool row_sharded = c->world > 1 && !repl;
+    if (row_sharded) { if (int rc = njs_setup(c)) return rc; }
+    else c->nj_exchange_active = kNjsLegacy;
+    const bool peer_plan = row_sharded && c->nj_exchange_active != kNjsLegacy;
     DPR_HIP(hipEventRecord(c->ev[0], c->stream));
     for (auto& b : c->nj) {
         if (source == DPR_SRC_MSA) {
@@ -518,9 +779,16 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
         } else {
             if (int rc = nj_expand_lower(b, c->packed_lower, c->stream)) return rc;
         }
-        if (int rc = nj_init_sums(b, c->stream)) return rc;
+        // row sums of the own rows: into U (one rank), the slice of the legacy exchange, or the window's slice (peer plans)
+        double* sums = !row_sharded ? nullptr : peer_plan ? reinterpret_cast<double*>(b.peer.win + b.peer.lay.off_slice) : b.slice;
+        if (int rc = nj_init_sums(b, c->stream, sums)) return rc;
     }
-    if (c->world > 1 && !repl) {
+    if (row_sharded && peer_plan) {
+        // every rank reads the other ranks' sums straight from their windows, behind one barrier
+        if (int rc = njs_barrier(c)) return rc;
+        for (auto& b : c->nj)
+            if (int rc = njs_launch_unpack_u(b, c->stream)) return rc;
+    } else if (row_sharded) {
         if (int rc = exchange(c, EX_U)) return rc;
         for (auto& b : c->nj)
             if (int rc = nj_launch_unpack_u(b, c->stream)) return rc;
@@ -612,6 +880,7 @@ int64_t dpr_nj_run(dpr_ctx* c, int64_t max_iters, int32_t* merge_x, int32_t* mer
     const int64_t it0 = st.it;
     c->nj[0].kt = &c->nj_kt;
     if (c->nj_kt.stride > 0 && it0 == 0) { c->nj_kt.samples = 0; for (double& v : c->nj_kt.us_sum) v = 0; }
+    c->nj_launches = 0; c->nj_collectives = 0;
     DPR_HIP(hipEventRecord(c->ev[2], c->stream));
     if (c->nj[0].pr.active) {
         if (int rc = njp_run(c->nj[0], it0, todo, c->stream)) return rc;
@@ -619,10 +888,20 @@ int64_t dpr_nj_run(dpr_ctx* c, int64_t max_iters, int32_t* merge_x, int32_t* mer
         for (int64_t k = 0; k < todo; ++k)
             if (int rc = nj_iteration(c, st.n - k, it0 + k)) return rc;
     }
-    for (auto& b : c->nj)
-        if (!b.pr.active)
-            if (int rc = nj_launch_finish(b, st.n - todo, it0 + todo, c->stream)) return rc;
-    DPR_HIP(hipEventRecord(c->ev[3], c->stream));
+    DPR_HIP(hipEventRecord(c->ev[3], c->stream));       // (the loop itself: the barrier + flush below are once per run)
+    const bool peer_plan = c->world > 1 && !c->nj_replicated && c->nj_exchange_active != kNjsLegacy;
+    if (peer_plan) {
+        // every rank must be through its pulls of the last iteration before an owner flushes the last row buffers
+        if (int rc = njs_barrier(c)) return rc;
+        for (auto& b : c->nj)
+            if (int rc = njs_launch_finish(b, st.n - todo, it0 + todo, c->njs_pending, c->stream)) return rc;
+        c->njs_pending = false;
+        if (int rc = njs_barrier(c)) return rc;      // the flushed rows may be read by other ranks (final distance, hooks)
+    } else {
+        for (auto& b : c->nj)
+            if (!b.pr.active)
+                if (int rc = nj_launch_finish(b, st.n - todo, it0 + todo, c->stream)) return rc;
+    }
     if (int rc = fetch_state(c, &st)) return rc;
     float ms = 0;
     DPR_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
@@ -647,6 +926,10 @@ int64_t dpr_nj_run(dpr_ctx* c, int64_t max_iters, int32_t* merge_x, int32_t* mer
         if (bl_x) DPR_HIP(hipMemcpy(bl_x, c->nj[0].log_bx + it0, sizeof(double) * (size_t)done, hipMemcpyDeviceToHost));
         if (bl_y) DPR_HIP(hipMemcpy(bl_y, c->nj[0].log_by + it0, sizeof(double) * (size_t)done, hipMemcpyDeviceToHost));
     }
+    if (st.status == 3) {
+        set_error("dpr_nj_run: the exchange between the ranks failed (a rank's record did not arrive within the poll limit, or the all-gather delivered a stale one)");
+        return DPR_ERR_COMM;
+    }
     if (st.status != 0) {
         set_error("dpr_nj_run: no Q candidate below the reference's init value 10000 (undefined in the reference)");
         return DPR_ERR_NOCAND;
@@ -660,6 +943,9 @@ int64_t dpr_nj_run(dpr_ctx* c, int64_t max_iters, int32_t* merge_x, int32_t* mer
             DPR_HIP(hipMemcpy(last_d, b0.pr.D + (int64_t)pos01[1] * b0.pr.ld + pos01[0], sizeof(double), hipMemcpyDeviceToHost));
         } else if (c->world == 1 || c->vworld > 0) {
             DPR_HIP(hipMemcpy(last_d, b0.D + 1 * b0.ld + 0, sizeof(double), hipMemcpyDeviceToHost));
+        } else if (peer_plan && !b0.peer.h_D.empty()) {
+            // rank 0's row 1 through the mapping of its matrix (its flush is behind the barrier above)
+            DPR_HIP(hipMemcpy(last_d, b0.peer.h_D[0] + 1 * b0.ld + 0, sizeof(double), hipMemcpyDeviceToHost));
         } else {
             NjRecord rec{ 0.0, 0ull, 0.0, 0ull };
             if (c->rank == 0) DPR_HIP(hipMemcpy(&rec.d, b0.D + 1 * b0.ld + 0, sizeof(double), hipMemcpyDeviceToHost));

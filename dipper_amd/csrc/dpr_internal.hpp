@@ -145,7 +145,34 @@ struct NjKernelTiming {
     int64_t samples = 0;
 };
 
+// ---- one-exchange row-sharded streaming NJ (njs.hip) --------------------------------------------------------------
+constexpr int kNjsMaxWorld = 64;
+constexpr int kNjsLegacy = 0;    // round 2's loop: 4 launches + 2 all-gathers per iteration (nj.hip)
+constexpr int kNjsPeer = 1;      // 2 launches + ONE RCCL all-gather (rank records); rows x / y pulled from their owners' memory
+constexpr int kNjsMailbox = 2;   // 2 launches, no collective: the records go straight into every rank's mailbox
+// layout of a rank's peer-visible window (byte offsets): mail[2][kNjsMaxWorld] records | barrier lines | slice | 4 row buffers
+struct NjsLayout {
+    int64_t off_bar = 0, off_slice = 0, off_rows = 0, bytes = 0;
+    int64_t slice_len = 0;   // doubles (initial row sums of the own rows)
+    int64_t ldv = 0;         // doubles per row buffer
+};
+struct NjPeer {
+    int plan = kNjsLegacy;
+    char* win = nullptr;             // this rank's window (fine-grained device memory)
+    NjsLayout lay;
+    unsigned int* ticket = nullptr;  // last-block ticket of the scan
+    char** d_win = nullptr;          // device arrays [kNjsMaxWorld]: every rank's window / matrix as mapped into THIS process
+    double** d_D = nullptr;
+    std::vector<double*> h_D;        // host copy of d_D
+    std::vector<void*> opened;       // hipIpc mappings to close
+    bool attached = false;
+    unsigned long long bar_epoch = 0;
+    unsigned long long run_id = 0;   // matrix builds on this window so far (part of every mail sequence number)
+    unsigned long long poll_ticks = 200000000ull;    // 2 s of the 100 MHz wall clock
+};
+
 struct NjBuffers {
+    NjPeer peer;
     NjKernelTiming* kt = nullptr;   // owned by the context
     double* D = nullptr;       // [rows_local_max][ld] (+ tail pad)
     int64_t ld = 0;
@@ -174,7 +201,7 @@ int nj_alloc(NjBuffers& b, int64_t N, int rank, int world, hipStream_t s);   // 
 int nj_fill_pads(double* D, int64_t ld, int64_t nrows, int64_t ncols, int64_t rows_alloc, int64_t tail, bool diag, hipStream_t s);
 void nj_free(NjBuffers& b);
 int nj_expand_lower(NjBuffers& b, const double* d_packed_lower, hipStream_t s);
-int nj_init_sums(NjBuffers& b, hipStream_t s);          // U (local rows), diag, state
+int nj_init_sums(NjBuffers& b, hipStream_t s, double* local_sums = nullptr);   // U (one rank) or the own rows' sums, state
 int nj_prepare(NjBuffers& b, hipStream_t s);            // Ur, KA for n = st->n
 int nj_launch_scan(NjBuffers& b, bool probe, int64_t n, int64_t it, hipStream_t s);
 void nj_scan_config(int rg, int nt, int grid);  // tuning knobs (dpr_scan_tune)
@@ -187,6 +214,17 @@ int nj_launch_commit_extract(NjBuffers& b, int64_t n, int64_t it, hipStream_t s)
 int nj_launch_update_sharded(NjBuffers& b, int64_t n, hipStream_t s);               // world > 1
 int nj_launch_unpack_u(NjBuffers& b, hipStream_t s);                                // world > 1: gathered row sums -> U
 int nj_launch_finish(NjBuffers& b, int64_t n, int64_t it, hipStream_t s);           // materialise U[x] after the loop
+
+// njs.hip: one-exchange row-sharded loop (world > 1)
+NjsLayout njs_layout(int64_t N, int world);
+int njs_alloc_window(NjBuffers& b, hipStream_t s);
+void njs_free_window(NjBuffers& b);
+int njs_set_peers(NjBuffers& b, char* const* wins, double* const* Ds, hipStream_t s);
+int njs_launch_scan(NjBuffers& b, int64_t n, int64_t it, bool pending, hipStream_t s);
+int njs_launch_post(NjBuffers& b, int64_t n, int64_t it, bool pending, hipStream_t s);
+int njs_launch_finish(NjBuffers& b, int64_t n, int64_t it, bool pending, hipStream_t s);
+int njs_launch_barrier(NjBuffers& b, hipStream_t s);
+int njs_launch_unpack_u(NjBuffers& b, hipStream_t s);
 
 // njp.hip: exact pruned NJ (world == 1)
 int njp_build(NjBuffers& b, hipStream_t s);   // permute the tip-order matrix by ascending row sum into the pruned path's own buffer

@@ -96,66 +96,6 @@ __global__ __launch_bounds__(kThreads) void nj_prepare_kernel(const NjState* __r
 // of the 256-chunk partials left by the update kernel, is finished here by every block for itself
 // (block 0 also stores it), which saves a kernel per iteration.
 // ------------------------------------------------------------------------------------------------
-template <bool DIAG, bool NT, bool FILT>
-__device__ __forceinline__ void scan_rows(const double* __restrict__ D, int64_t ld,
-                                          const double* __restrict__ Ur,
-                                          const uint64_t* __restrict__ KA, const uint64_t* __restrict__ KB,
-                                          int64_t a0, int64_t l0,
-                                          int nrows, int64_t c0, int64_t xprev, double urx, double ub0,
-                                          double ub1, uint64_t ka0, uint64_t ka1, uint64_t kb0,
-                                          uint64_t kb1, double& bq, uint64_t& bk)
-{
-    const int tid = threadIdx.x;
-    const int64_t b0 = c0 + 2 * tid, b1 = b0 + 1;
-    const v2d* base = reinterpret_cast<const v2d*>(D + l0 * ld + c0) + tid;
-    const int64_t ld2 = ld >> 1;
-    for (int r = 0; r < nrows; r += 8) {
-        v2d v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int rr = min(r + u, nrows - 1);  // clamp: duplicates are idempotent
-            const v2d* p = base + (int64_t)rr * ld2;
-            if (DIAG) p = (b0 < a0 + rr) ? p : p - tid;  // masked lanes share one line
-            v[u] = NT ? __builtin_nontemporal_load(p) : *p;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int64_t a = a0 + min(r + u, nrows - 1);
-            const double ua = (a == xprev) ? urx : Ur[a];
-            const uint64_t kaa = KA[a];
-            const uint64_t kba = KB ? KB[a] : nj_key_b(a);   // position-space matrices carry their slot keys
-            double d0 = v[u].x, d1 = v[u].y;
-            if (DIAG) {
-                d0 = (b0 < a) ? d0 : __builtin_nan("");
-                d1 = (b1 < a) ? d1 : __builtin_nan("");
-            }
-            const double q0a = (d0 - ua) - ub0, q0b = (d0 - ub0) - ua;
-            const double q1a = (d1 - ua) - ub1, q1b = (d1 - ub1) - ua;
-            if (FILT) {
-                // a lane's best improves O(log m) times over m elements: test once per row, update rarely
-                const double m = fmin(fmin(q0a, q0b), fmin(q1a, q1b));  // fmin drops NaN (masked / invalid)
-                if (!(m <= bq)) continue;
-            }
-            best_update(bq, bk, q0a, kaa | kb0);
-            best_update(bq, bk, q0b, ka0 | kba);
-            best_update(bq, bk, q1a, kaa | kb1);
-            best_update(bq, bk, q1b, ka1 | kba);
-        }
-    }
-}
-
-// strip geometry for active size n on (rank, world): first owned local row that can see column c0,
-// rounded down to a row group, and the number of row groups below it
-template <int RG>
-__device__ __forceinline__ void strip_geom(int64_t cb, int64_t n, int64_t nloc, int rank, int world,
-                                           int64_t& lstart, int& cnt)
-{
-    const int64_t c0 = cb * kTileCols;
-    const int64_t lmin = shard_rows(min(c0 + 1, n), rank, world);  // owned rows with global index <= c0
-    lstart = lmin / RG * RG;
-    cnt = nloc > lstart ? (int)((nloc - lstart + RG - 1) / RG) : 0;
-}
-
 template <bool PROBE, int RG, bool NT, bool FILT>
 __global__ __launch_bounds__(kThreads) void nj_scan_kernel(
     const double* __restrict__ D, int64_t ld, const NjState* __restrict__ st, double* __restrict__ U_w,
@@ -247,9 +187,9 @@ __global__ __launch_bounds__(kThreads) void nj_scan_kernel(
             const int nrows = (int)min((int64_t)RG, nloc - l0);
             const int64_t a0 = shard_global_row(l0, rank, world);
             if (a0 < c0 + kTileCols)
-                scan_rows<true, NT, FILT>(D, ld, Ur, KA, KB, a0, l0, nrows, c0, xprev, urx, ub0, ub1, ka0, ka1, kb0, kb1, bq, bk);
+                scan_rows<true, NT, FILT, false>(D, ld, Ur, KA, KB, a0, l0, nrows, c0, xprev, urx, ub0, ub1, ka0, ka1, kb0, kb1, bq, bk, RowView());
             else
-                scan_rows<false, NT, FILT>(D, ld, Ur, KA, KB, a0, l0, nrows, c0, xprev, urx, ub0, ub1, ka0, ka1, kb0, kb1, bq, bk);
+                scan_rows<false, NT, FILT, false>(D, ld, Ur, KA, KB, a0, l0, nrows, c0, xprev, urx, ub0, ub1, ka0, ka1, kb0, kb1, bq, bk, RowView());
             ++g;
         }
     }
@@ -592,11 +532,14 @@ static int nj_alloc_inner(NjBuffers& b, int64_t N, int rank, int world, hipStrea
 void nj_free(NjBuffers& b)
 {
     njp_free(b.pr);
+    njs_free_window(b);
     void* ptrs[] = { b.D, b.U, b.Ur, b.KA, b.partials, b.recs, b.xpart, b.gath, b.slice, b.st,
                      b.log_x, b.log_y, b.log_bx, b.log_by };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    const NjPeer keep = b.peer;      // (the plan and the poll limit are settings of the context, not of an allocation)
     b = NjBuffers();
+    b.peer.plan = keep.plan; b.peer.poll_ticks = keep.poll_ticks;
 }
 
 int nj_expand_lower(NjBuffers& b, const double* d_packed_lower, hipStream_t s)
@@ -610,13 +553,14 @@ int nj_expand_lower(NjBuffers& b, const double* d_packed_lower, hipStream_t s)
     return DPR_OK;
 }
 
-int nj_init_sums(NjBuffers& b, hipStream_t s)
+int nj_init_sums(NjBuffers& b, hipStream_t s, double* local_sums)
 {
     if (b.rows_local > 0) {
         const unsigned grid = (unsigned)(b.rows_local < 4096 ? b.rows_local : 4096);
-        // world > 1: sums of the owned rows go to slice[0..rows_local) and are all-gathered by the caller
+        // local_sums != null (several ranks): the sums of the own rows go to local_sums[0 .. rows_local) and are gathered
+        // by the caller
         hipLaunchKernelGGL(nj_row_sums_kernel, dim3(grid), dim3(kThreads), 0, s, b.D, b.ld, b.N,
-                           b.rows_local, b.rank, b.world, b.world > 1 ? b.slice : b.U, b.world > 1 ? 1 : 0);
+                           b.rows_local, b.rank, b.world, local_sums ? local_sums : b.U, local_sums ? 1 : 0);
         DPR_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(nj_state_init_kernel, dim3(1), dim3(1), 0, s, b.st, b.N);

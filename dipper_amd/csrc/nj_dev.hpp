@@ -183,6 +183,83 @@ __device__ __forceinline__ void reduce_records(const NjRecord* __restrict__ recs
     __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Q-argmin scan of a group of rows over one 512-column strip (shared by nj.hip and njs.hip; see the scan kernels)
+// ------------------------------------------------------------------------------------------------
+// Row view of the one-exchange sharded path (njs.hip): the rows of the two slots rewritten by the previous merge live in
+// row buffers (xrow, yrow) until the next update flushes them into the matrix; VIEW = false: every row is in D.
+struct RowView {
+    int64_t xp = -1, yp = -1;                 // slots whose authoritative row is xrow / yrow (-1: none)
+    const double* xrow = nullptr;
+    const double* yrow = nullptr;
+};
+
+template <bool DIAG, bool NT, bool FILT, bool VIEW>
+__device__ __forceinline__ void scan_rows(const double* __restrict__ D, int64_t ld,
+                                          const double* __restrict__ Ur,
+                                          const uint64_t* __restrict__ KA, const uint64_t* __restrict__ KB,
+                                          int64_t a0, int64_t l0,
+                                          int nrows, int64_t c0, int64_t xprev, double urx, double ub0,
+                                          double ub1, uint64_t ka0, uint64_t ka1, uint64_t kb0,
+                                          uint64_t kb1, double& bq, uint64_t& bk, const RowView rv)
+{
+    const int tid = threadIdx.x;
+    const int64_t b0 = c0 + 2 * tid, b1 = b0 + 1;
+    const v2d* base = reinterpret_cast<const v2d*>(D + l0 * ld + c0) + tid;
+    const int64_t ld2 = ld >> 1;
+    for (int r = 0; r < nrows; r += 8) {
+        v2d v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int rr = min(r + u, nrows - 1);  // clamp: duplicates are idempotent
+            const v2d* p = base + (int64_t)rr * ld2;
+            if (VIEW) {      // (wave-uniform: the row index does not depend on the lane)
+                const int64_t ar = a0 + rr;
+                if (ar == rv.xp) p = reinterpret_cast<const v2d*>(rv.xrow + c0) + tid;
+                else if (ar == rv.yp) p = reinterpret_cast<const v2d*>(rv.yrow + c0) + tid;
+            }
+            if (DIAG) p = (b0 < a0 + rr) ? p : p - tid;  // masked lanes share one line
+            v[u] = NT ? __builtin_nontemporal_load(p) : *p;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t a = a0 + min(r + u, nrows - 1);
+            const double ua = (a == xprev) ? urx : Ur[a];
+            const uint64_t kaa = KA[a];
+            const uint64_t kba = KB ? KB[a] : nj_key_b(a);   // position-space matrices carry their slot keys
+            double d0 = v[u].x, d1 = v[u].y;
+            if (DIAG) {
+                d0 = (b0 < a) ? d0 : __builtin_nan("");
+                d1 = (b1 < a) ? d1 : __builtin_nan("");
+            }
+            const double q0a = (d0 - ua) - ub0, q0b = (d0 - ub0) - ua;
+            const double q1a = (d1 - ua) - ub1, q1b = (d1 - ub1) - ua;
+            if (FILT) {
+                // a lane's best improves O(log m) times over m elements: test once per row, update rarely
+                const double m = fmin(fmin(q0a, q0b), fmin(q1a, q1b));  // fmin drops NaN (masked / invalid)
+                if (!(m <= bq)) continue;
+            }
+            best_update(bq, bk, q0a, kaa | kb0);
+            best_update(bq, bk, q0b, ka0 | kba);
+            best_update(bq, bk, q1a, kaa | kb1);
+            best_update(bq, bk, q1b, ka1 | kba);
+        }
+    }
+}
+
+// strip geometry for active size n on (rank, world): first owned local row that can see column c0,
+// rounded down to a row group, and the number of row groups below it
+template <int RG>
+__device__ __forceinline__ void strip_geom(int64_t cb, int64_t n, int64_t nloc, int rank, int world,
+                                           int64_t& lstart, int& cnt)
+{
+    const int64_t c0 = cb * kTileCols;
+    const int64_t lmin = shard_rows(min(c0 + 1, n), rank, world);  // owned rows with global index <= c0
+    lstart = lmin / RG * RG;
+    cnt = nloc > lstart ? (int)((nloc - lstart + RG - 1) / RG) : 0;
+}
+
+
 // host part of the reference's loop (src/neighborJoining.cu:219-239): branch lengths, merge log, state
 __device__ __forceinline__ void commit_merge(NjState* __restrict__ st, const double* __restrict__ U,
                                              int64_t n, int64_t it, int64_t x, int64_t y, double d, double q,

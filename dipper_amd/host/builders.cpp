@@ -22,12 +22,16 @@ struct AsyncDeviceContext::Impl {
     std::condition_variable cv;
     size_t reserve_n = 0;
     bool closing = false;
+    double create_ms = 0;
 };
+double AsyncDeviceContext::createMs() const { return impl->create_ms; }
 AsyncDeviceContext::AsyncDeviceContext(int device) : impl(new Impl)
 {
     Impl* q = impl;
     impl->th = std::thread([q, device] {
+        const auto tc0 = std::chrono::steady_clock::now();
         q->dev = new DeviceContext(device);
+        q->create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
         // (helper of the helper: the one-time graph set-up of the HIP runtime runs beside the allocation below, the uploads
         //  and the distance kernels; joined when the context goes away)
         q->warm = std::thread([ctx = q->dev->ctx] { (void)dpr_warm_graphs(ctx); });

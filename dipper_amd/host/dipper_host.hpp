@@ -83,6 +83,8 @@ struct AsyncDeviceContext {
     DeviceContext& get();
     // ask the helper thread to allocate the NJ matrices for n tips (dpr_reserve_nj) once the context exists; returns at once
     void reserveNJ(size_t n);
+    // milliseconds dpr_create took on the helper thread (HIP runtime start-up + code object load); valid after get()
+    double createMs() const;
 private:
     struct Impl;
     Impl* impl;

@@ -360,6 +360,9 @@ int main(int argc, char** argv)
             else mashDeviceArrays.allocateDeviceArrays(dev, seqs, ids);
         }
         std::cerr << "Input in: " << ms_since(inputStart) << " ms\n";
+        // (not a line of the reference: how much of the input phase was the HIP runtime coming up on the helper thread --
+        //  the input phase ends when BOTH the parsed input and the device context are there)
+        std::cerr << "Device ready in: " << (long long)adev.createMs() << " ms\n";
         auto createArrayStart = std::chrono::high_resolution_clock::now();
         if (!aligned) {
             // the reference sketches only in placement/DC mode (-i r + NJ reads unsketched

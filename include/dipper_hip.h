@@ -92,6 +92,15 @@ int dpr_comm_unique_id(void *out128);
 int dpr_comm_init(dpr_ctx *ctx, int rank, int world, const void *id128);
 /* 1-rank RCCL round trip on this context's GPU (plumbing check on a single-GPU box) */
 int dpr_comm_selftest(dpr_ctx *ctx);
+/* Ranks without RCCL: processes whose devices (or ONE shared device -- which RCCL refuses) can map each other's memory.
+ * The row-sharded NJ then runs its mailbox plan.  dpr_peer_export allocates this rank's NJ buffers + peer window for
+ * n_tips and writes a 192-byte description; the launcher hands every rank all descriptions in rank order
+ * (dpr_peer_attach) before dpr_dist_matrix.  With RCCL (dpr_comm_init) the library exchanges them itself. */
+int dpr_comm_init_local(dpr_ctx *ctx, int rank, int world);
+int dpr_peer_export(dpr_ctx *ctx, int64_t n_tips, void *out192);
+int dpr_peer_attach(dpr_ctx *ctx, const void *all192);
+/* rank and rank count AS THE COMMUNICATOR REPORTS THEM (ncclCommUserRank / ncclCommCount); 0 / 1 without one */
+int dpr_comm_info(dpr_ctx *ctx, int *rank, int *nranks);
 
 /* ---- inputs ----------------------------------------------------------------------------------*/
 /* MSADeviceArrays::allocateDeviceArrays (src/MSA.cu:14-72): packed4 is [n][ceil(L/16)] words as
@@ -165,6 +174,16 @@ int dpr_nj_is_unit_sharded(dpr_ctx *ctx);
  * dpr_dist_matrix. */
 int dpr_ctx_set_nj_mode(dpr_ctx *ctx, int mode);
 int dpr_ctx_set_nj_multi_plan(dpr_ctx *ctx, int plan);
+/* Exchange plan of the ROW-SHARDED streaming NJ loop (several ranks, DPR_NJ_MODE=stream / dpr_ctx_set_nj_mode(ctx, 0);
+ * replaces src/neighborJoining.cu:211-243): 0 = legacy (4 launches + 2 all-gathers per iteration), 1 = peer (default:
+ * 2 launches + ONE all-gather of the rank records; rows x / y are pulled from their owners' memory), 2 = mailbox
+ * (2 launches, no collective: the records go straight into every rank's mailbox); -1 = DPR_NJ_EXCHANGE / default.
+ * A plan that cannot be set up on every rank falls back to 0 on all ranks together (note in dpr_get_nj_exchange_info). */
+int dpr_ctx_set_nj_exchange(dpr_ctx *ctx, int plan);
+/* what the last dpr_dist_matrix set up (*active_plan, note) and what the last dpr_nj_run enqueued on this rank */
+int dpr_get_nj_exchange_info(dpr_ctx *ctx, int *active_plan, int64_t *launches, int64_t *collectives, char *note, int cap);
+/* bound of one mailbox / barrier poll in ms (default 2000): a rank whose record does not arrive ends the run with DPR_ERR_COMM */
+int dpr_ctx_set_poll_limit_ms(dpr_ctx *ctx, int ms);
 int dpr_ctx_set_nj_virtual_shards(dpr_ctx *ctx, int w);
 /* Measurement aid of the pruned NJ loop (bench.py's `timed_kernels` record): stride > 0 makes the following dpr_nj_run
  * calls enqueue their iterations eagerly (no hipGraph replay) with HIP events on the library's stream around the launches

@@ -1,0 +1,75 @@
+"""The row-sharded NJ loop across PROCESSES on one GPU: every rank is its own process with its own HIP context, the
+other ranks' matrix rows and windows are mapped through hipIpc handles, records travel through the mailboxes and rows
+x / y are pulled from their owner's memory -- the same code path as one process per GPU over xGMI, minus the link.
+(RCCL cannot be used here: it refuses two ranks on one device.)  Merge logs must equal the oracle's on every rank."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import _util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_ranks(tmp_path, world, n, seed, source="matrix", timeout=240):
+    procs = []
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for r in range(world):
+        procs.append(subprocess.Popen([sys.executable, "-m", "tests._njs_worker", str(r), str(world), str(n), str(seed),
+                                       str(tmp_path / ("r%d.npz" % r)), source], cwd=ROOT, env=env, stdin=subprocess.PIPE,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    try:
+        blobs = [p.stdout.readline().strip() for p in procs]
+        assert all(len(b) == 384 for b in blobs), [p.stderr.read()[-2000:] for p, b in zip(procs, blobs) if len(b) != 384]
+        for p in procs:
+            p.stdin.write("\n".join(blobs) + "\n")
+            p.stdin.flush()
+        outs = [p.communicate(timeout=timeout) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and "done" in so, se[-3000:]
+    return [np.load(tmp_path / ("r%d.npz" % r)) for r in range(world)]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,n", [(2, 300), (3, 777), (4, 130)])
+def test_process_ranks_on_one_gpu_match_oracle(tmp_path, orc, world, n):
+    seed = 100 * world + n
+    res = _run_ranks(tmp_path, world, n, seed)
+    D = _util.random_additive_matrix(np.random.default_rng(seed), n, zero_frac=0.3)
+    ref = orc.nj_run(np.tril(D, -1))
+    for r, got in enumerate(res):
+        assert str(got["plan"]) == "mailbox" and int(got["collectives"]) == 0
+        assert int(got["iters"]) == n - 2
+        for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
+            assert np.array_equal(got[key], ref[key]), (r, key)
+        assert float(got["last_d"]) == ref["last_d"]
+
+
+@pytest.mark.timeout(600)
+def test_process_ranks_msa_source(tmp_path):
+    """aligned input: every rank computes the distance rows it owns; all ranks end with the single-GPU merge log"""
+    import dipper_amd
+    from dipper_amd import capi
+    world, n, seed = 2, 500, 42
+    res = _run_ranks(tmp_path, world, n, seed, source="msa")
+    seqs = _util.synth_alignment(np.random.default_rng(seed), n, 800, mean_bl=5e-3, lo=1e-4, hi=5e-2)
+    one = dipper_amd.Dipper(0)
+    try:
+        one.set_nj_mode(0)
+        one.set_msa(capi.pack4_many(seqs), 800)
+        one.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+        ref = one.nj_run()
+    finally:
+        one.close()
+    for got in res:
+        for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
+            assert np.array_equal(got[key], ref[key]), key
+        assert float(got["last_d"]) == ref["last_d"]

@@ -9,17 +9,25 @@ from tests import _util
 pytestmark = pytest.mark.gpu
 
 
+PLANS = {"legacy": 0, "peer": 1, "mailbox": 2}
+
+
+@pytest.mark.parametrize("plan", ["legacy", "peer", "mailbox"])
 @pytest.mark.parametrize("world", [2, 3, 8])
 @pytest.mark.parametrize("n", [5, 64, 130, 700])
-def test_virtual_ranks_match_oracle(orc, world, n):
+def test_virtual_ranks_match_oracle(orc, world, n, plan):
+    """every exchange plan of the row-sharded loop (njs.hip: one exchange + two launches per iteration with the rows of
+    the merged pair pulled through row views; nj.hip: round 2's two-exchange loop) gives the oracle's merge log"""
     import dipper_amd
     from dipper_amd import capi
     rng = np.random.default_rng(n * 10 + world)
     D = _util.random_additive_matrix(rng, n, zero_frac=0.3)
     d = dipper_amd.Dipper(0, virtual_world=world)
     try:
+        d.set_nj_exchange(PLANS[plan])
         d.set_matrix_full(D)
         d.dist_matrix(capi.SRC_MATRIX)
+        assert d.nj_exchange_info()["plan"] == plan
         Dsym = np.tril(D, -1) + np.tril(D, -1).T
         assert np.array_equal(d.matrix(), Dsym)
         U = orc.row_sums(np.ascontiguousarray(Dsym))
@@ -33,8 +41,51 @@ def test_virtual_ranks_match_oracle(orc, world, n):
         for k in ("merge_x", "merge_y", "bl_x", "bl_y"):
             assert np.array_equal(res[k], ref[k]), k
         assert res["last_d"] == ref["last_d"]
+        info = d.nj_exchange_info()
+        per_it = 4 if plan == "legacy" else 2
+        assert info["launches"] == per_it * (n - 2)
+        # the matrix the hooks see after the run is consistent again (row buffers flushed): D[1][0] is the last distance
+        if n > 2:
+            assert d.matrix_row(1)[0] == ref["last_d"]
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("plan", ["peer", "mailbox"])
+def test_virtual_ranks_interrupted_runs_and_ties(orc, plan):
+    """resumed runs (dpr_nj_run with max_iters: the row buffers are flushed at the end of every call and the next call
+    starts without pending rows) and tie-heavy input, where the new node is merged again at once -- the case in which a
+    pulled row comes from a row buffer instead of the matrix"""
+    import dipper_amd
+    from dipper_amd import capi
+    rng = np.random.default_rng(5)
+    n = 400
+    D = rng.integers(1, 4, size=(n, n)).astype(np.float64)
+    D = np.tril(D, -1) + np.tril(D, -1).T
+    ref = orc.nj_run(np.tril(D, -1))
+    for world in (2, 5):
+        d = dipper_amd.Dipper(0, virtual_world=world)
+        try:
+            d.set_nj_exchange(PLANS[plan])
+            d.set_matrix_full(D)
+            d.dist_matrix(capi.SRC_MATRIX)
+            got = {k: [] for k in ("merge_x", "merge_y", "bl_x", "bl_y")}
+            done = 0
+            for chunk in (1, 2, 7, 1, 100, 3, 10 ** 6):
+                res = d.nj_run(max_iters=chunk)
+                k = res["iters"]
+                for key in got:
+                    got[key].append(res[key][:k])
+                done += k
+                if done < n - 2:      # between the calls the matrix in memory is the oracle's
+                    cur = orc.nj_run(np.tril(D, -1), max_iters=done)
+                    assert np.array_equal(d.row_sums()[:n - done], cur["U"][:n - done])
+            assert done == n - 2
+            for key in got:
+                assert np.array_equal(np.concatenate(got[key]), ref[key]), key
+            assert res["last_d"] == ref["last_d"]
+        finally:
+            d.close()
 
 
 def test_virtual_ranks_msa(orc):
