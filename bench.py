@@ -8,9 +8,16 @@ parse, pack, H2D, all-pairs JC69 distances, all N-2 NJ iterations, Newick write)
 is BASELINE.json's metric measured over exactly K such steps.  The hot path alone (packed tips resident in HBM
 -> distances -> NJ merge log, in process through the C ABI) is timed over the same K/W next to it (`hot_path`).
 Run as `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it under
-torch.distributed.run (one rank per GPU, RCCL): a 30k-tip tree is ~15-20 us of dependent latency per NJ iteration,
-which sharding only lengthens, so the ranks build independent trees (replicas, `scaling: weak`); the sharded NJ
-plan is measured where it can win, at 100 000 tips (`sharded_100k`).
+torch.distributed.run (one rank per GPU, RCCL).  At 30 000 tips the default NJ (exact pruned scan) is ~16 us of
+dependent latency per iteration, which no exchange can shorten, so the headline steps are replicas (`scaling: weak`);
+north_star's own partitioning -- the matrix row-sharded over the ranks, one full Q scan per iteration -- is measured
+next to it for every exchange plan of the library (`nj_scaling`), and the other sizes in `sharded_100k`.
+
+Made for a first contact with several GPUs that cannot be rehearsed: every synthetic input is generated ONCE (rank 0,
+native generator tools/bin/gen_synth, all host threads) into a shared directory and mapped by the ranks; every
+child process and CPU leg gets host_cores() // ranks threads; optional legs are dropped against one global deadline
+(`{"skipped": "budget"}`, exit code still 0); a hung collective is ended by one watchdog that prints the record and
+exits non-zero; every multi-rank leg reports the rank count RCCL itself reports.
 """
 import argparse
 import hashlib
@@ -23,6 +30,8 @@ import tempfile
 import threading
 import time
 
+T_START = time.monotonic()
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -32,14 +41,20 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 UNIT_BYTES = 16 * 512 * 8      # one unit of the pruned scan: 16 rows x 512 columns of fp64
 EXE = os.path.join(ROOT, "dipper_amd", "bin", "dipper")
+GEN = os.path.join(ROOT, "tools", "bin", "gen_synth")
+NRF = os.path.join(ROOT, "tools", "bin", "nrf")
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def elapsed():
+    return time.monotonic() - T_START
+
+
 def host_cores():
-    """Threads the CPU baselines may use: the smallest of os.cpu_count(), the affinity mask and the cgroup CPU
+    """Threads this process may use: the smallest of os.cpu_count(), the affinity mask and the cgroup CPU
     quota (a GPU box exposes 256 logical CPUs but grants 16; oversubscribed OpenMP teams run many times slower)."""
     c = os.cpu_count() or 1
     try:
@@ -55,12 +70,20 @@ def host_cores():
     return max(1, c)
 
 
-def make_input(n, L, seed):
-    """Seeded stand-in for `iqtree2 --alisim` (scripts/alisim.sh:14): Yule-Harding tree, JC69,
-    branch lengths exponential(2e-5) clipped to [2e-6, 2e-4], no indels (aligned input)."""
-    from tests import _util
-    rng = np.random.default_rng(seed)
-    return _util.synth_alignment(rng, n, L, mean_bl=2e-5, lo=2e-6, hi=2e-4)
+class Budget:
+    """One global deadline (seconds since process start).  Optional legs ask before they start."""
+
+    def __init__(self, deadline_s):
+        self.deadline = float(deadline_s)
+
+    def left(self):
+        return self.deadline - elapsed()
+
+    def allows(self, need_s):
+        return self.left() > need_s
+
+    def skip(self, need_s):
+        return {"skipped": "budget", "needed_s": need_s, "left_s": round(self.left(), 1)}
 
 
 def stats_ms(xs):
@@ -86,13 +109,84 @@ def pmc_traffic(n, world):
 
 def merge_digest(res):
     h = hashlib.sha256()
+    k = int(res.get("iters", len(res["merge_x"])))
     for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
-        h.update(np.ascontiguousarray(res[key]).tobytes())
+        h.update(np.ascontiguousarray(res[key][:k]).tobytes())
     return h.hexdigest()[:16]
 
 
 def same_log(a, b):
     return bool(all(np.array_equal(a[k], b[k]) for k in ("merge_x", "merge_y", "bl_x", "bl_y")) and a["last_d"] == b["last_d"])
+
+
+def nrf_of(true_tree, newick_text_or_path, tmp, tag):
+    """normalised RF against the generating tree (the reference authors' accuracy measure, scripts/nrf.sh:26,36-60)"""
+    path = newick_text_or_path
+    if not os.path.exists(str(path)):
+        path = os.path.join(tmp, "nrf_%s.nwk" % tag)
+        with open(path, "w") as f:
+            f.write(newick_text_or_path)
+    r = subprocess.run([NRF, true_tree, path], capture_output=True, text=True)
+    if r.returncode != 0:
+        return {"error": r.stderr[-200:]}
+    d = json.loads(r.stdout)
+    return {"nrf": d["nrf"], "rf": d["rf"], "splits_true": d["splits_a"], "splits_inferred": d["splits_b"]}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# inputs: generated once per job by rank 0 into a shared directory, mapped by every rank
+# ---------------------------------------------------------------------------------------------------------
+class Stage:
+    def __init__(self, rank, world, dist):
+        self.rank, self.world, self.dist = rank, world, dist
+        path = [None]
+        if rank == 0:
+            base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (4 << 30) else tempfile.gettempdir()
+            path[0] = tempfile.mkdtemp(prefix="dipper_bench_", dir=base)
+        if dist is not None:
+            dist.broadcast_object_list(path, src=0)
+        self.dir = path[0]
+        self.times = {}
+
+    def sync(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def gen(self, tag, tips, sites, seed, mean, lo, hi, fasta=False, reads=False, shuffle=None):
+        """returns the paths of input `tag`; rank 0 runs the generator (all host threads: the other ranks wait)"""
+        base = os.path.join(self.dir, tag)
+        p = {"tips": tips, "sites": sites, "tree": base + ".nwk", "fasta": base + ".fa" if fasta else None,
+             "packed4": None if reads else base + ".p4", "packed2": base if reads else None, "order": base + ".ord" if shuffle is not None else None}
+        if self.rank == 0 and not os.path.exists(p["tree"]):
+            t0 = time.perf_counter()
+            cmd = [GEN, "--tips", str(tips), "--sites", str(sites), "--seed", str(seed), "--mean-bl", repr(mean), "--lo", repr(lo), "--hi", repr(hi),
+                   "--tree", p["tree"], "--threads", str(host_cores())]
+            if fasta:
+                cmd += ["--fasta", p["fasta"]]
+            if reads:
+                cmd += ["--indel", "0.03,0.09", "--packed2", p["packed2"]]
+            else:
+                cmd += ["--packed4", p["packed4"]]
+            if shuffle is not None:
+                cmd += ["--shuffle", str(shuffle), "--order", p["order"]]
+            subprocess.run(cmd, check=True)
+            self.times[tag] = time.perf_counter() - t0
+            log(f"[bench] input {tag}: {tips} x {sites} generated in {self.times[tag]:.1f} s")
+        self.sync()
+        return p
+
+    @staticmethod
+    def packed4(p):
+        return np.memmap(p["packed4"], dtype=np.uint64, mode="r", shape=(p["tips"], (p["sites"] + 15) // 16))
+
+    @staticmethod
+    def reads(p):
+        return (np.fromfile(p["packed2"] + ".flat", dtype=np.uint64), np.fromfile(p["packed2"] + ".off", dtype=np.uint64),
+                np.fromfile(p["packed2"] + ".len", dtype=np.uint64))
+
+    def cleanup(self):
+        if self.rank == 0 and self.dir:
+            shutil.rmtree(self.dir, ignore_errors=True)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -217,22 +311,31 @@ def rapidnj_probe(dip, n, cores, tmp, budget_s=30.0):
 
 
 # ---------------------------------------------------------------------------------------------------------
-def cli_step(fa, out, device):
+def cli_step(fa, out, device, threads):
+    env = dict(os.environ, DPR_HOST_THREADS=str(threads))
     t0 = time.perf_counter()
     r = subprocess.run([EXE, "-i", "m", "-I", fa, "-O", out, "-m", "2", "-d", "2", "--device", str(device)],
-                       capture_output=True, text=True)
+                       capture_output=True, text=True, env=env)
     dt = time.perf_counter() - t0
     if r.returncode != 0:
         raise RuntimeError("dipper failed: " + r.stderr[-400:])
     phases = {}
-    for line in r.stderr.splitlines():          # the CLI's own progress lines (the reference prints the same ones)
-        for key, tag in (("input", "Input in:"), ("tree", "Tree Created in:")):
+    for line in r.stderr.splitlines():          # the CLI's own progress lines (the reference prints the first and the last one too)
+        for key, tag in (("input", "Input in:"), ("tree", "Tree Created in:"), ("device_ready", "Device ready in:")):
             if line.startswith(tag):
                 try:
                     phases[key] = float(line.split(":")[1].split()[0])
                 except Exception:
                     pass
     return dt, phases
+
+
+def join_comm(dip, rank, world, dist):
+    """the library's own RCCL communicator on `dip`; returns the rank count RCCL reports"""
+    uid = [dip.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    dip.comm_init(rank, world, uid[0])
+    return dip.comm_info()[1]
 
 
 def main():
@@ -244,17 +347,22 @@ def main():
     ap.add_argument("--sites", type=int, default=10000)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--probe-reps", type=int, default=20)
+    ap.add_argument("--deadline-s", type=float, default=float(os.environ.get("DPR_BENCH_DEADLINE_S", "500")),
+                    help="optional legs are skipped when they would not finish this many seconds after process start "
+                         "(the driver allows 600 s); a watchdog ends the run 60 s later, non-zero")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cli", action="store_true",
                     help="skip the command-line steps: `value` is then the in-process hot path (used when profiling the kernels)")
     ap.add_argument("--no-parity", action="store_true", help="skip the untimed self-check of the timed result")
-    ap.add_argument("--no-sharded", action="store_true", help="several GPUs: skip the 100 000-tip unit-sharded sub-record")
-    ap.add_argument("--no-stream-leg", action="store_true", help="skip the row-sharded streaming-NJ sub-record")
+    ap.add_argument("--no-sharded", action="store_true", help="several GPUs: skip the 100 000-tip sub-record")
+    ap.add_argument("--no-stream-leg", action="store_true", help="skip the row-sharded streaming-NJ sub-record (nj_scaling)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="one GPU: skip the single runs of the other BASELINE sizes (NJ at 100 000 tips, placement of 100 000 unaligned tips, "
                          "divide-and-conquer of 1 000 000 tips)")
     ap.add_argument("--stream-iters", type=int, default=256)
-    ap.add_argument("--dc-tips", type=int, default=1000000, help="several GPUs: size of the divide-and-conquer sub-record")
+    ap.add_argument("--exchanges", default=os.environ.get("DPR_BENCH_EXCHANGES", "legacy,peer,mailbox"),
+                    help="exchange plans of the row-sharded NJ loop to time on several GPUs, in this order")
+    ap.add_argument("--dc-tips", type=int, default=1000000, help="size of the divide-and-conquer sub-record")
     ap.add_argument("--sharded-tips", type=int, default=100000)
     ap.add_argument("--sharded-sites", type=int, default=10000)
     ap.add_argument("--probe-only", action="store_true",
@@ -271,8 +379,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if world != args.gpus:
         log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE")
+    threads = max(1, host_cores() // max(1, local_world))      # host threads of THIS rank (CLI readers, CPU legs)
+    os.environ["DPR_HOST_THREADS"] = str(threads)
+    budget = Budget(args.deadline_s)
 
     import torch
     import dipper_amd
@@ -292,23 +404,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    n, L = args.tips, args.sites
-    t0 = time.perf_counter()
-    seqs = make_input(n, L, args.seed)
-    packed = capi.pack4_many(seqs)
-    log(f"[bench r{rank}] synthetic input {n} x {L} generated+packed in {time.perf_counter()-t0:.1f}s")
-    names = ["T%d" % (i + 1) for i in range(n)]
+    out = {}
+    stage = Stage(rank, world, dist)
 
+    # ONE watchdog for the whole run: a hung collective (or anything else) must not outlive the driver's limit -- the
+    # record so far is printed and the process ends NON-ZERO, which makes the launcher tear the job down
+    def give_up():
+        out["watchdog"] = "no result %d s after start: record printed by the watchdog, exit code 3" % int(elapsed())
+        if rank == 0:
+            os.write(json_fd, (json.dumps(out, default=str) + "\n").encode())
+        stage.cleanup()
+        os._exit(3)
+
+    dog = threading.Timer(max(30.0, args.deadline_s + 60.0 - elapsed()), give_up)
+    dog.daemon = True
+    dog.start()
+
+    n, L = args.tips, args.sites
     want_cli = not args.no_cli and not args.probe_only and os.path.exists(EXE)
+    inp = stage.gen("main", n, L, args.seed, 2e-5, 2e-6, 2e-4, fasta=want_cli)
+    packed = Stage.packed4(inp)
+    names = ["T%d" % (i + 1) for i in range(n)]
     tmp = tempfile.mkdtemp(prefix="dipper_bench_r%d_" % rank)
-    fa, nwk = os.path.join(tmp, "in.fa"), os.path.join(tmp, "out.nwk")
-    if want_cli:
-        _util.write_fasta(fa, names, seqs, width=0)
-    del seqs
+    fa, nwk = inp["fasta"], os.path.join(tmp, "out.nwk")
     if args.probe_only:
         args.steps = args.warmup = 0
 
-    out = {}
     try:
         # =====================================================================================================
         # A. BASELINE.json's metric: FASTA -> Newick, the whole `dipper` command, K timed steps after W warm-ups
@@ -316,25 +437,31 @@ def main():
         cli = None
         if want_cli:
             for _ in range(args.warmup):
-                cli_step(fa, nwk, local_rank)
+                cli_step(fa, nwk, local_rank, threads)
             barrier()
             t0 = time.perf_counter()
-            walls, inputs, trees = [], [], []
+            walls, inputs, trees, readies = [], [], [], []
             for _ in range(args.steps):
-                dt, ph = cli_step(fa, nwk, local_rank)
+                dt, ph = cli_step(fa, nwk, local_rank, threads)
                 walls.append(dt * 1e3)
                 inputs.append(ph.get("input", float("nan")))
                 trees.append(ph.get("tree", float("nan")))
+                readies.append(ph.get("device_ready", float("nan")))
             barrier()
             dt_cli = time.perf_counter() - t0
             if dist is not None:
                 t = torch.tensor([dt_cli], dtype=torch.float64, device="cuda")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt_cli = float(t.item())
+            others = [w - i - t for w, i, t in zip(walls, inputs, trees)]
             cli = {"metric": "tips/sec FASTA -> Newick, whole CLI run (process start, FASTA parse, pack, H2D, JC69 distances, NJ, Newick write)",
                    "command": "dipper -i m -I in.fa -O out.nwk -m 2 -d 2 --device <local rank>",
-                   "steps": args.steps, "warmup": args.warmup,
+                   "steps": args.steps, "warmup": args.warmup, "host_threads_per_rank": threads,
                    "wall_ms": stats_ms(walls), "input_ms": stats_ms(inputs), "tree_ms": stats_ms(trees),
+                   "other_ms": stats_ms(others), "hip_startup_ms": stats_ms(readies),
+                   "note": "wall = input + tree + other; input ends when BOTH the parsed FASTA and the device context are there, "
+                           "hip_startup = dpr_create on the helper thread (runtime start-up + code object load), other = process "
+                           "start + Newick write + exit",
                    "tips_per_s_median": n / (float(np.median(walls)) * 1e-3) if walls else None,
                    "fasta_bytes": os.path.getsize(fa), "newick_bytes": os.path.getsize(nwk) if os.path.exists(nwk) else None}
             log(f"[bench r{rank}] CLI steps: {cli['wall_ms']}")
@@ -344,34 +471,6 @@ def main():
         # =====================================================================================================
         dip = dipper_amd.Dipper(local_rank)
         dip.set_nj_multi_plan(2)        # timed steps: every rank builds its own tree (no collective at 30k tips)
-        comm_note = None
-        have_comm = False
-        if world > 1:
-            # the library's own RCCL communicator (used by the sharded 100k leg); if any rank cannot create it the
-            # bench line says so
-            ok, err = 1, ""
-            try:
-                uid = [dip.comm_unique_id() if rank == 0 else None]
-            except Exception as e:
-                uid, ok, err = [None], 0, repr(e)
-            dist.broadcast_object_list(uid, src=0)
-            if ok and uid[0] is not None:
-                try:
-                    dip.comm_init(rank, world, uid[0])
-                except Exception as e:
-                    ok, err = 0, repr(e)
-            else:
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                comm_note = "the library's RCCL communicator could not be created on every rank (%s)" % (err or "another rank failed")
-                log(f"[bench r{rank}] {comm_note}")
-                dip.close()
-                dip = dipper_amd.Dipper(local_rank)
-                dip.set_nj_multi_plan(2)
-            else:
-                have_comm = True
         dip.set_msa(packed, L)          # H2D + bit-plane conversion: inputs now resident in HBM
         if rank == 0:
             log(f"[bench] device: {dip.device_name()}")
@@ -441,7 +540,7 @@ def main():
             rec.update({k: v for k, v in kt.items() if k != "kernels_per_iteration"})
             if kt.get("scan_us_avg"):
                 # an event pair with nothing in between costs ~5 us on this stream: subtract it (the rocprofv3 averages of
-                # the same kernels, profiles/r2/, are the reference these net figures have to agree with)
+                # the same kernels, profiles/, are the reference these net figures have to agree with)
                 ev = kt.get("kernel_us_avg", {}).get("(empty event pair)", 0.0)
                 net = {k: max(v - ev, 0.0) for k, v in kt.get("kernel_us_avg", {}).items() if not k.startswith("(")}
                 rec["kernel_us_net_of_event_overhead"] = net
@@ -481,11 +580,11 @@ def main():
                 orc = _orc.load()
                 m = min(n, 1500)
                 chk = dipper_amd.Dipper(local_rank)
-                chk.set_msa(packed[:m], L)
+                chk.set_msa(np.ascontiguousarray(packed[:m]), L)
                 chk.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
                 Dm = chk.matrix()
                 got = chk.nj_run()
-                want = orc.nj_run(np.tril(Dm, -1), threads=host_cores())
+                want = orc.nj_run(np.tril(Dm, -1), threads=threads)
                 parity["oracle_prefix_equal"] = same_log(want, got)
                 parity["oracle_prefix_tips"] = m
                 Dref = orc.msa_dist_lower(np.ascontiguousarray(packed[:m]), L, 2)
@@ -500,11 +599,14 @@ def main():
                     # (3) the Newick text the CLI writes for the unshuffled input (--seed -1; the timed runs shuffle the input
                     # order like the reference) == the Newick assembled from the in-process merge log
                     r = subprocess.run([EXE, "-i", "m", "-I", fa, "-O", nwk, "-m", "2", "-d", "2", "--device", str(local_rank),
-                                        "--seed", "-1"], capture_output=True, text=True)
+                                        "--seed", "-1"], capture_output=True, text=True, env=dict(os.environ, DPR_HOST_THREADS=str(threads)))
                     txt = open(nwk).read()
                     mine = _util.newick_from_merges(names, last_res["merge_x"], last_res["merge_y"], last_res["bl_x"],
                                                     last_res["bl_y"], last_res["last_d"])
                     parity["cli_newick_equals_merge_log"] = bool(r.returncode == 0 and txt.strip() == mine.strip())
+                    # (4) the reference authors' accuracy measure: normalised RF of the tree the CLI wrote against the tree the
+                    # input was generated from (near-clonal data: most true branches carry no substitution at all)
+                    parity["nrf_vs_generating_tree"] = nrf_of(inp["tree"], nwk, tmp, "main")
                 except Exception as e:
                     parity["cli_newick_equals_merge_log"] = None
                     parity["cli_error"] = repr(e)
@@ -534,7 +636,7 @@ def main():
 
         primary = cli is not None
         ms_per_step = (dt_cli / max(args.steps, 1) * 1e3) if primary else ms_hp
-        out = {
+        out.update({
             "metric": "tips/sec FASTA->Newick at N=%d" % n if primary else hot["metric"],
             "value": world * n / (ms_per_step * 1e-3) if args.steps else None,
             "unit": "tips/s",
@@ -544,14 +646,14 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic (seeded Yule-Harding tree, JC69, L=%d, no indels; own generator: no alisim in the image)" % L,
+            "data": "synthetic (seeded Yule-Harding tree, JC69, L=%d, no indels; own native generator tools/gen_synth.cpp: no alisim in the image)" % L,
             "config": {"workload": "configs[1]: %d aligned tips, -d 2 (JC69), conventional NJ (-m 2)" % n,
                        "tips": n, "sites": L,
                        "step": "one whole `dipper` command per rank (FASTA -> Newick)" if primary else "in-process hot path (HBM-resident input -> merge log)",
                        "parallelism": "1 GPU" if world == 1 else
                                       ("replicas%d: every rank builds its own %d-tip tree on its own GPU, no collective "
-                                       "(an NJ iteration at this size is dependent latency, not bandwidth); value = %d x tips / step time. "
-                                       "The sharded NJ plan is measured at %d tips: sharded_100k" % (world, n, world, args.sharded_tips))},
+                                       "(an iteration of the default pruned NJ at this size is dependent latency, not bandwidth); value = %d x tips / step time. "
+                                       "The row-sharded NJ loop is measured in nj_scaling, the 100 000-tip plans in sharded_100k" % (world, n, world))},
             "step_ms": cli["wall_ms"] if primary else hot["step_ms"],
             "e2e_cli": cli,
             "hot_path": hot,
@@ -559,9 +661,9 @@ def main():
                          "nj": hot["phase_ms"]["nj"]["mean"] if hot["phase_ms"]["nj"] else None},
             "roofline": roofline,
             "parity_check": parity,
-        }
-        if comm_note:
-            out["comm_note"] = comm_note
+            "input_staging": {"generated_once_by": "rank 0 (tools/bin/gen_synth, %d host threads)" % host_cores(), "seconds": dict(stage.times),
+                              "directory": os.path.dirname(stage.dir), "host_threads_per_rank": threads},
+        })
         if mgpu_check is not None:
             out["multi_gpu_check"] = mgpu_check
 
@@ -569,10 +671,13 @@ def main():
         # E. CPU baselines (rank 0, one GPU): bounded samples on the GPU's own matrix
         # =====================================================================================================
         if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.probe_only:
-            cores = host_cores()
-            for key, fn, kw in (("cpu_baseline", cpu_baseline, {"cores": cores}),
-                                ("cpu_baseline_1core", cpu_baseline, {"cores": 1, "budget_s": 10.0}),
-                                ("cpu_baseline_rapidnj", cpu_baseline_rapidnj, {"cores": cores})):
+            cores = threads
+            for key, fn, kw, need in (("cpu_baseline", cpu_baseline, {"cores": cores}, 35),
+                                      ("cpu_baseline_1core", cpu_baseline, {"cores": 1, "budget_s": 10.0}, 25),
+                                      ("cpu_baseline_rapidnj", cpu_baseline_rapidnj, {"cores": cores}, 45)):
+                if not budget.allows(need):
+                    out[key] = dict(budget.skip(need), value=None, unit="tips/s", cores=kw.get("cores"), kind="port", sample="skipped")
+                    continue
                 try:
                     out[key] = fn(dip, n, **kw)
                 except Exception as e:  # a baseline must never take the bench line down
@@ -586,27 +691,18 @@ def main():
 
         # =====================================================================================================
         # E2. north_star's partitioning on this run's GPUs: matrix row-sharded over the ranks, one full Q scan per
-        #     iteration (streaming NJ), the block winners exchanged with RCCL -- NJ iterations/s and aggregate GB/s
+        #     iteration (streaming NJ) -- NJ iterations/s per exchange plan, next to one GPU alone and to the default plan
         # =====================================================================================================
-        if not args.probe_only and not args.no_stream_leg and (world == 1 or have_comm):
-            dog = None
-            if world > 1:
-                def give_up_stream():
-                    out["streaming_row_sharded"] = {"error": "no result within the time limit"}
-                    if rank == 0:
-                        os.write(json_fd, (json.dumps(out) + "\n").encode())
-                    os._exit(3)
-                dog = threading.Timer(300.0, give_up_stream)
-                dog.daemon = True
-                dog.start()
-            try:
-                out["streaming_row_sharded"] = streaming_leg(rank, world, local_rank, dist, torch, barrier, packed, n, L,
-                                                             args.stream_iters, solo_denominator=True)
-            except Exception as e:
-                out["streaming_row_sharded"] = {"error": repr(e)}
-            finally:
-                if dog is not None:
-                    dog.cancel()
+        if not args.probe_only and not args.no_stream_leg:
+            need = 25 + 12 * (len(args.exchanges.split(",")) if world > 1 else 0)
+            if budget.allows(need):
+                try:
+                    out["nj_scaling"] = nj_scaling(args, rank, world, local_rank, dist, torch, barrier, packed, n, L, args.stream_iters,
+                                                   hot.get("nj_iterations_per_s"))
+                except Exception as e:
+                    out["nj_scaling"] = {"error": repr(e)}
+            else:
+                out["nj_scaling"] = budget.skip(need)
 
         # =====================================================================================================
         # E3. north_star's other sizes, one run each on this GPU (rank 0 of a single-GPU run; no warm-up: first-touch of
@@ -615,34 +711,28 @@ def main():
         # =====================================================================================================
         if world == 1 and rank == 0 and not args.no_other_configs and not args.probe_only:
             try:
-                out["other_configs"] = other_configs(args, local_rank)
+                out["other_configs"] = other_configs(args, local_rank, stage, budget, tmp)
             except Exception as e:
                 out["other_configs"] = {"error": repr(e)}
 
         # =====================================================================================================
-        # F. several GPUs: the unit-sharded NJ plan where it can pay -- N = 100 000 (80 GB matrix per rank), one step
+        # F. several GPUs: 100 000 tips (80 GB matrix): unit-sharded pruned plan, row-sharded streaming plans, DC of 1 M tips
         # =====================================================================================================
-        run_sharded = (world > 1 and have_comm) or force_check
+        run_sharded = world > 1 or force_check
         if run_sharded and not args.no_sharded and not args.probe_only:
-            # last of all, with the record complete, under a watchdog: a hung RCCL path must not take the line down --
-            # the record is printed and the process ends NON-ZERO so that the launcher tears the job down
-            def give_up():
-                out["sharded_100k"] = {"error": "no result within the time limit"}
-                if rank == 0:
-                    os.write(json_fd, (json.dumps(out) + "\n").encode())
-                os._exit(3)
-
-            dog = threading.Timer(900.0, give_up)
-            dog.daemon = True
-            dog.start()
             try:
-                out["sharded_100k"] = sharded_leg(args, rank, world, local_rank, dist, torch, barrier, force_check)
+                out["sharded_100k"] = sharded_leg(args, rank, world, local_rank, dist, torch, barrier, stage, budget)
             except Exception as e:
                 out["sharded_100k"] = {"error": repr(e)}
-            finally:
-                dog.cancel()
+        out["bench_wall_s"] = round(elapsed(), 1)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+        try:
+            stage.sync()          # (still under the watchdog: a rank that died leaves the others here)
+        except Exception:
+            pass
+        dog.cancel()
+        stage.cleanup()
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
@@ -650,15 +740,19 @@ def main():
         dist.destroy_process_group()
 
 
-def other_configs(args, local_rank):
+def other_configs(args, local_rank, stage, budget, tmp):
     """BASELINE.json configs[2] / configs[3] and north_star's N = 100 000 NJ, one run each (synthetic inputs as everywhere:
-    seeded Yule tree, JC69; unaligned reads with seeded indels).  Every record: tips, seconds of the timed part, tips/s."""
+    seeded Yule tree, JC69; unaligned reads with seeded indels).  Every record: tips, seconds of the timed part, tips/s, and
+    the normalised RF of the result against the generating tree."""
     import dipper_amd
     from dipper_amd import capi
     from tests import _util
     rec = {}
 
-    def leg(name, fn):
+    def leg(name, fn, need):
+        if not budget.allows(need):
+            rec[name] = budget.skip(need)
+            return
         t0 = time.perf_counter()
         try:
             rec[name] = fn()
@@ -669,9 +763,8 @@ def other_configs(args, local_rank):
 
     def nj_100k():
         n, L = 100000, 10000
-        seqs = _util.synth_alignment(np.random.default_rng(args.seed + 7), n, L, mean_bl=2e-5, lo=2e-6, hi=2e-4)
-        packed = capi.pack4_many(seqs)
-        del seqs
+        inp = stage.gen("nj100k", n, L, args.seed + 7, 2e-5, 2e-6, 2e-4)
+        packed = Stage.packed4(inp)
         d = dipper_amd.Dipper(local_rank)
         try:
             d.reserve_nj(n)          # the two 80 GB buffers (the CLI allocates them on its device thread while it parses the input)
@@ -682,165 +775,207 @@ def other_configs(args, local_rank):
             wall = time.perf_counter() - t0
             dist_ms, nj_ms = d.timing()
             sc, _ = d.prune_stats()
-            return {"workload": "conventional NJ, %d aligned tips x %d sites, JC69 (80 GB matrix on one GPU), packed tips in HBM -> merge log" % (n, L),
-                    "tips": n, "seconds": wall, "tips_per_s": n / wall, "dist_ms": dist_ms, "nj_ms": nj_ms,
-                    "nj_iterations_per_s": res["iters"] / (nj_ms * 1e-3), "units_scanned": sc, "merge_log_digest": merge_digest(res)}
+            out = {"workload": "conventional NJ, %d aligned tips x %d sites, JC69 (80 GB matrix on one GPU), packed tips in HBM -> merge log" % (n, L),
+                   "tips": n, "seconds": wall, "tips_per_s": n / wall, "dist_ms": dist_ms, "nj_ms": nj_ms,
+                   "nj_iterations_per_s": res["iters"] / (nj_ms * 1e-3), "units_scanned": sc, "merge_log_digest": merge_digest(res)}
         finally:
             d.close()
+        if budget.allows(20):
+            names = ["T%d" % (i + 1) for i in range(n)]
+            out["nrf_vs_generating_tree"] = nrf_of(inp["tree"], _util.newick_from_merges(names, res["merge_x"], res["merge_y"], res["bl_x"],
+                                                                                       res["bl_y"], res["last_d"], fmt=repr), tmp, "nj100k")
+        return out
 
     def place_100k_unaligned():
         n, L = 100000, 3000
-        seqs = _util.synth_reads(np.random.default_rng(args.seed + 8), n, L, mean_bl=2e-5, lo=2e-6, hi=2e-4)
+        inp = stage.gen("reads100k", n, L, args.seed + 8, 2e-5, 2e-6, 2e-4, reads=True)
+        flat, off, lens = Stage.reads(inp)
         d = dipper_amd.Dipper(local_rank)
         try:
-            d.set_reads(seqs)
+            d.set_reads_packed(flat, off, lens)
             t0 = time.perf_counter()
             d.sketch(15, 1000, fetch=False)
             t1 = time.perf_counter()
             st = d.place_run(capi.SRC_MASH, n, k=15)
             wall = time.perf_counter() - t0
             dist_ms, tree_ms = d.place_timing()
-            return {"workload": "configs[2]: %d unaligned tips x ~%d bases, Mash sketches (k 15, 1000 values) + k-closest placement, reads in HBM -> tree arrays" % (n, L),
-                    "tips": n, "seconds": wall, "tips_per_s": n / wall, "sketch_s": t1 - t0, "distance_part_ms": dist_ms, "tree_part_ms": tree_ms,
-                    "trace_digest": hashlib.sha256(np.ascontiguousarray(st["trace"]).tobytes()).hexdigest()[:16]}
+            overlapped, busy_ms = d.place_overlap()
+            out = {"workload": "configs[2]: %d unaligned tips x ~%d bases, Mash sketches (k 15, 1000 values) + k-closest placement, reads in HBM -> tree arrays" % (n, L),
+                   "tips": n, "seconds": wall, "tips_per_s": n / wall, "sketch_s": t1 - t0,
+                   "distance_wait_ms": dist_ms, "tree_part_ms": tree_ms, "distance_batches_overlapped": overlapped, "distance_busy_ms": busy_ms,
+                   "trace_digest": hashlib.sha256(np.ascontiguousarray(st["trace"]).tobytes()).hexdigest()[:16]}
         finally:
             d.close()
+        if budget.allows(20):
+            names = ["T%d" % (i + 1) for i in range(n)]
+            out["nrf_vs_generating_tree"] = nrf_of(inp["tree"], _util.newick_from_placement(names, st["head"], st["e"], st["nxt"], st["len"], n, fmt=repr), tmp, "place100k")
+        return out
 
     def dc_1m():
-        n, L = 1000000, 400
-        seqs = _util.synth_alignment(np.random.default_rng(args.seed + 9), n, L, mean_bl=2e-3, lo=2e-4, hi=2e-2)
-        order = np.random.default_rng(7).permutation(n)      # the CLI shuffles its input (src/tree_generation.cu:341-344)
-        packed = capi.pack4_many([seqs[i] for i in order])
-        del seqs
+        n, L = args.dc_tips, 400
+        inp = stage.gen("dc1m", n, L, args.seed + 9, 2e-3, 2e-4, 2e-2, shuffle=7)   # the CLI shuffles its input (src/tree_generation.cu:341-344)
+        packed = Stage.packed4(inp)
         d = dipper_amd.Dipper(local_rank)
         try:
             d.set_msa(packed, L)
             t0 = time.perf_counter()
             st = d.dc_run(capi.SRC_MSA, n, n // 20, dist_type=capi.DIST_JC)
             wall = time.perf_counter() - t0
-            return {"workload": "configs[3] on one GPU: divide-and-conquer, %d aligned tips x %d sites, backbone %d, packed tips in HBM -> tree arrays" % (n, L, n // 20),
-                    "tips": n, "seconds": wall, "tips_per_s": n / wall,
-                    "device_s": (st["stats"]["backbone_ms"] + st["stats"]["assign_ms"] + st["stats"]["cluster_ms"]) * 1e-3,
-                    "note": "seconds includes copying the tree arrays and closest lists (0.5 GB) back to the host",
-                    "stats": {k: (float(v) if isinstance(v, float) else int(v)) for k, v in st["stats"].items()}}
+            out = {"workload": "configs[3] on one GPU: divide-and-conquer, %d aligned tips x %d sites, backbone %d, packed tips in HBM -> tree arrays" % (n, L, n // 20),
+                   "tips": n, "seconds": wall, "tips_per_s": n / wall,
+                   "device_s": (st["stats"]["backbone_ms"] + st["stats"]["assign_ms"] + st["stats"]["cluster_ms"]) * 1e-3,
+                   "note": "seconds includes copying the tree arrays and closest lists (0.5 GB) back to the host",
+                   "stats": {k: (float(v) if isinstance(v, float) else int(v)) for k, v in st["stats"].items()}}
         finally:
             d.close()
+        if budget.allows(60):
+            order = np.fromfile(inp["order"], dtype=np.int32)
+            names = ["T%d" % (k + 1) for k in order]
+            out["nrf_vs_generating_tree"] = nrf_of(inp["tree"], _util.newick_from_placement(names, st["head"], st["e"], st["nxt"], st["len"], n, fmt=repr), tmp, "dc1m")
+        return out
 
-    leg("nj_100k", nj_100k)
-    leg("place_100k_unaligned", place_100k_unaligned)
-    leg("dc_1m", dc_1m)
+    leg("nj_100k", nj_100k, 30)
+    leg("place_100k_unaligned", place_100k_unaligned, 25)
+    leg("dc_1m", dc_1m, 30)
     return rec
 
 
-def streaming_leg(rank, world, local_rank, dist, torch, barrier, packed, n, L, iters, solo_denominator=False):
-    """The streaming NJ (the reference's algorithm: one full Q-argmin scan per iteration, src/neighborJoining.cu:211-243)
-    with the matrix row-sharded block-cyclically over the ranks: `iters` iterations on the given input.  Every rank
-    scans its rows; the per-rank winners and the two merged rows travel in RCCL all-gathers (ctx.hip, exchange()).
-    With one rank this is the single-GPU streaming loop -- the denominator of the scaling figure; with
-    solo_denominator rank 0 also runs that loop alone so that the record carries its own 1-GPU figure."""
-    import dipper_amd
+PLAN_ID = {"legacy": 0, "peer": 1, "mailbox": 2}
+
+
+def streaming_run(d, torch, dist, barrier, packed, n, L, iters, timed_world):
+    """`iters` iterations of the streaming NJ on an already configured context; returns (result, record)"""
     from dipper_amd import capi
+    d.set_nj_mode(0)
+    d.set_msa(packed, L)
+    d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+    d.nj_run(max_iters=8)           # warm-up: first launches / communicator channels
+    d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+    if timed_world > 1:
+        barrier()
+    else:
+        torch.cuda.synchronize()
+    ts = time.perf_counter()
+    res = d.nj_run(max_iters=iters)
+    if timed_world > 1:
+        barrier()
+    wall = time.perf_counter() - ts
+    _, loop_ms = d.timing()
+    if timed_world > 1:
+        t = torch.tensor([wall, loop_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, loop_ms = float(t[0].item()), float(t[1].item())
+    k = max(int(res["iters"]), 1)
+    # algorithmic bytes of iteration k: strict lower triangle of the n-k active rows, 8 bytes per element, read
+    # once, + the row sums -- what the single-GPU roofline record counts (4 n^2 + 4 n)
+    by = sum(4.0 * (n - j) * (n - j) + 4.0 * (n - j) for j in range(k))
+    info = d.nj_exchange_info()
+    rec = {"iterations": int(res["iters"]), "wall_s": wall, "loop_ms_hip_events": loop_ms,
+           "us_per_iteration": loop_ms * 1e3 / k, "nj_iterations_per_s": k / (loop_ms * 1e-3),
+           "aggregate_GBps": by / (loop_ms * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBS * timed_world,
+           "frac_of_aggregate_peak": by / (loop_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * timed_world),
+           "launches_per_iteration": info["launches"] / k if timed_world > 1 else 2.0,
+           "collectives_per_iteration": info["collectives"] / k if timed_world > 1 else 0.0,
+           "merge_log_digest": merge_digest(res)}
+    if timed_world > 1:
+        rec["exchange_plan_active"] = info["plan"]
+        if info["note"]:
+            rec["exchange_note"] = info["note"]
+    return res, rec
+
+
+def nj_scaling(args, rank, world, local_rank, dist, torch, barrier, packed, n, L, iters, solo_pruned_its):
+    """NJ-iteration throughput side by side (north_star's scaling metric): the default plan on one GPU (exact pruned scan),
+    the streaming loop (the reference's algorithm, src/neighborJoining.cu:211-243: one full Q scan per iteration) on one GPU
+    alone, and row-sharded over this run's GPUs with every exchange plan of the library.  Every multi-rank record carries the
+    rank count RCCL reports, launches and collectives per iteration as counted by the library, and digests checked against
+    rank 0's single-GPU loop."""
+    import dipper_amd
     iters = max(1, min(iters, n - 2))
-
-    def run(d, timed_world):
-        d.set_nj_mode(0)
-        d.set_msa(packed, L)
-        d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
-        d.nj_run(max_iters=8)           # warm-up: first launches / communicator channels
-        d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
-        if timed_world > 1:
-            barrier()
-        else:
-            torch.cuda.synchronize()
-        ts = time.perf_counter()
-        res = d.nj_run(max_iters=iters)
-        if timed_world > 1:
-            barrier()
-        wall = time.perf_counter() - ts
-        if timed_world > 1:
-            t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            wall = float(t.item())
-        # algorithmic bytes of iteration k: strict lower triangle of the n-k active rows, 8 bytes per element, read
-        # once, + the row sums -- what the single-GPU roofline record counts (4 n^2 + 4 n)
-        by = sum(4.0 * (n - k) * (n - k) + 4.0 * (n - k) for k in range(res["iters"]))
-        return res, {"iterations": int(res["iters"]), "wall_s": wall,
-                     "us_per_iteration": wall / max(res["iters"], 1) * 1e6,
-                     "nj_iterations_per_s": res["iters"] / wall,
-                     "aggregate_GBps": by / wall / 1e9, "peak_GBps": HBM_PEAK_GBS * timed_world,
-                     "frac_of_aggregate_peak": by / wall / 1e9 / (HBM_PEAK_GBS * timed_world),
-                     "merge_log_digest": merge_digest(res)}
-
-    rec = {"tips": n, "sites": L, "world": world,
-           "layout": "rows block-cyclic over the ranks (dpr_shard_owner), one full Q scan per iteration, all-gather of "
-                     "the per-rank winners + of the two merged rows; nj_run(max_iters) -- the first iterations of the run"}
-    d = dipper_amd.Dipper(local_rank)
-    try:
-        if world > 1:
-            uid = [d.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            d.comm_init(rank, world, uid[0])
-        res, r = run(d, world)
-        rec.update(r)
-    finally:
-        d.close()
-    if world > 1:
-        digest = int(merge_digest(res)[:14], 16)
-        mine = torch.tensor([digest], dtype=torch.int64, device="cuda")
-        allh = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allh, mine)
-        rec["ranks_agree"] = bool(all(int(t.item()) == digest for t in allh))
-        if solo_denominator:
-            if rank == 0:
-                s1 = dipper_amd.Dipper(local_rank)
-                try:
-                    ref, r1 = run(s1, 1)
-                finally:
-                    s1.close()
-                rec["single_gpu"] = r1
-                rec["matches_single_gpu"] = same_log(ref, res)
-                rec["iteration_speedup_vs_single_gpu"] = r1["wall_s"] / rec["wall_s"]
-            dist.barrier()
+    rec = {"tips": n, "sites": L, "iterations_timed": iters, "world": world,
+           "layout": "rows block-cyclic over the ranks (dpr_shard_owner), one full Q scan of the own rows per iteration; "
+                     "timed part: the first iterations of the run (dpr_nj_run with max_iters), HIP events on the library's stream",
+           "default_plan_one_gpu": {"algorithm": "exact pruned scan (njp.hip)", "nj_iterations_per_s": (solo_pruned_its / world) if solo_pruned_its else None,
+                                    "note": "whole-run average of hot_path (the early iterations timed below are the largest ones)"}}
+    # one GPU alone (rank 0; the denominator of every speed-up below)
+    solo = None
+    if rank == 0:
+        s1 = dipper_amd.Dipper(local_rank)
+        try:
+            solo, r1 = streaming_run(s1, torch, dist, barrier, packed, n, L, iters, 1)
+        finally:
+            s1.close()
+        rec["streaming_one_gpu"] = r1
+    if dist is not None:
+        dist.barrier()
+    if world == 1:
+        return rec
+    rec["row_sharded"] = {}
+    for plan in [p.strip() for p in args.exchanges.split(",") if p.strip() in PLAN_ID]:
+        d = dipper_amd.Dipper(local_rank)
+        try:
+            ranks = join_comm(d, rank, world, dist)
+            d.set_nj_exchange(PLAN_ID[plan])
+            try:
+                res, r = streaming_run(d, torch, dist, barrier, packed, n, L, iters, world)
+                ok = 1
+            except Exception as e:      # e.g. DPR_ERR_COMM when a mailbox poll ran out: every rank gets it, nobody hangs
+                r, res, ok = {"error": repr(e)}, None, 0
+            r["rccl_ranks"] = ranks
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                digest = int(merge_digest(res)[:14], 16)
+                mine = torch.tensor([digest], dtype=torch.int64, device="cuda")
+                allh = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(allh, mine)
+                r["ranks_agree"] = bool(all(int(t.item()) == digest for t in allh))
+                if rank == 0 and solo is not None:
+                    r["matches_single_gpu"] = bool(all(np.array_equal(res[k][:res["iters"]], solo[k][:solo["iters"]]) for k in ("merge_x", "merge_y", "bl_x", "bl_y")))
+                    r["iteration_speedup_vs_one_gpu"] = rec["streaming_one_gpu"]["us_per_iteration"] / r["us_per_iteration"]
+            elif "error" not in r:
+                r["error"] = "another rank failed"
+            rec["row_sharded"][plan] = r
+        finally:
+            d.close()
+        if rank == 0:
+            log(f"[bench] nj_scaling.row_sharded.{plan}: {rec['row_sharded'][plan]}")
     return rec
 
 
-def sharded_leg(args, rank, world, local_rank, dist, torch, barrier, rehearsal):
-    """N = 100 000 x 2 000 sites, one NJ run with the unit-sharded plan over the library's RCCL communicator (matrix
-    replicated, unit tests and scans owned by rank, one all-gather of block records per iteration), next to the
-    single-GPU plan on rank 0's GPU alone.  Reports NJ iterations/s for both and whether the merge logs agree."""
+def sharded_leg(args, rank, world, local_rank, dist, torch, barrier, stage, budget):
+    """100 000 tips x 10 000 sites (80 GB matrix): the unit-sharded pruned plan over the library's RCCL communicator (matrix
+    replicated, unit tests and scans owned by rank, one all-gather of block records per iteration) next to the single-GPU
+    plan on rank 0's GPU alone; the row-sharded streaming loop per exchange plan; divide-and-conquer of 1 000 000 tips."""
     import dipper_amd
     from dipper_amd import capi
     ns, Ls = args.sharded_tips, args.sharded_sites
-    t0 = time.perf_counter()
-    rng = np.random.default_rng(args.seed + 7)
-    from tests import _util
-    seqs = _util.synth_alignment(rng, ns, Ls, mean_bl=2e-5 * 10000 / Ls, lo=2e-6 * 10000 / Ls, hi=2e-4 * 10000 / Ls)
-    packed = capi.pack4_many(seqs)
-    del seqs
-    log(f"[bench r{rank}] sharded leg: input {ns} x {Ls} in {time.perf_counter()-t0:.1f}s")
     rec = {"tips": ns, "sites": Ls, "world": world}
+    if not budget.allows(60):
+        return dict(rec, **budget.skip(60))
+    inp = stage.gen("nj100k", ns, Ls, args.seed + 7, 2e-5 * 10000 / Ls, 2e-6 * 10000 / Ls, 2e-4 * 10000 / Ls)
+    packed = Stage.packed4(inp)
     d = dipper_amd.Dipper(local_rank)
-    if world > 1:
-        uid = [d.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        d.comm_init(rank, world, uid[0])
-    d.set_nj_multi_plan(1)
-    d.set_msa(packed, Ls)
-    barrier()
-    ts = time.perf_counter()
-    d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
-    res = d.nj_run()
-    barrier()
-    wall = time.perf_counter() - ts
-    dist_ms, nj_ms = d.timing()
-    rec["unit_sharded_plan"] = {"is_unit_sharded": d.nj_is_unit_sharded(), "rccl_ranks": world, "wall_s": wall, "dist_ms": dist_ms, "nj_ms": nj_ms,
-                                "nj_iterations_per_s": (ns - 2) / (nj_ms * 1e-3), "merge_log_digest": merge_digest(res)}
     try:
-        sc, full = d.prune_stats()
-        rec["unit_sharded_plan"]["units_scanned_this_rank"] = sc
-    except Exception:
-        pass
-    d.close()
+        ranks = join_comm(d, rank, world, dist) if world > 1 else 1
+        d.set_nj_multi_plan(1)
+        d.set_msa(packed, Ls)
+        barrier()
+        ts = time.perf_counter()
+        d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+        res = d.nj_run()
+        barrier()
+        wall = time.perf_counter() - ts
+        dist_ms, nj_ms = d.timing()
+        rec["unit_sharded_plan"] = {"is_unit_sharded": d.nj_is_unit_sharded(), "rccl_ranks": ranks, "wall_s": wall, "dist_ms": dist_ms, "nj_ms": nj_ms,
+                                    "nj_iterations_per_s": (ns - 2) / (nj_ms * 1e-3), "merge_log_digest": merge_digest(res)}
+        try:
+            sc, full = d.prune_stats()
+            rec["unit_sharded_plan"]["units_scanned_this_rank"] = sc
+        except Exception:
+            pass
+    finally:
+        d.close()
     digest = int(merge_digest(res)[:14], 16)
     if dist is not None:
         mine = torch.tensor([digest], dtype=torch.int64, device="cuda")
@@ -849,50 +984,55 @@ def sharded_leg(args, rank, world, local_rank, dist, torch, barrier, rehearsal):
         rec["ranks_agree"] = bool(all(int(t.item()) == digest for t in allh))
     if rank == 0:       # the single-GPU plan on one GPU, for the 1-GPU denominator (the other ranks wait)
         s = dipper_amd.Dipper(local_rank)
-        s.set_nj_multi_plan(2)
-        s.set_msa(packed, Ls)
-        ts = time.perf_counter()
-        s.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
-        ref = s.nj_run()
-        wall1 = time.perf_counter() - ts
-        d1, n1 = s.timing()
-        rec["single_gpu_plan"] = {"wall_s": wall1, "dist_ms": d1, "nj_ms": n1, "nj_iterations_per_s": (ns - 2) / (n1 * 1e-3)}
-        rec["matches_single_gpu"] = same_log(ref, res)
-        rec["nj_speedup_vs_single_gpu"] = n1 / nj_ms
-        s.close()
+        try:
+            s.set_nj_multi_plan(2)
+            s.set_msa(packed, Ls)
+            ts = time.perf_counter()
+            s.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+            ref = s.nj_run()
+            wall1 = time.perf_counter() - ts
+            d1, n1 = s.timing()
+            rec["single_gpu_plan"] = {"wall_s": wall1, "dist_ms": d1, "nj_ms": n1, "nj_iterations_per_s": (ns - 2) / (n1 * 1e-3)}
+            rec["matches_single_gpu"] = same_log(ref, res)
+            rec["nj_speedup_vs_single_gpu"] = n1 / nj_ms
+        finally:
+            s.close()
     if dist is not None:
         dist.barrier()
-    # the row-sharded streaming plan at this size too (scan = 40 GB per iteration: the size where the exchange is small
-    # beside the scan)
-    try:
-        rec["streaming_row_sharded"] = streaming_leg(rank, world, local_rank, dist if world > 1 else None, torch, barrier, packed, ns, Ls,
-                                                     max(8, args.stream_iters // 4), solo_denominator=True)
-    except Exception as e:
-        rec["streaming_row_sharded"] = {"error": repr(e)}
+    # the row-sharded streaming loop at this size too (a scan is 40 GB per iteration: the exchange is small beside it)
+    need = 30 + 15 * len(args.exchanges.split(","))
+    if budget.allows(need):
+        try:
+            rec["nj_scaling"] = nj_scaling(args, rank, world, local_rank, dist if world > 1 else None, torch, barrier, packed, ns, Ls,
+                                           max(8, args.stream_iters // 4), None)
+        except Exception as e:
+            rec["nj_scaling"] = {"error": repr(e)}
+    else:
+        rec["nj_scaling"] = budget.skip(need)
     del packed
     # configs[3]: divide-and-conquer of 1 000 000 tips over the ranks (query shares of the assignment and the clusters dealt
     # to the ranks, backbone distance rows sharded; dpr_dc_run after dpr_comm_init), with rank 0's single-GPU run beside it
-    try:
-        rec["dc_1m"] = dc_leg(args, rank, world, local_rank, dist if world > 1 else None, torch, barrier)
-    except Exception as e:
-        rec["dc_1m"] = {"error": repr(e)}
+    if budget.allows(45):
+        try:
+            rec["dc_1m"] = dc_leg(args, rank, world, local_rank, dist if world > 1 else None, torch, barrier, stage)
+        except Exception as e:
+            rec["dc_1m"] = {"error": repr(e)}
+    else:
+        rec["dc_1m"] = budget.skip(45)
     return rec
 
 
-def dc_leg(args, rank, world, local_rank, dist, torch, barrier):
+def dc_leg(args, rank, world, local_rank, dist, torch, barrier, stage):
     import dipper_amd
     from dipper_amd import capi
-    from tests import _util
     n, L = args.dc_tips, 400
-    seqs = _util.synth_alignment(np.random.default_rng(args.seed + 9), n, L, mean_bl=2e-3, lo=2e-4, hi=2e-2)
-    order = np.random.default_rng(7).permutation(n)      # the CLI shuffles its input (src/tree_generation.cu:341-344)
-    packed = capi.pack4_many([seqs[i] for i in order])
-    del seqs
+    inp = stage.gen("dc1m", n, L, args.seed + 9, 2e-3, 2e-4, 2e-2, shuffle=7)      # the CLI shuffles its input (src/tree_generation.cu:341-344)
+    packed = Stage.packed4(inp)
     rec = {"tips": n, "sites": L, "backbone": n // 20, "world": world}
 
-    def run(d):
+    def run(d, multi):
         d.set_msa(packed, L)
-        if world > 1 and d is not solo:
+        if multi:
             barrier()
         t0 = time.perf_counter()
         st = d.dc_run(capi.SRC_MSA, n, n // 20, dist_type=capi.DIST_JC)
@@ -902,14 +1042,11 @@ def dc_leg(args, rank, world, local_rank, dist, torch, barrier):
             h.update(np.ascontiguousarray(st[key]).tobytes())
         return wall, st["stats"], h.hexdigest()[:16]
 
-    solo = None
     d = dipper_amd.Dipper(local_rank)
     try:
         if world > 1:
-            uid = [d.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            d.comm_init(rank, world, uid[0])
-        wall, stats, digest = run(d)
+            rec["rccl_ranks"] = join_comm(d, rank, world, dist)
+        wall, stats, digest = run(d, world > 1)
     finally:
         d.close()
     if world > 1:
@@ -926,7 +1063,7 @@ def dc_leg(args, rank, world, local_rank, dist, torch, barrier):
         if rank == 0:
             solo = dipper_amd.Dipper(local_rank)
             try:
-                w1, st1, dg1 = run(solo)
+                w1, st1, dg1 = run(solo, False)
             finally:
                 solo.close()
             rec["single_gpu"] = {"seconds": w1, "tips_per_s": n / w1}

@@ -64,6 +64,8 @@ def load_library():
     L.dpr_ctx_set_nj_exchange.argtypes = [C.c_void_p, C.c_int]
     L.dpr_get_nj_exchange_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_char_p, C.c_int]
     L.dpr_ctx_set_poll_limit_ms.argtypes = [C.c_void_p, C.c_int]
+    L.dpr_ctx_set_nj_adaptive.argtypes = [C.c_void_p, C.c_int]
+    L.dpr_get_nj_adaptive_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.dpr_scan_tune.argtypes = [C.c_int, C.c_int, C.c_int]
     L.dpr_set_nj_mode.argtypes = [C.c_int]
     L.dpr_set_nj_multi_plan.argtypes = [C.c_int]
@@ -242,6 +244,16 @@ class Dipper:
         _chk(self.L, self.L.dpr_get_nj_exchange_info(self.h, C.byref(p), C.byref(nl), C.byref(nc), note, 256))
         return {"plan": {0: "legacy", 1: "peer", 2: "mailbox"}.get(p.value, str(p.value)), "launches": int(nl.value),
                 "collectives": int(nc.value), "note": note.value.decode()}
+
+    def set_nj_adaptive(self, on):
+        _chk(self.L, self.L.dpr_ctx_set_nj_adaptive(self.h, on))
+
+    def nj_adaptive_stats(self):
+        """(iterations run as streaming scans, epochs that switched) since the matrix was built"""
+        a = C.c_int64()
+        b = C.c_int64()
+        _chk(self.L, self.L.dpr_get_nj_adaptive_stats(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def set_poll_limit_ms(self, ms):
         _chk(self.L, self.L.dpr_ctx_set_poll_limit_ms(self.h, ms))

@@ -90,6 +90,7 @@ struct dpr_ctx {
     double dc_ms[3] = { 0, 0, 0 };   // backbone, cluster assignment, cluster trees
     // plan knobs of THIS context (dpr_ctx_set_*); -1 = follow the process-wide default (dpr_set_* / environment)
     int nj_mode = -1, nj_vshards = -1, nj_multi_plan = -1;
+    int nj_adaptive = -1;            // adaptive pruned / streaming plan of the single-rank NJ (-1 = DPR_NJ_ADAPTIVE, default on)
     // row-sharded streaming NJ: exchange plan of the loop (-1 = DPR_NJ_EXCHANGE, default peer; see njs.hip) and what the
     // last dpr_dist_matrix actually set up (a failed peer set-up falls back to the legacy loop and says why)
     int nj_exchange = -1;
@@ -802,7 +803,9 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
         c->nj_unit_sharded = shard;
         if (shard) { q.sh_world = c->world; q.sh_rank = c->rank; q.sh_virtual = false; q.gather = njp_gather_cb; q.gather_ctx = c; }
         else if (ctx_vshards(c) > 1) { q.sh_world = ctx_vshards(c); q.sh_rank = 0; q.sh_virtual = true; }
+        if (c->nj_adaptive >= 0) q.adaptive = c->nj_adaptive;
         if (int rc = njp_build(c->nj[0], c->stream)) return rc;
+        if (c->nj_adaptive >= 0) q.adaptive = c->nj_adaptive;      // (the explicit setting wins over the environment)
     }
     DPR_HIP(hipEventRecord(c->ev[1], c->stream));
     DPR_HIP(hipStreamSynchronize(c->stream));
@@ -937,7 +940,7 @@ int64_t dpr_nj_run(dpr_ctx* c, int64_t max_iters, int32_t* merge_x, int32_t* mer
     if (last_d && st.n == 2) {
         // D[0][1] of the final pair (src/neighborJoining.cu:245-249); row 1 lives on rank 0
         NjBuffers& b0 = c->nj[0];
-        if (b0.pr.active) {
+        if (b0.pr.in_positions()) {
             int32_t pos01[2];
             DPR_HIP(hipMemcpy(pos01, b0.pr.pos_of_slot, sizeof(pos01), hipMemcpyDeviceToHost));
             DPR_HIP(hipMemcpy(last_d, b0.pr.D + (int64_t)pos01[1] * b0.pr.ld + pos01[0], sizeof(double), hipMemcpyDeviceToHost));
@@ -969,7 +972,7 @@ int dpr_argmin_once(dpr_ctx* c, int reps, int32_t* out_i, int32_t* out_j, double
     // pruned mode: the streaming kernel runs over the position-space matrix (all P positions, dead
     // ones carry NaN row sums); it = 0 because the bounds kernel already finished U[x]
     auto probe = [&](NjBuffers& b) -> int {
-        return b.pr.active ? nj_launch_scan(b, true, b.pr.P, 0, c->stream) : nj_launch_scan(b, true, st0.n, st0.it, c->stream);
+        return b.pr.in_positions() ? nj_launch_scan(b, true, b.pr.P, 0, c->stream) : nj_launch_scan(b, true, st0.n, st0.it, c->stream);
     };
     for (auto& b : c->nj)
         if (int rc = probe(b)) return rc;  // warm
@@ -1063,6 +1066,25 @@ int dpr_set_nj_mode(int mode)
     return DPR_OK;
 }
 
+// Adaptive plan of the single-rank NJ (default on): the exact pruned scan while its bounds prune, full streaming scans for
+// the rest of an epoch once more than half of the epoch's units are listed per iteration (see dpr_internal.hpp).  The
+// merge log does not depend on it.  on = 0: pruned scans only; -1: DPR_NJ_ADAPTIVE / default.  Takes effect at the next
+// dpr_dist_matrix.
+int dpr_ctx_set_nj_adaptive(dpr_ctx* c, int on)
+{
+    if (!c || on < -1 || on > 1) { set_error("dpr_ctx_set_nj_adaptive: -1, 0 or 1"); return DPR_ERR_ARG; }
+    c->nj_adaptive = on;
+    return DPR_OK;
+}
+// iterations that ran as streaming scans and epochs that switched, since the matrix was built
+int dpr_get_nj_adaptive_stats(dpr_ctx* c, int64_t* stream_iterations, int64_t* stream_epochs)
+{
+    if (!c || !c->have_matrix || !c->nj[0].pr.active) { set_error("dpr_get_nj_adaptive_stats: pruned path not active"); return DPR_ERR_STATE; }
+    if (stream_iterations) *stream_iterations = c->nj[0].pr.stream_iterations;
+    if (stream_epochs) *stream_epochs = c->nj[0].pr.stream_epochs;
+    return DPR_OK;
+}
+
 // units scanned by the pruned path since the matrix was built, and units per full scan
 int dpr_get_prune_stats(dpr_ctx* c, uint64_t* units_scanned, uint64_t* units_per_full_scan)
 {
@@ -1135,8 +1157,8 @@ int dpr_bw_probe(dpr_ctx* c, int64_t bytes, int nt, int grid, int reps, float* o
     // the buffer the Q-argmin scans: the position-space matrix of the pruned path (whose tip-order matrix is dead
     // once the first epoch is built), else this rank's rows
     NjBuffers& b = c->nj[0];
-    const double* buf = b.pr.active ? b.pr.D : b.D;
-    const int64_t cap = b.pr.active ? b.pr.P * b.pr.ld * (int64_t)sizeof(double) : b.rows_local * b.ld * (int64_t)sizeof(double);
+    const double* buf = b.pr.in_positions() ? b.pr.D : b.D;
+    const int64_t cap = b.pr.in_positions() ? b.pr.P * b.pr.ld * (int64_t)sizeof(double) : b.rows_local * b.ld * (int64_t)sizeof(double);
     if (!buf || cap <= 0) { set_error("dpr_bw_probe: no matrix buffer"); return DPR_ERR_STATE; }
     return nj_bw_probe(buf, cap, b.xpart, bytes, nt, grid, reps, c->stream, c->ev[2], c->ev[3], out_ms);
 }
@@ -1156,7 +1178,7 @@ int dpr_get_matrix_row(dpr_ctx* c, int64_t i, double* out)
 {
     if (!c || !c->have_matrix || !out || i < 0 || i >= c->nj[0].N) { set_error("dpr_get_matrix_row: bad argument"); return DPR_ERR_ARG; }
     DPR_HIP(hipStreamSynchronize(c->stream));   // the plain copies below run on the null stream, which does not wait for c->stream
-    if (c->nj[0].pr.active) {
+    if (c->nj[0].pr.in_positions()) {
         // position space: row of slot i, columns gathered through pos_of_slot (dead slots read +inf)
         NjPruned& q = c->nj[0].pr;
         const int64_t N = c->nj[0].N;
@@ -1182,7 +1204,7 @@ int dpr_get_row_sums(dpr_ctx* c, double* out)
 {
     if (!c || !c->have_matrix || !out) { set_error("dpr_get_row_sums: bad argument"); return DPR_ERR_ARG; }
     DPR_HIP(hipStreamSynchronize(c->stream));   // the plain copies below run on the null stream, which does not wait for c->stream
-    if (c->nj[0].pr.active) {
+    if (c->nj[0].pr.in_positions()) {
         NjPruned& q = c->nj[0].pr;
         const int64_t N = c->nj[0].N;
         std::vector<int32_t> pos((size_t)N);

@@ -126,6 +126,20 @@ struct NjPruned {
     // plan of THIS context (set by njp_build; two contexts of one process may differ and run on different host threads)
     int scan_grid = 1024;             // blocks of the unit scan (256 below 50 000 tips; DPR_NJP_GRID)
     int graph_iters = 32;             // iterations per captured hipGraph (DPR_NJ_GRAPH_ITERS)
+    // Adaptive plan (single rank): the exact pruned scan only pays while its bounds prune.  The host looks at the units
+    // listed per iteration after the first graph of an epoch and then every 2 048 iterations; once more than stream_frac of
+    // the epoch's units are listed on average, the run is HANDED OVER to the streaming loop of nj.hip: the live positions
+    // are permuted back into a dense slot-space matrix (one n^2 copy) and the reference's own algorithm -- one full Q scan
+    // per iteration, last slot moved into y -- continues from the same state (same keys, same update arithmetic, so the
+    // same merge log).  Every so often (after the active size has shrunk by the epoch factor once, twice, four times, ...
+    // while the probes keep failing) a fresh pruned epoch is built from the slot-space matrix and probed again.
+    int adaptive = 1;                 // DPR_NJ_ADAPTIVE=0 / dpr_ctx_set_nj_adaptive
+    double stream_frac = 0.5;         // DPR_NJ_STREAM_FRAC (tests force the hand-over with 0)
+    bool slots_mode = false;          // the run currently lives in slot space (b.D, b.U, b.Ur, b.KA: nj.hip's loop)
+    int64_t slots_probe_n = 0;        // slots mode: build and probe a pruned epoch again once the active size is <= this
+    int probe_fail_streak = 0;
+    int64_t stream_iterations = 0, stream_epochs = 0;     // iterations run by the streaming loop / hand-overs, since the matrix was built
+    bool in_positions() const { return active && !slots_mode; }     // the matrix and the vectors of the moment are the position-space ones
     unsigned long long* dbg = nullptr;   // DPR_NJ_PHASES: [2 kernels][2048 blocks][8 stamps], then 32768 words of accumulate-mode statistics
     int64_t dbg_it = -1;
     int32_t* list = nullptr;         // units selected by the tests (sub-unit mask << 28 | strip << 18 | group)

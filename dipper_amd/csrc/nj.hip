@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kThreads) void nj_scan_kernel(
             if (pos_of_slot) {   // position space (single GPU): keys hold slots, the matrix is indexed by position
                 const int64_t pi = pos_of_slot[i], pj = pos_of_slot[j];
                 x = pi < pj ? pi : pj; y = pi < pj ? pj : pi;
-                rec.pad = (uint64_t)y | ((uint64_t)x << 32);
+                rec.pad = (uint64_t)pi | ((uint64_t)pj << 32);      // the pruned path's record format: position of key slot i | of key slot j << 32
             }
             rec.d = D[shard_local_row(y, world) * ld + x];
         }
@@ -588,11 +588,12 @@ static void scan_dispatch(NjBuffers& b, int64_t n, int64_t it, hipStream_t s)
     const size_t lds = sizeof(int32_t) * (size_t)((b.N + kTileCols - 1) / kTileCols + 2);
     // pruned mode keeps the matrix in position space with explicit slot keys (probe only)
     const NjPruned& q = b.pr;
-    const double* D = q.active ? q.D : b.D;
-    const int64_t ld = q.active ? q.ld : b.ld;
-    double *U = q.active ? q.U : b.U, *Ur = q.active ? q.Ur : b.Ur;
-    const uint64_t *KA = q.active ? q.KA : b.KA, *KB = q.active ? q.KB : nullptr;
-    const int32_t* pos = q.active ? q.pos_of_slot : nullptr;
+    const bool posn = q.in_positions();
+    const double* D = posn ? q.D : b.D;
+    const int64_t ld = posn ? q.ld : b.ld;
+    double *U = posn ? q.U : b.U, *Ur = posn ? q.Ur : b.Ur;
+    const uint64_t *KA = posn ? q.KA : b.KA, *KB = posn ? q.KB : nullptr;
+    const int32_t* pos = posn ? q.pos_of_slot : nullptr;
 #define DPR_SCAN(RG, NT, FILT)                                                                                     \
     hipLaunchKernelGGL((nj_scan_kernel<PROBE, RG, NT, FILT>), dim3(grid), dim3(kThreads), lds, s, D, ld, b.st,     \
                        U, Ur, Ur, KA, KB, pos, b.xpart, n, it, b.rank, b.world, b.partials)

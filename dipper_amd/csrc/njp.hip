@@ -911,10 +911,12 @@ static SlabPlan slab_plan(int64_t P, int64_t N, int local_ranks)
     p.total = off;
     return p;
 }
-static size_t matrix_bytes(int64_t P)
+// (the same size as NjBuffers::D for N tips, nj_alloc: the two matrix buffers of a context are interchangeable -- the
+//  hand-over to the streaming loop swaps them when the epoch of the moment lives in NjBuffers::D)
+static size_t matrix_bytes(int64_t N)
 {
-    const int64_t rows_alloc = (P + kUR - 1) / kUR * kUR + kUR;
-    return (size_t)(rows_alloc * round_up16(P) + kTileCols + 16) * sizeof(double);
+    const int64_t rows_alloc = (N + kRowBlock - 1) / kRowBlock * kRowBlock + 32;
+    return (size_t)(rows_alloc * round_up16(N) + kTileCols + 16) * sizeof(double);
 }
 
 static int njp_arena(NjPruned& q, int64_t N, hipStream_t s)
@@ -1013,6 +1015,9 @@ int njp_build(NjBuffers& b, hipStream_t s)
         const int g = e ? std::atoi(e) : (b.N < 50000 ? 256 : 1024);
         b.pr.scan_grid = g < 1 ? 1 : (g > 1024 ? 1024 : g);
     }
+    if (const char* e = std::getenv("DPR_NJ_ADAPTIVE")) b.pr.adaptive = std::atoi(e) != 0 ? 1 : 0;
+    if (const char* e = std::getenv("DPR_NJ_STREAM_FRAC")) b.pr.stream_frac = std::atof(e);
+    b.pr.stream_iterations = 0; b.pr.stream_epochs = 0;
     if (const char* e = std::getenv("DPR_NJ_GRAPH_ITERS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) b.pr.graph_iters = v; }
     if (const char* e = std::getenv("DPR_NJ_PHASES")) {
         b.pr.dbg_it = std::atoll(e);
@@ -1097,6 +1102,80 @@ static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s, bool* rebuilt)
     return DPR_OK;
 }
 
+// ---- adaptive plan: hand-over between the pruned path (position space) and nj.hip's streaming loop (slot space) ----
+__global__ __launch_bounds__(kThreads) void njp_gather_u_kernel(const double* __restrict__ Ucur, const int32_t* __restrict__ pos_of_slot,
+                                                                int64_t n, double* __restrict__ U)
+{
+    const int64_t s = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (s < n) U[s] = Ucur[pos_of_slot[s]];
+}
+
+// position space -> dense slot space (b.D, b.U, b.Ur, b.KA).  Called between iterations with the node in quarantine
+// materialised (njp_finish_kernel) and the stream idle.
+static int njp_to_slots(NjBuffers& b, hipStream_t s)
+{
+    NjPruned& q = b.pr;
+    NjState st;
+    DPR_HIP(hipMemcpy(&st, b.st, sizeof(NjState), hipMemcpyDeviceToHost));
+    const int64_t n = st.n;
+    if (st.status != 0 || n < 3) return DPR_OK;
+    if (q.graph) { (void)hipGraphExecDestroy(q.graph); q.graph = nullptr; }
+    // the slot-space matrix goes into the buffer the epoch does not live in; the streaming kernels read b.D
+    if (q.D == b.D) std::swap(b.D, q.arena_D);
+    dim3 grid((unsigned)((n + kThreads - 1) / kThreads > 64 ? 64 : (n + kThreads - 1) / kThreads), (unsigned)(n < 32768 ? n : 32768));
+    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, (const double*)q.D, q.ld, b.D, b.ld, (const int32_t*)q.pos_of_slot, n);
+    hipLaunchKernelGGL(njp_gather_u_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                       njp_current_u(q, st.it), (const int32_t*)q.pos_of_slot, n, b.U);
+    DPR_HIP(hipGetLastError());
+    if (int rc = nj_prepare(b, s)) return rc;        // Ur, KA for the active size in the state
+    q.slots_mode = true;
+    ++q.stream_epochs;
+    return DPR_OK;
+}
+
+// dense slot space -> a fresh pruned epoch over the n active slots (the counterpart of njp_build for a run in progress)
+static int njp_from_slots(NjBuffers& b, hipStream_t s)
+{
+    NjPruned& q = b.pr;
+    NjState st;
+    DPR_HIP(hipStreamSynchronize(s));
+    DPR_HIP(hipMemcpy(&st, b.st, sizeof(NjState), hipMemcpyDeviceToHost));
+    const int64_t n = st.n;
+    if (st.status != 0 || n < 3) return DPR_OK;
+    std::vector<double> hU((size_t)n);
+    DPR_HIP(hipMemcpy(hU.data(), b.U, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    std::vector<int32_t> perm((size_t)n);
+    std::iota(perm.begin(), perm.end(), 0);
+    sort_by_row_sum(perm, hU);
+    q.epoch_index = 0;                       // even: the epoch lives in arena_D (b.D holds the slot-space matrix it is built from)
+    if (int rc = njp_alloc_epoch(q, n, b.N, q.arena_D, q.arena_slab[0], s)) return rc;
+    DPR_HIP(hipMemcpyAsync(q.perm, perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
+    dim3 grid((unsigned)((n + kThreads - 1) / kThreads > 64 ? 64 : (n + kThreads - 1) / kThreads), (unsigned)(n < 32768 ? n : 32768));
+    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, (const double*)b.D, b.ld, q.D, q.ld, (const int32_t*)q.perm, n);
+    hipLaunchKernelGGL(njp_init_vectors_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                       (const double*)b.U, (const int32_t*)q.perm, (const int32_t*)nullptr, n, n, q.U + (st.it & 1) * q.vstride, q.Ur, q.KA, q.KB,
+                       q.slot_of_pos, q.pos_of_slot);
+    DPR_HIP(hipGetLastError());
+    st.pnew[0] = -1; st.pnew[1] = -1;
+    for (auto& c : st.cnt_list) c = 0ull;
+    DPR_HIP(hipMemcpyAsync(b.st, &st, sizeof(NjState), hipMemcpyHostToDevice, s));
+    DPR_HIP(hipStreamSynchronize(s));        // `st`, `perm` are host objects
+    q.slots_mode = false;
+    return DPR_OK;
+}
+
+// `todo` iterations of nj.hip's streaming loop on the slot-space matrix (two launches per iteration, a full Q scan each)
+static int njp_run_slots(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
+{
+    const int64_t n0 = b.N - it0;
+    for (int64_t k = 0; k < todo; ++k) {
+        if (int rc = nj_launch_scan(b, false, n0 - k, it0 + k, s)) return rc;
+        if (int rc = nj_launch_post(b, n0 - k, it0 + k, s)) return rc;
+    }
+    b.pr.stream_iterations += todo;
+    return nj_launch_finish(b, n0 - todo, it0 + todo, s);
+}
+
 // epoch state only: the next njp_build finds the arena in place
 void njp_reset(NjPruned& q)
 {
@@ -1105,6 +1184,7 @@ void njp_reset(NjPruned& q)
     NjPruned fresh;
     fresh.arena_D = q.arena_D; fresh.arena_slab[0] = q.arena_slab[0]; fresh.arena_slab[1] = q.arena_slab[1];
     fresh.arena_slab_bytes = q.arena_slab_bytes; fresh.arena_N = q.arena_N; fresh.arena_ranks = q.arena_ranks;
+    fresh.adaptive = q.adaptive;      // (a setting of the context)
     fresh.dbg = q.dbg;      // (debug buffer: kept for njp_phase_stamps, a few hundred KB, DPR_NJ_PHASES runs only)
     q = fresh;
 }
@@ -1295,17 +1375,33 @@ int njp_phase_stamps(unsigned long long* out)
 const double* njp_current_u(const NjPruned& q, int64_t it) { return q.U + (it & 1) * q.vstride; }
 
 // enqueue `todo` iterations starting at iteration it0, in epochs: whenever the active size has dropped to
-// pct % of the epoch's positions (and the epoch is large enough to matter) the position space is rebuilt
+// pct % of the epoch's positions (and the epoch is large enough to matter) the position space is rebuilt; with the
+// adaptive plan on, the listing rate is watched and the run handed over to the streaming loop (and back) as described in
+// dpr_internal.hpp
 int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
 {
     const char* e_min = std::getenv("DPR_NJ_EPOCH_MIN");
     const int64_t epoch_min = e_min ? std::atoll(e_min) : 2048;   // epochs smaller than this are not rebuilt
     const char* e_pct = std::getenv("DPR_NJ_EPOCH_PCT");
     const int64_t pct = e_pct ? std::atoll(e_pct) : 80;           // rebuild once n <= pct% of the epoch's positions
+    NjPruned& q = b.pr;
     int64_t it = it0, left = todo;
-    if (left <= 0) return njp_run_segment(b, it0, 0, s);
+    if (left <= 0) return q.slots_mode ? DPR_OK : njp_run_segment(b, it0, 0, s);
     while (left > 0) {
-        const int64_t n = b.N - it, P = b.pr.P;
+        const int64_t n = b.N - it;
+        if (q.slots_mode) {
+            // streaming loop until the next probe point (or the end); probes only while an epoch is worth building
+            if (n <= q.slots_probe_n && n >= epoch_min && n >= 3) {
+                if (int rc = njp_from_slots(b, s)) return rc;
+                if (!q.slots_mode) continue;        // a fresh pruned epoch: probed below
+            }
+            int64_t seg = left;
+            if (n > q.slots_probe_n && q.slots_probe_n >= epoch_min && n - q.slots_probe_n < seg) seg = n - q.slots_probe_n;
+            if (int rc = njp_run_slots(b, it, seg, s)) return rc;
+            it += seg; left -= seg;
+            continue;
+        }
+        const int64_t P = q.P;
         int64_t seg = left;
         if (epoch_min > 0 && P >= epoch_min) {
             const int64_t target = P * pct / 100;
@@ -1324,8 +1420,46 @@ int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
             }
             if (n - target < seg) seg = n - target;
         }
+        // adaptive plan: look at the listing rate after the first graph of an epoch and then every 2 048 iterations
+        const bool watch = q.adaptive && q.sh_world <= 1 && q.utot > 0;
+        unsigned long long units0 = 0;
+        bool first_of_epoch = false;
+        if (watch) {
+            first_of_epoch = q.fresh;
+            const int64_t chunk = first_of_epoch ? (int64_t)q.graph_iters : 2048;
+            if (seg > chunk) seg = chunk;
+            NjState st0;
+            DPR_HIP(hipStreamSynchronize(s));
+            DPR_HIP(hipMemcpy(&st0, b.st, sizeof(NjState), hipMemcpyDeviceToHost));
+            units0 = st0.units_scanned;
+        }
         if (int rc = njp_run_segment(b, it, seg, s)) return rc;
         it += seg; left -= seg;
+        if (watch && left > 0) {
+            NjState st1;
+            DPR_HIP(hipStreamSynchronize(s));
+            DPR_HIP(hipMemcpy(&st1, b.st, sizeof(NjState), hipMemcpyDeviceToHost));
+            if (st1.status != 0) continue;
+            // (the first scan of an epoch lists every unit by construction: left out of the rate)
+            const double listed = (double)(st1.units_scanned - units0) - (first_of_epoch ? (double)q.utot : 0.0);
+            const double iters = (double)seg - (first_of_epoch ? 1.0 : 0.0);
+            const double rate = iters >= 1.0 ? listed / (iters * (double)q.utot) : 0.0;
+            if (iters >= 1.0 && rate > q.stream_frac) {
+                // hand over; probe a pruned epoch again after the active size has shrunk by the epoch factor 1, 2, 4, 8 ... times
+                const int64_t na = b.N - it;
+                int64_t pn = na;
+                const int hops = 1 << (q.probe_fail_streak < 4 ? q.probe_fail_streak : 4);
+                for (int h = 0; h < hops; ++h) pn = pn * pct / 100;
+                ++q.probe_fail_streak;
+                q.slots_probe_n = pn;
+                if (int rc = njp_to_slots(b, s)) return rc;
+                if (std::getenv("DPR_NJ_EPOCH_LOG"))
+                    std::fprintf(stderr, "[njp] %.0f %% of the units listed per iteration at n=%lld: handed over to the streaming loop; next pruned probe at n <= %lld\n",
+                                 100.0 * rate, (long long)na, (long long)pn);
+            } else if (!first_of_epoch) {
+                q.probe_fail_streak = 0;       // the epoch keeps pruning
+            }
+        }
     }
     return DPR_OK;
 }

@@ -27,9 +27,21 @@
 namespace dpr {
 
 __device__ __forceinline__ double ld_sys_f64(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ unsigned long long ld_acq_u64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void st_rel_u64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+// Flag words of the windows.  No acquire / release FENCES (an acquire is an L2 invalidate after every poll, a release an L2
+// write-back): everything that travels behind a flag is written with system-scope write-through stores and read with
+// system-scope loads, which bypass the non-coherent caches on both sides; the writer drains its stores (vmcnt) before the
+// flag store, the reader issues its data loads after the poll returned (same thread, address dependency through control).
+__device__ __forceinline__ unsigned long long ld_acq_u64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_rel_u64(unsigned long long* p, unsigned long long v)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ void st_sys_u64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// stores that other DEVICES read after the next exchange (matrix rows / columns, row buffers): write-through at system scope,
+// so nothing of them is left dirty in this device's (per-XCD) L2 when the kernel ends -- a release fence per block instead
+// wrote the whole L2 back every iteration
+__device__ __forceinline__ void st_sys_f64(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // arguments shared by the kernels of the loop
 struct NjsArgs {
@@ -68,8 +80,14 @@ __device__ __forceinline__ const double* row_view(const NjsArgs& a, int64_t slot
 // SCAN(it): nj_scan_kernel's unit walk over the own rows (rows rewritten by the previous merge come from the row
 // buffers), then the last block to finish reduces the block records and publishes the rank's record.
 // ------------------------------------------------------------------------------------------------
+// (The streamed arrays are DIRECT kernel parameters, const __restrict__: only then does the compiler keep the rows' parameters
+//  -- Ur[a], KA[a], uniform per row -- in scalar loads.  With every pointer inside the by-value struct the same loop ran 2.25 x
+//  slower: 189 instead of 84 us for an eighth of the 30 000-tip triangle.  a.Ur aliases Ur: block 0 stores the single element
+//  Ur[xprev] through it, and no block ever USES Ur[xprev] read through the const pointer -- every use substitutes urx.)
 template <int RG, bool NT>
-__global__ __launch_bounds__(kThreads) void njs_scan_kernel(NjsArgs a)
+__global__ __launch_bounds__(kThreads) void njs_scan_kernel(const double* __restrict__ D, const double* __restrict__ Ur,
+                                                            const uint64_t* __restrict__ KA, const double* __restrict__ xrow_p,
+                                                            const double* __restrict__ yrow_p, NjsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int32_t* pref = reinterpret_cast<int32_t*>(smem);
@@ -96,12 +114,10 @@ __global__ __launch_bounds__(kThreads) void njs_scan_kernel(NjsArgs a)
         if (blockIdx.x == 0 && tid == 0) { a.U[xprev] = ux; a.Ur[xprev] = urx; }
         if (a.has_pending) {
             rv.xp = xprev; rv.yp = a.st->y;
-            rv.xrow = win_row(a.win[rank], a.lay, 0, (int)((it - 1) & 1));
-            rv.yrow = win_row(a.win[rank], a.lay, 1, (int)((it - 1) & 1));
+            rv.xrow = xrow_p;       // this rank's row buffers of merge it - 1 (host: window base + row offset)
+            rv.yrow = yrow_p;
         }
     }
-    const double* __restrict__ Ur = a.Ur;
-    const uint64_t* __restrict__ KA = a.KA;
 
     const int64_t nloc = shard_rows(n, rank, world);
     int nstrips = n > 1 ? (int)((n - 1 + kTileCols - 1) / kTileCols) : 0;
@@ -158,9 +174,9 @@ __global__ __launch_bounds__(kThreads) void njs_scan_kernel(NjsArgs a)
             const int nrows = (int)min((int64_t)RG, nloc - l0);
             const int64_t a0 = shard_global_row(l0, rank, world);
             if (a0 < c0 + kTileCols)
-                scan_rows<true, NT, false, true>(a.D, a.ld, Ur, KA, nullptr, a0, l0, nrows, c0, xprev, urx, ub0, ub1, ka0, ka1, kb0, kb1, bq, bk, rv);
+                scan_rows<true, NT, false, true>(D, a.ld, Ur, KA, nullptr, a0, l0, nrows, c0, xprev, urx, ub0, ub1, ka0, ka1, kb0, kb1, bq, bk, rv);
             else
-                scan_rows<false, NT, false, true>(a.D, a.ld, Ur, KA, nullptr, a0, l0, nrows, c0, xprev, urx, ub0, ub1, ka0, ka1, kb0, kb1, bq, bk, rv);
+                scan_rows<false, NT, false, true>(D, a.ld, Ur, KA, nullptr, a0, l0, nrows, c0, xprev, urx, ub0, ub1, ka0, ka1, kb0, kb1, bq, bk, rv);
             ++g;
         }
     }
@@ -173,7 +189,7 @@ __global__ __launch_bounds__(kThreads) void njs_scan_kernel(NjsArgs a)
             // d = D[max][min]: the block only visited own rows a > b, so the row (or its buffer) is local
             const int64_t i = (int64_t)(bk & 0xFFFFFFull), j = (int64_t)((bk >> 24) & 0xFFFFFFull);
             const int64_t x = i < j ? i : j, y = i < j ? j : i;
-            const double* row = (y == rv.xp) ? rv.xrow : (y == rv.yp) ? rv.yrow : a.D + shard_local_row(y, world) * a.ld;
+            const double* row = (y == rv.xp) ? rv.xrow : (y == rv.yp) ? rv.yrow : D + shard_local_row(y, world) * a.ld;
             rec.d = row[x];
         }
         // the record must be visible to the block that reduces (possibly on another XCD): agent-scope stores, then the ticket
@@ -181,7 +197,11 @@ __global__ __launch_bounds__(kThreads) void njs_scan_kernel(NjsArgs a)
         __hip_atomic_store(dst + 0, (unsigned long long)__double_as_longlong(rec.q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(dst + 1, (unsigned long long)rec.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(dst + 2, (unsigned long long)__double_as_longlong(rec.d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned int t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        // (NOT a release fence: on this chip a device-scope release is an L2 write-back per block, which made this kernel 2.2 x
+        //  slower -- 183 instead of 84 us for an eighth of the 30 000-tip triangle.  The three stores above are write-through
+        //  (sc1); draining them before a RELAXED ticket increment orders them for the reader, whose loads are sc1 too.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (t == gridDim.x - 1) ? 1u : 0u;
     }
     __syncthreads();
@@ -259,6 +279,7 @@ __global__ __launch_bounds__(kThreads) void njs_post_kernel(NjsArgs a)
                 __builtin_amdgcn_s_sleep(1);
             }
             if (!ok) s_fail = 1;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // (compiler ordering only: the record words are loaded after the poll)
             s_q[tid] = __longlong_as_double((long long)__hip_atomic_load(w + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
             s_k[tid] = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             s_d[tid] = __longlong_as_double((long long)__hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
@@ -308,29 +329,29 @@ __global__ __launch_bounds__(kThreads) void njs_post_kernel(NjsArgs a)
             const double u = a.U[i] + (-dxi - dyi + val);
             a.U[i] = u;
             a.Ur[i] = u / r1;
-            if (own_x) RXn[i] = val;
-            if (own_y) RYn[i] = ld_sys_f64(rowl + i);
+            if (own_x) st_sys_f64(RXn + i, val);
+            if (own_y) st_sys_f64(RYn + i, ld_sys_f64(rowl + i));
             if (shard_owner(i, world) == rank && i != xp && i != yp) {
                 // columns x and y of an own row that lives in the matrix (a pending row gets them with its flush below)
                 double* row = a.D + shard_local_row(i, world) * a.ld;
                 const double far = row[last];
-                row[x] = val;
-                row[y] = far;
+                st_sys_f64(row + x, val);
+                st_sys_f64(row + y, far);
             }
         } else {
             // tail of the reference (thread (0,0), src/neighborJoining.cu:184-193)
             const double uy = a.U[last] + (-dxi - dyi + val);
             a.U[y] = uy;
             a.Ur[y] = uy / r1;
-            if (own_x) RXn[y] = val;
-            if (own_y) RYn[x] = val;
+            if (own_x) st_sys_f64(RXn + y, val);
+            if (own_y) st_sys_f64(RYn + x, val);
         }
     } else if (i == x) {
-        if (own_x) RXn[x] = 0.0;          // diagonal
-        if (own_y && y == last) RYn[x] = 0.0;      // (y == last: no tail; the row dies with the slot, keep it defined)
+        if (own_x) st_sys_f64(RXn + x, 0.0);          // diagonal
+        if (own_y && y == last) st_sys_f64(RYn + x, 0.0);      // (y == last: no tail; the row dies with the slot, keep it defined)
     } else if (i == y) {
-        if (own_y) RYn[y] = 0.0;
-        if (own_x && y == last) RXn[y] = 0.0;
+        if (own_y) st_sys_f64(RYn + y, 0.0);
+        if (own_x && y == last) st_sys_f64(RXn + y, 0.0);
     }
     // ---- flush the row buffers of merge it - 1 into the matrix (their owner; a row consumed by this merge or dead now is
     // not flushed).  Column x / y of such a row are the values its own thread would have written.
@@ -343,13 +364,12 @@ __global__ __launch_bounds__(kThreads) void njs_post_kernel(NjsArgs a)
             double v = Rp[i];
             if (i == x) v = (ld_sys_f64(rowx + p) + ld_sys_f64(rowy + p) - d) * 0.5;
             else if (i == y) v = Rp[last];
-            a.D[shard_local_row(p, world) * a.ld + i] = v;
+            st_sys_f64(a.D + shard_local_row(p, world) * a.ld + i, v);
         }
     }
     if (i < n1) a.KA[i] = nj_key_a(i, n1);
     const double cs = block_tree256(val, s);
     if (tid == 0) a.xpart[blockIdx.x] = cs;
-    __threadfence_system();      // the matrix / buffer rows written here are pulled by other devices after the next exchange
 }
 
 // after the loop (behind a barrier over the ranks): flush the row buffers of the last merge, materialise U[x]
@@ -371,7 +391,7 @@ __global__ __launch_bounds__(kThreads) void njs_finish_kernel(NjsArgs a)
         const int64_t p = w ? yp : xp;
         if (p < 0 || p >= n || shard_owner(p, a.world) != a.rank) continue;
         const double* __restrict__ Rp = win_row(a.win[a.rank], a.lay, w, (int)((it - 1) & 1));
-        a.D[shard_local_row(p, a.world) * a.ld + i] = Rp[i];
+        st_sys_f64(a.D + shard_local_row(p, a.world) * a.ld + i, Rp[i]);
     }
 }
 
@@ -381,7 +401,6 @@ __global__ void njs_barrier_kernel(NjsArgs a, unsigned long long epoch)
     const int tid = threadIdx.x;
     if (tid >= a.world) return;
     unsigned long long* theirs = reinterpret_cast<unsigned long long*>(a.win[tid] + a.lay.off_bar) + 8 * a.rank;
-    __threadfence_system();
     st_rel_u64(theirs, epoch);
     const unsigned long long* mine = reinterpret_cast<const unsigned long long*>(a.win[a.rank] + a.lay.off_bar) + 8 * tid;
     const unsigned long long t0 = wall_clock64();
@@ -435,7 +454,12 @@ int njs_launch_scan(NjBuffers& b, int64_t n, int64_t it, bool pending, hipStream
 {
     const NjsArgs a = njs_args(b, n, it, pending);
     const size_t lds = sizeof(int32_t) * (size_t)((b.N + kTileCols - 1) / kTileCols + 2);
-    hipLaunchKernelGGL((njs_scan_kernel<16, true>), dim3((unsigned)a.nparts), dim3(kThreads), lds, s, a);
+    const int par = (int)((it - 1) & 1);
+    const double* rows = reinterpret_cast<const double*>(b.peer.win + b.peer.lay.off_rows);
+    const double* xrow = rows + (int64_t)(0 * 2 + par) * b.peer.lay.ldv;
+    const double* yrow = rows + (int64_t)(1 * 2 + par) * b.peer.lay.ldv;
+    hipLaunchKernelGGL((njs_scan_kernel<16, true>), dim3((unsigned)a.nparts), dim3(kThreads), lds, s, (const double*)b.D, (const double*)b.Ur,
+                       (const uint64_t*)b.KA, xrow, yrow, a);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }

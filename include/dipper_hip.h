@@ -174,6 +174,12 @@ int dpr_nj_is_unit_sharded(dpr_ctx *ctx);
  * dpr_dist_matrix. */
 int dpr_ctx_set_nj_mode(dpr_ctx *ctx, int mode);
 int dpr_ctx_set_nj_multi_plan(dpr_ctx *ctx, int plan);
+/* Adaptive plan of the single-rank NJ (default on; DPR_NJ_ADAPTIVE=0 switches it off): the exact pruned scan while its
+ * bounds prune; once more than half of an epoch's units are listed per iteration (divergent / tie-heavy / arbitrary `-i d`
+ * matrices, src/matrix_reader.cu:23-45 feeds NJ anything) the rest of the epoch runs the full streaming scan of
+ * src/neighborJoining.cu:117-148 on the same position-space matrix.  Same merge log either way. */
+int dpr_ctx_set_nj_adaptive(dpr_ctx *ctx, int on);
+int dpr_get_nj_adaptive_stats(dpr_ctx *ctx, int64_t *stream_iterations, int64_t *stream_epochs);
 /* Exchange plan of the ROW-SHARDED streaming NJ loop (several ranks, DPR_NJ_MODE=stream / dpr_ctx_set_nj_mode(ctx, 0);
  * replaces src/neighborJoining.cu:211-243): 0 = legacy (4 launches + 2 all-gathers per iteration), 1 = peer (default:
  * 2 launches + ONE all-gather of the rank records; rows x / y are pulled from their owners' memory), 2 = mailbox

@@ -14,17 +14,20 @@ nq = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
 kind = sys.argv[4] if len(sys.argv) > 4 else "m"
 n = m + nq
-seqs = _util.synth_alignment(np.random.default_rng(1), n, L, mean_bl=1e-3, lo=1e-4, hi=1e-2)
-seqs = [seqs[i] for i in np.random.default_rng(7).permutation(n)]
+import tempfile, shutil
+tmp = tempfile.mkdtemp(prefix="addb_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+inp = _util.gen_synth(tmp, "a", n, L, 1, 1e-3, 1e-4, 1e-2, reads=(kind == "r"), shuffle=7)      # native generator, seeded (tools/gen_synth.cpp)
+data = inp["reads"] if kind == "r" else np.asarray(inp["packed4"])
+shutil.rmtree(tmp, ignore_errors=True)
 from profiles import _mgpu
 d, rank, world, dist = _mgpu.open_dipper()      # multi-GPU: see profiles/_mgpu.py
-def load(ss):
+def load(order):
     if kind == "r":
-        d.set_reads(ss); d.sketch(15, 1000, fetch=False)
+        d.set_reads_packed(*_util.reads_reorder(data, order)); d.sketch(15, 1000, fetch=False)
     else:
-        d.set_msa(capi.pack4_many(ss), L)
+        d.set_msa(np.ascontiguousarray(data[order]), L)
 src = capi.SRC_MASH if kind == "r" else capi.SRC_MSA
-load(seqs[:m])
+load(np.arange(m))
 t0 = time.perf_counter()
 bb = d.dc_run(src, m, max(m // 20, 3), dist_type=2, k=15)
 t1 = time.perf_counter()
@@ -32,10 +35,9 @@ names = [f"T{i}" for i in range(n)]
 nwk = _util.newick_from_placement(names[:m], bb["head"], bb["e"], bb["nxt"], bb["len"], m)
 t2 = time.perf_counter()
 st, leaf_names = _util.backbone_state(_orc.load(), nwk, n)      # Tree::Tree ids + adjacency (host, Python mirror)
-order = [int(x[1:]) for x in leaf_names]                           # backbone tips in import order, then the queries
-seq_order = [seqs[i] for i in order] + seqs[m:]
+order = [int(x[1:]) for x in leaf_names] + list(range(m, n))      # backbone tips in import order, then the queries
 t3 = time.perf_counter()
-load(seq_order)
+load(np.asarray(order))
 t4 = time.perf_counter()
 res = d.place_run(src, n, first=m, dist_type=2, k=15, state={k: st[k] for k in ("head", "e", "nxt", "belong", "len")})
 t5 = time.perf_counter()

@@ -35,15 +35,11 @@ def used_gb():
 def run(tag, setup, dist_type, modes=(1, 0, -1)):
     for mode in modes:
         d = dipper_amd.Dipper(0)
-        rec = {"input": tag, "tips": n, "algorithm": {1: "pruned", 0: "stream", -1: "auto"}[mode]}
+        rec = {"input": tag, "tips": n, "algorithm": {1: "pruned only", 0: "stream only", -1: "default (adaptive)"}[mode]}
         try:
-            if mode >= 0:
-                d.set_nj_mode(mode)
-            elif not hasattr(d, "set_nj_adaptive"):
-                continue
-            else:
-                d.set_nj_mode(1)
-                d.set_nj_adaptive(1)
+            d.set_nj_mode(0 if mode == 0 else 1)
+            if mode == 1:
+                d.set_nj_adaptive(0)          # pruned scans only
             setup(d)
             base = used_gb()
             t0 = time.perf_counter()
@@ -78,7 +74,9 @@ def run(tag, setup, dist_type, modes=(1, 0, -1)):
             if mode != 0:
                 try:
                     sc, full = d.prune_stats()
-                    rec.update(units_scanned=int(sc), units_per_full_scan=int(full), scanned_fraction=sc / (full * (n - 2.0)))
+                    rec.update(units_listed=int(sc), units_per_full_scan=int(full), listed_fraction_of_full_scans=sc / (full * (n - 2.0)))
+                    si, se = d.nj_adaptive_stats()
+                    rec.update(streamed_iterations=si, epochs_switched_to_streaming=se)
                 except Exception:
                     pass
         finally:
@@ -102,6 +100,13 @@ try:
         if mean >= 1e-2:
             run(tag + ", p-distance", lambda d: d.set_msa(packed, L), (capi.SRC_MSA, 1))
         del packed
+    if not only or "const" in only:
+        m = n * (n - 1) // 2
+        run("constant matrix (every distance 1: one global tie)", lambda d: d.set_matrix_lower(np.ones(m), n), (capi.SRC_MATRIX,))
+    if not only or "ints" in only:
+        m = n * (n - 1) // 2
+        ints = np.random.default_rng(4).integers(1, 4, size=m).astype(np.float64)
+        run("small integers 1..3 (ties everywhere)", lambda d: d.set_matrix_lower(ints, n), (capi.SRC_MATRIX,))
     if not only or "random" in only:
         rng = np.random.default_rng(3)
         m = n * (n - 1) // 2

@@ -399,3 +399,70 @@ def backbone_state(orc, newick, N):
         if not kids[v]:
             leaf_names[idx[v]] = name[v]
     return st, leaf_names
+
+
+# ---- native generator / normalised RF (tools/) -------------------------------------------------------------------------
+import json as _json
+import os as _os
+import subprocess as _subprocess
+
+_ROOT = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+GEN_SYNTH = _os.path.join(_ROOT, "tools", "bin", "gen_synth")
+NRF_TOOL = _os.path.join(_ROOT, "tools", "bin", "nrf")
+
+
+def gen_synth(outdir, tag, tips, sites, seed, mean_bl, lo, hi, reads=False, shuffle=None, fasta=False):
+    """Seeded synthetic input with its generating tree (tools/gen_synth.cpp).  Returns a dict: tree (path), names (tip
+    names in OUTPUT order), packed4 ([tips][ceil(sites/16)] uint64 memmap) or reads (flat, off, len), fasta (path)."""
+    base = _os.path.join(str(outdir), tag)
+    cmd = [GEN_SYNTH, "--tips", str(tips), "--sites", str(sites), "--seed", str(seed), "--mean-bl", repr(mean_bl), "--lo", repr(lo),
+           "--hi", repr(hi), "--tree", base + ".nwk", "--order", base + ".ord"]
+    if reads:
+        cmd += ["--indel", "0.03,0.09", "--packed2", base]
+    else:
+        cmd += ["--packed4", base + ".p4"]
+    if shuffle is not None:
+        cmd += ["--shuffle", str(shuffle)]
+    if fasta:
+        cmd += ["--fasta", base + ".fa"]
+    _subprocess.run(cmd, check=True)
+    order = np.fromfile(base + ".ord", dtype=np.int32)
+    out = {"tree": base + ".nwk", "names": ["T%d" % (k + 1) for k in order], "fasta": base + ".fa" if fasta else None}
+    if reads:
+        out["reads"] = tuple(np.fromfile(base + ext, dtype=np.uint64) for ext in (".flat", ".off", ".len"))
+    else:
+        out["packed4"] = np.memmap(base + ".p4", dtype=np.uint64, mode="r", shape=(tips, (sites + 15) // 16))
+    return out
+
+
+def nrf(true_tree_path, newick_text, workdir, tag="t"):
+    """normalised Robinson-Foulds distance of a Newick text against a tree file (tools/nrf.cpp; the reference authors'
+    accuracy measure, scripts/nrf.sh:26,36-60)"""
+    path = _os.path.join(str(workdir), "nrf_%s.nwk" % tag)
+    with open(path, "w") as f:
+        f.write(newick_text)
+    r = _subprocess.run([NRF_TOOL, true_tree_path, path], check=True, capture_output=True, text=True)
+    _os.unlink(path)
+    return _json.loads(r.stdout)
+
+
+def reads_prefix(reads, m):
+    """the first m reads of a packed (flat, off, len) triple"""
+    flat, off, ln = reads
+    end = int(off[m]) if m < len(off) else len(flat)
+    return flat[:end], off[:m], ln[:m]
+
+
+def reads_reorder(reads, order):
+    """packed reads in another order: read k of the result is read order[k] of the input"""
+    flat, off, ln = reads
+    order = np.asarray(order, dtype=np.int64)
+    nw = (ln.astype(np.int64) + 31) // 32
+    new_nw = nw[order]
+    new_off = np.zeros(len(order), dtype=np.uint64)
+    new_off[1:] = np.cumsum(new_nw)[:-1].astype(np.uint64)
+    # gather the words: index of every output word in the input array
+    starts = off.astype(np.int64)[order]
+    tot = int(new_nw.sum())
+    idx = np.repeat(starts - np.concatenate(([0], np.cumsum(new_nw)[:-1])), new_nw) + np.arange(tot)
+    return np.ascontiguousarray(flat[idx]), new_off, np.ascontiguousarray(ln[order])

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from tests import _util
+from tests.conftest import dirty_device_memory as _dirty_device_memory
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(os.environ.get("DPR_SKIP_FULLSIZE") == "1", reason="DPR_SKIP_FULLSIZE=1")]
@@ -27,10 +28,14 @@ def _tree_degrees_ok(st, n):
     assert np.array_equal(st["len"][:live][order], st["len"][:live][rorder])
 
 
-def test_config1_nj_30k_two_algorithms_agree():
+@pytest.mark.parametrize("fill", [0xFF, 0x40], ids=["memory_0xFF", "memory_0x40"])
+def test_config1_nj_30k_two_algorithms_agree(fill):
     """30 000 tips x 1 000 sites, JC69: the exact pruned scan and the full streaming scan (the reference's
     algorithm) are independent implementations and must produce the same merge log bit for bit; the log
-    is a valid NJ history (x < y < active size, finite branch lengths)."""
+    is a valid NJ history (x < y < active size, finite branch lengths).
+    Runs on POISONED device memory in the default suite (24 GB filled with 0xFF = NaN patterns, resp. 0x40, and freed
+    right before the contexts allocate): round 2's two-kernel NJ had a cross-thread race that showed as one NaN branch
+    length in 30 000 iterations and only under 0xFF."""
     import dipper_amd
     from dipper_amd import capi
     n, L = 30000, 1000
@@ -42,6 +47,7 @@ def test_config1_nj_30k_two_algorithms_agree():
         capi.set_nj_mode(mode)
         d = dipper_amd.Dipper(0)
         try:
+            _dirty_device_memory(24 << 30, fill)
             d.set_msa(packed, L)
             d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
             res[mode] = d.nj_run()
@@ -194,9 +200,6 @@ def test_config4_add_50k_onto_500k(orc):
         d.close()
 
 
-from tests.conftest import dirty_device_memory as _dirty_device_memory
-
-
 def test_config1_matrix_build_is_stream_ordered():
     """Regression: the 7 GB zero fill of a fresh 30 000-tip matrix ran on the null stream, which the context's
     non-blocking stream does not wait for, and wiped distance tiles that had already been written (zero blocks
@@ -224,3 +227,125 @@ def test_config1_matrix_build_is_stream_ordered():
         capi.set_nj_mode(1)
     assert not np.any(np.isnan(sums[0].view(np.float64)))
     assert np.array_equal(sums[0], sums[1]) and np.array_equal(sums[0], sums[2])
+
+
+def test_config1_pruned_nj_repeats_with_varied_launch_shapes(monkeypatch):
+    """Ten pruned NJ runs of the 30 000-tip input with the scan grid, the graph length and the memory poison varied: every
+    merge log digest must equal the first one.  The design depends on intra-launch ordering between update blocks and test
+    blocks of the post kernel (njp.hip); a race there shows as a run-to-run difference under some launch shape."""
+    import hashlib
+    import dipper_amd
+    from dipper_amd import capi
+    n, L = 30000, 1000
+    seqs = _util.synth_alignment(np.random.default_rng(1), n, L, mean_bl=2e-4, lo=2e-5, hi=2e-3)
+    packed = capi.pack4_many(seqs)
+    del seqs
+    shapes = [(256, 32, None), (64, 8, 0xFF), (1024, 32, 0x40), (128, 128, 0xFF), (512, 16, None), (256, 32, 0xFF),
+              (1024, 8, 0xFF), (64, 64, 0x40), (256, 1, 0xFF), (37, 32, 0xFF)]
+    digests = []
+    for grid, giters, fill in shapes:
+        monkeypatch.setenv("DPR_NJP_GRID", str(grid))
+        monkeypatch.setenv("DPR_NJ_GRAPH_ITERS", str(giters))
+        d = dipper_amd.Dipper(0)
+        try:
+            if fill is not None:
+                _dirty_device_memory(20 << 30, fill)
+            d.set_nj_mode(1)
+            d.set_msa(packed, L)
+            d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+            res = d.nj_run()
+        finally:
+            d.close()
+        assert res["iters"] == n - 2
+        assert np.all(np.isfinite(res["bl_x"])) and np.all(np.isfinite(res["bl_y"])), (grid, giters, fill)
+        h = hashlib.sha256()
+        for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
+            h.update(np.ascontiguousarray(res[key]).tobytes())
+        h.update(np.float64(res["last_d"]).tobytes())
+        digests.append(h.hexdigest())
+    assert len(set(digests)) == 1, digests
+
+
+@pytest.mark.parametrize("source", ["msa", "mash"])
+def test_placement_on_poisoned_memory(source):
+    """k-closest placement (20 000 tips; the multi-tip path forced for the second half through DPR_PLACE_MULTI_MIN) on clean,
+    0xFF- and 0x40-poisoned device memory: adjacency, lengths, closest lists and trace must be identical bit for bit."""
+    import dipper_amd
+    from dipper_amd import capi
+    n = 20000
+    rng = np.random.default_rng(21)
+    if source == "msa":
+        L = 600
+        seqs = _util.synth_alignment(rng, n, L, mean_bl=2e-3, lo=2e-4, hi=2e-2)
+        packed = capi.pack4_many(seqs)
+    else:
+        seqs = _util.synth_reads(rng, n, 1500, mean_bl=2e-3, lo=2e-4, hi=2e-2)
+    os.environ["DPR_PLACE_MULTI_MIN"] = "10000"
+    try:
+        outs = []
+        for fill in (None, 0xFF, 0x40):
+            d = dipper_amd.Dipper(0)
+            try:
+                if fill is not None:
+                    _dirty_device_memory(16 << 30, fill)
+                if source == "msa":
+                    d.set_msa(packed, L)
+                    st = d.place_run(capi.SRC_MSA, n, dist_type=capi.DIST_JC)
+                else:
+                    d.set_reads(seqs)
+                    d.sketch(15, 1000, fetch=False)
+                    st = d.place_run(capi.SRC_MASH, n, k=15)
+            finally:
+                d.close()
+            outs.append(st)
+        live = 4 * n - 4
+        for other in outs[1:]:
+            for key, m in (("head", 2 * n), ("e", live), ("nxt", live), ("belong", live), ("len", live), ("cid", 5 * live), ("cdis", 5 * live)):
+                assert np.array_equal(outs[0][key][:m].view(np.uint8), other[key][:m].view(np.uint8)), key
+            assert np.array_equal(outs[0]["trace"].view(np.uint64), other["trace"].view(np.uint64))
+        _tree_degrees_ok(outs[0], n)
+    finally:
+        os.environ.pop("DPR_PLACE_MULTI_MIN", None)
+
+
+def test_config4_add_50k_onto_500k_mash_source(tmp_path, orc):
+    """BASELINE configs[4] through its OWN distance path (unaligned reads, Mash sketches): --add of 50 000 queries onto a
+    500 000-tip backbone.  Size-independent properties: the result is a binary tree over all 550 000 tips; every query's
+    (edge, split position, pendant length) is valid; the trace of the first 10 000 queries does not depend on the 40 000
+    later ones."""
+    import sys
+    import dipper_amd
+    from dipper_amd import capi
+    if not os.path.exists(_util.GEN_SYNTH):
+        pytest.skip("tools not built")
+    sys.setrecursionlimit(max(sys.getrecursionlimit(), 100000))
+    m, nq, q1 = 500000, 50000, 10000
+    n = m + nq
+    inp = _util.gen_synth(tmp_path, "r", n, 3000, 9, 1e-3, 1e-4, 1e-2, reads=True, shuffle=6)
+    reads = inp["reads"]
+    d = dipper_amd.Dipper(0)
+    try:
+        d.set_reads_packed(*_util.reads_prefix(reads, m))
+        d.sketch(15, 1000, fetch=False)
+        bb = d.dc_run(capi.SRC_MASH, m, m // 20, k=15)
+        names = ["T%d" % i for i in range(n)]
+        nwk = _util.newick_from_placement(names[:m], bb["head"], bb["e"], bb["nxt"], bb["len"], m)
+        del bb
+        st, leaf_names = _util.backbone_state(orc, nwk, n)
+        order = [int(x[1:]) for x in leaf_names] + list(range(m, n))
+        reads2 = _util.reads_reorder(reads, order)
+        adj = ("head", "e", "nxt", "belong", "len")
+        d.set_reads_packed(*reads2)
+        d.sketch(15, 1000, fetch=False)
+        full = d.place_run(capi.SRC_MASH, n, first=m, k=15, state={k: st[k].copy() for k in adj})
+        _tree_degrees_ok(full, n)
+        tr = full["trace"][m:]
+        assert np.all(tr[:, 0] >= 0) and np.all(tr[:, 0] < 4 * n - 4) and np.all(tr[:, 1] >= 0) and np.all(tr[:, 2] >= 0)
+        n2 = m + q1
+        st2 = _renumber_nodes(st, n, n2)
+        d.set_reads_packed(*_util.reads_prefix(reads2, n2))
+        d.sketch(15, 1000, fetch=False)
+        part = d.place_run(capi.SRC_MASH, n2, first=m, k=15, state={k: st2[k].copy() for k in adj})
+        assert np.array_equal(full["trace"][m:n2], part["trace"][m:n2])
+    finally:
+        d.close()

@@ -375,3 +375,79 @@ def test_context_reuse_msa_and_mash_sources(orc):
     finally:
         d.close()
         fresh.close()
+
+
+@pytest.mark.parametrize("kind", ["ties", "additive", "random"])
+def test_nj_adaptive_switch_to_streaming_mid_run(monkeypatch, orc, kind):
+    """Adaptive plan: with the switch forced (threshold 0: every epoch goes over to full streaming scans on the position-space
+    matrix after its first graph of pruned iterations) and many small epochs, the merge log is still the oracle's -- pruned and
+    streaming iterations alternate within ONE run, with epoch rebuilds and interrupted calls in between."""
+    import dipper_amd
+    from dipper_amd import capi
+    monkeypatch.setenv("DPR_NJ_STREAM_FRAC", "0")
+    monkeypatch.setenv("DPR_NJ_EPOCH_MIN", "64")
+    monkeypatch.setenv("DPR_NJ_GRAPH_ITERS", "8")
+    rng = np.random.default_rng(11)
+    n = 900
+    if kind == "ties":
+        D = rng.integers(1, 4, size=(n, n)).astype(np.float64)
+        D = np.tril(D, -1) + np.tril(D, -1).T
+    elif kind == "additive":
+        D = _util.random_additive_matrix(rng, n, zero_frac=0.3)
+    else:
+        D = rng.random((n, n))
+        D = np.tril(D, -1) + np.tril(D, -1).T
+    ref = orc.nj_run(np.tril(D, -1))
+    d = dipper_amd.Dipper(0)
+    try:
+        d.set_nj_mode(1)
+        d.set_matrix_full(D)
+        d.dist_matrix(capi.SRC_MATRIX)
+        got = {k: [] for k in ("merge_x", "merge_y", "bl_x", "bl_y")}
+        done = 0
+        for chunk in (5, 40, 1, 300, 10 ** 6):
+            res = d.nj_run(max_iters=chunk)
+            k = res["iters"]
+            for key in got:
+                got[key].append(res[key][:k])
+            done += k
+        assert done == n - 2
+        for key in got:
+            assert np.array_equal(np.concatenate(got[key]), ref[key]), key
+        assert res["last_d"] == ref["last_d"]
+        streamed, switched = d.nj_adaptive_stats()
+        assert switched >= 3 and 0 < streamed < n - 2          # both kinds of iterations really ran
+    finally:
+        d.close()
+
+
+def test_nj_adaptive_off_is_pruned_only(orc):
+    import dipper_amd
+    from dipper_amd import capi
+    rng = np.random.default_rng(12)
+    n = 500
+    D = np.ones((n, n)) - np.eye(n)           # one global tie: every unit is listed every iteration
+    d = dipper_amd.Dipper(0)
+    try:
+        d.set_nj_mode(1)
+        d.set_nj_adaptive(0)
+        d.set_matrix_full(D)
+        d.dist_matrix(capi.SRC_MATRIX)
+        res = d.nj_run()
+        assert d.nj_adaptive_stats() == (0, 0)
+        ref = orc.nj_run(np.tril(D, -1))
+        for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
+            assert np.array_equal(res[key], ref[key]), key
+    finally:
+        d.close()
+    d = dipper_amd.Dipper(0)
+    try:
+        d.set_nj_mode(1)                     # default: adaptive on -- this input switches by itself
+        d.set_matrix_full(D)
+        d.dist_matrix(capi.SRC_MATRIX)
+        res2 = d.nj_run()
+        assert d.nj_adaptive_stats()[0] > 0
+        for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
+            assert np.array_equal(res2[key], ref[key]), key
+    finally:
+        d.close()
