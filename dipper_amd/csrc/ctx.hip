@@ -1066,8 +1066,8 @@ int dpr_set_nj_mode(int mode)
     return DPR_OK;
 }
 
-// Adaptive plan of the single-rank NJ (default on): the exact pruned scan while its bounds prune, full streaming scans for
-// the rest of an epoch once more than half of the epoch's units are listed per iteration (see dpr_internal.hpp).  The
+// Adaptive plan of the single-rank NJ (default on): the exact pruned scan while its bounds prune; hand-over to the streaming
+// loop once more than 70 % of an epoch's units are listed per iteration, pruned probes with back-off (see dpr_internal.hpp).  The
 // merge log does not depend on it.  on = 0: pruned scans only; -1: DPR_NJ_ADAPTIVE / default.  Takes effect at the next
 // dpr_dist_matrix.
 int dpr_ctx_set_nj_adaptive(dpr_ctx* c, int on)

@@ -134,7 +134,7 @@ struct NjPruned {
     // same merge log).  Every so often (after the active size has shrunk by the epoch factor once, twice, four times, ...
     // while the probes keep failing) a fresh pruned epoch is built from the slot-space matrix and probed again.
     int adaptive = 1;                 // DPR_NJ_ADAPTIVE=0 / dpr_ctx_set_nj_adaptive
-    double stream_frac = 0.5;         // DPR_NJ_STREAM_FRAC (tests force the hand-over with 0)
+    double stream_frac = 0.7;         // DPR_NJ_STREAM_FRAC (tests force the hand-over with 0); a listed unit costs ~1.6 x a streamed one, part of its sub-units are skipped
     bool slots_mode = false;          // the run currently lives in slot space (b.D, b.U, b.Ur, b.KA: nj.hip's loop)
     int64_t slots_probe_n = 0;        // slots mode: build and probe a pruned epoch again once the active size is <= this
     int probe_fail_streak = 0;

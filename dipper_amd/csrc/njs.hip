@@ -24,6 +24,8 @@
 // (a rank that never answers makes the run end with DPR_ERR_COMM, not hang).
 #include "nj_dev.hpp"
 
+#include <cstdlib>
+
 namespace dpr {
 
 __device__ __forceinline__ double ld_sys_f64(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -443,7 +445,10 @@ static NjsArgs njs_args(NjBuffers& b, int64_t n, int64_t it, bool pending)
     a.win = b.peer.d_win; a.peerD = b.peer.d_D; a.lay = b.peer.lay;
     a.n = n; a.it = it; a.has_pending = pending ? 1 : 0;
     a.rank = b.rank; a.world = b.world; a.plan = b.peer.plan;
-    a.nparts = nj_scan_grid();
+    // blocks of the scan: the single-GPU grid (2 048) by default; a rank streams only 1 / world of the triangle, so a
+    // smaller grid may ramp and drain faster (DPR_NJS_GRID, profiles/njs_vworld_stats.py)
+    static const int env_grid = std::getenv("DPR_NJS_GRID") ? std::atoi(std::getenv("DPR_NJS_GRID")) : 0;
+    a.nparts = env_grid >= 64 && env_grid <= kScanBlocks ? env_grid : nj_scan_grid();
     a.poll_ticks = b.peer.poll_ticks;
     a.seq_base = b.peer.run_id << 32;
     a.log_x = b.log_x; a.log_y = b.log_y; a.log_bx = b.log_bx; a.log_by = b.log_by;

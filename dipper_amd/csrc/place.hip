@@ -613,19 +613,12 @@ __device__ __forceinline__ void place_eval_slot(const PlaceBuffers& p, const dou
     }
 }
 
-// scan of the slots [0, 4 num0 - 4) for the tips num0 .. num0 + nb - 1 (rows dis0 + j ldb): partials[j * nblk + block] = the
-// block's first minimum, runners[j * nblk + block] = its first minimum WITHOUT that slot (round 3).  The update launch
-// re-evaluates every dirty slot itself, so what it needs from a block is the minimum over the block's CLEAN slots: the winner
-// if it is clean, else the runner-up if that one is clean (nothing but the dirty winner lies below it) -- only when both are
-// dirty does the block have to be scanned again (1.4 re-scans of 256 slots per tip before, three dependent round trips each).
+// scan of the slots [0, 4 num0 - 4) for the tips num0 .. num0 + nb - 1 (rows dis0 + j ldb): partials[j * nblk + block]
 __global__ __launch_bounds__(kTipThreads) void place_tip_multi_kernel(PlaceBuffers p, const double* __restrict__ dis0, int64_t ldb,
-                                                                   int64_t num0, int nb, PlacePartial* __restrict__ partials,
-                                                                   PlacePartial* __restrict__ runners, int nblk)
+                                                                   int64_t num0, int nb, PlacePartial* __restrict__ partials, int nblk)
 {
     __shared__ double sadd[kMultiB][kTipThreads / 64];
     __shared__ int sidx[kMultiB][kTipThreads / 64];
-    __shared__ double sadd2[kMultiB][kTipThreads / 64];
-    __shared__ int sidx2[kMultiB][kTipThreads / 64];
     const int64_t live = 4 * num0 - 4;
     const int64_t idx = (int64_t)blockIdx.x * kTipThreads + threadIdx.x;
     const bool have = idx < live;
@@ -705,34 +698,6 @@ __global__ __launch_bounds__(kTipThreads) void place_tip_multi_kernel(PlaceBuffe
         if (threadIdx.x == 0 && bi == 0x7fffffff) {
             PlacePartial pp; pp.add = __builtin_inf(); pp.idx = 0x7fffffff; pp.eid = 0; pp.frac = 0; pp.rev = -1; pp.pad = 0;
             partials[(int64_t)j * nblk + blockIdx.x] = pp;
-        }
-        // runner-up: the same reduction without the winner's slot
-        double ra = (have && (int)idx != bi && add[j] == add[j]) ? add[j] : __builtin_inf();
-        int ri = (have && (int)idx != bi) ? (int)idx : 0x7fffffff;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double oa = __shfl_down(ra, off, 64);
-            const int oi = __shfl_down(ri, off, 64);
-            if (oa < ra || (oa == ra && oi < ri)) { ra = oa; ri = oi; }
-        }
-        if (lane == 0) { sadd2[j][w] = ra; sidx2[j][w] = ri; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kMultiB; ++j) {
-        if (j >= nb) break;
-        double ra = sadd2[j][0];
-        int ri = sidx2[j][0];
-#pragma unroll
-        for (int i = 1; i < kTipThreads / 64; ++i)
-            if (sadd2[j][i] < ra || (sadd2[j][i] == ra && sidx2[j][i] < ri)) { ra = sadd2[j][i]; ri = sidx2[j][i]; }
-        if (have && (int)idx == ri) {
-            PlacePartial pp; pp.add = add[j]; pp.idx = (int)idx; pp.eid = eid; pp.frac = d1[j]; pp.rev = eid ? myrev : -1; pp.pad = 0;
-            runners[(int64_t)j * nblk + blockIdx.x] = pp;
-        }
-        if (threadIdx.x == 0 && ri == 0x7fffffff) {
-            PlacePartial pp; pp.add = __builtin_inf(); pp.idx = 0x7fffffff; pp.eid = 0; pp.frac = 0; pp.rev = -1; pp.pad = 0;
-            runners[(int64_t)j * nblk + blockIdx.x] = pp;
         }
     }
 }
@@ -858,8 +823,7 @@ __device__ __forceinline__ void closest_update_wave_rec(const PlaceBuffers& p, i
 }
 
 constexpr int kMultiMaxThreads = 1024;      // (launched with 256 threads, or 1024 when there are many block minima to go through)
-__global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(PlaceBuffers p, const PlacePartial* __restrict__ partials,
-                                                                         const PlacePartial* __restrict__ runners, int nblk,
+__global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(PlaceBuffers p, const PlacePartial* __restrict__ partials, int nblk,
                                                                          int64_t num0, int nb, const double* __restrict__ dis0, int64_t ldb,
                                                                          double* __restrict__ trace)
 {
@@ -882,7 +846,6 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
         const int ec0 = (int)(4 * num - 4);             // live slots of this tip = slot id of its first new slot
         const double* __restrict__ dis = dis0 + (int64_t)jt * ldb;
         const PlacePartial* __restrict__ part = partials + (int64_t)jt * nblk;
-        const PlacePartial* __restrict__ part2 = runners + (int64_t)jt * nblk;
         double badd = __builtin_inf(), bfrac = 0;
         int bidx = 0x7fffffff, beid = 0, brev = -1;
         auto consider = [&](double a, int idx, int eid, double frac, int rv) {
@@ -896,16 +859,8 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
             for (int b = tid; b < nblk; b += nthr) {
                 const PlacePartial pp = part[b];
                 if (jt > 0 && pp.idx != 0x7fffffff && dirty_has(ds, pp.idx)) {
-                    // the dirty winner is evaluated again in (B); the block's minimum over its CLEAN slots is the runner-up if
-                    // that one is clean (or nothing, if the block holds no other slot)
-                    const PlacePartial p2 = part2[b];
-                    if (p2.idx == 0x7fffffff) {
-                    } else if (!dirty_has(ds, p2.idx)) {
-                        consider(p2.add, p2.idx, p2.eid, p2.frac, p2.rev);
-                    } else {
-                        const int k = atomicAdd(&s_nrescan, 1);
-                        if (k < kRescanCap) s_rescan[k] = b;
-                    }
+                    const int k = atomicAdd(&s_nrescan, 1);
+                    if (k < kRescanCap) s_rescan[k] = b;
                 } else {
                     consider(pp.add, pp.idx, pp.eid, pp.frac, pp.rev);
                 }
@@ -1091,7 +1046,7 @@ int place_alloc(PlaceBuffers& p, int64_t N, int64_t M)
     p.nparts_max = (int)((4 * N + kThreads - 1) / kThreads + 1);
     DPR_HIP(hipMalloc(&p.partials, sizeof(PlacePartial) * (size_t)p.nparts_max));
     p.nparts_multi = (int64_t)p.nparts_max * kMultiB;
-    DPR_HIP(hipMalloc(&p.partials_multi, sizeof(PlacePartial) * (size_t)(2 * p.nparts_multi)));      // block minima + their runner-ups
+    DPR_HIP(hipMalloc(&p.partials_multi, sizeof(PlacePartial) * (size_t)p.nparts_multi));
     return DPR_OK;
 }
 
@@ -1212,10 +1167,8 @@ int place_tips(PlaceBuffers& p, const double* d_dis0, int64_t ldb, int64_t tip0,
             continue;
         }
         PlacePartial* parts = reinterpret_cast<PlacePartial*>(p.partials_multi);
-        PlacePartial* runs = parts + (int64_t)kMultiB * nblk;
-        hipLaunchKernelGGL(place_tip_multi_kernel, dim3((unsigned)nblk), dim3(kTipThreads), 0, s, p, d_dis0 + k * ldb, ldb, tip, nb, parts, runs, nblk);
-        hipLaunchKernelGGL(place_update_multi_kernel, dim3(1), dim3((nblk > 2048 || big_block) ? kMultiMaxThreads : kUpdThreads), 0, s, p, (const PlacePartial*)parts,
-                           (const PlacePartial*)runs, nblk, tip, nb,
+        hipLaunchKernelGGL(place_tip_multi_kernel, dim3((unsigned)nblk), dim3(kTipThreads), 0, s, p, d_dis0 + k * ldb, ldb, tip, nb, parts, nblk);
+        hipLaunchKernelGGL(place_update_multi_kernel, dim3(1), dim3((nblk > 2048 || big_block) ? kMultiMaxThreads : kUpdThreads), 0, s, p, (const PlacePartial*)parts, nblk, tip, nb,
                            d_dis0 + k * ldb, ldb, d_trace);
         DPR_HIP(hipGetLastError());
         k += nb;

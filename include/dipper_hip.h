@@ -175,9 +175,10 @@ int dpr_nj_is_unit_sharded(dpr_ctx *ctx);
 int dpr_ctx_set_nj_mode(dpr_ctx *ctx, int mode);
 int dpr_ctx_set_nj_multi_plan(dpr_ctx *ctx, int plan);
 /* Adaptive plan of the single-rank NJ (default on; DPR_NJ_ADAPTIVE=0 switches it off): the exact pruned scan while its
- * bounds prune; once more than half of an epoch's units are listed per iteration (divergent / tie-heavy / arbitrary `-i d`
- * matrices, src/matrix_reader.cu:23-45 feeds NJ anything) the rest of the epoch runs the full streaming scan of
- * src/neighborJoining.cu:117-148 on the same position-space matrix.  Same merge log either way. */
+ * bounds prune; once more than 70 % of an epoch's units are listed per iteration (tie-heavy / arbitrary `-i d` matrices,
+ * src/matrix_reader.cu:23-45 feeds NJ anything) the run is handed over to the streaming loop of src/neighborJoining.cu:
+ * 117-148,211-243 (dense slot-space matrix, one full Q scan per iteration); pruned epochs are probed again later with a
+ * back-off.  Same merge log either way. */
 int dpr_ctx_set_nj_adaptive(dpr_ctx *ctx, int on);
 int dpr_get_nj_adaptive_stats(dpr_ctx *ctx, int64_t *stream_iterations, int64_t *stream_epochs);
 /* Exchange plan of the ROW-SHARDED streaming NJ loop (several ranks, DPR_NJ_MODE=stream / dpr_ctx_set_nj_mode(ctx, 0);
