@@ -1479,8 +1479,8 @@ int dpr_place_run(dpr_ctx* c, int source, int dist_type, int k, int64_t first, i
 }
 
 // ---- exact placement mode -----------------------------------------------------------------------------
-int dpr_place_exact_run(dpr_ctx* c, int source, int dist_type, int k, int64_t n, int32_t* head, int32_t* e,
-                        int32_t* nxt, int32_t* belong, double* len)
+static int place_exact_attempt(dpr_ctx* c, int source, int dist_type, int k, int64_t n, int32_t* head, int32_t* e,
+                               int32_t* nxt, int32_t* belong, double* len)
 {
     if (!c || !head || !e || !nxt || !belong || !len || n < 3) { set_error("dpr_place_exact_run: bad argument"); return DPR_ERR_ARG; }
     DPR_HIP(hipSetDevice(c->device));
@@ -1541,6 +1541,25 @@ int dpr_place_exact_run(dpr_ctx* c, int source, int dist_type, int k, int64_t n,
     DPR_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
     c->nj_ms = ms;
     return DPR_OK;
+}
+
+int dpr_place_exact_run(dpr_ctx* c, int source, int dist_type, int k, int64_t n, int32_t* head, int32_t* e,
+                        int32_t* nxt, int32_t* belong, double* len)
+{
+    if (!c) { set_error("dpr_place_exact_run: bad argument"); return DPR_ERR_ARG; }
+    // The fast schedule (small subtrees on all CUs + top tree in LDS) gives the reference's lim[] whenever the reference's
+    // depths are the tree's depths.  They stop being that only if the default tuple (slot 0, pendant length 2) wins an argmin
+    // (updateTreeStructure's swap, src/placement.cu:236-239); the run is then repeated with the literal level-by-depth
+    // schedule, the only one that reproduces what the reference computes from there on.
+    c->exact.literal = std::getenv("DPR_EXACT_LITERAL") != nullptr;
+    int rc = place_exact_attempt(c, source, dist_type, k, n, head, e, nxt, belong, len);
+    if (rc != DPR_OK || c->exact.literal) return rc;
+    bool quirk = false;
+    if (int rq = exact_quirk(c->exact, c->stream, &quirk)) return rq;
+    if (!quirk) return DPR_OK;
+    c->exact.literal = true;
+    rc = place_exact_attempt(c, source, dist_type, k, n, head, e, nxt, belong, len);
+    return rc;
 }
 
 int dpr_get_exact_state(dpr_ctx* c, int32_t* rev, int32_t* dep)

@@ -365,15 +365,30 @@ int place_tip(PlaceBuffers& p, const double* d_dis, int64_t tip, double* d_trace
 int place_tips(PlaceBuffers& p, const double* d_dis0, int64_t ldb, int64_t tip0, int64_t count, double* d_trace, hipStream_t s);
 
 // exact.hip: exact placement mode (src/placement.cu)
+struct XStep {                   // scalars of the last split (device), and the counters of the two node lists
+    int rrk, ysz, small;         // rank the new internal node takes (= old rank of y), size of y's subtree, last rank of the moved subtree
+    int middle, outside;
+    int nroot, ntop;
+    int quirk;                   // the reference's swap in updateTreeStructure was taken: its depths are no tree depths any more (see exact.hip)
+};
 struct ExactBuffers {
     double* lim = nullptr;       // [8N] per directed slot
     int32_t* dep = nullptr;      // [2N] depth below node N
-    int32_t* dfsrk = nullptr;    // [2N] DFS pre-order rank
-    int32_t* order = nullptr;    // [2N] placed nodes grouped by depth
+    int32_t* rk[2] = { nullptr, nullptr };   // [2N] DFS pre-order rank, double-buffered: placing tip i reads rk[i & 1] and writes rk[(i + 1) & 1]
+    int32_t* sz[2] = { nullptr, nullptr };   // [2N] nodes in the subtree, same buffering
+    int32_t* nar = nullptr;      // [2N] node at rank
+    int32_t* tix = nullptr;      // [2N] top node -> index in the level-sorted top list (-1: not a top node)
+    int32_t* roots = nullptr;    // roots of the small subtrees (<= 64 nodes, parent's subtree larger)
+    int32_t* tops = nullptr;     // nodes whose subtree has more than 64 nodes
+    int32_t* order = nullptr;    // [2N] top nodes grouped by depth
     int32_t* lvoff = nullptr;    // [2N+2] first index of every level in order[]
     int32_t* hist = nullptr;     // [2N+2]
     int32_t* nd = nullptr;       // [2N][12] node records: slot[3], reverse slot[3], target node[3], pad
+    XStep* st = nullptr;
     void* partials = nullptr;
+    int32_t* dfsrk = nullptr;    // literal schedule: the reference's single rank array (alias of rk[0])
+    bool literal = false;        // run the literal one-workgroup schedule (fallback / DPR_EXACT_LITERAL=1)
+    bool top_in_memory = false;  // tests (DPR_EXACT_TOP_MEM=1): the top-tree pass keeps its values in memory even when they fit LDS
 };
 int exact_alloc(ExactBuffers& x, int64_t N);
 void exact_free(ExactBuffers& x);
@@ -381,6 +396,7 @@ int exact_init(PlaceBuffers& p, ExactBuffers& x, const double* d_dis_row1, const
                hipStream_t s);
 int exact_tip(PlaceBuffers& p, ExactBuffers& x, int64_t tip, const double* d_dis_next, bool has_next, double* d_trace,
               hipStream_t s);
+int exact_quirk(ExactBuffers& x, hipStream_t s, bool* quirk);    // did the fast schedule meet the case only the literal one reproduces?
 
 // dc.hip: divide-and-conquer mode (cluster assignment + concurrent cluster trees)
 struct DcTable {

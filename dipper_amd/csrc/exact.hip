@@ -19,7 +19,11 @@
 
 namespace dpr {
 
-constexpr int kXT = 1024;   // threads of the single-workgroup step kernel
+constexpr int kXT = 1024;   // threads of the single-workgroup top-tree kernel
+constexpr int kSm = 64;     // a "small" subtree has at most this many nodes: one wavefront, one lane per node
+constexpr int kTopLds = 6144;   // top nodes whose pass values fit the workgroup's LDS (2 x 8 bytes each)
+constexpr int kTopLevLds = 4094;   // levels of the top tree whose offsets fit LDS
+constexpr int kTopReg = 4;         // top nodes per thread whose contexts stay in registers over both passes
 
 struct PlacePartialX { double add; int32_t idx; int32_t eid; double frac; };
 
@@ -39,6 +43,120 @@ __device__ __forceinline__ void px_retarget(const ExactBuffers& x, int node, int
         if (q[k] == slot) { q[3 + k] = new_rev; q[6 + k] = new_nb; }
 }
 
+// The recurrences of the two passes (src/placement.cu:296-364) are functions of a node's neighbours only, so ANY schedule
+// that evaluates children before parents (bottom-up) and parents before children (top-down) gives the reference's lim[] bit
+// for bit.  Round 3 schedule (the reference: one launch per tree level and direction; rounds 1-2: one workgroup, one barrier
+// per level, 18 MB per tip through one CU at 30 000 tips):
+//   * the tree is cut, per tip, into SMALL subtrees (maximal subtrees of <= 64 nodes) and the TOP tree above them.  With
+//     pre-order ranks and subtree sizes maintained next to the reference's depths, a small subtree is a contiguous run of ranks,
+//     "v is a block root" is a local test (size(v) <= 64 < size(parent(v))), and one WAVEFRONT evaluates a whole small subtree
+//     with one lane per node, the values travelling through LDS: all small subtrees in parallel on all CUs;
+//   * the top tree (a few per cent of the nodes) is evaluated level by level by one workgroup as before, but its values live
+//     in LDS, so a level costs an LDS round trip and a barrier instead of an L2 round trip;
+//   * the O(N) bookkeeping after a split (rank shift, depth update, subtree sizes, the node-at-rank table, the two node lists)
+//     is ONE elementwise kernel over all CUs: every new value is a pure function of the OLD arrays (double-buffered ranks and
+//     sizes) and four scalars of the split.  The end of the moved subtree, which the reference finds with a reduction over all
+//     nodes (findEndRk, :382-398 + thrust::reduce :746), is rank(y) + size(y) + 1 here -- the same number.
+
+// node context of a lane / thread: its (up to three) edges
+struct XCtx {
+    int v;                   // node (-1: idle lane)
+    int slot[3], rslot[3];
+    int ref[3];              // small subtrees: lane of the neighbour; top tree: index of the neighbour in the top list (-1: not a top node)
+    bool down[3];            // the edge leads to a child (pre-order rank of the neighbour is larger)
+    double len[3];
+    double init;             // 0, or the distance of the tip for a leaf (src/placement.cu:317-318)
+};
+
+__device__ __forceinline__ XCtx px_ctx(const ExactBuffers& x, const PlaceBuffers& p, const double* __restrict__ dis,
+                                       const int32_t* __restrict__ rk, int v, int base_rank, bool top)
+{
+    XCtx c;
+    c.v = v;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { c.slot[k] = -1; c.rslot[k] = -1; c.ref[k] = -1; c.down[k] = false; c.len[k] = 0; }
+    c.init = 0;
+    if (v < 0) return c;
+    const int4 a = reinterpret_cast<const int4*>(x.nd + 12 * (int64_t)v)[0];
+    const int4 b = reinterpret_cast<const int4*>(x.nd + 12 * (int64_t)v)[1];
+    const int4 cc = reinterpret_cast<const int4*>(x.nd + 12 * (int64_t)v)[2];
+    c.slot[0] = a.x; c.slot[1] = a.y; c.slot[2] = a.z;
+    c.rslot[0] = a.w; c.rslot[1] = b.x; c.rslot[2] = b.y;
+    const int nb[3] = { b.z, b.w, cc.x };
+    const int myrk = rk[v];
+    if (v < (int)p.N) c.init = dis[v];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (c.slot[k] >= 0) {
+            const int nrk = rk[nb[k]];
+            c.down[k] = nrk > myrk;
+            c.ref[k] = top ? x.tix[nb[k]] : nrk - base_rank;
+            c.len[k] = p.len[c.slot[k]];
+        }
+    return c;
+}
+
+// calculateBranchLength over the live slots + block-level first minimum
+__global__ __launch_bounds__(kThreads) void px_scan_kernel(PlaceBuffers p, ExactBuffers x, int64_t num,
+                                                           PlacePartialX* __restrict__ partials)
+{
+    __shared__ double sadd[kThreads / 64];
+    __shared__ int sidx[kThreads / 64];
+    const int64_t live = 4 * num - 4;
+    const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    double add = 2.0, d1 = 0.0;
+    int eid = 0;
+    const bool have = idx < live;
+    if (have && !(x.dep[p.belong[idx]] > x.dep[p.e[idx]])) {
+        eid = (int)idx;
+        double dis1 = x.lim[eid], dis2 = x.lim[p.rev[eid]];
+        const double L = p.len[eid];
+        double a = (dis1 + dis2 - L) / 2;
+        if (a < 0) a = 0;
+        dis1 -= a; dis2 -= a;
+        if (dis1 < 0) dis1 = 0;
+        if (dis2 < 0) dis2 = 0;
+        if (dis1 > L) { a += dis1 - L; dis1 = L; }
+        if (dis2 > L) { a += dis2 - L; dis2 = L; }
+        const double rest = L - dis1 - dis2;
+        dis1 += rest / 2; dis2 += rest / 2;
+        add = a; d1 = dis1;
+    }
+    double badd = have ? add : __builtin_inf();
+    int bidx = have ? (int)idx : 0x7fffffff;
+    if (have && !(add == add)) badd = __builtin_inf();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oa = __shfl_down(badd, off, 64);
+        const int oi = __shfl_down(bidx, off, 64);
+        if (oa < badd || (oa == badd && oi < bidx)) { badd = oa; bidx = oi; }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sadd[w] = badd; sidx[w] = bidx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < kThreads / 64; ++i)
+            if (sadd[i] < badd || (sadd[i] == badd && sidx[i] < bidx)) { badd = sadd[i]; bidx = sidx[i]; }
+        sadd[0] = badd; sidx[0] = bidx;
+    }
+    __syncthreads();
+    if (have && (int)idx == sidx[0]) {
+        PlacePartialX pp; pp.add = add; pp.idx = (int)idx; pp.eid = eid; pp.frac = d1;
+        partials[blockIdx.x] = pp;
+    }
+    if (threadIdx.x == 0 && sidx[0] == 0x7fffffff) {
+        PlacePartialX pp; pp.add = __builtin_inf(); pp.idx = 0x7fffffff; pp.eid = 0; pp.frac = 0;
+        partials[blockIdx.x] = pp;
+    }
+}
+
+// ================================================================================================
+// LITERAL schedule (rounds 1-2): one workgroup per tip, level lists over ALL nodes by the reference's depths, one barrier
+// per level.  Kept as the fallback for the one situation in which the reference's own result depends on its level order:
+// when the default tuple (slot 0, pendant length 2) wins the argmin, updateTreeStructure's swap (:236-239) leaves depths
+// that are not the tree's, and only the level-by-depth schedule reproduces what the reference then computes.  The fast
+// schedule notices (XStep::quirk) and dpr_place_exact_run repeats the run with this one; DPR_EXACT_LITERAL=1 forces it.
+// ================================================================================================
 // Node record (12 ints): the node's up to three slots, their reverse slots and their target nodes.  Slots
 // are write-once per node (a split only retargets them), so a record changes only where the split
 // happens.  With it a level step needs ONE dependent memory hop: everything that does not depend on the
@@ -140,63 +258,9 @@ __device__ void px_dp(const ExactBuffers& x, const PlaceBuffers& p, const double
     }
 }
 
-// calculateBranchLength over the live slots + block-level first minimum
-__global__ __launch_bounds__(kThreads) void px_scan_kernel(PlaceBuffers p, ExactBuffers x, int64_t num,
-                                                           PlacePartialX* __restrict__ partials)
-{
-    __shared__ double sadd[kThreads / 64];
-    __shared__ int sidx[kThreads / 64];
-    const int64_t live = 4 * num - 4;
-    const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    double add = 2.0, d1 = 0.0;
-    int eid = 0;
-    const bool have = idx < live;
-    if (have && !(x.dep[p.belong[idx]] > x.dep[p.e[idx]])) {
-        eid = (int)idx;
-        double dis1 = x.lim[eid], dis2 = x.lim[p.rev[eid]];
-        const double L = p.len[eid];
-        double a = (dis1 + dis2 - L) / 2;
-        if (a < 0) a = 0;
-        dis1 -= a; dis2 -= a;
-        if (dis1 < 0) dis1 = 0;
-        if (dis2 < 0) dis2 = 0;
-        if (dis1 > L) { a += dis1 - L; dis1 = L; }
-        if (dis2 > L) { a += dis2 - L; dis2 = L; }
-        const double rest = L - dis1 - dis2;
-        dis1 += rest / 2; dis2 += rest / 2;
-        add = a; d1 = dis1;
-    }
-    double badd = have ? add : __builtin_inf();
-    int bidx = have ? (int)idx : 0x7fffffff;
-    if (have && !(add == add)) badd = __builtin_inf();
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double oa = __shfl_down(badd, off, 64);
-        const int oi = __shfl_down(bidx, off, 64);
-        if (oa < badd || (oa == badd && oi < bidx)) { badd = oa; bidx = oi; }
-    }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) { sadd[w] = badd; sidx[w] = bidx; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < kThreads / 64; ++i)
-            if (sadd[i] < badd || (sadd[i] == badd && sidx[i] < bidx)) { badd = sadd[i]; bidx = sidx[i]; }
-        sadd[0] = badd; sidx[0] = bidx;
-    }
-    __syncthreads();
-    if (have && (int)idx == sidx[0]) {
-        PlacePartialX pp; pp.add = add; pp.idx = (int)idx; pp.eid = eid; pp.frac = d1;
-        partials[blockIdx.x] = pp;
-    }
-    if (threadIdx.x == 0 && sidx[0] == 0x7fffffff) {
-        PlacePartialX pp; pp.add = __builtin_inf(); pp.idx = 0x7fffffff; pp.eid = 0; pp.frac = 0;
-        partials[blockIdx.x] = pp;
-    }
-}
-
 // dis_tree != nullptr: build the initial two-tip tree from it (row of tip 1), then the passes for tip 2.
 // otherwise: place `tip` from the scan partials, patch ranks/depths/levels, passes for tip+1 (dis_next).
-__global__ __launch_bounds__(kXT) void px_step_kernel(PlaceBuffers p, ExactBuffers x,
+__global__ __launch_bounds__(kXT) void px_step_literal_kernel(PlaceBuffers p, ExactBuffers x,
                                                       const PlacePartialX* __restrict__ partials, int nparts,
                                                       int64_t tip, const double* __restrict__ dis_tree,
                                                       const double* __restrict__ dis_next, int has_next,
@@ -355,12 +419,505 @@ __global__ __launch_bounds__(kXT) void px_step_kernel(PlaceBuffers p, ExactBuffe
     px_dp(x, p, dis_next, maxdep);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// finish the argmin of the scan, split the edge (updateTreeStructure, src/placement.cu:199-243) and leave the scalars
+// of the split for the patch kernel.  One workgroup; thread 0 does the split.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void px_split_kernel(PlaceBuffers p, ExactBuffers x, const PlacePartialX* __restrict__ partials,
+                                                      int nparts, int64_t tip, double* __restrict__ trace)
+{
+    constexpr int kT = 256;
+    __shared__ double s_add[kT / 64], s_frac[kT / 64];
+    __shared__ int s_idx[kT / 64], s_eid[kT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int N = (int)p.N;
+    const int i = (int)tip;
+    const int32_t* __restrict__ rk_in = x.rk[i & 1];
+    const int32_t* __restrict__ sz_in = x.sz[i & 1];
+    // ---- thrust::min_element over all 4N-4 tuples, first occurrence
+    double badd = __builtin_inf(), bfrac = 0;
+    int bidx = 0x7fffffff, beid = 0;
+    for (int k = tid; k < nparts; k += kT) {
+        const PlacePartialX pp = partials[k];
+        if (pp.add < badd || (pp.add == badd && pp.idx < bidx)) { badd = pp.add; bidx = pp.idx; beid = pp.eid; bfrac = pp.frac; }
+    }
+    const int64_t live = 4 * (int64_t)i - 4, lim = 4 * (int64_t)N - 4;
+    if (tid == 0 && live < lim)   // slots >= 4i-4 all carry (0,0,2): the first of them competes
+        if (2.0 < badd || (2.0 == badd && (int)live < bidx)) { badd = 2.0; bidx = (int)live; beid = 0; bfrac = 0; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oa = __shfl_down(badd, off, 64), of = __shfl_down(bfrac, off, 64);
+        const int oi = __shfl_down(bidx, off, 64), oe = __shfl_down(beid, off, 64);
+        if (oa < badd || (oa == badd && oi < bidx)) { badd = oa; bidx = oi; beid = oe; bfrac = of; }
+    }
+    if (lane == 0) { s_add[w] = badd; s_idx[w] = bidx; s_eid[w] = beid; s_frac[w] = bfrac; }
+    __syncthreads();
+    if (tid != 0) return;
+    for (int k = 1; k < kT / 64; ++k)
+        if (s_add[k] < badd || (s_add[k] == badd && s_idx[k] < bidx)) { badd = s_add[k]; bidx = s_idx[k]; beid = s_eid[k]; bfrac = s_frac[k]; }
+    const int eid = beid;
+    const double fracLen = bfrac, addLen = badd;
+    if (trace) { trace[3 * i] = eid; trace[3 * i + 1] = fracLen; trace[3 * i + 2] = addLen; }
+    int ec = 4 * i - 4;
+    const int middle = i + N - 1, outside = i;
+    int xn = p.belong[eid], yn = p.e[eid];
+    const double originalDis = p.len[eid];
+    const int xe = eid, ye = p.rev[eid];   // the reference finds them by walking head[x] / head[y]
+    p.e[xe] = middle; p.len[xe] = fracLen; p.rev[xe] = ec;
+    p.e[ye] = middle; p.len[ye] -= fracLen; p.rev[ye] = ec + 1;
+    p.e[ec] = xn; p.len[ec] = fracLen; p.nxt[ec] = p.head[middle]; p.head[middle] = ec; p.belong[ec] = middle; p.rev[ec] = xe; ec++;
+    p.e[ec] = yn; p.len[ec] = originalDis - fracLen; p.nxt[ec] = p.head[middle]; p.head[middle] = ec; p.belong[ec] = middle; p.rev[ec] = ye; ec++;
+    p.e[ec] = middle; p.len[ec] = addLen; p.nxt[ec] = p.head[outside]; p.head[outside] = ec; p.belong[ec] = outside; p.rev[ec] = ec + 1; ec++;
+    p.e[ec] = outside; p.len[ec] = addLen; p.nxt[ec] = p.head[middle]; p.head[middle] = ec; p.belong[ec] = middle; p.rev[ec] = ec - 1; ec++;
+    // node records: x and y keep their slots, which now lead to `middle`
+    px_retarget(x, xn, xe, ec - 4, middle);
+    px_retarget(x, yn, ye, ec - 3, middle);
+    px_set_node(x, middle, ec - 4, xe, xn, ec - 3, ye, yn, ec - 1, ec - 2, outside);
+    px_set_node(x, outside, ec - 2, ec - 1, middle, -1, -1, -1, -1, -1, -1);
+    const bool quirk = rk_in[xn] > rk_in[yn];
+    if (quirk) { const int t2 = xn; yn = xn; xn = t2; }   // the reference's swap, :236-239: taken only when the default tuple (slot 0) won
+    // dfsrk[middle] = dfsrk[y], dfsrk[outside] = dfsrk[middle] + 1 and the shift of the ranks >= it: the patch kernel, from these
+    XStep st;
+    st.rrk = rk_in[yn];
+    st.ysz = sz_in[yn];
+    st.small = st.rrk + 1 + st.ysz;      // last rank of the moved subtree after the shift (findEndRk + reduce of the reference)
+    st.middle = middle; st.outside = outside;
+    st.nroot = 0; st.ntop = 0;
+    st.quirk = (x.st->quirk || quirk) ? 1 : 0;      // sticky: the host repeats the run with the literal schedule
+    x.dep[middle] = x.dep[xn]; x.dep[outside] = x.dep[middle] + 1;
+    *x.st = st;
+}
+
+// ------------------------------------------------------------------------------------------------
+// updateDfsRk (:366-379), updateDepth (:400-416), subtree sizes, node-at-rank table, small-subtree roots and top nodes:
+// elementwise over the placed nodes, every new value from the OLD rank / size arrays and the scalars of the split
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void px_patch_kernel(PlaceBuffers p, ExactBuffers x, int64_t tip)
+{
+    __shared__ int s_cnt[2], s_base[2];
+    const int N = (int)p.N, i = (int)tip;
+    const int tot = N + i;
+    const int idx = (int)((int64_t)blockIdx.x * kThreads + threadIdx.x);
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const bool live = idx < tot && px_placed(idx, i, N);
+    const XStep st = *x.st;            // (the two counters in it are being incremented: only the scalars of the split are used)
+    const int32_t* __restrict__ rk_in = x.rk[i & 1];
+    const int32_t* __restrict__ sz_in = x.sz[i & 1];
+    int32_t* __restrict__ rk_out = x.rk[(i + 1) & 1];
+    int32_t* __restrict__ sz_out = x.sz[(i + 1) & 1];
+    const int rrk = st.rrk;
+    auto new_rank = [&](int v) { if (v == st.middle) return rrk; if (v == st.outside) return rrk + 1; const int r = rk_in[v]; return r >= rrk ? r + 2 : r; };
+    auto new_size = [&](int v) {
+        if (v == st.middle) return st.ysz + 2;
+        if (v == st.outside) return 1;
+        const int r = rk_in[v], s = sz_in[v];
+        return (r < rrk && r + s > rrk) ? s + 2 : s;      // the ancestors of y gain the two new nodes
+    };
+    int kind = -1, mine = 0;          // 0: root of a small subtree, 1: top node
+    if (live) {
+        const int rn = new_rank(idx), sn = new_size(idx);
+        rk_out[idx] = rn;
+        sz_out[idx] = sn;
+        x.nar[rn] = idx;
+        x.tix[idx] = -1;
+        if (rn >= rrk && rn <= st.small) x.dep[idx] += 1;
+        // parent = the neighbour with the smaller rank
+        const int32_t* q = x.nd + 12 * (int64_t)idx;
+        int parent = -1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (q[k] >= 0 && new_rank(q[6 + k]) < rn) parent = q[6 + k];
+        if (sn > kSm) kind = 1;
+        else if (parent < 0 || new_size(parent) > kSm) kind = 0;
+        if (kind >= 0) mine = atomicAdd(&s_cnt[kind], 1);
+    }
+    // one append per block and list (a few thousand single appends to one counter cost more than the rest of the kernel)
+    __syncthreads();
+    if (threadIdx.x < 2 && s_cnt[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(threadIdx.x == 0 ? &x.st->nroot : &x.st->ntop, s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (kind == 0) x.roots[s_base[0] + mine] = idx;
+    else if (kind == 1) x.tops[s_base[1] + mine] = idx;
+}
+
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------------
+// bottom-up pass inside the small subtrees (updateFromBottomToTop, :296-329): one wavefront per subtree, lane = node in
+// pre-order, a node's value = lim[node -> parent]; children's values come from LDS
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void px_small_up_kernel(PlaceBuffers p, ExactBuffers x, const double* __restrict__ dis, int par)
+{
+    __shared__ double s_val[kThreads / 64][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nroot = x.st->nroot;
+    const int32_t* __restrict__ rk = x.rk[par];
+    const int32_t* __restrict__ sz = x.sz[par];
+    for (int r = (int)blockIdx.x * (kThreads / 64) + w; r < nroot; r += (int)gridDim.x * (kThreads / 64)) {
+        const int v0 = x.roots[r];
+        const int r0 = rk[v0], s = sz[v0], d0 = x.dep[v0];
+        const int v = lane < s ? x.nar[r0 + lane] : -1;
+        const XCtx c = px_ctx(x, p, dis, rk, v, r0, false);
+        const int ld = v >= 0 ? x.dep[v] - d0 : -1;
+        const int maxld = wave_max_i32(ld);
+        for (int lev = maxld; lev >= 0; --lev) {
+            if (ld == lev) {
+                double mx = c.init;
+                int up = -1;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if (c.slot[k] >= 0) {
+                        if (c.down[k]) { const double req = s_val[w][c.ref[k]] - c.len[k]; if (req > mx) mx = req; }
+                        else up = c.slot[k];
+                    }
+                s_val[w][lane] = mx;
+                if (up >= 0) x.lim[up] = mx;
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
+// top-down pass inside the small subtrees (updateFromTopToBottom, :331-364): the value a node receives from its parent
+// comes from LDS (the subtree's root: from memory, written by the top-tree kernel); children's bottom-up values from memory
+__global__ __launch_bounds__(kThreads) void px_small_down_kernel(PlaceBuffers p, ExactBuffers x, const double* __restrict__ dis, int par)
+{
+    __shared__ double s_in[kThreads / 64][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nroot = x.st->nroot;
+    const int32_t* __restrict__ rk = x.rk[par];
+    const int32_t* __restrict__ sz = x.sz[par];
+    for (int r = (int)blockIdx.x * (kThreads / 64) + w; r < nroot; r += (int)gridDim.x * (kThreads / 64)) {
+        const int v0 = x.roots[r];
+        const int r0 = rk[v0], s = sz[v0], d0 = x.dep[v0];
+        const int v = lane < s ? x.nar[r0 + lane] : -1;
+        const XCtx c = px_ctx(x, p, dis, rk, v, r0, false);
+        const int ld = v >= 0 ? x.dep[v] - d0 : -1;
+        const int maxld = wave_max_i32(ld);
+        // what does not depend on this pass: lim[child -> node] of the bottom-up pass, and for the subtree's root lim[parent -> root]
+        double inc[3] = { 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (c.slot[k] >= 0 && (c.down[k] || lane == 0)) inc[k] = x.lim[c.rslot[k]];
+        for (int lev = 0; lev <= maxld; ++lev) {
+            if (ld == lev) {
+                double rq[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    double in = inc[k];
+                    if (c.slot[k] >= 0 && !c.down[k] && lane != 0) in = s_in[w][lane];
+                    rq[k] = c.slot[k] >= 0 ? in - c.len[k] : 0.0;
+                }
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    if (c.slot[a] >= 0 && c.down[a]) {
+                        double mx = 0;
+#pragma unroll
+                        for (int b = 0; b < 3; ++b)
+                            if (b != a && c.slot[b] >= 0 && rq[b] > mx) mx = rq[b];
+                        x.lim[c.slot[a]] = mx;
+                        s_in[w][c.ref[a]] = mx;
+                    }
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the top tree: level lists by counting sort on depth (replaces stable_sort_by_key :766 + updateLevelStEd :419-434; the
+// order inside a level is irrelevant to every result), then both passes level by level, one workgroup barrier per level;
+// values in LDS when the top tree fits (else in memory, as rounds 1-2 did for the whole tree)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kXT) void px_top_kernel(PlaceBuffers p, ExactBuffers x, const double* __restrict__ dis, int par)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];      // [2][kTopLds]: bottom-up value, value received from the parent
+    __shared__ int s_red[kXT / 64], s_maxdep;
+    __shared__ int s_lv[kTopLevLds + 2];                                // level offsets (lists of at most kTopLevLds levels: else in memory)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int T = x.st->ntop;
+    if (T == 0) return;
+    const int32_t* __restrict__ rk = x.rk[par];
+    const bool lds = T <= kTopLds && !x.top_in_memory;
+    double* up_l = s_dyn;
+    double* in_l = s_dyn + kTopLds;
+    int mymax = 0;
+    for (int t = tid; t < T; t += kXT) mymax = max(mymax, x.dep[x.tops[t]]);
+    mymax = wave_max_i32(mymax);
+    if (lane == 0) s_red[w] = mymax;
+    __syncthreads();
+    if (tid == 0) {
+        int m = 0;
+        for (int k = 0; k < kXT / 64; ++k) m = max(m, s_red[k]);
+        s_maxdep = m;
+    }
+    __syncthreads();
+    const int maxdep = s_maxdep;
+    const bool lvl = maxdep + 2 <= kTopLevLds + 2;                       // histogram / level offsets in LDS
+    int* hist = lvl ? s_lv : x.hist;
+    for (int k = tid; k <= maxdep + 1; k += kXT) hist[k] = 0;
+    __syncthreads();
+    for (int t = tid; t < T; t += kXT) atomicAdd(&hist[x.dep[x.tops[t]]], 1);
+    __syncthreads();
+    {
+        const int nlev = maxdep + 1;
+        const int per = (nlev + kXT - 1) / kXT;
+        const int b0 = tid * per, b1 = min(nlev, b0 + per);
+        int sum = 0;
+        for (int k = b0; k < b1; ++k) sum += hist[k];
+        // exclusive scan of the per-thread sums over the workgroup: wave scans + the 16 wave totals (thread 0 walking all
+        // 1 024 LDS entries one after the other, as the literal kernel does, was ~100 us of this kernel's 128)
+        int incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_red[w] = incl;
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int k = 0; k < kXT / 64; ++k) { const int v = s_red[k]; s_red[k] = run; run += v; }
+        }
+        __syncthreads();
+        int run = s_red[w] + incl - sum;
+        for (int k = b0; k < b1; ++k) { const int v = hist[k]; x.lvoff[k] = run; hist[k] = run; run += v; }
+        if (tid == 0) x.lvoff[nlev] = T;
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += kXT) {
+        const int idx = x.tops[t];
+        const int pos = atomicAdd(&hist[x.dep[idx]], 1);
+        x.order[pos] = idx;
+        x.tix[idx] = pos;
+    }
+    __syncthreads();
+    // after the scatter hist[k] = first index of level k + 1: the level offsets without another pass (LDS copy)
+    auto lv0 = [&](int j) { return j == 0 ? 0 : (lvl ? s_lv[j - 1] : x.lvoff[j]); };
+    auto lv1 = [&](int j) { return lvl ? s_lv[j] : x.lvoff[j + 1]; };
+    // context of this thread's first node of a level, loaded ONE LEVEL AHEAD of its use: what a level then costs is an LDS
+    // round trip and the barrier.  The values of children outside the top tree (small-subtree roots: written by the small
+    // bottom-up kernel before this launch) are loaded with it.
+    struct TCtx { XCtx c; double cv[3]; };
+    auto load = [&](int j) {
+        TCtx r;
+        const int t = lv0(j) + tid;
+        r.c = px_ctx(x, p, dis, rk, t < lv1(j) ? x.order[t] : -1, 0, true);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            r.cv[k] = (r.c.slot[k] >= 0 && r.c.down[k] && !(lds && r.c.ref[k] >= 0)) ? x.lim[r.c.rslot[k]] : 0.0;
+        return r;
+    };
+    auto up_node = [&](const XCtx& c, const double* cv, int t, bool fresh) {
+        double mx = c.init;
+        int up = -1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (c.slot[k] >= 0) {
+                if (c.down[k]) {
+                    double v;
+                    if (lds && c.ref[k] >= 0) v = up_l[c.ref[k]];
+                    else v = fresh ? x.lim[c.rslot[k]] : cv[k];       // memory mode: a top child's value is one level old -> read now
+                    const double req = v - c.len[k];
+                    if (req > mx) mx = req;
+                } else up = c.slot[k];
+            }
+        if (lds) up_l[t] = mx;
+        if (up >= 0) x.lim[up] = mx;
+    };
+    auto down_node = [&](const XCtx& c, const double* cv, int t) {
+        double rq[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double in = 0.0;
+            if (c.slot[k] >= 0) {
+                if (!c.down[k]) in = lds ? in_l[t] : x.lim[c.rslot[k]];
+                else in = (lds && c.ref[k] >= 0) ? up_l[c.ref[k]] : cv[k];      // bottom-up values are final by now
+            }
+            rq[k] = c.slot[k] >= 0 ? in - c.len[k] : 0.0;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            if (c.slot[a] >= 0 && c.down[a]) {
+                double mx = 0;
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+                    if (b != a && c.slot[b] >= 0 && rq[b] > mx) mx = rq[b];
+                x.lim[c.slot[a]] = mx;
+                if (lds && c.ref[a] >= 0) in_l[c.ref[a]] = mx;
+            }
+    };
+    if (lds && T <= kTopReg * kXT) {
+        // ---- the common case: every thread keeps the contexts of its (at most kTopReg) top nodes in registers for both
+        // passes, all their loads in flight together up front.  Loading a level's contexts inside the level loop -- even one
+        // level ahead -- left a chain of three dependent memory round trips per level (list entry -> node record -> the
+        // neighbours' ranks / indices / lengths): 1.15 us per level, 118 us per tip at 30 000 tips.  A level now costs LDS
+        // traffic and the barrier.  (A top node is never a leaf: its start value is 0.)
+        struct RCtx { int slot[3]; int rf[3]; double len[3]; double cv[3]; };     // rf: -1 no edge; else (ref + 1) << 1 | down
+        RCtx rc[kTopReg];
+#pragma unroll
+        for (int m = 0; m < kTopReg; ++m) {
+            const int t = tid + m * kXT;
+            const XCtx c = px_ctx(x, p, dis, rk, t < T ? x.order[t] : -1, 0, true);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                rc[m].slot[k] = c.slot[k];
+                rc[m].rf[k] = c.slot[k] >= 0 ? (((c.ref[k] + 1) << 1) | (c.down[k] ? 1 : 0)) : -1;
+                rc[m].len[k] = c.len[k];
+                rc[m].cv[k] = (c.slot[k] >= 0 && c.down[k] && c.ref[k] < 0) ? x.lim[c.rslot[k]] : 0.0;    // child outside the top tree
+            }
+        }
+        for (int j = maxdep; j >= 0; --j) {
+            const int t0 = lv0(j), t1 = lv1(j);
+#pragma unroll
+            for (int m = 0; m < kTopReg; ++m) {
+                const int t = tid + m * kXT;
+                if (t >= t0 && t < t1) {
+                    double mx = 0.0;
+                    int up = -1;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        if (rc[m].rf[k] >= 0) {
+                            if (rc[m].rf[k] & 1) {
+                                const int ref = (rc[m].rf[k] >> 1) - 1;
+                                const double req = (ref >= 0 ? up_l[ref] : rc[m].cv[k]) - rc[m].len[k];
+                                if (req > mx) mx = req;
+                            } else up = rc[m].slot[k];
+                        }
+                    up_l[t] = mx;
+                    if (up >= 0) x.lim[up] = mx;
+                }
+            }
+            __syncthreads();
+        }
+        for (int j = 0; j <= maxdep; ++j) {
+            const int t0 = lv0(j), t1 = lv1(j);
+#pragma unroll
+            for (int m = 0; m < kTopReg; ++m) {
+                const int t = tid + m * kXT;
+                if (t >= t0 && t < t1) {
+                    double rq[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        double in = 0.0;
+                        if (rc[m].rf[k] >= 0) {
+                            const int ref = (rc[m].rf[k] >> 1) - 1;
+                            if (!(rc[m].rf[k] & 1)) in = in_l[t];
+                            else in = ref >= 0 ? up_l[ref] : rc[m].cv[k];
+                        }
+                        rq[k] = rc[m].rf[k] >= 0 ? in - rc[m].len[k] : 0.0;
+                    }
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+                        if (rc[m].rf[a] >= 0 && (rc[m].rf[a] & 1)) {
+                            double mx = 0;
+#pragma unroll
+                            for (int b = 0; b < 3; ++b)
+                                if (b != a && rc[m].rf[b] >= 0 && rq[b] > mx) mx = rq[b];
+                            x.lim[rc[m].slot[a]] = mx;
+                            const int ref = (rc[m].rf[a] >> 1) - 1;
+                            if (ref >= 0) in_l[ref] = mx;
+                        }
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // ---- bottom-up: lim[node -> parent] = max(init, max over the child edges of lim[child -> node] - len)
+    {
+        TCtx cur = load(maxdep);
+        for (int j = maxdep; j >= 0; --j) {
+            const int t0 = lv0(j), t1 = lv1(j);
+            TCtx nxt;
+            nxt.c.v = -1;
+            if (j > 0) nxt = load(j - 1);
+            if (cur.c.v >= 0) up_node(cur.c, cur.cv, t0 + tid, !lds);
+            for (int t = t0 + tid + kXT; t < t1; t += kXT) {
+                const XCtx c = px_ctx(x, p, dis, rk, x.order[t], 0, true);
+                double cv[3] = { 0.0, 0.0, 0.0 };
+                up_node(c, cv, t, true);
+            }
+            __syncthreads();
+            cur = nxt;
+        }
+    }
+    // ---- top-down: lim[node -> child] = max(0, max over the node's other edges of lim[other -> node] - len)
+    {
+        auto load_dn = [&](int j) {      // children's bottom-up values are final now: all of them can come with the context
+            TCtx r;
+            const int t = lv0(j) + tid;
+            r.c = px_ctx(x, p, dis, rk, t < lv1(j) ? x.order[t] : -1, 0, true);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                r.cv[k] = (r.c.slot[k] >= 0 && r.c.down[k] && !(lds && r.c.ref[k] >= 0)) ? x.lim[r.c.rslot[k]] : 0.0;
+            return r;
+        };
+        TCtx cur = load_dn(0);
+        for (int j = 0; j <= maxdep; ++j) {
+            const int t0 = lv0(j), t1 = lv1(j);
+            TCtx nxt;
+            nxt.c.v = -1;
+            if (j < maxdep) nxt = load_dn(j + 1);
+            if (cur.c.v >= 0) down_node(cur.c, cur.cv, t0 + tid);
+            for (int t = t0 + tid + kXT; t < t1; t += kXT) {
+                const XCtx c = px_ctx(x, p, dis, rk, x.order[t], 0, true);
+                double cv[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) cv[k] = (c.slot[k] >= 0 && c.down[k]) ? x.lim[c.rslot[k]] : 0.0;
+                down_node(c, cv, t);
+            }
+            __syncthreads();
+            cur = nxt;
+        }
+    }
+}
+
 // initialize (src/placement.cu:119-140)
 __global__ __launch_bounds__(kThreads) void px_init_kernel(PlaceBuffers p, ExactBuffers x, int64_t lim, int64_t nodes)
 {
     const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (idx < lim) { p.nxt[idx] = -1; p.e[idx] = -1; p.belong[idx] = -1; p.rev[idx] = -1; }
-    if (idx < nodes) { p.head[idx] = -1; x.dep[idx] = (int)(nodes * 10); x.dfsrk[idx] = -1; }
+    if (idx < nodes) { p.head[idx] = -1; x.dep[idx] = (int)(nodes * 10); x.rk[0][idx] = -1; x.rk[1][idx] = -1; x.sz[0][idx] = 0; x.sz[1][idx] = 0; x.tix[idx] = -1; }
+}
+
+// buildInitialTree (src/placement.cu:245-293) from the row of tip 1; ranks, sizes and lists of the three-node tree
+__global__ void px_init_tree_kernel(PlaceBuffers p, ExactBuffers x, const double* __restrict__ dis_tree)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int nv = (int)p.N;
+    const double d = dis_tree[0];
+    int ec = 0;
+    p.e[ec] = nv; p.len[ec] = d / 2; p.nxt[ec] = p.head[0]; p.head[0] = ec; p.belong[ec] = 0; ec++;
+    p.e[ec] = nv; p.len[ec] = d / 2; p.nxt[ec] = p.head[1]; p.head[1] = ec; p.belong[ec] = 1; ec++;
+    p.e[ec] = 0;  p.len[ec] = d / 2; p.nxt[ec] = p.head[nv]; p.head[nv] = ec; p.belong[ec] = nv; ec++;
+    p.e[ec] = 1;  p.len[ec] = d / 2; p.nxt[ec] = p.head[nv]; p.head[nv] = ec; p.belong[ec] = nv; ec++;
+    p.rev[0] = 2; p.rev[2] = 0; p.rev[1] = 3; p.rev[3] = 1;
+    x.dep[nv] = 0; x.dep[0] = 1; x.dep[1] = 1;
+    // (the state before tip 2 is placed: buffers of parity 2 & 1 = 0)
+    x.rk[0][nv] = 0; x.rk[0][0] = 1; x.rk[0][1] = 2;
+    x.sz[0][nv] = 3; x.sz[0][0] = 1; x.sz[0][1] = 1;
+    x.nar[0] = nv; x.nar[1] = 0; x.nar[2] = 1;
+    px_set_node(x, 0, 0, 2, nv, -1, -1, -1, -1, -1, -1);
+    px_set_node(x, 1, 1, 3, nv, -1, -1, -1, -1, -1, -1);
+    px_set_node(x, nv, 2, 0, 0, 3, 1, 1, -1, -1, -1);
+    XStep st;
+    st.rrk = 0; st.ysz = 0; st.small = 0; st.middle = -1; st.outside = -1;
+    st.nroot = 1; st.ntop = 0;
+    st.quirk = 0;
+    x.roots[0] = nv;
+    *x.st = st;
 }
 
 int exact_alloc(ExactBuffers& x, int64_t N)
@@ -368,21 +925,48 @@ int exact_alloc(ExactBuffers& x, int64_t N)
     exact_free(x);
     DPR_HIP(hipMalloc(&x.lim, sizeof(double) * (size_t)(8 * N)));
     DPR_HIP(hipMalloc(&x.dep, sizeof(int32_t) * (size_t)(2 * N)));
-    DPR_HIP(hipMalloc(&x.dfsrk, sizeof(int32_t) * (size_t)(2 * N)));
+    for (int k = 0; k < 2; ++k) {
+        DPR_HIP(hipMalloc(&x.rk[k], sizeof(int32_t) * (size_t)(2 * N)));
+        DPR_HIP(hipMalloc(&x.sz[k], sizeof(int32_t) * (size_t)(2 * N)));
+    }
+    DPR_HIP(hipMalloc(&x.nar, sizeof(int32_t) * (size_t)(2 * N + 2)));
+    DPR_HIP(hipMalloc(&x.tix, sizeof(int32_t) * (size_t)(2 * N)));
+    DPR_HIP(hipMalloc(&x.roots, sizeof(int32_t) * (size_t)(2 * N)));
+    DPR_HIP(hipMalloc(&x.tops, sizeof(int32_t) * (size_t)(2 * N)));
     DPR_HIP(hipMalloc(&x.order, sizeof(int32_t) * (size_t)(2 * N)));
     DPR_HIP(hipMalloc(&x.lvoff, sizeof(int32_t) * (size_t)(2 * N + 2)));
     DPR_HIP(hipMalloc(&x.hist, sizeof(int32_t) * (size_t)(2 * N + 2)));
     DPR_HIP(hipMalloc(&x.nd, sizeof(int32_t) * (size_t)(12 * 2 * N)));
+    x.dfsrk = x.rk[0];
+    x.top_in_memory = std::getenv("DPR_EXACT_TOP_MEM") != nullptr;
+    DPR_HIP(hipMalloc(&x.st, sizeof(XStep)));
+    DPR_HIP(hipMemset(x.st, 0, sizeof(XStep)));
     DPR_HIP(hipMalloc(&x.partials, sizeof(PlacePartialX) * (size_t)((4 * N + kThreads - 1) / kThreads + 1)));
+    DPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(px_top_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(double) * 2 * kTopLds)));
     return DPR_OK;
 }
 
 void exact_free(ExactBuffers& x)
 {
-    void* ptrs[] = { x.lim, x.dep, x.dfsrk, x.order, x.lvoff, x.hist, x.partials, x.nd };
+    void* ptrs[] = { x.lim, x.dep, x.rk[0], x.rk[1], x.sz[0], x.sz[1], x.nar, x.tix, x.roots, x.tops, x.order, x.lvoff, x.hist, x.partials, x.nd, x.st };
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
+    const bool literal = x.literal;
     x = ExactBuffers();
+    x.literal = literal;
+}
+
+// the two passes for the tip whose distance row is `dis`, on the tree as it stands (rank / size buffers of parity `par`)
+static int exact_passes(PlaceBuffers& p, ExactBuffers& x, const double* dis, int par, int64_t placed_nodes, hipStream_t s)
+{
+    int64_t g = (placed_nodes + 63) / 64;        // ~ one wavefront per 16 nodes: the subtree roots are a few per cent of the nodes
+    g = g < 1 ? 1 : (g > 2048 ? 2048 : g);
+    hipLaunchKernelGGL(px_small_up_kernel, dim3((unsigned)g), dim3(kThreads), 0, s, p, x, dis, par);
+    hipLaunchKernelGGL(px_top_kernel, dim3(1), dim3(kXT), sizeof(double) * 2 * kTopLds, s, p, x, dis, par);
+    hipLaunchKernelGGL(px_small_down_kernel, dim3((unsigned)g), dim3(kThreads), 0, s, p, x, dis, par);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
 }
 
 // initialize + buildInitialTree (row of tip 1) + the passes for tip 2 (its row)
@@ -392,9 +976,15 @@ int exact_init(PlaceBuffers& p, ExactBuffers& x, const double* d_dis_row1, const
     const int64_t lim = 4 * p.N - 4, nodes = 2 * p.N - 1;
     DPR_HIP(hipMemsetAsync(x.lim, 0, sizeof(double) * (size_t)(8 * p.N), s));
     hipLaunchKernelGGL(px_init_kernel, dim3((unsigned)((lim + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, x, lim, nodes);
-    hipLaunchKernelGGL(px_step_kernel, dim3(1), dim3(kXT), 0, s, p, x, (const PlacePartialX*)nullptr, 0, (int64_t)1,
-                       d_dis_row1, d_dis_row2, has_tip2 ? 1 : 0, (double*)nullptr);
+    if (x.literal) {
+        hipLaunchKernelGGL(px_step_literal_kernel, dim3(1), dim3(kXT), 0, s, p, x, (const PlacePartialX*)nullptr, 0, (int64_t)1,
+                           d_dis_row1, d_dis_row2, has_tip2 ? 1 : 0, (double*)nullptr);
+        DPR_HIP(hipGetLastError());
+        return DPR_OK;
+    }
+    hipLaunchKernelGGL(px_init_tree_kernel, dim3(1), dim3(64), 0, s, p, x, d_dis_row1);
     DPR_HIP(hipGetLastError());
+    if (has_tip2) return exact_passes(p, x, d_dis_row2, 0, 3, s);
     return DPR_OK;
 }
 
@@ -406,9 +996,28 @@ int exact_tip(PlaceBuffers& p, ExactBuffers& x, int64_t tip, const double* d_dis
     const int nblk = (int)((live + kThreads - 1) / kThreads);
     PlacePartialX* parts = reinterpret_cast<PlacePartialX*>(x.partials);
     hipLaunchKernelGGL(px_scan_kernel, dim3((unsigned)nblk), dim3(kThreads), 0, s, p, x, tip, parts);
-    hipLaunchKernelGGL(px_step_kernel, dim3(1), dim3(kXT), 0, s, p, x, (const PlacePartialX*)parts, nblk, tip,
-                       (const double*)nullptr, d_dis_next, has_next ? 1 : 0, d_trace);
+    if (x.literal) {
+        hipLaunchKernelGGL(px_step_literal_kernel, dim3(1), dim3(kXT), 0, s, p, x, (const PlacePartialX*)parts, nblk, tip,
+                           (const double*)nullptr, d_dis_next, has_next ? 1 : 0, d_trace);
+        DPR_HIP(hipGetLastError());
+        return DPR_OK;
+    }
+    hipLaunchKernelGGL(px_split_kernel, dim3(1), dim3(256), 0, s, p, x, (const PlacePartialX*)parts, nblk, tip, d_trace);
+    const int64_t tot = p.N + tip;
+    hipLaunchKernelGGL(px_patch_kernel, dim3((unsigned)((tot + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, x, tip);
     DPR_HIP(hipGetLastError());
+    if (has_next) return exact_passes(p, x, d_dis_next, (int)((tip + 1) & 1), 2 * tip + 1, s);
+    return DPR_OK;
+}
+
+int exact_quirk(ExactBuffers& x, hipStream_t s, bool* quirk)
+{
+    *quirk = false;
+    if (x.literal || !x.st) return DPR_OK;
+    XStep st;
+    DPR_HIP(hipMemcpyAsync(&st, x.st, sizeof(XStep), hipMemcpyDeviceToHost, s));
+    DPR_HIP(hipStreamSynchronize(s));
+    *quirk = st.quirk != 0;
     return DPR_OK;
 }
 

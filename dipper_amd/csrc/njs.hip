@@ -448,7 +448,8 @@ static NjsArgs njs_args(NjBuffers& b, int64_t n, int64_t it, bool pending)
     // blocks of the scan: the single-GPU grid (2 048) by default; a rank streams only 1 / world of the triangle, so a
     // smaller grid may ramp and drain faster (DPR_NJS_GRID, profiles/njs_vworld_stats.py)
     static const int env_grid = std::getenv("DPR_NJS_GRID") ? std::atoi(std::getenv("DPR_NJS_GRID")) : 0;
-    a.nparts = env_grid >= 64 && env_grid <= kScanBlocks ? env_grid : nj_scan_grid();
+    // (measured with 8 virtual ranks at 30 000 tips: 97.6 / 93.1 / 93.4 us per rank and iteration with 2 048 / 1 024 / 512 blocks)
+    a.nparts = env_grid >= 64 && env_grid <= kScanBlocks ? env_grid : (b.world >= 4 ? 1024 : nj_scan_grid());
     a.poll_ticks = b.peer.poll_ticks;
     a.seq_base = b.peer.run_id << 32;
     a.log_x = b.log_x; a.log_y = b.log_y; a.log_bx = b.log_bx; a.log_by = b.log_by;

@@ -84,3 +84,57 @@ def test_exact_msa_and_mash_sources(gpu, orc):
     M = gpu.matrix()
     got = gpu.place_exact_run(capi.SRC_MASH, len(reads), k=15)
     _same_exact_state(got, orc.place_exact_run(M), len(reads))
+
+
+def test_exact_default_tuple_wins_falls_back_to_literal_schedule(gpu, orc):
+    """Large distances: the pendant length of every candidate exceeds 2, so the default tuple (slot 0, 2.0) wins the argmin,
+    the reference's swap in updateTreeStructure (src/placement.cu:236-239) is taken and its depths stop being tree depths.
+    Only the level-by-depth schedule reproduces what the reference computes from there on: the fast schedule flags the
+    case and the run is repeated literally -- same state as the oracle."""
+    from dipper_amd import capi
+    rng = np.random.default_rng(4)
+    n = 120
+    D = _util.random_additive_matrix(rng, n) * 6.0
+    gpu.set_matrix_full(D)
+    got = gpu.place_exact_run(capi.SRC_MATRIX, n)
+    ref = orc.place_exact_run(D)
+    assert np.any(ref["trace"][2:, 2] == 2.0)          # the default tuple did win
+    _same_exact_state(got, ref, n)
+
+
+@pytest.mark.parametrize("n", [9, 300, 1100])
+def test_exact_literal_schedule_forced(monkeypatch, orc, n):
+    """the one-workgroup literal schedule (rounds 1-2) stays under test: DPR_EXACT_LITERAL=1"""
+    import dipper_amd
+    from dipper_amd import capi
+    monkeypatch.setenv("DPR_EXACT_LITERAL", "1")
+    rng = np.random.default_rng(n)
+    D = _util.random_additive_matrix(rng, n, zero_frac=0.3)
+    D *= 0.9 / D.max()
+    d = dipper_amd.Dipper(0)
+    try:
+        d.set_matrix_full(D)
+        _same_exact_state(d.place_exact_run(capi.SRC_MATRIX, n), orc.place_exact_run(D), n)
+    finally:
+        d.close()
+
+
+@pytest.mark.parametrize("top_mem", [False, True], ids=["top_in_lds", "top_in_memory"])
+def test_exact_larger_tree_both_top_variants(monkeypatch, orc, top_mem):
+    """4 000 tips: hundreds of top nodes above the one-wavefront subtrees; the top-tree pass with its values in LDS and
+    (forced: what trees beyond ~100 000 tips use) in memory"""
+    import dipper_amd
+    from dipper_amd import capi
+    if top_mem:
+        monkeypatch.setenv("DPR_EXACT_TOP_MEM", "1")
+    rng = np.random.default_rng(77)
+    n = 4000
+    D = _util.random_additive_matrix(rng, n, zero_frac=0.2)
+    D *= 0.9 / D.max()
+    ref = orc.place_exact_run(D)
+    d = dipper_amd.Dipper(0)
+    try:
+        d.set_matrix_full(D)
+        _same_exact_state(d.place_exact_run(capi.SRC_MATRIX, n), ref, n)
+    finally:
+        d.close()
