@@ -486,8 +486,12 @@ __global__ __launch_bounds__(kThreads) void njp_finish_kernel(NjpArgs a)
 //    the same way; the row of the node that LEAVES quarantine (merge it - 1, row buffer R[(it - 1) & 1]) is
 //    folded into the bounds of the sub-units it crosses; survivors are appended to the list of scan it + 1.
 // ------------------------------------------------------------------------------------------------
+// (large shape: DPR_NJP_BIG_WAVES = waves per SIMD the compiler has to leave room for -- experiment knob)
+#ifndef DPR_NJP_BIG_WAVES
+#define DPR_NJP_BIG_WAVES 1
+#endif
 template <int kTG, int kNS>
-__global__ __launch_bounds__(kThreads) void njp_post_kernel(NjpArgs a)
+__global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void njp_post_kernel(NjpArgs a)
 {
     __shared__ double s[kThreads];
     __shared__ double sq[kThreads / 64], sdd[kThreads / 64];

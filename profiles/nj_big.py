@@ -12,9 +12,13 @@ L = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 runs = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 t0 = time.perf_counter()
 k = 10000 / L
-seqs = _util.synth_alignment(np.random.default_rng(8), n, L, mean_bl=2e-5 * k, lo=2e-6 * k, hi=2e-4 * k)
-packed = capi.pack4_many(seqs)
-del seqs
+import subprocess, tempfile
+_tmp = tempfile.mkdtemp(prefix="njbig_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+_p4 = os.path.join(_tmp, "a.p4")
+subprocess.run([os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "tools", "bin", "gen_synth"), "--tips", str(n), "--sites", str(L), "--seed", "8",
+                "--mean-bl", repr(2e-5 * k), "--lo", repr(2e-6 * k), "--hi", repr(2e-4 * k), "--packed4", _p4], check=True)
+packed = np.fromfile(_p4, dtype=np.uint64).reshape(n, (L + 15) // 16)
+os.unlink(_p4); os.rmdir(_tmp)
 print(f"input {n} x {L} in {time.perf_counter()-t0:.1f}s", flush=True)
 d = dipper_amd.Dipper(0)
 d.set_msa(packed, L)
@@ -26,5 +30,9 @@ for r in range(runs):
     wall = time.perf_counter() - t0
     dist_ms, nj_ms = d.timing()
     sc, full = d.prune_stats()
-    out.append(dict(wall_s=wall, dist_ms=dist_ms, nj_ms=nj_ms, units_scanned=sc, us_per_iteration=nj_ms * 1e3 / (n - 2)))
+    import hashlib
+    h = hashlib.sha256()
+    for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
+        h.update(np.ascontiguousarray(res[key]).tobytes())
+    out.append(dict(wall_s=wall, dist_ms=dist_ms, nj_ms=nj_ms, units_scanned=sc, us_per_iteration=nj_ms * 1e3 / (n - 2), digest=h.hexdigest()[:16]))
     print(json.dumps(out[-1]), flush=True)
