@@ -405,6 +405,11 @@ def main():
         torch.cuda.synchronize()
 
     out = {}
+    # the native input generator and the nRF tool are built by __graft_entry__.build(); a tree that was copied without its
+    # binaries builds them here (g++ only), once, before any rank needs them
+    if rank == 0 and not (os.path.exists(GEN) and os.path.exists(NRF)):
+        log("[bench] building tools/ (gen_synth, nrf)")
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tools")], check=True, capture_output=True)
     stage = Stage(rank, world, dist)
 
     # ONE watchdog for the whole run: a hung collective (or anything else) must not outlive the driver's limit -- the

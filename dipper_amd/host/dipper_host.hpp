@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <iosfwd>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/dipper_hip.h"
@@ -39,6 +40,20 @@ unsigned hostThreads(unsigned cap = 64);
 // text by all host threads and packed straight into the flat 4-bit / 2-bit arrays of the device interface -- no
 // per-sequence std::string copies.  Same records, names and codes as readSequences + dpr_pack4 / dpr_pack2
 // (klib-kseq semantics); ok = false: the text needs the serial parser (FASTQ), use readSequences.
+// storage that is NOT zero-filled when it is sized: the 150 MB of packed words of a 30 000 x 10 000 alignment are written
+// completely by the packing threads, and a value-initialising resize() was 70 ms of SERIAL page faults in front of them
+template <class T> struct NoInitAlloc {
+    using value_type = T;
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+    T* allocate(size_t n) { return static_cast<T*>(::operator new(n * sizeof(T))); }
+    void deallocate(T* p, size_t) { ::operator delete(p); }
+    template <class U, class... A> void construct(U* p, A&&... a) { if (sizeof...(A) > 0) ::new ((void*)p) U(std::forward<A>(a)...); }
+    template <class U> bool operator==(const NoInitAlloc<U>&) const { return true; }
+    template <class U> bool operator!=(const NoInitAlloc<U>&) const { return false; }
+};
+using WordVec = std::vector<uint64_t, NoInitAlloc<uint64_t>>;
+
 struct PackedSequences {
     bool ok = false;
     size_t numSequences = 0;
@@ -46,7 +61,8 @@ struct PackedSequences {
     // aligned (4-bit): flat [n][W], seqLen = length of the sequence in slot 0 (src/MSA.cu:19)
     int seqLen = 0;
     // unaligned (2-bit): flat words at off[slot], lens[slot] bases
-    std::vector<uint64_t> flat, off, lens;
+    WordVec flat;
+    std::vector<uint64_t> off, lens;
 };
 // on_count(n) is called as soon as the number of records is known (the device thread reserves its matrices then)
 void readSequencesPacked(const std::string& path, bool aligned, long long seed, PackedSequences& out,

@@ -3,6 +3,8 @@
 // (src/tree_generation.cu:33-99,159-646); host orchestration is plain C++ over the C ABI.
 #include "dipper_host.hpp"
 
+#include <algorithm>
+
 #include <unistd.h>
 
 #include <chrono>
@@ -173,12 +175,12 @@ int main(int argc, char** argv)
         if (aligned) {
             std::vector<uint64_t> flat; int seqLen = 0;
             packAligned(seqs, ids, flat, seqLen);
-            same = same && seqLen == fast.seqLen && flat == fast.flat;
+            same = same && seqLen == fast.seqLen && flat.size() == fast.flat.size() && std::equal(flat.begin(), flat.end(), fast.flat.begin());
             std::printf("%zu %d %zu\n", seqs.size(), seqLen, flat.size());
         } else {
             std::vector<uint64_t> flat, off, lens;
             packUnaligned(seqs, ids, flat, off, lens);
-            same = same && flat == fast.flat && off == fast.off && lens == fast.lens;
+            same = same && flat.size() == fast.flat.size() && std::equal(flat.begin(), flat.end(), fast.flat.begin()) && off == fast.off && lens == fast.lens;
             std::printf("%zu %zu\n", seqs.size(), flat.size());
         }
         std::printf(same ? "IDENTICAL\n" : "DIFFERENT\n");
