@@ -82,6 +82,14 @@ class Budget:
     def allows(self, need_s):
         return self.left() > need_s
 
+    agree = None        # several ranks: callable(bool) -> bool, true only when true on every rank (set once the ranks are joined)
+
+    def allows_all(self, need_s):
+        """the same answer on every rank (the clocks of the ranks start a little apart: a leg full of collectives must not
+        be entered by some ranks and skipped by others)"""
+        ok = self.allows(need_s)
+        return self.agree(ok) if self.agree is not None else ok
+
     def skip(self, need_s):
         return {"skipped": "budget", "needed_s": need_s, "left_s": round(self.left(), 1)}
 
@@ -396,13 +404,25 @@ def main():
     force_check = os.environ.get("DPR_BENCH_CHECK") == "1" and "RANK" in os.environ
     if world > 1 or force_check:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if ONE_GPU:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if dist is not None and world > 1:
+        def agree(flag):
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=TDEV)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+        budget.agree = agree
 
     out = {}
     # the native input generator and the nRF tool are built by __graft_entry__.build(); a tree that was copied without its
@@ -424,6 +444,9 @@ def main():
     dog = threading.Timer(max(30.0, args.deadline_s + 60.0 - elapsed()), give_up)
     dog.daemon = True
     dog.start()
+    # ... and shortly before that, where every thread of this rank is (stderr): a hang is then a line number, not a guess
+    import faulthandler
+    faulthandler.dump_traceback_later(max(20.0, args.deadline_s + 45.0 - elapsed()), exit=False)
 
     n, L = args.tips, args.sites
     want_cli = not args.no_cli and not args.probe_only and os.path.exists(EXE)
@@ -455,7 +478,7 @@ def main():
             barrier()
             dt_cli = time.perf_counter() - t0
             if dist is not None:
-                t = torch.tensor([dt_cli], dtype=torch.float64, device="cuda")
+                t = torch.tensor([dt_cli], dtype=torch.float64, device=TDEV)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt_cli = float(t.item())
             others = [w - i - t for w, i, t in zip(walls, inputs, trees)]
@@ -507,7 +530,7 @@ def main():
         barrier()
         dt_hp = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([dt_hp], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt_hp], dtype=torch.float64, device=TDEV)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_hp = float(t.item())
         ms_hp = dt_hp / max(args.steps, 1) * 1e3 if args.steps else float("nan")
@@ -619,9 +642,10 @@ def main():
 
         # ---- several ranks: same merge log everywhere (every rank built the same tree from the same input) ----
         mgpu_check = None
+        log(f"[bench r{rank}] +{elapsed():.0f}s: multi-rank digest check / roofline probe")
         if dist is not None and last_res is not None:
             digest = int(merge_digest(last_res)[:14], 16)
-            mine = torch.tensor([digest], dtype=torch.int64, device="cuda")
+            mine = torch.tensor([digest], dtype=torch.int64, device=TDEV)
             allh = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(allh, mine)
             mgpu_check = {"ranks_agree": bool(all(int(t.item()) == digest for t in allh))}
@@ -698,12 +722,13 @@ def main():
         # E2. north_star's partitioning on this run's GPUs: matrix row-sharded over the ranks, one full Q scan per
         #     iteration (streaming NJ) -- NJ iterations/s per exchange plan, next to one GPU alone and to the default plan
         # =====================================================================================================
+        log(f"[bench r{rank}] +{elapsed():.0f}s: nj_scaling")
         if not args.probe_only and not args.no_stream_leg:
             need = 25 + 12 * (len(args.exchanges.split(",")) if world > 1 else 0)
-            if budget.allows(need):
+            if budget.allows_all(need):
                 try:
                     out["nj_scaling"] = nj_scaling(args, rank, world, local_rank, dist, torch, barrier, packed, n, L, args.stream_iters,
-                                                   hot.get("nj_iterations_per_s"))
+                                                   hot.get("nj_iterations_per_s"), budget)
                 except Exception as e:
                     out["nj_scaling"] = {"error": repr(e)}
             else:
@@ -723,6 +748,7 @@ def main():
         # =====================================================================================================
         # F. several GPUs: 100 000 tips (80 GB matrix): unit-sharded pruned plan, row-sharded streaming plans, DC of 1 M tips
         # =====================================================================================================
+        log(f"[bench r{rank}] +{elapsed():.0f}s: other sizes")
         run_sharded = world > 1 or force_check
         if run_sharded and not args.no_sharded and not args.probe_only:
             try:
@@ -737,6 +763,7 @@ def main():
         except Exception:
             pass
         dog.cancel()
+        faulthandler.cancel_dump_traceback_later()
         stage.cleanup()
     if rank == 0:
         sys.stdout.flush()
@@ -847,6 +874,13 @@ def other_configs(args, local_rank, stage, budget, tmp):
 
 PLAN_ID = {"legacy": 0, "peer": 1, "mailbox": 2}
 
+# DPR_BENCH_ONE_GPU=1: rehearsal of the N > 1 control flow with N PROCESSES ON ONE GPU (a single-GPU box is all the builder
+# has): torch.distributed over gloo, every rank on device 0, the library's ranks joined WITHOUT RCCL (dpr_comm_init_local +
+# hipIpc windows; RCCL refuses two ranks on one device) -- so only the mailbox plan of the row-sharded loop runs and the
+# legs that need RCCL collectives (unit-sharded pruned NJ, multi-rank divide-and-conquer) say so instead.
+ONE_GPU = os.environ.get("DPR_BENCH_ONE_GPU") == "1"
+TDEV = "cpu" if ONE_GPU else "cuda"
+
 
 def streaming_run(d, torch, dist, barrier, packed, n, L, iters, timed_world):
     """`iters` iterations of the streaming NJ on an already configured context; returns (result, record)"""
@@ -854,6 +888,7 @@ def streaming_run(d, torch, dist, barrier, packed, n, L, iters, timed_world):
     d.set_nj_mode(0)
     d.set_msa(packed, L)
     d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+    log(f"[bench] +{elapsed():.0f}s: streaming run: matrix built, plan {d.nj_exchange_info()['plan'] if timed_world > 1 else 'single rank'}")
     d.nj_run(max_iters=8)           # warm-up: first launches / communicator channels
     d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
     if timed_world > 1:
@@ -867,29 +902,191 @@ def streaming_run(d, torch, dist, barrier, packed, n, L, iters, timed_world):
     wall = time.perf_counter() - ts
     _, loop_ms = d.timing()
     if timed_world > 1:
-        t = torch.tensor([wall, loop_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall, loop_ms], dtype=torch.float64, device=TDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, loop_ms = float(t[0].item()), float(t[1].item())
-    k = max(int(res["iters"]), 1)
+    info = d.nj_exchange_info() if timed_world > 1 else {"launches": 2 * int(res["iters"]), "collectives": 0, "plan": "single rank", "note": ""}
+    return res, stream_record(n, int(res["iters"]), loop_ms, wall, info, timed_world, merge_digest(res))
+
+
+def stream_record(n, iters, loop_ms, wall, info, timed_world, digest):
+    k = max(int(iters), 1)
     # algorithmic bytes of iteration k: strict lower triangle of the n-k active rows, 8 bytes per element, read
     # once, + the row sums -- what the single-GPU roofline record counts (4 n^2 + 4 n)
     by = sum(4.0 * (n - j) * (n - j) + 4.0 * (n - j) for j in range(k))
-    info = d.nj_exchange_info()
-    rec = {"iterations": int(res["iters"]), "wall_s": wall, "loop_ms_hip_events": loop_ms,
+    rec = {"iterations": int(iters), "wall_s": wall, "loop_ms_hip_events": loop_ms,
            "us_per_iteration": loop_ms * 1e3 / k, "nj_iterations_per_s": k / (loop_ms * 1e-3),
            "aggregate_GBps": by / (loop_ms * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBS * timed_world,
            "frac_of_aggregate_peak": by / (loop_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * timed_world),
-           "launches_per_iteration": info["launches"] / k if timed_world > 1 else 2.0,
-           "collectives_per_iteration": info["collectives"] / k if timed_world > 1 else 0.0,
-           "merge_log_digest": merge_digest(res)}
+           "launches_per_iteration": info["launches"] / k, "collectives_per_iteration": info["collectives"] / k,
+           "merge_log_digest": digest}
     if timed_world > 1:
         rec["exchange_plan_active"] = info["plan"]
-        if info["note"]:
+        if info.get("note"):
             rec["exchange_note"] = info["note"]
-    return res, rec
+    return rec
 
 
-def nj_scaling(args, rank, world, local_rank, dist, torch, barrier, packed, n, L, iters, solo_pruned_its):
+# ---------------------------------------------------------------------------------------------------------
+# the row-sharded legs run in one CHILD PROCESS per rank that never imports torch
+# ---------------------------------------------------------------------------------------------------------
+# Why: a process that imports torch runs this library on the HIP runtime bundled with the wheel (7.0.51831 here), and that
+# runtime does not return from hipIpcOpenMemHandle for allocations of 2^31 .. 2^32 bytes (profiles/r3/ipc_runtime_probe.txt) --
+# a rank's rows of a 100 000-tip matrix are 10 - 40 GB.  The library refuses such mappings on that runtime (legacy loop), so
+# the one-exchange plans would never be measured from inside this process.  The product (the `dipper` command, any C++ host)
+# links the system runtime (7.2), where they map; a child without torch is that configuration.  It also keeps a hang of
+# the one path that has never met a second GPU away from the benchmark's own process: the parent waits with a timeout
+# and kills the child.  Parent and child talk in JSON lines over the child's stdin / stdout; the parents carry the RCCL id
+# (or, ranks on one GPU: the 192-byte peer descriptions) between the children with torch.distributed.
+def njs_worker():
+    cfg = json.loads(sys.argv[2])
+    out_fd = os.dup(1)
+    os.dup2(2, 1)           # (RCCL prints its banner on fd 1)
+
+    def say(obj):
+        os.write(out_fd, (json.dumps(obj) + "\n").encode())
+
+    def hear():
+        line = sys.stdin.readline()
+        if not line:
+            os._exit(4)     # parent gone
+        return json.loads(line)
+
+    try:
+        import ctypes
+        import dipper_amd
+        from dipper_amd import capi
+        rank, world, n, L, iters = cfg["rank"], cfg["world"], cfg["tips"], cfg["sites"], cfg["iters"]
+        packed = np.memmap(cfg["p4"], dtype=np.uint64, mode="r", shape=(n, (L + 15) // 16))
+        d = dipper_amd.Dipper(cfg["device"])
+        try:
+            d.set_nj_mode(0)
+            if cfg["local"]:
+                d.comm_init_local(rank, world)
+                say({"blob": d.peer_export(n).hex()})
+                d.peer_attach([bytes.fromhex(b) for b in hear()["blobs"]])
+                ranks = world
+            else:
+                if rank == 0:
+                    say({"uid": bytes(d.comm_unique_id()).hex()})
+                d.comm_init(rank, world, bytes.fromhex(hear()["uid"]))
+                ranks = d.comm_info()[1]
+            d.set_nj_exchange(PLAN_ID[cfg["plan"]])
+            d.set_msa(packed, L)
+            d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+            d.nj_run(max_iters=8)           # warm-up: first launches / communicator channels
+            d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+            ver = ctypes.c_int(0)
+            for line in open("/proc/self/maps"):
+                if "libamdhip64" in line:
+                    ctypes.CDLL(line.split()[-1]).hipRuntimeGetVersion(ctypes.byref(ver))
+                    break
+            say({"ready": 1, "plan": d.nj_exchange_info()["plan"], "hip_runtime": ver.value, "torch_loaded": "torch" in sys.modules})
+            hear()                          # go
+            ts = time.perf_counter()
+            res = d.nj_run(max_iters=iters)
+            wall = time.perf_counter() - ts
+            _, loop_ms = d.timing()
+            info = d.nj_exchange_info()
+            say({"result": {"iters": int(res["iters"]), "wall_s": wall, "loop_ms": loop_ms, "launches": info["launches"], "collectives": info["collectives"],
+                            "plan": info["plan"], "note": info["note"], "digest": merge_digest(res), "ranks": ranks}})
+        finally:
+            d.close()
+    except BaseException as e:      # every failure is a line the parent can read (DPR_ERR_COMM when a mailbox poll ran out, ...)
+        say({"error": repr(e)[:400]})
+        os._exit(1)
+    os._exit(0)
+
+
+class Child:
+    def __init__(self, cfg):
+        import queue
+        self.q = queue.Queue()
+        self.p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--njs-worker", json.dumps(cfg)], stdin=subprocess.PIPE,
+                                  stdout=subprocess.PIPE, text=True, cwd=ROOT)
+        t = threading.Thread(target=self._pump, daemon=True)
+        t.start()
+
+    def _pump(self):
+        for line in self.p.stdout:
+            try:
+                self.q.put(json.loads(line))
+            except Exception:
+                pass
+        self.q.put(None)            # end of file
+
+    def get(self, timeout_s):
+        """next message of the child; {"error": ...} when it said nothing in time or ended"""
+        import queue
+        try:
+            m = self.q.get(timeout=max(1.0, timeout_s))
+        except queue.Empty:
+            return {"error": "child said nothing for %d s (killed)" % int(timeout_s)}
+        return m if m is not None else {"error": "child ended (exit code %s)" % self.p.poll()}
+
+    def put(self, obj):
+        try:
+            self.p.stdin.write(json.dumps(obj) + "\n")
+            self.p.stdin.flush()
+        except Exception:
+            pass
+
+    def close(self):
+        if self.p.poll() is None:
+            try:
+                self.p.wait(timeout=5)
+            except Exception:
+                self.p.kill()       # this exact process
+                self.p.wait()
+
+
+def njs_child_leg(plan, rank, world, local_rank, dist, torch, p4, n, L, iters, setup_s, run_s):
+    """one exchange plan of the row-sharded loop in a child per rank; every rank returns the same verdict, rank 0 the record"""
+    def everyone(flag):
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=TDEV)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    ch = Child({"rank": rank, "world": world, "device": local_rank, "tips": n, "sites": L, "iters": iters, "p4": p4, "plan": plan, "local": ONE_GPU})
+    try:
+        if ONE_GPU:
+            m = ch.get(setup_s)
+            blobs = [None] * world
+            dist.all_gather_object(blobs, m.get("blob"))
+            if any(b is None for b in blobs):
+                return {"error": "peer description missing: " + str(m.get("error"))}
+            ch.put({"blobs": blobs})
+        else:
+            uid = [None]
+            if rank == 0:
+                uid[0] = ch.get(setup_s).get("uid")
+            dist.broadcast_object_list(uid, src=0)
+            if uid[0] is None:
+                return {"error": "rank 0's child made no communicator id"}
+            ch.put({"uid": uid[0]})
+        m = ch.get(setup_s)
+        if not everyone("ready" in m):
+            return {"error": m.get("error", "another rank did not get ready")}
+        ready = m
+        ch.put({"go": 1})
+        m = ch.get(run_s)
+        if not everyone("result" in m):
+            return {"error": m.get("error", "another rank failed")}
+        mine = m["result"]
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        loop_ms = max(r["loop_ms"] for r in allr)
+        wall = max(r["wall_s"] for r in allr)
+        rec = stream_record(n, mine["iters"], loop_ms, wall, mine, world, mine["digest"])
+        rec["rccl_ranks"] = mine["ranks"]
+        rec["ranks_agree"] = len({r["digest"] for r in allr}) == 1 and len({r["iters"] for r in allr}) == 1
+        rec["child_process"] = {"hip_runtime": ready.get("hip_runtime"), "torch_loaded": ready.get("torch_loaded")}
+        return rec
+    finally:
+        ch.close()
+
+
+def nj_scaling(args, rank, world, local_rank, dist, torch, barrier, packed, n, L, iters, solo_pruned_its, budget=None):
     """NJ-iteration throughput side by side (north_star's scaling metric): the default plan on one GPU (exact pruned scan),
     the streaming loop (the reference's algorithm, src/neighborJoining.cu:211-243: one full Q scan per iteration) on one GPU
     alone, and row-sharded over this run's GPUs with every exchange plan of the library.  Every multi-rank record carries the
@@ -904,6 +1101,7 @@ def nj_scaling(args, rank, world, local_rank, dist, torch, barrier, packed, n, L
                                     "note": "whole-run average of hot_path (the early iterations timed below are the largest ones)"}}
     # one GPU alone (rank 0; the denominator of every speed-up below)
     solo = None
+    log(f"[bench r{rank}] +{elapsed():.0f}s: nj_scaling at {n} tips: streaming loop on one GPU alone (rank 0)")
     if rank == 0:
         s1 = dipper_amd.Dipper(local_rank)
         try:
@@ -913,38 +1111,31 @@ def nj_scaling(args, rank, world, local_rank, dist, torch, barrier, packed, n, L
         rec["streaming_one_gpu"] = r1
     if dist is not None:
         dist.barrier()
-    if world == 1:
-        return rec
+    if world == 1 and not (dist is not None and os.environ.get("DPR_BENCH_CHECK") == "1"):
+        return rec          # (DPR_BENCH_CHECK: one rank walks through the child legs too -- RCCL id relay, pipes, time limits)
     rec["row_sharded"] = {}
+    rec["row_sharded_runs_in"] = "one child process per rank without torch (system HIP runtime; see njs_worker)"
+    p4 = getattr(packed, "filename", None)
+    solo_digest = merge_digest(solo) if solo is not None else None
     for plan in [p.strip() for p in args.exchanges.split(",") if p.strip() in PLAN_ID]:
-        d = dipper_amd.Dipper(local_rank)
+        if ONE_GPU and plan != "mailbox":
+            rec["row_sharded"][plan] = {"skipped": "needs RCCL (rehearsal with process ranks on one GPU)"}
+            continue
+        # a plan that hangs costs its time limits (60 + 30 s): the ranks agree on whether the deadline still allows that
+        if budget is not None and not budget.allows_all(100):
+            rec["row_sharded"][plan] = budget.skip(100)
+            continue
+        log(f"[bench r{rank}] +{elapsed():.0f}s: nj_scaling at {n} tips: row-sharded over {world} ranks, exchange plan {plan}")
         try:
-            ranks = join_comm(d, rank, world, dist)
-            d.set_nj_exchange(PLAN_ID[plan])
-            try:
-                res, r = streaming_run(d, torch, dist, barrier, packed, n, L, iters, world)
-                ok = 1
-            except Exception as e:      # e.g. DPR_ERR_COMM when a mailbox poll ran out: every rank gets it, nobody hangs
-                r, res, ok = {"error": repr(e)}, None, 0
-            r["rccl_ranks"] = ranks
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                digest = int(merge_digest(res)[:14], 16)
-                mine = torch.tensor([digest], dtype=torch.int64, device="cuda")
-                allh = [torch.zeros_like(mine) for _ in range(world)]
-                dist.all_gather(allh, mine)
-                r["ranks_agree"] = bool(all(int(t.item()) == digest for t in allh))
-                if rank == 0 and solo is not None:
-                    r["matches_single_gpu"] = bool(all(np.array_equal(res[k][:res["iters"]], solo[k][:solo["iters"]]) for k in ("merge_x", "merge_y", "bl_x", "bl_y")))
-                    r["iteration_speedup_vs_one_gpu"] = rec["streaming_one_gpu"]["us_per_iteration"] / r["us_per_iteration"]
-            elif "error" not in r:
-                r["error"] = "another rank failed"
-            rec["row_sharded"][plan] = r
-        finally:
-            d.close()
+            r = njs_child_leg(plan, rank, world, local_rank, dist, torch, str(p4), n, L, iters, setup_s=60.0, run_s=30.0)
+        except Exception as e:
+            r = {"error": repr(e)}
+        if rank == 0 and "error" not in r and solo_digest is not None:
+            r["matches_single_gpu"] = bool(r["merge_log_digest"] == solo_digest and r["iterations"] == int(solo["iters"]))
+            r["iteration_speedup_vs_one_gpu"] = rec["streaming_one_gpu"]["us_per_iteration"] / r["us_per_iteration"]
+        rec["row_sharded"][plan] = r
         if rank == 0:
-            log(f"[bench] nj_scaling.row_sharded.{plan}: {rec['row_sharded'][plan]}")
+            log(f"[bench] nj_scaling.row_sharded.{plan}: {r}")
     return rec
 
 
@@ -956,10 +1147,18 @@ def sharded_leg(args, rank, world, local_rank, dist, torch, barrier, stage, budg
     from dipper_amd import capi
     ns, Ls = args.sharded_tips, args.sharded_sites
     rec = {"tips": ns, "sites": Ls, "world": world}
-    if not budget.allows(60):
+    if not budget.allows_all(60):
         return dict(rec, **budget.skip(60))
     inp = stage.gen("nj100k", ns, Ls, args.seed + 7, 2e-5 * 10000 / Ls, 2e-6 * 10000 / Ls, 2e-4 * 10000 / Ls)
     packed = Stage.packed4(inp)
+    if ONE_GPU and world > 1:
+        rec["unit_sharded_plan"] = {"skipped": "needs RCCL (rehearsal with process ranks on one GPU)"}
+        rec["dc_1m"] = {"skipped": "needs RCCL (rehearsal with process ranks on one GPU)"}
+        try:
+            rec["nj_scaling"] = nj_scaling(args, rank, world, local_rank, dist, torch, barrier, packed, ns, Ls, max(8, args.stream_iters // 4), None, budget)
+        except Exception as e:
+            rec["nj_scaling"] = {"error": repr(e)}
+        return rec
     d = dipper_amd.Dipper(local_rank)
     try:
         ranks = join_comm(d, rank, world, dist) if world > 1 else 1
@@ -983,7 +1182,7 @@ def sharded_leg(args, rank, world, local_rank, dist, torch, barrier, stage, budg
         d.close()
     digest = int(merge_digest(res)[:14], 16)
     if dist is not None:
-        mine = torch.tensor([digest], dtype=torch.int64, device="cuda")
+        mine = torch.tensor([digest], dtype=torch.int64, device=TDEV)
         allh = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allh, mine)
         rec["ranks_agree"] = bool(all(int(t.item()) == digest for t in allh))
@@ -1006,10 +1205,10 @@ def sharded_leg(args, rank, world, local_rank, dist, torch, barrier, stage, budg
         dist.barrier()
     # the row-sharded streaming loop at this size too (a scan is 40 GB per iteration: the exchange is small beside it)
     need = 30 + 15 * len(args.exchanges.split(","))
-    if budget.allows(need):
+    if budget.allows_all(need):
         try:
             rec["nj_scaling"] = nj_scaling(args, rank, world, local_rank, dist if world > 1 else None, torch, barrier, packed, ns, Ls,
-                                           max(8, args.stream_iters // 4), None)
+                                           max(8, args.stream_iters // 4), None, budget)
         except Exception as e:
             rec["nj_scaling"] = {"error": repr(e)}
     else:
@@ -1017,7 +1216,7 @@ def sharded_leg(args, rank, world, local_rank, dist, torch, barrier, stage, budg
     del packed
     # configs[3]: divide-and-conquer of 1 000 000 tips over the ranks (query shares of the assignment and the clusters dealt
     # to the ranks, backbone distance rows sharded; dpr_dc_run after dpr_comm_init), with rank 0's single-GPU run beside it
-    if budget.allows(45):
+    if budget.allows_all(45):
         try:
             rec["dc_1m"] = dc_leg(args, rank, world, local_rank, dist if world > 1 else None, torch, barrier, stage)
         except Exception as e:
@@ -1055,10 +1254,10 @@ def dc_leg(args, rank, world, local_rank, dist, torch, barrier, stage):
     finally:
         d.close()
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall], dtype=torch.float64, device=TDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
-        mine = torch.tensor([int(digest[:14], 16)], dtype=torch.int64, device="cuda")
+        mine = torch.tensor([int(digest[:14], 16)], dtype=torch.int64, device=TDEV)
         allh = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allh, mine)
         rec["ranks_agree"] = bool(all(int(x.item()) == int(digest[:14], 16) for x in allh))
@@ -1077,6 +1276,9 @@ def dc_leg(args, rank, world, local_rank, dist, torch, barrier, stage):
         dist.barrier()
     return rec
 
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[1] == "--njs-worker":
+    njs_worker()
 
 if __name__ == "__main__":
     main()

@@ -201,12 +201,36 @@ struct PeerBlob {                  // what a rank tells the others about its buf
 };
 static_assert(sizeof(PeerBlob) == 192, "PeerBlob layout");
 
+// The HIP runtime bundled with PyTorch 2.10+rocm7.0 (7.0.51831: a process that imports torch first runs this library on it)
+// does not return from hipIpcOpenMemHandle for an allocation whose size has bit 31 set (2.3, 3.6, 3.9 GB hang; 1.9 GB and
+// 5.8 GB map), while the system runtime (/opt/rocm, 7.2) maps 14 GB (profiles/ipc_torch_probe.py, profiles/r3/
+// ipc_runtime_probe.txt).  A hang cannot be caught, so matrices of 2 GiB and more per rank are not offered to the peers on a
+// runtime older than 7.2 at all: the ranks then agree on the legacy loop (dpr_dist_matrix) or dpr_peer_export fails.
+// DPR_IPC_ANY_SIZE=1 lifts the guard.
+static bool ipc_size_allowed(size_t bytes)
+{
+    static int large_ok = -1;
+    if (large_ok < 0) {
+        int v = 0;
+        if (hipRuntimeGetVersion(&v) != hipSuccess) { (void)hipGetLastError(); v = 0; }
+        large_ok = (v >= 70200000 || std::getenv("DPR_IPC_ANY_SIZE")) ? 1 : 0;
+    }
+    return large_ok == 1 || bytes < ((size_t)1 << 31);
+}
+
 static int peer_blob_of(dpr_ctx* c, PeerBlob* out)
 {
     NjBuffers& b = c->nj[0];
     std::memset(out, 0, sizeof(PeerBlob));
     out->n_tips = (uint64_t)b.N;
     if (!b.D || !b.peer.win) return DPR_OK;
+    {
+        hipDeviceptr_t base = nullptr;
+        size_t bytes = 0;
+        if (hipMemGetAddressRange(&base, &bytes, b.D) != hipSuccess) { (void)hipGetLastError(); bytes = ~(size_t)0; }
+        out->pad[0] = (uint64_t)bytes;
+        if (!ipc_size_allowed(bytes)) { out->pad[1] = 2; return DPR_OK; }      // 2: refused by the runtime guard
+    }
     if (hipIpcGetMemHandle(&out->d, b.D) != hipSuccess || hipIpcGetMemHandle(&out->w, b.peer.win) != hipSuccess) { (void)hipGetLastError(); return DPR_OK; }
     out->ok = 1;
     return DPR_OK;
@@ -218,7 +242,7 @@ static int peer_attach_blobs(dpr_ctx* c, const PeerBlob* all, int* ok)
     NjBuffers& b = c->nj[0];
     *ok = 1;
     for (int r = 0; r < c->world; ++r)
-        if (!all[r].ok || all[r].n_tips != (uint64_t)b.N) *ok = 0;
+        if (!all[r].ok || all[r].n_tips != (uint64_t)b.N || (r != c->rank && !ipc_size_allowed((size_t)all[r].pad[0]))) *ok = 0;
     if (!*ok) return DPR_OK;
     std::vector<char*> wins((size_t)c->world, nullptr);
     std::vector<double*> Ds((size_t)c->world, nullptr);
@@ -305,7 +329,10 @@ static int njs_setup(dpr_ctx* c)
             b.peer.opened.clear();
             b.peer.attached = false;
             b.peer.plan = kNjsLegacy;
-            c->nj_exchange_note = "peer windows could not be mapped on every rank (hipIpc): legacy two-exchange loop";
+            bool guard = false;
+            for (const PeerBlob& pb : all) guard = guard || pb.pad[1] == 2;
+            c->nj_exchange_note = guard ? "this HIP runtime (older than 7.2) does not map IPC allocations of 2 GiB and more reliably: legacy two-exchange loop"
+                                        : "peer windows could not be mapped on every rank (hipIpc): legacy two-exchange loop";
             return DPR_OK;
         }
     }
@@ -570,6 +597,11 @@ int dpr_peer_export(dpr_ctx* c, int64_t n_tips, void* out192)
     DPR_HIP(hipStreamSynchronize(c->stream));
     PeerBlob blob;
     peer_blob_of(c, &blob);
+    if (!blob.ok && blob.pad[1] == 2) {
+        set_error("dpr_peer_export: this HIP runtime (older than 7.2) does not map IPC allocations of 2 GiB and more reliably; this rank's rows take " +
+                  std::to_string(blob.pad[0]) + " bytes (use the system runtime, more ranks, or DPR_IPC_ANY_SIZE=1)");
+        return DPR_ERR_STATE;
+    }
     if (!blob.ok) { set_error("dpr_peer_export: hipIpcGetMemHandle failed"); return DPR_ERR_HIP; }
     std::memcpy(out192, &blob, sizeof blob);
     return DPR_OK;

@@ -73,3 +73,43 @@ def test_process_ranks_msa_source(tmp_path):
         for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
             assert np.array_equal(got[key], ref[key]), key
         assert float(got["last_d"]) == ref["last_d"]
+
+
+@pytest.mark.timeout(300)
+def test_large_export_is_refused_on_an_old_runtime_instead_of_hanging():
+    """A process that imports torch runs the library on the wheel's HIP runtime; 7.0 never returns from hipIpcOpenMemHandle
+    for an allocation of 2^31 .. 2^32 bytes (profiles/r3/ipc_runtime_probe.txt).  The library must refuse to describe such a
+    matrix to the peers there (dpr_peer_export fails with a message; dpr_dist_matrix over RCCL falls back to the legacy
+    loop) -- and must still export it on the system runtime."""
+    code = r"""
+import ctypes, sys
+if sys.argv[1] == "torch":
+    import torch
+import dipper_amd
+from dipper_amd import capi
+capi.load_library()
+ver = ctypes.c_int(0)
+for line in open("/proc/self/maps"):
+    if "libamdhip64" in line:
+        ctypes.CDLL(line.split()[-1]).hipRuntimeGetVersion(ctypes.byref(ver))
+        break
+d = dipper_amd.Dipper(0)
+d.set_nj_mode(0)
+d.comm_init_local(0, 2)
+try:
+    blob = d.peer_export(24000)          # 12000 rows x 24000 x 8 = 2.3 GB: bit 31 set
+    print("RESULT", ver.value, "exported", len(blob))
+except capi.DipperError as e:
+    print("RESULT", ver.value, "refused", str(e))
+d.close()
+"""
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for mode in ("plain", "torch"):
+        r = subprocess.run([sys.executable, "-c", code, mode], cwd=ROOT, env=env, capture_output=True, text=True, timeout=200)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+        assert r.returncode == 0 and line, r.stderr[-2000:]
+        _, ver, verdict, rest = line[0].split(" ", 3)
+        if int(ver) >= 70200000:
+            assert verdict == "exported" and rest == "192", line
+        else:
+            assert verdict == "refused" and "older than 7.2" in rest, line
