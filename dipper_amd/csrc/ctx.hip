@@ -965,6 +965,10 @@ int64_t dpr_nj_run(dpr_ctx* c, int64_t max_iters, int32_t* merge_x, int32_t* mer
         set_error("dpr_nj_run: the exchange between the ranks failed (a rank's record did not arrive within the poll limit, or the all-gather delivered a stale one)");
         return DPR_ERR_COMM;
     }
+    if (st.status == 5) {
+        set_error("dpr_nj_run: internal: the test blocks of the post kernel did not see the producer blocks' tag within 2 ms (njp_post2_kernel; DPR_NJP_POST2=0 selects the fused kernel)");
+        return DPR_ERR_HIP;
+    }
     if (st.status != 0) {
         set_error("dpr_nj_run: no Q candidate below the reference's init value 10000 (undefined in the reference)");
         return DPR_ERR_NOCAND;

@@ -194,6 +194,8 @@ struct NjpArgs {
     unsigned long long* iterstats;
     int flags;        // experiments (DPR_NJP_FLAGS): 1 = column of the new node stored with plain stores instead of write-through (sc1)
     unsigned long long* dbg; int64_t dbg_it;     // DPR_NJ_PHASES=<iteration>: per-block phase stamps of that iteration (profiles/nj_phases.py)
+    // njp_post2_kernel (large shape): what its producer blocks hand to its test blocks
+    void* t2_hdr; double* t2_rmax; double* t2_cmax; double* t2_colmin; double* t2_rowmin; double* t2_cmin;
 };
 
 // phase stamps (debug; 100 MHz wall clock): thread 0 of every block, kernel k (0 scan, 1 post), slot j
@@ -852,6 +854,328 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
 }
 
 // ------------------------------------------------------------------------------------------------
+// POST(it), LARGE shape (P >= njp_big_p(), single rank), as TWO launches with the redundancy taken out.
+// njp_post_kernel's test blocks each recompute the row sums after the merge for their own 4096 rows and 2048 columns and
+// reduce all scan records themselves: ~220 KB of L2 reads per block, 230 MB per iteration at 100 000 tips (of which the unit
+// bounds are 20 MB) with 230 registers per thread, i.e. two rounds of blocks -- 21.5 us per launch, the largest item of that
+// run.  Here the work that does not depend on the unit is done ONCE:
+//   launch A (njp_post2_kernel<kNS, 0>), light blocks, all resident:
+//     U blocks [0, nupd)          the update role, unchanged (indexed by reference slot);
+//     M blocks, one per 512 positions: row sums after the merge by POSITION -> per 16-row group the maximum (rmax), per
+//               128-column sub-strip the maximum (cmax); where the node that leaves quarantine crosses: per sub-strip the
+//               minimum of its buffered row over the live columns before it, per group over the live rows behind it;
+//     S block   the seed bound (scan records re-evaluated with the new row sums) and the winner's positions;
+//   launch B (njp_post2_kernel<kNS, 1>): T blocks of 256 row groups x up to kNS strips: their unit bounds, one 8-byte load per
+//     group and 4 per strip instead of the rows; 72 registers.
+// Same values as the fused blocks computed (max and min are exact, the division by n - 3 is applied after the maximum in
+// both), so the lists hold the same units and the merge log is the same bit for bit.
+// (Tried first: A and B as roles of ONE launch, the T blocks polling a tag that the last producer publishes -- agent-scope
+//  write-through stores, drained, ticket; correct, but every hand-over step is a round trip across the XCDs (~2 us each, ten
+//  of them in a chain): 40 us per launch instead of 27 for the fused kernel at 100 000 tips, profiles/r3/nj_kt_100k.txt.
+//  A kernel boundary is cheaper than that chain.)
+// ------------------------------------------------------------------------------------------------
+struct Post2Hdr { double seed; long long px, py; };
+
+template <int kNS, int kPart>
+__global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
+{
+    constexpr int kTG = 256;
+    __shared__ double s[kThreads];
+    __shared__ double sq[kThreads / 64], sdd[kThreads / 64];
+    __shared__ uint64_t sk[kThreads / 64], spp[kThreads / 64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int bx = (int)blockIdx.x;
+    const int nmb = a.nrb;                                   // M blocks: one per 512 positions
+    const int role = kPart == 1 ? 3 : bx < a.nupd ? 0 : bx < a.nupd + nmb ? 1 : 2;
+    const int ubi = bx, mbi = bx - a.nupd, tb = bx;
+    Post2Hdr* hdr = reinterpret_cast<Post2Hdr*>(a.t2_hdr);
+    const double NINF = -__builtin_inf(), PINF = __builtin_inf();
+
+    const int64_t it = a.st->itb;
+    const int64_t limit = a.st->it_limit, N = a.st->N;
+    const int64_t pz = (int64_t)a.st->pnew[it & 1];
+    const int64_t P = a.P;
+    const int64_t G16 = (P + kUR - 1) / kUR;
+    const double* __restrict__ Uc = a.U + (it & 1) * a.vstride;
+    double* __restrict__ Un = a.U + ((it + 1) & 1) * a.vstride;
+    const double* __restrict__ Rz = a.R + ((it + 1) & 1) * a.vstride;        // written by POST(it - 1)
+
+    if (role == 3) {
+        // ------------------------------------------------------------------------------------------ test role
+        const int cb0 = a.blk_cb[tb];
+        const int64_t g = (int64_t)a.blk_g0[tb] + tid;
+        const bool have_g = g < G16;
+        const int64_t send = njp_strips_of_rows((int64_t)a.blk_g0[tb], kTG, P);
+        const int nsb = (int)(send - cb0 < kNS ? send - cb0 : kNS);
+        // hop 1: everything the COARSE test needs.  The block's 256 groups x nsb strips are one coarse cell with the bound
+        // t2_cmin[tb] <= every sub-unit bound of the cell (kept by this block alone: lowered together with a unit bound,
+        // recomputed exactly whenever the block reads its unit bounds); monotonicity of fl(x - y) gives, for every unit of the
+        // cell,  lb(unit) >= fl(fl(cmin - rmaxC) - cmaxC)  with the maxima over the cell's groups / sub-strips -- a cell whose
+        // coarse bound exceeds the seed bound holds no candidate and its 32 KB of unit bounds are not read at all.
+        const double rmax = have_g ? a.t2_rmax[g] : NINF;
+        double cm4[kNS][4];
+#pragma unroll
+        for (int k = 0; k < kNS; ++k)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) cm4[k][w] = k < nsb ? a.t2_cmax[4 * (cb0 + k) + w] : NINF;
+        const double cmin = a.t2_cmin[tb];
+        const int64_t px = (int64_t)hdr->px, py = (int64_t)hdr->py;
+        const double bound = hdr->seed;
+        if (a.st->status != 0 || it >= limit || !a.do_tests) return;
+        const int64_t n = N - it;
+        if (n < 3) return;
+        const bool fold = pz >= 0 && pz != px && pz != py;                       // block-uniform
+        const int64_t gz = fold ? pz / kUR : -1;
+        const bool gz_here = fold && gz >= (int64_t)a.blk_g0[tb] && gz < (int64_t)a.blk_g0[tb] + kTG;
+        const int wpz = fold ? (int)((pz % kTileCols) / (kTileCols / 4)) : -1;
+        const int64_t cbz = fold ? pz / kTileCols : -1;
+        const bool pz_here = fold && cbz >= cb0 && cbz < cb0 + nsb;              // block-uniform
+        {
+            double rC = wave_fmax(rmax);
+            if (lane == 0) sq[tid >> 6] = rC;
+            __syncthreads();
+            rC = fmax(fmax(sq[0], sq[1]), fmax(sq[2], sq[3]));
+            double cC = NINF;
+#pragma unroll
+            for (int k = 0; k < kNS; ++k)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) cC = fmax(cC, cm4[k][w]);
+            const double lbC = fmin((cmin - rC) - cC, (cmin - cC) - rC);
+            // the node leaving quarantine lowers unit bounds of this cell: those lanes must run (block-uniform decision)
+            if (!gz_here && !pz_here && !(lbC <= bound) && !(a.flags & 4)) return;
+        }
+        ulonglong2 um0[kNS], um1[kNS];
+#pragma unroll
+        for (int k = 0; k < kNS; ++k) {
+            um0[k] = make_ulonglong2(0ull, 0ull); um1[k] = um0[k];
+            if (k < nsb && have_g && g >= 32 * (int64_t)(cb0 + k)) {
+                const unsigned long long* up = a.umin + ((int64_t)(cb0 + k) * G16 + g) * 4;
+                um0[k] = *reinterpret_cast<const ulonglong2*>(up); um1[k] = *reinterpret_cast<const ulonglong2*>(up + 2);
+            }
+        }
+        double mymin = PINF;           // minimum of this lane's sub-unit bounds after the fold: the cell's new coarse bound
+#pragma unroll
+        for (int sidx = 0; sidx < kNS; ++sidx) {
+            if (sidx >= nsb) break;                       // block-uniform
+            const int cb = cb0 + sidx;
+            const bool pz_strip = fold && cbz == cb;                                 // block-uniform
+            const bool have = have_g && g >= 32 * (int64_t)cb;
+            unsigned long long* up4 = a.umin + ((int64_t)cb * G16 + (have ? g : 0)) * 4;
+            double u4[4] = { PINF, PINF, PINF, PINF };
+            if (have) { u4[0] = dec_f64(um0[sidx].x); u4[1] = dec_f64(um0[sidx].y); u4[2] = dec_f64(um1[sidx].x); u4[3] = dec_f64(um1[sidx].y); }
+            const double newminA = (pz_strip && have_g) ? a.t2_rowmin[g] : PINF;
+            int submask = 0;
+            if (have) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const double cmw = cm4[sidx][w];
+                    double nm = (gz_here && g == gz) ? a.t2_colmin[4 * cb + w] : PINF;      // the unit (this strip, group of pz)
+                    if (pz_strip && w == wpz) nm = fmin(nm, newminA);
+                    if (nm < u4[w]) {                          // persist the lowered bound (this lane is the unit's only writer here)
+                        u4[w] = nm;
+                        up4[w] = enc_f64(nm);
+                    }
+                    mymin = fmin(mymin, u4[w]);
+                    const double lb = fmin((u4[w] - rmax) - cmw, (u4[w] - cmw) - rmax);
+                    if ((cmw > NINF) && (lb <= bound)) submask |= 1 << w;
+                }
+            }
+            const bool keep = have && (rmax > NINF) && submask != 0;
+            const unsigned long long mask = __ballot(keep);
+            unsigned long long base = 0;
+            if (lane == 0 && mask) base = atomicAdd(&a.cnt[(it + 1) % 3], (unsigned long long)__popcll(mask));
+            base = __shfl(base, 0, 64);
+            if (keep) a.list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)(((uint32_t)submask << 28) | ((uint32_t)cb << 18) | (uint32_t)g);
+        }
+        mymin = wave_fmin(mymin);
+        __syncthreads();               // (sq: the coarse maxima above were read by every thread)
+        if (lane == 0) sq[tid >> 6] = mymin;
+        __syncthreads();
+        if (tid == 0) a.t2_cmin[tb] = fmin(fmin(sq[0], sq[1]), fmin(sq[2], sq[3]));
+        return;
+    }
+
+    // ------------------------------------------------------------------------------ producers: U, M, S
+    // hop 1: scan records and what each role can address without knowing the winner
+    const int nrec_all = a.urecs + a.nrb;
+    NjRecord r0; r0.q = 10000.0; r0.key = ~0ull; r0.d = 0; r0.pad = 0;
+    constexpr int kMine = 5;
+    NjRecord mine[kMine] = { r0, r0, r0, r0, r0 };
+#pragma unroll
+    for (int k = 0; k < kMine; ++k) {
+        const int idx = tid + k * kThreads;
+        if (idx < nrec_all) mine[k] = a.partials[idx];
+    }
+    const unsigned long long cnt_raw = a.all_defined ? (unsigned long long)a.urecs : a.cnt[it % 3];
+    const int64_t uvalid = (int64_t)(cnt_raw < (unsigned long long)a.urecs ? cnt_raw : (unsigned long long)a.urecs);
+    // S: the seed candidate of this thread (as in njp_post_kernel)
+    const int nseed_rows = a.nrb < kThreads / 2 ? a.nrb : kThreads / 2;
+    const int nseed_units = kThreads - nseed_rows;
+    const int64_t sstride = a.all_defined && a.urecs >= 2 * nseed_units ? a.urecs / nseed_units : 1;
+    const bool seed_is_unit = tid < nseed_units;
+    NjRecord cand = r0;
+    if (role == 2) {
+        if (!seed_is_unit) cand = a.partials[a.urecs + (tid - nseed_units)];
+        else if ((int64_t)tid * sstride < a.urecs) cand = a.partials[(int64_t)tid * sstride];
+    }
+    // U: position and row sum of this thread's slot;  M: row sums (and the buffered row of the node leaving quarantine) of its two positions
+    const int64_t i = (int64_t)ubi * kThreads + tid;     // reference slot (U)
+    int64_t p = -1;
+    double up = 0.0;
+    const int64_t p0 = (int64_t)mbi * kTileCols + 2 * tid;      // (M) < P + 512
+    v2d uc; uc.x = 0.0; uc.y = 0.0;
+    v2d rz; rz.x = PINF; rz.y = PINF;
+    if (role == 0) p = (int64_t)a.pos_of_slot[i];
+    if (role == 1) {
+        uc = *reinterpret_cast<const v2d*>(Uc + p0);
+        if (pz >= 0) rz = *reinterpret_cast<const v2d*>(Rz + p0);
+    }
+#pragma unroll
+    for (int k = 0; k < kMine; ++k) {
+        const int idx = tid + k * kThreads;
+        if (idx >= uvalid && idx < a.urecs) mine[k] = r0;   // not written by this iteration's scan
+    }
+    if (role == 0) up = (i < N && p >= 0) ? Uc[p] : 0.0;
+    if (a.st->status != 0 || it >= limit) return;
+    const int64_t n = N - it;
+    if (n < 3) return;
+    if (role == 0 && (!a.do_update || (int64_t)ubi * kThreads >= n)) return;
+    if (role != 0 && !a.do_tests) return;
+
+    // ---- select (thrust::min_element, src/neighborJoining.cu:214)
+    double bq = 10000.0, d = 0.0; uint64_t bk = ~0ull, bp = 0;
+    const int nmine = (nrec_all + kThreads - 1) / kThreads;
+#pragma unroll
+    for (int k = 0; k < kMine; ++k)
+        if (k < nmine) best_update4(bq, bk, bp, d, mine[k].q, mine[k].key, mine[k].pad, mine[k].d);
+    for (int64_t idx = tid + kMine * kThreads; idx < nrec_all; idx += kThreads)
+        if (idx < uvalid || idx >= a.urecs) best_update4(bq, bk, bp, d, a.partials[idx].q, a.partials[idx].key, a.partials[idx].pad, a.partials[idx].d);
+    wave_best4(bq, bk, bp, d);
+    if (lane == 0) { sq[tid >> 6] = bq; sk[tid >> 6] = bk; spp[tid >> 6] = bp; sdd[tid >> 6] = d; }
+    __syncthreads();
+    bq = sq[0]; bk = sk[0]; bp = spp[0]; d = sdd[0];
+#pragma unroll
+    for (int w = 1; w < kThreads / 64; ++w) best_update4(bq, bk, bp, d, sq[w], sk[w], spp[w], sdd[w]);
+
+    const int64_t last = n - 1;
+    if (bk == ~0ull) {
+        // no candidate: the run ends with status 1 (launch B sees it and returns)
+        if ((role == 0 && i == last) || (role == 2 && tid == 0)) a.st->status = 1;
+        return;
+    }
+    const int64_t ki = (int64_t)(bk & 0xFFFFFFull), kj = (int64_t)((bk >> 24) & 0xFFFFFFull);
+    const int64_t pi = (int64_t)(bp & 0xffffffffull), pj = (int64_t)(bp >> 32);
+    const int64_t x = ki < kj ? ki : kj, y = ki < kj ? kj : ki;
+    const int64_t px = ki < kj ? pi : pj, py = ki < kj ? pj : pi;
+    const int64_t n1 = n - 1;
+    const double r1 = (double)(n1 - 2);
+    const double* __restrict__ rowx = a.D + px * a.ld;
+    const double* __restrict__ rowy = a.D + py * a.ld;
+
+    if (role == 0) {
+        // ------------------------------------------------------------------------------ update role (as njp_post_kernel's)
+        double* __restrict__ Rw = a.R + (it & 1) * a.vstride;
+        double val = 0.0;
+        if (i < n) {
+            if (i == last) {
+                const double r = (double)(n - 2);
+                double blX = (d + Uc[px] / r - Uc[py] / r) * 0.5;
+                double blY = d - blX;
+                if (blX < 0) { blY += blX; blX = 0; }
+                if (blY < 0) { blX += blY; blY = 0; }
+                a.log_x[it] = (int32_t)x; a.log_y[it] = (int32_t)y; a.log_bx[it] = blX; a.log_by[it] = blY;
+                a.st->x = (int32_t)x; a.st->y = (int32_t)y; a.st->d = d; a.st->q = bq;
+                a.st->n = n1; a.st->it = it + 1;
+                a.st->pnew[(it + 1) & 1] = (int32_t)px;
+                a.U[(it & 1) * a.vstride + py] = __builtin_nan("");       // (this thread's own store, behind its read of U[py] above)
+                a.st->cnt_list[(it + 2) % 3] = 0ull;
+                for (int v = 0; v < a.cnt_ranks; ++v) a.cnt_all[4 * v + (it + 2) % 3] = 0ull;
+            }
+            int64_t new_slot = i;
+            if (i != x && i != y) {
+                const double dxi = rowx[p], dyi = rowy[p];
+                val = nj_val(dxi, dyi, d);
+                const double u = nj_unew(up, dxi, dyi, val);
+                Un[p] = u;
+                a.Ur[p] = u / r1;
+                Rw[p] = val;
+                if (a.flags & 8) { }       // experiment (WRONG results): no column store -- what do the n scattered stores cost?
+                else if (a.flags & 1) a.D[p * a.ld + px] = val;
+                else __hip_atomic_store(a.D + p * a.ld + px, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (i == last) {
+                    new_slot = y;
+                    a.slot_of_pos[p] = (int32_t)y;
+                    a.pos_of_slot[y] = (int32_t)p;
+                }
+            } else if (i == y) {
+                a.Ur[py] = __builtin_nan("");
+                Un[py] = __builtin_nan("");
+                a.slot_of_pos[py] = -1;
+                Rw[py] = 0.0;
+                new_slot = -1;
+            } else {
+                a.Ur[px] = __builtin_nan("");
+                Rw[px] = 0.0;
+            }
+            if (new_slot >= 0) { a.KA[p] = nj_key_a(new_slot, n1); a.KB[p] = nj_key_b(new_slot); }
+        }
+        const double cs = block_tree256_lane0(val, s);
+        if (tid == 0) a.xpart[ubi] = cs;
+        return;
+    }
+
+    const bool fold = pz >= 0 && pz != px && pz != py;
+    if (role == 1) {
+        // ------------------------------------------------------------------------------ M: maxima by position
+        const v2d dx = *reinterpret_cast<const v2d*>(rowx + p0);
+        const v2d dy = *reinterpret_cast<const v2d*>(rowy + p0);
+        const bool live0 = (uc.x == uc.x) & (p0 != px) & (p0 != py) & (p0 < P);
+        const bool live1 = (uc.y == uc.y) & (p0 + 1 != px) & (p0 + 1 != py) & (p0 + 1 < P);
+        const double un0 = nj_unew(uc.x, dx.x, dy.x, nj_val(dx.x, dy.x, d));
+        const double un1 = nj_unew(uc.y, dx.y, dy.y, nj_val(dx.y, dy.y, d));
+        const double m2 = fmax(live0 ? un0 : NINF, live1 ? un1 : NINF);
+        double gm = m2;                                                   // group of 16 positions = 8 lanes
+        gm = fmax(gm, __shfl_xor(gm, 1, 64)); gm = fmax(gm, __shfl_xor(gm, 2, 64)); gm = fmax(gm, __shfl_xor(gm, 4, 64));
+        const double cm = wave_fmax(m2) / r1;                             // sub-strip of 128 positions = this wave
+        const int64_t gidx = p0 >> 4;
+        if ((tid & 7) == 0) a.t2_rmax[gidx] = gm / r1;           // (-inf stays -inf)
+        if (lane == 0) a.t2_cmax[4 * mbi + (tid >> 6)] = cm;
+        if (fold) {
+            const double c2 = fmin((live0 & (p0 < pz)) ? rz.x : PINF, (live1 & (p0 + 1 < pz)) ? rz.y : PINF);
+            double r2 = fmin((live0 & (p0 > pz)) ? rz.x : PINF, (live1 & (p0 + 1 > pz)) ? rz.y : PINF);
+            r2 = fmin(r2, __shfl_xor(r2, 1, 64)); r2 = fmin(r2, __shfl_xor(r2, 2, 64)); r2 = fmin(r2, __shfl_xor(r2, 4, 64));
+            const double cz = wave_fmin(c2);
+            if ((tid & 7) == 0) a.t2_rowmin[gidx] = r2;
+            if (lane == 0) a.t2_colmin[4 * mbi + (tid >> 6)] = cz;
+        }
+    } else {
+        // ------------------------------------------------------------------------------ S: seed bound, winner
+        double qc = PINF;
+        if (seed_is_unit && (int64_t)tid * sstride >= uvalid) cand.key = ~0ull;
+        if (cand.key != ~0ull) {
+            const int64_t ci = (int64_t)(cand.pad & 0xffffffffull), cj = (int64_t)(cand.pad >> 32);
+            if (ci < P && cj < P && ci != px && cj != px && ci != py && cj != py) {
+                const double uia = Uc[ci], uib = Uc[cj];
+                const double xa = rowx[ci], ya = rowy[ci], xb = rowx[cj], yb = rowy[cj];
+                const double ua = nj_unew(uia, xa, ya, nj_val(xa, ya, d)) / r1;
+                const double ub = nj_unew(uib, xb, yb, nj_val(xb, yb, d)) / r1;
+                const double qk = fmin((cand.d - ua) - ub, (cand.d - ub) - ua);
+                qc = qk == qk ? qk : qc;
+            }
+        }
+        qc = wave_fmin(qc);
+        __syncthreads();            // (sq was read by every thread above)
+        if (lane == 0) sq[tid >> 6] = qc;
+        __syncthreads();
+        if (tid == 0) {
+            hdr->seed = fmin(fmin(sq[0], sq[1]), fmin(sq[2], sq[3]));
+            hdr->px = (long long)px; hdr->py = (long long)py;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static int64_t round_up16(int64_t v) { return (v + 15) / 16 * 16; }
@@ -866,7 +1190,7 @@ static unsigned long long* g_njp_dbg_last = nullptr;
 // hipFree of the 7.2 GB matrices (and of ~15 vectors per epoch, 8 epochs per run) serialise with the device and
 // cost more than the distance kernel when a context builds its matrix again (bench.py's steps).
 struct SlabPlan {
-    size_t U, R, Ur, KA, KB, slot_of_pos, pos_of_slot, perm, umin, list, blk_cb, blk_g0, cnt_all, total;
+    size_t U, R, Ur, KA, KB, slot_of_pos, pos_of_slot, perm, umin, list, blk_cb, blk_g0, cnt_all, t2_hdr, t2_rmax, t2_cmax, t2_colmin, t2_rowmin, t2_cmin, total;
     int64_t list_stride;
 };
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -912,6 +1236,11 @@ static SlabPlan slab_plan(int64_t P, int64_t N, int local_ranks)
     }
     p.blk_cb = take(nprep * 4); p.blk_g0 = take(nprep * 4);
     p.cnt_all = take((size_t)(4 * local_ranks) * 8);
+    // njp_post2_kernel: header, per-group and per-sub-strip values (M block m writes groups 32 m .. 32 m + 31, sub-strips 4 m .. 4 m + 3)
+    p.t2_hdr = take(256);
+    p.t2_rmax = take((size_t)(32 * (S + 1)) * 8); p.t2_rowmin = take((size_t)(32 * (S + 1)) * 8);
+    p.t2_cmax = take((size_t)(4 * (S + 1)) * 8); p.t2_colmin = take((size_t)(4 * (S + 1)) * 8);
+    p.t2_cmin = take(nprep * 8);       // one coarse bound per test block
     p.total = off;
     return p;
 }
@@ -971,6 +1300,11 @@ static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, char
     q.blk_cb = reinterpret_cast<int32_t*>(slab + plan.blk_cb);
     q.blk_g0 = reinterpret_cast<int32_t*>(slab + plan.blk_g0);
     q.cnt_all = reinterpret_cast<unsigned long long*>(slab + plan.cnt_all);
+    q.t2_hdr = slab + plan.t2_hdr;
+    q.t2_rmax = reinterpret_cast<double*>(slab + plan.t2_rmax); q.t2_rowmin = reinterpret_cast<double*>(slab + plan.t2_rowmin);
+    q.t2_cmax = reinterpret_cast<double*>(slab + plan.t2_cmax); q.t2_colmin = reinterpret_cast<double*>(slab + plan.t2_colmin);
+    q.t2_cmin = reinterpret_cast<double*>(slab + plan.t2_cmin);
+    DPR_HIP(hipMemsetAsync(q.t2_hdr, 0, 256, s));
     DPR_HIP(hipMemsetAsync(q.U, 0xff, 2 * vec * sizeof(double), s));   // NaN = dead / padding, in both buffers
     DPR_HIP(hipMemsetAsync(q.R, 0, 2 * vec * sizeof(double), s));
     DPR_HIP(hipMemsetAsync(q.Ur, 0xff, vec * sizeof(double), s));   // NaN beyond P
@@ -995,6 +1329,7 @@ static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, char
     DPR_HIP(hipMemsetAsync(q.cnt_all, 0, sizeof(unsigned long long) * (size_t)(4 * local_ranks), s));
     hipLaunchKernelGGL(njp_fill_u64_kernel, dim3(256), dim3(256), 0, s, (uint64_t*)q.umin, q.nunits_alloc,
                        enc_f64_host(-__builtin_inf()));
+    hipLaunchKernelGGL(njp_fill_u64_kernel, dim3(16), dim3(256), 0, s, (uint64_t*)q.t2_cmin, (int64_t)q.nprep, 0xFFF0000000000000ull);   // -inf (plain doubles)
     DPR_HIP(hipGetLastError());
     q.fresh = true;
     return DPR_OK;
@@ -1236,6 +1571,7 @@ static NjpArgs njp_args(NjBuffers& b, int v)
     a.log_x = b.log_x; a.log_y = b.log_y; a.log_bx = b.log_bx; a.log_by = b.log_by;
     a.iterstats = (unsigned long long*)q.iterstats;
     a.dbg = q.dbg; a.dbg_it = q.dbg_it;
+    a.t2_hdr = q.t2_hdr; a.t2_rmax = q.t2_rmax; a.t2_cmax = q.t2_cmax; a.t2_colmin = q.t2_colmin; a.t2_rowmin = q.t2_rowmin; a.t2_cmin = q.t2_cmin;
     { static const int fl = std::getenv("DPR_NJP_FLAGS") ? std::atoi(std::getenv("DPR_NJP_FLAGS")) : 0; a.flags = fl; }
     return a;
 }
@@ -1256,6 +1592,14 @@ static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
     const unsigned ublocks = update ? (unsigned)((b.N + kThreads - 1) / kThreads) : 0u;
     a.nupd = (int)ublocks;
     if ((unsigned)a.ntest + ublocks == 0u) return DPR_OK;      // (a rank without test blocks in a tests-only launch)
+    // large shape on a single rank: producers, then the test blocks (njp_post2_kernel; DPR_NJP_POST2=0: the fused kernel)
+    static const bool post2 = !(std::getenv("DPR_NJP_POST2") && std::atoi(std::getenv("DPR_NJP_POST2")) == 0);
+    if (post2 && a.tg == 256 && a.ns == kBigNS && a.sh_world == 1 && a.dbg == nullptr) {
+        hipLaunchKernelGGL((njp_post2_kernel<kBigNS, 0>), dim3(ublocks + (unsigned)a.nrb + 1u), dim3(kThreads), 0, s, a);
+        if (a.ntest > 0) hipLaunchKernelGGL((njp_post2_kernel<kBigNS, 1>), dim3((unsigned)a.ntest), dim3(kThreads), 0, s, a);
+        DPR_HIP(hipGetLastError());
+        return DPR_OK;
+    }
     if (a.tg == 64) hipLaunchKernelGGL((njp_post_kernel<64, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
     else if (a.tg == 32) hipLaunchKernelGGL((njp_post_kernel<32, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
     else if (a.tg == 128) hipLaunchKernelGGL((njp_post_kernel<128, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);

@@ -1,0 +1,64 @@
+"""Worker of tests/test_gpu_nj.py::test_large_shape_post_kernels: the pruned NJ with the LARGE launch shape of the post kernel
+forced at small sizes (DPR_NJ_BIG_P is read once per process, hence a process of its own), checked against the oracle.
+    python -m tests._njp_shape_worker  -> prints one JSON line"""
+import json
+import sys
+
+import numpy as np
+
+
+def main():
+    import dipper_amd
+    from dipper_amd import capi
+    from tests import _orc, _util
+    orc = _orc.load()
+    out = []
+    cases = [("additive", 700, 3), ("additive", 2100, 4), ("ties", 900, 5), ("additive", 4500, 6), ("msa", 5000, 7)]
+    for kind, n, seed in cases:
+        rng = np.random.default_rng(seed)
+        d = dipper_amd.Dipper(0)
+        try:
+            d.set_nj_mode(1)
+            d.set_nj_adaptive(0)                 # the pruned plan from the first to the last iteration
+            if kind == "msa":
+                seqs = _util.synth_alignment(rng, n, 600, mean_bl=2e-3, lo=2e-4, hi=2e-2)
+                d.set_msa(capi.pack4_many(seqs), 600)
+                d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+                D = d.matrix()
+            else:
+                if kind == "ties":
+                    D = rng.integers(1, 4, size=(n, n)).astype(np.float64)
+                    D = np.tril(D, -1) + np.tril(D, -1).T
+                else:
+                    D = _util.random_additive_matrix(rng, n, zero_frac=0.3)
+                d.set_matrix_full(D)
+                d.dist_matrix(capi.SRC_MATRIX)
+            res = d.nj_run()
+        finally:
+            d.close()
+        ref = orc.nj_run(np.tril(D, -1))
+        ok = res["iters"] == n - 2 and all(np.array_equal(res[k], ref[k]) for k in ("merge_x", "merge_y", "bl_x", "bl_y")) and res["last_d"] == ref["last_d"]
+        out.append({"kind": kind, "n": n, "ok": bool(ok)})
+    # no Q candidate below 10000 from the first iteration on (tests/test_gpu_nj.py::test_nj_no_candidate): error -4, no hang
+    for n in (8, 1500):
+        D = np.full((n, n), -1.0e5)
+        np.fill_diagonal(D, 0.0)
+        d = dipper_amd.Dipper(0)
+        try:
+            d.set_nj_mode(1)
+            d.set_nj_adaptive(0)
+            d.set_matrix_full(D)
+            d.dist_matrix(capi.SRC_MATRIX)
+            try:
+                d.nj_run()
+                code = 0
+            except dipper_amd.DipperError as e:
+                code = e.code
+        finally:
+            d.close()
+        out.append({"kind": "no candidate", "n": n, "ok": code == -4})
+    print("RESULT " + json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -451,3 +451,23 @@ def test_nj_adaptive_off_is_pruned_only(orc):
             assert np.array_equal(res2[key], ref[key]), key
     finally:
         d.close()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("post2", ["1", "0"])
+def test_large_shape_post_kernels(post2):
+    """The large launch shape of the pruned path's post kernel (used from 40 000 positions: 256 row groups x 4 strips per test
+    block) forced at small sizes, with both kernels for it: njp_post2_kernel (producer blocks hand row / column maxima to the
+    test blocks of the same launch) and the fused njp_post_kernel<256, 4> -- merge logs equal the oracle's.  Also a run
+    without any Q candidate: the test blocks must leave their poll (status 1), not wait for the producers' tag."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DPR_NJ_BIG_P="1", DPR_NJP_POST2=post2, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-m", "tests._njp_shape_worker"], cwd=root, env=env, capture_output=True, text=True, timeout=800)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert r.returncode == 0 and line, r.stderr[-3000:]
+    out = json.loads(line[0][7:])
+    assert len(out) == 7 and all(c["ok"] for c in out), out
