@@ -130,14 +130,41 @@ int njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world)
 // ------------------------------------------------------------------------------------------------
 // epoch build: B[a][b] = A[perm[a]][perm[b]]
 // ------------------------------------------------------------------------------------------------
+// Range of the entries an epoch has held, for njp_post2_kernel's proof: mm[0] = enc_f64(m'), mm[1] = enc_f64(A') with
+//   every entry >= 2 min(m', 0)   and   every |entry| <= 2 A'.
+// Millions of waves report; an atomic per wave on two words serialises (the epoch build of 26 000 positions went from 3.6 to
+// 84 ms).  So a wave only writes when it moves a word by more than a factor of two -- or across zero, the one fact that
+// matters for non-negative input (no wave ever writes then): a few atomics per doubling.
+__device__ __forceinline__ void njp_note_range(unsigned long long* mm, double lo, double hi)
+{
+    if (lo < 0.0) {
+        const double cur = dec_f64(mm[0]);
+        if (cur >= 0.0 || lo < 2.0 * cur) atomicMin(&mm[0], (unsigned long long)enc_f64(lo));
+    }
+    if (hi > 0.0) {
+        const double cur = dec_f64(mm[1]);
+        if (hi > 2.0 * cur) atomicMax(&mm[1], (unsigned long long)enc_f64(hi));
+    }
+}
+
+// mm (may be null): see njp_note_range
 __global__ __launch_bounds__(kThreads) void njp_permute_kernel(const double* __restrict__ A, int64_t lda,
                                                                double* __restrict__ B, int64_t ldb,
-                                                               const int32_t* __restrict__ perm, int64_t P)
+                                                               const int32_t* __restrict__ perm, int64_t P,
+                                                               unsigned long long* __restrict__ mm)
 {
+    double lo = __builtin_inf(), hi = 0.0;
     for (int64_t a = blockIdx.y; a < P; a += gridDim.y) {
         const double* row = A + (int64_t)perm[a] * lda;
-        for (int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x; b < P; b += (int64_t)gridDim.x * kThreads)
-            B[a * ldb + b] = row[perm[b]];
+        for (int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x; b < P; b += (int64_t)gridDim.x * kThreads) {
+            const double v = row[perm[b]];
+            B[a * ldb + b] = v;
+            lo = fmin(lo, v); hi = fmax(hi, fabs(v));
+        }
+    }
+    if (mm != nullptr) {
+        lo = wave_fmin(lo); hi = wave_fmax(hi);
+        if ((threadIdx.x & 63) == 0) njp_note_range(mm, lo, hi);
     }
 }
 
@@ -854,150 +881,78 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
 }
 
 // ------------------------------------------------------------------------------------------------
-// POST(it), LARGE shape (P >= njp_big_p(), single rank), as TWO launches with the redundancy taken out.
-// njp_post_kernel's test blocks each recompute the row sums after the merge for their own 4096 rows and 2048 columns and
-// reduce all scan records themselves: ~220 KB of L2 reads per block, 230 MB per iteration at 100 000 tips (of which the unit
-// bounds are 20 MB) with 230 registers per thread, i.e. two rounds of blocks -- 21.5 us per launch, the largest item of that
-// run.  Here the work that does not depend on the unit is done ONCE:
-//   launch A (njp_post2_kernel<kNS, 0>), light blocks, all resident:
-//     U blocks [0, nupd)          the update role, unchanged (indexed by reference slot);
-//     M blocks, one per 512 positions: row sums after the merge by POSITION -> per 16-row group the maximum (rmax), per
-//               128-column sub-strip the maximum (cmax); where the node that leaves quarantine crosses: per sub-strip the
-//               minimum of its buffered row over the live columns before it, per group over the live rows behind it;
-//     S block   the seed bound (scan records re-evaluated with the new row sums) and the winner's positions;
-//   launch B (njp_post2_kernel<kNS, 1>): T blocks of 256 row groups x up to kNS strips: their unit bounds, one 8-byte load per
-//     group and 4 per strip instead of the rows; 72 registers.
-// Same values as the fused blocks computed (max and min are exact, the division by n - 3 is applied after the maximum in
-// both), so the lists hold the same units and the merge log is the same bit for bit.
-// (Tried first: A and B as roles of ONE launch, the T blocks polling a tag that the last producer publishes -- agent-scope
-//  write-through stores, drained, ticket; correct, but every hand-over step is a round trip across the XCDs (~2 us each, ten
-//  of them in a chain): 40 us per launch instead of 27 for the fused kernel at 100 000 tips, profiles/r3/nj_kt_100k.txt.
-//  A kernel boundary is cheaper than that chain.)
+// POST(it), LARGE shape (P >= njp_big_p(), single rank): ONE launch of light blocks.
+// njp_post_kernel's test blocks each recompute the row sums after the merge for their own 4096 rows and 2048 columns (the
+// test of iteration it + 1 needs the maxima of the row sums AFTER merge it, which the update blocks of the same launch are
+// only just storing) and reduce all scan records: ~220 KB of L2 reads per block, 230 MB per iteration at 100 000 tips, 230
+// registers per thread, two rounds of blocks -- 21.5 us per launch, the largest item of that run.
+// Here nothing is recomputed per test block.  The maxima come from the PREVIOUS launch plus a proof:
+//   * M blocks (one per 512 positions) of POST(it - 1) stored, per 16-row group and per 128-column sub-strip, the maximum of
+//     the row sums after merge it - 1 (undivided) -- these ARE the current row sums of iteration it;
+//   * merge it changes a row sum by  t_i = fl(fl(-dxi - dyi) + val_i),  val_i = fl(fl(dxi + dyi - d) / 2).  While every live
+//     matrix entry is >= 0, t_i <= 0 (val_i <= fl(dxi + dyi) / 2), so fl(U_i + t_i) <= U_i: the maxima of the previous
+//     launch are upper bounds of the maxima after this merge, and fl(max / (n - 3)) bounds every fl(U'_i / (n - 3)) because
+//     division by a positive number is monotone.  With negative entries (NJ creates them when the triangle inequality
+//     fails) the bound gets a slack T >= every t_i:  T = 1.5 |m| (1 + 2^-30) + A 2^-48  with m the smallest entry and A the
+//     largest magnitude the epoch has held (the header keeps both within a factor of two, njp_note_range: the epoch build
+//     reduces the matrix, the M blocks add every val they create) -- exact value -(s + d) / 2 <= 1.5 |m| for
+//     s = fl(dxi + dyi) >= 2 m, d >= m, plus the rounding of three operations on magnitudes <= 3 A;
+//   * the node that leaves quarantine (created by merge it - 1) has no entry in those maxima -- its row sum is stored by
+//     SCAN(it) -- so its own value is added to its group and its sub-strip;
+//   * its row was written by the U blocks of POST(it - 1); the M blocks of that launch stored its minimum per sub-strip (live
+//     columns before it) and per group (live rows behind it) over the nodes alive THEN, a superset of those alive now: a
+//     smaller minimum, still a valid lower bound for the units it crosses.
+// Looser bounds list more units, never fewer: the scan computes exact minima whatever is listed, so the merge log stays the
+// reference's bit for bit (the first 20 000 iterations at 100 000 tips list 1.00x as many units as the exact test).
+// Roles: U blocks [0, nupd) the update role, unchanged; M blocks; T blocks of 256 row groups x up to kNS strips, each ONE
+// coarse cell: t2_cmin[tb] <= every sub-unit bound of the cell (kept by this block alone) and, by the same monotonicity,
+// lb(unit) >= fl(fl(cmin - rmaxC) - cmaxC) -- a cell whose coarse bound exceeds the seed bound reads none of its 32 KB of unit
+// bounds.  No block waits for another one.
+// (Tried before, profiles/r3/nj_kt_100k_post2_split.txt: exact maxima handed from producer blocks to the test blocks of the
+//  SAME launch through a tag -- every hand-over step is a round trip across the XCDs, 40 us per launch; as two launches --
+//  14.6 + 8.8 us, each pays launch + two dependent misses + drain: 2.60 s instead of 2.68 s for the whole run.)
 // ------------------------------------------------------------------------------------------------
-struct Post2Hdr { double seed; long long px, py; };
+struct Post2Hdr { unsigned long long min_enc, maxabs_enc; };      // enc_f64 order; over all entries the epoch has held
 
-template <int kNS, int kPart>
+// epoch start: maxima of the row sums as they stand (buffer `par`), nothing in quarantine
+__global__ __launch_bounds__(kThreads) void njp_t2_init_kernel(const double* __restrict__ Uc, int64_t P, double* __restrict__ rmaxU,
+                                                               double* __restrict__ cmaxU)
+{
+    const int tid = threadIdx.x;
+    const int64_t p0 = (int64_t)blockIdx.x * kTileCols + 2 * tid;
+    const v2d uc = *reinterpret_cast<const v2d*>(Uc + p0);
+    const double NINF = -__builtin_inf();
+    const double m2 = fmax(((uc.x == uc.x) & (p0 < P)) ? uc.x : NINF, ((uc.y == uc.y) & (p0 + 1 < P)) ? uc.y : NINF);
+    double gm = m2;
+    gm = fmax(gm, __shfl_xor(gm, 1, 64)); gm = fmax(gm, __shfl_xor(gm, 2, 64)); gm = fmax(gm, __shfl_xor(gm, 4, 64));
+    const double cm = wave_fmax(m2);
+    if ((tid & 7) == 0) rmaxU[p0 >> 4] = gm;
+    if ((tid & 63) == 0) cmaxU[4 * blockIdx.x + (tid >> 6)] = cm;
+}
+
+template <int kNS>
 __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
 {
     constexpr int kTG = 256;
     __shared__ double s[kThreads];
     __shared__ double sq[kThreads / 64], sdd[kThreads / 64];
     __shared__ uint64_t sk[kThreads / 64], spp[kThreads / 64];
+    __shared__ double sseed[kThreads / 64], srC[kThreads / 64];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int bx = (int)blockIdx.x;
     const int nmb = a.nrb;                                   // M blocks: one per 512 positions
-    const int role = kPart == 1 ? 3 : bx < a.nupd ? 0 : bx < a.nupd + nmb ? 1 : 2;
-    const int ubi = bx, mbi = bx - a.nupd, tb = bx;
+    const int role = bx < a.nupd ? 0 : bx < a.nupd + nmb ? 1 : 3;
+    const int ubi = bx, mbi = bx - a.nupd, tb = bx - a.nupd - nmb;
     Post2Hdr* hdr = reinterpret_cast<Post2Hdr*>(a.t2_hdr);
     const double NINF = -__builtin_inf(), PINF = __builtin_inf();
 
+    // hop 1: state line, scan records, and what each role can address without knowing the winner
     const int64_t it = a.st->itb;
     const int64_t limit = a.st->it_limit, N = a.st->N;
     const int64_t pz = (int64_t)a.st->pnew[it & 1];
     const int64_t P = a.P;
     const int64_t G16 = (P + kUR - 1) / kUR;
-    const double* __restrict__ Uc = a.U + (it & 1) * a.vstride;
-    double* __restrict__ Un = a.U + ((it + 1) & 1) * a.vstride;
-    const double* __restrict__ Rz = a.R + ((it + 1) & 1) * a.vstride;        // written by POST(it - 1)
-
-    if (role == 3) {
-        // ------------------------------------------------------------------------------------------ test role
-        const int cb0 = a.blk_cb[tb];
-        const int64_t g = (int64_t)a.blk_g0[tb] + tid;
-        const bool have_g = g < G16;
-        const int64_t send = njp_strips_of_rows((int64_t)a.blk_g0[tb], kTG, P);
-        const int nsb = (int)(send - cb0 < kNS ? send - cb0 : kNS);
-        // hop 1: everything the COARSE test needs.  The block's 256 groups x nsb strips are one coarse cell with the bound
-        // t2_cmin[tb] <= every sub-unit bound of the cell (kept by this block alone: lowered together with a unit bound,
-        // recomputed exactly whenever the block reads its unit bounds); monotonicity of fl(x - y) gives, for every unit of the
-        // cell,  lb(unit) >= fl(fl(cmin - rmaxC) - cmaxC)  with the maxima over the cell's groups / sub-strips -- a cell whose
-        // coarse bound exceeds the seed bound holds no candidate and its 32 KB of unit bounds are not read at all.
-        const double rmax = have_g ? a.t2_rmax[g] : NINF;
-        double cm4[kNS][4];
-#pragma unroll
-        for (int k = 0; k < kNS; ++k)
-#pragma unroll
-            for (int w = 0; w < 4; ++w) cm4[k][w] = k < nsb ? a.t2_cmax[4 * (cb0 + k) + w] : NINF;
-        const double cmin = a.t2_cmin[tb];
-        const int64_t px = (int64_t)hdr->px, py = (int64_t)hdr->py;
-        const double bound = hdr->seed;
-        if (a.st->status != 0 || it >= limit || !a.do_tests) return;
-        const int64_t n = N - it;
-        if (n < 3) return;
-        const bool fold = pz >= 0 && pz != px && pz != py;                       // block-uniform
-        const int64_t gz = fold ? pz / kUR : -1;
-        const bool gz_here = fold && gz >= (int64_t)a.blk_g0[tb] && gz < (int64_t)a.blk_g0[tb] + kTG;
-        const int wpz = fold ? (int)((pz % kTileCols) / (kTileCols / 4)) : -1;
-        const int64_t cbz = fold ? pz / kTileCols : -1;
-        const bool pz_here = fold && cbz >= cb0 && cbz < cb0 + nsb;              // block-uniform
-        {
-            double rC = wave_fmax(rmax);
-            if (lane == 0) sq[tid >> 6] = rC;
-            __syncthreads();
-            rC = fmax(fmax(sq[0], sq[1]), fmax(sq[2], sq[3]));
-            double cC = NINF;
-#pragma unroll
-            for (int k = 0; k < kNS; ++k)
-#pragma unroll
-                for (int w = 0; w < 4; ++w) cC = fmax(cC, cm4[k][w]);
-            const double lbC = fmin((cmin - rC) - cC, (cmin - cC) - rC);
-            // the node leaving quarantine lowers unit bounds of this cell: those lanes must run (block-uniform decision)
-            if (!gz_here && !pz_here && !(lbC <= bound) && !(a.flags & 4)) return;
-        }
-        ulonglong2 um0[kNS], um1[kNS];
-#pragma unroll
-        for (int k = 0; k < kNS; ++k) {
-            um0[k] = make_ulonglong2(0ull, 0ull); um1[k] = um0[k];
-            if (k < nsb && have_g && g >= 32 * (int64_t)(cb0 + k)) {
-                const unsigned long long* up = a.umin + ((int64_t)(cb0 + k) * G16 + g) * 4;
-                um0[k] = *reinterpret_cast<const ulonglong2*>(up); um1[k] = *reinterpret_cast<const ulonglong2*>(up + 2);
-            }
-        }
-        double mymin = PINF;           // minimum of this lane's sub-unit bounds after the fold: the cell's new coarse bound
-#pragma unroll
-        for (int sidx = 0; sidx < kNS; ++sidx) {
-            if (sidx >= nsb) break;                       // block-uniform
-            const int cb = cb0 + sidx;
-            const bool pz_strip = fold && cbz == cb;                                 // block-uniform
-            const bool have = have_g && g >= 32 * (int64_t)cb;
-            unsigned long long* up4 = a.umin + ((int64_t)cb * G16 + (have ? g : 0)) * 4;
-            double u4[4] = { PINF, PINF, PINF, PINF };
-            if (have) { u4[0] = dec_f64(um0[sidx].x); u4[1] = dec_f64(um0[sidx].y); u4[2] = dec_f64(um1[sidx].x); u4[3] = dec_f64(um1[sidx].y); }
-            const double newminA = (pz_strip && have_g) ? a.t2_rowmin[g] : PINF;
-            int submask = 0;
-            if (have) {
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const double cmw = cm4[sidx][w];
-                    double nm = (gz_here && g == gz) ? a.t2_colmin[4 * cb + w] : PINF;      // the unit (this strip, group of pz)
-                    if (pz_strip && w == wpz) nm = fmin(nm, newminA);
-                    if (nm < u4[w]) {                          // persist the lowered bound (this lane is the unit's only writer here)
-                        u4[w] = nm;
-                        up4[w] = enc_f64(nm);
-                    }
-                    mymin = fmin(mymin, u4[w]);
-                    const double lb = fmin((u4[w] - rmax) - cmw, (u4[w] - cmw) - rmax);
-                    if ((cmw > NINF) && (lb <= bound)) submask |= 1 << w;
-                }
-            }
-            const bool keep = have && (rmax > NINF) && submask != 0;
-            const unsigned long long mask = __ballot(keep);
-            unsigned long long base = 0;
-            if (lane == 0 && mask) base = atomicAdd(&a.cnt[(it + 1) % 3], (unsigned long long)__popcll(mask));
-            base = __shfl(base, 0, 64);
-            if (keep) a.list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)(((uint32_t)submask << 28) | ((uint32_t)cb << 18) | (uint32_t)g);
-        }
-        mymin = wave_fmin(mymin);
-        __syncthreads();               // (sq: the coarse maxima above were read by every thread)
-        if (lane == 0) sq[tid >> 6] = mymin;
-        __syncthreads();
-        if (tid == 0) a.t2_cmin[tb] = fmin(fmin(sq[0], sq[1]), fmin(sq[2], sq[3]));
-        return;
-    }
-
-    // ------------------------------------------------------------------------------ producers: U, M, S
-    // hop 1: scan records and what each role can address without knowing the winner
     const int nrec_all = a.urecs + a.nrb;
     NjRecord r0; r0.q = 10000.0; r0.key = ~0ull; r0.d = 0; r0.pad = 0;
     constexpr int kMine = 5;
@@ -1007,40 +962,64 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
         const int idx = tid + k * kThreads;
         if (idx < nrec_all) mine[k] = a.partials[idx];
     }
-    const unsigned long long cnt_raw = a.all_defined ? (unsigned long long)a.urecs : a.cnt[it % 3];
-    const int64_t uvalid = (int64_t)(cnt_raw < (unsigned long long)a.urecs ? cnt_raw : (unsigned long long)a.urecs);
-    // S: the seed candidate of this thread (as in njp_post_kernel)
+    // T: the seed candidate of this thread (as in njp_post_kernel)
     const int nseed_rows = a.nrb < kThreads / 2 ? a.nrb : kThreads / 2;
     const int nseed_units = kThreads - nseed_rows;
     const int64_t sstride = a.all_defined && a.urecs >= 2 * nseed_units ? a.urecs / nseed_units : 1;
     const bool seed_is_unit = tid < nseed_units;
     NjRecord cand = r0;
-    if (role == 2) {
+    int cb0 = 0;
+    int64_t g0 = 0;
+    if (role == 3) {
         if (!seed_is_unit) cand = a.partials[a.urecs + (tid - nseed_units)];
         else if ((int64_t)tid * sstride < a.urecs) cand = a.partials[(int64_t)tid * sstride];
+        cb0 = a.blk_cb[tb];
+        g0 = (int64_t)a.blk_g0[tb];
     }
-    // U: position and row sum of this thread's slot;  M: row sums (and the buffered row of the node leaving quarantine) of its two positions
-    const int64_t i = (int64_t)ubi * kThreads + tid;     // reference slot (U)
-    int64_t p = -1;
-    double up = 0.0;
+    // (U) a block takes TWO chunks of 256 reference slots (the chunk sums stay per 256 slots: the canonical order of U[x]) --
+    // with one chunk per block the grid of a 100 000-tip epoch is 1 183 blocks for 1 024 resident ones (110 registers), and
+    // the test blocks, last in the grid, wait for a second round
+    const int64_t i = (int64_t)ubi * (2 * kThreads) + tid;     // first reference slot (U); the second one is i + 256
+    int64_t p = -1, pb = -1;
+    int2 sl = make_int2(-1, -1);                             // (M) reference slots of its two positions (-1: dead / padding)
+    if (role == 0) { p = (int64_t)a.pos_of_slot[i]; pb = (int64_t)a.pos_of_slot[i + kThreads]; }
+    if (role == 1) sl = *reinterpret_cast<const int2*>(a.slot_of_pos + (int64_t)(bx - a.nupd) * kTileCols + 2 * tid);
+    // hop 2: needs the iteration index / the position
+    const int par = (int)(it & 1);                           // T reads the maxima of buffer par, M writes buffer 1 - par
+    const double* __restrict__ Uc = a.U + (it & 1) * a.vstride;
+    double* __restrict__ Un = a.U + ((it + 1) & 1) * a.vstride;
+    const unsigned long long cnt_raw = a.all_defined ? (unsigned long long)a.urecs : a.cnt[it % 3];
+    const int64_t uvalid = (int64_t)(cnt_raw < (unsigned long long)a.urecs ? cnt_raw : (unsigned long long)a.urecs);
+    const double emin = dec_f64(hdr->min_enc), eabs = dec_f64(hdr->maxabs_enc);
     const int64_t p0 = (int64_t)mbi * kTileCols + 2 * tid;      // (M) < P + 512
     v2d uc; uc.x = 0.0; uc.y = 0.0;
-    v2d rz; rz.x = PINF; rz.y = PINF;
-    if (role == 0) p = (int64_t)a.pos_of_slot[i];
-    if (role == 1) {
-        uc = *reinterpret_cast<const v2d*>(Uc + p0);
-        if (pz >= 0) rz = *reinterpret_cast<const v2d*>(Rz + p0);
+    const int64_t g = g0 + tid;                                  // (T) this lane's row group
+    const bool have_g = role == 3 && g < G16;
+    int nsb = 0;
+    double rmaxU = NINF, cmin = NINF, uz = NINF;
+    double cm4[kNS][4];
+    double sUa = 0.0, sUb = 0.0;
+    int64_t ci = -1, cj = -1;
+    if (role == 1) uc = *reinterpret_cast<const v2d*>(Uc + p0);
+    if (role == 3) {
+        const int64_t send = njp_strips_of_rows(g0, kTG, P);
+        nsb = (int)(send - cb0 < kNS ? send - cb0 : kNS);
+        if (pz >= 0) uz = Uc[pz];
+        if (seed_is_unit && (int64_t)tid * sstride >= uvalid) cand.key = ~0ull;          // not written by this iteration's scan
+        if (cand.key != ~0ull) {
+            ci = (int64_t)(cand.pad & 0xffffffffull); cj = (int64_t)(cand.pad >> 32);
+            if (ci < P && cj < P) { sUa = Uc[ci]; sUb = Uc[cj]; } else ci = -1;
+        }
     }
 #pragma unroll
     for (int k = 0; k < kMine; ++k) {
         const int idx = tid + k * kThreads;
         if (idx >= uvalid && idx < a.urecs) mine[k] = r0;   // not written by this iteration's scan
     }
-    if (role == 0) up = (i < N && p >= 0) ? Uc[p] : 0.0;
     if (a.st->status != 0 || it >= limit) return;
     const int64_t n = N - it;
     if (n < 3) return;
-    if (role == 0 && (!a.do_update || (int64_t)ubi * kThreads >= n)) return;
+    if (role == 0 && (!a.do_update || (int64_t)ubi * (2 * kThreads) >= n)) return;
     if (role != 0 && !a.do_tests) return;
 
     // ---- select (thrust::min_element, src/neighborJoining.cu:214)
@@ -1060,8 +1039,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
 
     const int64_t last = n - 1;
     if (bk == ~0ull) {
-        // no candidate: the run ends with status 1 (launch B sees it and returns)
-        if ((role == 0 && i == last) || (role == 2 && tid == 0)) a.st->status = 1;
+        if (role == 0 && (i == last || i + kThreads == last)) a.st->status = 1;
         return;
     }
     const int64_t ki = (int64_t)(bk & 0xFFFFFFull), kj = (int64_t)((bk >> 24) & 0xFFFFFFull);
@@ -1074,11 +1052,16 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
     const double* __restrict__ rowy = a.D + py * a.ld;
 
     if (role == 0) {
-        // ------------------------------------------------------------------------------ update role (as njp_post_kernel's)
-        double* __restrict__ Rw = a.R + (it & 1) * a.vstride;
-        double val = 0.0;
-        if (i < n) {
-            if (i == last) {
+        // ------------------------------------------------------------------------------ U: what needs the SLOT order
+        // the chunk sums of the new node's row (canonical order of U[x]), the log, the state, the relabel of the last slot;
+        // every per-position store of the update is the M blocks' (coalesced there, a scatter through pos_of_slot here)
+        double val2[2] = { 0.0, 0.0 };
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t ii = i + h * kThreads;
+            const int64_t pp = h ? pb : p;
+            if (ii >= n) continue;
+            if (ii == last) {
                 const double r = (double)(n - 2);
                 double blX = (d + Uc[px] / r - Uc[py] / r) * 0.5;
                 double blY = d - blX;
@@ -1092,87 +1075,196 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
                 a.st->cnt_list[(it + 2) % 3] = 0ull;
                 for (int v = 0; v < a.cnt_ranks; ++v) a.cnt_all[4 * v + (it + 2) % 3] = 0ull;
             }
-            int64_t new_slot = i;
-            if (i != x && i != y) {
-                const double dxi = rowx[p], dyi = rowy[p];
-                val = nj_val(dxi, dyi, d);
-                const double u = nj_unew(up, dxi, dyi, val);
-                Un[p] = u;
-                a.Ur[p] = u / r1;
-                Rw[p] = val;
-                if (a.flags & 8) { }       // experiment (WRONG results): no column store -- what do the n scattered stores cost?
-                else if (a.flags & 1) a.D[p * a.ld + px] = val;
-                else __hip_atomic_store(a.D + p * a.ld + px, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (i == last) {
-                    new_slot = y;
-                    a.slot_of_pos[p] = (int32_t)y;
-                    a.pos_of_slot[y] = (int32_t)p;
+            if (ii != x && ii != y) {
+                val2[h] = (a.flags & 32) ? 0.0 : nj_val(rowx[pp], rowy[pp], d);      // (32: timing experiment, WRONG results)
+                if (ii == last) {           // relabel: the node of the last slot now lives in slot y
+                    a.slot_of_pos[pp] = (int32_t)y;
+                    a.pos_of_slot[y] = (int32_t)pp;
                 }
-            } else if (i == y) {
-                a.Ur[py] = __builtin_nan("");
-                Un[py] = __builtin_nan("");
+            } else if (ii == y) {
                 a.slot_of_pos[py] = -1;
-                Rw[py] = 0.0;
-                new_slot = -1;
-            } else {
-                a.Ur[px] = __builtin_nan("");
-                Rw[px] = 0.0;
             }
-            if (new_slot >= 0) { a.KA[p] = nj_key_a(new_slot, n1); a.KB[p] = nj_key_b(new_slot); }
         }
-        const double cs = block_tree256_lane0(val, s);
-        if (tid == 0) a.xpart[ubi] = cs;
+        const double cs0 = block_tree256_lane0(val2[0], s);
+        if (tid == 0) a.xpart[2 * ubi] = cs0;
+        if ((int64_t)(2 * ubi + 1) * kThreads < n) {      // block-uniform: the second chunk holds live slots
+            __syncthreads();
+            const double cs1 = block_tree256_lane0(val2[1], s);
+            if (tid == 0) a.xpart[2 * ubi + 1] = cs1;
+        }
         return;
     }
 
-    const bool fold = pz >= 0 && pz != px && pz != py;
+    const int64_t GS = 32 * ((P + kTileCols - 1) / kTileCols + 2), SS4 = 4 * ((P + kTileCols - 1) / kTileCols + 2);
     if (role == 1) {
-        // ------------------------------------------------------------------------------ M: maxima by position
+        // ------------------------------------------------------------------------------ M: the update by POSITION, and the maxima for POST(it + 1)
         const v2d dx = *reinterpret_cast<const v2d*>(rowx + p0);
         const v2d dy = *reinterpret_cast<const v2d*>(rowy + p0);
         const bool live0 = (uc.x == uc.x) & (p0 != px) & (p0 != py) & (p0 < P);
         const bool live1 = (uc.y == uc.y) & (p0 + 1 != px) & (p0 + 1 != py) & (p0 + 1 < P);
-        const double un0 = nj_unew(uc.x, dx.x, dy.x, nj_val(dx.x, dy.x, d));
-        const double un1 = nj_unew(uc.y, dx.y, dy.y, nj_val(dx.y, dy.y, d));
+        const double v0 = nj_val(dx.x, dy.x, d), v1 = nj_val(dx.y, dy.y, d);       // the new node's row
+        const double un0 = nj_unew(uc.x, dx.x, dy.x, v0);
+        const double un1 = nj_unew(uc.y, dx.y, dy.y, v1);
+        if (a.do_update && !(a.flags & 64)) {      // (64: timing experiment, WRONG results)
+            // same values, same destinations as njp_post_kernel's update role (which reaches them through pos_of_slot): new row
+            // sums into the other buffer, the new node's row into the row buffer and its column into the matrix, keys from the
+            // slot (the node of the last slot is relabelled to slot y), quarantine / death marks of the merged pair
+            double* __restrict__ Rw = a.R + (it & 1) * a.vstride;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int64_t pp = p0 + k;
+                const int slot = k ? sl.y : sl.x;
+                const double v = k ? v1 : v0, u = k ? un1 : un0;
+                if (pp >= P) continue;
+                if (pp == px) {
+                    a.Ur[px] = __builtin_nan("");   // quarantine until SCAN(it + 1) has finished its row sum
+                    Rw[px] = 0.0;                  // diagonal
+                    a.KA[px] = nj_key_a(x, n1); a.KB[px] = nj_key_b(x);
+                } else if (pp == py) {
+                    a.Ur[py] = __builtin_nan("");   // dead
+                    Un[py] = __builtin_nan("");
+                    Rw[py] = 0.0;
+                } else if (slot >= 0) {
+                    Un[pp] = u;
+                    a.Ur[pp] = u / r1;
+                    Rw[pp] = v;
+                    if (a.flags & 1) a.D[pp * a.ld + px] = v;
+                    else __hip_atomic_store(a.D + pp * a.ld + px, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // (slot_of_pos of the last slot's position is being rewritten to y by a U block: either value gives y here)
+                    const int64_t new_slot = slot == (int)last ? y : (int64_t)slot;
+                    a.KA[pp] = nj_key_a(new_slot, n1); a.KB[pp] = nj_key_b(new_slot);
+                }
+            }
+        }
         const double m2 = fmax(live0 ? un0 : NINF, live1 ? un1 : NINF);
         double gm = m2;                                                   // group of 16 positions = 8 lanes
         gm = fmax(gm, __shfl_xor(gm, 1, 64)); gm = fmax(gm, __shfl_xor(gm, 2, 64)); gm = fmax(gm, __shfl_xor(gm, 4, 64));
-        const double cm = wave_fmax(m2) / r1;                             // sub-strip of 128 positions = this wave
+        const double cm = wave_fmax(m2);                                  // sub-strip of 128 positions = this wave
         const int64_t gidx = p0 >> 4;
-        if ((tid & 7) == 0) a.t2_rmax[gidx] = gm / r1;           // (-inf stays -inf)
-        if (lane == 0) a.t2_cmax[4 * mbi + (tid >> 6)] = cm;
-        if (fold) {
-            const double c2 = fmin((live0 & (p0 < pz)) ? rz.x : PINF, (live1 & (p0 + 1 < pz)) ? rz.y : PINF);
-            double r2 = fmin((live0 & (p0 > pz)) ? rz.x : PINF, (live1 & (p0 + 1 > pz)) ? rz.y : PINF);
-            r2 = fmin(r2, __shfl_xor(r2, 1, 64)); r2 = fmin(r2, __shfl_xor(r2, 2, 64)); r2 = fmin(r2, __shfl_xor(r2, 4, 64));
-            const double cz = wave_fmin(c2);
-            if ((tid & 7) == 0) a.t2_rowmin[gidx] = r2;
-            if (lane == 0) a.t2_colmin[4 * mbi + (tid >> 6)] = cz;
+        const int wq = 1 - par;
+        if ((tid & 7) == 0) a.t2_rmax[wq * GS + gidx] = gm;                 // undivided
+        if (lane == 0) a.t2_cmax[wq * SS4 + 4 * mbi + (tid >> 6)] = cm;
+        // the new node's row (position px): minimum per sub-strip over the live columns before it, per group over the live
+        // rows behind it
+        const double c2 = fmin((live0 & (p0 < px)) ? v0 : PINF, (live1 & (p0 + 1 < px)) ? v1 : PINF);
+        double r2 = fmin((live0 & (p0 > px)) ? v0 : PINF, (live1 & (p0 + 1 > px)) ? v1 : PINF);
+        r2 = fmin(r2, __shfl_xor(r2, 1, 64)); r2 = fmin(r2, __shfl_xor(r2, 2, 64)); r2 = fmin(r2, __shfl_xor(r2, 4, 64));
+        const double cz = wave_fmin(c2);
+        if ((tid & 7) == 0) a.t2_rowmin[wq * GS + gidx] = r2;
+        if (lane == 0) a.t2_colmin[wq * SS4 + 4 * mbi + (tid >> 6)] = cz;
+        // smallest entry / largest magnitude the epoch has held: this block's new values
+        double vmin = fmin(live0 ? v0 : PINF, live1 ? v1 : PINF);
+        double vabs = fmax(live0 ? fabs(v0) : 0.0, live1 ? fabs(v1) : 0.0);
+        vmin = wave_fmin(vmin); vabs = wave_fmax(vabs);
+        if (lane == 0) njp_note_range(&hdr->min_enc, vmin, vabs);
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------- T: tests of iteration it + 1
+    if (a.flags & 16) return;          // (timing experiment, WRONG results)
+    // hop 3: the maxima of the previous launch (issued here, not with hop 2: the scan records are dead by now and their
+    // 40 registers free -- the chain has this hop anyway) and the seed candidates re-evaluated with the row sums after this merge
+    if (have_g) rmaxU = a.t2_rmax[par * GS + g];
+#pragma unroll
+    for (int k = 0; k < kNS; ++k)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) cm4[k][w] = k < nsb ? a.t2_cmax[par * SS4 + 4 * (cb0 + k) + w] : NINF;
+    cmin = a.t2_cmin[tb];
+    double qc = PINF;
+    if (ci >= 0 && ci != px && cj != px && ci != py && cj != py) {
+        const double xa = rowx[ci], ya = rowy[ci], xb = rowx[cj], yb = rowy[cj];
+        const double ua = nj_unew(sUa, xa, ya, nj_val(xa, ya, d)) / r1;
+        const double ub = nj_unew(sUb, xb, yb, nj_val(xb, yb, d)) / r1;
+        const double qk = fmin((cand.d - ua) - ub, (cand.d - ub) - ua);
+        qc = qk == qk ? qk : qc;
+    }
+    qc = wave_fmin(qc);
+    if (lane == 0) sseed[tid >> 6] = qc;
+    // upper bounds of the maxima after this merge (see the header)
+    const double slack = emin >= 0.0 ? 0.0 : (3.0 * -emin) * (1.0 + 0x1p-30) + eabs * 0x1p-47;      // (the header's values are within a factor of two)
+    const bool zlive = pz >= 0 && pz != px && pz != py;                        // the node leaving quarantine stays
+    uz = (uz == uz) ? uz : PINF;                                               // (its row sum is always in memory here; NaN would silently drop out of fmax)
+    const int64_t gz = zlive ? pz / kUR : -1;
+    const int64_t sz = zlive ? pz / (kTileCols / 4) : -1;                      // its sub-strip (global index)
+    double rU = rmaxU;
+    if (have_g && g == gz) rU = fmax(rU, uz);
+    const double rmax = (rU + slack) / r1;                                     // (-inf stays -inf)
+#pragma unroll
+    for (int k = 0; k < kNS; ++k)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            double cU = cm4[k][w];
+            if (4 * (int64_t)(cb0 + k) + w == sz) cU = fmax(cU, uz);
+            cm4[k][w] = (cU + slack) / r1;
         }
-    } else {
-        // ------------------------------------------------------------------------------ S: seed bound, winner
-        double qc = PINF;
-        if (seed_is_unit && (int64_t)tid * sstride >= uvalid) cand.key = ~0ull;
-        if (cand.key != ~0ull) {
-            const int64_t ci = (int64_t)(cand.pad & 0xffffffffull), cj = (int64_t)(cand.pad >> 32);
-            if (ci < P && cj < P && ci != px && cj != px && ci != py && cj != py) {
-                const double uia = Uc[ci], uib = Uc[cj];
-                const double xa = rowx[ci], ya = rowy[ci], xb = rowx[cj], yb = rowy[cj];
-                const double ua = nj_unew(uia, xa, ya, nj_val(xa, ya, d)) / r1;
-                const double ub = nj_unew(uib, xb, yb, nj_val(xb, yb, d)) / r1;
-                const double qk = fmin((cand.d - ua) - ub, (cand.d - ub) - ua);
-                qc = qk == qk ? qk : qc;
-            }
-        }
-        qc = wave_fmin(qc);
-        __syncthreads();            // (sq was read by every thread above)
-        if (lane == 0) sq[tid >> 6] = qc;
-        __syncthreads();
-        if (tid == 0) {
-            hdr->seed = fmin(fmin(sq[0], sq[1]), fmin(sq[2], sq[3]));
-            hdr->px = (long long)px; hdr->py = (long long)py;
+    const bool fold = zlive;                                                   // block-uniform
+    const bool gz_here = fold && gz >= g0 && gz < g0 + kTG;
+    const int wpz = fold ? (int)((pz % kTileCols) / (kTileCols / 4)) : -1;
+    const int64_t cbz = fold ? pz / kTileCols : -1;
+    const bool pz_here = fold && cbz >= cb0 && cbz < cb0 + nsb;              // block-uniform
+    double rC = wave_fmax(rmax);
+    if (lane == 0) srC[tid >> 6] = rC;
+    __syncthreads();
+    const double bound = fmin(fmin(sseed[0], sseed[1]), fmin(sseed[2], sseed[3]));
+    {
+        rC = fmax(fmax(srC[0], srC[1]), fmax(srC[2], srC[3]));
+        double cC = NINF;
+#pragma unroll
+        for (int k = 0; k < kNS; ++k)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) cC = fmax(cC, cm4[k][w]);
+        const double lbC = fmin((cmin - rC) - cC, (cmin - cC) - rC);
+        // the node leaving quarantine lowers unit bounds of this cell: those lanes must run (block-uniform decision)
+        if (!gz_here && !pz_here && !(lbC <= bound) && !(a.flags & 4)) return;
+    }
+    ulonglong2 um0[kNS], um1[kNS];
+#pragma unroll
+    for (int k = 0; k < kNS; ++k) {
+        um0[k] = make_ulonglong2(0ull, 0ull); um1[k] = um0[k];
+        if (k < nsb && have_g && g >= 32 * (int64_t)(cb0 + k)) {
+            const unsigned long long* up = a.umin + ((int64_t)(cb0 + k) * G16 + g) * 4;
+            um0[k] = *reinterpret_cast<const ulonglong2*>(up); um1[k] = *reinterpret_cast<const ulonglong2*>(up + 2);
         }
     }
+    double mymin = PINF;           // minimum of this lane's sub-unit bounds after the fold: the cell's new coarse bound
+#pragma unroll
+    for (int sidx = 0; sidx < kNS; ++sidx) {
+        if (sidx >= nsb) break;                       // block-uniform
+        const int cb = cb0 + sidx;
+        const bool pz_strip = fold && cbz == cb;                                 // block-uniform
+        const bool have = have_g && g >= 32 * (int64_t)cb;
+        unsigned long long* up4 = a.umin + ((int64_t)cb * G16 + (have ? g : 0)) * 4;
+        double u4[4] = { PINF, PINF, PINF, PINF };
+        if (have) { u4[0] = dec_f64(um0[sidx].x); u4[1] = dec_f64(um0[sidx].y); u4[2] = dec_f64(um1[sidx].x); u4[3] = dec_f64(um1[sidx].y); }
+        const double newminA = (pz_strip && have_g) ? a.t2_rowmin[par * GS + g] : PINF;
+        int submask = 0;
+        if (have) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const double cmw = cm4[sidx][w];
+                double nm = (gz_here && g == gz) ? a.t2_colmin[par * SS4 + 4 * cb + w] : PINF;      // the unit (this strip, group of pz)
+                if (pz_strip && w == wpz) nm = fmin(nm, newminA);
+                if (nm < u4[w]) {                          // persist the lowered bound (this lane is the unit's only writer here)
+                    u4[w] = nm;
+                    up4[w] = enc_f64(nm);
+                }
+                mymin = fmin(mymin, u4[w]);
+                const double lb = fmin((u4[w] - rmax) - cmw, (u4[w] - cmw) - rmax);
+                if ((cmw > NINF) && (lb <= bound)) submask |= 1 << w;
+            }
+        }
+        const bool keep = have && (rmax > NINF) && submask != 0;
+        const unsigned long long mask = __ballot(keep);
+        unsigned long long base = 0;
+        if (lane == 0 && mask) base = atomicAdd(&a.cnt[(it + 1) % 3], (unsigned long long)__popcll(mask));
+        base = __shfl(base, 0, 64);
+        if (keep) a.list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)(((uint32_t)submask << 28) | ((uint32_t)cb << 18) | (uint32_t)g);
+    }
+    mymin = wave_fmin(mymin);
+    __syncthreads();               // (srC: the coarse maxima above were read by every thread)
+    if (lane == 0) srC[tid >> 6] = mymin;
+    __syncthreads();
+    if (tid == 0) a.t2_cmin[tb] = fmin(fmin(srC[0], srC[1]), fmin(srC[2], srC[3]));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1238,8 +1330,8 @@ static SlabPlan slab_plan(int64_t P, int64_t N, int local_ranks)
     p.cnt_all = take((size_t)(4 * local_ranks) * 8);
     // njp_post2_kernel: header, per-group and per-sub-strip values (M block m writes groups 32 m .. 32 m + 31, sub-strips 4 m .. 4 m + 3)
     p.t2_hdr = take(256);
-    p.t2_rmax = take((size_t)(32 * (S + 1)) * 8); p.t2_rowmin = take((size_t)(32 * (S + 1)) * 8);
-    p.t2_cmax = take((size_t)(4 * (S + 1)) * 8); p.t2_colmin = take((size_t)(4 * (S + 1)) * 8);
+    p.t2_rmax = take((size_t)(2 * 32 * (S + 1)) * 8); p.t2_rowmin = take((size_t)(2 * 32 * (S + 1)) * 8);       // [2]: by iteration parity
+    p.t2_cmax = take((size_t)(2 * 4 * (S + 1)) * 8); p.t2_colmin = take((size_t)(2 * 4 * (S + 1)) * 8);
     p.t2_cmin = take(nprep * 8);       // one coarse bound per test block
     p.total = off;
     return p;
@@ -1304,7 +1396,11 @@ static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, char
     q.t2_rmax = reinterpret_cast<double*>(slab + plan.t2_rmax); q.t2_rowmin = reinterpret_cast<double*>(slab + plan.t2_rowmin);
     q.t2_cmax = reinterpret_cast<double*>(slab + plan.t2_cmax); q.t2_colmin = reinterpret_cast<double*>(slab + plan.t2_colmin);
     q.t2_cmin = reinterpret_cast<double*>(slab + plan.t2_cmin);
-    DPR_HIP(hipMemsetAsync(q.t2_hdr, 0, 256, s));
+    {
+        const unsigned long long h0[2] = { 0xFFF0000000000000ull /* enc(+inf) */, 0x8000000000000000ull /* enc(0.0) */ };
+        DPR_HIP(hipMemcpyAsync(q.t2_hdr, h0, sizeof h0, hipMemcpyHostToDevice, s));
+        DPR_HIP(hipStreamSynchronize(s));
+    }
     DPR_HIP(hipMemsetAsync(q.U, 0xff, 2 * vec * sizeof(double), s));   // NaN = dead / padding, in both buffers
     DPR_HIP(hipMemsetAsync(q.R, 0, 2 * vec * sizeof(double), s));
     DPR_HIP(hipMemsetAsync(q.Ur, 0xff, vec * sizeof(double), s));   // NaN beyond P
@@ -1383,7 +1479,7 @@ int njp_build(NjBuffers& b, hipStream_t s)
         DPR_HIP(hipMemsetAsync(q.iterstats, 0, sizeof(uint64_t) * (size_t)(2 * N + 2), s));
     }
     dim3 grid((unsigned)((N + kThreads - 1) / kThreads > 64 ? 64 : (N + kThreads - 1) / kThreads), (unsigned)(N < 32768 ? N : 32768));
-    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, b.D, b.ld, q.D, q.ld, q.perm, N);
+    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, b.D, b.ld, q.D, q.ld, q.perm, N, (unsigned long long*)(std::getenv("DPR_NJP_NO_MM") ? nullptr : q.t2_hdr));
     // (iteration 0 reads U buffer 0)
     hipLaunchKernelGGL(njp_init_vectors_kernel, dim3((unsigned)((N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                        b.U, q.perm, (const int32_t*)nullptr, N, N, q.U, q.Ur, q.KA, q.KB, q.slot_of_pos, q.pos_of_slot);
@@ -1427,7 +1523,7 @@ static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s, bool* rebuilt)
     if (int rc = njp_alloc_epoch(q, n, b.N, (e & 1) ? b.D : q.arena_D, q.arena_slab[e & 1], s)) return rc;
     DPR_HIP(hipMemcpyAsync(q.perm, perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
     dim3 grid((unsigned)((n + kThreads - 1) / kThreads > 64 ? 64 : (n + kThreads - 1) / kThreads), (unsigned)(n < 32768 ? n : 32768));
-    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, old.D, old.ld, q.D, q.ld, q.perm, n);
+    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, old.D, old.ld, q.D, q.ld, q.perm, n, (unsigned long long*)(std::getenv("DPR_NJP_NO_MM") ? nullptr : q.t2_hdr));
     hipLaunchKernelGGL(njp_init_vectors_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                        Ucur, q.perm, (const int32_t*)old.slot_of_pos, n, n, q.U + (st.it & 1) * q.vstride, q.Ur, q.KA, q.KB,
                        q.slot_of_pos, q.pos_of_slot);
@@ -1462,7 +1558,7 @@ static int njp_to_slots(NjBuffers& b, hipStream_t s)
     // the slot-space matrix goes into the buffer the epoch does not live in; the streaming kernels read b.D
     if (q.D == b.D) std::swap(b.D, q.arena_D);
     dim3 grid((unsigned)((n + kThreads - 1) / kThreads > 64 ? 64 : (n + kThreads - 1) / kThreads), (unsigned)(n < 32768 ? n : 32768));
-    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, (const double*)q.D, q.ld, b.D, b.ld, (const int32_t*)q.pos_of_slot, n);
+    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, (const double*)q.D, q.ld, b.D, b.ld, (const int32_t*)q.pos_of_slot, n, (unsigned long long*)nullptr);
     hipLaunchKernelGGL(njp_gather_u_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                        njp_current_u(q, st.it), (const int32_t*)q.pos_of_slot, n, b.U);
     DPR_HIP(hipGetLastError());
@@ -1490,7 +1586,7 @@ static int njp_from_slots(NjBuffers& b, hipStream_t s)
     if (int rc = njp_alloc_epoch(q, n, b.N, q.arena_D, q.arena_slab[0], s)) return rc;
     DPR_HIP(hipMemcpyAsync(q.perm, perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
     dim3 grid((unsigned)((n + kThreads - 1) / kThreads > 64 ? 64 : (n + kThreads - 1) / kThreads), (unsigned)(n < 32768 ? n : 32768));
-    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, (const double*)b.D, b.ld, q.D, q.ld, (const int32_t*)q.perm, n);
+    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, (const double*)b.D, b.ld, q.D, q.ld, (const int32_t*)q.perm, n, (unsigned long long*)(std::getenv("DPR_NJP_NO_MM") ? nullptr : q.t2_hdr));
     hipLaunchKernelGGL(njp_init_vectors_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                        (const double*)b.U, (const int32_t*)q.perm, (const int32_t*)nullptr, n, n, q.U + (st.it & 1) * q.vstride, q.Ur, q.KA, q.KB,
                        q.slot_of_pos, q.pos_of_slot);
@@ -1585,6 +1681,13 @@ static int njp_launch_scan(NjBuffers& b, hipStream_t s, int v, bool rows)
     return DPR_OK;
 }
 
+static bool njp_use_post2(const NjPruned& q)
+{
+    static const bool on = !(std::getenv("DPR_NJP_POST2") && std::atoi(std::getenv("DPR_NJP_POST2")) == 0);
+    static const int64_t min_p = std::getenv("DPR_NJP_POST2_MIN_P") ? std::atoll(std::getenv("DPR_NJP_POST2_MIN_P")) : 0;
+    return on && q.P >= min_p && njp_tg(q.P) == 256 && njp_ns(q.P) == kBigNS && q.sh_world <= 1 && q.dbg == nullptr;
+}
+
 static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
 {
     NjpArgs a = njp_args(b, v);
@@ -1592,11 +1695,11 @@ static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
     const unsigned ublocks = update ? (unsigned)((b.N + kThreads - 1) / kThreads) : 0u;
     a.nupd = (int)ublocks;
     if ((unsigned)a.ntest + ublocks == 0u) return DPR_OK;      // (a rank without test blocks in a tests-only launch)
-    // large shape on a single rank: producers, then the test blocks (njp_post2_kernel; DPR_NJP_POST2=0: the fused kernel)
-    static const bool post2 = !(std::getenv("DPR_NJP_POST2") && std::atoi(std::getenv("DPR_NJP_POST2")) == 0);
-    if (post2 && a.tg == 256 && a.ns == kBigNS && a.sh_world == 1 && a.dbg == nullptr) {
-        hipLaunchKernelGGL((njp_post2_kernel<kBigNS, 0>), dim3(ublocks + (unsigned)a.nrb + 1u), dim3(kThreads), 0, s, a);
-        if (a.ntest > 0) hipLaunchKernelGGL((njp_post2_kernel<kBigNS, 1>), dim3((unsigned)a.ntest), dim3(kThreads), 0, s, a);
+    // large shape on a single rank: light blocks, maxima of the previous launch (njp_post2_kernel; DPR_NJP_POST2=0: the fused kernel)
+    if (njp_use_post2(b.pr)) {
+        const unsigned u2 = update ? (unsigned)((b.N + 2 * kThreads - 1) / (2 * kThreads)) : 0u;      // two slot chunks per U block
+        a.nupd = (int)u2;
+        hipLaunchKernelGGL((njp_post2_kernel<kBigNS>), dim3(u2 + (unsigned)a.nrb + (unsigned)a.ntest), dim3(kThreads), 0, s, a);
         DPR_HIP(hipGetLastError());
         return DPR_OK;
     }
@@ -1671,6 +1774,14 @@ static int njp_run_segment(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t 
             if (a.ntest > 0) hipLaunchKernelGGL(njp_list_all_kernel, dim3((unsigned)a.ntest), dim3(kThreads), 0, s, a);
         }
         DPR_HIP(hipGetLastError());
+        if (njp_use_post2(q)) {
+            // the maxima the first post launch of the epoch reads: the row sums as they stand (buffer of the current iteration)
+            const int64_t S2 = (q.P + kTileCols - 1) / kTileCols + 2;
+            const int par = (int)(it0 & 1);
+            hipLaunchKernelGGL(njp_t2_init_kernel, dim3((unsigned)((q.P + kTileCols - 1) / kTileCols)), dim3(kThreads), 0, s,
+                               (const double*)(q.U + (it0 & 1) * q.vstride), q.P, q.t2_rmax + par * 32 * S2, q.t2_cmax + par * 4 * S2);
+            DPR_HIP(hipGetLastError());
+        }
         q.fresh = false;
     }
     const bool timing = b.kt && b.kt->stride > 0 && q.sh_world <= 1;

@@ -7,8 +7,7 @@ cd $REPO
 timeout -k 10 600 python -m pytest tests/test_gpu_nj.py -x -q -m gpu -k "large_shape" 2>&1 | tail -5 || exit 1
 rm -f $OUT/nj_kt_100k.txt
 for v in 1 0; do
-  DPR_NJP_POST2=$v timeout -k 10 300 python profiles/nj_kt.py 100000 10000 20000 10 2>&1 | tail -1 | tee -a $OUT/nj_kt_100k.txt
+  DPR_NJP_POST2=$v timeout -k 10 300 python profiles/nj_kt.py 100000 10000 20000 10 2>&1 | tail -1 | tee -a $OUT/nj_kt_100k.txt | cut -c1-330
 done
-DPR_NJP_FLAGS=4 timeout -k 10 300 python profiles/nj_kt.py 100000 10000 20000 10 2>&1 | tail -1 | tee -a $OUT/nj_kt_100k.txt
 echo "== post2 (default)"
 timeout -k 10 300 python profiles/nj_big.py 100000 10000 2 2>&1 | tee $OUT/nj100k_post2.txt | tail -2 || exit 1

@@ -13,7 +13,8 @@ def main():
     from tests import _orc, _util
     orc = _orc.load()
     out = []
-    cases = [("additive", 700, 3), ("additive", 2100, 4), ("ties", 900, 5), ("additive", 4500, 6), ("msa", 5000, 7)]
+    # ("ties" and "random" create negative distances -- (1 + 1 - 3) / 2 -- i.e. the slack branch of njp_post2_kernel's bounds)
+    cases = [("additive", 700, 3), ("additive", 2100, 4), ("ties", 900, 5), ("additive", 4500, 6), ("msa", 5000, 7), ("random", 1800, 8)]
     for kind, n, seed in cases:
         rng = np.random.default_rng(seed)
         d = dipper_amd.Dipper(0)
@@ -28,6 +29,9 @@ def main():
             else:
                 if kind == "ties":
                     D = rng.integers(1, 4, size=(n, n)).astype(np.float64)
+                    D = np.tril(D, -1) + np.tril(D, -1).T
+                elif kind == "random":
+                    D = rng.random((n, n)) * 3.0 + 0.01
                     D = np.tril(D, -1) + np.tril(D, -1).T
                 else:
                     D = _util.random_additive_matrix(rng, n, zero_frac=0.3)
