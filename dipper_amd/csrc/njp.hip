@@ -904,10 +904,20 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
 //     smaller minimum, still a valid lower bound for the units it crosses.
 // Looser bounds list more units, never fewer: the scan computes exact minima whatever is listed, so the merge log stays the
 // reference's bit for bit (the first 20 000 iterations at 100 000 tips list 1.00x as many units as the exact test).
-// Roles: U blocks [0, nupd) the update role, unchanged; M blocks; T blocks of 256 row groups x up to kNS strips, each ONE
-// coarse cell: t2_cmin[tb] <= every sub-unit bound of the cell (kept by this block alone) and, by the same monotonicity,
+// Roles.  T blocks (first in the grid: the longest chain) of 256 row groups x up to kNS strips, each ONE coarse cell:
+// t2_cmin[tb] <= every sub-unit bound of the cell (kept by this block alone) and, by the same monotonicity,
 // lb(unit) >= fl(fl(cmin - rmaxC) - cmaxC) -- a cell whose coarse bound exceeds the seed bound reads none of its 32 KB of unit
-// bounds.  No block waits for another one.
+// bounds (DPR_NJP_FLAGS=4 switches the skip off); one list append per wave.  UM blocks: block u does, for the reference slots
+// [512 u, 512 u + 512), what needs the SLOT order (the chunk sums of the new node's row -- the canonical order of U[x] --, log,
+// state, relabel of the last slot) and, for the positions [512 u, 512 u + 512), every per-position store of the update (row
+// sums, row buffer, keys, the new node's column) plus the maxima and minima for the next launch: coalesced, where
+// njp_post_kernel's update role scatters them through pos_of_slot.  No block waits for another one; 845 blocks of 108
+// registers at 100 000 tips, all resident.
+// Measured at 100 000 tips x 10 000 sites: 38.5 -> 24.2 us per iteration in the first epoch, NJ 2.83 -> 2.21 s on the same box,
+// same merge log (profiles/r3/nj100k_post2.txt, nj100k_fused.txt, nj_kt_100k.txt; nj_phases2_100k.txt: the launch ends 11.8 us
+// after its first block starts).  Steps on the way: separate U and M blocks -- 1 041 blocks for 1 024 resident ones, the
+// stragglers started 8 us late; one list atomic per strip -- four dependent round trips; 16 fp64 divisions per thread for the
+// 16 block-uniform column maxima -- now 16 lanes, through LDS.
 // (Tried before, profiles/r3/nj_kt_100k_post2_split.txt: exact maxima handed from producer blocks to the test blocks of the
 //  SAME launch through a tag -- every hand-over step is a round trip across the XCDs, 40 us per launch; as two launches --
 //  14.6 + 8.8 us, each pays launch + two dependent misses + drain: 2.60 s instead of 2.68 s for the whole run.)
@@ -937,13 +947,16 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
     __shared__ double s[kThreads];
     __shared__ double sq[kThreads / 64], sdd[kThreads / 64];
     __shared__ uint64_t sk[kThreads / 64], spp[kThreads / 64];
-    __shared__ double sseed[kThreads / 64], srC[kThreads / 64];
+    __shared__ double sseed[kThreads / 64], srC[kThreads / 64], scm[kNS * 4];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int bx = (int)blockIdx.x;
-    const int nmb = a.nrb;                                   // M blocks: one per 512 positions
-    const int role = bx < a.nupd ? 0 : bx < a.nupd + nmb ? 1 : 3;
-    const int ubi = bx, mbi = bx - a.nupd, tb = bx - a.nupd - nmb;
+    // T blocks FIRST (the longest chain), then the UM blocks: block u does the slot-order part of the update for the reference
+    // slots [512 u, 512 u + 512) and the position-order part for the positions [512 u, 512 u + 512) -- one select for both,
+    // and 845 blocks at 100 000 tips where separate U and M blocks made 1 041 for 1 024 resident ones (110 registers): the
+    // blocks of the second round started 8 us late and set the length of the launch (profiles/r3/nj_phases2_100k.txt)
+    const bool trole = bx < a.ntest;
+    const int tb = bx, umb = bx - a.ntest;
     Post2Hdr* hdr = reinterpret_cast<Post2Hdr*>(a.t2_hdr);
     const double NINF = -__builtin_inf(), PINF = __builtin_inf();
 
@@ -970,38 +983,39 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
     NjRecord cand = r0;
     int cb0 = 0;
     int64_t g0 = 0;
-    if (role == 3) {
+    // UM: the block's two chunks of 256 reference slots (the chunk sums stay per 256 slots: the canonical order of U[x]) and
+    // its 512 positions, two per thread
+    const int64_t i = (int64_t)umb * (2 * kThreads) + tid;     // first reference slot; the second one is i + 256
+    const int64_t p0 = (int64_t)umb * kTileCols + 2 * tid;     // first position (< P + 512 when the M part is active)
+    const bool m_part = !trole && umb < a.nrb;
+    const bool u_slots = !trole && (int64_t)umb * (2 * kThreads) < N;
+    int64_t p = -1, pb = -1;
+    int2 sl = make_int2(-1, -1);                             // reference slots of the two positions (-1: dead / padding)
+    if (trole) {
         if (!seed_is_unit) cand = a.partials[a.urecs + (tid - nseed_units)];
         else if ((int64_t)tid * sstride < a.urecs) cand = a.partials[(int64_t)tid * sstride];
         cb0 = a.blk_cb[tb];
         g0 = (int64_t)a.blk_g0[tb];
+    } else {
+        if (u_slots) { p = (int64_t)a.pos_of_slot[i]; pb = (int64_t)a.pos_of_slot[i + kThreads]; }      // (padded past N)
+        if (m_part) sl = *reinterpret_cast<const int2*>(a.slot_of_pos + p0);
     }
-    // (U) a block takes TWO chunks of 256 reference slots (the chunk sums stay per 256 slots: the canonical order of U[x]) --
-    // with one chunk per block the grid of a 100 000-tip epoch is 1 183 blocks for 1 024 resident ones (110 registers), and
-    // the test blocks, last in the grid, wait for a second round
-    const int64_t i = (int64_t)ubi * (2 * kThreads) + tid;     // first reference slot (U); the second one is i + 256
-    int64_t p = -1, pb = -1;
-    int2 sl = make_int2(-1, -1);                             // (M) reference slots of its two positions (-1: dead / padding)
-    if (role == 0) { p = (int64_t)a.pos_of_slot[i]; pb = (int64_t)a.pos_of_slot[i + kThreads]; }
-    if (role == 1) sl = *reinterpret_cast<const int2*>(a.slot_of_pos + (int64_t)(bx - a.nupd) * kTileCols + 2 * tid);
-    // hop 2: needs the iteration index / the position
+    // hop 2: needs the iteration index
     const int par = (int)(it & 1);                           // T reads the maxima of buffer par, M writes buffer 1 - par
     const double* __restrict__ Uc = a.U + (it & 1) * a.vstride;
     double* __restrict__ Un = a.U + ((it + 1) & 1) * a.vstride;
     const unsigned long long cnt_raw = a.all_defined ? (unsigned long long)a.urecs : a.cnt[it % 3];
     const int64_t uvalid = (int64_t)(cnt_raw < (unsigned long long)a.urecs ? cnt_raw : (unsigned long long)a.urecs);
     const double emin = dec_f64(hdr->min_enc), eabs = dec_f64(hdr->maxabs_enc);
-    const int64_t p0 = (int64_t)mbi * kTileCols + 2 * tid;      // (M) < P + 512
     v2d uc; uc.x = 0.0; uc.y = 0.0;
     const int64_t g = g0 + tid;                                  // (T) this lane's row group
-    const bool have_g = role == 3 && g < G16;
+    const bool have_g = trole && g < G16;
     int nsb = 0;
-    double rmaxU = NINF, cmin = NINF, uz = NINF;
-    double cm4[kNS][4];
+    double uz = NINF;
     double sUa = 0.0, sUb = 0.0;
     int64_t ci = -1, cj = -1;
-    if (role == 1) uc = *reinterpret_cast<const v2d*>(Uc + p0);
-    if (role == 3) {
+    if (m_part) uc = *reinterpret_cast<const v2d*>(Uc + p0);
+    if (trole) {
         const int64_t send = njp_strips_of_rows(g0, kTG, P);
         nsb = (int)(send - cb0 < kNS ? send - cb0 : kNS);
         if (pz >= 0) uz = Uc[pz];
@@ -1016,11 +1030,13 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
         const int idx = tid + k * kThreads;
         if (idx >= uvalid && idx < a.urecs) mine[k] = r0;   // not written by this iteration's scan
     }
+    NJP_STAMP(1, 0, false);
+    NJP_STAMP(1, 1, true);
     if (a.st->status != 0 || it >= limit) return;
     const int64_t n = N - it;
     if (n < 3) return;
-    if (role == 0 && (!a.do_update || (int64_t)ubi * (2 * kThreads) >= n)) return;
-    if (role != 0 && !a.do_tests) return;
+    const bool u_part = u_slots && a.do_update && (int64_t)umb * (2 * kThreads) < n;
+    if (trole ? !a.do_tests : (!u_part && !m_part)) return;
 
     // ---- select (thrust::min_element, src/neighborJoining.cu:214)
     double bq = 10000.0, d = 0.0; uint64_t bk = ~0ull, bp = 0;
@@ -1037,9 +1053,10 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
 #pragma unroll
     for (int w = 1; w < kThreads / 64; ++w) best_update4(bq, bk, bp, d, sq[w], sk[w], spp[w], sdd[w]);
 
+    NJP_STAMP(1, 2, false);
     const int64_t last = n - 1;
     if (bk == ~0ull) {
-        if (role == 0 && (i == last || i + kThreads == last)) a.st->status = 1;
+        if (u_part && (i == last || i + kThreads == last)) a.st->status = 1;
         return;
     }
     const int64_t ki = (int64_t)(bk & 0xFFFFFFull), kj = (int64_t)((bk >> 24) & 0xFFFFFFull);
@@ -1050,126 +1067,134 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
     const double r1 = (double)(n1 - 2);
     const double* __restrict__ rowx = a.D + px * a.ld;
     const double* __restrict__ rowy = a.D + py * a.ld;
-
-    if (role == 0) {
-        // ------------------------------------------------------------------------------ U: what needs the SLOT order
-        // the chunk sums of the new node's row (canonical order of U[x]), the log, the state, the relabel of the last slot;
-        // every per-position store of the update is the M blocks' (coalesced there, a scatter through pos_of_slot here)
-        double val2[2] = { 0.0, 0.0 };
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int64_t ii = i + h * kThreads;
-            const int64_t pp = h ? pb : p;
-            if (ii >= n) continue;
-            if (ii == last) {
-                const double r = (double)(n - 2);
-                double blX = (d + Uc[px] / r - Uc[py] / r) * 0.5;
-                double blY = d - blX;
-                if (blX < 0) { blY += blX; blX = 0; }
-                if (blY < 0) { blX += blY; blY = 0; }
-                a.log_x[it] = (int32_t)x; a.log_y[it] = (int32_t)y; a.log_bx[it] = blX; a.log_by[it] = blY;
-                a.st->x = (int32_t)x; a.st->y = (int32_t)y; a.st->d = d; a.st->q = bq;
-                a.st->n = n1; a.st->it = it + 1;
-                a.st->pnew[(it + 1) & 1] = (int32_t)px;
-                a.U[(it & 1) * a.vstride + py] = __builtin_nan("");       // (this thread's own store, behind its read of U[py] above)
-                a.st->cnt_list[(it + 2) % 3] = 0ull;
-                for (int v = 0; v < a.cnt_ranks; ++v) a.cnt_all[4 * v + (it + 2) % 3] = 0ull;
-            }
-            if (ii != x && ii != y) {
-                val2[h] = (a.flags & 32) ? 0.0 : nj_val(rowx[pp], rowy[pp], d);      // (32: timing experiment, WRONG results)
-                if (ii == last) {           // relabel: the node of the last slot now lives in slot y
-                    a.slot_of_pos[pp] = (int32_t)y;
-                    a.pos_of_slot[y] = (int32_t)pp;
-                }
-            } else if (ii == y) {
-                a.slot_of_pos[py] = -1;
-            }
-        }
-        const double cs0 = block_tree256_lane0(val2[0], s);
-        if (tid == 0) a.xpart[2 * ubi] = cs0;
-        if ((int64_t)(2 * ubi + 1) * kThreads < n) {      // block-uniform: the second chunk holds live slots
-            __syncthreads();
-            const double cs1 = block_tree256_lane0(val2[1], s);
-            if (tid == 0) a.xpart[2 * ubi + 1] = cs1;
-        }
-        return;
-    }
-
     const int64_t GS = 32 * ((P + kTileCols - 1) / kTileCols + 2), SS4 = 4 * ((P + kTileCols - 1) / kTileCols + 2);
-    if (role == 1) {
-        // ------------------------------------------------------------------------------ M: the update by POSITION, and the maxima for POST(it + 1)
-        const v2d dx = *reinterpret_cast<const v2d*>(rowx + p0);
-        const v2d dy = *reinterpret_cast<const v2d*>(rowy + p0);
-        const bool live0 = (uc.x == uc.x) & (p0 != px) & (p0 != py) & (p0 < P);
-        const bool live1 = (uc.y == uc.y) & (p0 + 1 != px) & (p0 + 1 != py) & (p0 + 1 < P);
-        const double v0 = nj_val(dx.x, dy.x, d), v1 = nj_val(dx.y, dy.y, d);       // the new node's row
-        const double un0 = nj_unew(uc.x, dx.x, dy.x, v0);
-        const double un1 = nj_unew(uc.y, dx.y, dy.y, v1);
-        if (a.do_update && !(a.flags & 64)) {      // (64: timing experiment, WRONG results)
-            // same values, same destinations as njp_post_kernel's update role (which reaches them through pos_of_slot): new row
-            // sums into the other buffer, the new node's row into the row buffer and its column into the matrix, keys from the
-            // slot (the node of the last slot is relabelled to slot y), quarantine / death marks of the merged pair
-            double* __restrict__ Rw = a.R + (it & 1) * a.vstride;
+
+    if (!trole) {
+        // hop 3, both parts: rows x / y at this thread's two slots' positions (a gather) and at its two positions (coalesced)
+        double gx[2] = { 0.0, 0.0 }, gy[2] = { 0.0, 0.0 };
+        v2d dx, dy; dx.x = dx.y = dy.x = dy.y = 0.0;
+        if (u_part) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int64_t pp = p0 + k;
-                const int slot = k ? sl.y : sl.x;
-                const double v = k ? v1 : v0, u = k ? un1 : un0;
-                if (pp >= P) continue;
-                if (pp == px) {
-                    a.Ur[px] = __builtin_nan("");   // quarantine until SCAN(it + 1) has finished its row sum
-                    Rw[px] = 0.0;                  // diagonal
-                    a.KA[px] = nj_key_a(x, n1); a.KB[px] = nj_key_b(x);
-                } else if (pp == py) {
-                    a.Ur[py] = __builtin_nan("");   // dead
-                    Un[py] = __builtin_nan("");
-                    Rw[py] = 0.0;
-                } else if (slot >= 0) {
-                    Un[pp] = u;
-                    a.Ur[pp] = u / r1;
-                    Rw[pp] = v;
-                    if (a.flags & 1) a.D[pp * a.ld + px] = v;
-                    else __hip_atomic_store(a.D + pp * a.ld + px, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    // (slot_of_pos of the last slot's position is being rewritten to y by a U block: either value gives y here)
-                    const int64_t new_slot = slot == (int)last ? y : (int64_t)slot;
-                    a.KA[pp] = nj_key_a(new_slot, n1); a.KB[pp] = nj_key_b(new_slot);
-                }
+            for (int h = 0; h < 2; ++h) {
+                const int64_t ii = i + h * kThreads, pp = h ? pb : p;
+                if (ii < n && ii != x && ii != y) { gx[h] = rowx[pp]; gy[h] = rowy[pp]; }
             }
         }
-        const double m2 = fmax(live0 ? un0 : NINF, live1 ? un1 : NINF);
-        double gm = m2;                                                   // group of 16 positions = 8 lanes
-        gm = fmax(gm, __shfl_xor(gm, 1, 64)); gm = fmax(gm, __shfl_xor(gm, 2, 64)); gm = fmax(gm, __shfl_xor(gm, 4, 64));
-        const double cm = wave_fmax(m2);                                  // sub-strip of 128 positions = this wave
-        const int64_t gidx = p0 >> 4;
-        const int wq = 1 - par;
-        if ((tid & 7) == 0) a.t2_rmax[wq * GS + gidx] = gm;                 // undivided
-        if (lane == 0) a.t2_cmax[wq * SS4 + 4 * mbi + (tid >> 6)] = cm;
-        // the new node's row (position px): minimum per sub-strip over the live columns before it, per group over the live
-        // rows behind it
-        const double c2 = fmin((live0 & (p0 < px)) ? v0 : PINF, (live1 & (p0 + 1 < px)) ? v1 : PINF);
-        double r2 = fmin((live0 & (p0 > px)) ? v0 : PINF, (live1 & (p0 + 1 > px)) ? v1 : PINF);
-        r2 = fmin(r2, __shfl_xor(r2, 1, 64)); r2 = fmin(r2, __shfl_xor(r2, 2, 64)); r2 = fmin(r2, __shfl_xor(r2, 4, 64));
-        const double cz = wave_fmin(c2);
-        if ((tid & 7) == 0) a.t2_rowmin[wq * GS + gidx] = r2;
-        if (lane == 0) a.t2_colmin[wq * SS4 + 4 * mbi + (tid >> 6)] = cz;
-        // smallest entry / largest magnitude the epoch has held: this block's new values
-        double vmin = fmin(live0 ? v0 : PINF, live1 ? v1 : PINF);
-        double vabs = fmax(live0 ? fabs(v0) : 0.0, live1 ? fabs(v1) : 0.0);
-        vmin = wave_fmin(vmin); vabs = wave_fmax(vabs);
-        if (lane == 0) njp_note_range(&hdr->min_enc, vmin, vabs);
+        if (m_part) { dx = *reinterpret_cast<const v2d*>(rowx + p0); dy = *reinterpret_cast<const v2d*>(rowy + p0); }
+        if (m_part) {
+            // ------------------------------------------------------------------ M: the update by POSITION, and the maxima for POST(it + 1)
+            const bool live0 = (uc.x == uc.x) & (p0 != px) & (p0 != py) & (p0 < P);
+            const bool live1 = (uc.y == uc.y) & (p0 + 1 != px) & (p0 + 1 != py) & (p0 + 1 < P);
+            const double v0 = nj_val(dx.x, dy.x, d), v1 = nj_val(dx.y, dy.y, d);       // the new node's row
+            const double un0 = nj_unew(uc.x, dx.x, dy.x, v0);
+            const double un1 = nj_unew(uc.y, dx.y, dy.y, v1);
+            if (a.do_update) {
+                // same values, same destinations as njp_post_kernel's update role (which reaches them through pos_of_slot): new row
+                // sums into the other buffer, the new node's row into the row buffer and its column into the matrix, keys from the
+                // slot (the node of the last slot is relabelled to slot y), quarantine / death marks of the merged pair
+                double* __restrict__ Rw = a.R + (it & 1) * a.vstride;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int64_t pp = p0 + k;
+                    const int slot = k ? sl.y : sl.x;
+                    const double v = k ? v1 : v0, u = k ? un1 : un0;
+                    if (pp >= P) continue;
+                    if (pp == px) {
+                        a.Ur[px] = __builtin_nan("");   // quarantine until SCAN(it + 1) has finished its row sum
+                        Rw[px] = 0.0;                  // diagonal
+                        a.KA[px] = nj_key_a(x, n1); a.KB[px] = nj_key_b(x);
+                    } else if (pp == py) {
+                        a.Ur[py] = __builtin_nan("");   // dead
+                        Un[py] = __builtin_nan("");
+                        Rw[py] = 0.0;
+                    } else if (slot >= 0) {
+                        Un[pp] = u;
+                        a.Ur[pp] = u / r1;
+                        Rw[pp] = v;
+                        if (a.flags & 1) a.D[pp * a.ld + px] = v;
+                        else __hip_atomic_store(a.D + pp * a.ld + px, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // (slot_of_pos of the last slot's position is being rewritten to y by the U part of some block: either value gives y here)
+                        const int64_t new_slot = slot == (int)last ? y : (int64_t)slot;
+                        a.KA[pp] = nj_key_a(new_slot, n1); a.KB[pp] = nj_key_b(new_slot);
+                    }
+                }
+            }
+            const double m2 = fmax(live0 ? un0 : NINF, live1 ? un1 : NINF);
+            double gm = m2;                                                   // group of 16 positions = 8 lanes
+            gm = fmax(gm, __shfl_xor(gm, 1, 64)); gm = fmax(gm, __shfl_xor(gm, 2, 64)); gm = fmax(gm, __shfl_xor(gm, 4, 64));
+            const double cm = wave_fmax(m2);                                  // sub-strip of 128 positions = this wave
+            const int64_t gidx = p0 >> 4;
+            const int wq = 1 - par;
+            if ((tid & 7) == 0) a.t2_rmax[wq * GS + gidx] = gm;                 // undivided
+            if (lane == 0) a.t2_cmax[wq * SS4 + 4 * umb + (tid >> 6)] = cm;
+            // the new node's row (position px): minimum per sub-strip over the live columns before it, per group over the live
+            // rows behind it
+            const double c2 = fmin((live0 & (p0 < px)) ? v0 : PINF, (live1 & (p0 + 1 < px)) ? v1 : PINF);
+            double r2 = fmin((live0 & (p0 > px)) ? v0 : PINF, (live1 & (p0 + 1 > px)) ? v1 : PINF);
+            r2 = fmin(r2, __shfl_xor(r2, 1, 64)); r2 = fmin(r2, __shfl_xor(r2, 2, 64)); r2 = fmin(r2, __shfl_xor(r2, 4, 64));
+            const double cz = wave_fmin(c2);
+            if ((tid & 7) == 0) a.t2_rowmin[wq * GS + gidx] = r2;
+            if (lane == 0) a.t2_colmin[wq * SS4 + 4 * umb + (tid >> 6)] = cz;
+            // smallest entry / largest magnitude the epoch has held: this block's new values
+            double vmin = fmin(live0 ? v0 : PINF, live1 ? v1 : PINF);
+            double vabs = fmax(live0 ? fabs(v0) : 0.0, live1 ? fabs(v1) : 0.0);
+            vmin = wave_fmin(vmin); vabs = wave_fmax(vabs);
+            if (lane == 0) njp_note_range(&hdr->min_enc, vmin, vabs);
+        }
+        NJP_STAMP(1, 3, true);
+        if (u_part) {
+            // ------------------------------------------------------------------ U: what needs the SLOT order
+            // the chunk sums of the new node's row (canonical order of U[x]), the log, the state, the relabel of the last slot
+            double val2[2] = { 0.0, 0.0 };
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int64_t ii = i + h * kThreads;
+                const int64_t pp = h ? pb : p;
+                if (ii >= n) continue;
+                if (ii == last) {
+                    const double r = (double)(n - 2);
+                    double blX = (d + Uc[px] / r - Uc[py] / r) * 0.5;
+                    double blY = d - blX;
+                    if (blX < 0) { blY += blX; blX = 0; }
+                    if (blY < 0) { blX += blY; blY = 0; }
+                    a.log_x[it] = (int32_t)x; a.log_y[it] = (int32_t)y; a.log_bx[it] = blX; a.log_by[it] = blY;
+                    a.st->x = (int32_t)x; a.st->y = (int32_t)y; a.st->d = d; a.st->q = bq;
+                    a.st->n = n1; a.st->it = it + 1;
+                    a.st->pnew[(it + 1) & 1] = (int32_t)px;
+                    a.U[(it & 1) * a.vstride + py] = __builtin_nan("");       // (this thread's own store, behind its read of U[py] above)
+                    a.st->cnt_list[(it + 2) % 3] = 0ull;
+                    for (int v = 0; v < a.cnt_ranks; ++v) a.cnt_all[4 * v + (it + 2) % 3] = 0ull;
+                }
+                if (ii != x && ii != y) {
+                    val2[h] = nj_val(gx[h], gy[h], d);
+                    if (ii == last) {           // relabel: the node of the last slot now lives in slot y
+                        a.slot_of_pos[pp] = (int32_t)y;
+                        a.pos_of_slot[y] = (int32_t)pp;
+                    }
+                } else if (ii == y) {
+                    a.slot_of_pos[py] = -1;
+                }
+            }
+            const double cs0 = block_tree256_lane0(val2[0], s);
+            if (tid == 0) a.xpart[2 * umb] = cs0;
+            if ((int64_t)(2 * umb + 1) * kThreads < n) {      // block-uniform: the second chunk holds live slots
+                __syncthreads();
+                const double cs1 = block_tree256_lane0(val2[1], s);
+                if (tid == 0) a.xpart[2 * umb + 1] = cs1;
+            }
+        }
+        NJP_STAMP(1, 6, true);
+        if (a.dbg != nullptr && it == a.dbg_it && tid == 0) a.dbg[(2048 + bx) * 8 + 7] = 1ull;
         return;
     }
 
     // ---------------------------------------------------------------------------------- T: tests of iteration it + 1
-    if (a.flags & 16) return;          // (timing experiment, WRONG results)
     // hop 3: the maxima of the previous launch (issued here, not with hop 2: the scan records are dead by now and their
     // 40 registers free -- the chain has this hop anyway) and the seed candidates re-evaluated with the row sums after this merge
-    if (have_g) rmaxU = a.t2_rmax[par * GS + g];
-#pragma unroll
-    for (int k = 0; k < kNS; ++k)
-#pragma unroll
-        for (int w = 0; w < 4; ++w) cm4[k][w] = k < nsb ? a.t2_cmax[par * SS4 + 4 * (cb0 + k) + w] : NINF;
-    cmin = a.t2_cmin[tb];
+    const double rmaxU = have_g ? a.t2_rmax[par * GS + g] : NINF;
+    double cmU = NINF;                                                 // lanes 0 .. 4 kNS - 1: one sub-strip of the cell each
+    if (tid < 4 * kNS && (tid >> 2) < nsb) cmU = a.t2_cmax[par * SS4 + 4 * (cb0 + (tid >> 2)) + (tid & 3)];
+    const double cmin = a.t2_cmin[tb];
     double qc = PINF;
     if (ci >= 0 && ci != px && cj != px && ci != py && cj != py) {
         const double xa = rowx[ci], ya = rowy[ci], xb = rowx[cj], yb = rowy[cj];
@@ -1180,6 +1205,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
     }
     qc = wave_fmin(qc);
     if (lane == 0) sseed[tid >> 6] = qc;
+    NJP_STAMP(1, 3, true);
     // upper bounds of the maxima after this merge (see the header)
     const double slack = emin >= 0.0 ? 0.0 : (3.0 * -emin) * (1.0 + 0x1p-30) + eabs * 0x1p-47;      // (the header's values are within a factor of two)
     const bool zlive = pz >= 0 && pz != px && pz != py;                        // the node leaving quarantine stays
@@ -1189,14 +1215,11 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
     double rU = rmaxU;
     if (have_g && g == gz) rU = fmax(rU, uz);
     const double rmax = (rU + slack) / r1;                                     // (-inf stays -inf)
-#pragma unroll
-    for (int k = 0; k < kNS; ++k)
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            double cU = cm4[k][w];
-            if (4 * (int64_t)(cb0 + k) + w == sz) cU = fmax(cU, uz);
-            cm4[k][w] = (cU + slack) / r1;
-        }
+    if (tid < 4 * kNS) {
+        double cU = cmU;
+        if (4 * (int64_t)(cb0 + (tid >> 2)) + (tid & 3) == sz) cU = fmax(cU, uz);
+        scm[tid] = (cU + slack) / r1;
+    }
     const bool fold = zlive;                                                   // block-uniform
     const bool gz_here = fold && gz >= g0 && gz < g0 + kTG;
     const int wpz = fold ? (int)((pz % kTileCols) / (kTileCols / 4)) : -1;
@@ -1206,6 +1229,11 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
     if (lane == 0) srC[tid >> 6] = rC;
     __syncthreads();
     const double bound = fmin(fmin(sseed[0], sseed[1]), fmin(sseed[2], sseed[3]));
+    double cm4[kNS][4];
+#pragma unroll
+    for (int k = 0; k < kNS; ++k)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) cm4[k][w] = scm[4 * k + w];
     {
         rC = fmax(fmax(srC[0], srC[1]), fmax(srC[2], srC[3]));
         double cC = NINF;
@@ -1215,7 +1243,12 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
             for (int w = 0; w < 4; ++w) cC = fmax(cC, cm4[k][w]);
         const double lbC = fmin((cmin - rC) - cC, (cmin - cC) - rC);
         // the node leaving quarantine lowers unit bounds of this cell: those lanes must run (block-uniform decision)
-        if (!gz_here && !pz_here && !(lbC <= bound) && !(a.flags & 4)) return;
+        if (!gz_here && !pz_here && !(lbC <= bound) && !(a.flags & 4)) {
+            NJP_STAMP(1, 6, false);
+            if (a.dbg != nullptr && it == a.dbg_it && tid == 0) a.dbg[(2048 + bx) * 8 + 7] = 3ull;
+            return;
+        }
+        NJP_STAMP(1, 4, false);
     }
     ulonglong2 um0[kNS], um1[kNS];
 #pragma unroll
@@ -1226,10 +1259,13 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
             um0[k] = *reinterpret_cast<const ulonglong2*>(up); um1[k] = *reinterpret_cast<const ulonglong2*>(up + 2);
         }
     }
+    NJP_STAMP(1, 5, true);
     double mymin = PINF;           // minimum of this lane's sub-unit bounds after the fold: the cell's new coarse bound
+    int sub[kNS];                  // per strip: sub-unit mask of this lane's unit, 0 = not listed
 #pragma unroll
     for (int sidx = 0; sidx < kNS; ++sidx) {
-        if (sidx >= nsb) break;                       // block-uniform
+        sub[sidx] = 0;
+        if (sidx >= nsb) continue;                    // block-uniform
         const int cb = cb0 + sidx;
         const bool pz_strip = fold && cbz == cb;                                 // block-uniform
         const bool have = have_g && g >= 32 * (int64_t)cb;
@@ -1253,18 +1289,34 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
                 if ((cmw > NINF) && (lb <= bound)) submask |= 1 << w;
             }
         }
-        const bool keep = have && (rmax > NINF) && submask != 0;
-        const unsigned long long mask = __ballot(keep);
-        unsigned long long base = 0;
-        if (lane == 0 && mask) base = atomicAdd(&a.cnt[(it + 1) % 3], (unsigned long long)__popcll(mask));
-        base = __shfl(base, 0, 64);
-        if (keep) a.list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)(((uint32_t)submask << 28) | ((uint32_t)cb << 18) | (uint32_t)g);
+        if (have && (rmax > NINF)) sub[sidx] = submask;
+    }
+    // ONE list append per wave for all its strips (an atomic per strip is a chain of kNS dependent round trips)
+    {
+        unsigned long long masks[kNS];
+        int total = 0;
+#pragma unroll
+        for (int sidx = 0; sidx < kNS; ++sidx) { masks[sidx] = __ballot(sub[sidx] != 0); total += __popcll(masks[sidx]); }
+        if (total > 0) {                              // wave-uniform
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(&a.cnt[(it + 1) % 3], (unsigned long long)total);
+            base = __shfl(base, 0, 64);
+#pragma unroll
+            for (int sidx = 0; sidx < kNS; ++sidx) {
+                if (sub[sidx] != 0)
+                    a.list[base + __popcll(masks[sidx] & ((1ull << lane) - 1ull))] =
+                        (int32_t)(((uint32_t)sub[sidx] << 28) | ((uint32_t)(cb0 + sidx) << 18) | (uint32_t)g);
+                base += (unsigned long long)__popcll(masks[sidx]);
+            }
+        }
     }
     mymin = wave_fmin(mymin);
     __syncthreads();               // (srC: the coarse maxima above were read by every thread)
     if (lane == 0) srC[tid >> 6] = mymin;
     __syncthreads();
     if (tid == 0) a.t2_cmin[tb] = fmin(fmin(srC[0], srC[1]), fmin(srC[2], srC[3]));
+    NJP_STAMP(1, 6, true);
+    if (a.dbg != nullptr && it == a.dbg_it && tid == 0) a.dbg[(2048 + bx) * 8 + 7] = 4ull;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1685,7 +1737,7 @@ static bool njp_use_post2(const NjPruned& q)
 {
     static const bool on = !(std::getenv("DPR_NJP_POST2") && std::atoi(std::getenv("DPR_NJP_POST2")) == 0);
     static const int64_t min_p = std::getenv("DPR_NJP_POST2_MIN_P") ? std::atoll(std::getenv("DPR_NJP_POST2_MIN_P")) : 0;
-    return on && q.P >= min_p && njp_tg(q.P) == 256 && njp_ns(q.P) == kBigNS && q.sh_world <= 1 && q.dbg == nullptr;
+    return on && q.P >= min_p && njp_tg(q.P) == 256 && njp_ns(q.P) == kBigNS && q.sh_world <= 1 && (q.dbg == nullptr || q.dbg_it >= 0);
 }
 
 static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
@@ -1697,9 +1749,10 @@ static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
     if ((unsigned)a.ntest + ublocks == 0u) return DPR_OK;      // (a rank without test blocks in a tests-only launch)
     // large shape on a single rank: light blocks, maxima of the previous launch (njp_post2_kernel; DPR_NJP_POST2=0: the fused kernel)
     if (njp_use_post2(b.pr)) {
-        const unsigned u2 = update ? (unsigned)((b.N + 2 * kThreads - 1) / (2 * kThreads)) : 0u;      // two slot chunks per U block
-        a.nupd = (int)u2;
-        hipLaunchKernelGGL((njp_post2_kernel<kBigNS>), dim3(u2 + (unsigned)a.nrb + (unsigned)a.ntest), dim3(kThreads), 0, s, a);
+        const unsigned u2 = update ? (unsigned)((b.N + 2 * kThreads - 1) / (2 * kThreads)) : 0u;      // UM blocks: 512 reference slots and 512 positions each
+        const unsigned um = u2 > (unsigned)a.nrb ? u2 : (unsigned)a.nrb;
+        a.nupd = (int)um;
+        hipLaunchKernelGGL((njp_post2_kernel<kBigNS>), dim3((unsigned)a.ntest + um), dim3(kThreads), 0, s, a);
         DPR_HIP(hipGetLastError());
         return DPR_OK;
     }
