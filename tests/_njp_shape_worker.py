@@ -43,6 +43,34 @@ def main():
         ref = orc.nj_run(np.tril(D, -1))
         ok = res["iters"] == n - 2 and all(np.array_equal(res[k], ref[k]) for k in ("merge_x", "merge_y", "bl_x", "bl_y")) and res["last_d"] == ref["last_d"]
         out.append({"kind": kind, "n": n, "ok": bool(ok)})
+    # resumed runs (dpr_nj_run with max_iters: the maxima njp_post2_kernel hands from launch to launch live across the calls) and
+    # the adaptive plan (small-integer distances: the run is handed to the streaming loop and back; every hand-back builds an epoch)
+    for kind, n, seed in (("resumed", 3000, 11), ("adaptive", 2600, 12)):
+        rng = np.random.default_rng(seed)
+        if kind == "adaptive":
+            D = rng.integers(1, 4, size=(n, n)).astype(np.float64)
+            D = np.tril(D, -1) + np.tril(D, -1).T
+        else:
+            D = _util.random_additive_matrix(rng, n, zero_frac=0.3)
+        ref = orc.nj_run(np.tril(D, -1))
+        d = dipper_amd.Dipper(0)
+        try:
+            d.set_nj_mode(1)
+            d.set_nj_adaptive(1 if kind == "adaptive" else 0)
+            d.set_matrix_full(D)
+            d.dist_matrix(capi.SRC_MATRIX)
+            got = {k: [] for k in ("merge_x", "merge_y", "bl_x", "bl_y")}
+            done = 0
+            for chunk in ((1, 7, 100, 33, 1000, 10 ** 6) if kind == "resumed" else (10 ** 6,)):
+                res = d.nj_run(max_iters=chunk)
+                for key in got:
+                    got[key].append(res[key][:res["iters"]])
+                done += res["iters"]
+            stats = d.nj_adaptive_stats() if kind == "adaptive" else None
+        finally:
+            d.close()
+        ok = done == n - 2 and all(np.array_equal(np.concatenate(got[k]), ref[k]) for k in got) and res["last_d"] == ref["last_d"]
+        out.append({"kind": kind, "n": n, "ok": bool(ok), "stats": str(stats)})
     # no Q candidate below 10000 from the first iteration on (tests/test_gpu_nj.py::test_nj_no_candidate): error -4, no hang
     for n in (8, 1500):
         D = np.full((n, n), -1.0e5)
