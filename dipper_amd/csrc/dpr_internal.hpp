@@ -100,6 +100,7 @@ struct NjPruned {
     int64_t vstride = 0;
     uint64_t *KA = nullptr, *KB = nullptr;  // key parts from the reference slot of each position
     // njp_post2_kernel (large shape): header + arrays its producer blocks hand to its test blocks (in the epoch's slab)
+    bool range_known = false;         // t2_hdr holds the range of every entry of this run (njp_range_kernel + the M parts since)
     char* t2_hdr = nullptr; double *t2_rmax = nullptr, *t2_cmax = nullptr, *t2_colmin = nullptr, *t2_rowmin = nullptr, *t2_cmin = nullptr;
     int32_t *slot_of_pos = nullptr, *pos_of_slot = nullptr, *perm = nullptr;   // slot_of_pos < 0: dead position
     uint64_t* umin = nullptr;   // [strips][groups][4] order-encoded lower bound of D per sub-unit

@@ -130,11 +130,14 @@ int njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world)
 // ------------------------------------------------------------------------------------------------
 // epoch build: B[a][b] = A[perm[a]][perm[b]]
 // ------------------------------------------------------------------------------------------------
-// Range of the entries an epoch has held, for njp_post2_kernel's proof: mm[0] = enc_f64(m'), mm[1] = enc_f64(A') with
+// Range of the entries a run has held, for njp_post2_kernel's proof: mm[0] = enc_f64(m'), mm[1] = enc_f64(A') with
 //   every entry >= 2 min(m', 0)   and   every |entry| <= 2 A'.
-// Millions of waves report; an atomic per wave on two words serialises (the epoch build of 26 000 positions went from 3.6 to
-// 84 ms).  So a wave only writes when it moves a word by more than a factor of two -- or across zero, the one fact that
-// matters for non-negative input (no wave ever writes then): a few atomics per doubling.
+// njp_range_kernel reduces the initial matrix once; the M part of every post launch adds the values it creates through
+// njp_note_range: a wave only writes when it moves a word by more than a factor of two -- or across zero, the one fact that
+// matters for non-negative input (no wave ever writes then).  The header is CARRIED from epoch to epoch (the entries of a new
+// epoch are a subset of the old one's).  (First version: the epoch build's permute kernel reported per wave.  The waves of
+// seven of the eight XCDs never saw the others' updates -- plain loads, per-XCD L2 -- so nearly all of 8 M waves went to the
+// atomic: an epoch build of 24 000 positions 65 ms instead of 3.6, NJ at 30 000 tips 476 -> 590 ms.)
 __device__ __forceinline__ void njp_note_range(unsigned long long* mm, double lo, double hi)
 {
     if (lo < 0.0) {
@@ -147,24 +150,37 @@ __device__ __forceinline__ void njp_note_range(unsigned long long* mm, double lo
     }
 }
 
-// mm (may be null): see njp_note_range
 __global__ __launch_bounds__(kThreads) void njp_permute_kernel(const double* __restrict__ A, int64_t lda,
                                                                double* __restrict__ B, int64_t ldb,
-                                                               const int32_t* __restrict__ perm, int64_t P,
-                                                               unsigned long long* __restrict__ mm)
+                                                               const int32_t* __restrict__ perm, int64_t P)
 {
-    double lo = __builtin_inf(), hi = 0.0;
     for (int64_t a = blockIdx.y; a < P; a += gridDim.y) {
         const double* row = A + (int64_t)perm[a] * lda;
-        for (int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x; b < P; b += (int64_t)gridDim.x * kThreads) {
-            const double v = row[perm[b]];
-            B[a * ldb + b] = v;
+        for (int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x; b < P; b += (int64_t)gridDim.x * kThreads)
+            B[a * ldb + b] = row[perm[b]];
+    }
+}
+
+// range of the n x n matrix A (slot space, rows contiguous) into mm: once per run, before the first large-shape epoch, and
+// after a hand-back from the streaming loop (which creates values nobody tracked).  2 048 blocks, one report each.
+__global__ __launch_bounds__(kThreads) void njp_range_kernel(const double* __restrict__ A, int64_t lda, int64_t n, unsigned long long* __restrict__ mm)
+{
+    __shared__ double slo[kThreads / 64], shi[kThreads / 64];
+    double lo = __builtin_inf(), hi = 0.0;
+    for (int64_t a = blockIdx.x; a < n; a += gridDim.x) {
+        const double* row = A + a * lda;
+        for (int64_t b = threadIdx.x; b < n; b += kThreads) {
+            const double v = row[b];
             lo = fmin(lo, v); hi = fmax(hi, fabs(v));
         }
     }
-    if (mm != nullptr) {
-        lo = wave_fmin(lo); hi = wave_fmax(hi);
-        if ((threadIdx.x & 63) == 0) njp_note_range(mm, lo, hi);
+    lo = wave_fmin(lo); hi = wave_fmax(hi);
+    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kThreads / 64; ++w) { lo = fmin(lo, slo[w]); hi = fmax(hi, shi[w]); }
+        atomicMin(&mm[0], (unsigned long long)enc_f64(lo));
+        atomicMax(&mm[1], (unsigned long long)enc_f64(hi));
     }
 }
 
@@ -913,7 +929,7 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
 // sums, row buffer, keys, the new node's column) plus the maxima and minima for the next launch: coalesced, where
 // njp_post_kernel's update role scatters them through pos_of_slot.  No block waits for another one; 845 blocks of 108
 // registers at 100 000 tips, all resident.
-// Measured at 100 000 tips x 10 000 sites: 38.5 -> 24.2 us per iteration in the first epoch, NJ 2.83 -> 2.21 s on the same box,
+// Measured at 100 000 tips x 10 000 sites: 39.7 -> 24.3 us per iteration in the first epoch, NJ 2.68 -> 2.09 s on the same box,
 // same merge log (profiles/r3/nj100k_post2.txt, nj100k_fused.txt, nj_kt_100k.txt; nj_phases2_100k.txt: the launch ends 11.8 us
 // after its first block starts).  Steps on the way: separate U and M blocks -- 1 041 blocks for 1 024 resident ones, the
 // stragglers started 8 us late; one list atomic per strip -- four dependent round trips; 16 fp64 divisions per thread for the
@@ -1323,6 +1339,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
 // host side
 // ------------------------------------------------------------------------------------------------
 static int64_t round_up16(int64_t v) { return (v + 15) / 16 * 16; }
+static bool njp_use_post2(const NjPruned& q);
 // (the scan grid, the graph length and the debug buffer are per-context state of NjPruned: two contexts of one process
 // may run different plans, from different host threads)
 // the stamps of the last context that ran with DPR_NJ_PHASES (debug hook njp_phase_stamps; a process-wide pointer to a
@@ -1418,7 +1435,7 @@ int njp_reserve(NjPruned& q, int64_t N, hipStream_t s) { return njp_arena(q, N, 
 
 // point q at the position-space structures of an epoch with P positions (N = total tips: slot arrays) inside
 // matrix buffer `Dbuf` and slab `slab`, and initialise them (all fills ordered on s)
-static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, char* slab, hipStream_t s)
+static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, char* slab, hipStream_t s, const void* hdr_from = nullptr)
 {
     if (P >= (int64_t)kTileCols * 1024) { set_error("pruned NJ: the list encoding holds fewer than 524288 positions"); return DPR_ERR_ARG; }
     const int local_ranks = q.sh_world > 1 && q.sh_virtual ? q.sh_world : 1;
@@ -1448,7 +1465,9 @@ static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, char
     q.t2_rmax = reinterpret_cast<double*>(slab + plan.t2_rmax); q.t2_rowmin = reinterpret_cast<double*>(slab + plan.t2_rowmin);
     q.t2_cmax = reinterpret_cast<double*>(slab + plan.t2_cmax); q.t2_colmin = reinterpret_cast<double*>(slab + plan.t2_colmin);
     q.t2_cmin = reinterpret_cast<double*>(slab + plan.t2_cmin);
-    {
+    if (hdr_from != nullptr) {
+        DPR_HIP(hipMemcpyAsync(q.t2_hdr, hdr_from, 16, hipMemcpyDeviceToDevice, s));      // the range of the run so far
+    } else {
         const unsigned long long h0[2] = { 0xFFF0000000000000ull /* enc(+inf) */, 0x8000000000000000ull /* enc(0.0) */ };
         DPR_HIP(hipMemcpyAsync(q.t2_hdr, h0, sizeof h0, hipMemcpyHostToDevice, s));
         DPR_HIP(hipStreamSynchronize(s));
@@ -1531,7 +1550,12 @@ int njp_build(NjBuffers& b, hipStream_t s)
         DPR_HIP(hipMemsetAsync(q.iterstats, 0, sizeof(uint64_t) * (size_t)(2 * N + 2), s));
     }
     dim3 grid((unsigned)((N + kThreads - 1) / kThreads > 64 ? 64 : (N + kThreads - 1) / kThreads), (unsigned)(N < 32768 ? N : 32768));
-    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, b.D, b.ld, q.D, q.ld, q.perm, N, (unsigned long long*)(std::getenv("DPR_NJP_NO_MM") ? nullptr : q.t2_hdr));
+    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, b.D, b.ld, q.D, q.ld, q.perm, N);
+    q.range_known = false;
+    if (njp_use_post2(q)) {        // the large-shape post kernel's bounds need the range of the entries (one pass, once per run)
+        hipLaunchKernelGGL(njp_range_kernel, dim3(2048), dim3(kThreads), 0, s, (const double*)b.D, b.ld, N, (unsigned long long*)q.t2_hdr);
+        q.range_known = true;
+    }
     // (iteration 0 reads U buffer 0)
     hipLaunchKernelGGL(njp_init_vectors_kernel, dim3((unsigned)((N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                        b.U, q.perm, (const int32_t*)nullptr, N, N, q.U, q.Ur, q.KA, q.KB, q.slot_of_pos, q.pos_of_slot);
@@ -1572,10 +1596,10 @@ static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s, bool* rebuilt)
     const NjPruned old = q;              // the old epoch's pointers (read by the permute / init kernels below)
     const int e = old.epoch_index + 1;
     q.epoch_index = e;
-    if (int rc = njp_alloc_epoch(q, n, b.N, (e & 1) ? b.D : q.arena_D, q.arena_slab[e & 1], s)) return rc;
+    if (int rc = njp_alloc_epoch(q, n, b.N, (e & 1) ? b.D : q.arena_D, q.arena_slab[e & 1], s, old.range_known ? old.t2_hdr : nullptr)) return rc;
     DPR_HIP(hipMemcpyAsync(q.perm, perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
     dim3 grid((unsigned)((n + kThreads - 1) / kThreads > 64 ? 64 : (n + kThreads - 1) / kThreads), (unsigned)(n < 32768 ? n : 32768));
-    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, old.D, old.ld, q.D, q.ld, q.perm, n, (unsigned long long*)(std::getenv("DPR_NJP_NO_MM") ? nullptr : q.t2_hdr));
+    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, old.D, old.ld, q.D, q.ld, q.perm, n);
     hipLaunchKernelGGL(njp_init_vectors_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                        Ucur, q.perm, (const int32_t*)old.slot_of_pos, n, n, q.U + (st.it & 1) * q.vstride, q.Ur, q.KA, q.KB,
                        q.slot_of_pos, q.pos_of_slot);
@@ -1610,7 +1634,7 @@ static int njp_to_slots(NjBuffers& b, hipStream_t s)
     // the slot-space matrix goes into the buffer the epoch does not live in; the streaming kernels read b.D
     if (q.D == b.D) std::swap(b.D, q.arena_D);
     dim3 grid((unsigned)((n + kThreads - 1) / kThreads > 64 ? 64 : (n + kThreads - 1) / kThreads), (unsigned)(n < 32768 ? n : 32768));
-    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, (const double*)q.D, q.ld, b.D, b.ld, (const int32_t*)q.pos_of_slot, n, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, (const double*)q.D, q.ld, b.D, b.ld, (const int32_t*)q.pos_of_slot, n);
     hipLaunchKernelGGL(njp_gather_u_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                        njp_current_u(q, st.it), (const int32_t*)q.pos_of_slot, n, b.U);
     DPR_HIP(hipGetLastError());
@@ -1638,7 +1662,12 @@ static int njp_from_slots(NjBuffers& b, hipStream_t s)
     if (int rc = njp_alloc_epoch(q, n, b.N, q.arena_D, q.arena_slab[0], s)) return rc;
     DPR_HIP(hipMemcpyAsync(q.perm, perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
     dim3 grid((unsigned)((n + kThreads - 1) / kThreads > 64 ? 64 : (n + kThreads - 1) / kThreads), (unsigned)(n < 32768 ? n : 32768));
-    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, (const double*)b.D, b.ld, q.D, q.ld, (const int32_t*)q.perm, n, (unsigned long long*)(std::getenv("DPR_NJP_NO_MM") ? nullptr : q.t2_hdr));
+    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, (const double*)b.D, b.ld, q.D, q.ld, (const int32_t*)q.perm, n);
+    q.range_known = false;
+    if (njp_use_post2(q)) {        // (the streaming iterations created values nobody tracked: reduce the matrix again)
+        hipLaunchKernelGGL(njp_range_kernel, dim3(2048), dim3(kThreads), 0, s, (const double*)b.D, b.ld, n, (unsigned long long*)q.t2_hdr);
+        q.range_known = true;
+    }
     hipLaunchKernelGGL(njp_init_vectors_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                        (const double*)b.U, (const int32_t*)q.perm, (const int32_t*)nullptr, n, n, q.U + (st.it & 1) * q.vstride, q.Ur, q.KA, q.KB,
                        q.slot_of_pos, q.pos_of_slot);
