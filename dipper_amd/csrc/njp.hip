@@ -972,7 +972,8 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
     // and 845 blocks at 100 000 tips where separate U and M blocks made 1 041 for 1 024 resident ones (110 registers): the
     // blocks of the second round started 8 us late and set the length of the launch (profiles/r3/nj_phases2_100k.txt)
     const bool trole = bx < a.ntest;
-    const int tb = bx, umb = bx - a.ntest;
+    const int tb = a.sh_rank + bx * a.sh_world;      // (unit-sharded plan: a rank launches only its own test blocks; tb is the global index)
+    const int umb = bx - a.ntest;
     Post2Hdr* hdr = reinterpret_cast<Post2Hdr*>(a.t2_hdr);
     const double NINF = -__builtin_inf(), PINF = __builtin_inf();
 
@@ -1003,7 +1004,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
     // its 512 positions, two per thread
     const int64_t i = (int64_t)umb * (2 * kThreads) + tid;     // first reference slot; the second one is i + 256
     const int64_t p0 = (int64_t)umb * kTileCols + 2 * tid;     // first position (< P + 512 when the M part is active)
-    const bool m_part = !trole && umb < a.nrb;
+    const bool m_part = !trole && umb < a.nrb && a.do_update;      // (a tests-only launch -- virtual ranks -- has no UM blocks at all)
     const bool u_slots = !trole && (int64_t)umb * (2 * kThreads) < N;
     int64_t p = -1, pb = -1;
     int2 sl = make_int2(-1, -1);                             // reference slots of the two positions (-1: dead / padding)
@@ -1200,7 +1201,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
             }
         }
         NJP_STAMP(1, 6, true);
-        if (a.dbg != nullptr && it == a.dbg_it && tid == 0) a.dbg[(2048 + bx) * 8 + 7] = 1ull;
+        if (a.dbg != nullptr && it == a.dbg_it && tid == 0 && bx < 2048) a.dbg[(2048 + bx) * 8 + 7] = 1ull;
         return;
     }
 
@@ -1766,7 +1767,7 @@ static bool njp_use_post2(const NjPruned& q)
 {
     static const bool on = !(std::getenv("DPR_NJP_POST2") && std::atoi(std::getenv("DPR_NJP_POST2")) == 0);
     static const int64_t min_p = std::getenv("DPR_NJP_POST2_MIN_P") ? std::atoll(std::getenv("DPR_NJP_POST2_MIN_P")) : 0;
-    return on && q.P >= min_p && njp_tg(q.P) == 256 && njp_ns(q.P) == kBigNS && q.sh_world <= 1 && (q.dbg == nullptr || q.dbg_it >= 0);
+    return on && q.P >= min_p && njp_tg(q.P) == 256 && njp_ns(q.P) == kBigNS && (q.dbg == nullptr || q.dbg_it >= 0);
 }
 
 static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
@@ -1779,8 +1780,9 @@ static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
     // large shape on a single rank: light blocks, maxima of the previous launch (njp_post2_kernel; DPR_NJP_POST2=0: the fused kernel)
     if (njp_use_post2(b.pr)) {
         const unsigned u2 = update ? (unsigned)((b.N + 2 * kThreads - 1) / (2 * kThreads)) : 0u;      // UM blocks: 512 reference slots and 512 positions each
-        const unsigned um = u2 > (unsigned)a.nrb ? u2 : (unsigned)a.nrb;
+        const unsigned um = !update ? 0u : (u2 > (unsigned)a.nrb ? u2 : (unsigned)a.nrb);
         a.nupd = (int)um;
+        if ((unsigned)a.ntest + um == 0u) return DPR_OK;
         hipLaunchKernelGGL((njp_post2_kernel<kBigNS>), dim3((unsigned)a.ntest + um), dim3(kThreads), 0, s, a);
         DPR_HIP(hipGetLastError());
         return DPR_OK;

@@ -71,6 +71,38 @@ def main():
             d.close()
         ok = done == n - 2 and all(np.array_equal(np.concatenate(got[k]), ref[k]) for k in got) and res["last_d"] == ref["last_d"]
         out.append({"kind": kind, "n": n, "ok": bool(ok), "stats": str(stats)})
+    # the unit-sharded multi-GPU plan emulated on one GPU (virtual ranks: every rank tests and scans only its own units, the update
+    # runs once with the first rank's launch, the other ranks' launches are tests only)
+    for world, kind, n, seed in ((3, "additive", 2500, 21), (8, "ties", 1300, 22), (4, "msa", 3000, 23)):
+        rng = np.random.default_rng(seed)
+        capi.set_nj_virtual_shards(world)
+        try:
+            d = dipper_amd.Dipper(0)
+            try:
+                d.set_nj_mode(1)
+                d.set_nj_adaptive(0)
+                if kind == "msa":
+                    seqs = _util.synth_alignment(rng, n, 500, mean_bl=2e-3, lo=2e-4, hi=2e-2)
+                    d.set_msa(capi.pack4_many(seqs), 500)
+                    d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+                    D = d.matrix()
+                else:
+                    if kind == "ties":
+                        D = rng.integers(1, 4, size=(n, n)).astype(np.float64)
+                        D = np.tril(D, -1) + np.tril(D, -1).T
+                    else:
+                        D = _util.random_additive_matrix(rng, n, zero_frac=0.3)
+                    d.set_matrix_full(D)
+                    d.dist_matrix(capi.SRC_MATRIX)
+                parts = [d.nj_run(max_iters=k) for k in (n // 3, 7, -1)]
+            finally:
+                d.close()
+        finally:
+            capi.set_nj_virtual_shards(1)
+        ref = orc.nj_run(np.tril(D, -1))
+        ok = all(np.array_equal(np.concatenate([q[key][:q["iters"]] for q in parts]), ref[key]) for key in ("merge_x", "merge_y", "bl_x", "bl_y")) \
+            and parts[-1]["last_d"] == ref["last_d"]
+        out.append({"kind": "unit-sharded x%d %s" % (world, kind), "n": n, "ok": bool(ok)})
     # no Q candidate below 10000 from the first iteration on (tests/test_gpu_nj.py::test_nj_no_candidate): error -4, no hang
     for n in (8, 1500):
         D = np.full((n, n), -1.0e5)

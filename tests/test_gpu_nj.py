@@ -470,4 +470,4 @@ def test_large_shape_post_kernels(post2):
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
     assert r.returncode == 0 and line, r.stderr[-3000:]
     out = json.loads(line[0][7:])
-    assert len(out) == 10 and all(c["ok"] for c in out), out
+    assert len(out) == 13 and all(c["ok"] for c in out), out
