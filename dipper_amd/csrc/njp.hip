@@ -553,7 +553,8 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
     // hop 1: state line, scan records, and what each role can address without knowing the winner
     const int64_t it = a.st->itb;   // stable: the writer below only advances st->it
     const int64_t limit = a.st->it_limit, N = a.st->N;
-    const int64_t pz = (int64_t)a.st->pnew[it & 1];        // node leaving quarantine (its U was stored by SCAN(it))
+    const int32_t pn0 = a.st->pnew[0], pn1 = a.st->pnew[1];      // (both with the state line)
+    const int64_t pz = (int64_t)((it & 1) ? pn1 : pn0);          // node leaving quarantine (its U was stored by SCAN(it))
     const int nrec_all = a.urecs + a.nrb;
     NjRecord r0; r0.q = 10000.0; r0.key = ~0ull; r0.d = 0; r0.pad = 0;
     constexpr int kMine = 5;           // records per thread loaded up front (1280: the default 1024 unit records + 256 new-row records)
@@ -574,7 +575,9 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
         if (!seed_is_unit) cand = a.partials[a.urecs + (tid - nseed_units)];
         else if ((int64_t)tid * sstride < a.urecs) cand = a.partials[(int64_t)tid * sstride];
     }
-    const unsigned long long cnt_raw = a.all_defined ? (unsigned long long)a.urecs : a.cnt[it % 3];
+    const unsigned long long cl0 = a.cnt[0], cl1 = a.cnt[1], cl2 = a.cnt[2];      // all three list counters with the first round trip (not a second, dependent load)
+    const int m3 = (int)(it % 3);
+    const unsigned long long cnt_raw = a.all_defined ? (unsigned long long)a.urecs : (m3 == 0 ? cl0 : m3 == 1 ? cl1 : cl2);
     const int64_t uvalid = (int64_t)(cnt_raw < (unsigned long long)a.urecs ? cnt_raw : (unsigned long long)a.urecs);   // unit records written by SCAN(it)
     const double* __restrict__ Uc = a.U + (it & 1) * a.vstride;
     double* __restrict__ Un = a.U + ((it + 1) & 1) * a.vstride;
@@ -980,7 +983,8 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
     // hop 1: state line, scan records, and what each role can address without knowing the winner
     const int64_t it = a.st->itb;
     const int64_t limit = a.st->it_limit, N = a.st->N;
-    const int64_t pz = (int64_t)a.st->pnew[it & 1];
+    const int32_t pn0 = a.st->pnew[0], pn1 = a.st->pnew[1];      // (both with the state line)
+    const int64_t pz = (int64_t)((it & 1) ? pn1 : pn0);
     const int64_t P = a.P;
     const int64_t G16 = (P + kUR - 1) / kUR;
     const int nrec_all = a.urecs + a.nrb;
@@ -1021,7 +1025,9 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
     const int par = (int)(it & 1);                           // T reads the maxima of buffer par, M writes buffer 1 - par
     const double* __restrict__ Uc = a.U + (it & 1) * a.vstride;
     double* __restrict__ Un = a.U + ((it + 1) & 1) * a.vstride;
-    const unsigned long long cnt_raw = a.all_defined ? (unsigned long long)a.urecs : a.cnt[it % 3];
+    const unsigned long long cl0 = a.cnt[0], cl1 = a.cnt[1], cl2 = a.cnt[2];      // all three list counters with the first round trip (not a second, dependent load)
+    const int m3 = (int)(it % 3);
+    const unsigned long long cnt_raw = a.all_defined ? (unsigned long long)a.urecs : (m3 == 0 ? cl0 : m3 == 1 ? cl1 : cl2);
     const int64_t uvalid = (int64_t)(cnt_raw < (unsigned long long)a.urecs ? cnt_raw : (unsigned long long)a.urecs);
     const double emin = dec_f64(hdr->min_enc), eabs = dec_f64(hdr->maxabs_enc);
     v2d uc; uc.x = 0.0; uc.y = 0.0;
