@@ -8,10 +8,23 @@ import numpy as np
 
 
 def main():
+    import os
     import dipper_amd
     from dipper_amd import capi
     from tests import _orc, _util
     orc = _orc.load()
+    poison = os.environ.get("DPR_SHAPE_POISON")
+    if poison:
+        # every context of this process is created on memory that held this byte pattern (0xFF: NaN as fp64): what a kernel reads
+        # without having written it -- the arrays njp_post2_kernel hands from launch to launch, the coarse bounds -- shows
+        from tests.conftest import dirty_device_memory
+        capi.load_library()
+        real = dipper_amd.Dipper
+
+        def dirty_dipper(*a, **k):
+            dirty_device_memory(3 << 30, int(poison))
+            return real(*a, **k)
+        dipper_amd.Dipper = dirty_dipper
     out = []
     # ("ties" and "random" create negative distances -- (1 + 1 - 3) / 2 -- i.e. the slack branch of njp_post2_kernel's bounds)
     cases = [("additive", 700, 3), ("additive", 2100, 4), ("ties", 900, 5), ("additive", 4500, 6), ("msa", 5000, 7), ("random", 1800, 8)]

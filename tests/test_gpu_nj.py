@@ -454,8 +454,8 @@ def test_nj_adaptive_off_is_pruned_only(orc):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("post2", ["1", "0"])
-def test_large_shape_post_kernels(post2):
+@pytest.mark.parametrize("post2,poison", [("1", None), ("0", None), ("1", "255"), ("1", "64")])
+def test_large_shape_post_kernels(post2, poison):
     """The large launch shape of the pruned path's post kernel (used from 40 000 positions: 256 row groups x 4 strips per test
     block) forced at small sizes, with both kernels for it: njp_post2_kernel (producer blocks hand row / column maxima to the
     test blocks of the same launch) and the fused njp_post_kernel<256, 4> -- merge logs equal the oracle's.  Also a run
@@ -466,6 +466,8 @@ def test_large_shape_post_kernels(post2):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DPR_NJ_BIG_P="1", DPR_NJP_POST2=post2, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    if poison:
+        env["DPR_SHAPE_POISON"] = poison          # (0xFF / 0x40 patterns in the memory every context is created on)
     r = subprocess.run([sys.executable, "-m", "tests._njp_shape_worker"], cwd=root, env=env, capture_output=True, text=True, timeout=800)
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
     assert r.returncode == 0 and line, r.stderr[-3000:]
