@@ -8,8 +8,13 @@ from dipper_amd import capi
 from tests import _util
 n, L = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (30000, 1000)
 mbl = float(sys.argv[3]) if len(sys.argv) > 3 else 2e-4
-seqs = _util.synth_alignment(np.random.default_rng(1), n, L, mean_bl=mbl, lo=mbl / 10, hi=mbl * 10)
-packed = capi.pack4_many(seqs)
+import subprocess, tempfile
+_tmp = tempfile.mkdtemp(prefix="njdiff_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+_p4 = os.path.join(_tmp, "a.p4")
+subprocess.run([os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "tools", "bin", "gen_synth"), "--tips", str(n), "--sites", str(L), "--seed", "1",
+                "--mean-bl", repr(mbl), "--lo", repr(mbl / 10), "--hi", repr(mbl * 10), "--packed4", _p4], check=True)      # native generator (tools/gen_synth.cpp)
+packed = np.fromfile(_p4, dtype=np.uint64).reshape(n, (L + 15) // 16)
+os.unlink(_p4); os.rmdir(_tmp)
 res = {}
 dirty = os.environ.get("DIAG_DIRTY")
 for mode in (1, 0, 1):
@@ -22,6 +27,7 @@ for mode in (1, 0, 1):
     d.set_msa(packed, L)
     d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
     r = d.nj_run()
+    print("mode", "pruned" if mode else "streaming", "nj_ms", round(d.timing()[1], 1), flush=True)
     d.close()
     if mode in res:
         print("pruned run twice: identical", all(np.array_equal(res[mode][k], r[k]) for k in ("merge_x", "merge_y", "bl_x", "bl_y")))
