@@ -420,12 +420,16 @@ int main(int argc, char** argv)
             njDeviceArrays.findNeighbourJoiningTree(dev, names, *output_);
             std::cerr << "Tree Created in: " << ms_since(t0) << " ms\n";
         }
-        // the tree is written: close the output and leave without tearing down ~15 GB of device buffers
-        // and the HIP runtime one by one (the driver reclaims them with the process)
+        // the tree is written: close the output and leave without running the static destructors of the HIP runtime
         output_.reset();
         if (std::getenv("DPR_CLI_TIMING")) std::cerr << "Main in: " << ms_since(inputStart) << " ms\n";
         std::cerr.flush();
         std::fflush(nullptr);
+        // ... but the device buffers and streams ARE released here, by the process itself: left to the kernel driver, the ~15 GB of
+        // live allocations of a 30 000-tip run delay the runtime start-up of the NEXT process by 0.35-0.45 s in four runs out of
+        // ten on some hosts (30 runs each, back to back: none with this call, 12 without; the call itself costs nothing
+        // measurable -- profiles/r3/cli_exit_sweep.jsonl).  DPR_CLI_FAST_EXIT=1 skips it.
+        if (!std::getenv("DPR_CLI_FAST_EXIT")) { dpr_destroy(dev.ctx); dev.ctx = nullptr; }
         _exit(0);
     } else if (params.in == "d" && params.out == "t") {
         MatrixReader matrixReader;

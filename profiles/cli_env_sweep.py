@@ -13,6 +13,8 @@ exe = os.path.join(ROOT, "dipper_amd", "bin", "dipper")
 D = {"DPR_CLI_RUNTIME_DEFAULTS": "1"}       # (main.cpp sets HSA_ENABLE_SDMA=0 and GPU_MAX_HW_QUEUES=2 for itself unless this is set)
 variants = [("runtime defaults", D), ("HSA_ENABLE_SDMA=0 GPU_MAX_HW_QUEUES=2 (what the command sets for itself)", {}),
             ("HSA_ENABLE_SDMA=0 only", dict(D, HSA_ENABLE_SDMA="0")), ("GPU_MAX_HW_QUEUES=2 only", dict(D, GPU_MAX_HW_QUEUES="2"))] * 2
+if os.environ.get("SWEEP_EXIT"):
+    variants = [("_exit with everything live (DPR_CLI_FAST_EXIT=1)", {"DPR_CLI_FAST_EXIT": "1"}), ("dpr_destroy, then _exit (default)", {})] * 3
 for name, env in variants:
     walls, mains, inputs = [], [], []
     for r in range(runs + 1):
