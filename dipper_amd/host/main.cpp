@@ -336,6 +336,12 @@ int main(int argc, char** argv)
     if ((params.in == "m" || params.in == "r") && params.out == "t") {
         const bool aligned = params.in == "m";
         std::vector<std::string> names;
+        // (checked BEFORE the device thread starts: on a host without a GPU that thread ends the process with its own message,
+        //  and which of the two a caller saw for a missing file depended on the race)
+        if (access(inputFile.c_str(), R_OK) != 0) {
+            std::fprintf(stderr, "ERROR: cant open file: %s\n", inputFile.c_str());  // src/tree_generation.cu:138-141
+            return 1;
+        }
         AsyncDeviceContext adev(device);          // HIP start-up runs while the input is read
         // fast path: records indexed in the mapped text and packed straight into the device interface's flat arrays;
         // as soon as the number of records is known the device thread allocates the NJ matrices (when NJ is the mode)
