@@ -454,7 +454,7 @@ def test_nj_adaptive_off_is_pruned_only(orc):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("post2,poison", [("1", None), ("0", None), ("1", "255"), ("1", "64")])
+@pytest.mark.parametrize("post2,poison", [("1", None), ("0", None), ("1", "255")])
 def test_large_shape_post_kernels(post2, poison):
     """The large launch shape of the pruned path's post kernel (used from 40 000 positions: 256 row groups x 4 strips per test
     block) forced at small sizes, with both kernels for it: njp_post2_kernel (producer blocks hand row / column maxima to the
