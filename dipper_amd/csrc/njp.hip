@@ -1523,9 +1523,10 @@ int njp_build(NjBuffers& b, hipStream_t s)
 {
     {   // blocks of the unit scan (tests shrink it so that every block walks several units and cnt > grid)
         // default: 256 blocks while an iteration lists ~100 units (a 1000-block grid takes ~1.5 us just to start; NJ 515 ->
-        // 512 ms at 30 000 tips), 1024 where the scans are bandwidth-bound (thousands of units per iteration at 100 000 tips)
+        // 512 ms at 30 000 tips), 512 above (round 2: 1024; every block of the post kernels reduces one record per scan block --
+        // NJ at 100 000 tips 2.10 / 2.07 / 2.06 / 2.08 / 2.10 s with 256 / 384 / 512 / 768 / 1024, round 3)
         const char* e = std::getenv("DPR_NJP_GRID");
-        const int g = e ? std::atoi(e) : (b.N < 50000 ? 256 : 1024);
+        const int g = e ? std::atoi(e) : (b.N < 50000 ? 256 : 512);
         b.pr.scan_grid = g < 1 ? 1 : (g > 1024 ? 1024 : g);
     }
     if (const char* e = std::getenv("DPR_NJ_ADAPTIVE")) b.pr.adaptive = std::atoi(e) != 0 ? 1 : 0;
