@@ -8,8 +8,8 @@ import numpy as np
 import dipper_amd
 from dipper_amd import capi
 ROOT = os.environ.get("GRAFT_REPO_ROOT", ".")
-n, L = 30000, 10000
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+n, L = (int(sys.argv[2]) if len(sys.argv) > 2 else 30000), 10000
 tmp = tempfile.mkdtemp(prefix="pmc_")
 p4 = os.path.join(tmp, "a.p4")
 subprocess.run([os.path.join(ROOT, "tools", "bin", "gen_synth"), "--tips", str(n), "--sites", str(L), "--seed", "1", "--packed4", p4], check=True)
