@@ -1773,8 +1773,7 @@ static int njp_launch_scan(NjBuffers& b, hipStream_t s, int v, bool rows)
 static bool njp_use_post2(const NjPruned& q)
 {
     static const bool on = !(std::getenv("DPR_NJP_POST2") && std::atoi(std::getenv("DPR_NJP_POST2")) == 0);
-    static const int64_t min_p = std::getenv("DPR_NJP_POST2_MIN_P") ? std::atoll(std::getenv("DPR_NJP_POST2_MIN_P")) : 0;
-    return on && q.P >= min_p && njp_tg(q.P) == 256 && njp_ns(q.P) == kBigNS && (q.dbg == nullptr || q.dbg_it >= 0);
+    return on && njp_tg(q.P) == 256 && njp_ns(q.P) == kBigNS && (q.dbg == nullptr || q.dbg_it >= 0);
 }
 
 static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
