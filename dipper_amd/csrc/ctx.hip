@@ -1145,6 +1145,8 @@ int dpr_get_iterstats(dpr_ctx* c, uint64_t* out, int64_t iters)
 // microbenchmark: wall time per launch of a chain of trivial dependent kernels (eager or graph replay)
 __global__ void dpr_nop_kernel(unsigned long long* p) { if (threadIdx.x == 0 && blockIdx.x == 0 && p[7] == 12345) p[6] = 1; }
 
+__global__ void dpr_mark_kernel(unsigned long long* out, long long idx) { if (threadIdx.x == 0 && blockIdx.x == 0) out[idx] = (unsigned long long)idx + 1ull; }
+
 int dpr_launch_bench(dpr_ctx* c, int nlaunch, int grid, int use_graph, float* us_per_launch)
 {
     if (!c || nlaunch < 1 || grid < 1 || !us_per_launch) { set_error("dpr_launch_bench: bad argument"); return DPR_ERR_ARG; }
@@ -1162,19 +1164,68 @@ int dpr_launch_bench(dpr_ctx* c, int nlaunch, int grid, int use_graph, float* us
         DPR_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         DPR_HIP(hipGraphDestroy(g));
     }
+    // use_graph == 2: an explicitly built chain whose nodes get NEW PARAMETERS (argument and grid) before every replay --
+    // what a loop with per-launch arguments (placement: the tip index, the distance row) would have to do to be replayed
+    std::vector<hipGraphNode_t> nodes;
+    hipGraph_t g_keep = nullptr;
+    unsigned long long* marks = nullptr;          // use_graph == 2: launch i writes marks[i] = i + 1 (every launch must see ITS parameters)
+    if (use_graph == 2) {
+        DPR_HIP(hipMalloc(&marks, sizeof(unsigned long long) * (size_t)nlaunch));
+        DPR_HIP(hipMemset(marks, 0, sizeof(unsigned long long) * (size_t)nlaunch));
+    }
+    unsigned long long* argp = marks;
+    long long argi = 0;
+    void* kargs[2] = { &argp, &argi };
+    if (use_graph == 2) {
+        if (ge) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
+        hipGraph_t g = nullptr;
+        DPR_HIP(hipGraphCreate(&g, 0));
+        for (int k = 0; k < per; ++k) {
+            hipKernelNodeParams kp{};
+            kp.func = reinterpret_cast<void*>(dpr_mark_kernel);
+            kp.gridDim = dim3((unsigned)grid); kp.blockDim = dim3(256); kp.sharedMemBytes = 0; kp.kernelParams = kargs; kp.extra = nullptr;
+            hipGraphNode_t nd = nullptr;
+            DPR_HIP(hipGraphAddKernelNode(&nd, g, k ? &nodes.back() : nullptr, k ? 1 : 0, &kp));
+            nodes.push_back(nd);
+        }
+        DPR_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        g_keep = g;       // (the node handles live in the graph: it stays until the replays are done)
+    }
     DPR_HIP(hipStreamSynchronize(c->stream));
     DPR_HIP(hipEventRecord(c->ev[2], c->stream));
     int done = 0;
-    if (use_graph) for (; done + per <= nlaunch; done += per) DPR_HIP(hipGraphLaunch(ge, c->stream));
+    if (use_graph == 2) {
+        for (; done + per <= nlaunch; done += per) {
+            for (int k = 0; k < per; ++k) {
+                hipKernelNodeParams kp{};
+                kp.func = reinterpret_cast<void*>(dpr_mark_kernel);
+                argi = (long long)(done + k);
+                kp.gridDim = dim3((unsigned)(grid + ((done / per + k) & 1))); kp.blockDim = dim3(256); kp.sharedMemBytes = 0; kp.kernelParams = kargs; kp.extra = nullptr;
+                DPR_HIP(hipGraphExecKernelNodeSetParams(ge, nodes[(size_t)k], &kp));
+            }
+            DPR_HIP(hipGraphLaunch(ge, c->stream));
+        }
+    } else if (use_graph) for (; done + per <= nlaunch; done += per) DPR_HIP(hipGraphLaunch(ge, c->stream));
     for (; done < nlaunch; ++done) hipLaunchKernelGGL(dpr_nop_kernel, dim3(grid), dim3(256), 0, c->stream, buf);
     DPR_HIP(hipEventRecord(c->ev[3], c->stream));
     DPR_HIP(hipStreamSynchronize(c->stream));
     float ms = 0;
     DPR_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
     *us_per_launch = ms * 1e3f / (float)nlaunch;
+    int rc_marks = DPR_OK;
+    if (marks) {
+        std::vector<unsigned long long> h((size_t)done);
+        if (done > 0 && hipMemcpy(h.data(), marks, sizeof(unsigned long long) * (size_t)done, hipMemcpyDeviceToHost) == hipSuccess) {
+            long long bad = 0;
+            for (long long i = 0; i < done; ++i) bad += h[(size_t)i] != (unsigned long long)i + 1ull;
+            if (bad) { set_error("dpr_launch_bench: " + std::to_string(bad) + " of " + std::to_string(done) + " replayed launches did not run with their own parameters"); rc_marks = DPR_ERR_STATE; }
+        }
+        (void)hipFree(marks);
+    }
     if (ge) (void)hipGraphExecDestroy(ge);
+    if (g_keep) (void)hipGraphDestroy(g_keep);
     (void)hipFree(buf);
-    return DPR_OK;
+    return rc_marks;
 }
 
 // tuning hook: row-group size (16/32/64), non-temporal loads (0/1), scan grid (<= 2048; 0 = default)
