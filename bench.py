@@ -1121,13 +1121,13 @@ def nj_scaling(args, rank, world, local_rank, dist, torch, barrier, packed, n, L
         if ONE_GPU and plan != "mailbox":
             rec["row_sharded"][plan] = {"skipped": "needs RCCL (rehearsal with process ranks on one GPU)"}
             continue
-        # a plan that hangs costs its time limits (60 + 30 s): the ranks agree on whether the deadline still allows that
-        if budget is not None and not budget.allows_all(100):
-            rec["row_sharded"][plan] = budget.skip(100)
+        # a plan that hangs costs its time limits (90 + 30 s): the ranks agree on whether the deadline still allows that
+        if budget is not None and not budget.allows_all(130):
+            rec["row_sharded"][plan] = budget.skip(130)
             continue
         log(f"[bench r{rank}] +{elapsed():.0f}s: nj_scaling at {n} tips: row-sharded over {world} ranks, exchange plan {plan}")
         try:
-            r = njs_child_leg(plan, rank, world, local_rank, dist, torch, str(p4), n, L, iters, setup_s=60.0, run_s=30.0)
+            r = njs_child_leg(plan, rank, world, local_rank, dist, torch, str(p4), n, L, iters, setup_s=90.0, run_s=30.0)      # (set-up: child start, RCCL communicator of the children, matrix build, peer mappings, warm-up)
         except Exception as e:
             r = {"error": repr(e)}
         if rank == 0 and "error" not in r and solo_digest is not None:
