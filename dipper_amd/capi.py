@@ -457,7 +457,10 @@ class Dipper:
 
     def matrix(self):
         n = self.n_total()
-        return np.stack([self.matrix_row(i) for i in range(n)])
+        out = np.zeros((n, n), dtype=np.float64)
+        for i in range(n):
+            _chk(self.L, self.L.dpr_get_matrix_row(self.h, i, _p(out[i], c_f64p)))
+        return out
 
     def row_sums(self):
         out = np.zeros(self.n_total(), dtype=np.float64)
