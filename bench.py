@@ -160,7 +160,7 @@ class Stage:
         if self.dist is not None:
             self.dist.barrier()
 
-    def gen(self, tag, tips, sites, seed, mean, lo, hi, fasta=False, reads=False, shuffle=None):
+    def gen(self, tag, tips, sites, seed, mean, lo, hi, fasta=False, reads=False, shuffle=None, gap=0.0):
         """returns the paths of input `tag`; rank 0 runs the generator (all host threads: the other ranks wait)"""
         base = os.path.join(self.dir, tag)
         p = {"tips": tips, "sites": sites, "tree": base + ".nwk", "fasta": base + ".fa" if fasta else None,
@@ -175,6 +175,8 @@ class Stage:
                 cmd += ["--indel", "0.03,0.09", "--packed2", p["packed2"]]
             else:
                 cmd += ["--packed4", p["packed4"]]
+                if gap and gap > 0:
+                    cmd += ["--gap-frac", repr(float(gap))]
             if shuffle is not None:
                 cmd += ["--shuffle", str(shuffle), "--order", p["order"]]
             subprocess.run(cmd, check=True)
@@ -354,6 +356,9 @@ def main():
     ap.add_argument("--tips", type=int, default=30000)
     ap.add_argument("--sites", type=int, default=10000)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--gap-frac", type=float, default=0.03,
+                    help="fraction of '-' cells in the ALIGNED inputs (gen_synth --gap-frac; the authors simulate with indels, "
+                         "scripts/alisim.sh:14 -- an alignment of such data holds gap columns); 0 = the gap-free inputs of rounds 1-3")
     ap.add_argument("--probe-reps", type=int, default=20)
     ap.add_argument("--deadline-s", type=float, default=float(os.environ.get("DPR_BENCH_DEADLINE_S", "500")),
                     help="optional legs are skipped when they would not finish this many seconds after process start "
@@ -450,7 +455,7 @@ def main():
 
     n, L = args.tips, args.sites
     want_cli = not args.no_cli and not args.probe_only and os.path.exists(EXE)
-    inp = stage.gen("main", n, L, args.seed, 2e-5, 2e-6, 2e-4, fasta=want_cli)
+    inp = stage.gen("main", n, L, args.seed, 2e-5, 2e-6, 2e-4, fasta=want_cli, gap=args.gap_frac)
     packed = Stage.packed4(inp)
     names = ["T%d" % (i + 1) for i in range(n)]
     tmp = tempfile.mkdtemp(prefix="dipper_bench_r%d_" % rank)
@@ -675,7 +680,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic (seeded Yule-Harding tree, JC69, L=%d, no indels; own native generator tools/gen_synth.cpp: no alisim in the image)" % L,
+            "data": "synthetic (seeded Yule-Harding tree, JC69, L=%d, %s; own native generator tools/gen_synth.cpp: no alisim in the image)"
+                    % (L, ("%.3g of the cells are '-' (per-tip runs + inherited deletions, gen_synth --gap-frac)" % args.gap_frac) if args.gap_frac > 0 else "no gaps"),
             "config": {"workload": "configs[1]: %d aligned tips, -d 2 (JC69), conventional NJ (-m 2)" % n,
                        "tips": n, "sites": L,
                        "step": "one whole `dipper` command per rank (FASTA -> Newick)" if primary else "in-process hot path (HBM-resident input -> merge log)",
@@ -756,6 +762,10 @@ def main():
             except Exception as e:
                 out["sharded_100k"] = {"error": repr(e)}
         out["bench_wall_s"] = round(elapsed(), 1)
+        try:
+            out = with_scaling_summary(out, world)
+        except Exception as e:
+            out["nj_iteration_scaling"] = {"error": repr(e)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
         try:
@@ -795,7 +805,7 @@ def other_configs(args, local_rank, stage, budget, tmp):
 
     def nj_100k():
         n, L = 100000, 10000
-        inp = stage.gen("nj100k", n, L, args.seed + 7, 2e-5, 2e-6, 2e-4)
+        inp = stage.gen("nj100k", n, L, args.seed + 7, 2e-5, 2e-6, 2e-4, gap=args.gap_frac)
         packed = Stage.packed4(inp)
         d = dipper_amd.Dipper(local_rank)
         try:
@@ -845,7 +855,7 @@ def other_configs(args, local_rank, stage, budget, tmp):
 
     def dc_1m():
         n, L = args.dc_tips, 400
-        inp = stage.gen("dc1m", n, L, args.seed + 9, 2e-3, 2e-4, 2e-2, shuffle=7)   # the CLI shuffles its input (src/tree_generation.cu:341-344)
+        inp = stage.gen("dc1m", n, L, args.seed + 9, 2e-3, 2e-4, 2e-2, shuffle=7, gap=args.gap_frac)   # the CLI shuffles its input (src/tree_generation.cu:341-344)
         packed = Stage.packed4(inp)
         d = dipper_amd.Dipper(local_rank)
         try:
@@ -907,6 +917,36 @@ def streaming_run(d, torch, dist, barrier, packed, n, L, iters, timed_world):
         wall, loop_ms = float(t[0].item()), float(t[1].item())
     info = d.nj_exchange_info() if timed_world > 1 else {"launches": 2 * int(res["iters"]), "collectives": 0, "plan": "single rank", "note": ""}
     return res, stream_record(n, int(res["iters"]), loop_ms, wall, info, timed_world, merge_digest(res))
+
+
+def with_scaling_summary(out, world):
+    """north_star's scaling metric in ONE small object placed right behind `roofline` (so a truncated record still carries
+    it): NJ iterations per second of the streaming loop on one GPU, of the default plan on one GPU, and of the row-sharded loop
+    per exchange plan on this run's ranks, with what joined the ranks.  The top-level `scaling` key stays the contract's string."""
+    njs = out.get("nj_scaling")
+    if not isinstance(njs, dict) or "tips" not in njs:
+        return out
+    comp = {"tips": njs.get("tips"), "iterations_timed": njs.get("iterations_timed"), "n_gpus": world,
+            "streaming_one_gpu_its_per_s": (njs.get("streaming_one_gpu") or {}).get("nj_iterations_per_s"),
+            "default_plan_one_gpu_its_per_s": (njs.get("default_plan_one_gpu") or {}).get("nj_iterations_per_s"),
+            "row_sharded": {}}
+    for plan, r in (njs.get("row_sharded") or {}).items():
+        if not isinstance(r, dict):
+            continue
+        if "nj_iterations_per_s" in r:
+            comp["row_sharded"][plan] = {"its_per_s": r.get("nj_iterations_per_s"), "speedup_vs_streaming_one_gpu": r.get("iteration_speedup_vs_one_gpu"),
+                                         "ranks": r.get("ranks"), "rccl": r.get("rccl"), "matches_single_gpu": r.get("matches_single_gpu"),
+                                         "launches_per_iteration": r.get("launches_per_iteration"), "collectives_per_iteration": r.get("collectives_per_iteration")}
+        else:
+            comp["row_sharded"][plan] = {k: r[k] for k in ("skipped", "error") if k in r}
+    new = {}
+    for k, v in out.items():
+        new[k] = v
+        if k == "roofline":
+            new["nj_iteration_scaling"] = comp
+    if "nj_iteration_scaling" not in new:
+        new["nj_iteration_scaling"] = comp
+    return new
 
 
 def stream_record(n, iters, loop_ms, wall, info, timed_world, digest):
@@ -989,7 +1029,8 @@ def njs_worker():
             _, loop_ms = d.timing()
             info = d.nj_exchange_info()
             say({"result": {"iters": int(res["iters"]), "wall_s": wall, "loop_ms": loop_ms, "launches": info["launches"], "collectives": info["collectives"],
-                            "plan": info["plan"], "note": info["note"], "digest": merge_digest(res), "ranks": ranks}})
+                            "plan": info["plan"], "note": info["note"], "digest": merge_digest(res), "ranks": ranks,
+                            "rccl": not cfg["local"]}})
         finally:
             d.close()
     except BaseException as e:      # every failure is a line the parent can read (DPR_ERR_COMM when a mailbox poll ran out, ...)
@@ -1078,7 +1119,12 @@ def njs_child_leg(plan, rank, world, local_rank, dist, torch, p4, n, L, iters, s
         loop_ms = max(r["loop_ms"] for r in allr)
         wall = max(r["wall_s"] for r in allr)
         rec = stream_record(n, mine["iters"], loop_ms, wall, mine, world, mine["digest"])
-        rec["rccl_ranks"] = mine["ranks"]
+        # `ranks` = processes that took part; `rccl` says whether an RCCL communicator joined them (process ranks on ONE GPU are
+        # joined through hipIpc windows only) -- a run without RCCL is never reported as rccl_ranks
+        rec["ranks"] = mine["ranks"]
+        rec["rccl"] = bool(mine.get("rccl"))
+        if rec["rccl"]:
+            rec["rccl_ranks"] = mine["ranks"]
         rec["ranks_agree"] = len({r["digest"] for r in allr}) == 1 and len({r["iters"] for r in allr}) == 1
         rec["child_process"] = {"hip_runtime": ready.get("hip_runtime"), "torch_loaded": ready.get("torch_loaded")}
         return rec
@@ -1149,7 +1195,7 @@ def sharded_leg(args, rank, world, local_rank, dist, torch, barrier, stage, budg
     rec = {"tips": ns, "sites": Ls, "world": world}
     if not budget.allows_all(60):
         return dict(rec, **budget.skip(60))
-    inp = stage.gen("nj100k", ns, Ls, args.seed + 7, 2e-5 * 10000 / Ls, 2e-6 * 10000 / Ls, 2e-4 * 10000 / Ls)
+    inp = stage.gen("nj100k", ns, Ls, args.seed + 7, 2e-5 * 10000 / Ls, 2e-6 * 10000 / Ls, 2e-4 * 10000 / Ls, gap=args.gap_frac)
     packed = Stage.packed4(inp)
     if ONE_GPU and world > 1:
         rec["unit_sharded_plan"] = {"skipped": "needs RCCL (rehearsal with process ranks on one GPU)"}
@@ -1230,7 +1276,7 @@ def dc_leg(args, rank, world, local_rank, dist, torch, barrier, stage):
     import dipper_amd
     from dipper_amd import capi
     n, L = args.dc_tips, 400
-    inp = stage.gen("dc1m", n, L, args.seed + 9, 2e-3, 2e-4, 2e-2, shuffle=7)      # the CLI shuffles its input (src/tree_generation.cu:341-344)
+    inp = stage.gen("dc1m", n, L, args.seed + 9, 2e-3, 2e-4, 2e-2, shuffle=7, gap=args.gap_frac)      # the CLI shuffles its input (src/tree_generation.cu:341-344)
     packed = Stage.packed4(inp)
     rec = {"tips": n, "sites": L, "backbone": n // 20, "world": world}
 

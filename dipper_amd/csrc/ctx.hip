@@ -147,7 +147,10 @@ static int ctx_exchange_plan(const dpr_ctx* c)
     if (c->nj_exchange >= 0) return c->nj_exchange;
     if (g_nj_exchange < 0) {
         const char* e = std::getenv("DPR_NJ_EXCHANGE");
-        g_nj_exchange = (e && std::strcmp(e, "legacy") == 0) ? kNjsLegacy : (e && std::strcmp(e, "mailbox") == 0) ? kNjsMailbox : kNjsPeer;
+        // Default LEGACY (round 4, advisor): the one-exchange plans have only ever run with virtual ranks and process ranks on
+        // ONE device, where peer memory is local; until `bench.py --gpus G` has shown `matches_single_gpu` for them on real
+        // multi-GPU hardware they are opt-in (DPR_NJ_EXCHANGE=peer|mailbox, dpr_ctx_set_nj_exchange -- bench.py times all three).
+        g_nj_exchange = (e && std::strcmp(e, "peer") == 0) ? kNjsPeer : (e && std::strcmp(e, "mailbox") == 0) ? kNjsMailbox : kNjsLegacy;
     }
     return g_nj_exchange;
 }
@@ -155,7 +158,7 @@ static int ctx_multi_plan(const dpr_ctx* c) { return c->nj_multi_plan >= 0 ? c->
 static int ctx_vshards(const dpr_ctx* c) { return c->nj_vshards >= 1 ? c->nj_vshards : g_nj_vshards; }
 
 // ---- exchange step of the sharded path: RCCL all-gather, or device copies between virtual ranks --
-enum ExKind { EX_RECS, EX_SLICES, EX_U };
+enum ExKind { EX_RECS, EX_SLICES, EX_U, EX_RECS64 /* rank records of the one-exchange loop (NjsRec) */ };
 static const int kNcclUint8 = 1, kNcclFloat64 = 8, kNcclInt32 = 2, kNcclUint64 = 5, kNcclSum = 0;
 
 static int exchange(dpr_ctx* c, ExKind kind)
@@ -169,6 +172,9 @@ static int exchange(dpr_ctx* c, ExKind kind)
                 if (kind == EX_RECS) {
                     if (t == r) continue;
                     DPR_HIP(hipMemcpyAsync(dst.recs + r, src.recs + r, sizeof(NjRecord), hipMemcpyDeviceToDevice, c->stream));
+                } else if (kind == EX_RECS64) {
+                    if (t == r) continue;
+                    DPR_HIP(hipMemcpyAsync(dst.recs64 + r, src.recs64 + r, sizeof(NjsRec), hipMemcpyDeviceToDevice, c->stream));
                 } else {
                     const size_t cnt = (size_t)(kind == EX_SLICES ? 3 : 1) * (size_t)src.slice_len;
                     DPR_HIP(hipMemcpyAsync(dst.gath + (size_t)r * cnt, src.slice, cnt * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -183,6 +189,8 @@ static int exchange(dpr_ctx* c, ExKind kind)
     ++c->nj_collectives;
     if (kind == EX_RECS)
         rc = g_rccl.AllGather(b.recs + c->rank, b.recs, sizeof(NjRecord), kNcclUint8, c->comm, c->stream);
+    else if (kind == EX_RECS64)
+        rc = g_rccl.AllGather(b.recs64 + c->rank, b.recs64, sizeof(NjsRec), kNcclUint8, c->comm, c->stream);
     else
         rc = g_rccl.AllGather(b.slice, b.gath, (size_t)(kind == EX_SLICES ? 3 : 1) * (size_t)b.slice_len, kNcclFloat64, c->comm, c->stream);
     if (rc != 0) {
@@ -311,7 +319,25 @@ static int njs_setup(dpr_ctx* c)
         c->nj_exchange_active = kNjsMailbox;
         return DPR_OK;
     }
-    if (!b.peer.attached) {
+    // attach or skip: decided on GATHERED flags, never on this rank's own state -- if one rank's buffers were recreated
+    // (a context re-made, nj_alloc after a failed call) while the others still hold their mappings, a rank-local test would
+    // send some ranks into the all-gathers below and the others past them (advisor, round 3).  Mixed state: everybody
+    // drops its mappings and attaches again.
+    bool attach = true;
+    {
+        std::vector<uint64_t> af((size_t)c->world, 0);
+        const uint64_t mine_attached = (ok && b.peer.attached) ? 1 : 0;
+        if (int rc = rccl_gather_bytes(c, &mine_attached, af.data(), sizeof(uint64_t))) return rc;
+        bool all_attached = true;
+        for (uint64_t f : af) all_attached = all_attached && f == 1;
+        attach = !all_attached;
+        if (attach && b.peer.attached) {
+            for (void* m : b.peer.opened) (void)hipIpcCloseMemHandle(m);
+            b.peer.opened.clear();
+            b.peer.attached = false;
+        }
+    }
+    if (attach) {
         PeerBlob mine;
         std::vector<PeerBlob> all((size_t)c->world);
         if (ok) peer_blob_of(c, &mine); else std::memset(&mine, 0, sizeof mine);
@@ -368,7 +394,7 @@ static int nj_iteration(dpr_ctx* c, int64_t n, int64_t it)
         for (auto& b : c->nj)
             if (int rc = njs_launch_scan(b, n, it, c->njs_pending, c->stream)) return rc;
         if (c->nj_exchange_active == kNjsPeer)
-            if (int rc = exchange(c, EX_RECS)) return rc;
+            if (int rc = exchange(c, EX_RECS64)) return rc;
         for (auto& b : c->nj)
             if (int rc = njs_launch_post(b, n, it, c->njs_pending, c->stream)) return rc;
         c->njs_pending = true;
@@ -963,6 +989,15 @@ int64_t dpr_nj_run(dpr_ctx* c, int64_t max_iters, int32_t* merge_x, int32_t* mer
     }
     if (st.status == 3) {
         set_error("dpr_nj_run: the exchange between the ranks failed (a rank's record did not arrive within the poll limit, or the all-gather delivered a stale one)");
+        return DPR_ERR_COMM;
+    }
+    if (st.status == 4) {
+        // (njs_post_kernel left the two differing words in st.q / st.d and the ranks in st.x / st.y)
+        char msg[320];
+        std::snprintf(msg, sizeof msg, "dpr_nj_run: the ranks' replicated row sums differ after %lld iterations (rank %d: %a, rank %d: %a): a row pulled from its owner "
+                      "was stale or torn -- the merge log up to here is not trustworthy; use the legacy exchange (dpr_ctx_set_nj_exchange(ctx, 0))",
+                      (long long)st.it, (int)st.x, st.q, (int)st.y, st.d);
+        set_error(msg);
         return DPR_ERR_COMM;
     }
     if (st.status == 5) {

@@ -167,7 +167,25 @@ constexpr int kNjsMaxWorld = 64;
 constexpr int kNjsLegacy = 0;    // round 2's loop: 4 launches + 2 all-gathers per iteration (nj.hip)
 constexpr int kNjsPeer = 1;      // 2 launches + ONE RCCL all-gather (rank records); rows x / y pulled from their owners' memory
 constexpr int kNjsMailbox = 2;   // 2 launches, no collective: the records go straight into every rank's mailbox
-// layout of a rank's peer-visible window (byte offsets): mail[2][kNjsMaxWorld] records | barrier lines | slice | 4 row buffers
+// A rank's record of one iteration as the one-exchange loop publishes it (one 64-byte line).  Besides the rank's best
+// candidate it carries what lets every rank CHECK the others each iteration (round 4; the loop has no fences and had
+// never met a second GPU):
+//   seq     run id << 32 | it + 1 -- written last; a record of another iteration means the exchange did not happen;
+//   ux      bits of the row sum U[x] of the node created by merge it - 1 as THIS rank computed it: a sum over values
+//           derived from every element of the rows x and y the rank pulled from their owners.  The row sums are
+//           replicated state, bit-identical on every rank by construction, so one differing word proves that some rank
+//           pulled stale or torn data -- the run ends with DPR_ERR_COMM instead of a silently different merge log;
+//   status  the publishing rank's state (3 / 4: it has already failed) -- the others fail the same way, not with NOCAND.
+struct alignas(64) NjsRec {
+    double q;
+    uint64_t key;
+    double d;
+    uint64_t seq;
+    uint64_t ux;
+    uint64_t status;
+    uint64_t pad[2];
+};
+// layout of a rank's peer-visible window (byte offsets): mail[2][kNjsMaxWorld] records (NjsRec) | barrier lines | slice | 4 row buffers
 struct NjsLayout {
     int64_t off_bar = 0, off_slice = 0, off_rows = 0, bytes = 0;
     int64_t slice_len = 0;   // doubles (initial row sums of the own rows)
@@ -186,6 +204,7 @@ struct NjPeer {
     unsigned long long bar_epoch = 0;
     unsigned long long run_id = 0;   // matrix builds on this window so far (part of every mail sequence number)
     unsigned long long poll_ticks = 200000000ull;    // 2 s of the 100 MHz wall clock
+    int64_t fault_it = -1; int fault_rank = -1;      // test hook DPR_NJS_FAULT (njs_alloc_window)
 };
 
 struct NjBuffers {
@@ -200,6 +219,7 @@ struct NjBuffers {
     uint64_t* KA = nullptr;    // [N] nj_key_a(i, n) for the current n
     NjRecord* partials = nullptr;  // [kScanBlocks]
     NjRecord* recs = nullptr;      // [world]
+    NjsRec* recs64 = nullptr;      // [world] rank records of the one-exchange loop (njs.hip)
     double* xpart = nullptr;   // [ceil(N/256)]
     double* gath = nullptr;    // [3][world][slice] gathered column slices (world > 1)
     double* slice = nullptr;   // [3][slice] local column slices (world > 1)

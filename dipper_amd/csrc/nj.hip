@@ -11,6 +11,8 @@
 // with -ffp-contract=off.
 #include "nj_dev.hpp"
 
+#include <atomic>
+
 namespace dpr {
 
 // ------------------------------------------------------------------------------------------------
@@ -109,7 +111,6 @@ __global__ __launch_bounds__(kThreads) void nj_scan_kernel(
     // scalar loads for the row parameters.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int32_t* pref = reinterpret_cast<int32_t*>(smem);  // [nstrips + 1] exclusive prefix of unit counts
-    __shared__ int32_t ssum[kThreads];
     __shared__ double sd[kThreads];
     __shared__ double sq[kThreads / 64];
     __shared__ uint64_t sk[kThreads / 64];
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(kThreads) void nj_scan_kernel(
     double urx = 0.0;
     if (it > 0 && !dead) {
         xprev = st->x;
-        const double ux = finish_ux(xpart, n + 1, sd);
+        const double ux = finish_ux_bcast(xpart, n + 1, sd);
         urx = ux / (double)(n - 2);
         if (blockIdx.x == 0 && tid == 0) { U_w[xprev] = ux; Ur_w[xprev] = urx; }
     }
@@ -132,30 +133,8 @@ __global__ __launch_bounds__(kThreads) void nj_scan_kernel(
     int nstrips = n > 1 ? (int)((n - 1 + kTileCols - 1) / kTileCols) : 0;
     if (dead) nstrips = 0;
 
-    // unit counts per strip -> exclusive prefix in LDS (thread t owns strips [t*per, t*per+per))
-    const int per = (nstrips + kThreads - 1) / kThreads;
-    int mysum = 0;
-    for (int k = 0; k < per; ++k) {
-        const int cb = tid * per + k;
-        if (cb < nstrips) { int64_t ls; int c; strip_geom<RG>(cb, n, nloc, rank, world, ls, c); mysum += c; }
-    }
-    ssum[tid] = mysum;
-    __syncthreads();
-    for (int off = 1; off < kThreads; off <<= 1) {
-        const int v = tid >= off ? ssum[tid - off] : 0;
-        __syncthreads();
-        ssum[tid] += v;
-        __syncthreads();
-    }
-    {
-        int run = ssum[tid] - mysum;
-        for (int k = 0; k < per; ++k) {
-            const int cb = tid * per + k;
-            if (cb < nstrips) { int64_t ls; int c; strip_geom<RG>(cb, n, nloc, rank, world, ls, c); pref[cb] = run; run += c; }
-        }
-        if (tid == kThreads - 1) pref[nstrips] = ssum[tid];
-    }
-    __syncthreads();
+    // unit counts per strip -> exclusive prefix in LDS (one barrier; nj_dev.hpp)
+    strip_prefix_lds<RG>(pref, nstrips, n, nloc, rank, world);
     const int64_t utot = nstrips > 0 ? pref[nstrips] : 0;
     const int64_t ub = utot * blockIdx.x / gridDim.x, ue = utot * (blockIdx.x + 1) / gridDim.x;
 
@@ -498,6 +477,8 @@ static int nj_alloc_inner(NjBuffers& b, int64_t N, int rank, int world, hipStrea
         DPR_HIP(hipMalloc(&b.KA, vec * sizeof(uint64_t)));
         DPR_HIP(hipMalloc(&b.partials, sizeof(NjRecord) * kScanBlocks));
         DPR_HIP(hipMalloc(&b.recs, sizeof(NjRecord) * (size_t)(world > 1 ? world : 1)));
+        DPR_HIP(hipMalloc(&b.recs64, sizeof(NjsRec) * (size_t)(world > 1 ? world : 1)));
+        DPR_HIP(hipMemsetAsync(b.recs64, 0, sizeof(NjsRec) * (size_t)(world > 1 ? world : 1), s));
         // (at least 512 entries: the pruned scan's new-row blocks load entry threadIdx.x before they know the chunk count)
         const size_t xcnt = (size_t)((N + kThreads - 1) / kThreads + 1);
         DPR_HIP(hipMalloc(&b.xpart, sizeof(double) * (xcnt < 512 ? 512 : xcnt)));
@@ -533,7 +514,7 @@ void nj_free(NjBuffers& b)
 {
     njp_free(b.pr);
     njs_free_window(b);
-    void* ptrs[] = { b.D, b.U, b.Ur, b.KA, b.partials, b.recs, b.xpart, b.gath, b.slice, b.st,
+    void* ptrs[] = { b.D, b.U, b.Ur, b.KA, b.partials, b.recs, b.recs64, b.xpart, b.gath, b.slice, b.st,
                      b.log_x, b.log_y, b.log_bx, b.log_by };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -577,9 +558,11 @@ int nj_prepare(NjBuffers& b, hipStream_t s)
 }
 
 // scan tuning knobs (dpr_scan_tune): row-group size, non-temporal loads, grid size
-static int g_scan_rg = 16, g_scan_nt = 1, g_scan_grid = 2048;
-void nj_scan_config(int rg, int nt, int grid) { g_scan_rg = rg; g_scan_nt = nt; g_scan_grid = grid; }
-int nj_scan_grid() { return g_scan_grid > 0 ? g_scan_grid : 2048; }
+// (process-wide by the ABI's definition of dpr_scan_tune; atomics, so that a tuning call from one host thread and a launch
+//  from another context's thread are at least well-defined -- results never depend on them)
+static std::atomic<int> g_scan_rg{ 16 }, g_scan_nt{ 1 }, g_scan_grid{ 2048 };
+void nj_scan_config(int rg, int nt, int grid) { g_scan_rg.store(rg, std::memory_order_relaxed); g_scan_nt.store(nt, std::memory_order_relaxed); g_scan_grid.store(grid, std::memory_order_relaxed); }
+int nj_scan_grid() { const int g = g_scan_grid.load(std::memory_order_relaxed); return g > 0 ? g : 2048; }
 
 template <bool PROBE>
 static void scan_dispatch(NjBuffers& b, int64_t n, int64_t it, hipStream_t s)
@@ -597,13 +580,14 @@ static void scan_dispatch(NjBuffers& b, int64_t n, int64_t it, hipStream_t s)
 #define DPR_SCAN(RG, NT, FILT)                                                                                     \
     hipLaunchKernelGGL((nj_scan_kernel<PROBE, RG, NT, FILT>), dim3(grid), dim3(kThreads), lds, s, D, ld, b.st,     \
                        U, Ur, Ur, KA, KB, pos, b.xpart, n, it, b.rank, b.world, b.partials)
-    const int rg = g_scan_rg & 127;
-    const bool filt = (g_scan_rg & 128) != 0;   // bit 7 of the row-group knob selects the filtered update
+    const int rg_knob = g_scan_rg.load(std::memory_order_relaxed), nt_knob = g_scan_nt.load(std::memory_order_relaxed);
+    const int rg = rg_knob & 127;
+    const bool filt = (rg_knob & 128) != 0;   // bit 7 of the row-group knob selects the filtered update
     if (filt) {
-        if (g_scan_nt) { if (rg == 64) DPR_SCAN(64, true, true); else DPR_SCAN(16, true, true); }
+        if (nt_knob) { if (rg == 64) DPR_SCAN(64, true, true); else DPR_SCAN(16, true, true); }
         else { if (rg == 64) DPR_SCAN(64, false, true); else DPR_SCAN(16, false, true); }
     } else {
-        if (g_scan_nt) { if (rg == 64) DPR_SCAN(64, true, false); else DPR_SCAN(16, true, false); }
+        if (nt_knob) { if (rg == 64) DPR_SCAN(64, true, false); else DPR_SCAN(16, true, false); }
         else { if (rg == 64) DPR_SCAN(64, false, false); else DPR_SCAN(16, false, false); }
     }
 #undef DPR_SCAN

@@ -154,6 +154,19 @@ __device__ __forceinline__ double finish_ux(const double* __restrict__ xpart, in
     for (int64_t c = threadIdx.x; c < nchunk; c += kThreads) acc += xpart[c];
     return block_tree256(acc, s);
 }
+// The same value in every thread with three barriers instead of nine (the scan kernels run this prologue in each of their
+// 1 024 - 2 048 blocks): block_tree256_lane0 adds the same operand pairs at every level, thread 0 hands the sum out through
+// s[255], which nobody reads inside the tree after its second barrier.  `s` may be reused after the call.
+__device__ __forceinline__ double finish_ux_bcast(const double* __restrict__ xpart, int64_t n_prev, double* s)
+{
+    const int64_t nchunk = (n_prev + kThreads - 1) / kThreads;
+    double acc = 0.0;
+    for (int64_t c = threadIdx.x; c < nchunk; c += kThreads) acc += xpart[c];
+    const double r = block_tree256_lane0(acc, s);
+    if (threadIdx.x == 0) s[kThreads - 1] = r;
+    __syncthreads();
+    return s[kThreads - 1];
+}
 
 // block-wide reduction of `cnt` records to the winner (q, key, d); result in every thread
 __device__ __forceinline__ void reduce_records(const NjRecord* __restrict__ recs, int cnt, double& bq,
@@ -257,6 +270,37 @@ __device__ __forceinline__ void strip_geom(int64_t cb, int64_t n, int64_t nloc, 
     const int64_t lmin = shard_rows(min(c0 + 1, n), rank, world);  // owned rows with global index <= c0
     lstart = lmin / RG * RG;
     cnt = nloc > lstart ? (int)((nloc - lstart + RG - 1) / RG) : 0;
+}
+
+// Exclusive prefix of the strips' unit counts into LDS, pref[0 .. nstrips], pref[nstrips] = total: ONE barrier.  Wave 0
+// alone does it (lane l: strips l * per .. l * per + per - 1, a wave-level scan of the lanes' sums); round 3's version was a
+// 256-thread Hillis-Steele scan through LDS -- 17 barriers in every block of the scan grid, ~10 % of a rank's scan time
+// once a rank streams only an eighth of the triangle.
+template <int RG>
+__device__ __forceinline__ void strip_prefix_lds(int32_t* pref, int nstrips, int64_t n, int64_t nloc, int rank, int world)
+{
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const int per = (nstrips + 63) / 64;
+        int mysum = 0;
+        for (int k = 0; k < per; ++k) {
+            const int cb = lane * per + k;
+            if (cb < nstrips) { int64_t ls; int c; strip_geom<RG>(cb, n, nloc, rank, world, ls, c); mysum += c; }
+        }
+        int incl = mysum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        int run = incl - mysum;
+        for (int k = 0; k < per; ++k) {
+            const int cb = lane * per + k;
+            if (cb < nstrips) { int64_t ls; int c; strip_geom<RG>(cb, n, nloc, rank, world, ls, c); pref[cb] = run; run += c; }
+        }
+        if (lane == 63) pref[nstrips] = incl;
+    }
+    __syncthreads();
 }
 
 

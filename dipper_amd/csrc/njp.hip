@@ -36,6 +36,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
+#include <string>
 
 namespace dpr {
 
@@ -49,10 +50,26 @@ static int64_t njp_big_p()
     static const int64_t v = std::getenv("DPR_NJ_BIG_P") ? std::atoll(std::getenv("DPR_NJ_BIG_P")) : 40000;
     return v;
 }
+// Round 4: njp_post2_kernel (light test blocks, maxima of the previous launch) can serve the small shape too: its test blocks
+// are then ONE strip x 256 row groups (kNS = 1: ~250 blocks at 30 000 positions, every lane one unit).  Bit-exact (every NJ
+// test passes on it), but MEASURED SLOWER at 30 000 tips: 505 vs 475 ms -- its UM blocks (512 slots + 512 positions each, the
+// position part and the slot part one behind the other) end 7 us after the launch's first stamp where the fused kernel's
+// update blocks end after 4.2 (profiles/r4/phases_post2_small_shape_*.txt); the test blocks (4.0 - 5.4 us) are not what
+// bounds the launch.  Opt-in: DPR_NJP_SMALL=post2.
+static bool njp_post2_on()
+{
+    static const bool on = !(std::getenv("DPR_NJP_POST2") && std::atoi(std::getenv("DPR_NJP_POST2")) == 0);
+    return on;
+}
+static bool njp_small_post2()
+{
+    static const bool on = njp_post2_on() && std::getenv("DPR_NJP_SMALL") && std::string(std::getenv("DPR_NJP_SMALL")) == "post2";
+    return on;
+}
 static int njp_tg_small()
 {
-    static const int v = std::getenv("DPR_NJ_TG_SMALL") ? std::atoi(std::getenv("DPR_NJ_TG_SMALL")) : 64;
-    return v == 32 || v == 128 ? v : 64;
+    static const int v = std::getenv("DPR_NJ_TG_SMALL") ? std::atoi(std::getenv("DPR_NJ_TG_SMALL")) : (njp_small_post2() ? 256 : 64);
+    return v == 32 || v == 128 || v == 256 ? v : 64;
 }
 static int njp_tg(int64_t P) { return P < njp_big_p() ? njp_tg_small() : 256; }
 // Strips per test block.  In the small shape a test block is one strip x 64 row groups (the post kernel is a chain of
@@ -67,7 +84,7 @@ static int njp_big_ns()
     static const int v = std::getenv("DPR_NJ_BIG_NS") ? std::atoi(std::getenv("DPR_NJ_BIG_NS")) : kBigNS;
     return v == 2 ? v : kBigNS;
 }
-static int njp_ns(int64_t P) { return njp_tg(P) != 256 ? 1 : njp_big_ns(); }
+static int njp_ns(int64_t P) { return (njp_tg(P) != 256 || P < njp_big_p()) ? 1 : njp_big_ns(); }
 // strips that hold a valid unit for some group of the row block [g0, g0 + tg)
 __host__ __device__ inline int64_t njp_strips_of_rows(int64_t g0, int64_t tg, int64_t P)
 {
@@ -1045,7 +1062,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
         if (seed_is_unit && (int64_t)tid * sstride >= uvalid) cand.key = ~0ull;          // not written by this iteration's scan
         if (cand.key != ~0ull) {
             ci = (int64_t)(cand.pad & 0xffffffffull); cj = (int64_t)(cand.pad >> 32);
-            if (ci < P && cj < P) { sUa = Uc[ci]; sUb = Uc[cj]; } else ci = -1;
+            if (!(ci < P && cj < P)) ci = -1;
         }
     }
 #pragma unroll
@@ -1218,13 +1235,49 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
     double cmU = NINF;                                                 // lanes 0 .. 4 kNS - 1: one sub-strip of the cell each
     if (tid < 4 * kNS && (tid >> 2) < nsb) cmU = a.t2_cmax[par * SS4 + 4 * (cb0 + (tid >> 2)) + (tid & 3)];
     const double cmin = a.t2_cmin[tb];
+    // Seed bound.  Any live pair gives a valid upper bound of the next optimum, so not every record has to be re-evaluated:
+    // of each group of 16 lanes only the candidate with the smallest OLD q (pairs touching x or y left out) gathers its six
+    // values (two row sums, rows x / y at both ends) and is re-evaluated -- 16 candidates per block instead of 256.  Round 4:
+    // every block gathering the same 256 x 6 scattered words was ~70 % of the L2 requests of a post launch (673 k per launch
+    // at 30 000 tips) and what stretched its second round trip from 1.1 to 3.5 us; the iteration's minimum by old q is in
+    // the set by construction and a merge moves a q by ~1 / n of its size, so the bound hardly ever loosens
+    // (DPR_NJP_FLAGS bits 4-5: 0x10 one candidate per wave, 0x20 per 8 lanes, 0x30 all of them).
     double qc = PINF;
-    if (ci >= 0 && ci != px && cj != px && ci != py && cj != py) {
-        const double xa = rowx[ci], ya = rowy[ci], xb = rowx[cj], yb = rowy[cj];
-        const double ua = nj_unew(sUa, xa, ya, nj_val(xa, ya, d)) / r1;
-        const double ub = nj_unew(sUb, xb, yb, nj_val(xb, yb, d)) / r1;
-        const double qk = fmin((cand.d - ua) - ub, (cand.d - ub) - ua);
-        qc = qk == qk ? qk : qc;
+    {
+        const bool live = ci >= 0 && ci != px && cj != px && ci != py && cj != py;
+        const double oq = live ? cand.q : PINF;
+        const int sgm = (a.flags >> 4) & 3;
+        bool lead = live;
+        if (sgm != 3) {
+            double gmin = oq;
+            gmin = fmin(gmin, dpp_f64<kDppXor1>(gmin));
+            gmin = fmin(gmin, dpp_f64<kDppXor2>(gmin));
+            gmin = fmin(gmin, dpp_f64<kDppHalfMirror>(gmin));
+            if (sgm != 2) gmin = fmin(gmin, dpp_f64<kDppMirror>(gmin));
+            if (sgm == 1) gmin = fmin(fmin(readlane_f64(gmin, 0), readlane_f64(gmin, 16)), fmin(readlane_f64(gmin, 32), readlane_f64(gmin, 48)));
+            const int sgl = sgm == 1 ? 64 : sgm == 2 ? 8 : 16;                   // lanes per group
+            const unsigned long long hit = __builtin_amdgcn_ballot_w64(live & (oq == gmin));
+            const int gbase = lane & ~(sgl - 1);
+            const unsigned long long mine_g = (hit >> gbase) & (sgl == 64 ? ~0ull : ((1ull << sgl) - 1ull));
+            lead = live && mine_g != 0ull && (lane - gbase) == (int)__builtin_ctzll(mine_g);
+        }
+        if (lead) {
+            sUa = Uc[ci]; sUb = Uc[cj];
+            const double xa = rowx[ci], ya = rowy[ci], xb = rowx[cj], yb = rowy[cj];
+            const double ua = nj_unew(sUa, xa, ya, nj_val(xa, ya, d)) / r1;
+            const double ub = nj_unew(sUb, xb, yb, nj_val(xb, yb, d)) / r1;
+            const double qk = fmin((cand.d - ua) - ub, (cand.d - ub) - ua);
+            qc = qk == qk ? qk : qc;
+        }
+    }
+    // small shape (one strip per block): the unit bounds travel with this round trip -- waiting for the coarse decision first
+    // is a dependent round trip, and a block holds 8 KB of them
+    ulonglong2 um0[kNS], um1[kNS];
+#pragma unroll
+    for (int k = 0; k < kNS; ++k) { um0[k] = make_ulonglong2(0ull, 0ull); um1[k] = um0[k]; }
+    if (kNS == 1 && nsb > 0 && have_g && g >= 32 * (int64_t)cb0) {
+        const unsigned long long* up = a.umin + ((int64_t)cb0 * G16 + g) * 4;
+        um0[0] = *reinterpret_cast<const ulonglong2*>(up); um1[0] = *reinterpret_cast<const ulonglong2*>(up + 2);
     }
     qc = wave_fmin(qc);
     if (lane == 0) sseed[tid >> 6] = qc;
@@ -1273,13 +1326,13 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
         }
         NJP_STAMP(1, 4, false);
     }
-    ulonglong2 um0[kNS], um1[kNS];
+    if (kNS > 1) {
 #pragma unroll
-    for (int k = 0; k < kNS; ++k) {
-        um0[k] = make_ulonglong2(0ull, 0ull); um1[k] = um0[k];
-        if (k < nsb && have_g && g >= 32 * (int64_t)(cb0 + k)) {
-            const unsigned long long* up = a.umin + ((int64_t)(cb0 + k) * G16 + g) * 4;
-            um0[k] = *reinterpret_cast<const ulonglong2*>(up); um1[k] = *reinterpret_cast<const ulonglong2*>(up + 2);
+        for (int k = 0; k < kNS; ++k) {
+            if (k < nsb && have_g && g >= 32 * (int64_t)(cb0 + k)) {
+                const unsigned long long* up = a.umin + ((int64_t)(cb0 + k) * G16 + g) * 4;
+                um0[k] = *reinterpret_cast<const ulonglong2*>(up); um1[k] = *reinterpret_cast<const ulonglong2*>(up + 2);
+            }
         }
     }
     NJP_STAMP(1, 5, true);
@@ -1772,8 +1825,8 @@ static int njp_launch_scan(NjBuffers& b, hipStream_t s, int v, bool rows)
 
 static bool njp_use_post2(const NjPruned& q)
 {
-    static const bool on = !(std::getenv("DPR_NJP_POST2") && std::atoi(std::getenv("DPR_NJP_POST2")) == 0);
-    return on && njp_tg(q.P) == 256 && njp_ns(q.P) == kBigNS && (q.dbg == nullptr || q.dbg_it >= 0);
+    const int ns = njp_ns(q.P);
+    return njp_post2_on() && njp_tg(q.P) == 256 && (ns == kBigNS || (ns == 1 && njp_small_post2())) && (q.dbg == nullptr || q.dbg_it >= 0);
 }
 
 static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
@@ -1789,13 +1842,15 @@ static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
         const unsigned um = !update ? 0u : (u2 > (unsigned)a.nrb ? u2 : (unsigned)a.nrb);
         a.nupd = (int)um;
         if ((unsigned)a.ntest + um == 0u) return DPR_OK;
-        hipLaunchKernelGGL((njp_post2_kernel<kBigNS>), dim3((unsigned)a.ntest + um), dim3(kThreads), 0, s, a);
+        if (a.ns == 1) hipLaunchKernelGGL((njp_post2_kernel<1>), dim3((unsigned)a.ntest + um), dim3(kThreads), 0, s, a);
+        else hipLaunchKernelGGL((njp_post2_kernel<kBigNS>), dim3((unsigned)a.ntest + um), dim3(kThreads), 0, s, a);
         DPR_HIP(hipGetLastError());
         return DPR_OK;
     }
     if (a.tg == 64) hipLaunchKernelGGL((njp_post_kernel<64, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
     else if (a.tg == 32) hipLaunchKernelGGL((njp_post_kernel<32, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
     else if (a.tg == 128) hipLaunchKernelGGL((njp_post_kernel<128, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
+    else if (a.ns == 1) hipLaunchKernelGGL((njp_post_kernel<256, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
     else if (a.ns == 2) hipLaunchKernelGGL((njp_post_kernel<256, 2>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
     else hipLaunchKernelGGL((njp_post_kernel<256, kBigNS>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
     DPR_HIP(hipGetLastError());

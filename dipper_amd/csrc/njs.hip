@@ -24,6 +24,7 @@
 // (a rank that never answers makes the run end with DPR_ERR_COMM, not hang).
 #include "nj_dev.hpp"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace dpr {
@@ -49,7 +50,7 @@ __device__ __forceinline__ void st_sys_f64(double* p, double v) { __hip_atomic_s
 struct NjsArgs {
     double* D; int64_t ld; NjState* st;
     double* U; double* Ur; uint64_t* KA; double* xpart;
-    NjRecord* partials; NjRecord* recs;          // block records of the scan; gathered rank records (plan PEER)
+    NjRecord* partials; NjsRec* recs;            // block records of the scan; gathered rank records (plan PEER)
     unsigned int* ticket;
     char* const* win;                            // [world] every rank's window (own one included), valid in this process
     double* const* peerD;                        // [world] every rank's matrix rows
@@ -60,6 +61,7 @@ struct NjsArgs {
     int nparts;                                  // scan grid
     unsigned long long poll_ticks;               // bound of a mailbox poll (100 MHz wall clock)
     unsigned long long seq_base;                 // run id << 32: sequence numbers are unique across the runs of a context
+    int64_t fault_it; int fault_rank;            // test hook (DPR_NJS_FAULT=iteration,rank): that rank corrupts one pulled element there
     int32_t* log_x; int32_t* log_y; double* log_bx; double* log_by;
 };
 
@@ -67,7 +69,7 @@ __device__ __forceinline__ double* win_row(char* w, const NjsLayout& lay, int wh
 {
     return reinterpret_cast<double*>(w + lay.off_rows) + (int64_t)(which * 2 + parity) * lay.ldv;      // which: 0 = x row, 1 = y row
 }
-__device__ __forceinline__ NjRecord* win_mail(char* w, int parity, int r) { return reinterpret_cast<NjRecord*>(w) + parity * kNjsMaxWorld + r; }
+__device__ __forceinline__ NjsRec* win_mail(char* w, int parity, int r) { return reinterpret_cast<NjsRec*>(w) + parity * kNjsMaxWorld + r; }
 
 // row of slot a as it stands BEFORE merge `it` (see the header): pointer valid in this process, owner's memory
 __device__ __forceinline__ const double* row_view(const NjsArgs& a, int64_t slot, int64_t xp, int64_t yp)
@@ -93,7 +95,6 @@ __global__ __launch_bounds__(kThreads) void njs_scan_kernel(const double* __rest
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int32_t* pref = reinterpret_cast<int32_t*>(smem);
-    __shared__ int32_t ssum[kThreads];
     __shared__ double sd[kThreads];
     __shared__ double sq[kThreads / 64], sdd[kThreads / 64];
     __shared__ uint64_t sk[kThreads / 64];
@@ -107,11 +108,11 @@ __global__ __launch_bounds__(kThreads) void njs_scan_kernel(const double* __rest
     const bool dead = a.st->status != 0;
 
     int64_t xprev = -1;
-    double urx = 0.0;
+    double urx = 0.0, ux = 0.0;
     RowView rv;
     if (it > 0 && !dead) {
         xprev = a.st->x;
-        const double ux = finish_ux(a.xpart, n + 1, sd);
+        ux = finish_ux_bcast(a.xpart, n + 1, sd);
         urx = ux / (double)(n - 2);
         if (blockIdx.x == 0 && tid == 0) { a.U[xprev] = ux; a.Ur[xprev] = urx; }
         if (a.has_pending) {
@@ -124,29 +125,8 @@ __global__ __launch_bounds__(kThreads) void njs_scan_kernel(const double* __rest
     const int64_t nloc = shard_rows(n, rank, world);
     int nstrips = n > 1 ? (int)((n - 1 + kTileCols - 1) / kTileCols) : 0;
     if (dead) nstrips = 0;
-    const int per = (nstrips + kThreads - 1) / kThreads;
-    int mysum = 0;
-    for (int k = 0; k < per; ++k) {
-        const int cb = tid * per + k;
-        if (cb < nstrips) { int64_t ls; int c; strip_geom<RG>(cb, n, nloc, rank, world, ls, c); mysum += c; }
-    }
-    ssum[tid] = mysum;
-    __syncthreads();
-    for (int off = 1; off < kThreads; off <<= 1) {
-        const int v = tid >= off ? ssum[tid - off] : 0;
-        __syncthreads();
-        ssum[tid] += v;
-        __syncthreads();
-    }
-    {
-        int run = ssum[tid] - mysum;
-        for (int k = 0; k < per; ++k) {
-            const int cb = tid * per + k;
-            if (cb < nstrips) { int64_t ls; int c; strip_geom<RG>(cb, n, nloc, rank, world, ls, c); pref[cb] = run; run += c; }
-        }
-        if (tid == kThreads - 1) pref[nstrips] = ssum[tid];
-    }
-    __syncthreads();
+    // unit counts per strip -> exclusive prefix in LDS (one barrier; nj_dev.hpp)
+    strip_prefix_lds<RG>(pref, nstrips, n, nloc, rank, world);
     const int64_t utot = nstrips > 0 ? pref[nstrips] : 0;
     const int64_t ub = utot * blockIdx.x / gridDim.x, ue = utot * (blockIdx.x + 1) / gridDim.x;
     if (ub < ue) {
@@ -234,22 +214,29 @@ __global__ __launch_bounds__(kThreads) void njs_scan_kernel(const double* __rest
         if (dead) { wq = 10000.0; wk = ~0ull; wd = 0.0; }
         *a.ticket = 0u;                       // next launch (stream order)
     }
+    // the record also carries this rank's view of the replicated state (NjsRec: the row sum of the node of merge it - 1, bit
+    // for bit, and the rank's status), which POST compares across the ranks
+    const unsigned long long uxb = (unsigned long long)__double_as_longlong(ux);
+    const unsigned long long stw = (unsigned long long)(unsigned int)a.st->status;
     if (a.plan == kNjsMailbox) {
         // thread r sends the record to rank r's mailbox (own one included): data words, then the sequence word with
         // release semantics; the reader acquires on the sequence word
         if (tid == 0) { sq[0] = wq; sk[0] = wk; sdd[0] = wd; }
         __syncthreads();
         if (tid < world) {
-            NjRecord* m = win_mail(a.win[tid], (int)(it & 1), rank);
+            NjsRec* m = win_mail(a.win[tid], (int)(it & 1), rank);
             unsigned long long* w = reinterpret_cast<unsigned long long*>(m);
             st_sys_u64(w + 0, (unsigned long long)__double_as_longlong(sq[0]));
             st_sys_u64(w + 1, (unsigned long long)sk[0]);
             st_sys_u64(w + 2, (unsigned long long)__double_as_longlong(sdd[0]));
+            st_sys_u64(w + 4, uxb);
+            st_sys_u64(w + 5, stw);
             st_rel_u64(w + 3, a.seq_base + (unsigned long long)(it + 1));
         }
     } else if (tid == 0) {
-        NjRecord rec;
-        rec.q = wq; rec.key = wk; rec.d = wd; rec.pad = a.seq_base + (uint64_t)(it + 1);
+        NjsRec rec;
+        rec.q = wq; rec.key = wk; rec.d = wd; rec.seq = a.seq_base + (uint64_t)(it + 1);
+        rec.ux = uxb; rec.status = stw; rec.pad[0] = 0; rec.pad[1] = 0;
         a.recs[rank] = rec;
     }
 }
@@ -262,16 +249,20 @@ __global__ __launch_bounds__(kThreads) void njs_post_kernel(NjsArgs a)
     __shared__ double s[kThreads];
     __shared__ double s_q[kNjsMaxWorld], s_d[kNjsMaxWorld];
     __shared__ uint64_t s_k[kNjsMaxWorld];
-    __shared__ int s_fail;
+    __shared__ unsigned long long s_ux[kNjsMaxWorld];
+    __shared__ int s_fail, s_dead;
     const int tid = threadIdx.x;
     const int64_t n = a.n, it = a.it;
     const int rank = a.rank, world = a.world;
-    if (a.st->status != 0) return;
     if ((int64_t)blockIdx.x * kThreads >= n) return;
-    if (tid == 0) s_fail = 0;
+    // (one read per block: another block of this launch may be storing a failure status right now, and the waves of a
+    //  block must agree before the barriers below)
+    if (tid == 0) { s_fail = 0; s_dead = a.st->status != 0 ? 1 : 0; }
     __syncthreads();
+    if (s_dead) return;
     // ---- the G rank records of this iteration
     if (tid < world) {
+        unsigned long long their_status = 0ull;
         if (a.plan == kNjsMailbox) {
             const unsigned long long* w = reinterpret_cast<const unsigned long long*>(win_mail(a.win[rank], (int)(it & 1), tid));
             const unsigned long long t0 = wall_clock64();
@@ -280,21 +271,40 @@ __global__ __launch_bounds__(kThreads) void njs_post_kernel(NjsArgs a)
                 if (wall_clock64() - t0 > a.poll_ticks) { ok = false; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
-            if (!ok) s_fail = 1;
+            if (!ok) s_fail = 3;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // (compiler ordering only: the record words are loaded after the poll)
             s_q[tid] = __longlong_as_double((long long)__hip_atomic_load(w + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
             s_k[tid] = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             s_d[tid] = __longlong_as_double((long long)__hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+            s_ux[tid] = __hip_atomic_load(w + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            their_status = ok ? __hip_atomic_load(w + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
         } else {
             s_q[tid] = a.recs[tid].q; s_k[tid] = a.recs[tid].key; s_d[tid] = a.recs[tid].d;
-            if (a.recs[tid].pad != a.seq_base + (uint64_t)(it + 1)) s_fail = 1;       // a record of another iteration: the exchange did not happen
+            s_ux[tid] = a.recs[tid].ux;
+            their_status = a.recs[tid].status;
+            if (a.recs[tid].seq != a.seq_base + (uint64_t)(it + 1)) s_fail = 3;       // a record of another iteration: the exchange did not happen
         }
+        // a rank that has already failed says so in its record: fail the same way (not with "no candidate")
+        if (their_status == 3ull || their_status == 4ull) s_fail = (int)their_status;
     }
+    __syncthreads();
+    // every rank derived the row sum of the node of merge it - 1 from the rows it pulled: the words must agree bit for bit
+    if (tid < world && s_fail == 0 && s_ux[tid] != s_ux[rank]) s_fail = 4;
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * kThreads + tid;
     const int64_t last = n - 1;
     if (s_fail) {
-        if (i == last) a.st->status = 3;      // exchange failed (mailbox poll timed out / stale record): DPR_ERR_COMM
+        // 3: exchange failed (mailbox poll timed out / stale record); 4: the ranks' replicated row sums differ (a pulled
+        // row was stale or torn) -- both DPR_ERR_COMM; st->q / st->d keep the two words for the message
+        if (i == last) {
+            a.st->status = s_fail;
+            if (s_fail == 4) {
+                int other = 0;
+                for (int r = 0; r < world; ++r) if (s_ux[r] != s_ux[rank]) { other = r; break; }
+                a.st->q = __longlong_as_double((long long)s_ux[rank]); a.st->d = __longlong_as_double((long long)s_ux[other]);
+                a.st->x = rank; a.st->y = other;
+            }
+        }
         return;
     }
     double bq = 10000.0, d = 0.0;
@@ -325,7 +335,9 @@ __global__ __launch_bounds__(kThreads) void njs_post_kernel(NjsArgs a)
     double val = 0.0;
     if (i == last) commit_merge(a.st, a.U, n, it, x, y, d, bq, a.log_x, a.log_y, a.log_bx, a.log_by);   // reads U[y] before the tail rewrites it
     if (i < n && i != x && i != y) {
-        const double dxi = ld_sys_f64(rowx + i), dyi = ld_sys_f64(rowy + i);
+        double dxi = ld_sys_f64(rowx + i);
+        const double dyi = ld_sys_f64(rowy + i);
+        if (it == a.fault_it && rank == a.fault_rank && tid == 7 && blockIdx.x == 0) dxi = dxi * 0.5 + 1.0e-3;      // test hook: a "stale" pull
         val = (dxi + dyi - d) * 0.5;
         if (i != last) {
             const double u = a.U[i] + (-dxi - dyi + val);
@@ -378,8 +390,11 @@ __global__ __launch_bounds__(kThreads) void njs_post_kernel(NjsArgs a)
 __global__ __launch_bounds__(kThreads) void njs_finish_kernel(NjsArgs a)
 {
     __shared__ double s[kThreads];
+    __shared__ int s_dead;
     const int64_t n = a.n, it = a.it;      // state after `it` iterations, n active
-    if (a.st->status != 0 || it <= 0) return;
+    if (threadIdx.x == 0) s_dead = a.st->status != 0 ? 1 : 0;      // (block-uniform, as in njs_post_kernel)
+    __syncthreads();
+    if (s_dead || it <= 0) return;
     const int64_t xp = a.st->x, yp = a.st->y;
     if (blockIdx.x == 0) {
         const double ux = finish_ux(a.xpart, n + 1, s);
@@ -430,7 +445,7 @@ NjsLayout njs_layout(int64_t N, int world)
     const int64_t nblk = (N + kRowBlock - 1) / kRowBlock;
     l.slice_len = ((nblk + world - 1) / world) * kRowBlock;
     l.ldv = (N + kTileCols + 16 + 15) / 16 * 16;
-    l.off_bar = (int64_t)sizeof(NjRecord) * 2 * kNjsMaxWorld;                 // mail: [2][kNjsMaxWorld] records
+    l.off_bar = (int64_t)sizeof(NjsRec) * 2 * kNjsMaxWorld;                   // mail: [2][kNjsMaxWorld] records
     l.off_slice = l.off_bar + 64 * kNjsMaxWorld;                              // bar: one 64-byte line per rank
     l.off_rows = (l.off_slice + (int64_t)sizeof(double) * l.slice_len + 255) / 256 * 256;
     l.bytes = l.off_rows + (int64_t)sizeof(double) * 4 * l.ldv;
@@ -441,7 +456,7 @@ static NjsArgs njs_args(NjBuffers& b, int64_t n, int64_t it, bool pending)
 {
     NjsArgs a;
     a.D = b.D; a.ld = b.ld; a.st = b.st; a.U = b.U; a.Ur = b.Ur; a.KA = b.KA; a.xpart = b.xpart;
-    a.partials = b.partials; a.recs = b.recs; a.ticket = b.peer.ticket;
+    a.partials = b.partials; a.recs = b.recs64; a.ticket = b.peer.ticket;
     a.win = b.peer.d_win; a.peerD = b.peer.d_D; a.lay = b.peer.lay;
     a.n = n; a.it = it; a.has_pending = pending ? 1 : 0;
     a.rank = b.rank; a.world = b.world; a.plan = b.peer.plan;
@@ -452,6 +467,7 @@ static NjsArgs njs_args(NjBuffers& b, int64_t n, int64_t it, bool pending)
     a.nparts = env_grid >= 64 && env_grid <= kScanBlocks ? env_grid : (b.world >= 4 ? 1024 : nj_scan_grid());
     a.poll_ticks = b.peer.poll_ticks;
     a.seq_base = b.peer.run_id << 32;
+    a.fault_it = b.peer.fault_it; a.fault_rank = b.peer.fault_rank;
     a.log_x = b.log_x; a.log_y = b.log_y; a.log_bx = b.log_bx; a.log_by = b.log_by;
     return a;
 }
@@ -507,6 +523,15 @@ int njs_alloc_window(NjBuffers& b, hipStream_t s)
 {
     NjPeer& p = b.peer;
     const NjsLayout lay = njs_layout(b.N, b.world);
+    {
+        // DPR_NJS_FAULT=iteration,rank: that rank corrupts one element of a pulled row at that iteration (tests of the
+        // cross-check: the run must end with DPR_ERR_COMM one iteration later, on every rank, with both plans)
+        p.fault_it = -1; p.fault_rank = -1;
+        if (const char* e = std::getenv("DPR_NJS_FAULT")) {
+            long long fi = -1; int fr = -1;
+            if (std::sscanf(e, "%lld,%d", &fi, &fr) == 2) { p.fault_it = fi; p.fault_rank = fr; }
+        }
+    }
     if (p.win && p.lay.bytes == lay.bytes) {
         // Reuse (same shape again): nothing in the window is cleared -- another rank may already be ahead of this one and
         // writing into it.  Mail sequence numbers carry the run id, barrier epochs only grow, the slice and the row
@@ -543,8 +568,9 @@ void njs_free_window(NjBuffers& b)
     if (p.d_D) (void)hipFree(p.d_D);
     const int plan = p.plan;
     const unsigned long long ticks = p.poll_ticks;
+    const int64_t fi = p.fault_it; const int fr = p.fault_rank;
     p = NjPeer();
-    p.plan = plan; p.poll_ticks = ticks;
+    p.plan = plan; p.poll_ticks = ticks; p.fault_it = fi; p.fault_rank = fr;
 }
 
 // pointers of all ranks as seen from this process: wins[r], Ds[r] (host arrays of `world` entries)

@@ -13,8 +13,11 @@
  *   - the caller owns every host buffer; the library owns all device memory of a dpr_ctx.
  *   - one dpr_ctx drives ONE GPU from ONE host thread at a time.  Multi-GPU = one process (and one
  *     ctx) per GPU, joined by dpr_comm_init(); the N x N matrix is then sharded by rows
- *     (block-cyclic, DPR_ROW_BLOCK rows) and the NJ loop exchanges one record and three column
- *     slices per iteration over RCCL.
+ *     (block-cyclic, DPR_ROW_BLOCK rows).  The row-sharded NJ loop has three exchange plans
+ *     (dpr_ctx_set_nj_exchange): legacy = two RCCL all-gathers per iteration (one record, three column
+ *     slices; the default until the others have been validated on a multi-GPU node), peer = ONE
+ *     all-gather of the rank records, rows x / y pulled from their owners' memory, mailbox = no
+ *     collective at all (records stored straight into every rank's mailbox over xGMI).
  *   - nothing here falls back to the CPU: without a usable gfx950 device dpr_create() fails.
  */
 #ifndef DIPPER_HIP_H
@@ -148,8 +151,10 @@ int64_t dpr_nj_run(dpr_ctx *ctx, int64_t max_iters, int32_t *merge_x, int32_t *m
 
 /* ---- single Q-argmin at the CURRENT active size (findMinDist + thrust::min_element,
  * src/neighborJoining.cu:117-148,214).  Returns the reference's winning ordered tuple (i,j,q).
- * reps>1 repeats the scan kernel `reps` times (kernel symbol nj_scan_probe) and reports the
- * average duration measured with HIP events on the library's stream; used for the roofline. */
+ * reps>1 repeats the scan kernel `reps` times (kernel symbol dpr::nj_scan_kernel<true,16,true,false>:
+ * the production streaming scan; the first template flag only tags probe launches in profiles,
+ * the code is the same) and reports the average duration measured with HIP events on the library's stream;
+ * used for the roofline. */
 int dpr_argmin_once(dpr_ctx *ctx, int reps, int32_t *out_i, int32_t *out_j, double *out_q,
                     float *out_ms_per_scan);
 
@@ -182,10 +187,14 @@ int dpr_ctx_set_nj_multi_plan(dpr_ctx *ctx, int plan);
 int dpr_ctx_set_nj_adaptive(dpr_ctx *ctx, int on);
 int dpr_get_nj_adaptive_stats(dpr_ctx *ctx, int64_t *stream_iterations, int64_t *stream_epochs);
 /* Exchange plan of the ROW-SHARDED streaming NJ loop (several ranks, DPR_NJ_MODE=stream / dpr_ctx_set_nj_mode(ctx, 0);
- * replaces src/neighborJoining.cu:211-243): 0 = legacy (4 launches + 2 all-gathers per iteration), 1 = peer (default:
- * 2 launches + ONE all-gather of the rank records; rows x / y are pulled from their owners' memory), 2 = mailbox
- * (2 launches, no collective: the records go straight into every rank's mailbox); -1 = DPR_NJ_EXCHANGE / default.
- * A plan that cannot be set up on every rank falls back to 0 on all ranks together (note in dpr_get_nj_exchange_info). */
+ * replaces src/neighborJoining.cu:211-243): 0 = legacy (4 launches + 2 all-gathers per iteration; the DEFAULT since round 4:
+ * the other two have only run on one device so far), 1 = peer (2 launches + ONE all-gather of the rank records; rows x / y are
+ * pulled from their owners' memory), 2 = mailbox (2 launches, no collective: the records go straight into every rank's
+ * mailbox); -1 = DPR_NJ_EXCHANGE (legacy | peer | mailbox) / default.
+ * A plan that cannot be set up on every rank falls back to 0 on all ranks together (note in dpr_get_nj_exchange_info).
+ * Plans 1 and 2 check themselves every iteration: each rank's record carries the bits of the row sum it derived from the rows
+ * it pulled (replicated state: identical on every rank by construction) and its status; a differing word, a record of another
+ * iteration or a poll that times out ends dpr_nj_run with DPR_ERR_COMM on every rank. */
 int dpr_ctx_set_nj_exchange(dpr_ctx *ctx, int plan);
 /* what the last dpr_dist_matrix set up (*active_plan, note) and what the last dpr_nj_run enqueued on this rank */
 int dpr_get_nj_exchange_info(dpr_ctx *ctx, int *active_plan, int64_t *launches, int64_t *collectives, char *note, int cap);

@@ -34,6 +34,18 @@ def main():
         d.set_matrix_full(D)
         d.dist_matrix(capi.SRC_MATRIX)
     info0 = d.nj_exchange_info()
+    if os.environ.get("DPR_NJS_FAULT"):
+        # tests of the cross-check: the run must END with DPR_ERR_COMM on every rank (the message names the row sums)
+        try:
+            d.nj_run()
+            verdict = "no error"
+        except capi.DipperError as e:
+            verdict = "code %d: %s" % (e.code, e)
+        np.savez(out, verdict=verdict, plan=info0["plan"])
+        d.close()
+        sys.stdout.write("done\n")
+        sys.stdout.flush()
+        return
     first = d.nj_run(max_iters=3)          # a resumed run: barrier + flush between the calls
     k = first["iters"]
     res = d.nj_run()

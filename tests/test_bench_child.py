@@ -46,3 +46,30 @@ def test_child_silence_is_bounded():
     ch.p.kill()
     ch.close()
     assert ch.p.poll() is not None
+
+
+def test_scaling_summary_sits_behind_roofline_and_labels_rccl():
+    """the compact `nj_iteration_scaling` object (north_star's scaling metric) comes right behind `roofline` in the bench line,
+    carries `ranks` and `rccl` separately (a run joined without RCCL must not be reported as rccl_ranks) and leaves the contract's
+    `scaling` string alone"""
+    sys.path.insert(0, ROOT)
+    import bench
+    out = {"metric": "m", "value": 1.0, "scaling": "weak", "roofline": {"frac": 0.7}, "parity_check": {}, "nj_scaling": {
+        "tips": 30000, "iterations_timed": 256, "streaming_one_gpu": {"nj_iterations_per_s": 1000.0}, "default_plan_one_gpu": {"nj_iterations_per_s": 60000.0},
+        "row_sharded": {"legacy": {"nj_iterations_per_s": 3000.0, "iteration_speedup_vs_one_gpu": 3.0, "ranks": 8, "rccl": True, "rccl_ranks": 8,
+                                   "matches_single_gpu": True, "launches_per_iteration": 4.0, "collectives_per_iteration": 2.0},
+                        "mailbox": {"nj_iterations_per_s": 5000.0, "iteration_speedup_vs_one_gpu": 5.0, "ranks": 2, "rccl": False, "matches_single_gpu": True,
+                                    "launches_per_iteration": 2.0, "collectives_per_iteration": 0.0},
+                        "peer": {"error": "child said nothing for 30 s (killed)"}}}}
+    new = bench.with_scaling_summary(dict(out), 8)
+    keys = list(new)
+    assert keys.index("nj_iteration_scaling") == keys.index("roofline") + 1
+    assert new["scaling"] == "weak"
+    comp = new["nj_iteration_scaling"]
+    assert comp["streaming_one_gpu_its_per_s"] == 1000.0 and comp["default_plan_one_gpu_its_per_s"] == 60000.0 and comp["n_gpus"] == 8
+    assert comp["row_sharded"]["legacy"] == {"its_per_s": 3000.0, "speedup_vs_streaming_one_gpu": 3.0, "ranks": 8, "rccl": True, "matches_single_gpu": True,
+                                             "launches_per_iteration": 4.0, "collectives_per_iteration": 2.0}
+    assert comp["row_sharded"]["mailbox"]["rccl"] is False and comp["row_sharded"]["mailbox"]["ranks"] == 2
+    assert comp["row_sharded"]["peer"] == {"error": "child said nothing for 30 s (killed)"}
+    # no nj_scaling leg (skipped by the budget): the line is returned unchanged
+    assert bench.with_scaling_summary({"roofline": {}, "nj_scaling": {"skipped": "budget"}}, 1) == {"roofline": {}, "nj_scaling": {"skipped": "budget"}}

@@ -15,9 +15,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_ranks(tmp_path, world, n, seed, source="matrix", timeout=240):
+def _run_ranks(tmp_path, world, n, seed, source="matrix", timeout=240, extra_env=None):
     procs = []
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.update(extra_env or {})
     for r in range(world):
         procs.append(subprocess.Popen([sys.executable, "-m", "tests._njs_worker", str(r), str(world), str(n), str(seed),
                                        str(tmp_path / ("r%d.npz" % r)), source], cwd=ROOT, env=env, stdin=subprocess.PIPE,
@@ -51,6 +52,18 @@ def test_process_ranks_on_one_gpu_match_oracle(tmp_path, orc, world, n):
         for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
             assert np.array_equal(got[key], ref[key]), (r, key)
         assert float(got["last_d"]) == ref["last_d"]
+
+
+@pytest.mark.timeout(600)
+def test_process_ranks_detect_a_corrupted_pull(tmp_path):
+    """DPR_NJS_FAULT=40,1: rank 1 of 3 corrupts one element of a row it pulled at iteration 40.  Its replicated row sums
+    then differ from the other ranks'; every rank's record carries the bits of the row sum it derived (NjsRec::ux), so
+    POST(41) sees the difference on EVERY rank and all three runs end with DPR_ERR_COMM (-5) instead of three merge logs
+    of which one is silently wrong."""
+    res = _run_ranks(tmp_path, 3, 400, 7, extra_env={"DPR_NJS_FAULT": "40,1"})
+    for got in res:
+        v = str(got["verdict"])
+        assert v.startswith("code -5") and "row sums differ after 41 iterations" in v, v
 
 
 @pytest.mark.timeout(600)

@@ -88,6 +88,32 @@ def test_virtual_ranks_interrupted_runs_and_ties(orc, plan):
             d.close()
 
 
+@pytest.mark.parametrize("plan", ["peer", "mailbox"])
+def test_virtual_ranks_detect_a_corrupted_pull(monkeypatch, plan):
+    """the cross-check of the one-exchange plans (NjsRec::ux, njs.hip): DPR_NJS_FAULT=25,2 makes virtual rank 2 of 4 use a
+    wrong value for one element of a pulled row at iteration 25; the ranks' replicated row sums differ from then on and the
+    run ends with DPR_ERR_COMM at iteration 26 -- while the same run without the fault completes."""
+    import dipper_amd
+    from dipper_amd import capi
+    D = _util.random_additive_matrix(np.random.default_rng(3), 300, zero_frac=0.2)
+    for fault in (None, "25,2"):
+        if fault:
+            monkeypatch.setenv("DPR_NJS_FAULT", fault)
+        d = dipper_amd.Dipper(0, virtual_world=4)
+        try:
+            d.set_nj_exchange(PLANS[plan])
+            d.set_matrix_full(D)
+            d.dist_matrix(capi.SRC_MATRIX)
+            if fault is None:
+                assert d.nj_run()["iters"] == 298
+            else:
+                with pytest.raises(capi.DipperError) as ei:
+                    d.nj_run()
+                assert ei.value.code == -5 and "row sums differ after 26 iterations" in str(ei.value)
+        finally:
+            d.close()
+
+
 def test_virtual_ranks_msa(orc):
     import dipper_amd
     from dipper_amd import capi

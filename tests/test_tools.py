@@ -55,6 +55,31 @@ def test_gen_synth_outputs_agree_and_do_not_depend_on_threads(tmp_path, orc):
     assert all(1e-3 <= length[v] <= 1e-1 for v in length)
 
 
+def test_gen_synth_gap_fraction(tmp_path, orc):
+    """--gap-frac: about that fraction of the cells become '-', every other cell and the tree are the gap-free run's, the
+    4-bit words carry code 4 there (src/fourBitCompressor.cpp:33-35), and the output does not depend on the thread count"""
+    n, L = 300, 3000
+    out = {}
+    for tag, extra in (("plain", []), ("gaps", ["--gap-frac", "0.03"]), ("gaps5", ["--gap-frac", "0.03", "--threads", "5"])):
+        base = str(tmp_path / tag)
+        subprocess.run([GEN, "--tips", str(n), "--sites", str(L), "--seed", "9", "--mean-bl", "1e-3", "--lo", "1e-4", "--hi", "1e-2",
+                        "--fasta", base + ".fa", "--packed4", base + ".p4", "--tree", base + ".nwk"] + extra, check=True)
+        out[tag] = {k: open(base + k, "rb").read() for k in (".fa", ".p4", ".nwk")}
+    assert out["gaps"] == out["gaps5"]
+    assert out["gaps"][".nwk"] == out["plain"][".nwk"]
+    _, plain = _fasta(str(tmp_path / "plain.fa"))
+    names, gaps = _fasta(str(tmp_path / "gaps.fa"))
+    a = np.frombuffer(b"".join(plain), dtype=np.uint8)
+    b = np.frombuffer(b"".join(gaps), dtype=np.uint8)
+    isgap = b == ord("-")
+    assert 0.02 < isgap.mean() < 0.04
+    assert np.array_equal(a[~isgap], b[~isgap])
+    per_tip = isgap.reshape(n, L).mean(axis=1)
+    assert (per_tip > 0).mean() > 0.98 and per_tip.max() < 0.12        # (nearly) every tip has gaps, none is mostly gaps
+    packed = np.frombuffer(out["gaps"][".p4"], dtype=np.uint64).reshape(n, (L + 15) // 16)
+    assert np.array_equal(packed, orc.pack4_many(gaps))
+
+
 def test_gen_synth_reads_with_indels(tmp_path, orc):
     n, L = 200, 2000
     base = str(tmp_path / "r")
@@ -131,3 +156,15 @@ def test_nrf_ignores_the_root(tmp_path):
     open(tmp_path / "other.nwk", "w").write("((A:1,C:1):1,((B:1,D:1):1,E:1):1);\n")
     got = _nrf(str(tmp_path / "f0.nwk"), str(tmp_path / "other.nwk"))
     assert got["rf"] == 4 and got["nrf"] == 1.0
+
+
+def test_nrf_rejects_labels_outside_the_tree(tmp_path):
+    """malformed / truncated Newick (a label with no enclosing parentheses, text before the first '(') must end in a
+    diagnostic and exit code 1, not in an out-of-bounds write (advisor, round 3)"""
+    ok = tmp_path / "ok.nwk"
+    ok.write_text("((T1:1,T2:1):1,T3:2);\n")
+    for text in ("T1:0.1;\n", "x((T1:1,T2:1):1,T3:2);\n", "((T1:1,T2:1):1,T3:2);(T1,T2);\n"):
+        bad = tmp_path / "bad.nwk"
+        bad.write_text(text)
+        r = subprocess.run([NRF, str(bad), str(ok)], capture_output=True, text=True)
+        assert r.returncode == 1 and r.stderr.startswith("nrf: "), (text, r.returncode, r.stderr)

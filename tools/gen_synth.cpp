@@ -12,7 +12,15 @@
 // and the ranks of a multi-GPU bench map the files.
 //
 //   gen_synth --tips N --sites L [--seed S] [--mean-bl m --lo a --hi b] [--indel INS,DEL[,MEANLEN]] [--shuffle SEED]
-//             [--threads T] [--fasta out.fa] [--packed4 out.u64] [--packed2 prefix] [--tree out.nwk] [--order out.i32]
+//             [--gap-frac F[,MEANRUN]] [--threads T] [--fasta out.fa] [--packed4 out.u64] [--packed2 prefix] [--tree out.nwk]
+//             [--order out.i32]
+//
+// --gap-frac F (aligned output only; round 4): what the authors' indel model leaves in an ALIGNMENT -- '-' cells.  Two
+// sources: deletions on branches at the authors' rate (0.09 per substitution, geometric lengths, `--indel`'s numbers), which
+// every descendant inherits, and -- these alone would be ~1e-4 of the cells at the protocol's branch lengths -- per-tip runs of
+// '-' (Poisson number, geometric length, mean MEANRUN = 10) up to an expected fraction F of every tip, so that the
+// not-a-base plane of the distance kernel (src/MSA.cu:103-156: `useful`, `match`) does work at bench size.  Gap cells are
+// code 4 in the 4-bit packing (src/fourBitCompressor.cpp:33-35) and '-' in the FASTA.  F = 0 leaves every output byte as before.
 //
 // Tip names are T<k+1> with k the tip's index in the generating tree's creation order (the true tree uses the same
 // names).  Output order = creation order, or a seeded permutation of it (--shuffle; --order writes the permutation:
@@ -89,6 +97,7 @@ struct Args {
     double mean_bl = 2e-5, lo = 2e-6, hi = 2e-4;
     bool indels = false;
     double ins = 0.03, del = 0.09, indel_mean = 2.0;
+    double gap_frac = 0.0, gap_run = 10.0;
     bool shuffle = false;
     uint64_t shuffle_seed = 0;
     int threads = 0;
@@ -154,7 +163,7 @@ Tree yule(int64_t n, const Args& a)
     return t;
 }
 
-using Seq = std::vector<uint8_t>;      // codes 0..3
+using Seq = std::vector<uint8_t>;      // codes 0..3; 4 = gap (aligned output with --gap-frac)
 
 void evolve(const Seq& src, Seq& dst, double bl, uint64_t node, const Args& a)
 {
@@ -163,7 +172,20 @@ void evolve(const Seq& src, Seq& dst, double bl, uint64_t node, const Args& a)
     const uint64_t k = r.poisson((double)dst.size() * bl);
     for (uint64_t i = 0; i < k; ++i) {
         const size_t p = (size_t)r.below(dst.size());
-        dst[p] = (uint8_t)((dst[p] + 1 + r.below(3)) & 3);
+        const uint8_t nb = (uint8_t)((dst[p] + 1 + r.below(3)) & 3);
+        if (dst[p] < 4) dst[p] = nb;          // a deleted site stays deleted
+    }
+    if (!a.indels && a.gap_frac > 0.0) {
+        // aligned output: a deletion on this branch is a run of gap cells that every descendant inherits (own generator:
+        // the substitution stream above is the same with and without gaps)
+        Rng rg(a.seed, node, 7);
+        const double pg = 1.0 / (a.indel_mean > 1.0 ? a.indel_mean : 1.0);
+        const uint64_t nd = rg.poisson((double)dst.size() * bl * a.del);
+        for (uint64_t i = 0; i < nd; ++i) {
+            const uint64_t m = rg.geometric(pg);
+            const size_t p0 = (size_t)rg.below(dst.size());
+            for (size_t j = p0; j < dst.size() && j < p0 + m; ++j) dst[j] = 4;
+        }
     }
     if (!a.indels) return;
     const double pg = 1.0 / (a.indel_mean > 1.0 ? a.indel_mean : 1.0);
@@ -287,6 +309,13 @@ int main(int argc, char** argv)
             while (n < 3 && p <= v.size()) { const size_t q = v.find(',', p); x[n++] = std::atof(v.substr(p, q - p).c_str()); if (q == std::string::npos) break; p = q + 1; }
             a.ins = x[0]; a.del = x[1]; a.indel_mean = x[2];
         }
+        else if (k == "--gap-frac") {
+            const std::string v = val();
+            a.gap_frac = std::atof(v.c_str());
+            const size_t q = v.find(',');
+            if (q != std::string::npos) a.gap_run = std::atof(v.substr(q + 1).c_str());
+            if (!(a.gap_frac >= 0.0 && a.gap_frac < 0.9) || !(a.gap_run >= 1.0)) die("--gap-frac F[,MEANRUN]: 0 <= F < 0.9, MEANRUN >= 1");
+        }
         else if (k == "--shuffle") { a.shuffle = true; a.shuffle_seed = std::strtoull(val(), nullptr, 10); }
         else if (k == "--threads") a.threads = std::atoi(val());
         else if (k == "--fasta") a.fasta = val();
@@ -296,12 +325,13 @@ int main(int argc, char** argv)
         else if (k == "--order") a.order = val();
         else if (k == "-h" || k == "--help") {
             std::fprintf(stderr, "usage: gen_synth --tips N --sites L [--seed S] [--mean-bl m --lo a --hi b] [--indel INS,DEL[,MEANLEN]] [--shuffle SEED]\n"
-                                 "                 [--threads T] [--fasta f] [--packed4 f] [--packed2 prefix] [--tree f] [--order f]\n");
+                                 "                 [--gap-frac F[,MEANRUN]] [--threads T] [--fasta f] [--packed4 f] [--packed2 prefix] [--tree f] [--order f]\n");
             return 0;
         } else die("unknown argument " + k);
     }
     if (a.tips < 2 || a.sites < 1) die("--tips >= 2 and --sites >= 1 are required");
     if (a.indels && !a.packed4.empty()) die("--packed4 needs aligned output (no --indel)");
+    if (a.indels && a.gap_frac > 0.0) die("--gap-frac is for aligned output (no --indel)");
     const int64_t N = a.tips, L = a.sites;
     const int T = a.threads > 0 ? a.threads : host_threads();
 
@@ -365,9 +395,18 @@ int main(int argc, char** argv)
         fa_bytes = off;
         mfa.open_rw(a.fasta, fa_bytes);
     }
-    static const char kBase[4] = { 'A', 'C', 'G', 'T' };
+    static const char kBase[5] = { 'A', 'C', 'G', 'T', '-' };
     auto emit = [&](int32_t tip, Seq& s) {
         const size_t p = (size_t)pos[(size_t)tip];
+        if (aligned && a.gap_frac > 0.0) {       // this tip's own runs of missing cells
+            Rng rg(a.seed, (uint64_t)tip, 8);
+            const uint64_t nr = rg.poisson(a.gap_frac * (double)s.size() / a.gap_run);
+            for (uint64_t i = 0; i < nr; ++i) {
+                const uint64_t m = rg.geometric(1.0 / a.gap_run);
+                const size_t p0 = (size_t)rg.below(s.size());
+                for (size_t j = p0; j < s.size() && j < p0 + m; ++j) s[j] = 4;
+            }
+        }
         if (m4.p) pack4_row(s, (uint64_t*)m4.p + p * W4, W4);
         if (mfa.p) {
             char* o = (char*)mfa.p + fa_off[p];

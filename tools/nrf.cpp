@@ -77,7 +77,10 @@ Parsed parse(const std::string& s)
     bool after_close = false;
     while (i < n) {
         const char c = s[i];
-        if (c == '(') { st.push_back(add()); ++i; after_close = false; }
+        if (c == '(') {
+            if (st.empty() && !t.parent.empty()) die("a second tree (or text) behind the first one");      // node 0 is THE root
+            st.push_back(add()); ++i; after_close = false;
+        }
         else if (c == ',') { ++i; after_close = false; }
         else if (c == ')') { if (st.empty()) die("unbalanced ')'"); st.pop_back(); ++i; after_close = true; }
         else if (c == ':') { ++i; while (i < n && s[i] != ',' && s[i] != ')' && s[i] != '(' && s[i] != ';') ++i; }
@@ -87,6 +90,9 @@ Parsed parse(const std::string& s)
             if (c == '\'') { j = s.find('\'', i + 1); if (j == std::string::npos) die("unterminated quote"); ++j; }
             else while (j < n && s[j] != ':' && s[j] != ',' && s[j] != '(' && s[j] != ')' && s[j] != ';') ++j;
             if (!after_close) {         // a tip label (labels behind ')' name internal nodes: ignored)
+                // a label outside every '(' would get parent -1 and the sums below would index hsum[-1]: truncated or
+                // malformed output of the command under test must end in a diagnostic, not in an out-of-bounds write
+                if (st.empty()) die("label outside the tree (input without enclosing parentheses, or text before '(')");
                 const int32_t v = add();
                 t.hsum[(size_t)v] = name_hash(s.data() + i, j - i);
                 t.cnt[(size_t)v] = 1;
