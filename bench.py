@@ -363,6 +363,9 @@ def main():
     ap.add_argument("--deadline-s", type=float, default=float(os.environ.get("DPR_BENCH_DEADLINE_S", "500")),
                     help="optional legs are skipped when they would not finish this many seconds after process start "
                          "(the driver allows 600 s); a watchdog ends the run 60 s later, non-zero")
+    ap.add_argument("--add-backbone", type=int, default=500000)
+    ap.add_argument("--add-queries", type=int, default=50000)
+    ap.add_argument("--no-add-leg", action="store_true", help="skip other_configs' configs[4] legs (--add of 50 000 queries onto 500 000 tips, aligned and Mash)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cli", action="store_true",
                     help="skip the command-line steps: `value` is then the in-process hot path (used when profiling the kernels)")
@@ -876,9 +879,67 @@ def other_configs(args, local_rank, stage, budget, tmp):
             out["nrf_vs_generating_tree"] = nrf_of(inp["tree"], _util.newick_from_placement(names, st["head"], st["e"], st["nxt"], st["len"], n, fmt=repr), tmp, "dc1m")
         return out
 
+    def add_onto_backbone(kind):
+        """BASELINE configs[4]: 50 000 queries added to a 500 000-tip backbone (src/placement_close_k.cu:858-990 addQuery,
+        :126-264 initializeDeviceArrays) through the `dipper` command itself -- the backbone tree is the command's own
+        divide-and-conquer tree of the first 500 000 records (untimed set-up), the timed step is
+        `dipper -a -t backbone.nwk -I all.fa`.  kind "m": aligned input (-i m -d 2), "r": unaligned reads through Mash (-i r)."""
+        m, nq = args.add_backbone, args.add_queries
+        n = m + nq
+        L = 1000 if kind == "m" else 3000
+        inp = stage.gen("add_%s" % kind, n, L, args.seed + (10 if kind == "m" else 11), 1e-3, 1e-4, 1e-2, fasta=True, reads=(kind == "r"), shuffle=7,
+                        gap=args.gap_frac if kind == "m" else 0.0)
+        fa_all = inp["fasta"]
+        # the first m records as their own file (the backbone's tips)
+        buf = np.memmap(fa_all, dtype=np.uint8, mode="r")
+        starts = np.flatnonzero(buf == ord(">"))
+        cut = int(starts[m])
+        fa_bb = os.path.join(tmp, "bb_%s.fa" % kind)
+        with open(fa_bb, "wb") as f:
+            f.write(buf[:cut].tobytes())
+        del buf, starts
+        bb_nwk, out_nwk = os.path.join(tmp, "bb_%s.nwk" % kind), os.path.join(tmp, "add_%s.nwk" % kind)
+        env = dict(os.environ, DPR_HOST_THREADS=str(host_cores()))
+        fmt = ["-i", kind] + (["-d", "2"] if kind == "m" else [])
+        t0 = time.perf_counter()
+        r = subprocess.run([EXE] + fmt + ["-m", "3", "-I", fa_bb, "-O", bb_nwk, "--device", str(local_rank)], capture_output=True, text=True, env=env)
+        t_bb = time.perf_counter() - t0
+        if r.returncode != 0:
+            raise RuntimeError("dipper (backbone) failed: " + r.stderr[-300:])
+        t0 = time.perf_counter()
+        r = subprocess.run([EXE] + fmt + ["-a", "-t", bb_nwk, "-I", fa_all, "-O", out_nwk, "--device", str(local_rank)], capture_output=True, text=True, env=env)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            raise RuntimeError("dipper --add failed: " + r.stderr[-300:])
+        ph = {}
+        for line in r.stderr.splitlines():          # the command's progress lines (the reference prints the same ones, src/placement_close_k.cu:985-986)
+            for key, tag in (("input_ms", "Input in:"), ("tree_ms", "Tree Created in:"), ("distance_ms", "Distance Operation Time"), ("tree_op_ms", "Tree Operation Time"),
+                             ("sketch_ms", "Sketch Created in:")):
+                if line.startswith(tag):
+                    try:
+                        ph[key] = float(line[len(tag):].replace(":", " ").split()[0])
+                    except Exception:
+                        pass
+        out = {"workload": "configs[4] on one GPU: %d queries added to a %d-tip backbone, %s; the whole `dipper -a -t backbone.nwk` command "
+                           "(FASTA of all %d records in, Newick out)" % (nq, m, "aligned x %d sites, -d 2" % L if kind == "m" else "unaligned reads x ~%d bases through Mash" % L, n),
+               "backbone": m, "queries": nq, "seconds": wall, "queries_per_s": nq / wall, "phases_ms": ph,
+               "placement_s": ph.get("tree_ms", float("nan")) * 1e-3,
+               "setup_untimed": {"backbone_tree_by_dc_s": t_bb, "fasta_bytes": os.path.getsize(fa_all)}}
+        for f in (fa_bb,):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+        if budget.allows(40):
+            out["nrf_vs_generating_tree"] = nrf_of(inp["tree"], out_nwk, tmp, "add_%s" % kind)
+        return out
+
     leg("nj_100k", nj_100k, 30)
     leg("place_100k_unaligned", place_100k_unaligned, 25)
     leg("dc_1m", dc_1m, 30)
+    if not args.no_add_leg:
+        leg("add_50k_onto_500k_aligned", lambda: add_onto_backbone("m"), 45)
+        leg("add_50k_onto_500k_mash", lambda: add_onto_backbone("r"), 75)
     return rec
 
 

@@ -79,6 +79,7 @@ def load_library():
     L.dpr_nj_kernel_name.restype = C.c_char_p
     L.dpr_get_place_timing.argtypes = [C.c_void_p, c_f64p, c_f64p]
     L.dpr_get_place_overlap.argtypes = [C.c_void_p, C.POINTER(C.c_int), c_f64p]
+    L.dpr_get_place_policy.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.dpr_get_prune_stats.argtypes = [C.c_void_p, c_u64p, c_u64p]
     L.dpr_bw_probe.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.dpr_set_msa.argtypes = [C.c_void_p, c_u64p, C.c_int64, C.c_int64]
@@ -442,6 +443,13 @@ class Dipper:
         b = C.c_double()
         _chk(self.L, self.L.dpr_get_place_overlap(self.h, C.byref(o), C.byref(b)))
         return bool(o.value), b.value
+
+    def place_policy(self):
+        """(batches, batches produced beside the previous batch's tree kernels) of the last placement run"""
+        a = C.c_int64()
+        b = C.c_int64()
+        _chk(self.L, self.L.dpr_get_place_policy(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     # ---- hooks ------------------------------------------------------------------------------------
     def n_active(self):

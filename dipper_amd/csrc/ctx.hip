@@ -85,7 +85,9 @@ struct dpr_ctx {
     std::vector<hipEvent_t> place_ev;   // event pairs whose sum is the reported distance part of the current placement run
     std::vector<hipEvent_t> place_ev_busy;   // overlap mode: event pairs around the distance batches on the second stream
     double place_dist_busy_ms = 0;      // overlap mode: time the distance batches were in flight beside the tree kernels
-    bool place_overlapped = false;
+    bool place_overlapped = false;      // some batch of the last placement run was produced beside the tree kernels
+    std::vector<hipEvent_t> place_ev_tree;   // per-batch event pairs around the tree kernels (the overlap policy's probes)
+    int64_t place_batches = 0, place_batches_overlapped = 0;      // of the last placement run
     dpr::DcStats dc_stats;
     double dc_ms[3] = { 0, 0, 0 };   // backbone, cluster assignment, cluster trees
     // plan knobs of THIS context (dpr_ctx_set_*); -1 = follow the process-wide default (dpr_set_* / environment)
@@ -535,6 +537,7 @@ int dpr_destroy(dpr_ctx* c)
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     for (hipEvent_t e : c->place_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->place_ev_busy) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->place_ev_tree) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->nj_kt.ev) (void)hipEventDestroy(e);
     for (auto& b : c->nj) nj_free(b);
     msa_free(c->msa);
@@ -1162,7 +1165,11 @@ int dpr_get_prune_stats(dpr_ctx* c, uint64_t* units_scanned, uint64_t* units_per
     if (!c || !c->have_matrix || !c->nj[0].pr.active) { set_error("dpr_get_prune_stats: pruned path not active"); return DPR_ERR_STATE; }
     NjState st;
     if (int rc = fetch_state(c, &st)) return rc;
-    if (units_scanned) *units_scanned = st.units_scanned;
+    if (units_scanned) {
+        unsigned long long tot = 0;
+        if (int rc = njp_units_scanned(c->nj[0], &tot)) return rc;      // (state counter + the per-block counters of the cells mode)
+        *units_scanned = tot;
+    }
     if (units_per_full_scan) *units_per_full_scan = (uint64_t)c->nj[0].pr.utot0;
     return DPR_OK;
 }
@@ -1261,6 +1268,49 @@ int dpr_launch_bench(dpr_ctx* c, int nlaunch, int grid, int use_graph, float* us
     if (g_keep) (void)hipGraphDestroy(g_keep);
     (void)hipFree(buf);
     return rc_marks;
+}
+
+// measurement aid (round 4): a background load on a stream of its own -- `blocks` workgroups of 64 threads spin on FMAs until
+// dpr_spin_stop sets the flag or `max_ms` of the 100 MHz wall clock have passed (every wave reaches that exit).  Used to find out
+// whether the latency-bound loops run at reduced clocks when the chip is otherwise idle (profiles/nj_target.py --spin).
+__global__ void dpr_spin_kernel(const unsigned int* flag, unsigned long long max_ticks, double* sink)
+{
+    const unsigned long long t0 = wall_clock64();
+    double x = 1.0 + threadIdx.x * 1e-9, y = 0.999999;
+    for (;;) {
+#pragma unroll
+        for (int k = 0; k < 256; ++k) x = x * y + 1e-12;
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
+        if (wall_clock64() - t0 > max_ticks) break;
+    }
+    if (x == 12345.678) *sink = x;
+}
+static hipStream_t g_spin_stream = nullptr;
+static unsigned int* g_spin_flag = nullptr;      // host-pinned, device-visible
+static double* g_spin_sink = nullptr;
+int dpr_spin_start(dpr_ctx* c, int blocks, int max_ms)
+{
+    if (!c || blocks < 1 || blocks > 4096 || max_ms < 1 || max_ms > 60000) { set_error("dpr_spin_start: bad argument"); return DPR_ERR_ARG; }
+    DPR_HIP(hipSetDevice(c->device));
+    if (!g_spin_stream) {
+        int least = 0, greatest = 0;
+        DPR_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        DPR_HIP(hipStreamCreateWithPriority(&g_spin_stream, hipStreamNonBlocking, least));
+        DPR_HIP(hipHostMalloc(reinterpret_cast<void**>(&g_spin_flag), sizeof(unsigned int), hipHostMallocMapped));
+        DPR_HIP(hipMalloc(&g_spin_sink, sizeof(double)));
+    }
+    *g_spin_flag = 0u;
+    hipLaunchKernelGGL(dpr_spin_kernel, dim3((unsigned)blocks), dim3(64), 0, g_spin_stream, (const unsigned int*)g_spin_flag,
+                       (unsigned long long)max_ms * 100000ull, g_spin_sink);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+int dpr_spin_stop(dpr_ctx* c)
+{
+    if (!c || !g_spin_stream) { set_error("dpr_spin_stop: not started"); return DPR_ERR_STATE; }
+    *g_spin_flag = 1u;
+    DPR_HIP(hipStreamSynchronize(g_spin_stream));
+    return DPR_OK;
 }
 
 // tuning hook: row-group size (16/32/64), non-temporal loads (0/1), scan grid (<= 2048; 0 = default)
@@ -1385,22 +1435,33 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
     const bool sharded = c->world > 1 && c->vworld == 0 && c->comm != nullptr && source != DPR_SRC_MATRIX;
     const int W = sharded ? c->world : 1;
     const int64_t per = (R + W - 1) / W;         // rows per rank and batch
-    // The distance rows of the NEXT batch are produced on a second stream while the tree kernels of the current batch
-    // run (they are latency-bound and occupy two workgroups; the pair kernels fill the rest of the chip): two row
-    // buffers, the producer waits for the batch that last read the buffer it overwrites.
-    // (Mash input only: 5 000 000 000 pair distances against 1.8 s of tree kernels at 100 000 tips -- 5.02 -> 3.81 s; with
-    // aligned input the distance part is 4 % of the run and the contention costs more than it hides: 1.63 -> 1.82 s)
-    const bool overlap = source == DPR_SRC_MASH && !std::getenv("DPR_PLACE_NO_OVERLAP");
+    // The distance rows of the NEXT batch may be produced on a second stream while the tree kernels of the current batch run
+    // (they are latency-bound and occupy a few workgroups; the pair kernels fill the rest of the chip): two row buffers, the
+    // producer waits for the batch that last read the buffer it overwrites.  Mash input only: with aligned input the distance part
+    // is 4 % of the run and the contention costs more than it hides (1.63 -> 1.82 s at 100 000 tips).
+    // Round 4: the decision is taken PER BATCH.  Overlap pays while a batch's distance part is the SHORTER one -- it then
+    // disappears behind the tree kernels (100 000 unaligned tips from scratch: 3.2 -> 2.5 s).  Where it is the longer one
+    // nothing can hide it, and sharing the chip slows both sides: adding 50 000 queries to a 500 000-tip backbone, every batch is
+    // 5 x 10^8 pairs (~100 ms alone) against ~50 ms of tree kernels; overlapped, the pair kernel ran at half its rate and the
+    // update kernel 5.6 x slower (profiles/r3/kernel_stats_add_mash_500k_plus_50k.csv): 9.2 s where back to back is 7.6 s.
+    // So: batch k + 1 is produced beside batch k's tree kernels iff its predicted time alone (pairs / the rate measured on this
+    // run's batches that ran alone, 4.5 G pairs/s until there is one) is below the tree time of a batch as last measured on
+    // a batch that ran alone (batch 0 always does); otherwise it is produced on the main stream right before its own tips, at
+    // full chip.  The host waits for batch k - 1 before it decides about batch k + 1 (it never runs more than one batch ahead
+    // of the device any more; enqueueing is ~10 x faster than the tree kernels execute, so the device does not starve).
+    // Results cannot depend on the policy: the rows are the same numbers whichever stream produced them.
+    const bool overlap_allowed = source == DPR_SRC_MASH && !std::getenv("DPR_PLACE_NO_OVERLAP");
+    const bool overlap_always = overlap_allowed && std::getenv("DPR_PLACE_OVERLAP_ALWAYS") != nullptr;      // round 3's policy (A / B runs)
     double* rows_buf[2] = { nullptr, nullptr };
     const size_t row_bytes = sizeof(double) * (size_t)(per * W * ldb);
     if (source != DPR_SRC_MATRIX) {
         DPR_HIP(hipMalloc(&rows_buf[0], row_bytes));
-        if (overlap) {
+        if (overlap_allowed) {
             const hipError_t me = hipMalloc(&rows_buf[1], row_bytes);
             if (me != hipSuccess) { (void)hipFree(rows_buf[0]); return hip_fail(me, "hipMalloc(second row buffer)"); }
         }
     }
-    if (overlap && !c->stream2) {
+    if (overlap_allowed && !c->stream2) {
         // lowest priority: the distance kernels fill the chip, the tree kernels of the current batch (one wavefront or a few
         // blocks each, on the context's stream) must not queue behind them
         int least = 0, greatest = 0;
@@ -1414,8 +1475,6 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
             DPR_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, least));
         }
     }
-    hipStream_t ds = overlap ? c->stream2 : c->stream;          // stream of the distance kernels
-    c->mash.share_chip = overlap;
     std::vector<hipEvent_t> sync_ev;                             // fill-done / tree-done events of this run
     auto new_event = [&](hipEvent_t* e) -> int { DPR_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming)); sync_ev.push_back(*e); return DPR_OK; };
     auto row_ptr = [&](int64_t i, int64_t i0, const double* rows) -> const double* {
@@ -1427,7 +1486,7 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
         if (source == DPR_SRC_MASH) return mash_dist_rows(c->mash, i0, nr, 0, 0, false, i0 + nr, out, ldb, st);
         return DPR_OK;
     };
-    auto fill_rows_inner = [&](int64_t i0, int64_t nr, double* rows) -> int {
+    auto fill_rows_inner = [&](int64_t i0, int64_t nr, double* rows, hipStream_t ds) -> int {
         if (!sharded) return fill_some(i0, nr, rows, ds);
         const int64_t a = (int64_t)c->rank * per, b = a + per < nr ? a + per : nr;     // this rank's rows of the batch
         if (int rc = fill_some(i0 + a, b - a, rows + a * ldb, ds)) return rc;
@@ -1438,22 +1497,27 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
         return DPR_OK;
     };
     // the reference reports the distance and the tree part of a placement run separately
-    // (src/placement_close_k.cu:852-853,985-986): an event pair around every distance batch, summed by the caller
-    // Overlap mode: the batches run on the second stream BESIDE the tree kernels, so their own intervals overlap the tree
-    // work in wall time (and stretch while they share the chip) -- they are kept as `busy` time; what is reported as the
-    // distance part is the time the tree stream actually WAITED for a batch (event pairs around its waits below), so
-    // distance + tree = the run's wall time again.
-    c->place_overlapped = overlap;
-    auto fill_rows = [&](int64_t i0, int64_t nr, double* rows) -> int {
+    // (src/placement_close_k.cu:852-853,985-986).  A batch produced on the main stream: an event pair around it (c->place_ev).
+    // A batch produced beside the tree kernels: its own interval overlaps the tree work in wall time (and stretches while it
+    // shares the chip) -- kept as `busy` time (c->place_ev_busy); what counts as distance time is the time the tree stream
+    // actually WAITED for it (an event pair around the wait, c->place_ev), so distance + tree = the run's wall time again.
+    c->place_overlapped = false;
+    c->place_batches = 0; c->place_batches_overlapped = 0;
+    auto fill_rows = [&](int64_t i0, int64_t nr, double* rows, bool beside, hipEvent_t* t0, hipEvent_t* t1) -> int {
+        hipStream_t ds = beside ? c->stream2 : c->stream;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (source != DPR_SRC_MATRIX) {
             DPR_HIP(hipEventCreate(&e0)); DPR_HIP(hipEventCreate(&e1));
-            std::vector<hipEvent_t>& dst = overlap ? c->place_ev_busy : c->place_ev;
+            std::vector<hipEvent_t>& dst = beside ? c->place_ev_busy : c->place_ev;
             dst.push_back(e0); dst.push_back(e1);
             DPR_HIP(hipEventRecord(e0, ds));
         }
-        const int rc = fill_rows_inner(i0, nr, rows);
+        c->mash.share_chip = beside;
+        const int rc = fill_rows_inner(i0, nr, rows, ds);
+        c->mash.share_chip = false;
         if (e1) DPR_HIP(hipEventRecord(e1, ds));
+        if (t0) *t0 = e0;
+        if (t1) *t1 = e1;
         return rc;
     };
     auto run = [&]() -> int {
@@ -1466,33 +1530,37 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
         }
         if (first >= last) return DPR_OK;
         hipEvent_t filled[2] = { nullptr, nullptr }, consumed[2] = { nullptr, nullptr };
-        if (overlap) {
-            // the first batch overwrites buffer 0, which the initial tree just read on the main stream
-            hipEvent_t e;
-            if (int rc = new_event(&e)) return rc;
-            DPR_HIP(hipEventRecord(e, c->stream));
-            DPR_HIP(hipStreamWaitEvent(ds, e, 0));
-        }
+        bool ahead = false;                       // the rows of the batch about to be placed were produced beside the previous batch
+        // policy state: what a batch that ran alone cost
+        double tree_ms_per_tip = -1.0, pairs_per_ms = 4.5e6;
+        struct Probe { hipEvent_t d0, d1, t0, t1; double pairs; int64_t nr; bool dist_alone, tree_alone; };
+        std::vector<Probe> probes;                // one per batch
+        size_t harvested = 0;
+        auto batch_pairs = [&](int64_t i0, int64_t nr) { return (double)nr * ((double)i0 + 0.5 * (double)(nr - 1)); };
+        auto harvest = [&](size_t upto) -> int {  // read the timings of the batches < upto (host waits for the last of them)
+            for (; harvested < upto; ++harvested) {
+                Probe& pr = probes[harvested];
+                if (!pr.t1) continue;
+                DPR_HIP(hipEventSynchronize(pr.t1));
+                float ms = 0;
+                if (pr.tree_alone && hipEventElapsedTime(&ms, pr.t0, pr.t1) == hipSuccess && pr.nr > 0) tree_ms_per_tip = (double)ms / (double)pr.nr;
+                if (pr.dist_alone && pr.d0 && pr.d1 && pr.pairs >= 5.0e7 && hipEventElapsedTime(&ms, pr.d0, pr.d1) == hipSuccess && ms > 0.0f)
+                    pairs_per_ms = pr.pairs / (double)ms;
+            }
+            return DPR_OK;
+        };
         int64_t i0 = first;
         int cur = 0;
-        {
-            const int64_t nr = last - i0 < R ? last - i0 : R;
-            if (int rc = fill_rows(i0, nr, rows_buf[0])) return rc;
-            if (overlap) { if (int rc = new_event(&filled[0])) return rc; DPR_HIP(hipEventRecord(filled[0], ds)); }
-        }
-        for (; i0 < last; i0 += R, cur ^= 1) {
+        for (size_t k = 0; i0 < last; i0 += R, cur ^= 1, ++k) {
             const int64_t nr = last - i0 < R ? last - i0 : R;
             const int64_t j0 = i0 + R;
-            if (overlap && j0 < last) {          // next batch into the other buffer, once its last reader is done
-                const int nb = cur ^ 1;
-                if (consumed[nb]) DPR_HIP(hipStreamWaitEvent(ds, consumed[nb], 0));
-                const int64_t nr2 = last - j0 < R ? last - j0 : R;
-                if (int rc = fill_rows(j0, nr2, rows_buf[nb])) return rc;
-                if (int rc = new_event(&filled[nb])) return rc;
-                DPR_HIP(hipEventRecord(filled[nb], ds));
-            }
-            double* rows = rows_buf[overlap ? cur : 0];
-            if (overlap) {
+            double* rows = rows_buf[overlap_allowed ? cur : 0];
+            Probe pr{ nullptr, nullptr, nullptr, nullptr, batch_pairs(i0, nr), nr, false, true };
+            if (!ahead) {
+                // this batch's rows on the main stream, at full chip (a buffer's last reader ran on this stream: ordered)
+                if (int rc = fill_rows(i0, nr, rows, false, &pr.d0, &pr.d1)) return rc;
+                pr.dist_alone = true;
+            } else {
                 hipEvent_t w0 = nullptr, w1 = nullptr;
                 DPR_HIP(hipEventCreate(&w0)); DPR_HIP(hipEventCreate(&w1));
                 c->place_ev.push_back(w0); c->place_ev.push_back(w1);
@@ -1500,14 +1568,51 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
                 DPR_HIP(hipStreamWaitEvent(c->stream, filled[cur], 0));
                 DPR_HIP(hipEventRecord(w1, c->stream));
             }
-            else if (i0 > first) { if (int rc = fill_rows(i0, nr, rows)) return rc; }
+            ++c->place_batches;
+            // the next batch beside this batch's tree kernels?
+            bool next_ahead = false;
+            if (overlap_allowed && j0 < last) {
+                const int64_t nr2 = last - j0 < R ? last - j0 : R;
+                if (overlap_always) next_ahead = true;
+                else {
+                    if (k >= 1) { if (int rc = harvest(k)) return rc; }      // batches 0 .. k-1 (the host waits for batch k-1 here)
+                    const double dist_alone_ms = batch_pairs(j0, nr2) / pairs_per_ms;
+                    // (no tree timing yet -- this is batch 0: its successor is produced alone too, unless its distance part is tiny)
+                    next_ahead = tree_ms_per_tip > 0.0 ? dist_alone_ms < tree_ms_per_tip * (double)nr : dist_alone_ms < 1.0;
+                }
+                if (next_ahead) {
+                    const int nb = cur ^ 1;
+                    if (consumed[nb]) DPR_HIP(hipStreamWaitEvent(c->stream2, consumed[nb], 0));
+                    else {
+                        // (first use of that buffer by the second stream: everything enqueued so far may still read it)
+                        hipEvent_t e;
+                        if (int rc = new_event(&e)) return rc;
+                        DPR_HIP(hipEventRecord(e, c->stream));
+                        DPR_HIP(hipStreamWaitEvent(c->stream2, e, 0));
+                    }
+                    if (int rc = fill_rows(j0, nr2, rows_buf[nb], true, nullptr, nullptr)) return rc;
+                    if (int rc = new_event(&filled[nb])) return rc;
+                    DPR_HIP(hipEventRecord(filled[nb], c->stream2));
+                    c->place_overlapped = true;
+                    ++c->place_batches_overlapped;
+                    pr.tree_alone = false;
+                }
+            }
+            if (source != DPR_SRC_MATRIX) {
+                DPR_HIP(hipEventCreate(&pr.t0)); DPR_HIP(hipEventCreate(&pr.t1));
+                c->place_ev_tree.push_back(pr.t0); c->place_ev_tree.push_back(pr.t1);
+                DPR_HIP(hipEventRecord(pr.t0, c->stream));
+            }
             if (source == DPR_SRC_MATRIX) {      // packed triangle: rows are not evenly spaced
                 for (int64_t i = i0; i < i0 + nr; ++i)
                     if (int rc = place_tip(p, row_ptr(i, i0, rows), i, c->place_trace, c->stream)) return rc;
             } else {
                 if (int rc = place_tips(p, rows, ldb, i0, nr, c->place_trace, c->stream)) return rc;
             }
-            if (overlap) { if (int rc = new_event(&consumed[cur])) return rc; DPR_HIP(hipEventRecord(consumed[cur], c->stream)); }
+            if (pr.t1) DPR_HIP(hipEventRecord(pr.t1, c->stream));
+            if (overlap_allowed) { if (int rc = new_event(&consumed[cur])) return rc; DPR_HIP(hipEventRecord(consumed[cur], c->stream)); }
+            probes.push_back(pr);
+            ahead = next_ahead;
         }
         return DPR_OK;
     };
@@ -1515,7 +1620,7 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
     c->mash.share_chip = false;
     if (rows_buf[0] || rows_buf[1]) {
         (void)hipStreamSynchronize(c->stream);
-        if (overlap) (void)hipStreamSynchronize(c->stream2);
+        if (c->stream2) (void)hipStreamSynchronize(c->stream2);
         for (double* q : rows_buf) if (q) (void)hipFree(q);
     }
     for (hipEvent_t e : sync_ev) (void)hipEventDestroy(e);
@@ -1537,6 +1642,7 @@ static void place_collect_dist_ms(dpr_ctx* c)
     };
     c->place_dist_ms = sum(c->place_ev);
     c->place_dist_busy_ms = sum(c->place_ev_busy);
+    (void)sum(c->place_ev_tree);       // (the policy's probes; released here)
 }
 
 // dist_ms: the part of the run the tree kernels could not proceed for want of distance rows (without overlap: the
@@ -1556,6 +1662,16 @@ int dpr_get_place_overlap(dpr_ctx* c, int* overlapped, double* dist_busy_ms)
     if (!c) { set_error("dpr_get_place_overlap: null ctx"); return DPR_ERR_ARG; }
     if (overlapped) *overlapped = c->place_overlapped ? 1 : 0;
     if (dist_busy_ms) *dist_busy_ms = c->place_overlapped ? c->place_dist_busy_ms : 0.0;
+    return DPR_OK;
+}
+
+// batches of the last placement run and how many of them were produced beside the previous batch's tree kernels (the per-batch
+// overlap policy of place_range)
+int dpr_get_place_policy(dpr_ctx* c, int64_t* batches, int64_t* overlapped_batches)
+{
+    if (!c) { set_error("dpr_get_place_policy: null ctx"); return DPR_ERR_ARG; }
+    if (batches) *batches = c->place_batches;
+    if (overlapped_batches) *overlapped_batches = c->place_batches_overlapped;
     return DPR_OK;
 }
 

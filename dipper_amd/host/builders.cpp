@@ -339,7 +339,11 @@ static void printPlaceTiming(DeviceContext& dev)
     dpr_get_place_overlap(dev.ctx, &overlapped, &busy_ms);
     std::cerr << "Distance Operation Time " << (long long)dist_ms << " ms\n";
     std::cerr << "Tree Operation Time " << (long long)tree_ms << " ms\n";
-    if (overlapped) std::cerr << "Distance batches overlapped with tree operations: " << (long long)busy_ms << " ms in flight\n";
+    if (overlapped) {
+        int64_t batches = 0, beside = 0;
+        dpr_get_place_policy(dev.ctx, &batches, &beside);
+        std::cerr << "Distance batches overlapped with tree operations: " << beside << " of " << batches << ", " << (long long)busy_ms << " ms in flight\n";
+    }
 }
 
 void KPlacementDeviceArrays::findPlacementTree(DeviceContext& dev, Param& params)

@@ -222,6 +222,10 @@ int dpr_get_prune_stats(dpr_ctx *ctx, uint64_t *units_scanned, uint64_t *units_p
 /* microbenchmark: microseconds per launch of a chain of `nlaunch` trivial dependent kernels of `grid`
  * blocks on the context's stream, eager (0) or hipGraph replay of 128-node chains (1) */
 int dpr_launch_bench(dpr_ctx *ctx, int nlaunch, int grid, int use_graph, float *us_per_launch);
+/* measurement aid: a background load of `blocks` 64-thread workgroups spinning on FMAs on a stream of its own until
+ * dpr_spin_stop (or max_ms at the latest) -- to see whether the latency-bound loops run at reduced clocks on an idle chip */
+int dpr_spin_start(dpr_ctx *ctx, int blocks, int max_ms);
+int dpr_spin_stop(dpr_ctx *ctx);
 /* debug, needs DPR_NJ_ITERSTATS=1: per iteration {units scanned, most units scanned by one block} */
 int dpr_get_iterstats(dpr_ctx *ctx, uint64_t *out, int64_t iters);
 
@@ -266,6 +270,11 @@ int dpr_get_place_timing(dpr_ctx *ctx, double *dist_ms, double *tree_ms);
 /* *overlapped = 1 if the last placement run computed its distance rows beside the tree kernels; *dist_busy_ms = time the
  * distance batches were in flight then (concurrent with tree work: not a summand of the wall time); 0 / 0.0 otherwise */
 int dpr_get_place_overlap(dpr_ctx *ctx, int *overlapped, double *dist_busy_ms);
+/* The overlap decision is taken per batch of distance rows (1 024 tips for Mash input): a batch is produced beside the tree
+ * kernels of the previous one only while its distance part is the shorter of the two (src/placement_close_k.cu:756-851 computes
+ * one row per tip, serially).  *batches / *overlapped_batches of the last placement run.  DPR_PLACE_NO_OVERLAP=1: never,
+ * DPR_PLACE_OVERLAP_ALWAYS=1: round 3's policy (every batch).  Results do not depend on it. */
+int dpr_get_place_policy(dpr_ctx *ctx, int64_t *batches, int64_t *overlapped_batches);
 
 /* ---- exact placement mode: PlacementDeviceArrays::{allocateDeviceArrays,findPlacementTree}
  * (src/placement.cu:17-117,508-789), reached in the reference through `-m 0` with 30000 <= n < 1000000

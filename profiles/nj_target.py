@@ -22,6 +22,8 @@ ap.add_argument("--reps", type=int, default=1)
 ap.add_argument("--mode", default="pruned")
 ap.add_argument("--phases", type=int, default=None)
 ap.add_argument("--json", default=None)
+ap.add_argument("--clocks", type=float, default=0.0, help="seconds into the NJ loop at which `rocm-smi --showclocks` is sampled (0 = not)")
+ap.add_argument("--spin", type=int, default=0, help="background load while the NJ loop runs: this many 64-thread workgroups spinning on FMAs (dpr_spin_start)")
 ap.add_argument("--no-torch", action="store_true",
                 help="do not import torch first.  With torch imported the process runs on the HIP runtime bundled with PyTorch (7.0), as bench.py "
                      "does; without it on /opt/rocm's 7.2 -- where rocprofv3 --kernel-trace segfaults inside the first hipGraphLaunch of the "
@@ -63,11 +65,31 @@ d.set_msa(packed, args.sites)
 out = []
 for rep in range(args.reps):
     d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+    if args.spin > 0:
+        import ctypes as C
+        L_ = capi.load_library()
+        L_.dpr_spin_start.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L_.dpr_spin_stop.argtypes = [C.c_void_p]
+        assert L_.dpr_spin_start(d.h, args.spin, 20000) == 0
+    clocks = {}
+    if args.clocks:
+        import threading, time as _t
+        def _peek():
+            _t.sleep(args.clocks)
+            r = subprocess.run(["rocm-smi", "--showclocks"], capture_output=True, text=True)
+            clocks["during_nj"] = [l.strip() for l in r.stdout.splitlines() if "clk" in l.lower() and "GPU[0]" in l]
+        th = threading.Thread(target=_peek); th.start()
     res = d.nj_run(max_iters=args.iters)
+    if args.clocks:
+        th.join()
+    if args.spin > 0:
+        assert L_.dpr_spin_stop(d.h) == 0
     dist_ms, nj_ms = d.timing()
-    rec = {"tips": args.tips, "sites": args.sites, "gap_frac": args.gap_frac, "mode": args.mode, "rep": rep, "iters": int(res["iters"]), "dist_ms": dist_ms, "nj_ms": nj_ms,
+    rec = {"tips": args.tips, "sites": args.sites, "gap_frac": args.gap_frac, "spin_blocks": args.spin, "mode": args.mode, "rep": rep, "iters": int(res["iters"]), "dist_ms": dist_ms, "nj_ms": nj_ms,
            "us_per_iteration": nj_ms * 1e3 / max(int(res["iters"]), 1), "units_listed": d.prune_stats()[0] if args.mode != "stream" else None, "digest": digest(res),
            "env": {k: v for k, v in os.environ.items() if k.startswith("DPR_")}}
+    if clocks:
+        rec["clocks"] = clocks
     out.append(rec)
     print(json.dumps(rec), flush=True)
 if args.json:
@@ -93,8 +115,8 @@ if args.phases is not None:
         roles = [("all", used)]
         if k == 1:
             code = b[:, 7]
-            if (code[used] > 0).any() and (code[used] < 16).all():      # njp_post2_kernel: 1 = UM block, 3 = T block that left after the coarse test, 4 = T block
-                roles = [("UM", used & (code == 1)), ("T-coarse-exit", used & (code == 3)), ("T-full", used & (code == 4)), ("other", used & (code == 0))]
+            if (code[used] > 0).any() and (code[used] < 16).all():      # njp_post2 / post3: 1 = UM (U) block, 2 = M block, 3 = T block that left after the coarse test, 4 = T block
+                roles = [("U / UM", used & (code == 1)), ("M", used & (code == 2)), ("T-coarse-exit", used & (code == 3)), ("T-full", used & (code == 4)), ("other", used & (code == 0))]
             else:                                                        # fused kernel: test blocks stamp slot 5
                 roles = [("test", used & (b[:, 5] > 0)), ("update", used & (b[:, 5] == 0))]
         for rname, m in roles:
