@@ -160,7 +160,7 @@ class Stage:
         if self.dist is not None:
             self.dist.barrier()
 
-    def gen(self, tag, tips, sites, seed, mean, lo, hi, fasta=False, reads=False, shuffle=None, gap=0.0):
+    def gen(self, tag, tips, sites, seed, mean, lo, hi, fasta=False, reads=False, shuffle=None, gap=None):
         """returns the paths of input `tag`; rank 0 runs the generator (all host threads: the other ranks wait)"""
         base = os.path.join(self.dir, tag)
         p = {"tips": tips, "sites": sites, "tree": base + ".nwk", "fasta": base + ".fa" if fasta else None,
@@ -175,8 +175,10 @@ class Stage:
                 cmd += ["--indel", "0.03,0.09", "--packed2", p["packed2"]]
             else:
                 cmd += ["--packed4", p["packed4"]]
-                if gap and gap > 0:
-                    cmd += ["--gap-frac", repr(float(gap))]
+                if gap is not None and gap >= 0:      # (gap < 0 / None: gap-free; 0: inherited deletions only; > 0: + per-tip runs)
+                    cmd += ["--indel-gaps"]
+                    if gap > 0:
+                        cmd += ["--gap-frac", repr(float(gap))]
             if shuffle is not None:
                 cmd += ["--shuffle", str(shuffle), "--order", p["order"]]
             subprocess.run(cmd, check=True)
@@ -356,9 +358,12 @@ def main():
     ap.add_argument("--tips", type=int, default=30000)
     ap.add_argument("--sites", type=int, default=10000)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--gap-frac", type=float, default=0.03,
-                    help="fraction of '-' cells in the ALIGNED inputs (gen_synth --gap-frac; the authors simulate with indels, "
-                         "scripts/alisim.sh:14 -- an alignment of such data holds gap columns); 0 = the gap-free inputs of rounds 1-3")
+    ap.add_argument("--gap-frac", type=float, default=0.0,
+                    help="STRESS input: expected fraction of '-' cells per tip in the aligned inputs, independent from tip to tip "
+                         "(gen_synth --gap-frac).  Not the authors' protocol; at 0.03 the pruned NJ lists 80 x the units (5.7 s at 30 000 tips)")
+    ap.add_argument("--no-indel-gaps", action="store_true",
+                    help="aligned inputs without the inherited deletion gaps of the authors' indel model (gen_synth --indel-gaps, "
+                         "scripts/alisim.sh:14): the gap-free inputs of rounds 1-3")
     ap.add_argument("--probe-reps", type=int, default=20)
     ap.add_argument("--deadline-s", type=float, default=float(os.environ.get("DPR_BENCH_DEADLINE_S", "500")),
                     help="optional legs are skipped when they would not finish this many seconds after process start "
@@ -458,7 +463,7 @@ def main():
 
     n, L = args.tips, args.sites
     want_cli = not args.no_cli and not args.probe_only and os.path.exists(EXE)
-    inp = stage.gen("main", n, L, args.seed, 2e-5, 2e-6, 2e-4, fasta=want_cli, gap=args.gap_frac)
+    inp = stage.gen("main", n, L, args.seed, 2e-5, 2e-6, 2e-4, fasta=want_cli, gap=None if args.no_indel_gaps else args.gap_frac)
     packed = Stage.packed4(inp)
     names = ["T%d" % (i + 1) for i in range(n)]
     tmp = tempfile.mkdtemp(prefix="dipper_bench_r%d_" % rank)
@@ -684,7 +689,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic (seeded Yule-Harding tree, JC69, L=%d, %s; own native generator tools/gen_synth.cpp: no alisim in the image)"
-                    % (L, ("%.3g of the cells are '-' (per-tip runs + inherited deletions, gen_synth --gap-frac)" % args.gap_frac) if args.gap_frac > 0 else "no gaps"),
+                    % (L, "no gaps" if args.no_indel_gaps else ("deletions of the authors' indel model as inherited gap runs (gen_synth --indel-gaps)"
+                                                                 + ("; stress: + %.3g of every tip's cells as its own '-' runs" % args.gap_frac if args.gap_frac > 0 else ""))),
             "config": {"workload": "configs[1]: %d aligned tips, -d 2 (JC69), conventional NJ (-m 2)" % n,
                        "tips": n, "sites": L,
                        "step": "one whole `dipper` command per rank (FASTA -> Newick)" if primary else "in-process hot path (HBM-resident input -> merge log)",
@@ -808,7 +814,7 @@ def other_configs(args, local_rank, stage, budget, tmp):
 
     def nj_100k():
         n, L = 100000, 10000
-        inp = stage.gen("nj100k", n, L, args.seed + 7, 2e-5, 2e-6, 2e-4, gap=args.gap_frac)
+        inp = stage.gen("nj100k", n, L, args.seed + 7, 2e-5, 2e-6, 2e-4, gap=None if args.no_indel_gaps else args.gap_frac)
         packed = Stage.packed4(inp)
         d = dipper_amd.Dipper(local_rank)
         try:
@@ -858,7 +864,7 @@ def other_configs(args, local_rank, stage, budget, tmp):
 
     def dc_1m():
         n, L = args.dc_tips, 400
-        inp = stage.gen("dc1m", n, L, args.seed + 9, 2e-3, 2e-4, 2e-2, shuffle=7, gap=args.gap_frac)   # the CLI shuffles its input (src/tree_generation.cu:341-344)
+        inp = stage.gen("dc1m", n, L, args.seed + 9, 2e-3, 2e-4, 2e-2, shuffle=7, gap=None if args.no_indel_gaps else args.gap_frac)   # the CLI shuffles its input (src/tree_generation.cu:341-344)
         packed = Stage.packed4(inp)
         d = dipper_amd.Dipper(local_rank)
         try:
@@ -888,7 +894,7 @@ def other_configs(args, local_rank, stage, budget, tmp):
         n = m + nq
         L = 1000 if kind == "m" else 3000
         inp = stage.gen("add_%s" % kind, n, L, args.seed + (10 if kind == "m" else 11), 1e-3, 1e-4, 1e-2, fasta=True, reads=(kind == "r"), shuffle=7,
-                        gap=args.gap_frac if kind == "m" else 0.0)
+                        gap=(None if args.no_indel_gaps else args.gap_frac) if kind == "m" else None)
         fa_all = inp["fasta"]
         # the first m records as their own file (the backbone's tips)
         buf = np.memmap(fa_all, dtype=np.uint8, mode="r")
@@ -1256,7 +1262,7 @@ def sharded_leg(args, rank, world, local_rank, dist, torch, barrier, stage, budg
     rec = {"tips": ns, "sites": Ls, "world": world}
     if not budget.allows_all(60):
         return dict(rec, **budget.skip(60))
-    inp = stage.gen("nj100k", ns, Ls, args.seed + 7, 2e-5 * 10000 / Ls, 2e-6 * 10000 / Ls, 2e-4 * 10000 / Ls, gap=args.gap_frac)
+    inp = stage.gen("nj100k", ns, Ls, args.seed + 7, 2e-5 * 10000 / Ls, 2e-6 * 10000 / Ls, 2e-4 * 10000 / Ls, gap=None if args.no_indel_gaps else args.gap_frac)
     packed = Stage.packed4(inp)
     if ONE_GPU and world > 1:
         rec["unit_sharded_plan"] = {"skipped": "needs RCCL (rehearsal with process ranks on one GPU)"}
@@ -1337,7 +1343,7 @@ def dc_leg(args, rank, world, local_rank, dist, torch, barrier, stage):
     import dipper_amd
     from dipper_amd import capi
     n, L = args.dc_tips, 400
-    inp = stage.gen("dc1m", n, L, args.seed + 9, 2e-3, 2e-4, 2e-2, shuffle=7, gap=args.gap_frac)      # the CLI shuffles its input (src/tree_generation.cu:341-344)
+    inp = stage.gen("dc1m", n, L, args.seed + 9, 2e-3, 2e-4, 2e-2, shuffle=7, gap=None if args.no_indel_gaps else args.gap_frac)      # the CLI shuffles its input (src/tree_generation.cu:341-344)
     packed = Stage.packed4(inp)
     rec = {"tips": n, "sites": L, "backbone": n // 20, "world": world}
 

@@ -1165,11 +1165,7 @@ int dpr_get_prune_stats(dpr_ctx* c, uint64_t* units_scanned, uint64_t* units_per
     if (!c || !c->have_matrix || !c->nj[0].pr.active) { set_error("dpr_get_prune_stats: pruned path not active"); return DPR_ERR_STATE; }
     NjState st;
     if (int rc = fetch_state(c, &st)) return rc;
-    if (units_scanned) {
-        unsigned long long tot = 0;
-        if (int rc = njp_units_scanned(c->nj[0], &tot)) return rc;      // (state counter + the per-block counters of the cells mode)
-        *units_scanned = tot;
-    }
+    if (units_scanned) *units_scanned = st.units_scanned;
     if (units_per_full_scan) *units_per_full_scan = (uint64_t)c->nj[0].pr.utot0;
     return DPR_OK;
 }
@@ -1445,9 +1441,10 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
     // 5 x 10^8 pairs (~100 ms alone) against ~50 ms of tree kernels; overlapped, the pair kernel ran at half its rate and the
     // update kernel 5.6 x slower (profiles/r3/kernel_stats_add_mash_500k_plus_50k.csv): 9.2 s where back to back is 7.6 s.
     // So: batch k + 1 is produced beside batch k's tree kernels iff its predicted time alone (pairs / the rate measured on this
-    // run's batches that ran alone, 4.5 G pairs/s until there is one) is below the tree time of a batch as last measured on
-    // a batch that ran alone (batch 0 always does); otherwise it is produced on the main stream right before its own tips, at
-    // full chip.  The host waits for batch k - 1 before it decides about batch k + 1 (it never runs more than one batch ahead
+    // run's batches that ran alone, 4.5 G pairs/s until there is one) is below the tree time of the latest finished batch
+    // (deflated by 1.4 if that batch shared the chip); otherwise it is produced on the main stream right before its own tips, at
+    // full chip.  Measured (profiles/r4/place_policy_*.jsonl): --add 500 000 + 50 000 through Mash 8.87 s (every batch beside)
+    // -> 6.56 s (none); 100 000 tips from scratch 3.07 s (none) / 2.52 s (every batch) / 2.5x s (policy).  The host waits for batch k - 1 before it decides about batch k + 1 (it never runs more than one batch ahead
     // of the device any more; enqueueing is ~10 x faster than the tree kernels execute, so the device does not starve).
     // Results cannot depend on the policy: the rows are the same numbers whichever stream produced them.
     const bool overlap_allowed = source == DPR_SRC_MASH && !std::getenv("DPR_PLACE_NO_OVERLAP");
@@ -1543,7 +1540,10 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
                 if (!pr.t1) continue;
                 DPR_HIP(hipEventSynchronize(pr.t1));
                 float ms = 0;
-                if (pr.tree_alone && hipEventElapsedTime(&ms, pr.t0, pr.t1) == hipSuccess && pr.nr > 0) tree_ms_per_tip = (double)ms / (double)pr.nr;
+                // (tree kernels that shared the chip with a distance batch ran ~1.3 x slower at 100 000 tips: such a batch's time
+                //  is deflated by 1.4 before it stands for "the tree part alone" -- the tree part grows with the tree, so the
+                //  latest batch is the better estimate than batch 0's clean one)
+                if (hipEventElapsedTime(&ms, pr.t0, pr.t1) == hipSuccess && pr.nr > 0) tree_ms_per_tip = (double)ms / (double)pr.nr / (pr.tree_alone ? 1.0 : 1.4);
                 if (pr.dist_alone && pr.d0 && pr.d1 && pr.pairs >= 5.0e7 && hipEventElapsedTime(&ms, pr.d0, pr.d1) == hipSuccess && ms > 0.0f)
                     pairs_per_ms = pr.pairs / (double)ms;
             }

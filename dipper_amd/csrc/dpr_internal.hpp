@@ -102,10 +102,6 @@ struct NjPruned {
     // njp_post2_kernel (large shape): header + arrays its producer blocks hand to its test blocks (in the epoch's slab)
     bool range_known = false;         // t2_hdr holds the range of every entry of this run (njp_range_kernel + the M parts since)
     char* t2_hdr = nullptr; double *t2_rmax = nullptr, *t2_cmax = nullptr, *t2_colmin = nullptr, *t2_rowmin = nullptr, *t2_cmin = nullptr;
-    // njp_post3_kernel (small shape, one rank): one cell per unit of the test blocks instead of an atomic list (in the epoch's slab);
-    // scan_stat: units scanned per scan block in cells mode (one allocation per context, zeroed when a run starts)
-    uint32_t* cells = nullptr;
-    unsigned long long* scan_stat = nullptr;
     int32_t *slot_of_pos = nullptr, *pos_of_slot = nullptr, *perm = nullptr;   // slot_of_pos < 0: dead position
     uint64_t* umin = nullptr;   // [strips][groups][4] order-encoded lower bound of D per sub-unit
     int64_t nunits_alloc = 0, utot = 0;
@@ -258,8 +254,6 @@ int nj_launch_finish(NjBuffers& b, int64_t n, int64_t it, hipStream_t s);       
 
 // njs.hip: one-exchange row-sharded loop (world > 1)
 NjsLayout njs_layout(int64_t N, int world);
-// units the pruned scans have listed since the run started (state counter + the per-block counters of the cells mode); stream idle
-int njp_units_scanned(NjBuffers& b, unsigned long long* out);
 int njs_alloc_window(NjBuffers& b, hipStream_t s);
 void njs_free_window(NjBuffers& b);
 int njs_set_peers(NjBuffers& b, char* const* wins, double* const* Ds, hipStream_t s);

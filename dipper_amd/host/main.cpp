@@ -436,6 +436,9 @@ int main(int argc, char** argv)
         // ten on some hosts (30 runs each, back to back: none with this call, 12 without; the call itself costs nothing
         // measurable -- profiles/r3/cli_exit_sweep.jsonl).  DPR_CLI_FAST_EXIT=1 skips it.
         if (!std::getenv("DPR_CLI_FAST_EXIT")) { dpr_destroy(dev.ctx); dev.ctx = nullptr; }
+        // (DPR_CLI_NORMAL_EXIT=1: return through main and the exit handlers -- a profiler that writes its output at exit,
+        //  rocprofv3 for one, sees nothing of a process that leaves through _exit)
+        if (std::getenv("DPR_CLI_NORMAL_EXIT")) return 0;
         _exit(0);
     } else if (params.in == "d" && params.out == "t") {
         MatrixReader matrixReader;

@@ -42,6 +42,10 @@ t4 = time.perf_counter()
 res = d.place_run(src, n, first=m, dist_type=2, k=15, state={k: st[k] for k in ("head", "e", "nxt", "belong", "len")})
 t5 = time.perf_counter()
 if rank == 0:
+  dist_ms, tree_ms = d.place_timing()
+  batches, beside = d.place_policy()
   print(json.dumps(dict(n_gpus=world, kind=kind, backbone=m, queries=nq, sites=L, backbone_tree_s=t1 - t0, newick_host_s=t3 - t1,
-                      upload_s=t4 - t3, add_s=t5 - t4, add_device_ms=d.timing()[1], queries_per_s=nq / (t5 - t4))))
+                      upload_s=t4 - t3, add_s=t5 - t4, add_device_ms=d.timing()[1], queries_per_s=nq / (t5 - t4), distance_wait_ms=dist_ms, tree_part_ms=tree_ms,
+                      batches=batches, batches_beside_tree_kernels=beside, distance_busy_ms=d.place_overlap()[1],
+                      policy_env={k: v for k, v in os.environ.items() if k.startswith("DPR_PLACE")})))
 _mgpu.finish(dist)

@@ -60,7 +60,7 @@ def test_gen_synth_gap_fraction(tmp_path, orc):
     4-bit words carry code 4 there (src/fourBitCompressor.cpp:33-35), and the output does not depend on the thread count"""
     n, L = 300, 3000
     out = {}
-    for tag, extra in (("plain", []), ("gaps", ["--gap-frac", "0.03"]), ("gaps5", ["--gap-frac", "0.03", "--threads", "5"])):
+    for tag, extra in (("plain", []), ("gaps", ["--gap-frac", "0.03"]), ("gaps5", ["--gap-frac", "0.03", "--threads", "5"]), ("indel", ["--indel-gaps"])):
         base = str(tmp_path / tag)
         subprocess.run([GEN, "--tips", str(n), "--sites", str(L), "--seed", "9", "--mean-bl", "1e-3", "--lo", "1e-4", "--hi", "1e-2",
                         "--fasta", base + ".fa", "--packed4", base + ".p4", "--tree", base + ".nwk"] + extra, check=True)
@@ -78,6 +78,15 @@ def test_gen_synth_gap_fraction(tmp_path, orc):
     assert (per_tip > 0).mean() > 0.98 and per_tip.max() < 0.12        # (nearly) every tip has gaps, none is mostly gaps
     packed = np.frombuffer(out["gaps"][".p4"], dtype=np.uint64).reshape(n, (L + 15) // 16)
     assert np.array_equal(packed, orc.pack4_many(gaps))
+    # --indel-gaps alone: only the inherited deletions of the authors' indel model -- few cells, shared by clades (a gap cell is
+    # far more often shared with another tip than the per-tip runs above), every other cell unchanged
+    _, indel = _fasta(str(tmp_path / "indel.fa"))
+    c = np.frombuffer(b"".join(indel), dtype=np.uint8).reshape(n, L)
+    ig = c == ord("-")
+    assert 0 < ig.mean() < 0.01 and out["indel"][".nwk"] == out["plain"][".nwk"]
+    assert np.array_equal(a[~ig.ravel()], c.ravel()[~ig.ravel()])
+    shared = (ig.sum(axis=0) >= 2)[None, :] & ig
+    assert shared.sum() > 0.5 * ig.sum()
 
 
 def test_gen_synth_reads_with_indels(tmp_path, orc):

@@ -12,15 +12,21 @@
 // and the ranks of a multi-GPU bench map the files.
 //
 //   gen_synth --tips N --sites L [--seed S] [--mean-bl m --lo a --hi b] [--indel INS,DEL[,MEANLEN]] [--shuffle SEED]
-//             [--gap-frac F[,MEANRUN]] [--threads T] [--fasta out.fa] [--packed4 out.u64] [--packed2 prefix] [--tree out.nwk]
+//             [--indel-gaps] [--gap-frac F[,MEANRUN]] [--threads T] [--fasta out.fa] [--packed4 out.u64] [--packed2 prefix] [--tree out.nwk]
 //             [--order out.i32]
 //
-// --gap-frac F (aligned output only; round 4): what the authors' indel model leaves in an ALIGNMENT -- '-' cells.  Two
-// sources: deletions on branches at the authors' rate (0.09 per substitution, geometric lengths, `--indel`'s numbers), which
-// every descendant inherits, and -- these alone would be ~1e-4 of the cells at the protocol's branch lengths -- per-tip runs of
-// '-' (Poisson number, geometric length, mean MEANRUN = 10) up to an expected fraction F of every tip, so that the
-// not-a-base plane of the distance kernel (src/MSA.cu:103-156: `useful`, `match`) does work at bench size.  Gap cells are
-// code 4 in the 4-bit packing (src/fourBitCompressor.cpp:33-35) and '-' in the FASTA.  F = 0 leaves every output byte as before.
+// Gaps in ALIGNED output (round 4; gap cells are code 4 in the 4-bit packing, src/fourBitCompressor.cpp:33-35, and '-' in the
+// FASTA; without either switch every output byte is as before):
+//   --indel-gaps       what the authors' indel model (scripts/alisim.sh:14: `--indel 0.03,0.09`) leaves in an alignment:
+//                      deletions on branches at 0.09 per substitution, geometric lengths (`--indel`'s numbers), as runs of gap
+//                      cells that every descendant inherits -- ~1e-4 of the cells at the protocol's branch lengths, shared by
+//                      clades.  (Insertions, which would add a few per cent of mostly-gap columns, are not modelled.)
+//   --gap-frac F[,RUN] a STRESS input, not the protocol: on top of that, per-tip runs of '-' (Poisson number, geometric length,
+//                      mean RUN = 10) up to an expected fraction F of every tip -- missing data that is independent from tip to
+//                      tip, as in assemblies with dropped amplicons.  It makes the not-a-base plane of the distance kernel
+//                      (src/MSA.cu:103-156: `useful`, `match`) do work at any size; it also perturbs every distance by its own
+//                      ~F, which the pruned NJ scan pays for (30 000 tips, F = 0.03: 80 x the units listed, NJ 5.7 s instead of
+//                      0.48 s, still below the streaming loop's 6.3 s; profiles/r4/post3_cells_variants_30k.txt).
 //
 // Tip names are T<k+1> with k the tip's index in the generating tree's creation order (the true tree uses the same
 // names).  Output order = creation order, or a seeded permutation of it (--shuffle; --order writes the permutation:
@@ -98,6 +104,7 @@ struct Args {
     bool indels = false;
     double ins = 0.03, del = 0.09, indel_mean = 2.0;
     double gap_frac = 0.0, gap_run = 10.0;
+    bool indel_gaps = false;
     bool shuffle = false;
     uint64_t shuffle_seed = 0;
     int threads = 0;
@@ -175,7 +182,7 @@ void evolve(const Seq& src, Seq& dst, double bl, uint64_t node, const Args& a)
         const uint8_t nb = (uint8_t)((dst[p] + 1 + r.below(3)) & 3);
         if (dst[p] < 4) dst[p] = nb;          // a deleted site stays deleted
     }
-    if (!a.indels && a.gap_frac > 0.0) {
+    if (!a.indels && (a.indel_gaps || a.gap_frac > 0.0)) {
         // aligned output: a deletion on this branch is a run of gap cells that every descendant inherits (own generator:
         // the substitution stream above is the same with and without gaps)
         Rng rg(a.seed, node, 7);
@@ -316,6 +323,7 @@ int main(int argc, char** argv)
             if (q != std::string::npos) a.gap_run = std::atof(v.substr(q + 1).c_str());
             if (!(a.gap_frac >= 0.0 && a.gap_frac < 0.9) || !(a.gap_run >= 1.0)) die("--gap-frac F[,MEANRUN]: 0 <= F < 0.9, MEANRUN >= 1");
         }
+        else if (k == "--indel-gaps") a.indel_gaps = true;
         else if (k == "--shuffle") { a.shuffle = true; a.shuffle_seed = std::strtoull(val(), nullptr, 10); }
         else if (k == "--threads") a.threads = std::atoi(val());
         else if (k == "--fasta") a.fasta = val();
@@ -325,13 +333,13 @@ int main(int argc, char** argv)
         else if (k == "--order") a.order = val();
         else if (k == "-h" || k == "--help") {
             std::fprintf(stderr, "usage: gen_synth --tips N --sites L [--seed S] [--mean-bl m --lo a --hi b] [--indel INS,DEL[,MEANLEN]] [--shuffle SEED]\n"
-                                 "                 [--gap-frac F[,MEANRUN]] [--threads T] [--fasta f] [--packed4 f] [--packed2 prefix] [--tree f] [--order f]\n");
+                                 "                 [--indel-gaps] [--gap-frac F[,MEANRUN]] [--threads T] [--fasta f] [--packed4 f] [--packed2 prefix] [--tree f] [--order f]\n");
             return 0;
         } else die("unknown argument " + k);
     }
     if (a.tips < 2 || a.sites < 1) die("--tips >= 2 and --sites >= 1 are required");
     if (a.indels && !a.packed4.empty()) die("--packed4 needs aligned output (no --indel)");
-    if (a.indels && a.gap_frac > 0.0) die("--gap-frac is for aligned output (no --indel)");
+    if (a.indels && (a.gap_frac > 0.0 || a.indel_gaps)) die("--gap-frac / --indel-gaps are for aligned output (no --indel)");
     const int64_t N = a.tips, L = a.sites;
     const int T = a.threads > 0 ? a.threads : host_threads();
 
