@@ -275,12 +275,16 @@ def cpu_baseline_rapidnj(dip, n, cores, budget_s=20.0):
         log(f"[cpu_baseline_rapidnj] {D.shape[0]} tips: {dt:.2f} s")
         return dt
 
-    m0 = min(n, 3000)
-    m1 = min(n, 6000)
+    # (round 4: the exponent is measured between 4 000 and 8 000 tips and kept within 1.8 .. 2.6.  Between 3 000 and 6 000 it
+    #  came out anywhere from 2.2 to 3.0 from run to run -- a 4 x spread of the extrapolated figure, 48 .. 182 tips/s; the FULL
+    #  run at 30 000 tips takes 161 s on 16 threads = 186 tips/s, exponent 2.14 between 15 295 and 30 000 tips:
+    #  profiles/r4/cpu_baseline_validation.jsonl)
+    m0 = min(n, 4000)
+    m1 = min(n, 8000)
     D1 = gpu_matrix_block(dip, m1)
-    t0 = run(D1[:m0, :m0])
+    t0 = run(np.ascontiguousarray(D1[:m0, :m0]))
     t1 = run(D1) if m1 > m0 else t0
-    expo = max(1.5, min(3.0, np.log(max(t1, 1e-3) / max(t0, 1e-3)) / np.log(m1 / m0))) if m1 > m0 else 2.0
+    expo = max(1.8, min(2.6, np.log(max(t1, 1e-3) / max(t0, 1e-3)) / np.log(m1 / m0))) if m1 > m0 else 2.15
     est_full = t1 * (n / m1) ** expo
     avail = psutil.virtual_memory().available
     m = n
@@ -296,7 +300,7 @@ def cpu_baseline_rapidnj(dip, n, cores, budget_s=20.0):
     t_full = tm * (n / m) ** expo
     return {"value": n / t_full, "unit": "tips/s", "cores": cores, "kind": "rapidnj-style reimplementation (not the oracle)",
             "sample": f"exact NJ with RapidNJ's sorted-row search on the GPU's matrix, leading {m} of {n} tips in {tm:.1f} s "
-                      + ("(whole run)" if m == n else f"scaled by (N/m)^{expo:.2f} (exponent measured between {m0} and {m1} tips)")
+                      + ("(whole run)" if m == n else f"scaled by (N/m)^{expo:.2f} (exponent measured between {m0} and {m1} tips; validated once against the full 30 000-tip run: 186 tips/s, profiles/r4/cpu_baseline_validation.jsonl)")
                       + "; distance stage excluded"}
 
 
@@ -929,7 +933,9 @@ def other_configs(args, local_rank, stage, budget, tmp):
         out = {"workload": "configs[4] on one GPU: %d queries added to a %d-tip backbone, %s; the whole `dipper -a -t backbone.nwk` command "
                            "(FASTA of all %d records in, Newick out)" % (nq, m, "aligned x %d sites, -d 2" % L if kind == "m" else "unaligned reads x ~%d bases through Mash" % L, n),
                "backbone": m, "queries": nq, "seconds": wall, "queries_per_s": nq / wall, "phases_ms": ph,
-               "placement_s": ph.get("tree_ms", float("nan")) * 1e-3,
+               "addquery_s": (ph["distance_ms"] + ph["tree_op_ms"]) * 1e-3 if ("distance_ms" in ph and "tree_op_ms" in ph) else None,
+               "note": "seconds = the whole command (FASTA parse of all records, packing, sketches, backbone import, addQuery, Newick write); addquery_s = the "
+                       "command's own `Distance Operation Time` + `Tree Operation Time` lines (src/placement_close_k.cu:985-986)",
                "setup_untimed": {"backbone_tree_by_dc_s": t_bb, "fasta_bytes": os.path.getsize(fa_all)}}
         for f in (fa_bb,):
             try:

@@ -1448,7 +1448,9 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
     // of the device any more; enqueueing is ~10 x faster than the tree kernels execute, so the device does not starve).
     // Results cannot depend on the policy: the rows are the same numbers whichever stream produced them.
     const bool overlap_allowed = source == DPR_SRC_MASH && !std::getenv("DPR_PLACE_NO_OVERLAP");
-    const bool overlap_always = overlap_allowed && std::getenv("DPR_PLACE_OVERLAP_ALWAYS") != nullptr;      // round 3's policy (A / B runs)
+    // (several ranks: every rank must take the same decisions -- the batches' all-gathers are enqueued on the stream the decision
+    //  picks -- and a rank's share of a batch is 1 / G of the pairs, i.e. the short side: every batch beside, as in round 3)
+    const bool overlap_always = overlap_allowed && (sharded || std::getenv("DPR_PLACE_OVERLAP_ALWAYS") != nullptr);
     double* rows_buf[2] = { nullptr, nullptr };
     const size_t row_bytes = sizeof(double) * (size_t)(per * W * ldb);
     if (source != DPR_SRC_MATRIX) {

@@ -59,7 +59,7 @@ static int64_t njp_big_p()
 // (Also measured in round 4 and NOT kept -- commit 9d05741 holds it: njp_post3_kernel, the roles split again for the small shape
 //  (update by slot as in the fused kernel, light test blocks, maxima by position: 430 blocks instead of 1 018) and the list
 //  replaced by one cell per unit that the scan blocks read directly, i.e. no atomic at all.  Bit-exact on every NJ test and on
-//  the 10 000-tip oracle runs, 507 ms against the fused kernel's 480 at 30 000 tips, 2.20 against 2.10 s at 100 000:
+//  the 10 000-tip parity runs, 507 ms against the fused kernel's 480 at 30 000 tips, 2.20 against 2.10 s at 100 000:
 //  profiles/r4/post3_cells_variants_*.txt, phases_post3_it*.txt -- its test blocks still end 6.1 us after the first stamp
 //  (start 1.1, select 2.0, seed candidates 4.4, tests 5.6): shorter blocks, the same number of dependent steps.)
 static bool njp_post2_on()
