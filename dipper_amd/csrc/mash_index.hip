@@ -8,7 +8,9 @@
 // ascending order, with three small integers each: the position of v in A, the position of v in B, the multiplicity
 // of v in B -- and one counter.  That is a join, not a merge:
 //   * index (once per sketch set): the tips are cut into chunks of 512; a chunk's (value, tip, position) triples --
-//     first occurrences only -- are sorted by value (rocPRIM segmented radix sort: preprocessing, not the hot path);
+//     first occurrences only -- are sorted by value (round 4: every tip's sketch is already ascending, so a chunk is 512
+//     sorted runs and the sort is nine rounds of pairwise merge-path merges, mi_merge_kernel; until round 3 a rocPRIM
+//     segmented radix sort -- the one piece of vendor device code near the path, and 3.7 of the library's 5 MB);
 //     per chunk the distinct values, the start of each value's posting list, and a 65 536-bucket directory on the
 //     leading bits;
 //   * query: ONE WAVEFRONT per (row, chunk).  It walks the row's distinct values in ascending order (64 directory
@@ -28,10 +30,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/device/device_segmented_radix_sort.hpp>
-#include <rocprim/functional.hpp>
 
 namespace dpr {
 
@@ -62,6 +60,184 @@ __global__ __launch_bounds__(kIThreads) void mi_payload_kernel(const uint64_t* _
     }
     mult[idx] = (uint16_t)m;
     pay[idx] = first ? (((uint32_t)(2 * (t & (kIC - 1))) << 16) | (uint32_t)p) : kINone;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Index build without vendor device code (round 4).
+// (1) Sort of a chunk's entries by value = MERGE of its 512 runs: a tip's sketch is ascending already.  Round r merges
+//     neighbouring runs of R = S 2^r entries; nine rounds.  One workgroup produces 1 024 consecutive outputs of one pair of
+//     runs: two merge-path searches on the pair's diagonals find the inputs it needs (<= 1 024 entries, staged in LDS), every
+//     thread then finds its own four outputs by the same search in LDS and merges them serially.  Ties take the LEFT run
+//     first and runs keep their order, i.e. the result is the stable sort of the tip-major input -- what the radix sort gave.
+// (2) Inclusive scan of 32-bit flags: block sums, one block over the block sums, block-local scan + offset.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMT = 1024;            // outputs per workgroup of the merge kernel (4 per thread)
+
+__global__ __launch_bounds__(kIThreads) void mi_merge_kernel(const uint64_t* __restrict__ srcK, const uint32_t* __restrict__ srcP,
+                                                             uint64_t* __restrict__ dstK, uint32_t* __restrict__ dstP, int64_t total,
+                                                             int64_t seg, int64_t R, int64_t pairs_per_chunk, int64_t tiles_per_pair)
+{
+    __shared__ uint64_t sk[kMT];
+    __shared__ uint32_t sp[kMT];
+    __shared__ int64_t s_part[4];
+    const int tid = threadIdx.x;
+    const int64_t blk = blockIdx.x;
+    const int64_t tile = blk % tiles_per_pair;
+    const int64_t pj = (blk / tiles_per_pair) % pairs_per_chunk;
+    const int64_t c = blk / (tiles_per_pair * pairs_per_chunk);
+    const int64_t cbeg = c * seg, cend = cbeg + seg < total ? cbeg + seg : total;
+    const int64_t abeg = cbeg + 2 * pj * R;
+    if (abeg >= cend) return;
+    const int64_t aend = abeg + R < cend ? abeg + R : cend;
+    const int64_t bbeg = aend, bend = bbeg + R < cend ? bbeg + R : cend;
+    const int64_t la = aend - abeg, lb = bend - bbeg;
+    const int64_t d0 = tile * kMT;
+    if (d0 >= la + lb) return;
+    const int64_t d1 = d0 + kMT < la + lb ? d0 + kMT : la + lb;
+    const uint64_t* __restrict__ A = srcK + abeg;
+    const uint64_t* __restrict__ B = srcK + bbeg;
+    if (tid < 2) {      // merge path: the number of A entries among the first d outputs (ties: A first)
+        const int64_t d = tid ? d1 : d0;
+        int64_t lo = d > lb ? d - lb : 0, hi = d < la ? d : la;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (A[mid] <= B[d - 1 - mid]) lo = mid + 1; else hi = mid;
+        }
+        s_part[tid] = lo;
+    }
+    __syncthreads();
+    const int64_t a0 = s_part[0], a1 = s_part[1];
+    const int64_t b0 = d0 - a0, b1 = d1 - a1;
+    const int na = (int)(a1 - a0), nb = (int)(b1 - b0);
+    for (int k = tid; k < na; k += kIThreads) { sk[k] = A[a0 + k]; sp[k] = srcP[abeg + a0 + k]; }
+    for (int k = tid; k < nb; k += kIThreads) { sk[na + k] = B[b0 + k]; sp[na + k] = srcP[bbeg + b0 + k]; }
+    __syncthreads();
+    const int nout = na + nb;
+    const int o0 = 4 * tid;
+    if (o0 >= nout) return;
+    int lo = o0 > nb ? o0 - nb : 0, hi = o0 < na ? o0 : na;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sk[mid] <= sk[na + o0 - 1 - mid]) lo = mid + 1; else hi = mid;
+    }
+    int ai = lo, bi = o0 - lo;
+    const int64_t obase = abeg + d0 + o0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (o0 + k >= nout) break;
+        const bool takeA = ai < na && (bi >= nb || sk[ai] <= sk[na + bi]);
+        const int src = takeA ? ai : na + bi;
+        dstK[obase + k] = sk[src];
+        dstP[obase + k] = sp[src];
+        ai += takeA ? 1 : 0;
+        bi += takeA ? 0 : 1;
+    }
+}
+
+constexpr int kScanItems = 16;       // per thread: a workgroup scans 4 096 flags
+__device__ __forceinline__ uint32_t mi_block_scan_incl(uint32_t v, uint32_t* swarp)      // inclusive scan over the 256 threads
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(v, off, 64);
+        if (lane >= off) v += u;
+    }
+    if (lane == 63) swarp[w] = v;
+    __syncthreads();
+    uint32_t add = 0;
+    for (int k = 0; k < w; ++k) add += swarp[k];
+    __syncthreads();
+    return v + add;
+}
+__global__ __launch_bounds__(kIThreads) void mi_scan_sums_kernel(const uint32_t* __restrict__ in, int64_t n, uint32_t* __restrict__ bsum)
+{
+    __shared__ uint32_t swarp[kIThreads / 64];
+    const int64_t base = ((int64_t)blockIdx.x * kIThreads + threadIdx.x) * kScanItems;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) acc += base + k < n ? in[base + k] : 0u;
+    const uint32_t incl = mi_block_scan_incl(acc, swarp);
+    if (threadIdx.x == kIThreads - 1) bsum[blockIdx.x] = incl;
+}
+// exclusive scan of the block sums in place, one workgroup
+__global__ __launch_bounds__(kIThreads) void mi_scan_top_kernel(uint32_t* __restrict__ bsum, int64_t nb)
+{
+    __shared__ uint32_t swarp[kIThreads / 64];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0u;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < nb; b0 += kIThreads) {
+        const int64_t i = b0 + threadIdx.x;
+        const uint32_t v = i < nb ? bsum[i] : 0u;
+        const uint32_t incl = mi_block_scan_incl(v, swarp);
+        const uint32_t carry = s_carry;
+        if (i < nb) bsum[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == kIThreads - 1) s_carry = carry + incl;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(kIThreads) void mi_scan_apply_kernel(const uint32_t* __restrict__ in, int64_t n, const uint32_t* __restrict__ bsum,
+                                                                  uint32_t* __restrict__ out)
+{
+    __shared__ uint32_t swarp[kIThreads / 64];
+    const int64_t base = ((int64_t)blockIdx.x * kIThreads + threadIdx.x) * kScanItems;
+    uint32_t v[kScanItems];
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) { v[k] = base + k < n ? in[base + k] : 0u; acc += v[k]; }
+    uint32_t run = mi_block_scan_incl(acc, swarp) - acc + bsum[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        run += v[k];
+        if (base + k < n) out[base + k] = run;
+    }
+}
+// out[i] = in[0] + ... + in[i]; in and out may be the same buffer only if ... they must not alias
+static int mi_inclusive_scan(const uint32_t* in, uint32_t* out, int64_t n, hipStream_t s)
+{
+    if (n <= 0) return DPR_OK;
+    const int64_t per = (int64_t)kIThreads * kScanItems;
+    const int64_t nb = (n + per - 1) / per;
+    uint32_t* bsum = nullptr;
+    DPR_HIP(hipMalloc(&bsum, sizeof(uint32_t) * (size_t)nb));
+    hipLaunchKernelGGL(mi_scan_sums_kernel, dim3((unsigned)nb), dim3(kIThreads), 0, s, in, n, bsum);
+    hipLaunchKernelGGL(mi_scan_top_kernel, dim3(1), dim3(kIThreads), 0, s, bsum, nb);
+    hipLaunchKernelGGL(mi_scan_apply_kernel, dim3((unsigned)nb), dim3(kIThreads), 0, s, in, n, (const uint32_t*)bsum, out);
+    const hipError_t e = hipGetLastError();
+    const hipError_t e2 = hipStreamSynchronize(s);       // (the block sums are released here)
+    (void)hipFree(bsum);
+    if (e != hipSuccess) return hip_fail(e, "mi_inclusive_scan");
+    if (e2 != hipSuccess) return hip_fail(e2, "mi_inclusive_scan");
+    return DPR_OK;
+}
+
+// dst (keys, payload) = every chunk's entries sorted by key (stable); src: the sketches (every tip's S values ascending) and
+// their payloads.  k2 / p2: scratch of `total` entries each.
+static int mi_sort_chunks(const uint64_t* sketches, const uint32_t* pay, uint64_t* ks, uint32_t* post, uint64_t* k2, uint32_t* p2,
+                          int64_t total, int64_t seg, int S, hipStream_t s)
+{
+    int rounds = 0;
+    for (int v = kIC; v > 1; v >>= 1) ++rounds;          // 9
+    for (int r = 0; r < rounds; ++r) {
+        // round r writes buffer (rounds - 1 - r) & 1: the last round writes buffer 0 = (ks, post)
+        const int dsti = (rounds - 1 - r) & 1;
+        const uint64_t* sK = r == 0 ? sketches : (dsti ? ks : k2);
+        const uint32_t* sP = r == 0 ? pay : (dsti ? post : p2);
+        uint64_t* dK = dsti ? k2 : ks;
+        uint32_t* dP = dsti ? p2 : post;
+        const int64_t R = (int64_t)S << r;
+        const int64_t ppc = (int64_t)(kIC >> (r + 1));
+        const int64_t tpp = (2 * R + kMT - 1) / kMT;
+        const int64_t chunks = (total + seg - 1) / seg;
+        const int64_t blocks = chunks * ppc * tpp;
+        if (blocks > (int64_t)0x7FFFFFFF) { set_error("mash_index_build: too many merge tiles"); return DPR_ERR_ARG; }
+        hipLaunchKernelGGL(mi_merge_kernel, dim3((unsigned)blocks), dim3(kIThreads), 0, s, sK, sP, dK, dP, total, seg, R, ppc, tpp);
+        DPR_HIP(hipGetLastError());
+    }
+    return DPR_OK;
 }
 
 // head flags of the sorted keys (chunks are fixed segments of 512 S entries)
@@ -293,10 +469,9 @@ int mash_index_build(MashBuffers& m, hipStream_t s)
     const int64_t seg = (int64_t)kIC * S, chunks = (n + kIC - 1) / kIC;
     const unsigned gt = (unsigned)((total + kIThreads - 1) / kIThreads);
     uint64_t* ks = nullptr;
-    uint32_t *pay = nullptr, *flag = nullptr, *g = nullptr, *segoff = nullptr;
-    void* tmp = nullptr;
+    uint32_t *pay = nullptr, *flag = nullptr, *g = nullptr;
     auto cleanup = [&]() {
-        void* ptrs[] = { ks, pay, flag, g, segoff, tmp };
+        void* ptrs[] = { ks, pay, flag, g };
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     };
@@ -312,29 +487,26 @@ int mash_index_build(MashBuffers& m, hipStream_t s)
     MI_HIP(hipMalloc(&ks, sizeof(uint64_t) * (size_t)total));
     hipLaunchKernelGGL(mi_payload_kernel, dim3(gt), dim3(kIThreads), 0, s, m.sketches, S, total, pay, ix.mult);
     MI_HIP(hipGetLastError());
-    // sort every chunk's entries by value
-    std::vector<uint32_t> hseg((size_t)chunks + 1);
-    for (int64_t c = 0; c <= chunks; ++c) hseg[(size_t)c] = (uint32_t)(c * seg < total ? c * seg : total);
-    MI_HIP(hipMalloc(&segoff, sizeof(uint32_t) * (size_t)(chunks + 1)));
-    MI_HIP(hipMemcpyAsync(segoff, hseg.data(), sizeof(uint32_t) * (size_t)(chunks + 1), hipMemcpyHostToDevice, s));
-    size_t tb = 0;
-    MI_HIP(rocprim::segmented_radix_sort_pairs(nullptr, tb, (const uint64_t*)m.sketches, ks, (const uint32_t*)pay, ix.post, (unsigned)total,
-                                               (unsigned)chunks, (const uint32_t*)segoff, (const uint32_t*)segoff + 1, 0u, 64u, s));
-    MI_HIP(hipMalloc(&tmp, tb ? tb : 16));
-    MI_HIP(rocprim::segmented_radix_sort_pairs(tmp, tb, (const uint64_t*)m.sketches, ks, (const uint32_t*)pay, ix.post, (unsigned)total,
-                                               (unsigned)chunks, (const uint32_t*)segoff, (const uint32_t*)segoff + 1, 0u, 64u, s));
-    MI_HIP(hipStreamSynchronize(s));      // (hseg leaves scope; temporary storage is reused)
-    (void)hipFree(tmp); tmp = nullptr;
+    // sort every chunk's entries by value: nine rounds of pairwise merges of the (already ascending) sketches
+    {
+        uint64_t* k2 = nullptr;
+        uint32_t* p2 = nullptr;
+        MI_HIP(hipMalloc(&k2, sizeof(uint64_t) * (size_t)total));
+        const hipError_t e2 = hipMalloc(&p2, sizeof(uint32_t) * (size_t)total);
+        if (e2 != hipSuccess) { (void)hipFree(k2); return fail(hip_fail(e2, "hipMalloc(merge scratch)")); }
+        const int rcs = mi_sort_chunks((const uint64_t*)m.sketches, pay, ks, ix.post, k2, p2, total, seg, S, s);
+        const hipError_t es = hipStreamSynchronize(s);
+        (void)hipFree(k2); (void)hipFree(p2);
+        if (rcs != DPR_OK) return fail(rcs);
+        if (es != hipSuccess) return fail(hip_fail(es, "mash_index_build: chunk sort"));
+    }
     (void)hipFree(pay); pay = nullptr;
     // distinct values of every chunk and the start of their posting lists
     MI_HIP(hipMalloc(&flag, sizeof(uint32_t) * (size_t)total));
     MI_HIP(hipMalloc(&g, sizeof(uint32_t) * (size_t)total));
     hipLaunchKernelGGL(mi_heads_kernel, dim3(gt), dim3(kIThreads), 0, s, ks, total, seg, flag);
     MI_HIP(hipGetLastError());
-    tb = 0;
-    MI_HIP(rocprim::inclusive_scan(nullptr, tb, (const uint32_t*)flag, g, (size_t)total, rocprim::plus<uint32_t>(), s));
-    MI_HIP(hipMalloc(&tmp, tb ? tb : 16));
-    MI_HIP(rocprim::inclusive_scan(tmp, tb, (const uint32_t*)flag, g, (size_t)total, rocprim::plus<uint32_t>(), s));
+    if (int rcq = mi_inclusive_scan((const uint32_t*)flag, g, total, s)) return fail(rcq);
     uint32_t nu = 0;
     MI_HIP(hipMemcpyAsync(&nu, g + (total - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));
@@ -360,11 +532,8 @@ int mash_index_build(MashBuffers& m, hipStream_t s)
         MI_HIP(hipGetLastError());
         uint32_t* dscan = nullptr;
         MI_HIP(hipMalloc(&dscan, sizeof(uint32_t) * (size_t)nu));
-        (void)hipFree(tmp); tmp = nullptr;
-        tb = 0;
-        hipError_t e1 = rocprim::inclusive_scan(nullptr, tb, (const uint32_t*)flag, dscan, (size_t)nu, rocprim::plus<uint32_t>(), s);
-        if (e1 == hipSuccess) e1 = hipMalloc(&tmp, tb ? tb : 16);
-        if (e1 == hipSuccess) e1 = rocprim::inclusive_scan(tmp, tb, (const uint32_t*)flag, dscan, (size_t)nu, rocprim::plus<uint32_t>(), s);
+        hipError_t e1 = hipSuccess;
+        if (int rcq = mi_inclusive_scan((const uint32_t*)flag, dscan, (int64_t)nu, s)) { (void)hipFree(dscan); return fail(rcq); }
         uint32_t nd = 0;
         if (e1 == hipSuccess) e1 = hipMemcpyAsync(&nd, dscan + (nu - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s);
         if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);

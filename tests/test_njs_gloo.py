@@ -4,7 +4,11 @@ from their owners, the update with deferred row buffers R[it & 1] and the flush 
 by the PRODUCT's host helpers (dpr_shard_*, dpr_nj_key, dpr_record_reduce).  It must reproduce the single-rank oracle's
 merge log bit for bit, AND the storage a pull reads must be untouched by the owner's own update of the same iteration:
 every pull is repeated after the owner has finished its update and has to return the same bits (that is what makes one
-exchange per iteration enough; see the header of njs.hip)."""
+exchange per iteration enough; see the header of njs.hip).
+Round 4: the rank records are the 64-byte NjsRec of the product -- besides (q, key, d) a sequence word, the bits of the row sum
+U[x] of the previous merge AS THIS RANK DERIVED IT from the rows it pulled, and the rank's status; every rank compares the
+words of all ranks before it updates.  A rank that used a wrong pulled value (the fault hook) is found out one iteration
+later BY EVERY RANK, which is what turns a silently different merge log into DPR_ERR_COMM."""
 import os
 
 import numpy as np
@@ -17,7 +21,7 @@ from tests import _util
 from tests.test_sharded_gloo import _tree256
 
 
-def _worker(rank, world, port, D, out_q):
+def _worker(rank, world, port, D, out_q, fault=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -67,8 +71,11 @@ def _worker(rank, world, port, D, out_q):
     g = allgather(Uloc)
     U = np.array([g[owner(i)][L.dpr_shard_local_row(i, world)] for i in range(N)])
 
-    rec_t = np.dtype([("q", "f8"), ("key", "u8"), ("d", "f8"), ("pad", "u8")])
+    rec_t = np.dtype([("q", "f8"), ("key", "u8"), ("d", "f8"), ("seq", "u8"), ("ux", "u8"), ("status", "u8"), ("pad0", "u8"), ("pad1", "u8")])
+    assert rec_t.itemsize == 64
     merges = []
+    x_prev = -1
+    detected = None
     for it in range(N - 2):
         n = N - it
         r = float(n - 2)
@@ -88,15 +95,28 @@ def _worker(rank, world, port, D, out_q):
                         best = (q, k, d)
         rec = np.zeros(1, dtype=rec_t)
         rec["q"], rec["key"], rec["d"] = best
+        rec["seq"] = (1 << 32) | (it + 1)
+        rec["ux"] = np.float64(U[x_prev] if x_prev >= 0 else 0.0).view(np.uint64)      # this rank's view of the replicated state
         recs = np.concatenate([np.frombuffer(x.tobytes(), dtype=rec_t) for x in allgather(np.frombuffer(rec.tobytes(), dtype=np.uint8).copy())])
-        # ---- POST(it)
-        w = L.dpr_record_reduce(recs.ctypes.data, world)
+        # ---- POST(it): the exchange happened (sequence words) and the ranks agree on the replicated row sums
+        assert np.all(recs["seq"] == ((1 << 32) | (it + 1)))
+        if len(set(recs["ux"].tolist())) != 1:
+            detected = it
+            break
+        # (the winner is reduced from the first 32 bytes of every record, the product's NjRecord prefix)
+        recs32 = np.zeros(world, dtype=np.dtype([("q", "f8"), ("key", "u8"), ("d", "f8"), ("pad", "u8")]))
+        recs32["q"], recs32["key"], recs32["d"] = recs["q"], recs["key"], recs["d"]
+        w = L.dpr_record_reduce(recs32.ctypes.data, world)
         assert w >= 0
         key = int(recs["key"][w]); d = float(recs["d"][w])
         i, j = key & 0xFFFFFF, (key >> 24) & 0xFFFFFF
         x, y = min(i, j), max(i, j)
         last = n - 1
         rowx, rowy, rowl = pull(x, it, xp, yp), pull(y, it, xp, yp), pull(last, it, xp, yp)
+        pulled = (rowx.copy(), rowy.copy(), rowl.copy())
+        if fault is not None and fault == (it, rank):
+            k = next(i for i in range(n) if i not in (x, y))
+            rowx[k] = rowx[k] * 0.5 + 1.0e-3          # "a stale pull": this rank alone uses a wrong element of row x
         blX = (d + U[x] / r - U[y] / r) * 0.5
         blY = d - blX
         if blX < 0:
@@ -151,10 +171,16 @@ def _worker(rank, world, port, D, out_q):
         Unew[x] = _tree256(p256)
         U = Unew
         # ---- the owner's update of THIS iteration must not have touched what the other ranks pull in it
-        for slot, first in ((x, rowx), (y, rowy), (last, rowl)):
+        for slot, first in ((x, pulled[0]), (y, pulled[1]), (last, pulled[2])):
             again = pull(slot, it, xp, yp)
             assert np.array_equal(again[:n].view(np.uint64), first[:n].view(np.uint64)), ("pulled storage modified", it, slot)
         pend = (x, y)
+        x_prev = x
+    if fault is not None:
+        out_q.put((rank, detected))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # after the loop: flush the last buffers (njs_finish_kernel), then the final distance from rank owner(1)
     n = 2
     for wch, p in ((0, pend[0]), (1, pend[1])):
@@ -194,3 +220,21 @@ def test_one_exchange_protocol_model(orc, world, n):
     assert [m[2] for m in merges] == ref["bl_x"].tolist()
     assert [m[3] for m in merges] == ref["bl_y"].tolist()
     assert last_d == ref["last_d"]
+
+
+def test_one_exchange_protocol_model_detects_a_stale_pull():
+    """rank 1 of 3 uses a wrong element of a pulled row at iteration 12: its U[x] of that merge differs, the records of
+    iteration 13 carry three words of which one differs, and EVERY rank stops there (the product: DPR_ERR_COMM on every rank)"""
+    n, world, fault = 60, 3, (12, 1)
+    D = _util.random_additive_matrix(np.random.default_rng(5), n, zero_frac=0.2)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33600 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, D, q, fault)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == {0: 13, 1: 13, 2: 13}
