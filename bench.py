@@ -261,7 +261,7 @@ def cpu_baseline_rapidnj(dip, n, cores, budget_s=20.0):
     """Stronger CPU baseline: a from-scratch RapidNJ-style exact NJ (sorted rows + q_min pruning, OpenMP;
     oracle/rapidnj_baseline.c -- north_star names RapidNJ, which is not installed and cannot be fetched).
     Whole NJ run on the leading m tips of the GPU's matrix, m sized to the time budget; scaled to N with the
-    exponent measured between two smaller blocks.  Distances excluded."""
+    exponent validated once against the full run.  Distances excluded."""
     import psutil
     from tests import _orc
     orc = _orc.load()
@@ -275,32 +275,22 @@ def cpu_baseline_rapidnj(dip, n, cores, budget_s=20.0):
         log(f"[cpu_baseline_rapidnj] {D.shape[0]} tips: {dt:.2f} s")
         return dt
 
-    # (round 4: the exponent is measured between 4 000 and 8 000 tips and kept within 1.8 .. 2.6.  Between 3 000 and 6 000 it
-    #  came out anywhere from 2.2 to 3.0 from run to run -- a 4 x spread of the extrapolated figure, 48 .. 182 tips/s; the FULL
-    #  run at 30 000 tips takes 161 s on 16 threads = 186 tips/s, exponent 2.14 between 15 295 and 30 000 tips:
-    #  profiles/r4/cpu_baseline_validation.jsonl)
-    m0 = min(n, 4000)
-    m1 = min(n, 8000)
-    D1 = gpu_matrix_block(dip, m1)
-    t0 = run(np.ascontiguousarray(D1[:m0, :m0]))
-    t1 = run(D1) if m1 > m0 else t0
-    expo = max(1.8, min(2.6, np.log(max(t1, 1e-3) / max(t0, 1e-3)) / np.log(m1 / m0))) if m1 > m0 else 2.15
-    est_full = t1 * (n / m1) ** expo
+    # Round 4: ONE block as large as the budget allows, scaled with the exponent VALIDATED against the full run: 30 000 tips take
+    # 161 s on 16 threads (186 tips/s), 15 295 tips 38.2 s -> exponent 2.14 (profiles/r4/cpu_baseline_validation.jsonl).  Until round 3
+    # the exponent was measured in every run between two small blocks (3 000 / 6 000, then 4 000 / 8 000 tips): it came out anywhere
+    # from 2.2 to 3.0 on the shared host, a 4 x spread of the extrapolated figure (48 .. 182 tips/s).
+    expo = 2.14
+    m0 = min(n, 2000)
+    t0 = run(gpu_matrix_block(dip, m0))            # (also warms the OpenMP team)
     avail = psutil.virtual_memory().available
-    m = n
-    if est_full > budget_s:
-        m = int(m1 * (budget_s / max(t1, 1e-3)) ** (1.0 / expo))
+    m = min(n, int(m0 * (budget_s / max(t0, 1e-3)) ** (1.0 / expo)))
     m = min(m, int((0.4 * avail / 14.0) ** 0.5))       # matrix copy + working copy + sorted rows
-    m = max(m1, min(m, n))
-    if m > m1:
-        del D1
-        tm = run(gpu_matrix_block(dip, m))
-    else:
-        tm = t1
+    m = max(m0, min(m, n))
+    tm = run(gpu_matrix_block(dip, m)) if m > m0 else t0
     t_full = tm * (n / m) ** expo
     return {"value": n / t_full, "unit": "tips/s", "cores": cores, "kind": "rapidnj-style reimplementation (not the oracle)",
             "sample": f"exact NJ with RapidNJ's sorted-row search on the GPU's matrix, leading {m} of {n} tips in {tm:.1f} s "
-                      + ("(whole run)" if m == n else f"scaled by (N/m)^{expo:.2f} (exponent measured between {m0} and {m1} tips; validated once against the full 30 000-tip run: 186 tips/s, profiles/r4/cpu_baseline_validation.jsonl)")
+                      + ("(whole run)" if m == n else f"scaled by (N/m)^{expo:.2f} (exponent from the full 30 000-tip run, 161 s = 186 tips/s on 16 threads: profiles/r4/cpu_baseline_validation.jsonl)")
                       + "; distance stage excluded"}
 
 

@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <iosfwd>
+#include <functional>
 #include <string>
 #include <utility>
 #include <vector>
@@ -64,9 +65,13 @@ struct PackedSequences {
     WordVec flat;
     std::vector<uint64_t> off, lens;
 };
-// on_count(n) is called as soon as the number of records is known (the device thread reserves its matrices then)
+// on_count(n) is called as soon as the number of records is known (the device thread reserves its matrices then).
+// ids_of (optional) replaces the seeded shuffle: called once with the record names IN INPUT ORDER, it returns ids[r] = slot of
+// input record r (a permutation) -- the --add path puts the backbone's tips into the slots their tree indices name
+// (src/tree_generation.cu:271-282).
 void readSequencesPacked(const std::string& path, bool aligned, long long seed, PackedSequences& out,
-                         void (*on_count)(size_t n, void* user) = nullptr, void* user = nullptr);
+                         void (*on_count)(size_t n, void* user) = nullptr, void* user = nullptr,
+                         const std::function<std::vector<int>(const std::vector<std::string>&)>* ids_of = nullptr);
 
 // the per-sequence encoders of the general path (seqs[i] goes to slot ids[i]); the fast path must produce the same arrays
 void packAligned(const std::vector<std::string>& seqs, const std::vector<int>& ids, std::vector<uint64_t>& flat, int& seqLen);

@@ -328,7 +328,8 @@ static inline uint32_t pack2x16(const char* s)
 }  // namespace
 
 void readSequencesPacked(const std::string& path, bool aligned, long long seed, PackedSequences& out,
-                         void (*on_count)(size_t n, void* user), void* user)
+                         void (*on_count)(size_t n, void* user), void* user,
+                         const std::function<std::vector<int>(const std::vector<std::string>&)>* ids_of)
 {
     out = PackedSequences();
     TextSource src;
@@ -366,22 +367,26 @@ void readSequencesPacked(const std::string& path, bool aligned, long long seed, 
     st.push_back(n);
     out.numSequences = nrec;
     if (on_count) on_count(nrec, user);
-    const std::vector<int> ids = shuffledIds(nrec, seed);
-    // ---- names, body offsets and lengths
-    out.names.assign(nrec, std::string());
+    // ---- names (input order), body offsets and lengths
+    std::vector<std::string> in_names(nrec);
     std::vector<size_t> body(nrec), len(nrec);
     parallelFor(nrec, nt, [&](size_t r, unsigned) {
         size_t p = st[r] + 1;
         const size_t end = st[r + 1];
         size_t e = p;
         while (e < end && !std::isspace((unsigned char)data[e])) ++e;
-        out.names[(size_t)ids[r]].assign(data + p, e - p);
+        in_names[r].assign(data + p, e - p);
         while (e < end && data[e] != '\n') ++e;
         body[r] = e < end ? e + 1 : end;
         size_t l = 0;
         forEachSegment(data, body[r], end, [&](const char*, size_t k) { l += k; });
         len[r] = l;
     });
+    // ---- slots: the seeded shuffle, or the caller's rule (which sees the names)
+    const std::vector<int> ids = ids_of ? (*ids_of)(in_names) : shuffledIds(nrec, seed);
+    if (ids.size() != nrec) { std::fprintf(stderr, "ERROR: internal: slot map of %zu entries for %zu records\n", ids.size(), nrec); std::exit(1); }
+    out.names.assign(nrec, std::string());
+    for (size_t r = 0; r < nrec; ++r) out.names[(size_t)ids[r]] = std::move(in_names[r]);
     if (aligned) {
         size_t slot0 = 0;
         for (size_t r = 0; r < nrec; ++r) if (ids[r] == 0) slot0 = r;

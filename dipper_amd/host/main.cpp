@@ -253,39 +253,71 @@ int main(int argc, char** argv)
             std::cerr << "Adding new sequnces only supported with input aligned and unaligned sequences\n";
             return 1;
         }
-        std::vector<std::string> seqs, names, namesDump;
-        readSequences(inputFile, seqs, namesDump);
-        std::cerr << "Read " << seqs.size() << " sequences from input file.\n";
-        if (seqs.empty()) die("No sequences found in the input file.");
         std::string newickTree;
         std::getline(treeFileStream, newickTree);
-        Tree t(newickTree, namesDump.size());
-        std::cerr << "Tree loaded successfully with " << t.nodes.size() << " nodes and root " << t.nodes[(size_t)t.root].name << ".\n";
-        const size_t backboneSize = t.m_numLeaves, numSequences = seqs.size();
-        std::unordered_map<std::string, int> leafIdx;
-        for (const Node& nd : t.nodes) if (nd.children.empty()) leafIdx[nd.name] = nd.idx;
-        names.assign(backboneSize, "");
-        std::vector<int> ids(numSequences);
-        size_t found = 0;
-        for (size_t i = 0; i < numSequences; ++i) {
-            auto it = leafIdx.find(namesDump[i]);
-            if (it == leafIdx.end()) { names.push_back(namesDump[i]); ids[i] = (int)names.size() - 1; }
-            else { names[(size_t)it->second] = namesDump[i]; ids[i] = it->second; ++found; }
+        // The slot of a sequence is the index its name has in the backbone tree (Tree::Tree numbers the leaves in order of
+        // appearance, src/tree.cpp:341), queries follow in input order (src/tree_generation.cu:271-282).  Round 4: the
+        // records go through the packed reader of the other modes (indexed in the mapped text, packed in parallel straight
+        // into the device interface's arrays, HIP start-up on a helper thread meanwhile) -- the serial parser + per-sequence
+        // encoders cost 1.6 s of a 4.1 s command for 550 000 x 1 000 sites; FASTQ input still takes that route.
+        std::unique_ptr<Tree> tp;
+        size_t backboneSize = 0;
+        auto slots_of = [&](const std::vector<std::string>& namesDump, std::vector<std::string>* names_out) -> std::vector<int> {
+            std::cerr << "Read " << namesDump.size() << " sequences from input file.\n";
+            if (namesDump.empty()) die("No sequences found in the input file.");
+            tp.reset(new Tree(newickTree, namesDump.size()));
+            const Tree& t = *tp;
+            std::cerr << "Tree loaded successfully with " << t.nodes.size() << " nodes and root " << t.nodes[(size_t)t.root].name << ".\n";
+            backboneSize = t.m_numLeaves;
+            const size_t numSequences = namesDump.size();
+            std::unordered_map<std::string, int> leafIdx;
+            for (const Node& nd : t.nodes) if (nd.children.empty()) leafIdx[nd.name] = nd.idx;
+            std::vector<int> ids(numSequences);
+            size_t found = 0, next = backboneSize;
+            if (names_out) names_out->assign(backboneSize, "");
+            for (size_t i = 0; i < numSequences; ++i) {
+                auto it = leafIdx.find(namesDump[i]);
+                if (it == leafIdx.end()) { ids[i] = (int)next++; if (names_out) names_out->push_back(namesDump[i]); }
+                else { ids[i] = it->second; ++found; if (names_out) (*names_out)[(size_t)it->second] = namesDump[i]; }
+            }
+            if (found != backboneSize || next != numSequences) die("ERROR: every backbone tip needs exactly one sequence in the input file");
+            if (backboneSize >= numSequences) die("ERROR: no query sequences to add");
+            return ids;
+        };
+        if (access(inputFile.c_str(), R_OK) != 0) {
+            std::fprintf(stderr, "ERROR: cant open file: %s\n", inputFile.c_str());  // src/tree_generation.cu:138-141
+            return 1;
         }
-        if (found != backboneSize || names.size() != numSequences) die("ERROR: every backbone tip needs exactly one sequence in the input file");
-        if (backboneSize >= numSequences) die("ERROR: no query sequences to add");
+        AsyncDeviceContext adev(device);          // HIP start-up runs while the input is read
+        const std::function<std::vector<int>(const std::vector<std::string>&)> ids_fn =
+            [&](const std::vector<std::string>& nd) { return slots_of(nd, nullptr); };
+        PackedSequences packed;
+        readSequencesPacked(inputFile, params.in == "m", -1, packed, nullptr, nullptr, &ids_fn);
+        std::vector<std::string> seqs, names;
+        std::vector<int> ids;
+        if (!packed.ok) {                         // FASTQ: serial parser + the per-sequence encoders
+            std::vector<std::string> namesDump;
+            readSequences(inputFile, seqs, namesDump);
+            ids = slots_of(namesDump, &names);
+        } else {
+            names = std::move(packed.names);
+        }
+        const Tree& t = *tp;
+        const size_t numSequences = packed.ok ? packed.numSequences : seqs.size();
         auto output_ = open_out();
-        DeviceContext dev(device);
+        DeviceContext& dev = adev.get();
         KPlacementDeviceArrays kplacementDeviceArrays;
         if (params.in == "r") {
             MashDeviceArrays mashDeviceArrays;
             std::cerr << "Allocating Mash Device Arrays" << std::endl;
-            mashDeviceArrays.allocateDeviceArrays(dev, seqs, ids);
+            if (packed.ok) mashDeviceArrays.allocateDeviceArrays(dev, packed);
+            else mashDeviceArrays.allocateDeviceArrays(dev, seqs, ids);
             std::cerr << "Sketch Construction in Progress" << std::endl;
             mashDeviceArrays.sketchConstructionOnGpu(dev, params);
         } else {
             MSADeviceArrays msaDeviceArrays;
-            msaDeviceArrays.allocateDeviceArrays(dev, seqs, ids);
+            if (packed.ok) msaDeviceArrays.allocateDeviceArrays(dev, packed);
+            else msaDeviceArrays.allocateDeviceArrays(dev, seqs, ids);
         }
         kplacementDeviceArrays.allocateDeviceArrays(numSequences, (int)backboneSize);
         kplacementDeviceArrays.initializeDeviceArrays(t);
