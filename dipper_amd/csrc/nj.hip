@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kThreads) void nj_prepare_kernel(const NjState* __r
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * kThreads) {
         Ur[i] = U[i] / r;
-        KA[i] = nj_key_a(i, n);
+        KA[i] = nj_key_a_dev(i, n);
     }
 }
 
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kThreads) void nj_post_kernel(double* __restrict__ 
             D[y * ld + x] = val;
         }
     }
-    if (i < n1) KA[i] = nj_key_a(i, n1);
+    if (i < n1) KA[i] = nj_key_a_dev(i, n1);
     const double cs = block_tree256(val, s);
     if (threadIdx.x == 0) xpart[blockIdx.x] = cs;
 }
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(kThreads) void nj_update_sharded_kernel(
             if (own_y) D[ly * ld + x] = val;
         }
     }
-    if (i < n1) KA[i] = nj_key_a(i, n1);
+    if (i < n1) KA[i] = nj_key_a_dev(i, n1);
     const double cs = block_tree256(val, s);
     if (threadIdx.x == 0) xpart[blockIdx.x] = cs;
 }

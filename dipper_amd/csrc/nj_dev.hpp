@@ -9,6 +9,26 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 // ------------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------------
+// nj_key_a on the device.  nj_band (dpr_internal.hpp) divides 64-bit integers by a run-time divisor -- two software divisions
+// of ~80 instructions each, in every thread of every update role of the NJ loops, which run one wave per SIMD with nothing to
+// hide instruction latency (round 4).  Slot numbers and sizes are below 2^24 (the key gives them 24 bits) and a band index is
+// below 256, so: 32-bit operands, quotient from a float reciprocal, one exact correction step.  Same value as nj_band, always.
+__device__ __forceinline__ uint64_t nj_key_a_dev(int64_t i64, int64_t n64)
+{
+    const uint32_t i = (uint32_t)i64, n = (uint32_t)n64;
+    const uint32_t sz0 = n >> 8, rem = n & 255u, thr = (sz0 + 1u) * rem;
+    const bool lo = i < thr;
+    const uint32_t num = lo ? i : i - thr;
+    uint32_t den = lo ? sz0 + 1u : sz0;
+    den = den ? den : 1u;                                   // (only for slots >= n, whose keys nobody uses)
+    uint32_t q = (uint32_t)((float)num * __builtin_amdgcn_rcpf((float)den));
+    int32_t r = (int32_t)(num - q * den);
+    if (r < 0) { --q; r += (int32_t)den; }
+    if (r >= (int32_t)den) { ++q; }
+    const uint32_t band = lo ? q : rem + q;
+    return ((uint64_t)band << 56) | (uint64_t)i64;
+}
+
 __device__ __forceinline__ void best_update(double& bq, uint64_t& bk, double q, uint64_t k)
 {
     // strict '<' on q (NaN never wins), ties resolved by the reference's visiting order (key)

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(kThreads) void njs_post_kernel(NjsArgs a)
             st_sys_f64(a.D + shard_local_row(p, world) * a.ld + i, v);
         }
     }
-    if (i < n1) a.KA[i] = nj_key_a(i, n1);
+    if (i < n1) a.KA[i] = nj_key_a_dev(i, n1);
     const double cs = block_tree256(val, s);
     if (tid == 0) a.xpart[blockIdx.x] = cs;
 }
