@@ -50,39 +50,41 @@ static int64_t njp_big_p()
     static const int64_t v = std::getenv("DPR_NJ_BIG_P") ? std::atoll(std::getenv("DPR_NJ_BIG_P")) : 40000;
     return v;
 }
-// Round 4, small shape on ONE rank: njp_post3_kernel -- three light roles (update by slot, tests from the maxima of the previous
-// launch, maxima by position); its test blocks are ONE strip x 256 row groups (kNS = 1: ~250 blocks at 30 000 positions, every
-// lane one unit).  DPR_NJP_SMALL = post3 (default) | post2 (njp_post2_kernel<1>: 505 vs 475 ms at 30 000 tips -- its UM blocks,
-// 512 slots + 512 positions one behind the other, end 7 us after the launch's first stamp;
-// profiles/r4/phases_post2_small_shape_*.txt) | fused (round 2's kernel).
-// History of post3 (NOTES.md, round 4): its first version also replaced the list by one cell per unit that the scan blocks read
-// (no atomic at all; commit 9d05741): POST 8.27 -> 7.73 us per launch, but the scan that had to read and compact cells in every
-// one of its 256 blocks went 6.85 -> 8.29 us (profiles/r4/trace_summary_post3_cells_30k.txt) -- 507 vs 480 ms.  So the list
-// stays (one atomic append per listing BLOCK) and the scan kernel is round 3's.
-// The unit-sharded plan (several ranks) keeps the fused kernel in the small shape.
+// Round 4: njp_post2_kernel (light test blocks, maxima of the previous launch) can serve the small shape too: its test blocks
+// are then ONE strip x 256 row groups (kNS = 1: ~250 blocks at 30 000 positions, every lane one unit).  Bit-exact (every NJ
+// test passes on it), but MEASURED SLOWER at 30 000 tips: 505 vs 475 ms -- its UM blocks (512 slots + 512 positions each, the
+// position part and the slot part one behind the other) end 7 us after the launch's first stamp where the fused kernel's
+// update blocks end after 4.2 (profiles/r4/phases_post2_small_shape_*.txt); the test blocks (4.0 - 5.4 us) are not what
+// bounds the launch.  Opt-in: DPR_NJP_SMALL=post2.
+// (Also measured in round 4 and NOT kept -- commit 9d05741 holds it: njp_post3_kernel, the roles split again for the small shape
+//  (update by slot as in the fused kernel, light test blocks, maxima by position: 430 blocks instead of 1 018) and the list
+//  replaced by one cell per unit that the scan blocks read directly, i.e. no atomic at all.  Bit-exact on every NJ test and on
+//  the 10 000-tip parity runs, 507 ms against the fused kernel's 480 at 30 000 tips, 2.20 against 2.10 s at 100 000:
+//  profiles/r4/post3_cells_variants_*.txt, phases_post3_it*.txt -- its test blocks still end 6.1 us after the first stamp
+//  (start 1.1, select 2.0, seed candidates 4.4, tests 5.6): shorter blocks, the same number of dependent steps.
+//  Per kernel (profiles/r4/trace_summary_post3_cells_30k.txt): POST 8.27 -> 7.73 us, but SCAN 6.85 -> 8.29 us -- reading and
+//  compacting cells in all 256 scan blocks costs more than the atomics it removes.  Second version, commit 03fdc34: the same
+//  three roles with the atomic list (round 3's scan kernel) and a seed bound WITHOUT gathers -- the candidate's old q plus
+//  6 eabs / (n - 3), which is rigorous (derivation in that commit's kernel; fixed slacks below it give a different merge log,
+//  profiles/r4/seed_slack_listing_30k.txt) and lists 16 % more units: 482 vs 479 ms, POST 8.02 us, SCAN 7.26 us.  Its test
+//  blocks wait 1.6 us for loads issued before the winner is known (unit bounds, maxima): a dependent step costs ~1.5 us in
+//  these launches, whatever it fetches, because every kernel starts with all eight L2s cold.)
 static bool njp_post2_on()
 {
     static const bool on = !(std::getenv("DPR_NJP_POST2") && std::atoi(std::getenv("DPR_NJP_POST2")) == 0);
     return on;
 }
-static int njp_small_kind()     // 0 fused, 2 post2<1>, 3 post3
+static bool njp_small_post2()
 {
-    static const int k = [] {
-        const char* e = std::getenv("DPR_NJP_SMALL");
-        if (!njp_post2_on()) return 0;
-        if (e && std::string(e) == "fused") return 0;
-        if (e && std::string(e) == "post2") return 2;
-        return 3;
-    }();
-    return k;
+    static const bool on = njp_post2_on() && std::getenv("DPR_NJP_SMALL") && std::string(std::getenv("DPR_NJP_SMALL")) == "post2";
+    return on;
 }
-static int njp_tg_small(bool single)
+static int njp_tg_small()
 {
-    static const int env = std::getenv("DPR_NJ_TG_SMALL") ? std::atoi(std::getenv("DPR_NJ_TG_SMALL")) : 0;
-    const int v = env ? env : ((single && njp_small_kind() != 0) ? 256 : 64);
+    static const int v = std::getenv("DPR_NJ_TG_SMALL") ? std::atoi(std::getenv("DPR_NJ_TG_SMALL")) : (njp_small_post2() ? 256 : 64);
     return v == 32 || v == 128 || v == 256 ? v : 64;
 }
-static int njp_tg(int64_t P, bool single) { return P < njp_big_p() ? njp_tg_small(single) : 256; }
+static int njp_tg(int64_t P) { return P < njp_big_p() ? njp_tg_small() : 256; }
 // Strips per test block.  In the small shape a test block is one strip x 64 row groups (the post kernel is a chain of
 // dependent round trips there and all blocks are resident at once).  In the large shape one strip x 256 groups left
 // ~2 900 blocks of ~160 registers per thread, i.e. several rounds of resident blocks, each paying the whole chain (select,
@@ -95,7 +97,7 @@ static int njp_big_ns()
     static const int v = std::getenv("DPR_NJ_BIG_NS") ? std::atoi(std::getenv("DPR_NJ_BIG_NS")) : kBigNS;
     return v == 2 ? v : kBigNS;
 }
-static int njp_ns(int64_t P, bool single) { return (njp_tg(P, single) != 256 || P < njp_big_p()) ? 1 : njp_big_ns(); }
+static int njp_ns(int64_t P) { return (njp_tg(P) != 256 || P < njp_big_p()) ? 1 : njp_big_ns(); }
 // strips that hold a valid unit for some group of the row block [g0, g0 + tg)
 __host__ __device__ inline int64_t njp_strips_of_rows(int64_t g0, int64_t tg, int64_t P)
 {
@@ -143,7 +145,7 @@ int njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world)
     const int64_t G16 = (P + kUR - 1) / kUR;
     if (strip < 0 || group < 0 || group >= G16 || group < 32 * strip || strip * kTileCols >= P - 1 || world < 1) return -1;
     int64_t t = 0;
-    const int64_t tg = njp_tg(P, world <= 1), ns = njp_ns(P, world <= 1);
+    const int64_t tg = njp_tg(P), ns = njp_ns(P);
     if (ns == 1) {
         for (int64_t c = 0; c < strip; ++c) t += (G16 - 32 * c + tg - 1) / tg;     // test blocks of the strips before
         t += (group - 32 * strip) / tg;
@@ -267,7 +269,6 @@ struct NjpArgs {
     unsigned long long* dbg; int64_t dbg_it;     // DPR_NJ_PHASES=<iteration>: per-block phase stamps of that iteration (profiles/nj_phases.py)
     // njp_post2_kernel (large shape): what its producer blocks hand to its test blocks
     void* t2_hdr; double* t2_rmax; double* t2_cmax; double* t2_colmin; double* t2_rowmin; double* t2_cmin;
-    double exp_slack;      // experiment (DPR_NJP_SEED_SLACK >= 0): the fused kernel's seed bound = old q of the candidate + this slack
 };
 
 // phase stamps (debug; 100 MHz wall clock): thread 0 of every block, kernel k (0 scan, 1 post), slot j
@@ -809,9 +810,6 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
             const double ub = nj_unew(uib, xb, yb, nj_val(xb, yb, d)) / r1;
             const double qk = fmin((cand.d - ua) - ub, (cand.d - ub) - ua);
             qc = qk == qk ? qk : qc;
-            // experiment: what a seed bound WITHOUT gathers would list -- the candidate's old q plus a slack that covers what one
-            // merge can add to it (round 4, NOTES.md): only the listing is of interest here, the gathers above still run
-            if (a.exp_slack >= 0.0 && qc < PINF) qc = cand.q + a.exp_slack;
         }
     }
     NJP_STAMP(1, 3, true);
@@ -1411,389 +1409,10 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// POST(it), SMALL shape on one rank (round 4): njp_post3_kernel.
-// What round 3's profile of the fused kernel showed at 30 000 tips (profiles/r4/phases_fused_it*.txt, trace_summary_baseline_30k):
-// 10 - 11 us per launch while an epoch is young (1 006 blocks, four resident per CU: every block's select, row-sum recomputation
-// and LDS round trips queue behind its neighbours'), 6.7 us with 73 blocks late in the run; its test blocks end 5.0 us (median) /
-// 6.5 us (max) after the launch's first stamp, its update blocks after 4.2.  tools/lat_probe.hip says what the links of those
-// chains cost on an idle chip: L2 hit 90 ns, HBM 380 - 480 ns, store + drain 130 (write-through 270) ns, an atomicAdd that returns
-// 350 ns alone but 744 / 3 045 ns with 64 / 256 workgroups on the same word.  So this kernel keeps the block count near the
-// CU count and gives every block ONE role with the shortest chain that role allows:
-//   U blocks (first: the longest chain): the update by reference SLOT, 256 slots each -- njp_post_kernel's update role verbatim
-//     (new row sums, the new node's row into the row buffer and its column into the matrix, keys, relabel, log, state, chunk sums);
-//   T blocks: one strip x 256 row groups, one lane per unit, njp_post2_kernel's test role: maxima of the PREVIOUS launch with the
-//     monotonicity proof (header of njp_post2_kernel), seed bound from 16 re-evaluated candidates per block, coarse cell -- but every
-//     load whose address does not need the winner travels with the first round trips (unit bounds, maxima, the minima of the
-//     node leaving quarantine); ONE list append per listing block;
-//   M blocks: 512 positions each, read-only apart from a few words: the maxima / minima the next launch's T blocks need.
-// ~430 blocks at 30 000 positions (118 + 250 + 59) instead of 1 018, ~170 late in the run.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void njp_post3_kernel(NjpArgs a)
-{
-    constexpr int kTG = 256;
-    __shared__ double s[kThreads];
-    __shared__ double sq[kThreads / 64], sdd[kThreads / 64];
-    __shared__ uint64_t sk[kThreads / 64], spp[kThreads / 64];
-    __shared__ double sseed[kThreads / 64], srC[kThreads / 64], scm[4];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int bx = (int)blockIdx.x;
-    const bool urole = bx < a.nupd;
-    const bool trole = !urole && bx < a.nupd + a.ntest;
-    const bool mrole = !urole && !trole;
-    const int ubi = bx, tb = bx - a.nupd, mb = bx - a.nupd - a.ntest;
-    Post2Hdr* hdr = reinterpret_cast<Post2Hdr*>(a.t2_hdr);
-    const double NINF = -__builtin_inf(), PINF = __builtin_inf();
-
-    // hop 1: state line, scan records, and what each role can address without knowing the iteration or the winner
-    const int64_t it = a.st->itb;
-    const int64_t limit = a.st->it_limit, N = a.st->N;
-    const int32_t pn0 = a.st->pnew[0], pn1 = a.st->pnew[1];
-    const int64_t pz = (int64_t)((it & 1) ? pn1 : pn0);          // node leaving quarantine (its U was stored by SCAN(it))
-    const int64_t P = a.P;
-    const int64_t G16 = (P + kUR - 1) / kUR;
-    const int nrec_all = a.urecs + a.nrb;
-    NjRecord r0; r0.q = 10000.0; r0.key = ~0ull; r0.d = 0; r0.pad = 0;
-    constexpr int kMine = 5;
-    NjRecord mine[kMine] = { r0, r0, r0, r0, r0 };
-#pragma unroll
-    for (int k = 0; k < kMine; ++k) {
-        const int idx = tid + k * kThreads;
-        if (idx < nrec_all) mine[k] = a.partials[idx];
-    }
-    const int nseed_rows = a.nrb < kThreads / 2 ? a.nrb : kThreads / 2;
-    const int nseed_units = kThreads - nseed_rows;
-    const bool seed_is_unit = tid < nseed_units;
-    NjRecord cand = r0;
-    int cb0 = 0;
-    int64_t g0 = 0;
-    const int64_t i = (int64_t)ubi * kThreads + tid;             // U: reference slot
-    int64_t p = -1;
-    const int64_t p0 = (int64_t)mb * kTileCols + 2 * tid;        // M: first of this thread's two positions
-    if (trole) {
-        if (!seed_is_unit) cand = a.partials[a.urecs + (tid - nseed_units)];
-        else if (tid < a.urecs) cand = a.partials[tid];
-        cb0 = a.blk_cb[tb];
-        g0 = (int64_t)a.blk_g0[tb];
-    } else if (urole) {
-        p = (int64_t)a.pos_of_slot[i];                           // (the slot arrays are padded past N)
-    }
-    // hop 2: needs the iteration index (parity of the double buffers) -- it travels behind the state line while the records arrive
-    const int par = (int)(it & 1);
-    const double* __restrict__ Uc = a.U + (it & 1) * a.vstride;
-    double* __restrict__ Un = a.U + ((it + 1) & 1) * a.vstride;
-    const int64_t GS = 32 * ((P + kTileCols - 1) / kTileCols + 2), SS4 = 4 * ((P + kTileCols - 1) / kTileCols + 2);
-    // (the scan of this iteration wrote min(listed, grid) unit records)
-    const unsigned long long cl0 = a.cnt[0], cl1 = a.cnt[1], cl2 = a.cnt[2];
-    const int m3 = (int)(it % 3);
-    const unsigned long long cnt_raw = m3 == 0 ? cl0 : m3 == 1 ? cl1 : cl2;
-    const int64_t uvalid = (int64_t)(cnt_raw < (unsigned long long)a.urecs ? cnt_raw : (unsigned long long)a.urecs);
-    const double emin = dec_f64(hdr->min_enc), eabs = dec_f64(hdr->maxabs_enc);
-    double up = 0.0;                                             // U
-    v2d uc; uc.x = 0.0; uc.y = 0.0;                              // M
-    const int64_t g = g0 + tid;                                  // T: this lane's row group
-    const bool have_g = trole && g < G16;
-    const bool have = have_g && g >= 32 * (int64_t)cb0;          // ... and its unit (strip cb0, group g) exists
-    double uz = NINF, rmaxU = NINF, cmU = NINF, cmin = NINF, newminA_pf = PINF;
-    double colmin_pf[4] = { PINF, PINF, PINF, PINF };
-    ulonglong2 um0 = make_ulonglong2(0ull, 0ull), um1 = um0;
-    const int64_t gz0 = pz >= 0 ? pz / kUR : -1, cbz0 = pz >= 0 ? pz / kTileCols : -1;
-    const bool gz_here0 = trole && pz >= 0 && gz0 >= g0 && gz0 < g0 + kTG;      // block-uniform
-    const bool pz_strip0 = trole && pz >= 0 && cbz0 == (int64_t)cb0;             // block-uniform
-    if (urole) up = (i < N && p >= 0) ? Uc[p] : 0.0;
-    if (mrole) uc = *reinterpret_cast<const v2d*>(Uc + p0);
-    if (trole) {
-        if (pz >= 0) uz = Uc[pz];
-        if (have_g) rmaxU = a.t2_rmax[par * GS + g];
-        if (tid < 4) cmU = a.t2_cmax[par * SS4 + 4 * cb0 + tid];
-        cmin = a.t2_cmin[tb];
-        if (have) {
-            const unsigned long long* upq = a.umin + ((int64_t)cb0 * G16 + g) * 4;
-            um0 = *reinterpret_cast<const ulonglong2*>(upq); um1 = *reinterpret_cast<const ulonglong2*>(upq + 2);
-        }
-        // minima of the row of the node leaving quarantine (stored by the M blocks of the previous launch): only the blocks it crosses
-        if (pz_strip0 && have_g) newminA_pf = a.t2_rowmin[par * GS + g];
-        if (gz_here0 && g == gz0) {
-#pragma unroll
-            for (int w = 0; w < 4; ++w) colmin_pf[w] = a.t2_colmin[par * SS4 + 4 * cb0 + w];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < kMine; ++k) {
-        const int idx = tid + k * kThreads;
-        if (idx >= uvalid && idx < a.urecs) mine[k] = r0;       // not written by this iteration's scan
-    }
-    if (a.st->status != 0 || it >= limit) return;
-    const int64_t n = N - it;
-    if (n < 3) return;
-    if (urole && (int64_t)ubi * kThreads >= n) return;
-    NJP_STAMP(1, 0, false);
-    NJP_STAMP(1, 1, true);
-
-    // ---- select (thrust::min_element, src/neighborJoining.cu:214)
-    double bq = 10000.0, d = 0.0; uint64_t bk = ~0ull, bp = 0;
-    const int nmine = (nrec_all + kThreads - 1) / kThreads;
-#pragma unroll
-    for (int k = 0; k < kMine; ++k)
-        if (k < nmine) best_update4(bq, bk, bp, d, mine[k].q, mine[k].key, mine[k].pad, mine[k].d);
-    for (int64_t idx = tid + kMine * kThreads; idx < nrec_all; idx += kThreads)
-        if (idx < uvalid || idx >= a.urecs) best_update4(bq, bk, bp, d, a.partials[idx].q, a.partials[idx].key, a.partials[idx].pad, a.partials[idx].d);
-    wave_best4(bq, bk, bp, d);
-    if (lane == 0) { sq[tid >> 6] = bq; sk[tid >> 6] = bk; spp[tid >> 6] = bp; sdd[tid >> 6] = d; }
-    __syncthreads();
-    bq = sq[0]; bk = sk[0]; bp = spp[0]; d = sdd[0];
-#pragma unroll
-    for (int w = 1; w < kThreads / 64; ++w) best_update4(bq, bk, bp, d, sq[w], sk[w], spp[w], sdd[w]);
-    NJP_STAMP(1, 2, false);
-    const int64_t last = n - 1;
-    if (bk == ~0ull) {
-        if (urole && i == last) a.st->status = 1;
-        return;
-    }
-    const int64_t ki = (int64_t)(bk & 0xFFFFFFull), kj = (int64_t)((bk >> 24) & 0xFFFFFFull);
-    const int64_t pi = (int64_t)(bp & 0xffffffffull), pj = (int64_t)(bp >> 32);
-    const int64_t x = ki < kj ? ki : kj, y = ki < kj ? kj : ki;
-    const int64_t px = ki < kj ? pi : pj, py = ki < kj ? pj : pi;
-    const int64_t n1 = n - 1;
-    const double r1 = (double)(n1 - 2);
-    const double* __restrict__ rowx = a.D + px * a.ld;
-    const double* __restrict__ rowy = a.D + py * a.ld;
-
-    if (urole) {
-        // ------------------------------------------------------------------------------ U: njp_post_kernel's update role
-        double* __restrict__ Rw = a.R + (it & 1) * a.vstride;
-        double val = 0.0;
-        if (i < n) {
-            if (i == last) {
-                // single writer of the log and the state (reads U[px], U[py] of the current buffer)
-                const double r = (double)(n - 2);
-                double blX = (d + Uc[px] / r - Uc[py] / r) * 0.5;
-                double blY = d - blX;
-                if (blX < 0) { blY += blX; blX = 0; }
-                if (blY < 0) { blX += blY; blY = 0; }
-                a.log_x[it] = (int32_t)x; a.log_y[it] = (int32_t)y; a.log_bx[it] = blX; a.log_by[it] = blY;
-                a.st->x = (int32_t)x; a.st->y = (int32_t)y; a.st->d = d; a.st->q = bq;
-                a.st->n = n1; a.st->it = it + 1;
-                a.st->pnew[(it + 1) & 1] = (int32_t)px;
-                a.U[(it & 1) * a.vstride + py] = __builtin_nan("");       // (this thread's own store, behind its read of U[py] above)
-                // list counter of the scan after next (nobody reads or appends to it in this launch)
-                a.st->cnt_list[(it + 2) % 3] = 0ull;
-            }
-            int64_t new_slot = i;
-            if (i != x && i != y) {
-                const double dxi = rowx[p], dyi = rowy[p];
-                val = nj_val(dxi, dyi, d);
-                const double u = nj_unew(up, dxi, dyi, val);   // i == last: "U[y] = U[last] + ..." of the reference's tail
-                Un[p] = u;
-                a.Ur[p] = u / r1;
-                Rw[p] = val;                   // row of the new node: into the matrix by the next scan's new-row blocks
-                if (a.flags & 1) a.D[p * a.ld + px] = val;
-                else __hip_atomic_store(a.D + p * a.ld + px, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (i == last) {           // relabel: the node of the last slot now lives in slot y
-                    new_slot = y;
-                    a.slot_of_pos[p] = (int32_t)y;
-                    a.pos_of_slot[y] = (int32_t)p;
-                }
-            } else if (i == y) {
-                a.Ur[py] = __builtin_nan("");   // dead
-                Un[py] = __builtin_nan("");
-                a.slot_of_pos[py] = -1;
-                Rw[py] = 0.0;
-                new_slot = -1;
-            } else {
-                a.Ur[px] = __builtin_nan("");   // quarantine until SCAN(it + 1) has finished its row sum
-                Rw[px] = 0.0;                  // diagonal
-            }
-            if (new_slot >= 0) { a.KA[p] = nj_key_a_dev(new_slot, n1); a.KB[p] = nj_key_b(new_slot); }
-        }
-        NJP_STAMP(1, 3, false);
-        const double cs = block_tree256_lane0(val, s);
-        if (tid == 0) a.xpart[ubi] = cs;
-        NJP_STAMP(1, 6, true);
-        if (a.dbg != nullptr && it == a.dbg_it && tid == 0 && bx < 2048) a.dbg[(2048 + bx) * 8 + 7] = 1ull;
-        return;
-    }
-
-    if (mrole) {
-        // ------------------------------------------------------------------------------ M: maxima / minima for POST(it + 1)
-        // (njp_post2_kernel's M part without the update stores: the U blocks above write the same row sums through pos_of_slot)
-        const v2d dx = *reinterpret_cast<const v2d*>(rowx + p0), dy = *reinterpret_cast<const v2d*>(rowy + p0);
-        NJP_STAMP(1, 3, true);
-        const bool live0 = (uc.x == uc.x) & (p0 != px) & (p0 != py) & (p0 < P);
-        const bool live1 = (uc.y == uc.y) & (p0 + 1 != px) & (p0 + 1 != py) & (p0 + 1 < P);
-        const double v0 = nj_val(dx.x, dy.x, d), v1 = nj_val(dx.y, dy.y, d);       // the new node's row
-        const double un0 = nj_unew(uc.x, dx.x, dy.x, v0);
-        const double un1 = nj_unew(uc.y, dx.y, dy.y, v1);
-        const double m2 = fmax(live0 ? un0 : NINF, live1 ? un1 : NINF);
-        double gm = m2;                                                   // group of 16 positions = 8 lanes
-        gm = fmax(gm, __shfl_xor(gm, 1, 64)); gm = fmax(gm, __shfl_xor(gm, 2, 64)); gm = fmax(gm, __shfl_xor(gm, 4, 64));
-        const double cm = wave_fmax(m2);                                  // sub-strip of 128 positions = this wave
-        const int64_t gidx = p0 >> 4;
-        const int wq = 1 - par;
-        if ((tid & 7) == 0) a.t2_rmax[wq * GS + gidx] = gm;                 // undivided
-        if (lane == 0) a.t2_cmax[wq * SS4 + 4 * mb + (tid >> 6)] = cm;
-        const double c2 = fmin((live0 & (p0 < px)) ? v0 : PINF, (live1 & (p0 + 1 < px)) ? v1 : PINF);
-        double r2 = fmin((live0 & (p0 > px)) ? v0 : PINF, (live1 & (p0 + 1 > px)) ? v1 : PINF);
-        r2 = fmin(r2, __shfl_xor(r2, 1, 64)); r2 = fmin(r2, __shfl_xor(r2, 2, 64)); r2 = fmin(r2, __shfl_xor(r2, 4, 64));
-        const double cz = wave_fmin(c2);
-        if ((tid & 7) == 0) a.t2_rowmin[wq * GS + gidx] = r2;
-        if (lane == 0) a.t2_colmin[wq * SS4 + 4 * mb + (tid >> 6)] = cz;
-        double vmin = fmin(live0 ? v0 : PINF, live1 ? v1 : PINF);
-        double vabs = fmax(live0 ? fabs(v0) : 0.0, live1 ? fabs(v1) : 0.0);
-        vmin = wave_fmin(vmin); vabs = wave_fmax(vabs);
-        if (lane == 0) njp_note_range(&hdr->min_enc, vmin, vabs);
-        NJP_STAMP(1, 6, true);
-        if (a.dbg != nullptr && it == a.dbg_it && tid == 0 && bx < 2048) a.dbg[(2048 + bx) * 8 + 7] = 2ull;
-        return;
-    }
-
-    // ---------------------------------------------------------------------------------- T: tests of iteration it + 1
-    // seed bound: of each group of 16 lanes the candidate with the smallest old q (pairs touching x or y left out) is re-evaluated
-    // with the row sums after this merge (see njp_post2_kernel)
-    double qc = PINF;
-    {
-        if (seed_is_unit && tid >= uvalid) cand.key = ~0ull;             // not written by this iteration's scan
-        int64_t ci = -1, cj = -1;
-        if (cand.key != ~0ull) {
-            ci = (int64_t)(cand.pad & 0xffffffffull); cj = (int64_t)(cand.pad >> 32);
-            if (!(ci < P && cj < P)) ci = -1;
-        }
-        const bool livec = ci >= 0 && ci != px && cj != px && ci != py && cj != py;
-        if (!(a.flags & 64)) {
-            // SEED BOUND WITHOUT GATHERS (default; DPR_NJP_FLAGS=64: the gathered one below).  The record of a pair (i, j) that this
-            // merge does not touch holds d = D[i][j] and q = fl(fl(d - Ur_i) - Ur_j), Ur = fl(U / r), r = n - 2.  After the merge
-            //   U'_a = fl(U_a + t_a),  t_a = fl(fl(-dxa - dya) + val_a) = -(dxa + dya) / 2 - d_w / 2 >= -1.5 E   (exact value; d_w the
-            //   winner's distance, E >= every |entry|: E = 2 eabs from the range header) -- so U'_a >= U_a - T2, T2 = 1.5 E + rounding,
-            //   Ur'_a = fl(U'_a / (r - 1)) >= (U_a - T2) / (r - 1) - rounding, and with S = Ur_i + Ur_j:
-            //   Ur'_i + Ur'_j >= S r / (r - 1) - 2 T2 / (r - 1) >= Sx - 2 T2 / (r - 1),  Sx = S if S >= 0, else S r / (r - 1);
-            //   q' = fl(fl(d - Ur'_i) - Ur'_j) <= d - Sx + 2 T2 / (r - 1) + rounding,  and S >= (d - q) - rounding.
-            // Every rounding term is < 2^-50 of the magnitudes involved; 2^-44 of their sum is added.  The bound is the OLD q plus
-            // 6 eabs / (n - 3) (3.2e-7 .. 6.4e-7 at 30 000 tips on the bench's input, growing as n shrinks): it lists ~10 % more
-            // units than the gathered seeds (profiles/r4/seed_slack_listing_30k.txt) and takes the six gathers per candidate -- one
-            // whole dependent round trip -- out of every test block.
-            if (livec) {
-                const double r = (double)(n - 2);
-                const double T2 = 3.0 * eabs * (1.0 + 0x1p-30) + eabs * 0x1p-45;
-                const double S = (cand.d - cand.q) - 0x1p-45 * (fabs(cand.d) + fabs(cand.q));
-                const double Sx = S < 0.0 ? S * (r / r1) * (1.0 + 0x1p-50) : S;
-                const double B = (cand.d - Sx) + 2.0 * T2 / r1;
-                qc = B + 0x1p-44 * (fabs(cand.d) + fabs(Sx) + T2 / r1);
-            }
-        } else {
-        const double oq = livec ? cand.q : PINF;
-        double gmin = oq;
-        gmin = fmin(gmin, dpp_f64<kDppXor1>(gmin));
-        gmin = fmin(gmin, dpp_f64<kDppXor2>(gmin));
-        gmin = fmin(gmin, dpp_f64<kDppHalfMirror>(gmin));
-        gmin = fmin(gmin, dpp_f64<kDppMirror>(gmin));
-        const unsigned long long hit = __builtin_amdgcn_ballot_w64(livec & (oq == gmin));
-        const int gbase = lane & ~15;
-        const unsigned long long mine_g = (hit >> gbase) & 0xFFFFull;
-        const bool lead = livec && mine_g != 0ull && (lane - gbase) == (int)__builtin_ctzll(mine_g);
-        if (lead) {
-            const double sUa = Uc[ci], sUb = Uc[cj];
-            const double xa = rowx[ci], ya = rowy[ci], xb = rowx[cj], yb = rowy[cj];
-            const double ua = nj_unew(sUa, xa, ya, nj_val(xa, ya, d)) / r1;
-            const double ub = nj_unew(sUb, xb, yb, nj_val(xb, yb, d)) / r1;
-            const double qk = fmin((cand.d - ua) - ub, (cand.d - ub) - ua);
-            qc = qk == qk ? qk : qc;
-        }
-            }
-    }
-    qc = wave_fmin(qc);
-    if (lane == 0) sseed[tid >> 6] = qc;
-    NJP_STAMP(1, 3, true);
-    // upper bounds of the maxima after this merge (header of njp_post2_kernel)
-    const double slack = emin >= 0.0 ? 0.0 : (3.0 * -emin) * (1.0 + 0x1p-30) + eabs * 0x1p-47;
-    const bool zlive = pz >= 0 && pz != px && pz != py;                        // the node leaving quarantine stays
-    uz = (uz == uz) ? uz : PINF;
-    const int64_t gz = zlive ? gz0 : -1;
-    const int64_t sz = zlive ? pz / (kTileCols / 4) : -1;                      // its sub-strip (global index)
-    double rU = rmaxU;
-    if (have_g && g == gz) rU = fmax(rU, uz);
-    const double rmax = (rU + slack) / r1;                                     // (-inf stays -inf)
-    if (tid < 4) {
-        double cU = cmU;
-        if (4 * (int64_t)cb0 + tid == sz) cU = fmax(cU, uz);
-        scm[tid] = (cU + slack) / r1;
-    }
-    const bool gz_here = zlive && gz_here0;
-    const bool pz_strip = zlive && pz_strip0;                                  // block-uniform
-    const int wpz = zlive ? (int)((pz % kTileCols) / (kTileCols / 4)) : -1;
-    double rC = wave_fmax(rmax);
-    if (lane == 0) srC[tid >> 6] = rC;
-    __syncthreads();
-    const double bound = fmin(fmin(sseed[0], sseed[1]), fmin(sseed[2], sseed[3]));
-    const double cm4[4] = { scm[0], scm[1], scm[2], scm[3] };
-    {
-        rC = fmax(fmax(srC[0], srC[1]), fmax(srC[2], srC[3]));
-        const double cC = fmax(fmax(cm4[0], cm4[1]), fmax(cm4[2], cm4[3]));
-        const double lbC = fmin((cmin - rC) - cC, (cmin - cC) - rC);
-        // the node leaving quarantine lowers unit bounds of this cell: those lanes must run (block-uniform decision)
-        if (!gz_here && !pz_strip && !(lbC <= bound) && !(a.flags & 4)) {
-            NJP_STAMP(1, 6, false);
-            if (a.dbg != nullptr && it == a.dbg_it && tid == 0 && bx < 2048) a.dbg[(2048 + bx) * 8 + 7] = 3ull;
-            return;
-        }
-        NJP_STAMP(1, 4, false);
-    }
-    double mymin = PINF;           // minimum of this lane's sub-unit bounds after the fold: the cell's new coarse bound
-    int submask = 0;
-    {
-        unsigned long long* up4 = a.umin + ((int64_t)cb0 * G16 + (have ? g : 0)) * 4;
-        double u4[4] = { PINF, PINF, PINF, PINF };
-        if (have) { u4[0] = dec_f64(um0.x); u4[1] = dec_f64(um0.y); u4[2] = dec_f64(um1.x); u4[3] = dec_f64(um1.y); }
-        const double newminA = pz_strip ? newminA_pf : PINF;
-        if (have) {
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const double cmw = cm4[w];
-                double nm = (gz_here && g == gz) ? colmin_pf[w] : PINF;      // the unit (this strip, group of pz)
-                if (pz_strip && w == wpz) nm = fmin(nm, newminA);
-                if (nm < u4[w]) {                          // persist the lowered bound (this lane is the unit's only writer here)
-                    u4[w] = nm;
-                    up4[w] = enc_f64(nm);
-                }
-                mymin = fmin(mymin, u4[w]);
-                const double lb = fmin((u4[w] - rmax) - cmw, (u4[w] - cmw) - rmax);
-                if ((cmw > NINF) && (lb <= bound)) submask |= 1 << w;
-            }
-        }
-        if (!(have && (rmax > NINF))) submask = 0;
-    }
-    NJP_STAMP(1, 5, false);
-    // ONE list append per block (tools/lat_probe.hip: an atomicAdd that returns costs 350 ns alone and 12 ns more for every
-    // other workgroup on the word; ~50 blocks list per launch)
-    __shared__ int s_wcnt[kThreads / 64];
-    __shared__ unsigned long long s_base;
-    const unsigned long long lmask = __ballot(submask != 0);
-    mymin = wave_fmin(mymin);
-    __syncthreads();               // (srC: the coarse maxima above were read by every thread)
-    if (lane == 0) { srC[tid >> 6] = mymin; s_wcnt[tid >> 6] = __popcll(lmask); }
-    __syncthreads();
-    const int c0 = s_wcnt[0], c1 = s_wcnt[1], c2 = s_wcnt[2], c3 = s_wcnt[3];
-    if (tid == 0) {
-        a.t2_cmin[tb] = fmin(fmin(srC[0], srC[1]), fmin(srC[2], srC[3]));
-        if (c0 + c1 + c2 + c3 > 0) s_base = atomicAdd(&a.cnt[(it + 1) % 3], (unsigned long long)(c0 + c1 + c2 + c3));
-    }
-    if (c0 + c1 + c2 + c3 > 0) {                      // block-uniform
-        __syncthreads();
-        const int wv = tid >> 6;
-        const unsigned long long base = s_base + (unsigned long long)(wv > 0 ? c0 : 0) + (unsigned long long)(wv > 1 ? c1 : 0) + (unsigned long long)(wv > 2 ? c2 : 0);
-        if (submask != 0)
-            a.list[base + __popcll(lmask & ((1ull << lane) - 1ull))] = (int32_t)(((uint32_t)submask << 28) | ((uint32_t)cb0 << 18) | (uint32_t)g);
-    }
-    NJP_STAMP(1, 6, true);
-    if (a.dbg != nullptr && it == a.dbg_it && tid == 0 && bx < 2048) a.dbg[(2048 + bx) * 8 + 7] = 4ull;
-}
-
-// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static int64_t round_up16(int64_t v) { return (v + 15) / 16 * 16; }
 static bool njp_use_post2(const NjPruned& q);
-static bool njp_use_post3(const NjPruned& q);
-static bool njp_uses_t2(const NjPruned& q);
 // (the scan grid, the graph length and the debug buffer are per-context state of NjPruned: two contexts of one process
 // may run different plans, from different host threads)
 // the stamps of the last context that ran with DPR_NJ_PHASES (debug hook njp_phase_stamps; a process-wide pointer to a
@@ -1809,19 +1428,19 @@ struct SlabPlan {
     int64_t list_stride;
 };
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
-static int64_t prep_blocks(int64_t P, bool single, std::vector<int32_t>* hcb, std::vector<int32_t>* hg0)
+static int64_t prep_blocks(int64_t P, std::vector<int32_t>* hcb, std::vector<int32_t>* hg0)
 {
     const int64_t G16 = (P + kUR - 1) / kUR;
     int64_t cnt = 0;
-    if (njp_ns(P, single) == 1) {
+    if (njp_ns(P) == 1) {
         for (int64_t c = 0; 32 * c < G16 && c * kTileCols < P - 1; ++c)
-            for (int64_t g0 = 32 * c; g0 < G16; g0 += njp_tg(P, single)) {
+            for (int64_t g0 = 32 * c; g0 < G16; g0 += njp_tg(P)) {
                 if (hcb) { hcb->push_back((int32_t)c); hg0->push_back((int32_t)g0); }
                 ++cnt;
             }
     } else {
-        for (int64_t g0 = 0; g0 < G16; g0 += njp_tg(P, single))
-            for (int64_t c0 = 0; c0 < njp_strips_of_rows(g0, njp_tg(P, single), P); c0 += njp_ns(P, single)) {
+        for (int64_t g0 = 0; g0 < G16; g0 += njp_tg(P))
+            for (int64_t c0 = 0; c0 < njp_strips_of_rows(g0, njp_tg(P), P); c0 += njp_ns(P)) {
                 if (hcb) { hcb->push_back((int32_t)c0); hg0->push_back((int32_t)g0); }
                 ++cnt;
             }
@@ -1939,7 +1558,7 @@ static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, char
     {
         // test blocks: one strip and up to 256 consecutive row groups each (groups >= 32*cb see the strip)
         std::vector<int32_t> hcb, hg0;
-        q.nprep = (int)prep_blocks(P, q.sh_world <= 1, &hcb, &hg0);
+        q.nprep = (int)prep_blocks(P, &hcb, &hg0);
         DPR_HIP(hipMemcpyAsync(q.blk_cb, hcb.data(), sizeof(int32_t) * hcb.size(), hipMemcpyHostToDevice, s));
         DPR_HIP(hipMemcpyAsync(q.blk_g0, hg0.data(), sizeof(int32_t) * hg0.size(), hipMemcpyHostToDevice, s));
         DPR_HIP(hipStreamSynchronize(s));   // the host vectors go out of scope
@@ -2007,7 +1626,7 @@ int njp_build(NjBuffers& b, hipStream_t s)
     dim3 grid((unsigned)((N + kThreads - 1) / kThreads > 64 ? 64 : (N + kThreads - 1) / kThreads), (unsigned)(N < 32768 ? N : 32768));
     hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, b.D, b.ld, q.D, q.ld, q.perm, N);
     q.range_known = false;
-    if (njp_uses_t2(q)) {        // the post kernels that take their maxima from the previous launch need the range of the entries (one pass, once per run)
+    if (njp_use_post2(q)) {        // the large-shape post kernel's bounds need the range of the entries (one pass, once per run)
         hipLaunchKernelGGL(njp_range_kernel, dim3(2048), dim3(kThreads), 0, s, (const double*)b.D, b.ld, N, (unsigned long long*)q.t2_hdr);
         q.range_known = true;
     }
@@ -2119,7 +1738,7 @@ static int njp_from_slots(NjBuffers& b, hipStream_t s)
     dim3 grid((unsigned)((n + kThreads - 1) / kThreads > 64 ? 64 : (n + kThreads - 1) / kThreads), (unsigned)(n < 32768 ? n : 32768));
     hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, (const double*)b.D, b.ld, q.D, q.ld, (const int32_t*)q.perm, n);
     q.range_known = false;
-    if (njp_uses_t2(q)) {        // (the streaming iterations created values nobody tracked: reduce the matrix again)
+    if (njp_use_post2(q)) {        // (the streaming iterations created values nobody tracked: reduce the matrix again)
         hipLaunchKernelGGL(njp_range_kernel, dim3(2048), dim3(kThreads), 0, s, (const double*)b.D, b.ld, n, (unsigned long long*)q.t2_hdr);
         q.range_known = true;
     }
@@ -2187,7 +1806,7 @@ static NjpArgs njp_args(NjBuffers& b, int v)
     a.xpart = b.xpart; a.partials = b.partials; a.umin = (unsigned long long*)q.umin;
     a.P = q.P;
     a.blk_cb = q.blk_cb; a.blk_g0 = q.blk_g0;
-    a.tg = njp_tg(q.P, q.sh_world <= 1); a.ns = njp_ns(q.P, q.sh_world <= 1); a.nupd = 0;
+    a.tg = njp_tg(q.P); a.ns = njp_ns(q.P); a.nupd = 0;
     a.ntest = sh ? (q.nprep - v + q.sh_world - 1) / q.sh_world : q.nprep;     // test blocks v, v + world, ... are this rank's
     a.list = q.list + (int64_t)slot * q.list_stride;
     a.cnt = sh ? q.cnt_all + 4 * slot : b.st->cnt_list;
@@ -2205,7 +1824,6 @@ static NjpArgs njp_args(NjBuffers& b, int v)
     a.dbg = q.dbg; a.dbg_it = q.dbg_it;
     a.t2_hdr = q.t2_hdr; a.t2_rmax = q.t2_rmax; a.t2_cmax = q.t2_cmax; a.t2_colmin = q.t2_colmin; a.t2_rowmin = q.t2_rowmin; a.t2_cmin = q.t2_cmin;
     { static const int fl = std::getenv("DPR_NJP_FLAGS") ? std::atoi(std::getenv("DPR_NJP_FLAGS")) : 0; a.flags = fl; }
-    { static const double sl = std::getenv("DPR_NJP_SEED_SLACK") ? std::atof(std::getenv("DPR_NJP_SEED_SLACK")) : -1.0; a.exp_slack = sl; }
     return a;
 }
 
@@ -2218,20 +1836,11 @@ static int njp_launch_scan(NjBuffers& b, hipStream_t s, int v, bool rows)
     return DPR_OK;
 }
 
-static bool njp_use_post3(const NjPruned& q)
-{
-    const bool single = q.sh_world <= 1;
-    return single && njp_small_kind() == 3 && q.P < njp_big_p() && njp_tg(q.P, true) == 256 && (q.dbg == nullptr || q.dbg_it >= 0);
-}
 static bool njp_use_post2(const NjPruned& q)
 {
-    const bool single = q.sh_world <= 1;
-    const int ns = njp_ns(q.P, single);
-    if (njp_use_post3(q)) return false;
-    return njp_post2_on() && njp_tg(q.P, single) == 256 && (ns == kBigNS || (ns == 1 && single && njp_small_kind() == 2)) && (q.dbg == nullptr || q.dbg_it >= 0);
+    const int ns = njp_ns(q.P);
+    return njp_post2_on() && njp_tg(q.P) == 256 && (ns == kBigNS || (ns == 1 && njp_small_post2())) && (q.dbg == nullptr || q.dbg_it >= 0);
 }
-// the post kernels that read the maxima of the previous launch (njp_t2_init_kernel at the start of an epoch, the range header)
-static bool njp_uses_t2(const NjPruned& q) { return njp_use_post2(q) || njp_use_post3(q); }
 
 static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
 {
@@ -2240,14 +1849,6 @@ static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
     const unsigned ublocks = update ? (unsigned)((b.N + kThreads - 1) / kThreads) : 0u;
     a.nupd = (int)ublocks;
     if ((unsigned)a.ntest + ublocks == 0u) return DPR_OK;      // (a rank without test blocks in a tests-only launch)
-    // small shape on one rank (round 4): U blocks by slot, T blocks, M blocks by position (njp_post3_kernel)
-    if (njp_use_post3(b.pr)) {
-        if (!update) return DPR_OK;       // (tests-only launches exist for virtual ranks only)
-        a.nupd = (int)ublocks;
-        hipLaunchKernelGGL(njp_post3_kernel, dim3((unsigned)a.nupd + (unsigned)a.ntest + (unsigned)a.nrb), dim3(kThreads), 0, s, a);
-        DPR_HIP(hipGetLastError());
-        return DPR_OK;
-    }
     // large shape on a single rank: light blocks, maxima of the previous launch (njp_post2_kernel; DPR_NJP_POST2=0: the fused kernel)
     if (njp_use_post2(b.pr)) {
         const unsigned u2 = update ? (unsigned)((b.N + 2 * kThreads - 1) / (2 * kThreads)) : 0u;      // UM blocks: 512 reference slots and 512 positions each
@@ -2331,7 +1932,7 @@ static int njp_run_segment(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t 
             if (a.ntest > 0) hipLaunchKernelGGL(njp_list_all_kernel, dim3((unsigned)a.ntest), dim3(kThreads), 0, s, a);
         }
         DPR_HIP(hipGetLastError());
-        if (njp_uses_t2(q)) {
+        if (njp_use_post2(q)) {
             // the maxima the first post launch of the epoch reads: the row sums as they stand (buffer of the current iteration)
             const int64_t S2 = (q.P + kTileCols - 1) / kTileCols + 2;
             const int par = (int)(it0 & 1);
