@@ -280,10 +280,13 @@ def cpu_baseline_rapidnj(dip, n, cores, budget_s=20.0):
     # the exponent was measured in every run between two small blocks (3 000 / 6 000, then 4 000 / 8 000 tips): it came out anywhere
     # from 2.2 to 3.0 on the shared host, a 4 x spread of the extrapolated figure (48 .. 182 tips/s).
     expo = 2.14
-    m0 = min(n, 2000)
-    t0 = run(gpu_matrix_block(dip, m0))            # (also warms the OpenMP team)
+    # (sizing: a pilot at 4 000 tips, and a deliberately steep exponent -- 2.6 -- for choosing the block, so that a slow or busy
+    #  host cannot turn the 20 s budget into 100 s: the first version sized the block from a 2 000-tip pilot with 2.14 and once
+    #  spent 102 s on 16 213 tips)
+    m0 = min(n, 4000)
+    t0 = run(gpu_matrix_block(dip, m0))
     avail = psutil.virtual_memory().available
-    m = min(n, int(m0 * (budget_s / max(t0, 1e-3)) ** (1.0 / expo)))
+    m = min(n, int(m0 * (budget_s / max(t0, 1e-3)) ** (1.0 / 2.6)), 12000)
     m = min(m, int((0.4 * avail / 14.0) ** 0.5))       # matrix copy + working copy + sorted rows
     m = max(m0, min(m, n))
     tm = run(gpu_matrix_block(dip, m)) if m > m0 else t0
@@ -317,6 +320,24 @@ def rapidnj_probe(dip, n, cores, tmp, budget_s=30.0):
 
 
 # ---------------------------------------------------------------------------------------------------------
+CLI_PHASE_TAGS = (("input_ms", "Input in:"), ("device_ready_ms", "Device ready in:"), ("tree_ms", "Tree Created in:"), ("sketch_ms", "Sketch Created in:"),
+                  ("distance_ms", "Distance Operation Time"), ("tree_op_ms", "Tree Operation Time"))
+
+
+def cli_phases(stderr_text):
+    """milliseconds of the `dipper` command's own progress lines (the reference prints the same ones: src/tree_generation.cu:369-536,
+    src/placement_close_k.cu:852-853,985-986); lines look like `Input in: 132 ms` or `Distance Operation Time 3640 ms`"""
+    ph = {}
+    for line in stderr_text.splitlines():
+        for key, tag in CLI_PHASE_TAGS:
+            if line.startswith(tag):
+                try:
+                    ph[key] = float(line[len(tag):].replace(":", " ").split()[0])
+                except Exception:
+                    pass
+    return ph
+
+
 def cli_step(fa, out, device, threads):
     env = dict(os.environ, DPR_HOST_THREADS=str(threads))
     t0 = time.perf_counter()
@@ -325,15 +346,8 @@ def cli_step(fa, out, device, threads):
     dt = time.perf_counter() - t0
     if r.returncode != 0:
         raise RuntimeError("dipper failed: " + r.stderr[-400:])
-    phases = {}
-    for line in r.stderr.splitlines():          # the CLI's own progress lines (the reference prints the first and the last one too)
-        for key, tag in (("input", "Input in:"), ("tree", "Tree Created in:"), ("device_ready", "Device ready in:")):
-            if line.startswith(tag):
-                try:
-                    phases[key] = float(line.split(":")[1].split()[0])
-                except Exception:
-                    pass
-    return dt, phases
+    ph = cli_phases(r.stderr)
+    return dt, {k: ph[v] for k, v in (("input", "input_ms"), ("tree", "tree_ms"), ("device_ready", "device_ready_ms")) if v in ph}
 
 
 def join_comm(dip, rank, world, dist):
@@ -911,15 +925,7 @@ def other_configs(args, local_rank, stage, budget, tmp):
         wall = time.perf_counter() - t0
         if r.returncode != 0:
             raise RuntimeError("dipper --add failed: " + r.stderr[-300:])
-        ph = {}
-        for line in r.stderr.splitlines():          # the command's progress lines (the reference prints the same ones, src/placement_close_k.cu:985-986)
-            for key, tag in (("input_ms", "Input in:"), ("tree_ms", "Tree Created in:"), ("distance_ms", "Distance Operation Time"), ("tree_op_ms", "Tree Operation Time"),
-                             ("sketch_ms", "Sketch Created in:")):
-                if line.startswith(tag):
-                    try:
-                        ph[key] = float(line[len(tag):].replace(":", " ").split()[0])
-                    except Exception:
-                        pass
+        ph = cli_phases(r.stderr)
         out = {"workload": "configs[4] on one GPU: %d queries added to a %d-tip backbone, %s; the whole `dipper -a -t backbone.nwk` command "
                            "(FASTA of all %d records in, Newick out)" % (nq, m, "aligned x %d sites, -d 2" % L if kind == "m" else "unaligned reads x ~%d bases through Mash" % L, n),
                "backbone": m, "queries": nq, "seconds": wall, "queries_per_s": nq / wall, "phases_ms": ph,

@@ -73,3 +73,13 @@ def test_scaling_summary_sits_behind_roofline_and_labels_rccl():
     assert comp["row_sharded"]["peer"] == {"error": "child said nothing for 30 s (killed)"}
     # no nj_scaling leg (skipped by the budget): the line is returned unchanged
     assert bench.with_scaling_summary({"roofline": {}, "nj_scaling": {"skipped": "budget"}}, 1) == {"roofline": {}, "nj_scaling": {"skipped": "budget"}}
+
+
+def test_cli_phase_lines_are_parsed():
+    """bench.py reads the command's own progress lines (with and without a colon before the number)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    text = ("Read 550000 sequences from input file.\nTree loaded successfully with 999999 nodes and root node_550000.\nInput in: 132 ms\n"
+            "Device ready in: 111 ms\nSketch Created in: 38 ms\nDistance Operation Time 3640 ms\nTree Operation Time 2269 ms\n"
+            "Distance batches overlapped with tree operations: 0 of 49, 0 ms in flight\nTree Created in: 557 ms\n")
+    assert bench.cli_phases(text) == {"input_ms": 132.0, "device_ready_ms": 111.0, "sketch_ms": 38.0, "distance_ms": 3640.0, "tree_op_ms": 2269.0, "tree_ms": 557.0}

@@ -11,7 +11,7 @@
 * divide-and-conquer at 40 000 tips / backbone 2 000 (src/divide_and_conquer/placement_close_k.cu:731-1535).
 * exact placement at 8 000 tips (src/placement.cu:508-789).
 
-Set DPR_SKIP_NATURAL=1 to skip (about 3 minutes)."""
+Set DPR_SKIP_NATURAL=1 to skip (81 s on the GPU box: the oracle NJ at 10 000 tips takes ~4 s on 16 host threads there)."""
 import os
 
 import numpy as np
