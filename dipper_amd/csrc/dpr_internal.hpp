@@ -75,7 +75,7 @@ struct NjState {
     double d;        // D[x][y]
     double q;        // winning Q value
     int32_t status;  // 0 ok, 1 = no candidate (DPR_ERR_NOCAND)
-    int32_t pad;
+    int32_t pad;     // njs.hip: 1 once a failed rank has announced its status to the other ranks (it does so once)
     // pruned path (graph-replayed kernels read their iteration from memory): `it` is advanced by the post kernel while
     // it runs, so the post kernel reads `itb`, which the scan kernel (that reads `it`) publishes for it
     int64_t itb;
@@ -164,6 +164,8 @@ struct NjKernelTiming {
 
 // ---- one-exchange row-sharded streaming NJ (njs.hip) --------------------------------------------------------------
 constexpr int kNjsMaxWorld = 64;
+constexpr unsigned int kNjsTicketGroups = 32;                                   // two-level last-block ticket of njs_scan_kernel
+constexpr size_t kNjsTicketBytes = 128 * (1 + (size_t)kNjsTicketGroups);       // one 128-byte line per counter
 constexpr int kNjsLegacy = 0;    // round 2's loop: 4 launches + 2 all-gathers per iteration (nj.hip)
 constexpr int kNjsPeer = 1;      // 2 launches + ONE RCCL all-gather (rank records); rows x / y pulled from their owners' memory
 constexpr int kNjsMailbox = 2;   // 2 launches, no collective: the records go straight into every rank's mailbox
@@ -195,7 +197,7 @@ struct NjPeer {
     int plan = kNjsLegacy;
     char* win = nullptr;             // this rank's window (fine-grained device memory)
     NjsLayout lay;
-    unsigned int* ticket = nullptr;  // last-block ticket of the scan
+    unsigned int* ticket = nullptr;  // last-block tickets of the scan (kNjsTicketBytes)
     char** d_win = nullptr;          // device arrays [kNjsMaxWorld]: every rank's window / matrix as mapped into THIS process
     double** d_D = nullptr;
     std::vector<double*> h_D;        // host copy of d_D

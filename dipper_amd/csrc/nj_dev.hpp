@@ -188,6 +188,20 @@ __device__ __forceinline__ double finish_ux_bcast(const double* __restrict__ xpa
     return s[kThreads - 1];
 }
 
+// the same with the thread's first chunk partial already loaded (xp0 = xpart[threadIdx.x], issued by the caller together with
+// its other first loads; same additions in the same order)
+__device__ __forceinline__ double finish_ux_bcast_pre(double xp0, const double* __restrict__ xpart, int64_t n_prev, double* s)
+{
+    const int64_t nchunk = (n_prev + kThreads - 1) / kThreads;
+    double acc = 0.0;
+    if ((int64_t)threadIdx.x < nchunk) acc += xp0;
+    for (int64_t c = threadIdx.x + kThreads; c < nchunk; c += kThreads) acc += xpart[c];
+    const double r = block_tree256_lane0(acc, s);
+    if (threadIdx.x == 0) s[kThreads - 1] = r;
+    __syncthreads();
+    return s[kThreads - 1];
+}
+
 // block-wide reduction of `cnt` records to the winner (q, key, d); result in every thread
 __device__ __forceinline__ void reduce_records(const NjRecord* __restrict__ recs, int cnt, double& bq,
                                                uint64_t& bk, double& bd, double* sq, uint64_t* sk,

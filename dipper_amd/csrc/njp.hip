@@ -331,25 +331,41 @@ __global__ __launch_bounds__(kThreads) void njp_list_all_kernel(NjpArgs a)
 // position from the row buffer, and move the buffered row into the matrix (nobody reads that row validly
 // during this launch); the first of them stores U[x].
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjpArgs a)
+// The leading scalar parameters (NjpHead) repeat what the first round trip needs: with -mllvm -amdgpu-kernarg-preload-count
+// (Makefile) they arrive in SGPRs with the wave, so hop 1 leaves without waiting for the s_load of the argument block.
+__global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjState* h_st, const int32_t* h_list, const unsigned long long* h_cnt,
+                                                            const double* h_xpart, int h_nrl, NjpArgs a)
 {
     __shared__ double sq[kThreads / 64], sd[kThreads / 64];
     __shared__ uint64_t sk[kThreads / 64], sp[kThreads / 64];
     __shared__ double stree[kThreads];
 
     const int tid = threadIdx.x;
-    // hop 1: state line and (speculatively) this block's first list entry / chunk partial
-    const int64_t it = a.st->it, limit = a.st->it_limit, N = a.st->N;
+    // hop 1: state line, all three list counters and (speculatively) this block's first list entry / chunk partial
+    const int64_t it = h_st->it, limit = h_st->it_limit, N = h_st->N;
     // (the new-row blocks come FIRST in the grid: a 1000-block grid takes ~1.5 us to start, and their chain -- chunk
     // partials, canonical tree, division, candidates -- is the longer one)
-    const int nrl = a.do_rows ? a.nrb : 0;
+    const int nrl = h_nrl;
     const bool unit_block = (int)blockIdx.x >= nrl;
     const int ub = (int)blockIdx.x - nrl;                        // unit block index
-    const int32_t first = unit_block ? a.list[ub] : 0;
-    const double xp0 = unit_block ? 0.0 : a.xpart[tid];          // (the array is padded to a multiple of 256 entries)
-    const int64_t pz = (int64_t)a.st->pnew[it & 1];
-    if (blockIdx.x == 0 && tid == 0) a.st->itb = it;             // the post kernel's iteration index (it advances `it` itself); also beyond the limit
-    if (it >= limit || a.st->status != 0) return;
+    const int32_t first = unit_block ? h_list[ub] : 0;
+    const double xp0 = unit_block ? 0.0 : h_xpart[tid];          // (the array is padded to a multiple of 256 entries)
+    const unsigned long long cl0 = h_cnt[0], cl1 = h_cnt[1], cl2 = h_cnt[2];      // (not a second, dependent load behind `it`)
+    // new-row blocks: this thread's two positions of the buffered row (BOTH buffers: which one is current needs `it`) and
+    // their vectors -- nothing here waits for the state line (the vectors are padded past the last block's columns)
+    const int64_t j0 = (int64_t)blockIdx.x * kTileCols + 2 * tid;
+    v2d dv0, dv1, uv; ulonglong2 kav, kbv;
+    dv0.x = dv0.y = 0.0; dv1 = dv0; uv = dv0; kav = make_ulonglong2(0ull, 0ull); kbv = kav;
+    if (!unit_block) {
+        dv0 = *reinterpret_cast<const v2d*>(a.R + j0);
+        dv1 = *reinterpret_cast<const v2d*>(a.R + a.vstride + j0);
+        uv = *reinterpret_cast<const v2d*>(a.Ur + j0);
+        kav = *reinterpret_cast<const ulonglong2*>(a.KA + j0); kbv = *reinterpret_cast<const ulonglong2*>(a.KB + j0);
+    }
+    const int32_t pn0 = h_st->pnew[0], pn1 = h_st->pnew[1];      // (both with the state line)
+    const int64_t pz = (int64_t)((it & 1) ? pn1 : pn0);
+    if (blockIdx.x == 0 && tid == 0) h_st->itb = it;             // the post kernel's iteration index (it advances `it` itself); also beyond the limit
+    if (it >= limit || h_st->status != 0) return;
     NJP_STAMP(0, 0, true);
     const int64_t P = a.P;
     double bq = 10000.0, bd = 0.0;  // the reference's init value
@@ -368,12 +384,8 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjpArgs a)
         const int64_t nchunk = (n + 1 + kThreads - 1) / kThreads;        // chunks of the previous update (n + 1 slots)
         double acc = tid < nchunk ? xp0 : 0.0;
         for (int64_t c = tid + kThreads; c < nchunk; c += kThreads) acc += a.xpart[c];
-        // hop 2 (independent of the sum): this thread's two positions of the buffered row and their vectors
-        const double* __restrict__ Rz = a.R + ((it + 1) & 1) * a.vstride;     // written by POST(it - 1)
-        const int64_t j0 = (int64_t)r * kTileCols + 2 * tid;
-        const v2d dv = *reinterpret_cast<const v2d*>(Rz + j0);
-        const v2d uv = *reinterpret_cast<const v2d*>(a.Ur + j0);
-        const ulonglong2 kav = *reinterpret_cast<const ulonglong2*>(a.KA + j0), kbv = *reinterpret_cast<const ulonglong2*>(a.KB + j0);
+        // hop 2: only the keys of the new node itself (needed after the sum)
+        const v2d dv = ((it + 1) & 1) ? dv1 : dv0;                             // buffer (it + 1) & 1 was written by POST(it - 1)
         const uint64_t kax = a.KA[pz], kbx = a.KB[pz];
         NJP_STAMP(0, 1, true);
         double ux = block_tree256_lane0(acc, stree);
@@ -396,7 +408,8 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjpArgs a)
     } else {
         // ---------------------------------------------------------------- unit block
         rec_out = a.partials + a.rec_off + ub;
-        const int64_t cnt = (int64_t)a.cnt[it % 3];
+        const int m3 = (int)(it % 3);
+        const int64_t cnt = (int64_t)(m3 == 0 ? cl0 : m3 == 1 ? cl1 : cl2);
         if ((int64_t)ub >= cnt) {
             if (a.all_defined && tid == 0) {      // unit-sharded mode: every record of the gathered array is defined
                 NjRecord rec; rec.q = 10000.0; rec.key = ~0ull; rec.d = 0.0; rec.pad = 0ull;
@@ -566,7 +579,8 @@ __global__ __launch_bounds__(kThreads) void njp_finish_kernel(NjpArgs a)
 #define DPR_NJP_BIG_WAVES 1
 #endif
 template <int kTG, int kNS>
-__global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void njp_post_kernel(NjpArgs a)
+__global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void njp_post_kernel(NjState* h_st, const NjRecord* h_partials, const unsigned long long* h_cnt, const int32_t* h_blk_cb,
+                                                                                              const int32_t* h_blk_g0, const int32_t* h_pos_of_slot, int h_ntest, int h_nupd, NjpArgs a)
 {
     __shared__ double s[kThreads];
     __shared__ double sq[kThreads / 64], sdd[kThreads / 64];
@@ -577,13 +591,13 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
     // test blocks when the grid does not fit on the chip at once -- measured 5 % slower at 100 000 tips)
     const int bx = (int)blockIdx.x;
     const bool upd_first = (a.flags & 2) != 0;
-    const bool test_block = upd_first ? bx >= a.nupd : bx < a.ntest;
-    const int tbi = upd_first ? bx - a.nupd : bx, ubi = upd_first ? bx : bx - a.ntest;
+    const bool test_block = upd_first ? bx >= h_nupd : bx < h_ntest;
+    const int tbi = upd_first ? bx - h_nupd : bx, ubi = upd_first ? bx : bx - h_ntest;
     const int tb = test_block ? a.sh_rank + tbi * a.sh_world : 0;      // this rank's tbi-th test block
     // hop 1: state line, scan records, and what each role can address without knowing the winner
-    const int64_t it = a.st->itb;   // stable: the writer below only advances st->it
-    const int64_t limit = a.st->it_limit, N = a.st->N;
-    const int32_t pn0 = a.st->pnew[0], pn1 = a.st->pnew[1];      // (both with the state line)
+    const int64_t it = h_st->itb;   // stable: the writer below only advances st->it
+    const int64_t limit = h_st->it_limit, N = h_st->N;
+    const int32_t pn0 = h_st->pnew[0], pn1 = h_st->pnew[1];      // (both with the state line)
     const int64_t pz = (int64_t)((it & 1) ? pn1 : pn0);          // node leaving quarantine (its U was stored by SCAN(it))
     const int nrec_all = a.urecs + a.nrb;
     NjRecord r0; r0.q = 10000.0; r0.key = ~0ull; r0.d = 0; r0.pad = 0;
@@ -592,7 +606,7 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
 #pragma unroll
     for (int k = 0; k < kMine; ++k) {
         const int idx = tid + k * kThreads;
-        if (idx < nrec_all) mine[k] = a.partials[idx];
+        if (idx < nrec_all) mine[k] = h_partials[idx];
     }
     // seed candidate of the test role, ONE per thread (two fp64 divisions each): the last threads take the new-row
     // records, the others a unit record (every sstride-th when all of them are defined)
@@ -602,10 +616,10 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
     const bool seed_is_unit = tid < nseed_units;
     NjRecord cand = r0;
     if (test_block) {
-        if (!seed_is_unit) cand = a.partials[a.urecs + (tid - nseed_units)];
-        else if ((int64_t)tid * sstride < a.urecs) cand = a.partials[(int64_t)tid * sstride];
+        if (!seed_is_unit) cand = h_partials[a.urecs + (tid - nseed_units)];
+        else if ((int64_t)tid * sstride < a.urecs) cand = h_partials[(int64_t)tid * sstride];
     }
-    const unsigned long long cl0 = a.cnt[0], cl1 = a.cnt[1], cl2 = a.cnt[2];      // all three list counters with the first round trip (not a second, dependent load)
+    const unsigned long long cl0 = h_cnt[0], cl1 = h_cnt[1], cl2 = h_cnt[2];      // all three list counters with the first round trip (not a second, dependent load)
     const int m3 = (int)(it % 3);
     const unsigned long long cnt_raw = a.all_defined ? (unsigned long long)a.urecs : (m3 == 0 ? cl0 : m3 == 1 ? cl1 : cl2);
     const int64_t uvalid = (int64_t)(cnt_raw < (unsigned long long)a.urecs ? cnt_raw : (unsigned long long)a.urecs);   // unit records written by SCAN(it)
@@ -644,13 +658,13 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
         }
     };
     if (test_block) {
-        cb0 = a.blk_cb[tb];
-        g = (int64_t)a.blk_g0[tb] + tid;
+        cb0 = h_blk_cb[tb];
+        g = (int64_t)h_blk_g0[tb] + tid;
         have_g = g < G16 && tid < kTG;
-        rbase = (int64_t)a.blk_g0[tb] * kUR;
+        rbase = (int64_t)h_blk_g0[tb] * kUR;
         if (kNS == 1) nsb = 1;
         else {
-            const int64_t send = njp_strips_of_rows((int64_t)a.blk_g0[tb], kTG, P);
+            const int64_t send = njp_strips_of_rows((int64_t)h_blk_g0[tb], kTG, P);
             nsb = (int)(send - cb0 < kNS ? send - cb0 : kNS);
         }
 #pragma unroll
@@ -662,7 +676,7 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
             urow[c] = *reinterpret_cast<const v2d*>(Uc + (pp < P ? pp : pclamp));      // behind P: padding (NaN = dead)
         }
     } else {
-        p = (int64_t)a.pos_of_slot[i];                 // (the slot arrays are padded past N)
+        p = (int64_t)h_pos_of_slot[i];                 // (the slot arrays are padded past N)
     }
 #pragma unroll
     for (int k = 0; k < kMine; ++k) {
@@ -670,7 +684,7 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
         if (idx >= uvalid && idx < a.urecs) mine[k] = r0;   // not written by this iteration's scan
     }
     if (!test_block) up = (i < N && p >= 0) ? Uc[p] : 0.0;      // hop 1b (address needs the position only)
-    if (a.st->status != 0 || it >= limit) return;
+    if (h_st->status != 0 || it >= limit) return;
     const int64_t n = N - it;
     if (n < 3) return;
     if (!test_block && (!a.do_update || (int64_t)ubi * kThreads >= n)) return;
@@ -990,7 +1004,8 @@ __global__ __launch_bounds__(kThreads) void njp_t2_init_kernel(const double* __r
 }
 
 template <int kNS>
-__global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
+__global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, const NjRecord* h_partials, const unsigned long long* h_cnt, const int32_t* h_blk_cb,
+                                                         const int32_t* h_blk_g0, const int32_t* h_pos_of_slot, int h_ntest, int h_nupd, NjpArgs a)
 {
     constexpr int kTG = 256;
     __shared__ double s[kThreads];
@@ -1004,16 +1019,16 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
     // slots [512 u, 512 u + 512) and the position-order part for the positions [512 u, 512 u + 512) -- one select for both,
     // and 845 blocks at 100 000 tips where separate U and M blocks made 1 041 for 1 024 resident ones (110 registers): the
     // blocks of the second round started 8 us late and set the length of the launch (profiles/r3/nj_phases2_100k.txt)
-    const bool trole = bx < a.ntest;
+    const bool trole = bx < h_ntest;
     const int tb = a.sh_rank + bx * a.sh_world;      // (unit-sharded plan: a rank launches only its own test blocks; tb is the global index)
-    const int umb = bx - a.ntest;
+    const int umb = bx - h_ntest;
     Post2Hdr* hdr = reinterpret_cast<Post2Hdr*>(a.t2_hdr);
     const double NINF = -__builtin_inf(), PINF = __builtin_inf();
 
     // hop 1: state line, scan records, and what each role can address without knowing the winner
-    const int64_t it = a.st->itb;
-    const int64_t limit = a.st->it_limit, N = a.st->N;
-    const int32_t pn0 = a.st->pnew[0], pn1 = a.st->pnew[1];      // (both with the state line)
+    const int64_t it = h_st->itb;
+    const int64_t limit = h_st->it_limit, N = h_st->N;
+    const int32_t pn0 = h_st->pnew[0], pn1 = h_st->pnew[1];      // (both with the state line)
     const int64_t pz = (int64_t)((it & 1) ? pn1 : pn0);
     const int64_t P = a.P;
     const int64_t G16 = (P + kUR - 1) / kUR;
@@ -1024,7 +1039,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
 #pragma unroll
     for (int k = 0; k < kMine; ++k) {
         const int idx = tid + k * kThreads;
-        if (idx < nrec_all) mine[k] = a.partials[idx];
+        if (idx < nrec_all) mine[k] = h_partials[idx];
     }
     // T: the seed candidate of this thread (as in njp_post_kernel)
     const int nseed_rows = a.nrb < kThreads / 2 ? a.nrb : kThreads / 2;
@@ -1043,19 +1058,19 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
     int64_t p = -1, pb = -1;
     int2 sl = make_int2(-1, -1);                             // reference slots of the two positions (-1: dead / padding)
     if (trole) {
-        if (!seed_is_unit) cand = a.partials[a.urecs + (tid - nseed_units)];
-        else if ((int64_t)tid * sstride < a.urecs) cand = a.partials[(int64_t)tid * sstride];
-        cb0 = a.blk_cb[tb];
-        g0 = (int64_t)a.blk_g0[tb];
+        if (!seed_is_unit) cand = h_partials[a.urecs + (tid - nseed_units)];
+        else if ((int64_t)tid * sstride < a.urecs) cand = h_partials[(int64_t)tid * sstride];
+        cb0 = h_blk_cb[tb];
+        g0 = (int64_t)h_blk_g0[tb];
     } else {
-        if (u_slots) { p = (int64_t)a.pos_of_slot[i]; pb = (int64_t)a.pos_of_slot[i + kThreads]; }      // (padded past N)
+        if (u_slots) { p = (int64_t)h_pos_of_slot[i]; pb = (int64_t)h_pos_of_slot[i + kThreads]; }      // (padded past N)
         if (m_part) sl = *reinterpret_cast<const int2*>(a.slot_of_pos + p0);
     }
     // hop 2: needs the iteration index
     const int par = (int)(it & 1);                           // T reads the maxima of buffer par, M writes buffer 1 - par
     const double* __restrict__ Uc = a.U + (it & 1) * a.vstride;
     double* __restrict__ Un = a.U + ((it + 1) & 1) * a.vstride;
-    const unsigned long long cl0 = a.cnt[0], cl1 = a.cnt[1], cl2 = a.cnt[2];      // all three list counters with the first round trip (not a second, dependent load)
+    const unsigned long long cl0 = h_cnt[0], cl1 = h_cnt[1], cl2 = h_cnt[2];      // all three list counters with the first round trip (not a second, dependent load)
     const int m3 = (int)(it % 3);
     const unsigned long long cnt_raw = a.all_defined ? (unsigned long long)a.urecs : (m3 == 0 ? cl0 : m3 == 1 ? cl1 : cl2);
     const int64_t uvalid = (int64_t)(cnt_raw < (unsigned long long)a.urecs ? cnt_raw : (unsigned long long)a.urecs);
@@ -1085,7 +1100,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjpArgs a)
     }
     NJP_STAMP(1, 0, false);
     NJP_STAMP(1, 1, true);
-    if (a.st->status != 0 || it >= limit) return;
+    if (h_st->status != 0 || it >= limit) return;
     const int64_t n = N - it;
     if (n < 3) return;
     const bool u_part = u_slots && a.do_update && (int64_t)umb * (2 * kThreads) < n;
@@ -1831,7 +1846,8 @@ static int njp_launch_scan(NjBuffers& b, hipStream_t s, int v, bool rows)
 {
     NjpArgs a = njp_args(b, v);
     a.do_rows = rows ? 1 : 0;
-    hipLaunchKernelGGL(njp_scan_kernel, dim3((unsigned)(a.ugrid + (rows ? a.nrb : 0))), dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL(njp_scan_kernel, dim3((unsigned)(a.ugrid + (rows ? a.nrb : 0))), dim3(kThreads), 0, s, a.st, (const int32_t*)a.list,
+                       (const unsigned long long*)a.cnt, (const double*)a.xpart, rows ? a.nrb : 0, a);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
@@ -1855,17 +1871,17 @@ static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
         const unsigned um = !update ? 0u : (u2 > (unsigned)a.nrb ? u2 : (unsigned)a.nrb);
         a.nupd = (int)um;
         if ((unsigned)a.ntest + um == 0u) return DPR_OK;
-        if (a.ns == 1) hipLaunchKernelGGL((njp_post2_kernel<1>), dim3((unsigned)a.ntest + um), dim3(kThreads), 0, s, a);
-        else hipLaunchKernelGGL((njp_post2_kernel<kBigNS>), dim3((unsigned)a.ntest + um), dim3(kThreads), 0, s, a);
+        if (a.ns == 1) hipLaunchKernelGGL((njp_post2_kernel<1>), dim3((unsigned)a.ntest + um), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
+        else hipLaunchKernelGGL((njp_post2_kernel<kBigNS>), dim3((unsigned)a.ntest + um), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
         DPR_HIP(hipGetLastError());
         return DPR_OK;
     }
-    if (a.tg == 64) hipLaunchKernelGGL((njp_post_kernel<64, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
-    else if (a.tg == 32) hipLaunchKernelGGL((njp_post_kernel<32, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
-    else if (a.tg == 128) hipLaunchKernelGGL((njp_post_kernel<128, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
-    else if (a.ns == 1) hipLaunchKernelGGL((njp_post_kernel<256, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
-    else if (a.ns == 2) hipLaunchKernelGGL((njp_post_kernel<256, 2>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
-    else hipLaunchKernelGGL((njp_post_kernel<256, kBigNS>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a);
+    if (a.tg == 64) hipLaunchKernelGGL((njp_post_kernel<64, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
+    else if (a.tg == 32) hipLaunchKernelGGL((njp_post_kernel<32, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
+    else if (a.tg == 128) hipLaunchKernelGGL((njp_post_kernel<128, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
+    else if (a.ns == 1) hipLaunchKernelGGL((njp_post_kernel<256, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
+    else if (a.ns == 2) hipLaunchKernelGGL((njp_post_kernel<256, 2>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
+    else hipLaunchKernelGGL((njp_post_kernel<256, kBigNS>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }

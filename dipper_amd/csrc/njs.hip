@@ -51,7 +51,7 @@ struct NjsArgs {
     double* D; int64_t ld; NjState* st;
     double* U; double* Ur; uint64_t* KA; double* xpart;
     NjRecord* partials; NjsRec* recs;            // block records of the scan; gathered rank records (plan PEER)
-    unsigned int* ticket;
+    unsigned int* ticket;                        // [1 + kNjsTicketGroups] counters, 128 bytes apart: the top word, then one per group
     char* const* win;                            // [world] every rank's window (own one included), valid in this process
     double* const* peerD;                        // [world] every rank's matrix rows
     NjsLayout lay;
@@ -105,18 +105,22 @@ __global__ __launch_bounds__(kThreads) void njs_scan_kernel(const double* __rest
     const int rank = a.rank, world = a.world;
     double bq = 10000.0;
     uint64_t bk = ~0ull;
-    const bool dead = a.st->status != 0;
+    // one round trip: the state words and this thread's first chunk partial of the row sum (xpart holds >= 512 entries)
+    const int st_status = a.st->status;
+    const int32_t st_x = a.st->x, st_y = a.st->y;
+    const double xp0 = a.xpart[tid];
+    const bool dead = st_status != 0;
 
     int64_t xprev = -1;
     double urx = 0.0, ux = 0.0;
     RowView rv;
     if (it > 0 && !dead) {
-        xprev = a.st->x;
-        ux = finish_ux_bcast(a.xpart, n + 1, sd);
+        xprev = st_x;
+        ux = finish_ux_bcast_pre(xp0, a.xpart, n + 1, sd);
         urx = ux / (double)(n - 2);
         if (blockIdx.x == 0 && tid == 0) { a.U[xprev] = ux; a.Ur[xprev] = urx; }
         if (a.has_pending) {
-            rv.xp = xprev; rv.yp = a.st->y;
+            rv.xp = xprev; rv.yp = st_y;
             rv.xrow = xrow_p;       // this rank's row buffers of merge it - 1 (host: window base + row offset)
             rv.yrow = yrow_p;
         }
@@ -183,8 +187,20 @@ __global__ __launch_bounds__(kThreads) void njs_scan_kernel(const double* __rest
         //  slower -- 183 instead of 84 us for an eighth of the 30 000-tip triangle.  The three stores above are write-through
         //  (sc1); draining them before a RELAXED ticket increment orders them for the reader, whose loads are sc1 too.)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+        // Two-level ticket.  The units are split evenly, so the blocks of a launch finish within a microsecond of each other, and
+        // an atomic with return on ONE word costs 3 us with 256 blocks on it and 11.7 us with 1 024 (tools/lat_probe): a launch
+        // over 4 MB spent 23 us, mostly here.  Block b takes a ticket of group b % kNjsTicketGroups (one 128-byte line each);
+        // the last of a group takes one of the top word; the last of those reduces.  Every increment is issued after the
+        // block's own stores are drained and after the increments it has seen, so the chain orders all records for the reader.
+        const unsigned int G = gridDim.x, grp = blockIdx.x % kNjsTicketGroups;
+        const unsigned int in_grp = (G - grp + kNjsTicketGroups - 1) / kNjsTicketGroups, groups = G < kNjsTicketGroups ? G : kNjsTicketGroups;
+        unsigned int last = 0u;
+        const unsigned int t = __hip_atomic_fetch_add(a.ticket + 32 * (1 + grp), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == in_grp - 1) {
+            const unsigned int tt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (tt == groups - 1) ? 1u : 0u;
+        }
+        s_last = last;
     }
     __syncthreads();
     if (!s_last) return;
@@ -212,18 +228,24 @@ __global__ __launch_bounds__(kThreads) void njs_scan_kernel(const double* __rest
         for (int w = 1; w < kThreads / 64; ++w)
             if ((sq[w] < wq) | ((sq[w] == wq) & (sk[w] < wk))) { wq = sq[w]; wk = sk[w]; wd = sdd[w]; }
         if (dead) { wq = 10000.0; wk = ~0ull; wd = 0.0; }
-        *a.ticket = 0u;                       // next launch (stream order)
     }
+    if (tid <= kNjsTicketGroups) a.ticket[32 * tid] = 0u;      // next launch (stream order)
     // the record also carries this rank's view of the replicated state (NjsRec: the row sum of the node of merge it - 1, bit
     // for bit, and the rank's status), which POST compares across the ranks
     const unsigned long long uxb = (unsigned long long)__double_as_longlong(ux);
-    const unsigned long long stw = (unsigned long long)(unsigned int)a.st->status;
+    const unsigned long long stw = (unsigned long long)(unsigned int)st_status;      // (nobody changes the status during a scan launch)
     if (a.plan == kNjsMailbox) {
         // thread r sends the record to rank r's mailbox (own one included): data words, then the sequence word with
-        // release semantics; the reader acquires on the sequence word
+        // release semantics; the reader acquires on the sequence word.
+        // A rank that has failed announces it ONCE, with the record of the first scan after the failure.  Its post kernels
+        // return at once, so nothing paces it any more: were it to keep sending, its record of iteration it + 2 would
+        // overwrite the one of iteration it (same mailbox line) that a slower rank may not have read yet -- that rank
+        // then ended with "record did not arrive" instead of the failure the others report.
+        const bool announced = dead && a.st->pad != 0;
         if (tid == 0) { sq[0] = wq; sk[0] = wk; sdd[0] = wd; }
         __syncthreads();
-        if (tid < world) {
+        if (dead && tid == 0) a.st->pad = 1;
+        if (tid < world && !announced) {
             NjsRec* m = win_mail(a.win[tid], (int)(it & 1), rank);
             unsigned long long* w = reinterpret_cast<unsigned long long*>(m);
             st_sys_u64(w + 0, (unsigned long long)__double_as_longlong(sq[0]));
@@ -463,8 +485,9 @@ static NjsArgs njs_args(NjBuffers& b, int64_t n, int64_t it, bool pending)
     // blocks of the scan: the single-GPU grid (2 048) by default; a rank streams only 1 / world of the triangle, so a
     // smaller grid may ramp and drain faster (DPR_NJS_GRID, profiles/njs_vworld_stats.py)
     static const int env_grid = std::getenv("DPR_NJS_GRID") ? std::atoi(std::getenv("DPR_NJS_GRID")) : 0;
-    // (measured with 8 virtual ranks at 30 000 tips: 97.6 / 93.1 / 93.4 us per rank and iteration with 2 048 / 1 024 / 512 blocks)
-    a.nparts = env_grid >= 64 && env_grid <= kScanBlocks ? env_grid : (b.world >= 4 ? 1024 : nj_scan_grid());
+    // (measured with 8 virtual ranks at 30 000 tips, round 4: 85.1 / 83.6 / 85.2 / 88.5 / 87.7 us per rank and iteration with
+    //  512 / 768 / 1 024 / 1 536 / 2 048 blocks)
+    a.nparts = env_grid >= 64 && env_grid <= kScanBlocks ? env_grid : (b.world >= 4 ? 768 : nj_scan_grid());
     a.poll_ticks = b.peer.poll_ticks;
     a.seq_base = b.peer.run_id << 32;
     a.fault_it = b.peer.fault_it; a.fault_rank = b.peer.fault_rank;
@@ -536,7 +559,7 @@ int njs_alloc_window(NjBuffers& b, hipStream_t s)
         // Reuse (same shape again): nothing in the window is cleared -- another rank may already be ahead of this one and
         // writing into it.  Mail sequence numbers carry the run id, barrier epochs only grow, the slice and the row
         // buffers are written before they are read.
-        DPR_HIP(hipMemsetAsync(p.ticket, 0, sizeof(unsigned int), s));
+        DPR_HIP(hipMemsetAsync(p.ticket, 0, kNjsTicketBytes, s));
         ++p.run_id;
         return DPR_OK;
     }
@@ -545,8 +568,8 @@ int njs_alloc_window(NjBuffers& b, hipStream_t s)
     hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(&p.win), (size_t)lay.bytes, hipDeviceMallocFinegrained);
     if (e != hipSuccess) return hip_fail(e, "hipExtMallocWithFlags(peer window, fine-grained)");
     DPR_HIP(hipMemsetAsync(p.win, 0, (size_t)lay.bytes, s));
-    DPR_HIP(hipMalloc(&p.ticket, sizeof(unsigned int)));
-    DPR_HIP(hipMemsetAsync(p.ticket, 0, sizeof(unsigned int), s));
+    DPR_HIP(hipMalloc(&p.ticket, kNjsTicketBytes));
+    DPR_HIP(hipMemsetAsync(p.ticket, 0, kNjsTicketBytes, s));
     DPR_HIP(hipMalloc(&p.d_win, sizeof(char*) * kNjsMaxWorld));
     DPR_HIP(hipMalloc(&p.d_D, sizeof(double*) * kNjsMaxWorld));
     DPR_HIP(hipMemsetAsync(p.d_win, 0, sizeof(char*) * kNjsMaxWorld, s));
