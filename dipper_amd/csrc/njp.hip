@@ -180,15 +180,33 @@ __device__ __forceinline__ void njp_note_range(unsigned long long* mm, double lo
     }
 }
 
+// B[a][b] = A[perm[a]][perm[b]]: a gather of 8-byte elements out of the source row, whose 64-byte lines are each wanted by
+// eight different threads.  Every block of an output row runs on ONE XCD (blockIdx.x & 7 = the XCD of a block when gridDim.x
+// is a multiple of 8: workgroups go round-robin), so the source row enters one L2 once; with the row's blocks spread over all
+// eight XCDs (round 1 - 3) every L2 fetched every row: 8 x the reads, 120 ms for the first epoch of 100 000 tips.
+// gridDim.x = 8 x chunks: enough blocks per row that only a few rows (<= 4 MB) are in flight per XCD.
 __global__ __launch_bounds__(kThreads) void njp_permute_kernel(const double* __restrict__ A, int64_t lda,
                                                                double* __restrict__ B, int64_t ldb,
                                                                const int32_t* __restrict__ perm, int64_t P)
 {
-    for (int64_t a = blockIdx.y; a < P; a += gridDim.y) {
+    const int xcd = (int)(blockIdx.x & 7u), chunk = (int)(blockIdx.x >> 3), nchunk = (int)(gridDim.x >> 3);
+    for (int64_t a = (int64_t)blockIdx.y * 8 + xcd; a < P; a += (int64_t)gridDim.y * 8) {
         const double* row = A + (int64_t)perm[a] * lda;
-        for (int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x; b < P; b += (int64_t)gridDim.x * kThreads)
+        for (int64_t b = (int64_t)chunk * kThreads + threadIdx.x; b < P; b += (int64_t)nchunk * kThreads)
             B[a * ldb + b] = row[perm[b]];
     }
+}
+
+static void njp_launch_permute(const double* A, int64_t lda, double* B, int64_t ldb, const int32_t* perm, int64_t n, hipStream_t s)
+{
+    // blocks per row: one per 1 024 columns, 1 ... 64 (DPR_NJP_PERMUTE_CHUNKS; the first epoch of 100 000 tips: 97 / 80 / 70 ms
+    // with 24 / 32 / 64, of 30 000 tips: 10.9 / 6.5 / 6.0 ms with 4 / 15 / 32 -- 120 and 9.0 ms with the rows spread over the XCDs)
+    static const int env_chunks = std::getenv("DPR_NJP_PERMUTE_CHUNKS") ? std::atoi(std::getenv("DPR_NJP_PERMUTE_CHUNKS")) : 0;
+    int64_t chunks = env_chunks > 0 ? env_chunks : (n + 1023) / 1024;
+    chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
+    const int64_t gy = (n + 7) / 8;
+    dim3 grid((unsigned)(8 * chunks), (unsigned)(gy < 32768 ? gy : 32768));
+    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, A, lda, B, ldb, perm, n);
 }
 
 // range of the n x n matrix A (slot space, rows contiguous) into mm: once per run, before the first large-shape epoch, and
@@ -1606,9 +1624,13 @@ int njp_build(NjBuffers& b, hipStream_t s)
         // default: 256 blocks while an iteration lists ~100 units (a 1000-block grid takes ~1.5 us just to start; NJ 515 ->
         // 512 ms at 30 000 tips), 512 above (round 2: 1024; every block of the post kernels reduces one record per scan block --
         // NJ at 100 000 tips 2.10 / 2.07 / 2.06 / 2.08 / 2.10 s with 256 / 384 / 512 / 768 / 1024, round 3)
+        // Round 4: the listing rate depends on the data -- branch lengths x 5 / x 25 list 500 / 820 units per iteration instead of
+        // 85 at 30 000 tips, and every block then walks 2 - 4 units one after the other (NJ 574 / 663 ms with 256 blocks,
+        // 544 / 614 with 512): below 50 000 tips the grid follows the rate the adaptive plan watches (njp_run).
         const char* e = std::getenv("DPR_NJP_GRID");
         const int g = e ? std::atoi(e) : (b.N < 50000 ? 256 : 512);
         b.pr.scan_grid = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+        b.pr.scan_grid_auto = !e && b.N < 50000;
     }
     if (const char* e = std::getenv("DPR_NJ_ADAPTIVE")) b.pr.adaptive = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("DPR_NJ_STREAM_FRAC")) b.pr.stream_frac = std::atof(e);
@@ -1638,8 +1660,7 @@ int njp_build(NjBuffers& b, hipStream_t s)
         DPR_HIP(hipMalloc(&q.iterstats, sizeof(uint64_t) * (size_t)(2 * N + 2)));
         DPR_HIP(hipMemsetAsync(q.iterstats, 0, sizeof(uint64_t) * (size_t)(2 * N + 2), s));
     }
-    dim3 grid((unsigned)((N + kThreads - 1) / kThreads > 64 ? 64 : (N + kThreads - 1) / kThreads), (unsigned)(N < 32768 ? N : 32768));
-    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, b.D, b.ld, q.D, q.ld, q.perm, N);
+    njp_launch_permute(b.D, b.ld, q.D, q.ld, q.perm, N, s);
     q.range_known = false;
     if (njp_use_post2(q)) {        // the large-shape post kernel's bounds need the range of the entries (one pass, once per run)
         hipLaunchKernelGGL(njp_range_kernel, dim3(2048), dim3(kThreads), 0, s, (const double*)b.D, b.ld, N, (unsigned long long*)q.t2_hdr);
@@ -1666,6 +1687,14 @@ static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s, bool* rebuilt)
 {
     NjPruned& q = b.pr;
     *rebuilt = false;
+    const bool tlog = std::getenv("DPR_NJ_EPOCH_LOG") && std::atoi(std::getenv("DPR_NJ_EPOCH_LOG")) >= 3;
+    auto tprev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!tlog) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[njp]   rebuild: %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - tprev).count());
+        tprev = t;
+    };
     NjState st;
     DPR_HIP(hipMemcpy(&st, b.st, sizeof(NjState), hipMemcpyDeviceToHost));
     const int64_t n = st.n, Pold = q.P;
@@ -1675,20 +1704,22 @@ static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s, bool* rebuilt)
     const double* Ucur = q.U + (st.it & 1) * q.vstride;
     DPR_HIP(hipMemcpy(hU.data(), Ucur, sizeof(double) * (size_t)Pold, hipMemcpyDeviceToHost));
     DPR_HIP(hipMemcpy(hslot.data(), q.slot_of_pos, sizeof(int32_t) * (size_t)Pold, hipMemcpyDeviceToHost));
+    lap("state + vectors to the host");
     std::vector<int32_t> perm;
     perm.reserve((size_t)n);
     for (int64_t p = 0; p < Pold; ++p)
         if (hslot[(size_t)p] >= 0) perm.push_back((int32_t)p);      // (Ur does not tell: the node in quarantine carries NaN there)
     if ((int64_t)perm.size() != n) { set_error("njp_rebuild_epoch: live positions do not match the active size"); return DPR_ERR_STATE; }
     sort_by_row_sum(perm, hU);
+    lap("sort");
     if (q.graph) { (void)hipGraphExecDestroy(q.graph); q.graph = nullptr; }
     const NjPruned old = q;              // the old epoch's pointers (read by the permute / init kernels below)
     const int e = old.epoch_index + 1;
     q.epoch_index = e;
     if (int rc = njp_alloc_epoch(q, n, b.N, (e & 1) ? b.D : q.arena_D, q.arena_slab[e & 1], s, old.range_known ? old.t2_hdr : nullptr)) return rc;
+    lap("njp_alloc_epoch");
     DPR_HIP(hipMemcpyAsync(q.perm, perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
-    dim3 grid((unsigned)((n + kThreads - 1) / kThreads > 64 ? 64 : (n + kThreads - 1) / kThreads), (unsigned)(n < 32768 ? n : 32768));
-    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, old.D, old.ld, q.D, q.ld, q.perm, n);
+    njp_launch_permute(old.D, old.ld, q.D, q.ld, q.perm, n, s);
     hipLaunchKernelGGL(njp_init_vectors_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                        Ucur, q.perm, (const int32_t*)old.slot_of_pos, n, n, q.U + (st.it & 1) * q.vstride, q.Ur, q.KA, q.KB,
                        q.slot_of_pos, q.pos_of_slot);
@@ -1697,7 +1728,9 @@ static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s, bool* rebuilt)
     st.pnew[0] = -1; st.pnew[1] = -1;
     for (auto& c : st.cnt_list) c = 0ull;
     DPR_HIP(hipMemcpyAsync(b.st, &st, sizeof(NjState), hipMemcpyHostToDevice, s));
+    lap("enqueue");
     DPR_HIP(hipStreamSynchronize(s));    // `st`, `perm` are host objects
+    lap("device work");
     *rebuilt = true;
     return DPR_OK;
 }
@@ -1722,8 +1755,7 @@ static int njp_to_slots(NjBuffers& b, hipStream_t s)
     if (q.graph) { (void)hipGraphExecDestroy(q.graph); q.graph = nullptr; }
     // the slot-space matrix goes into the buffer the epoch does not live in; the streaming kernels read b.D
     if (q.D == b.D) std::swap(b.D, q.arena_D);
-    dim3 grid((unsigned)((n + kThreads - 1) / kThreads > 64 ? 64 : (n + kThreads - 1) / kThreads), (unsigned)(n < 32768 ? n : 32768));
-    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, (const double*)q.D, q.ld, b.D, b.ld, (const int32_t*)q.pos_of_slot, n);
+    njp_launch_permute((const double*)q.D, q.ld, b.D, b.ld, (const int32_t*)q.pos_of_slot, n, s);
     hipLaunchKernelGGL(njp_gather_u_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                        njp_current_u(q, st.it), (const int32_t*)q.pos_of_slot, n, b.U);
     DPR_HIP(hipGetLastError());
@@ -1750,8 +1782,7 @@ static int njp_from_slots(NjBuffers& b, hipStream_t s)
     q.epoch_index = 0;                       // even: the epoch lives in arena_D (b.D holds the slot-space matrix it is built from)
     if (int rc = njp_alloc_epoch(q, n, b.N, q.arena_D, q.arena_slab[0], s)) return rc;
     DPR_HIP(hipMemcpyAsync(q.perm, perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
-    dim3 grid((unsigned)((n + kThreads - 1) / kThreads > 64 ? 64 : (n + kThreads - 1) / kThreads), (unsigned)(n < 32768 ? n : 32768));
-    hipLaunchKernelGGL(njp_permute_kernel, grid, dim3(kThreads), 0, s, (const double*)b.D, b.ld, q.D, q.ld, (const int32_t*)q.perm, n);
+    njp_launch_permute((const double*)b.D, b.ld, q.D, q.ld, (const int32_t*)q.perm, n, s);
     q.range_known = false;
     if (njp_use_post2(q)) {        // (the streaming iterations created values nobody tracked: reduce the matrix again)
         hipLaunchKernelGGL(njp_range_kernel, dim3(2048), dim3(kThreads), 0, s, (const double*)b.D, b.ld, n, (unsigned long long*)q.t2_hdr);
@@ -2077,6 +2108,18 @@ int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
             const double listed = (double)(st1.units_scanned - units0) - (first_of_epoch ? (double)q.utot : 0.0);
             const double iters = (double)seg - (first_of_epoch ? 1.0 : 0.0);
             const double rate = iters >= 1.0 ? listed / (iters * (double)q.utot) : 0.0;
+            const double per_it = iters >= 1.0 ? listed / iters : 0.0;       // units per iteration
+            if (const char* el = std::getenv("DPR_NJ_EPOCH_LOG")) if (std::atoi(el) >= 2)
+                std::fprintf(stderr, "[njp] watch at n=%lld: %.0f units per iteration over %.0f iterations (first of epoch %d, P=%lld, utot=%lld, scan grid %d)\n",
+                             (long long)(b.N - it), per_it, iters, (int)first_of_epoch, (long long)q.P, (long long)q.utot, q.scan_grid);
+            if (q.scan_grid_auto && iters >= 1.0) {
+                // units per iteration against the blocks that walk them (hysteresis: up from 160, down below 110)
+                const int want = per_it >= 160.0 ? 512 : (per_it < 110.0 ? 256 : q.scan_grid);
+                if (want != q.scan_grid) {
+                    q.scan_grid = want;
+                    if (q.graph) { (void)hipGraphExecDestroy(q.graph); q.graph = nullptr; }      // (the stream is idle: synchronised above)
+                }
+            }
             if (iters >= 1.0 && rate > q.stream_frac) {
                 // hand over; probe a pruned epoch again after the active size has shrunk by the epoch factor 1, 2, 4, 8 ... times
                 const int64_t na = b.N - it;

@@ -129,8 +129,9 @@ int dpr_sketch(dpr_ctx *ctx, int k, int S, uint64_t *host_sketches);
  * and calculateU (:94-115).  Builds the (sharded) symmetric fp64 matrix and the row sums U. */
 int dpr_dist_matrix(dpr_ctx *ctx, int source, int dist_type, int k);
 
-/* Pay the one-time cost of the process's first hipGraph instantiation (~30 ms; dpr_nj_run replays graphs) now, on a
- * private stream -- the CLI calls it from a helper thread while it reads its input.  No reference counterpart.
+/* Pay the one-time costs of the process's first hipGraph instantiation (~30 ms; dpr_nj_run replays graphs) and of its first
+ * staged device-to-host copy (~8 ms; the first epoch rebuild of an NJ run reads the row sums back) now, on a private
+ * stream -- the CLI calls it from a helper thread while it reads its input.  No reference counterpart.
  * Threading: this is the ONE entry point that may run concurrently with other dpr_* calls on the same context (it
  * touches nothing of the context but its device index; thread-local stream capture, thread-local error string);
  * join the helper thread before dpr_destroy. */
