@@ -127,8 +127,7 @@ struct NjPruned {
     int epoch_index = 0;             // epoch e uses slab e & 1; its matrix lives in arena_D for even e, in NjBuffers::D for odd e
     hipGraphExec_t graph = nullptr;   // graph_iters iterations of (scan, post)
     // plan of THIS context (set by njp_build; two contexts of one process may differ and run on different host threads)
-    int scan_grid = 1024;             // blocks of the unit scan (256 below 50 000 tips; DPR_NJP_GRID)
-    bool scan_grid_auto = false;      // below 50 000 tips, no DPR_NJP_GRID: 256 <-> 512 by the listing rate the adaptive plan watches
+    int scan_grid = 512;              // blocks of the unit scan (DPR_NJP_GRID)
     int graph_iters = 32;             // iterations per captured hipGraph (DPR_NJ_GRAPH_ITERS)
     // Adaptive plan (single rank): the exact pruned scan only pays while its bounds prune.  The host looks at the units
     // listed per iteration after the first graph of an epoch and then every 2 048 iterations; once more than stream_frac of

@@ -1624,13 +1624,14 @@ int njp_build(NjBuffers& b, hipStream_t s)
         // default: 256 blocks while an iteration lists ~100 units (a 1000-block grid takes ~1.5 us just to start; NJ 515 ->
         // 512 ms at 30 000 tips), 512 above (round 2: 1024; every block of the post kernels reduces one record per scan block --
         // NJ at 100 000 tips 2.10 / 2.07 / 2.06 / 2.08 / 2.10 s with 256 / 384 / 512 / 768 / 1024, round 3)
-        // Round 4: the listing rate depends on the data -- branch lengths x 5 / x 25 list 500 / 820 units per iteration instead of
-        // 85 at 30 000 tips, and every block then walks 2 - 4 units one after the other (NJ 574 / 663 ms with 256 blocks,
-        // 544 / 614 with 512): below 50 000 tips the grid follows the rate the adaptive plan watches (njp_run).
+        // Round 4: 512 for every size.  The listing rate depends on the data and on the age of the epoch (4 - 60 units per
+        // iteration in a fresh epoch, 150 - 350 in an old one at 30 000 tips, 770 - 1 180 at 100 000; branch lengths x 5 / x 25:
+        // 500 / 820 on average): with 256 blocks the diverged inputs took 574 / 663 ms, with 512 blocks 544 / 614 ms, the bench
+        // input 479.5 vs 481.5 ms.  A grid that followed the watched rate (256 / 512 / 1 024, graph re-captured) was slower than
+        // 512 throughout: 2.08 vs 2.05 s at 100 000 tips, 657 vs 614 ms on the x 25 input (profiles/r4/scan_grid_*.txt).
         const char* e = std::getenv("DPR_NJP_GRID");
-        const int g = e ? std::atoi(e) : (b.N < 50000 ? 256 : 512);
+        const int g = e ? std::atoi(e) : 512;
         b.pr.scan_grid = g < 1 ? 1 : (g > 1024 ? 1024 : g);
-        b.pr.scan_grid_auto = !e && b.N < 50000;
     }
     if (const char* e = std::getenv("DPR_NJ_ADAPTIVE")) b.pr.adaptive = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("DPR_NJ_STREAM_FRAC")) b.pr.stream_frac = std::atof(e);
@@ -2112,14 +2113,6 @@ int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
             if (const char* el = std::getenv("DPR_NJ_EPOCH_LOG")) if (std::atoi(el) >= 2)
                 std::fprintf(stderr, "[njp] watch at n=%lld: %.0f units per iteration over %.0f iterations (first of epoch %d, P=%lld, utot=%lld, scan grid %d)\n",
                              (long long)(b.N - it), per_it, iters, (int)first_of_epoch, (long long)q.P, (long long)q.utot, q.scan_grid);
-            if (q.scan_grid_auto && iters >= 1.0) {
-                // units per iteration against the blocks that walk them (hysteresis: up from 160, down below 110)
-                const int want = per_it >= 160.0 ? 512 : (per_it < 110.0 ? 256 : q.scan_grid);
-                if (want != q.scan_grid) {
-                    q.scan_grid = want;
-                    if (q.graph) { (void)hipGraphExecDestroy(q.graph); q.graph = nullptr; }      // (the stream is idle: synchronised above)
-                }
-            }
             if (iters >= 1.0 && rate > q.stream_frac) {
                 // hand over; probe a pruned epoch again after the active size has shrunk by the epoch factor 1, 2, 4, 8 ... times
                 const int64_t na = b.N - it;
