@@ -160,7 +160,9 @@ class Stage:
         if self.dist is not None:
             self.dist.barrier()
 
-    def gen(self, tag, tips, sites, seed, mean, lo, hi, fasta=False, reads=False, shuffle=None, gap=None):
+    model = "gtr+g+i"      # substitution model of the aligned inputs (--model)
+
+    def gen(self, tag, tips, sites, seed, mean, lo, hi, fasta=False, reads=False, shuffle=None, gap=None, model=None):
         """returns the paths of input `tag`; rank 0 runs the generator (all host threads: the other ranks wait)"""
         base = os.path.join(self.dir, tag)
         p = {"tips": tips, "sites": sites, "tree": base + ".nwk", "fasta": base + ".fa" if fasta else None,
@@ -175,6 +177,8 @@ class Stage:
                 cmd += ["--indel", "0.03,0.09", "--packed2", p["packed2"]]
             else:
                 cmd += ["--packed4", p["packed4"]]
+                if (model or self.model) != "jc69":
+                    cmd += ["--model", model or self.model]
                 if gap is not None and gap >= 0:      # (gap < 0 / None: gap-free; 0: inherited deletions only; > 0: + per-tip runs)
                     cmd += ["--indel-gaps"]
                     if gap > 0:
@@ -369,6 +373,9 @@ def main():
     ap.add_argument("--gap-frac", type=float, default=0.0,
                     help="STRESS input: expected fraction of '-' cells per tip in the aligned inputs, independent from tip to tip "
                          "(gen_synth --gap-frac).  Not the authors' protocol; at 0.03 the pruned NJ lists 80 x the units (5.7 s at 30 000 tips)")
+    ap.add_argument("--model", default="gtr+g+i", choices=["jc69", "gtr+g+i"],
+                    help="substitution model of the generated ALIGNED inputs (gen_synth --model): gtr+g+i = the authors' protocol "
+                         "(scripts/alisim.sh:14), jc69 = the inputs of rounds 1-3.  The distance type of the runs stays -d 2 (JC69) either way")
     ap.add_argument("--no-indel-gaps", action="store_true",
                     help="aligned inputs without the inherited deletion gaps of the authors' indel model (gen_synth --indel-gaps, "
                          "scripts/alisim.sh:14): the gap-free inputs of rounds 1-3")
@@ -452,6 +459,7 @@ def main():
         log("[bench] building tools/ (gen_synth, nrf)")
         subprocess.run(["make", "-C", os.path.join(ROOT, "tools")], check=True, capture_output=True)
     stage = Stage(rank, world, dist)
+    stage.model = args.model
 
     # ONE watchdog for the whole run: a hung collective (or anything else) must not outlive the driver's limit -- the
     # record so far is printed and the process ends NON-ZERO, which makes the launcher tear the job down
@@ -696,8 +704,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic (seeded Yule-Harding tree, JC69, L=%d, %s; own native generator tools/gen_synth.cpp: no alisim in the image)"
-                    % (L, "no gaps" if args.no_indel_gaps else ("deletions of the authors' indel model as inherited gap runs (gen_synth --indel-gaps)"
+            "data": "synthetic (seeded Yule-Harding tree, %s, L=%d, %s; own native generator tools/gen_synth.cpp: no alisim in the image)"
+                    % ("GTR+G4+I substitutions with the parameters of scripts/alisim.sh:21" if args.model == "gtr+g+i" else "JC69 substitutions", L, "no gaps" if args.no_indel_gaps else ("deletions of the authors' indel model as inherited gap runs (gen_synth --indel-gaps)"
                                                                  + ("; stress: + %.3g of every tip's cells as its own '-' runs" % args.gap_frac if args.gap_frac > 0 else ""))),
             "config": {"workload": "configs[1]: %d aligned tips, -d 2 (JC69), conventional NJ (-m 2)" % n,
                        "tips": n, "sites": L,
@@ -837,6 +845,15 @@ def other_configs(args, local_rank, stage, budget, tmp):
             out = {"workload": "conventional NJ, %d aligned tips x %d sites, JC69 (80 GB matrix on one GPU), packed tips in HBM -> merge log" % (n, L),
                    "tips": n, "seconds": wall, "tips_per_s": n / wall, "dist_ms": dist_ms, "nj_ms": nj_ms,
                    "nj_iterations_per_s": res["iters"] / (nj_ms * 1e-3), "units_scanned": sc, "merge_log_digest": merge_digest(res)}
+            out["input"] = "%s, %s" % (args.model, "no gaps" if args.no_indel_gaps else "inherited deletion gaps")
+            if (args.model != "jc69" or not args.no_indel_gaps) and budget.allows(40):
+                # the same size on the input of rounds 1-3 (JC69, gap-free), for comparison across rounds
+                inp3 = stage.gen("nj100k_r3", n, L, args.seed + 7, 2e-5, 2e-6, 2e-4, gap=None, model="jc69")
+                d.set_msa(Stage.packed4(inp3), L)
+                d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+                res3 = d.nj_run()
+                out["rounds_1_to_3_input"] = {"input": "jc69, no gaps", "dist_ms": d.timing()[0], "nj_ms": d.timing()[1], "units_scanned": d.prune_stats()[0],
+                                              "merge_log_digest": merge_digest(res3)}
         finally:
             d.close()
         if budget.allows(20):

@@ -18,6 +18,7 @@ ap.add_argument("--sites", type=int, default=10000)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--gap-frac", type=float, default=0.0)
 ap.add_argument("--indel-gaps", action="store_true")
+ap.add_argument("--model", default="jc69", help="substitution model of the generated alignment: jc69 | gtr+g+i (gen_synth --model)")
 ap.add_argument("--bl-scale", type=float, default=1.0, help="branch lengths of the generating tree times this (1 = the authors' -rlen; 20: hardly any identical tips, so hardly any tied q)")
 ap.add_argument("--iters", type=int, default=-1)
 ap.add_argument("--reps", type=int, default=1)
@@ -41,13 +42,13 @@ import dipper_amd  # noqa: E402
 from dipper_amd import capi  # noqa: E402
 
 
-def alignment(n, L, seed, gap=0.0, indel_gaps=False, bl_scale=1.0):
+def alignment(n, L, seed, gap=0.0, indel_gaps=False, bl_scale=1.0, model="jc69"):
     k = bl_scale * 10000.0 / L            # same expected number of substitutions per branch as the bench's 10 000 sites
     tmp = tempfile.mkdtemp(prefix="njt_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     p4 = os.path.join(tmp, "a.p4")
     subprocess.run([os.path.join(ROOT, "tools", "bin", "gen_synth"), "--tips", str(n), "--sites", str(L), "--seed", str(seed),
                     "--mean-bl", repr(2e-5 * k), "--lo", repr(2e-6 * k), "--hi", repr(2e-4 * k), "--packed4", p4]
-                   + (["--gap-frac", repr(gap)] if gap > 0 else []) + (["--indel-gaps"] if indel_gaps else []), check=True)
+                   + (["--gap-frac", repr(gap)] if gap > 0 else []) + (["--indel-gaps"] if indel_gaps else []) + (["--model", model] if model != "jc69" else []), check=True)
     packed = np.fromfile(p4, dtype=np.uint64).reshape(n, (L + 15) // 16)
     os.unlink(p4); os.rmdir(tmp)
     return packed
@@ -60,7 +61,7 @@ def digest(res):
     return h.hexdigest()[:16]
 
 
-packed = alignment(args.tips, args.sites, args.seed, args.gap_frac, args.indel_gaps, args.bl_scale)
+packed = alignment(args.tips, args.sites, args.seed, args.gap_frac, args.indel_gaps, args.bl_scale, args.model)
 capi.set_nj_mode(0 if args.mode == "stream" else 1)
 d = dipper_amd.Dipper(0)
 d.set_msa(packed, args.sites)
@@ -87,7 +88,7 @@ for rep in range(args.reps):
     if args.spin > 0:
         assert L_.dpr_spin_stop(d.h) == 0
     dist_ms, nj_ms = d.timing()
-    rec = {"tips": args.tips, "sites": args.sites, "gap_frac": args.gap_frac, "indel_gaps": args.indel_gaps, "bl_scale": args.bl_scale, "spin_blocks": args.spin, "mode": args.mode, "rep": rep, "iters": int(res["iters"]), "dist_ms": dist_ms, "nj_ms": nj_ms,
+    rec = {"tips": args.tips, "sites": args.sites, "gap_frac": args.gap_frac, "indel_gaps": args.indel_gaps, "bl_scale": args.bl_scale, "model": args.model, "spin_blocks": args.spin, "mode": args.mode, "rep": rep, "iters": int(res["iters"]), "dist_ms": dist_ms, "nj_ms": nj_ms,
            "us_per_iteration": nj_ms * 1e3 / max(int(res["iters"]), 1), "units_listed": d.prune_stats()[0] if args.mode != "stream" else None, "digest": digest(res),
            "env": {k: v for k, v in os.environ.items() if k.startswith("DPR_")}}
     if clocks:

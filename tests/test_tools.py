@@ -177,3 +177,46 @@ def test_nrf_rejects_labels_outside_the_tree(tmp_path):
         bad.write_text(text)
         r = subprocess.run([NRF, str(bad), str(ok)], capture_output=True, text=True)
         assert r.returncode == 1 and r.stderr.startswith("nrf: "), (text, r.returncode, r.stderr)
+
+
+def test_gen_synth_gtr_g_i_model(tmp_path):
+    """--model gtr+g+i (the substitution model of scripts/alisim.sh:14 with the explicit parameters of its line 21): base
+    composition F{0.3,0.2,0.2,0.3}, a fifth of the sites invariant plus the slow gamma class, C<->T and G<->T exchanges far
+    ahead of the others, same bytes for any thread count, and the JC69 default untouched."""
+    n, L = 64, 40000
+    base = str(tmp_path / "g")
+    args = [GEN, "--tips", str(n), "--sites", str(L), "--seed", "5", "--mean-bl", "0.05", "--lo", "0.01", "--hi", "0.2"]
+    subprocess.run(args + ["--model", "gtr+g+i", "--threads", "1", "--fasta", base + "1.fa"], check=True)
+    subprocess.run(args + ["--model", "GTR+G+I", "--threads", "4", "--fasta", base + "4.fa"], check=True)
+    assert open(base + "1.fa", "rb").read() == open(base + "4.fa", "rb").read()
+    _, seqs = _fasta(base + "1.fa")
+    A = np.frombuffer(b"".join(seqs), dtype=np.uint8).reshape(n, L)
+    freq = {c: float((A == ord(c)).mean()) for c in "ACGT"}
+    for c, f in zip("ACGT", (0.3, 0.2, 0.2, 0.3)):
+        assert abs(freq[c] - f) < 0.02, freq
+    constant = float((A == A[0]).all(axis=0).mean())
+    assert 0.2 <= constant < 0.5, constant            # 20 % invariant + most of the slowest gamma class
+    # exchanges between the first tip and every other one, by unordered pair of bases (short branches: hardly any site hit twice)
+    subprocess.run([GEN, "--tips", str(n), "--sites", str(L), "--seed", "5", "--mean-bl", "0.001", "--lo", "0.0002", "--hi", "0.004",
+                    "--model", "gtr+g+i", "--fasta", base + "s.fa"], check=True)
+    _, ss = _fasta(base + "s.fa")
+    B = np.frombuffer(b"".join(ss), dtype=np.uint8).reshape(n, L)
+    pairs = {}
+    for r in range(1, n):
+        d = B[0] != B[r]
+        for x, y in zip(B[0][d], B[r][d]):
+            k = "".join(sorted(chr(x) + chr(y)))
+            pairs[k] = pairs.get(k, 0) + 1
+    tot = sum(pairs.values())
+    assert (pairs.get("CT", 0) + pairs.get("GT", 0)) / tot > 0.75, pairs
+    assert pairs.get("CG", 0) / tot < 0.02 and pairs.get("AC", 0) / tot < 0.03, pairs
+    # the default model is still JC69: uniform composition, every exchange alike
+    subprocess.run(args + ["--fasta", base + "j.fa"], check=True)
+    subprocess.run(args + ["--model", "jc69", "--fasta", base + "j2.fa"], check=True)
+    assert open(base + "j.fa", "rb").read() == open(base + "j2.fa", "rb").read()
+    _, sj = _fasta(base + "j.fa")
+    J = np.frombuffer(b"".join(sj), dtype=np.uint8).reshape(n, L)
+    for c in "ACGT":
+        assert abs(float((J == ord(c)).mean()) - 0.25) < 0.02
+    r = subprocess.run([GEN, "--tips", "10", "--sites", "100", "--model", "hky", "--fasta", base + "x.fa"], capture_output=True, text=True)
+    assert r.returncode != 0 and "--model" in r.stderr

@@ -12,7 +12,7 @@
 // and the ranks of a multi-GPU bench map the files.
 //
 //   gen_synth --tips N --sites L [--seed S] [--mean-bl m --lo a --hi b] [--indel INS,DEL[,MEANLEN]] [--shuffle SEED]
-//             [--indel-gaps] [--gap-frac F[,MEANRUN]] [--threads T] [--fasta out.fa] [--packed4 out.u64] [--packed2 prefix] [--tree out.nwk]
+//             [--model jc69|gtr+g+i] [--indel-gaps] [--gap-frac F[,MEANRUN]] [--threads T] [--fasta out.fa] [--packed4 out.u64] [--packed2 prefix] [--tree out.nwk]
 //             [--order out.i32]
 //
 // Gaps in ALIGNED output (round 4; gap cells are code 4 in the 4-bit packing, src/fourBitCompressor.cpp:33-35, and '-' in the
@@ -105,6 +105,7 @@ struct Args {
     double ins = 0.03, del = 0.09, indel_mean = 2.0;
     double gap_frac = 0.0, gap_run = 10.0;
     bool indel_gaps = false;
+    bool gtr = false;                  // --model gtr+g+i
     bool shuffle = false;
     uint64_t shuffle_seed = 0;
     int threads = 0;
@@ -170,17 +171,79 @@ Tree yule(int64_t n, const Args& a)
     return t;
 }
 
-using Seq = std::vector<uint8_t>;      // codes 0..3; 4 = gap (aligned output with --gap-frac)
+using Seq = std::vector<uint8_t>;      // codes 0..3 = A C G T; 4 = gap (aligned output with --gap-frac)
+
+// --model gtr+g+i: the substitution model of the authors' protocol (scripts/alisim.sh:14: -m "GTR+G+I"; alisim draws the
+// parameters when none are given -- the values here are the explicit ones of the same script's commented variant, line 21:
+// GTR{0.0132,0.105,0.0417,0.00745,1.0254}+F{0.3,0.2,0.2,0.3}+G4{0.5}+I{0.2}).  Simulated by uniformisation: events arrive at
+// rate mu x (site rate) per site, an event at a site in state i moves it to j with probability Q_ij / mu (or leaves it);
+// a branch of length bl carries bl expected substitutions per site, as under JC69.
+struct GtrModel {
+    double freq[4] = { 0.3, 0.2, 0.2, 0.3 };
+    double P[4][4];                    // jump probabilities of an event (row: from), diagonal = stay
+    double mu = 1.0;
+    std::vector<double> cum;           // cumulative site rates (0 for invariant sites)
+    double total = 0.0;
+    void setup(uint64_t seed, size_t L)
+    {
+        const double ex[6] = { 0.013206908228919744, 0.10497798848628515, 0.04165255672197765, 0.007450050795800881, 1.0253979004402303, 1.0 };   // AC AG AT CG CT GT
+        double S[4][4] = {};
+        int e = 0;
+        for (int i = 0; i < 4; ++i) for (int j = i + 1; j < 4; ++j) { S[i][j] = S[j][i] = ex[e++]; }
+        double Q[4][4], scale = 0.0;
+        for (int i = 0; i < 4; ++i) {
+            double row = 0.0;
+            for (int j = 0; j < 4; ++j) if (j != i) { Q[i][j] = S[i][j] * freq[j]; row += Q[i][j]; }
+            Q[i][i] = -row;
+            scale += freq[i] * row;
+        }
+        mu = 0.0;
+        for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) Q[i][j] /= scale; if (-Q[i][i] > mu) mu = -Q[i][i]; }
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) P[i][j] = i == j ? 1.0 + Q[i][i] / mu : Q[i][j] / mu;
+        // +I{0.2}: a fifth of the sites never change; +G4{0.5}: the others fall into four equiprobable classes with the mean
+        // rates of a gamma(0.5) distribution's quartiles; scaled so that the mean over all sites is 1
+        const double pinv = 0.2, cat[4] = { 0.03338775, 0.25191592, 0.82026848, 2.89442785 };
+        Rng r(seed, 0, 11);
+        cum.resize(L);
+        total = 0.0;
+        for (size_t s2 = 0; s2 < L; ++s2) {
+            const double u = r.uniform();
+            const double rate = u < pinv ? 0.0 : cat[r.below(4)] / (1.0 - pinv);
+            total += rate;
+            cum[s2] = total;
+        }
+    }
+    uint8_t root_base(Rng& r) const
+    {
+        const double u = r.uniform();
+        return u < freq[0] ? 0 : (u < freq[0] + freq[1] ? 1 : (u < freq[0] + freq[1] + freq[2] ? 2 : 3));
+    }
+};
+static GtrModel g_gtr;
 
 void evolve(const Seq& src, Seq& dst, double bl, uint64_t node, const Args& a)
 {
     dst = src;
     Rng r(a.seed, node, 3);
-    const uint64_t k = r.poisson((double)dst.size() * bl);
-    for (uint64_t i = 0; i < k; ++i) {
-        const size_t p = (size_t)r.below(dst.size());
-        const uint8_t nb = (uint8_t)((dst[p] + 1 + r.below(3)) & 3);
-        if (dst[p] < 4) dst[p] = nb;          // a deleted site stays deleted
+    if (a.gtr) {
+        const uint64_t k = r.poisson(g_gtr.total * g_gtr.mu * bl);
+        for (uint64_t i = 0; i < k; ++i) {
+            const double u = r.uniform() * g_gtr.total;
+            size_t p = (size_t)(std::upper_bound(g_gtr.cum.begin(), g_gtr.cum.end(), u) - g_gtr.cum.begin());
+            if (p >= dst.size()) p = dst.size() - 1;
+            const double v = r.uniform();
+            if (dst[p] >= 4) continue;        // a deleted site stays deleted
+            const double* row = g_gtr.P[dst[p]];
+            double c = 0.0;
+            for (uint8_t j = 0; j < 4; ++j) { c += row[j]; if (v < c || j == 3) { dst[p] = j; break; } }
+        }
+    } else {
+        const uint64_t k = r.poisson((double)dst.size() * bl);
+        for (uint64_t i = 0; i < k; ++i) {
+            const size_t p = (size_t)r.below(dst.size());
+            const uint8_t nb = (uint8_t)((dst[p] + 1 + r.below(3)) & 3);
+            if (dst[p] < 4) dst[p] = nb;          // a deleted site stays deleted
+        }
     }
     if (!a.indels && (a.indel_gaps || a.gap_frac > 0.0)) {
         // aligned output: a deletion on this branch is a run of gap cells that every descendant inherits (own generator:
@@ -324,6 +387,12 @@ int main(int argc, char** argv)
             if (!(a.gap_frac >= 0.0 && a.gap_frac < 0.9) || !(a.gap_run >= 1.0)) die("--gap-frac F[,MEANRUN]: 0 <= F < 0.9, MEANRUN >= 1");
         }
         else if (k == "--indel-gaps") a.indel_gaps = true;
+        else if (k == "--model") {
+            std::string v = val();
+            for (auto& c : v) c = (char)std::tolower((unsigned char)c);
+            if (v == "gtr+g+i") a.gtr = true;
+            else if (v != "jc" && v != "jc69") die("--model jc69 | gtr+g+i");
+        }
         else if (k == "--shuffle") { a.shuffle = true; a.shuffle_seed = std::strtoull(val(), nullptr, 10); }
         else if (k == "--threads") a.threads = std::atoi(val());
         else if (k == "--fasta") a.fasta = val();
@@ -333,13 +402,15 @@ int main(int argc, char** argv)
         else if (k == "--order") a.order = val();
         else if (k == "-h" || k == "--help") {
             std::fprintf(stderr, "usage: gen_synth --tips N --sites L [--seed S] [--mean-bl m --lo a --hi b] [--indel INS,DEL[,MEANLEN]] [--shuffle SEED]\n"
-                                 "                 [--indel-gaps] [--gap-frac F[,MEANRUN]] [--threads T] [--fasta f] [--packed4 f] [--packed2 prefix] [--tree f] [--order f]\n");
+                                 "                 [--model jc69|gtr+g+i] [--indel-gaps] [--gap-frac F[,MEANRUN]] [--threads T] [--fasta f] [--packed4 f] [--packed2 prefix] [--tree f] [--order f]\n");
             return 0;
         } else die("unknown argument " + k);
     }
     if (a.tips < 2 || a.sites < 1) die("--tips >= 2 and --sites >= 1 are required");
     if (a.indels && !a.packed4.empty()) die("--packed4 needs aligned output (no --indel)");
     if (a.indels && (a.gap_frac > 0.0 || a.indel_gaps)) die("--gap-frac / --indel-gaps are for aligned output (no --indel)");
+    if (a.indels && a.gtr) die("--model gtr+g+i is for aligned output (per-site rates; no --indel)");
+    if (a.gtr) g_gtr.setup(a.seed, (size_t)a.sites);
     const int64_t N = a.tips, L = a.sites;
     const int T = a.threads > 0 ? a.threads : host_threads();
 
@@ -370,7 +441,7 @@ int main(int argc, char** argv)
         std::vector<Fr> st;
         Seq root((size_t)L);
         Rng r0(a.seed, 0, 5);
-        for (auto& c : root) c = (uint8_t)r0.below(4);
+        for (auto& c : root) c = a.gtr ? g_gtr.root_base(r0) : (uint8_t)r0.below(4);
         st.push_back({ 0, std::move(root) });
         while (!st.empty()) {
             Fr f = std::move(st.back());
