@@ -1138,6 +1138,12 @@ int dpr_get_nj_kernel_timing(dpr_ctx* c, int* kernels, double* us_avg, int64_t* 
 }
 const char* dpr_nj_kernel_name(int idx) { return njp_kernel_name(idx); }
 int dpr_get_nj_phase_stamps(uint64_t* out) { return njp_phase_stamps((unsigned long long*)out); }
+int dpr_get_njp_list(dpr_ctx* c, int32_t* out, int64_t cap, int64_t* count, int64_t* positions, double* ur, int64_t ur_cap)
+{
+    if (!c || !out || !count || !positions) { set_error("dpr_get_njp_list: null argument"); return DPR_ERR_ARG; }
+    DPR_HIP(hipSetDevice(c->device));
+    return njp_debug_list(c->nj[0], out, cap, count, positions, ur, ur_cap);
+}
 
 int dpr_ctx_set_nj_virtual_shards(dpr_ctx* c, int w)
 {

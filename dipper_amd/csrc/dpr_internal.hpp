@@ -274,6 +274,7 @@ int njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world);
 int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s);   // enqueue `todo` iterations (hipGraph replays)
 const char* njp_kernel_name(int idx);   // kernels of one iteration, in launch order
 int njp_phase_stamps(unsigned long long* out);   // debug (DPR_NJ_PHASES)
+int njp_debug_list(NjBuffers& b, int32_t* out, int64_t cap, int64_t* count, int64_t* P, double* ur, int64_t urcap);   // debug
 const double* njp_current_u(const NjPruned& q, int64_t it);   // row sums by position after `it` iterations
 
 // Divide-and-conquer cluster distances (dc.hip builds the jobs; msa.hip / mash.hip run them).

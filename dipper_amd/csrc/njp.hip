@@ -2027,6 +2027,24 @@ const char* njp_kernel_name(int idx)
     return idx >= 0 && idx < 3 ? names[idx] : "";
 }
 
+// debug: the unit list the next scan would walk (codes: sub-unit mask << 28 | strip << 18 | row group) and the row sums by position
+// (Ur: U / (n - 2); NaN = dead position or the node in quarantine) of the current epoch, after a dpr_nj_run that stopped early
+int njp_debug_list(NjBuffers& b, int32_t* out, int64_t cap, int64_t* count, int64_t* P, double* ur, int64_t urcap)
+{
+    NjPruned& q = b.pr;
+    if (!q.active || q.slots_mode || q.sh_world > 1) { set_error("njp_debug_list: no single-rank pruned epoch"); return DPR_ERR_STATE; }
+    DPR_HIP(hipDeviceSynchronize());
+    NjState st;
+    DPR_HIP(hipMemcpy(&st, b.st, sizeof(NjState), hipMemcpyDeviceToHost));
+    const int64_t cnt = (int64_t)st.cnt_list[st.it % 3];
+    *count = cnt; *P = q.P;
+    const int64_t take = cnt < cap ? cnt : cap;
+    if (take > 0) DPR_HIP(hipMemcpy(out, q.list, sizeof(int32_t) * (size_t)take, hipMemcpyDeviceToHost));
+    const int64_t tu = q.P < urcap ? q.P : urcap;
+    if (ur && tu > 0) DPR_HIP(hipMemcpy(ur, q.Ur, sizeof(double) * (size_t)tu, hipMemcpyDeviceToHost));
+    return DPR_OK;
+}
+
 // debug: the phase stamps of iteration DPR_NJ_PHASES (2 x 2048 x 8 words), 0 = not stamped
 int njp_phase_stamps(unsigned long long* out)
 {

@@ -212,6 +212,10 @@ const char *dpr_nj_kernel_name(int idx);
 /* debug, needs DPR_NJ_PHASES=<iteration>: 2 kernels x 2048 blocks x 8 phase stamps (100 MHz ticks, 0 = none) of that
  * iteration of the last pruned NJ run (profiles/nj_phases.py) */
 int dpr_get_nj_phase_stamps(uint64_t *out32768);
+/* debug (profiles/njp_list_shape.py): after a dpr_nj_run that stopped early on the default single-GPU plan, the units the next
+ * scan would walk -- codes (sub-unit mask << 28 | strip << 18 | row group), *count of them (at most cap copied) -- the number
+ * of positions of the current epoch and, if ur != NULL, the row sums U / (n - 2) by position (NaN: dead / in quarantine) */
+int dpr_get_njp_list(dpr_ctx *ctx, int32_t *out, int64_t cap, int64_t *count, int64_t *positions, double *ur, int64_t ur_cap);
 /* host-only: owner of the 16-row x 512-column unit (strip = column block, group = row group) among `world` ranks
  * when the position space has P positions (units are tested in blocks of one strip x 256 consecutive row groups,
  * strip-major; test block t and its units belong to rank t mod world); -1 if the unit holds no pair of the strict
