@@ -41,6 +41,7 @@
 namespace dpr {
 
 constexpr int kUR = 16;  // rows per unit
+constexpr int kReserve = 128;     // units of the reserve a scan walks at most (njp_post2_kernel): as many as there are seed candidates among the unit records
 // Row groups (= units of one strip) per test block of the post kernel: 64 below 40 000 positions (1024 row positions per
 // block: the row phase of a block is short, NJ 500 -> 482 ms at 30 000 tips), 256 above (fewer blocks, less repeated
 // column and record work where the kernel is throughput-bound).  The switch: 38 000-50 000 positions measured within
@@ -268,11 +269,13 @@ struct NjpArgs {
     double* U; double* R; int64_t vstride;      // U, R: [2][vstride]
     double* Ur; uint64_t* KA; uint64_t* KB; int32_t* slot_of_pos; int32_t* pos_of_slot;
     double* xpart; NjRecord* partials; unsigned long long* umin;
+    double* hq; double umax0;     // second bound per sub-unit (large shape; see njp_q_drift) and the epoch's largest row sum
     int64_t P;
     const int32_t* blk_cb; const int32_t* blk_g0; int ntest;     // test blocks: (first strip, first group), up to 256 groups each
     int tg, ns;                                                  // ... of tg row groups x up to ns strips
     int nupd;                                                    // update blocks of this post launch
     int32_t* list; unsigned long long* cnt;     // the list of THIS launch's rank and its counters cnt[0..2]
+    int64_t list_cap;                           // entries of that list: units that MUST be scanned grow from the front, the reserve (see njp_post2_kernel) from the back
     int ugrid;        // unit-scan blocks per rank
     int urecs;        // unit records in partials (ugrid x ranks); the new-row records follow them
     int nrb;          // new-row blocks = ceil(P / 512)
@@ -302,6 +305,28 @@ struct NjpArgs {
 // test role that needs the same row sums before they are stored
 __device__ __forceinline__ double nj_val(double dxi, double dyi, double d) { return (dxi + dyi - d) * 0.5; }
 __device__ __forceinline__ double nj_unew(double up, double dxi, double dyi, double val) { return up + (-dxi - dyi + val); }
+
+// Second bound of a sub-unit (large shape; round 4).  An epoch ages: a merged node keeps a child's position with distances and a
+// row sum both smaller than its neighbours' by ~ d_xy / 2, the unit minimum follows the distances, the group's maximal row sum
+// stays with the neighbours -- every unit along that row group fails the test `umin - rmax - cmax <= seed` iteration after
+// iteration although one scan shows that its candidates are far from winning (64 % of the units an old epoch of 100 000 tips
+// lists lie more than ten strips off the diagonal, 43 % in 50 of 6 250 row groups: profiles/njp_list_shape.py).  The scan
+// computes the exact minimum q of every sub-unit it walks (pass 1's wave minimum) anyway; it stores it, and a unit is listed
+// only if that minimum, less everything the merges since then can have taken off it, reaches the seed bound as well.
+//   q_ij = fl(fl(d_ij - Ur_i) - Ur_j), Ur = fl(U / (n - 2)).  One merge changes U_i by t_i <= T (T = 0 while every entry is >= 0,
+//   njp_post2_kernel's `slack` otherwise) and n - 2 into n - 3, so Ur_i grows by at most
+//       (U_i + T) / (n - 3) - U_i / (n - 2)  =  U_i / ((n - 2)(n - 3)) + T / (n - 3)   (+ roundings of relative size 2^-52),
+//   and q_ij falls by at most twice that.  U_i <= umax0 + (k + n) T after k merges of the epoch (every merge adds at most T to
+//   a row sum; a new node's row sum is at most the mean of its children's plus n |d_xy| / 2 <= n T).  NjState::acc sums these
+//   per-merge bounds over the epoch; the stored value is `minimum q + acc at scan time`, the test subtracts acc of ITS time.
+//   The factor 1 + 2^-30 pays for every rounding involved (n < 10^6); a fixed relative margin pays for the two subtractions.
+// A merge that puts a new node into a unit's rows or columns voids the stored value (-inf) until the unit is scanned again.
+__device__ __forceinline__ double njp_q_drift(double umax0, double slack, int64_t P, int64_t n)
+{
+    const double r0 = (double)(n - 2), r1 = (double)(n - 3);
+    const double umax = umax0 + (double)(P - n + 1 + n) * slack;
+    return 2.0 * (umax / (r0 * r1) + slack / r1) * (1.0 + 0x1p-30);
+}
 
 __device__ __forceinline__ void best_update4(double& bq, uint64_t& bk, uint64_t& bp, double& bd, double q, uint64_t k,
                                              uint64_t pp, double d)
@@ -369,6 +394,7 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjState* h_st, const
     const int32_t first = unit_block ? h_list[ub] : 0;
     const double xp0 = unit_block ? 0.0 : h_xpart[tid];          // (the array is padded to a multiple of 256 entries)
     const unsigned long long cl0 = h_cnt[0], cl1 = h_cnt[1], cl2 = h_cnt[2];      // (not a second, dependent load behind `it`)
+    const double acc = h_st->acc;                                                  // (njp_q_drift; same line)
     // new-row blocks: this thread's two positions of the buffered row (BOTH buffers: which one is current needs `it`) and
     // their vectors -- nothing here waits for the state line (the vectors are padded past the last block's columns)
     const int64_t j0 = (int64_t)blockIdx.x * kTileCols + 2 * tid;
@@ -382,6 +408,8 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjState* h_st, const
     }
     const int32_t pn0 = h_st->pnew[0], pn1 = h_st->pnew[1];      // (both with the state line)
     const int64_t pz = (int64_t)((it & 1) ? pn1 : pn0);
+    // (the reserve entry this block would take, see below; issued behind the loads above: its index needs the argument block)
+    const int32_t first_res = unit_block ? h_list[a.list_cap - a.ugrid + ub] : 0;
     if (blockIdx.x == 0 && tid == 0) h_st->itb = it;             // the post kernel's iteration index (it advances `it` itself); also beyond the limit
     if (it >= limit || h_st->status != 0) return;
     NJP_STAMP(0, 0, true);
@@ -427,14 +455,23 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjState* h_st, const
         // ---------------------------------------------------------------- unit block
         rec_out = a.partials + a.rec_off + ub;
         const int m3 = (int)(it % 3);
-        const int64_t cnt = (int64_t)(m3 == 0 ? cl0 : m3 == 1 ? cl1 : cl2);
-        if ((int64_t)ub >= cnt) {
+        // the counter word: low half = units that MUST be scanned (front of the list), high half = the RESERVE (njp_post2_kernel:
+        // units only the second bound excludes; entry k at list[cap - 1 - k]).  A block without a unit of the first kind takes
+        // ONE reserve entry -- block ugrid - 1 - k takes entry k -- so that the records the next seed bound is taken from stay
+        // as many as before (see njp_post2_kernel), at no cost: the block would have been idle.
+        const unsigned long long craw = m3 == 0 ? cl0 : m3 == 1 ? cl1 : cl2;
+        const int64_t cnt = (int64_t)(craw & 0xFFFFFFFFull);
+        const int64_t res_n = (int64_t)(craw >> 32) < kReserve ? (int64_t)(craw >> 32) : kReserve;
+        const bool res_block = (int64_t)ub >= cnt && (int64_t)(a.ugrid - 1 - ub) < res_n;
+        if ((int64_t)ub >= cnt && !res_block) {
             if (a.all_defined && tid == 0) {      // unit-sharded mode: every record of the gathered array is defined
                 NjRecord rec; rec.q = 10000.0; rec.key = ~0ull; rec.d = 0.0; rec.pad = 0ull;
                 *rec_out = rec;
             }
             return;
         }
+        const int64_t e_end = res_block ? (int64_t)ub + 1 : cnt;
+        const int32_t first_code = res_block ? first_res : first;
         const int64_t G16 = (P + kUR - 1) / kUR;
         // Two passes per unit instead of a (q, key, positions, d) compare-and-select per candidate (64 candidates
         // per lane and unit, ~20 VALU instructions each, were 2 us of this kernel's critical path): pass 1 computes
@@ -443,8 +480,8 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjState* h_st, const
         // bq is wave-uniform; (bk, bp, bd) is this lane's best candidate AT q == bq (bk == ~0: none).
         int64_t scanned = 0;
         const int wv = tid >> 6;                         // this wave's sub-strip of every unit
-        for (int64_t e = ub; e < cnt; e += a.ugrid, ++scanned) {
-            const uint32_t code = (uint32_t)__builtin_amdgcn_readfirstlane(e == (int64_t)ub ? first : a.list[e]);
+        for (int64_t e = ub; e < e_end; e += a.ugrid, ++scanned) {
+            const uint32_t code = (uint32_t)__builtin_amdgcn_readfirstlane(e == (int64_t)ub ? first_code : a.list[e]);
             if (!((code >> (28 + wv)) & 1u)) continue;   // the bound of this wave's sub-unit rules it out (wave-uniform)
             const int cb = (int)((code >> 18) & 1023u);
             const int64_t g_s = (int64_t)(code & 0x3FFFFu);
@@ -525,7 +562,10 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjState* h_st, const
             NJP_STAMP(0, 7, false);
             // exact minimum of this wave's sub-unit -> its bound (no cross-wave step)
             m = wave_fmin(m);
-            if ((tid & 63) == 0) a.umin[((int64_t)cb * G16 + g_s) * 4 + wv] = enc_f64(m);
+            if ((tid & 63) == 0) {
+                a.umin[((int64_t)cb * G16 + g_s) * 4 + wv] = enc_f64(m);
+                a.hq[((int64_t)cb * G16 + g_s) * 4 + wv] = wm + acc;        // exact minimum q of the sub-unit now (+inf: no live pair)
+            }
         }
         // wave winner: the smallest key among the lanes' candidates at bq, then that lane's positions and distance
         {
@@ -639,7 +679,7 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
     }
     const unsigned long long cl0 = h_cnt[0], cl1 = h_cnt[1], cl2 = h_cnt[2];      // all three list counters with the first round trip (not a second, dependent load)
     const int m3 = (int)(it % 3);
-    const unsigned long long cnt_raw = a.all_defined ? (unsigned long long)a.urecs : (m3 == 0 ? cl0 : m3 == 1 ? cl1 : cl2);
+    const unsigned long long cnt_raw = a.all_defined ? (unsigned long long)a.urecs : ((m3 == 0 ? cl0 : m3 == 1 ? cl1 : cl2) & 0xFFFFFFFFull);   // (no reserve in this kernel's epochs)
     const int64_t uvalid = (int64_t)(cnt_raw < (unsigned long long)a.urecs ? cnt_raw : (unsigned long long)a.urecs);   // unit records written by SCAN(it)
     const double* __restrict__ Uc = a.U + (it & 1) * a.vstride;
     double* __restrict__ Un = a.U + ((it + 1) & 1) * a.vstride;
@@ -1064,7 +1104,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
     const int nseed_units = kThreads - nseed_rows;
     const int64_t sstride = a.all_defined && a.urecs >= 2 * nseed_units ? a.urecs / nseed_units : 1;
     const bool seed_is_unit = tid < nseed_units;
-    NjRecord cand = r0;
+    NjRecord cand = r0, cand_res = r0;
     int cb0 = 0;
     int64_t g0 = 0;
     // UM: the block's two chunks of 256 reference slots (the chunk sums stay per 256 slots: the canonical order of U[x]) and
@@ -1091,8 +1131,17 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
     const unsigned long long cl0 = h_cnt[0], cl1 = h_cnt[1], cl2 = h_cnt[2];      // all three list counters with the first round trip (not a second, dependent load)
     const int m3 = (int)(it % 3);
     const unsigned long long cnt_raw = a.all_defined ? (unsigned long long)a.urecs : (m3 == 0 ? cl0 : m3 == 1 ? cl1 : cl2);
-    const int64_t uvalid = (int64_t)(cnt_raw < (unsigned long long)a.urecs ? cnt_raw : (unsigned long long)a.urecs);
+    // unit records written by SCAN(it): blocks [0, uvalid) walked the units that had to be scanned, blocks [ures0, urecs) one unit
+    // of the reserve each (njp_scan_kernel)
+    const int64_t cnt_must = (int64_t)(cnt_raw & 0xFFFFFFFFull), cnt_res = (int64_t)(cnt_raw >> 32) < kReserve ? (int64_t)(cnt_raw >> 32) : kReserve;
+    const int64_t uvalid = cnt_must < (int64_t)a.urecs ? cnt_must : (int64_t)a.urecs;
+    const int64_t ures0 = (int64_t)a.urecs - (cnt_res < (int64_t)a.urecs - uvalid ? cnt_res : (int64_t)a.urecs - uvalid);
     const double emin = dec_f64(hdr->min_enc), eabs = dec_f64(hdr->maxabs_enc);
+    const double acc = h_st->acc;                               // (njp_q_drift: the merges of this epoch so far)
+    // T >= every t_i of this merge (see the header of this kernel); the header's values are within a factor of two.
+    // (evaluated where it is used: computed here, the wait for the header's line sat in front of every later load of the first
+    //  round trip -- 0.5 us on every block of the launch)
+    auto slack_of = [&]() { return emin >= 0.0 ? 0.0 : (3.0 * -emin) * (1.0 + 0x1p-30) + eabs * 0x1p-47; };
     v2d uc; uc.x = 0.0; uc.y = 0.0;
     const int64_t g = g0 + tid;                                  // (T) this lane's row group
     const bool have_g = trole && g < G16;
@@ -1105,7 +1154,15 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
         const int64_t send = njp_strips_of_rows(g0, kTG, P);
         nsb = (int)(send - cb0 < kNS ? send - cb0 : kNS);
         if (pz >= 0) uz = Uc[pz];
-        if (seed_is_unit && (int64_t)tid * sstride >= uvalid) cand.key = ~0ull;          // not written by this iteration's scan
+        // the record of the scan block that walked reserve entry `tid`: the seed candidate of this thread when its own block had
+        // no unit (with the second bound only a dozen units MUST be scanned per iteration).  Loaded HERE, with the second round
+        // trip: its index needs the argument block, and a load in front of the first round trip would hold that back until the
+        // s_load of the arguments has returned (+ 0.5 us on every block of the launch, measured)
+        if (seed_is_unit && sstride == 1 && tid < a.urecs) cand_res = h_partials[a.urecs - 1 - tid];
+        if (seed_is_unit && (int64_t)tid * sstride >= uvalid && (int64_t)tid * sstride < ures0) cand.key = ~0ull;          // not written by this iteration's scan
+        if (seed_is_unit && sstride == 1 && (int64_t)(a.urecs - 1 - tid) >= ures0 && (int64_t)(a.urecs - 1 - tid) >= uvalid && cand_res.key != ~0ull &&
+            (cand.key == ~0ull || cand_res.q < cand.q))
+            cand = cand_res;
         if (cand.key != ~0ull) {
             ci = (int64_t)(cand.pad & 0xffffffffull); cj = (int64_t)(cand.pad >> 32);
             if (!(ci < P && cj < P)) ci = -1;
@@ -1114,7 +1171,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
 #pragma unroll
     for (int k = 0; k < kMine; ++k) {
         const int idx = tid + k * kThreads;
-        if (idx >= uvalid && idx < a.urecs) mine[k] = r0;   // not written by this iteration's scan
+        if (idx >= uvalid && idx < ures0) mine[k] = r0;   // not written by this iteration's scan
     }
     NJP_STAMP(1, 0, false);
     NJP_STAMP(1, 1, true);
@@ -1131,7 +1188,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
     for (int k = 0; k < kMine; ++k)
         if (k < nmine) best_update4(bq, bk, bp, d, mine[k].q, mine[k].key, mine[k].pad, mine[k].d);
     for (int64_t idx = tid + kMine * kThreads; idx < nrec_all; idx += kThreads)
-        if (idx < uvalid || idx >= a.urecs) best_update4(bq, bk, bp, d, a.partials[idx].q, a.partials[idx].key, a.partials[idx].pad, a.partials[idx].d);
+        if (idx < uvalid || idx >= ures0) best_update4(bq, bk, bp, d, a.partials[idx].q, a.partials[idx].key, a.partials[idx].pad, a.partials[idx].d);
     wave_best4(bq, bk, bp, d);
     if (lane == 0) { sq[tid >> 6] = bq; sk[tid >> 6] = bk; spp[tid >> 6] = bp; sdd[tid >> 6] = d; }
     __syncthreads();
@@ -1247,6 +1304,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
                     a.st->x = (int32_t)x; a.st->y = (int32_t)y; a.st->d = d; a.st->q = bq;
                     a.st->n = n1; a.st->it = it + 1;
                     a.st->pnew[(it + 1) & 1] = (int32_t)px;
+                    a.st->acc = acc + njp_q_drift(a.umax0, slack_of(), a.P, n);       // (what the next scan adds to the minima it stores)
                     a.U[(it & 1) * a.vstride + py] = __builtin_nan("");       // (this thread's own store, behind its read of U[py] above)
                     a.st->cnt_list[(it + 2) % 3] = 0ull;
                     for (int v = 0; v < a.cnt_ranks; ++v) a.cnt_all[4 * v + (it + 2) % 3] = 0ull;
@@ -1329,7 +1387,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
     if (lane == 0) sseed[tid >> 6] = qc;
     NJP_STAMP(1, 3, true);
     // upper bounds of the maxima after this merge (see the header)
-    const double slack = emin >= 0.0 ? 0.0 : (3.0 * -emin) * (1.0 + 0x1p-30) + eabs * 0x1p-47;      // (the header's values are within a factor of two)
+    const double slack = slack_of();
     const bool zlive = pz >= 0 && pz != px && pz != py;                        // the node leaving quarantine stays
     uz = (uz == uz) ? uz : PINF;                                               // (its row sum is always in memory here; NaN would silently drop out of fmax)
     const int64_t gz = zlive ? pz / kUR : -1;
@@ -1406,6 +1464,8 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
                     u4[w] = nm;
                     up4[w] = enc_f64(nm);
                 }
+                // the new node brings candidates of its own into this sub-unit: the minimum q of its last scan says nothing about them
+                if (nm < PINF) a.hq[((int64_t)cb * G16 + g) * 4 + w] = NINF;
                 mymin = fmin(mymin, u4[w]);
                 const double lb = fmin((u4[w] - rmax) - cmw, (u4[w] - cmw) - rmax);
                 if ((cmw > NINF) && (lb <= bound)) submask |= 1 << w;
@@ -1413,22 +1473,58 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
         }
         if (have && (rmax > NINF)) sub[sidx] = submask;
     }
-    // ONE list append per wave for all its strips (an atomic per strip is a chain of kNS dependent round trips)
-    {
-        unsigned long long masks[kNS];
-        int total = 0;
+    int res[kNS];                  // per strip: the sub-units only the second bound excludes (the reserve, below)
 #pragma unroll
-        for (int sidx = 0; sidx < kNS; ++sidx) { masks[sidx] = __ballot(sub[sidx] != 0); total += __popcll(masks[sidx]); }
-        if (total > 0) {                              // wave-uniform
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(&a.cnt[(it + 1) % 3], (unsigned long long)total);
-            base = __shfl(base, 0, 64);
+    for (int sidx = 0; sidx < kNS; ++sidx) res[sidx] = 0;
+    // second bound (njp_q_drift): of the sub-units that failed the first test, list only those whose exact minimum q of their last
+    // scan, less the drift since then (this merge included), reaches the seed bound too.  All loads of a lane in one round trip.
+    if (!(a.flags & 64)) {
+        const double accn = acc + njp_q_drift(a.umax0, slack, P, n);
+        double hv[kNS][4];
+#pragma unroll
+        for (int sidx = 0; sidx < kNS; ++sidx) res[sidx] = 0;
+#pragma unroll
+        for (int sidx = 0; sidx < kNS; ++sidx)
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                hv[sidx][w] = ((sub[sidx] >> w) & 1) ? a.hq[((int64_t)(cb0 + sidx) * G16 + g) * 4 + w] : NINF;
+#pragma unroll
+        for (int sidx = 0; sidx < kNS; ++sidx)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const double lb2 = hv[sidx][w] - accn;
+                const double margin = (fabs(hv[sidx][w]) + accn) * 0x1p-40;
+                if (((sub[sidx] >> w) & 1) && lb2 - margin > bound) { sub[sidx] &= ~(1 << w); res[sidx] |= 1 << w; }       // (-inf, NaN: stays listed)
+            }
+    }
+    // ONE list append per wave for all its strips (an atomic per strip is a chain of kNS dependent round trips).  The units the
+    // second bound excludes go to the RESERVE -- the back of the same list, counted in the high half of the same word: scan
+    // blocks that would be idle walk one each.  Without them the scan would produce a dozen records per iteration instead of
+    // hundreds, and whenever the merge kills the best of them the seed bound of the next tests is so poor that every unit is
+    // listed (measured: median 10 units per iteration, mean 5 000; profiles/r4/iterstats_second_bound_without_reserve.txt).
+    {
+        unsigned long long masks[kNS], rmasks[kNS];
+        int total = 0, rtotal = 0;
+#pragma unroll
+        for (int sidx = 0; sidx < kNS; ++sidx) {
+            masks[sidx] = __ballot(sub[sidx] != 0); total += __popcll(masks[sidx]);
+            rmasks[sidx] = __ballot(res[sidx] != 0 && sub[sidx] == 0); rtotal += __popcll(rmasks[sidx]);
+        }
+        if (total + rtotal > 0) {                     // wave-uniform
+            unsigned long long old = 0;
+            if (lane == 0) old = atomicAdd(&a.cnt[(it + 1) % 3], (unsigned long long)total | ((unsigned long long)rtotal << 32));
+            old = __shfl(old, 0, 64);
+            unsigned long long base = old & 0xFFFFFFFFull, rbase = old >> 32;
 #pragma unroll
             for (int sidx = 0; sidx < kNS; ++sidx) {
-                if (sub[sidx] != 0)
+                if (sub[sidx] != 0)      // (a unit with sub-units of both kinds is scanned for all of them)
                     a.list[base + __popcll(masks[sidx] & ((1ull << lane) - 1ull))] =
-                        (int32_t)(((uint32_t)sub[sidx] << 28) | ((uint32_t)(cb0 + sidx) << 18) | (uint32_t)g);
+                        (int32_t)(((uint32_t)(sub[sidx] | res[sidx]) << 28) | ((uint32_t)(cb0 + sidx) << 18) | (uint32_t)g);
                 base += (unsigned long long)__popcll(masks[sidx]);
+                const unsigned long long k = rbase + __popcll(rmasks[sidx] & ((1ull << lane) - 1ull));
+                if (res[sidx] != 0 && sub[sidx] == 0 && k < (unsigned long long)kReserve && k < (unsigned long long)a.ugrid)
+                    a.list[a.list_cap - 1 - (int64_t)k] = (int32_t)(((uint32_t)res[sidx] << 28) | ((uint32_t)(cb0 + sidx) << 18) | (uint32_t)g);
+                rbase += (unsigned long long)__popcll(rmasks[sidx]);
             }
         }
     }
@@ -1457,7 +1553,7 @@ static unsigned long long* g_njp_dbg_last = nullptr;
 // hipFree of the 7.2 GB matrices (and of ~15 vectors per epoch, 8 epochs per run) serialise with the device and
 // cost more than the distance kernel when a context builds its matrix again (bench.py's steps).
 struct SlabPlan {
-    size_t U, R, Ur, KA, KB, slot_of_pos, pos_of_slot, perm, umin, list, blk_cb, blk_g0, cnt_all, t2_hdr, t2_rmax, t2_cmax, t2_colmin, t2_rowmin, t2_cmin, total;
+    size_t U, R, Ur, KA, KB, slot_of_pos, pos_of_slot, perm, umin, hq, list, blk_cb, blk_g0, cnt_all, t2_hdr, t2_rmax, t2_cmax, t2_colmin, t2_rowmin, t2_cmin, total;
     int64_t list_stride;
 };
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -1493,6 +1589,7 @@ static SlabPlan slab_plan(int64_t P, int64_t N, int local_ranks)
     p.Ur = take(vec * 8); p.KA = take(vec * 8); p.KB = take(vec * 8);
     p.slot_of_pos = take(vec * 4); p.pos_of_slot = take(vec * 4); p.perm = take(vec * 4);
     p.umin = take((size_t)(S * G16 * 4) * 8);
+    p.hq = take((size_t)(S * G16 * 4) * 8);
     p.list_stride = unit_total(P) + kScanBlocks + 64;
     p.list = take((size_t)(p.list_stride * local_ranks) * 4);
     // (capacity for the finest test-block size: a later, smaller epoch of the same arena may use it)
@@ -1563,6 +1660,7 @@ static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, char
     q.pos_of_slot = reinterpret_cast<int32_t*>(slab + plan.pos_of_slot);
     q.perm = reinterpret_cast<int32_t*>(slab + plan.perm);
     q.umin = reinterpret_cast<uint64_t*>(slab + plan.umin);
+    q.hq = reinterpret_cast<double*>(slab + plan.hq);
     q.list = reinterpret_cast<int32_t*>(slab + plan.list);
     q.blk_cb = reinterpret_cast<int32_t*>(slab + plan.blk_cb);
     q.blk_g0 = reinterpret_cast<int32_t*>(slab + plan.blk_g0);
@@ -1603,9 +1701,17 @@ static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, char
     hipLaunchKernelGGL(njp_fill_u64_kernel, dim3(256), dim3(256), 0, s, (uint64_t*)q.umin, q.nunits_alloc,
                        enc_f64_host(-__builtin_inf()));
     hipLaunchKernelGGL(njp_fill_u64_kernel, dim3(16), dim3(256), 0, s, (uint64_t*)q.t2_cmin, (int64_t)q.nprep, 0xFFF0000000000000ull);   // -inf (plain doubles)
+    hipLaunchKernelGGL(njp_fill_u64_kernel, dim3(256), dim3(256), 0, s, (uint64_t*)q.hq, q.nunits_alloc, 0xFFF0000000000000ull);        // -inf (plain doubles): no second bound yet
     DPR_HIP(hipGetLastError());
     q.fresh = true;
     return DPR_OK;
+}
+
+static double max_row_sum(const std::vector<int32_t>& perm, const std::vector<double>& hU)
+{
+    double m = 0.0;
+    for (int32_t p : perm) { const double u = hU[(size_t)p]; if (u == u && u > m) m = u; }
+    return m;
 }
 
 static void sort_by_row_sum(std::vector<int32_t>& perm, const std::vector<double>& hU)
@@ -1655,6 +1761,7 @@ int njp_build(NjBuffers& b, hipStream_t s)
     if (int rc = njp_arena(q, N, s)) return rc;
     q.epoch_index = 0;
     if (int rc = njp_alloc_epoch(q, N, N, q.arena_D, q.arena_slab[0], s)) return rc;
+    q.umax0 = max_row_sum(perm, hU);
     q.utot0 = q.utot;
     DPR_HIP(hipMemcpyAsync(q.perm, perm.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, s));
     if (std::getenv("DPR_NJ_ITERSTATS")) {
@@ -1718,6 +1825,7 @@ static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s, bool* rebuilt)
     const int e = old.epoch_index + 1;
     q.epoch_index = e;
     if (int rc = njp_alloc_epoch(q, n, b.N, (e & 1) ? b.D : q.arena_D, q.arena_slab[e & 1], s, old.range_known ? old.t2_hdr : nullptr)) return rc;
+    q.umax0 = max_row_sum(perm, hU);
     lap("njp_alloc_epoch");
     DPR_HIP(hipMemcpyAsync(q.perm, perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
     njp_launch_permute(old.D, old.ld, q.D, q.ld, q.perm, n, s);
@@ -1726,7 +1834,7 @@ static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s, bool* rebuilt)
                        q.slot_of_pos, q.pos_of_slot);
     DPR_HIP(hipGetLastError());
     // iteration state: nothing in quarantine (every row sum is in memory), empty lists
-    st.pnew[0] = -1; st.pnew[1] = -1;
+    st.pnew[0] = -1; st.pnew[1] = -1; st.acc = 0.0;
     for (auto& c : st.cnt_list) c = 0ull;
     DPR_HIP(hipMemcpyAsync(b.st, &st, sizeof(NjState), hipMemcpyHostToDevice, s));
     lap("enqueue");
@@ -1782,6 +1890,7 @@ static int njp_from_slots(NjBuffers& b, hipStream_t s)
     sort_by_row_sum(perm, hU);
     q.epoch_index = 0;                       // even: the epoch lives in arena_D (b.D holds the slot-space matrix it is built from)
     if (int rc = njp_alloc_epoch(q, n, b.N, q.arena_D, q.arena_slab[0], s)) return rc;
+    q.umax0 = max_row_sum(perm, hU);
     DPR_HIP(hipMemcpyAsync(q.perm, perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
     njp_launch_permute((const double*)b.D, b.ld, q.D, q.ld, (const int32_t*)q.perm, n, s);
     q.range_known = false;
@@ -1793,7 +1902,7 @@ static int njp_from_slots(NjBuffers& b, hipStream_t s)
                        (const double*)b.U, (const int32_t*)q.perm, (const int32_t*)nullptr, n, n, q.U + (st.it & 1) * q.vstride, q.Ur, q.KA, q.KB,
                        q.slot_of_pos, q.pos_of_slot);
     DPR_HIP(hipGetLastError());
-    st.pnew[0] = -1; st.pnew[1] = -1;
+    st.pnew[0] = -1; st.pnew[1] = -1; st.acc = 0.0;
     for (auto& c : st.cnt_list) c = 0ull;
     DPR_HIP(hipMemcpyAsync(b.st, &st, sizeof(NjState), hipMemcpyHostToDevice, s));
     DPR_HIP(hipStreamSynchronize(s));        // `st`, `perm` are host objects
@@ -1851,11 +1960,13 @@ static NjpArgs njp_args(NjBuffers& b, int v)
     a.U = q.U; a.R = q.R; a.vstride = q.vstride;
     a.Ur = q.Ur; a.KA = q.KA; a.KB = q.KB; a.slot_of_pos = q.slot_of_pos; a.pos_of_slot = q.pos_of_slot;
     a.xpart = b.xpart; a.partials = b.partials; a.umin = (unsigned long long*)q.umin;
+    a.hq = q.hq; a.umax0 = q.umax0;
     a.P = q.P;
     a.blk_cb = q.blk_cb; a.blk_g0 = q.blk_g0;
     a.tg = njp_tg(q.P); a.ns = njp_ns(q.P); a.nupd = 0;
     a.ntest = sh ? (q.nprep - v + q.sh_world - 1) / q.sh_world : q.nprep;     // test blocks v, v + world, ... are this rank's
     a.list = q.list + (int64_t)slot * q.list_stride;
+    a.list_cap = q.list_stride;
     a.cnt = sh ? q.cnt_all + 4 * slot : b.st->cnt_list;
     a.ugrid = njp_grid_rank(q);
     a.urecs = njp_grid_total(q);
@@ -2036,7 +2147,7 @@ int njp_debug_list(NjBuffers& b, int32_t* out, int64_t cap, int64_t* count, int6
     DPR_HIP(hipDeviceSynchronize());
     NjState st;
     DPR_HIP(hipMemcpy(&st, b.st, sizeof(NjState), hipMemcpyDeviceToHost));
-    const int64_t cnt = (int64_t)st.cnt_list[st.it % 3];
+    const int64_t cnt = (int64_t)(st.cnt_list[st.it % 3] & 0xFFFFFFFFull);      // (the high half counts the reserve at the back of the list)
     *count = cnt; *P = q.P;
     const int64_t take = cnt < cap ? cnt : cap;
     if (take > 0) DPR_HIP(hipMemcpy(out, q.list, sizeof(int32_t) * (size_t)take, hipMemcpyDeviceToHost));

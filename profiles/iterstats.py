@@ -1,17 +1,23 @@
-"""Units listed per iteration over a pruned NJ run (DPR_NJ_ITERSTATS=1): python profiles/iterstats.py [tips] [sites]"""
+"""Units listed per iteration over a pruned NJ run (DPR_NJ_ITERSTATS=1): python profiles/iterstats.py [tips] [sites] [gen_synth options]"""
 import ctypes as C, os, sys
 import numpy as np
 os.environ["DPR_NJ_ITERSTATS"] = "1"
-os.environ["DPR_NJ_EPOCH_LOG"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import subprocess, tempfile
 import dipper_amd
 from dipper_amd import capi
-from tests import _util
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
-seqs = _util.synth_alignment(np.random.default_rng(1), n, L, mean_bl=2e-5 * 10000 / L, lo=2e-6 * 10000 / L, hi=2e-4 * 10000 / L)
+extra = sys.argv[3:]          # passed to tools/bin/gen_synth (e.g. --model gtr+g+i --indel-gaps)
+tmp = tempfile.mkdtemp(prefix="its_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+p4 = os.path.join(tmp, "a.p4")
+subprocess.run([os.path.join(ROOT, "tools", "bin", "gen_synth"), "--tips", str(n), "--sites", str(L), "--seed", "1", "--mean-bl", repr(2e-5 * 10000 / L),
+                "--lo", repr(2e-6 * 10000 / L), "--hi", repr(2e-4 * 10000 / L), "--packed4", p4] + extra, check=True)
+packed = np.fromfile(p4, dtype=np.uint64).reshape(n, (L + 15) // 16)
+os.unlink(p4); os.rmdir(tmp)
 d = dipper_amd.Dipper(0)
-d.set_msa(capi.pack4_many(seqs), L)
+d.set_msa(packed, L)
 d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
 r = d.nj_run()
 print("nj ms", d.timing()[1], "units", d.prune_stats())
