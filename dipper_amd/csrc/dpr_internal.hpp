@@ -90,6 +90,7 @@ struct NjState {
     // pruned path, large shape: sum over the merges of the current epoch of an upper bound of what ONE merge can take off any
     // candidate's q (njp_q_drift); the scan stores a sub-unit's exact minimum q plus this, the tests subtract the value of their time
     double acc;
+    double seed;     // the seed bound the tests of the last post launch used (+inf: none) -- the next scan's second test reads it
 };
 
 // position-space state of the pruned path (njp.hip)

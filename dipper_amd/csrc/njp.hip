@@ -41,7 +41,6 @@
 namespace dpr {
 
 constexpr int kUR = 16;  // rows per unit
-constexpr int kReserve = 128;     // units of the reserve a scan walks at most (njp_post2_kernel): as many as there are seed candidates among the unit records
 // Row groups (= units of one strip) per test block of the post kernel: 64 below 40 000 positions (1024 row positions per
 // block: the row phase of a block is short, NJ 500 -> 482 ms at 30 000 tips), 256 above (fewer blocks, less repeated
 // column and record work where the kernel is throughput-bound).  The switch: 38 000-50 000 positions measured within
@@ -275,7 +274,6 @@ struct NjpArgs {
     int tg, ns;                                                  // ... of tg row groups x up to ns strips
     int nupd;                                                    // update blocks of this post launch
     int32_t* list; unsigned long long* cnt;     // the list of THIS launch's rank and its counters cnt[0..2]
-    int64_t list_cap;                           // entries of that list: units that MUST be scanned grow from the front, the reserve (see njp_post2_kernel) from the back
     int ugrid;        // unit-scan blocks per rank
     int urecs;        // unit records in partials (ugrid x ranks); the new-row records follow them
     int nrb;          // new-row blocks = ceil(P / 512)
@@ -408,8 +406,10 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjState* h_st, const
     }
     const int32_t pn0 = h_st->pnew[0], pn1 = h_st->pnew[1];      // (both with the state line)
     const int64_t pz = (int64_t)((it & 1) ? pn1 : pn0);
-    // (the reserve entry this block would take, see below; issued behind the loads above: its index needs the argument block)
-    const int32_t first_res = unit_block ? h_list[a.list_cap - a.ugrid + ub] : 0;
+    // (behind the loads above: their indices need the argument block)  The list entries of this block's SECOND and THIRD unit,
+    // speculatively (in bounds whatever the count: the list has kScanBlocks spare entries), and the seed bound of the last tests
+    const int32_t code1 = unit_block ? h_list[ub + a.ugrid] : 0, code2 = unit_block ? h_list[ub + 2 * a.ugrid] : 0;
+    const double seed = h_st->seed;
     if (blockIdx.x == 0 && tid == 0) h_st->itb = it;             // the post kernel's iteration index (it advances `it` itself); also beyond the limit
     if (it >= limit || h_st->status != 0) return;
     NJP_STAMP(0, 0, true);
@@ -455,23 +455,14 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjState* h_st, const
         // ---------------------------------------------------------------- unit block
         rec_out = a.partials + a.rec_off + ub;
         const int m3 = (int)(it % 3);
-        // the counter word: low half = units that MUST be scanned (front of the list), high half = the RESERVE (njp_post2_kernel:
-        // units only the second bound excludes; entry k at list[cap - 1 - k]).  A block without a unit of the first kind takes
-        // ONE reserve entry -- block ugrid - 1 - k takes entry k -- so that the records the next seed bound is taken from stay
-        // as many as before (see njp_post2_kernel), at no cost: the block would have been idle.
-        const unsigned long long craw = m3 == 0 ? cl0 : m3 == 1 ? cl1 : cl2;
-        const int64_t cnt = (int64_t)(craw & 0xFFFFFFFFull);
-        const int64_t res_n = (int64_t)(craw >> 32) < kReserve ? (int64_t)(craw >> 32) : kReserve;
-        const bool res_block = (int64_t)ub >= cnt && (int64_t)(a.ugrid - 1 - ub) < res_n;
-        if ((int64_t)ub >= cnt && !res_block) {
+        const int64_t cnt = (int64_t)(m3 == 0 ? cl0 : m3 == 1 ? cl1 : cl2);
+        if ((int64_t)ub >= cnt) {
             if (a.all_defined && tid == 0) {      // unit-sharded mode: every record of the gathered array is defined
                 NjRecord rec; rec.q = 10000.0; rec.key = ~0ull; rec.d = 0.0; rec.pad = 0ull;
                 *rec_out = rec;
             }
             return;
         }
-        const int64_t e_end = res_block ? (int64_t)ub + 1 : cnt;
-        const int32_t first_code = res_block ? first_res : first;
         const int64_t G16 = (P + kUR - 1) / kUR;
         // Two passes per unit instead of a (q, key, positions, d) compare-and-select per candidate (64 candidates
         // per lane and unit, ~20 VALU instructions each, were 2 us of this kernel's critical path): pass 1 computes
@@ -480,9 +471,28 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjState* h_st, const
         // bq is wave-uniform; (bk, bp, bd) is this lane's best candidate AT q == bq (bk == ~0: none).
         int64_t scanned = 0;
         const int wv = tid >> 6;                         // this wave's sub-strip of every unit
-        for (int64_t e = ub; e < e_end; e += a.ugrid, ++scanned) {
-            const uint32_t code = (uint32_t)__builtin_amdgcn_readfirstlane(e == (int64_t)ub ? first_code : a.list[e]);
+        // Second test (njp_q_drift) for every unit of this block but the first: the sub-unit's exact minimum q of its last scan,
+        // less the drift since then, against the seed bound the tests used.  An old epoch lists hundreds of units along the row
+        // groups of merged nodes iteration after iteration (profiles/njp_list_shape.py); with more of them than blocks, every
+        // block used to walk two or three, one behind the other.  The FIRST unit is always scanned: it costs nothing extra, and
+        // the block's record is where the next seed bound comes from (a scan that skipped whatever it could left a dozen
+        // records per iteration; whenever the merge killed the best of them, the next tests listed every unit of the epoch).
+        // The stored minima of units 2 and 3 are fetched now, behind their list entries and beside the first unit's data.
+        auto hq_index = [&](uint32_t c) { return ((int64_t)((c >> 18) & 1023u) * G16 + (int64_t)(c & 0x3FFFFu)) * 4 + wv; };
+        const uint32_t uc1 = (uint32_t)__builtin_amdgcn_readfirstlane(code1), uc2 = (uint32_t)__builtin_amdgcn_readfirstlane(code2);
+        double hq1 = -__builtin_inf(), hq2 = hq1;
+        if ((int64_t)ub + a.ugrid < cnt && ((uc1 >> (28 + wv)) & 1u)) hq1 = a.hq[hq_index(uc1)];
+        if ((int64_t)ub + 2 * a.ugrid < cnt && ((uc2 >> (28 + wv)) & 1u)) hq2 = a.hq[hq_index(uc2)];
+        int kth = 0;
+        for (int64_t e = ub; e < cnt; e += a.ugrid, ++scanned, ++kth) {
+            const uint32_t code = kth == 0 ? (uint32_t)__builtin_amdgcn_readfirstlane(first) : kth == 1 ? uc1 : kth == 2 ? uc2
+                                                                                                : (uint32_t)__builtin_amdgcn_readfirstlane(a.list[e]);
             if (!((code >> (28 + wv)) & 1u)) continue;   // the bound of this wave's sub-unit rules it out (wave-uniform)
+            if (kth >= 1 && !(a.flags & 64)) {
+                const double h = kth == 1 ? hq1 : kth == 2 ? hq2 : a.hq[hq_index(code)];
+                const bool skip = (h - acc) - (fabs(h) + acc) * 0x1p-40 > seed;          // (-inf / NaN: scanned)
+                if (__builtin_amdgcn_readfirstlane((int)skip)) continue;                 // (the same value in every lane)
+            }
             const int cb = (int)((code >> 18) & 1023u);
             const int64_t g_s = (int64_t)(code & 0x3FFFFu);
             const int64_t c0 = (int64_t)cb * kTileCols, a0 = g_s * kUR;
@@ -679,7 +689,7 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
     }
     const unsigned long long cl0 = h_cnt[0], cl1 = h_cnt[1], cl2 = h_cnt[2];      // all three list counters with the first round trip (not a second, dependent load)
     const int m3 = (int)(it % 3);
-    const unsigned long long cnt_raw = a.all_defined ? (unsigned long long)a.urecs : ((m3 == 0 ? cl0 : m3 == 1 ? cl1 : cl2) & 0xFFFFFFFFull);   // (no reserve in this kernel's epochs)
+    const unsigned long long cnt_raw = a.all_defined ? (unsigned long long)a.urecs : (m3 == 0 ? cl0 : m3 == 1 ? cl1 : cl2);
     const int64_t uvalid = (int64_t)(cnt_raw < (unsigned long long)a.urecs ? cnt_raw : (unsigned long long)a.urecs);   // unit records written by SCAN(it)
     const double* __restrict__ Uc = a.U + (it & 1) * a.vstride;
     double* __restrict__ Un = a.U + ((it + 1) & 1) * a.vstride;
@@ -1104,7 +1114,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
     const int nseed_units = kThreads - nseed_rows;
     const int64_t sstride = a.all_defined && a.urecs >= 2 * nseed_units ? a.urecs / nseed_units : 1;
     const bool seed_is_unit = tid < nseed_units;
-    NjRecord cand = r0, cand_res = r0;
+    NjRecord cand = r0;
     int cb0 = 0;
     int64_t g0 = 0;
     // UM: the block's two chunks of 256 reference slots (the chunk sums stay per 256 slots: the canonical order of U[x]) and
@@ -1131,11 +1141,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
     const unsigned long long cl0 = h_cnt[0], cl1 = h_cnt[1], cl2 = h_cnt[2];      // all three list counters with the first round trip (not a second, dependent load)
     const int m3 = (int)(it % 3);
     const unsigned long long cnt_raw = a.all_defined ? (unsigned long long)a.urecs : (m3 == 0 ? cl0 : m3 == 1 ? cl1 : cl2);
-    // unit records written by SCAN(it): blocks [0, uvalid) walked the units that had to be scanned, blocks [ures0, urecs) one unit
-    // of the reserve each (njp_scan_kernel)
-    const int64_t cnt_must = (int64_t)(cnt_raw & 0xFFFFFFFFull), cnt_res = (int64_t)(cnt_raw >> 32) < kReserve ? (int64_t)(cnt_raw >> 32) : kReserve;
-    const int64_t uvalid = cnt_must < (int64_t)a.urecs ? cnt_must : (int64_t)a.urecs;
-    const int64_t ures0 = (int64_t)a.urecs - (cnt_res < (int64_t)a.urecs - uvalid ? cnt_res : (int64_t)a.urecs - uvalid);
+    const int64_t uvalid = (int64_t)(cnt_raw < (unsigned long long)a.urecs ? cnt_raw : (unsigned long long)a.urecs);
     const double emin = dec_f64(hdr->min_enc), eabs = dec_f64(hdr->maxabs_enc);
     const double acc = h_st->acc;                               // (njp_q_drift: the merges of this epoch so far)
     // T >= every t_i of this merge (see the header of this kernel); the header's values are within a factor of two.
@@ -1154,15 +1160,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
         const int64_t send = njp_strips_of_rows(g0, kTG, P);
         nsb = (int)(send - cb0 < kNS ? send - cb0 : kNS);
         if (pz >= 0) uz = Uc[pz];
-        // the record of the scan block that walked reserve entry `tid`: the seed candidate of this thread when its own block had
-        // no unit (with the second bound only a dozen units MUST be scanned per iteration).  Loaded HERE, with the second round
-        // trip: its index needs the argument block, and a load in front of the first round trip would hold that back until the
-        // s_load of the arguments has returned (+ 0.5 us on every block of the launch, measured)
-        if (seed_is_unit && sstride == 1 && tid < a.urecs) cand_res = h_partials[a.urecs - 1 - tid];
-        if (seed_is_unit && (int64_t)tid * sstride >= uvalid && (int64_t)tid * sstride < ures0) cand.key = ~0ull;          // not written by this iteration's scan
-        if (seed_is_unit && sstride == 1 && (int64_t)(a.urecs - 1 - tid) >= ures0 && (int64_t)(a.urecs - 1 - tid) >= uvalid && cand_res.key != ~0ull &&
-            (cand.key == ~0ull || cand_res.q < cand.q))
-            cand = cand_res;
+        if (seed_is_unit && (int64_t)tid * sstride >= uvalid) cand.key = ~0ull;          // not written by this iteration's scan
         if (cand.key != ~0ull) {
             ci = (int64_t)(cand.pad & 0xffffffffull); cj = (int64_t)(cand.pad >> 32);
             if (!(ci < P && cj < P)) ci = -1;
@@ -1171,7 +1169,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
 #pragma unroll
     for (int k = 0; k < kMine; ++k) {
         const int idx = tid + k * kThreads;
-        if (idx >= uvalid && idx < ures0) mine[k] = r0;   // not written by this iteration's scan
+        if (idx >= uvalid && idx < a.urecs) mine[k] = r0;   // not written by this iteration's scan
     }
     NJP_STAMP(1, 0, false);
     NJP_STAMP(1, 1, true);
@@ -1188,7 +1186,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
     for (int k = 0; k < kMine; ++k)
         if (k < nmine) best_update4(bq, bk, bp, d, mine[k].q, mine[k].key, mine[k].pad, mine[k].d);
     for (int64_t idx = tid + kMine * kThreads; idx < nrec_all; idx += kThreads)
-        if (idx < uvalid || idx >= ures0) best_update4(bq, bk, bp, d, a.partials[idx].q, a.partials[idx].key, a.partials[idx].pad, a.partials[idx].d);
+        if (idx < uvalid || idx >= a.urecs) best_update4(bq, bk, bp, d, a.partials[idx].q, a.partials[idx].key, a.partials[idx].pad, a.partials[idx].d);
     wave_best4(bq, bk, bp, d);
     if (lane == 0) { sq[tid >> 6] = bq; sk[tid >> 6] = bk; spp[tid >> 6] = bp; sdd[tid >> 6] = d; }
     __syncthreads();
@@ -1409,6 +1407,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
     if (lane == 0) srC[tid >> 6] = rC;
     __syncthreads();
     const double bound = fmin(fmin(sseed[0], sseed[1]), fmin(sseed[2], sseed[3]));
+    if (bx == 0 && tid == 0) a.st->seed = bound;      // (every test block has the same value; the next scan's second test reads it, njp_q_drift)
     double cm4[kNS][4];
 #pragma unroll
     for (int k = 0; k < kNS; ++k)
@@ -1440,6 +1439,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
         }
     }
     NJP_STAMP(1, 5, true);
+    unsigned int voided = 0u;      // sub-units (4 x strip + sub-strip) of this lane's units that the new node has entered
     double mymin = PINF;           // minimum of this lane's sub-unit bounds after the fold: the cell's new coarse bound
     int sub[kNS];                  // per strip: sub-unit mask of this lane's unit, 0 = not listed
 #pragma unroll
@@ -1464,8 +1464,10 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
                     u4[w] = nm;
                     up4[w] = enc_f64(nm);
                 }
-                // the new node brings candidates of its own into this sub-unit: the minimum q of its last scan says nothing about them
-                if (nm < PINF) a.hq[((int64_t)cb * G16 + g) * 4 + w] = NINF;
+                // the new node brings candidates of its own into this sub-unit: the minimum q of its last scan says nothing about
+                // them (voided BEHIND this loop: a store here, conditional on a value just loaded and possibly aliasing the next
+                // load, chained the loads of the one block that holds the new node -- the launch's last block, + 1.4 us)
+                if (nm < PINF) voided |= 1u << (4 * sidx + w);
                 mymin = fmin(mymin, u4[w]);
                 const double lb = fmin((u4[w] - rmax) - cmw, (u4[w] - cmw) - rmax);
                 if ((cmw > NINF) && (lb <= bound)) submask |= 1 << w;
@@ -1473,58 +1475,29 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
         }
         if (have && (rmax > NINF)) sub[sidx] = submask;
     }
-    int res[kNS];                  // per strip: the sub-units only the second bound excludes (the reserve, below)
-#pragma unroll
-    for (int sidx = 0; sidx < kNS; ++sidx) res[sidx] = 0;
-    // second bound (njp_q_drift): of the sub-units that failed the first test, list only those whose exact minimum q of their last
-    // scan, less the drift since then (this merge included), reaches the seed bound too.  All loads of a lane in one round trip.
-    if (!(a.flags & 64)) {
-        const double accn = acc + njp_q_drift(a.umax0, slack, P, n);
-        double hv[kNS][4];
-#pragma unroll
-        for (int sidx = 0; sidx < kNS; ++sidx) res[sidx] = 0;
+    if (voided != 0u) {            // (rare: the block of the new node's strip or row group)
 #pragma unroll
         for (int sidx = 0; sidx < kNS; ++sidx)
 #pragma unroll
             for (int w = 0; w < 4; ++w)
-                hv[sidx][w] = ((sub[sidx] >> w) & 1) ? a.hq[((int64_t)(cb0 + sidx) * G16 + g) * 4 + w] : NINF;
-#pragma unroll
-        for (int sidx = 0; sidx < kNS; ++sidx)
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const double lb2 = hv[sidx][w] - accn;
-                const double margin = (fabs(hv[sidx][w]) + accn) * 0x1p-40;
-                if (((sub[sidx] >> w) & 1) && lb2 - margin > bound) { sub[sidx] &= ~(1 << w); res[sidx] |= 1 << w; }       // (-inf, NaN: stays listed)
-            }
+                if ((voided >> (4 * sidx + w)) & 1u) a.hq[((int64_t)(cb0 + sidx) * G16 + g) * 4 + w] = NINF;
     }
-    // ONE list append per wave for all its strips (an atomic per strip is a chain of kNS dependent round trips).  The units the
-    // second bound excludes go to the RESERVE -- the back of the same list, counted in the high half of the same word: scan
-    // blocks that would be idle walk one each.  Without them the scan would produce a dozen records per iteration instead of
-    // hundreds, and whenever the merge kills the best of them the seed bound of the next tests is so poor that every unit is
-    // listed (measured: median 10 units per iteration, mean 5 000; profiles/r4/iterstats_second_bound_without_reserve.txt).
+    // ONE list append per wave for all its strips (an atomic per strip is a chain of kNS dependent round trips)
     {
-        unsigned long long masks[kNS], rmasks[kNS];
-        int total = 0, rtotal = 0;
+        unsigned long long masks[kNS];
+        int total = 0;
 #pragma unroll
-        for (int sidx = 0; sidx < kNS; ++sidx) {
-            masks[sidx] = __ballot(sub[sidx] != 0); total += __popcll(masks[sidx]);
-            rmasks[sidx] = __ballot(res[sidx] != 0 && sub[sidx] == 0); rtotal += __popcll(rmasks[sidx]);
-        }
-        if (total + rtotal > 0) {                     // wave-uniform
-            unsigned long long old = 0;
-            if (lane == 0) old = atomicAdd(&a.cnt[(it + 1) % 3], (unsigned long long)total | ((unsigned long long)rtotal << 32));
-            old = __shfl(old, 0, 64);
-            unsigned long long base = old & 0xFFFFFFFFull, rbase = old >> 32;
+        for (int sidx = 0; sidx < kNS; ++sidx) { masks[sidx] = __ballot(sub[sidx] != 0); total += __popcll(masks[sidx]); }
+        if (total > 0) {                              // wave-uniform
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(&a.cnt[(it + 1) % 3], (unsigned long long)total);
+            base = __shfl(base, 0, 64);
 #pragma unroll
             for (int sidx = 0; sidx < kNS; ++sidx) {
-                if (sub[sidx] != 0)      // (a unit with sub-units of both kinds is scanned for all of them)
+                if (sub[sidx] != 0)
                     a.list[base + __popcll(masks[sidx] & ((1ull << lane) - 1ull))] =
-                        (int32_t)(((uint32_t)(sub[sidx] | res[sidx]) << 28) | ((uint32_t)(cb0 + sidx) << 18) | (uint32_t)g);
+                        (int32_t)(((uint32_t)sub[sidx] << 28) | ((uint32_t)(cb0 + sidx) << 18) | (uint32_t)g);
                 base += (unsigned long long)__popcll(masks[sidx]);
-                const unsigned long long k = rbase + __popcll(rmasks[sidx] & ((1ull << lane) - 1ull));
-                if (res[sidx] != 0 && sub[sidx] == 0 && k < (unsigned long long)kReserve && k < (unsigned long long)a.ugrid)
-                    a.list[a.list_cap - 1 - (int64_t)k] = (int32_t)(((uint32_t)res[sidx] << 28) | ((uint32_t)(cb0 + sidx) << 18) | (uint32_t)g);
-                rbase += (unsigned long long)__popcll(rmasks[sidx]);
             }
         }
     }
@@ -1834,7 +1807,7 @@ static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s, bool* rebuilt)
                        q.slot_of_pos, q.pos_of_slot);
     DPR_HIP(hipGetLastError());
     // iteration state: nothing in quarantine (every row sum is in memory), empty lists
-    st.pnew[0] = -1; st.pnew[1] = -1; st.acc = 0.0;
+    st.pnew[0] = -1; st.pnew[1] = -1; st.acc = 0.0; st.seed = __builtin_inf();
     for (auto& c : st.cnt_list) c = 0ull;
     DPR_HIP(hipMemcpyAsync(b.st, &st, sizeof(NjState), hipMemcpyHostToDevice, s));
     lap("enqueue");
@@ -1902,7 +1875,7 @@ static int njp_from_slots(NjBuffers& b, hipStream_t s)
                        (const double*)b.U, (const int32_t*)q.perm, (const int32_t*)nullptr, n, n, q.U + (st.it & 1) * q.vstride, q.Ur, q.KA, q.KB,
                        q.slot_of_pos, q.pos_of_slot);
     DPR_HIP(hipGetLastError());
-    st.pnew[0] = -1; st.pnew[1] = -1; st.acc = 0.0;
+    st.pnew[0] = -1; st.pnew[1] = -1; st.acc = 0.0; st.seed = __builtin_inf();
     for (auto& c : st.cnt_list) c = 0ull;
     DPR_HIP(hipMemcpyAsync(b.st, &st, sizeof(NjState), hipMemcpyHostToDevice, s));
     DPR_HIP(hipStreamSynchronize(s));        // `st`, `perm` are host objects
@@ -1966,7 +1939,6 @@ static NjpArgs njp_args(NjBuffers& b, int v)
     a.tg = njp_tg(q.P); a.ns = njp_ns(q.P); a.nupd = 0;
     a.ntest = sh ? (q.nprep - v + q.sh_world - 1) / q.sh_world : q.nprep;     // test blocks v, v + world, ... are this rank's
     a.list = q.list + (int64_t)slot * q.list_stride;
-    a.list_cap = q.list_stride;
     a.cnt = sh ? q.cnt_all + 4 * slot : b.st->cnt_list;
     a.ugrid = njp_grid_rank(q);
     a.urecs = njp_grid_total(q);
@@ -2147,7 +2119,7 @@ int njp_debug_list(NjBuffers& b, int32_t* out, int64_t cap, int64_t* count, int6
     DPR_HIP(hipDeviceSynchronize());
     NjState st;
     DPR_HIP(hipMemcpy(&st, b.st, sizeof(NjState), hipMemcpyDeviceToHost));
-    const int64_t cnt = (int64_t)(st.cnt_list[st.it % 3] & 0xFFFFFFFFull);      // (the high half counts the reserve at the back of the list)
+    const int64_t cnt = (int64_t)st.cnt_list[st.it % 3];
     *count = cnt; *P = q.P;
     const int64_t take = cnt < cap ? cnt : cap;
     if (take > 0) DPR_HIP(hipMemcpy(out, q.list, sizeof(int32_t) * (size_t)take, hipMemcpyDeviceToHost));
