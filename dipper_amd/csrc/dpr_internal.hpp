@@ -87,10 +87,6 @@ struct NjState {
     // QUARANTINE: its row sum is not materialised yet (Ur = NaN, so the unit scans skip it), its pairs are evaluated
     // by the scan kernel's new-row blocks from the row buffer R[(it - 1) & 1]
     int32_t pnew[2];
-    // pruned path, large shape: sum over the merges of the current epoch of an upper bound of what ONE merge can take off any
-    // candidate's q (njp_q_drift); the scan stores a sub-unit's exact minimum q plus this, the tests subtract the value of their time
-    double acc;
-    double seed;     // the seed bound the tests of the last post launch used (+inf: none) -- the next scan's second test reads it
 };
 
 // position-space state of the pruned path (njp.hip)
@@ -100,8 +96,6 @@ struct NjPruned {
     double* D = nullptr;        // [P][ld] position space
     double* U = nullptr;        // [2][vstride] by position, double-buffered: iteration it reads U + (it & 1) * vstride
     double* Ur = nullptr;       // by position; NaN for dead positions and for the node in quarantine
-    double* hq = nullptr;       // [units][4] second bound per sub-unit: exact minimum q at its last scan + NjState::acc of that time (-inf: none)
-    double umax0 = 0.0;         // largest row sum at the start of the epoch (njp_q_drift)
     double* R = nullptr;        // [2][vstride] row of the node created by merge it: R + (it & 1) * vstride
     int64_t vstride = 0;
     uint64_t *KA = nullptr, *KB = nullptr;  // key parts from the reference slot of each position

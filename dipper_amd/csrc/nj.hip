@@ -66,7 +66,7 @@ __global__ void nj_state_init_kernel(NjState* st, int64_t N)
     st->n = N; st->it = 0; st->x = 0; st->y = 0; st->d = 0.0; st->q = 0.0; st->status = 0; st->pad = 0;
     st->itb = 0; st->it_limit = 0; st->N = N;
     st->cnt_list[0] = 0; st->cnt_list[1] = 0; st->cnt_list[2] = 0; st->cnt_list[3] = 0; st->units_scanned = 0;
-    st->pnew[0] = -1; st->pnew[1] = -1; st->acc = 0.0; st->seed = __builtin_inf();
+    st->pnew[0] = -1; st->pnew[1] = -1;
 }
 
 // Ur[i] = U[i]/(n-2) (plain division, src/neighborJoining.cu:130,137) and the i-part of the key

@@ -268,7 +268,6 @@ struct NjpArgs {
     double* U; double* R; int64_t vstride;      // U, R: [2][vstride]
     double* Ur; uint64_t* KA; uint64_t* KB; int32_t* slot_of_pos; int32_t* pos_of_slot;
     double* xpart; NjRecord* partials; unsigned long long* umin;
-    double* hq; double umax0;     // second bound per sub-unit (large shape; see njp_q_drift) and the epoch's largest row sum
     int64_t P;
     const int32_t* blk_cb; const int32_t* blk_g0; int ntest;     // test blocks: (first strip, first group), up to 256 groups each
     int tg, ns;                                                  // ... of tg row groups x up to ns strips
@@ -303,28 +302,6 @@ struct NjpArgs {
 // test role that needs the same row sums before they are stored
 __device__ __forceinline__ double nj_val(double dxi, double dyi, double d) { return (dxi + dyi - d) * 0.5; }
 __device__ __forceinline__ double nj_unew(double up, double dxi, double dyi, double val) { return up + (-dxi - dyi + val); }
-
-// Second bound of a sub-unit (large shape; round 4).  An epoch ages: a merged node keeps a child's position with distances and a
-// row sum both smaller than its neighbours' by ~ d_xy / 2, the unit minimum follows the distances, the group's maximal row sum
-// stays with the neighbours -- every unit along that row group fails the test `umin - rmax - cmax <= seed` iteration after
-// iteration although one scan shows that its candidates are far from winning (64 % of the units an old epoch of 100 000 tips
-// lists lie more than ten strips off the diagonal, 43 % in 50 of 6 250 row groups: profiles/njp_list_shape.py).  The scan
-// computes the exact minimum q of every sub-unit it walks (pass 1's wave minimum) anyway; it stores it, and a unit is listed
-// only if that minimum, less everything the merges since then can have taken off it, reaches the seed bound as well.
-//   q_ij = fl(fl(d_ij - Ur_i) - Ur_j), Ur = fl(U / (n - 2)).  One merge changes U_i by t_i <= T (T = 0 while every entry is >= 0,
-//   njp_post2_kernel's `slack` otherwise) and n - 2 into n - 3, so Ur_i grows by at most
-//       (U_i + T) / (n - 3) - U_i / (n - 2)  =  U_i / ((n - 2)(n - 3)) + T / (n - 3)   (+ roundings of relative size 2^-52),
-//   and q_ij falls by at most twice that.  U_i <= umax0 + (k + n) T after k merges of the epoch (every merge adds at most T to
-//   a row sum; a new node's row sum is at most the mean of its children's plus n |d_xy| / 2 <= n T).  NjState::acc sums these
-//   per-merge bounds over the epoch; the stored value is `minimum q + acc at scan time`, the test subtracts acc of ITS time.
-//   The factor 1 + 2^-30 pays for every rounding involved (n < 10^6); a fixed relative margin pays for the two subtractions.
-// A merge that puts a new node into a unit's rows or columns voids the stored value (-inf) until the unit is scanned again.
-__device__ __forceinline__ double njp_q_drift(double umax0, double slack, int64_t P, int64_t n)
-{
-    const double r0 = (double)(n - 2), r1 = (double)(n - 3);
-    const double umax = umax0 + (double)(P - n + 1 + n) * slack;
-    return 2.0 * (umax / (r0 * r1) + slack / r1) * (1.0 + 0x1p-30);
-}
 
 __device__ __forceinline__ void best_update4(double& bq, uint64_t& bk, uint64_t& bp, double& bd, double q, uint64_t k,
                                              uint64_t pp, double d)
@@ -392,7 +369,6 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjState* h_st, const
     const int32_t first = unit_block ? h_list[ub] : 0;
     const double xp0 = unit_block ? 0.0 : h_xpart[tid];          // (the array is padded to a multiple of 256 entries)
     const unsigned long long cl0 = h_cnt[0], cl1 = h_cnt[1], cl2 = h_cnt[2];      // (not a second, dependent load behind `it`)
-    const double acc = h_st->acc;                                                  // (njp_q_drift; same line)
     // new-row blocks: this thread's two positions of the buffered row (BOTH buffers: which one is current needs `it`) and
     // their vectors -- nothing here waits for the state line (the vectors are padded past the last block's columns)
     const int64_t j0 = (int64_t)blockIdx.x * kTileCols + 2 * tid;
@@ -406,10 +382,6 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjState* h_st, const
     }
     const int32_t pn0 = h_st->pnew[0], pn1 = h_st->pnew[1];      // (both with the state line)
     const int64_t pz = (int64_t)((it & 1) ? pn1 : pn0);
-    // (behind the loads above: their indices need the argument block)  The list entries of this block's SECOND and THIRD unit,
-    // speculatively (in bounds whatever the count: the list has kScanBlocks spare entries), and the seed bound of the last tests
-    const int32_t code1 = unit_block ? h_list[ub + a.ugrid] : 0, code2 = unit_block ? h_list[ub + 2 * a.ugrid] : 0;
-    const double seed = h_st->seed;
     if (blockIdx.x == 0 && tid == 0) h_st->itb = it;             // the post kernel's iteration index (it advances `it` itself); also beyond the limit
     if (it >= limit || h_st->status != 0) return;
     NJP_STAMP(0, 0, true);
@@ -471,28 +443,9 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjState* h_st, const
         // bq is wave-uniform; (bk, bp, bd) is this lane's best candidate AT q == bq (bk == ~0: none).
         int64_t scanned = 0;
         const int wv = tid >> 6;                         // this wave's sub-strip of every unit
-        // Second test (njp_q_drift) for every unit of this block but the first: the sub-unit's exact minimum q of its last scan,
-        // less the drift since then, against the seed bound the tests used.  An old epoch lists hundreds of units along the row
-        // groups of merged nodes iteration after iteration (profiles/njp_list_shape.py); with more of them than blocks, every
-        // block used to walk two or three, one behind the other.  The FIRST unit is always scanned: it costs nothing extra, and
-        // the block's record is where the next seed bound comes from (a scan that skipped whatever it could left a dozen
-        // records per iteration; whenever the merge killed the best of them, the next tests listed every unit of the epoch).
-        // The stored minima of units 2 and 3 are fetched now, behind their list entries and beside the first unit's data.
-        auto hq_index = [&](uint32_t c) { return ((int64_t)((c >> 18) & 1023u) * G16 + (int64_t)(c & 0x3FFFFu)) * 4 + wv; };
-        const uint32_t uc1 = (uint32_t)__builtin_amdgcn_readfirstlane(code1), uc2 = (uint32_t)__builtin_amdgcn_readfirstlane(code2);
-        double hq1 = -__builtin_inf(), hq2 = hq1;
-        if ((int64_t)ub + a.ugrid < cnt && ((uc1 >> (28 + wv)) & 1u)) hq1 = a.hq[hq_index(uc1)];
-        if ((int64_t)ub + 2 * a.ugrid < cnt && ((uc2 >> (28 + wv)) & 1u)) hq2 = a.hq[hq_index(uc2)];
-        int kth = 0;
-        for (int64_t e = ub; e < cnt; e += a.ugrid, ++scanned, ++kth) {
-            const uint32_t code = kth == 0 ? (uint32_t)__builtin_amdgcn_readfirstlane(first) : kth == 1 ? uc1 : kth == 2 ? uc2
-                                                                                                : (uint32_t)__builtin_amdgcn_readfirstlane(a.list[e]);
+        for (int64_t e = ub; e < cnt; e += a.ugrid, ++scanned) {
+            const uint32_t code = (uint32_t)__builtin_amdgcn_readfirstlane(e == (int64_t)ub ? first : a.list[e]);
             if (!((code >> (28 + wv)) & 1u)) continue;   // the bound of this wave's sub-unit rules it out (wave-uniform)
-            if (kth >= 1 && !(a.flags & 64)) {
-                const double h = kth == 1 ? hq1 : kth == 2 ? hq2 : a.hq[hq_index(code)];
-                const bool skip = (h - acc) - (fabs(h) + acc) * 0x1p-40 > seed;          // (-inf / NaN: scanned)
-                if (__builtin_amdgcn_readfirstlane((int)skip)) continue;                 // (the same value in every lane)
-            }
             const int cb = (int)((code >> 18) & 1023u);
             const int64_t g_s = (int64_t)(code & 0x3FFFFu);
             const int64_t c0 = (int64_t)cb * kTileCols, a0 = g_s * kUR;
@@ -572,10 +525,7 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjState* h_st, const
             NJP_STAMP(0, 7, false);
             // exact minimum of this wave's sub-unit -> its bound (no cross-wave step)
             m = wave_fmin(m);
-            if ((tid & 63) == 0) {
-                a.umin[((int64_t)cb * G16 + g_s) * 4 + wv] = enc_f64(m);
-                a.hq[((int64_t)cb * G16 + g_s) * 4 + wv] = wm + acc;        // exact minimum q of the sub-unit now (+inf: no live pair)
-            }
+            if ((tid & 63) == 0) a.umin[((int64_t)cb * G16 + g_s) * 4 + wv] = enc_f64(m);
         }
         // wave winner: the smallest key among the lanes' candidates at bq, then that lane's positions and distance
         {
@@ -1143,11 +1093,6 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
     const unsigned long long cnt_raw = a.all_defined ? (unsigned long long)a.urecs : (m3 == 0 ? cl0 : m3 == 1 ? cl1 : cl2);
     const int64_t uvalid = (int64_t)(cnt_raw < (unsigned long long)a.urecs ? cnt_raw : (unsigned long long)a.urecs);
     const double emin = dec_f64(hdr->min_enc), eabs = dec_f64(hdr->maxabs_enc);
-    const double acc = h_st->acc;                               // (njp_q_drift: the merges of this epoch so far)
-    // T >= every t_i of this merge (see the header of this kernel); the header's values are within a factor of two.
-    // (evaluated where it is used: computed here, the wait for the header's line sat in front of every later load of the first
-    //  round trip -- 0.5 us on every block of the launch)
-    auto slack_of = [&]() { return emin >= 0.0 ? 0.0 : (3.0 * -emin) * (1.0 + 0x1p-30) + eabs * 0x1p-47; };
     v2d uc; uc.x = 0.0; uc.y = 0.0;
     const int64_t g = g0 + tid;                                  // (T) this lane's row group
     const bool have_g = trole && g < G16;
@@ -1302,7 +1247,6 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
                     a.st->x = (int32_t)x; a.st->y = (int32_t)y; a.st->d = d; a.st->q = bq;
                     a.st->n = n1; a.st->it = it + 1;
                     a.st->pnew[(it + 1) & 1] = (int32_t)px;
-                    a.st->acc = acc + njp_q_drift(a.umax0, slack_of(), a.P, n);       // (what the next scan adds to the minima it stores)
                     a.U[(it & 1) * a.vstride + py] = __builtin_nan("");       // (this thread's own store, behind its read of U[py] above)
                     a.st->cnt_list[(it + 2) % 3] = 0ull;
                     for (int v = 0; v < a.cnt_ranks; ++v) a.cnt_all[4 * v + (it + 2) % 3] = 0ull;
@@ -1385,7 +1329,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
     if (lane == 0) sseed[tid >> 6] = qc;
     NJP_STAMP(1, 3, true);
     // upper bounds of the maxima after this merge (see the header)
-    const double slack = slack_of();
+    const double slack = emin >= 0.0 ? 0.0 : (3.0 * -emin) * (1.0 + 0x1p-30) + eabs * 0x1p-47;      // (the header's values are within a factor of two)
     const bool zlive = pz >= 0 && pz != px && pz != py;                        // the node leaving quarantine stays
     uz = (uz == uz) ? uz : PINF;                                               // (its row sum is always in memory here; NaN would silently drop out of fmax)
     const int64_t gz = zlive ? pz / kUR : -1;
@@ -1407,7 +1351,6 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
     if (lane == 0) srC[tid >> 6] = rC;
     __syncthreads();
     const double bound = fmin(fmin(sseed[0], sseed[1]), fmin(sseed[2], sseed[3]));
-    if (bx == 0 && tid == 0) a.st->seed = bound;      // (every test block has the same value; the next scan's second test reads it, njp_q_drift)
     double cm4[kNS][4];
 #pragma unroll
     for (int k = 0; k < kNS; ++k)
@@ -1439,7 +1382,6 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
         }
     }
     NJP_STAMP(1, 5, true);
-    unsigned int voided = 0u;      // sub-units (4 x strip + sub-strip) of this lane's units that the new node has entered
     double mymin = PINF;           // minimum of this lane's sub-unit bounds after the fold: the cell's new coarse bound
     int sub[kNS];                  // per strip: sub-unit mask of this lane's unit, 0 = not listed
 #pragma unroll
@@ -1464,23 +1406,12 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
                     u4[w] = nm;
                     up4[w] = enc_f64(nm);
                 }
-                // the new node brings candidates of its own into this sub-unit: the minimum q of its last scan says nothing about
-                // them (voided BEHIND this loop: a store here, conditional on a value just loaded and possibly aliasing the next
-                // load, chained the loads of the one block that holds the new node -- the launch's last block, + 1.4 us)
-                if (nm < PINF) voided |= 1u << (4 * sidx + w);
                 mymin = fmin(mymin, u4[w]);
                 const double lb = fmin((u4[w] - rmax) - cmw, (u4[w] - cmw) - rmax);
                 if ((cmw > NINF) && (lb <= bound)) submask |= 1 << w;
             }
         }
         if (have && (rmax > NINF)) sub[sidx] = submask;
-    }
-    if (voided != 0u) {            // (rare: the block of the new node's strip or row group)
-#pragma unroll
-        for (int sidx = 0; sidx < kNS; ++sidx)
-#pragma unroll
-            for (int w = 0; w < 4; ++w)
-                if ((voided >> (4 * sidx + w)) & 1u) a.hq[((int64_t)(cb0 + sidx) * G16 + g) * 4 + w] = NINF;
     }
     // ONE list append per wave for all its strips (an atomic per strip is a chain of kNS dependent round trips)
     {
@@ -1526,7 +1457,7 @@ static unsigned long long* g_njp_dbg_last = nullptr;
 // hipFree of the 7.2 GB matrices (and of ~15 vectors per epoch, 8 epochs per run) serialise with the device and
 // cost more than the distance kernel when a context builds its matrix again (bench.py's steps).
 struct SlabPlan {
-    size_t U, R, Ur, KA, KB, slot_of_pos, pos_of_slot, perm, umin, hq, list, blk_cb, blk_g0, cnt_all, t2_hdr, t2_rmax, t2_cmax, t2_colmin, t2_rowmin, t2_cmin, total;
+    size_t U, R, Ur, KA, KB, slot_of_pos, pos_of_slot, perm, umin, list, blk_cb, blk_g0, cnt_all, t2_hdr, t2_rmax, t2_cmax, t2_colmin, t2_rowmin, t2_cmin, total;
     int64_t list_stride;
 };
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -1562,7 +1493,6 @@ static SlabPlan slab_plan(int64_t P, int64_t N, int local_ranks)
     p.Ur = take(vec * 8); p.KA = take(vec * 8); p.KB = take(vec * 8);
     p.slot_of_pos = take(vec * 4); p.pos_of_slot = take(vec * 4); p.perm = take(vec * 4);
     p.umin = take((size_t)(S * G16 * 4) * 8);
-    p.hq = take((size_t)(S * G16 * 4) * 8);
     p.list_stride = unit_total(P) + kScanBlocks + 64;
     p.list = take((size_t)(p.list_stride * local_ranks) * 4);
     // (capacity for the finest test-block size: a later, smaller epoch of the same arena may use it)
@@ -1633,7 +1563,6 @@ static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, char
     q.pos_of_slot = reinterpret_cast<int32_t*>(slab + plan.pos_of_slot);
     q.perm = reinterpret_cast<int32_t*>(slab + plan.perm);
     q.umin = reinterpret_cast<uint64_t*>(slab + plan.umin);
-    q.hq = reinterpret_cast<double*>(slab + plan.hq);
     q.list = reinterpret_cast<int32_t*>(slab + plan.list);
     q.blk_cb = reinterpret_cast<int32_t*>(slab + plan.blk_cb);
     q.blk_g0 = reinterpret_cast<int32_t*>(slab + plan.blk_g0);
@@ -1674,17 +1603,9 @@ static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, char
     hipLaunchKernelGGL(njp_fill_u64_kernel, dim3(256), dim3(256), 0, s, (uint64_t*)q.umin, q.nunits_alloc,
                        enc_f64_host(-__builtin_inf()));
     hipLaunchKernelGGL(njp_fill_u64_kernel, dim3(16), dim3(256), 0, s, (uint64_t*)q.t2_cmin, (int64_t)q.nprep, 0xFFF0000000000000ull);   // -inf (plain doubles)
-    hipLaunchKernelGGL(njp_fill_u64_kernel, dim3(256), dim3(256), 0, s, (uint64_t*)q.hq, q.nunits_alloc, 0xFFF0000000000000ull);        // -inf (plain doubles): no second bound yet
     DPR_HIP(hipGetLastError());
     q.fresh = true;
     return DPR_OK;
-}
-
-static double max_row_sum(const std::vector<int32_t>& perm, const std::vector<double>& hU)
-{
-    double m = 0.0;
-    for (int32_t p : perm) { const double u = hU[(size_t)p]; if (u == u && u > m) m = u; }
-    return m;
 }
 
 static void sort_by_row_sum(std::vector<int32_t>& perm, const std::vector<double>& hU)
@@ -1734,7 +1655,6 @@ int njp_build(NjBuffers& b, hipStream_t s)
     if (int rc = njp_arena(q, N, s)) return rc;
     q.epoch_index = 0;
     if (int rc = njp_alloc_epoch(q, N, N, q.arena_D, q.arena_slab[0], s)) return rc;
-    q.umax0 = max_row_sum(perm, hU);
     q.utot0 = q.utot;
     DPR_HIP(hipMemcpyAsync(q.perm, perm.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, s));
     if (std::getenv("DPR_NJ_ITERSTATS")) {
@@ -1798,7 +1718,6 @@ static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s, bool* rebuilt)
     const int e = old.epoch_index + 1;
     q.epoch_index = e;
     if (int rc = njp_alloc_epoch(q, n, b.N, (e & 1) ? b.D : q.arena_D, q.arena_slab[e & 1], s, old.range_known ? old.t2_hdr : nullptr)) return rc;
-    q.umax0 = max_row_sum(perm, hU);
     lap("njp_alloc_epoch");
     DPR_HIP(hipMemcpyAsync(q.perm, perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
     njp_launch_permute(old.D, old.ld, q.D, q.ld, q.perm, n, s);
@@ -1807,7 +1726,7 @@ static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s, bool* rebuilt)
                        q.slot_of_pos, q.pos_of_slot);
     DPR_HIP(hipGetLastError());
     // iteration state: nothing in quarantine (every row sum is in memory), empty lists
-    st.pnew[0] = -1; st.pnew[1] = -1; st.acc = 0.0; st.seed = __builtin_inf();
+    st.pnew[0] = -1; st.pnew[1] = -1;
     for (auto& c : st.cnt_list) c = 0ull;
     DPR_HIP(hipMemcpyAsync(b.st, &st, sizeof(NjState), hipMemcpyHostToDevice, s));
     lap("enqueue");
@@ -1863,7 +1782,6 @@ static int njp_from_slots(NjBuffers& b, hipStream_t s)
     sort_by_row_sum(perm, hU);
     q.epoch_index = 0;                       // even: the epoch lives in arena_D (b.D holds the slot-space matrix it is built from)
     if (int rc = njp_alloc_epoch(q, n, b.N, q.arena_D, q.arena_slab[0], s)) return rc;
-    q.umax0 = max_row_sum(perm, hU);
     DPR_HIP(hipMemcpyAsync(q.perm, perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
     njp_launch_permute((const double*)b.D, b.ld, q.D, q.ld, (const int32_t*)q.perm, n, s);
     q.range_known = false;
@@ -1875,7 +1793,7 @@ static int njp_from_slots(NjBuffers& b, hipStream_t s)
                        (const double*)b.U, (const int32_t*)q.perm, (const int32_t*)nullptr, n, n, q.U + (st.it & 1) * q.vstride, q.Ur, q.KA, q.KB,
                        q.slot_of_pos, q.pos_of_slot);
     DPR_HIP(hipGetLastError());
-    st.pnew[0] = -1; st.pnew[1] = -1; st.acc = 0.0; st.seed = __builtin_inf();
+    st.pnew[0] = -1; st.pnew[1] = -1;
     for (auto& c : st.cnt_list) c = 0ull;
     DPR_HIP(hipMemcpyAsync(b.st, &st, sizeof(NjState), hipMemcpyHostToDevice, s));
     DPR_HIP(hipStreamSynchronize(s));        // `st`, `perm` are host objects
@@ -1933,7 +1851,6 @@ static NjpArgs njp_args(NjBuffers& b, int v)
     a.U = q.U; a.R = q.R; a.vstride = q.vstride;
     a.Ur = q.Ur; a.KA = q.KA; a.KB = q.KB; a.slot_of_pos = q.slot_of_pos; a.pos_of_slot = q.pos_of_slot;
     a.xpart = b.xpart; a.partials = b.partials; a.umin = (unsigned long long*)q.umin;
-    a.hq = q.hq; a.umax0 = q.umax0;
     a.P = q.P;
     a.blk_cb = q.blk_cb; a.blk_g0 = q.blk_g0;
     a.tg = njp_tg(q.P); a.ns = njp_ns(q.P); a.nupd = 0;
