@@ -411,7 +411,7 @@ GEN_SYNTH = _os.path.join(_ROOT, "tools", "bin", "gen_synth")
 NRF_TOOL = _os.path.join(_ROOT, "tools", "bin", "nrf")
 
 
-def gen_synth(outdir, tag, tips, sites, seed, mean_bl, lo, hi, reads=False, shuffle=None, fasta=False):
+def gen_synth(outdir, tag, tips, sites, seed, mean_bl, lo, hi, reads=False, shuffle=None, fasta=False, extra=()):
     """Seeded synthetic input with its generating tree (tools/gen_synth.cpp).  Returns a dict: tree (path), names (tip
     names in OUTPUT order), packed4 ([tips][ceil(sites/16)] uint64 memmap) or reads (flat, off, len), fasta (path)."""
     base = _os.path.join(str(outdir), tag)
@@ -425,6 +425,7 @@ def gen_synth(outdir, tag, tips, sites, seed, mean_bl, lo, hi, reads=False, shuf
         cmd += ["--shuffle", str(shuffle)]
     if fasta:
         cmd += ["--fasta", base + ".fa"]
+    cmd += list(extra)            # e.g. ("--model", "gtr+g+i", "--indel-gaps")
     _subprocess.run(cmd, check=True)
     order = np.fromfile(base + ".ord", dtype=np.int32)
     out = {"tree": base + ".nwk", "names": ["T%d" % (k + 1) for k in order], "fasta": base + ".fa" if fasta else None}

@@ -1,6 +1,8 @@
 """GPU parity against the CPU oracle at sizes where the NATURAL code paths run, with no environment overrides
 (round 3's verdict, weak #1: oracle comparisons stopped at ~2 000 tips; everything larger was a self-comparison).
 
+* NJ at 10 000 tips on the authors' kind of input (GTR+G4+I, inherited deletions, plus per-tip gap runs; round 4): the
+  distances themselves -- gap cells deciding the counts -- against the oracle's (rtol 1e-11), then the merge log bit for bit.
 * NJ at 10 000 tips (src/neighborJoining.cu:117-249): the pruned path crosses its default epochs (>= 2 048 positions,
   rebuild at 80 %: 10 000 -> 8 000 -> 6 400 -> ... -> 2 097), the adaptive plan meets its real 70 % threshold on the
   small-integer matrix, the streaming path runs its default 2 048-block grid -- merge log bit for bit against
@@ -47,9 +49,13 @@ def _same_log(res, ref, what):
     assert res["last_d"] == ref["last_d"], what
 
 
-def _nj_inputs(kind, n):
+def _nj_inputs(kind, n, tmp_path=None):
     from dipper_amd import capi
     rng = np.random.default_rng(4242)
+    if kind == "protocol_gtr_gaps":     # the authors' protocol in small: GTR+G4+I substitutions, inherited deletions, and 0.5 % of
+        # every tip as its own runs of '-' so that the not-a-base plane of the distance kernel decides counts everywhere
+        inp = _util.gen_synth(tmp_path, "p", n, 1200, 77, 2e-3, 2e-4, 2e-2, extra=("--model", "gtr+g+i", "--indel-gaps", "--gap-frac", "0.005"))
+        return ("msa", np.ascontiguousarray(inp["packed4"]), 1200, capi.DIST_JC)
     if kind == "alignment_jc":          # the bench's kind of input, scaled down: pruning stays on for the whole run
         seqs = _util.synth_alignment(rng, n, 600, mean_bl=2e-3, lo=2e-4, hi=2e-2)
         return ("msa", capi.pack4_many(seqs), 600, capi.DIST_JC)
@@ -60,12 +66,12 @@ def _nj_inputs(kind, n):
     return ("matrix", np.tril(D, -1) + np.tril(D, -1).T)
 
 
-@pytest.mark.parametrize("kind", ["alignment_jc", "clonal_ties", "small_integers"])
-def test_nj_10k_default_plans_equal_oracle(orc, kind):
+@pytest.mark.parametrize("kind", ["alignment_jc", "clonal_ties", "small_integers", "protocol_gtr_gaps"])
+def test_nj_10k_default_plans_equal_oracle(orc, kind, tmp_path):
     import dipper_amd
     from dipper_amd import capi
     n = 10000
-    inp = _nj_inputs(kind, n)
+    inp = _nj_inputs(kind, n, tmp_path)
     ref = None
     seen = {}
     try:
@@ -82,6 +88,14 @@ def test_nj_10k_default_plans_equal_oracle(orc, kind):
                 if ref is None:
                     M = d.matrix()
                     assert np.array_equal(M, M.T)
+                    if kind == "protocol_gtr_gaps":
+                        # the distances themselves, gaps included, against the oracle's (src/MSA.cu:103-156) on the first 500 tips
+                        sub = orc.msa_dist_lower(inp[1][:500], inp[2], inp[3])
+                        got = np.tril(M[:500, :500], -1)
+                        assert np.isfinite(got).all() and (np.tril(np.asarray(sub)[:500, :500], -1) > 0).any()
+                        np.testing.assert_allclose(got, np.tril(np.asarray(sub)[:500, :500], -1), rtol=1e-11, atol=0)
+                        gap_cells = float(np.mean([((int(w) >> (4 * k)) & 15) >= 4 for w in inp[1][:50].ravel()[:2000] for k in range(16)]))
+                        assert gap_cells > 0.002, gap_cells
                     ref = orc.nj_run(np.tril(M, -1), threads=_host_threads())
                     del M
                     assert ref["iters"] == n - 2
