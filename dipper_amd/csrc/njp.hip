@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
     __shared__ double s[kThreads];
     __shared__ double sq[kThreads / 64], sdd[kThreads / 64];
     __shared__ uint64_t sk[kThreads / 64], spp[kThreads / 64];
-    __shared__ double sseed[kThreads / 64], srC[kThreads / 64], scm[kNS * 4];
+    __shared__ double sseed[kThreads / 64], srC[kThreads / 64], scm[kNS * 4], s_colmin[kNS * 4];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int bx = (int)blockIdx.x;
@@ -1174,6 +1174,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
             const double v0 = nj_val(dx.x, dy.x, d), v1 = nj_val(dx.y, dy.y, d);       // the new node's row
             const double un0 = nj_unew(uc.x, dx.x, dy.x, v0);
             const double un1 = nj_unew(uc.y, dx.y, dy.y, v1);
+            NJP_STAMP(2, 4, false);           // (finer stamps of this kernel live in group 2: rows x / y have arrived)
             if (a.do_update) {
                 // same values, same destinations as njp_post_kernel's update role (which reaches them through pos_of_slot): new row
                 // sums into the other buffer, the new node's row into the row buffer and its column into the matrix, keys from the
@@ -1205,6 +1206,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
                     }
                 }
             }
+            NJP_STAMP(2, 5, false);           // (the position-order stores are issued)
             const double m2 = fmax(live0 ? un0 : NINF, live1 ? un1 : NINF);
             double gm = m2;                                                   // group of 16 positions = 8 lanes
             gm = fmax(gm, __shfl_xor(gm, 1, 64)); gm = fmax(gm, __shfl_xor(gm, 2, 64)); gm = fmax(gm, __shfl_xor(gm, 4, 64));
@@ -1372,6 +1374,8 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
         }
         NJP_STAMP(1, 4, false);
     }
+    double colz = PINF;            // (issued with the unit bounds; see below)
+    if (gz_here && tid < 4 * kNS && (tid >> 2) < nsb) colz = a.t2_colmin[par * SS4 + 4 * (cb0 + (tid >> 2)) + (tid & 3)];
     if (kNS > 1) {
 #pragma unroll
         for (int k = 0; k < kNS; ++k) {
@@ -1382,6 +1386,13 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
         }
     }
     NJP_STAMP(1, 5, true);
+    if (gz_here) {                 // block-uniform: the ~20 blocks whose row groups hold the node leaving quarantine
+        // its column minima for this block's 4 x kNS sub-strips in ONE round trip: loaded where they are used -- one lane, inside
+        // the loop below, each behind a wait and in front of a conditional store -- they were sixteen round trips in a row in
+        // exactly the blocks that end the launch (ISA: load, s_waitcnt vmcnt(0), store, load, ...)
+        if (tid < 4 * kNS) s_colmin[tid] = colz;
+        __syncthreads();
+    }
     double mymin = PINF;           // minimum of this lane's sub-unit bounds after the fold: the cell's new coarse bound
     int sub[kNS];                  // per strip: sub-unit mask of this lane's unit, 0 = not listed
 #pragma unroll
@@ -1400,7 +1411,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const double cmw = cm4[sidx][w];
-                double nm = (gz_here && g == gz) ? a.t2_colmin[par * SS4 + 4 * cb + w] : PINF;      // the unit (this strip, group of pz)
+                double nm = (gz_here && g == gz) ? s_colmin[4 * sidx + w] : PINF;      // the unit (this strip, group of pz)
                 if (pz_strip && w == wpz) nm = fmin(nm, newminA);
                 if (nm < u4[w]) {                          // persist the lowered bound (this lane is the unit's only writer here)
                     u4[w] = nm;
@@ -1413,6 +1424,9 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
         }
         if (have && (rmax > NINF)) sub[sidx] = submask;
     }
+    // (finer stamps, group 2.  A stamp is a store, and the next wait for "all memory operations" includes it: ~0.5 us each --
+    //  read differences between stamps with that in mind; two more stamps inside the loop above made every strip "cost" 0.6 us)
+    NJP_STAMP(2, 0, false);                   // (the unit tests are done)
     // ONE list append per wave for all its strips (an atomic per strip is a chain of kNS dependent round trips)
     {
         unsigned long long masks[kNS];
@@ -1423,6 +1437,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
             unsigned long long base = 0;
             if (lane == 0) base = atomicAdd(&a.cnt[(it + 1) % 3], (unsigned long long)total);
             base = __shfl(base, 0, 64);
+            NJP_STAMP(2, 1, false);           // (wave 0 only, if it lists: the atomic has returned)
 #pragma unroll
             for (int sidx = 0; sidx < kNS; ++sidx) {
                 if (sub[sidx] != 0)
@@ -1432,10 +1447,12 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
             }
         }
     }
+    NJP_STAMP(2, 2, false);                   // (the list stores are issued)
     mymin = wave_fmin(mymin);
     __syncthreads();               // (srC: the coarse maxima above were read by every thread)
     if (lane == 0) srC[tid >> 6] = mymin;
     __syncthreads();
+    NJP_STAMP(2, 3, false);                   // (every wave of the block has got here)
     if (tid == 0) a.t2_cmin[tb] = fmin(fmin(srC[0], srC[1]), fmin(srC[2], srC[3]));
     NJP_STAMP(1, 6, true);
     if (a.dbg != nullptr && it == a.dbg_it && tid == 0) a.dbg[(2048 + bx) * 8 + 7] = 4ull;

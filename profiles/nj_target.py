@@ -105,6 +105,7 @@ if args.phases is not None:
     L_ = capi.load_library()
     L_.dpr_get_nj_phase_stamps.argtypes = [C.c_void_p]
     assert L_.dpr_get_nj_phase_stamps(buf.ctypes.data) == 0
+    fine = buf[2 * 2048 * 8:3 * 2048 * 8].reshape(2048, 8).astype(np.int64)      # njp_post2_kernel's finer stamps (group 2)
     buf = buf[:2 * 2048 * 8].reshape(2, 2048, 8).astype(np.int64)
     t_scan0 = buf[0][buf[0] > 0].min()
     for k, name in ((0, "scan"), (1, "post")):
@@ -132,4 +133,12 @@ if args.phases is not None:
                 if ok.any():
                     v = 10 * (col[ok] - t0)
                     print(f"   stamp {j}: blocks {ok.sum():5d}  min {v.min():7d}  median {int(np.median(v)):7d}  p90 {int(np.percentile(v, 90)):7d}  max {v.max():7d}")
+            if k == 1:
+                names = {0: "tests done", 1: "list atomic returned (wave 0)", 2: "list stores issued", 3: "after the coarse-bound barriers", 4: "rows x / y arrived", 5: "position-order stores issued"}
+                for j in range(8):
+                    col = fine[m][:, j]
+                    ok = col > 1000000
+                    if ok.any():
+                        v = 10 * (col[ok] - t0)
+                        print(f"   fine {j} ({names.get(j, '')}): blocks {ok.sum():5d}  min {v.min():7d}  median {int(np.median(v)):7d}  p90 {int(np.percentile(v, 90)):7d}  max {v.max():7d}")
 d.close()
