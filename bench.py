@@ -574,6 +574,28 @@ def main():
                "nj_algorithm": "exact pruned scan (njp.hip)" if prune else "full streaming scan (nj.hip)",
                "prune": prune}
         log(f"[bench r{rank}] hot path steps: {hot['step_ms']} phases {hot['phase_ms']}")
+        if (args.model != "jc69" or not args.no_indel_gaps) and args.steps > 0 and not args.probe_only and n <= 50000:
+            # the same hot path on the input of rounds 1-3 (JC69 substitutions, no gaps), for comparison across rounds:
+            # one warm-up + two timed steps on a context of its own
+            try:
+                inp3 = stage.gen("main_r3", n, L, args.seed, 2e-5, 2e-6, 2e-4, gap=None, model="jc69")
+                d3 = dipper_amd.Dipper(local_rank)
+                try:
+                    d3.set_nj_multi_plan(2)
+                    d3.set_msa(Stage.packed4(inp3), L)
+                    ph3 = []
+                    for k in range(3):
+                        d3.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+                        r3 = d3.nj_run()
+                        if k:
+                            ph3.append(d3.timing())
+                    hot["rounds_1_to_3_input"] = {"input": "jc69, no gaps", "dist_ms": float(np.mean([p[0] for p in ph3])),
+                                                  "nj_ms": float(np.mean([p[1] for p in ph3])), "units_scanned": d3.prune_stats()[0],
+                                                  "merge_log_digest": merge_digest(r3)}
+                finally:
+                    d3.close()
+            except Exception as e:
+                hot["rounds_1_to_3_input"] = {"error": repr(e)}
 
         # ---- the timed kernels' own record: what the pruned scan read, and how fast ---------------------------
         if prune and nj_ms and not args.probe_only:
