@@ -818,13 +818,22 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
         c.rzc.x = PINF; c.rzc.y = PINF;
         if (gz_here) c.rzc = *reinterpret_cast<const v2d*>(Rz + pc0);
     };
-    v2d dxr[kRC], dyr[kRC];
+    // (the ~30 blocks of the strip that holds the node leaving quarantine also need ITS buffered row over their rows: fetched
+    //  here, with rows x / y.  Fetched where it is used -- behind the first barrier of the strip loop -- it was one more round
+    //  trip to HBM in exactly the blocks that end the launch: tests + list append ended at 4.4 - 5.0 us, theirs at 6.5.)
+    constexpr bool kPreRz = kRC <= 4;                                        // (8 registers per 512 rows)
+    const bool pz_block = fold && pz / kTileCols >= cb0 && pz / kTileCols < cb0 + nsb;      // block-uniform
+    v2d dxr[kRC], dyr[kRC], rzr[kPreRz ? kRC : 1];
 #pragma unroll
     for (int c = 0; c < kRC; ++c) {
         const int64_t pp = rbase + c * kTileCols + 2 * tid;
         const int64_t po = pp < P ? pp : pclamp;
         dxr[c] = *reinterpret_cast<const v2d*>(rowx + po);
         dyr[c] = *reinterpret_cast<const v2d*>(rowy + po);
+        if (kPreRz) {
+            rzr[c].x = 0.0; rzr[c].y = 0.0;
+            if (pz_block) rzr[c] = *reinterpret_cast<const v2d*>(Rz + po);
+        }
     }
 #pragma unroll
     for (int k = 0; k < kNS; ++k)
@@ -915,7 +924,7 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
             for (int c = 0; c < kRC; ++c) {
                 const int lp = c * kTileCols + 2 * tid;
                 const int64_t pp = rbase + lp;
-                const v2d rz = *reinterpret_cast<const v2d*>(Rz + (pp < P ? pp : pclamp));
+                const v2d rz = kPreRz ? rzr[kPreRz ? c : 0] : *reinterpret_cast<const v2d*>(Rz + (pp < P ? pp : pclamp));
                 const double u0 = urow[c].x, u1 = urow[c].y;
                 const bool live0 = (u0 == u0) & (lp != lxp) & (lp != lyp) & (lp > lzp);
                 const bool live1 = (u1 == u1) & (lp + 1 != lxp) & (lp + 1 != lyp) & (lp + 1 > lzp);
