@@ -117,6 +117,15 @@ static double run_chase(int mode, const uint64_t* d, int warm, int steps, uint64
     return 10.0 * (double)h[0] / steps;      // ns per dependent load
 }
 
+// dispatch ramp: every workgroup stamps the clock when it starts (then idles ~3 us so that early workgroups do not make room
+// for late ones); the spread of the stamps is how long the dispatcher takes to get a grid going
+__global__ void ramp_kernel(uint64_t* stamps)
+{
+    const uint64_t t0 = wall_clock64();
+    if (threadIdx.x == 0) stamps[blockIdx.x] = t0;
+    while (wall_clock64() - t0 < 300) { }
+}
+
 int main()
 {
     CK(hipSetDevice(0));
@@ -192,8 +201,31 @@ int main()
             CK(hipMemcpy(&h, dout, 8, hipMemcpyDeviceToHost));
             std::printf(", \"with_%d_blocks_on_the_word\": %.0f", blocks, 10.0 * (double)h / 200);
         }
-        std::printf("}\n");
+        std::printf("},\n");
         CK(hipFree(w));
+    }
+    // ---- dispatch ramp: last start - first start of a grid, by shape (the post launch of the NJ loop: ~1 000 x 256 threads)
+    {
+        uint64_t* st = nullptr;
+        CK(hipMalloc(&st, 8 * 8192));
+        std::printf(" \"dispatch_ramp_ns\": {");
+        const int shapes[][2] = { { 256, 256 }, { 512, 256 }, { 1024, 256 }, { 2048, 256 }, { 1024, 128 }, { 2048, 128 }, { 512, 512 }, { 256, 1024 }, { 1024, 64 }, { 4096, 64 } };
+        bool first = true;
+        for (const auto& sh : shapes) {
+            std::vector<uint64_t> h((size_t)sh[0]);
+            double best = 1e30, med_sum = 0;
+            for (int rep = 0; rep < 5; ++rep) {
+                hipLaunchKernelGGL(ramp_kernel, dim3(sh[0]), dim3(sh[1]), 0, 0, st);
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(h.data(), st, 8 * (size_t)sh[0], hipMemcpyDeviceToHost));
+                const uint64_t lo = *std::min_element(h.begin(), h.end()), hi = *std::max_element(h.begin(), h.end());
+                if (rep) { best = std::min(best, 10.0 * (double)(hi - lo)); med_sum += 10.0 * (double)(hi - lo); }
+            }
+            std::printf("%s\"%dx%d\": {\"min\": %.0f, \"mean\": %.0f}", first ? "" : ", ", sh[0], sh[1], best, med_sum / 4);
+            first = false;
+        }
+        std::printf("}\n");
+        CK(hipFree(st));
     }
     std::printf("}\n");
     return 0;
