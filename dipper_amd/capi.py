@@ -81,6 +81,9 @@ def load_library():
     L.dpr_get_place_overlap.argtypes = [C.c_void_p, C.POINTER(C.c_int), c_f64p]
     L.dpr_get_place_policy.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.dpr_get_prune_stats.argtypes = [C.c_void_p, c_u64p, c_u64p]
+    L.dpr_ctx_set_debug_fault.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+    L.dpr_get_nj_progress.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.dpr_get_njp_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.dpr_bw_probe.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.dpr_set_msa.argtypes = [C.c_void_p, c_u64p, C.c_int64, C.c_int64]
     L.dpr_set_reads.argtypes = [C.c_void_p, c_u64p, c_u64p, c_u64p, C.c_int64]
@@ -256,6 +259,10 @@ class Dipper:
         _chk(self.L, self.L.dpr_get_nj_adaptive_stats(self.h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
+    def set_debug_fault(self, iteration, rank):
+        """test hook of the one-exchange loops' cross-check: `rank` corrupts one pulled element at `iteration` (-1, -1: off)"""
+        _chk(self.L, self.L.dpr_ctx_set_debug_fault(self.h, iteration, rank))
+
     def set_poll_limit_ms(self, ms):
         _chk(self.L, self.L.dpr_ctx_set_poll_limit_ms(self.h, ms))
 
@@ -391,6 +398,38 @@ class Dipper:
                                               _p(bx, c_f64p), _p(by, c_f64p), C.byref(last)))
         return dict(iters=done, merge_x=mx[:done], merge_y=my[:done], bl_x=bx[:done], bl_y=by[:done],
                     last_d=last.value)
+
+    def nj_run_partial(self, max_iters=-1):
+        """like nj_run, but a run that ends without a Q candidate (DPR_ERR_NOCAND: the reference's undefined (0,0) merge) returns
+        the log up to there instead of raising: dict(..., code=0 or -4)"""
+        N = self.L.dpr_n_total(self.h)
+        k = max(N - 2, 1)
+        mx = np.zeros(k, dtype=np.int32)
+        my = np.zeros(k, dtype=np.int32)
+        bx = np.zeros(k, dtype=np.float64)
+        by = np.zeros(k, dtype=np.float64)
+        last = C.c_double(0.0)
+        it0, _ = self.nj_progress()
+        rc = self.L.dpr_nj_run(self.h, max_iters, _p(mx, c_i32p), _p(my, c_i32p), _p(bx, c_f64p), _p(by, c_f64p), C.byref(last))
+        if rc < 0 and rc != -4:
+            _chk(self.L, rc)
+        done = self.nj_progress()[0] - it0
+        return dict(iters=done, code=0 if rc >= 0 else int(rc), merge_x=mx[:done], merge_y=my[:done], bl_x=bx[:done], bl_y=by[:done],
+                    last_d=last.value)
+
+    def nj_progress(self):
+        """(iterations done since dist_matrix, active size)"""
+        a = C.c_int64()
+        b = C.c_int64()
+        _chk(self.L, self.L.dpr_get_nj_progress(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def njp_shape(self):
+        """launch shape of the pruned path's current epoch: dict(positions, row_groups, strips, post2, scan_grid)"""
+        P = C.c_int64()
+        v = [C.c_int() for _ in range(4)]
+        _chk(self.L, self.L.dpr_get_njp_shape(self.h, C.byref(P), *[C.byref(x) for x in v]))
+        return dict(positions=int(P.value), row_groups=v[0].value, strips=v[1].value, post2=bool(v[2].value), scan_grid=v[3].value)
 
     def nj_is_unit_sharded(self):
         return bool(self.L.dpr_nj_is_unit_sharded(self.h))

@@ -671,6 +671,16 @@ int dpr_get_nj_exchange_info(dpr_ctx* c, int* active_plan, int64_t* launches, in
     return DPR_OK;
 }
 // bound of one mailbox poll in milliseconds (default 2000): a rank whose record does not arrive ends the run with DPR_ERR_COMM
+// Test hook of the one-exchange loops' cross-check: rank `rank` uses a wrong value for one element of a row it pulled at
+// iteration `iteration` (-1, -1 switches it off).  The run must then end with DPR_ERR_COMM on every rank one iteration later.
+// A setter of the context, not an environment variable: nothing outside a test can switch it on.
+int dpr_ctx_set_debug_fault(dpr_ctx* c, int64_t iteration, int rank)
+{
+    if (!c) { set_error("dpr_ctx_set_debug_fault: null ctx"); return DPR_ERR_ARG; }
+    for (auto& b : c->nj) { b.peer.fault_it = iteration; b.peer.fault_rank = rank; }
+    return DPR_OK;
+}
+
 int dpr_ctx_set_poll_limit_ms(dpr_ctx* c, int ms)
 {
     if (!c || ms < 1) { set_error("dpr_ctx_set_poll_limit_ms: ms >= 1"); return DPR_ERR_ARG; }
@@ -927,8 +937,13 @@ int dpr_warm_graphs(dpr_ctx* c)
             std::vector<char> h(kWarmBytes);
             (void)hipMemsetAsync(d, 0, kWarmBytes, st);
             (void)hipStreamSynchronize(st);
-            (void)hipMemcpy(h.data(), d, kWarmBytes, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(d, h.data(), kWarmBytes, hipMemcpyHostToDevice);
+            // (on the private stream: a synchronous hipMemcpy runs on the NULL stream, which serialises with every blocking
+            //  stream of the device -- this function may run beside other dpr_* calls of the context; pageable staging is
+            //  exercised all the same)
+            (void)hipMemcpyAsync(h.data(), d, kWarmBytes, hipMemcpyDeviceToHost, st);
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpyAsync(d, h.data(), kWarmBytes, hipMemcpyHostToDevice, st);
+            (void)hipStreamSynchronize(st);
             (void)hipFree(d);
         }
     }
@@ -1191,6 +1206,23 @@ int dpr_get_prune_stats(dpr_ctx* c, uint64_t* units_scanned, uint64_t* units_per
 }
 
 // debug (DPR_NJ_ITERSTATS=1): per iteration [units scanned, max units of one block]
+int dpr_get_nj_progress(dpr_ctx* c, int64_t* iterations_done, int64_t* active)
+{
+    if (!c || !c->have_matrix) { set_error("dpr_get_nj_progress: call dpr_dist_matrix first"); return DPR_ERR_STATE; }
+    DPR_HIP(hipSetDevice(c->device));
+    NjState st;
+    if (int rc = fetch_state(c, &st)) return rc;
+    if (iterations_done) *iterations_done = st.it;
+    if (active) *active = st.n;
+    return DPR_OK;
+}
+
+int dpr_get_njp_shape(dpr_ctx* c, int64_t* positions, int* row_groups, int* strips, int* post2, int* scan_grid)
+{
+    if (!c || !c->have_matrix || !c->nj[0].pr.active) { set_error("dpr_get_njp_shape: no pruned NJ state"); return DPR_ERR_STATE; }
+    return njp_shape(c->nj[0].pr, positions, row_groups, strips, post2, scan_grid);
+}
+
 int dpr_get_iterstats(dpr_ctx* c, uint64_t* out, int64_t iters)
 {
     if (!c || !c->have_matrix || !c->nj[0].pr.iterstats) { set_error("dpr_get_iterstats: not enabled"); return DPR_ERR_STATE; }

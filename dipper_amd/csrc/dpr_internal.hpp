@@ -206,7 +206,7 @@ struct NjPeer {
     unsigned long long bar_epoch = 0;
     unsigned long long run_id = 0;   // matrix builds on this window so far (part of every mail sequence number)
     unsigned long long poll_ticks = 200000000ull;    // 2 s of the 100 MHz wall clock
-    int64_t fault_it = -1; int fault_rank = -1;      // test hook DPR_NJS_FAULT (njs_alloc_window)
+    int64_t fault_it = -1; int fault_rank = -1;      // test hook (dpr_ctx_set_debug_fault)
 };
 
 struct NjBuffers {
@@ -275,7 +275,8 @@ int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s);   // enqueu
 const char* njp_kernel_name(int idx);   // kernels of one iteration, in launch order
 int njp_phase_stamps(unsigned long long* out);   // debug (DPR_NJ_PHASES)
 int njp_debug_list(NjBuffers& b, int32_t* out, int64_t cap, int64_t* count, int64_t* P, double* ur, int64_t urcap);   // debug
-const double* njp_current_u(const NjPruned& q, int64_t it);   // row sums by position after `it` iterations
+const double* njp_current_u(const NjPruned& q, int64_t it);
+int njp_shape(const NjPruned& q, int64_t* positions, int* row_groups, int* strips, int* post2, int* scan_grid);   // launch shape of the current epoch   // row sums by position after `it` iterations
 
 // Divide-and-conquer cluster distances (dc.hip builds the jobs; msa.hip / mash.hip run them).
 // Cluster ci has cl_m[ci] members (tip ids members[cl_moff[ci] + t], ascending) and a leaf list

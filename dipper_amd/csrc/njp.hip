@@ -2083,6 +2083,16 @@ int njp_phase_stamps(unsigned long long* out)
 // current U buffer of the pruned path (row sums by position) after `it` iterations
 const double* njp_current_u(const NjPruned& q, int64_t it) { return q.U + (it & 1) * q.vstride; }
 
+int njp_shape(const NjPruned& q, int64_t* positions, int* row_groups, int* strips, int* post2, int* scan_grid)
+{
+    if (positions) *positions = q.P;
+    if (row_groups) *row_groups = njp_tg(q.P);
+    if (strips) *strips = njp_ns(q.P);
+    if (post2) *post2 = njp_use_post2(q) ? 1 : 0;
+    if (scan_grid) *scan_grid = q.scan_grid;
+    return DPR_OK;
+}
+
 // enqueue `todo` iterations starting at iteration it0, in epochs: whenever the active size has dropped to
 // pct % of the epoch's positions (and the epoch is large enough to matter) the position space is rebuilt; with the
 // adaptive plan on, the listing rate is watched and the run handed over to the streaming loop (and back) as described in
@@ -2119,8 +2129,9 @@ int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
                 const auto t0 = std::chrono::steady_clock::now();
                 bool rebuilt = false;
                 if (int rc = njp_rebuild_epoch(b, s, &rebuilt)) return rc;
-                // not rebuilt: the run has no candidate left (status != 0: any NaN / inf distance at iteration 0 makes every
-                // row sum NaN) and every queued kernel is a no-op -- stop here, dpr_nj_run reports DPR_ERR_NOCAND
+                // not rebuilt: the run has no candidate left (status != 0: e.g. only rows with NaN row sums are still active -- a NaN
+                // distance makes the row sums of ITS two rows NaN, those rows never win and stay to the end) and every queued
+                // kernel is a no-op -- stop here, dpr_nj_run reports DPR_ERR_NOCAND
                 if (!rebuilt) return DPR_OK;
                 if (std::getenv("DPR_NJ_EPOCH_LOG"))
                     std::fprintf(stderr, "[njp] epoch rebuild at n=%lld: %.2f ms\n", (long long)n,

@@ -61,7 +61,7 @@ struct NjsArgs {
     int nparts;                                  // scan grid
     unsigned long long poll_ticks;               // bound of a mailbox poll (100 MHz wall clock)
     unsigned long long seq_base;                 // run id << 32: sequence numbers are unique across the runs of a context
-    int64_t fault_it; int fault_rank;            // test hook (DPR_NJS_FAULT=iteration,rank): that rank corrupts one pulled element there
+    int64_t fault_it; int fault_rank;            // test hook (dpr_ctx_set_debug_fault): that rank corrupts one pulled element there
     int32_t* log_x; int32_t* log_y; double* log_bx; double* log_by;
 };
 
@@ -546,15 +546,8 @@ int njs_alloc_window(NjBuffers& b, hipStream_t s)
 {
     NjPeer& p = b.peer;
     const NjsLayout lay = njs_layout(b.N, b.world);
-    {
-        // DPR_NJS_FAULT=iteration,rank: that rank corrupts one element of a pulled row at that iteration (tests of the
-        // cross-check: the run must end with DPR_ERR_COMM one iteration later, on every rank, with both plans)
-        p.fault_it = -1; p.fault_rank = -1;
-        if (const char* e = std::getenv("DPR_NJS_FAULT")) {
-            long long fi = -1; int fr = -1;
-            if (std::sscanf(e, "%lld,%d", &fi, &fr) == 2) { p.fault_it = fi; p.fault_rank = fr; }
-        }
-    }
+    // (p.fault_it / p.fault_rank -- the test hook of the cross-check -- are set by dpr_ctx_set_debug_fault only: no environment
+    //  variable can make a production run corrupt a pulled element)
     if (p.win && p.lay.bytes == lay.bytes) {
         // Reuse (same shape again): nothing in the window is cleared -- another rank may already be ahead of this one and
         // writing into it.  Mail sequence numbers carry the run id, barrier epochs only grow, the slice and the row

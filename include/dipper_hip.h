@@ -197,6 +197,9 @@ int dpr_get_nj_adaptive_stats(dpr_ctx *ctx, int64_t *stream_iterations, int64_t 
  * it pulled (replicated state: identical on every rank by construction) and its status; a differing word, a record of another
  * iteration or a poll that times out ends dpr_nj_run with DPR_ERR_COMM on every rank. */
 int dpr_ctx_set_nj_exchange(dpr_ctx *ctx, int plan);
+/* test hook of that cross-check (no counterpart in the reference): rank `rank` uses a wrong value for one element of a row it
+ * pulled at iteration `iteration`; (-1, -1) = off.  Effective for the context's following dpr_nj_run calls. */
+int dpr_ctx_set_debug_fault(dpr_ctx *ctx, int64_t iteration, int rank);
 /* what the last dpr_dist_matrix set up (*active_plan, note) and what the last dpr_nj_run enqueued on this rank */
 int dpr_get_nj_exchange_info(dpr_ctx *ctx, int *active_plan, int64_t *launches, int64_t *collectives, char *note, int cap);
 /* bound of one mailbox / barrier poll in ms (default 2000): a rank whose record does not arrive ends the run with DPR_ERR_COMM */
@@ -223,6 +226,13 @@ int dpr_get_njp_list(dpr_ctx *ctx, int32_t *out, int64_t cap, int64_t *count, in
 int dpr_njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world);
 /* pruned path: 16x512 units scanned since dpr_dist_matrix, and units of one full scan */
 int dpr_get_prune_stats(dpr_ctx *ctx, uint64_t *units_scanned, uint64_t *units_per_full_scan);
+/* state of the NJ run after the last dpr_nj_run: iterations done since dpr_dist_matrix and active size -- also after a
+ * call that ended with DPR_ERR_NOCAND (the reference's undefined (0,0) merge, src/neighborJoining.cu:134-141,214): the merge
+ * log up to there has been copied to the caller's arrays, this says how many entries it holds */
+int dpr_get_nj_progress(dpr_ctx *ctx, int64_t *iterations_done, int64_t *active);
+/* pruned path, current epoch: positions, row groups per test block, strips per test block, 1 if the large-shape post
+ * kernel (njp_post2_kernel) serves it, blocks of the unit scan (tests: which launch shape a run really used) */
+int dpr_get_njp_shape(dpr_ctx *ctx, int64_t *positions, int *row_groups, int *strips, int *post2, int *scan_grid);
 
 /* microbenchmark: microseconds per launch of a chain of `nlaunch` trivial dependent kernels of `grid`
  * blocks on the context's stream, eager (0) or hipGraph replay of 128-node chains (1) */

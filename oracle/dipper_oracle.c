@@ -321,6 +321,11 @@ ORC_API int orc_nj_argmin(const double *D, int64_t n, int64_t ld, const double *
  * +0.0 elsewhere; chunk sums over 256 consecutive i by the pairwise tree; chunk sums folded
  * p[t] = sum_k cs[t+256k] (ascending k) and combined by the same tree.
  * ------------------------------------------------------------------------------------------ */
+/* iterations the last orc_nj_run completed -- also when it returned -1 (no candidate left: the reference's undefined (0,0)
+ * merge); its log arrays hold that many valid entries.  Test infrastructure: one run at a time per process. */
+static int64_t orc_nj_done_last = 0;
+ORC_API int64_t orc_nj_last_iterations(void) { return orc_nj_done_last; }
+
 ORC_API int64_t orc_nj_run(double *D, int64_t N, int64_t ld, int threads, int64_t max_iters,
                            int32_t *merge_x, int32_t *merge_y, double *bl_x, double *bl_y,
                            double *last_d, double *U_out /* N or NULL */)
@@ -338,7 +343,7 @@ ORC_API int64_t orc_nj_run(double *D, int64_t N, int64_t ld, int threads, int64_
         double r = (double)(n - 2);
         for (int64_t i = 0; i < n; ++i) Ur[i] = U[i] / r;
         orc_best b = orc_scan(D, n, ld, Ur, threads);
-        if (b.key == UINT64_MAX) { it = -1; break; }
+        if (b.key == UINT64_MAX) { orc_nj_done_last = it; it = -1; break; }
         int64_t x = (int64_t)(b.key & 0xFFFFFF), y = (int64_t)((b.key >> 24) & 0xFFFFFF);
         if (x > y) { int64_t t = x; x = y; y = t; }
         double d = D[x * ld + y];
@@ -388,6 +393,7 @@ ORC_API int64_t orc_nj_run(double *D, int64_t N, int64_t ld, int threads, int64_
             U[x] = orc_tree256(p);
         }
     }
+    if (it >= 0) orc_nj_done_last = it;
     if (it >= 0 && it == N - 2 && last_d) *last_d = D[0 * ld + 1];
     if (U_out) memcpy(U_out, U, sizeof(double) * (size_t)N);
     free(U); free(Ur); free(cs);

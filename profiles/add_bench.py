@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """--add timing (BASELINE configs[4] shape, scaled): python profiles/add_bench.py [backbone tips] [queries] [sites] [kind m|r]
 Backbone tree = divide-and-conquer tree of the first m tips (built here), imported like Tree::Tree +
 initializeDeviceArrays, then the queries are placed with addQuery (dpr_place_run first = m)."""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Whole-command wall time of `dipper` (30 000 x 10 000 FASTA -> Newick, back to back) under HIP / ROCr environment settings that change
 how many queues the runtime creates and tears down: python profiles/cli_env_sweep.py [tips] [sites] [runs]"""
 import json, os, statistics, subprocess, sys, tempfile, time

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """The `dipper` command's own runtime settings (HSA_ENABLE_SDMA=0, GPU_MAX_HW_QUEUES=2, main.cpp) against the runtime's defaults
 (DPR_CLI_RUNTIME_DEFAULTS=1) in every mode: wall time of the whole command, interleaved runs.  python profiles/cli_modes_sweep.py [runs]"""
 import json, os, statistics, subprocess, sys, tempfile, time

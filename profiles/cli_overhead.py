@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Where the `dipper` command's wall time goes outside its own clock: python profiles/cli_overhead.py [tips] [sites] [runs]
 wall (parent's clock around the child) vs "Main in" (the child's clock from main() to the exit call): the difference is process start
 (exec, dynamic linking, static initialisers) + process end (the kernel driver tearing down the GPU context and its allocations)."""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """CLI input phase against the host threads a rank gets (8 ranks on a 16-core grant: 2 each): python profiles/cli_threads.py"""
 import json, os, subprocess, sys, tempfile, time
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Validates the two extrapolations of bench.py's CPU baselines ONCE, outside the bench's time budget (round 3's verdict, weak #9):
   (a) the RapidNJ-style baseline (oracle/rapidnj_baseline.c) run IN FULL on the bench's 30 000-tip matrix, next to what
       bench.py's rule -- the largest block that fits 20 s, scaled by (N/m)^e with e measured between 3 000 and 6 000 tips -- predicts;

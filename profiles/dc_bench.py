@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Divide-and-conquer mode timing (BASELINE configs[3]): python profiles/dc_bench.py [tips] [sites] [kind m|r] [backbone|0] [mean branch length]
 Synthetic alignment as bench.py (Yule-Harding tree, JC69, no indels); backbone defaults to tips/20 as the CLI."""
 import json, os, sys, time

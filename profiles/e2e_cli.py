@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """End-to-end `dipper` CLI timing (FASTA -> Newick) on the GPU box: python profiles/e2e_cli.py [tips] [sites]"""
 import os, subprocess, sys, time
 sys.path.insert(0, ".")

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Exact placement mode timing: python profiles/exact_bench.py [tips] [sites] [mean branch length]"""
 import json, os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))

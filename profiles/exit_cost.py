@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """What does the END of a process cost that holds device memory?  python profiles/exit_cost.py
 child: hipMalloc + hipMemset of X GB in k buffers, hipDeviceSynchronize, os._exit(0); parent: wall of the child minus the child's own clock."""
 import ctypes, os, subprocess, sys, time

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """One-off cross-check at scale: k-closest placement of n unaligned tips with the inverted-index kernel and with the bucket-table
 kernel (round 1) must give the same trace (winning edge, split position, pendant length of every tip) -- i.e. every distance the
 placement read was the same double.  python profiles/mash_kernels_agree.py [n] [mean branch]"""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Mash pair-distance kernel alone: sketches of n unaligned reads (seeded indels, tests/_util.synth_reads) and the
 whole lower triangle through mash_dist_lookup_kernel (few launches: safe under rocprofv3 --pmc).
 usage: python profiles/mash_pairs.py [n] [L] [mean_bl] [identical]"""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """NJ hot path at a large size on one GPU: python profiles/nj_big.py [tips] [sites] [runs]
 (same generator and branch-length scale as bench.py's sharded leg: mean 2e-5 substitutions per site at 10 000 sites)"""
 import os, sys, time, json

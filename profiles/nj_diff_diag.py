@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """pruned vs streaming NJ on one input: where do the merge logs differ?  python profiles/nj_diff_diag.py [tips sites mean_bl]"""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Per-kernel averages (HIP events around every stride-th iteration, eager) of the first `iters` iterations of the pruned NJ:
 python profiles/nj_kt.py [tips] [sites] [iters] [stride]   (rocprofv3 is not needed; DPR_NJP_POST2=0/1 selects the post kernel)"""
 import json, os, subprocess, sys, tempfile, time

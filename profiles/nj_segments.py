@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """NJ loop time per segment of a run (graph replay): python profiles/nj_segments.py [tips] [sites] [segment]"""
 import json, os, subprocess, sys, tempfile
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """ONE parameterised target for everything that profiles the NJ loop (replaces the one-off scripts of earlier rounds):
 
   python3 profiles/nj_target.py [--tips 30000] [--sites 10000] [--seed 1] [--iters -1] [--reps 1] [--mode pruned|stream]
@@ -7,7 +6,9 @@
 Generates the alignment with tools/bin/gen_synth (the bench's input for seed 1), builds the JC69 matrix and runs the NJ loop
 `reps` times; prints one JSON line per repetition: nj_ms, microseconds per iteration, units listed, digest of the merge log.
 --phases: DPR_NJ_PHASES stamps of that iteration (eager launches of it), summarised per kernel and role.
-Put it directly behind `rocprofv3 ... --` (no shell in between)."""
+Run it as `rocprofv3 ... -- python3 /abs/path/profiles/nj_target.py ...` -- the interpreter itself behind `--` (no shell,
+no `env`, no shebang hop: the profiler's preload has initialised the GPU by then, and an exec from such a process is refused on
+the GPU boxes); profiles/prof.sh does exactly that."""
 import argparse, hashlib, json, os, subprocess, sys, tempfile
 
 ROOT = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

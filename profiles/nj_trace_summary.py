@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace CSV of an NJ run: per kernel the distribution of the dispatch durations and of the
 gaps to the previous dispatch, overall and per block of 2 000 dispatches (= how an iteration's cost moves along the run).
 usage: python3 profiles/nj_trace_summary.py <dir or kernel_trace.csv> [out.json]"""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Worst-case table of the two single-GPU NJ algorithms (verdict r2 item 3): NJ time, units scanned and device memory at
 30 000 tips for alignments of growing divergence and for a uniform-random matrix, exact pruned scan vs full streaming scan.
   python profiles/nj_worstcase.py [tips] [sites] > gpurun_out/r3/nj_worstcase.jsonl

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Where do the units listed by an OLD epoch of the pruned NJ loop lie?  Runs the default plan up to iteration --stop (inside an
 epoch), fetches the list of the next scan and the row sums by position (dpr_get_njp_list), and prints
   * units per strip (512 columns) and per row group (16 rows): a few full strips / rows = an outlier row sum in that group;

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Per-iteration cost of the one-exchange row-sharded NJ loop with the ranks as PROCESSES on ONE GPU (mailbox plan: IPC
 windows, no RCCL -- it refuses two ranks on one device).  The ranks share the GPU's HBM, so the scan part of an iteration
 cannot get faster than the single-process streaming loop; what the figure shows is the OVERHEAD the exchange adds to it:

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Kernel times of the one-exchange row-sharded NJ loop with 8 VIRTUAL ranks on one GPU (run under rocprofv3 --kernel-trace
 --stats): every rank's SCAN streams 1/8 of the rows and its POST does the whole update, as on 8 GPUs -- except that the
 pulls of rows x / y stay in local HBM and the kernels of the 8 ranks run one after the other on one stream.

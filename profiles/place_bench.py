@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """k-closest placement from scratch (BASELINE configs[2] shape): python3 profiles/place_bench.py [tips] [sites] [kind m|r] [mean branch]
 Reads (kind r: Mash sketches) or an alignment (kind m) from tools/bin/gen_synth (bench.py's protocol: mean branch 2e-5 at 10 000 sites,
 scaled to the length); prints one JSON line: seconds, distance / tree part, batches and how many were produced beside the tree kernels."""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Phase clocks of place_update_kernel (DPR_PLACE_CLOCKS=1 overwrites the trace with wall_clock64 deltas, 10 ns units)."""
 import os, sys
 os.environ["DPR_PLACE_CLOCKS"] = "1"

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Which blocks end a launch of the fused post kernel?  DPR_NJ_PHASES stamps of one iteration (30 000 tips), per block:
 the 20 blocks that end last, with their role, strip, first row group and every stamp.  python3 profiles/post_tail_blocks.py [iteration]"""
 import os, sys, subprocess, tempfile, ctypes as C

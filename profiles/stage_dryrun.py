@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Dry run of bench.py's input staging for an 8-rank job on a box WITHOUT GPUs (verdict r2 item 1: "a dry run of the 8-rank
 input path on the CPU box (8 processes, no GPU calls) showing the wall time of input staging"): 8 processes joined by
 gloo build bench.Stage, rank 0 generates every input bench.py uses once (tools/bin/gen_synth), all ranks map them and

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """What delays the HIP start-up of a `dipper` run that starts right behind another process?  A predecessor process allocates and
 touches `gb` GB of device memory and leaves in one of several ways; the next process's `Device ready in:` line is read.
   python3 profiles/startup_after_teardown.py [gb 15] [repeats 6]

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Sweep the tuning knobs of the Q-argmin scan at n = N (run on the GPU box)."""
 import itertools
 import sys

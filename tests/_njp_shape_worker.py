@@ -116,6 +116,25 @@ def main():
         ok = all(np.array_equal(np.concatenate([q[key][:q["iters"]] for q in parts]), ref[key]) for key in ("merge_x", "merge_y", "bl_x", "bl_y")) \
             and parts[-1]["last_d"] == ref["last_d"]
         out.append({"kind": "unit-sharded x%d %s" % (world, kind), "n": n, "ok": bool(ok)})
+    # NaN / +inf distances that leave the run going (tests/_nonfinite.py) on the large shape: njp_post2_kernel takes its maxima
+    # from the previous launch and tracks the range of the entries (eabs = +inf here); epochs rebuilt along the way
+    from tests import _nonfinite
+    os.environ["DPR_NJ_EPOCH_MIN"] = "256"      # (read at every dpr_nj_run)
+    for name, D in _nonfinite.matrices(1500, 41):
+        d = dipper_amd.Dipper(0)
+        try:
+            d.set_nj_mode(1)
+            d.set_nj_adaptive(0)
+            try:
+                done, code = _nonfinite.check(d, orc, D, chunks=(400, 3, 10 ** 9), threads=8)
+                ok = done >= 1490
+            except AssertionError as e:
+                ok = False
+                sys.stderr.write("nonfinite %s: %s\n" % (name, e))
+        finally:
+            d.close()
+        out.append({"kind": "nonfinite " + name, "n": 1500, "ok": bool(ok)})
+    del os.environ["DPR_NJ_EPOCH_MIN"]
     # no Q candidate below 10000 from the first iteration on (tests/test_gpu_nj.py::test_nj_no_candidate): error -4, no hang
     for n in (8, 1500):
         D = np.full((n, n), -1.0e5)

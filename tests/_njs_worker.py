@@ -34,7 +34,9 @@ def main():
         d.set_matrix_full(D)
         d.dist_matrix(capi.SRC_MATRIX)
     info0 = d.nj_exchange_info()
-    if os.environ.get("DPR_NJS_FAULT"):
+    if os.environ.get("DPR_TEST_NJS_FAULT"):      # "iteration,rank": read HERE (the test's worker), handed to the context's debug setter
+        fi, fr = os.environ["DPR_TEST_NJS_FAULT"].split(",")
+        d.set_debug_fault(int(fi), int(fr))
         # tests of the cross-check: the run must END with DPR_ERR_COMM on every rank (the message names the row sums)
         try:
             d.nj_run()

@@ -34,6 +34,7 @@ class Oracle:
         L.orc_nj_run.argtypes = [c_f64p, C.c_int64, C.c_int64, C.c_int, C.c_int64, c_i32p, c_i32p,
                                  c_f64p, c_f64p, c_f64p, c_f64p]
         L.orc_nj_run.restype = C.c_int64
+        L.orc_nj_last_iterations.restype = C.c_int64
         L.orc_murmur3_x64_128.argtypes = [C.c_char_p, C.c_int, C.c_uint32, c_u64p]
         L.orc_kmer_hash.argtypes = [c_u64p, C.c_uint64, C.c_int]
         L.orc_kmer_hash.restype = C.c_uint64
@@ -125,7 +126,8 @@ class Oracle:
         it = self.lib.orc_nj_run(_p(D, c_f64p), N, ld, threads, max_iters, _p(mx, c_i32p),
                                  _p(my, c_i32p), _p(bx, c_f64p), _p(by, c_f64p), C.byref(last),
                                  _p(U, c_f64p))
-        return dict(iters=it, merge_x=mx, merge_y=my, bl_x=bx, bl_y=by, last_d=last.value, U=U, D=D)
+        # iters = -1: no candidate left (the reference's undefined (0,0) merge); `done` entries of the log are valid either way
+        return dict(iters=it, done=int(self.lib.orc_nj_last_iterations()), merge_x=mx, merge_y=my, bl_x=bx, bl_y=by, last_d=last.value, U=U, D=D)
 
     # ---- Mash -------------------------------------------------------------------------------
     def murmur(self, data: bytes, seed: int):

@@ -56,11 +56,11 @@ def test_process_ranks_on_one_gpu_match_oracle(tmp_path, orc, world, n):
 
 @pytest.mark.timeout(600)
 def test_process_ranks_detect_a_corrupted_pull(tmp_path):
-    """DPR_NJS_FAULT=40,1: rank 1 of 3 corrupts one element of a row it pulled at iteration 40.  Its replicated row sums
+    """dpr_ctx_set_debug_fault(40, 1) (through the worker's DPR_TEST_NJS_FAULT=40,1): rank 1 of 3 corrupts one element of a row it pulled at iteration 40.  Its replicated row sums
     then differ from the other ranks'; every rank's record carries the bits of the row sum it derived (NjsRec::ux), so
     POST(41) sees the difference on EVERY rank and all three runs end with DPR_ERR_COMM (-5) instead of three merge logs
     of which one is silently wrong."""
-    res = _run_ranks(tmp_path, 3, 400, 7, extra_env={"DPR_NJS_FAULT": "40,1"})
+    res = _run_ranks(tmp_path, 3, 400, 7, extra_env={"DPR_TEST_NJS_FAULT": "40,1"})
     for got in res:
         v = str(got["verdict"])
         assert v.startswith("code -5") and "row sums differ after 41 iterations" in v, v

@@ -27,7 +27,9 @@ pytestmark = [pytest.mark.gpu,
 _OVERRIDES = ("DPR_NJ_EPOCH_MIN", "DPR_NJ_EPOCH_PCT", "DPR_NJP_GRID", "DPR_NJ_STREAM_FRAC", "DPR_NJ_ADAPTIVE",
               "DPR_NJ_GRAPH_ITERS", "DPR_NJ_BIG_P", "DPR_NJ_MODE", "DPR_NJP_POST2", "DPR_NJP_FLAGS", "DPR_NJ_NOGRAPH",
               "DPR_PLACE_BATCH", "DPR_PLACE_NO_OVERLAP", "DPR_PLACE_MULTI_MIN", "DPR_PLACE_SINGLE", "DPR_PLACE_MULTI_BIG",
-              "DPR_MASH_INDEX", "DPR_MASH_LOOKUP", "DPR_MASH_SIMPLE", "DPR_DC_BUDGET_MB", "DPR_EXACT_LITERAL")
+              "DPR_MASH_INDEX", "DPR_MASH_LOOKUP", "DPR_MASH_SIMPLE", "DPR_DC_BUDGET_MB", "DPR_EXACT_LITERAL",
+              "DPR_NJS_FAULT", "DPR_NJ_EXCHANGE", "DPR_NJP_SMALL", "DPR_NJ_TG_SMALL", "DPR_PLACE_OVERLAP_ALWAYS", "DPR_NJ_BIG_NS",
+              "DPR_NJP_PERMUTE_CHUNKS", "DPR_NJ_MULTI")
 
 
 @pytest.fixture(autouse=True)
@@ -117,6 +119,64 @@ def test_nj_10k_default_plans_equal_oracle(orc, kind, tmp_path):
         # the bounds prune: far fewer units than n - 2 full scans, and the run never left the pruned loop
         assert stream_iters == 0, seen
         assert 0 < scanned < 0.5 * per_full * (n - 2) / 3, seen
+
+
+@pytest.mark.parametrize("case", [0, 2], ids=["nan_pair", "nan_and_inf"])
+def test_nj_3k_nonfinite_default_plans_equal_oracle(orc, case):
+    """NaN / +inf distances (tests/_nonfinite.py) at 3 000 tips with no overrides: the pruned path crosses its natural epoch
+    boundaries (3 000 -> 2 400 -> 1 920 positions) with live rows whose row sums are NaN / +inf; both plans follow the oracle
+    to the same end (src/neighborJoining.cu:117-148,161-194; src/MSA.cu:233-235 is where such distances come from)."""
+    import dipper_amd
+    from tests import _nonfinite
+    n = 3000
+    name, D = _nonfinite.matrices(n, 51)[case]
+    for mode in (1, 0):
+        d = dipper_amd.Dipper(0)
+        try:
+            d.set_nj_mode(mode)
+            done, code = _nonfinite.check(d, orc, D, threads=_host_threads())
+            assert done >= n - 10 and code == -4, (name, mode, done, code)
+        finally:
+            d.close()
+
+
+@pytest.mark.timeout(900)
+def test_nj_48k_large_shape_pruned_equals_streaming_and_oracle_prefix(orc, tmp_path):
+    """48 000 tips x 1 000 sites, no overrides: above the 40 000-position switch the pruned path runs its LARGE launch shape
+    (njp_post2_kernel<4>: 256 row groups x 4 strips per test block, maxima of the previous launch; 512-block unit scan) until
+    the epochs have shrunk below it -- the shape the 100 000-tip runs use and that every other -m gpu test only reaches through
+    DPR_NJ_BIG_P.  The whole merge log equals the streaming loop's (the reference's algorithm, src/neighborJoining.cu:117-148,
+    161-194: sum 4 n^2 = 1.5e14 bytes, ~30 s), and the first 40 iterations equal the oracle's on the GPU's own matrix."""
+    import dipper_amd
+    from dipper_amd import capi
+    n, L = 48000, 1000
+    inp = _util.gen_synth(tmp_path, "n48k", n, L, 48, 2e-3, 2e-4, 2e-2, extra=("--model", "gtr+g+i", "--indel-gaps"))
+    packed = np.ascontiguousarray(inp["packed4"])
+    res, ref = {}, None
+    for mode in (1, 0):
+        d = dipper_amd.Dipper(0)
+        try:
+            d.set_nj_mode(mode)
+            d.set_msa(packed, L)
+            d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+            if mode == 1:
+                shape = d.njp_shape()
+                assert shape["positions"] == n and shape["post2"] and shape["row_groups"] == 256 and shape["strips"] == 4 and shape["scan_grid"] == 512, shape
+                M = d.matrix()
+                ref = orc.nj_run(np.tril(M, -1), threads=_host_threads(), max_iters=40)
+                del M
+            res[mode] = d.nj_run()
+            if mode == 1:
+                assert d.nj_adaptive_stats() == (0, 0)          # the run never left the pruned loop
+                scanned, per_full = d.prune_stats()
+                assert 0 < scanned < 0.5 * per_full * (n - 2) / 3, (scanned, per_full)
+        finally:
+            d.close()
+    assert ref["iters"] == 40
+    for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
+        assert np.array_equal(res[1][key][:40], ref[key][:40]), key
+    _same_log(res[1], res[0], "48 000 tips: pruned (large shape) vs streaming")
+    assert res[1]["iters"] == n - 2
 
 
 def _same_place_state(a, b, n):

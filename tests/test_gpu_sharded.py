@@ -90,18 +90,18 @@ def test_virtual_ranks_interrupted_runs_and_ties(orc, plan):
 
 @pytest.mark.parametrize("plan", ["peer", "mailbox"])
 def test_virtual_ranks_detect_a_corrupted_pull(monkeypatch, plan):
-    """the cross-check of the one-exchange plans (NjsRec::ux, njs.hip): DPR_NJS_FAULT=25,2 makes virtual rank 2 of 4 use a
+    """the cross-check of the one-exchange plans (NjsRec::ux, njs.hip): dpr_ctx_set_debug_fault(25, 2) makes virtual rank 2 of 4 use a
     wrong value for one element of a pulled row at iteration 25; the ranks' replicated row sums differ from then on and the
     run ends with DPR_ERR_COMM at iteration 26 -- while the same run without the fault completes."""
     import dipper_amd
     from dipper_amd import capi
     D = _util.random_additive_matrix(np.random.default_rng(3), 300, zero_frac=0.2)
-    for fault in (None, "25,2"):
-        if fault:
-            monkeypatch.setenv("DPR_NJS_FAULT", fault)
+    for fault in (None, (25, 2)):
         d = dipper_amd.Dipper(0, virtual_world=4)
         try:
             d.set_nj_exchange(PLANS[plan])
+            if fault:
+                d.set_debug_fault(*fault)
             d.set_matrix_full(D)
             d.dist_matrix(capi.SRC_MATRIX)
             if fault is None:
