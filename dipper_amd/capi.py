@@ -459,7 +459,7 @@ class Dipper:
         """per-kernel averages of the last timed NJ run (set_nj_kernel_timing): launch order, microseconds"""
         nk = C.c_int()
         ns = C.c_int64()
-        us = np.zeros(4, np.float64)
+        us = np.zeros(8, np.float64)
         _chk(self.L, self.L.dpr_get_nj_kernel_timing(self.h, C.byref(nk), _p(us, c_f64p), C.byref(ns)))
         names = [(self.L.dpr_nj_kernel_name(i) or b"").decode() for i in range(nk.value)]
         rec = {"kernels_per_iteration": sum(1 for nm in names if not nm.startswith("(")), "sampled_iterations": int(ns.value),

@@ -80,6 +80,7 @@ struct dpr_ctx {
     int have_matrix = 0;
     bool nj_replicated = false;      // several ranks, each holding the whole matrix (pruned NJ)
     bool nj_unit_sharded = false;    // ... and sharing the unit tests / scans of an iteration (else: every rank runs the single-GPU plan)
+    bool nj_row_pruned = false;      // several ranks, rows sharded, exact pruned NJ (njr.hip)
     double dist_ms = 0, nj_ms = 0;
     double place_dist_ms = 0;        // distance rows of the last placement run (the rest of nj_ms is tree work)
     std::vector<hipEvent_t> place_ev;   // event pairs whose sum is the reported distance part of the current placement run
@@ -111,14 +112,15 @@ static int g_nj_mode = -1;
 static int g_nj_vshards = 1;   // > 1: a single-rank context emulates that many unit-sharded ranks (validation)
 // Several ranks, pruned NJ: 0 = auto (unit-sharded scans from kNjShardTips tips on, below that every rank runs the
 // single-GPU plan on its own copy: an iteration is then ~20 us of dependent latency and a collective per iteration
-// would only add to it), 1 = always unit-sharded, 2 = never (dpr_set_nj_multi_plan / DPR_NJ_MULTI=auto|shard|solo)
+// would only add to it; ROW-SHARDED pruned -- njr.hip -- once two copies of the matrix no longer fit one GPU), 1 = always
+// unit-sharded, 2 = never, 3 = row-sharded pruned (dpr_set_nj_multi_plan / DPR_NJ_MULTI=auto|shard|solo|rows)
 static int g_nj_multi_plan = -1;
 constexpr int64_t kNjShardTips = 65536;
 static int nj_multi_plan()
 {
     if (g_nj_multi_plan < 0) {
         const char* e = std::getenv("DPR_NJ_MULTI");
-        g_nj_multi_plan = (e && std::strcmp(e, "shard") == 0) ? 1 : (e && std::strcmp(e, "solo") == 0) ? 2 : 0;
+        g_nj_multi_plan = (e && std::strcmp(e, "shard") == 0) ? 1 : (e && std::strcmp(e, "solo") == 0) ? 2 : (e && std::strcmp(e, "rows") == 0) ? 3 : 0;
     }
     return g_nj_multi_plan;
 }
@@ -158,6 +160,55 @@ static int ctx_exchange_plan(const dpr_ctx* c)
 }
 static int ctx_multi_plan(const dpr_ctx* c) { return c->nj_multi_plan >= 0 ? c->nj_multi_plan : nj_multi_plan(); }
 static int ctx_vshards(const dpr_ctx* c) { return c->nj_vshards >= 1 ? c->nj_vshards : g_nj_vshards; }
+
+// Row-sharded exact pruned NJ (njr.hip): asked for (plan 3; the only way for a context of virtual ranks), or -- real ranks,
+// plan auto -- when the two epoch buffers of the replicated plans (2 x 8 n^2 bytes) no longer fit this device
+static bool ctx_njr(const dpr_ctx* c, int64_t n)
+{
+    if (c->world < 2 || n < 3 || !want_pruned(c)) return false;
+    const int plan = ctx_multi_plan(c);
+    if (plan == 3) return true;
+    if (plan != 0 || c->vworld > 0) return false;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return 2.0 * 8.0 * (double)n * (double)n > 0.85 * (double)total_b;
+}
+// matrix rows per epoch buffer of a rank under that plan: the same on every rank (the peers compute each other's second half)
+static int64_t njr_twin_rows(int64_t n, int world)
+{
+    const int64_t nblk = (n + kRowBlock - 1) / kRowBlock;
+    const int64_t tip_rows = ((nblk + world - 1) / world) * kRowBlock + 32, pos_rows = njr_rows_cap(n, world);
+    return tip_rows > pos_rows ? tip_rows : pos_rows;
+}
+static std::vector<NjBuffers*> njr_ranks(dpr_ctx* c)
+{
+    std::vector<NjBuffers*> v;
+    for (auto& b : c->nj) v.push_back(&b);
+    return v;
+}
+// collective plan: kind 0 = every rank's header + unit records (in place in partials), kind 1 = its column slices (rows_plain)
+static int njr_gather_cb(void* ctx, int kind, hipStream_t s)
+{
+    dpr_ctx* c = static_cast<dpr_ctx*>(ctx);
+    NjBuffers& b0 = c->nj[0];
+    const int world = c->world;
+    const int ugrid = b0.pr.scan_grid / world > 0 ? b0.pr.scan_grid / world : 1;
+    const size_t seg = kind == 0 ? sizeof(NjRecord) * (size_t)(ugrid + 1) : sizeof(double) * 2 * (size_t)b0.rs.lay.slice;
+    if (c->vworld > 0) {
+        for (int r = 0; r < c->vworld; ++r)
+            for (int t = 0; t < c->vworld; ++t) {
+                if (t == r) continue;
+                char* src = kind == 0 ? reinterpret_cast<char*>(c->nj[(size_t)r].partials) : reinterpret_cast<char*>(c->nj[(size_t)r].rs.rows_plain);
+                char* dst = kind == 0 ? reinterpret_cast<char*>(c->nj[(size_t)t].partials) : reinterpret_cast<char*>(c->nj[(size_t)t].rs.rows_plain);
+                DPR_HIP(hipMemcpyAsync(dst + (size_t)r * seg, src + (size_t)r * seg, seg, hipMemcpyDeviceToDevice, s));
+            }
+        return DPR_OK;
+    }
+    if (!c->comm) { set_error("njr: the collective plan needs an RCCL communicator"); return DPR_ERR_COMM; }
+    char* buf = kind == 0 ? reinterpret_cast<char*>(b0.partials) : reinterpret_cast<char*>(b0.rs.rows_plain);
+    if (g_rccl.AllGather(buf + (size_t)c->rank * seg, buf, seg, 1 /* ncclUint8 */, c->comm, s) != 0) { set_error("ncclAllGather (row-sharded pruned NJ) failed"); return DPR_ERR_COMM; }
+    return DPR_OK;
+}
 
 // ---- exchange step of the sharded path: RCCL all-gather, or device copies between virtual ranks --
 enum ExKind { EX_RECS, EX_SLICES, EX_U, EX_RECS64 /* rank records of the one-exchange loop (NjsRec) */ };
@@ -291,9 +342,12 @@ static int rccl_gather_bytes(dpr_ctx* c, const void* mine, void* all, size_t byt
 // on EVERY rank (no fine-grained window, IPC handles refused, a mapping fails) falls back to the legacy loop on all
 // ranks together -- the decision is taken on gathered flags, so the ranks cannot disagree -- and says why in
 // nj_exchange_note.  Ranks joined without RCCL (dpr_comm_init_local) have nothing to fall back to: error.
-static int njs_setup(dpr_ctx* c)
+// force_windows (row-sharded pruned NJ): windows and peer mappings are needed whatever the streaming loop's plan is -- the
+// epoch builds pull rows from the peers' buffers, the mailbox plan exchanges through the windows
+static int njs_setup(dpr_ctx* c, bool force_windows = false)
 {
-    const int plan = ctx_exchange_plan(c);
+    int plan = ctx_exchange_plan(c);
+    if (force_windows && plan == kNjsLegacy) plan = (c->comm && c->vworld == 0) ? kNjsPeer : kNjsMailbox;
     c->nj_exchange_active = kNjsLegacy;
     c->nj_exchange_note.clear();
     c->njs_pending = false;
@@ -374,6 +428,16 @@ static int njs_barrier(dpr_ctx* c)
     if (c->vworld > 0 || c->world == 1) return DPR_OK;       // one stream: already ordered
     if (c->comm) return exchange(c, EX_RECS);                // (the gathered records are dead between iterations)
     return njs_launch_barrier(c->nj[0], c->stream);
+}
+
+// row-sharded pruned NJ, ranks joined by RCCL: all ranks in step with idle streams (epoch builds)
+static int njr_barrier_cb(void* ctx)
+{
+    dpr_ctx* c = static_cast<dpr_ctx*>(ctx);
+    DPR_HIP(hipStreamSynchronize(c->stream));
+    if (int rc = exchange(c, EX_RECS)) return rc;
+    DPR_HIP(hipStreamSynchronize(c->stream));
+    return DPR_OK;
 }
 
 static NjBuffers* owner_buffers(dpr_ctx* c, int64_t row)
@@ -619,7 +683,7 @@ int dpr_peer_export(dpr_ctx* c, int64_t n_tips, void* out192)
     DPR_HIP(hipSetDevice(c->device));
     c->have_matrix = 0;
     NjBuffers& b = c->nj[0];
-    if (int rc = nj_alloc(b, n_tips, c->rank, c->world, c->stream)) return rc;
+    if (int rc = nj_alloc(b, n_tips, c->rank, c->world, c->stream, ctx_njr(c, n_tips) ? njr_twin_rows(n_tips, c->world) : 0)) return rc;
     b.peer.plan = kNjsMailbox;
     if (int rc = njs_alloc_window(b, c->stream)) return rc;
     --b.peer.run_id;          // (dpr_dist_matrix's own njs_alloc_window call counts the run)
@@ -831,13 +895,19 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
     // Several real ranks + pruned NJ: every rank builds and keeps the WHOLE matrix (7.2 GB at 30 000 tips, 80 GB at
     // 100 000) and the ranks share the per-iteration unit tests and scans (njp.hip, unit-sharded mode).  The
     // streaming algorithm (DPR_NJ_MODE=stream) keeps the row-sharded layout.
-    const bool repl = c->world > 1 && c->vworld == 0 && want_pruned(c) && n >= 3;
+    const bool njr = ctx_njr(c, n);
+    const bool repl = !njr && c->world > 1 && c->vworld == 0 && want_pruned(c) && n >= 3;
     c->nj_replicated = repl;
+    c->nj_row_pruned = false;
     for (size_t r = 0; r < c->nj.size(); ++r)
-        if (int rc = nj_alloc(c->nj[r], n, repl ? 0 : (c->vworld > 0 ? (int)r : c->rank), repl ? 1 : c->world, c->stream)) return rc;
+        if (int rc = nj_alloc(c->nj[r], n, repl ? 0 : (c->vworld > 0 ? (int)r : c->rank), repl ? 1 : c->world, c->stream, njr ? njr_twin_rows(n, c->world) : 0)) return rc;
     const bool row_sharded = c->world > 1 && !repl;
-    if (row_sharded) { if (int rc = njs_setup(c)) return rc; }
+    if (row_sharded) { if (int rc = njs_setup(c, njr)) return rc; }
     else c->nj_exchange_active = kNjsLegacy;
+    if (njr && c->nj_exchange_active == kNjsLegacy) {
+        set_error("dpr_dist_matrix: the row-sharded pruned NJ needs the peers' buffers mapped on every rank (" + c->nj_exchange_note + "); use DPR_NJ_MODE=stream");
+        return DPR_ERR_STATE;
+    }
     const bool peer_plan = row_sharded && c->nj_exchange_active != kNjsLegacy;
     DPR_HIP(hipEventRecord(c->ev[0], c->stream));
     for (auto& b : c->nj) {
@@ -867,6 +937,25 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
     }
     for (auto& b : c->nj)
         if (int rc = nj_prepare(b, c->stream)) return rc;
+    if (njr) {
+        // exchange plan of the loop: -1 / 0 = default (collective -- all-gathers -- with RCCL and between virtual ranks; mailbox for
+        // ranks joined without RCCL), 1 = collective, 2 = mailbox
+        int rplan = c->nj_exchange == 2 ? kNjrMailbox : c->nj_exchange == 1 ? kNjrCollective : (c->local_comm ? kNjrMailbox : kNjrCollective);
+        if (c->nj_exchange < 0 && !c->local_comm)
+            if (const char* e = std::getenv("DPR_NJ_EXCHANGE")) rplan = std::strcmp(e, "mailbox") == 0 ? kNjrMailbox : kNjrCollective;
+        if (rplan == kNjrCollective && c->vworld == 0 && !c->comm) { set_error("dpr_dist_matrix: the collective plan of the row-sharded pruned NJ needs RCCL ranks"); return DPR_ERR_STATE; }
+        for (size_t r = 0; r < c->nj.size(); ++r) {
+            NjBuffers& b = c->nj[r];
+            b.rs.world = c->world; b.rs.rank = c->vworld > 0 ? (int)r : c->rank; b.rs.plan = rplan;
+            b.rs.win_off = b.peer.lay.off_njr;
+            b.rs.gather = njr_gather_cb; b.rs.cb_ctx = c;
+            b.rs.barrier = (c->vworld == 0 && c->comm) ? njr_barrier_cb : nullptr;
+            b.rs.launches = 0; b.rs.collectives = 0;
+        }
+        std::vector<NjBuffers*> ranks = njr_ranks(c);
+        if (int rc = njr_build(ranks, c->stream)) return rc;
+        c->nj_row_pruned = true;
+    }
     if ((c->world == 1 || repl) && want_pruned(c) && n >= 3) {
         NjPruned& q = c->nj[0].pr;
         const int plan = ctx_multi_plan(c);
@@ -975,14 +1064,19 @@ int64_t dpr_nj_run(dpr_ctx* c, int64_t max_iters, int32_t* merge_x, int32_t* mer
     if (c->nj_kt.stride > 0 && it0 == 0) { c->nj_kt.samples = 0; for (double& v : c->nj_kt.us_sum) v = 0; }
     c->nj_launches = 0; c->nj_collectives = 0;
     DPR_HIP(hipEventRecord(c->ev[2], c->stream));
-    if (c->nj[0].pr.active) {
+    if (c->nj_row_pruned) {
+        std::vector<NjBuffers*> ranks = njr_ranks(c);
+        c->nj[0].rs.launches = 0; c->nj[0].rs.collectives = 0;
+        if (int rc = njr_run(ranks, it0, todo, c->stream)) return rc;
+        c->nj_launches = c->nj[0].rs.launches; c->nj_collectives = c->nj[0].rs.collectives;
+    } else if (c->nj[0].pr.active) {
         if (int rc = njp_run(c->nj[0], it0, todo, c->stream)) return rc;
     } else {
         for (int64_t k = 0; k < todo; ++k)
             if (int rc = nj_iteration(c, st.n - k, it0 + k)) return rc;
     }
     DPR_HIP(hipEventRecord(c->ev[3], c->stream));       // (the loop itself: the barrier + flush below are once per run)
-    const bool peer_plan = c->world > 1 && !c->nj_replicated && c->nj_exchange_active != kNjsLegacy;
+    const bool peer_plan = c->world > 1 && !c->nj_replicated && !c->nj_row_pruned && c->nj_exchange_active != kNjsLegacy;
     if (peer_plan) {
         // every rank must be through its pulls of the last iteration before an owner flushes the last row buffers
         if (int rc = njs_barrier(c)) return rc;
@@ -1043,7 +1137,16 @@ int64_t dpr_nj_run(dpr_ctx* c, int64_t max_iters, int32_t* merge_x, int32_t* mer
     if (last_d && st.n == 2) {
         // D[0][1] of the final pair (src/neighborJoining.cu:245-249); row 1 lives on rank 0
         NjBuffers& b0 = c->nj[0];
-        if (b0.pr.in_positions()) {
+        if (c->nj_row_pruned) {
+            // the row of slot 1 lives on its position's owner: read through the mapping of that rank's epoch buffer (every
+            // rank's finish kernel has run: the stream was synchronised by fetch_state; process ranks: the owner's flush is
+            // behind its own finish kernel, ordered by the barrier below)
+            int32_t pos01[2];
+            DPR_HIP(hipMemcpy(pos01, b0.pr.pos_of_slot, sizeof(pos01), hipMemcpyDeviceToHost));
+            if (c->vworld == 0 && b0.rs.barrier) { if (int rc = b0.rs.barrier(b0.rs.cb_ctx)) return rc; }
+            const int half = (b0.pr.epoch_index + 1) & 1, o = njr_owner(pos01[1], c->world);
+            DPR_HIP(hipMemcpy(last_d, b0.rs.peer_half[half][(size_t)o] + njr_local_row(pos01[1], c->world) * b0.pr.ld + pos01[0], sizeof(double), hipMemcpyDeviceToHost));
+        } else if (b0.pr.in_positions()) {
             int32_t pos01[2];
             DPR_HIP(hipMemcpy(pos01, b0.pr.pos_of_slot, sizeof(pos01), hipMemcpyDeviceToHost));
             DPR_HIP(hipMemcpy(last_d, b0.pr.D + (int64_t)pos01[1] * b0.pr.ld + pos01[0], sizeof(double), hipMemcpyDeviceToHost));
@@ -1115,7 +1218,7 @@ int dpr_set_nj_virtual_shards(int w)
 
 int dpr_set_nj_multi_plan(int plan)
 {
-    if (plan < 0 || plan > 2) { set_error("dpr_set_nj_multi_plan: 0 auto, 1 unit-sharded, 2 single-GPU plan on every rank"); return DPR_ERR_ARG; }
+    if (plan < 0 || plan > 3) { set_error("dpr_set_nj_multi_plan: 0 auto, 1 unit-sharded, 2 single-GPU plan on every rank, 3 row-sharded pruned"); return DPR_ERR_ARG; }
     g_nj_multi_plan = plan;
     return DPR_OK;
 }
@@ -1131,7 +1234,7 @@ int dpr_ctx_set_nj_mode(dpr_ctx* c, int mode)
 }
 int dpr_ctx_set_nj_multi_plan(dpr_ctx* c, int plan)
 {
-    if (!c || plan < -1 || plan > 2) { set_error("dpr_ctx_set_nj_multi_plan: -1 default, 0 auto, 1 unit-sharded, 2 single-GPU plan on every rank"); return DPR_ERR_ARG; }
+    if (!c || plan < -1 || plan > 3) { set_error("dpr_ctx_set_nj_multi_plan: -1 default, 0 auto, 1 unit-sharded, 2 single-GPU plan on every rank, 3 row-sharded pruned"); return DPR_ERR_ARG; }
     c->nj_multi_plan = plan;
     return DPR_OK;
 }
@@ -1405,8 +1508,14 @@ int dpr_get_matrix_row(dpr_ctx* c, int64_t i, double* out)
         std::vector<int32_t> pos((size_t)N);
         std::vector<double> row((size_t)q.P);
         DPR_HIP(hipMemcpy(pos.data(), q.pos_of_slot, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
-        if (pos[(size_t)i] >= 0 && pos[(size_t)i] < q.P)
-            DPR_HIP(hipMemcpy(row.data(), q.D + (int64_t)pos[(size_t)i] * q.ld, sizeof(double) * (size_t)q.P, hipMemcpyDeviceToHost));
+        if (pos[(size_t)i] >= 0 && pos[(size_t)i] < q.P) {
+            const double* src = q.D + (int64_t)pos[(size_t)i] * q.ld;
+            if (c->nj_row_pruned) {      // rows sharded: the owner's epoch buffer as mapped here
+                const NjRowShard& rs = c->nj[0].rs;
+                src = rs.peer_half[(q.epoch_index + 1) & 1][(size_t)njr_owner(pos[(size_t)i], c->world)] + njr_local_row(pos[(size_t)i], c->world) * q.ld;
+            }
+            DPR_HIP(hipMemcpy(row.data(), src, sizeof(double) * (size_t)q.P, hipMemcpyDeviceToHost));
+        }
         if (pos[(size_t)i] < 0 || pos[(size_t)i] >= q.P) {      // slot not alive any more
             for (int64_t j = 0; j < N; ++j) out[j] = __builtin_inf();
             return DPR_OK;

@@ -153,12 +153,12 @@ struct NjPruned {
 
 // optional per-kernel timing of the pruned NJ loop (dpr_ctx_set_nj_kernel_timing): the run is enqueued eagerly and every
 // stride-th iteration's launches are bracketed by HIP events on the library's stream
-constexpr int kNjKernelsMax = 4;
+constexpr int kNjKernelsMax = 6;
 struct NjKernelTiming {
     int stride = 0;                    // 0 = off
     int nk = 0;                        // kernels per iteration of the last timed run
     std::vector<hipEvent_t> ev;        // (nk + 1) events per sampled iteration
-    double us_sum[kNjKernelsMax] = { 0, 0, 0, 0 };
+    double us_sum[kNjKernelsMax] = { 0, 0, 0, 0, 0, 0 };
     int64_t samples = 0;
 };
 
@@ -190,6 +190,7 @@ struct alignas(64) NjsRec {
 // layout of a rank's peer-visible window (byte offsets): mail[2][kNjsMaxWorld] records (NjsRec) | barrier lines | slice | 4 row buffers
 struct NjsLayout {
     int64_t off_bar = 0, off_slice = 0, off_rows = 0, bytes = 0;
+    int64_t off_njr = 0;     // region of the row-sharded pruned NJ (njr.hip), 0 = none
     int64_t slice_len = 0;   // doubles (initial row sums of the own rows)
     int64_t ldv = 0;         // doubles per row buffer
 };
@@ -201,6 +202,7 @@ struct NjPeer {
     char** d_win = nullptr;          // device arrays [kNjsMaxWorld]: every rank's window / matrix as mapped into THIS process
     double** d_D = nullptr;
     std::vector<double*> h_D;        // host copy of d_D
+    std::vector<char*> h_win;        // host copy of d_win
     std::vector<void*> opened;       // hipIpc mappings to close
     bool attached = false;
     unsigned long long bar_epoch = 0;
@@ -209,10 +211,57 @@ struct NjPeer {
     int64_t fault_it = -1; int fault_rank = -1;      // test hook (dpr_ctx_set_debug_fault)
 };
 
+// ---- row-sharded pruned NJ (njr.hip): the position-space matrix of njp.hip with its rows dealt to the ranks ------------
+// Chunk k of kNjrChunk positions (64 row groups: the rows of one test block of njp_post_kernel<64, 1>) belongs to rank
+// k % world; a rank stores its chunks one behind the other at full width.  Units, their bounds, lists and scans belong to
+// the owner of their rows.
+constexpr int kNjrChunk = 1024;
+constexpr int kNjrCollective = 1;        // block records and column slices travel by all-gathers (RCCL; device copies between virtual ranks)
+constexpr int kNjrMailbox = 2;           // ... by stores straight into every rank's window: no collective
+__host__ __device__ inline int njr_owner(int64_t p, int world) { return (int)((p / kNjrChunk) % world); }
+__host__ __device__ inline int64_t njr_local_row(int64_t p, int world) { return (p / kNjrChunk / world) * kNjrChunk + p % kNjrChunk; }
+__host__ __device__ inline int64_t njr_global_pos(int64_t l, int rank, int world) { return ((l / kNjrChunk) * world + rank) * kNjrChunk + l % kNjrChunk; }
+// matrix rows a rank must be able to hold for P positions (whole chunks)
+__host__ __device__ inline int64_t njr_rows_cap(int64_t P, int world)
+{
+    const int64_t chunks = (P + kNjrChunk - 1) / kNjrChunk;
+    return ((chunks + world - 1) / world) * kNjrChunk;
+}
+// doubles per exchanged column slice: local rows of positions < N + 2 chunks (the kernels read vectors up to 511 positions
+// behind P and an even index behind the last position)
+__host__ __device__ inline int64_t njr_slice_len(int64_t N, int world) { return ((N / kNjrChunk + 2 + world - 1) / world) * kNjrChunk; }
+// the njr region of a rank's peer-visible window (offsets relative to the region's start)
+struct NjrLayout {
+    int64_t off_recflag = 0, off_recs = 0, off_rowflag = 0, off_rows = 0, bytes = 0;
+    int64_t rec_stride = 0;     // records per (parity, source rank): unit-scan blocks per rank + 1 header record
+    int64_t slice = 0;          // doubles per column slice
+};
+struct NjRowShard {
+    int world = 1, rank = 0, plan = 0;     // world > 1: active
+    NjrLayout lay;
+    int64_t win_off = 0;                   // start of the njr region inside the window (NjPeer::win)
+    double* rows_plain = nullptr;          // collective plan: [world][2][slice] all-gather buffer (mailbox plan: the window's region)
+    double* stage = nullptr;               // epoch builds: source rows pulled from their owners, [stage_rows][stage_ld]
+    int64_t stage_rows = 0, stage_ld = 0;
+    char** d_region = nullptr;             // device array [world]: the njr regions of all ranks' windows
+    double** d_src = nullptr;              // device array [world]: source buffers of the epoch build in progress
+    unsigned int* ticket = nullptr;        // last-block tickets of SCAN and EXTRACT (2 x kNjsTicketBytes)
+    double* half[2] = { nullptr, nullptr };   // the two epoch buffers of this rank (halves of NjBuffers::D)
+    std::vector<double*> peer_half[2];     // ... of every rank, as mapped into this process (epoch builds pull from them)
+    int (*gather)(void* ctx, int kind, hipStream_t s) = nullptr;   // collective plan: kind 0 = block records (in place, b.partials), 1 = column slices (in place, rows_plain)
+    int (*barrier)(void* ctx) = nullptr;   // all ranks' streams idle and in step (epoch builds)
+    void* cb_ctx = nullptr;
+    int64_t launches = 0, collectives = 0;
+};
+
 struct NjBuffers {
     NjPeer peer;
     NjKernelTiming* kt = nullptr;   // owned by the context
     double* D = nullptr;       // [rows_local_max][ld] (+ tail pad)
+    // row-sharded pruned NJ: D is ONE allocation of two halves of twin_rows rows each (the epochs of njr.hip alternate between
+    // them; one hipIpc handle covers both); D points at the first half, which also receives the tip-order rows
+    int64_t twin_rows = 0;
+    size_t half_bytes = 0;
     int64_t ld = 0;
     int64_t N = 0;             // total tips
     int64_t rows_local = 0;    // local rows at n = N
@@ -233,10 +282,11 @@ struct NjBuffers {
     double* log_by = nullptr;
     int rank = 0, world = 1;
     NjPruned pr;
+    NjRowShard rs;
 };
 
 // nj.hip
-int nj_alloc(NjBuffers& b, int64_t N, int rank, int world, hipStream_t s);   // fills ordered on s; same shape again: buffers kept
+int nj_alloc(NjBuffers& b, int64_t N, int rank, int world, hipStream_t s, int64_t twin_rows = 0);   // fills ordered on s; same shape again: buffers kept
 int nj_fill_pads(double* D, int64_t ld, int64_t nrows, int64_t ncols, int64_t rows_alloc, int64_t tail, bool diag, hipStream_t s);
 void nj_free(NjBuffers& b);
 int nj_expand_lower(NjBuffers& b, const double* d_packed_lower, hipStream_t s);
@@ -255,7 +305,7 @@ int nj_launch_unpack_u(NjBuffers& b, hipStream_t s);                            
 int nj_launch_finish(NjBuffers& b, int64_t n, int64_t it, hipStream_t s);           // materialise U[x] after the loop
 
 // njs.hip: one-exchange row-sharded loop (world > 1)
-NjsLayout njs_layout(int64_t N, int world);
+NjsLayout njs_layout(int64_t N, int world, bool with_njr = false);
 int njs_alloc_window(NjBuffers& b, hipStream_t s);
 void njs_free_window(NjBuffers& b);
 int njs_set_peers(NjBuffers& b, char* const* wins, double* const* Ds, hipStream_t s);
@@ -265,6 +315,13 @@ int njs_launch_finish(NjBuffers& b, int64_t n, int64_t it, bool pending, hipStre
 int njs_launch_barrier(NjBuffers& b, hipStream_t s);
 int njs_launch_unpack_u(NjBuffers& b, hipStream_t s);
 
+// njr.hip: row-sharded exact pruned NJ (world > 1; NjRowShard)
+NjrLayout njr_layout(int64_t N, int world);
+int njr_build(std::vector<NjBuffers*>& ranks, hipStream_t s);      // the ranks held by this process (all of them: virtual ranks; one: a process rank)
+int njr_run(std::vector<NjBuffers*>& ranks, int64_t it0, int64_t todo, hipStream_t s);
+void njr_free(NjBuffers& b);
+int njr_debug_matrix_row(std::vector<NjBuffers*>& ranks, int64_t slot, double* d_out, hipStream_t s);   // test hook: row of a live slot in slot order
+
 // njp.hip: exact pruned NJ (world == 1)
 int njp_build(NjBuffers& b, hipStream_t s);   // permute the tip-order matrix by ascending row sum into the pruned path's own buffer
 void njp_free(NjPruned& q);                   // everything, the arena included
@@ -272,7 +329,8 @@ int njp_reserve(NjPruned& q, int64_t N, hipStream_t s);   // allocate the arena 
 void njp_reset(NjPruned& q);                  // epoch state only (graph, pointers); the arena stays for the next build
 int njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world);
 int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s);   // enqueue `todo` iterations (hipGraph replays)
-const char* njp_kernel_name(int idx);   // kernels of one iteration, in launch order
+const char* njp_kernel_name(int idx);   // intervals of one timed iteration of the LAST timed run, in launch order
+void njp_set_kernel_names(const char* const* names);     // (up to kNjKernelsMax, "" terminated; names in () are not kernels)
 int njp_phase_stamps(unsigned long long* out);   // debug (DPR_NJ_PHASES)
 int njp_debug_list(NjBuffers& b, int32_t* out, int64_t cap, int64_t* count, int64_t* P, double* ur, int64_t urcap);   // debug
 const double* njp_current_u(const NjPruned& q, int64_t it);

@@ -446,27 +446,32 @@ int nj_fill_pads(double* D, int64_t ld, int64_t nrows, int64_t ncols, int64_t ro
 // A context that builds a matrix of the same shape again (bench.py's steps, a second dpr_dist_matrix) keeps every
 // buffer: freeing and re-allocating 2 x 7.2 GB per call at 30 000 tips cost more than the distance kernel itself.
 // Only the pads are zeroed then -- every element of the n x n block is overwritten by the distance kernels.
-static int nj_alloc_inner(NjBuffers& b, int64_t N, int rank, int world, hipStream_t s);
-int nj_alloc(NjBuffers& b, int64_t N, int rank, int world, hipStream_t s)
+static int nj_alloc_inner(NjBuffers& b, int64_t N, int rank, int world, hipStream_t s, int64_t twin_rows);
+int nj_alloc(NjBuffers& b, int64_t N, int rank, int world, hipStream_t s, int64_t twin_rows)
 {
     // a failure part-way (out of memory after the matrix) must not leave a half-built NjBuffers behind: the reuse test
     // of the next call looks at b.D only (dpr_reserve_nj is called best-effort by the CLI, its return code ignored)
-    const int rc = nj_alloc_inner(b, N, rank, world, s);
+    const int rc = nj_alloc_inner(b, N, rank, world, s, twin_rows);
     if (rc != DPR_OK) nj_free(b);
     return rc;
 }
-static int nj_alloc_inner(NjBuffers& b, int64_t N, int rank, int world, hipStream_t s)
+static int nj_alloc_inner(NjBuffers& b, int64_t N, int rank, int world, hipStream_t s, int64_t twin_rows)
 {
-    const bool reuse = b.D != nullptr && b.N == N && b.rank == rank && b.world == world;
+    const bool reuse = b.D != nullptr && b.N == N && b.rank == rank && b.world == world && b.twin_rows == twin_rows;
     if (!reuse) {
         nj_free(b);
         b.N = N; b.rank = rank; b.world = world;
         b.ld = round_up(N, 16);
         b.rows_local = shard_rows(N, rank, world);
+        b.twin_rows = twin_rows;
     }
     // (+32 rows: the pruned path reuses this buffer for its odd epochs, whose row groups end up to 31 rows behind N)
-    const int64_t rows_alloc = round_up(b.rows_local > 0 ? b.rows_local : 1, kRowBlock) + 32;
-    const size_t dbytes = (size_t)(rows_alloc * b.ld + kTileCols + 16) * sizeof(double);
+    int64_t rows_alloc = round_up(b.rows_local > 0 ? b.rows_local : 1, kRowBlock) + 32;
+    if (twin_rows > rows_alloc) rows_alloc = twin_rows;
+    // (twin: two halves of this size in ONE allocation, njr.hip)
+    const size_t hbytes = ((size_t)(rows_alloc * b.ld + kTileCols + 16) * sizeof(double) + 4095) / 4096 * 4096;
+    const size_t dbytes = twin_rows > 0 ? 2 * hbytes : hbytes;
+    b.half_bytes = hbytes;
     const size_t vec = (size_t)(N + kTileCols + 16);
     const int64_t nblk = (N + kRowBlock - 1) / kRowBlock;
     if (!reuse) {
@@ -496,6 +501,7 @@ static int nj_alloc_inner(NjBuffers& b, int64_t N, int rank, int world, hipStrea
         DPR_HIP(hipMalloc(&b.log_by, sizeof(double) * (size_t)(N + 1)));
     } else {
         njp_reset(b.pr);       // the pruned path's arena stays, its epoch state goes
+        njr_free(b);           // (the row-sharded pruned path's epoch state; its window region and buffers stay with b.peer / b.D)
         // the rows [0, rows_local) x [0, N) are rewritten by the producers; zero what they leave alone
         if (int rc = nj_fill_pads(b.D, b.ld, b.rows_local, N, rows_alloc, kTileCols + 16, world == 1, s)) return rc;
     }
@@ -512,6 +518,7 @@ static int nj_alloc_inner(NjBuffers& b, int64_t N, int rank, int world, hipStrea
 
 void nj_free(NjBuffers& b)
 {
+    njr_free(b);
     njp_free(b.pr);
     njs_free_window(b);
     void* ptrs[] = { b.D, b.U, b.Ur, b.KA, b.partials, b.recs, b.recs64, b.xpart, b.gath, b.slice, b.st,
@@ -521,6 +528,7 @@ void nj_free(NjBuffers& b)
     const NjPeer keep = b.peer;      // (the plan and the poll limit are settings of the context, not of an allocation)
     b = NjBuffers();
     b.peer.plan = keep.plan; b.peer.poll_ticks = keep.poll_ticks;
+    b.peer.fault_it = keep.fault_it; b.peer.fault_rank = keep.fault_rank;      // (dpr_ctx_set_debug_fault: a setting of the context too)
 }
 
 int nj_expand_lower(NjBuffers& b, const double* d_packed_lower, hipStream_t s)

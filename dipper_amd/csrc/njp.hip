@@ -29,7 +29,7 @@
 //             writes the new node's row to a buffer instead of over row x.
 // The kernels take no per-iteration arguments (they read the iteration index from the device state), so 32
 // iterations are captured into one hipGraph and replayed.
-#include "nj_dev.hpp"
+#include "njp_args.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -40,7 +40,6 @@
 
 namespace dpr {
 
-constexpr int kUR = 16;  // rows per unit
 // Row groups (= units of one strip) per test block of the post kernel: 64 below 40 000 positions (1024 row positions per
 // block: the row phase of a block is short, NJ 500 -> 482 ms at 30 000 tips), 256 above (fewer blocks, less repeated
 // column and record work where the kernel is throughput-bound).  The switch: 38 000-50 000 positions measured within
@@ -107,33 +106,6 @@ __host__ __device__ inline int64_t njp_strips_of_rows(int64_t g0, int64_t tg, in
     int64_t c = glast / 32 + 1;                       // strips with 32 c <= glast
     const int64_t cp = (P - 2) / 512 + 1;             // strips with 512 c < P - 1
     return P >= 2 ? (c < cp ? c : cp) : 0;
-}
-
-__device__ __forceinline__ uint64_t enc_f64(double x)
-{
-    const uint64_t b = (uint64_t)__double_as_longlong(x);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double dec_f64(uint64_t k)
-{
-    const uint64_t b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
-    return __longlong_as_double((long long)b);
-}
-static uint64_t enc_f64_host(double x)
-{
-    union { double d; uint64_t u; } c;
-    c.d = x;
-    return (c.u >> 63) ? ~c.u : (c.u | 0x8000000000000000ull);
-}
-
-// valid units: strip cb holds groups g >= 32*cb (row a = 16g.. can see column 512cb iff a > 512cb)
-__host__ __device__ inline int64_t unit_prefix(int64_t cb, int64_t G16) { return cb * G16 - 16 * cb * (cb - 1); }
-__host__ __device__ inline int64_t unit_total(int64_t P)
-{
-    const int64_t G16 = (P + kUR - 1) / kUR;
-    int64_t S = (P - 1 + kTileCols - 1) / kTileCols;       // strips with at least one valid column
-    while (S > 0 && G16 - 32 * (S - 1) <= 0) --S;
-    return S > 0 ? unit_prefix(S, G16) : 0;
 }
 
 // Unit ownership of the unit-sharded mode (also exported for the CPU tests of the N > 1 logic).  Units are tested in
@@ -259,57 +231,6 @@ __global__ void njp_fill_u64_kernel(uint64_t* __restrict__ a, int64_t cnt, uint6
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x) a[i] = v;
 }
 
-// Latency is what matters in the kernels of the loop (a few hundred KB of data per iteration): every kernel issues
-// all of its global loads in as few dependent hops as possible.
-
-// arguments shared by the kernels of the loop (by value: one kernarg block)
-struct NjpArgs {
-    double* D; int64_t ld; NjState* st;
-    double* U; double* R; int64_t vstride;      // U, R: [2][vstride]
-    double* Ur; uint64_t* KA; uint64_t* KB; int32_t* slot_of_pos; int32_t* pos_of_slot;
-    double* xpart; NjRecord* partials; unsigned long long* umin;
-    int64_t P;
-    const int32_t* blk_cb; const int32_t* blk_g0; int ntest;     // test blocks: (first strip, first group), up to 256 groups each
-    int tg, ns;                                                  // ... of tg row groups x up to ns strips
-    int nupd;                                                    // update blocks of this post launch
-    int32_t* list; unsigned long long* cnt;     // the list of THIS launch's rank and its counters cnt[0..2]
-    int ugrid;        // unit-scan blocks per rank
-    int urecs;        // unit records in partials (ugrid x ranks); the new-row records follow them
-    int nrb;          // new-row blocks = ceil(P / 512)
-    int rec_off;      // first unit record of this launch's rank
-    int all_defined;  // unit-sharded mode: every unit record is written by every scan
-    int sh_rank, sh_world;
-    unsigned long long* cnt_all; int cnt_ranks;     // all local counter quadruples (the update role zeroes the next ones)
-    int do_update, do_tests, do_rows;
-    int32_t* log_x; int32_t* log_y; double* log_bx; double* log_by;
-    unsigned long long* iterstats;
-    int flags;        // experiments (DPR_NJP_FLAGS): 1 = column of the new node stored with plain stores instead of write-through (sc1)
-    unsigned long long* dbg; int64_t dbg_it;     // DPR_NJ_PHASES=<iteration>: per-block phase stamps of that iteration (profiles/nj_phases.py)
-    // njp_post2_kernel (large shape): what its producer blocks hand to its test blocks
-    void* t2_hdr; double* t2_rmax; double* t2_cmax; double* t2_colmin; double* t2_rowmin; double* t2_cmin;
-};
-
-// phase stamps (debug; 100 MHz wall clock): thread 0 of every block, kernel k (0 scan, 1 post), slot j
-#define NJP_STAMP(k, j, drain)                                                                             \
-    do {                                                                                                   \
-        if (a.dbg != nullptr && it == a.dbg_it && threadIdx.x == 0) {                                      \
-            if (drain) __builtin_amdgcn_s_waitcnt(0);                                                      \
-            a.dbg[((k) * 2048 + (int)blockIdx.x) * 8 + (j)] = wall_clock64();                              \
-        }                                                                                                  \
-    } while (0)
-
-// the reference's update arithmetic (src/neighborJoining.cu:171-176), one place for the update role and for the
-// test role that needs the same row sums before they are stored
-__device__ __forceinline__ double nj_val(double dxi, double dyi, double d) { return (dxi + dyi - d) * 0.5; }
-__device__ __forceinline__ double nj_unew(double up, double dxi, double dyi, double val) { return up + (-dxi - dyi + val); }
-
-__device__ __forceinline__ void best_update4(double& bq, uint64_t& bk, uint64_t& bp, double& bd, double q, uint64_t k,
-                                             uint64_t pp, double d)
-{
-    const bool take = (q < bq) | ((q == bq) & (k < bk));
-    bq = take ? q : bq; bk = take ? k : bk; bp = take ? pp : bp; bd = take ? d : bd;
-}
-
 // ------------------------------------------------------------------------------------------------
 // epoch start: every unit is listed with all four sub-units (the bounds start at -inf and there is no
 // seed, so no test could rule anything out); nothing is in quarantine
@@ -351,12 +272,17 @@ __global__ __launch_bounds__(kThreads) void njp_list_all_kernel(NjpArgs a)
 // ------------------------------------------------------------------------------------------------
 // The leading scalar parameters (NjpHead) repeat what the first round trip needs: with -mllvm -amdgpu-kernarg-preload-count
 // (Makefile) they arrive in SGPRs with the wave, so hop 1 leaves without waiting for the s_load of the argument block.
+// kRS (row-sharded mode, njr.hip): D holds this rank's chunks of rows (njp_lrow), only the owner of a position stores its row,
+// the first new-row block adds the rank's header record (the row sum it derived, for the cross-check of the replicated state),
+// and -- mailbox plan -- the last block of the launch to finish pushes the rank's records into every rank's window.
+template <bool kRS>
 __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjState* h_st, const int32_t* h_list, const unsigned long long* h_cnt,
                                                             const double* h_xpart, int h_nrl, NjpArgs a)
 {
     __shared__ double sq[kThreads / 64], sd[kThreads / 64];
     __shared__ uint64_t sk[kThreads / 64], sp[kThreads / 64];
     __shared__ double stree[kThreads];
+    __shared__ unsigned int s_last;
 
     const int tid = threadIdx.x;
     // hop 1: state line, all three list counters and (speculatively) this block's first list entry / chunk partial
@@ -396,6 +322,10 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjState* h_st, const
         rec_out = a.partials + a.urecs + r;
         if (pz < 0) {
             if (tid == 0) { NjRecord rec; rec.q = 10000.0; rec.key = ~0ull; rec.d = 0.0; rec.pad = 0ull; *rec_out = rec; }
+            if (kRS) {
+                if (r == 0 && tid == 0) njr_store_record(a.partials + a.rec_off - 1, 10000.0, ~0ull, it == a.rs_fault_it ? 1.0e-3 : 0.0, a.rs_seq_base + (unsigned long long)(it + 1));
+                njr_scan_publish(a, it, &s_last);
+            }
             return;
         }
         const int64_t n = N - it;
@@ -413,7 +343,9 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjState* h_st, const
         NJP_STAMP(0, 2, false);
         const double urx = ux / (double)(n - 2);
         if (r == 0 && tid == 0) a.U[(it & 1) * a.vstride + pz] = ux;
-        if (j0 < P) *reinterpret_cast<v2d*>(a.D + pz * a.ld + j0) = dv;        // (R[pz] = 0: the diagonal stays 0)
+        if (kRS && r == 0 && tid == 0)       // header record: this rank's view of the replicated state (inert for every reduction: key = ~0)
+            njr_store_record(a.partials + a.rec_off - 1, 10000.0, ~0ull, it == a.rs_fault_it ? ux * 0.5 + 1.0e-3 : ux, a.rs_seq_base + (unsigned long long)(it + 1));
+        if (j0 < P && njp_owns<kRS>(a, pz)) *reinterpret_cast<v2d*>(a.D + njp_lrow<kRS>(a, pz) * a.ld + j0) = dv;        // (R[pz] = 0: the diagonal stays 0)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const double d = k ? dv.y : dv.x, uj = k ? uv.y : uv.x;       // dead / padding / pz itself: NaN row sum -> NaN q
@@ -430,9 +362,10 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjState* h_st, const
         const int64_t cnt = (int64_t)(m3 == 0 ? cl0 : m3 == 1 ? cl1 : cl2);
         if ((int64_t)ub >= cnt) {
             if (a.all_defined && tid == 0) {      // unit-sharded mode: every record of the gathered array is defined
-                NjRecord rec; rec.q = 10000.0; rec.key = ~0ull; rec.d = 0.0; rec.pad = 0ull;
-                *rec_out = rec;
+                if (kRS) njr_store_record(rec_out, 10000.0, ~0ull, 0.0, 0ull);
+                else { NjRecord rec; rec.q = 10000.0; rec.key = ~0ull; rec.d = 0.0; rec.pad = 0ull; *rec_out = rec; }
             }
+            if (kRS) njr_scan_publish(a, it, &s_last);
             return;
         }
         const int64_t G16 = (P + kUR - 1) / kUR;
@@ -456,7 +389,7 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjState* h_st, const
             const ulonglong2 kav = *reinterpret_cast<const ulonglong2*>(a.KA + b0), kbv = *reinterpret_cast<const ulonglong2*>(a.KB + b0);
             const double ub0 = ubv.x, ub1 = ubv.y;
             const uint64_t ka0 = kav.x, ka1 = kav.y, kb0 = kbv.x, kb1 = kbv.y;
-            const v2d* basep = reinterpret_cast<const v2d*>(a.D + a0 * a.ld + c0) + tid;
+            const v2d* basep = reinterpret_cast<const v2d*>(a.D + njp_lrow<kRS>(a, a0) * a.ld + c0) + tid;
             const int64_t ld2 = a.ld >> 1;
             const bool diag = a0 < c0 + kTileCols;
             const bool live0 = ub0 == ub0, live1 = ub1 == ub1;   // dead columns carry NaN row sums
@@ -549,16 +482,21 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjState* h_st, const
     if (tid == 0) {
 #pragma unroll
         for (int w = 1; w < kThreads / 64; ++w) best_update4(bq, bk, bp, bd, sq[w], sk[w], sp[w], sd[w]);
-        NjRecord rec;
-        rec.q = bq; rec.key = bk; rec.d = bd; rec.pad = bp;   // pad = pos_i | pos_j << 32
-        *rec_out = rec;
+        if (kRS && unit_block) njr_store_record(rec_out, bq, bk, bd, bp);      // (read by the launch's last block, possibly on another XCD)
+        else {
+            NjRecord rec;
+            rec.q = bq; rec.key = bk; rec.d = bd; rec.pad = bp;   // pad = pos_i | pos_j << 32
+            *rec_out = rec;
+        }
     }
+    if (kRS) njr_scan_publish(a, it, &s_last);
     NJP_STAMP(0, 4, true);
 }
 
 // after the last enqueued iteration: what the next scan's new-row blocks would materialise (row sum of the node in
 // quarantine, its row in the matrix), so that hooks, epoch rebuilds and a resumed run find them in memory.  The node
 // stays in quarantine (Ur = NaN): the next scan repeats the two stores with the same values.
+template <bool kRS>
 __global__ __launch_bounds__(kThreads) void njp_finish_kernel(NjpArgs a)
 {
     __shared__ double stree[kThreads];
@@ -575,7 +513,7 @@ __global__ __launch_bounds__(kThreads) void njp_finish_kernel(NjpArgs a)
     const v2d dv = *reinterpret_cast<const v2d*>(Rz + j0);
     const double ux = block_tree256_lane0(acc, stree);
     if (blockIdx.x == 0 && tid == 0) a.U[(it & 1) * a.vstride + pz] = ux;
-    if (j0 < a.P) *reinterpret_cast<v2d*>(a.D + pz * a.ld + j0) = dv;
+    if (j0 < a.P && njp_owns<kRS>(a, pz)) *reinterpret_cast<v2d*>(a.D + njp_lrow<kRS>(a, pz) * a.ld + j0) = dv;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -596,7 +534,10 @@ __global__ __launch_bounds__(kThreads) void njp_finish_kernel(NjpArgs a)
 #ifndef DPR_NJP_BIG_WAVES
 #define DPR_NJP_BIG_WAVES 1
 #endif
-template <int kTG, int kNS>
+// kRS (row-sharded mode, njr.hip): rows x and y are not read from the matrix -- which holds this rank's chunks only -- but from
+// the columns px / py every rank extracted from its own rows and exchanged (a.rs_rows; the matrix is symmetric, bit for bit); the
+// new node's column is stored into own rows only; the test blocks are this rank's (blk_cb / blk_g0 list them).
+template <int kTG, int kNS, bool kRS>
 __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void njp_post_kernel(NjState* h_st, const NjRecord* h_partials, const unsigned long long* h_cnt, const int32_t* h_blk_cb,
                                                                                               const int32_t* h_blk_g0, const int32_t* h_pos_of_slot, int h_ntest, int h_nupd, NjpArgs a)
 {
@@ -737,8 +678,30 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
     const int64_t px = ki < kj ? pi : pj, py = ki < kj ? pj : pi;
     const int64_t n1 = n - 1;
     const double r1 = (double)(n1 - 2);
-    const double* __restrict__ rowx = a.D + px * a.ld;
-    const double* __restrict__ rowy = a.D + py * a.ld;
+    const double* __restrict__ rowx = kRS ? a.rs_rows : a.D + px * a.ld;
+    const double* __restrict__ rowy = kRS ? a.rs_rows + a.rs_slice : a.D + py * a.ld;
+    // entry of row x / row y at position p (pointer: also used for aligned pairs, p even)
+    auto RX = [&](int64_t pp_) -> const double* { return kRS ? rowx + njp_xoff(a, pp_) : rowx + pp_; };
+    auto RY = [&](int64_t pp_) -> const double* { return kRS ? rowy + njp_xoff(a, pp_) : rowy + pp_; };
+    if (kRS && a.rs_plan == kNjrMailbox) {
+        // the column slices of this iteration must have arrived from every rank (njr_extract_kernel sends them)
+        __shared__ int s_fail;
+        if (tid == 0) s_fail = 0;
+        __syncthreads();
+        if (tid < a.rs_world) {
+            const unsigned long long* f = njr_win_rowflag(a.rs_win[a.rs_rank], a.rs_lay, tid);
+            const unsigned long long want = a.rs_seq_base + (unsigned long long)(it + 1), t0 = wall_clock64();
+            while (njr_ld_sys(f) != want) {
+                if (wall_clock64() - t0 > a.rs_poll_ticks) { s_fail = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+        if (s_fail) {
+            if (!test_block && i == last) a.st->status = 3;
+            return;
+        }
+    }
 
     if (!test_block) {
         // ------------------------------------------------------------------------------ update role
@@ -766,7 +729,7 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
             }
             int64_t new_slot = i;
             if (i != x && i != y) {
-                const double dxi = rowx[p], dyi = rowy[p];
+                const double dxi = *RX(p), dyi = *RY(p);
                 val = nj_val(dxi, dyi, d);
                 const double u = nj_unew(up, dxi, dyi, val);   // i == last: "U[y] = U[last] + ..." of the reference's tail
                 Un[p] = u;
@@ -774,7 +737,8 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
                 Rw[p] = val;                   // row of the new node: into the matrix by the next scan's new-row blocks
                 // its column: 8 bytes into n different lines.  Stored write-through (sc1): as plain stores they leave n dirty
                 // 128-byte lines in L2 that the end-of-kernel write-back has to flush (NJ 515 -> 508 ms at 30 000 tips)
-                if (a.flags & 1) a.D[p * a.ld + px] = val;
+                if (kRS) { if (njp_owns<true>(a, p)) __hip_atomic_store(a.D + njp_lrow<true>(a, p) * a.ld + px, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                else if (a.flags & 1) a.D[p * a.ld + px] = val;
                 else __hip_atomic_store(a.D + p * a.ld + px, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (i == last) {           // relabel: the node of the last slot now lives in slot y
                     new_slot = y;
@@ -813,8 +777,8 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
     // winner-dependent part of a strip
     auto load_b = [&](int cb, ColData& c) {
         const int64_t pc0 = (int64_t)cb * kTileCols + 2 * tid;
-        c.dxc = *reinterpret_cast<const v2d*>(rowx + pc0);
-        c.dyc = *reinterpret_cast<const v2d*>(rowy + pc0);
+        c.dxc = *reinterpret_cast<const v2d*>(RX(pc0));
+        c.dyc = *reinterpret_cast<const v2d*>(RY(pc0));
         c.rzc.x = PINF; c.rzc.y = PINF;
         if (gz_here) c.rzc = *reinterpret_cast<const v2d*>(Rz + pc0);
     };
@@ -828,8 +792,8 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
     for (int c = 0; c < kRC; ++c) {
         const int64_t pp = rbase + c * kTileCols + 2 * tid;
         const int64_t po = pp < P ? pp : pclamp;
-        dxr[c] = *reinterpret_cast<const v2d*>(rowx + po);
-        dyr[c] = *reinterpret_cast<const v2d*>(rowy + po);
+        dxr[c] = *reinterpret_cast<const v2d*>(RX(po));
+        dyr[c] = *reinterpret_cast<const v2d*>(RY(po));
         if (kPreRz) {
             rzr[c].x = 0.0; rzr[c].y = 0.0;
             if (pz_block) rzr[c] = *reinterpret_cast<const v2d*>(Rz + po);
@@ -846,7 +810,7 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
         // the record carries D of the pair; the entry is unchanged by this merge unless one end is x or y
         if (ci < P && cj < P && ci != px && cj != px && ci != py && cj != py) {
             const double uia = Uc[ci], uib = Uc[cj];
-            const double xa = rowx[ci], ya = rowy[ci], xb = rowx[cj], yb = rowy[cj];
+            const double xa = *RX(ci), ya = *RY(ci), xb = *RX(cj), yb = *RY(cj);
             const double ua = nj_unew(uia, xa, ya, nj_val(xa, ya, d)) / r1;
             const double ub = nj_unew(uib, xb, yb, nj_val(xb, yb, d)) / r1;
             const double qk = fmin((cand.d - ua) - ub, (cand.d - ub) - ua);
@@ -1567,7 +1531,11 @@ int njp_reserve(NjPruned& q, int64_t N, hipStream_t s) { return njp_arena(q, N, 
 
 // point q at the position-space structures of an epoch with P positions (N = total tips: slot arrays) inside
 // matrix buffer `Dbuf` and slab `slab`, and initialise them (all fills ordered on s)
-static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, char* slab, hipStream_t s, const void* hdr_from = nullptr)
+// rs_world > 1 (row-sharded mode, njr.hip): Dbuf holds the chunks of rank rs_rank only (the caller has cleared it), and the
+// test blocks are this rank's -- one strip x 64 row groups ALIGNED to the ownership chunks (a strip's first block may start
+// up to 32 groups in front of the strip's first valid group: those lanes are masked by g >= 32 cb in the kernels)
+static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, char* slab, hipStream_t s, const void* hdr_from = nullptr,
+                           int rs_world = 1, int rs_rank = 0)
 {
     if (P >= (int64_t)kTileCols * 1024) { set_error("pruned NJ: the list encoding holds fewer than 524288 positions"); return DPR_ERR_ARG; }
     const int local_ranks = q.sh_world > 1 && q.sh_virtual ? q.sh_world : 1;
@@ -1577,7 +1545,8 @@ static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, char
     q.D = Dbuf;
     const int64_t rows_alloc = (P + kUR - 1) / kUR * kUR + kUR;
     // what the permute kernel does not write: columns [P, ld), the group of rows behind position P, the tail pad
-    if (int rc = nj_fill_pads(q.D, q.ld, P, P, rows_alloc, kTileCols + 16, false, s)) return rc;
+    if (rs_world <= 1)
+        if (int rc = nj_fill_pads(q.D, q.ld, P, P, rows_alloc, kTileCols + 16, false, s)) return rc;
     const size_t vec = (size_t)vec_len(N);
     q.vstride = (int64_t)vec;
     q.U = reinterpret_cast<double*>(slab + plan.U);
@@ -1617,6 +1586,14 @@ static int njp_alloc_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, char
     {
         // test blocks: one strip and up to 256 consecutive row groups each (groups >= 32*cb see the strip)
         std::vector<int32_t> hcb, hg0;
+        if (rs_world > 1) {
+            const int64_t G16r = (P + kUR - 1) / kUR, gpc = kNjrChunk / kUR;      // row groups per ownership chunk (64)
+            for (int64_t c = 0; 32 * c < G16r && c * kTileCols < P - 1; ++c)
+                for (int64_t g0 = (32 * c) / gpc * gpc; g0 < G16r; g0 += gpc)
+                    if (njr_owner(g0 * kUR, rs_world) == rs_rank) { hcb.push_back((int32_t)c); hg0.push_back((int32_t)g0); }
+            q.nprep = (int)hcb.size();
+            if (hcb.empty()) { hcb.push_back(0); hg0.push_back(0); }      // (a rank without units: nprep = 0, nothing is launched for it)
+        } else
         q.nprep = (int)prep_blocks(P, &hcb, &hg0);
         DPR_HIP(hipMemcpyAsync(q.blk_cb, hcb.data(), sizeof(int32_t) * hcb.size(), hipMemcpyHostToDevice, s));
         DPR_HIP(hipMemcpyAsync(q.blk_g0, hg0.data(), sizeof(int32_t) * hg0.size(), hipMemcpyHostToDevice, s));
@@ -1655,9 +1632,7 @@ int njp_build(NjBuffers& b, hipStream_t s)
         // 500 / 820 on average): with 256 blocks the diverged inputs took 574 / 663 ms, with 512 blocks 544 / 614 ms, the bench
         // input 479.5 vs 481.5 ms.  A grid that followed the watched rate (256 / 512 / 1 024, graph re-captured) was slower than
         // 512 throughout: 2.08 vs 2.05 s at 100 000 tips, 657 vs 614 ms on the x 25 input (profiles/r4/scan_grid_*.txt).
-        const char* e = std::getenv("DPR_NJP_GRID");
-        const int g = e ? std::atoi(e) : 512;
-        b.pr.scan_grid = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+        b.pr.scan_grid = njp_scan_grid_default();
     }
     if (const char* e = std::getenv("DPR_NJ_ADAPTIVE")) b.pr.adaptive = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("DPR_NJ_STREAM_FRAC")) b.pr.stream_frac = std::atof(e);
@@ -1904,7 +1879,7 @@ static int njp_launch_scan(NjBuffers& b, hipStream_t s, int v, bool rows)
 {
     NjpArgs a = njp_args(b, v);
     a.do_rows = rows ? 1 : 0;
-    hipLaunchKernelGGL(njp_scan_kernel, dim3((unsigned)(a.ugrid + (rows ? a.nrb : 0))), dim3(kThreads), 0, s, a.st, (const int32_t*)a.list,
+    hipLaunchKernelGGL((njp_scan_kernel<false>), dim3((unsigned)(a.ugrid + (rows ? a.nrb : 0))), dim3(kThreads), 0, s, a.st, (const int32_t*)a.list,
                        (const unsigned long long*)a.cnt, (const double*)a.xpart, rows ? a.nrb : 0, a);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
@@ -1934,14 +1909,78 @@ static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
         DPR_HIP(hipGetLastError());
         return DPR_OK;
     }
-    if (a.tg == 64) hipLaunchKernelGGL((njp_post_kernel<64, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
-    else if (a.tg == 32) hipLaunchKernelGGL((njp_post_kernel<32, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
-    else if (a.tg == 128) hipLaunchKernelGGL((njp_post_kernel<128, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
-    else if (a.ns == 1) hipLaunchKernelGGL((njp_post_kernel<256, 1>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
-    else if (a.ns == 2) hipLaunchKernelGGL((njp_post_kernel<256, 2>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
-    else hipLaunchKernelGGL((njp_post_kernel<256, kBigNS>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
+    if (a.tg == 64) hipLaunchKernelGGL((njp_post_kernel<64, 1, false>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
+    else if (a.tg == 32) hipLaunchKernelGGL((njp_post_kernel<32, 1, false>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
+    else if (a.tg == 128) hipLaunchKernelGGL((njp_post_kernel<128, 1, false>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
+    else if (a.ns == 1) hipLaunchKernelGGL((njp_post_kernel<256, 1, false>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
+    else if (a.ns == 2) hipLaunchKernelGGL((njp_post_kernel<256, 2, false>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
+    else hipLaunchKernelGGL((njp_post_kernel<256, kBigNS, false>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
+}
+
+// ---- the row-sharded instantiations (njr.hip builds the arguments and owns the loop) ----------------------------------
+int njp_rs_launch_list_all(const NjpArgs& a, hipStream_t s)
+{
+    if (a.ntest > 0) hipLaunchKernelGGL(njp_list_all_kernel, dim3((unsigned)a.ntest), dim3(kThreads), 0, s, a);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+int njp_rs_launch_scan(const NjpArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL((njp_scan_kernel<true>), dim3((unsigned)(a.ugrid + a.nrb)), dim3(kThreads), 0, s, a.st, (const int32_t*)a.list,
+                       (const unsigned long long*)a.cnt, (const double*)a.xpart, a.nrb, a);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+int njp_rs_launch_post(const NjpArgs& a0, int64_t N, hipStream_t s)
+{
+    NjpArgs a = a0;
+    const unsigned ublocks = (unsigned)((N + kThreads - 1) / kThreads);
+    a.nupd = (int)ublocks;
+    hipLaunchKernelGGL((njp_post_kernel<64, 1, true>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials,
+                       (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+int njp_rs_launch_finish(const NjpArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL((njp_finish_kernel<true>), dim3((unsigned)a.nrb), dim3(kThreads), 0, s, a);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+// epoch e of a row-sharded run on this rank: slabs allocated on first use (the arena of the single-GPU path without its matrix
+// buffer), the epoch's structures inside slab e & 1, matrix rows in Dbuf (one half of NjBuffers::D)
+int njp_rs_epoch(NjPruned& q, int64_t P, int64_t N, double* Dbuf, int epoch_index, int rs_rank, int rs_world, const void* hdr_from, hipStream_t s)
+{
+    const SlabPlan plan = slab_plan(N, N, 1);
+    if (!q.arena_slab[0] || q.arena_N != N || q.arena_slab_bytes < plan.total) {
+        for (int k = 0; k < 2; ++k) { if (q.arena_slab[k]) (void)hipFree(q.arena_slab[k]); q.arena_slab[k] = nullptr; }
+        for (int k = 0; k < 2; ++k) DPR_HIP(hipMalloc(&q.arena_slab[k], plan.total));
+        q.arena_slab_bytes = plan.total; q.arena_N = N; q.arena_ranks = 1;
+    }
+    if (q.graph) { (void)hipGraphExecDestroy(q.graph); q.graph = nullptr; }
+    q.sh_world = 1; q.sh_rank = 0; q.sh_virtual = false;
+    q.epoch_index = epoch_index;
+    if (int rc = njp_alloc_epoch(q, P, N, Dbuf, q.arena_slab[epoch_index & 1], s, hdr_from, rs_world, rs_rank)) return rc;
+    q.active = true;
+    return DPR_OK;
+}
+// vectors of a new epoch from the previous one's (or from the tip-order row sums: slot_src = nullptr), as njp_build / njp_rebuild_epoch do
+int njp_rs_init_vectors(NjPruned& q, const double* U_src, const int32_t* slot_src, int64_t P, int64_t n, int64_t it, hipStream_t s)
+{
+    hipLaunchKernelGGL(njp_init_vectors_kernel, dim3((unsigned)((P + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                       U_src, (const int32_t*)q.perm, slot_src, P, n, q.U + (it & 1) * q.vstride, q.Ur, q.KA, q.KB, q.slot_of_pos, q.pos_of_slot);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+void njp_rs_sort_by_row_sum(std::vector<int32_t>& perm, const std::vector<double>& hU) { sort_by_row_sum(perm, hU); }
+int64_t njp_vec_len(int64_t N) { return vec_len(N); }
+int njp_scan_grid_default()
+{
+    const char* e = std::getenv("DPR_NJP_GRID");
+    const int g = e ? std::atoi(e) : 512;
+    return g < 1 ? 1 : (g > 1024 ? 1024 : g);
 }
 
 // one iteration: SCAN -> POST; every kernel reads its iteration index from the device state.
@@ -1958,7 +1997,7 @@ static int njp_enqueue_iteration(NjBuffers& b, hipStream_t s, bool sample = fals
             DPR_HIP(hipEventRecord(e, s));
             return DPR_OK;
         };
-        if (sample) b.kt->nk = 3;      // the third interval holds nothing: what an event pair itself costs
+        if (sample) { b.kt->nk = 3; njp_set_kernel_names(nullptr); }      // the third interval holds nothing: what an event pair itself costs
         if (int rc = mark()) return rc;
         if (int rc = njp_launch_scan(b, s, 0, true)) return rc;
         if (int rc = mark()) return rc;
@@ -2041,16 +2080,21 @@ static int njp_run_segment(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t 
         if (int rc = njp_enqueue_iteration(b, s, timing && (it0 + done) % b.kt->stride == 0)) return rc;
     {
         NjpArgs a = njp_args(b, v0);
-        hipLaunchKernelGGL(njp_finish_kernel, dim3((unsigned)a.nrb), dim3(kThreads), 0, s, a);
+        hipLaunchKernelGGL((njp_finish_kernel<false>), dim3((unsigned)a.nrb), dim3(kThreads), 0, s, a);
         DPR_HIP(hipGetLastError());
     }
     return DPR_OK;
 }
 
+static const char* const kNjpKernelNames[] = { "njp_scan_kernel", "njp_post_kernel", "(empty event pair)", "" };
+static const char* const* g_kernel_names = kNjpKernelNames;
+void njp_set_kernel_names(const char* const* names) { g_kernel_names = names ? names : kNjpKernelNames; }
 const char* njp_kernel_name(int idx)
 {
-    static const char* names[] = { "njp_scan_kernel", "njp_post_kernel", "(empty event pair)" };
-    return idx >= 0 && idx < 3 ? names[idx] : "";
+    if (idx < 0 || idx >= kNjKernelsMax) return "";
+    for (int k = 0; k <= idx; ++k)
+        if (g_kernel_names[k][0] == 0) return "";
+    return g_kernel_names[idx];
 }
 
 // debug: the unit list the next scan would walk (codes: sub-unit mask << 28 | strip << 18 | row group) and the row sums by position

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(kThreads) void njs_unpack_u_kernel(NjsArgs a, int64
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-NjsLayout njs_layout(int64_t N, int world)
+NjsLayout njs_layout(int64_t N, int world, bool with_njr)
 {
     NjsLayout l;
     const int64_t nblk = (N + kRowBlock - 1) / kRowBlock;
@@ -471,6 +471,10 @@ NjsLayout njs_layout(int64_t N, int world)
     l.off_slice = l.off_bar + 64 * kNjsMaxWorld;                              // bar: one 64-byte line per rank
     l.off_rows = (l.off_slice + (int64_t)sizeof(double) * l.slice_len + 255) / 256 * 256;
     l.bytes = l.off_rows + (int64_t)sizeof(double) * 4 * l.ldv;
+    if (with_njr) {        // the region of the row-sharded pruned NJ behind the streaming loop's (njr.hip)
+        l.off_njr = (l.bytes + 4095) / 4096 * 4096;
+        l.bytes = l.off_njr + njr_layout(N, world).bytes;
+    }
     return l;
 }
 
@@ -545,7 +549,7 @@ int njs_launch_unpack_u(NjBuffers& b, hipStream_t s)
 int njs_alloc_window(NjBuffers& b, hipStream_t s)
 {
     NjPeer& p = b.peer;
-    const NjsLayout lay = njs_layout(b.N, b.world);
+    const NjsLayout lay = njs_layout(b.N, b.world, b.twin_rows > 0);
     // (p.fault_it / p.fault_rank -- the test hook of the cross-check -- are set by dpr_ctx_set_debug_fault only: no environment
     //  variable can make a production run corrupt a pulled element)
     if (p.win && p.lay.bytes == lay.bytes) {
@@ -597,6 +601,7 @@ int njs_set_peers(NjBuffers& b, char* const* wins, double* const* Ds, hipStream_
     DPR_HIP(hipMemcpyAsync(p.d_D, Ds, sizeof(double*) * (size_t)b.world, hipMemcpyHostToDevice, s));
     DPR_HIP(hipStreamSynchronize(s));      // the host arrays may be temporaries
     p.h_D.assign(Ds, Ds + b.world);
+    p.h_win.assign(wins, wins + b.world);
     p.attached = true;
     return DPR_OK;
 }
