@@ -406,6 +406,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the untimed self-check of the timed result")
     ap.add_argument("--no-sharded", action="store_true", help="several GPUs: skip the 100 000-tip sub-record")
     ap.add_argument("--no-stream-leg", action="store_true", help="skip the row-sharded streaming-NJ sub-record (nj_scaling)")
+    ap.add_argument("--no-virtual-pruned", action="store_true", help="skip the row-sharded pruned NJ with 8 virtual ranks on one GPU (nj_scaling.row_sharded_pruned_virtual)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="one GPU: skip the single runs of the other BASELINE sizes (NJ at 100 000 tips, placement of 100 000 unaligned tips, "
                          "divide-and-conquer of 1 000 000 tips)")
@@ -791,11 +792,11 @@ def main():
         # =====================================================================================================
         log(f"[bench r{rank}] +{elapsed():.0f}s: nj_scaling")
         if not args.probe_only and not args.no_stream_leg:
-            need = 25 + 12 * (len(args.exchanges.split(",")) if world > 1 else 0)
+            need = 25 + (0 if args.no_virtual_pruned else 45) + (12 * len(args.exchanges.split(",")) + 40 if world > 1 else 0)
             if budget.allows_all(need):
                 try:
                     out["nj_scaling"] = nj_scaling(args, rank, world, local_rank, dist, torch, barrier, packed, n, L, args.stream_iters,
-                                                   hot.get("nj_iterations_per_s"), budget)
+                                                   hot.get("nj_iterations_per_s"), budget, merge_digest(last_res) if last_res is not None else None)
                 except Exception as e:
                     out["nj_scaling"] = {"error": repr(e)}
             else:
@@ -1018,6 +1019,7 @@ def other_configs(args, local_rank, stage, budget, tmp):
 
 
 PLAN_ID = {"legacy": 0, "peer": 1, "mailbox": 2}
+PRUNED_PLAN_ID = {"collective": 1, "mailbox": 2}      # exchange plans of the row-sharded pruned NJ (njr.hip)
 
 # DPR_BENCH_ONE_GPU=1: rehearsal of the N > 1 control flow with N PROCESSES ON ONE GPU (a single-GPU box is all the builder
 # has): torch.distributed over gloo, every rank on device 0, the library's ranks joined WITHOUT RCCL (dpr_comm_init_local +
@@ -1074,6 +1076,19 @@ def with_scaling_summary(out, world):
                                          "launches_per_iteration": r.get("launches_per_iteration"), "collectives_per_iteration": r.get("collectives_per_iteration")}
         else:
             comp["row_sharded"][plan] = {k: r[k] for k in ("skipped", "error") if k in r}
+    comp["row_sharded_pruned"] = {}
+    for plan, r in (njs.get("row_sharded_pruned") or {}).items():
+        if isinstance(r, dict):
+            comp["row_sharded_pruned"][plan] = ({"its_per_s": r.get("nj_iterations_per_s"), "ranks": r.get("ranks"), "rccl": r.get("rccl"),
+                                                 "matches_single_gpu": r.get("matches_single_gpu"), "speedup_vs_streaming_one_gpu": r.get("iteration_speedup_vs_streaming_one_gpu"),
+                                                 "speedup_vs_default_plan_one_gpu": r.get("iteration_speedup_vs_default_plan_one_gpu"),
+                                                 "launches_per_iteration": r.get("launches_per_iteration"), "collectives_per_iteration": r.get("collectives_per_iteration")}
+                                                if "nj_iterations_per_s" in r else {k: r[k] for k in ("skipped", "error") if k in r})
+    v = njs.get("row_sharded_pruned_virtual")
+    if isinstance(v, dict):
+        comp["row_sharded_pruned_8_virtual_ranks_one_gpu"] = {plan: ({"per_rank_iteration_us": r.get("per_rank_iteration_us"), "per_rank_kernel_us": r.get("per_rank_kernel_us"),
+                                                                      "matches_single_gpu": r.get("matches_single_gpu")} if isinstance(r, dict) and "per_rank_iteration_us" in r else r)
+                                                              for plan, r in v.items() if plan in ("mailbox", "collective")}
     new = {}
     for k, v in out.items():
         new[k] = v
@@ -1134,8 +1149,13 @@ def njs_worker():
         rank, world, n, L, iters = cfg["rank"], cfg["world"], cfg["tips"], cfg["sites"], cfg["iters"]
         packed = np.memmap(cfg["p4"], dtype=np.uint64, mode="r", shape=(n, (L + 15) // 16))
         d = dipper_amd.Dipper(cfg["device"])
+        pruned_rows = cfg.get("algo") == "pruned_rows"      # the row-sharded exact PRUNED NJ (njr.hip) instead of the streaming loop
         try:
-            d.set_nj_mode(0)
+            if pruned_rows:
+                d.set_nj_mode(1)
+                d.set_nj_multi_plan(3)
+            else:
+                d.set_nj_mode(0)
             if cfg["local"]:
                 d.comm_init_local(rank, world)
                 say({"blob": d.peer_export(n).hex()})
@@ -1146,7 +1166,7 @@ def njs_worker():
                     say({"uid": bytes(d.comm_unique_id()).hex()})
                 d.comm_init(rank, world, bytes.fromhex(hear()["uid"]))
                 ranks = d.comm_info()[1]
-            d.set_nj_exchange(PLAN_ID[cfg["plan"]])
+            d.set_nj_exchange(PRUNED_PLAN_ID[cfg["plan"]] if pruned_rows else PLAN_ID[cfg["plan"]])
             d.set_msa(packed, L)
             d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
             d.nj_run(max_iters=8)           # warm-up: first launches / communicator channels
@@ -1216,14 +1236,14 @@ class Child:
                 self.p.wait()
 
 
-def njs_child_leg(plan, rank, world, local_rank, dist, torch, p4, n, L, iters, setup_s, run_s):
+def njs_child_leg(plan, rank, world, local_rank, dist, torch, p4, n, L, iters, setup_s, run_s, algo="stream"):
     """one exchange plan of the row-sharded loop in a child per rank; every rank returns the same verdict, rank 0 the record"""
     def everyone(flag):
         t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=TDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(int(t.item()))
 
-    ch = Child({"rank": rank, "world": world, "device": local_rank, "tips": n, "sites": L, "iters": iters, "p4": p4, "plan": plan, "local": ONE_GPU})
+    ch = Child({"rank": rank, "world": world, "device": local_rank, "tips": n, "sites": L, "iters": iters, "p4": p4, "plan": plan, "local": ONE_GPU, "algo": algo})
     try:
         if ONE_GPU:
             m = ch.get(setup_s)
@@ -1253,7 +1273,13 @@ def njs_child_leg(plan, rank, world, local_rank, dist, torch, p4, n, L, iters, s
         dist.all_gather_object(allr, mine)
         loop_ms = max(r["loop_ms"] for r in allr)
         wall = max(r["wall_s"] for r in allr)
-        rec = stream_record(n, mine["iters"], loop_ms, wall, mine, world, mine["digest"])
+        if algo == "pruned_rows":
+            k = max(int(mine["iters"]), 1)
+            rec = {"iterations": int(mine["iters"]), "wall_s": wall, "loop_ms_hip_events": loop_ms, "us_per_iteration": loop_ms * 1e3 / k,
+                   "nj_iterations_per_s": k / (loop_ms * 1e-3), "launches_per_iteration": mine["launches"] / k,
+                   "collectives_per_iteration": mine["collectives"] / k, "merge_log_digest": mine["digest"], "exchange_plan": plan}
+        else:
+            rec = stream_record(n, mine["iters"], loop_ms, wall, mine, world, mine["digest"])
         # `ranks` = processes that took part; `rccl` says whether an RCCL communicator joined them (process ranks on ONE GPU are
         # joined through hipIpc windows only) -- a run without RCCL is never reported as rccl_ranks
         rec["ranks"] = mine["ranks"]
@@ -1267,7 +1293,48 @@ def njs_child_leg(plan, rank, world, local_rank, dist, torch, p4, n, L, iters, s
         ch.close()
 
 
-def nj_scaling(args, rank, world, local_rank, dist, torch, barrier, packed, n, L, iters, solo_pruned_its, budget=None):
+def row_sharded_pruned_virtual(local_rank, packed, n, L, vworld, solo_digest, budget):
+    """The row-sharded exact pruned NJ (njr.hip) with `vworld` VIRTUAL ranks on this one GPU: every rank holds only its chunks of
+    the position-space rows, its own vectors, lists and window; the whole NJ runs, its merge log is checked against the
+    single-GPU run, and the launches of ONE rank are bracketed by HIP events every 16th iteration -- the per-rank iteration time a
+    real rank would see without its exchange (the other ranks' launches serialise behind it on the one stream here)."""
+    import dipper_amd
+    from dipper_amd import capi
+    out = {"virtual_ranks": vworld, "tips": n, "sites": L,
+           "what": "whole NJ run, rows of the position-space matrix dealt to the ranks in chunks of 1 024; per-rank kernel times = HIP events around rank 0's "
+                   "three launches of every 16th iteration (eager launches; all ranks share this GPU, so wall time is NOT a multi-GPU figure)"}
+    for plan in ("mailbox", "collective"):
+        if budget is not None and not budget.allows(25):
+            out[plan] = budget.skip(25)
+            continue
+        d = dipper_amd.Dipper(local_rank, virtual_world=vworld)
+        try:
+            d.set_nj_mode(1)
+            d.set_nj_multi_plan(3)
+            d.set_nj_exchange(PRUNED_PLAN_ID[plan])
+            d.set_nj_kernel_timing(16)
+            d.set_msa(packed, L)
+            t0 = time.perf_counter()
+            d.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+            t1 = time.perf_counter()
+            res = d.nj_run()
+            wall = time.perf_counter() - t1
+            kt = d.nj_kernel_timing()
+            info = d.nj_exchange_info()
+            per_rank = {k: v for k, v in kt["kernel_us_avg"].items() if not k.startswith("(")}
+            out[plan] = {"iterations": int(res["iters"]), "matches_single_gpu": (merge_digest(res) == solo_digest) if solo_digest else None,
+                         "merge_log_digest": merge_digest(res), "per_rank_kernel_us": per_rank, "per_rank_iteration_us": sum(per_rank.values()),
+                         "sampled_iterations": kt["sampled_iterations"], "launches_per_iteration_per_rank": 3,
+                         "collectives_per_iteration": info["collectives"] / max(int(res["iters"]), 1),
+                         "build_s_all_ranks_on_one_gpu": t1 - t0, "nj_wall_s_all_ranks_on_one_gpu": wall}
+        except Exception as e:
+            out[plan] = {"error": repr(e)}
+        finally:
+            d.close()
+    return out
+
+
+def nj_scaling(args, rank, world, local_rank, dist, torch, barrier, packed, n, L, iters, solo_pruned_its, budget=None, solo_pruned_digest=None):
     """NJ-iteration throughput side by side (north_star's scaling metric): the default plan on one GPU (exact pruned scan),
     the streaming loop (the reference's algorithm, src/neighborJoining.cu:211-243: one full Q scan per iteration) on one GPU
     alone, and row-sharded over this run's GPUs with every exchange plan of the library.  Every multi-rank record carries the
@@ -1290,6 +1357,14 @@ def nj_scaling(args, rank, world, local_rank, dist, torch, barrier, packed, n, L
         finally:
             s1.close()
         rec["streaming_one_gpu"] = r1
+    # the row-sharded PRUNED plan with 8 virtual ranks on rank 0's GPU: merge log checked, per-rank kernel times
+    if rank == 0 and not args.no_virtual_pruned and (budget is None or budget.allows(45)):
+        log(f"[bench] +{elapsed():.0f}s: nj_scaling at {n} tips: row-sharded pruned NJ, 8 virtual ranks on one GPU")
+        try:
+            rec["row_sharded_pruned_virtual"] = row_sharded_pruned_virtual(local_rank, packed, n, L, 8, solo_pruned_digest, budget)
+        except Exception as e:
+            rec["row_sharded_pruned_virtual"] = {"error": repr(e)}
+        log(f"[bench] nj_scaling.row_sharded_pruned_virtual: {rec['row_sharded_pruned_virtual']}")
     if dist is not None:
         dist.barrier()
     if world == 1 and not (dist is not None and os.environ.get("DPR_BENCH_CHECK") == "1"):
@@ -1317,6 +1392,30 @@ def nj_scaling(args, rank, world, local_rank, dist, torch, barrier, packed, n, L
         rec["row_sharded"][plan] = r
         if rank == 0:
             log(f"[bench] nj_scaling.row_sharded.{plan}: {r}")
+    # the row-sharded exact PRUNED NJ on this run's ranks (njr.hip): the WHOLE run (it is short), per exchange plan
+    rec["row_sharded_pruned"] = {}
+    for plan in ("collective", "mailbox"):
+        if ONE_GPU and plan != "mailbox":
+            rec["row_sharded_pruned"][plan] = {"skipped": "needs RCCL (rehearsal with process ranks on one GPU)"}
+            continue
+        if budget is not None and not budget.allows_all(150):
+            rec["row_sharded_pruned"][plan] = budget.skip(150)
+            continue
+        log(f"[bench r{rank}] +{elapsed():.0f}s: nj_scaling at {n} tips: row-sharded PRUNED over {world} ranks, exchange plan {plan}")
+        try:
+            r = njs_child_leg(plan, rank, world, local_rank, dist, torch, str(p4), n, L, -1, setup_s=90.0, run_s=60.0, algo="pruned_rows")
+        except Exception as e:
+            r = {"error": repr(e)}
+        if rank == 0 and "error" not in r:
+            if solo_pruned_digest is not None:
+                r["matches_single_gpu"] = bool(r["merge_log_digest"] == solo_pruned_digest and r["iterations"] == n - 2)
+            if solo_pruned_its:
+                r["iteration_speedup_vs_default_plan_one_gpu"] = r["nj_iterations_per_s"] / solo_pruned_its
+            if "streaming_one_gpu" in rec:
+                r["iteration_speedup_vs_streaming_one_gpu"] = r["nj_iterations_per_s"] / rec["streaming_one_gpu"]["nj_iterations_per_s"]
+        rec["row_sharded_pruned"][plan] = r
+        if rank == 0:
+            log(f"[bench] nj_scaling.row_sharded_pruned.{plan}: {r}")
     return rec
 
 
@@ -1389,7 +1488,7 @@ def sharded_leg(args, rank, world, local_rank, dist, torch, barrier, stage, budg
     if budget.allows_all(need):
         try:
             rec["nj_scaling"] = nj_scaling(args, rank, world, local_rank, dist if world > 1 else None, torch, barrier, packed, ns, Ls,
-                                           max(8, args.stream_iters // 4), None, budget)
+                                           max(8, args.stream_iters // 4), rec.get("single_gpu_plan", {}).get("nj_iterations_per_s"), budget, merge_digest(res))
         except Exception as e:
             rec["nj_scaling"] = {"error": repr(e)}
     else:

@@ -40,6 +40,13 @@ def load_library():
     L.dpr_abi_version.restype = C.c_int
     L.dpr_pack4.argtypes = [C.c_char_p, C.c_uint64, c_u64p]
     L.dpr_pack2.argtypes = [C.c_char_p, C.c_uint64, c_u64p]
+    L.dpr_njr_owner.argtypes = [C.c_int64, C.c_int]
+    L.dpr_njr_local_row.argtypes = [C.c_int64, C.c_int]
+    L.dpr_njr_local_row.restype = C.c_int64
+    L.dpr_njr_global_pos.argtypes = [C.c_int64, C.c_int, C.c_int]
+    L.dpr_njr_global_pos.restype = C.c_int64
+    L.dpr_njr_rows_cap.argtypes = [C.c_int64, C.c_int]
+    L.dpr_njr_rows_cap.restype = C.c_int64
     L.dpr_shard_owner.argtypes = [C.c_int64, C.c_int]
     L.dpr_shard_local_row.argtypes = [C.c_int64, C.c_int]
     L.dpr_shard_local_row.restype = C.c_int64

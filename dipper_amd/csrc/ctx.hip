@@ -528,6 +528,10 @@ int dpr_pack2(const char* seq, uint64_t len, uint64_t* out)
 }
 
 // ---- sharding helpers -------------------------------------------------------------------------------
+int dpr_njr_owner(int64_t position, int world) { return world > 0 && position >= 0 ? njr_owner(position, world) : -1; }
+int64_t dpr_njr_local_row(int64_t position, int world) { return world > 0 && position >= 0 ? njr_local_row(position, world) : -1; }
+int64_t dpr_njr_global_pos(int64_t local_row, int rank, int world) { return world > 0 && local_row >= 0 ? njr_global_pos(local_row, rank, world) : -1; }
+int64_t dpr_njr_rows_cap(int64_t positions, int world) { return world > 0 && positions >= 0 ? njr_rows_cap(positions, world) : -1; }
 int dpr_shard_owner(int64_t row, int world) { return shard_owner(row, world); }
 int64_t dpr_shard_local_row(int64_t row, int world) { return shard_local_row(row, world); }
 int64_t dpr_shard_rows(int64_t n, int rank, int world) { return shard_rows(n, rank, world); }

@@ -66,6 +66,16 @@ int dpr_pack4(const char *seq, uint64_t len, uint64_t *out);
 int dpr_pack2(const char *seq, uint64_t len, uint64_t *out);
 
 /* ---- host-only sharding helpers (pure functions; used by the N>1 host logic and its CPU tests) */
+/* ... and of the ROW-SHARDED EXACT PRUNED NJ (njr.hip; several ranks, dpr_ctx_set_nj_multi_plan(ctx, 3) / DPR_NJ_MULTI=rows, or
+ * chosen by itself once two copies of the matrix no longer fit one GPU): north_star's row-block split of the N x N matrix
+ * (src/neighborJoining.cu:117-148) under the pruned algorithm.  The position-space matrix (positions = nodes sorted by row sum,
+ * per epoch) is dealt in chunks of DPR_NJR_CHUNK positions: chunk k belongs to rank k % world and is that rank's (k / world)-th
+ * chunk; the 16 x 512 units, their bounds, tests and scans belong to the owner of their rows. */
+#define DPR_NJR_CHUNK 1024
+int dpr_njr_owner(int64_t position, int world);              /* rank owning the matrix row of `position`           */
+int64_t dpr_njr_local_row(int64_t position, int world);      /* its index in the owner's storage                   */
+int64_t dpr_njr_global_pos(int64_t local_row, int rank, int world);   /* inverse                                  */
+int64_t dpr_njr_rows_cap(int64_t positions, int world);      /* matrix rows a rank must be able to hold (whole chunks) */
 int dpr_shard_owner(int64_t row, int world);                 /* rank owning matrix slot `row`      */
 int64_t dpr_shard_local_row(int64_t row, int world);         /* its index in the owner's storage  */
 int64_t dpr_shard_rows(int64_t n, int rank, int world);      /* #slots < n owned by `rank`         */

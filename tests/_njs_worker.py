@@ -18,7 +18,11 @@ def main():
     rng = np.random.default_rng(seed)
     d = dipper_amd.Dipper(0)
     d.comm_init_local(rank, world)
-    d.set_nj_mode(0)
+    if os.environ.get("DPR_TEST_NJ_ROWS_PRUNED") == "1":     # the row-sharded exact pruned NJ (njr.hip) instead of the streaming loop
+        d.set_nj_mode(1)
+        d.set_nj_multi_plan(3)
+    else:
+        d.set_nj_mode(0)
     blob = d.peer_export(n)
     sys.stdout.write(blob.hex() + "\n")
     sys.stdout.flush()

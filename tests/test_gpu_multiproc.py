@@ -88,6 +88,48 @@ def test_process_ranks_msa_source(tmp_path):
         assert float(got["last_d"]) == ref["last_d"]
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,n", [(2, 2500), (3, 1300), (3, 3300)])
+def test_process_ranks_row_sharded_pruned_match_oracle(tmp_path, orc, world, n):
+    """the row-sharded exact PRUNED NJ (njr.hip) with one process per rank on one GPU: each process holds its chunks of the
+    position-space rows only; block records and the winner's two columns travel through the mailboxes of the hipIpc-mapped
+    windows (no collective), the epoch rebuilds pull source rows out of the other processes' buffers; every rank ends with the
+    oracle's merge log (src/neighborJoining.cu:197-249), epochs rebuilt on the way, the run resumed once."""
+    seed = 1000 * world + n
+    res = _run_ranks(tmp_path, world, n, seed, extra_env={"DPR_TEST_NJ_ROWS_PRUNED": "1", "DPR_NJ_EPOCH_MIN": "300"})
+    D = _util.random_additive_matrix(np.random.default_rng(seed), n, zero_frac=0.3)
+    ref = orc.nj_run(np.tril(D, -1), threads=8)
+    for r, got in enumerate(res):
+        assert int(got["collectives"]) == 0 and int(got["launches"]) > 0
+        assert int(got["iters"]) == n - 2
+        for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
+            assert np.array_equal(got[key], ref[key]), (r, key)
+        assert float(got["last_d"]) == ref["last_d"]
+
+
+@pytest.mark.timeout(600)
+def test_process_ranks_row_sharded_pruned_msa_source(tmp_path):
+    """aligned input, 3 000 tips (natural epochs): distance rows computed by their owners, sharded build of epoch 0 out of the
+    tip-order rows of both processes; both ranks end with the single-GPU pruned merge log"""
+    import dipper_amd
+    from dipper_amd import capi
+    world, n, seed = 2, 3000, 43
+    res = _run_ranks(tmp_path, world, n, seed, source="msa", extra_env={"DPR_TEST_NJ_ROWS_PRUNED": "1"})
+    seqs = _util.synth_alignment(np.random.default_rng(seed), n, 800, mean_bl=5e-3, lo=1e-4, hi=5e-2)
+    one = dipper_amd.Dipper(0)
+    try:
+        one.set_nj_mode(1)
+        one.set_msa(capi.pack4_many(seqs), 800)
+        one.dist_matrix(capi.SRC_MSA, capi.DIST_JC)
+        ref = one.nj_run()
+    finally:
+        one.close()
+    for got in res:
+        for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
+            assert np.array_equal(got[key], ref[key]), key
+        assert float(got["last_d"]) == ref["last_d"]
+
+
 @pytest.mark.timeout(300)
 def test_large_export_is_refused_on_an_old_runtime_instead_of_hanging():
     """A process that imports torch runs the library on the wheel's HIP runtime; 7.0 never returns from hipIpcOpenMemHandle
