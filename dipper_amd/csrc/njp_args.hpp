@@ -133,7 +133,12 @@ __device__ __forceinline__ unsigned long long* njr_win_rowflag(char* region, con
 // finished last.  The caller resets the words (stream order protects the next launch).
 __device__ __forceinline__ bool njr_last_block(unsigned int* ticket, unsigned int* s_last)
 {
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && gridDim.x <= kNjsTicketGroups) {
+        // few blocks: one word (a second level would only add a dependent atomic)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int tt = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_last = (tt == gridDim.x - 1) ? 1u : 0u;
+    } else if (threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned int G = gridDim.x, grp = blockIdx.x % kNjsTicketGroups;
         const unsigned int in_grp = (G - grp + kNjsTicketGroups - 1) / kNjsTicketGroups, groups = G < kNjsTicketGroups ? G : kNjsTicketGroups;
@@ -159,10 +164,17 @@ __device__ __forceinline__ void njr_scan_publish(const NjpArgs& a, int64_t it, u
     const int nrec = a.ugrid + 1, par = (int)(it & 1);
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.partials + a.rec_off - 1);
     const int words = 4 * nrec;
-    for (int w = tid; w < words * a.rs_world; w += kThreads) {
-        const int peer = w / words, k = w - peer * words;
-        const unsigned long long v = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        njr_st_sys(reinterpret_cast<unsigned long long*>(njr_win_recs(a.rs_win[peer], a.rs_lay, par, a.rs_rank)) + k, v);
+    // a thread loads its words ONCE (all loads in flight together), then stores them to every rank
+    for (int k0 = tid; k0 < words; k0 += 4 * kThreads) {
+        unsigned long long v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (k0 + u * kThreads < words) ? __hip_atomic_load(src + k0 + u * kThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        for (int peer = 0; peer < a.rs_world; ++peer) {
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(njr_win_recs(a.rs_win[peer], a.rs_lay, par, a.rs_rank));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k0 + u * kThreads < words) njr_st_sys(dst + k0 + u * kThreads, v[u]);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

@@ -98,20 +98,36 @@ __global__ __launch_bounds__(kThreads) void njr_extract_kernel(NjpArgs a, int64_
     }
     // ---- the winner over all ranks' unit records and the (replicated) new-row records
     double bq = 10000.0, d = 0.0; uint64_t bk = ~0ull, bp = 0;
-    for (int idx = tid; idx < W * nrec; idx += kThreads) {
-        const int r = idx / nrec, k = idx - r * nrec;
-        double q; unsigned long long key, pad; double dd;
-        if (mailbox) {
-            const unsigned long long* w = reinterpret_cast<const unsigned long long*>(njr_win_recs(a.rs_win[rank], a.rs_lay, par, r)) + 4 * k;
-            q = __longlong_as_double((long long)njr_ld_sys(w + 0)); key = njr_ld_sys(w + 1);
-            dd = __longlong_as_double((long long)njr_ld_sys(w + 2)); pad = njr_ld_sys(w + 3);
-            if (blockIdx.x == 0) { NjRecord rec; rec.q = q; rec.key = key; rec.d = dd; rec.pad = pad; a.partials[idx] = rec; }      // POST reads them here
-        } else {
-            const NjRecord rec = a.partials[idx];
-            q = rec.q; key = rec.key; dd = rec.d; pad = rec.pad;
+    // (a thread's records are all loaded before the first one is used: one round trip, not one per record)
+    constexpr int kPre = 4;
+    for (int idx0 = tid; idx0 < W * nrec; idx0 += kPre * kThreads) {
+        unsigned long long w4[kPre][4];
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const int idx = idx0 + u * kThreads;
+            w4[u][0] = (unsigned long long)__double_as_longlong(10000.0); w4[u][1] = ~0ull; w4[u][2] = 0ull; w4[u][3] = 0ull;
+            if (idx >= W * nrec) continue;
+            const int r = idx / nrec, k = idx - r * nrec;
+            if (mailbox) {
+                const unsigned long long* w = reinterpret_cast<const unsigned long long*>(njr_win_recs(a.rs_win[rank], a.rs_lay, par, r)) + 4 * k;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) w4[u][c] = njr_ld_sys(w + c);
+            } else {
+                const unsigned long long* w = reinterpret_cast<const unsigned long long*>(a.partials + idx);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) w4[u][c] = w[c];
+            }
         }
-        if (k == 0) { s_hdr[r] = (unsigned long long)__double_as_longlong(dd); s_seq[r] = pad; }      // header: row sum bits, sequence number
-        best_update4(bq, bk, bp, d, q, key, pad, dd);
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const int idx = idx0 + u * kThreads;
+            if (idx >= W * nrec) continue;
+            const int r = idx / nrec, k = idx - r * nrec;
+            const double q = __longlong_as_double((long long)w4[u][0]), dd = __longlong_as_double((long long)w4[u][2]);
+            if (mailbox && blockIdx.x == 0) { NjRecord rec; rec.q = q; rec.key = w4[u][1]; rec.d = dd; rec.pad = w4[u][3]; a.partials[idx] = rec; }      // POST reads them here
+            if (k == 0) { s_hdr[r] = w4[u][2]; s_seq[r] = w4[u][3]; }      // header: row sum bits, sequence number
+            best_update4(bq, bk, bp, d, q, w4[u][1], w4[u][3], dd);
+        }
     }
     for (int idx = tid; idx < a.nrb; idx += kThreads) {
         const NjRecord rec = a.partials[a.urecs + idx];

@@ -4,9 +4,9 @@
 #   bash profiles/prof.sh trace  <tag> <program> [args...]    ... and the per-dispatch distribution (profiles/nj_trace_summary.py) as <tag>_trace_summary.json
 #   bash profiles/prof.sh pmc    <tag> "<counters>" <program> [args...]    one --pmc pass (kernel trace only); per-kernel mean of every counter
 # <program> is started directly behind `--` (python3 script.py ... or a binary), never through a shell.
-# Output under gpurun_out/r4/<tag>/ ; the per-dispatch CSVs are deleted (tens of MB).
+# Output under gpurun_out/${DPR_ROUND:-r5}/<tag>/ ; the per-dispatch CSVs are deleted (tens of MB).
 MODE=$1; TAG=$2; shift 2
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r4/$TAG
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${DPR_ROUND:-r5}/$TAG
 mkdir -p $OUT
 # rocprofv3 wants /tmp as the working directory: paths relative to the repository become absolute
 ARGS=()
