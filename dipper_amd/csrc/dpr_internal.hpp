@@ -440,6 +440,15 @@ struct PlaceBuffers {
     void* partials_multi = nullptr;   // block minima of a scan launch that serves several tips (place_tips)
     int64_t nparts_multi = 0;
     int dbg = 0;   // 4: place_update_kernel writes its phase clocks into the trace (DPR_PLACE_CLOCKS, profiling only)
+    // Edge records (round 5): a read-optimised MIRROR of what the per-tip scan (calculateBranchLength, src/placement_close_k.cu:
+    // 309-358) needs, one entry per UNDIRECTED edge = the slot pair s / rev[s]; side 0 is the slot with belong >= e (the one the
+    // reference evaluates), side 1 its reverse.  Struct of arrays (every load of the scan coalesced); the slot-indexed arrays
+    // above stay the authoritative state -- the split and the closest-list BFS write both.
+    double* er_d = nullptr;      // [11][ecap]: cdis of side 0 (fields 0..4), of side 1 (5..9), len (10)
+    int32_t* er_i = nullptr;     // [12][ecap]: cid of side 0 (0..4), of side 1 (5..9), slot of side 0 (10), slot of side 1 (11)
+    int32_t* eidx = nullptr;     // [8N] slot -> 2 * edge + side
+    int64_t ecap = 0;
+    int32_t* misc = nullptr;     // [0]: smallest live slot with belong < e (its tuple (0, 0, 2) competes for the first minimum); [1]: edge counter of an import
 };
 int place_alloc(PlaceBuffers& p, int64_t N, int64_t M = 0);   // M = 0: M = N
 void place_free(PlaceBuffers& p);

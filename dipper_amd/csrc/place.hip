@@ -67,6 +67,25 @@ __device__ __forceinline__ void list_insert(double* cdis, int32_t* cid, int slot
     }
 }
 
+// ---- edge records (PlaceBuffers::er_d / er_i / eidx, see dpr_internal.hpp) ----------------------------------------
+// the list of one side of an edge record; ex = eidx[slot] = 2 * edge + side
+__device__ __forceinline__ void er_write_side(const PlaceBuffers& p, int ex, const double* cd, const int* ci)
+{
+    const int64_t k = ex >> 1;
+    const int o = (ex & 1) * K5;
+#pragma unroll
+    for (int i = 0; i < K5; ++i) { p.er_d[(int64_t)(o + i) * p.ecap + k] = cd[i]; p.er_i[(int64_t)(o + i) * p.ecap + k] = ci[i]; }
+}
+// a whole record: edge k = (slot s0 with its list, slot s1 with its list), length
+__device__ __forceinline__ void er_write_edge(const PlaceBuffers& p, int k, int s0, const double* cd0, const int* ci0, int s1, const double* cd1, const int* ci1, double len)
+{
+    er_write_side(p, 2 * k, cd0, ci0);
+    er_write_side(p, 2 * k + 1, cd1, ci1);
+    p.er_d[(int64_t)10 * p.ecap + k] = len;
+    p.er_i[(int64_t)10 * p.ecap + k] = s0; p.er_i[(int64_t)11 * p.ecap + k] = s1;
+    p.eidx[s0] = 2 * k; p.eidx[s1] = 2 * k + 1;
+}
+
 // updateClosestNodes, one wave: frontier entries l..r processed 64 at a time.  The frontier holds SLOTS:
 // reaching slot i = (u -> v) with the distance d of u inserts the new leaf into list[i]; if it entered, the
 // slots leaving v other than the reverse of i (cont[2i], cont[2i+1]; write-once except at a split) follow
@@ -106,6 +125,7 @@ __device__ __forceinline__ void closest_update_wave(const PlaceBuffers& p, int x
             for (int j = 0; j < K5; ++j) { cd[j] = p.cdis[sl * K5 + j]; ci[j] = p.cid[sl * K5 + j]; }
             const double ln = p.len[sl];
             const int k0 = p.cont[2 * sl], k1 = p.cont[2 * sl + 1];
+            const int ex = p.eidx[sl];
             int j = K5;
 #pragma unroll
             for (int t = K5 - 1; t >= 0; --t)
@@ -116,6 +136,12 @@ __device__ __forceinline__ void closest_update_wave(const PlaceBuffers& p, int x
                     if (t > j) { p.cdis[sl * K5 + t] = cd[t - 1]; p.cid[sl * K5 + t] = ci[t - 1]; }
                 p.cdis[sl * K5 + j] = d;
                 p.cid[sl * K5 + j] = x;
+                {   // the same list into the slot's edge record (the scan of the next tip reads it there)
+                    double nd[K5]; int ni[K5];
+#pragma unroll
+                    for (int t = 0; t < K5; ++t) { nd[t] = t < j ? cd[t] : (t == j ? d : cd[t > 0 ? t - 1 : 0]); ni[t] = t < j ? ci[t] : (t == j ? x : ci[t > 0 ? t - 1 : 0]); }
+                    er_write_side(p, ex, nd, ni);
+                }
                 dn = d + ln;
                 if (k0 == -2) {                        // high-degree target: count its other slots
                     walk = true;
@@ -187,6 +213,12 @@ __global__ __launch_bounds__(64) void place_initial_tree_kernel(PlaceBuffers p, 
         // continuation slots: beyond 0 -> nv lies nv -> 1, beyond 1 -> nv lies nv -> 0, leaves end the walk
         p.cont[0] = 3; p.cont[1] = -1; p.cont[2] = 2; p.cont[3] = -1;
         p.cont[4] = -1; p.cont[5] = -1; p.cont[6] = -1; p.cont[7] = -1;
+        // edge records: (nv -> 0 | 0 -> nv), (nv -> 1 | 1 -> nv); the lists are still the initial ones (2 / -1)
+        double l2[K5]; int lm[K5];
+        for (int i = 0; i < K5; ++i) { l2[i] = 2; lm[i] = -1; }
+        er_write_edge(p, 0, 2, l2, lm, 0, l2, lm, d / 2);
+        er_write_edge(p, 1, 3, l2, lm, 1, l2, lm, d / 2);
+        p.misc[0] = 0;                       // slot 0 (0 -> nv) is the smallest slot with belong < e, now and later
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -309,7 +341,7 @@ __global__ __launch_bounds__(64) void place_backbone_lists_kernel(PlaceBuffers p
     for (int64_t t = t0; t < t1; ++t) closest_update_wave(p, (int)t, p.head[t]);   // a leaf has one slot
 }
 
-// Per tip two kernels: place_tip_kernel (calculateBranchLength for the live slots idx < 4*num-4 and the
+// Per tip two kernels: place_tip_edges_kernel (calculateBranchLength for the live edges and the
 // block-level first minimum) and the single-wavefront place_update_kernel, which finishes the argmin,
 // splits the edge (updateTreeStructure) and runs the closest-list update (updateClosestNodes) -- the
 // reference's Thrust reduction, device->host copy and two single-thread kernels.  (Fusing the two with a
@@ -326,15 +358,18 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
     const unsigned long long tk0 = wall_clock64();
     // (a) loads that do not depend on the winner: the (initial) lists of the new slots ec, ec+1, ec+3 -- slots the
     // reference never touched keep the init values 2 / -1, which it reads back at the split; in flight during (b)
-    double i0d[K5], i1d[K5], i3d[K5];
-    int i0i[K5], i1i[K5], i3i[K5];
+    double i0d[K5], i1d[K5], i2d[K5], i3d[K5];
+    int i0i[K5], i1i[K5], i2i[K5], i3i[K5];
+    int mininel = 0x7fffffff;
     if (tid == 0) {
 #pragma unroll
         for (int i = 0; i < K5; ++i) {
             i0d[i] = p.cdis[ec * K5 + i]; i0i[i] = p.cid[ec * K5 + i];
             i1d[i] = p.cdis[(ec + 1) * K5 + i]; i1i[i] = p.cid[(ec + 1) * K5 + i];
+            i2d[i] = p.cdis[(ec + 2) * K5 + i]; i2i[i] = p.cid[(ec + 2) * K5 + i];
             i3d[i] = p.cdis[(ec + 3) * K5 + i]; i3i[i] = p.cid[(ec + 3) * K5 + i];
         }
+        mininel = p.misc[0];
     }
     // (b) first minimum over the block partials of the scan: four waves, eight loads in flight per thread
     double badd = __builtin_inf(), bfrac = 0;
@@ -352,10 +387,12 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
         for (int u = 0; u < 8; ++u)
             if (pp[u].add < badd || (pp[u].add == badd && pp[u].idx < bidx)) { badd = pp[u].add; bidx = pp[u].idx; beid = pp[u].eid; bfrac = pp[u].frac; brev = pp[u].rev; }
     }
-    // slots >= 4*num-4 (and < 4M-4) all carry the tuple (0,0,2): the first of them competes
+    // slots >= 4*num-4 (and < 4M-4) all carry the tuple (0,0,2): the first of them competes -- and so does the first live slot
+    // with belong < e, which the edge scan does not visit (same tuple; src/placement_close_k.cu:309-358 writes it for those)
     const int64_t live = 4 * num - 4, lim = 4 * p.M - 4;
-    if (tid == 0 && live < lim) {
-        if (2.0 < badd || (2.0 == badd && (int)live < bidx)) { badd = 2.0; bidx = (int)live; beid = 0; bfrac = 0; brev = -1; }
+    if (tid == 0) {
+        if (live < lim && (2.0 < badd || (2.0 == badd && (int)live < bidx))) { badd = 2.0; bidx = (int)live; beid = 0; bfrac = 0; brev = -1; }
+        if (mininel < (int)live && (2.0 < badd || (2.0 == badd && mininel < bidx))) { badd = 2.0; bidx = mininel; beid = 0; bfrac = 0; brev = -1; }
     }
     {   // wave winner (smallest add, then smallest idx; add is never NaN here), then the four wave winners through LDS
         const double wa = wave_fmin(badd);
@@ -388,6 +425,7 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
         for (int i = 0; i < K5; ++i) { cdx[i] = p.cdis[xe * K5 + i]; cix[i] = p.cid[xe * K5 + i]; cdy[i] = p.cdis[ye * K5 + i]; ciy[i] = p.cid[ye * K5 + i]; }
         const double lenye = p.len[ye];
         const int ox0 = p.cont[2 * xe], ox1 = p.cont[2 * xe + 1], oy0 = p.cont[2 * ye], oy1 = p.cont[2 * ye + 1];
+        const int kold = p.eidx[xe] >> 1;                  // the record of the edge being split: taken over by (middle, x)
         p.e[xe] = middle; p.len[xe] = fracLen;
         p.e[ye] = middle; p.len[ye] = lenye - fracLen;
         // middle -> x: inherits the list of y -> x (slots untouched by the reference keep the init values 2 / -1)
@@ -458,6 +496,14 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
         p.cont[2 * ye] = e0; p.cont[2 * ye + 1] = e3;
         p.cont[2 * e2] = e0; p.cont[2 * e2 + 1] = e1;
         p.cont[2 * e3] = -1; p.cont[2 * e3 + 1] = -1;
+        // edge records: `middle` has the largest node id, so the slots leaving it are the evaluated sides; xe and ye (and
+        // e2) now have belong < e
+        const int nedge = (int)(2 * num - 2);
+        er_write_edge(p, kold, e0, n0d, n0i, xe, cdx, cix, fracLen);
+        er_write_edge(p, nedge, e1, n1d, n1i, ye, cdy, ciy, originalDis - fracLen);
+        er_write_edge(p, nedge + 1, e3, md, mi, e2, i2d, i2i, addLen);
+        const int lo = xe < ye ? xe : ye;
+        if (lo < mininel) p.misc[0] = lo;
     }
     // the wave reads what its lane 0 just stored: program order within the wavefront
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -472,60 +518,53 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
 }
 
 constexpr int kTipThreads = 256;
-__global__ __launch_bounds__(kTipThreads) void place_tip_kernel(PlaceBuffers p, const double* __restrict__ dis,
-                                                             int64_t num, PlacePartial* __restrict__ partials)
+// The per-tip scan over the EDGE RECORDS (round 5): one thread per undirected edge instead of one per directed slot -- the slot
+// scan of rounds 1-4 loaded every list twice (as the slot's own and as its reverse's) and kept half of its threads for slots
+// with belong < e, whose tuple is the constant (0, 0, 2): 10.8 -> 6.7 us per launch at 100 000 tips.  Here a thread reads the 2 x 5 list entries, the length and the two slot ids
+// of its edge in one round trip of coalesced loads (struct of arrays), then the ten distance gathers: two dependent hops, half
+// the bytes, half the blocks.  Same arithmetic per edge, same key (pendant length, slot of the evaluated side); the constant
+// tuple of the smallest slot with belong < e joins in place_finish_and_update.
+__global__ __launch_bounds__(kTipThreads) void place_tip_edges_kernel(PlaceBuffers p, const double* __restrict__ dis,
+                                                                   int64_t num, PlacePartial* __restrict__ partials)
 {
     __shared__ double sadd[kTipThreads / 64];
     __shared__ int sidx[kTipThreads / 64];
-    const int64_t live = 4 * num - 4;
-    const int64_t idx = (int64_t)blockIdx.x * kTipThreads + threadIdx.x;
+    const int64_t nedge = 2 * num - 2;
+    const int64_t k = (int64_t)blockIdx.x * kTipThreads + threadIdx.x;
+    const bool have = k < nedge;
     double add = 2.0, d1 = 0.0;
-    int eid = 0;
-    bool have = idx < live;
-    // Three dependent round trips instead of four: everything whose address follows from the slot number is loaded
-    // up front (eligibility, reverse slot, length, the slot's own list) and the eligibility test comes afterwards;
-    // then the reverse slot's list together with the distance gathers of the own list; then the remaining gathers.
-    int myrev = -1;
+    int sl0 = 0x7fffffff, sl1 = -1;
     if (have) {
-        const int sl = (int)idx;
-        const int bel = p.belong[sl], tgt = p.e[sl];
-        const int oe = p.rev[sl];
-        const double L = p.len[sl];
         double cd[2 * K5];
         int ci[2 * K5];
 #pragma unroll
-        for (int i = 0; i < K5; ++i) { ci[i] = p.cid[sl * K5 + i]; cd[i] = p.cdis[sl * K5 + i]; }
-        if (bel >= tgt) {
-            eid = sl;
-            myrev = oe;
+        for (int i = 0; i < 2 * K5; ++i) { cd[i] = p.er_d[(int64_t)i * p.ecap + k]; ci[i] = p.er_i[(int64_t)i * p.ecap + k]; }
+        const double L = p.er_d[(int64_t)10 * p.ecap + k];
+        sl0 = p.er_i[(int64_t)10 * p.ecap + k]; sl1 = p.er_i[(int64_t)11 * p.ecap + k];
+        double dv[2 * K5];
 #pragma unroll
-            for (int i = 0; i < K5; ++i) { ci[K5 + i] = p.cid[oe * K5 + i]; cd[K5 + i] = p.cdis[oe * K5 + i]; }
-            double dv[2 * K5];
+        for (int i = 0; i < 2 * K5; ++i) dv[i] = ci[i] != -1 ? dis[ci[i]] : 0.0;
+        double dis1 = 0, dis2 = 0, val;
 #pragma unroll
-            for (int i = 0; i < 2 * K5; ++i) dv[i] = ci[i] != -1 ? dis[ci[i]] : 0.0;
-            double dis1 = 0, dis2 = 0, val;
+        for (int i = 0; i < K5; ++i)
+            if (ci[i] != -1) { val = dv[i] - cd[i]; if (val > dis1) dis1 = val; }
 #pragma unroll
-            for (int i = 0; i < K5; ++i)
-                if (ci[i] != -1) { val = dv[i] - cd[i]; if (val > dis1) dis1 = val; }
-#pragma unroll
-            for (int i = 0; i < K5; ++i)
-                if (ci[K5 + i] != -1) { val = dv[K5 + i] - cd[K5 + i]; if (val > dis2) dis2 = val; }
-            double a = (dis1 + dis2 - L) / 2;
-            if (a < 0) a = 0;
-            dis1 -= a; dis2 -= a;
-            if (dis1 < 0) dis1 = 0;
-            if (dis2 < 0) dis2 = 0;
-            if (dis1 > L) { a += dis1 - L; dis1 = L; }
-            if (dis2 > L) { a += dis2 - L; dis2 = L; }
-            const double rest = L - dis1 - dis2;
-            dis1 += rest / 2; dis2 += rest / 2;
-            add = a; d1 = dis1;
-        }
+        for (int i = 0; i < K5; ++i)
+            if (ci[K5 + i] != -1) { val = dv[K5 + i] - cd[K5 + i]; if (val > dis2) dis2 = val; }
+        double a = (dis1 + dis2 - L) / 2;
+        if (a < 0) a = 0;
+        dis1 -= a; dis2 -= a;
+        if (dis1 < 0) dis1 = 0;
+        if (dis2 < 0) dis2 = 0;
+        if (dis1 > L) { a += dis1 - L; dis1 = L; }
+        if (dis2 > L) { a += dis2 - L; dis2 = L; }
+        const double rest = L - dis1 - dis2;
+        dis1 += rest / 2; dis2 += rest / 2;
+        add = a; d1 = dis1;
     }
-    // first minimum of add over idx (thrust::min_element): key (add, idx); NaN never wins
-    double badd = have ? add : __builtin_inf();
-    int bidx = have ? (int)idx : 0x7fffffff;
-    if (have && !(add == add)) { badd = __builtin_inf(); }
+    // first minimum of add over the slot index (thrust::min_element): key (add, slot); NaN never wins
+    double badd = (have && add == add) ? add : __builtin_inf();
+    int bidx = have ? sl0 : 0x7fffffff;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const double oa = __shfl_down(badd, off, 64);
@@ -541,15 +580,30 @@ __global__ __launch_bounds__(kTipThreads) void place_tip_kernel(PlaceBuffers p, 
         sadd[0] = badd; sidx[0] = bidx;
     }
     __syncthreads();
-    // the winner of the block publishes its tuple
-    if (have && (int)idx == sidx[0]) {
-        PlacePartial pp; pp.add = add; pp.idx = (int)idx; pp.eid = eid; pp.frac = d1; pp.rev = eid ? myrev : -1; pp.pad = 0;
+    if (have && sl0 == sidx[0]) {
+        PlacePartial pp; pp.add = add; pp.idx = sl0; pp.eid = sl0; pp.frac = d1; pp.rev = sl1; pp.pad = 0;
         partials[blockIdx.x] = pp;
     }
     if (threadIdx.x == 0 && sidx[0] == 0x7fffffff) {
         PlacePartial pp; pp.add = __builtin_inf(); pp.idx = 0x7fffffff; pp.eid = 0; pp.frac = 0; pp.rev = -1; pp.pad = 0;
         partials[blockIdx.x] = pp;
     }
+}
+
+// edge records of an adjacency that was not built by splits (imported backbone): one record per slot with belong >= e
+__global__ __launch_bounds__(kThreads) void place_pack_edges_kernel(PlaceBuffers p, int64_t nslots)
+{
+    const int64_t s = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (s >= nslots) return;
+    const int bel = p.belong[s], tgt = p.e[s];
+    if (bel < tgt) { atomicMin(&p.misc[0], (int)s); return; }
+    const int r = p.rev[s];
+    const int k = atomicAdd(&p.misc[1], 1);
+    double c0[K5], c1[K5];
+    int i0[K5], i1[K5];
+#pragma unroll
+    for (int i = 0; i < K5; ++i) { c0[i] = p.cdis[s * K5 + i]; i0[i] = p.cid[s * K5 + i]; c1[i] = p.cdis[(int64_t)r * K5 + i]; i1[i] = p.cid[(int64_t)r * K5 + i]; }
+    er_write_edge(p, k, (int)s, c0, i0, r, c1, i1, p.len[s]);
 }
 
 __global__ __launch_bounds__(kUpdThreads) void place_update_kernel(PlaceBuffers p, const PlacePartial* partials, int nparts,
@@ -573,7 +627,7 @@ __global__ __launch_bounds__(kUpdThreads) void place_update_kernel(PlaceBuffers 
 constexpr int kMultiB = 4;
 constexpr int kDirtyHash = 4096, kDirtyCap = 2048, kRescanCap = 128;
 
-// calculateBranchLength for one slot (the arithmetic of place_tip_kernel)
+// calculateBranchLength for one slot (the arithmetic of place_tip_edges_kernel, from the slot-indexed arrays)
 __device__ __forceinline__ void place_eval_slot(const PlaceBuffers& p, const double* __restrict__ dis, int sl, double& add, double& d1,
                                                 int& eid, int& myrev)
 {
@@ -613,58 +667,51 @@ __device__ __forceinline__ void place_eval_slot(const PlaceBuffers& p, const dou
     }
 }
 
-// scan of the slots [0, 4 num0 - 4) for the tips num0 .. num0 + nb - 1 (rows dis0 + j ldb): partials[j * nblk + block]
+// scan of the EDGES [0, 2 num0 - 2) (edge records, as place_tip_edges_kernel) for the tips num0 .. num0 + nb - 1 (rows dis0 + j ldb):
+// partials[j * nblk + block]; block b covers the edges [256 b, 256 b + 256)
 __global__ __launch_bounds__(kTipThreads) void place_tip_multi_kernel(PlaceBuffers p, const double* __restrict__ dis0, int64_t ldb,
                                                                    int64_t num0, int nb, PlacePartial* __restrict__ partials, int nblk)
 {
     __shared__ double sadd[kMultiB][kTipThreads / 64];
     __shared__ int sidx[kMultiB][kTipThreads / 64];
-    const int64_t live = 4 * num0 - 4;
-    const int64_t idx = (int64_t)blockIdx.x * kTipThreads + threadIdx.x;
-    const bool have = idx < live;
+    const int64_t nedge = 2 * num0 - 2;
+    const int64_t k = (int64_t)blockIdx.x * kTipThreads + threadIdx.x;
+    const bool have = k < nedge;
     double add[kMultiB], d1[kMultiB];
-    int eid = 0, myrev = -1;
+    int sl0 = 0x7fffffff, sl1 = -1;
 #pragma unroll
     for (int j = 0; j < kMultiB; ++j) { add[j] = 2.0; d1[j] = 0.0; }
     if (have) {
-        const int sl = (int)idx;
-        const int bel = p.belong[sl], tgt = p.e[sl];
-        const int oe = p.rev[sl];
-        const double L = p.len[sl];
-        if (bel >= tgt) {
-            double cd[2 * K5];
-            int ci[2 * K5];
+        double cd[2 * K5];
+        int ci[2 * K5];
 #pragma unroll
-            for (int i = 0; i < K5; ++i) { ci[i] = p.cid[sl * K5 + i]; cd[i] = p.cdis[sl * K5 + i]; }
+        for (int i = 0; i < 2 * K5; ++i) { cd[i] = p.er_d[(int64_t)i * p.ecap + k]; ci[i] = p.er_i[(int64_t)i * p.ecap + k]; }
+        const double L = p.er_d[(int64_t)10 * p.ecap + k];
+        sl0 = p.er_i[(int64_t)10 * p.ecap + k]; sl1 = p.er_i[(int64_t)11 * p.ecap + k];
 #pragma unroll
-            for (int i = 0; i < K5; ++i) { ci[K5 + i] = p.cid[oe * K5 + i]; cd[K5 + i] = p.cdis[oe * K5 + i]; }
-            eid = sl;
-            myrev = oe;
+        for (int j = 0; j < kMultiB; ++j) {
+            if (j >= nb) break;
+            const double* __restrict__ dis = dis0 + (int64_t)j * ldb;
+            double dv[2 * K5];
 #pragma unroll
-            for (int j = 0; j < kMultiB; ++j) {
-                if (j >= nb) break;
-                const double* __restrict__ dis = dis0 + (int64_t)j * ldb;
-                double dv[2 * K5];
+            for (int i = 0; i < 2 * K5; ++i) dv[i] = ci[i] != -1 ? dis[ci[i]] : 0.0;
+            double dis1 = 0, dis2 = 0, val;
 #pragma unroll
-                for (int i = 0; i < 2 * K5; ++i) dv[i] = ci[i] != -1 ? dis[ci[i]] : 0.0;
-                double dis1 = 0, dis2 = 0, val;
+            for (int i = 0; i < K5; ++i)
+                if (ci[i] != -1) { val = dv[i] - cd[i]; if (val > dis1) dis1 = val; }
 #pragma unroll
-                for (int i = 0; i < K5; ++i)
-                    if (ci[i] != -1) { val = dv[i] - cd[i]; if (val > dis1) dis1 = val; }
-#pragma unroll
-                for (int i = 0; i < K5; ++i)
-                    if (ci[K5 + i] != -1) { val = dv[K5 + i] - cd[K5 + i]; if (val > dis2) dis2 = val; }
-                double a = (dis1 + dis2 - L) / 2;
-                if (a < 0) a = 0;
-                dis1 -= a; dis2 -= a;
-                if (dis1 < 0) dis1 = 0;
-                if (dis2 < 0) dis2 = 0;
-                if (dis1 > L) { a += dis1 - L; dis1 = L; }
-                if (dis2 > L) { a += dis2 - L; dis2 = L; }
-                const double rest = L - dis1 - dis2;
-                dis1 += rest / 2; dis2 += rest / 2;
-                add[j] = a; d1[j] = dis1;
-            }
+            for (int i = 0; i < K5; ++i)
+                if (ci[K5 + i] != -1) { val = dv[K5 + i] - cd[K5 + i]; if (val > dis2) dis2 = val; }
+            double a = (dis1 + dis2 - L) / 2;
+            if (a < 0) a = 0;
+            dis1 -= a; dis2 -= a;
+            if (dis1 < 0) dis1 = 0;
+            if (dis2 < 0) dis2 = 0;
+            if (dis1 > L) { a += dis1 - L; dis1 = L; }
+            if (dis2 > L) { a += dis2 - L; dis2 = L; }
+            const double rest = L - dis1 - dis2;
+            dis1 += rest / 2; dis2 += rest / 2;
+            add[j] = a; d1[j] = dis1;
         }
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -673,7 +720,7 @@ __global__ __launch_bounds__(kTipThreads) void place_tip_multi_kernel(PlaceBuffe
 #pragma unroll
     for (int j = 0; j < kMultiB; ++j) {
         badd[j] = (have && add[j] == add[j]) ? add[j] : __builtin_inf();      // NaN never wins
-        bidx[j] = have ? (int)idx : 0x7fffffff;
+        bidx[j] = have ? sl0 : 0x7fffffff;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const double oa = __shfl_down(badd[j], off, 64);
@@ -691,8 +738,8 @@ __global__ __launch_bounds__(kTipThreads) void place_tip_multi_kernel(PlaceBuffe
 #pragma unroll
         for (int i = 1; i < kTipThreads / 64; ++i)
             if (sadd[j][i] < ba || (sadd[j][i] == ba && sidx[j][i] < bi)) { ba = sadd[j][i]; bi = sidx[j][i]; }
-        if (have && (int)idx == bi) {
-            PlacePartial pp; pp.add = add[j]; pp.idx = (int)idx; pp.eid = eid; pp.frac = d1[j]; pp.rev = eid ? myrev : -1; pp.pad = 0;
+        if (have && sl0 == bi) {
+            PlacePartial pp; pp.add = add[j]; pp.idx = sl0; pp.eid = sl0; pp.frac = d1[j]; pp.rev = sl1; pp.pad = 0;
             partials[(int64_t)j * nblk + blockIdx.x] = pp;
         }
         if (threadIdx.x == 0 && bi == 0x7fffffff) {
@@ -763,6 +810,7 @@ __device__ __forceinline__ void closest_update_wave_rec(const PlaceBuffers& p, i
             const double ln = p.len[sl];
             const int k0 = p.cont[2 * sl], k1 = p.cont[2 * sl + 1];
             const int back = p.rev[sl];
+            const int ex = p.eidx[sl];
             int j = K5;
 #pragma unroll
             for (int t = K5 - 1; t >= 0; --t)
@@ -773,6 +821,12 @@ __device__ __forceinline__ void closest_update_wave_rec(const PlaceBuffers& p, i
                     if (t > j) { p.cdis[sl * K5 + t] = cd[t - 1]; p.cid[sl * K5 + t] = ci[t - 1]; }
                 p.cdis[sl * K5 + j] = d;
                 p.cid[sl * K5 + j] = x;
+                {   // (edge record, as closest_update_wave)
+                    double nd[K5]; int ni[K5];
+#pragma unroll
+                    for (int t = 0; t < K5; ++t) { nd[t] = t < j ? cd[t] : (t == j ? d : cd[t > 0 ? t - 1 : 0]); ni[t] = t < j ? ci[t] : (t == j ? x : ci[t > 0 ? t - 1 : 0]); }
+                    er_write_side(p, ex, nd, ni);
+                }
                 dirty_add(ds, sl);
                 dirty_add(ds, back);
                 dn = d + ln;
@@ -840,7 +894,7 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
     if (tid == 0) { s_count = 0; s_nrescan = 0; }
     __syncthreads();
     DirtySet ds{ s_hash, s_list, &s_count };
-    const int64_t live0 = 4 * num0 - 4;                 // slots the scan launch covered
+    const int64_t nedge0 = 2 * num0 - 2;                // edges the scan launch covered
     for (int jt = 0; jt < nb; ++jt) {
         const int64_t num = num0 + jt;
         const int ec0 = (int)(4 * num - 4);             // live slots of this tip = slot id of its first new slot
@@ -886,18 +940,22 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
                 consider(a, sl, e2, f, e2 ? rv : -1);
             }
         } else {
-            // (C) blocks whose speculative winner is dirty: all their slots again
+            // (C) blocks whose speculative winner is dirty: the evaluated slots of all their edges again (an edge created or
+            // taken over since the scan launch -- its slots are dirty -- is evaluated here or in (B): same value, same key)
             for (int k = 0; k < nres; ++k) {
-                const int64_t sl = (int64_t)s_rescan[k] * kTipThreads + tid;
-                if (tid < kTipThreads && sl < live0) {
+                const int64_t ek = (int64_t)s_rescan[k] * kTipThreads + tid;
+                if (tid < kTipThreads && ek < nedge0) {
+                    const int sl = p.er_i[(int64_t)10 * p.ecap + ek];
                     double a, f; int e2, rv;
-                    place_eval_slot(p, dis, (int)sl, a, f, e2, rv);
-                    consider(a, (int)sl, e2, f, e2 ? rv : -1);
+                    place_eval_slot(p, dis, sl, a, f, e2, rv);
+                    consider(a, sl, e2, f, e2 ? rv : -1);
                 }
             }
         }
         // slots >= 4*num-4 (and < 4M-4) all carry the tuple (0,0,2): the first of them competes
         if (tid == 0 && (int64_t)ec0 < 4 * p.M - 4) consider(2.0, ec0, 0, 0.0, -1);
+        // ... and so does the smallest live slot with belong < e (the edge scan does not visit those; p.misc[0] is kept by the splits)
+        if (tid == 0) consider(2.0, p.misc[0], 0, 0.0, -1);
         {
             const double wa = wave_fmin(badd);
             const uint64_t wi = wave_umin64(badd == wa ? (uint64_t)(uint32_t)bidx : ~0ull);
@@ -920,14 +978,16 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
                 const int N = (int)p.N;
                 const int middle = placeId + N - 1, outside = placeId;
                 const int xe = eid, ye = brev >= 0 ? brev : p.rev[eid];
-                double i0d[K5], i1d[K5], i3d[K5];
-                int i0i[K5], i1i[K5], i3i[K5];
+                double i0d[K5], i1d[K5], i2d[K5], i3d[K5];
+                int i0i[K5], i1i[K5], i2i[K5], i3i[K5];
 #pragma unroll
                 for (int i = 0; i < K5; ++i) {
                     i0d[i] = p.cdis[ec * K5 + i]; i0i[i] = p.cid[ec * K5 + i];
                     i1d[i] = p.cdis[(ec + 1) * K5 + i]; i1i[i] = p.cid[(ec + 1) * K5 + i];
+                    i2d[i] = p.cdis[(ec + 2) * K5 + i]; i2i[i] = p.cid[(ec + 2) * K5 + i];
                     i3d[i] = p.cdis[(ec + 3) * K5 + i]; i3i[i] = p.cid[(ec + 3) * K5 + i];
                 }
+                const int mininel = p.misc[0];
                 const int x = p.belong[eid], y = p.e[eid];
                 const double originalDis = p.len[eid];
                 double cdx[K5], cdy[K5];
@@ -936,6 +996,7 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
                 for (int i = 0; i < K5; ++i) { cdx[i] = p.cdis[xe * K5 + i]; cix[i] = p.cid[xe * K5 + i]; cdy[i] = p.cdis[ye * K5 + i]; ciy[i] = p.cid[ye * K5 + i]; }
                 const double lenye = p.len[ye];
                 const int ox0 = p.cont[2 * xe], ox1 = p.cont[2 * xe + 1], oy0 = p.cont[2 * ye], oy1 = p.cont[2 * ye + 1];
+                const int kold = p.eidx[xe] >> 1;
                 p.e[xe] = middle; p.len[xe] = fracLen;
                 p.e[ye] = middle; p.len[ye] = lenye - fracLen;
                 double n0d[K5], n1d[K5];
@@ -1000,6 +1061,14 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
                 p.cont[2 * ye] = e0; p.cont[2 * ye + 1] = e3;
                 p.cont[2 * e2] = e0; p.cont[2 * e2 + 1] = e1;
                 p.cont[2 * e3] = -1; p.cont[2 * e3 + 1] = -1;
+                {   // edge records (as place_finish_and_update)
+                    const int nedge = (int)(2 * num - 2);
+                    er_write_edge(p, kold, e0, n0d, n0i, xe, cdx, cix, fracLen);
+                    er_write_edge(p, nedge, e1, n1d, n1i, ye, cdy, ciy, originalDis - fracLen);
+                    er_write_edge(p, nedge + 1, e3, md, mi, e2, i2d, i2i, addLen);
+                    const int lo = xe < ye ? xe : ye;
+                    if (lo < mininel) p.misc[0] = lo;
+                }
                 // what the split changed for later evaluations: the edge's two slots and the four new ones
                 dirty_add(ds, xe); dirty_add(ds, ye);
                 dirty_add(ds, e0); dirty_add(ds, e1); dirty_add(ds, e2); dirty_add(ds, e3);
@@ -1033,6 +1102,15 @@ int place_alloc(PlaceBuffers& p, int64_t N, int64_t M)
     DPR_HIP(hipMalloc(&p.cont, sizeof(int32_t) * (size_t)(16 * N)));
     DPR_HIP(hipMalloc(&p.cid, sizeof(int32_t) * (size_t)(40 * N)));
     DPR_HIP(hipMalloc(&p.cdis, sizeof(double) * (size_t)(40 * N)));
+    p.ecap = (2 * p.M + 63) / 64 * 64;                                         // 2M - 2 edges
+    DPR_HIP(hipMalloc(&p.er_d, sizeof(double) * (size_t)(11 * p.ecap)));
+    DPR_HIP(hipMalloc(&p.er_i, sizeof(int32_t) * (size_t)(12 * p.ecap)));
+    DPR_HIP(hipMalloc(&p.eidx, sizeof(int32_t) * (size_t)(8 * N)));
+    DPR_HIP(hipMalloc(&p.misc, sizeof(int32_t) * 16));
+    DPR_HIP(hipMemset(p.er_d, 0, sizeof(double) * (size_t)(11 * p.ecap)));
+    DPR_HIP(hipMemset(p.er_i, 0xff, sizeof(int32_t) * (size_t)(12 * p.ecap)));
+    DPR_HIP(hipMemset(p.eidx, 0, sizeof(int32_t) * (size_t)(8 * N)));
+    DPR_HIP(hipMemset(p.misc, 0, sizeof(int32_t) * 16));
     DPR_HIP(hipMalloc(&p.q_id, sizeof(int32_t) * (size_t)(4 * N + 64)));      // BFS frontier: every slot at most once
     DPR_HIP(hipMalloc(&p.q_from, sizeof(int32_t) * (size_t)(2 * N + 64)));
     DPR_HIP(hipMalloc(&p.q_dis, sizeof(double) * (size_t)(4 * N + 64)));
@@ -1052,7 +1130,8 @@ int place_alloc(PlaceBuffers& p, int64_t N, int64_t M)
 
 void place_free(PlaceBuffers& p)
 {
-    void* ptrs[] = { p.head, p.e, p.nxt, p.belong, p.rev, p.len, p.cid, p.cdis, p.q_id, p.q_from, p.q_dis, p.partials, p.partials_multi, p.cont };
+    void* ptrs[] = { p.head, p.e, p.nxt, p.belong, p.rev, p.len, p.cid, p.cdis, p.q_id, p.q_from, p.q_dis, p.partials, p.partials_multi, p.cont,
+                     p.er_d, p.er_i, p.eidx, p.misc };
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     p = PlaceBuffers();
@@ -1141,6 +1220,12 @@ int place_import_backbone(PlaceBuffers& p, int64_t m, hipStream_t s)
             hipLaunchKernelGGL(place_backbone_lists_kernel, dim3(1), dim3(64), 0, s, p, t0, t1);
         }
     }
+    {   // edge records of the imported tree (the lists are final now)
+        const int32_t m0[2] = { 0x7fffffff, 0 };
+        DPR_HIP(hipMemcpyAsync(p.misc, m0, sizeof m0, hipMemcpyHostToDevice, s));
+        DPR_HIP(hipStreamSynchronize(s));      // (m0 is a stack variable)
+        hipLaunchKernelGGL(place_pack_edges_kernel, dim3((unsigned)((nslots + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, nslots);
+    }
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
@@ -1158,8 +1243,7 @@ int place_tips(PlaceBuffers& p, const double* d_dis0, int64_t ldb, int64_t tip0,
     int64_t k = 0;
     while (k < count) {
         const int64_t tip = tip0 + k;
-        const int64_t live = 4 * tip - 4;
-        const int nblk = (int)((live + kTipThreads - 1) / kTipThreads);
+        const int nblk = (int)((2 * tip - 2 + kTipThreads - 1) / kTipThreads);      // blocks of the edge scan
         const int nb = (int)(count - k < kMultiB ? count - k : kMultiB);
         if (off || tip < min_tip || nb < 2 || (int64_t)nblk * kMultiB > p.nparts_multi) {
             if (int rc = place_tip(p, d_dis0 + k * ldb, tip, d_trace, s)) return rc;
@@ -1178,10 +1262,9 @@ int place_tips(PlaceBuffers& p, const double* d_dis0, int64_t ldb, int64_t tip0,
 
 int place_tip(PlaceBuffers& p, const double* d_dis, int64_t tip, double* d_trace, hipStream_t s)
 {
-    const int64_t live = 4 * tip - 4;
-    const int nblk = (int)((live + kTipThreads - 1) / kTipThreads);
     PlacePartial* parts = reinterpret_cast<PlacePartial*>(p.partials);
-    hipLaunchKernelGGL(place_tip_kernel, dim3((unsigned)nblk), dim3(kTipThreads), 0, s, p, d_dis, tip, parts);
+    const int nblk = (int)((2 * tip - 2 + kTipThreads - 1) / kTipThreads);
+    hipLaunchKernelGGL(place_tip_edges_kernel, dim3((unsigned)nblk), dim3(kTipThreads), 0, s, p, d_dis, tip, parts);
     hipLaunchKernelGGL(place_update_kernel, dim3(1), dim3(kUpdThreads), 0, s, p, (const PlacePartial*)parts, nblk, tip, d_trace);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
