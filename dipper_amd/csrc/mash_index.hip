@@ -341,7 +341,7 @@ __global__ __launch_bounds__(64) void mash_dist_index_kernel(MashIndex ix, const
                                                              int64_t cchunks, double* __restrict__ out, int64_t ld,
                                                              int mirror, int transposed)
 {
-    __shared__ uint16_t cnt[kIC];
+    __shared__ __attribute__((aligned(16))) uint16_t cnt[kIC];
     const int lane = threadIdx.x;
     for (int64_t task = (int64_t)blockIdx.x; task < cchunks * nr; task += (int64_t)gridDim.x) {
     const int64_t c = task / nr, t = task - c * nr;
@@ -375,16 +375,25 @@ __global__ __launch_bounds__(64) void mash_dist_index_kernel(MashIndex ix, const
             if (lo < hi0 && ix.uniq[lo] == v) { start = ix.off[lo]; len = ix.off[lo + 1] - start; dense = ix.dblk[lo]; }
         }
         unsigned long long todo = __builtin_amdgcn_ballot_w64(len > 0);
-        // the row's values in ascending order; the first 64 postings of the NEXT value are loaded while this one is applied
-        // the first load of a value (64 postings, or tips 0..63 of its dense block) is issued while the previous value is applied
-        auto first_load = [&](int l) -> uint32_t {
+        // the row's values in ascending order
+        // the loads of the NEXT value are issued while this one is applied: the first 64 postings, or -- dense value -- the whole
+        // block of positions (4 words per lane: tips 2 lane, 2 lane + 1 of each quarter of the chunk)
+        constexpr int kPQ = kIC / 128;
+        auto first_load = [&](int l, uint32_t* w) {
             const int dn = __builtin_amdgcn_readlane(dense, l);
-            if (dn >= 0) return (uint32_t)ix.dense[(int64_t)dn * kIC + lane];
+            if (dn >= 0) {
+                const uint32_t* __restrict__ db = reinterpret_cast<const uint32_t*>(ix.dense + (int64_t)dn * kIC);
+#pragma unroll
+                for (int q = 0; q < kPQ; ++q) w[q] = db[64 * q + lane];
+                return;
+            }
             const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)start, l), ln = (uint32_t)__builtin_amdgcn_readlane((int)len, l);
-            return (uint32_t)lane < ln ? ix.post[st + lane] : kINone;
+            w[0] = (uint32_t)lane < ln ? ix.post[st + lane] : kINone;
         };
-        uint32_t pre = kINone;
-        if (todo) pre = first_load((int)__builtin_ctzll(todo));
+        uint32_t pre[kPQ];
+#pragma unroll
+        for (int q = 0; q < kPQ; ++q) pre[q] = kINone;
+        if (todo) first_load((int)__builtin_ctzll(todo), pre);
         while (todo) {
             const int l = (int)__builtin_ctzll(todo);
             todo &= todo - 1;
@@ -393,20 +402,28 @@ __global__ __launch_bounds__(64) void mash_dist_index_kernel(MashIndex ix, const
             const int m = __builtin_amdgcn_readlane(mu, l);
             const int dn = __builtin_amdgcn_readlane(dense, l);
             const int nb = b0 + l;                  // position of the value's first copy in the row sketch
-            const uint32_t ent0 = pre;
-            if (todo) pre = first_load((int)__builtin_ctzll(todo));
+            uint32_t cur[kPQ];
+#pragma unroll
+            for (int q = 0; q < kPQ; ++q) cur[q] = pre[q];
+            const uint32_t ent0 = cur[0];
+            if (todo) first_load((int)__builtin_ctzll(todo), pre);
             // reference's condition first_A(v) + nb - c < S  <=>  c - first_A(v) > nb - S
             const int K = nb - S;
-            if (dn >= 0) {                          // dense value: positions by tip, counters in tip order
-                const uint16_t* __restrict__ db = ix.dense + (int64_t)dn * kIC;
-                uint32_t ps[kIC / 64];
-                ps[0] = ent0;
+            if (dn >= 0) {
+                // Dense value: positions by tip, counters in tip order -- TWO tips per lane and step in packed 16-bit arithmetic
+                // (round 5: this path is ~all of the work on clonal data; halves its LDS and vector instructions).  Counters and
+                // positions stay below 4 096, K = nb - S lies in [-S, -1], an absent tip carries position 0x7F7F: every
+                // difference fits 16 signed bits, and  K - (c - pos) < 0  <=>  c - pos > K  (absent: never).
+                typedef short pk16 __attribute__((ext_vector_type(2)));
+                uint32_t* c32 = reinterpret_cast<uint32_t*>(cnt);
+                const pk16 Kp = { (short)K, (short)K }, mp = { (short)m, (short)m };
 #pragma unroll
-                for (int q = 1; q < kIC / 64; ++q) ps[q] = (uint32_t)db[64 * q + lane];
-#pragma unroll
-                for (int q = 0; q < kIC / 64; ++q) {
-                    const int c0 = (int)cnt[64 * q + lane];
-                    if (c0 - (int)ps[q] > K) cnt[64 * q + lane] = (uint16_t)(c0 + m);      // absent: position 65535, never true
+                for (int q = 0; q < kIC / 128; ++q) {
+                    const uint32_t cw = c32[64 * q + lane];
+                    const pk16 cv = __builtin_bit_cast(pk16, cw), pv = __builtin_bit_cast(pk16, cur[q]);
+                    const pk16 t = Kp - (cv - pv);
+                    const pk16 inc = (t >> 15) & mp;                     // all ones where the reference's condition holds
+                    c32[64 * q + lane] = __builtin_bit_cast(uint32_t, (pk16)(cv + inc));
                 }
                 continue;
             }
@@ -539,7 +556,7 @@ int mash_index_build(MashBuffers& m, hipStream_t s)
         if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);
         if (e1 == hipSuccess) e1 = hipMalloc(&ix.dblk, sizeof(int32_t) * (size_t)nu);
         if (e1 == hipSuccess) e1 = hipMalloc(&ix.dense, sizeof(uint16_t) * ((size_t)nd * kIC + 64));
-        if (e1 == hipSuccess) e1 = hipMemsetAsync(ix.dense, 0xff, sizeof(uint16_t) * ((size_t)nd * kIC + 64), s);
+        if (e1 == hipSuccess) e1 = hipMemsetAsync(ix.dense, 0x7f, sizeof(uint16_t) * ((size_t)nd * kIC + 64), s);      // absent: position 0x7F7F
         if (e1 == hipSuccess) {
             hipLaunchKernelGGL(mi_dense_index_kernel, dim3(gu), dim3(kIThreads), 0, s, flag, dscan, (int64_t)nu, ix.dblk);
             hipLaunchKernelGGL(mi_dense_fill_kernel, dim3(gt), dim3(kIThreads), 0, s, ix.post, g, ix.dblk, total, ix.dense);
