@@ -338,7 +338,7 @@ def rapidnj_probe(dip, n, cores, tmp, budget_s=30.0):
 
 
 # ---------------------------------------------------------------------------------------------------------
-CLI_PHASE_TAGS = (("input_ms", "Input in:"), ("device_ready_ms", "Device ready in:"), ("tree_ms", "Tree Created in:"), ("sketch_ms", "Sketch Created in:"),
+CLI_PHASE_TAGS = (("input_ms", "Input in:"), ("device_ready_ms", "Device ready in:"), ("parsed_ms", "Parsed in:"), ("tree_ms", "Tree Created in:"), ("sketch_ms", "Sketch Created in:"),
                   ("distance_ms", "Distance Operation Time"), ("tree_op_ms", "Tree Operation Time"))
 
 
@@ -365,7 +365,7 @@ def cli_step(fa, out, device, threads):
     if r.returncode != 0:
         raise RuntimeError("dipper failed: " + r.stderr[-400:])
     ph = cli_phases(r.stderr)
-    return dt, {k: ph[v] for k, v in (("input", "input_ms"), ("tree", "tree_ms"), ("device_ready", "device_ready_ms")) if v in ph}
+    return dt, {k: ph[v] for k, v in (("input", "input_ms"), ("tree", "tree_ms"), ("device_ready", "device_ready_ms"), ("parsed", "parsed_ms")) if v in ph}
 
 
 def join_comm(dip, rank, world, dist):
@@ -512,13 +512,14 @@ def main():
                 cli_step(fa, nwk, local_rank, threads)
             barrier()
             t0 = time.perf_counter()
-            walls, inputs, trees, readies = [], [], [], []
+            walls, inputs, trees, readies, parses = [], [], [], [], []
             for _ in range(args.steps):
                 dt, ph = cli_step(fa, nwk, local_rank, threads)
                 walls.append(dt * 1e3)
                 inputs.append(ph.get("input", float("nan")))
                 trees.append(ph.get("tree", float("nan")))
                 readies.append(ph.get("device_ready", float("nan")))
+                parses.append(ph.get("parsed", float("nan")))
             barrier()
             dt_cli = time.perf_counter() - t0
             if dist is not None:
@@ -530,10 +531,14 @@ def main():
                    "command": "dipper -i m -I in.fa -O out.nwk -m 2 -d 2 --device <local rank>",
                    "steps": args.steps, "warmup": args.warmup, "host_threads_per_rank": threads,
                    "wall_ms": stats_ms(walls), "input_ms": stats_ms(inputs), "tree_ms": stats_ms(trees),
-                   "other_ms": stats_ms(others), "hip_startup_ms": stats_ms(readies),
-                   "note": "wall = input + tree + other; input ends when BOTH the parsed FASTA and the device context are there, "
-                           "hip_startup = dpr_create on the helper thread (runtime start-up + code object load), other = process "
-                           "start + Newick write + exit",
+                   "other_ms": stats_ms(others), "hip_startup_ms": stats_ms(readies), "parse_ms": stats_ms(parses),
+                   "input_bound_by": {"device_ready": int(sum(1 for r_, p_ in zip(readies, parses) if r_ >= p_)),
+                                      "parse": int(sum(1 for r_, p_ in zip(readies, parses) if r_ < p_))},
+                   "note": "wall = input + tree + other; input ends when BOTH the parsed FASTA (parse_ms: file read + packed, host side) and "
+                           "the device context (hip_startup_ms: dpr_create on the helper thread = runtime start-up + code object load; "
+                           "waits for the PREVIOUS process's teardown in the kernel driver when steps run back to back) are there -- "
+                           "input_bound_by counts which side ended it per step; other = process start + Newick write + exit "
+                           "(mostly the driver taking this process's GPU context apart)",
                    "tips_per_s_median": n / (float(np.median(walls)) * 1e-3) if walls else None,
                    "fasta_bytes": os.path.getsize(fa), "newick_bytes": os.path.getsize(nwk) if os.path.exists(nwk) else None}
             log(f"[bench r{rank}] CLI steps: {cli['wall_ms']}")

@@ -15,6 +15,20 @@ namespace dpr {
 
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
+int log_level(const char* category)
+{
+    const char* e = std::getenv("DPR_LOG");
+    if (!e) return 0;
+    const size_t n = std::strlen(category);
+    for (const char* p = e; *p;) {
+        const char* q = std::strchr(p, ',');
+        const size_t len = q ? (size_t)(q - p) : std::strlen(p);
+        if (len >= n && std::strncmp(p, category, n) == 0 && (len == n || p[n] == '=')) return len == n ? 1 : std::atoi(p + n + 1);
+        if (!q) break;
+        p = q + 1;
+    }
+    return 0;
+}
 int hip_fail(hipError_t e, const char* what)
 {
     // same wording family as the reference's "Gpu_ERROR: ..." messages
@@ -554,7 +568,7 @@ int dpr_create(dpr_ctx** out, int device)
 {
     if (!out) { set_error("dpr_create: null out"); return DPR_ERR_ARG; }
     *out = nullptr;
-    const bool tlog = std::getenv("DPR_CLI_TIMING") != nullptr;
+    const bool tlog = log_level("cli") > 0;
     const auto tc0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (tlog) std::fprintf(stderr, "  dpr_create: %s at %.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
@@ -1312,7 +1326,12 @@ int dpr_get_prune_stats(dpr_ctx* c, uint64_t* units_scanned, uint64_t* units_per
     return DPR_OK;
 }
 
-// debug (DPR_NJ_ITERSTATS=1): per iteration [units scanned, max units of one block]
+
+// microbenchmark: wall time per launch of a chain of trivial dependent kernels (eager or graph replay)
+__global__ void dpr_nop_kernel(unsigned long long* p) { if (threadIdx.x == 0 && blockIdx.x == 0 && p[7] == 12345) p[6] = 1; }
+
+__global__ void dpr_mark_kernel(unsigned long long* out, long long idx) { if (threadIdx.x == 0 && blockIdx.x == 0) out[idx] = (unsigned long long)idx + 1ull; }
+
 int dpr_get_nj_progress(dpr_ctx* c, int64_t* iterations_done, int64_t* active)
 {
     if (!c || !c->have_matrix) { set_error("dpr_get_nj_progress: call dpr_dist_matrix first"); return DPR_ERR_STATE; }
@@ -1329,20 +1348,6 @@ int dpr_get_njp_shape(dpr_ctx* c, int64_t* positions, int* row_groups, int* stri
     if (!c || !c->have_matrix || !c->nj[0].pr.active) { set_error("dpr_get_njp_shape: no pruned NJ state"); return DPR_ERR_STATE; }
     return njp_shape(c->nj[0].pr, positions, row_groups, strips, post2, scan_grid);
 }
-
-int dpr_get_iterstats(dpr_ctx* c, uint64_t* out, int64_t iters)
-{
-    if (!c || !c->have_matrix || !c->nj[0].pr.iterstats) { set_error("dpr_get_iterstats: not enabled"); return DPR_ERR_STATE; }
-    DPR_HIP(hipStreamSynchronize(c->stream));   // the plain copies below run on the null stream, which does not wait for c->stream
-    // iters > N - 2 reads on into the tail (iters = N + 33 returns the 64 phase-clock words behind the 2N + 2 counters)
-    DPR_HIP(hipMemcpy(out, c->nj[0].pr.iterstats, sizeof(uint64_t) * (size_t)(2 * iters), hipMemcpyDeviceToHost));
-    return DPR_OK;
-}
-
-// microbenchmark: wall time per launch of a chain of trivial dependent kernels (eager or graph replay)
-__global__ void dpr_nop_kernel(unsigned long long* p) { if (threadIdx.x == 0 && blockIdx.x == 0 && p[7] == 12345) p[6] = 1; }
-
-__global__ void dpr_mark_kernel(unsigned long long* out, long long idx) { if (threadIdx.x == 0 && blockIdx.x == 0) out[idx] = (unsigned long long)idx + 1ull; }
 
 int dpr_launch_bench(dpr_ctx* c, int nlaunch, int grid, int use_graph, float* us_per_launch)
 {
@@ -1615,7 +1620,7 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
     const bool overlap_allowed = source == DPR_SRC_MASH && !std::getenv("DPR_PLACE_NO_OVERLAP");
     // (several ranks: every rank must take the same decisions -- the batches' all-gathers are enqueued on the stream the decision
     //  picks -- and a rank's share of a batch is 1 / G of the pairs, i.e. the short side: every batch beside, as in round 3)
-    const bool overlap_always = overlap_allowed && (sharded || std::getenv("DPR_PLACE_OVERLAP_ALWAYS") != nullptr);
+    const bool overlap_always = overlap_allowed && sharded;
     double* rows_buf[2] = { nullptr, nullptr };
     const size_t row_bytes = sizeof(double) * (size_t)(per * W * ldb);
     if (source != DPR_SRC_MATRIX) {
@@ -1630,14 +1635,7 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
         // blocks each, on the context's stream) must not queue behind them
         int least = 0, greatest = 0;
         DPR_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        if (const char* e = std::getenv("DPR_PLACE_DIST_CUMASK")) {      // experiment: keep some CUs free of distance kernels
-            const uint32_t pat = (uint32_t)std::strtoul(e, nullptr, 16);
-            uint32_t mask[8];
-            for (uint32_t& w : mask) w = pat;
-            DPR_HIP(hipExtStreamCreateWithCUMask(&c->stream2, 8, mask));
-        } else {
-            DPR_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, least));
-        }
+        DPR_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, least));
     }
     std::vector<hipEvent_t> sync_ev;                             // fill-done / tree-done events of this run
     auto new_event = [&](hipEvent_t* e) -> int { DPR_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming)); sync_ev.push_back(*e); return DPR_OK; };

@@ -550,8 +550,7 @@ int dc_cluster_phase(PlaceBuffers& p, const int32_t* h_cluster_id, int64_t N, in
         if (d_out) (void)hipFree(d_out);
         d_i32 = nullptr; d_i64 = nullptr; d_jobs = nullptr; d_out = nullptr;
     };
-    int64_t big_m = 64;         // clusters above this size get a whole workgroup (DPR_DC_BIG_CLUSTER: validation / tuning)
-    if (const char* e = std::getenv("DPR_DC_BIG_CLUSTER")) big_m = std::atoll(e);
+    const int64_t big_m = 64;   // clusters above this size get a whole workgroup
     auto run = [&]() -> int {
         while (g0 < ncl) {
             // ---- a group of clusters whose distance blocks fit the budget

@@ -15,6 +15,10 @@ constexpr int kScanBlocks = 8192;         // capacity of the partials array (sca
 constexpr int kThreads = 256;
 
 void set_error(const std::string& msg);
+// stderr logging of the library, ONE variable: DPR_LOG = comma list of categories, optionally with a level: epoch[=1|2|3]
+// (pruned NJ: epoch rebuilds and graph captures; 2: + units listed per watched window; 3: + laps of a rebuild), mash (kernel
+// choice, index sizes), import (backbone import rounds), cli (start-up and phase laps of the `dipper` command).  0 = off.
+int log_level(const char* category);
 int hip_fail(hipError_t e, const char* what);
 #define DPR_HIP(call)                                            \
     do {                                                         \
@@ -148,7 +152,6 @@ struct NjPruned {
     int32_t* list = nullptr;         // units selected by the tests (sub-unit mask << 28 | strip << 18 | group)
     int32_t *blk_cb = nullptr, *blk_g0 = nullptr;   // test block -> (strip, first group)
     int nprep = 0;
-    uint64_t* iterstats = nullptr;   // optional (DPR_NJ_ITERSTATS): per iteration units scanned, max per block
 };
 
 // optional per-kernel timing of the pruned NJ loop (dpr_ctx_set_nj_kernel_timing): the run is enqueued eagerly and every

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include <cstdlib>
+#include <cstring>
 
 namespace dpr {
 
@@ -636,27 +637,37 @@ void mash_free(MashBuffers& m)
 
 // Kernel choice for the row-against-columns shapes (read at every call: the tests switch kernels inside one process).
 // The inverted index (mash_index.hip) wherever it can be built: 4.4-10 G pairs/s at any divergence (20 000 reads x 3 kb);
-// without it (no memory, more than 2^32 sketch values, DPR_MASH_INDEX=0) the run-encoded tokens while the sketches resemble the
+// without it (no memory, more than 2^32 sketch values, DPR_MASH_KERNEL=noindex) the run-encoded tokens while the sketches resemble the
 // reference list (3.4 G pairs/s at 13 tokens per sketch, 0.8 G at 97; up to 150 tokens), else the bucket tables (0.4-0.7 G),
-// which also serve the cluster jobs.  DPR_MASH_INDEX=1 / 0 forces / forbids the index; DPR_MASH_TOKENS_MAX, when set, gives
-// the token kernel every sketch set with at most that many tokens per sketch (ahead of the index).
-static bool mash_tok_forced() { return std::getenv("DPR_MASH_TOKENS_MAX") != nullptr; }
-static double mash_tok_max()
+// which also serve the cluster jobs.  ONE switch for tests and A/B runs, DPR_MASH_KERNEL = auto (default) | index (always) |
+// noindex (the automatic choice without the index) | tokens | table | literal (the reference's merge, one thread per pair).
+enum MashKernel { kMkAuto = 0, kMkIndex, kMkNoIndex, kMkTokens, kMkTable, kMkLiteral };
+static int mash_kernel_choice()
 {
-    const char* e = std::getenv("DPR_MASH_TOKENS_MAX");
-    return e ? std::atof(e) : 150.0;
+    const char* e = std::getenv("DPR_MASH_KERNEL");
+    if (!e) return kMkAuto;
+    const char* names[] = { "auto", "index", "noindex", "tokens", "table", "literal" };
+    for (int k = 0; k < 6; ++k)
+        if (std::strcmp(e, names[k]) == 0) return k;
+    return kMkAuto;
+}
+static bool mash_tok_forced() { return mash_kernel_choice() == kMkTokens; }
+static double mash_tok_max()        // tokens per sketch up to which the token kernel is used
+{
+    const int c = mash_kernel_choice();
+    return c == kMkTokens ? 1e300 : (c == kMkTable || c == kMkLiteral) ? -1.0 : 150.0;
 }
 static int mash_index_policy()      // 1 always, 0 never, -1 automatic
 {
-    const char* e = std::getenv("DPR_MASH_INDEX");
-    return e ? std::atoi(e) : -1;
+    const int c = mash_kernel_choice();
+    return c == kMkIndex ? 1 : c == kMkAuto ? -1 : 0;
 }
 static bool mash_indexable(const MashBuffers& m) { return m.S <= 4096 && m.n >= 2 && m.n * (int64_t)m.S < (int64_t)0xFFFF0000ll; }
 
 // run encoding of all sketches against the distinct values of sketch 0 (see mash_dist_tokens_kernel)
 static int mash_encode(MashBuffers& m, hipStream_t s)
 {
-    if (std::getenv("DPR_MASH_LOOKUP")) return DPR_OK;            // A/B: the table kernel of round 1 everywhere
+    if (mash_kernel_choice() == kMkTable || mash_kernel_choice() == kMkLiteral) return DPR_OK;      // (A/B runs: no token kernel at all)
     const int S = m.S;
     DPR_HIP(hipMalloc(&m.tokens, sizeof(uint4) * (size_t)(m.n * S)));
     DPR_HIP(hipMalloc(&m.tok_cnt, sizeof(int32_t) * (size_t)m.n));
@@ -709,7 +720,7 @@ static int mash_encode(MashBuffers& m, hipStream_t s)
     double sum = 0;
     for (int32_t c : cnt) sum += c;
     m.tok_mean = sum / (double)ns;
-    if (std::getenv("DPR_MASH_LOG")) {
+    if (log_level("mash") > 0) {
         int32_t mx = 0;
         for (int32_t c : cnt) mx = c > mx ? c : mx;
         std::fprintf(stderr, "[mash] run encoding against the sketch of tip %lld (%d distinct values): %.1f tokens per sketch (sample of %lld, most %d)\n",
@@ -784,7 +795,7 @@ int mash_dist_rows(const MashBuffers& m, int64_t r0, int64_t nr, int rank, int w
 {
     if (nr <= 0 || ncols <= 0) return DPR_OK;
     // lower-triangle pairs (placement batches; single-GPU NJ with a mirror write): token kernel while the sketches
-    // resemble each other (at most DPR_MASH_TOKENS_MAX tokens per sketch on average, default 150 of up to S: measured break-even with the table kernel), else the table kernel
+    // resemble each other (at most 150 tokens per sketch on average, of up to S: the measured break-even with the table kernel), else the table kernel
     const bool mirror = full && world == 1 && r0 == 0;
     const bool tokens_ok = m.tokens && m.tok_mean <= mash_tok_max();
     const bool use_index = m.index.post && mash_index_policy() != 0 && (mash_index_policy() == 1 || !(mash_tok_forced() && tokens_ok));
@@ -810,7 +821,7 @@ int mash_dist_rows(const MashBuffers& m, int64_t r0, int64_t nr, int rank, int w
         DPR_HIP(hipGetLastError());
         return DPR_OK;
     }
-    if (m.S <= kLS && (!full || mirror) && world <= 1 && (transposed || !std::getenv("DPR_MASH_SIMPLE"))) {
+    if (m.S <= kLS && (!full || mirror) && world <= 1 && (transposed || mash_kernel_choice() != kMkLiteral)) {
         if (int rc = lookup_attr()) return rc;
         const size_t tlds = kTLds;
         dim3 tgrid((unsigned)((ncols + kLColsPerBlock - 1) / kLColsPerBlock), (unsigned)((nr + kLRows - 1) / kLRows));

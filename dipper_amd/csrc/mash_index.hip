@@ -574,7 +574,7 @@ int mash_index_build(MashBuffers& m, hipStream_t s)
 #undef MI_HIP
     cleanup();
     ix.chunks = chunks;
-    if (std::getenv("DPR_MASH_LOG"))
+    if (log_level("mash") > 0)
         std::fprintf(stderr, "[mash] inverted index: %lld chunks of %d tips, %u distinct (chunk, value) pairs of %lld entries, %u of them dense\n",
                      (long long)chunks, kIC, nu, (long long)total, ix.ndense);
     return DPR_OK;
@@ -595,7 +595,7 @@ int mash_dist_index(const MashBuffers& m, int64_t r0, int64_t nr, int64_t ncols,
     // 16 wavefronts per CU walk the tasks.  A grid of 100 000 small workgroups keeps the dispatcher busy and every wave slot
     // taken, and the tree kernels -- 2 launches per tip, up to 1 500 workgroups each -- then make NO progress beside it
     // (100 000 tips: distance 1.2 s + tree 2.0 s = 3.2 s, nothing hidden).
-    static const int share_waves = std::getenv("DPR_MASH_INDEX_SHARE_WAVES") ? std::atoi(std::getenv("DPR_MASH_INDEX_SHARE_WAVES")) : 20;
+    constexpr int share_waves = 20;
     if (m.share_chip && share_waves > 0 && blocks > 256ll * share_waves) blocks = 256ll * share_waves;
     const size_t pad = 0;
     hipLaunchKernelGGL(mash_dist_index_kernel, dim3((unsigned)blocks), dim3(64), pad, s, ix, m.sketches, m.S, m.n, r0, nr, ncols, cchunks,

@@ -49,41 +49,18 @@ static int64_t njp_big_p()
     static const int64_t v = std::getenv("DPR_NJ_BIG_P") ? std::atoll(std::getenv("DPR_NJ_BIG_P")) : 40000;
     return v;
 }
-// Round 4: njp_post2_kernel (light test blocks, maxima of the previous launch) can serve the small shape too: its test blocks
-// are then ONE strip x 256 row groups (kNS = 1: ~250 blocks at 30 000 positions, every lane one unit).  Bit-exact (every NJ
-// test passes on it), but MEASURED SLOWER at 30 000 tips: 505 vs 475 ms -- its UM blocks (512 slots + 512 positions each, the
-// position part and the slot part one behind the other) end 7 us after the launch's first stamp where the fused kernel's
-// update blocks end after 4.2 (profiles/r4/phases_post2_small_shape_*.txt); the test blocks (4.0 - 5.4 us) are not what
-// bounds the launch.  Opt-in: DPR_NJP_SMALL=post2.
-// (Also measured in round 4 and NOT kept -- commit 9d05741 holds it: njp_post3_kernel, the roles split again for the small shape
-//  (update by slot as in the fused kernel, light test blocks, maxima by position: 430 blocks instead of 1 018) and the list
-//  replaced by one cell per unit that the scan blocks read directly, i.e. no atomic at all.  Bit-exact on every NJ test and on
-//  the 10 000-tip parity runs, 507 ms against the fused kernel's 480 at 30 000 tips, 2.20 against 2.10 s at 100 000:
-//  profiles/r4/post3_cells_variants_*.txt, phases_post3_it*.txt -- its test blocks still end 6.1 us after the first stamp
-//  (start 1.1, select 2.0, seed candidates 4.4, tests 5.6): shorter blocks, the same number of dependent steps.
-//  Per kernel (profiles/r4/trace_summary_post3_cells_30k.txt): POST 8.27 -> 7.73 us, but SCAN 6.85 -> 8.29 us -- reading and
-//  compacting cells in all 256 scan blocks costs more than the atomics it removes.  Second version, commit 03fdc34: the same
-//  three roles with the atomic list (round 3's scan kernel) and a seed bound WITHOUT gathers -- the candidate's old q plus
-//  6 eabs / (n - 3), which is rigorous (derivation in that commit's kernel; fixed slacks below it give a different merge log,
-//  profiles/r4/seed_slack_listing_30k.txt) and lists 16 % more units: 482 vs 479 ms, POST 8.02 us, SCAN 7.26 us.  Its test
-//  blocks wait 1.6 us for loads issued before the winner is known (unit bounds, maxima): a dependent step costs ~1.5 us in
-//  these launches, whatever it fetches, because every kernel starts with all eight L2s cold.)
+// Round 4 measured the alternatives for the SMALL shape and kept none (history: commits 9d05741, 03fdc34; NOTES.md round 4 items
+// 5, 8, 20-25): njp_post2_kernel with one strip x 256 row groups per test block (505 vs 475 ms at 30 000 tips), a three-role
+// kernel with one cell per unit instead of the atomic list (507 ms), the same with the list and a seed bound without gathers
+// (482 ms: neutral); test blocks of 32 / 128 row groups (513 / 480 ms).  Round 5 removed their switches and instantiations:
+// the small shape is njp_post_kernel<64, 1>, the large one njp_post2_kernel<4> (DPR_NJP_POST2=0: the fused njp_post_kernel<256, 4>,
+// kept as the independent second implementation the tests compare it with).
 static bool njp_post2_on()
 {
     static const bool on = !(std::getenv("DPR_NJP_POST2") && std::atoi(std::getenv("DPR_NJP_POST2")) == 0);
     return on;
 }
-static bool njp_small_post2()
-{
-    static const bool on = njp_post2_on() && std::getenv("DPR_NJP_SMALL") && std::string(std::getenv("DPR_NJP_SMALL")) == "post2";
-    return on;
-}
-static int njp_tg_small()
-{
-    static const int v = std::getenv("DPR_NJ_TG_SMALL") ? std::atoi(std::getenv("DPR_NJ_TG_SMALL")) : (njp_small_post2() ? 256 : 64);
-    return v == 32 || v == 128 || v == 256 ? v : 64;
-}
-static int njp_tg(int64_t P) { return P < njp_big_p() ? njp_tg_small() : 256; }
+static int njp_tg(int64_t P) { return P < njp_big_p() ? 64 : 256; }
 // Strips per test block.  In the small shape a test block is one strip x 64 row groups (the post kernel is a chain of
 // dependent round trips there and all blocks are resident at once).  In the large shape one strip x 256 groups left
 // ~2 900 blocks of ~160 registers per thread, i.e. several rounds of resident blocks, each paying the whole chain (select,
@@ -91,12 +68,7 @@ static int njp_tg(int64_t P) { return P < njp_big_p() ? njp_tg_small() : 256; }
 // with them, all strips' loads in flight together: 23 us per launch (2 strips: +9 %, 8 strips one load ahead: +4 %, 16: +29 %;
 // the block that owns 256 row groups then needs 247 registers, two blocks per CU, and the grid still takes two rounds).
 constexpr int kBigNS = 4;
-static int njp_big_ns()
-{
-    static const int v = std::getenv("DPR_NJ_BIG_NS") ? std::atoi(std::getenv("DPR_NJ_BIG_NS")) : kBigNS;
-    return v == 2 ? v : kBigNS;
-}
-static int njp_ns(int64_t P) { return (njp_tg(P) != 256 || P < njp_big_p()) ? 1 : njp_big_ns(); }
+static int njp_ns(int64_t P) { return P < njp_big_p() ? 1 : kBigNS; }
 // strips that hold a valid unit for some group of the row block [g0, g0 + tg)
 __host__ __device__ inline int64_t njp_strips_of_rows(int64_t g0, int64_t tg, int64_t P)
 {
@@ -171,10 +143,9 @@ __global__ __launch_bounds__(kThreads) void njp_permute_kernel(const double* __r
 
 static void njp_launch_permute(const double* A, int64_t lda, double* B, int64_t ldb, const int32_t* perm, int64_t n, hipStream_t s)
 {
-    // blocks per row: one per 1 024 columns, 1 ... 64 (DPR_NJP_PERMUTE_CHUNKS; the first epoch of 100 000 tips: 97 / 80 / 70 ms
+    // blocks per row: one per 1 024 columns, 1 ... 64 (the first epoch of 100 000 tips: 97 / 80 / 70 ms
     // with 24 / 32 / 64, of 30 000 tips: 10.9 / 6.5 / 6.0 ms with 4 / 15 / 32 -- 120 and 9.0 ms with the rows spread over the XCDs)
-    static const int env_chunks = std::getenv("DPR_NJP_PERMUTE_CHUNKS") ? std::atoi(std::getenv("DPR_NJP_PERMUTE_CHUNKS")) : 0;
-    int64_t chunks = env_chunks > 0 ? env_chunks : (n + 1023) / 1024;
+    int64_t chunks = (n + 1023) / 1024;
     chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
     const int64_t gy = (n + 7) / 8;
     dim3 grid((unsigned)(8 * chunks), (unsigned)(gy < 32768 ? gy : 32768));
@@ -472,7 +443,6 @@ __global__ __launch_bounds__(kThreads) void njp_scan_kernel(NjState* h_st, const
             bk = wk;
         }
         if (tid == 0) {
-            if (a.iterstats) { atomicAdd(&a.iterstats[2 * it], (unsigned long long)scanned); atomicMax(&a.iterstats[2 * it + 1], (unsigned long long)scanned); }
             if (ub == 0) atomicAdd(&a.st->units_scanned, (unsigned long long)cnt);   // statistics
         }
     }
@@ -549,9 +519,8 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
     // block roles: test blocks first, then the update blocks (the other way round -- the short update blocks ahead of the
     // test blocks when the grid does not fit on the chip at once -- measured 5 % slower at 100 000 tips)
     const int bx = (int)blockIdx.x;
-    const bool upd_first = (a.flags & 2) != 0;
-    const bool test_block = upd_first ? bx >= h_nupd : bx < h_ntest;
-    const int tbi = upd_first ? bx - h_nupd : bx, ubi = upd_first ? bx : bx - h_ntest;
+    const bool test_block = bx < h_ntest;
+    const int tbi = bx, ubi = bx - h_ntest;
     const int tb = test_block ? a.sh_rank + tbi * a.sh_world : 0;      // this rank's tbi-th test block
     // hop 1: state line, scan records, and what each role can address without knowing the winner
     const int64_t it = h_st->itb;   // stable: the writer below only advances st->it
@@ -738,7 +707,6 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
                 // its column: 8 bytes into n different lines.  Stored write-through (sc1): as plain stores they leave n dirty
                 // 128-byte lines in L2 that the end-of-kernel write-back has to flush (NJ 515 -> 508 ms at 30 000 tips)
                 if (kRS) { if (njp_owns<true>(a, p)) __hip_atomic_store(a.D + njp_lrow<true>(a, p) * a.ld + px, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                else if (a.flags & 1) a.D[p * a.ld + px] = val;
                 else __hip_atomic_store(a.D + p * a.ld + px, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (i == last) {           // relabel: the node of the last slot now lives in slot y
                     new_slot = y;
@@ -961,7 +929,7 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
 // Roles.  T blocks (first in the grid: the longest chain) of 256 row groups x up to kNS strips, each ONE coarse cell:
 // t2_cmin[tb] <= every sub-unit bound of the cell (kept by this block alone) and, by the same monotonicity,
 // lb(unit) >= fl(fl(cmin - rmaxC) - cmaxC) -- a cell whose coarse bound exceeds the seed bound reads none of its 32 KB of unit
-// bounds (DPR_NJP_FLAGS=4 switches the skip off); one list append per wave.  UM blocks: block u does, for the reference slots
+// bounds; one list append per wave.  UM blocks: block u does, for the reference slots
 // [512 u, 512 u + 512), what needs the SLOT order (the chunk sums of the new node's row -- the canonical order of U[x] --, log,
 // state, relabel of the last slot) and, for the positions [512 u, 512 u + 512), every per-position store of the update (row
 // sums, row buffer, keys, the new node's column) plus the maxima and minima for the next launch: coalesced, where
@@ -1171,8 +1139,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
                         Un[pp] = u;
                         a.Ur[pp] = u / r1;
                         Rw[pp] = v;
-                        if (a.flags & 1) a.D[pp * a.ld + px] = v;
-                        else __hip_atomic_store(a.D + pp * a.ld + px, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(a.D + pp * a.ld + px, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         // (slot_of_pos of the last slot's position is being rewritten to y by the U part of some block: either value gives y here)
                         const int64_t new_slot = slot == (int)last ? y : (int64_t)slot;
                         a.KA[pp] = nj_key_a_dev(new_slot, n1); a.KB[pp] = nj_key_b(new_slot);
@@ -1262,12 +1229,12 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
     // every block gathering the same 256 x 6 scattered words was ~70 % of the L2 requests of a post launch (673 k per launch
     // at 30 000 tips) and what stretched its second round trip from 1.1 to 3.5 us; the iteration's minimum by old q is in
     // the set by construction and a merge moves a q by ~1 / n of its size, so the bound hardly ever loosens
-    // (DPR_NJP_FLAGS bits 4-5: 0x10 one candidate per wave, 0x20 per 8 lanes, 0x30 all of them).
+    // (one candidate per wave, per 8 lanes, all of them: measured equal or slower, NOTES.md round 4 item 4).
     double qc = PINF;
     {
         const bool live = ci >= 0 && ci != px && cj != px && ci != py && cj != py;
         const double oq = live ? cand.q : PINF;
-        const int sgm = (a.flags >> 4) & 3;
+        constexpr int sgm = 0;      // (round 4: one candidate per wave / per 8 lanes / all of them measured equal or slower)
         bool lead = live;
         if (sgm != 3) {
             double gmin = oq;
@@ -1340,7 +1307,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
             for (int w = 0; w < 4; ++w) cC = fmax(cC, cm4[k][w]);
         const double lbC = fmin((cmin - rC) - cC, (cmin - cC) - rC);
         // the node leaving quarantine lowers unit bounds of this cell: those lanes must run (block-uniform decision)
-        if (!gz_here && !pz_here && !(lbC <= bound) && !(a.flags & 4)) {
+        if (!gz_here && !pz_here && !(lbC <= bound)) {
             NJP_STAMP(1, 6, false);
             if (a.dbg != nullptr && it == a.dbg_it && tid == 0) a.dbg[(2048 + bx) * 8 + 7] = 3ull;
             return;
@@ -1658,10 +1625,6 @@ int njp_build(NjBuffers& b, hipStream_t s)
     if (int rc = njp_alloc_epoch(q, N, N, q.arena_D, q.arena_slab[0], s)) return rc;
     q.utot0 = q.utot;
     DPR_HIP(hipMemcpyAsync(q.perm, perm.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, s));
-    if (std::getenv("DPR_NJ_ITERSTATS")) {
-        DPR_HIP(hipMalloc(&q.iterstats, sizeof(uint64_t) * (size_t)(2 * N + 2)));
-        DPR_HIP(hipMemsetAsync(q.iterstats, 0, sizeof(uint64_t) * (size_t)(2 * N + 2), s));
-    }
     njp_launch_permute(b.D, b.ld, q.D, q.ld, q.perm, N, s);
     q.range_known = false;
     if (njp_use_post2(q)) {        // the large-shape post kernel's bounds need the range of the entries (one pass, once per run)
@@ -1689,7 +1652,7 @@ static int njp_rebuild_epoch(NjBuffers& b, hipStream_t s, bool* rebuilt)
 {
     NjPruned& q = b.pr;
     *rebuilt = false;
-    const bool tlog = std::getenv("DPR_NJ_EPOCH_LOG") && std::atoi(std::getenv("DPR_NJ_EPOCH_LOG")) >= 3;
+    const bool tlog = log_level("epoch") >= 3;
     auto tprev = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!tlog) return;
@@ -1818,7 +1781,6 @@ static int njp_run_slots(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
 void njp_reset(NjPruned& q)
 {
     if (q.graph) { (void)hipGraphExecDestroy(q.graph); q.graph = nullptr; }
-    if (q.iterstats) { (void)hipFree(q.iterstats); q.iterstats = nullptr; }
     NjPruned fresh;
     fresh.arena_D = q.arena_D; fresh.arena_slab[0] = q.arena_slab[0]; fresh.arena_slab[1] = q.arena_slab[1];
     fresh.arena_slab_bytes = q.arena_slab_bytes; fresh.arena_N = q.arena_N; fresh.arena_ranks = q.arena_ranks;
@@ -1868,10 +1830,8 @@ static NjpArgs njp_args(NjBuffers& b, int v)
     a.cnt_ranks = sh ? (q.sh_virtual ? q.sh_world : 1) : 0;
     a.do_update = 1; a.do_tests = 1; a.do_rows = 1;
     a.log_x = b.log_x; a.log_y = b.log_y; a.log_bx = b.log_bx; a.log_by = b.log_by;
-    a.iterstats = (unsigned long long*)q.iterstats;
     a.dbg = q.dbg; a.dbg_it = q.dbg_it;
     a.t2_hdr = q.t2_hdr; a.t2_rmax = q.t2_rmax; a.t2_cmax = q.t2_cmax; a.t2_colmin = q.t2_colmin; a.t2_rowmin = q.t2_rowmin; a.t2_cmin = q.t2_cmin;
-    { static const int fl = std::getenv("DPR_NJP_FLAGS") ? std::atoi(std::getenv("DPR_NJP_FLAGS")) : 0; a.flags = fl; }
     return a;
 }
 
@@ -1888,7 +1848,7 @@ static int njp_launch_scan(NjBuffers& b, hipStream_t s, int v, bool rows)
 static bool njp_use_post2(const NjPruned& q)
 {
     const int ns = njp_ns(q.P);
-    return njp_post2_on() && njp_tg(q.P) == 256 && (ns == kBigNS || (ns == 1 && njp_small_post2())) && (q.dbg == nullptr || q.dbg_it >= 0);
+    return njp_post2_on() && ns == kBigNS && (q.dbg == nullptr || q.dbg_it >= 0);
 }
 
 static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
@@ -1904,16 +1864,11 @@ static int njp_launch_post(NjBuffers& b, hipStream_t s, int v, bool update)
         const unsigned um = !update ? 0u : (u2 > (unsigned)a.nrb ? u2 : (unsigned)a.nrb);
         a.nupd = (int)um;
         if ((unsigned)a.ntest + um == 0u) return DPR_OK;
-        if (a.ns == 1) hipLaunchKernelGGL((njp_post2_kernel<1>), dim3((unsigned)a.ntest + um), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
-        else hipLaunchKernelGGL((njp_post2_kernel<kBigNS>), dim3((unsigned)a.ntest + um), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
+        hipLaunchKernelGGL((njp_post2_kernel<kBigNS>), dim3((unsigned)a.ntest + um), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
         DPR_HIP(hipGetLastError());
         return DPR_OK;
     }
     if (a.tg == 64) hipLaunchKernelGGL((njp_post_kernel<64, 1, false>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
-    else if (a.tg == 32) hipLaunchKernelGGL((njp_post_kernel<32, 1, false>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
-    else if (a.tg == 128) hipLaunchKernelGGL((njp_post_kernel<128, 1, false>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
-    else if (a.ns == 1) hipLaunchKernelGGL((njp_post_kernel<256, 1, false>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
-    else if (a.ns == 2) hipLaunchKernelGGL((njp_post_kernel<256, 2, false>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
     else hipLaunchKernelGGL((njp_post_kernel<256, kBigNS, false>), dim3((unsigned)a.ntest + ublocks), dim3(kThreads), 0, s, a.st, (const NjRecord*)a.partials, (const unsigned long long*)a.cnt, a.blk_cb, a.blk_g0, (const int32_t*)a.pos_of_slot, a.ntest, a.nupd, a);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
@@ -2057,7 +2012,7 @@ static int njp_run_segment(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t 
     }
     const bool timing = b.kt && b.kt->stride > 0 && q.sh_world <= 1;
     const int kGraphIters = q.graph_iters;
-    const bool use_graph = q.sh_world <= 1 && todo >= kGraphIters && !timing && !std::getenv("DPR_NJ_NOGRAPH");
+    const bool use_graph = q.sh_world <= 1 && todo >= kGraphIters && !timing;      // (DPR_NJ_GRAPH_ITERS above `todo`: eager launches)
     if (use_graph && !q.graph) {
         const auto tg0 = std::chrono::steady_clock::now();
         hipGraph_t g = nullptr;
@@ -2069,7 +2024,7 @@ static int njp_run_segment(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t 
         if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
         DPR_HIP(hipGraphInstantiate(&q.graph, g, nullptr, nullptr, 0));
         DPR_HIP(hipGraphDestroy(g));
-        if (std::getenv("DPR_NJ_EPOCH_LOG"))
+        if (log_level("epoch") > 0)
             std::fprintf(stderr, "[njp] graph capture + instantiate (P=%lld): %.2f ms\n", (long long)q.P,
                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg0).count());
     }
@@ -2145,8 +2100,7 @@ int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
 {
     const char* e_min = std::getenv("DPR_NJ_EPOCH_MIN");
     const int64_t epoch_min = e_min ? std::atoll(e_min) : 2048;   // epochs smaller than this are not rebuilt
-    const char* e_pct = std::getenv("DPR_NJ_EPOCH_PCT");
-    const int64_t pct = e_pct ? std::atoll(e_pct) : 80;           // rebuild once n <= pct% of the epoch's positions
+    const int64_t pct = 80;           // rebuild once n <= pct% of the epoch's positions (85 / 90 measured: DESIGN.md section 4.4)
     NjPruned& q = b.pr;
     int64_t it = it0, left = todo;
     if (left <= 0) return q.slots_mode ? DPR_OK : njp_run_segment(b, it0, 0, s);
@@ -2177,7 +2131,7 @@ int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
                 // distance makes the row sums of ITS two rows NaN, those rows never win and stay to the end) and every queued
                 // kernel is a no-op -- stop here, dpr_nj_run reports DPR_ERR_NOCAND
                 if (!rebuilt) return DPR_OK;
-                if (std::getenv("DPR_NJ_EPOCH_LOG"))
+                if (log_level("epoch") > 0)
                     std::fprintf(stderr, "[njp] epoch rebuild at n=%lld: %.2f ms\n", (long long)n,
                                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
                 continue;
@@ -2209,7 +2163,7 @@ int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
             const double iters = (double)seg - (first_of_epoch ? 1.0 : 0.0);
             const double rate = iters >= 1.0 ? listed / (iters * (double)q.utot) : 0.0;
             const double per_it = iters >= 1.0 ? listed / iters : 0.0;       // units per iteration
-            if (const char* el = std::getenv("DPR_NJ_EPOCH_LOG")) if (std::atoi(el) >= 2)
+            if (log_level("epoch") >= 2)
                 std::fprintf(stderr, "[njp] watch at n=%lld: %.0f units per iteration over %.0f iterations (first of epoch %d, P=%lld, utot=%lld, scan grid %d)\n",
                              (long long)(b.N - it), per_it, iters, (int)first_of_epoch, (long long)q.P, (long long)q.utot, q.scan_grid);
             if (iters >= 1.0 && rate > q.stream_frac) {
@@ -2221,7 +2175,7 @@ int njp_run(NjBuffers& b, int64_t it0, int64_t todo, hipStream_t s)
                 ++q.probe_fail_streak;
                 q.slots_probe_n = pn;
                 if (int rc = njp_to_slots(b, s)) return rc;
-                if (std::getenv("DPR_NJ_EPOCH_LOG"))
+                if (log_level("epoch") > 0)
                     std::fprintf(stderr, "[njp] %.0f %% of the units listed per iteration at n=%lld: handed over to the streaming loop; next pruned probe at n <= %lld\n",
                                  100.0 * rate, (long long)na, (long long)pn);
             } else if (!first_of_epoch) {

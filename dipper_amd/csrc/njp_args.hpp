@@ -58,8 +58,6 @@ struct NjpArgs {
     unsigned long long* cnt_all; int cnt_ranks;     // all local counter quadruples (the update role zeroes the next ones)
     int do_update, do_tests, do_rows;
     int32_t* log_x; int32_t* log_y; double* log_bx; double* log_by;
-    unsigned long long* iterstats;
-    int flags;        // experiments (DPR_NJP_FLAGS): 1 = column of the new node stored with plain stores instead of write-through (sc1)
     unsigned long long* dbg; int64_t dbg_it;     // DPR_NJ_PHASES=<iteration>: per-block phase stamps of that iteration (profiles/nj_phases.py)
     // njp_post2_kernel (large shape): what its producer blocks hand to its test blocks
     void* t2_hdr; double* t2_rmax; double* t2_cmax; double* t2_colmin; double* t2_rowmin; double* t2_cmin;

@@ -275,7 +275,7 @@ static NjpArgs njr_args(NjBuffers& b)
     a.cnt_all = nullptr; a.cnt_ranks = 0;
     a.do_update = 1; a.do_tests = 1; a.do_rows = 1;
     a.log_x = b.log_x; a.log_y = b.log_y; a.log_bx = b.log_bx; a.log_by = b.log_by;
-    a.iterstats = nullptr; a.flags = 0; a.dbg = nullptr; a.dbg_it = -1;
+    a.dbg = nullptr; a.dbg_it = -1;
     a.t2_hdr = q.t2_hdr; a.t2_rmax = q.t2_rmax; a.t2_cmax = q.t2_cmax; a.t2_colmin = q.t2_colmin; a.t2_rowmin = q.t2_rowmin; a.t2_cmin = q.t2_cmin;
     a.rs_world = r.world; a.rs_rank = r.rank;
     a.rs_inv16 = (65536u + (unsigned int)r.world - 1u) / (unsigned int)r.world;
@@ -512,7 +512,7 @@ static int njr_run_segment(std::vector<NjBuffers*>& ranks, int64_t it0, int64_t 
     // Mailbox plan on a rank of its own: nothing between the kernels involves the host, so graph_iters iterations are captured
     // once per epoch and replayed (as njp.hip does); virtual ranks and the collective plan launch eagerly.
     const int gi = b0.pr.graph_iters;
-    const bool use_graph = ranks.size() == 1 && b0.rs.plan == kNjrMailbox && todo >= gi && !timing && !std::getenv("DPR_NJ_NOGRAPH");
+    const bool use_graph = ranks.size() == 1 && b0.rs.plan == kNjrMailbox && todo >= gi && !timing;
     if (use_graph && !b0.pr.graph) {
         hipGraph_t g = nullptr;
         DPR_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -541,8 +541,7 @@ int njr_run(std::vector<NjBuffers*>& ranks, int64_t it0, int64_t todo, hipStream
 {
     const char* e_min = std::getenv("DPR_NJ_EPOCH_MIN");
     const int64_t epoch_min = e_min ? std::atoll(e_min) : 2048;
-    const char* e_pct = std::getenv("DPR_NJ_EPOCH_PCT");
-    const int64_t pct = e_pct ? std::atoll(e_pct) : 80;
+    const int64_t pct = 80;
     NjBuffers& b0 = *ranks[0];
     int64_t it = it0, left = todo;
     if (left <= 0) return njr_run_segment(ranks, it0, 0, s);

@@ -487,11 +487,10 @@ static NjsArgs njs_args(NjBuffers& b, int64_t n, int64_t it, bool pending)
     a.n = n; a.it = it; a.has_pending = pending ? 1 : 0;
     a.rank = b.rank; a.world = b.world; a.plan = b.peer.plan;
     // blocks of the scan: the single-GPU grid (2 048) by default; a rank streams only 1 / world of the triangle, so a
-    // smaller grid may ramp and drain faster (DPR_NJS_GRID, profiles/njs_vworld_stats.py)
-    static const int env_grid = std::getenv("DPR_NJS_GRID") ? std::atoi(std::getenv("DPR_NJS_GRID")) : 0;
+    // smaller grid may ramp and drain faster (profiles/njs_vworld_stats.py)
     // (measured with 8 virtual ranks at 30 000 tips, round 4: 85.1 / 83.6 / 85.2 / 88.5 / 87.7 us per rank and iteration with
     //  512 / 768 / 1 024 / 1 536 / 2 048 blocks)
-    a.nparts = env_grid >= 64 && env_grid <= kScanBlocks ? env_grid : (b.world >= 4 ? 768 : nj_scan_grid());
+    a.nparts = b.world >= 4 ? 768 : nj_scan_grid();
     a.poll_ticks = b.peer.poll_ticks;
     a.seq_base = b.peer.run_id << 32;
     a.fault_it = b.peer.fault_it; a.fault_rank = b.peer.fault_rank;

@@ -1172,7 +1172,7 @@ int place_import_backbone(PlaceBuffers& p, int64_t m, hipStream_t s)
         int* d_flags = nullptr;
         unsigned long long* pool_top = nullptr;
         // (a slot pointing away from the root has nearly all leaves behind it: its passers are the 5-records of their
-        // distances in id order, O(5 ln m); measured mean over all slots of a 500 000-tip backbone: see DPR_IMPORT_LOG)
+        // distances in id order, O(5 ln m); measured mean over all slots of a 500 000-tip backbone: see DPR_LOG=import)
         const unsigned long long pool_cap = (unsigned long long)nslots * 192ull;
         auto release = [&]() { void* q[] = { level, pcnt, poff, pid, pdis, d_flags, pool_top }; for (void* x : q) if (x) (void)hipFree(x); };
         hipError_t ae = hipMalloc(&level, sizeof(int32_t) * (size_t)nslots);
@@ -1200,7 +1200,7 @@ int place_import_backbone(PlaceBuffers& p, int64_t m, hipStream_t s)
             if (h[1]) bail = true;                 // passer pool exhausted or a node of very high degree
             else converged = (h[0] == 0);          // no slot finished in the last 16 rounds: all are done
         }
-        if (std::getenv("DPR_IMPORT_LOG")) {
+        if (log_level("import") > 0) {
             std::vector<int32_t> hc((size_t)nslots);
             (void)hipMemcpy(hc.data(), pcnt, sizeof(int32_t) * (size_t)nslots, hipMemcpyDeviceToHost);
             int mx = 0; double sum = 0;
@@ -1233,19 +1233,18 @@ int place_import_backbone(PlaceBuffers& p, int64_t m, hipStream_t s)
 // tips tip0 .. tip0 + count - 1, distance rows at d_dis0 + k * ldb: kMultiB tips per pair of launches once the tree is large
 // enough for the shared scan to outweigh the fix-up chain of the update launch (measured: 100 000 tips 1.61 -> 1.91 s, i.e. NOT
 // there; 300 000 tips 7.00 -> 6.76 s; 50 000 queries onto a 500 000-tip backbone 2.85 -> 2.59 s).  DPR_PLACE_MULTI_MIN moves the
-// switch (the tests run the multi-tip path from the third tip on), DPR_PLACE_SINGLE turns it off.
+// switch (the tests run the multi-tip path from the third tip on).
 int place_tips(PlaceBuffers& p, const double* d_dis0, int64_t ldb, int64_t tip0, int64_t count, double* d_trace, hipStream_t s)
 {
     // (read per call: the tests switch inside one process)
     const int64_t min_tip = std::getenv("DPR_PLACE_MULTI_MIN") ? std::atoll(std::getenv("DPR_PLACE_MULTI_MIN")) : 150000;
-    const bool off = std::getenv("DPR_PLACE_SINGLE") != nullptr;
     const bool big_block = std::getenv("DPR_PLACE_MULTI_BIG") != nullptr;      // tests: the 1024-thread update workgroup at any size
     int64_t k = 0;
     while (k < count) {
         const int64_t tip = tip0 + k;
         const int nblk = (int)((2 * tip - 2 + kTipThreads - 1) / kTipThreads);      // blocks of the edge scan
         const int nb = (int)(count - k < kMultiB ? count - k : kMultiB);
-        if (off || tip < min_tip || nb < 2 || (int64_t)nblk * kMultiB > p.nparts_multi) {
+        if (tip < min_tip || nb < 2 || (int64_t)nblk * kMultiB > p.nparts_multi) {
             if (int rc = place_tip(p, d_dis0 + k * ldb, tip, d_trace, s)) return rc;
             k += 1;
             continue;

@@ -152,7 +152,7 @@ void NJDeviceArrays::findNeighbourJoiningTree(DeviceContext& dev, std::vector<st
     if (done < 0) gpuCheck((int)done, "dpr_nj_run");
     const auto t1 = std::chrono::steady_clock::now();
     writeNewickFromMerges(output_, name, mx, my, bx, by, last);
-    if (std::getenv("DPR_CLI_TIMING")) {
+    if (cliLog()) {
         double dist_ms = 0, nj_ms = 0;
         dpr_get_timing(dev.ctx, &dist_ms, &nj_ms);
         std::cerr << "  device: distances " << dist_ms << " ms, NJ " << nj_ms << " ms; dpr_nj_run call "

@@ -9,6 +9,7 @@
 #include <ostream>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <iosfwd>
 #include <functional>
 #include <string>
@@ -180,6 +181,14 @@ struct KPlacementDeviceArraysDC : KPlacementDeviceArrays {
 // THE number formatter of every Newick writer of this build: the reference streams its doubles with the default
 // ostream settings (6 significant digits, %g style; src/neighborJoining.cu:252-270, src/placement_close_k.cu:568-643)
 inline void putLength(std::ostream& os, double v) { os << v; }
+// extra timing lines of the command on stderr: the category `cli` of the library's one logging variable, DPR_LOG
+inline bool cliLog()
+{
+    const char* e = std::getenv("DPR_LOG");
+    if (!e) return false;
+    const std::string s = std::string(",") + e + ",";
+    return s.find(",cli,") != std::string::npos || s.find(",cli=") != std::string::npos;
+}
 
 // Newick text of an NJ merge log (bookkeeping + print of src/neighborJoining.cu:233-270), iterative.
 void writeNewickFromMerges(std::ostream& os, const std::vector<std::string>& name, const std::vector<int32_t>& mx,

@@ -128,12 +128,10 @@ int main(int argc, char** argv)
     // This process lives for one tree: what the HIP runtime sets up and the kernel driver tears down around it counts.  Two of
     // ROCr's / HIP's own switches, set for THIS process only and only when the caller has not set them: no SDMA queues (the few
     // copies of a run go through shader copies) and at most two hardware queues (the runs use at most two streams at a time):
-    // the whole command, 30 000 x 10 000 back to back, 987 -> 920 ms (profiles/r3/cli_env_sweep.jsonl).  DPR_CLI_RUNTIME_DEFAULTS=1
-    // leaves the runtime's defaults alone.
-    if (!std::getenv("DPR_CLI_RUNTIME_DEFAULTS")) {
-        setenv("HSA_ENABLE_SDMA", "0", 0);
-        setenv("GPU_MAX_HW_QUEUES", "2", 0);
-    }
+    // the whole command, 30 000 x 10 000 back to back, 987 -> 920 ms (profiles/r3/cli_env_sweep.jsonl; a caller who wants the
+    // runtime's defaults sets the two variables himself).
+    setenv("HSA_ENABLE_SDMA", "0", 0);
+    setenv("GPU_MAX_HW_QUEUES", "2", 0);
     auto inputStart = std::chrono::high_resolution_clock::now();
     auto vm = parseArguments(argc, argv);
     if (vm.count("help")) { std::cerr << kHelp << std::endl; return 0; }
@@ -383,6 +381,7 @@ int main(int argc, char** argv)
             Hook* h = static_cast<Hook*>(u);
             if (n >= 3 && (*h->pick)((long long)n) == 2) h->adev->reserveNJ(n);
         }, &hook);
+        const long long parsed_ms = ms_since(inputStart);      // the file is read and packed (host side of the input phase)
         std::vector<std::string> seqs;
         std::vector<int> ids;
         if (!packed.ok) {                         // FASTQ: serial parser + the per-sequence encoders
@@ -412,6 +411,7 @@ int main(int argc, char** argv)
         // (not a line of the reference: how much of the input phase was the HIP runtime coming up on the helper thread --
         //  the input phase ends when BOTH the parsed input and the device context are there)
         std::cerr << "Device ready in: " << (long long)adev.createMs() << " ms\n";
+        std::cerr << "Parsed in: " << parsed_ms << " ms\n";      // (not a line of the reference either: the host side alone)
         auto createArrayStart = std::chrono::high_resolution_clock::now();
         if (!aligned) {
             // the reference sketches only in placement/DC mode (-i r + NJ reads unsketched
@@ -454,20 +454,20 @@ int main(int argc, char** argv)
             auto t0 = std::chrono::high_resolution_clock::now();
             NJDeviceArrays njDeviceArrays;
             njDeviceArrays.getDismatrix(dev, (int)numSequences, params, nullptr);
-            if (std::getenv("DPR_CLI_TIMING")) std::cerr << "  getDismatrix call " << ms_since(t0) << " ms\n";
+            if (cliLog()) std::cerr << "  getDismatrix call " << ms_since(t0) << " ms\n";
             njDeviceArrays.findNeighbourJoiningTree(dev, names, *output_);
             std::cerr << "Tree Created in: " << ms_since(t0) << " ms\n";
         }
         // the tree is written: close the output and leave without running the static destructors of the HIP runtime
         output_.reset();
-        if (std::getenv("DPR_CLI_TIMING")) std::cerr << "Main in: " << ms_since(inputStart) << " ms\n";
+        if (cliLog()) std::cerr << "Main in: " << ms_since(inputStart) << " ms\n";
         std::cerr.flush();
         std::fflush(nullptr);
         // ... but the device buffers and streams ARE released here, by the process itself: left to the kernel driver, the ~15 GB of
         // live allocations of a 30 000-tip run delay the runtime start-up of the NEXT process by 0.35-0.45 s in four runs out of
         // ten on some hosts (30 runs each, back to back: none with this call, 12 without; the call itself costs nothing
-        // measurable -- profiles/r3/cli_exit_sweep.jsonl).  DPR_CLI_FAST_EXIT=1 skips it.
-        if (!std::getenv("DPR_CLI_FAST_EXIT")) { dpr_destroy(dev.ctx); dev.ctx = nullptr; }
+        // measurable -- profiles/r3/cli_exit_sweep.jsonl).
+        dpr_destroy(dev.ctx); dev.ctx = nullptr;
         // (DPR_CLI_NORMAL_EXIT=1: return through main and the exit handlers -- a profiler that writes its output at exit,
         //  rocprofv3 for one, sees nothing of a process that leaves through _exit)
         if (std::getenv("DPR_CLI_NORMAL_EXIT")) return 0;

@@ -251,8 +251,6 @@ int dpr_launch_bench(dpr_ctx *ctx, int nlaunch, int grid, int use_graph, float *
  * dpr_spin_stop (or max_ms at the latest) -- to see whether the latency-bound loops run at reduced clocks on an idle chip */
 int dpr_spin_start(dpr_ctx *ctx, int blocks, int max_ms);
 int dpr_spin_stop(dpr_ctx *ctx);
-/* debug, needs DPR_NJ_ITERSTATS=1: per iteration {units scanned, most units scanned by one block} */
-int dpr_get_iterstats(dpr_ctx *ctx, uint64_t *out, int64_t iters);
 
 /* tuning knobs of the streaming Q-argmin scan (process-wide): rows per work unit (16 or 64; +128 selects the
  * filtered candidate update), non-temporal loads (0/1), grid size (0 = default 2048, <= 8192).  Results never

@@ -46,7 +46,7 @@ with tempfile.TemporaryDirectory() as tmp:
     dt, r = run([EXE, "-i", "m", "-I", small, "-O", out, "-m", "2", "-d", "2"])
     print("64 tips end to end (HIP start-up + exit floor): %.0f ms" % (dt * 1e3))
     print("    " + " | ".join(l for l in r.stderr.splitlines() if " in:" in l))
-    os.environ["DPR_CLI_TIMING"] = "1"
+    os.environ["DPR_LOG"] = "cli"
     for extra in ([], ["--seed", "-1"]):
         dt, r = run([EXE, "-i", "m", "-I", fa, "-O", out, "-m", "2", "-d", "2"] + extra, reps=4)
         print("%d tips end to end %s: %.0f ms" % (n, extra, dt * 1e3))

@@ -3,5 +3,5 @@
 FA=$1
 for pause in 0 0 0 1 1; do
   sleep $pause
-  DPR_CLI_TIMING=1 ./dipper_amd/bin/dipper -i m -I $FA -O /tmp/o.nwk -m 2 -d 2 2>&1 | grep -E "dpr_create|Input in|Main in" | tr '\n' '|'; echo " (pause $pause s)"
+  DPR_LOG=cli ./dipper_amd/bin/dipper -i m -I $FA -O /tmp/o.nwk -m 2 -d 2 2>&1 | grep -E "dpr_create|Input in|Main in" | tr '\n' '|'; echo " (pause $pause s)"
 done

@@ -15,7 +15,7 @@ for mode in ("plain", "help", "true"):
     for r in range(runs):
         cmd = [exe, "-i", "m", "-I", fa, "-O", os.path.join(tmp, "o.nwk"), "-m", "2", "-d", "2"] if mode == "plain" else [exe, "--help"] if mode == "help" else ["/bin/true"]
         t0 = time.perf_counter()
-        p = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, DPR_CLI_TIMING="1"))
+        p = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, DPR_LOG="cli"))
         wall = (time.perf_counter() - t0) * 1e3
         main_ms = None
         for line in p.stderr.splitlines():

@@ -12,8 +12,8 @@ mbl = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-3
 seqs = _util.synth_reads(np.random.default_rng(11), n, 3000, mean_bl=mbl, lo=mbl / 10, hi=mbl * 10)
 seqs = [seqs[i] for i in np.random.default_rng(12).permutation(n)]
 res = {}
-for name, env in (("index", {"DPR_MASH_INDEX": "1"}), ("table", {"DPR_MASH_INDEX": "0", "DPR_MASH_TOKENS_MAX": "-1"})):
-    for k in ("DPR_MASH_INDEX", "DPR_MASH_TOKENS_MAX"):
+for name, env in (("index", {"DPR_MASH_KERNEL": "index"}), ("table", {"DPR_MASH_KERNEL": "table"})):
+    for k in ("DPR_MASH_KERNEL",):
         os.environ.pop(k, None)
     os.environ.update(env)
     d = dipper_amd.Dipper(0)

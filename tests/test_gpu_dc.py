@@ -140,7 +140,7 @@ def test_dc_mash_large_sketch_without_index_is_rejected(monkeypatch):
     clusters from a mis-laid block without any error)."""
     import dipper_amd
     from dipper_amd import capi
-    monkeypatch.setenv("DPR_MASH_INDEX", "0")
+    monkeypatch.setenv("DPR_MASH_KERNEL", "noindex")
     rng = np.random.default_rng(77)
     reads = [rng.choice(_util.BASES, size=2500).tobytes() for _ in range(300)]      # unrelated reads: ~S tokens per sketch
     d = dipper_amd.Dipper(0)

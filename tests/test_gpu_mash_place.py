@@ -81,8 +81,7 @@ def test_mash_dist_token_kernel_cases(orc, monkeypatch, S, k, kernel):
     import dipper_amd
     from dipper_amd import capi
     # (the library reads these at every sketch / distance call)
-    monkeypatch.setenv("DPR_MASH_INDEX", "1" if kernel == "index" else "0")
-    monkeypatch.setenv("DPR_MASH_TOKENS_MAX", "1e9" if kernel == "tokens" else "-1")   # the token kernel whatever the token counts are / never
+    monkeypatch.setenv("DPR_MASH_KERNEL", kernel)      # index | tokens (whatever the token counts are) | table
     rng = np.random.default_rng(S * 31 + k)
     L = 2500
     clonal = _util.synth_reads(rng, 60, L, mean_bl=3e-4, lo=3e-5, hi=3e-3)
@@ -250,7 +249,7 @@ def test_mash_index_kernel_several_chunks(orc, monkeypatch, S, k):
     assignment through dc_run's own test elsewhere."""
     import dipper_amd
     from dipper_amd import capi
-    monkeypatch.setenv("DPR_MASH_INDEX", "1")
+    monkeypatch.setenv("DPR_MASH_KERNEL", "index")
     rng = np.random.default_rng(S + k)
     L = 1500
     seqs = _util.synth_reads(rng, 700, L, mean_bl=5e-5, lo=5e-6, hi=5e-4)
@@ -288,7 +287,7 @@ def test_mash_index_kernel_edges(orc, monkeypatch, n, S, k):
     against the oracle's literal loop."""
     import dipper_amd
     from dipper_amd import capi
-    monkeypatch.setenv("DPR_MASH_INDEX", "1")
+    monkeypatch.setenv("DPR_MASH_KERNEL", "index")
     rng = np.random.default_rng(n * 131 + S * 7 + k)
     seqs = _reads(rng, n, 12, 220, related=(n % 2 == 1))
     seqs[0] = b"AC"                                   # shorter than k for k > 2: an all-padding sketch

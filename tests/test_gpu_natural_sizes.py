@@ -24,12 +24,11 @@ from tests import _util
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(os.environ.get("DPR_SKIP_NATURAL") == "1", reason="DPR_SKIP_NATURAL=1")]
 
-_OVERRIDES = ("DPR_NJ_EPOCH_MIN", "DPR_NJ_EPOCH_PCT", "DPR_NJP_GRID", "DPR_NJ_STREAM_FRAC", "DPR_NJ_ADAPTIVE",
-              "DPR_NJ_GRAPH_ITERS", "DPR_NJ_BIG_P", "DPR_NJ_MODE", "DPR_NJP_POST2", "DPR_NJP_FLAGS", "DPR_NJ_NOGRAPH",
-              "DPR_PLACE_BATCH", "DPR_PLACE_NO_OVERLAP", "DPR_PLACE_MULTI_MIN", "DPR_PLACE_SINGLE", "DPR_PLACE_MULTI_BIG",
-              "DPR_MASH_INDEX", "DPR_MASH_LOOKUP", "DPR_MASH_SIMPLE", "DPR_DC_BUDGET_MB", "DPR_EXACT_LITERAL",
-              "DPR_NJS_FAULT", "DPR_NJ_EXCHANGE", "DPR_NJP_SMALL", "DPR_NJ_TG_SMALL", "DPR_PLACE_OVERLAP_ALWAYS", "DPR_NJ_BIG_NS",
-              "DPR_NJP_PERMUTE_CHUNKS", "DPR_NJ_MULTI")
+# (every switch of the product that changes a plan, a launch shape or a kernel choice: INTEGRATION.md lists them all)
+_OVERRIDES = ("DPR_NJ_EPOCH_MIN", "DPR_NJP_GRID", "DPR_NJ_STREAM_FRAC", "DPR_NJ_ADAPTIVE", "DPR_NJ_GRAPH_ITERS", "DPR_NJ_BIG_P",
+              "DPR_NJ_MODE", "DPR_NJP_POST2", "DPR_NJ_EXCHANGE", "DPR_NJ_MULTI",
+              "DPR_PLACE_BATCH", "DPR_PLACE_NO_OVERLAP", "DPR_PLACE_MULTI_MIN", "DPR_PLACE_MULTI_BIG",
+              "DPR_MASH_KERNEL", "DPR_DC_BUDGET_MB", "DPR_EXACT_LITERAL", "DPR_EXACT_TOP_MEM", "DPR_IMPORT_SERIAL")
 
 
 @pytest.fixture(autouse=True)
