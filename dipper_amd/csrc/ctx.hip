@@ -1,15 +1,7 @@
-// C ABI of libdipper_hip.so (see include/dipper_hip.h).  Owns the device context, the streams and
-// the host-side orchestration of the hot path.  No CPU fallback: every compute entry point needs a
-// gfx950 device.
-#include "dpr_internal.hpp"
-
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <dlfcn.h>
-
-struct Id128 { char b[128]; };  // ncclUniqueId is 128 opaque bytes passed by value
+// C ABI of libdipper_hip.so (see include/dipper_hip.h): the device context, errors and logging, encoders, inputs, sketches,
+// measurement aids and test hooks.  The other entry points: ctx_comm.hip (ranks, exchanges), ctx_nj.hip (distance matrix, NJ),
+// ctx_place.hip (placement, exact mode, divide-and-conquer).  No CPU fallback: every compute entry point needs a gfx950 device.
+#include "ctx_internal.hpp"
 
 namespace dpr {
 
@@ -35,465 +27,10 @@ int hip_fail(hipError_t e, const char* what)
     g_err = std::string("Gpu_ERROR: ") + what + ": " + hipGetErrorString(e);
     return DPR_ERR_HIP;
 }
-
-// ---- RCCL, resolved at run time so that the single-GPU path has no link dependency ----------------
-struct Rccl {
-    void* lib = nullptr;
-    int (*GetUniqueId)(void*) = nullptr;
-    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
-    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
-    int (*CommDestroy)(void*) = nullptr;
-    int (*CommCount)(void*, int*) = nullptr;
-    int (*CommUserRank)(void*, int*) = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
-};
-
-static Rccl g_rccl;
-static int rccl_load()
-{
-    if (g_rccl.lib) return DPR_OK;
-    const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-    for (const char* nm : names) {
-        g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-        if (g_rccl.lib) break;
-    }
-    if (!g_rccl.lib) { set_error("cannot load librccl.so"); return DPR_ERR_COMM; }
-    g_rccl.GetUniqueId = (int (*)(void*))dlsym(g_rccl.lib, "ncclGetUniqueId");
-    g_rccl.CommInitRank = (int (*)(void**, int, Id128, int))dlsym(g_rccl.lib, "ncclCommInitRank");
-    g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(g_rccl.lib, "ncclAllGather");
-    g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
-    g_rccl.CommDestroy = (int (*)(void*))dlsym(g_rccl.lib, "ncclCommDestroy");
-    g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
-    g_rccl.CommCount = (int (*)(void*, int*))dlsym(g_rccl.lib, "ncclCommCount");
-    g_rccl.CommUserRank = (int (*)(void*, int*))dlsym(g_rccl.lib, "ncclCommUserRank");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
-        set_error("librccl.so lacks a required symbol");
-        return DPR_ERR_COMM;
-    }
-    return DPR_OK;
-}
+const std::string& last_error() { return g_err; }
 }  // namespace dpr
 
-struct dpr_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;   // distance rows of the next placement batch (created on first use)
-    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
-    int rank = 0, world = 1;  // RCCL rank/world, or world = number of virtual ranks
-    int vworld = 0;           // > 0: all ranks live in this context on one device (validation mode)
-    void* comm = nullptr;
-    std::vector<dpr::NjBuffers> nj = std::vector<dpr::NjBuffers>(1);  // one per rank held here
-    dpr::MsaBuffers msa;
-    dpr::MashBuffers mash;
-    dpr::PlaceBuffers place;
-    dpr::ExactBuffers exact;
-    double* place_trace = nullptr;   // [3N] (eid, frac, add) per placed tip
-    double* packed_lower = nullptr;  // MATRIX source, device
-    int64_t n_input = 0;
-    int have_matrix = 0;
-    bool nj_replicated = false;      // several ranks, each holding the whole matrix (pruned NJ)
-    bool nj_unit_sharded = false;    // ... and sharing the unit tests / scans of an iteration (else: every rank runs the single-GPU plan)
-    bool nj_row_pruned = false;      // several ranks, rows sharded, exact pruned NJ (njr.hip)
-    double dist_ms = 0, nj_ms = 0;
-    double place_dist_ms = 0;        // distance rows of the last placement run (the rest of nj_ms is tree work)
-    std::vector<hipEvent_t> place_ev;   // event pairs whose sum is the reported distance part of the current placement run
-    std::vector<hipEvent_t> place_ev_busy;   // overlap mode: event pairs around the distance batches on the second stream
-    double place_dist_busy_ms = 0;      // overlap mode: time the distance batches were in flight beside the tree kernels
-    bool place_overlapped = false;      // some batch of the last placement run was produced beside the tree kernels
-    std::vector<hipEvent_t> place_ev_tree;   // per-batch event pairs around the tree kernels (the overlap policy's probes)
-    int64_t place_batches = 0, place_batches_overlapped = 0;      // of the last placement run
-    dpr::DcStats dc_stats;
-    double dc_ms[3] = { 0, 0, 0 };   // backbone, cluster assignment, cluster trees
-    // plan knobs of THIS context (dpr_ctx_set_*); -1 = follow the process-wide default (dpr_set_* / environment)
-    int nj_mode = -1, nj_vshards = -1, nj_multi_plan = -1;
-    int nj_adaptive = -1;            // adaptive pruned / streaming plan of the single-rank NJ (-1 = DPR_NJ_ADAPTIVE, default on)
-    // row-sharded streaming NJ: exchange plan of the loop (-1 = DPR_NJ_EXCHANGE, default peer; see njs.hip) and what the
-    // last dpr_dist_matrix actually set up (a failed peer set-up falls back to the legacy loop and says why)
-    int nj_exchange = -1;
-    int nj_exchange_active = dpr::kNjsLegacy;
-    std::string nj_exchange_note;
-    bool local_comm = false;         // ranks joined by dpr_comm_init_local: no RCCL, windows attached by the launcher
-    bool njs_pending = false;        // the rows of the last merge still live in the row buffers
-    int64_t nj_launches = 0, nj_collectives = 0;     // of the last dpr_nj_run (per rank)
-    dpr::NjKernelTiming nj_kt;
-};
-
 using namespace dpr;
-
-// NJ algorithm on a single GPU: 1 = exact pruned scan (njp.hip, default), 0 = full streaming scan
-static int g_nj_mode = -1;
-static int g_nj_vshards = 1;   // > 1: a single-rank context emulates that many unit-sharded ranks (validation)
-// Several ranks, pruned NJ: 0 = auto (unit-sharded scans from kNjShardTips tips on, below that every rank runs the
-// single-GPU plan on its own copy: an iteration is then ~20 us of dependent latency and a collective per iteration
-// would only add to it; ROW-SHARDED pruned -- njr.hip -- once two copies of the matrix no longer fit one GPU), 1 = always
-// unit-sharded, 2 = never, 3 = row-sharded pruned (dpr_set_nj_multi_plan / DPR_NJ_MULTI=auto|shard|solo|rows)
-static int g_nj_multi_plan = -1;
-constexpr int64_t kNjShardTips = 65536;
-static int nj_multi_plan()
-{
-    if (g_nj_multi_plan < 0) {
-        const char* e = std::getenv("DPR_NJ_MULTI");
-        g_nj_multi_plan = (e && std::strcmp(e, "shard") == 0) ? 1 : (e && std::strcmp(e, "solo") == 0) ? 2 : (e && std::strcmp(e, "rows") == 0) ? 3 : 0;
-    }
-    return g_nj_multi_plan;
-}
-
-// in-place all-gather of the block records of the unit-sharded pruned NJ
-static int njp_gather_cb(void* ctx, void* buf, size_t bytes_per_rank, hipStream_t s)
-{
-    dpr_ctx* c = static_cast<dpr_ctx*>(ctx);
-    if (g_rccl.AllGather(static_cast<char*>(buf) + (size_t)c->rank * bytes_per_rank, buf, bytes_per_rank, 1 /* ncclUint8 */, c->comm, s) != 0) {
-        set_error("ncclAllGather(block records) failed");
-        return DPR_ERR_COMM;
-    }
-    return DPR_OK;
-}
-static bool want_pruned(const dpr_ctx* c)
-{
-    if (c->nj_mode >= 0) return c->nj_mode == 1;
-    if (g_nj_mode < 0) {
-        const char* e = std::getenv("DPR_NJ_MODE");
-        g_nj_mode = (e && std::strcmp(e, "stream") == 0) ? 0 : 1;
-    }
-    return g_nj_mode == 1;
-}
-static int g_nj_exchange = -1;
-static int ctx_exchange_plan(const dpr_ctx* c)
-{
-    if (c->local_comm) return kNjsMailbox;
-    if (c->nj_exchange >= 0) return c->nj_exchange;
-    if (g_nj_exchange < 0) {
-        const char* e = std::getenv("DPR_NJ_EXCHANGE");
-        // Default LEGACY (round 4, advisor): the one-exchange plans have only ever run with virtual ranks and process ranks on
-        // ONE device, where peer memory is local; until `bench.py --gpus G` has shown `matches_single_gpu` for them on real
-        // multi-GPU hardware they are opt-in (DPR_NJ_EXCHANGE=peer|mailbox, dpr_ctx_set_nj_exchange -- bench.py times all three).
-        g_nj_exchange = (e && std::strcmp(e, "peer") == 0) ? kNjsPeer : (e && std::strcmp(e, "mailbox") == 0) ? kNjsMailbox : kNjsLegacy;
-    }
-    return g_nj_exchange;
-}
-static int ctx_multi_plan(const dpr_ctx* c) { return c->nj_multi_plan >= 0 ? c->nj_multi_plan : nj_multi_plan(); }
-static int ctx_vshards(const dpr_ctx* c) { return c->nj_vshards >= 1 ? c->nj_vshards : g_nj_vshards; }
-
-// Row-sharded exact pruned NJ (njr.hip): asked for (plan 3; the only way for a context of virtual ranks), or -- real ranks,
-// plan auto -- when the two epoch buffers of the replicated plans (2 x 8 n^2 bytes) no longer fit this device
-static bool ctx_njr(const dpr_ctx* c, int64_t n)
-{
-    if (c->world < 2 || n < 3 || !want_pruned(c)) return false;
-    const int plan = ctx_multi_plan(c);
-    if (plan == 3) return true;
-    if (plan != 0 || c->vworld > 0) return false;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return 2.0 * 8.0 * (double)n * (double)n > 0.85 * (double)total_b;
-}
-// matrix rows per epoch buffer of a rank under that plan: the same on every rank (the peers compute each other's second half)
-static int64_t njr_twin_rows(int64_t n, int world)
-{
-    const int64_t nblk = (n + kRowBlock - 1) / kRowBlock;
-    const int64_t tip_rows = ((nblk + world - 1) / world) * kRowBlock + 32, pos_rows = njr_rows_cap(n, world);
-    return tip_rows > pos_rows ? tip_rows : pos_rows;
-}
-static std::vector<NjBuffers*> njr_ranks(dpr_ctx* c)
-{
-    std::vector<NjBuffers*> v;
-    for (auto& b : c->nj) v.push_back(&b);
-    return v;
-}
-// collective plan: kind 0 = every rank's header + unit records (in place in partials), kind 1 = its column slices (rows_plain)
-static int njr_gather_cb(void* ctx, int kind, hipStream_t s)
-{
-    dpr_ctx* c = static_cast<dpr_ctx*>(ctx);
-    NjBuffers& b0 = c->nj[0];
-    const int world = c->world;
-    const int ugrid = b0.pr.scan_grid / world > 0 ? b0.pr.scan_grid / world : 1;
-    const size_t seg = kind == 0 ? sizeof(NjRecord) * (size_t)(ugrid + 1) : sizeof(double) * 2 * (size_t)b0.rs.lay.slice;
-    if (c->vworld > 0) {
-        for (int r = 0; r < c->vworld; ++r)
-            for (int t = 0; t < c->vworld; ++t) {
-                if (t == r) continue;
-                char* src = kind == 0 ? reinterpret_cast<char*>(c->nj[(size_t)r].partials) : reinterpret_cast<char*>(c->nj[(size_t)r].rs.rows_plain);
-                char* dst = kind == 0 ? reinterpret_cast<char*>(c->nj[(size_t)t].partials) : reinterpret_cast<char*>(c->nj[(size_t)t].rs.rows_plain);
-                DPR_HIP(hipMemcpyAsync(dst + (size_t)r * seg, src + (size_t)r * seg, seg, hipMemcpyDeviceToDevice, s));
-            }
-        return DPR_OK;
-    }
-    if (!c->comm) { set_error("njr: the collective plan needs an RCCL communicator"); return DPR_ERR_COMM; }
-    char* buf = kind == 0 ? reinterpret_cast<char*>(b0.partials) : reinterpret_cast<char*>(b0.rs.rows_plain);
-    if (g_rccl.AllGather(buf + (size_t)c->rank * seg, buf, seg, 1 /* ncclUint8 */, c->comm, s) != 0) { set_error("ncclAllGather (row-sharded pruned NJ) failed"); return DPR_ERR_COMM; }
-    return DPR_OK;
-}
-
-// ---- exchange step of the sharded path: RCCL all-gather, or device copies between virtual ranks --
-enum ExKind { EX_RECS, EX_SLICES, EX_U, EX_RECS64 /* rank records of the one-exchange loop (NjsRec) */ };
-static const int kNcclUint8 = 1, kNcclFloat64 = 8, kNcclInt32 = 2, kNcclUint64 = 5, kNcclSum = 0;
-
-static int exchange(dpr_ctx* c, ExKind kind)
-{
-    if (c->world == 1 || c->nj_replicated) return DPR_OK;
-    if (c->vworld > 0) {
-        for (int r = 0; r < c->vworld; ++r) {
-            NjBuffers& src = c->nj[(size_t)r];
-            for (int t = 0; t < c->vworld; ++t) {
-                NjBuffers& dst = c->nj[(size_t)t];
-                if (kind == EX_RECS) {
-                    if (t == r) continue;
-                    DPR_HIP(hipMemcpyAsync(dst.recs + r, src.recs + r, sizeof(NjRecord), hipMemcpyDeviceToDevice, c->stream));
-                } else if (kind == EX_RECS64) {
-                    if (t == r) continue;
-                    DPR_HIP(hipMemcpyAsync(dst.recs64 + r, src.recs64 + r, sizeof(NjsRec), hipMemcpyDeviceToDevice, c->stream));
-                } else {
-                    const size_t cnt = (size_t)(kind == EX_SLICES ? 3 : 1) * (size_t)src.slice_len;
-                    DPR_HIP(hipMemcpyAsync(dst.gath + (size_t)r * cnt, src.slice, cnt * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-                }
-            }
-        }
-        return DPR_OK;
-    }
-    NjBuffers& b = c->nj[0];
-    int rc;
-    if (!c->comm) { set_error("exchange: no RCCL communicator on this context"); return DPR_ERR_COMM; }
-    ++c->nj_collectives;
-    if (kind == EX_RECS)
-        rc = g_rccl.AllGather(b.recs + c->rank, b.recs, sizeof(NjRecord), kNcclUint8, c->comm, c->stream);
-    else if (kind == EX_RECS64)
-        rc = g_rccl.AllGather(b.recs64 + c->rank, b.recs64, sizeof(NjsRec), kNcclUint8, c->comm, c->stream);
-    else
-        rc = g_rccl.AllGather(b.slice, b.gath, (size_t)(kind == EX_SLICES ? 3 : 1) * (size_t)b.slice_len, kNcclFloat64, c->comm, c->stream);
-    if (rc != 0) {
-        set_error(std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
-        return DPR_ERR_COMM;
-    }
-    return DPR_OK;
-}
-
-// ---- peer windows of the one-exchange sharded loop (njs.hip) -----------------------------------------------------
-struct PeerBlob {                  // what a rank tells the others about its buffers (192 bytes)
-    uint64_t ok;                   // 1: both handles valid
-    uint64_t n_tips;
-    hipIpcMemHandle_t d, w;        // matrix rows, window
-    uint64_t pad[6];
-};
-static_assert(sizeof(PeerBlob) == 192, "PeerBlob layout");
-
-// The HIP runtime bundled with PyTorch 2.10+rocm7.0 (7.0.51831: a process that imports torch first runs this library on it)
-// does not return from hipIpcOpenMemHandle for an allocation whose size has bit 31 set (2.3, 3.6, 3.9 GB hang; 1.9 GB and
-// 5.8 GB map), while the system runtime (/opt/rocm, 7.2) maps 14 GB (profiles/ipc_torch_probe.py, profiles/r3/
-// ipc_runtime_probe.txt).  A hang cannot be caught, so matrices of 2 GiB and more per rank are not offered to the peers on a
-// runtime older than 7.2 at all: the ranks then agree on the legacy loop (dpr_dist_matrix) or dpr_peer_export fails.
-// DPR_IPC_ANY_SIZE=1 lifts the guard.
-static bool ipc_size_allowed(size_t bytes)
-{
-    static int large_ok = -1;
-    if (large_ok < 0) {
-        int v = 0;
-        if (hipRuntimeGetVersion(&v) != hipSuccess) { (void)hipGetLastError(); v = 0; }
-        large_ok = (v >= 70200000 || std::getenv("DPR_IPC_ANY_SIZE")) ? 1 : 0;
-    }
-    return large_ok == 1 || bytes < ((size_t)1 << 31);
-}
-
-static int peer_blob_of(dpr_ctx* c, PeerBlob* out)
-{
-    NjBuffers& b = c->nj[0];
-    std::memset(out, 0, sizeof(PeerBlob));
-    out->n_tips = (uint64_t)b.N;
-    if (!b.D || !b.peer.win) return DPR_OK;
-    {
-        hipDeviceptr_t base = nullptr;
-        size_t bytes = 0;
-        if (hipMemGetAddressRange(&base, &bytes, b.D) != hipSuccess) { (void)hipGetLastError(); bytes = ~(size_t)0; }
-        out->pad[0] = (uint64_t)bytes;
-        if (!ipc_size_allowed(bytes)) { out->pad[1] = 2; return DPR_OK; }      // 2: refused by the runtime guard
-    }
-    if (hipIpcGetMemHandle(&out->d, b.D) != hipSuccess || hipIpcGetMemHandle(&out->w, b.peer.win) != hipSuccess) { (void)hipGetLastError(); return DPR_OK; }
-    out->ok = 1;
-    return DPR_OK;
-}
-
-// map the other ranks' buffers; all[r] for r = 0 .. world-1.  *ok = 0 when any blob is unusable or a mapping fails.
-static int peer_attach_blobs(dpr_ctx* c, const PeerBlob* all, int* ok)
-{
-    NjBuffers& b = c->nj[0];
-    *ok = 1;
-    for (int r = 0; r < c->world; ++r)
-        if (!all[r].ok || all[r].n_tips != (uint64_t)b.N || (r != c->rank && !ipc_size_allowed((size_t)all[r].pad[0]))) *ok = 0;
-    if (!*ok) return DPR_OK;
-    std::vector<char*> wins((size_t)c->world, nullptr);
-    std::vector<double*> Ds((size_t)c->world, nullptr);
-    for (int r = 0; r < c->world && *ok; ++r) {
-        if (r == c->rank) { wins[(size_t)r] = b.peer.win; Ds[(size_t)r] = b.D; continue; }
-        void *pd = nullptr, *pw = nullptr;
-        if (hipIpcOpenMemHandle(&pd, all[r].d, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); *ok = 0; break; }
-        b.peer.opened.push_back(pd);
-        if (hipIpcOpenMemHandle(&pw, all[r].w, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); *ok = 0; break; }
-        b.peer.opened.push_back(pw);
-        Ds[(size_t)r] = static_cast<double*>(pd);
-        wins[(size_t)r] = static_cast<char*>(pw);
-    }
-    if (!*ok) {
-        for (void* m : b.peer.opened) (void)hipIpcCloseMemHandle(m);
-        b.peer.opened.clear();
-        return DPR_OK;
-    }
-    return njs_set_peers(b, wins.data(), Ds.data(), c->stream);
-}
-
-// all-gather of `bytes` per rank through the staging buffer b.gath (RCCL); host arrays in / out
-static int rccl_gather_bytes(dpr_ctx* c, const void* mine, void* all, size_t bytes)
-{
-    NjBuffers& b = c->nj[0];
-    char* stage = reinterpret_cast<char*>(b.gath);
-    if (!stage || bytes * (size_t)c->world > sizeof(double) * (size_t)(3 * b.slice_len * c->world)) { set_error("rccl_gather_bytes: staging buffer too small"); return DPR_ERR_STATE; }
-    DPR_HIP(hipMemcpyAsync(stage + (size_t)c->rank * bytes, mine, bytes, hipMemcpyHostToDevice, c->stream));
-    if (g_rccl.AllGather(stage + (size_t)c->rank * bytes, stage, bytes, kNcclUint8, c->comm, c->stream) != 0) { set_error("ncclAllGather(peer handles) failed"); return DPR_ERR_COMM; }
-    DPR_HIP(hipMemcpyAsync(all, stage, bytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
-    DPR_HIP(hipStreamSynchronize(c->stream));
-    return DPR_OK;
-}
-
-// Set up the exchange plan of the row-sharded loop for the buffers nj_alloc just provided.  A plan that cannot be set up
-// on EVERY rank (no fine-grained window, IPC handles refused, a mapping fails) falls back to the legacy loop on all
-// ranks together -- the decision is taken on gathered flags, so the ranks cannot disagree -- and says why in
-// nj_exchange_note.  Ranks joined without RCCL (dpr_comm_init_local) have nothing to fall back to: error.
-// force_windows (row-sharded pruned NJ): windows and peer mappings are needed whatever the streaming loop's plan is -- the
-// epoch builds pull rows from the peers' buffers, the mailbox plan exchanges through the windows
-static int njs_setup(dpr_ctx* c, bool force_windows = false)
-{
-    int plan = ctx_exchange_plan(c);
-    if (force_windows && plan == kNjsLegacy) plan = (c->comm && c->vworld == 0) ? kNjsPeer : kNjsMailbox;
-    c->nj_exchange_active = kNjsLegacy;
-    c->nj_exchange_note.clear();
-    c->njs_pending = false;
-    if (plan == kNjsLegacy) return DPR_OK;
-    if (c->world > kNjsMaxWorld) { c->nj_exchange_note = "more ranks than mailbox slots"; return DPR_OK; }
-    int ok = 1;
-    for (auto& b : c->nj) {
-        b.peer.plan = plan;
-        if (njs_alloc_window(b, c->stream) != DPR_OK) { ok = 0; (void)hipGetLastError(); }
-    }
-    if (c->vworld > 0) {
-        if (!ok) { c->nj_exchange_note = "window allocation failed: " + g_err; for (auto& b : c->nj) b.peer.plan = kNjsLegacy; return DPR_OK; }
-        std::vector<char*> wins((size_t)c->vworld);
-        std::vector<double*> Ds((size_t)c->vworld);
-        for (int r = 0; r < c->vworld; ++r) { wins[(size_t)r] = c->nj[(size_t)r].peer.win; Ds[(size_t)r] = c->nj[(size_t)r].D; }
-        for (auto& b : c->nj)
-            if (int rc = njs_set_peers(b, wins.data(), Ds.data(), c->stream)) return rc;
-        c->nj_exchange_active = plan;
-        return DPR_OK;
-    }
-    NjBuffers& b = c->nj[0];
-    if (c->local_comm) {
-        if (!ok) return DPR_ERR_HIP;
-        if (!b.peer.attached) { set_error("dpr_dist_matrix: ranks joined by dpr_comm_init_local need dpr_peer_export / dpr_peer_attach for this tip count first"); return DPR_ERR_STATE; }
-        c->nj_exchange_active = kNjsMailbox;
-        return DPR_OK;
-    }
-    // attach or skip: decided on GATHERED flags, never on this rank's own state -- if one rank's buffers were recreated
-    // (a context re-made, nj_alloc after a failed call) while the others still hold their mappings, a rank-local test would
-    // send some ranks into the all-gathers below and the others past them (advisor, round 3).  Mixed state: everybody
-    // drops its mappings and attaches again.
-    bool attach = true;
-    {
-        std::vector<uint64_t> af((size_t)c->world, 0);
-        const uint64_t mine_attached = (ok && b.peer.attached) ? 1 : 0;
-        if (int rc = rccl_gather_bytes(c, &mine_attached, af.data(), sizeof(uint64_t))) return rc;
-        bool all_attached = true;
-        for (uint64_t f : af) all_attached = all_attached && f == 1;
-        attach = !all_attached;
-        if (attach && b.peer.attached) {
-            for (void* m : b.peer.opened) (void)hipIpcCloseMemHandle(m);
-            b.peer.opened.clear();
-            b.peer.attached = false;
-        }
-    }
-    if (attach) {
-        PeerBlob mine;
-        std::vector<PeerBlob> all((size_t)c->world);
-        if (ok) peer_blob_of(c, &mine); else std::memset(&mine, 0, sizeof mine);
-        if (int rc = rccl_gather_bytes(c, &mine, all.data(), sizeof(PeerBlob))) return rc;
-        int mapped = 0;
-        if (int rc = peer_attach_blobs(c, all.data(), &mapped)) return rc;
-        // second round: did every rank map every peer?
-        std::vector<uint64_t> flags((size_t)c->world, 0);
-        const uint64_t mf = mapped ? 1 : 0;
-        if (int rc = rccl_gather_bytes(c, &mf, flags.data(), sizeof(uint64_t))) return rc;
-        bool all_ok = true;
-        for (uint64_t f : flags) all_ok = all_ok && f == 1;
-        if (!all_ok) {
-            for (void* m : b.peer.opened) (void)hipIpcCloseMemHandle(m);
-            b.peer.opened.clear();
-            b.peer.attached = false;
-            b.peer.plan = kNjsLegacy;
-            bool guard = false;
-            for (const PeerBlob& pb : all) guard = guard || pb.pad[1] == 2;
-            c->nj_exchange_note = guard ? "this HIP runtime (older than 7.2) does not map IPC allocations of 2 GiB and more reliably: legacy two-exchange loop"
-                                        : "peer windows could not be mapped on every rank (hipIpc): legacy two-exchange loop";
-            return DPR_OK;
-        }
-    }
-    c->nj_exchange_active = plan;
-    return DPR_OK;
-}
-
-// barrier over the ranks of the sharded loop, enqueued on the context's stream
-static int njs_barrier(dpr_ctx* c)
-{
-    if (c->vworld > 0 || c->world == 1) return DPR_OK;       // one stream: already ordered
-    if (c->comm) return exchange(c, EX_RECS);                // (the gathered records are dead between iterations)
-    return njs_launch_barrier(c->nj[0], c->stream);
-}
-
-// row-sharded pruned NJ, ranks joined by RCCL: all ranks in step with idle streams (epoch builds)
-static int njr_barrier_cb(void* ctx)
-{
-    dpr_ctx* c = static_cast<dpr_ctx*>(ctx);
-    DPR_HIP(hipStreamSynchronize(c->stream));
-    if (int rc = exchange(c, EX_RECS)) return rc;
-    DPR_HIP(hipStreamSynchronize(c->stream));
-    return DPR_OK;
-}
-
-static NjBuffers* owner_buffers(dpr_ctx* c, int64_t row)
-{
-    const int o = shard_owner(row, c->world);
-    if (c->vworld > 0) return &c->nj[(size_t)o];
-    return o == c->rank ? &c->nj[0] : nullptr;
-}
-
-// one NJ iteration (active size n, iteration index it) on every rank held by this context
-static int nj_iteration(dpr_ctx* c, int64_t n, int64_t it)
-{
-    if (c->world == 1) {
-        NjBuffers& b = c->nj[0];
-        if (int rc = nj_launch_scan(b, false, n, it, c->stream)) return rc;
-        return nj_launch_post(b, n, it, c->stream);
-    }
-    if (c->nj_exchange_active != kNjsLegacy) {
-        // one exchange, two launches (njs.hip): scan + record, [all-gather of the records | nothing: mailboxes], update
-        for (auto& b : c->nj)
-            if (int rc = njs_launch_scan(b, n, it, c->njs_pending, c->stream)) return rc;
-        if (c->nj_exchange_active == kNjsPeer)
-            if (int rc = exchange(c, EX_RECS64)) return rc;
-        for (auto& b : c->nj)
-            if (int rc = njs_launch_post(b, n, it, c->njs_pending, c->stream)) return rc;
-        c->njs_pending = true;
-        c->nj_launches += 2;
-        return DPR_OK;
-    }
-    c->nj_launches += 4;
-    for (auto& b : c->nj) {
-        if (int rc = nj_launch_scan(b, false, n, it, c->stream)) return rc;
-        if (int rc = nj_launch_select_local(b, nj_scan_grid(), c->stream)) return rc;
-    }
-    if (int rc = exchange(c, EX_RECS)) return rc;
-    for (auto& b : c->nj)
-        if (int rc = nj_launch_commit_extract(b, n, it, c->stream)) return rc;
-    if (int rc = exchange(c, EX_SLICES)) return rc;
-    for (auto& b : c->nj)
-        if (int rc = nj_launch_update_sharded(b, n, c->stream)) return rc;
-    return DPR_OK;
-}
 
 __global__ void dpr_warm_kernel(int x) { if (x == 12345) __builtin_trap(); }
 
@@ -655,178 +192,6 @@ int dpr_device_name(dpr_ctx* c, char* buf, int cap)
     return DPR_OK;
 }
 
-// ---- multi-GPU ---------------------------------------------------------------------------------------
-int dpr_comm_unique_id(void* out128)
-{
-    if (!out128) { set_error("dpr_comm_unique_id: null"); return DPR_ERR_ARG; }
-    if (int rc = rccl_load()) return rc;
-    int r = g_rccl.GetUniqueId(out128);
-    if (r != 0) { set_error(std::string("ncclGetUniqueId: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?")); return DPR_ERR_COMM; }
-    return DPR_OK;
-}
-
-int dpr_comm_init(dpr_ctx* c, int rank, int world, const void* id128)
-{
-    if (!c || world < 1 || rank < 0 || rank >= world) { set_error("dpr_comm_init: bad argument"); return DPR_ERR_ARG; }
-    if (c->vworld > 0) { set_error("dpr_comm_init: context holds virtual ranks"); return DPR_ERR_STATE; }
-    c->rank = rank; c->world = world;
-    if (world == 1) return DPR_OK;
-    if (!id128) { set_error("dpr_comm_init: null id"); return DPR_ERR_ARG; }
-    if (int rc = rccl_load()) return rc;
-    DPR_HIP(hipSetDevice(c->device));
-    Id128 id;
-    std::memcpy(id.b, id128, 128);
-    int r = g_rccl.CommInitRank(&c->comm, world, id, rank);
-    if (r != 0) { set_error(std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?")); return DPR_ERR_COMM; }
-    return DPR_OK;
-}
-
-// Ranks WITHOUT RCCL (several processes whose GPUs -- or one shared GPU -- can map each other's memory): the row-sharded
-// NJ then runs its mailbox plan, and the launcher carries the 192-byte blobs of dpr_peer_export between the processes
-// (tests/test_gpu_multiproc.py does it with pipes on ONE GPU, which RCCL refuses: "duplicate GPU").
-int dpr_comm_init_local(dpr_ctx* c, int rank, int world)
-{
-    if (!c || world < 1 || world > kNjsMaxWorld || rank < 0 || rank >= world) { set_error("dpr_comm_init_local: bad argument"); return DPR_ERR_ARG; }
-    if (c->vworld > 0 || c->comm) { set_error("dpr_comm_init_local: context already holds ranks"); return DPR_ERR_STATE; }
-    c->rank = rank; c->world = world;
-    c->local_comm = world > 1;
-    return DPR_OK;
-}
-
-// allocate the NJ buffers and the window for n_tips on this rank and describe them (192 bytes) for the other ranks
-int dpr_peer_export(dpr_ctx* c, int64_t n_tips, void* out192)
-{
-    if (!c || !out192 || n_tips < 2 || n_tips >= (1 << 24)) { set_error("dpr_peer_export: bad argument"); return DPR_ERR_ARG; }
-    if (c->world < 2 || c->vworld > 0) { set_error("dpr_peer_export: needs a multi-rank context"); return DPR_ERR_STATE; }
-    DPR_HIP(hipSetDevice(c->device));
-    c->have_matrix = 0;
-    NjBuffers& b = c->nj[0];
-    if (int rc = nj_alloc(b, n_tips, c->rank, c->world, c->stream, ctx_njr(c, n_tips) ? njr_twin_rows(n_tips, c->world) : 0)) return rc;
-    b.peer.plan = kNjsMailbox;
-    if (int rc = njs_alloc_window(b, c->stream)) return rc;
-    --b.peer.run_id;          // (dpr_dist_matrix's own njs_alloc_window call counts the run)
-    DPR_HIP(hipStreamSynchronize(c->stream));
-    PeerBlob blob;
-    peer_blob_of(c, &blob);
-    if (!blob.ok && blob.pad[1] == 2) {
-        set_error("dpr_peer_export: this HIP runtime (older than 7.2) does not map IPC allocations of 2 GiB and more reliably; this rank's rows take " +
-                  std::to_string(blob.pad[0]) + " bytes (use the system runtime, more ranks, or DPR_IPC_ANY_SIZE=1)");
-        return DPR_ERR_STATE;
-    }
-    if (!blob.ok) { set_error("dpr_peer_export: hipIpcGetMemHandle failed"); return DPR_ERR_HIP; }
-    std::memcpy(out192, &blob, sizeof blob);
-    return DPR_OK;
-}
-
-// all192: the blobs of all ranks in rank order (this rank's own one is ignored)
-int dpr_peer_attach(dpr_ctx* c, const void* all192)
-{
-    if (!c || !all192) { set_error("dpr_peer_attach: bad argument"); return DPR_ERR_ARG; }
-    if (c->world < 2 || c->vworld > 0 || !c->nj[0].peer.win) { set_error("dpr_peer_attach: call dpr_peer_export first"); return DPR_ERR_STATE; }
-    DPR_HIP(hipSetDevice(c->device));
-    NjBuffers& b = c->nj[0];
-    for (void* m : b.peer.opened) (void)hipIpcCloseMemHandle(m);
-    b.peer.opened.clear();
-    b.peer.attached = false;
-    int ok = 0;
-    if (int rc = peer_attach_blobs(c, static_cast<const PeerBlob*>(all192), &ok)) return rc;
-    if (!ok) { set_error("dpr_peer_attach: a peer's buffers could not be mapped (hipIpcOpenMemHandle) or describe another tip count"); return DPR_ERR_HIP; }
-    return DPR_OK;
-}
-
-// exchange plan of the row-sharded NJ loop: 0 legacy (4 launches + 2 all-gathers), 1 peer (2 launches + 1 all-gather,
-// rows pulled from their owners), 2 mailbox (2 launches, no collective); -1 = DPR_NJ_EXCHANGE / default (peer)
-int dpr_ctx_set_nj_exchange(dpr_ctx* c, int plan)
-{
-    if (!c || plan < -1 || plan > 2) { set_error("dpr_ctx_set_nj_exchange: -1 default, 0 legacy, 1 peer, 2 mailbox"); return DPR_ERR_ARG; }
-    c->nj_exchange = plan;
-    return DPR_OK;
-}
-// what the last dpr_dist_matrix set up and what the last dpr_nj_run enqueued on this rank
-int dpr_get_nj_exchange_info(dpr_ctx* c, int* active_plan, int64_t* launches, int64_t* collectives, char* note, int cap)
-{
-    if (!c) { set_error("dpr_get_nj_exchange_info: null ctx"); return DPR_ERR_ARG; }
-    if (active_plan) *active_plan = c->nj_exchange_active;
-    if (launches) *launches = c->nj_launches;
-    if (collectives) *collectives = c->nj_collectives;
-    if (note && cap > 0) std::snprintf(note, (size_t)cap, "%s", c->nj_exchange_note.c_str());
-    return DPR_OK;
-}
-// bound of one mailbox poll in milliseconds (default 2000): a rank whose record does not arrive ends the run with DPR_ERR_COMM
-// Test hook of the one-exchange loops' cross-check: rank `rank` uses a wrong value for one element of a row it pulled at
-// iteration `iteration` (-1, -1 switches it off).  The run must then end with DPR_ERR_COMM on every rank one iteration later.
-// A setter of the context, not an environment variable: nothing outside a test can switch it on.
-int dpr_ctx_set_debug_fault(dpr_ctx* c, int64_t iteration, int rank)
-{
-    if (!c) { set_error("dpr_ctx_set_debug_fault: null ctx"); return DPR_ERR_ARG; }
-    for (auto& b : c->nj) { b.peer.fault_it = iteration; b.peer.fault_rank = rank; }
-    return DPR_OK;
-}
-
-int dpr_ctx_set_poll_limit_ms(dpr_ctx* c, int ms)
-{
-    if (!c || ms < 1) { set_error("dpr_ctx_set_poll_limit_ms: ms >= 1"); return DPR_ERR_ARG; }
-    for (auto& b : c->nj) b.peer.poll_ticks = (unsigned long long)ms * 100000ull;
-    return DPR_OK;
-}
-
-// what the communicator itself says (ncclCommCount / ncclCommUserRank), not what the caller passed to dpr_comm_init:
-// bench.py reports these per leg, so that a record claiming G ranks has RCCL's word for it
-int dpr_comm_info(dpr_ctx* c, int* rank, int* nranks)
-{
-    if (!c) { set_error("dpr_comm_info: null ctx"); return DPR_ERR_ARG; }
-    if (rank) *rank = 0;
-    if (nranks) *nranks = 1;
-    if (!c->comm) return DPR_OK;                 // no communicator: one rank
-    if (!g_rccl.CommCount || !g_rccl.CommUserRank) { set_error("librccl.so lacks ncclCommCount / ncclCommUserRank"); return DPR_ERR_COMM; }
-    int r = 0, n = 0;
-    if (g_rccl.CommCount(c->comm, &n) != 0 || g_rccl.CommUserRank(c->comm, &r) != 0) { set_error("ncclCommCount / ncclCommUserRank failed"); return DPR_ERR_COMM; }
-    if (rank) *rank = r;
-    if (nranks) *nranks = n;
-    return DPR_OK;
-}
-
-// RCCL plumbing self-test on ONE GPU: 1-rank communicator + all-gather of one record.  Exercises the
-// dlopen'ed entry points, the by-value ncclUniqueId ABI and the datatype constants used by exchange().
-int dpr_comm_selftest(dpr_ctx* c)
-{
-    if (!c) { set_error("dpr_comm_selftest: null ctx"); return DPR_ERR_ARG; }
-    if (int rc = rccl_load()) return rc;
-    DPR_HIP(hipSetDevice(c->device));
-    Id128 id;
-    int r = g_rccl.GetUniqueId(&id);
-    if (r != 0) { set_error("ncclGetUniqueId failed"); return DPR_ERR_COMM; }
-    void* comm = nullptr;
-    r = g_rccl.CommInitRank(&comm, 1, id, 0);
-    if (r != 0) { set_error(std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?")); return DPR_ERR_COMM; }
-    NjRecord h{ -1.5, 42ull, 2.25, 7ull }, back{ 0, 0, 0, 0 };
-    NjRecord* d = nullptr;
-    double *ds = nullptr, *dg = nullptr;
-    DPR_HIP(hipMalloc(&d, sizeof(NjRecord)));
-    DPR_HIP(hipMalloc(&ds, sizeof(double) * 192));
-    DPR_HIP(hipMalloc(&dg, sizeof(double) * 192));
-    std::vector<double> hs(192), hg(192, 0.0);
-    for (int i = 0; i < 192; ++i) hs[(size_t)i] = 0.5 * i;
-    DPR_HIP(hipMemcpy(d, &h, sizeof(NjRecord), hipMemcpyHostToDevice));
-    DPR_HIP(hipMemcpy(ds, hs.data(), sizeof(double) * 192, hipMemcpyHostToDevice));
-    r = g_rccl.AllGather(d, d, sizeof(NjRecord), kNcclUint8, comm, c->stream);          // in place
-    if (r == 0) r = g_rccl.AllGather(ds, dg, 192, kNcclFloat64, comm, c->stream);
-    // the all-reduces of the multi-GPU divide-and-conquer path: in place, uint64 / int32 sums
-    if (r == 0 && g_rccl.AllReduce) r = g_rccl.AllReduce(ds, ds, 192, kNcclUint64, kNcclSum, comm, c->stream);
-    if (r == 0 && g_rccl.AllReduce) r = g_rccl.AllReduce(ds, ds, 384, kNcclInt32, kNcclSum, comm, c->stream);
-    if (r == 0 && !g_rccl.AllReduce) r = -1;
-    DPR_HIP(hipStreamSynchronize(c->stream));
-    std::vector<double> hr(192, -1.0);
-    DPR_HIP(hipMemcpy(hr.data(), ds, sizeof(double) * 192, hipMemcpyDeviceToHost));
-    DPR_HIP(hipMemcpy(&back, d, sizeof(NjRecord), hipMemcpyDeviceToHost));
-    DPR_HIP(hipMemcpy(hg.data(), dg, sizeof(double) * 192, hipMemcpyDeviceToHost));
-    (void)hipFree(d); (void)hipFree(ds); (void)hipFree(dg);
-    g_rccl.CommDestroy(comm);
-    if (r != 0) { set_error("ncclAllGather / ncclAllReduce failed"); return DPR_ERR_COMM; }
-    if (back.q != h.q || back.key != h.key || back.d != h.d || hg != hs || hr != hs) { set_error("dpr_comm_selftest: data mismatch"); return DPR_ERR_COMM; }
-    return DPR_OK;
-}
-
 // ---- inputs ------------------------------------------------------------------------------------------
 int dpr_set_msa(dpr_ctx* c, const uint64_t* packed4, int64_t n, int64_t L)
 {
@@ -888,466 +253,10 @@ int dpr_get_kmer_hashes(dpr_ctx* c, int64_t seq, int k, const uint64_t* word_off
     return rc;
 }
 
-// ---- distance matrix ----------------------------------------------------------------------------------
-int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
-{
-    if (!c) { set_error("dpr_dist_matrix: null ctx"); return DPR_ERR_ARG; }
-    DPR_HIP(hipSetDevice(c->device));
-    if (c->world > 1 && c->vworld == 0 && !c->comm && !c->local_comm) { set_error("dpr_dist_matrix: dpr_comm_init was not called"); return DPR_ERR_STATE; }
-    int64_t n = 0;
-    if (source == DPR_SRC_MSA) {
-        if (!c->msa.planes) { set_error("dpr_dist_matrix: call dpr_set_msa first"); return DPR_ERR_STATE; }
-        n = c->msa.n;
-    } else if (source == DPR_SRC_MATRIX) {
-        if (!c->packed_lower) { set_error("dpr_dist_matrix: call dpr_set_matrix_lower first"); return DPR_ERR_STATE; }
-        n = c->n_input;
-    } else if (source == DPR_SRC_MASH) {
-        if (!c->mash.sketches) { set_error("dpr_dist_matrix: call dpr_set_reads and dpr_sketch first"); return DPR_ERR_STATE; }
-        if (k != c->mash.k) { set_error("dpr_dist_matrix: k differs from the sketch k"); return DPR_ERR_ARG; }
-        n = c->mash.n;
-    } else {
-        set_error("dpr_dist_matrix: source not available");
-        return DPR_ERR_ARG;
-    }
-    c->have_matrix = 0;
-    // Several real ranks + pruned NJ: every rank builds and keeps the WHOLE matrix (7.2 GB at 30 000 tips, 80 GB at
-    // 100 000) and the ranks share the per-iteration unit tests and scans (njp.hip, unit-sharded mode).  The
-    // streaming algorithm (DPR_NJ_MODE=stream) keeps the row-sharded layout.
-    const bool njr = ctx_njr(c, n);
-    const bool repl = !njr && c->world > 1 && c->vworld == 0 && want_pruned(c) && n >= 3;
-    c->nj_replicated = repl;
-    c->nj_row_pruned = false;
-    for (size_t r = 0; r < c->nj.size(); ++r)
-        if (int rc = nj_alloc(c->nj[r], n, repl ? 0 : (c->vworld > 0 ? (int)r : c->rank), repl ? 1 : c->world, c->stream, njr ? njr_twin_rows(n, c->world) : 0)) return rc;
-    const bool row_sharded = c->world > 1 && !repl;
-    if (row_sharded) { if (int rc = njs_setup(c, njr)) return rc; }
-    else c->nj_exchange_active = kNjsLegacy;
-    if (njr && c->nj_exchange_active == kNjsLegacy) {
-        set_error("dpr_dist_matrix: the row-sharded pruned NJ needs the peers' buffers mapped on every rank (" + c->nj_exchange_note + "); use DPR_NJ_MODE=stream");
-        return DPR_ERR_STATE;
-    }
-    const bool peer_plan = row_sharded && c->nj_exchange_active != kNjsLegacy;
-    DPR_HIP(hipEventRecord(c->ev[0], c->stream));
-    for (auto& b : c->nj) {
-        if (source == DPR_SRC_MSA) {
-            if (int rc = msa_dist_rows(c->msa, b, dist_type, c->stream)) return rc;
-        } else if (source == DPR_SRC_MASH) {
-            for (int64_t r0 = 0; r0 < b.rows_local; r0 += 32768) {
-                const int64_t nr = b.rows_local - r0 < 32768 ? b.rows_local - r0 : 32768;
-                if (int rc = mash_dist_rows(c->mash, r0, nr, b.rank, b.world, true, n, b.D + r0 * b.ld, b.ld, c->stream)) return rc;
-            }
-        } else {
-            if (int rc = nj_expand_lower(b, c->packed_lower, c->stream)) return rc;
-        }
-        // row sums of the own rows: into U (one rank), the slice of the legacy exchange, or the window's slice (peer plans)
-        double* sums = !row_sharded ? nullptr : peer_plan ? reinterpret_cast<double*>(b.peer.win + b.peer.lay.off_slice) : b.slice;
-        if (int rc = nj_init_sums(b, c->stream, sums)) return rc;
-    }
-    if (row_sharded && peer_plan) {
-        // every rank reads the other ranks' sums straight from their windows, behind one barrier
-        if (int rc = njs_barrier(c)) return rc;
-        for (auto& b : c->nj)
-            if (int rc = njs_launch_unpack_u(b, c->stream)) return rc;
-    } else if (row_sharded) {
-        if (int rc = exchange(c, EX_U)) return rc;
-        for (auto& b : c->nj)
-            if (int rc = nj_launch_unpack_u(b, c->stream)) return rc;
-    }
-    for (auto& b : c->nj)
-        if (int rc = nj_prepare(b, c->stream)) return rc;
-    if (njr) {
-        // exchange plan of the loop: -1 / 0 = default (collective -- all-gathers -- with RCCL and between virtual ranks; mailbox for
-        // ranks joined without RCCL), 1 = collective, 2 = mailbox
-        int rplan = c->nj_exchange == 2 ? kNjrMailbox : c->nj_exchange == 1 ? kNjrCollective : (c->local_comm ? kNjrMailbox : kNjrCollective);
-        if (c->nj_exchange < 0 && !c->local_comm)
-            if (const char* e = std::getenv("DPR_NJ_EXCHANGE")) rplan = std::strcmp(e, "mailbox") == 0 ? kNjrMailbox : kNjrCollective;
-        if (rplan == kNjrCollective && c->vworld == 0 && !c->comm) { set_error("dpr_dist_matrix: the collective plan of the row-sharded pruned NJ needs RCCL ranks"); return DPR_ERR_STATE; }
-        for (size_t r = 0; r < c->nj.size(); ++r) {
-            NjBuffers& b = c->nj[r];
-            b.rs.world = c->world; b.rs.rank = c->vworld > 0 ? (int)r : c->rank; b.rs.plan = rplan;
-            b.rs.win_off = b.peer.lay.off_njr;
-            b.rs.gather = njr_gather_cb; b.rs.cb_ctx = c;
-            b.rs.barrier = (c->vworld == 0 && c->comm) ? njr_barrier_cb : nullptr;
-            b.rs.launches = 0; b.rs.collectives = 0;
-        }
-        std::vector<NjBuffers*> ranks = njr_ranks(c);
-        if (int rc = njr_build(ranks, c->stream)) return rc;
-        c->nj_row_pruned = true;
-    }
-    if ((c->world == 1 || repl) && want_pruned(c) && n >= 3) {
-        NjPruned& q = c->nj[0].pr;
-        const int plan = ctx_multi_plan(c);
-        const bool shard = repl && (plan == 1 || (plan == 0 && n >= kNjShardTips));
-        c->nj_unit_sharded = shard;
-        if (shard) { q.sh_world = c->world; q.sh_rank = c->rank; q.sh_virtual = false; q.gather = njp_gather_cb; q.gather_ctx = c; }
-        else if (ctx_vshards(c) > 1) { q.sh_world = ctx_vshards(c); q.sh_rank = 0; q.sh_virtual = true; }
-        if (c->nj_adaptive >= 0) q.adaptive = c->nj_adaptive;
-        if (int rc = njp_build(c->nj[0], c->stream)) return rc;
-        if (c->nj_adaptive >= 0) q.adaptive = c->nj_adaptive;      // (the explicit setting wins over the environment)
-    }
-    DPR_HIP(hipEventRecord(c->ev[1], c->stream));
-    DPR_HIP(hipStreamSynchronize(c->stream));
-    float ms = 0;
-    DPR_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-    c->dist_ms = ms;
-    c->have_matrix = 1;   // (the packed triangle of a MATRIX source stays until dpr_set_matrix_lower / dpr_destroy)
-    return DPR_OK;
-}
-
-// Allocate the N x N matrix buffers of a following dpr_dist_matrix(n tips) now (single-rank contexts; a no-op
-// otherwise): dpr_dist_matrix finds them in place.  The CLI calls it from its device thread as soon as the number of
-// input sequences is known, while the host threads are still packing them.
-int dpr_reserve_nj(dpr_ctx* c, int64_t n)
-{
-    if (!c || n < 2 || n >= (1 << 24)) { set_error("dpr_reserve_nj: bad argument"); return DPR_ERR_ARG; }
-    if (c->world != 1 || c->vworld > 0) return DPR_OK;
-    DPR_HIP(hipSetDevice(c->device));
-    c->have_matrix = 0;
-    if (int rc = nj_alloc(c->nj[0], n, 0, 1, c->stream)) return rc;
-    if (want_pruned(c) && n >= 3) {
-        NjPruned& q = c->nj[0].pr;
-        if (ctx_vshards(c) > 1) { q.sh_world = ctx_vshards(c); q.sh_rank = 0; q.sh_virtual = true; }
-        if (int rc = njp_reserve(q, n, c->stream)) return rc;
-    }
-    DPR_HIP(hipStreamSynchronize(c->stream));
-    return DPR_OK;
-}
-
-// The first hipGraph of a process costs ~30 ms to instantiate (the next ones 0.2 ms); the pruned NJ replays graphs, so that
-// cost would sit in front of its first 32 iterations with the GPU idle.  The CLI calls this from a helper thread while it
-// reads its input (a private stream: nothing of the context's stream is touched).  Safe to call any number of times.
-int dpr_warm_graphs(dpr_ctx* c)
-{
-    if (!c) { set_error("dpr_warm_graphs: null ctx"); return DPR_ERR_ARG; }
-    DPR_HIP(hipSetDevice(c->device));
-    hipStream_t st = nullptr;
-    DPR_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    hipGraph_t g = nullptr;
-    hipGraphExec_t ge = nullptr;
-    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        hipLaunchKernelGGL(dpr_warm_kernel, dim3(1), dim3(64), 0, st, 0);
-        if (hipStreamEndCapture(st, &g) == hipSuccess && g) {
-            if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess && ge) {
-                (void)hipGraphLaunch(ge, st);
-                (void)hipStreamSynchronize(st);
-                (void)hipGraphExecDestroy(ge);
-            }
-            (void)hipGraphDestroy(g);
-        }
-    }
-    // ... and of its staged copies: the first device-to-host copy of more than a few KB into pageable memory costs 7.7 ms
-    // (staging buffers); without this it is the first epoch rebuild of the NJ run that pays (240 KB of row sums)
-    {
-        void* d = nullptr;
-        constexpr size_t kWarmBytes = 512 << 10;
-        if (hipMalloc(&d, kWarmBytes) == hipSuccess) {
-            std::vector<char> h(kWarmBytes);
-            (void)hipMemsetAsync(d, 0, kWarmBytes, st);
-            (void)hipStreamSynchronize(st);
-            // (on the private stream: a synchronous hipMemcpy runs on the NULL stream, which serialises with every blocking
-            //  stream of the device -- this function may run beside other dpr_* calls of the context; pageable staging is
-            //  exercised all the same)
-            (void)hipMemcpyAsync(h.data(), d, kWarmBytes, hipMemcpyDeviceToHost, st);
-            (void)hipStreamSynchronize(st);
-            (void)hipMemcpyAsync(d, h.data(), kWarmBytes, hipMemcpyHostToDevice, st);
-            (void)hipStreamSynchronize(st);
-            (void)hipFree(d);
-        }
-    }
-    (void)hipGetLastError();
-    (void)hipStreamDestroy(st);
-    return DPR_OK;
-}
-
-// ---- NJ -------------------------------------------------------------------------------------------------
-static int fetch_state(dpr_ctx* c, NjState* st)
-{
-    DPR_HIP(hipMemcpyAsync(st, c->nj[0].st, sizeof(NjState), hipMemcpyDeviceToHost, c->stream));
-    DPR_HIP(hipStreamSynchronize(c->stream));
-    return DPR_OK;
-}
-
-int64_t dpr_nj_run(dpr_ctx* c, int64_t max_iters, int32_t* merge_x, int32_t* merge_y, double* bl_x,
-                   double* bl_y, double* last_d)
-{
-    if (!c || !c->have_matrix) { set_error("dpr_nj_run: call dpr_dist_matrix first"); return DPR_ERR_STATE; }
-    DPR_HIP(hipSetDevice(c->device));
-    NjState st;
-    if (int rc = fetch_state(c, &st)) return rc;
-    int64_t todo = st.n - 2;
-    if (todo < 0) todo = 0;
-    if (max_iters >= 0 && max_iters < todo) todo = max_iters;
-    const int64_t it0 = st.it;
-    c->nj[0].kt = &c->nj_kt;
-    if (c->nj_kt.stride > 0 && it0 == 0) { c->nj_kt.samples = 0; for (double& v : c->nj_kt.us_sum) v = 0; }
-    c->nj_launches = 0; c->nj_collectives = 0;
-    DPR_HIP(hipEventRecord(c->ev[2], c->stream));
-    if (c->nj_row_pruned) {
-        std::vector<NjBuffers*> ranks = njr_ranks(c);
-        c->nj[0].rs.launches = 0; c->nj[0].rs.collectives = 0;
-        if (int rc = njr_run(ranks, it0, todo, c->stream)) return rc;
-        c->nj_launches = c->nj[0].rs.launches; c->nj_collectives = c->nj[0].rs.collectives;
-    } else if (c->nj[0].pr.active) {
-        if (int rc = njp_run(c->nj[0], it0, todo, c->stream)) return rc;
-    } else {
-        for (int64_t k = 0; k < todo; ++k)
-            if (int rc = nj_iteration(c, st.n - k, it0 + k)) return rc;
-    }
-    DPR_HIP(hipEventRecord(c->ev[3], c->stream));       // (the loop itself: the barrier + flush below are once per run)
-    const bool peer_plan = c->world > 1 && !c->nj_replicated && !c->nj_row_pruned && c->nj_exchange_active != kNjsLegacy;
-    if (peer_plan) {
-        // every rank must be through its pulls of the last iteration before an owner flushes the last row buffers
-        if (int rc = njs_barrier(c)) return rc;
-        for (auto& b : c->nj)
-            if (int rc = njs_launch_finish(b, st.n - todo, it0 + todo, c->njs_pending, c->stream)) return rc;
-        c->njs_pending = false;
-        if (int rc = njs_barrier(c)) return rc;      // the flushed rows may be read by other ranks (final distance, hooks)
-    } else {
-        for (auto& b : c->nj)
-            if (!b.pr.active)
-                if (int rc = nj_launch_finish(b, st.n - todo, it0 + todo, c->stream)) return rc;
-    }
-    if (int rc = fetch_state(c, &st)) return rc;
-    float ms = 0;
-    DPR_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
-    c->nj_ms = ms;
-    if (!c->nj_kt.ev.empty()) {       // per-kernel timing samples of this run (stream idle)
-        NjKernelTiming& kt = c->nj_kt;
-        const size_t grp = (size_t)kt.nk + 1;
-        for (size_t g0 = 0; kt.nk > 0 && g0 + grp <= kt.ev.size(); g0 += grp) {
-            for (int k = 0; k < kt.nk; ++k) {
-                float us = 0;
-                if (hipEventElapsedTime(&us, kt.ev[g0 + (size_t)k], kt.ev[g0 + (size_t)k + 1]) == hipSuccess) kt.us_sum[k] += (double)us * 1e3;
-            }
-            ++kt.samples;
-        }
-        for (hipEvent_t e : kt.ev) (void)hipEventDestroy(e);
-        kt.ev.clear();
-    }
-    const int64_t done = st.it - it0;
-    if (done > 0) {
-        if (merge_x) DPR_HIP(hipMemcpy(merge_x, c->nj[0].log_x + it0, sizeof(int32_t) * (size_t)done, hipMemcpyDeviceToHost));
-        if (merge_y) DPR_HIP(hipMemcpy(merge_y, c->nj[0].log_y + it0, sizeof(int32_t) * (size_t)done, hipMemcpyDeviceToHost));
-        if (bl_x) DPR_HIP(hipMemcpy(bl_x, c->nj[0].log_bx + it0, sizeof(double) * (size_t)done, hipMemcpyDeviceToHost));
-        if (bl_y) DPR_HIP(hipMemcpy(bl_y, c->nj[0].log_by + it0, sizeof(double) * (size_t)done, hipMemcpyDeviceToHost));
-    }
-    if (st.status == 3) {
-        set_error("dpr_nj_run: the exchange between the ranks failed (a rank's record did not arrive within the poll limit, or the all-gather delivered a stale one)");
-        return DPR_ERR_COMM;
-    }
-    if (st.status == 4) {
-        // (njs_post_kernel left the two differing words in st.q / st.d and the ranks in st.x / st.y)
-        char msg[320];
-        std::snprintf(msg, sizeof msg, "dpr_nj_run: the ranks' replicated row sums differ after %lld iterations (rank %d: %a, rank %d: %a): a row pulled from its owner "
-                      "was stale or torn -- the merge log up to here is not trustworthy; use the legacy exchange (dpr_ctx_set_nj_exchange(ctx, 0))",
-                      (long long)st.it, (int)st.x, st.q, (int)st.y, st.d);
-        set_error(msg);
-        return DPR_ERR_COMM;
-    }
-    if (st.status == 5) {
-        set_error("dpr_nj_run: internal: the test blocks of the post kernel did not see the producer blocks' tag within 2 ms (njp_post2_kernel; DPR_NJP_POST2=0 selects the fused kernel)");
-        return DPR_ERR_HIP;
-    }
-    if (st.status != 0) {
-        set_error("dpr_nj_run: no Q candidate below the reference's init value 10000 (undefined in the reference)");
-        return DPR_ERR_NOCAND;
-    }
-    if (last_d && st.n == 2) {
-        // D[0][1] of the final pair (src/neighborJoining.cu:245-249); row 1 lives on rank 0
-        NjBuffers& b0 = c->nj[0];
-        if (c->nj_row_pruned) {
-            // the row of slot 1 lives on its position's owner: read through the mapping of that rank's epoch buffer (every
-            // rank's finish kernel has run: the stream was synchronised by fetch_state; process ranks: the owner's flush is
-            // behind its own finish kernel, ordered by the barrier below)
-            int32_t pos01[2];
-            DPR_HIP(hipMemcpy(pos01, b0.pr.pos_of_slot, sizeof(pos01), hipMemcpyDeviceToHost));
-            if (c->vworld == 0 && b0.rs.barrier) { if (int rc = b0.rs.barrier(b0.rs.cb_ctx)) return rc; }
-            const int half = (b0.pr.epoch_index + 1) & 1, o = njr_owner(pos01[1], c->world);
-            DPR_HIP(hipMemcpy(last_d, b0.rs.peer_half[half][(size_t)o] + njr_local_row(pos01[1], c->world) * b0.pr.ld + pos01[0], sizeof(double), hipMemcpyDeviceToHost));
-        } else if (b0.pr.in_positions()) {
-            int32_t pos01[2];
-            DPR_HIP(hipMemcpy(pos01, b0.pr.pos_of_slot, sizeof(pos01), hipMemcpyDeviceToHost));
-            DPR_HIP(hipMemcpy(last_d, b0.pr.D + (int64_t)pos01[1] * b0.pr.ld + pos01[0], sizeof(double), hipMemcpyDeviceToHost));
-        } else if (c->world == 1 || c->vworld > 0) {
-            DPR_HIP(hipMemcpy(last_d, b0.D + 1 * b0.ld + 0, sizeof(double), hipMemcpyDeviceToHost));
-        } else if (peer_plan && !b0.peer.h_D.empty()) {
-            // rank 0's row 1 through the mapping of its matrix (its flush is behind the barrier above)
-            DPR_HIP(hipMemcpy(last_d, b0.peer.h_D[0] + 1 * b0.ld + 0, sizeof(double), hipMemcpyDeviceToHost));
-        } else {
-            NjRecord rec{ 0.0, 0ull, 0.0, 0ull };
-            if (c->rank == 0) DPR_HIP(hipMemcpy(&rec.d, b0.D + 1 * b0.ld + 0, sizeof(double), hipMemcpyDeviceToHost));
-            DPR_HIP(hipMemcpy(b0.recs + c->rank, &rec, sizeof(NjRecord), hipMemcpyHostToDevice));
-            if (int rc = exchange(c, EX_RECS)) return rc;
-            DPR_HIP(hipStreamSynchronize(c->stream));
-            DPR_HIP(hipMemcpy(&rec, b0.recs + 0, sizeof(NjRecord), hipMemcpyDeviceToHost));
-            *last_d = rec.d;
-        }
-    }
-    return done;
-}
-
-int dpr_argmin_once(dpr_ctx* c, int reps, int32_t* out_i, int32_t* out_j, double* out_q, float* out_ms)
-{
-    if (!c || !c->have_matrix) { set_error("dpr_argmin_once: call dpr_dist_matrix first"); return DPR_ERR_STATE; }
-    DPR_HIP(hipSetDevice(c->device));
-    if (reps < 1) reps = 1;
-    NjState st0;
-    if (int rc = fetch_state(c, &st0)) return rc;
-    // pruned mode: the streaming kernel runs over the position-space matrix (all P positions, dead
-    // ones carry NaN row sums); it = 0 because the bounds kernel already finished U[x]
-    auto probe = [&](NjBuffers& b) -> int {
-        return b.pr.in_positions() ? nj_launch_scan(b, true, b.pr.P, 0, c->stream) : nj_launch_scan(b, true, st0.n, st0.it, c->stream);
-    };
-    for (auto& b : c->nj)
-        if (int rc = probe(b)) return rc;  // warm
-    DPR_HIP(hipEventRecord(c->ev[2], c->stream));
-    for (int r = 0; r < reps; ++r)
-        for (auto& b : c->nj)
-            if (int rc = probe(b)) return rc;
-    DPR_HIP(hipEventRecord(c->ev[3], c->stream));
-    for (auto& b : c->nj)
-        if (int rc = nj_launch_select_local(b, nj_scan_grid(), c->stream)) return rc;
-    if (int rc = exchange(c, EX_RECS)) return rc;
-    const int ew = c->nj_replicated ? 1 : c->world;      // ranks whose records differ
-    std::vector<NjRecord> recs((size_t)ew);
-    DPR_HIP(hipMemcpyAsync(recs.data(), c->nj[0].recs, sizeof(NjRecord) * (size_t)ew, hipMemcpyDeviceToHost, c->stream));
-    DPR_HIP(hipStreamSynchronize(c->stream));
-    float ms = 0;
-    DPR_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
-    if (out_ms) *out_ms = ms / (float)reps;
-    const int w = dpr_record_reduce(recs.data(), ew);
-    if (w < 0) { set_error("dpr_argmin_once: no Q candidate below 10000"); return DPR_ERR_NOCAND; }
-    const NjRecord& rec = recs[(size_t)w];
-    if (out_i) *out_i = (int32_t)(rec.key & 0xFFFFFFull);
-    if (out_j) *out_j = (int32_t)((rec.key >> 24) & 0xFFFFFFull);
-    if (out_q) *out_q = rec.q;
-    return DPR_OK;
-}
-
-int dpr_njp_unit_owner(int64_t strip, int64_t group, int64_t P, int world) { return njp_unit_owner(strip, group, P, world); }
-
-// validation knob: the next dpr_dist_matrix on a single-rank context sets up `w` emulated unit-sharded ranks
-int dpr_set_nj_virtual_shards(int w)
-{
-    if (w < 1 || w > 64) { set_error("dpr_set_nj_virtual_shards: 1 <= w <= 64"); return DPR_ERR_ARG; }
-    g_nj_vshards = w;
-    return DPR_OK;
-}
-
-int dpr_set_nj_multi_plan(int plan)
-{
-    if (plan < 0 || plan > 3) { set_error("dpr_set_nj_multi_plan: 0 auto, 1 unit-sharded, 2 single-GPU plan on every rank, 3 row-sharded pruned"); return DPR_ERR_ARG; }
-    g_nj_multi_plan = plan;
-    return DPR_OK;
-}
-int dpr_nj_is_unit_sharded(dpr_ctx* c) { return c && c->nj_unit_sharded ? 1 : 0; }
-
-// the same three knobs for ONE context (two contexts in one process may run different plans); value -1 = follow
-// the process-wide default again.  Take effect at the context's next dpr_dist_matrix.
-int dpr_ctx_set_nj_mode(dpr_ctx* c, int mode)
-{
-    if (!c || mode < -1 || mode > 1) { set_error("dpr_ctx_set_nj_mode: mode must be -1, 0 or 1"); return DPR_ERR_ARG; }
-    c->nj_mode = mode;
-    return DPR_OK;
-}
-int dpr_ctx_set_nj_multi_plan(dpr_ctx* c, int plan)
-{
-    if (!c || plan < -1 || plan > 3) { set_error("dpr_ctx_set_nj_multi_plan: -1 default, 0 auto, 1 unit-sharded, 2 single-GPU plan on every rank, 3 row-sharded pruned"); return DPR_ERR_ARG; }
-    c->nj_multi_plan = plan;
-    return DPR_OK;
-}
-// Per-kernel timing of the pruned NJ loop: stride > 0 makes the following dpr_nj_run calls enqueue their iterations
-// eagerly (no hipGraph replay) with HIP events on the library's stream around the launches of every stride-th iteration.
-int dpr_ctx_set_nj_kernel_timing(dpr_ctx* c, int stride)
-{
-    if (!c || stride < 0) { set_error("dpr_ctx_set_nj_kernel_timing: stride >= 0"); return DPR_ERR_ARG; }
-    c->nj_kt.stride = stride;
-    return DPR_OK;
-}
-int dpr_get_nj_kernel_timing(dpr_ctx* c, int* kernels, double* us_avg, int64_t* samples)
-{
-    if (!c) { set_error("dpr_get_nj_kernel_timing: null ctx"); return DPR_ERR_ARG; }
-    if (kernels) *kernels = c->nj_kt.nk;
-    if (samples) *samples = c->nj_kt.samples;
-    if (us_avg) for (int k = 0; k < kNjKernelsMax; ++k) us_avg[k] = c->nj_kt.samples > 0 ? c->nj_kt.us_sum[k] / (double)c->nj_kt.samples : 0.0;
-    return DPR_OK;
-}
-const char* dpr_nj_kernel_name(int idx) { return njp_kernel_name(idx); }
-int dpr_get_nj_phase_stamps(uint64_t* out) { return njp_phase_stamps((unsigned long long*)out); }
-int dpr_get_njp_list(dpr_ctx* c, int32_t* out, int64_t cap, int64_t* count, int64_t* positions, double* ur, int64_t ur_cap)
-{
-    if (!c || !out || !count || !positions) { set_error("dpr_get_njp_list: null argument"); return DPR_ERR_ARG; }
-    DPR_HIP(hipSetDevice(c->device));
-    return njp_debug_list(c->nj[0], out, cap, count, positions, ur, ur_cap);
-}
-
-int dpr_ctx_set_nj_virtual_shards(dpr_ctx* c, int w)
-{
-    if (!c || w < -1 || w == 0 || w > 64) { set_error("dpr_ctx_set_nj_virtual_shards: -1 or 1 <= w <= 64"); return DPR_ERR_ARG; }
-    c->nj_vshards = w;
-    return DPR_OK;
-}
-
-// 0 = full streaming scan every iteration, 1 = exact pruned scan (default)
-int dpr_set_nj_mode(int mode)
-{
-    if (mode != 0 && mode != 1) { set_error("dpr_set_nj_mode: mode must be 0 or 1"); return DPR_ERR_ARG; }
-    g_nj_mode = mode;
-    return DPR_OK;
-}
-
-// Adaptive plan of the single-rank NJ (default on): the exact pruned scan while its bounds prune; hand-over to the streaming
-// loop once more than 70 % of an epoch's units are listed per iteration, pruned probes with back-off (see dpr_internal.hpp).  The
-// merge log does not depend on it.  on = 0: pruned scans only; -1: DPR_NJ_ADAPTIVE / default.  Takes effect at the next
-// dpr_dist_matrix.
-int dpr_ctx_set_nj_adaptive(dpr_ctx* c, int on)
-{
-    if (!c || on < -1 || on > 1) { set_error("dpr_ctx_set_nj_adaptive: -1, 0 or 1"); return DPR_ERR_ARG; }
-    c->nj_adaptive = on;
-    return DPR_OK;
-}
-// iterations that ran as streaming scans and epochs that switched, since the matrix was built
-int dpr_get_nj_adaptive_stats(dpr_ctx* c, int64_t* stream_iterations, int64_t* stream_epochs)
-{
-    if (!c || !c->have_matrix || !c->nj[0].pr.active) { set_error("dpr_get_nj_adaptive_stats: pruned path not active"); return DPR_ERR_STATE; }
-    if (stream_iterations) *stream_iterations = c->nj[0].pr.stream_iterations;
-    if (stream_epochs) *stream_epochs = c->nj[0].pr.stream_epochs;
-    return DPR_OK;
-}
-
-// units scanned by the pruned path since the matrix was built, and units per full scan
-int dpr_get_prune_stats(dpr_ctx* c, uint64_t* units_scanned, uint64_t* units_per_full_scan)
-{
-    if (!c || !c->have_matrix || !c->nj[0].pr.active) { set_error("dpr_get_prune_stats: pruned path not active"); return DPR_ERR_STATE; }
-    NjState st;
-    if (int rc = fetch_state(c, &st)) return rc;
-    if (units_scanned) *units_scanned = st.units_scanned;
-    if (units_per_full_scan) *units_per_full_scan = (uint64_t)c->nj[0].pr.utot0;
-    return DPR_OK;
-}
-
-
 // microbenchmark: wall time per launch of a chain of trivial dependent kernels (eager or graph replay)
 __global__ void dpr_nop_kernel(unsigned long long* p) { if (threadIdx.x == 0 && blockIdx.x == 0 && p[7] == 12345) p[6] = 1; }
 
 __global__ void dpr_mark_kernel(unsigned long long* out, long long idx) { if (threadIdx.x == 0 && blockIdx.x == 0) out[idx] = (unsigned long long)idx + 1ull; }
-
-int dpr_get_nj_progress(dpr_ctx* c, int64_t* iterations_done, int64_t* active)
-{
-    if (!c || !c->have_matrix) { set_error("dpr_get_nj_progress: call dpr_dist_matrix first"); return DPR_ERR_STATE; }
-    DPR_HIP(hipSetDevice(c->device));
-    NjState st;
-    if (int rc = fetch_state(c, &st)) return rc;
-    if (iterations_done) *iterations_done = st.it;
-    if (active) *active = st.n;
-    return DPR_OK;
-}
-
-int dpr_get_njp_shape(dpr_ctx* c, int64_t* positions, int* row_groups, int* strips, int* post2, int* scan_grid)
-{
-    if (!c || !c->have_matrix || !c->nj[0].pr.active) { set_error("dpr_get_njp_shape: no pruned NJ state"); return DPR_ERR_STATE; }
-    return njp_shape(c->nj[0].pr, positions, row_groups, strips, post2, scan_grid);
-}
 
 int dpr_launch_bench(dpr_ctx* c, int nlaunch, int grid, int use_graph, float* us_per_launch)
 {
@@ -1580,582 +489,6 @@ int dpr_get_timing(dpr_ctx* c, double* dist_ms, double* nj_ms)
     if (!c) { set_error("dpr_get_timing: null ctx"); return DPR_ERR_ARG; }
     if (dist_ms) *dist_ms = c->dist_ms;
     if (nj_ms) *nj_ms = c->nj_ms;
-    return DPR_OK;
-}
-
-// k-closest placement of tips [first, last) into c->place (findPlacementTree / addQuery loop,
-// src/placement_close_k.cu:756-851,888-987; findBackboneTreeDC, src/divide_and_conquer/
-// placement_close_k.cu:832-925): distance rows in batches of 256 (1024 for Mash input) from the row providers.
-// first == 2 starts from the two-tip tree, otherwise the imported backbone is already in the arrays.
-static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int64_t last)
-{
-    PlaceBuffers& p = c->place;
-    // distance rows per batch: 1024 for Mash input, whose batches run beside the tree kernels (100 000 unaligned tips:
-    // 3.81 / 3.60 / 3.93 s with 256 / 1024 / 4096 -- fewer launch tails, but a longer start-up without overlap)
-    int64_t R = source == DPR_SRC_MASH ? 1024 : 256;
-    if (const char* e = std::getenv("DPR_PLACE_BATCH")) { const int64_t v = std::atoll(e); if (v >= 16 && v <= 65536) R = v; }
-    const int64_t ldb = (last + 15) / 16 * 16;
-    // Multi-GPU (dpr_comm_init done, inputs replicated): the distance rows of a batch do not depend on the
-    // placements, so every rank computes R/world of them and one all-gather per batch completes the block;
-    // the tree kernels then run identically on every rank (deterministic), so no tree state is exchanged.
-    const bool sharded = c->world > 1 && c->vworld == 0 && c->comm != nullptr && source != DPR_SRC_MATRIX;
-    const int W = sharded ? c->world : 1;
-    const int64_t per = (R + W - 1) / W;         // rows per rank and batch
-    // The distance rows of the NEXT batch may be produced on a second stream while the tree kernels of the current batch run
-    // (they are latency-bound and occupy a few workgroups; the pair kernels fill the rest of the chip): two row buffers, the
-    // producer waits for the batch that last read the buffer it overwrites.  Mash input only: with aligned input the distance part
-    // is 4 % of the run and the contention costs more than it hides (1.63 -> 1.82 s at 100 000 tips).
-    // Round 4: the decision is taken PER BATCH.  Overlap pays while a batch's distance part is the SHORTER one -- it then
-    // disappears behind the tree kernels (100 000 unaligned tips from scratch: 3.2 -> 2.5 s).  Where it is the longer one
-    // nothing can hide it, and sharing the chip slows both sides: adding 50 000 queries to a 500 000-tip backbone, every batch is
-    // 5 x 10^8 pairs (~100 ms alone) against ~50 ms of tree kernels; overlapped, the pair kernel ran at half its rate and the
-    // update kernel 5.6 x slower (profiles/r3/kernel_stats_add_mash_500k_plus_50k.csv): 9.2 s where back to back is 7.6 s.
-    // So: batch k + 1 is produced beside batch k's tree kernels iff its predicted time alone (pairs / the rate measured on this
-    // run's batches that ran alone, 4.5 G pairs/s until there is one) is below the tree time of the latest finished batch
-    // (deflated by 1.4 if that batch shared the chip); otherwise it is produced on the main stream right before its own tips, at
-    // full chip.  Measured (profiles/r4/place_policy_*.jsonl): --add 500 000 + 50 000 through Mash 8.87 s (every batch beside)
-    // -> 6.56 s (none); 100 000 tips from scratch 3.07 s (none) / 2.52 s (every batch) / 2.5x s (policy).  The host waits for batch k - 1 before it decides about batch k + 1 (it never runs more than one batch ahead
-    // of the device any more; enqueueing is ~10 x faster than the tree kernels execute, so the device does not starve).
-    // Results cannot depend on the policy: the rows are the same numbers whichever stream produced them.
-    const bool overlap_allowed = source == DPR_SRC_MASH && !std::getenv("DPR_PLACE_NO_OVERLAP");
-    // (several ranks: every rank must take the same decisions -- the batches' all-gathers are enqueued on the stream the decision
-    //  picks -- and a rank's share of a batch is 1 / G of the pairs, i.e. the short side: every batch beside, as in round 3)
-    const bool overlap_always = overlap_allowed && sharded;
-    double* rows_buf[2] = { nullptr, nullptr };
-    const size_t row_bytes = sizeof(double) * (size_t)(per * W * ldb);
-    if (source != DPR_SRC_MATRIX) {
-        DPR_HIP(hipMalloc(&rows_buf[0], row_bytes));
-        if (overlap_allowed) {
-            const hipError_t me = hipMalloc(&rows_buf[1], row_bytes);
-            if (me != hipSuccess) { (void)hipFree(rows_buf[0]); return hip_fail(me, "hipMalloc(second row buffer)"); }
-        }
-    }
-    if (overlap_allowed && !c->stream2) {
-        // lowest priority: the distance kernels fill the chip, the tree kernels of the current batch (one wavefront or a few
-        // blocks each, on the context's stream) must not queue behind them
-        int least = 0, greatest = 0;
-        DPR_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        DPR_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, least));
-    }
-    std::vector<hipEvent_t> sync_ev;                             // fill-done / tree-done events of this run
-    auto new_event = [&](hipEvent_t* e) -> int { DPR_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming)); sync_ev.push_back(*e); return DPR_OK; };
-    auto row_ptr = [&](int64_t i, int64_t i0, const double* rows) -> const double* {
-        return source == DPR_SRC_MATRIX ? c->packed_lower + i * (i - 1) / 2 : rows + (i - i0) * ldb;
-    };
-    auto fill_some = [&](int64_t i0, int64_t nr, double* out, hipStream_t st) -> int {
-        if (nr <= 0) return DPR_OK;
-        if (source == DPR_SRC_MSA) return msa_dist_block_rows(c->msa, i0, nr, 0, 0, i0 + nr, dist_type, out, ldb, st);
-        if (source == DPR_SRC_MASH) return mash_dist_rows(c->mash, i0, nr, 0, 0, false, i0 + nr, out, ldb, st);
-        return DPR_OK;
-    };
-    auto fill_rows_inner = [&](int64_t i0, int64_t nr, double* rows, hipStream_t ds) -> int {
-        if (!sharded) return fill_some(i0, nr, rows, ds);
-        const int64_t a = (int64_t)c->rank * per, b = a + per < nr ? a + per : nr;     // this rank's rows of the batch
-        if (int rc = fill_some(i0 + a, b - a, rows + a * ldb, ds)) return rc;
-        if (g_rccl.AllGather(rows + a * ldb, rows, (size_t)(per * ldb), kNcclFloat64, c->comm, ds) != 0) {
-            set_error("ncclAllGather(distance rows) failed");
-            return DPR_ERR_COMM;
-        }
-        return DPR_OK;
-    };
-    // the reference reports the distance and the tree part of a placement run separately
-    // (src/placement_close_k.cu:852-853,985-986).  A batch produced on the main stream: an event pair around it (c->place_ev).
-    // A batch produced beside the tree kernels: its own interval overlaps the tree work in wall time (and stretches while it
-    // shares the chip) -- kept as `busy` time (c->place_ev_busy); what counts as distance time is the time the tree stream
-    // actually WAITED for it (an event pair around the wait, c->place_ev), so distance + tree = the run's wall time again.
-    c->place_overlapped = false;
-    c->place_batches = 0; c->place_batches_overlapped = 0;
-    auto fill_rows = [&](int64_t i0, int64_t nr, double* rows, bool beside, hipEvent_t* t0, hipEvent_t* t1) -> int {
-        hipStream_t ds = beside ? c->stream2 : c->stream;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (source != DPR_SRC_MATRIX) {
-            DPR_HIP(hipEventCreate(&e0)); DPR_HIP(hipEventCreate(&e1));
-            std::vector<hipEvent_t>& dst = beside ? c->place_ev_busy : c->place_ev;
-            dst.push_back(e0); dst.push_back(e1);
-            DPR_HIP(hipEventRecord(e0, ds));
-        }
-        c->mash.share_chip = beside;
-        const int rc = fill_rows_inner(i0, nr, rows, ds);
-        c->mash.share_chip = false;
-        if (e1) DPR_HIP(hipEventRecord(e1, ds));
-        if (t0) *t0 = e0;
-        if (t1) *t1 = e1;
-        return rc;
-    };
-    auto run = [&]() -> int {
-        if (first == 2) {
-            if (int rc = place_init_fresh(p, c->stream)) return rc;
-            if (int rc = fill_some(1, 1, rows_buf[0], c->stream)) return rc;
-            if (int rc = place_initial_tree(p, row_ptr(1, 1, rows_buf[0]), c->stream)) return rc;
-        } else {
-            if (int rc = place_import_backbone(p, first, c->stream)) return rc;
-        }
-        if (first >= last) return DPR_OK;
-        hipEvent_t filled[2] = { nullptr, nullptr }, consumed[2] = { nullptr, nullptr };
-        bool ahead = false;                       // the rows of the batch about to be placed were produced beside the previous batch
-        // policy state: what a batch that ran alone cost
-        double tree_ms_per_tip = -1.0, pairs_per_ms = 4.5e6;
-        struct Probe { hipEvent_t d0, d1, t0, t1; double pairs; int64_t nr; bool dist_alone, tree_alone; };
-        std::vector<Probe> probes;                // one per batch
-        size_t harvested = 0;
-        auto batch_pairs = [&](int64_t i0, int64_t nr) { return (double)nr * ((double)i0 + 0.5 * (double)(nr - 1)); };
-        auto harvest = [&](size_t upto) -> int {  // read the timings of the batches < upto (host waits for the last of them)
-            for (; harvested < upto; ++harvested) {
-                Probe& pr = probes[harvested];
-                if (!pr.t1) continue;
-                DPR_HIP(hipEventSynchronize(pr.t1));
-                float ms = 0;
-                // (tree kernels that shared the chip with a distance batch ran ~1.3 x slower at 100 000 tips: such a batch's time
-                //  is deflated by 1.4 before it stands for "the tree part alone" -- the tree part grows with the tree, so the
-                //  latest batch is the better estimate than batch 0's clean one)
-                if (hipEventElapsedTime(&ms, pr.t0, pr.t1) == hipSuccess && pr.nr > 0) tree_ms_per_tip = (double)ms / (double)pr.nr / (pr.tree_alone ? 1.0 : 1.4);
-                if (pr.dist_alone && pr.d0 && pr.d1 && pr.pairs >= 5.0e7 && hipEventElapsedTime(&ms, pr.d0, pr.d1) == hipSuccess && ms > 0.0f)
-                    pairs_per_ms = pr.pairs / (double)ms;
-            }
-            return DPR_OK;
-        };
-        int64_t i0 = first;
-        int cur = 0;
-        for (size_t k = 0; i0 < last; i0 += R, cur ^= 1, ++k) {
-            const int64_t nr = last - i0 < R ? last - i0 : R;
-            const int64_t j0 = i0 + R;
-            double* rows = rows_buf[overlap_allowed ? cur : 0];
-            Probe pr{ nullptr, nullptr, nullptr, nullptr, batch_pairs(i0, nr), nr, false, true };
-            if (!ahead) {
-                // this batch's rows on the main stream, at full chip (a buffer's last reader ran on this stream: ordered)
-                if (int rc = fill_rows(i0, nr, rows, false, &pr.d0, &pr.d1)) return rc;
-                pr.dist_alone = true;
-            } else {
-                hipEvent_t w0 = nullptr, w1 = nullptr;
-                DPR_HIP(hipEventCreate(&w0)); DPR_HIP(hipEventCreate(&w1));
-                c->place_ev.push_back(w0); c->place_ev.push_back(w1);
-                DPR_HIP(hipEventRecord(w0, c->stream));
-                DPR_HIP(hipStreamWaitEvent(c->stream, filled[cur], 0));
-                DPR_HIP(hipEventRecord(w1, c->stream));
-            }
-            ++c->place_batches;
-            // the next batch beside this batch's tree kernels?
-            bool next_ahead = false;
-            if (overlap_allowed && j0 < last) {
-                const int64_t nr2 = last - j0 < R ? last - j0 : R;
-                if (overlap_always) next_ahead = true;
-                else {
-                    if (k >= 1) { if (int rc = harvest(k)) return rc; }      // batches 0 .. k-1 (the host waits for batch k-1 here)
-                    const double dist_alone_ms = batch_pairs(j0, nr2) / pairs_per_ms;
-                    // (no tree timing yet -- this is batch 0: its successor is produced alone too, unless its distance part is tiny)
-                    next_ahead = tree_ms_per_tip > 0.0 ? dist_alone_ms < tree_ms_per_tip * (double)nr : dist_alone_ms < 1.0;
-                }
-                if (next_ahead) {
-                    const int nb = cur ^ 1;
-                    if (consumed[nb]) DPR_HIP(hipStreamWaitEvent(c->stream2, consumed[nb], 0));
-                    else {
-                        // (first use of that buffer by the second stream: everything enqueued so far may still read it)
-                        hipEvent_t e;
-                        if (int rc = new_event(&e)) return rc;
-                        DPR_HIP(hipEventRecord(e, c->stream));
-                        DPR_HIP(hipStreamWaitEvent(c->stream2, e, 0));
-                    }
-                    if (int rc = fill_rows(j0, nr2, rows_buf[nb], true, nullptr, nullptr)) return rc;
-                    if (int rc = new_event(&filled[nb])) return rc;
-                    DPR_HIP(hipEventRecord(filled[nb], c->stream2));
-                    c->place_overlapped = true;
-                    ++c->place_batches_overlapped;
-                    pr.tree_alone = false;
-                }
-            }
-            if (source != DPR_SRC_MATRIX) {
-                DPR_HIP(hipEventCreate(&pr.t0)); DPR_HIP(hipEventCreate(&pr.t1));
-                c->place_ev_tree.push_back(pr.t0); c->place_ev_tree.push_back(pr.t1);
-                DPR_HIP(hipEventRecord(pr.t0, c->stream));
-            }
-            if (source == DPR_SRC_MATRIX) {      // packed triangle: rows are not evenly spaced
-                for (int64_t i = i0; i < i0 + nr; ++i)
-                    if (int rc = place_tip(p, row_ptr(i, i0, rows), i, c->place_trace, c->stream)) return rc;
-            } else {
-                if (int rc = place_tips(p, rows, ldb, i0, nr, c->place_trace, c->stream)) return rc;
-            }
-            if (pr.t1) DPR_HIP(hipEventRecord(pr.t1, c->stream));
-            if (overlap_allowed) { if (int rc = new_event(&consumed[cur])) return rc; DPR_HIP(hipEventRecord(consumed[cur], c->stream)); }
-            probes.push_back(pr);
-            ahead = next_ahead;
-        }
-        return DPR_OK;
-    };
-    const int rc = run();
-    c->mash.share_chip = false;
-    if (rows_buf[0] || rows_buf[1]) {
-        (void)hipStreamSynchronize(c->stream);
-        if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-        for (double* q : rows_buf) if (q) (void)hipFree(q);
-    }
-    for (hipEvent_t e : sync_ev) (void)hipEventDestroy(e);
-    return rc;
-}
-
-// sum of the distance-batch event pairs of the run that just finished (stream idle); the events are released
-static void place_collect_dist_ms(dpr_ctx* c)
-{
-    auto sum = [](std::vector<hipEvent_t>& evs) {
-        double tot = 0;
-        for (size_t i = 0; i + 1 < evs.size(); i += 2) {
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, evs[i], evs[i + 1]) == hipSuccess) tot += ms;
-        }
-        for (hipEvent_t e : evs) (void)hipEventDestroy(e);
-        evs.clear();
-        return tot;
-    };
-    c->place_dist_ms = sum(c->place_ev);
-    c->place_dist_busy_ms = sum(c->place_ev_busy);
-    (void)sum(c->place_ev_tree);       // (the policy's probes; released here)
-}
-
-// dist_ms: the part of the run the tree kernels could not proceed for want of distance rows (without overlap: the
-// distance batches themselves; with overlap: the tree stream's waits for them); tree_ms: the rest of the run.
-int dpr_get_place_timing(dpr_ctx* c, double* dist_ms, double* tree_ms)
-{
-    if (!c) { set_error("dpr_get_place_timing: null ctx"); return DPR_ERR_ARG; }
-    if (dist_ms) *dist_ms = c->place_dist_ms;
-    if (tree_ms) *tree_ms = c->nj_ms > c->place_dist_ms ? c->nj_ms - c->place_dist_ms : 0.0;
-    return DPR_OK;
-}
-
-// overlap mode of the last placement run: *overlapped = 1 and *dist_busy_ms = time the distance batches were in flight on
-// the second stream (concurrent with the tree kernels, so NOT a summand of the run's wall time); else 0 / 0
-int dpr_get_place_overlap(dpr_ctx* c, int* overlapped, double* dist_busy_ms)
-{
-    if (!c) { set_error("dpr_get_place_overlap: null ctx"); return DPR_ERR_ARG; }
-    if (overlapped) *overlapped = c->place_overlapped ? 1 : 0;
-    if (dist_busy_ms) *dist_busy_ms = c->place_overlapped ? c->place_dist_busy_ms : 0.0;
-    return DPR_OK;
-}
-
-// batches of the last placement run and how many of them were produced beside the previous batch's tree kernels (the per-batch
-// overlap policy of place_range)
-int dpr_get_place_policy(dpr_ctx* c, int64_t* batches, int64_t* overlapped_batches)
-{
-    if (!c) { set_error("dpr_get_place_policy: null ctx"); return DPR_ERR_ARG; }
-    if (batches) *batches = c->place_batches;
-    if (overlapped_batches) *overlapped_batches = c->place_batches_overlapped;
-    return DPR_OK;
-}
-
-int dpr_place_run(dpr_ctx* c, int source, int dist_type, int k, int64_t first, int64_t n, int32_t* head,
-                  int32_t* e, int32_t* nxt, int32_t* belong, double* len)
-{
-    if (!c || !head || !e || !nxt || !belong || !len || n < 3 || first < 2 || first > n) { set_error("dpr_place_run: bad argument"); return DPR_ERR_ARG; }
-    DPR_HIP(hipSetDevice(c->device));
-    if (source == DPR_SRC_MSA) {
-        if (!c->msa.planes || c->msa.n != n) { set_error("dpr_place_run: call dpr_set_msa with n sequences first"); return DPR_ERR_STATE; }
-    } else if (source == DPR_SRC_MASH) {
-        if (!c->mash.sketches || c->mash.n != n) { set_error("dpr_place_run: call dpr_set_reads and dpr_sketch first"); return DPR_ERR_STATE; }
-        if (k != c->mash.k) { set_error("dpr_place_run: k differs from the sketch k"); return DPR_ERR_ARG; }
-    } else if (source == DPR_SRC_MATRIX) {
-        if (!c->packed_lower || c->n_input != n) { set_error("dpr_place_run: call dpr_set_matrix_lower first"); return DPR_ERR_STATE; }
-    } else { set_error("dpr_place_run: unknown source"); return DPR_ERR_ARG; }
-    if (int rc = place_alloc(c->place, n)) return rc;
-    PlaceBuffers& p = c->place;
-    if (c->place_trace) { (void)hipFree(c->place_trace); c->place_trace = nullptr; }
-    DPR_HIP(hipMalloc(&c->place_trace, sizeof(double) * (size_t)(3 * n)));
-    DPR_HIP(hipMemsetAsync(c->place_trace, 0, sizeof(double) * (size_t)(3 * n), c->stream));
-    if (first > 2) {
-        DPR_HIP(hipMemcpyAsync(p.head, head, sizeof(int32_t) * (size_t)(2 * n), hipMemcpyHostToDevice, c->stream));
-        DPR_HIP(hipMemcpyAsync(p.e, e, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyHostToDevice, c->stream));
-        DPR_HIP(hipMemcpyAsync(p.nxt, nxt, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyHostToDevice, c->stream));
-        DPR_HIP(hipMemcpyAsync(p.belong, belong, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyHostToDevice, c->stream));
-        DPR_HIP(hipMemcpyAsync(p.len, len, sizeof(double) * (size_t)(8 * n), hipMemcpyHostToDevice, c->stream));
-    }
-    DPR_HIP(hipEventRecord(c->ev[2], c->stream));
-    if (int rc = place_range(c, source, dist_type, first, n)) { place_collect_dist_ms(c); return rc; }
-    DPR_HIP(hipEventRecord(c->ev[3], c->stream));
-    DPR_HIP(hipMemcpyAsync(head, p.head, sizeof(int32_t) * (size_t)(2 * n), hipMemcpyDeviceToHost, c->stream));
-    DPR_HIP(hipMemcpyAsync(e, p.e, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
-    DPR_HIP(hipMemcpyAsync(nxt, p.nxt, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
-    DPR_HIP(hipMemcpyAsync(belong, p.belong, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
-    DPR_HIP(hipMemcpyAsync(len, p.len, sizeof(double) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
-    DPR_HIP(hipStreamSynchronize(c->stream));
-    float ms = 0;
-    DPR_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
-    c->nj_ms = ms;
-    place_collect_dist_ms(c);
-    return DPR_OK;
-}
-
-// ---- exact placement mode -----------------------------------------------------------------------------
-static int place_exact_attempt(dpr_ctx* c, int source, int dist_type, int k, int64_t n, int32_t* head, int32_t* e,
-                               int32_t* nxt, int32_t* belong, double* len)
-{
-    if (!c || !head || !e || !nxt || !belong || !len || n < 3) { set_error("dpr_place_exact_run: bad argument"); return DPR_ERR_ARG; }
-    DPR_HIP(hipSetDevice(c->device));
-    if (source == DPR_SRC_MSA) {
-        if (!c->msa.planes || c->msa.n != n) { set_error("dpr_place_exact_run: call dpr_set_msa with n sequences first"); return DPR_ERR_STATE; }
-    } else if (source == DPR_SRC_MASH) {
-        if (!c->mash.sketches || c->mash.n != n) { set_error("dpr_place_exact_run: call dpr_set_reads and dpr_sketch first"); return DPR_ERR_STATE; }
-        if (k != c->mash.k) { set_error("dpr_place_exact_run: k differs from the sketch k"); return DPR_ERR_ARG; }
-    } else if (source == DPR_SRC_MATRIX) {
-        if (!c->packed_lower || c->n_input != n) { set_error("dpr_place_exact_run: call dpr_set_matrix_lower first"); return DPR_ERR_STATE; }
-    } else { set_error("dpr_place_exact_run: unknown source"); return DPR_ERR_ARG; }
-    if (int rc = place_alloc(c->place, n)) return rc;
-    if (int rc = exact_alloc(c->exact, n)) return rc;
-    PlaceBuffers& p = c->place;
-    ExactBuffers& x = c->exact;
-    if (c->place_trace) { (void)hipFree(c->place_trace); c->place_trace = nullptr; }
-    DPR_HIP(hipMalloc(&c->place_trace, sizeof(double) * (size_t)(3 * n)));
-    DPR_HIP(hipMemsetAsync(c->place_trace, 0, sizeof(double) * (size_t)(3 * n), c->stream));
-    // distance rows in batches of R+1: the step of tip i also runs the passes of tip i+1, so a batch
-    // shares its last row with the next one
-    const int64_t R = 256;
-    const int64_t ldb = (n + 15) / 16 * 16;
-    double* rows = nullptr;
-    if (source != DPR_SRC_MATRIX) DPR_HIP(hipMalloc(&rows, sizeof(double) * (size_t)((R + 1) * ldb)));
-    int64_t r0 = 1;
-    auto row_ptr = [&](int64_t i) -> const double* {
-        return source == DPR_SRC_MATRIX ? c->packed_lower + i * (i - 1) / 2 : rows + (i - r0) * ldb;
-    };
-    auto fill_rows = [&](int64_t i0, int64_t nr) -> int {
-        if (source == DPR_SRC_MSA) return msa_dist_block_rows(c->msa, i0, nr, 0, 0, i0 + nr, dist_type, rows, ldb, c->stream);
-        if (source == DPR_SRC_MASH) return mash_dist_rows(c->mash, i0, nr, 0, 0, false, i0 + nr, rows, ldb, c->stream);
-        return DPR_OK;
-    };
-    DPR_HIP(hipEventRecord(c->ev[2], c->stream));
-    int rc = DPR_OK;
-    while (!rc) {
-        const int64_t nr = n - r0 < R + 1 ? n - r0 : R + 1;
-        rc = fill_rows(r0, nr);
-        if (!rc && r0 == 1) rc = exact_init(p, x, row_ptr(1), nr > 1 ? row_ptr(2) : nullptr, nr > 1, c->stream);
-        for (int64_t i = r0 < 2 ? 2 : r0; !rc && i < r0 + nr - 1; ++i) rc = exact_tip(p, x, i, row_ptr(i + 1), true, c->place_trace, c->stream);
-        if (rc) break;
-        if (r0 + nr == n) { rc = exact_tip(p, x, n - 1, nullptr, false, c->place_trace, c->stream); break; }
-        r0 = r0 + nr - 1;
-    }
-    if (!rc) {
-        DPR_HIP(hipEventRecord(c->ev[3], c->stream));
-        DPR_HIP(hipMemcpyAsync(head, p.head, sizeof(int32_t) * (size_t)(2 * n), hipMemcpyDeviceToHost, c->stream));
-        DPR_HIP(hipMemcpyAsync(e, p.e, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
-        DPR_HIP(hipMemcpyAsync(nxt, p.nxt, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
-        DPR_HIP(hipMemcpyAsync(belong, p.belong, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
-        DPR_HIP(hipMemcpyAsync(len, p.len, sizeof(double) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
-    }
-    const hipError_t se = hipStreamSynchronize(c->stream);
-    if (rows) (void)hipFree(rows);
-    if (rc) return rc;
-    DPR_HIP(se);
-    float ms = 0;
-    DPR_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
-    c->nj_ms = ms;
-    return DPR_OK;
-}
-
-int dpr_place_exact_run(dpr_ctx* c, int source, int dist_type, int k, int64_t n, int32_t* head, int32_t* e,
-                        int32_t* nxt, int32_t* belong, double* len)
-{
-    if (!c) { set_error("dpr_place_exact_run: bad argument"); return DPR_ERR_ARG; }
-    // The fast schedule (small subtrees on all CUs + top tree in LDS) gives the reference's lim[] whenever the reference's
-    // depths are the tree's depths.  They stop being that only if the default tuple (slot 0, pendant length 2) wins an argmin
-    // (updateTreeStructure's swap, src/placement.cu:236-239); the run is then repeated with the literal level-by-depth
-    // schedule, the only one that reproduces what the reference computes from there on.
-    c->exact.literal = std::getenv("DPR_EXACT_LITERAL") != nullptr;
-    int rc = place_exact_attempt(c, source, dist_type, k, n, head, e, nxt, belong, len);
-    if (rc != DPR_OK || c->exact.literal) return rc;
-    bool quirk = false;
-    if (int rq = exact_quirk(c->exact, c->stream, &quirk)) return rq;
-    if (!quirk) return DPR_OK;
-    c->exact.literal = true;
-    rc = place_exact_attempt(c, source, dist_type, k, n, head, e, nxt, belong, len);
-    return rc;
-}
-
-int dpr_get_exact_state(dpr_ctx* c, int32_t* rev, int32_t* dep)
-{
-    if (!c || !c->exact.dep || !c->place.rev) { set_error("dpr_get_exact_state: no exact placement state"); return DPR_ERR_STATE; }
-    DPR_HIP(hipStreamSynchronize(c->stream));   // the plain copies below run on the null stream, which does not wait for c->stream
-    const int64_t n = c->place.N;
-    if (rev) DPR_HIP(hipMemcpy(rev, c->place.rev, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost));
-    if (dep) DPR_HIP(hipMemcpy(dep, c->exact.dep, sizeof(int32_t) * (size_t)(2 * n), hipMemcpyDeviceToHost));
-    return DPR_OK;
-}
-
-// ---- divide-and-conquer mode ------------------------------------------------------------------------
-int dpr_dc_run(dpr_ctx* c, int source, int dist_type, int k, int64_t n, int64_t backbone, int flags, int32_t* head,
-               int32_t* e, int32_t* nxt, int32_t* belong, double* len, int32_t* cluster_id)
-{
-    if (!c || !head || !e || !nxt || !belong || !len || n < 4) { set_error("dpr_dc_run: bad argument"); return DPR_ERR_ARG; }
-    if (backbone < 3 || backbone >= n) { set_error("dpr_dc_run: backbone size must be in [3, n)"); return DPR_ERR_ARG; }
-    DPR_HIP(hipSetDevice(c->device));
-    if (source == DPR_SRC_MSA) {
-        if (!c->msa.planes || c->msa.n != n) { set_error("dpr_dc_run: call dpr_set_msa with n sequences first"); return DPR_ERR_STATE; }
-    } else if (source == DPR_SRC_MASH) {
-        if (!c->mash.sketches || c->mash.n != n) { set_error("dpr_dc_run: call dpr_set_reads and dpr_sketch first"); return DPR_ERR_STATE; }
-        if (k != c->mash.k) { set_error("dpr_dc_run: k differs from the sketch k"); return DPR_ERR_ARG; }
-    } else {
-        // src/divide_and_conquer/placement_close_k.cu:969-972
-        set_error("dpr_dc_run: input must be unaligned or aligned sequences for the clustering based approach");
-        return DPR_ERR_ARG;
-    }
-    const int64_t B = backbone;
-    if (int rc = place_alloc(c->place, n, B)) return rc;
-    PlaceBuffers& p = c->place;
-    if (c->place_trace) { (void)hipFree(c->place_trace); c->place_trace = nullptr; }
-    DPR_HIP(hipMalloc(&c->place_trace, sizeof(double) * (size_t)(3 * n)));
-    DPR_HIP(hipMemsetAsync(c->place_trace, 0, sizeof(double) * (size_t)(3 * n), c->stream));
-    hipEvent_t ev[4];
-    for (auto& x : ev) DPR_HIP(hipEventCreate(&x));
-    int32_t* d_cl = nullptr;
-    double* dT = nullptr;
-    uint64_t *snap_old = nullptr, *snap_acc = nullptr;
-    DcTable tab;
-    // ranks: RCCL ranks of dpr_comm_init, or -- validation on one GPU -- DPR_DC_VIRTUAL_RANKS(w) emulated in turn
-    const bool real = c->world > 1 && c->vworld == 0 && c->comm != nullptr;
-    const int W = real ? c->world : (((flags >> 8) & 0xff) > 1 ? ((flags >> 8) & 0xff) : 1);
-    std::vector<int32_t> h_cl((size_t)n, -1);
-    auto run = [&]() -> int {
-        // ---- backbone tree: tips [0, B) (findBackboneTreeDC)
-        DPR_HIP(hipEventRecord(ev[0], c->stream));
-        if (int rc = place_range(c, source, dist_type, 2, B)) return rc;
-        DPR_HIP(hipEventRecord(ev[1], c->stream));
-        // ---- cluster assignment of tips [B, n) (findClustersDC).  Multi-GPU: the backbone above is built
-        // identically on every rank (same inputs, deterministic kernels); the queries are independent, so each
-        // rank assigns a contiguous share and the ids are summed (zeros elsewhere) over RCCL.
-        if (int rc = dc_table_build(p, B, tab, c->stream)) return rc;
-        int64_t Q = ((int64_t)1 << 31) / (8 * B) / 256 * 256;
-        if (Q < 256) Q = 256;
-        if (Q > 8192) Q = 8192;
-        const int64_t nq = n - B;
-        if (Q > (nq + 255) / 256 * 256) Q = (nq + 255) / 256 * 256;
-        DPR_HIP(hipMalloc(&dT, sizeof(double) * (size_t)(B * Q)));
-        DPR_HIP(hipMalloc(&d_cl, sizeof(int32_t) * (size_t)(n + 1)));
-        DPR_HIP(hipMemsetAsync(d_cl, 0, sizeof(int32_t) * (size_t)(n + 1), c->stream));
-        // the reference's aligned-input kernel never writes the distance to backbone tip B-1
-        // (src/divide_and_conquer/msa.cu:331 `idx>=ed-st`) and scans the 0.0 of a fresh allocation
-        const bool skip_last = source == DPR_SRC_MSA && !(flags & DPR_DC_EXACT_LAST);
-        for (int v = 0; v < W; ++v) {
-            if (real && v != c->rank) continue;     // virtual ranks: every share is processed here, one after the other
-            int64_t q0 = 0, q1 = 0;
-            dc_query_share(n, B, v, W, &q0, &q1);
-            for (int64_t i0 = q0; i0 < q1; i0 += Q) {
-                const int64_t nr = q1 - i0 < Q ? q1 - i0 : Q;
-                int rc;
-                if (source == DPR_SRC_MSA) rc = msa_dist_block_rows(c->msa, i0, nr, 0, 0, B, dist_type, dT, Q, c->stream, true);
-                else rc = mash_dist_rows(c->mash, i0, nr, 0, 0, false, B, dT, Q, c->stream, true);
-                if (rc) return rc;
-                if (skip_last) DPR_HIP(hipMemsetAsync(dT + (B - 1) * Q, 0, sizeof(double) * (size_t)Q, c->stream));
-                if (int rc2 = dc_assign(tab, dT, Q, (int)nr, d_cl + i0, c->stream)) return rc2;
-            }
-        }
-        if (real) {
-            if (!g_rccl.AllReduce) { set_error("dpr_dc_run: librccl.so lacks ncclAllReduce"); return DPR_ERR_COMM; }
-            if (g_rccl.AllReduce(d_cl, d_cl, (size_t)n, kNcclInt32, kNcclSum, c->comm, c->stream) != 0) { set_error("ncclAllReduce(cluster ids) failed"); return DPR_ERR_COMM; }
-        }
-        DPR_HIP(hipMemcpyAsync(h_cl.data(), d_cl, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-        DPR_HIP(hipEventRecord(ev[2], c->stream));
-        DPR_HIP(hipStreamSynchronize(c->stream));
-        for (int64_t t = 0; t < B; ++t) h_cl[(size_t)t] = -1;
-        (void)hipFree(dT); dT = nullptr;
-        // ---- cluster trees (findClusterTreeDC).  Multi-GPU: clusters are dealt to the ranks; an array element
-        // is changed by at most one rank, so the states are merged as old + sum of (new - old) (dc_delta_*).
-        size_t free_b = 0, total_b = 0;
-        DPR_HIP(hipMemGetInfo(&free_b, &total_b));
-        size_t budget = free_b / 2;
-        if (const char* env = std::getenv("DPR_DC_BUDGET_MB")) budget = (size_t)std::atoll(env) << 20;
-        if (W == 1) {
-            if (int rc = dc_cluster_phase(p, h_cl.data(), n, B, source, dist_type, &c->msa, &c->mash, c->place_trace, budget,
-                                          &c->dc_stats, 0, 1, c->stream)) return rc;
-        } else {
-            struct Arr { void* cur; int64_t words; };
-            const Arr arrs[] = { { p.head, n }, { p.e, 4 * n }, { p.nxt, 4 * n }, { p.belong, 4 * n }, { p.rev, 4 * n },
-                                 { p.len, 8 * n }, { p.cid, 20 * n }, { p.cdis, 40 * n }, { c->place_trace, 3 * n } };
-            int64_t tot = 0;
-            for (const Arr& a : arrs) tot += a.words;
-            DPR_HIP(hipMalloc(&snap_old, sizeof(uint64_t) * (size_t)tot));
-            if (!real) { DPR_HIP(hipMalloc(&snap_acc, sizeof(uint64_t) * (size_t)tot)); DPR_HIP(hipMemsetAsync(snap_acc, 0, sizeof(uint64_t) * (size_t)tot, c->stream)); }
-            int64_t off = 0;
-            for (const Arr& a : arrs) { DPR_HIP(hipMemcpyAsync(snap_old + off, a.cur, sizeof(uint64_t) * (size_t)a.words, hipMemcpyDeviceToDevice, c->stream)); off += a.words; }
-            if (budget > sizeof(uint64_t) * (size_t)tot * 2) budget -= sizeof(uint64_t) * (size_t)tot * 2;
-            for (int v = 0; v < W; ++v) {
-                if (real && v != c->rank) continue;
-                if (!real && v > 0) {                // next virtual rank starts from the backbone state again
-                    off = 0;
-                    for (const Arr& a : arrs) { DPR_HIP(hipMemcpyAsync(a.cur, snap_old + off, sizeof(uint64_t) * (size_t)a.words, hipMemcpyDeviceToDevice, c->stream)); off += a.words; }
-                }
-                if (int rc = dc_cluster_phase(p, h_cl.data(), n, B, source, dist_type, &c->msa, &c->mash, c->place_trace, budget,
-                                              &c->dc_stats, v, W, c->stream)) return rc;
-                off = 0;
-                for (const Arr& a : arrs) {
-                    if (int rc = dc_delta_sub(a.cur, snap_old + off, a.words, c->stream)) return rc;
-                    if (!real) { if (int rc = dc_delta_add(snap_acc + off, a.cur, a.words, c->stream)) return rc; }
-                    off += a.words;
-                }
-            }
-            off = 0;
-            for (const Arr& a : arrs) {
-                if (real) {
-                    if (g_rccl.AllReduce(a.cur, a.cur, (size_t)a.words, kNcclUint64, kNcclSum, c->comm, c->stream) != 0) { set_error("ncclAllReduce(state delta) failed"); return DPR_ERR_COMM; }
-                } else {
-                    DPR_HIP(hipMemcpyAsync(a.cur, snap_acc + off, sizeof(uint64_t) * (size_t)a.words, hipMemcpyDeviceToDevice, c->stream));
-                }
-                if (int rc = dc_delta_add(a.cur, snap_old + off, a.words, c->stream)) return rc;
-                off += a.words;
-            }
-        }
-        DPR_HIP(hipEventRecord(ev[3], c->stream));
-        DPR_HIP(hipMemcpyAsync(head, p.head, sizeof(int32_t) * (size_t)(2 * n), hipMemcpyDeviceToHost, c->stream));
-        DPR_HIP(hipMemcpyAsync(e, p.e, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
-        DPR_HIP(hipMemcpyAsync(nxt, p.nxt, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
-        DPR_HIP(hipMemcpyAsync(belong, p.belong, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
-        DPR_HIP(hipMemcpyAsync(len, p.len, sizeof(double) * (size_t)(8 * n), hipMemcpyDeviceToHost, c->stream));
-        DPR_HIP(hipStreamSynchronize(c->stream));
-        float ms = 0;
-        DPR_HIP(hipEventElapsedTime(&ms, ev[0], ev[1])); c->dc_ms[0] = ms;
-        DPR_HIP(hipEventElapsedTime(&ms, ev[1], ev[2])); c->dc_ms[1] = ms;
-        DPR_HIP(hipEventElapsedTime(&ms, ev[2], ev[3])); c->dc_ms[2] = ms;
-        c->nj_ms = c->dc_ms[0] + c->dc_ms[1] + c->dc_ms[2];
-        if (cluster_id) std::copy(h_cl.begin(), h_cl.end(), cluster_id);
-        return DPR_OK;
-    };
-    const int rc = run();
-    place_collect_dist_ms(c);     // (backbone placement batches; the events must not outlive the run)
-    if (dT) (void)hipFree(dT);
-    if (d_cl) (void)hipFree(d_cl);
-    if (snap_old) (void)hipFree(snap_old);
-    if (snap_acc) (void)hipFree(snap_acc);
-    dc_table_free(tab);
-    for (auto& x : ev) (void)hipEventDestroy(x);
-    return rc;
-}
-
-int dpr_dc_query_share(int64_t n, int64_t backbone, int rank, int world, int64_t* q0, int64_t* q1)
-{
-    if (!q0 || !q1 || world < 1 || rank < 0 || rank >= world || backbone < 0 || backbone > n) { set_error("dpr_dc_query_share: bad argument"); return DPR_ERR_ARG; }
-    dc_query_share(n, backbone, rank, world, q0, q1);
-    return DPR_OK;
-}
-
-int dpr_dc_deal_clusters(const int64_t* sizes_desc, int64_t count, int world, int32_t* owner)
-{
-    if (!sizes_desc || !owner || count < 0 || world < 1) { set_error("dpr_dc_deal_clusters: bad argument"); return DPR_ERR_ARG; }
-    dc_deal_clusters(sizes_desc, count, world, owner);
-    return DPR_OK;
-}
-
-int dpr_get_dc_stats(dpr_ctx* c, int64_t* counts5, double* phase_ms3)
-{
-    if (!c) { set_error("dpr_get_dc_stats: null ctx"); return DPR_ERR_ARG; }
-    if (counts5) {
-        counts5[0] = c->dc_stats.clusters; counts5[1] = c->dc_stats.max_cluster; counts5[2] = c->dc_stats.pairs;
-        counts5[3] = c->dc_stats.groups; counts5[4] = c->dc_stats.jobs;
-    }
-    if (phase_ms3) for (int i = 0; i < 3; ++i) phase_ms3[i] = c->dc_ms[i];
-    return DPR_OK;
-}
-
-int dpr_get_place_state(dpr_ctx* c, int32_t* cid, double* cdis, double* trace)
-{
-    if (!c || !c->place.cid) { set_error("dpr_get_place_state: no placement state"); return DPR_ERR_STATE; }
-    DPR_HIP(hipStreamSynchronize(c->stream));   // the plain copies below run on the null stream, which does not wait for c->stream
-    const int64_t n = c->place.N;
-    if (cid) DPR_HIP(hipMemcpy(cid, c->place.cid, sizeof(int32_t) * (size_t)(40 * n), hipMemcpyDeviceToHost));
-    if (cdis) DPR_HIP(hipMemcpy(cdis, c->place.cdis, sizeof(double) * (size_t)(40 * n), hipMemcpyDeviceToHost));
-    if (trace) DPR_HIP(hipMemcpy(trace, c->place_trace, sizeof(double) * (size_t)(3 * n), hipMemcpyDeviceToHost));
     return DPR_OK;
 }
 
