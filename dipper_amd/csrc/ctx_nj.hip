@@ -199,6 +199,7 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
         std::vector<NjBuffers*> ranks = njr_ranks(c);
         if (int rc = njr_build(ranks, c->stream)) return rc;
         c->nj_row_pruned = true;
+        c->nj_exchange_note = std::string("row-sharded pruned NJ (njr.hip), exchange plan ") + (rplan == kNjrMailbox ? "mailbox" : "collective");
     }
     if ((c->world == 1 || repl) && want_pruned(c) && n >= 3) {
         NjPruned& q = c->nj[0].pr;

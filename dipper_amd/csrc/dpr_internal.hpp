@@ -323,7 +323,6 @@ NjrLayout njr_layout(int64_t N, int world);
 int njr_build(std::vector<NjBuffers*>& ranks, hipStream_t s);      // the ranks held by this process (all of them: virtual ranks; one: a process rank)
 int njr_run(std::vector<NjBuffers*>& ranks, int64_t it0, int64_t todo, hipStream_t s);
 void njr_free(NjBuffers& b);
-int njr_debug_matrix_row(std::vector<NjBuffers*>& ranks, int64_t slot, double* d_out, hipStream_t s);   // test hook: row of a live slot in slot order
 
 // njp.hip: exact pruned NJ (world == 1)
 int njp_build(NjBuffers& b, hipStream_t s);   // permute the tip-order matrix by ascending row sum into the pruned path's own buffer

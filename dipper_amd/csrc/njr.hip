@@ -565,27 +565,4 @@ int njr_run(std::vector<NjBuffers*>& ranks, int64_t it0, int64_t todo, hipStream
     return DPR_OK;
 }
 
-// test hook: the row of live slot `slot` as the ranks hold it, in SLOT order (n entries), into device memory d_out (rank 0's)
-__global__ __launch_bounds__(kThreads) void njr_row_by_slot_kernel(const double* __restrict__ row, const int32_t* __restrict__ pos_of_slot, int64_t n, double* __restrict__ out)
-{
-    const int64_t sl = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (sl < n) out[sl] = row[pos_of_slot[sl]];
-}
-int njr_debug_matrix_row(std::vector<NjBuffers*>& ranks, int64_t slot, double* d_out, hipStream_t s)
-{
-    NjBuffers& b0 = *ranks[0];
-    NjState st;
-    DPR_HIP(hipStreamSynchronize(s));
-    DPR_HIP(hipMemcpy(&st, b0.st, sizeof(NjState), hipMemcpyDeviceToHost));
-    if (slot < 0 || slot >= st.n) { set_error("njr_debug_matrix_row: slot out of range"); return DPR_ERR_ARG; }
-    int32_t p = -1;
-    DPR_HIP(hipMemcpy(&p, b0.pr.pos_of_slot + slot, sizeof(int32_t), hipMemcpyDeviceToHost));
-    const int half = (b0.pr.epoch_index + 1) & 1, o = njr_owner(p, b0.rs.world);
-    const double* row = b0.rs.peer_half[half][(size_t)o] + njr_local_row(p, b0.rs.world) * b0.pr.ld;
-    hipLaunchKernelGGL(njr_row_by_slot_kernel, dim3((unsigned)((st.n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, row, (const int32_t*)b0.pr.pos_of_slot, st.n, d_out);
-    DPR_HIP(hipGetLastError());
-    DPR_HIP(hipStreamSynchronize(s));
-    return DPR_OK;
-}
-
 }  // namespace dpr

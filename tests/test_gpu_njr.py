@@ -93,6 +93,30 @@ def test_virtual_ranks_msa_8k_equal_single_gpu_and_oracle_prefix(orc, world, pla
         assert np.array_equal(res[key][:300], ref[key][:300]), key
 
 
+@pytest.mark.parametrize("world,n,grid", [(5, 3000, None), (6, 9300, None), (7, 1024, None), (8, 4096, "4"), (3, 5121, "7")])
+def test_virtual_ranks_odd_worlds_chunk_edges_and_tiny_scan_grids(orc, monkeypatch, world, n, grid):
+    """rank counts that are no powers of two (the kernels divide chunk indices by the rank count through a 16-bit reciprocal),
+    position counts on and next to chunk boundaries, ranks without rows, and unit-scan grids smaller than the rank count (every
+    rank gets one scan block that walks all its listed units): the oracle's log, mailbox plan, many epochs"""
+    from dipper_amd import capi
+    monkeypatch.setenv("DPR_NJ_EPOCH_MIN", "500")
+    if grid:
+        monkeypatch.setenv("DPR_NJP_GRID", grid)
+    rng = np.random.default_rng(n * 31 + world)
+    D = np.round(rng.random((n, n)) * 0.9 + 0.1, 3)
+    D = np.tril(D, -1) + np.tril(D, -1).T
+    ref = orc.nj_run(np.tril(D, -1), threads=16)
+    d = _ctx(world, "mailbox")
+    try:
+        d.set_matrix_full(D)
+        d.dist_matrix(capi.SRC_MATRIX)
+        assert "row-sharded pruned" in d.nj_exchange_info()["note"]
+        res = d.nj_run()
+    finally:
+        d.close()
+    _same(res, ref, f"{world} ranks, {n} tips")
+
+
 @pytest.mark.parametrize("case", [0, 1, 2, 3], ids=["nan_pair", "inf_few", "nan_and_inf", "inf_row"])
 def test_virtual_ranks_nonfinite(orc, monkeypatch, case):
     from tests import _nonfinite
