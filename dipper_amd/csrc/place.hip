@@ -97,13 +97,17 @@ __device__ __forceinline__ void er_write_edge(const PlaceBuffers& p, int k, int 
 // program order.  cont[2i] == -2 marks a target node of degree > 3 (possible only in an imported backbone),
 // which falls back to walking that node's list.
 constexpr int kQueueLds = 2048;
-__device__ __forceinline__ void closest_update_wave(const PlaceBuffers& p, int x, int start_slot)
+// (seeded form: the frontier starts with `ns` entries (slot, distance) held by lane 0 -- the split has already applied the
+//  rounds it can do in registers, split_bfs_rounds01; ns is wave-uniform)
+__device__ __forceinline__ void closest_update_wave_seeded(const PlaceBuffers& p, int x, int ns, const int* seeds, const double* sdis)
 {
     __shared__ int32_t sq_id[kQueueLds];
     __shared__ double sq_dis[kQueueLds];
     const int lane = threadIdx.x & 63;
-    int l = 0, r = 1;  // queue [l, r)
-    if (lane == 0) { sq_id[0] = start_slot; sq_dis[0] = 0.0; }
+    int l = 0, r = ns;  // queue [l, r)
+    if (lane == 0)
+        for (int k = 0; k < 4; ++k)
+            if (k < ns) { sq_id[k] = seeds[k]; sq_dis[k] = sdis[k]; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     while (l < r) {
@@ -197,6 +201,52 @@ __device__ __forceinline__ void closest_update_wave(const PlaceBuffers& p, int x
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
+}
+
+__device__ __forceinline__ void closest_update_wave(const PlaceBuffers& p, int x, int start_slot)
+{
+    const int seeds[4] = { start_slot, -1, -1, -1 };
+    const double sdis[4] = { 0.0, 0.0, 0.0, 0.0 };
+    closest_update_wave_seeded(p, x, 1, seeds, sdis);
+}
+
+// Rounds 0 and 1 of the new leaf's closest-list BFS in REGISTERS, by the lane that has just split the edge (round 5: two dependent
+// global round trips less per tip).  Round 0 reaches e2 = outside -> middle with distance 0 (its list l2: whatever the slot held),
+// round 1 -- through cont[e2] = (e0, e1) with distance len[e2] = addLen -- e0 = middle -> x and e1 = middle -> y, whose lists
+// n0 / n1 and lengths len0 / len1 the split holds; a slot the leaf enters passes it on to its continuation slots (oy0, oy1 behind
+// e0; ox0, ox1 behind e1) with distance + length.  Same insertion rule as closest_update_wave (first entry strictly farther), same
+// additions in the same order.  The lists are updated in place; returns the number of seeds for round 2 (<= 4).
+__device__ __forceinline__ int split_bfs_rounds01(int leaf, double addLen, double len0, double len1, double* l2d, int* l2i, double* n0d, int* n0i,
+                                                  double* n1d, int* n1i, int oy0, int oy1, int ox0, int ox1, int* seeds, double* sdis)
+{
+    auto ins = [&](double* cd, int* ci, double d) -> bool {
+        int j = K5;
+#pragma unroll
+        for (int t = K5 - 1; t >= 0; --t)
+            if (cd[t] > d) j = t;
+        if (j == K5) return false;
+#pragma unroll
+        for (int t = K5 - 1; t > 0; --t)
+            if (t > j) { cd[t] = cd[t - 1]; ci[t] = ci[t - 1]; }
+#pragma unroll
+        for (int t = 0; t < K5; ++t)
+            if (t == j) { cd[t] = d; ci[t] = leaf; }
+        return true;
+    };
+    if (!ins(l2d, l2i, 0.0)) return 0;
+    const double d1 = 0.0 + addLen;                 // (d + len[e2], as the BFS computes it)
+    int ns = 0;
+    if (ins(n0d, n0i, d1)) {
+        const double dn = d1 + len0;
+        if (oy0 >= 0) { seeds[ns] = oy0; sdis[ns] = dn; ++ns; }
+        if (oy1 >= 0) { seeds[ns] = oy1; sdis[ns] = dn; ++ns; }
+    }
+    if (ins(n1d, n1i, d1)) {
+        const double dn = d1 + len1;
+        if (ox0 >= 0) { seeds[ns] = ox0; sdis[ns] = dn; ++ns; }
+        if (ox1 >= 0) { seeds[ns] = ox1; sdis[ns] = dn; ++ns; }
+    }
+    return ns;
 }
 
 // buildInitialTree + the two closest updates; dis = distance row of tip 1 (entry 0)
@@ -411,6 +461,9 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
     const double fracLen = bfrac, addLen = badd;
     const unsigned long long tk1 = wall_clock64();
     const int placeId = (int)num;
+    int bfs_ns = -1;                 // seeds of the BFS after the rounds done in registers (-1: none done, start at e2)
+    int bfs_seed[4] = { -1, -1, -1, -1 };
+    double bfs_dis[4] = { 0.0, 0.0, 0.0, 0.0 };
     if (lane == 0) {
         if (trace) { trace[3 * num] = eid; trace[3 * num + 1] = fracLen; trace[3 * num + 2] = addLen; }
         const int N = (int)p.N;
@@ -496,6 +549,16 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
         p.cont[2 * ye] = e0; p.cont[2 * ye + 1] = e3;
         p.cont[2 * e2] = e0; p.cont[2 * e2 + 1] = e1;
         p.cont[2 * e3] = -1; p.cont[2 * e3 + 1] = -1;
+        // rounds 0 and 1 of the closest-list BFS here, in registers (not behind a node of degree > 3: the walk form stays in the BFS)
+        if (ox0 != -2 && oy0 != -2) {
+            bfs_ns = split_bfs_rounds01(placeId, addLen, fracLen, originalDis - fracLen, i2d, i2i, n0d, n0i, n1d, n1i, oy0, oy1, ox0, ox1, bfs_seed, bfs_dis);
+#pragma unroll
+            for (int i = 0; i < K5; ++i) {
+                p.cid[e0 * K5 + i] = n0i[i]; p.cdis[e0 * K5 + i] = n0d[i];
+                p.cid[e1 * K5 + i] = n1i[i]; p.cdis[e1 * K5 + i] = n1d[i];
+                p.cid[e2 * K5 + i] = i2i[i]; p.cdis[e2 * K5 + i] = i2d[i];
+            }
+        }
         // edge records: `middle` has the largest node id, so the slots leaving it are the evaluated sides; xe and ye (and
         // e2) now have belong < e
         const int nedge = (int)(2 * num - 2);
@@ -509,7 +572,9 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const unsigned long long tk2 = wall_clock64();
-    closest_update_wave(p, placeId, (int)edge_count + 2);   // the new leaf's only slot: outside -> middle
+    bfs_ns = __builtin_amdgcn_readfirstlane(bfs_ns);
+    if (bfs_ns < 0) closest_update_wave(p, placeId, (int)edge_count + 2);   // the new leaf's only slot: outside -> middle
+    else if (bfs_ns > 0) closest_update_wave_seeded(p, placeId, bfs_ns, bfs_seed, bfs_dis);
     if ((p.dbg & 4) && trace && lane == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         const unsigned long long tk3 = wall_clock64();
@@ -782,12 +847,14 @@ __device__ __forceinline__ bool dirty_has(const DirtySet& ds, int slot)
 }
 
 // updateClosestNodes as closest_update_wave, additionally recording every slot whose list changed (and its reverse)
-__device__ __forceinline__ void closest_update_wave_rec(const PlaceBuffers& p, int x, int start_slot, const DirtySet& ds,
+__device__ __forceinline__ void closest_update_wave_rec(const PlaceBuffers& p, int x, int ns, const int* seeds, const double* sdis, const DirtySet& ds,
                                                         int32_t* sq_id, double* sq_dis)
 {
     const int lane = threadIdx.x & 63;
-    int l = 0, r = 1;
-    if (lane == 0) { sq_id[0] = start_slot; sq_dis[0] = 0.0; }
+    int l = 0, r = ns;
+    if (lane == 0)
+        for (int k = 0; k < 4; ++k)
+            if (k < ns) { sq_id[k] = seeds[k]; sq_dis[k] = sdis[k]; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     while (l < r) {
@@ -972,6 +1039,9 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
             const double fracLen = bfrac, addLen = badd;
             const int placeId = (int)num;
             int ec = ec0;
+            int bfs_ns = 1;                  // (default: the BFS starts at e2 with distance 0)
+            int bfs_seed[4] = { ec0 + 2, -1, -1, -1 };
+            double bfs_dis[4] = { 0.0, 0.0, 0.0, 0.0 };
             if (lane == 0) {
                 if (trace) { trace[3 * num] = eid; trace[3 * num + 1] = fracLen; trace[3 * num + 2] = addLen; }
                 s_nrescan = 0;
@@ -1061,6 +1131,15 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
                 p.cont[2 * ye] = e0; p.cont[2 * ye + 1] = e3;
                 p.cont[2 * e2] = e0; p.cont[2 * e2 + 1] = e1;
                 p.cont[2 * e3] = -1; p.cont[2 * e3 + 1] = -1;
+                if (ox0 != -2 && oy0 != -2) {      // rounds 0 and 1 of the BFS in registers (as place_finish_and_update)
+                    bfs_ns = split_bfs_rounds01(placeId, addLen, fracLen, originalDis - fracLen, i2d, i2i, n0d, n0i, n1d, n1i, oy0, oy1, ox0, ox1, bfs_seed, bfs_dis);
+#pragma unroll
+                    for (int i = 0; i < K5; ++i) {
+                        p.cid[e0 * K5 + i] = n0i[i]; p.cdis[e0 * K5 + i] = n0d[i];
+                        p.cid[e1 * K5 + i] = n1i[i]; p.cdis[e1 * K5 + i] = n1d[i];
+                        p.cid[e2 * K5 + i] = i2i[i]; p.cdis[e2 * K5 + i] = i2d[i];
+                    }
+                }
                 {   // edge records (as place_finish_and_update)
                     const int nedge = (int)(2 * num - 2);
                     er_write_edge(p, kold, e0, n0d, n0i, xe, cdx, cix, fracLen);
@@ -1075,7 +1154,8 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            closest_update_wave_rec(p, placeId, ec0 + 2, ds, sq_id, sq_dis);   // the new leaf's only slot: outside -> middle
+            bfs_ns = __builtin_amdgcn_readfirstlane(bfs_ns);
+            if (bfs_ns > 0) closest_update_wave_rec(p, placeId, bfs_ns, bfs_seed, bfs_dis, ds, sq_id, sq_dis);   // (from the new leaf's only slot, outside -> middle, or from where the rounds done in registers got)
         }
         // the other wavefronts evaluate the next tip against what wavefront 0 has just stored
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
