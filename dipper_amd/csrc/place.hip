@@ -210,42 +210,179 @@ __device__ __forceinline__ void closest_update_wave(const PlaceBuffers& p, int x
     closest_update_wave_seeded(p, x, 1, seeds, sdis);
 }
 
-// Rounds 0 and 1 of the new leaf's closest-list BFS in REGISTERS, by the lane that has just split the edge (round 5: two dependent
-// global round trips less per tip).  Round 0 reaches e2 = outside -> middle with distance 0 (its list l2: whatever the slot held),
-// round 1 -- through cont[e2] = (e0, e1) with distance len[e2] = addLen -- e0 = middle -> x and e1 = middle -> y, whose lists
-// n0 / n1 and lengths len0 / len1 the split holds; a slot the leaf enters passes it on to its continuation slots (oy0, oy1 behind
-// e0; ox0, ox1 behind e1) with distance + length.  Same insertion rule as closest_update_wave (first entry strictly farther), same
-// additions in the same order.  The lists are updated in place; returns the number of seeds for round 2 (<= 4).
-__device__ __forceinline__ int split_bfs_rounds01(int leaf, double addLen, double len0, double len1, double* l2d, int* l2i, double* n0d, int* n0i,
-                                                  double* n1d, int* n1i, int oy0, int oy1, int ox0, int ox1, int* seeds, double* sdis)
+// ---- the split, by one wavefront with the five list entries of a slot held one per LANE (lanes 0..4) -----------------
+// updateTreeStructure (src/placement_close_k.cu:430-527) was, through round 5's first half, the work of lane 0 alone: ~800
+// dependent instructions of list arithmetic and ~250 stores, 2.5 us of the 3.6 us the split took.  Here a list is a (double, int)
+// pair per lane: loads, inherits, inserts and stores of a list are one or two instructions for the wave, the four new slots'
+// scalars go out one slot per lane, and the merge of the two inherited lists is a rank computation over 15 lanes.
+//
+// insert (d, leaf) before the first entry strictly farther (list_insert); false if no entry is
+__device__ __forceinline__ bool lane_list_insert(double& cd, int& ci, double d, int leaf, int lane)
 {
-    auto ins = [&](double* cd, int* ci, double d) -> bool {
-        int j = K5;
-#pragma unroll
-        for (int t = K5 - 1; t >= 0; --t)
-            if (cd[t] > d) j = t;
-        if (j == K5) return false;
-#pragma unroll
-        for (int t = K5 - 1; t > 0; --t)
-            if (t > j) { cd[t] = cd[t - 1]; ci[t] = ci[t - 1]; }
-#pragma unroll
-        for (int t = 0; t < K5; ++t)
-            if (t == j) { cd[t] = d; ci[t] = leaf; }
-        return true;
-    };
-    if (!ins(l2d, l2i, 0.0)) return 0;
-    const double d1 = 0.0 + addLen;                 // (d + len[e2], as the BFS computes it)
-    int ns = 0;
-    if (ins(n0d, n0i, d1)) {
-        const double dn = d1 + len0;
-        if (oy0 >= 0) { seeds[ns] = oy0; sdis[ns] = dn; ++ns; }
-        if (oy1 >= 0) { seeds[ns] = oy1; sdis[ns] = dn; ++ns; }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(lane < K5 && cd > d);
+    if (m == 0ull) return false;
+    const int j = (int)__builtin_ctzll(m);
+    const double pd = __shfl_up(cd, 1, 64);
+    const int pi = __shfl_up(ci, 1, 64);
+    if (lane == j) { cd = d; ci = leaf; }
+    else if (lane > j) { cd = pd; ci = pi; }
+    return true;
+}
+__device__ __forceinline__ void lane_list_store(const PlaceBuffers& p, int slot, double cd, int ci, int lane)
+{
+    if (lane < K5) { p.cdis[slot * K5 + lane] = cd; p.cid[slot * K5 + lane] = ci; }
+}
+__device__ __forceinline__ void lane_er_write_side(const PlaceBuffers& p, int ex, double cd, int ci, int lane)
+{
+    const int64_t k = ex >> 1;
+    const int o = (ex & 1) * K5;
+    if (lane < K5) { p.er_d[(int64_t)(o + lane) * p.ecap + k] = cd; p.er_i[(int64_t)(o + lane) * p.ecap + k] = ci; }
+}
+
+// Splits edge slot `eid` (reverse slot brev, -1: look it up) at fracLen for tip `num` with pendant length addLen; ec0 = 4*num-4 is
+// the first of the four new slots e0 = middle->x, e1 = middle->y, e2 = outside->middle, e3 = middle->outside.  i0..i3 = what
+// those slots' lists hold now (lane-distributed; slots the reference never touched keep the init values 2 / -1, which it reads
+// back here).  Also applies rounds 0 and 1 of the new leaf's closest-list BFS while the lists are in registers (two dependent
+// global round trips less per tip): round 0 reaches e2 with distance 0, round 1 -- through cont[e2] = (e0, e1) with distance
+// len[e2] = addLen -- e0 and e1; a slot the leaf enters passes it on to its continuation slots (oy0, oy1 behind e0; ox0, ox1
+// behind e1) with distance + length: same insertion rule and the same additions in the same order as closest_update_wave.
+// Returns the number of frontier entries for round 2 (seeds / sdis, <= 4), or -1 when a node of degree > 3 lies behind x or y
+// (imported backbone: the BFS then starts at e2 and walks).  Everything returned is wave-uniform.
+// TWO wavefronts share the work (role = wavefront index 0 / 1, both called with the same arguments): wavefront 0 takes what the
+// closest-list BFS it runs next depends on -- the inherited lists of e0 / e1, rounds 0-1 of the BFS, their stores and record
+// sides -- and wavefront 1 the bookkeeping nothing in that BFS reads (the slots' scalars, continuation slots, the merged list of
+// e3, the record scalars and the sides of xe / ye / e3): 1.4 us of dependent instructions off the tip's critical path.  The BFS
+// only reaches slots beyond x and y, none of which the split writes -- except in the degree > 3 fallback, where it starts at e2
+// and reads the new slots: there wavefront 0 does everything itself and wavefront 1 nothing.  Disjoint stores; both end before
+// the next kernel / the block barrier of the multi-tip kernel.
+__device__ __forceinline__ int place_split_wave(const PlaceBuffers& p, int64_t num, int ec0, int eid, int brev, double fracLen, double addLen,
+                                                double i0d, int i0i, double i1d, int i1i, double i2d, int i2i, double i3d, int i3i,
+                                                int mininel, int role, int* seeds, double* sdis, int& xe_out, int& ye_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int li = lane < K5 ? lane : 0;
+    const int placeId = (int)num, N = (int)p.N;
+    const int middle = placeId + N - 1, outside = placeId;
+    const int xe = eid, ye = brev >= 0 ? brev : p.rev[eid];   // the reference finds them by walking head[x] / head[y]
+    // every load of the split in one round trip, before the first store (same addresses for all lanes but the list entries)
+    const int x = p.belong[eid], y = p.e[eid];
+    const double originalDis = p.len[eid];
+    const double cdx = p.cdis[xe * K5 + li], cdy = p.cdis[ye * K5 + li];
+    const int cix = p.cid[xe * K5 + li], ciy = p.cid[ye * K5 + li];
+    const double lenye = p.len[ye];
+    const int ox0 = p.cont[2 * xe], ox1 = p.cont[2 * xe + 1], oy0 = p.cont[2 * ye], oy1 = p.cont[2 * ye + 1];
+    const int kold = p.eidx[xe] >> 1;                  // the record of the edge being split: taken over by (middle, x)
+    const int e0 = ec0, e1 = ec0 + 1, e2 = ec0 + 2, e3 = ec0 + 3;
+    const int nedge = (int)(2 * num - 2);              // records of the two new edges: nedge = (middle, y), nedge + 1 = (middle, outside)
+    const double len1 = originalDis - fracLen;
+    const bool fallback = ox0 == -2 || oy0 == -2;
+    const bool lists = role == 0, book = fallback ? role == 0 : role == 1;
+    // middle -> x inherits the list of y -> x, middle -> y the list of x -> y (entry by entry; an empty entry keeps what the slot held)
+    const bool has0 = ciy != -1, has1 = cix != -1;
+    double n0d = has0 ? cdy + originalDis - fracLen : i0d, n1d = has1 ? cdx + fracLen : i1d;
+    int n0i = has0 ? ciy : i0i, n1i = has1 ? cix : i1i;
+    if (book) {
+        // the four new slots, one per lane: e0 = middle -> x, e1 = middle -> y, e2 = outside -> middle, e3 = middle -> outside
+        if (lane < 4) {
+            const int s = ec0 + lane;
+            p.e[s] = lane == 0 ? x : lane == 1 ? y : lane == 2 ? middle : outside;
+            p.len[s] = lane == 0 ? fracLen : lane == 1 ? len1 : addLen;
+            p.nxt[s] = lane == 1 ? e0 : lane == 3 ? e1 : -1;
+            p.belong[s] = lane == 2 ? outside : middle;
+            p.rev[s] = lane == 0 ? xe : lane == 1 ? ye : lane == 2 ? e3 : e2;
+            p.eidx[s] = lane == 0 ? 2 * kold : lane == 1 ? 2 * nedge : lane == 2 ? 2 * (nedge + 1) + 1 : 2 * (nedge + 1);
+        }
+        // continuation slots: the new slots towards x / y inherit what lay beyond y -> x / x -> y; e2 leads to e0 and e1, e3 ends at
+        // the new leaf; slots entering x or y from elsewhere keep theirs (slot ids do not change)
+        if (lane < 8)
+            p.cont[2 * ec0 + lane] = lane == 0 ? oy0 : lane == 1 ? oy1 : lane == 2 ? ox0 : lane == 3 ? ox1 : lane == 4 ? e0 : lane == 5 ? e1 : -1;
+        // the two slots of the split edge now end in `middle`
+        if (lane < 2) {
+            const int s = lane == 0 ? xe : ye;
+            p.e[s] = middle;
+            p.len[s] = lane == 0 ? fracLen : lenye - fracLen;
+            p.rev[s] = ec0 + lane;
+            p.cont[2 * s] = lane == 0 ? e1 : e0; p.cont[2 * s + 1] = e3;
+            p.eidx[s] = lane == 0 ? 2 * kold + 1 : 2 * nedge + 1;
+        }
+        // edge records (scalars): `middle` has the largest node id, so the slots leaving it are the evaluated sides
+        if (lane < 3) {
+            const int k = lane == 0 ? kold : nedge + lane - 1;
+            p.er_d[(int64_t)10 * p.ecap + k] = lane == 0 ? fracLen : lane == 1 ? len1 : addLen;
+            p.er_i[(int64_t)10 * p.ecap + k] = lane == 0 ? e0 : lane == 1 ? e1 : e3;
+            p.er_i[(int64_t)11 * p.ecap + k] = lane == 0 ? xe : lane == 1 ? ye : e2;
+        }
+        if (lane == 0) {
+            p.head[outside] = e2; p.head[middle] = e3;
+            const int lo = xe < ye ? xe : ye;                  // xe, ye (and e2) now have belong < e
+            if (lo < mininel) p.misc[0] = lo;
+        }
+        // middle -> outside: the slot's list, then the entries of e1's list up to its first empty one, then e0's likewise, each inserted
+        // before the first entry strictly farther, five kept (src/placement_close_k.cu:506-527).  An entry dropped at one insertion never
+        // comes back, so that is the first five of the 5 + a + b candidates in order of (distance, order of insertion): ranks over lanes
+        // 0..4 (slot's list), 5..9 (e1's), 10..14 (e0's)
+        double md;
+        int mi;
+        {
+            const unsigned long long m1 = __builtin_amdgcn_ballot_w64(lane < K5 && n1i != -1), m0 = __builtin_amdgcn_ballot_w64(lane < K5 && n0i != -1);
+            const int a = (int)__builtin_ctzll(~m1), b = (int)__builtin_ctzll(~m0);       // lengths of the non-empty prefixes
+            const int src = lane < K5 ? lane : lane < 2 * K5 ? lane - K5 : lane - 2 * K5;
+            const double s1d = __shfl(n1d, src, 64), s0d = __shfl(n0d, src, 64);
+            const int s1i = __shfl(n1i, src, 64), s0i = __shfl(n0i, src, 64);
+            const double cd = lane < K5 ? i3d : lane < 2 * K5 ? s1d : s0d;
+            const int ci = lane < K5 ? i3i : lane < 2 * K5 ? s1i : s0i;
+            const unsigned vmask = 0x1fu | (((1u << a) - 1u) << K5) | (((1u << b) - 1u) << (2 * K5));
+            const bool valid = lane < 3 * K5 && ((vmask >> lane) & 1u);
+            int rank = 0;
+    #pragma unroll
+            for (int k = 0; k < 3 * K5; ++k) {
+                const double dk = readlane_f64(cd, k);
+                const bool before = dk < cd || (dk == cd && k < lane);
+                rank += (((vmask >> k) & 1u) && before) ? 1 : 0;
+            }
+            md = 0.0; mi = 0;
+    #pragma unroll
+            for (int r = 0; r < K5; ++r) {
+                const unsigned long long mr = __builtin_amdgcn_ballot_w64(valid && rank == r);
+                const int from = mr ? (int)__builtin_ctzll(mr) : r;      // (exactly one lane unless a distance is NaN)
+                const double vd = readlane_f64(cd, from);
+                const int vi = __builtin_amdgcn_readlane(ci, from);
+                if (lane == r) { md = vd; mi = vi; }
+            }
+        }
+        lane_list_store(p, e3, md, mi, lane);
+        lane_er_write_side(p, 2 * kold + 1, cdx, cix, lane);
+        lane_er_write_side(p, 2 * nedge + 1, cdy, ciy, lane);
+        lane_er_write_side(p, 2 * (nedge + 1), md, mi, lane);
     }
-    if (ins(n1d, n1i, d1)) {
-        const double dn = d1 + len1;
-        if (ox0 >= 0) { seeds[ns] = ox0; sdis[ns] = dn; ++ns; }
-        if (ox1 >= 0) { seeds[ns] = ox1; sdis[ns] = dn; ++ns; }
+    // rounds 0 and 1 of the closest-list BFS (not behind a node of degree > 3: the walk form stays in the BFS)
+    int ns = -1;
+    if (lists) {
+        if (!fallback) {
+            ns = 0;
+            if (lane_list_insert(i2d, i2i, 0.0, placeId, lane)) {
+                const double d1 = 0.0 + addLen;             // (d + len[e2], as the BFS computes it)
+                if (lane_list_insert(n0d, n0i, d1, placeId, lane)) {
+                    const double dn = d1 + fracLen;         // len[e0]
+                    if (oy0 >= 0) { seeds[ns] = oy0; sdis[ns] = dn; ++ns; }
+                    if (oy1 >= 0) { seeds[ns] = oy1; sdis[ns] = dn; ++ns; }
+                }
+                if (lane_list_insert(n1d, n1i, d1, placeId, lane)) {
+                    const double dn = d1 + len1;            // len[e1]
+                    if (ox0 >= 0) { seeds[ns] = ox0; sdis[ns] = dn; ++ns; }
+                    if (ox1 >= 0) { seeds[ns] = ox1; sdis[ns] = dn; ++ns; }
+                }
+            }
+            lane_list_store(p, e2, i2d, i2i, lane);
+        }
+        lane_list_store(p, e0, n0d, n0i, lane);
+        lane_list_store(p, e1, n1d, n1i, lane);
+        // the same lists into the edge records (the scan of the next tip reads them there)
+        lane_er_write_side(p, 2 * kold, n0d, n0i, lane);
+        lane_er_write_side(p, 2 * nedge, n1d, n1i, lane);
+        lane_er_write_side(p, 2 * (nedge + 1) + 1, i2d, i2i, lane);
     }
+    xe_out = xe; ye_out = ye;
     return ns;
 }
 
@@ -408,19 +545,16 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
     const unsigned long long tk0 = wall_clock64();
     // (a) loads that do not depend on the winner: the (initial) lists of the new slots ec, ec+1, ec+3 -- slots the
     // reference never touched keep the init values 2 / -1, which it reads back at the split; in flight during (b)
-    double i0d[K5], i1d[K5], i2d[K5], i3d[K5];
-    int i0i[K5], i1i[K5], i2i[K5], i3i[K5];
+    double i0d = 2.0, i1d = 2.0, i2d = 2.0, i3d = 2.0;     // one list entry per lane (lanes 0..4 of wavefront 0)
+    int i0i = -1, i1i = -1, i2i = -1, i3i = -1;
     int mininel = 0x7fffffff;
-    if (tid == 0) {
-#pragma unroll
-        for (int i = 0; i < K5; ++i) {
-            i0d[i] = p.cdis[ec * K5 + i]; i0i[i] = p.cid[ec * K5 + i];
-            i1d[i] = p.cdis[(ec + 1) * K5 + i]; i1i[i] = p.cid[(ec + 1) * K5 + i];
-            i2d[i] = p.cdis[(ec + 2) * K5 + i]; i2i[i] = p.cid[(ec + 2) * K5 + i];
-            i3d[i] = p.cdis[(ec + 3) * K5 + i]; i3i[i] = p.cid[(ec + 3) * K5 + i];
-        }
-        mininel = p.misc[0];
+    if (tid < 128 && lane < K5) {          // (wavefronts 0 and 1 split the edge, place_split_wave)
+        i0d = p.cdis[ec * K5 + lane]; i0i = p.cid[ec * K5 + lane];
+        i1d = p.cdis[(ec + 1) * K5 + lane]; i1i = p.cid[(ec + 1) * K5 + lane];
+        i2d = p.cdis[(ec + 2) * K5 + lane]; i2i = p.cid[(ec + 2) * K5 + lane];
+        i3d = p.cdis[(ec + 3) * K5 + lane]; i3i = p.cid[(ec + 3) * K5 + lane];
     }
+    if (tid < 128 && lane == 0) mininel = p.misc[0];
     // (b) first minimum over the block partials of the scan: four waves, eight loads in flight per thread
     double badd = __builtin_inf(), bfrac = 0;
     int bidx = 0x7fffffff, beid = 0, brev = -1;
@@ -452,7 +586,8 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
         if (lane == src) { s_add[tid >> 6] = badd; s_idx[tid >> 6] = bidx; s_eid[tid >> 6] = beid; s_frac[tid >> 6] = bfrac; s_rev[tid >> 6] = brev; }
     }
     __syncthreads();
-    if (tid >= 64) return;                    // wave 0 goes on alone
+    if (tid >= 128) return;                   // wavefronts 0 and 1 go on: the split is shared, the BFS is wavefront 0's
+    const int role = __builtin_amdgcn_readfirstlane(tid >> 6);
     badd = s_add[0]; bidx = s_idx[0]; beid = s_eid[0]; bfrac = s_frac[0]; brev = s_rev[0];
 #pragma unroll
     for (int w = 1; w < nthr / 64; ++w)
@@ -461,118 +596,17 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
     const double fracLen = bfrac, addLen = badd;
     const unsigned long long tk1 = wall_clock64();
     const int placeId = (int)num;
-    int bfs_ns = -1;                 // seeds of the BFS after the rounds done in registers (-1: none done, start at e2)
-    int bfs_seed[4] = { -1, -1, -1, -1 };
+    if (tid == 0 && trace) { trace[3 * num] = eid; trace[3 * num + 1] = fracLen; trace[3 * num + 2] = addLen; }
+    // (c) the split and rounds 0-1 of the closest-list BFS, lists one entry per lane
+    int bfs_seed[4] = { -1, -1, -1, -1 }, xe_, ye_;
     double bfs_dis[4] = { 0.0, 0.0, 0.0, 0.0 };
-    if (lane == 0) {
-        if (trace) { trace[3 * num] = eid; trace[3 * num + 1] = fracLen; trace[3 * num + 2] = addLen; }
-        const int N = (int)p.N;
-        const int middle = placeId + N - 1, outside = placeId;
-        const int xe = eid, ye = brev >= 0 ? brev : p.rev[eid];   // the reference finds them by walking head[x] / head[y]
-        // (c) every load of the split in one round trip, before the first store
-        const int x = p.belong[eid], y = p.e[eid];
-        const double originalDis = p.len[eid];
-        double cdx[K5], cdy[K5];
-        int cix[K5], ciy[K5];
-#pragma unroll
-        for (int i = 0; i < K5; ++i) { cdx[i] = p.cdis[xe * K5 + i]; cix[i] = p.cid[xe * K5 + i]; cdy[i] = p.cdis[ye * K5 + i]; ciy[i] = p.cid[ye * K5 + i]; }
-        const double lenye = p.len[ye];
-        const int ox0 = p.cont[2 * xe], ox1 = p.cont[2 * xe + 1], oy0 = p.cont[2 * ye], oy1 = p.cont[2 * ye + 1];
-        const int kold = p.eidx[xe] >> 1;                  // the record of the edge being split: taken over by (middle, x)
-        p.e[xe] = middle; p.len[xe] = fracLen;
-        p.e[ye] = middle; p.len[ye] = lenye - fracLen;
-        // middle -> x: inherits the list of y -> x (slots untouched by the reference keep the init values 2 / -1)
-        double n0d[K5], n1d[K5];
-        int n0i[K5], n1i[K5];
-        p.e[ec] = x; p.len[ec] = fracLen; p.nxt[ec] = -1; p.belong[ec] = middle;
-#pragma unroll
-        for (int i = 0; i < K5; ++i) {
-            const bool has = ciy[i] != -1;
-            n0i[i] = has ? ciy[i] : i0i[i];
-            n0d[i] = has ? cdy[i] + originalDis - fracLen : i0d[i];
-            if (has) { p.cid[ec * K5 + i] = n0i[i]; p.cdis[ec * K5 + i] = n0d[i]; }
-        }
-        p.rev[ec] = xe; p.rev[xe] = ec;
-        ec++;
-        // middle -> y: inherits the list of x -> y
-        p.e[ec] = y; p.len[ec] = originalDis - fracLen; p.nxt[ec] = ec - 1; p.belong[ec] = middle;
-#pragma unroll
-        for (int i = 0; i < K5; ++i) {
-            const bool has = cix[i] != -1;
-            n1i[i] = has ? cix[i] : i1i[i];
-            n1d[i] = has ? cdx[i] + fracLen : i1d[i];
-            if (has) { p.cid[ec * K5 + i] = n1i[i]; p.cdis[ec * K5 + i] = n1d[i]; }
-        }
-        p.rev[ec] = ye; p.rev[ye] = ec;
-        ec++;
-        // outside -> middle
-        p.e[ec] = middle; p.len[ec] = addLen; p.nxt[ec] = -1; p.head[outside] = ec; p.belong[ec] = outside;
-        p.rev[ec] = ec + 1;
-        ec++;
-        // middle -> outside: merge of the two inherited lists (src/placement_close_k.cu:506-527), in registers
-        p.e[ec] = outside; p.len[ec] = addLen; p.nxt[ec] = ec - 2; p.head[middle] = ec; p.belong[ec] = middle;
-        p.rev[ec] = ec - 1;
-        double md[K5];
-        int mi[K5];
-#pragma unroll
-        for (int i = 0; i < K5; ++i) { md[i] = i3d[i]; mi[i] = i3i[i]; }
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            bool open = true;                                    // the reference stops a list at its first empty entry
-#pragma unroll
-            for (int i = 0; i < K5; ++i) {
-                const int si = pass == 0 ? n1i[i] : n0i[i];      // e1 = middle->y first, then e2 = middle->x
-                const double sd = pass == 0 ? n1d[i] : n0d[i];
-                open = open && si != -1;
-                int j = K5;
-#pragma unroll
-                for (int t = K5 - 1; t >= 0; --t)
-                    if (md[t] > sd) j = t;                       // first entry farther than sd
-                if (open && j < K5) {
-#pragma unroll
-                    for (int k = K5 - 1; k > 0; --k)
-                        if (k > j) { md[k] = md[k - 1]; mi[k] = mi[k - 1]; }
-#pragma unroll
-                    for (int k = 0; k < K5; ++k)
-                        if (k == j) { md[k] = sd; mi[k] = si; }
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < K5; ++i) { p.cdis[ec * K5 + i] = md[i]; p.cid[ec * K5 + i] = mi[i]; }
-        // continuation slots: the new slots towards x / y inherit what lay beyond y -> x / x -> y; xe and ye now
-        // end in `middle`; slots entering x or y from elsewhere keep theirs (slot ids do not change)
-        const int e0 = ec - 3, e1 = ec - 2, e2 = ec - 1, e3 = ec;
-        p.cont[2 * e0] = oy0; p.cont[2 * e0 + 1] = oy1;
-        p.cont[2 * e1] = ox0; p.cont[2 * e1 + 1] = ox1;
-        p.cont[2 * xe] = e1; p.cont[2 * xe + 1] = e3;
-        p.cont[2 * ye] = e0; p.cont[2 * ye + 1] = e3;
-        p.cont[2 * e2] = e0; p.cont[2 * e2 + 1] = e1;
-        p.cont[2 * e3] = -1; p.cont[2 * e3 + 1] = -1;
-        // rounds 0 and 1 of the closest-list BFS here, in registers (not behind a node of degree > 3: the walk form stays in the BFS)
-        if (ox0 != -2 && oy0 != -2) {
-            bfs_ns = split_bfs_rounds01(placeId, addLen, fracLen, originalDis - fracLen, i2d, i2i, n0d, n0i, n1d, n1i, oy0, oy1, ox0, ox1, bfs_seed, bfs_dis);
-#pragma unroll
-            for (int i = 0; i < K5; ++i) {
-                p.cid[e0 * K5 + i] = n0i[i]; p.cdis[e0 * K5 + i] = n0d[i];
-                p.cid[e1 * K5 + i] = n1i[i]; p.cdis[e1 * K5 + i] = n1d[i];
-                p.cid[e2 * K5 + i] = i2i[i]; p.cdis[e2 * K5 + i] = i2d[i];
-            }
-        }
-        // edge records: `middle` has the largest node id, so the slots leaving it are the evaluated sides; xe and ye (and
-        // e2) now have belong < e
-        const int nedge = (int)(2 * num - 2);
-        er_write_edge(p, kold, e0, n0d, n0i, xe, cdx, cix, fracLen);
-        er_write_edge(p, nedge, e1, n1d, n1i, ye, cdy, ciy, originalDis - fracLen);
-        er_write_edge(p, nedge + 1, e3, md, mi, e2, i2d, i2i, addLen);
-        const int lo = xe < ye ? xe : ye;
-        if (lo < mininel) p.misc[0] = lo;
-    }
-    // the wave reads what its lane 0 just stored: program order within the wavefront
+    const int bfs_ns = place_split_wave(p, num, ec, eid, brev, fracLen, addLen, i0d, i0i, i1d, i1i, i2d, i2i, i3d, i3i,
+                                        __builtin_amdgcn_readfirstlane(mininel), role, bfs_seed, bfs_dis, xe_, ye_);
+    if (role != 0) return;
+    // the wave reads what its lanes just stored: program order within the wavefront
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const unsigned long long tk2 = wall_clock64();
-    bfs_ns = __builtin_amdgcn_readfirstlane(bfs_ns);
     if (bfs_ns < 0) closest_update_wave(p, placeId, (int)edge_count + 2);   // the new leaf's only slot: outside -> middle
     else if (bfs_ns > 0) closest_update_wave_seeded(p, placeId, bfs_ns, bfs_seed, bfs_dis);
     if ((p.dbg & 4) && trace && lane == 0) {
@@ -1031,133 +1065,37 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
             if (lane == src) { s_add[tid >> 6] = badd; s_idx[tid >> 6] = bidx; s_eid[tid >> 6] = beid; s_frac[tid >> 6] = bfrac; s_rev[tid >> 6] = brev; }
         }
         __syncthreads();
-        if (tid < 64) {                      // wavefront 0: split + closest-list update, as place_finish_and_update
+        if (tid < 128) {                     // wavefronts 0 and 1: the split; wavefront 0: the closest-list update (as place_finish_and_update)
+            const int role = __builtin_amdgcn_readfirstlane(tid >> 6);
             badd = s_add[0]; bidx = s_idx[0]; beid = s_eid[0]; bfrac = s_frac[0]; brev = s_rev[0];
             for (int w = 1; w < nthr / 64; ++w)
                 if (s_add[w] < badd || (s_add[w] == badd && s_idx[w] < bidx)) { badd = s_add[w]; bidx = s_idx[w]; beid = s_eid[w]; bfrac = s_frac[w]; brev = s_rev[w]; }
             const int eid = beid;
             const double fracLen = bfrac, addLen = badd;
             const int placeId = (int)num;
-            int ec = ec0;
-            int bfs_ns = 1;                  // (default: the BFS starts at e2 with distance 0)
-            int bfs_seed[4] = { ec0 + 2, -1, -1, -1 };
-            double bfs_dis[4] = { 0.0, 0.0, 0.0, 0.0 };
-            if (lane == 0) {
+            if (tid == 0) {
                 if (trace) { trace[3 * num] = eid; trace[3 * num + 1] = fracLen; trace[3 * num + 2] = addLen; }
                 s_nrescan = 0;
-                const int N = (int)p.N;
-                const int middle = placeId + N - 1, outside = placeId;
-                const int xe = eid, ye = brev >= 0 ? brev : p.rev[eid];
-                double i0d[K5], i1d[K5], i2d[K5], i3d[K5];
-                int i0i[K5], i1i[K5], i2i[K5], i3i[K5];
-#pragma unroll
-                for (int i = 0; i < K5; ++i) {
-                    i0d[i] = p.cdis[ec * K5 + i]; i0i[i] = p.cid[ec * K5 + i];
-                    i1d[i] = p.cdis[(ec + 1) * K5 + i]; i1i[i] = p.cid[(ec + 1) * K5 + i];
-                    i2d[i] = p.cdis[(ec + 2) * K5 + i]; i2i[i] = p.cid[(ec + 2) * K5 + i];
-                    i3d[i] = p.cdis[(ec + 3) * K5 + i]; i3i[i] = p.cid[(ec + 3) * K5 + i];
-                }
-                const int mininel = p.misc[0];
-                const int x = p.belong[eid], y = p.e[eid];
-                const double originalDis = p.len[eid];
-                double cdx[K5], cdy[K5];
-                int cix[K5], ciy[K5];
-#pragma unroll
-                for (int i = 0; i < K5; ++i) { cdx[i] = p.cdis[xe * K5 + i]; cix[i] = p.cid[xe * K5 + i]; cdy[i] = p.cdis[ye * K5 + i]; ciy[i] = p.cid[ye * K5 + i]; }
-                const double lenye = p.len[ye];
-                const int ox0 = p.cont[2 * xe], ox1 = p.cont[2 * xe + 1], oy0 = p.cont[2 * ye], oy1 = p.cont[2 * ye + 1];
-                const int kold = p.eidx[xe] >> 1;
-                p.e[xe] = middle; p.len[xe] = fracLen;
-                p.e[ye] = middle; p.len[ye] = lenye - fracLen;
-                double n0d[K5], n1d[K5];
-                int n0i[K5], n1i[K5];
-                p.e[ec] = x; p.len[ec] = fracLen; p.nxt[ec] = -1; p.belong[ec] = middle;
-#pragma unroll
-                for (int i = 0; i < K5; ++i) {
-                    const bool has = ciy[i] != -1;
-                    n0i[i] = has ? ciy[i] : i0i[i];
-                    n0d[i] = has ? cdy[i] + originalDis - fracLen : i0d[i];
-                    if (has) { p.cid[ec * K5 + i] = n0i[i]; p.cdis[ec * K5 + i] = n0d[i]; }
-                }
-                p.rev[ec] = xe; p.rev[xe] = ec;
-                ec++;
-                p.e[ec] = y; p.len[ec] = originalDis - fracLen; p.nxt[ec] = ec - 1; p.belong[ec] = middle;
-#pragma unroll
-                for (int i = 0; i < K5; ++i) {
-                    const bool has = cix[i] != -1;
-                    n1i[i] = has ? cix[i] : i1i[i];
-                    n1d[i] = has ? cdx[i] + fracLen : i1d[i];
-                    if (has) { p.cid[ec * K5 + i] = n1i[i]; p.cdis[ec * K5 + i] = n1d[i]; }
-                }
-                p.rev[ec] = ye; p.rev[ye] = ec;
-                ec++;
-                p.e[ec] = middle; p.len[ec] = addLen; p.nxt[ec] = -1; p.head[outside] = ec; p.belong[ec] = outside;
-                p.rev[ec] = ec + 1;
-                ec++;
-                p.e[ec] = outside; p.len[ec] = addLen; p.nxt[ec] = ec - 2; p.head[middle] = ec; p.belong[ec] = middle;
-                p.rev[ec] = ec - 1;
-                double md[K5];
-                int mi[K5];
-#pragma unroll
-                for (int i = 0; i < K5; ++i) { md[i] = i3d[i]; mi[i] = i3i[i]; }
-#pragma unroll
-                for (int pass = 0; pass < 2; ++pass) {
-                    bool open = true;
-#pragma unroll
-                    for (int i = 0; i < K5; ++i) {
-                        const int si = pass == 0 ? n1i[i] : n0i[i];
-                        const double sd = pass == 0 ? n1d[i] : n0d[i];
-                        open = open && si != -1;
-                        int j = K5;
-#pragma unroll
-                        for (int t = K5 - 1; t >= 0; --t)
-                            if (md[t] > sd) j = t;
-                        if (open && j < K5) {
-#pragma unroll
-                            for (int k = K5 - 1; k > 0; --k)
-                                if (k > j) { md[k] = md[k - 1]; mi[k] = mi[k - 1]; }
-#pragma unroll
-                            for (int k = 0; k < K5; ++k)
-                                if (k == j) { md[k] = sd; mi[k] = si; }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < K5; ++i) { p.cdis[ec * K5 + i] = md[i]; p.cid[ec * K5 + i] = mi[i]; }
-                const int e0 = ec - 3, e1 = ec - 2, e2 = ec - 1, e3 = ec;
-                p.cont[2 * e0] = oy0; p.cont[2 * e0 + 1] = oy1;
-                p.cont[2 * e1] = ox0; p.cont[2 * e1 + 1] = ox1;
-                p.cont[2 * xe] = e1; p.cont[2 * xe + 1] = e3;
-                p.cont[2 * ye] = e0; p.cont[2 * ye + 1] = e3;
-                p.cont[2 * e2] = e0; p.cont[2 * e2 + 1] = e1;
-                p.cont[2 * e3] = -1; p.cont[2 * e3 + 1] = -1;
-                if (ox0 != -2 && oy0 != -2) {      // rounds 0 and 1 of the BFS in registers (as place_finish_and_update)
-                    bfs_ns = split_bfs_rounds01(placeId, addLen, fracLen, originalDis - fracLen, i2d, i2i, n0d, n0i, n1d, n1i, oy0, oy1, ox0, ox1, bfs_seed, bfs_dis);
-#pragma unroll
-                    for (int i = 0; i < K5; ++i) {
-                        p.cid[e0 * K5 + i] = n0i[i]; p.cdis[e0 * K5 + i] = n0d[i];
-                        p.cid[e1 * K5 + i] = n1i[i]; p.cdis[e1 * K5 + i] = n1d[i];
-                        p.cid[e2 * K5 + i] = i2i[i]; p.cdis[e2 * K5 + i] = i2d[i];
-                    }
-                }
-                {   // edge records (as place_finish_and_update)
-                    const int nedge = (int)(2 * num - 2);
-                    er_write_edge(p, kold, e0, n0d, n0i, xe, cdx, cix, fracLen);
-                    er_write_edge(p, nedge, e1, n1d, n1i, ye, cdy, ciy, originalDis - fracLen);
-                    er_write_edge(p, nedge + 1, e3, md, mi, e2, i2d, i2i, addLen);
-                    const int lo = xe < ye ? xe : ye;
-                    if (lo < mininel) p.misc[0] = lo;
-                }
-                // what the split changed for later evaluations: the edge's two slots and the four new ones
-                dirty_add(ds, xe); dirty_add(ds, ye);
-                dirty_add(ds, e0); dirty_add(ds, e1); dirty_add(ds, e2); dirty_add(ds, e3);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            bfs_ns = __builtin_amdgcn_readfirstlane(bfs_ns);
-            if (bfs_ns > 0) closest_update_wave_rec(p, placeId, bfs_ns, bfs_seed, bfs_dis, ds, sq_id, sq_dis);   // (from the new leaf's only slot, outside -> middle, or from where the rounds done in registers got)
+            const int li = lane < K5 ? lane : 0;
+            const double i0d = p.cdis[ec0 * K5 + li], i1d = p.cdis[(ec0 + 1) * K5 + li], i2d = p.cdis[(ec0 + 2) * K5 + li], i3d = p.cdis[(ec0 + 3) * K5 + li];
+            const int i0i = p.cid[ec0 * K5 + li], i1i = p.cid[(ec0 + 1) * K5 + li], i2i = p.cid[(ec0 + 2) * K5 + li], i3i = p.cid[(ec0 + 3) * K5 + li];
+            int bfs_seed[4] = { ec0 + 2, -1, -1, -1 }, xe, ye;
+            double bfs_dis[4] = { 0.0, 0.0, 0.0, 0.0 };
+            int bfs_ns = place_split_wave(p, num, ec0, eid, brev, fracLen, addLen, i0d, i0i, i1d, i1i, i2d, i2i, i3d, i3i, p.misc[0], role, bfs_seed, bfs_dis, xe, ye);
+            if (role == 0) {
+                if (bfs_ns < 0) { bfs_ns = 1; bfs_seed[0] = ec0 + 2; bfs_dis[0] = 0.0; }     // (degree > 3 behind x or y: the BFS starts at e2 with distance 0)
+                if (tid == 0) {
+                    // what the split changed for later evaluations: the edge's two slots and the four new ones
+                    dirty_add(ds, xe); dirty_add(ds, ye);
+                    dirty_add(ds, ec0); dirty_add(ds, ec0 + 1); dirty_add(ds, ec0 + 2); dirty_add(ds, ec0 + 3);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (bfs_ns > 0) closest_update_wave_rec(p, placeId, bfs_ns, bfs_seed, bfs_dis, ds, sq_id, sq_dis);   // (from the new leaf's only slot, outside -> middle, or from where the rounds done in registers got)
+            }
         }
-        // the other wavefronts evaluate the next tip against what wavefront 0 has just stored
+        // the other wavefronts evaluate the next tip against what wavefronts 0 and 1 have just stored
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
