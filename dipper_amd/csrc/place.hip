@@ -86,6 +86,59 @@ __device__ __forceinline__ void er_write_edge(const PlaceBuffers& p, int k, int 
     p.eidx[s0] = 2 * k; p.eidx[s1] = 2 * k + 1;
 }
 
+constexpr int kDirtyHash = 4096, kDirtyCap = 2048, kRescanCap = 128;
+struct DirtySet {          // slots whose evaluation inputs changed since the scan launch (LDS)
+    int* hash;             // [kDirtyHash] open addressing, -1 = empty
+    int* list;             // [kDirtyCap]
+    int* count;            // entries in list (may run past kDirtyCap: overflow)
+};
+__device__ __forceinline__ void dirty_add(const DirtySet& ds, int slot)
+{
+    if (*ds.count >= kDirtyCap) { atomicAdd(ds.count, 1); return; }      // overflow: the caller falls back to a full scan
+    unsigned h = ((unsigned)slot * 2654435761u) >> 20;
+    for (int probe = 0; probe < kDirtyHash; ++probe) {
+        const int old = atomicCAS(&ds.hash[h], -1, slot);
+        if (old == slot) return;
+        if (old == -1) {
+            const int k = atomicAdd(ds.count, 1);
+            if (k < kDirtyCap) ds.list[k] = slot;
+            return;
+        }
+        h = (h + 1) & (kDirtyHash - 1);
+    }
+}
+// two slots at once (a slot and its reverse): the two probes in flight together, one addition to the count
+__device__ __forceinline__ void dirty_add2(const DirtySet& ds, int a, int b)
+{
+    if (*ds.count >= kDirtyCap) { atomicAdd(ds.count, 2); return; }       // overflow: the caller falls back to a full scan
+    unsigned ha = ((unsigned)a * 2654435761u) >> 20, hb = ((unsigned)b * 2654435761u) >> 20;
+    bool doa = true, dob = true, newa = false, newb = false;
+    for (int probe = 0; probe < kDirtyHash && (doa || dob); ++probe) {
+        int olda = 0, oldb = 0;
+        if (doa) olda = atomicCAS(&ds.hash[ha], -1, a);
+        if (dob) oldb = atomicCAS(&ds.hash[hb], -1, b);
+        if (doa) { if (olda == a) doa = false; else if (olda == -1) { doa = false; newa = true; } else ha = (ha + 1) & (kDirtyHash - 1); }
+        if (dob) { if (oldb == b) dob = false; else if (oldb == -1) { dob = false; newb = true; } else hb = (hb + 1) & (kDirtyHash - 1); }
+    }
+    const int n = (newa ? 1 : 0) + (newb ? 1 : 0);
+    if (n) {
+        int k = atomicAdd(ds.count, n);
+        if (newa) { if (k < kDirtyCap) ds.list[k] = a; ++k; }
+        if (newb && k < kDirtyCap) ds.list[k] = b;
+    }
+}
+__device__ __forceinline__ bool dirty_has(const DirtySet& ds, int slot)
+{
+    unsigned h = ((unsigned)slot * 2654435761u) >> 20;
+    for (int probe = 0; probe < kDirtyHash; ++probe) {
+        const int v = ds.hash[h];
+        if (v == slot) return true;
+        if (v == -1) return false;
+        h = (h + 1) & (kDirtyHash - 1);
+    }
+    return false;
+}
+
 // updateClosestNodes, one wave: frontier entries l..r processed 64 at a time.  The frontier holds SLOTS:
 // reaching slot i = (u -> v) with the distance d of u inserts the new leaf into list[i]; if it entered, the
 // slots leaving v other than the reverse of i (cont[2i], cont[2i+1]; write-once except at a split) follow
@@ -97,17 +150,14 @@ __device__ __forceinline__ void er_write_edge(const PlaceBuffers& p, int k, int 
 // program order.  cont[2i] == -2 marks a target node of degree > 3 (possible only in an imported backbone),
 // which falls back to walking that node's list.
 constexpr int kQueueLds = 2048;
-// (seeded form: the frontier starts with `ns` entries (slot, distance) held by lane 0 -- the split has already applied the
-//  rounds it can do in registers, split_bfs_rounds01; ns is wave-uniform)
-__device__ __forceinline__ void closest_update_wave_seeded(const PlaceBuffers& p, int x, int ns, const int* seeds, const double* sdis)
+// (the frontier starts with the `ns` entries (slot, distance) the caller has put into the LDS queue -- one for a BFS from the new
+//  leaf's slot; the split applies the first two rounds in registers and leaves the entries of round 2, place_split_wave)
+// (kRec, the multi-tip launch: every slot whose list changed and its reverse are recorded in the block's dirty set)
+template <bool kRec>
+__device__ __forceinline__ void closest_update_wave_impl(const PlaceBuffers& p, int x, int ns, const DirtySet& ds, int32_t* sq_id, double* sq_dis)
 {
-    __shared__ int32_t sq_id[kQueueLds];
-    __shared__ double sq_dis[kQueueLds];
     const int lane = threadIdx.x & 63;
-    int l = 0, r = ns;  // queue [l, r)
-    if (lane == 0)
-        for (int k = 0; k < 4; ++k)
-            if (k < ns) { sq_id[k] = seeds[k]; sq_dis[k] = sdis[k]; }
+    int l = 0, r = ns;  // queue [l, r): the first ns entries are in sq_id / sq_dis (stored by a lane of this wavefront)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     while (l < r) {
@@ -130,6 +180,8 @@ __device__ __forceinline__ void closest_update_wave_seeded(const PlaceBuffers& p
             const double ln = p.len[sl];
             const int k0 = p.cont[2 * sl], k1 = p.cont[2 * sl + 1];
             const int ex = p.eidx[sl];
+            int back = -1;
+            if (kRec) back = p.rev[sl];
             int j = K5;
 #pragma unroll
             for (int t = K5 - 1; t >= 0; --t)
@@ -146,6 +198,7 @@ __device__ __forceinline__ void closest_update_wave_seeded(const PlaceBuffers& p
                     for (int t = 0; t < K5; ++t) { nd[t] = t < j ? cd[t] : (t == j ? d : cd[t > 0 ? t - 1 : 0]); ni[t] = t < j ? ci[t] : (t == j ? x : ci[t > 0 ? t - 1 : 0]); }
                     er_write_side(p, ex, nd, ni);
                 }
+                if (kRec) dirty_add2(ds, sl, back);
                 dn = d + ln;
                 if (k0 == -2) {                        // high-degree target: count its other slots
                     walk = true;
@@ -205,9 +258,10 @@ __device__ __forceinline__ void closest_update_wave_seeded(const PlaceBuffers& p
 
 __device__ __forceinline__ void closest_update_wave(const PlaceBuffers& p, int x, int start_slot)
 {
-    const int seeds[4] = { start_slot, -1, -1, -1 };
-    const double sdis[4] = { 0.0, 0.0, 0.0, 0.0 };
-    closest_update_wave_seeded(p, x, 1, seeds, sdis);
+    __shared__ int32_t sq_id[kQueueLds];
+    __shared__ double sq_dis[kQueueLds];
+    if ((threadIdx.x & 63) == 0) { sq_id[0] = start_slot; sq_dis[0] = 0.0; }
+    closest_update_wave_impl<false>(p, x, 1, DirtySet{ nullptr, nullptr, nullptr }, sq_id, sq_dis);
 }
 
 // ---- the split, by one wavefront with the five list entries of a slot held one per LANE (lanes 0..4) -----------------
@@ -246,7 +300,7 @@ __device__ __forceinline__ void lane_er_write_side(const PlaceBuffers& p, int ex
 // global round trips less per tip): round 0 reaches e2 with distance 0, round 1 -- through cont[e2] = (e0, e1) with distance
 // len[e2] = addLen -- e0 and e1; a slot the leaf enters passes it on to its continuation slots (oy0, oy1 behind e0; ox0, ox1
 // behind e1) with distance + length: same insertion rule and the same additions in the same order as closest_update_wave.
-// Returns the number of frontier entries for round 2 (seeds / sdis, <= 4), or -1 when a node of degree > 3 lies behind x or y
+// Returns the number of frontier entries for round 2 (stored into the LDS queue sq_id / sq_dis by lane 0 of wavefront 0; <= 4), or -1 when a node of degree > 3 lies behind x or y
 // (imported backbone: the BFS then starts at e2 and walks).  Everything returned is wave-uniform.
 // TWO wavefronts share the work (role = wavefront index 0 / 1, both called with the same arguments): wavefront 0 takes what the
 // closest-list BFS it runs next depends on -- the inherited lists of e0 / e1, rounds 0-1 of the BFS, their stores and record
@@ -254,10 +308,13 @@ __device__ __forceinline__ void lane_er_write_side(const PlaceBuffers& p, int ex
 // e3, the record scalars and the sides of xe / ye / e3): 1.4 us of dependent instructions off the tip's critical path.  The BFS
 // only reaches slots beyond x and y, none of which the split writes -- except in the degree > 3 fallback, where it starts at e2
 // and reads the new slots: there wavefront 0 does everything itself and wavefront 1 nothing.  Disjoint stores; both end before
-// the next kernel / the block barrier of the multi-tip kernel.
+// the next kernel / the block barrier of the multi-tip kernel.  Loads against the other wavefront's stores: wavefront 1 overwrites
+// what both read here (len / e / cont / eidx of the split edge's slots), so it stores only after wavefront 0 has its loads back
+// (*sync == tip, an LDS word the caller initialises to -1 before a block barrier); wavefront 0 overwrites the lists of e0..e2,
+// which both read as i0..i2: the caller loads those BEFORE the block barrier that publishes the winner.
 __device__ __forceinline__ int place_split_wave(const PlaceBuffers& p, int64_t num, int ec0, int eid, int brev, double fracLen, double addLen,
                                                 double i0d, int i0i, double i1d, int i1i, double i2d, int i2i, double i3d, int i3i,
-                                                int mininel, int role, int* seeds, double* sdis, int& xe_out, int& ye_out)
+                                                int mininel, int role, int32_t* sq_id, double* sq_dis, int* sync, int& xe_out, int& ye_out)
 {
     const int lane = threadIdx.x & 63;
     const int li = lane < K5 ? lane : 0;
@@ -277,6 +334,13 @@ __device__ __forceinline__ int place_split_wave(const PlaceBuffers& p, int64_t n
     const double len1 = originalDis - fracLen;
     const bool fallback = ox0 == -2 || oy0 == -2;
     const bool lists = role == 0, book = fallback ? role == 0 : role == 1;
+    if (role == 0) {
+        // every load above has returned (the waitcnt) -> wavefront 1 may overwrite what they read
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0) __hip_atomic_store(sync, (int)num, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (book) {
+        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)num) __builtin_amdgcn_s_sleep(1);
+    }
     // middle -> x inherits the list of y -> x, middle -> y the list of x -> y (entry by entry; an empty entry keeps what the slot held)
     const bool has0 = ciy != -1, has1 = cix != -1;
     double n0d = has0 ? cdy + originalDis - fracLen : i0d, n1d = has1 ? cdx + fracLen : i1d;
@@ -364,13 +428,13 @@ __device__ __forceinline__ int place_split_wave(const PlaceBuffers& p, int64_t n
                 const double d1 = 0.0 + addLen;             // (d + len[e2], as the BFS computes it)
                 if (lane_list_insert(n0d, n0i, d1, placeId, lane)) {
                     const double dn = d1 + fracLen;         // len[e0]
-                    if (oy0 >= 0) { seeds[ns] = oy0; sdis[ns] = dn; ++ns; }
-                    if (oy1 >= 0) { seeds[ns] = oy1; sdis[ns] = dn; ++ns; }
+                    if (oy0 >= 0) { if (lane == 0) { sq_id[ns] = oy0; sq_dis[ns] = dn; } ++ns; }
+                    if (oy1 >= 0) { if (lane == 0) { sq_id[ns] = oy1; sq_dis[ns] = dn; } ++ns; }
                 }
                 if (lane_list_insert(n1d, n1i, d1, placeId, lane)) {
                     const double dn = d1 + len1;            // len[e1]
-                    if (ox0 >= 0) { seeds[ns] = ox0; sdis[ns] = dn; ++ns; }
-                    if (ox1 >= 0) { seeds[ns] = ox1; sdis[ns] = dn; ++ns; }
+                    if (ox0 >= 0) { if (lane == 0) { sq_id[ns] = ox0; sq_dis[ns] = dn; } ++ns; }
+                    if (ox1 >= 0) { if (lane == 0) { sq_id[ns] = ox1; sq_dis[ns] = dn; } ++ns; }
                 }
             }
             lane_list_store(p, e2, i2d, i2i, lane);
@@ -535,13 +599,31 @@ __global__ __launch_bounds__(64) void place_backbone_lists_kernel(PlaceBuffers p
 // last-block-done ticket was measured 1.5-2x SLOWER: every block then needs a device-scope release
 // fence, i.e. an L2 write-back, which costs more than the kernel boundary it saves.)
 constexpr int kUpdThreads = 256;
+// the block's winner (smallest pendant length, then smallest slot) from the per-wavefront winners in LDS: lane w takes wavefront w's,
+// one wave reduction -- a loop over the entries is nw dependent LDS round trips (1.6 us for the 16 wavefronts of the multi-tip launch)
+__device__ __forceinline__ void place_block_winner(const double* s_add, const int* s_idx, const int* s_eid, const double* s_frac, const int* s_rev, int nw,
+                                                   double& badd, int& bidx, int& beid, double& bfrac, int& brev)
+{
+    const int lane = threadIdx.x & 63;
+    double a = __builtin_inf(), fr = 0.0;
+    int ix = 0x7fffffff, ei = 0, rv = -1;
+    if (lane < nw) { a = s_add[lane]; ix = s_idx[lane]; ei = s_eid[lane]; fr = s_frac[lane]; rv = s_rev[lane]; }
+    const double wa = wave_fmin(a);
+    const uint64_t wi = wave_umin64(a == wa ? (uint64_t)(uint32_t)ix : ~0ull);
+    const unsigned long long own = __builtin_amdgcn_ballot_w64((a == wa) & ((uint64_t)(uint32_t)ix == wi));
+    const int src = (int)__builtin_ctzll(own);
+    badd = readlane_f64(a, src); bfrac = readlane_f64(fr, src);
+    bidx = __builtin_amdgcn_readlane(ix, src); beid = __builtin_amdgcn_readlane(ei, src); brev = __builtin_amdgcn_readlane(rv, src);
+}
 __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, const PlacePartial* partials, int nparts,
                                                         int64_t num, int64_t edge_count, double* __restrict__ trace)
 {
     __shared__ double s_add[kUpdThreads / 64], s_frac[kUpdThreads / 64];
     __shared__ int s_idx[kUpdThreads / 64], s_eid[kUpdThreads / 64], s_rev[kUpdThreads / 64];
+    __shared__ int s_sync;                    // place_split_wave: wavefront 0's loads are back
     const int tid = threadIdx.x, lane = tid & 63;
     int ec = (int)edge_count;
+    if (tid == 0) s_sync = -1;
     const unsigned long long tk0 = wall_clock64();
     // (a) loads that do not depend on the winner: the (initial) lists of the new slots ec, ec+1, ec+3 -- slots the
     // reference never touched keep the init values 2 / -1, which it reads back at the split; in flight during (b)
@@ -588,27 +670,28 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
     __syncthreads();
     if (tid >= 128) return;                   // wavefronts 0 and 1 go on: the split is shared, the BFS is wavefront 0's
     const int role = __builtin_amdgcn_readfirstlane(tid >> 6);
-    badd = s_add[0]; bidx = s_idx[0]; beid = s_eid[0]; bfrac = s_frac[0]; brev = s_rev[0];
-#pragma unroll
-    for (int w = 1; w < nthr / 64; ++w)
-        if (s_add[w] < badd || (s_add[w] == badd && s_idx[w] < bidx)) { badd = s_add[w]; bidx = s_idx[w]; beid = s_eid[w]; bfrac = s_frac[w]; brev = s_rev[w]; }
+    place_block_winner(s_add, s_idx, s_eid, s_frac, s_rev, nthr / 64, badd, bidx, beid, bfrac, brev);
     const int eid = beid;
     const double fracLen = bfrac, addLen = badd;
     const unsigned long long tk1 = wall_clock64();
     const int placeId = (int)num;
     if (tid == 0 && trace) { trace[3 * num] = eid; trace[3 * num + 1] = fracLen; trace[3 * num + 2] = addLen; }
     // (c) the split and rounds 0-1 of the closest-list BFS, lists one entry per lane
-    int bfs_seed[4] = { -1, -1, -1, -1 }, xe_, ye_;
-    double bfs_dis[4] = { 0.0, 0.0, 0.0, 0.0 };
-    const int bfs_ns = place_split_wave(p, num, ec, eid, brev, fracLen, addLen, i0d, i0i, i1d, i1i, i2d, i2i, i3d, i3i,
-                                        __builtin_amdgcn_readfirstlane(mininel), role, bfs_seed, bfs_dis, xe_, ye_);
+    __shared__ int32_t sq_id[kQueueLds];      // the BFS frontier (wavefront 0's)
+    __shared__ double sq_dis[kQueueLds];
+    int xe_, ye_;
+    int bfs_ns = place_split_wave(p, num, ec, eid, brev, fracLen, addLen, i0d, i0i, i1d, i1i, i2d, i2i, i3d, i3i,
+                                  __builtin_amdgcn_readfirstlane(mininel), role, sq_id, sq_dis, &s_sync, xe_, ye_);
     if (role != 0) return;
     // the wave reads what its lanes just stored: program order within the wavefront
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const unsigned long long tk2 = wall_clock64();
-    if (bfs_ns < 0) closest_update_wave(p, placeId, (int)edge_count + 2);   // the new leaf's only slot: outside -> middle
-    else if (bfs_ns > 0) closest_update_wave_seeded(p, placeId, bfs_ns, bfs_seed, bfs_dis);
+    if (bfs_ns < 0) {                       // (degree > 3 behind x or y) from the new leaf's only slot: outside -> middle
+        if (lane == 0) { sq_id[0] = (int)edge_count + 2; sq_dis[0] = 0.0; }
+        bfs_ns = 1;
+    }
+    if (bfs_ns > 0) closest_update_wave_impl<false>(p, placeId, bfs_ns, DirtySet{ nullptr, nullptr, nullptr }, sq_id, sq_dis);
     if ((p.dbg & 4) && trace && lane == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         const unsigned long long tk3 = wall_clock64();
@@ -724,7 +807,6 @@ __global__ __launch_bounds__(kUpdThreads) void place_update_kernel(PlaceBuffers 
 // lists and trace are those of the tip-by-tip schedule bit for bit (tests/test_gpu_mash_place.py, test_gpu_fullsize.py).
 // ------------------------------------------------------------------------------------------------
 constexpr int kMultiB = 4;
-constexpr int kDirtyHash = 4096, kDirtyCap = 2048, kRescanCap = 128;
 
 // calculateBranchLength for one slot (the arithmetic of place_tip_edges_kernel, from the slot-indexed arrays)
 __device__ __forceinline__ void place_eval_slot(const PlaceBuffers& p, const double* __restrict__ dis, int sl, double& add, double& d1,
@@ -848,135 +930,6 @@ __global__ __launch_bounds__(kTipThreads) void place_tip_multi_kernel(PlaceBuffe
     }
 }
 
-struct DirtySet {          // slots whose evaluation inputs changed since the scan launch (LDS)
-    int* hash;             // [kDirtyHash] open addressing, -1 = empty
-    int* list;             // [kDirtyCap]
-    int* count;            // entries in list (may run past kDirtyCap: overflow)
-};
-__device__ __forceinline__ void dirty_add(const DirtySet& ds, int slot)
-{
-    if (*ds.count >= kDirtyCap) { atomicAdd(ds.count, 1); return; }      // overflow: the caller falls back to a full scan
-    unsigned h = ((unsigned)slot * 2654435761u) >> 20;
-    for (int probe = 0; probe < kDirtyHash; ++probe) {
-        const int old = atomicCAS(&ds.hash[h], -1, slot);
-        if (old == slot) return;
-        if (old == -1) {
-            const int k = atomicAdd(ds.count, 1);
-            if (k < kDirtyCap) ds.list[k] = slot;
-            return;
-        }
-        h = (h + 1) & (kDirtyHash - 1);
-    }
-}
-__device__ __forceinline__ bool dirty_has(const DirtySet& ds, int slot)
-{
-    unsigned h = ((unsigned)slot * 2654435761u) >> 20;
-    for (int probe = 0; probe < kDirtyHash; ++probe) {
-        const int v = ds.hash[h];
-        if (v == slot) return true;
-        if (v == -1) return false;
-        h = (h + 1) & (kDirtyHash - 1);
-    }
-    return false;
-}
-
-// updateClosestNodes as closest_update_wave, additionally recording every slot whose list changed (and its reverse)
-__device__ __forceinline__ void closest_update_wave_rec(const PlaceBuffers& p, int x, int ns, const int* seeds, const double* sdis, const DirtySet& ds,
-                                                        int32_t* sq_id, double* sq_dis)
-{
-    const int lane = threadIdx.x & 63;
-    int l = 0, r = ns;
-    if (lane == 0)
-        for (int k = 0; k < 4; ++k)
-            if (k < ns) { sq_id[k] = seeds[k]; sq_dis[k] = sdis[k]; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    while (l < r) {
-        const int cnt = min(64, r - l);
-        int sl = -1;
-        double d = 0.0;
-        if (lane < cnt) {
-            const int qi = l + lane;
-            if (qi < kQueueLds) { sl = sq_id[qi]; d = sq_dis[qi]; }
-            else { sl = p.q_id[qi]; d = p.q_dis[qi]; }
-        }
-        int c0 = -1, c1 = -1, nnew = 0;
-        double dn = 0.0;
-        bool walk = false;
-        if (sl >= 0) {
-            double cd[K5];
-            int ci[K5];
-#pragma unroll
-            for (int j = 0; j < K5; ++j) { cd[j] = p.cdis[sl * K5 + j]; ci[j] = p.cid[sl * K5 + j]; }
-            const double ln = p.len[sl];
-            const int k0 = p.cont[2 * sl], k1 = p.cont[2 * sl + 1];
-            const int back = p.rev[sl];
-            const int ex = p.eidx[sl];
-            int j = K5;
-#pragma unroll
-            for (int t = K5 - 1; t >= 0; --t)
-                if (cd[t] > d) j = t;                  // first entry farther than d
-            if (j < K5) {
-#pragma unroll
-                for (int t = K5 - 1; t > 0; --t)
-                    if (t > j) { p.cdis[sl * K5 + t] = cd[t - 1]; p.cid[sl * K5 + t] = ci[t - 1]; }
-                p.cdis[sl * K5 + j] = d;
-                p.cid[sl * K5 + j] = x;
-                {   // (edge record, as closest_update_wave)
-                    double nd[K5]; int ni[K5];
-#pragma unroll
-                    for (int t = 0; t < K5; ++t) { nd[t] = t < j ? cd[t] : (t == j ? d : cd[t > 0 ? t - 1 : 0]); ni[t] = t < j ? ci[t] : (t == j ? x : ci[t > 0 ? t - 1 : 0]); }
-                    er_write_side(p, ex, nd, ni);
-                }
-                dirty_add(ds, sl);
-                dirty_add(ds, back);
-                dn = d + ln;
-                if (k0 == -2) {                        // high-degree target: count its other slots
-                    walk = true;
-                    for (int i = p.head[p.e[sl]]; i != -1; i = p.nxt[i]) nnew += (i != back) ? 1 : 0;
-                } else {
-                    c0 = k0; c1 = k1;
-                    nnew = (c0 >= 0 ? 1 : 0) + (c1 >= 0 ? 1 : 0);
-                }
-            }
-        }
-        int incl = nnew;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
-        }
-        const int total = __shfl(incl, 63, 64);
-        const int excl = incl - nnew;
-        const bool spill = r + total > kQueueLds;               // wave-uniform
-        if (nnew) {
-            int w = r + excl;
-            auto push = [&](int slot) {
-                if (w < kQueueLds) { sq_id[w] = slot; sq_dis[w] = dn; }
-                else { p.q_id[w] = slot; p.q_dis[w] = dn; }
-                ++w;
-            };
-            if (!walk) {
-                if (c0 >= 0) push(c0);
-                if (c1 >= 0) push(c1);
-            } else {
-                const int back = p.rev[sl];
-                for (int i = p.head[p.e[sl]]; i != -1; i = p.nxt[i])
-                    if (i != back) push(i);
-            }
-        }
-        l += cnt;
-        r += total;
-        if (spill) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        } else {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-    }
-}
-
 constexpr int kMultiMaxThreads = 1024;      // (launched with 256 threads, or 1024 when there are many block minima to go through)
 __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(PlaceBuffers p, const PlacePartial* __restrict__ partials, int nblk,
                                                                          int64_t num0, int nb, const double* __restrict__ dis0, int64_t ldb,
@@ -992,7 +945,8 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
     __shared__ int s_idx[kMultiMaxThreads / 64], s_eid[kMultiMaxThreads / 64], s_rev[kMultiMaxThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, nthr = (int)blockDim.x;
     for (int i = tid; i < kDirtyHash; i += nthr) s_hash[i] = -1;
-    if (tid == 0) { s_count = 0; s_nrescan = 0; }
+    __shared__ int s_sync;                    // place_split_wave: wavefront 0's loads are back
+    if (tid == 0) { s_count = 0; s_nrescan = 0; s_sync = -1; }
     __syncthreads();
     DirtySet ds{ s_hash, s_list, &s_count };
     const int64_t nedge0 = 2 * num0 - 2;                // edges the scan launch covered
@@ -1007,20 +961,47 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
             const double aa = a == a ? a : __builtin_inf();
             if (aa < badd || (aa == badd && idx < bidx)) { badd = aa; bidx = idx; beid = eid; bfrac = frac; brev = rv; }
         };
+        const unsigned long long ck0 = wall_clock64();
+        // what the four new slots' lists hold (wavefronts 0 and 1, an entry per lane): loaded here, before the barriers of this
+        // tip, because wavefront 0 overwrites three of them while wavefront 1 may still be on its way (place_split_wave)
+        double i0d = 2.0, i1d = 2.0, i2d = 2.0, i3d = 2.0;
+        int i0i = -1, i1i = -1, i2i = -1, i3i = -1;
+        if (tid < 128 && lane < K5) {
+            i0d = p.cdis[ec0 * K5 + lane]; i0i = p.cid[ec0 * K5 + lane];
+            i1d = p.cdis[(ec0 + 1) * K5 + lane]; i1i = p.cid[(ec0 + 1) * K5 + lane];
+            i2d = p.cdis[(ec0 + 2) * K5 + lane]; i2i = p.cid[(ec0 + 2) * K5 + lane];
+            i3d = p.cdis[(ec0 + 3) * K5 + lane]; i3i = p.cid[(ec0 + 3) * K5 + lane];
+        }
         const int ndirty = s_count;                      // (stable: written before the last barrier)
         const bool overflow = ndirty > kDirtyCap;
+        int mis = 0x7fffffff;
+        if (tid == 0) mis = p.misc[0];                   // (kept by the splits; the previous tip's is behind the barrier)
         if (!overflow) {
-            // (A) speculative block minima whose winner is untouched
-            for (int b = tid; b < nblk; b += nthr) {
-                const PlacePartial pp = part[b];
-                if (jt > 0 && pp.idx != 0x7fffffff && dirty_has(ds, pp.idx)) {
+            // (A) the speculative block minima, their loads in flight together (a loop over them is one dependent round trip per
+            // entry: 4 300 blocks at 550 000 tips).  A minimum whose winner is untouched stands; the others' blocks are evaluated
+            // again in (C)
+            auto take = [&](const PlacePartial& q, int b) {
+                if (jt > 0 && q.idx != 0x7fffffff && dirty_has(ds, q.idx)) {
                     const int k = atomicAdd(&s_nrescan, 1);
                     if (k < kRescanCap) s_rescan[k] = b;
                 } else {
-                    consider(pp.add, pp.idx, pp.eid, pp.frac, pp.rev);
+                    consider(q.add, q.idx, q.eid, q.frac, q.rev);
                 }
+            };
+            constexpr int kPB = 5;
+            for (int b0 = tid; b0 < nblk; b0 += kPB * nthr) {
+                PlacePartial pp[kPB];
+#pragma unroll
+                for (int u = 0; u < kPB; ++u) {
+                    const int b = b0 + u * nthr;
+                    if (b < nblk) pp[u] = part[b];
+                    else { pp[u].add = __builtin_inf(); pp[u].idx = 0x7fffffff; pp[u].eid = 0; pp[u].frac = 0; pp[u].rev = -1; }
+                }
+#pragma unroll
+                for (int u = 0; u < kPB; ++u)
+                    if (b0 + u * nthr < nblk) take(pp[u], b0 + u * nthr);
             }
-            // (B) the dirty slots with the current state (new slots included)
+            // (B) the dirty slots with the current state (new slots included): three dependent hops
             for (int k = tid; k < ndirty; k += nthr) {
                 const int sl = s_list[k];
                 if (sl < ec0) {
@@ -1031,6 +1012,7 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
             }
         }
         __syncthreads();
+        const unsigned long long ck1 = wall_clock64();
         const int nres = s_nrescan;
         if (overflow || nres > kRescanCap) {
             // too much changed for the bookkeeping (small trees: every list still has room): scan everything here
@@ -1056,7 +1038,7 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
         // slots >= 4*num-4 (and < 4M-4) all carry the tuple (0,0,2): the first of them competes
         if (tid == 0 && (int64_t)ec0 < 4 * p.M - 4) consider(2.0, ec0, 0, 0.0, -1);
         // ... and so does the smallest live slot with belong < e (the edge scan does not visit those; p.misc[0] is kept by the splits)
-        if (tid == 0) consider(2.0, p.misc[0], 0, 0.0, -1);
+        if (tid == 0) consider(2.0, mis, 0, 0.0, -1);
         {
             const double wa = wave_fmin(badd);
             const uint64_t wi = wave_umin64(badd == wa ? (uint64_t)(uint32_t)bidx : ~0ull);
@@ -1065,11 +1047,10 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
             if (lane == src) { s_add[tid >> 6] = badd; s_idx[tid >> 6] = bidx; s_eid[tid >> 6] = beid; s_frac[tid >> 6] = bfrac; s_rev[tid >> 6] = brev; }
         }
         __syncthreads();
+        const unsigned long long ck2 = wall_clock64();
         if (tid < 128) {                     // wavefronts 0 and 1: the split; wavefront 0: the closest-list update (as place_finish_and_update)
             const int role = __builtin_amdgcn_readfirstlane(tid >> 6);
-            badd = s_add[0]; bidx = s_idx[0]; beid = s_eid[0]; bfrac = s_frac[0]; brev = s_rev[0];
-            for (int w = 1; w < nthr / 64; ++w)
-                if (s_add[w] < badd || (s_add[w] == badd && s_idx[w] < bidx)) { badd = s_add[w]; bidx = s_idx[w]; beid = s_eid[w]; bfrac = s_frac[w]; brev = s_rev[w]; }
+            place_block_winner(s_add, s_idx, s_eid, s_frac, s_rev, nthr / 64, badd, bidx, beid, bfrac, brev);
             const int eid = beid;
             const double fracLen = bfrac, addLen = badd;
             const int placeId = (int)num;
@@ -1077,28 +1058,25 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
                 if (trace) { trace[3 * num] = eid; trace[3 * num + 1] = fracLen; trace[3 * num + 2] = addLen; }
                 s_nrescan = 0;
             }
-            const int li = lane < K5 ? lane : 0;
-            const double i0d = p.cdis[ec0 * K5 + li], i1d = p.cdis[(ec0 + 1) * K5 + li], i2d = p.cdis[(ec0 + 2) * K5 + li], i3d = p.cdis[(ec0 + 3) * K5 + li];
-            const int i0i = p.cid[ec0 * K5 + li], i1i = p.cid[(ec0 + 1) * K5 + li], i2i = p.cid[(ec0 + 2) * K5 + li], i3i = p.cid[(ec0 + 3) * K5 + li];
-            int bfs_seed[4] = { ec0 + 2, -1, -1, -1 }, xe, ye;
-            double bfs_dis[4] = { 0.0, 0.0, 0.0, 0.0 };
-            int bfs_ns = place_split_wave(p, num, ec0, eid, brev, fracLen, addLen, i0d, i0i, i1d, i1i, i2d, i2i, i3d, i3i, p.misc[0], role, bfs_seed, bfs_dis, xe, ye);
+            int xe, ye;
+            int bfs_ns = place_split_wave(p, num, ec0, eid, brev, fracLen, addLen, i0d, i0i, i1d, i1i, i2d, i2i, i3d, i3i, p.misc[0], role, sq_id, sq_dis, &s_sync, xe, ye);
             if (role == 0) {
-                if (bfs_ns < 0) { bfs_ns = 1; bfs_seed[0] = ec0 + 2; bfs_dis[0] = 0.0; }     // (degree > 3 behind x or y: the BFS starts at e2 with distance 0)
-                if (tid == 0) {
-                    // what the split changed for later evaluations: the edge's two slots and the four new ones
-                    dirty_add(ds, xe); dirty_add(ds, ye);
-                    dirty_add(ds, ec0); dirty_add(ds, ec0 + 1); dirty_add(ds, ec0 + 2); dirty_add(ds, ec0 + 3);
-                }
+                if (bfs_ns < 0) { bfs_ns = 1; if (tid == 0) { sq_id[0] = ec0 + 2; sq_dis[0] = 0.0; } }     // (degree > 3 behind x or y: the BFS starts at e2 with distance 0)
+                // what the split changed for later evaluations: the edge's two slots and the four new ones (a lane each)
+                if (lane < 6) dirty_add(ds, lane == 0 ? xe : lane == 1 ? ye : ec0 + lane - 2);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (bfs_ns > 0) closest_update_wave_rec(p, placeId, bfs_ns, bfs_seed, bfs_dis, ds, sq_id, sq_dis);   // (from the new leaf's only slot, outside -> middle, or from where the rounds done in registers got)
+                if (bfs_ns > 0) closest_update_wave_impl<true>(p, placeId, bfs_ns, ds, sq_id, sq_dis);   // (from the new leaf's only slot, outside -> middle, or from where the rounds done in registers got)
             }
         }
         // the other wavefronts evaluate the next tip against what wavefronts 0 and 1 have just stored
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if ((p.dbg & 4) && trace && tid == 0) {   // profiles/place_phases.py: evaluation (A + B) / rescans + winner / split + BFS, 10 ns units
+            const unsigned long long ck3 = wall_clock64();
+            trace[3 * num] = (double)(ck1 - ck0); trace[3 * num + 1] = (double)(ck2 - ck1); trace[3 * num + 2] = (double)(ck3 - ck2);
+        }
     }
 }
 

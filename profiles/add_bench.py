@@ -47,4 +47,9 @@ if rank == 0:
                       upload_s=t4 - t3, add_s=t5 - t4, add_device_ms=d.timing()[1], queries_per_s=nq / (t5 - t4), distance_wait_ms=dist_ms, tree_part_ms=tree_ms,
                       batches=batches, batches_beside_tree_kernels=beside, distance_busy_ms=d.place_overlap()[1],
                       policy_env={k: v for k, v in os.environ.items() if k.startswith("DPR_PLACE")})))
+  if os.environ.get("DPR_PLACE_CLOCKS"):       # phase clocks of the four-tip update launch (10 ns units): evaluation / rescans + winner / split + BFS
+      tr = np.asarray(res["trace"])[m + 8:]
+      print("multi-tip update phases, mean us per tip: evaluate %.2f  rescan+winner %.2f  split+bfs %.2f" % tuple(tr.mean(axis=0) / 100.0))
+      for k, name in enumerate(("evaluate", "rescan+winner", "split+bfs")):
+          print(name, "quantiles 10/50/90/99 % (us):", np.quantile(tr[:, k], [0.1, 0.5, 0.9, 0.99]) / 100.0)
 _mgpu.finish(dist)

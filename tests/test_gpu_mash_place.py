@@ -180,6 +180,32 @@ def test_placement_msa_and_mash_sources(gpu, orc, monkeypatch, multi):
     _same_state(got, orc.place_run(M), len(reads))
 
 
+def test_placement_repeatable_in_both_launch_shapes(monkeypatch):
+    """the edge split is shared by two wavefronts of the update launch (place_split_wave): one must not overwrite what the other still
+    reads.  30 000 tips three times per launch shape (one tip per launch pair; four per pair from tip 64 on): every trace bit-equal
+    -- a race there showed up as a handful of differing tips between two runs of the same input."""
+    import dipper_amd
+    from dipper_amd import capi
+    n, L = 30000, 600
+    seqs = _util.synth_alignment(np.random.default_rng(77), n, L, mean_bl=2e-3, lo=1e-4, hi=2e-2)
+    packed = capi.pack4_many(seqs)
+    traces = []
+    for shape in ("single", "multi"):
+        if shape == "multi":
+            monkeypatch.setenv("DPR_PLACE_MULTI_MIN", "64")
+        for rep in range(3):
+            d = dipper_amd.Dipper(0)
+            try:
+                d.set_msa(packed, L)
+                traces.append(d.place_run(capi.SRC_MSA, n, dist_type=capi.DIST_JC)["trace"].copy())
+            finally:
+                d.close()
+    for k, t in enumerate(traces[1:], 1):
+        if not np.array_equal(t, traces[0]):
+            bad = np.flatnonzero((t != traces[0]).any(axis=1))
+            raise AssertionError(f"run {k} differs from run 0 at {len(bad)} tips, first tip {bad[0]}: {t[bad[0]]} vs {traces[0][bad[0]]}")
+
+
 @pytest.mark.parametrize("serial", [False, True], ids=["rounds", "serial"])
 def test_backbone_import_lists(gpu, orc, monkeypatch, serial):
     """initializeDeviceArrays (src/placement_close_k.cu:126-264): closest lists of an imported backbone.
