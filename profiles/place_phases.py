@@ -1,5 +1,5 @@
 """Phase clocks of place_update_kernel (DPR_PLACE_CLOCKS=1 overwrites the trace with wall_clock64 deltas, 10 ns units):
-reduce = block partials -> winner, split = the edge split by lane 0, bfs = the closest-list update.
+reduce = block partials -> winner, split = the edge split (wavefront 0's share), bfs = the closest-list update from round 2 on.
   python3 profiles/place_phases.py [tips 100000] [sites 3000]"""
 import os, sys, shutil, tempfile
 os.environ["DPR_PLACE_CLOCKS"] = "1"

@@ -1,3 +1,7 @@
+"""Repeatability / prefix property of k-closest placement: 100 000, 20 000, 100 000, 20 000 unaligned tips through Mash; the traces of the
+first 20 000 tips of all four runs must be equal (the decision for tip i depends on tips < i only).  Written to pin down a race between
+the two wavefronts that split an edge (NOTES.md, round 5, item 8): it showed 2 - 39 differing tips between runs before the fix.
+  python3 profiles/place_prefix_diag.py"""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import numpy as np
