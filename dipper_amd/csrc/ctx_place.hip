@@ -39,6 +39,11 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
     // full chip.  Measured (profiles/r4/place_policy_*.jsonl): --add 500 000 + 50 000 through Mash 8.87 s (every batch beside)
     // -> 6.56 s (none); 100 000 tips from scratch 3.07 s (none) / 2.52 s (every batch) / 2.5x s (policy).  The host waits for batch k - 1 before it decides about batch k + 1 (it never runs more than one batch ahead
     // of the device any more; enqueueing is ~10 x faster than the tree kernels execute, so the device does not starve).
+    // Round 5: while the tree kernels are the one-tip launch pairs (a 780-block scan and a one-workgroup update every 15 us) EVERY
+    // batch goes beside them, longer than the tree part or not -- 100 000 unaligned tips 2.18 -> 1.72 s (mean branch 2e-5), 2.30 ->
+    // 2.14 s (1e-3).  The rule above stays for the four-tip launch pairs (>= 150 000 tips): their scan fills the chip for 54 us of
+    // every ~120, so the pair kernel beside it gets half a chip (--add through Mash, every batch beside: 6.8 s against 4.0 s; the
+    // 1 024-thread update workgroup needs an empty CU and waits 0.5 ms for one).
     // Results cannot depend on the policy: the rows are the same numbers whichever stream produced them.
     const bool overlap_allowed = source == DPR_SRC_MASH && !std::getenv("DPR_PLACE_NO_OVERLAP");
     // (several ranks: every rank must take the same decisions -- the batches' all-gathers are enqueued on the stream the decision
@@ -161,7 +166,7 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
             bool next_ahead = false;
             if (overlap_allowed && j0 < last) {
                 const int64_t nr2 = last - j0 < R ? last - j0 : R;
-                if (overlap_always) next_ahead = true;
+                if (overlap_always || i0 + nr <= place_multi_min()) next_ahead = true;      // (one tip per launch pair: always, see above)
                 else {
                     if (k >= 1) { if (int rc = harvest(k)) return rc; }      // batches 0 .. k-1 (the host waits for batch k-1 here)
                     const double dist_alone_ms = batch_pairs(j0, nr2) / pairs_per_ms;

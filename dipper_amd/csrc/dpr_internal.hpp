@@ -459,6 +459,7 @@ int place_initial_tree(PlaceBuffers& p, const double* d_dis_row1, hipStream_t s)
 int place_import_backbone(PlaceBuffers& p, int64_t m, hipStream_t s);
 int place_tip(PlaceBuffers& p, const double* d_dis, int64_t tip, double* d_trace, hipStream_t s);
 int place_tips(PlaceBuffers& p, const double* d_dis0, int64_t ldb, int64_t tip0, int64_t count, double* d_trace, hipStream_t s);
+int64_t place_multi_min();        // first tip of the four-tip launch pairs
 
 // exact.hip: exact placement mode (src/placement.cu)
 struct XStep {                   // scalars of the last split (device), and the counters of the two node lists

@@ -33,8 +33,13 @@
 
 namespace dpr {
 
-constexpr int kIC = 512;             // tips per chunk (1024: -3 ... -12 % at mean branch 2e-5 ... 1e-3, +29 % for unrelated reads)
-// a posting: byte offset of the tip's 16-bit counter (2 * (tip mod 512)) in the high half, sketch position in the low half
+constexpr int kIC = 1024;            // tips per chunk.  Round 5, with the packed dense path: 1024 beats 512 at every divergence (distance rows of a
+                                     // 50 000-tip placement run, mean branch 2e-5 / 1e-3 / 1e-2 / 0.1 / 1: 201 / 199 / 123 / 99 / 25 -> 183 / 173 / 91 / 73 / 22 ms;
+                                     // --add 50 000 onto 500 000: 2 410 -> 2 164 ms); 2 048 is better from scratch (159 / 158 / 77 / 66 / 26) but
+                                     // worse for --add (2 337 ms: sketches of 1 000-base reads); beside the tree kernels of a run from scratch 512
+                                     // is 5 % ahead of 1024 (100 000 tips 1.71 / 1.80 s), which --add's 2 410 -> 2 164 ms outweighs;
+                                     // profiles/mash_rows_sweep.sh, mash_kic_eval.sh
+// a posting: byte offset of the tip's 16-bit counter (2 * (tip mod kIC)) in the high half, sketch position in the low half
 constexpr int kIBktLog = 16;
 constexpr int kINB = 1 << kIBktLog;  // directory buckets per chunk
 constexpr int kIThreads = 256;       // (index build kernels)
@@ -293,10 +298,10 @@ __global__ __launch_bounds__(kIThreads) void mi_buckets_kernel(const uint64_t* _
         for (int bb = b + 1; bb <= kINB; ++bb) row[bb] = (uint32_t)(u + 1);
 }
 
-// Dense values: a value held by at least kIDenseMin tips of a chunk gets, besides its posting list, a block of 512 positions
+// Dense values: a value held by at least kIDenseMin tips of a chunk gets, besides its posting list, a block of kIC positions
 // indexed by tip (65535 = absent) -- no larger than the list it replaces in the kernel's inner loop, read in tip order, and the
 // counters are then touched in tip order too (conflict-free, no address arithmetic).
-constexpr uint32_t kIDenseMin = 192;
+constexpr uint32_t kIDenseMin = 3 * kIC / 8;      // (a dense step costs ~7 wave instructions per 128 tips, a posting group ~10 per 64 entries)
 __global__ __launch_bounds__(kIThreads) void mi_dense_flag_kernel(const uint32_t* __restrict__ off, int64_t nu, uint32_t* __restrict__ dflag)
 {
     const int64_t u = (int64_t)blockIdx.x * kIThreads + threadIdx.x;

@@ -709,6 +709,7 @@ constexpr int kTipThreads = 256;
 __global__ __launch_bounds__(kTipThreads) void place_tip_edges_kernel(PlaceBuffers p, const double* __restrict__ dis,
                                                                    int64_t num, PlacePartial* __restrict__ partials)
 {
+    __builtin_amdgcn_s_setprio(3);      // chains of dependent steps: these waves go first where a distance kernel shares the SIMD
     __shared__ double sadd[kTipThreads / 64];
     __shared__ int sidx[kTipThreads / 64];
     const int64_t nedge = 2 * num - 2;
@@ -791,6 +792,7 @@ __global__ __launch_bounds__(kThreads) void place_pack_edges_kernel(PlaceBuffers
 __global__ __launch_bounds__(kUpdThreads) void place_update_kernel(PlaceBuffers p, const PlacePartial* partials, int nparts,
                                                           int64_t num, double* __restrict__ trace)
 {
+    __builtin_amdgcn_s_setprio(3);      // chains of dependent steps: these waves go first where a distance kernel shares the SIMD
     place_finish_and_update(p, partials, nparts, num, 4 * num - 4, trace);
 }
 
@@ -853,6 +855,7 @@ __device__ __forceinline__ void place_eval_slot(const PlaceBuffers& p, const dou
 __global__ __launch_bounds__(kTipThreads) void place_tip_multi_kernel(PlaceBuffers p, const double* __restrict__ dis0, int64_t ldb,
                                                                    int64_t num0, int nb, PlacePartial* __restrict__ partials, int nblk)
 {
+    __builtin_amdgcn_s_setprio(3);      // chains of dependent steps: these waves go first where a distance kernel shares the SIMD
     __shared__ double sadd[kMultiB][kTipThreads / 64];
     __shared__ int sidx[kMultiB][kTipThreads / 64];
     const int64_t nedge = 2 * num0 - 2;
@@ -935,6 +938,7 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
                                                                          int64_t num0, int nb, const double* __restrict__ dis0, int64_t ldb,
                                                                          double* __restrict__ trace)
 {
+    __builtin_amdgcn_s_setprio(3);      // chains of dependent steps: these waves go first where a distance kernel shares the SIMD
     __shared__ int s_hash[kDirtyHash];
     __shared__ int s_list[kDirtyCap];
     __shared__ int s_count, s_nrescan;
@@ -1226,6 +1230,12 @@ int place_import_backbone(PlaceBuffers& p, int64_t m, hipStream_t s)
     return DPR_OK;
 }
 
+// first tip of the four-tip launch pairs (smaller trees: one tip per pair of launches)
+int64_t place_multi_min()
+{
+    return std::getenv("DPR_PLACE_MULTI_MIN") ? std::atoll(std::getenv("DPR_PLACE_MULTI_MIN")) : 150000;
+}
+
 // tips tip0 .. tip0 + count - 1, distance rows at d_dis0 + k * ldb: kMultiB tips per pair of launches once the tree is large
 // enough for the shared scan to outweigh the fix-up chain of the update launch (measured: 100 000 tips 1.61 -> 1.91 s, i.e. NOT
 // there; 300 000 tips 7.00 -> 6.76 s; 50 000 queries onto a 500 000-tip backbone 2.85 -> 2.59 s).  DPR_PLACE_MULTI_MIN moves the
@@ -1233,7 +1243,7 @@ int place_import_backbone(PlaceBuffers& p, int64_t m, hipStream_t s)
 int place_tips(PlaceBuffers& p, const double* d_dis0, int64_t ldb, int64_t tip0, int64_t count, double* d_trace, hipStream_t s)
 {
     // (read per call: the tests switch inside one process)
-    const int64_t min_tip = std::getenv("DPR_PLACE_MULTI_MIN") ? std::atoll(std::getenv("DPR_PLACE_MULTI_MIN")) : 150000;
+    const int64_t min_tip = place_multi_min();
     const bool big_block = std::getenv("DPR_PLACE_MULTI_BIG") != nullptr;      // tests: the 1024-thread update workgroup at any size
     int64_t k = 0;
     while (k < count) {
