@@ -7,7 +7,7 @@
 // (and uni = S at the end; mash.hip).  So a pair needs nothing but its SHARED values, in
 // ascending order, with three small integers each: the position of v in A, the position of v in B, the multiplicity
 // of v in B -- and one counter.  That is a join, not a merge:
-//   * index (once per sketch set): the tips are cut into chunks of 512; a chunk's (value, tip, position) triples --
+//   * index (once per sketch set): the tips are cut into chunks of kIC = 1 024; a chunk's (value, tip, position) triples --
 //     first occurrences only -- are sorted by value (round 4: every tip's sketch is already ascending, so a chunk is 512
 //     sorted runs and the sort is nine rounds of pairwise merge-path merges, mi_merge_kernel; until round 3 a rocPRIM
 //     segmented radix sort -- the one piece of vendor device code near the path, and 3.7 of the library's 5 MB);
@@ -225,7 +225,7 @@ static int mi_sort_chunks(const uint64_t* sketches, const uint32_t* pay, uint64_
                           int64_t total, int64_t seg, int S, hipStream_t s)
 {
     int rounds = 0;
-    for (int v = kIC; v > 1; v >>= 1) ++rounds;          // 9
+    for (int v = kIC; v > 1; v >>= 1) ++rounds;          // log2(kIC)
     for (int r = 0; r < rounds; ++r) {
         // round r writes buffer (rounds - 1 - r) & 1: the last round writes buffer 0 = (ks, post)
         const int dsti = (rounds - 1 - r) & 1;
