@@ -11,11 +11,13 @@
 //  * everything stays resident in HBM (planes / sketches of ALL tips; 288 GB);
 //  * cluster assignment is batched: distances of Q queries to all backbone tips in one launch,
 //    written query-minor, then ONE scan where a lane is a query and the backbone edge (its two
-//    closest lists, 128 bytes) is wave-uniform, so every closest-leaf lookup is a coalesced row read;
+//    closest lists) is wave-uniform; a workgroup stages the distance rows its chunk of edges names
+//    in LDS once (neighbours in the tree share most of their closest leaves);
 //  * clusters are independent (disjoint edge slots, node ids and slots known from a prefix sum over
 //    the cluster sizes), so all cluster trees are built concurrently, one wavefront per cluster, from
 //    per-cluster distance blocks computed beforehand by the tiled pair kernels.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "dpr_internal.hpp"
@@ -23,7 +25,8 @@
 namespace dpr {
 
 constexpr int K5 = 5;
-constexpr int kAE = 256;   // backbone edges per scan block
+constexpr int kAE = 64;       // backbone edges per scan chunk at most (their records sit in LDS: 176 B each)
+constexpr int kDcRows = 48;   // distinct closest leaves per chunk = distance rows staged in LDS (64 queries x 8 B each) + one row of -inf
 
 // ------------------------------------------------------------------------------------------------
 // cluster assignment
@@ -46,35 +49,94 @@ __global__ __launch_bounds__(kThreads) void dc_edge_table_kernel(PlaceBuffers p,
     et_len[idx] = p.len[s];
 }
 
-// calculateBranchLengthDC for (edge chunk blockIdx.x) x (256 queries blockIdx.y); lane = query.
+// calculateBranchLengthDC for (chunk of table entries blockIdx.x) x (64 queries blockIdx.y); lane = query.
 // dT[c * ldq + q] = distance(query q, backbone tip c).  Writes the chunk's first minimum per query.
-__global__ __launch_bounds__(kThreads) void dc_assign_scan_kernel(const int32_t* __restrict__ et_cid,
-                                                                  const double* __restrict__ et_cdis,
-                                                                  const double* __restrict__ et_len,
-                                                                  const int32_t* __restrict__ vslots, int nv,
-                                                                  const double* __restrict__ dT, int64_t ldq, int Q,
-                                                                  double* __restrict__ part_add,
-                                                                  int32_t* __restrict__ part_pos)
+constexpr int kDcRec = 11;    // 16-byte words per packed table entry
+__global__ __launch_bounds__(kThreads) void dc_pack_records_kernel(const int32_t* __restrict__ off, const double* __restrict__ et_cdis,
+                                                                   const double* __restrict__ et_len, const int32_t* __restrict__ vslots,
+                                                                   int nv, uint4* __restrict__ rec)
 {
-    const int q = blockIdx.y * kThreads + threadIdx.x;
+    const int e = blockIdx.x * kThreads + threadIdx.x;
+    if (e >= nv) return;
+    uint4* r = rec + (int64_t)e * kDcRec;
+    for (int i = 0; i < 10; ++i) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(et_cdis[e * 10 + i]);
+        r[i] = make_uint4((uint32_t)off[e * 10 + i], 0u, (uint32_t)b, (uint32_t)(b >> 32));
+    }
+    const unsigned long long lb = (unsigned long long)__double_as_longlong(et_len[e]);
+    r[10] = make_uint4((uint32_t)vslots[e], 0u, (uint32_t)lb, (uint32_t)(lb >> 32));
+}
+
+// One workgroup = 64 queries x one chunk of table entries.  Round 5: the chunk's distinct closest leaves (<= kDcRows; neighbours in
+// the tree share most of theirs: 47 rows for 56 entries' 560 references on average) are staged in LDS once -- a lane per query,
+// the four wavefronts a quarter of the rows each, all loads in flight together -- and the 10 look-ups per entry read LDS at a
+// wave-uniform row; the former scan read every reference from L2 / Infinity Cache (7.6 TB per 950 000 queries x 100 000 edges,
+// 3.5 ms per launch).  The four wavefronts then take every fourth entry of the chunk for the same 64 queries and combine their
+// minima.  The entries' scalars (row offset and path length per list entry, edge length, slot) are copied to LDS with the rows and
+// read there at a wave-uniform address (a broadcast): as scalar loads they shared a counter with the LDS reads and made every
+// entry a chain of five dependent round trips (2.3 ms); as one record per entry read out with v_readlane they were a third of
+// the loop's vector instructions (1.4 ms).  An absent list entry points at a row of -inf: its candidate never exceeds the running
+// maximum, as the reference's `!= -1` test.  Same arithmetic per (query, edge); the minimum does not depend on the order (ties
+// by slot).
+__global__ __launch_bounds__(256) void dc_assign_scan_kernel(const int32_t* __restrict__ ch_e0, const int32_t* __restrict__ ch_l0,
+                                                             const int32_t* __restrict__ ch_leaf, const uint4* __restrict__ et_rec,
+                                                             const double* __restrict__ dT, int64_t ldq, int Q,
+                                                             double* __restrict__ part_add, int32_t* __restrict__ part_pos)
+{
+    __shared__ double rows[(kDcRows + 1) * 64];
+    __shared__ uint4 meta[kAE * kDcRec];
+    __shared__ double s_best[3][64];
+    __shared__ int s_pos[3][64];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ch = blockIdx.x;
+    const int q = blockIdx.y * 64 + lane;
     const int qq = q < Q ? q : Q - 1;
-    const int e0 = blockIdx.x * kAE, e1 = min(nv, e0 + kAE);
+    const int e0 = ch_e0[ch], e1 = ch_e0[ch + 1], l0 = ch_l0[ch], nrow = ch_l0[ch + 1] - l0;
     const double* col = dT + qq;
+    {
+        const int nm = (e1 - e0) * kDcRec;
+        const uint4* __restrict__ src = et_rec + (int64_t)e0 * kDcRec;
+        uint4 m[(kAE * kDcRec + 255) / 256];
+#pragma unroll
+        for (int k = 0; k < (kAE * kDcRec + 255) / 256; ++k) {
+            const int idx = (int)threadIdx.x + 256 * k;
+            m[k] = idx < nm ? src[idx] : make_uint4(0u, 0u, 0u, 0u);
+        }
+        double v[kDcRows / 4];
+#pragma unroll
+        for (int k = 0; k < kDcRows / 4; ++k) {
+            const int r = w + 4 * k;
+            v[k] = r < nrow ? col[(int64_t)ch_leaf[l0 + r] * ldq] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < (kAE * kDcRec + 255) / 256; ++k) {
+            const int idx = (int)threadIdx.x + 256 * k;
+            if (idx < nm) meta[idx] = m[k];
+        }
+#pragma unroll
+        for (int k = 0; k < kDcRows / 4; ++k) {
+            const int r = w + 4 * k;
+            if (r < nrow) rows[r * 64 + lane] = v[k];
+        }
+        if (w == 0) rows[kDcRows * 64 + lane] = -__builtin_inf();
+    }
+    __syncthreads();
     double best = __builtin_inf();
-    int bpos = 0x7fffffff;      // the SLOT of the best edge: the table is in tree order, ties go to the lowest slot
-    for (int e = e0; e < e1; ++e) {
-        double dis1 = 0, dis2 = 0, val;
+    int bpos = 0x7fffffff;      // the SLOT of the best edge: ties go to the lowest slot
+    auto f64_of = [](const uint4& u) -> double { return __longlong_as_double((long long)(((unsigned long long)u.w << 32) | u.z)); };
+    const int ne = e1 - e0;
+#pragma unroll 2
+    for (int el = w; el < ne; el += 4) {
+        const uint4* __restrict__ mr = meta + el * kDcRec;
+        // (fmax for the reference's `if (val > dis) dis = val`: dis starts at +0 and only ever takes a larger value, a NaN candidate is
+        //  passed over by both forms)
+        double dis1 = 0, dis2 = 0;
 #pragma unroll
-        for (int i = 0; i < K5; ++i) {
-            const int c = et_cid[e * 10 + i];
-            if (c != -1) { val = col[(int64_t)c * ldq] - et_cdis[e * 10 + i]; if (val > dis1) dis1 = val; }
-        }
+        for (int i = 0; i < K5; ++i) { const uint4 u = mr[i]; dis1 = fmax(dis1, rows[u.x + lane] - f64_of(u)); }
 #pragma unroll
-        for (int i = 0; i < K5; ++i) {
-            const int c = et_cid[e * 10 + 5 + i];
-            if (c != -1) { val = col[(int64_t)c * ldq] - et_cdis[e * 10 + 5 + i]; if (val > dis2) dis2 = val; }
-        }
-        const double L = et_len[e];
+        for (int i = 0; i < K5; ++i) { const uint4 u = mr[5 + i]; dis2 = fmax(dis2, rows[u.x + lane] - f64_of(u)); }
+        const uint4 t = mr[10];
+        const double L = f64_of(t);
         double a = (dis1 + dis2 - L) / 2;
         if (a < 0) a = 0;
         dis1 -= a; dis2 -= a;
@@ -82,31 +144,57 @@ __global__ __launch_bounds__(kThreads) void dc_assign_scan_kernel(const int32_t*
         if (dis2 < 0) dis2 = 0;
         if (dis1 > L) { a += dis1 - L; dis1 = L; }
         if (dis2 > L) { a += dis2 - L; dis2 = L; }
-        const int slot = vslots[e];
+        const int slot = (int)t.x;
         if (a < best || (a == best && slot < bpos)) { best = a; bpos = slot; }
     }
-    if (q < Q) {
-        part_add[(int64_t)blockIdx.x * ldq + q] = best;
-        part_pos[(int64_t)blockIdx.x * ldq + q] = bpos;
+    if (w > 0) { s_best[w - 1][lane] = best; s_pos[w - 1][lane] = bpos; }
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double a = s_best[k][lane];
+            const int sl = s_pos[k][lane];
+            if (a < best || (a == best && sl < bpos)) { best = a; bpos = sl; }
+        }
+        if (q < Q) {
+            part_add[(int64_t)blockIdx.x * ldq + q] = best;
+            part_pos[(int64_t)blockIdx.x * ldq + q] = bpos;
+        }
     }
 }
 
 // thrust::min_element over all 4B-4 tuples: ineligible slots carry (0,0,2) and slot 0 is always one
 // of them (belong 0 < e), so the winner is the first eligible minimum if it is < 2, else tuple eid 0.
-__global__ __launch_bounds__(kThreads) void dc_assign_reduce_kernel(const double* __restrict__ part_add,
-                                                                    const int32_t* __restrict__ part_pos, int nchunks,
-                                                                    int64_t ldq, int Q, int32_t* __restrict__ cluster_id)
+// (64 queries per workgroup, its 16 wavefronts every 16th chunk: a thread per query walking all chunks was 1 200 dependent steps)
+constexpr int kRedWaves = 16;
+__global__ __launch_bounds__(64 * kRedWaves) void dc_assign_reduce_kernel(const double* __restrict__ part_add,
+                                                                         const int32_t* __restrict__ part_pos, int nchunks,
+                                                                         int64_t ldq, int Q, int32_t* __restrict__ cluster_id)
 {
-    const int q = blockIdx.x * kThreads + threadIdx.x;
-    if (q >= Q) return;
+    __shared__ double s_best[kRedWaves][64];
+    __shared__ int s_pos[kRedWaves][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + lane;
+    const int qq = q < Q ? q : Q - 1;
     double best = __builtin_inf();
     int bpos = 0x7fffffff;
-    for (int c = 0; c < nchunks; ++c) {
-        const double a = part_add[(int64_t)c * ldq + q];
-        const int sl = part_pos[(int64_t)c * ldq + q];
+#pragma unroll 4
+    for (int c = w; c < nchunks; c += kRedWaves) {
+        const double a = part_add[(int64_t)c * ldq + qq];
+        const int sl = part_pos[(int64_t)c * ldq + qq];
         if (a < best || (a == best && sl < bpos)) { best = a; bpos = sl; }
     }
-    cluster_id[q] = (best < 2.0) ? bpos : 0;
+    s_best[w][lane] = best; s_pos[w][lane] = bpos;
+    __syncthreads();
+    if (w == 0 && q < Q) {
+#pragma unroll
+        for (int k = 1; k < kRedWaves; ++k) {
+            const double a = s_best[k][lane];
+            const int sl = s_pos[k][lane];
+            if (a < best || (a == best && sl < bpos)) { best = a; bpos = sl; }
+        }
+        cluster_id[q] = (best < 2.0) ? bpos : 0;
+    }
 }
 
 int dc_table_build(PlaceBuffers& p, int64_t B, DcTable& t, hipStream_t s)
@@ -153,12 +241,68 @@ int dc_table_build(PlaceBuffers& p, int64_t B, DcTable& t, hipStream_t s)
                        t.vslots, t.nv, t.et_cid, t.et_cdis, t.et_len);
     DPR_HIP(hipGetLastError());
     DPR_HIP(hipStreamSynchronize(s));   // vs goes out of scope
+    // chunks for the assignment scan: consecutive entries while their lists name at most kDcRows distinct tips (and kAE entries)
+    {
+        std::vector<int32_t> hc(vs.size() * 10), off(vs.size() * 10), e0v{ 0 }, l0v{ 0 }, leaf, cur;
+        DPR_HIP(hipMemcpy(hc.data(), t.et_cid, sizeof(int32_t) * hc.size(), hipMemcpyDeviceToHost));
+        std::vector<int32_t> loc((size_t)p.N, -1);          // tip -> row of the current chunk
+        leaf.reserve(vs.size());
+        int32_t fresh[10];
+        for (size_t e = 0; e < vs.size(); ++e) {
+            auto count_fresh = [&]() {
+                int nf = 0;
+                for (int i = 0; i < 10; ++i) {
+                    const int32_t id = hc[e * 10 + (size_t)i];
+                    if (id < 0 || loc[(size_t)id] >= 0) continue;
+                    bool seen = false;
+                    for (int k = 0; k < nf; ++k) seen = seen || fresh[k] == id;
+                    if (!seen) fresh[nf++] = id;
+                }
+                return nf;
+            };
+            int nf = count_fresh();
+            if ((int)cur.size() + nf > kDcRows || (int64_t)e - (int64_t)e0v.back() >= kAE) {      // close the chunk
+                for (int32_t id : cur) loc[(size_t)id] = -1;
+                cur.clear();
+                e0v.push_back((int32_t)e);
+                l0v.push_back((int32_t)leaf.size());
+                nf = count_fresh();
+            }
+            for (int k = 0; k < nf; ++k) { loc[(size_t)fresh[k]] = (int32_t)cur.size(); cur.push_back(fresh[k]); leaf.push_back(fresh[k]); }
+            for (int i = 0; i < 10; ++i) {
+                const int32_t id = hc[e * 10 + (size_t)i];
+                off[e * 10 + (size_t)i] = (id < 0 ? kDcRows : loc[(size_t)id]) * 64;
+            }
+        }
+        e0v.push_back((int32_t)vs.size());
+        l0v.push_back((int32_t)leaf.size());
+        t.nch = (int)e0v.size() - 1;
+        if (leaf.empty()) leaf.push_back(0);
+        DPR_HIP(hipMalloc(&t.ch_e0, sizeof(int32_t) * e0v.size()));
+        DPR_HIP(hipMalloc(&t.ch_l0, sizeof(int32_t) * l0v.size()));
+        DPR_HIP(hipMalloc(&t.ch_leaf, sizeof(int32_t) * leaf.size()));
+        int32_t* d_off = nullptr;
+        DPR_HIP(hipMalloc(&d_off, sizeof(int32_t) * off.size()));
+        DPR_HIP(hipMalloc(&t.et_rec, sizeof(uint4) * vs.size() * kDcRec));
+        DPR_HIP(hipMemcpy(t.ch_e0, e0v.data(), sizeof(int32_t) * e0v.size(), hipMemcpyHostToDevice));
+        DPR_HIP(hipMemcpy(t.ch_l0, l0v.data(), sizeof(int32_t) * l0v.size(), hipMemcpyHostToDevice));
+        DPR_HIP(hipMemcpy(t.ch_leaf, leaf.data(), sizeof(int32_t) * leaf.size(), hipMemcpyHostToDevice));
+        DPR_HIP(hipMemcpy(d_off, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(dc_pack_records_kernel, dim3((unsigned)((t.nv + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, d_off, t.et_cdis, t.et_len,
+                           t.vslots, t.nv, t.et_rec);
+        DPR_HIP(hipGetLastError());
+        DPR_HIP(hipStreamSynchronize(s));
+        (void)hipFree(d_off);
+        if (log_level("dc") > 0)
+            std::fprintf(stderr, "[dc] assignment table: %d entries in %d chunks (%.1f entries, %.1f distinct closest leaves per chunk)\n", t.nv, t.nch,
+                         (double)t.nv / (double)t.nch, (double)leaf.size() / (double)t.nch);
+    }
     return DPR_OK;
 }
 
 void dc_table_free(DcTable& t)
 {
-    void* ptrs[] = { t.vslots, t.et_cid, t.et_cdis, t.et_len, t.part_add, t.part_pos };
+    void* ptrs[] = { t.vslots, t.et_cid, t.et_cdis, t.et_len, t.ch_e0, t.ch_l0, t.ch_leaf, t.et_rec, t.part_add, t.part_pos };
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     t = DcTable();
@@ -166,7 +310,7 @@ void dc_table_free(DcTable& t)
 
 int dc_assign(DcTable& t, const double* dT, int64_t ldq, int Q, int32_t* d_cluster_id, hipStream_t s)
 {
-    const int nchunks = (t.nv + kAE - 1) / kAE;
+    const int nchunks = t.nch;
     const size_t need = (size_t)nchunks * (size_t)ldq;
     if (need > t.part_cap) {
         if (t.part_add) (void)hipFree(t.part_add);
@@ -176,12 +320,12 @@ int dc_assign(DcTable& t, const double* dT, int64_t ldq, int Q, int32_t* d_clust
         DPR_HIP(hipMalloc(&t.part_pos, sizeof(int32_t) * need));
         t.part_cap = need;
     }
-    // edge chunks are the fast grid index: the blocks in flight share few query groups, whose
-    // distance columns then stay in L2 / Infinity Cache while all chunks sweep them
-    dim3 grid((unsigned)nchunks, (unsigned)((Q + kThreads - 1) / kThreads));
-    hipLaunchKernelGGL(dc_assign_scan_kernel, grid, dim3(kThreads), 0, s, t.et_cid, t.et_cdis, t.et_len, t.vslots, t.nv, dT, ldq, Q,
+    // chunks are the fast grid index: the blocks in flight share few query groups, whose distance columns then stay in L2 /
+    // Infinity Cache while all chunks sweep them
+    dim3 grid((unsigned)nchunks, (unsigned)((Q + 63) / 64));
+    hipLaunchKernelGGL(dc_assign_scan_kernel, grid, dim3(256), 0, s, t.ch_e0, t.ch_l0, t.ch_leaf, t.et_rec, dT, ldq, Q,
                        t.part_add, t.part_pos);
-    hipLaunchKernelGGL(dc_assign_reduce_kernel, dim3((unsigned)((Q + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+    hipLaunchKernelGGL(dc_assign_reduce_kernel, dim3((unsigned)((Q + 63) / 64)), dim3(64 * kRedWaves), 0, s,
                        t.part_add, t.part_pos, nchunks, ldq, Q, d_cluster_id);
     DPR_HIP(hipGetLastError());
     return DPR_OK;

@@ -502,6 +502,14 @@ struct DcTable {
     int32_t* et_cid = nullptr;     // [nv][10] closest ids: own list, reverse list
     double* et_cdis = nullptr;     // [nv][10]
     double* et_len = nullptr;      // [nv]
+    // chunks of consecutive table entries (tree order) whose closest lists name at most kDcRows distinct backbone tips: the assignment
+    // scan stages those tips' distance rows in LDS once per (chunk, 64 queries)
+    int nch = 0;
+    int32_t* ch_e0 = nullptr;      // [nch + 1] first table entry of a chunk
+    int32_t* ch_l0 = nullptr;      // [nch + 1] first entry of a chunk in ch_leaf
+    int32_t* ch_leaf = nullptr;    // the chunks' distinct backbone tips
+    uint4* et_rec = nullptr;       // [nv][11] x 16 B per entry: for each of the 10 list entries {LDS offset (in doubles) of its staged row (absent: the
+                                   // -inf row), 0, path length}; then {slot, 0, edge length} -- copied to LDS per chunk, read there at a wave-uniform address
     double* part_add = nullptr;    // [chunks][ldq] per-chunk first minima
     int32_t* part_pos = nullptr;
     size_t part_cap = 0;
