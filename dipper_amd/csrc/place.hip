@@ -335,11 +335,12 @@ __device__ __forceinline__ int place_split_wave(const PlaceBuffers& p, int64_t n
     const bool fallback = ox0 == -2 || oy0 == -2;
     const bool lists = role == 0, book = fallback ? role == 0 : role == 1;
     if (role == 0) {
-        // every load above has returned (the waitcnt) -> wavefront 1 may overwrite what they read
+        // every load above has returned -> wavefront 1 may overwrite what they read.  (Release: the compiler must not sink a load
+        // below the store; the waitcnt: the hardware must have the data back, not just the requests out.)
         __builtin_amdgcn_s_waitcnt(0);
-        if (lane == 0) __hip_atomic_store(sync, (int)num, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_store(sync, (int)num, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (book) {
-        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)num) __builtin_amdgcn_s_sleep(1);
+        while (__hip_atomic_load(sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)num) __builtin_amdgcn_s_sleep(1);
     }
     // middle -> x inherits the list of y -> x, middle -> y the list of x -> y (entry by entry; an empty entry keeps what the slot held)
     const bool has0 = ciy != -1, has1 = cix != -1;
