@@ -17,6 +17,7 @@
 //    the cluster sizes), so all cluster trees are built concurrently, one wavefront per cluster, from
 //    per-cluster distance blocks computed beforehand by the tiled pair kernels.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(64 * kRedWaves) void dc_assign_reduce_kernel(const 
 int dc_table_build(PlaceBuffers& p, int64_t B, DcTable& t, hipStream_t s)
 {
     dc_table_free(t);
+    const auto tb0 = std::chrono::steady_clock::now();
     const int64_t lim = 4 * B - 4;
     std::vector<int32_t> hb((size_t)lim), he((size_t)lim), hn((size_t)lim), hh((size_t)(2 * p.N));
     DPR_HIP(hipMemcpyAsync(hb.data(), p.belong, sizeof(int32_t) * (size_t)lim, hipMemcpyDeviceToHost, s));
@@ -294,8 +296,9 @@ int dc_table_build(PlaceBuffers& p, int64_t B, DcTable& t, hipStream_t s)
         DPR_HIP(hipStreamSynchronize(s));
         (void)hipFree(d_off);
         if (log_level("dc") > 0)
-            std::fprintf(stderr, "[dc] assignment table: %d entries in %d chunks (%.1f entries, %.1f distinct closest leaves per chunk)\n", t.nv, t.nch,
-                         (double)t.nv / (double)t.nch, (double)leaf.size() / (double)t.nch);
+            std::fprintf(stderr, "[dc] assignment table: %d entries in %d chunks (%.1f entries, %.1f distinct closest leaves per chunk), built in %.1f ms\n", t.nv, t.nch,
+                         (double)t.nv / (double)t.nch, (double)leaf.size() / (double)t.nch,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count());
     }
     return DPR_OK;
 }

@@ -360,7 +360,12 @@ struct PairJobs {
 struct MsaBuffers {
     uint32_t* planes = nullptr;  // [4][n][W32]: X (not a base), LO, HI, LX = LO | X bit planes, 32 bases per word
     int64_t n = 0, L = 0, W32 = 0;
+    // alignments of at most kMsaTabSites sites: the distance of every (useful, match) pair of counts, types 1 and 2 -- the same
+    // function of the same two integers as the epilogue computes, read instead of recomputed (a division and a log per pair are
+    // half of the pair kernel's instructions at 400 sites)
+    double* jc_tab = nullptr;    // [2][(L + 1) * (L + 1)]
 };
+constexpr int64_t kMsaTabSites = 1024;
 int msa_upload(MsaBuffers& m, const uint64_t* packed4, int64_t n, int64_t L, hipStream_t s);
 void msa_free(MsaBuffers& m);
 int msa_dist_rows(const MsaBuffers& m, NjBuffers& b, int dist_type, hipStream_t s);

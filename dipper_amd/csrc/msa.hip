@@ -121,6 +121,7 @@ struct PairCounts {
         const double c = double(gc1) / tot + double(gc2) / tot - 2 * double(gc1) * double(gc2) / tot / tot;
         return -c * log(1 - pp / c - qq) - 0.5 * (1 - c) * log(1 - 2 * qq);
     }
+    __device__ __forceinline__ double value(int dist_type, const double*, int) const { return value(dist_type); }
 };
 // types 1 and 2 share one instantiation (TYPE = DPR_DIST_JC), the formula is picked at run time
 template <>
@@ -135,7 +136,20 @@ struct PairCounts<DPR_DIST_JC> {
         mism += __popc(m);
     }
     __device__ __forceinline__ double value(int dist_type) const { return msa_epilogue(sites - binv, sites - mism, dist_type); }
+    __device__ __forceinline__ double value(int dist_type, const double* tab, int tab_ld) const
+    {
+        return tab ? tab[(int64_t)(sites - binv) * tab_ld + (sites - mism)] : value(dist_type);
+    }
 };
+// (useful, match) -> distance for both types 1 and 2
+__global__ __launch_bounds__(kThreads) void msa_jc_table_kernel(int L, double* __restrict__ tab)
+{
+    const int64_t ld = (int64_t)L + 1, i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= ld * ld) return;
+    const int useful = (int)(i / ld), match = (int)(i % ld);
+    tab[i] = msa_epilogue(useful, match, DPR_DIST_UNCORRECTED);
+    tab[ld * ld + i] = msa_epilogue(useful, match, DPR_DIST_JC);
+}
 
 template <int TYPE> struct TileOf { static constexpr int SUB = 2; };              // 32 x 32 pairs, 2 x 2 per thread
 template <> struct TileOf<DPR_DIST_JC> { static constexpr int SUB = 4; };         // 64 x 64 pairs, 4 x 4 per thread
@@ -153,6 +167,8 @@ struct TileOut {
     int64_t mir_ld;
     bool skip_main;     // only the transposed target is written
     int64_t diag;       // element (r, c) with r + diag == c is a tip against itself -> 0 (kNoDiag: none)
+    const double* tab;  // types 1-2, short alignments: distance by (useful, match), row stride tab_ld (nullptr: computed)
+    int tab_ld;
 };
 
 // Block of 256 threads = 16 x 16; thread (ty,tx) owns rows ty*SUB.., cols tx*SUB..
@@ -241,7 +257,7 @@ __device__ __forceinline__ void msa_tile(const uint32_t* __restrict__ planes, in
         for (int c = 0; c < SUB; ++c) {
             const int rr = ty * SUB + r, cc = tx * SUB + c;
             double d = 0.0;
-            if (rr < o.nr && cc < o.nc && rr + o.diag != cc) d = acc[r][c].value(dist_type);
+            if (rr < o.nr && cc < o.nc && rr + o.diag != cc) d = acc[r][c].value(dist_type, o.tab, o.tab_ld);
             T[rr * (PT + 1) + cc] = d;
         }
     __syncthreads();
@@ -272,7 +288,7 @@ template <int TYPE>
 __global__ __launch_bounds__(kThreads) void msa_dist_kernel(const uint32_t* __restrict__ planes, int64_t n, int64_t W32,
                                                             int dist_type, double* __restrict__ D, int64_t ld,
                                                             int64_t rows_local, int rank, int world, int64_t row0,
-                                                            int64_t col0, int64_t ncols, int transposed)
+                                                            int64_t col0, int64_t ncols, int transposed, const double* __restrict__ tab, int tab_ld)
 {
     constexpr int PT = 16 * TileOf<TYPE>::SUB;
     __shared__ __attribute__((aligned(16))) char smem[msa_tile_lds<TYPE>()];
@@ -295,6 +311,7 @@ __global__ __launch_bounds__(kThreads) void msa_dist_kernel(const uint32_t* __re
     o.nc = (int)(ncl - c0 < PT ? ncl - c0 : PT);
     o.lower_base = -1; o.r_org = 0; o.c_org = 0;
     o.diag = g0 - c0;
+    o.tab = tab; o.tab_ld = tab_ld;
     if (transposed) {
         o.skip_main = true; o.out = nullptr; o.ld = 0;
         o.mir = D + (c0 - col0) * ld + l0; o.mir_ld = ld;
@@ -311,7 +328,7 @@ __global__ __launch_bounds__(kThreads) void msa_dist_kernel(const uint32_t* __re
 // u < 10 + t goes to out[cl_out + t * cl_ld + u].
 template <int TYPE>
 __global__ __launch_bounds__(kThreads) void msa_dist_jobs_kernel(const uint32_t* __restrict__ planes, int64_t n,
-                                                                 int64_t W32, int dist_type, PairJobs J)
+                                                                 int64_t W32, int dist_type, PairJobs J, const double* __restrict__ tab, int tab_ld)
 {
     constexpr int PT = 16 * TileOf<TYPE>::SUB;
     __shared__ __attribute__((aligned(16))) char smem[msa_tile_lds<TYPE>()];
@@ -330,18 +347,25 @@ __global__ __launch_bounds__(kThreads) void msa_dist_jobs_kernel(const uint32_t*
     o.nc = ncols - u0 < PT ? ncols - u0 : PT;
     o.lower_base = kDcLeaves; o.r_org = t0; o.c_org = u0;
     o.diag = kNoDiag; o.skip_main = false;
+    o.tab = tab; o.tab_ld = tab_ld;
     o.out = J.out + J.cl_out[ci] + (int64_t)t0 * J.cl_ld[ci] + u0; o.ld = J.cl_ld[ci];
     o.mir = nullptr; o.mir_ld = 0;
     msa_tile<TYPE>(planes, n, W32, dist_type, s_rid, s_cid, o, smem);
 }
 
+static const double* msa_jc_tab(const MsaBuffers& m, int dist_type)
+{
+    if (!m.jc_tab) return nullptr;
+    return m.jc_tab + (dist_type == DPR_DIST_JC ? (m.L + 1) * (m.L + 1) : 0);
+}
+
 template <int TYPE>
 static int launch_matrix(dim3 grid, hipStream_t s, const uint32_t* planes, int64_t n, int64_t W32, int dist_type,
                          double* D, int64_t ld, int64_t rows, int rank, int world, int64_t row0, int64_t col0,
-                         int64_t ncols, int transposed)
+                         int64_t ncols, int transposed, const double* tab, int tab_ld)
 {
     hipLaunchKernelGGL(msa_dist_kernel<TYPE>, grid, dim3(kThreads), 0, s, planes, n, W32, dist_type, D, ld, rows, rank,
-                       world, row0, col0, ncols, transposed);
+                       world, row0, col0, ncols, transposed, tab, tab_ld);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
@@ -353,11 +377,11 @@ static int msa_launch(int dist_type, hipStream_t s, const MsaBuffers& m, double*
     dim3 g((unsigned)((ncols + pt - 1) / pt), (unsigned)((rows + pt - 1) / pt));
     switch (dist_type) {
     case DPR_DIST_UNCORRECTED:
-    case DPR_DIST_JC:        return launch_matrix<DPR_DIST_JC>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed);
-    case DPR_DIST_TAJIMANEI: return launch_matrix<DPR_DIST_TAJIMANEI>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed);
-    case DPR_DIST_K2P:       return launch_matrix<DPR_DIST_K2P>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed);
-    case DPR_DIST_TAMURA:    return launch_matrix<DPR_DIST_TAMURA>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed);
-    case DPR_DIST_JINNEI:    return launch_matrix<DPR_DIST_JINNEI>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed);
+    case DPR_DIST_JC:        return launch_matrix<DPR_DIST_JC>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed, msa_jc_tab(m, dist_type), (int)m.L + 1);
+    case DPR_DIST_TAJIMANEI: return launch_matrix<DPR_DIST_TAJIMANEI>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed, nullptr, 0);
+    case DPR_DIST_K2P:       return launch_matrix<DPR_DIST_K2P>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed, nullptr, 0);
+    case DPR_DIST_TAMURA:    return launch_matrix<DPR_DIST_TAMURA>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed, nullptr, 0);
+    case DPR_DIST_JINNEI:    return launch_matrix<DPR_DIST_JINNEI>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed, nullptr, 0);
     default: set_error("unknown distance type (valid: 1-6)"); return DPR_ERR_ARG;
     }
 }
@@ -369,11 +393,11 @@ int msa_dist_jobs(const MsaBuffers& m, int dist_type, const PairJobs& J, int njo
     if (njobs <= 0) return DPR_OK;
     switch (dist_type) {
     case DPR_DIST_UNCORRECTED:
-    case DPR_DIST_JC:        hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_JC>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J); break;
-    case DPR_DIST_TAJIMANEI: hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_TAJIMANEI>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J); break;
-    case DPR_DIST_K2P:       hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_K2P>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J); break;
-    case DPR_DIST_TAMURA:    hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_TAMURA>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J); break;
-    case DPR_DIST_JINNEI:    hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_JINNEI>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J); break;
+    case DPR_DIST_JC:        hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_JC>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J, msa_jc_tab(m, dist_type), (int)m.L + 1); break;
+    case DPR_DIST_TAJIMANEI: hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_TAJIMANEI>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J, (const double*)nullptr, 0); break;
+    case DPR_DIST_K2P:       hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_K2P>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J, (const double*)nullptr, 0); break;
+    case DPR_DIST_TAMURA:    hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_TAMURA>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J, (const double*)nullptr, 0); break;
+    case DPR_DIST_JINNEI:    hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_JINNEI>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J, (const double*)nullptr, 0); break;
     default: set_error("unknown distance type (valid: 1-6)"); return DPR_ERR_ARG;
     }
     DPR_HIP(hipGetLastError());
@@ -415,6 +439,12 @@ int msa_upload(MsaBuffers& m, const uint64_t* packed4, int64_t n, int64_t L, hip
     hipLaunchKernelGGL(msa_planes_kernel, dim3(grid ? grid : 1), dim3(kThreads), 0, s, d_in, n, L, W64,
                        m.W32, m.planes);
     DPR_HIP(hipGetLastError());
+    if (L <= kMsaTabSites) {
+        const int64_t cells = (L + 1) * (L + 1);
+        DPR_HIP(hipMalloc(&m.jc_tab, sizeof(double) * (size_t)(2 * cells)));
+        hipLaunchKernelGGL(msa_jc_table_kernel, dim3((unsigned)((cells + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, (int)L, m.jc_tab);
+        DPR_HIP(hipGetLastError());
+    }
     DPR_HIP(hipStreamSynchronize(s));
     DPR_HIP(hipFree(d_in));
     return DPR_OK;
@@ -423,6 +453,7 @@ int msa_upload(MsaBuffers& m, const uint64_t* packed4, int64_t n, int64_t L, hip
 void msa_free(MsaBuffers& m)
 {
     if (m.planes) (void)hipFree(m.planes);
+    if (m.jc_tab) (void)hipFree(m.jc_tab);
     m = MsaBuffers();
 }
 
