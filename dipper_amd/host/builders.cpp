@@ -396,38 +396,47 @@ void KPlacementDeviceArraysDC::findTreeDC(DeviceContext& dev, Param& params)
 // adjacency-list order, the edge back to the parent skipped; a node with a single adjacency entry is a leaf.
 void KPlacementDeviceArrays::printTree(const std::vector<std::string>& name, std::ostream& output_)
 {
-    struct Frame { int node, from; std::vector<int> pos; size_t next; };
+    // (a node's adjacency entries other than the one it was entered through, gathered once into one array: no allocation per node)
+    struct Frame { int node, from; size_t first, count, next; };
+    std::vector<int> pos;
+    pos.reserve((size_t)numSequences * 4);
     auto make = [&](int node, int from) {
-        Frame f{ node, from, {}, 0 };
+        Frame f{ node, from, pos.size(), 0, 0 };
         for (int i = h_head[(size_t)node]; i != -1; i = h_nxt[(size_t)i])
-            if (h_e[(size_t)i] != from) f.pos.push_back(i);
+            if (h_e[(size_t)i] != from) pos.push_back(i);
+        f.count = pos.size() - f.first;
         return f;
     };
     auto is_internal = [&](int node) { return h_nxt[(size_t)h_head[(size_t)node]] != -1; };
     const int root = numSequences + bd - 2;
     std::vector<Frame> st;
     if (!is_internal(root)) { output_ << name[(size_t)root] << ";\n"; return; }
-    output_ << "(";
+    TextBuf out;
+    out.s.reserve((size_t)numSequences * 40);
+    out.put('(');
     st.push_back(make(root, -1));
     while (!st.empty()) {
         Frame& f = st.back();
-        if (f.next == f.pos.size()) {
+        if (f.next == f.count) {
+            pos.resize(f.first);             // (frames end in the order they began: the array is a stack)
             st.pop_back();
             if (st.empty()) break;
             Frame& up = st.back();
-            output_ << ":"; putLength(output_, h_len[(size_t)up.pos[up.next - 1]]); output_ << (up.next == up.pos.size() ? ')' : ',');
+            out.put(':'); out.putLength(h_len[(size_t)pos[up.first + up.next - 1]]); out.put(up.next == up.count ? ')' : ',');
             continue;
         }
-        const int slot = f.pos[f.next++];
+        const int slot = pos[f.first + f.next++];
         const int child = h_e[(size_t)slot];
         if (is_internal(child)) {
-            output_ << "(";
-            st.push_back(make(child, f.node));
+            out.put('(');
+            const int parent = f.node;       // (push_back may move the frames)
+            st.push_back(make(child, parent));
         } else {
-            output_ << name[(size_t)child] << ":"; putLength(output_, h_len[(size_t)slot]); output_ << (f.next == f.pos.size() ? ')' : ',');
+            out.put(name[(size_t)child]); out.put(':'); out.putLength(h_len[(size_t)slot]); out.put(f.next == f.count ? ')' : ',');
         }
     }
-    output_ << ";\n";
+    out.put(";\n");
+    output_.write(out.s.data(), (std::streamsize)out.s.size());
 }
 
 }  // namespace dipper

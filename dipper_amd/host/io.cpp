@@ -534,7 +534,9 @@ void writeNewickFromMerges(std::ostream& os, const std::vector<std::string>& nam
     struct Frame { int node; int next; };
     std::vector<Frame> st;
     st.push_back(Frame{ root, 0 });
-    os << "(";
+    TextBuf out;
+    out.s.reserve((size_t)N * 40);
+    out.put('(');
     while (!st.empty()) {
         Frame& f = st.back();
         if (f.next == 2) {
@@ -542,19 +544,20 @@ void writeNewickFromMerges(std::ostream& os, const std::vector<std::string>& nam
             if (st.empty()) break;
             Frame& up = st.back();
             const Child& c = kids[(size_t)up.node * 2 + (size_t)(up.next - 1)];
-            os << ":"; putLength(os, c.len); os << (up.next == 2 ? ')' : ',');
+            out.put(':'); out.putLength(c.len); out.put(up.next == 2 ? ')' : ',');
             continue;
         }
         const Child& c = kids[(size_t)f.node * 2 + (size_t)f.next];
         f.next++;
         if (c.node >= N) {
-            os << "(";
+            out.put('(');
             st.push_back(Frame{ c.node, 0 });
         } else {
-            os << name[(size_t)c.node] << ":"; putLength(os, c.len); os << (f.next == 2 ? ')' : ',');
+            out.put(name[(size_t)c.node]); out.put(':'); out.putLength(c.len); out.put(f.next == 2 ? ')' : ',');
         }
     }
-    os << ";\n";
+    out.put(";\n");
+    os.write(out.s.data(), (std::streamsize)out.s.size());
 }
 
 }  // namespace dipper

@@ -303,7 +303,9 @@ int main(int argc, char** argv)
         const Tree& t = *tp;
         const size_t numSequences = packed.ok ? packed.numSequences : seqs.size();
         auto output_ = open_out();
+        if (cliLog()) std::cerr << "  input read, backbone tree parsed at " << ms_since(inputStart) << " ms\n";
         DeviceContext& dev = adev.get();
+        if (cliLog()) std::cerr << "  device ready at " << ms_since(inputStart) << " ms\n";
         KPlacementDeviceArrays kplacementDeviceArrays;
         if (params.in == "r") {
             MashDeviceArrays mashDeviceArrays;
@@ -317,10 +319,14 @@ int main(int argc, char** argv)
             if (packed.ok) msaDeviceArrays.allocateDeviceArrays(dev, packed);
             else msaDeviceArrays.allocateDeviceArrays(dev, seqs, ids);
         }
+        if (cliLog()) std::cerr << "  sequences on the device (sketches built) at " << ms_since(inputStart) << " ms\n";
         kplacementDeviceArrays.allocateDeviceArrays(numSequences, (int)backboneSize);
         kplacementDeviceArrays.initializeDeviceArrays(t);
+        if (cliLog()) std::cerr << "  backbone state built at " << ms_since(inputStart) << " ms\n";
         kplacementDeviceArrays.addQuery(dev, params);
+        if (cliLog()) std::cerr << "  addQuery done at " << ms_since(inputStart) << " ms\n";
         kplacementDeviceArrays.printTree(names, *output_);
+        if (cliLog()) std::cerr << "  tree written at " << ms_since(inputStart) << " ms\n";
         return 0;
     }
 
