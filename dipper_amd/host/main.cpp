@@ -3,6 +3,8 @@
 // (src/tree_generation.cu:33-99,159-646); host orchestration is plain C++ over the C ABI.
 #include "dipper_host.hpp"
 
+#include <thread>
+#include <string_view>
 #include <algorithm>
 
 #include <unistd.h>
@@ -262,24 +264,54 @@ int main(int argc, char** argv)
         size_t backboneSize = 0;
         auto slots_of = [&](const std::vector<std::string>& namesDump, std::vector<std::string>* names_out) -> std::vector<int> {
             std::cerr << "Read " << namesDump.size() << " sequences from input file.\n";
+            if (cliLog()) std::cerr << "  records indexed at " << ms_since(inputStart) << " ms\n";
             if (namesDump.empty()) die("No sequences found in the input file.");
             tp.reset(new Tree(newickTree, namesDump.size()));
             const Tree& t = *tp;
             std::cerr << "Tree loaded successfully with " << t.nodes.size() << " nodes and root " << t.nodes[(size_t)t.root].name << ".\n";
+            if (cliLog()) std::cerr << "  backbone tree parsed at " << ms_since(inputStart) << " ms\n";
             backboneSize = t.m_numLeaves;
             const size_t numSequences = namesDump.size();
-            std::unordered_map<std::string, int> leafIdx;
-            for (const Node& nd : t.nodes) if (nd.children.empty()) leafIdx[nd.name] = nd.idx;
+            // name -> leaf index: an open-addressing table over the tree's own names (later duplicates win, as with a map), filled
+            // serially, then looked up by all host threads -- a node-based map cost 140 ms for 500 000 tips + 550 000 records
+            auto hash_of = [](const std::string& v) {
+                uint64_t h = 1469598103934665603ull;
+                for (unsigned char ch : v) { h ^= ch; h *= 1099511628211ull; }
+                return h ^ (h >> 29);
+            };
+            size_t cap = 16;
+            while (cap < 2 * t.nodes.size()) cap <<= 1;
+            std::vector<int32_t> table(cap, -1);
+            for (size_t k = 0; k < t.nodes.size(); ++k) {          // (the table holds positions in t.nodes)
+                const Node& nd = t.nodes[k];
+                if (!nd.children.empty()) continue;
+                size_t h = (size_t)hash_of(nd.name) & (cap - 1);
+                while (table[h] >= 0 && t.nodes[(size_t)table[h]].name != nd.name) h = (h + 1) & (cap - 1);
+                table[h] = (int32_t)k;
+            }
             std::vector<int> ids(numSequences);
+            {
+                const unsigned nt = hostThreads(32);
+                std::vector<std::thread> pool;
+                for (unsigned w = 0; w < nt; ++w)
+                    pool.emplace_back([&, w] {
+                        for (size_t i = numSequences * w / nt; i < numSequences * (w + 1) / nt; ++i) {
+                            size_t h = (size_t)hash_of(namesDump[i]) & (cap - 1);
+                            while (table[h] >= 0 && t.nodes[(size_t)table[h]].name != namesDump[i]) h = (h + 1) & (cap - 1);
+                            ids[i] = table[h] >= 0 ? t.nodes[(size_t)table[h]].idx : -1;
+                        }
+                    });
+                for (std::thread& th : pool) th.join();
+            }
             size_t found = 0, next = backboneSize;
             if (names_out) names_out->assign(backboneSize, "");
             for (size_t i = 0; i < numSequences; ++i) {
-                auto it = leafIdx.find(namesDump[i]);
-                if (it == leafIdx.end()) { ids[i] = (int)next++; if (names_out) names_out->push_back(namesDump[i]); }
-                else { ids[i] = it->second; ++found; if (names_out) (*names_out)[(size_t)it->second] = namesDump[i]; }
+                if (ids[i] < 0) { ids[i] = (int)next++; if (names_out) names_out->push_back(namesDump[i]); }
+                else { ++found; if (names_out) (*names_out)[(size_t)ids[i]] = namesDump[i]; }
             }
             if (found != backboneSize || next != numSequences) die("ERROR: every backbone tip needs exactly one sequence in the input file");
             if (backboneSize >= numSequences) die("ERROR: no query sequences to add");
+            if (cliLog()) std::cerr << "  records matched to the backbone's tips at " << ms_since(inputStart) << " ms\n";
             return ids;
         };
         if (access(inputFile.c_str(), R_OK) != 0) {
