@@ -202,8 +202,15 @@ void MashDeviceArrays::sketchConstructionOnGpu(DeviceContext& dev, Param& params
 // ---- Newick import ---------------------------------------------------------------------------------
 Tree::Tree(const std::string& newick_in, size_t totalLeaves)
 {
-    std::string s;
-    for (char c : newick_in) if (c != '\n' && c != '\r') s.push_back(c);
+    // (the text without line breaks; copied only if it has any.  500 000 tips: 17 MB, a million nodes -- the vector is sized once, a
+    //  node's children get room for two, nodes are moved into place)
+    std::string stripped;
+    if (newick_in.find_first_of("\n\r") != std::string::npos) {
+        stripped.reserve(newick_in.size());
+        for (char c : newick_in) if (c != '\n' && c != '\r') stripped.push_back(c);
+    }
+    const std::string& s = stripped.empty() ? newick_in : stripped;
+    nodes.reserve(2 * totalLeaves + 2);
     size_t nextInternal = totalLeaves, nextLeaf = 0;
     std::vector<int> stack;
     int last = -1;  // node whose label / length is being read
@@ -225,9 +232,11 @@ Tree::Tree(const std::string& newick_in, size_t totalLeaves)
             nd.idx = (int)nextInternal++;
             nd.name = "node_" + std::to_string(nd.idx);
             nd.parent = stack.empty() ? -1 : stack.back();
-            nodes.push_back(nd);
+            nd.children.reserve(2);
+            const int par = nd.parent;
+            nodes.push_back(std::move(nd));
             const int id = (int)nodes.size() - 1;
-            if (nd.parent >= 0) nodes[(size_t)nd.parent].children.push_back(id); else root = id;
+            if (par >= 0) nodes[(size_t)par].children.push_back(id); else root = id;
             stack.push_back(id);
             last = -1;
         } else if (c == ')') {
@@ -262,11 +271,12 @@ Tree::Tree(const std::string& newick_in, size_t totalLeaves)
             if (stack.empty()) die("ERROR: incorrect Newick format!");
             Node nd;
             nd.idx = (int)nextLeaf++;
-            nd.name = name;
+            nd.name = std::move(name);
             nd.parent = stack.back();
-            nodes.push_back(nd);
+            const int par = nd.parent;
+            nodes.push_back(std::move(nd));
             last = (int)nodes.size() - 1;
-            nodes[(size_t)nd.parent].children.push_back(last);
+            nodes[(size_t)par].children.push_back(last);
         }
     }
     if (!stack.empty()) die("ERROR: incorrect Newick format!");
