@@ -579,9 +579,18 @@ int mash_index_build(MashBuffers& m, hipStream_t s)
 #undef MI_HIP
     cleanup();
     ix.chunks = chunks;
-    if (log_level("mash") > 0)
-        std::fprintf(stderr, "[mash] inverted index: %lld chunks of %d tips, %u distinct (chunk, value) pairs of %lld entries, %u of them dense\n",
-                     (long long)chunks, kIC, nu, (long long)total, ix.ndense);
+    if (log_level("mash") > 0) {
+        // (how much of the pair kernel's work takes the dense path: the postings of dense values)
+        std::vector<uint32_t> hoff((size_t)nu + 1);
+        std::vector<int32_t> hblk((size_t)nu);
+        long long dense_post = 0;
+        if (hipMemcpy(hoff.data(), ix.off, sizeof(uint32_t) * hoff.size(), hipMemcpyDeviceToHost) == hipSuccess &&
+            hipMemcpy(hblk.data(), ix.dblk, sizeof(int32_t) * hblk.size(), hipMemcpyDeviceToHost) == hipSuccess)
+            for (size_t u = 0; u < hblk.size(); ++u)
+                if (hblk[u] >= 0) dense_post += (long long)(hoff[u + 1] - hoff[u]);
+        std::fprintf(stderr, "[mash] inverted index: %lld chunks of %d tips, %u distinct (chunk, value) pairs of %lld entries, %u of them dense "
+                     "(%.1f %% of the entries)\n", (long long)chunks, kIC, nu, (long long)total, ix.ndense, 100.0 * (double)dense_post / (double)total);
+    }
     return DPR_OK;
 }
 
