@@ -137,6 +137,30 @@ def test_msa_dist_and_nj(gpu, orc, n, L, inv):
             assert np.array_equal(res["bl_x"], ref["bl_x"]) and np.array_equal(res["bl_y"], ref["bl_y"])
 
 
+def test_msa_short_alignment_table_equals_computed_epilogue(gpu):
+    """alignments of at most 1 024 sites read the type-1 / type-2 distance of a (useful, match) count pair from a table filled with the
+    epilogue function itself (msa.hip, msa_jc_table_kernel).  Appending columns of gaps leaves every count unchanged but takes the
+    alignment over the limit, i.e. onto the computed epilogue: both matrices bit for bit, unknown bases and NaN / inf cells included."""
+    from dipper_amd import capi
+    n, L = 300, 1000
+    rng = np.random.default_rng(5)
+    seqs = _util.synth_alignment(rng, n, L, mean_bl=2e-2, lo=1e-4, hi=3e-1, invalid_frac=0.1)
+    seqs = [bytes(q) for q in seqs]
+    seqs[7] = b"-" * L                                  # a tip without a valid site: useful = 0
+    seqs[9] = bytes(b"ACGT"[(k * 7) % 4] for k in range(L))   # far from everything: saturated pairs
+    wide = [q + b"-" * 40 for q in seqs]
+    out = {}
+    for name, data, sites in (("table", seqs, L), ("computed", wide, L + 40)):
+        gpu.set_msa(capi.pack4_many(data), sites)
+        for dt in (capi.DIST_UNCORRECTED, capi.DIST_JC):
+            gpu.dist_matrix(capi.SRC_MSA, dt)
+            out[name, dt] = gpu.matrix().copy()
+    for dt in (capi.DIST_UNCORRECTED, capi.DIST_JC):
+        a, b = out["table", dt], out["computed", dt]
+        assert a.view(np.uint64).tobytes() == b.view(np.uint64).tobytes(), dt
+    assert not np.all(np.isfinite(out["table", capi.DIST_JC]))       # (the saturated / empty pairs are there)
+
+
 @pytest.mark.parametrize("n,kind", [(700, "additive"), (1500, "additive"), (777, "ties"), (900, "noisy")])
 def test_nj_epoch_rebuilds(orc, monkeypatch, n, kind):
     """pruned path with the position space rebuilt (compacted + re-sorted by the current row sums) every
