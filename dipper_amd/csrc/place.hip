@@ -153,18 +153,48 @@ constexpr int kQueueLds = 2048;
 // (the frontier starts with the `ns` entries (slot, distance) the caller has put into the LDS queue -- one for a BFS from the new
 //  leaf's slot; the split applies the first two rounds in registers and leaves the entries of round 2, place_split_wave)
 // (kRec, the multi-tip launch: every slot whose list changed and its reverse are recorded in the block's dirty set)
+// The first round after the split, loaded AHEAD by the split (place_split_wave): the slots behind x and y that round 2 can reach are known
+// as soon as the split's own loads are back, two list insertions before it is known whether the leaf gets that far.  Lane k < 4
+// holds candidate k (behind e0: oy0, oy1; behind e1: ox0, ox1) with everything a round reads about a slot; the round trip runs
+// beside the split's arithmetic and stores instead of after them (one dependent hop less per tip).
+struct BfsPre {
+    int sl;               // candidate slot (-1: none)
+    bool active;          // the leaf entered the list in front of it: the slot is on the frontier, reached with distance d
+    double d;
+    double cd[K5], ln;
+    int ci[K5], k0, k1, ex, back;
+};
+__device__ __forceinline__ void bfs_pre_load(const PlaceBuffers& p, int sl, BfsPre& q)
+{
+    q.sl = sl; q.active = false; q.d = 0.0; q.ln = 0.0; q.k0 = -1; q.k1 = -1; q.ex = 0; q.back = -1;
+#pragma unroll
+    for (int j = 0; j < K5; ++j) { q.cd[j] = 0.0; q.ci[j] = 0; }
+    if (sl >= 0) {
+#pragma unroll
+        for (int j = 0; j < K5; ++j) { q.cd[j] = p.cdis[sl * K5 + j]; q.ci[j] = p.cid[sl * K5 + j]; }
+        q.ln = p.len[sl];
+        q.k0 = p.cont[2 * sl]; q.k1 = p.cont[2 * sl + 1];
+        q.ex = p.eidx[sl];
+        q.back = p.rev[sl];
+    }
+}
+
 template <bool kRec>
-__device__ __forceinline__ void closest_update_wave_impl(const PlaceBuffers& p, int x, int ns, const DirtySet& ds, int32_t* sq_id, double* sq_dis)
+__device__ __forceinline__ void closest_update_wave_impl(const PlaceBuffers& p, int x, int ns, const DirtySet& ds, int32_t* sq_id, double* sq_dis,
+                                                         const BfsPre* pre = nullptr)
 {
     const int lane = threadIdx.x & 63;
     int l = 0, r = ns;  // queue [l, r): the first ns entries are in sq_id / sq_dis (stored by a lane of this wavefront)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    while (l < r) {
-        const int cnt = min(64, r - l);
+    bool first = pre != nullptr;            // (wave-uniform) the round whose slots and records the split has loaded
+    while (first || l < r) {
+        const int cnt = first ? 0 : min(64, r - l);
         int sl = -1;
         double d = 0.0;
-        if (lane < cnt) {
+        if (first) {
+            if (pre->active) { sl = pre->sl; d = pre->d; }
+        } else if (lane < cnt) {
             const int qi = l + lane;
             if (qi < kQueueLds) { sl = sq_id[qi]; d = sq_dis[qi]; }
             else { sl = p.q_id[qi]; d = p.q_dis[qi]; }
@@ -173,15 +203,20 @@ __device__ __forceinline__ void closest_update_wave_impl(const PlaceBuffers& p, 
         double dn = 0.0;
         bool walk = false;
         if (sl >= 0) {
-            double cd[K5];
-            int ci[K5];
+            double cd[K5], ln;
+            int ci[K5], k0, k1, ex, back = -1;
+            if (first) {
 #pragma unroll
-            for (int j = 0; j < K5; ++j) { cd[j] = p.cdis[sl * K5 + j]; ci[j] = p.cid[sl * K5 + j]; }
-            const double ln = p.len[sl];
-            const int k0 = p.cont[2 * sl], k1 = p.cont[2 * sl + 1];
-            const int ex = p.eidx[sl];
-            int back = -1;
-            if (kRec) back = p.rev[sl];
+                for (int j = 0; j < K5; ++j) { cd[j] = pre->cd[j]; ci[j] = pre->ci[j]; }
+                ln = pre->ln; k0 = pre->k0; k1 = pre->k1; ex = pre->ex; back = pre->back;
+            } else {
+#pragma unroll
+                for (int j = 0; j < K5; ++j) { cd[j] = p.cdis[sl * K5 + j]; ci[j] = p.cid[sl * K5 + j]; }
+                ln = p.len[sl];
+                k0 = p.cont[2 * sl]; k1 = p.cont[2 * sl + 1];
+                ex = p.eidx[sl];
+                if (kRec) back = p.rev[sl];
+            }
             int j = K5;
 #pragma unroll
             for (int t = K5 - 1; t >= 0; --t)
@@ -246,6 +281,7 @@ __device__ __forceinline__ void closest_update_wave_impl(const PlaceBuffers& p, 
         }
         l += cnt;
         r += total;
+        first = false;
         if (spill) {                                            // entries went to the global queue
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -300,7 +336,7 @@ __device__ __forceinline__ void lane_er_write_side(const PlaceBuffers& p, int ex
 // global round trips less per tip): round 0 reaches e2 with distance 0, round 1 -- through cont[e2] = (e0, e1) with distance
 // len[e2] = addLen -- e0 and e1; a slot the leaf enters passes it on to its continuation slots (oy0, oy1 behind e0; ox0, ox1
 // behind e1) with distance + length: same insertion rule and the same additions in the same order as closest_update_wave.
-// Returns the number of frontier entries for round 2 (stored into the LDS queue sq_id / sq_dis by lane 0 of wavefront 0; <= 4), or -1 when a node of degree > 3 lies behind x or y
+// Returns the number of frontier slots of round 2 (<= 4; lanes 0..3 of wavefront 0 hold them in `pre`, records included), or -1 when a node of degree > 3 lies behind x or y
 // (imported backbone: the BFS then starts at e2 and walks).  Everything returned is wave-uniform.
 // TWO wavefronts share the work (role = wavefront index 0 / 1, both called with the same arguments): wavefront 0 takes what the
 // closest-list BFS it runs next depends on -- the inherited lists of e0 / e1, rounds 0-1 of the BFS, their stores and record
@@ -314,7 +350,7 @@ __device__ __forceinline__ void lane_er_write_side(const PlaceBuffers& p, int ex
 // which both read as i0..i2: the caller loads those BEFORE the block barrier that publishes the winner.
 __device__ __forceinline__ int place_split_wave(const PlaceBuffers& p, int64_t num, int ec0, int eid, int brev, double fracLen, double addLen,
                                                 double i0d, int i0i, double i1d, int i1i, double i2d, int i2i, double i3d, int i3i,
-                                                int mininel, int role, int32_t* sq_id, double* sq_dis, int* sync, int& xe_out, int& ye_out)
+                                                int mininel, int role, BfsPre& pre, int* sync, int& xe_out, int& ye_out)
 {
     const int lane = threadIdx.x & 63;
     const int li = lane < K5 ? lane : 0;
@@ -342,6 +378,8 @@ __device__ __forceinline__ int place_split_wave(const PlaceBuffers& p, int64_t n
     } else if (book) {
         while (__hip_atomic_load(sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)num) __builtin_amdgcn_s_sleep(1);
     }
+    // round 2 of the BFS ahead of time (wavefront 0, lanes 0..3): in flight during everything below
+    bfs_pre_load(p, (lists && !fallback && lane < 4) ? (lane == 0 ? oy0 : lane == 1 ? oy1 : lane == 2 ? ox0 : ox1) : -1, pre);
     // middle -> x inherits the list of y -> x, middle -> y the list of x -> y (entry by entry; an empty entry keeps what the slot held)
     const bool has0 = ciy != -1, has1 = cix != -1;
     double n0d = has0 ? cdy + originalDis - fracLen : i0d, n1d = has1 ? cdx + fracLen : i1d;
@@ -424,20 +462,18 @@ __device__ __forceinline__ int place_split_wave(const PlaceBuffers& p, int64_t n
     int ns = -1;
     if (lists) {
         if (!fallback) {
-            ns = 0;
+            bool in0 = false, in1 = false;
+            double dn0 = 0.0, dn1 = 0.0;
             if (lane_list_insert(i2d, i2i, 0.0, placeId, lane)) {
                 const double d1 = 0.0 + addLen;             // (d + len[e2], as the BFS computes it)
-                if (lane_list_insert(n0d, n0i, d1, placeId, lane)) {
-                    const double dn = d1 + fracLen;         // len[e0]
-                    if (oy0 >= 0) { if (lane == 0) { sq_id[ns] = oy0; sq_dis[ns] = dn; } ++ns; }
-                    if (oy1 >= 0) { if (lane == 0) { sq_id[ns] = oy1; sq_dis[ns] = dn; } ++ns; }
-                }
-                if (lane_list_insert(n1d, n1i, d1, placeId, lane)) {
-                    const double dn = d1 + len1;            // len[e1]
-                    if (ox0 >= 0) { if (lane == 0) { sq_id[ns] = ox0; sq_dis[ns] = dn; } ++ns; }
-                    if (ox1 >= 0) { if (lane == 0) { sq_id[ns] = ox1; sq_dis[ns] = dn; } ++ns; }
-                }
+                in0 = lane_list_insert(n0d, n0i, d1, placeId, lane);
+                dn0 = d1 + fracLen;                         // len[e0]
+                in1 = lane_list_insert(n1d, n1i, d1, placeId, lane);
+                dn1 = d1 + len1;                            // len[e1]
             }
+            pre.active = pre.sl >= 0 && (lane < 2 ? in0 : in1);
+            pre.d = lane < 2 ? dn0 : dn1;
+            ns = __popcll(__builtin_amdgcn_ballot_w64(pre.active));
             lane_list_store(p, e2, i2d, i2i, lane);
         }
         lane_list_store(p, e0, n0d, n0i, lane);
@@ -681,8 +717,9 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
     __shared__ int32_t sq_id[kQueueLds];      // the BFS frontier (wavefront 0's)
     __shared__ double sq_dis[kQueueLds];
     int xe_, ye_;
+    BfsPre pre;
     int bfs_ns = place_split_wave(p, num, ec, eid, brev, fracLen, addLen, i0d, i0i, i1d, i1i, i2d, i2i, i3d, i3i,
-                                  __builtin_amdgcn_readfirstlane(mininel), role, sq_id, sq_dis, &s_sync, xe_, ye_);
+                                  __builtin_amdgcn_readfirstlane(mininel), role, pre, &s_sync, xe_, ye_);
     if (role != 0) return;
     // the wave reads what its lanes just stored: program order within the wavefront
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -690,9 +727,10 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
     const unsigned long long tk2 = wall_clock64();
     if (bfs_ns < 0) {                       // (degree > 3 behind x or y) from the new leaf's only slot: outside -> middle
         if (lane == 0) { sq_id[0] = (int)edge_count + 2; sq_dis[0] = 0.0; }
-        bfs_ns = 1;
+        closest_update_wave_impl<false>(p, placeId, 1, DirtySet{ nullptr, nullptr, nullptr }, sq_id, sq_dis);
+    } else if (bfs_ns > 0) {
+        closest_update_wave_impl<false>(p, placeId, 0, DirtySet{ nullptr, nullptr, nullptr }, sq_id, sq_dis, &pre);
     }
-    if (bfs_ns > 0) closest_update_wave_impl<false>(p, placeId, bfs_ns, DirtySet{ nullptr, nullptr, nullptr }, sq_id, sq_dis);
     if ((p.dbg & 4) && trace && lane == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         const unsigned long long tk3 = wall_clock64();
@@ -1064,14 +1102,19 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
                 s_nrescan = 0;
             }
             int xe, ye;
-            int bfs_ns = place_split_wave(p, num, ec0, eid, brev, fracLen, addLen, i0d, i0i, i1d, i1i, i2d, i2i, i3d, i3i, p.misc[0], role, sq_id, sq_dis, &s_sync, xe, ye);
+            BfsPre pre;
+            const int bfs_ns = place_split_wave(p, num, ec0, eid, brev, fracLen, addLen, i0d, i0i, i1d, i1i, i2d, i2i, i3d, i3i, p.misc[0], role, pre, &s_sync, xe, ye);
             if (role == 0) {
-                if (bfs_ns < 0) { bfs_ns = 1; if (tid == 0) { sq_id[0] = ec0 + 2; sq_dis[0] = 0.0; } }     // (degree > 3 behind x or y: the BFS starts at e2 with distance 0)
                 // what the split changed for later evaluations: the edge's two slots and the four new ones (a lane each)
                 if (lane < 6) dirty_add(ds, lane == 0 ? xe : lane == 1 ? ye : ec0 + lane - 2);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (bfs_ns > 0) closest_update_wave_impl<true>(p, placeId, bfs_ns, ds, sq_id, sq_dis);   // (from the new leaf's only slot, outside -> middle, or from where the rounds done in registers got)
+                if (bfs_ns < 0) {            // (degree > 3 behind x or y) from the new leaf's only slot, outside -> middle, with distance 0
+                    if (tid == 0) { sq_id[0] = ec0 + 2; sq_dis[0] = 0.0; }
+                    closest_update_wave_impl<true>(p, placeId, 1, ds, sq_id, sq_dis);
+                } else if (bfs_ns > 0) {     // from where the rounds done in registers got, records loaded ahead
+                    closest_update_wave_impl<true>(p, placeId, 0, ds, sq_id, sq_dis, &pre);
+                }
             }
         }
         // the other wavefronts evaluate the next tip against what wavefronts 0 and 1 have just stored
