@@ -151,6 +151,11 @@ int dpr_create(dpr_ctx** out, int device)
 int dpr_destroy(dpr_ctx* c)
 {
     if (!c) return DPR_OK;
+    const bool tlog = log_level("cli") > 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (tlog) std::fprintf(stderr, "  dpr_destroy: %s at %.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    };
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
@@ -158,7 +163,9 @@ int dpr_destroy(dpr_ctx* c)
     for (hipEvent_t e : c->place_ev_busy) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->place_ev_tree) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->nj_kt.ev) (void)hipEventDestroy(e);
+    lap("events destroyed");
     for (auto& b : c->nj) nj_free(b);
+    lap("NJ buffers freed");
     msa_free(c->msa);
     mash_free(c->mash);
     place_free(c->place);
@@ -167,7 +174,9 @@ int dpr_destroy(dpr_ctx* c)
     if (c->packed_lower) (void)hipFree(c->packed_lower);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    lap("other buffers freed");
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    lap("streams destroyed");
     delete c;
     return DPR_OK;
 }
