@@ -1,5 +1,6 @@
 """ctypes loader for the CPU oracle (oracle/liboracle.so).  Test infrastructure only."""
 import ctypes as C
+import os as _os
 import os
 import subprocess
 
@@ -112,10 +113,13 @@ class Oracle:
                                     C.byref(i), C.byref(j), C.byref(q))
         return rc, i.value, j.value, q.value
 
-    def nj_run(self, D_lower, threads=1, max_iters=-1):
-        """D_lower: (N, ld) float64, strict lower triangle valid.  Works on a copy."""
+    def nj_run(self, D_lower, threads=None, max_iters=-1):
+        """D_lower: (N, ld) float64, strict lower triangle valid.  Works on a copy.  threads=None: the host's cores (at most 16) from 600
+        tips on -- the result does not depend on the thread count (per-thread minima are combined with the reference's key)."""
         D = np.array(D_lower, dtype=np.float64, order="C", copy=True)
         N, ld = D.shape
+        if threads is None:
+            threads = max(1, min(16, _os.cpu_count() or 1)) if N >= 600 else 1
         k = max(N - 2, 0)
         mx = np.zeros(k, dtype=np.int32)
         my = np.zeros(k, dtype=np.int32)
