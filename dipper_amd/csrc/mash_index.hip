@@ -395,23 +395,16 @@ __global__ __launch_bounds__(64) void mash_dist_index_kernel(MashIndex ix, const
             const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)start, l), ln = (uint32_t)__builtin_amdgcn_readlane((int)len, l);
             w[0] = (uint32_t)lane < ln ? ix.post[st + lane] : kINone;
         };
-        uint32_t pre[kPQ];
-#pragma unroll
-        for (int q = 0; q < kPQ; ++q) pre[q] = kINone;
-        if (todo) first_load((int)__builtin_ctzll(todo), pre);
-        while (todo) {
-            const int l = (int)__builtin_ctzll(todo);
-            todo &= todo - 1;
+        // Two values per step: their loads (issued a step ahead) are in flight together, and when both are dense the counters make
+        // ONE round trip through LDS for the two updates (value A, then value B on A's result: the row's values in ascending order).
+        typedef short pk16 __attribute__((ext_vector_type(2)));
+        uint32_t* c32 = reinterpret_cast<uint32_t*>(cnt);
+        auto one_value = [&](int l, const uint32_t* cur) {
             const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)start, l);
             const uint32_t ln = (uint32_t)__builtin_amdgcn_readlane((int)len, l);
             const int m = __builtin_amdgcn_readlane(mu, l);
             const int dn = __builtin_amdgcn_readlane(dense, l);
             const int nb = b0 + l;                  // position of the value's first copy in the row sketch
-            uint32_t cur[kPQ];
-#pragma unroll
-            for (int q = 0; q < kPQ; ++q) cur[q] = pre[q];
-            const uint32_t ent0 = cur[0];
-            if (todo) first_load((int)__builtin_ctzll(todo), pre);
             // reference's condition first_A(v) + nb - c < S  <=>  c - first_A(v) > nb - S
             const int K = nb - S;
             if (dn >= 0) {
@@ -419,25 +412,23 @@ __global__ __launch_bounds__(64) void mash_dist_index_kernel(MashIndex ix, const
                 // (round 5: this path is ~all of the work on clonal data; halves its LDS and vector instructions).  Counters and
                 // positions stay below 4 096, K = nb - S lies in [-S, -1], an absent tip carries position 0x7F7F: every
                 // difference fits 16 signed bits, and  K - (c - pos) < 0  <=>  c - pos > K  (absent: never).
-                typedef short pk16 __attribute__((ext_vector_type(2)));
-                uint32_t* c32 = reinterpret_cast<uint32_t*>(cnt);
                 const pk16 Kp = { (short)K, (short)K }, mp = { (short)m, (short)m };
 #pragma unroll
-                for (int q = 0; q < kIC / 128; ++q) {
+                for (int q = 0; q < kPQ; ++q) {
                     const uint32_t cw = c32[64 * q + lane];
                     const pk16 cv = __builtin_bit_cast(pk16, cw), pv = __builtin_bit_cast(pk16, cur[q]);
                     const pk16 t = Kp - (cv - pv);
                     const pk16 inc = (t >> 15) & mp;                     // all ones where the reference's condition holds
                     c32[64 * q + lane] = __builtin_bit_cast(uint32_t, (pk16)(cv + inc));
                 }
-                continue;
+                return;
             }
             auto apply = [&](uint32_t ent) {
                 uint16_t* pc = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(cnt) + (ent >> 16));
                 const int c0 = (int)*pc;
                 if (c0 - (int)(ent & 0xFFFFu) > K) *pc = (uint16_t)(c0 + m);      // (tips of one posting list are distinct)
             };
-            apply(ent0);
+            apply(cur[0]);
             const uint32_t* __restrict__ pl = ix.post + st;
             uint32_t e0 = 64;
             for (; e0 + 192 <= ln; e0 += 192) {                 // whole groups, three in flight: no bounds to check
@@ -454,6 +445,50 @@ __global__ __launch_bounds__(64) void mash_dist_index_kernel(MashIndex ix, const
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
                     if (e0 + 64u * (uint32_t)q < ln) apply(ent[q]);
+            }
+        };
+        auto peek2 = [](unsigned long long t, int& a, int& b2) {
+            a = t ? (int)__builtin_ctzll(t) : -1;
+            const unsigned long long t2 = t & (t - 1);
+            b2 = t2 ? (int)__builtin_ctzll(t2) : -1;
+        };
+        uint32_t preA[kPQ], preB[kPQ];
+#pragma unroll
+        for (int q = 0; q < kPQ; ++q) { preA[q] = kINone; preB[q] = kINone; }
+        int la, lb;
+        peek2(todo, la, lb);
+        if (la >= 0) first_load(la, preA);
+        if (lb >= 0) first_load(lb, preB);
+        while (la >= 0) {
+            const int ca = la, cb = lb;
+            todo &= todo - 1;
+            if (cb >= 0) todo &= todo - 1;
+            uint32_t curA[kPQ], curB[kPQ];
+#pragma unroll
+            for (int q = 0; q < kPQ; ++q) { curA[q] = preA[q]; curB[q] = preB[q]; }
+            peek2(todo, la, lb);
+            if (la >= 0) first_load(la, preA);
+            if (lb >= 0) first_load(lb, preB);
+            const int dnA = __builtin_amdgcn_readlane(dense, ca);
+            const int dnB = cb >= 0 ? __builtin_amdgcn_readlane(dense, cb) : -1;
+            if (dnA >= 0 && dnB >= 0) {
+                const int KA = b0 + ca - S, KB = b0 + cb - S;
+                const int mA = __builtin_amdgcn_readlane(mu, ca), mB = __builtin_amdgcn_readlane(mu, cb);
+                const pk16 KpA = { (short)KA, (short)KA }, mpA = { (short)mA, (short)mA };
+                const pk16 KpB = { (short)KB, (short)KB }, mpB = { (short)mB, (short)mB };
+#pragma unroll
+                for (int q = 0; q < kPQ; ++q) {
+                    const uint32_t cw = c32[64 * q + lane];
+                    const pk16 cv = __builtin_bit_cast(pk16, cw);
+                    const pk16 tA = KpA - (cv - __builtin_bit_cast(pk16, curA[q]));
+                    const pk16 c1 = cv + ((tA >> 15) & mpA);
+                    const pk16 tB = KpB - (c1 - __builtin_bit_cast(pk16, curB[q]));
+                    const pk16 c2 = c1 + ((tB >> 15) & mpB);
+                    c32[64 * q + lane] = __builtin_bit_cast(uint32_t, c2);
+                }
+            } else {
+                one_value(ca, curA);
+                if (cb >= 0) one_value(cb, curB);
             }
         }
     }
