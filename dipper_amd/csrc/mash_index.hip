@@ -641,10 +641,11 @@ int mash_dist_index(const MashBuffers& m, int64_t r0, int64_t nr, int64_t ncols,
     int64_t blocks = cchunks * nr;                  // one task per wavefront (a bounded grid walking the tasks: 25 % slower, uneven tasks)
     if (blocks > (int64_t)0x3FFFFFFF) blocks = 0x3FFFFFFF;
     // When tree kernels of a placement batch run beside this launch on another stream (share_chip), the grid is bounded instead:
-    // 16 wavefronts per CU walk the tasks.  A grid of 100 000 small workgroups keeps the dispatcher busy and every wave slot
+    // 12 wavefronts per CU walk the tasks.  A grid of 100 000 small workgroups keeps the dispatcher busy and every wave slot
     // taken, and the tree kernels -- 2 launches per tip, up to 1 500 workgroups each -- then make NO progress beside it
     // (100 000 tips: distance 1.2 s + tree 2.0 s = 3.2 s, nothing hidden).
-    constexpr int share_waves = 20;
+    constexpr int share_waves = 12;      // (round 5, every batch beside + tree kernels at wave priority 3: 100 000 tips, mean branch 2e-5 / 1e-3:
+                                         //  8: 1.78 / 2.10 s, 12: 1.73 / 2.14, 16: 1.75 / 2.21, 20: 1.76 / 2.28, 24: 2.07 / 2.63)
     if (m.share_chip && share_waves > 0 && blocks > 256ll * share_waves) blocks = 256ll * share_waves;
     const size_t pad = 0;
     hipLaunchKernelGGL(mash_dist_index_kernel, dim3((unsigned)blocks), dim3(64), pad, s, ix, m.sketches, m.S, m.n, r0, nr, ncols, cchunks,
