@@ -738,7 +738,8 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
     }
 }
 
-constexpr int kTipThreads = 256;
+constexpr int kTipThreads = 128;      // edges per block of the one-tip scan (100 000 tips: 128: 1 413 ms of tree kernels, 256: 1 449, 512: 1 584)
+constexpr int kTipThreadsM = 256;     // ... of the four-tip scan (--add 50 000 onto 500 000: 128: 1 611 ms, 256: 1 554, 512: 1 716)
 // The per-tip scan over the EDGE RECORDS (round 5): one thread per undirected edge instead of one per directed slot -- the slot
 // scan of rounds 1-4 loaded every list twice (as the slot's own and as its reverse's) and kept half of its threads for slots
 // with belong < e, whose tuple is the constant (0, 0, 2): 10.8 -> 6.7 us per launch at 100 000 tips.  Here a thread reads the 2 x 5 list entries, the length and the two slot ids
@@ -891,14 +892,14 @@ __device__ __forceinline__ void place_eval_slot(const PlaceBuffers& p, const dou
 
 // scan of the EDGES [0, 2 num0 - 2) (edge records, as place_tip_edges_kernel) for the tips num0 .. num0 + nb - 1 (rows dis0 + j ldb):
 // partials[j * nblk + block]; block b covers the edges [256 b, 256 b + 256)
-__global__ __launch_bounds__(kTipThreads) void place_tip_multi_kernel(PlaceBuffers p, const double* __restrict__ dis0, int64_t ldb,
+__global__ __launch_bounds__(kTipThreadsM) void place_tip_multi_kernel(PlaceBuffers p, const double* __restrict__ dis0, int64_t ldb,
                                                                    int64_t num0, int nb, PlacePartial* __restrict__ partials, int nblk)
 {
     __builtin_amdgcn_s_setprio(3);      // chains of dependent steps: these waves go first where a distance kernel shares the SIMD
-    __shared__ double sadd[kMultiB][kTipThreads / 64];
-    __shared__ int sidx[kMultiB][kTipThreads / 64];
+    __shared__ double sadd[kMultiB][kTipThreadsM / 64];
+    __shared__ int sidx[kMultiB][kTipThreadsM / 64];
     const int64_t nedge = 2 * num0 - 2;
-    const int64_t k = (int64_t)blockIdx.x * kTipThreads + threadIdx.x;
+    const int64_t k = (int64_t)blockIdx.x * kTipThreadsM + threadIdx.x;
     const bool have = k < nedge;
     double add[kMultiB], d1[kMultiB];
     int sl0 = 0x7fffffff, sl1 = -1;
@@ -959,7 +960,7 @@ __global__ __launch_bounds__(kTipThreads) void place_tip_multi_kernel(PlaceBuffe
         double ba = sadd[j][0];
         int bi = sidx[j][0];
 #pragma unroll
-        for (int i = 1; i < kTipThreads / 64; ++i)
+        for (int i = 1; i < kTipThreadsM / 64; ++i)
             if (sadd[j][i] < ba || (sadd[j][i] == ba && sidx[j][i] < bi)) { ba = sadd[j][i]; bi = sidx[j][i]; }
         if (have && sl0 == bi) {
             PlacePartial pp; pp.add = add[j]; pp.idx = sl0; pp.eid = sl0; pp.frac = d1[j]; pp.rev = sl1; pp.pad = 0;
@@ -1069,8 +1070,8 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
             // (C) blocks whose speculative winner is dirty: the evaluated slots of all their edges again (an edge created or
             // taken over since the scan launch -- its slots are dirty -- is evaluated here or in (B): same value, same key)
             for (int k = 0; k < nres; ++k) {
-                const int64_t ek = (int64_t)s_rescan[k] * kTipThreads + tid;
-                if (tid < kTipThreads && ek < nedge0) {
+                const int64_t ek = (int64_t)s_rescan[k] * kTipThreadsM + tid;
+                if (tid < kTipThreadsM && ek < nedge0) {
                     const int sl = p.er_i[(int64_t)10 * p.ecap + ek];
                     double a, f; int e2, rv;
                     place_eval_slot(p, dis, sl, a, f, e2, rv);
@@ -1292,7 +1293,7 @@ int place_tips(PlaceBuffers& p, const double* d_dis0, int64_t ldb, int64_t tip0,
     int64_t k = 0;
     while (k < count) {
         const int64_t tip = tip0 + k;
-        const int nblk = (int)((2 * tip - 2 + kTipThreads - 1) / kTipThreads);      // blocks of the edge scan
+        const int nblk = (int)((2 * tip - 2 + kTipThreadsM - 1) / kTipThreadsM);      // blocks of the four-tip edge scan
         const int nb = (int)(count - k < kMultiB ? count - k : kMultiB);
         if (tip < min_tip || nb < 2 || (int64_t)nblk * kMultiB > p.nparts_multi) {
             if (int rc = place_tip(p, d_dis0 + k * ldb, tip, d_trace, s)) return rc;
@@ -1300,7 +1301,7 @@ int place_tips(PlaceBuffers& p, const double* d_dis0, int64_t ldb, int64_t tip0,
             continue;
         }
         PlacePartial* parts = reinterpret_cast<PlacePartial*>(p.partials_multi);
-        hipLaunchKernelGGL(place_tip_multi_kernel, dim3((unsigned)nblk), dim3(kTipThreads), 0, s, p, d_dis0 + k * ldb, ldb, tip, nb, parts, nblk);
+        hipLaunchKernelGGL(place_tip_multi_kernel, dim3((unsigned)nblk), dim3(kTipThreadsM), 0, s, p, d_dis0 + k * ldb, ldb, tip, nb, parts, nblk);
         hipLaunchKernelGGL(place_update_multi_kernel, dim3(1), dim3((nblk > 2048 || big_block) ? kMultiMaxThreads : kUpdThreads), 0, s, p, (const PlacePartial*)parts, nblk, tip, nb,
                            d_dis0 + k * ldb, ldb, d_trace);
         DPR_HIP(hipGetLastError());
