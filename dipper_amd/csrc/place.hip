@@ -630,8 +630,9 @@ __global__ __launch_bounds__(64) void place_backbone_lists_kernel(PlaceBuffers p
 }
 
 // Per tip two kernels: place_tip_edges_kernel (calculateBranchLength for the live edges and the
-// block-level first minimum) and the single-wavefront place_update_kernel, which finishes the argmin,
-// splits the edge (updateTreeStructure) and runs the closest-list update (updateClosestNodes) -- the
+// block-level first minimum) and the one-workgroup place_update_kernel, which finishes the argmin (four
+// wavefronts), splits the edge (updateTreeStructure; two wavefronts, place_split_wave) and runs the
+// closest-list update (updateClosestNodes; one wavefront, its first round loaded ahead by the split) -- the
 // reference's Thrust reduction, device->host copy and two single-thread kernels.  (Fusing the two with a
 // last-block-done ticket was measured 1.5-2x SLOWER: every block then needs a device-scope release
 // fence, i.e. an L2 write-back, which costs more than the kernel boundary it saves.)
