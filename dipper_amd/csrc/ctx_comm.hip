@@ -408,14 +408,21 @@ int dpr_get_nj_exchange_info(dpr_ctx* c, int* active_plan, int64_t* launches, in
 int dpr_ctx_set_debug_fault(dpr_ctx* c, int64_t iteration, int rank)
 {
     if (!c) { set_error("dpr_ctx_set_debug_fault: null ctx"); return DPR_ERR_ARG; }
-    for (auto& b : c->nj) { b.peer.fault_it = iteration; b.peer.fault_rank = rank; }
+    for (auto& b : c->nj) {
+        b.peer.fault_it = iteration; b.peer.fault_rank = rank;
+        // (a captured graph of the row-sharded pruned loop holds its arguments by value: capture again with the new setting)
+        if (c->nj_row_pruned && b.pr.graph) { (void)hipGraphExecDestroy(b.pr.graph); b.pr.graph = nullptr; }
+    }
     return DPR_OK;
 }
 
 int dpr_ctx_set_poll_limit_ms(dpr_ctx* c, int ms)
 {
     if (!c || ms < 1) { set_error("dpr_ctx_set_poll_limit_ms: ms >= 1"); return DPR_ERR_ARG; }
-    for (auto& b : c->nj) b.peer.poll_ticks = (unsigned long long)ms * 100000ull;
+    for (auto& b : c->nj) {
+        b.peer.poll_ticks = (unsigned long long)ms * 100000ull;
+        if (c->nj_row_pruned && b.pr.graph) { (void)hipGraphExecDestroy(b.pr.graph); b.pr.graph = nullptr; }
+    }
     return DPR_OK;
 }
 

@@ -388,11 +388,9 @@ int64_t dpr_nj_run(dpr_ctx* c, int64_t max_iters, int32_t* merge_x, int32_t* mer
         NjBuffers& b0 = c->nj[0];
         if (c->nj_row_pruned) {
             // the row of slot 1 lives on its position's owner: read through the mapping of that rank's epoch buffer (every
-            // rank's finish kernel has run: the stream was synchronised by fetch_state; process ranks: the owner's flush is
-            // behind its own finish kernel, ordered by the barrier below)
+            // rank's finish kernel has run: njr_run ends with a barrier over the ranks behind the finish launches)
             int32_t pos01[2];
             DPR_HIP(hipMemcpy(pos01, b0.pr.pos_of_slot, sizeof(pos01), hipMemcpyDeviceToHost));
-            if (c->vworld == 0 && b0.rs.barrier) { if (int rc = b0.rs.barrier(b0.rs.cb_ctx)) return rc; }
             const int half = (b0.pr.epoch_index + 1) & 1, o = njr_owner(pos01[1], c->world);
             DPR_HIP(hipMemcpy(last_d, b0.rs.peer_half[half][(size_t)o] + njr_local_row(pos01[1], c->world) * b0.pr.ld + pos01[0], sizeof(double), hipMemcpyDeviceToHost));
         } else if (b0.pr.in_positions()) {
@@ -447,7 +445,7 @@ int dpr_argmin_once(dpr_ctx* c, int reps, int32_t* out_i, int32_t* out_j, double
     DPR_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
     if (out_ms) *out_ms = ms / (float)reps;
     const int w = dpr_record_reduce(recs.data(), ew);
-    if (w < 0) { set_error("dpr_argmin_once: no Q candidate below 10000"); return DPR_ERR_NOCAND; }
+    if (w < 0 || !(recs[(size_t)w].q < 10000.0)) { set_error("dpr_argmin_once: no Q candidate below 10000"); return DPR_ERR_NOCAND; }
     const NjRecord& rec = recs[(size_t)w];
     if (out_i) *out_i = (int32_t)(rec.key & 0xFFFFFFull);
     if (out_j) *out_j = (int32_t)((rec.key >> 24) & 0xFFFFFFull);

@@ -281,6 +281,19 @@ int dpr_place_run(dpr_ctx* c, int source, int dist_type, int k, int64_t first, i
     } else if (source == DPR_SRC_MATRIX) {
         if (!c->packed_lower || c->n_input != n) { set_error("dpr_place_run: call dpr_set_matrix_lower first"); return DPR_ERR_STATE; }
     } else { set_error("dpr_place_run: unknown source"); return DPR_ERR_ARG; }
+    if (first > 2) {
+        // An imported backbone must be a rooted binary tree: `first` tips, first - 1 internal nodes, 2 first - 2 edges = the slots
+        // [0, 4 first - 4) all in use.  The reference's scan reads head[e[slot]] of every slot below 4 num - 4
+        // (src/placement_close_k.cu:325-338): an unused slot (e = belong = -1: a trifurcating root, a polytomy) is an
+        // out-of-bounds read there; here it is an error, since the edge records (one per undirected edge, dense: 2 num - 2 after
+        // num tips) have no place for a missing edge either (advisor, round 5).
+        for (int64_t s = 0; s < 4 * first - 4; ++s)
+            if (e[s] < 0 || belong[s] < 0) {
+                set_error("dpr_place_run: the backbone is not a rooted binary tree (directed edge slot " + std::to_string(s) + " of " +
+                          std::to_string(4 * first - 4) + " is unused: a trifurcating root or a polytomy); resolve it first");
+                return DPR_ERR_ARG;
+            }
+    }
     if (int rc = place_alloc(c->place, n)) return rc;
     PlaceBuffers& p = c->place;
     if (c->place_trace) { (void)hipFree(c->place_trace); c->place_trace = nullptr; }

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kThreads) void nj_post_kernel(double* __restrict__ 
     reduce_records(partials, nparts, bq, bk, d, sq, sk, sdd);
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     const int64_t last = n - 1;
-    if (bk == ~0ull) {
+    if (bk == ~0ull || !(bq < 10000.0)) {     // (q == 10000.0 is no candidate: the reference's strict `<` against its init value, src/neighborJoining.cu:134-141)
         if (i == last) st->status = 1;
         return;
     }
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(kThreads) void nj_commit_extract_kernel(
         if ((q < bq) | ((q == bq) & (k < bk))) { bq = q; bk = k; d = recs[r].d; }
     }
     const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
-    if (bk == ~0ull) { if (writer) st->status = 1; return; }
+    if (bk == ~0ull || !(bq < 10000.0)) { if (writer) st->status = 1; return; }
     const int64_t ki = (int64_t)(bk & 0xFFFFFFull), kj = (int64_t)((bk >> 24) & 0xFFFFFFull);
     const int64_t x = ki < kj ? ki : kj, y = ki < kj ? kj : ki;
     if (writer) commit_merge(st, U, n, it, x, y, d, bq, log_x, log_y, log_bx, log_by);

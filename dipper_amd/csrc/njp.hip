@@ -637,7 +637,7 @@ __global__ __launch_bounds__(kThreads, (kNS > 1 ? DPR_NJP_BIG_WAVES : 1)) void n
 
     NJP_STAMP(1, 2, false);
     const int64_t last = n - 1;
-    if (bk == ~0ull) {
+    if (bk == ~0ull || !(bq < 10000.0)) {     // (q == 10000.0 is no candidate: src/neighborJoining.cu:134-141 compares with a strict `<`)
         if (!test_block && i == last) a.st->status = 1;
         return;
     }
@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(kThreads) void njp_post2_kernel(NjState* h_st, cons
 
     NJP_STAMP(1, 2, false);
     const int64_t last = n - 1;
-    if (bk == ~0ull) {
+    if (bk == ~0ull || !(bq < 10000.0)) {
         if (u_part && (i == last || i + kThreads == last)) a.st->status = 1;
         return;
     }

@@ -129,8 +129,13 @@ __device__ __forceinline__ unsigned long long* njr_win_rowflag(char* region, con
 // Two-level last-block ticket of a launch (njs.hip's: one 128-byte line per group of blocks, then the top word).  Every
 // thread of the block must call it, with the block's own stores to be published issued before; returns true in the block that
 // finished last.  The caller resets the words (stream order protects the next launch).
+// vmcnt counts per WAVEFRONT: every wavefront drains its own stores and the block meets at a barrier BEFORE thread 0 takes the
+// ticket -- otherwise the last block could raise the flag while another wavefront's remote stores (njr_extract_kernel's column
+// slices, written by all 256 threads) are still in flight (advisor, round 5).
 __device__ __forceinline__ bool njr_last_block(unsigned int* ticket, unsigned int* s_last)
 {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x == 0 && gridDim.x <= kNjsTicketGroups) {
         // few blocks: one word (a second level would only add a dependent atomic)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

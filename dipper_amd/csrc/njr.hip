@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kThreads) void njr_extract_kernel(NjpArgs a, int64_
         }
         return;
     }
-    if (bk == ~0ull) return;                 // no candidate: POST reports it (status 1) on every rank
+    if (bk == ~0ull || !(bq < 10000.0)) return;                 // no candidate (q == 10000.0 is none: the reference's strict `<`): POST reports it (status 1) on every rank
     const int64_t ki = (int64_t)(bk & 0xFFFFFFull), kj = (int64_t)((bk >> 24) & 0xFFFFFFull);
     const int64_t pi = (int64_t)(bp & 0xffffffffull), pj = (int64_t)(bp >> 32);
     const int64_t px = ki < kj ? pi : pj, py = ki < kj ? pj : pi;
@@ -519,10 +519,11 @@ static int njr_run_segment(std::vector<NjBuffers*>& ranks, int64_t it0, int64_t 
         int rc = DPR_OK;
         for (int k = 0; k < gi && rc == DPR_OK; ++k) rc = njr_iteration(ranks, s, false);
         hipError_t e = hipStreamEndCapture(s, &g);
-        if (rc != DPR_OK) return rc;
+        if (rc != DPR_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
-        DPR_HIP(hipGraphInstantiate(&b0.pr.graph, g, nullptr, nullptr, 0));
-        DPR_HIP(hipGraphDestroy(g));
+        e = hipGraphInstantiate(&b0.pr.graph, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) { b0.pr.graph = nullptr; return hip_fail(e, "hipGraphInstantiate"); }
         b0.rs.launches -= 3 * gi;      // (captured, not launched)
     }
     int64_t done = 0;
@@ -562,7 +563,10 @@ int njr_run(std::vector<NjBuffers*>& ranks, int64_t it0, int64_t todo, hipStream
         if (int rc = njr_run_segment(ranks, it, seg, s)) return rc;
         it += seg; left -= seg;
     }
-    return DPR_OK;
+    // every rank's finish kernel (it stores the last new node's row) is done before anybody reads another rank's rows -- the
+    // final pair's distance in dpr_nj_run, the test hooks -- whichever way the ranks were joined (advisor, round 5: process ranks
+    // without RCCL had no barrier here)
+    return njr_barrier(ranks, s);
 }
 
 }  // namespace dpr

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kThreads) void njs_post_kernel(NjsArgs a)
         const uint64_t k = s_k[r];
         if ((q < bq) | ((q == bq) & (k < bk))) { bq = q; bk = k; d = s_d[r]; }
     }
-    if (bk == ~0ull) {
+    if (bk == ~0ull || !(bq < 10000.0)) {     // (q == 10000.0 is no candidate: strict `<` of src/neighborJoining.cu:134-141)
         if (i == last) a.st->status = 1;
         return;
     }

@@ -820,6 +820,7 @@ __global__ __launch_bounds__(kThreads) void place_pack_edges_kernel(PlaceBuffers
     const int64_t s = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (s >= nslots) return;
     const int bel = p.belong[s], tgt = p.e[s];
+    if (tgt < 0) return;                      // (unused slot; dpr_place_run rejects backbones that leave any below 4m - 4)
     if (bel < tgt) { atomicMin(&p.misc[0], (int)s); return; }
     const int r = p.rev[s];
     const int k = atomicAdd(&p.misc[1], 1);

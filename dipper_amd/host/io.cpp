@@ -70,7 +70,15 @@ static std::string slurp_gz(const std::string& path)
     std::vector<char> buf(1 << 22);
     int got;
     while ((got = gzread(f, buf.data(), (unsigned)buf.size())) > 0) data.append(buf.data(), (size_t)got);
-    gzclose(f);
+    // A gzip stream that ends early (a cut download, a full disk) inflates to a prefix of the records: the reference's kseq
+    // reader silently builds a tree of that prefix.  Here it is an error -- a tree of 29 of 700 sequences is not what was asked.
+    int zerr = Z_OK;
+    (void)gzerror(f, &zerr);
+    const int cerr = gzclose(f);
+    if (got < 0 || (zerr != Z_OK && zerr != Z_STREAM_END) || cerr != Z_OK) {
+        std::fprintf(stderr, "ERROR: truncated or corrupt gzip input: %s\n", path.c_str());
+        std::exit(1);
+    }
     return data;
 }
 

@@ -177,6 +177,7 @@ int main(int argc, char** argv)
         if (!fast.ok) { std::printf("SERIAL-ONLY\n"); return 0; }
         std::vector<std::string> seqs, names_;
         readSequences(strOr(vm, "input-file", ""), seqs, names_);
+        if (seqs.empty()) { std::printf("0 records\n%s\n", fast.numSequences == 0 ? "IDENTICAL" : "DIFFERENT"); return fast.numSequences == 0 ? 0 : 2; }
         const std::vector<int> ids = shuffledIds(seqs.size(), sd);
         std::vector<std::string> names(seqs.size());
         for (size_t i = 0; i < seqs.size(); ++i) names[(size_t)ids[i]] = names_[i];

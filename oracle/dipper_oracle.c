@@ -301,7 +301,7 @@ ORC_API int orc_nj_argmin(const double *D, int64_t n, int64_t ld, const double *
     for (int64_t i = 0; i < n; ++i) Ur[i] = U[i] / r;
     orc_best b = orc_scan(D, n, ld, Ur, threads);
     free(Ur);
-    if (b.key == UINT64_MAX) return -1;
+    if (b.key == UINT64_MAX || !(b.q < 10000.0)) return -1; /* strict `temp<minD` against the init 10000 (src/neighborJoining.cu:134-141) */
     *out_i = (int32_t)(b.key & 0xFFFFFF);
     *out_j = (int32_t)((b.key >> 24) & 0xFFFFFF);
     *out_q = b.q;
@@ -343,7 +343,7 @@ ORC_API int64_t orc_nj_run(double *D, int64_t N, int64_t ld, int threads, int64_
         double r = (double)(n - 2);
         for (int64_t i = 0; i < n; ++i) Ur[i] = U[i] / r;
         orc_best b = orc_scan(D, n, ld, Ur, threads);
-        if (b.key == UINT64_MAX) { orc_nj_done_last = it; it = -1; break; }
+        if (b.key == UINT64_MAX || !(b.q < 10000.0)) { orc_nj_done_last = it; it = -1; break; } /* q == 10000.0: no thread of the reference records it (strict `<`) */
         int64_t x = (int64_t)(b.key & 0xFFFFFF), y = (int64_t)((b.key >> 24) & 0xFFFFFF);
         if (x > y) { int64_t t = x; x = y; y = t; }
         double d = D[x * ld + y];

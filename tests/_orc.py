@@ -248,7 +248,9 @@ def load():
     if _LIB is None:
         path = os.path.join(ORACLE_DIR, "liboracle.so")
         srcs = [os.path.join(ORACLE_DIR, f) for f in ("dipper_oracle.c", "rapidnj_baseline.c")]
-        if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in srcs):
+        if os.environ.get("DPR_ORACLE_LIB"):       # the sanitizer build (`make -C oracle asan`; tests/test_tools.py runs it in a child with libasan preloaded)
+            path = os.environ["DPR_ORACLE_LIB"]
+        elif not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in srcs):
             build()
         _LIB = Oracle(C.CDLL(path))
     return _LIB

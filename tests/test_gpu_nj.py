@@ -102,6 +102,25 @@ def test_nj_no_candidate(gpu, orc):
     assert ei.value.code == -4
 
 
+def test_nj_q_exactly_10000_is_no_candidate(gpu, orc):
+    """The smallest Q is exactly the reference's init value 10000.0: its strict `temp<minD` (src/neighborJoining.cu:134-141)
+    records nothing, so this is the no-candidate case on both plans, as in the oracle (tests/test_oracle.py has the literal
+    emulation); at q = 9999.5 it is an ordinary run."""
+    from dipper_amd import capi, DipperError
+    D = np.array([[0.0, -5000.0, -2500.0], [-5000.0, 0.0, -2500.0], [-2500.0, -2500.0, 0.0]])
+    gpu.set_matrix_full(D)
+    gpu.dist_matrix(capi.SRC_MATRIX)
+    with pytest.raises(DipperError) as ei:
+        gpu.argmin_once()
+    assert ei.value.code == -4
+    with pytest.raises(DipperError) as ei:
+        gpu.nj_run()
+    assert ei.value.code == -4
+    D2 = D.copy()
+    D2[0, 1] = D2[1, 0] = -4999.5
+    _check_nj(gpu, orc, D2)
+
+
 @pytest.mark.parametrize("n,L,inv", [(40, 100, 0.0), (130, 1000, 0.05), (300, 2500, 0.0), (257, 33, 0.2)])
 def test_msa_dist_and_nj(gpu, orc, n, L, inv):
     from dipper_amd import capi

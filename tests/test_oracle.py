@@ -108,6 +108,27 @@ def test_argmin_key_matches_literal_kernel_emulation(orc, n):
         assert rc == 0 and (i, j, qq) == (x, y, q)
 
 
+def test_q_exactly_10000_is_no_candidate(orc):
+    """The reference keeps a candidate only if `temp < minD` with minD initialised to 10000 (src/neighborJoining.cu:134-141):
+    when the smallest Q of the matrix is EXACTLY 10000.0 no thread records it, every tuple stays (0, 0, 10000) and
+    min_element returns the first of them -- the undefined (0, 0) merge.  n = 3 with d01 = -5000, d02 = d12 = -2500:
+    q = -(d01 + d02 + d12) = 10000 for every pair, all arithmetic exact.  The oracle must report "no candidate" like the
+    literal emulation (round 5's verdict: it accepted q == 10000.0); at 9999.5 it must find the pair."""
+    D = np.array([[0.0, -5000.0, -2500.0], [-5000.0, 0.0, -2500.0], [-2500.0, -2500.0, 0.0]])
+    U = orc.row_sums(np.ascontiguousarray(D))
+    assert _util.ref_findmin_emulation(D, U, 3) == (0, 0, 10000.0)
+    rc, _, _, _ = orc.nj_argmin(np.ascontiguousarray(D), 3, U)
+    assert rc != 0
+    res = orc.nj_run(np.tril(D, -1))
+    assert res["iters"] == -1 and res["done"] == 0
+    D2 = D.copy()
+    D2[0, 1] = D2[1, 0] = -4999.5      # every q = 9999.5, exactly: candidates again
+    U2 = orc.row_sums(np.ascontiguousarray(D2))
+    x, y, q = _util.ref_findmin_emulation(D2, U2, 3)
+    rc, i, j, qq = orc.nj_argmin(np.ascontiguousarray(D2), 3, U2)
+    assert q < 10000.0 and rc == 0 and (i, j, qq) == (x, y, q)
+
+
 def test_nj_threads_do_not_change_result(orc):
     rng = np.random.default_rng(3)
     D = _util.random_additive_matrix(rng, 200, zero_frac=0.4)

@@ -220,3 +220,22 @@ def test_gen_synth_gtr_g_i_model(tmp_path):
         assert abs(float((J == ord(c)).mean()) - 0.25) < 0.02
     r = subprocess.run([GEN, "--tips", "10", "--sites", "100", "--model", "hky", "--fasta", base + "x.fa"], capture_output=True, text=True)
     assert r.returncode != 0 and "--model" in r.stderr
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """the CPU oracle built with -fsanitize=address,undefined (`make -C oracle asan`) runs its own test file in a
+    child process with libasan preloaded: no report.  CPU only (GPU sanitizers are not available on this pool)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    odir = os.path.join(root, "oracle")
+    r = subprocess.run(["make", "-C", odir, "asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    assert os.path.exists(libasan), libasan
+    env = dict(os.environ, DPR_ORACLE_LIB=os.path.join(odir, "liboracle_asan.so"), LD_PRELOAD=libasan,
+               ASAN_OPTIONS="detect_leaks=0:exitcode=66", UBSAN_OPTIONS="halt_on_error=1:exitcode=66", OMP_NUM_THREADS="4")
+    q = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_oracle.py")],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    tail = (q.stdout + q.stderr)[-3000:]
+    assert q.returncode == 0 and "passed" in q.stdout and "Sanitizer" not in tail and "runtime error" not in tail, tail
