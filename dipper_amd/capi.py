@@ -66,6 +66,12 @@ def load_library():
     L.dpr_comm_selftest.argtypes = [C.c_void_p]
     L.dpr_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.dpr_comm_init_local.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.dpr_comm_init_shared.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_int]
+    L.dpr_comm_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+    L.dpr_shared_abort.argtypes = [C.c_void_p]
+    L.dpr_shared_failed.argtypes = [C.c_void_p]
+    L.dpr_shared_barrier.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_int]
+    L.dpr_shared_gather.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     L.dpr_peer_export.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
     L.dpr_peer_attach.argtypes = [C.c_void_p, C.c_void_p]
     L.dpr_ctx_set_nj_exchange.argtypes = [C.c_void_p, C.c_int]
@@ -77,6 +83,7 @@ def load_library():
     L.dpr_set_nj_mode.argtypes = [C.c_int]
     L.dpr_set_nj_multi_plan.argtypes = [C.c_int]
     L.dpr_nj_is_unit_sharded.argtypes = [C.c_void_p]
+    L.dpr_get_nj_multi_info.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.dpr_ctx_set_nj_mode.argtypes = [C.c_void_p, C.c_int]
     L.dpr_ctx_set_nj_multi_plan.argtypes = [C.c_void_p, C.c_int]
     L.dpr_ctx_set_nj_virtual_shards.argtypes = [C.c_void_p, C.c_int]
@@ -128,6 +135,48 @@ def load_library():
 
 
 DC_EXACT_LAST = 1
+COMM_SHARED_BYTES = 65536
+TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_IPC = 0, 1, 2
+
+
+class SharedRegion:
+    """DPR_COMM_SHARED_BYTES of shared memory for dpr_comm_init_shared, backed by a file under /dev/shm: the process that
+    passes create=True makes it (zero-filled) BEFORE the ranks start, the ranks map it by name.  Test / bench plumbing: the
+    `dipper` command forks its ranks around an anonymous shared mapping instead."""
+
+    def __init__(self, name, create=False):
+        import mmap
+        self.path = os.path.join("/dev/shm", name)
+        if create:
+            with open(self.path, "wb") as f:
+                f.write(b"\0" * COMM_SHARED_BYTES)
+        self._f = open(self.path, "r+b")
+        self._m = mmap.mmap(self._f.fileno(), COMM_SHARED_BYTES)
+        self._buf = (C.c_char * COMM_SHARED_BYTES).from_buffer(self._m)
+        self.address = C.addressof(self._buf)
+        self.size = COMM_SHARED_BYTES
+
+    def abort(self):
+        load_library().dpr_shared_abort(self.address)
+
+    def failed(self):
+        return bool(load_library().dpr_shared_failed(self.address))
+
+    def barrier(self, world, sense, timeout_ms=10000):
+        L = load_library()
+        _chk(L, L.dpr_shared_barrier(self.address, world, C.byref(sense), timeout_ms))
+
+    def gather(self, rank, world, sense, mine: bytes, timeout_ms=10000):
+        L = load_library()
+        out = (C.c_char * (len(mine) * world))()
+        _chk(L, L.dpr_shared_gather(self.address, rank, world, C.byref(sense), timeout_ms, mine, out, len(mine)))
+        return [bytes(out[r * len(mine):(r + 1) * len(mine)]) for r in range(world)]
+
+    def unlink(self):
+        try:
+            os.unlink(self.path)
+        except OSError:
+            pass
 
 
 def dc_virtual_ranks(w):
@@ -232,6 +281,18 @@ class Dipper:
 
     def comm_init_local(self, rank, world):
         _chk(self.L, self.L.dpr_comm_init_local(self.h, rank, world))
+
+    def comm_init_shared(self, rank, world, region, transport=0):
+        """join `world` ranks through a shared host region (SharedRegion below); transport 0 auto, 1 RCCL, 2 ipc windows"""
+        self._region = region          # (the mapping must outlive the context)
+        _chk(self.L, self.L.dpr_comm_init_shared(self.h, rank, world, region.address, region.size, transport))
+
+    def comm_stats(self):
+        """(transport: 'none' | 'rccl' | 'ipc' | 'local', device collectives so far)"""
+        t = C.c_int()
+        n = C.c_int64()
+        _chk(self.L, self.L.dpr_comm_stats(self.h, C.byref(t), C.byref(n)))
+        return ["none", "rccl", "ipc", "local"][t.value], int(n.value)
 
     def peer_export(self, n_tips):
         buf = (C.c_char * 192)()
@@ -437,6 +498,11 @@ class Dipper:
         v = [C.c_int() for _ in range(4)]
         _chk(self.L, self.L.dpr_get_njp_shape(self.h, C.byref(P), *[C.byref(x) for x in v]))
         return dict(positions=int(P.value), row_groups=v[0].value, strips=v[1].value, post2=bool(v[2].value), scan_grid=v[3].value)
+
+    def nj_multi_info(self):
+        buf = C.create_string_buffer(256)
+        _chk(self.L, self.L.dpr_get_nj_multi_info(self.h, buf, 256))
+        return buf.value.decode()
 
     def nj_is_unit_sharded(self):
         return bool(self.L.dpr_nj_is_unit_sharded(self.h))

@@ -159,6 +159,7 @@ int dpr_destroy(dpr_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    shm_comm_free(c);
     for (hipEvent_t e : c->place_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->place_ev_busy) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->place_ev_tree) (void)hipEventDestroy(e);

@@ -33,11 +33,7 @@ int rccl_load()
 int njp_gather_cb(void* ctx, void* buf, size_t bytes_per_rank, hipStream_t s)
 {
     dpr_ctx* c = static_cast<dpr_ctx*>(ctx);
-    if (g_rccl.AllGather(static_cast<char*>(buf) + (size_t)c->rank * bytes_per_rank, buf, bytes_per_rank, 1 /* ncclUint8 */, c->comm, s) != 0) {
-        set_error("ncclAllGather(block records) failed");
-        return DPR_ERR_COMM;
-    }
-    return DPR_OK;
+    return comm_all_gather(c, static_cast<char*>(buf) + (size_t)c->rank * bytes_per_rank, buf, bytes_per_rank, s);
 }
 // collective plan: kind 0 = every rank's header + unit records (in place in partials), kind 1 = its column slices (rows_plain)
 int njr_gather_cb(void* ctx, int kind, hipStream_t s)
@@ -57,10 +53,9 @@ int njr_gather_cb(void* ctx, int kind, hipStream_t s)
             }
         return DPR_OK;
     }
-    if (!c->comm) { set_error("njr: the collective plan needs an RCCL communicator"); return DPR_ERR_COMM; }
+    if (!comm_real(c)) { set_error("njr: the collective plan needs a transport between the ranks (RCCL, or the windows of dpr_comm_init_shared)"); return DPR_ERR_COMM; }
     char* buf = kind == 0 ? reinterpret_cast<char*>(b0.partials) : reinterpret_cast<char*>(b0.rs.rows_plain);
-    if (g_rccl.AllGather(buf + (size_t)c->rank * seg, buf, seg, 1 /* ncclUint8 */, c->comm, s) != 0) { set_error("ncclAllGather (row-sharded pruned NJ) failed"); return DPR_ERR_COMM; }
-    return DPR_OK;
+    return comm_all_gather(c, buf + (size_t)c->rank * seg, buf, seg, s);
 }
 
 // ---- exchange step of the sharded path: RCCL all-gather, or device copies between virtual ranks --
@@ -88,20 +83,11 @@ int exchange(dpr_ctx* c, ExKind kind)
         return DPR_OK;
     }
     NjBuffers& b = c->nj[0];
-    int rc;
-    if (!c->comm) { set_error("exchange: no RCCL communicator on this context"); return DPR_ERR_COMM; }
+    if (!comm_real(c)) { set_error("exchange: no transport between the ranks of this context (dpr_comm_init / dpr_comm_init_shared)"); return DPR_ERR_COMM; }
     ++c->nj_collectives;
-    if (kind == EX_RECS)
-        rc = g_rccl.AllGather(b.recs + c->rank, b.recs, sizeof(NjRecord), kNcclUint8, c->comm, c->stream);
-    else if (kind == EX_RECS64)
-        rc = g_rccl.AllGather(b.recs64 + c->rank, b.recs64, sizeof(NjsRec), kNcclUint8, c->comm, c->stream);
-    else
-        rc = g_rccl.AllGather(b.slice, b.gath, (size_t)(kind == EX_SLICES ? 3 : 1) * (size_t)b.slice_len, kNcclFloat64, c->comm, c->stream);
-    if (rc != 0) {
-        set_error(std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
-        return DPR_ERR_COMM;
-    }
-    return DPR_OK;
+    if (kind == EX_RECS) return comm_all_gather(c, b.recs + c->rank, b.recs, sizeof(NjRecord), c->stream);
+    if (kind == EX_RECS64) return comm_all_gather(c, b.recs64 + c->rank, b.recs64, sizeof(NjsRec), c->stream);
+    return comm_all_gather(c, b.slice, b.gath, sizeof(double) * (size_t)(kind == EX_SLICES ? 3 : 1) * (size_t)b.slice_len, c->stream);
 }
 
 // ---- peer windows of the one-exchange sharded loop (njs.hip) -----------------------------------------------------
@@ -177,7 +163,7 @@ static int peer_attach_blobs(dpr_ctx* c, const PeerBlob* all, int* ok)
 }
 
 // all-gather of `bytes` per rank through the staging buffer b.gath (RCCL); host arrays in / out
-static int rccl_gather_bytes(dpr_ctx* c, const void* mine, void* all, size_t bytes)
+int rccl_gather_bytes(dpr_ctx* c, const void* mine, void* all, size_t bytes)
 {
     NjBuffers& b = c->nj[0];
     char* stage = reinterpret_cast<char*>(b.gath);
@@ -220,7 +206,7 @@ int njs_setup(dpr_ctx* c, bool force_windows)
         return DPR_OK;
     }
     NjBuffers& b = c->nj[0];
-    if (c->local_comm) {
+    if (c->local_comm && !c->shm) {       // (ranks joined through a shared region exchange their handles themselves, below)
         if (!ok) return DPR_ERR_HIP;
         if (!b.peer.attached) { set_error("dpr_dist_matrix: ranks joined by dpr_comm_init_local need dpr_peer_export / dpr_peer_attach for this tip count first"); return DPR_ERR_STATE; }
         c->nj_exchange_active = kNjsMailbox;
@@ -234,7 +220,7 @@ int njs_setup(dpr_ctx* c, bool force_windows)
     {
         std::vector<uint64_t> af((size_t)c->world, 0);
         const uint64_t mine_attached = (ok && b.peer.attached) ? 1 : 0;
-        if (int rc = rccl_gather_bytes(c, &mine_attached, af.data(), sizeof(uint64_t))) return rc;
+        if (int rc = comm_gather_host(c, &mine_attached, af.data(), sizeof(uint64_t))) return rc;
         bool all_attached = true;
         for (uint64_t f : af) all_attached = all_attached && f == 1;
         attach = !all_attached;
@@ -248,13 +234,13 @@ int njs_setup(dpr_ctx* c, bool force_windows)
         PeerBlob mine;
         std::vector<PeerBlob> all((size_t)c->world);
         if (ok) peer_blob_of(c, &mine); else std::memset(&mine, 0, sizeof mine);
-        if (int rc = rccl_gather_bytes(c, &mine, all.data(), sizeof(PeerBlob))) return rc;
+        if (int rc = comm_gather_host(c, &mine, all.data(), sizeof(PeerBlob))) return rc;
         int mapped = 0;
         if (int rc = peer_attach_blobs(c, all.data(), &mapped)) return rc;
         // second round: did every rank map every peer?
         std::vector<uint64_t> flags((size_t)c->world, 0);
         const uint64_t mf = mapped ? 1 : 0;
-        if (int rc = rccl_gather_bytes(c, &mf, flags.data(), sizeof(uint64_t))) return rc;
+        if (int rc = comm_gather_host(c, &mf, flags.data(), sizeof(uint64_t))) return rc;
         bool all_ok = true;
         for (uint64_t f : flags) all_ok = all_ok && f == 1;
         if (!all_ok) {
@@ -278,6 +264,7 @@ int njs_barrier(dpr_ctx* c)
 {
     if (c->vworld > 0 || c->world == 1) return DPR_OK;       // one stream: already ordered
     if (c->comm) return exchange(c, EX_RECS);                // (the gathered records are dead between iterations)
+    if (c->shm && c->nj_exchange_active == kNjsLegacy) return comm_barrier(c, c->stream);      // (no peer windows were set up)
     return njs_launch_barrier(c->nj[0], c->stream);
 }
 
@@ -285,10 +272,7 @@ int njs_barrier(dpr_ctx* c)
 int njr_barrier_cb(void* ctx)
 {
     dpr_ctx* c = static_cast<dpr_ctx*>(ctx);
-    DPR_HIP(hipStreamSynchronize(c->stream));
-    if (int rc = exchange(c, EX_RECS)) return rc;
-    DPR_HIP(hipStreamSynchronize(c->stream));
-    return DPR_OK;
+    return comm_barrier(c, c->stream);
 }
 
 NjBuffers* owner_buffers(dpr_ctx* c, int64_t row)
@@ -336,7 +320,7 @@ int dpr_comm_init(dpr_ctx* c, int rank, int world, const void* id128)
 int dpr_comm_init_local(dpr_ctx* c, int rank, int world)
 {
     if (!c || world < 1 || world > kNjsMaxWorld || rank < 0 || rank >= world) { set_error("dpr_comm_init_local: bad argument"); return DPR_ERR_ARG; }
-    if (c->vworld > 0 || c->comm) { set_error("dpr_comm_init_local: context already holds ranks"); return DPR_ERR_STATE; }
+    if (c->vworld > 0 || c->comm || c->shm) { set_error("dpr_comm_init_local: context already holds ranks"); return DPR_ERR_STATE; }
     c->rank = rank; c->world = world;
     c->local_comm = world > 1;
     return DPR_OK;
@@ -433,6 +417,11 @@ int dpr_comm_info(dpr_ctx* c, int* rank, int* nranks)
     if (!c) { set_error("dpr_comm_info: null ctx"); return DPR_ERR_ARG; }
     if (rank) *rank = 0;
     if (nranks) *nranks = 1;
+    if (!c->comm && c->shm) {                    // ranks joined through a shared region: the rank count the region itself has seen
+        if (rank) *rank = c->rank;
+        if (nranks) *nranks = shm_joined(c);
+        return DPR_OK;
+    }
     if (!c->comm) return DPR_OK;                 // no communicator: one rank
     if (!g_rccl.CommCount || !g_rccl.CommUserRank) { set_error("librccl.so lacks ncclCommCount / ncclCommUserRank"); return DPR_ERR_COMM; }
     int r = 0, n = 0;

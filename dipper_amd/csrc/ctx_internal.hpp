@@ -28,6 +28,7 @@ struct Rccl {
 extern Rccl g_rccl;
 int rccl_load();
 const std::string& last_error();
+struct ShmComm;                     // ranks joined through a shared host region (ctx_shm.hip)
 }  // namespace dpr
 
 struct dpr_ctx {
@@ -38,6 +39,8 @@ struct dpr_ctx {
     int rank = 0, world = 1;  // RCCL rank/world, or world = number of virtual ranks
     int vworld = 0;           // > 0: all ranks live in this context on one device (validation mode)
     void* comm = nullptr;
+    dpr::ShmComm* shm = nullptr;     // dpr_comm_init_shared: barrier / host gathers through the region; + device windows (ipc transport)
+    int64_t comm_collectives = 0;    // device collectives (all-gathers, all-reduces) this context has taken part in, any transport
     std::vector<dpr::NjBuffers> nj = std::vector<dpr::NjBuffers>(1);  // one per rank held here
     dpr::MsaBuffers msa;
     dpr::MashBuffers mash;
@@ -93,4 +96,14 @@ int njr_barrier_cb(void* ctx);
 int njr_gather_cb(void* ctx, int kind, hipStream_t s);
 int njp_gather_cb(void* ctx, void* buf, size_t bytes_per_rank, hipStream_t s);
 NjBuffers* owner_buffers(dpr_ctx* c, int64_t row);
+int rccl_gather_bytes(dpr_ctx* c, const void* mine, void* all, size_t bytes);
+// ctx_shm.hip: the transport-independent collectives the algorithms call (RCCL communicator, or the device windows of ranks
+// joined through a shared host region)
+bool comm_real(const dpr_ctx* c);      // several real ranks AND a data transport between them
+int comm_gather_host(dpr_ctx* c, const void* mine, void* all, size_t bytes);                         // host blobs, <= 512 bytes per rank
+int comm_all_gather(dpr_ctx* c, const void* send, void* recv, size_t seg_bytes, hipStream_t s);      // rank r's segment at recv + r * seg_bytes
+int comm_all_reduce_sum(dpr_ctx* c, void* buf, size_t count, int nccl_type, hipStream_t s);           // in place; kNcclInt32 / kNcclUint64
+int comm_barrier(dpr_ctx* c, hipStream_t s);
+void shm_comm_free(dpr_ctx* c);
+int shm_joined(const dpr_ctx* c);      // ranks that have joined the context's shared region
 }  // namespace dpr

@@ -119,7 +119,7 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
 {
     if (!c) { set_error("dpr_dist_matrix: null ctx"); return DPR_ERR_ARG; }
     DPR_HIP(hipSetDevice(c->device));
-    if (c->world > 1 && c->vworld == 0 && !c->comm && !c->local_comm) { set_error("dpr_dist_matrix: dpr_comm_init was not called"); return DPR_ERR_STATE; }
+    if (c->world > 1 && c->vworld == 0 && !c->comm && !c->local_comm && !c->shm) { set_error("dpr_dist_matrix: dpr_comm_init was not called"); return DPR_ERR_STATE; }
     int64_t n = 0;
     if (source == DPR_SRC_MSA) {
         if (!c->msa.planes) { set_error("dpr_dist_matrix: call dpr_set_msa first"); return DPR_ERR_STATE; }
@@ -187,13 +187,15 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
         int rplan = c->nj_exchange == 2 ? kNjrMailbox : c->nj_exchange == 1 ? kNjrCollective : (c->local_comm ? kNjrMailbox : kNjrCollective);
         if (c->nj_exchange < 0 && !c->local_comm)
             if (const char* e = std::getenv("DPR_NJ_EXCHANGE")) rplan = std::strcmp(e, "mailbox") == 0 ? kNjrMailbox : kNjrCollective;
-        if (rplan == kNjrCollective && c->vworld == 0 && !c->comm) { set_error("dpr_dist_matrix: the collective plan of the row-sharded pruned NJ needs RCCL ranks"); return DPR_ERR_STATE; }
+        if (rplan == kNjrCollective && c->vworld == 0 && !comm_real(c)) { set_error("dpr_dist_matrix: the collective plan of the row-sharded pruned NJ needs a transport between the ranks (RCCL, or dpr_comm_init_shared)"); return DPR_ERR_STATE; }
         for (size_t r = 0; r < c->nj.size(); ++r) {
             NjBuffers& b = c->nj[r];
             b.rs.world = c->world; b.rs.rank = c->vworld > 0 ? (int)r : c->rank; b.rs.plan = rplan;
             b.rs.win_off = b.peer.lay.off_njr;
             b.rs.gather = njr_gather_cb; b.rs.cb_ctx = c;
-            b.rs.barrier = (c->vworld == 0 && c->comm) ? njr_barrier_cb : nullptr;
+            // (ranks on the shared region's windows: with the mailbox plan the barrier runs through the njr windows, no callback;
+            //  with the collective plan through the region)
+            b.rs.barrier = (c->vworld == 0 && (c->comm || (c->shm && rplan == kNjrCollective))) ? njr_barrier_cb : nullptr;
             b.rs.launches = 0; b.rs.collectives = 0;
         }
         std::vector<NjBuffers*> ranks = njr_ranks(c);
@@ -470,6 +472,20 @@ int dpr_set_nj_multi_plan(int plan)
     return DPR_OK;
 }
 int dpr_nj_is_unit_sharded(dpr_ctx* c) { return c && c->nj_unit_sharded ? 1 : 0; }
+// the multi-rank NJ plan the last dpr_dist_matrix set up, in words (the CLI prints it; tests assert on it)
+int dpr_get_nj_multi_info(dpr_ctx* c, char* buf, int cap)
+{
+    if (!c || !buf || cap <= 0) { set_error("dpr_get_nj_multi_info: bad argument"); return DPR_ERR_ARG; }
+    static const char* const ex[] = { "legacy (two all-gathers per iteration)", "peer (one all-gather, rows pulled)", "mailbox (no collective)" };
+    std::string s;
+    if (c->world <= 1) s = "single rank";
+    else if (c->nj_row_pruned) s = c->nj_exchange_note;
+    else if (c->nj_replicated) s = c->nj_unit_sharded ? "pruned, matrix replicated, unit tests and scans sharded (one all-gather of block records per iteration)"
+                                                       : "pruned, every rank runs the single-GPU plan on its own copy of the matrix (replicas)";
+    else s = std::string("streaming, rows sharded block-cyclically, exchange ") + ex[c->nj_exchange_active >= 0 && c->nj_exchange_active <= 2 ? c->nj_exchange_active : 0];
+    std::snprintf(buf, (size_t)cap, "%s", s.c_str());
+    return DPR_OK;
+}
 
 // the same three knobs for ONE context (two contexts in one process may run different plans); value -1 = follow
 // the process-wide default again.  Take effect at the context's next dpr_dist_matrix.

@@ -21,7 +21,7 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
     // Multi-GPU (dpr_comm_init done, inputs replicated): the distance rows of a batch do not depend on the
     // placements, so every rank computes R/world of them and one all-gather per batch completes the block;
     // the tree kernels then run identically on every rank (deterministic), so no tree state is exchanged.
-    const bool sharded = c->world > 1 && c->vworld == 0 && c->comm != nullptr && source != DPR_SRC_MATRIX;
+    const bool sharded = comm_real(c) && source != DPR_SRC_MATRIX;
     const int W = sharded ? c->world : 1;
     const int64_t per = (R + W - 1) / W;         // rows per rank and batch
     // The distance rows of the NEXT batch may be produced on a second stream while the tree kernels of the current batch run
@@ -45,7 +45,8 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
     // every ~120, so the pair kernel beside it gets half a chip (--add through Mash, every batch beside: 6.8 s against 4.0 s; the
     // 1 024-thread update workgroup needs an empty CU and waits 0.5 ms for one).
     // Results cannot depend on the policy: the rows are the same numbers whichever stream produced them.
-    const bool overlap_allowed = source == DPR_SRC_MASH && !std::getenv("DPR_PLACE_NO_OVERLAP");
+    // (ranks on the window transport of dpr_comm_init_shared: its all-gather is synchronous with the host, nothing would overlap)
+    const bool overlap_allowed = source == DPR_SRC_MASH && !std::getenv("DPR_PLACE_NO_OVERLAP") && !(sharded && !c->comm);
     // (several ranks: every rank must take the same decisions -- the batches' all-gathers are enqueued on the stream the decision
     //  picks -- and a rank's share of a batch is 1 / G of the pairs, i.e. the short side: every batch beside, as in round 3)
     const bool overlap_always = overlap_allowed && sharded;
@@ -80,11 +81,7 @@ static int place_range(dpr_ctx* c, int source, int dist_type, int64_t first, int
         if (!sharded) return fill_some(i0, nr, rows, ds);
         const int64_t a = (int64_t)c->rank * per, b = a + per < nr ? a + per : nr;     // this rank's rows of the batch
         if (int rc = fill_some(i0 + a, b - a, rows + a * ldb, ds)) return rc;
-        if (g_rccl.AllGather(rows + a * ldb, rows, (size_t)(per * ldb), kNcclFloat64, c->comm, ds) != 0) {
-            set_error("ncclAllGather(distance rows) failed");
-            return DPR_ERR_COMM;
-        }
-        return DPR_OK;
+        return comm_all_gather(c, rows + a * ldb, rows, sizeof(double) * (size_t)(per * ldb), ds);
     };
     // the reference reports the distance and the tree part of a placement run separately
     // (src/placement_close_k.cu:852-853,985-986).  A batch produced on the main stream: an event pair around it (c->place_ev).
@@ -446,7 +443,7 @@ int dpr_dc_run(dpr_ctx* c, int source, int dist_type, int k, int64_t n, int64_t 
     uint64_t *snap_old = nullptr, *snap_acc = nullptr;
     DcTable tab;
     // ranks: RCCL ranks of dpr_comm_init, or -- validation on one GPU -- DPR_DC_VIRTUAL_RANKS(w) emulated in turn
-    const bool real = c->world > 1 && c->vworld == 0 && c->comm != nullptr;
+    const bool real = comm_real(c);
     const int W = real ? c->world : (((flags >> 8) & 0xff) > 1 ? ((flags >> 8) & 0xff) : 1);
     std::vector<int32_t> h_cl((size_t)n, -1);
     auto run = [&]() -> int {
@@ -484,8 +481,7 @@ int dpr_dc_run(dpr_ctx* c, int source, int dist_type, int k, int64_t n, int64_t 
             }
         }
         if (real) {
-            if (!g_rccl.AllReduce) { set_error("dpr_dc_run: librccl.so lacks ncclAllReduce"); return DPR_ERR_COMM; }
-            if (g_rccl.AllReduce(d_cl, d_cl, (size_t)n, kNcclInt32, kNcclSum, c->comm, c->stream) != 0) { set_error("ncclAllReduce(cluster ids) failed"); return DPR_ERR_COMM; }
+            if (int rc = comm_all_reduce_sum(c, d_cl, (size_t)n, kNcclInt32, c->stream)) return rc;
         }
         DPR_HIP(hipMemcpyAsync(h_cl.data(), d_cl, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
         DPR_HIP(hipEventRecord(ev[2], c->stream));
@@ -530,7 +526,7 @@ int dpr_dc_run(dpr_ctx* c, int source, int dist_type, int k, int64_t n, int64_t 
             off = 0;
             for (const Arr& a : arrs) {
                 if (real) {
-                    if (g_rccl.AllReduce(a.cur, a.cur, (size_t)a.words, kNcclUint64, kNcclSum, c->comm, c->stream) != 0) { set_error("ncclAllReduce(state delta) failed"); return DPR_ERR_COMM; }
+                    if (int rc = comm_all_reduce_sum(c, a.cur, (size_t)a.words, kNcclUint64, c->stream)) return rc;
                 } else {
                     DPR_HIP(hipMemcpyAsync(a.cur, snap_acc + off, sizeof(uint64_t) * (size_t)a.words, hipMemcpyDeviceToDevice, c->stream));
                 }

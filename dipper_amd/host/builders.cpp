@@ -12,8 +12,25 @@
 
 namespace dipper {
 
-DeviceContext::DeviceContext(int device) { gpuCheck(dpr_create(&ctx, device), "dpr_create"); }
+DeviceContext::DeviceContext(int device)
+{
+    gpuCheck(dpr_create(&ctx, device), "dpr_create");
+    // one of several ranks (startRanks): join the others before any input reaches the device
+    const RankInfo& ri = rankInfo();
+    if (ri.world > 1) gpuCheck(dpr_comm_init_shared(ctx, ri.rank, ri.world, ri.region, DPR_COMM_SHARED_BYTES, ri.transport), "dpr_comm_init_shared");
+}
 DeviceContext::~DeviceContext() { if (ctx) dpr_destroy(ctx); }
+
+void printRankSummary(dpr_ctx* ctx)
+{
+    if (rankInfo().world <= 1 || !ctx) return;
+    int transport = 0, rank = 0, nranks = 1;
+    int64_t coll = 0;
+    dpr_comm_stats(ctx, &transport, &coll);
+    dpr_comm_info(ctx, &rank, &nranks);
+    static const char* const names[] = { "none", "rccl", "ipc", "local" };
+    std::cerr << "Ranks: " << nranks << " (transport " << names[transport & 3] << ", " << coll << " device collectives)\n";
+}
 
 struct AsyncDeviceContext::Impl {
     std::thread th, warm;
@@ -138,6 +155,11 @@ void NJDeviceArrays::getDismatrix(DeviceContext& dev, int numSequences, Param& p
         gpuCheck(dpr_dist_matrix(dev.ctx, DPR_SRC_MSA, (int)params.distanceType, 0), "dpr_dist_matrix");
     } else {
         gpuCheck(dpr_dist_matrix(dev.ctx, DPR_SRC_MASH, 0, (int)params.kmerSize), "dpr_dist_matrix");
+    }
+    if (rankInfo().world > 1) {
+        char plan[256] = "";
+        dpr_get_nj_multi_info(dev.ctx, plan, (int)sizeof plan);
+        std::cerr << "NJ over " << rankInfo().world << " ranks: " << plan << "\n";
     }
 }
 

@@ -96,6 +96,38 @@ struct MatrixReader {
     void read(const std::string& path);
 };
 
+// ---- several GPUs: one PROCESS per rank (no reference counterpart: src/tree_generation.cu:240-245 selects one device) ---------
+// `dipper --gpus G`: once the input has been read and BEFORE the first GPU call the command forks G rank processes around one
+// anonymous shared mapping (the packed input is shared copy-on-write: read once, packed once); every rank creates its context on
+// its own device and joins the others through that region (dpr_comm_init_shared: RCCL over xGMI for one rank per GPU, device
+// windows over hipIpc for ranks that share a device).  The mode's multi-rank plan then runs inside the library: NJ with
+// replicated / unit-sharded / row-sharded matrices, placement and --add with the distance rows of a batch sharded + one
+// all-gather per batch, divide-and-conquer with query shares and clusters dealt to the ranks.  Every rank ends with the whole
+// tree; rank 0 writes it.  The launcher (the original process) never touches the GPU: it waits for its ranks, and if one fails
+// it raises the region's failure word (the others then leave their collectives with an error instead of hanging) and exits 1.
+// `--rank R --world G --rendezvous NAME`: the same for ranks started by somebody else (mpirun, srun, a test): the region is
+// the POSIX shared memory object NAME.
+struct RankInfo {
+    int rank = 0, world = 1;
+    void* region = nullptr;      // DPR_COMM_SHARED_BYTES of shared memory
+    int device = 0;              // this rank's GPU
+    int transport = 0;           // 0 auto, 1 rccl, 2 ipc
+};
+RankInfo& rankInfo();
+struct RankOptions {
+    int gpus = 1;                // --gpus
+    std::vector<int> devices;    // --devices a,b,..  (default: --device + rank)
+    int transport = 0;           // --transport auto|rccl|ipc
+    int ext_rank = -1, ext_world = 0;      // --rank / --world: ranks started from outside
+    std::string rendezvous;      // --rendezvous
+    bool multi() const { return gpus > 1 || ext_world > 1; }
+};
+// Returns in every RANK with rankInfo() filled in (ranks > 0: the progress lines on std::cerr are switched off; errors still
+// reach stderr).  In the launcher it does not return.  Must be called with no other thread alive and before any GPU call.
+void startRanks(const RankOptions& o, int base_device);
+// rank 0's closing line of a multi-rank run: "Ranks: G (transport, N device collectives; NJ plan ...)"; nothing with one rank
+void printRankSummary(dpr_ctx* ctx);
+
 struct DeviceContext {  // replaces cudaSetDevice (src/tree_generation.cu:240-245)
     dpr_ctx* ctx = nullptr;
     explicit DeviceContext(int device);

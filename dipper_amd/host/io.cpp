@@ -5,6 +5,10 @@
 #include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <signal.h>
+#include <cerrno>
+#include <chrono>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -18,18 +22,113 @@
 
 namespace dipper {
 
+RankInfo& rankInfo()
+{
+    static RankInfo info;
+    return info;
+}
+// a rank that gives up tells the others first: they leave their collectives with an error instead of waiting for it
+static void rankFailed()
+{
+    if (rankInfo().region) dpr_shared_abort(rankInfo().region);
+}
+
 void die(const std::string& msg)
 {
-    std::cerr << msg << std::endl;
+    std::fprintf(stderr, "%s\n", msg.c_str());      // (not std::cerr: ranks > 0 have their progress lines switched off)
+    rankFailed();
     std::exit(1);
 }
 
 void gpuCheck(int rc, const char* what)
 {
     if (rc < 0) {
-        std::fprintf(stderr, "Gpu_ERROR: %s failed: %s\n", what, dpr_last_error());
+        if (rankInfo().world > 1) std::fprintf(stderr, "Gpu_ERROR (rank %d of %d): %s failed: %s\n", rankInfo().rank, rankInfo().world, what, dpr_last_error());
+        else std::fprintf(stderr, "Gpu_ERROR: %s failed: %s\n", what, dpr_last_error());
+        rankFailed();
         std::exit(1);
     }
+}
+
+void startRanks(const RankOptions& o, int base_device)
+{
+    RankInfo& me = rankInfo();
+    auto device_of = [&](int r) { return r < (int)o.devices.size() ? o.devices[(size_t)r] : base_device + r; };
+    if (o.ext_world > 1) {
+        // ranks started from outside: the region is a POSIX shared memory object every rank opens (the first one creates it;
+        // a fresh object is zero-filled, which is the state dpr_comm_init_shared expects)
+        if (o.ext_rank < 0 || o.ext_rank >= o.ext_world || o.rendezvous.empty()) die("ERROR: --world needs --rank (0 <= rank < world) and --rendezvous NAME");
+        const std::string name = (o.rendezvous[0] == '/' ? "" : "/") + o.rendezvous;
+        const int fd = shm_open(name.c_str(), O_CREAT | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, DPR_COMM_SHARED_BYTES) != 0) die("ERROR: cannot open the rendezvous shared memory object " + name);
+        void* p = mmap(nullptr, DPR_COMM_SHARED_BYTES, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) die("ERROR: cannot map the rendezvous shared memory object " + name);
+        me.rank = o.ext_rank; me.world = o.ext_world; me.region = p; me.device = device_of(o.ext_rank); me.transport = o.transport;
+        if (me.rank > 0) std::cerr.setstate(std::ios_base::badbit);
+        return;
+    }
+    if (o.gpus <= 1) return;
+    const int G = o.gpus;
+    if (G > 64) die("ERROR: --gpus: at most 64 ranks");
+    void* region = mmap(nullptr, DPR_COMM_SHARED_BYTES, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    if (region == MAP_FAILED) die("ERROR: cannot allocate the ranks' shared region");
+    std::cerr << "Starting " << G << " ranks (devices";
+    for (int r = 0; r < G; ++r) std::cerr << " " << device_of(r);
+    std::cerr << ")\n";
+    std::cerr.flush();
+    std::fflush(nullptr);
+    std::vector<pid_t> pids((size_t)G, -1);
+    for (int r = 0; r < G; ++r) {
+        const pid_t pid = fork();
+        if (pid < 0) {
+            dpr_shared_abort(region);
+            for (int k = 0; k < r; ++k) kill(pids[(size_t)k], SIGTERM);
+            die("ERROR: fork failed");
+        }
+        if (pid == 0) {
+            me.rank = r; me.world = G; me.region = region; me.device = device_of(r); me.transport = o.transport;
+            if (r > 0) std::cerr.setstate(std::ios_base::badbit);      // one copy of the progress lines: rank 0's
+            return;
+        }
+        pids[(size_t)r] = pid;
+    }
+    // the launcher: no GPU call here, ever.  First failure -> failure word -> the others get a few seconds to leave by themselves.
+    int left = G, bad = 0;
+    double deadline = -1.0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    while (left > 0) {
+        int status = 0;
+        const pid_t pid = waitpid(-1, &status, deadline < 0 ? 0 : WNOHANG);
+        if (pid > 0) {
+            int r = -1;
+            for (int k = 0; k < G; ++k) if (pids[(size_t)k] == pid) r = k;
+            if (r < 0) continue;
+            pids[(size_t)r] = -1;
+            --left;
+            const bool ok = WIFEXITED(status) && WEXITSTATUS(status) == 0;
+            if (!ok) {
+                if (!bad) {
+                    if (WIFSIGNALED(status)) std::fprintf(stderr, "ERROR: rank %d was ended by signal %d\n", r, WTERMSIG(status));
+                    else std::fprintf(stderr, "ERROR: rank %d failed (exit code %d)\n", r, WIFEXITED(status) ? WEXITSTATUS(status) : -1);
+                    dpr_shared_abort(region);
+                    deadline = now() + 10.0;
+                }
+                ++bad;
+            }
+            continue;
+        }
+        if (pid < 0 && errno != EINTR) break;
+        if (deadline >= 0) {
+            if (now() > deadline) {
+                for (int k = 0; k < G; ++k) if (pids[(size_t)k] > 0) kill(pids[(size_t)k], SIGKILL);      // (exact pids: our own children)
+                deadline = now() + 1e9;
+            }
+            usleep(2000);
+        }
+    }
+    std::fflush(nullptr);
+    _exit(bad ? 1 : 0);
 }
 
 unsigned hostThreads(unsigned cap)

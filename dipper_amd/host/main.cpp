@@ -59,7 +59,15 @@ static const char* kHelp =
     "MI355X build options:\n"
     "  --seed arg                  Seed of the input-order shuffle (reference: time(NULL));\n"
     "                              default 1, negative keeps the input order\n"
-    "  --device arg                GPU index (default 0; the reference hard-codes 1)\n";
+    "  --device arg                GPU index (default 0; the reference hard-codes 1)\n"
+    "  --gpus arg                  Number of GPUs: one rank process per GPU, started by this command\n"
+    "                              once the input is read (devices --device, --device+1, ...)\n"
+    "  --devices arg               Comma-separated GPU index of every rank (the same index twice:\n"
+    "                              ranks share that GPU -- rehearsal of the multi-GPU paths)\n"
+    "  --transport arg             auto (default) | rccl | ipc: how the ranks exchange data\n"
+    "  --rank arg --world arg --rendezvous arg\n"
+    "                              this process is rank `rank` of `world` ranks started from outside;\n"
+    "                              they meet in the POSIX shared memory object `rendezvous`\n";
 
 struct Opt { const char* lng; char sht; bool has_arg; };
 static const Opt kOpts[] = {
@@ -67,7 +75,8 @@ static const Opt kOpts[] = {
     { "output-format", 'o', true }, { "algorithm", 'm', true }, { "placement-mode", 'p', true },
     { "kmer-size", 'k', true }, { "sketch-size", 's', true }, { "distance-type", 'd', true },
     { "add", 'a', false }, { "input-tree", 't', true }, { "help", 'h', false },
-    { "seed", 0, true }, { "device", 0, true }, { "dump-tree", 0, true }, { "dump-fasta", 0, false }, { "dump-lengths", 0, false }, { "dump-packed", 0, true },
+    { "seed", 0, true }, { "device", 0, true }, { "gpus", 0, true }, { "devices", 0, true }, { "transport", 0, true },
+    { "rank", 0, true }, { "world", 0, true }, { "rendezvous", 0, true }, { "dump-tree", 0, true }, { "dump-fasta", 0, false }, { "dump-lengths", 0, false }, { "dump-packed", 0, true },
 };
 
 static void usageError(const std::string& what)
@@ -226,13 +235,40 @@ int main(int argc, char** argv)
     try { if (vm.count("seed")) seed = std::stoll(vm["seed"]); } catch (...) {}
     const int device = (int)stoiOr(vm, "device", 0);
     const std::string inputFile = vm["input-file"], outputFile = vm["output-file"];
+    // several GPUs: one rank process per GPU, started once the input is read and before the first GPU call (startRanks)
+    RankOptions ranks;
+    ranks.gpus = (int)stoiOr(vm, "gpus", 1);
+    if (ranks.gpus < 1) usageError("--gpus must be at least 1");
+    if (vm.count("devices")) {
+        std::stringstream ss(vm["devices"]);
+        std::string tok;
+        while (std::getline(ss, tok, ',')) {
+            try { ranks.devices.push_back(std::stoi(tok)); } catch (...) { usageError("--devices: a comma-separated list of GPU indices"); }
+        }
+        if (!vm.count("gpus") && !vm.count("world")) ranks.gpus = (int)ranks.devices.size();
+    }
+    {
+        const std::string tr = strOr(vm, "transport", "auto");
+        if (tr == "auto") ranks.transport = 0; else if (tr == "rccl") ranks.transport = 1; else if (tr == "ipc") ranks.transport = 2;
+        else usageError("--transport: auto, rccl or ipc");
+    }
+    if (vm.count("world")) {
+        ranks.ext_world = (int)stoiOr(vm, "world", 1);
+        ranks.ext_rank = vm.count("rank") ? (int)stoiOr(vm, "rank", 0) : -1;
+        ranks.rendezvous = strOr(vm, "rendezvous", "");
+        ranks.gpus = 1;
+        if (ranks.ext_world > 1 && (ranks.ext_rank < 0 || ranks.ext_rank >= ranks.ext_world || ranks.rendezvous.empty()))
+            usageError("--world needs --rank (0 <= rank < world) and --rendezvous");
+    }
+    const bool multi = ranks.multi();
 
     const int placement_thr = 30000, dc_thr = 1000000;  // src/tree_generation.cu:247-248
     auto ms_since = [](std::chrono::high_resolution_clock::time_point t0) {
         return (long long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
     };
     auto open_out = [&]() {
-        auto os = std::make_unique<std::ofstream>(outputFile.c_str());
+        // (several ranks: every rank ends with the whole tree, rank 0 writes it)
+        auto os = std::make_unique<std::ofstream>(rankInfo().rank == 0 ? outputFile.c_str() : "/dev/null");
         if (!*os) die("ERROR: cannot open output file: " + outputFile);
         return os;
     };
@@ -319,7 +355,9 @@ int main(int argc, char** argv)
             std::fprintf(stderr, "ERROR: cant open file: %s\n", inputFile.c_str());  // src/tree_generation.cu:138-141
             return 1;
         }
-        AsyncDeviceContext adev(device);          // HIP start-up runs while the input is read
+        // one GPU: HIP start-up runs while the input is read; several: the ranks are started once it has been read
+        std::unique_ptr<AsyncDeviceContext> adev;
+        if (!multi) adev.reset(new AsyncDeviceContext(device));
         const std::function<std::vector<int>(const std::vector<std::string>&)> ids_fn =
             [&](const std::vector<std::string>& nd) { return slots_of(nd, nullptr); };
         PackedSequences packed;
@@ -335,9 +373,10 @@ int main(int argc, char** argv)
         }
         const Tree& t = *tp;
         const size_t numSequences = packed.ok ? packed.numSequences : seqs.size();
+        if (multi) { startRanks(ranks, device); adev.reset(new AsyncDeviceContext(rankInfo().device)); }
         auto output_ = open_out();
         if (cliLog()) std::cerr << "  input read, backbone tree parsed at " << ms_since(inputStart) << " ms\n";
-        DeviceContext& dev = adev.get();
+        DeviceContext& dev = adev->get();
         if (cliLog()) std::cerr << "  device ready at " << ms_since(inputStart) << " ms\n";
         KPlacementDeviceArrays kplacementDeviceArrays;
         if (params.in == "r") {
@@ -360,6 +399,7 @@ int main(int argc, char** argv)
         if (cliLog()) std::cerr << "  addQuery done at " << ms_since(inputStart) << " ms\n";
         kplacementDeviceArrays.printTree(names, *output_);
         if (cliLog()) std::cerr << "  tree written at " << ms_since(inputStart) << " ms\n";
+        printRankSummary(dev.ctx);
         return 0;
     }
 
@@ -411,14 +451,16 @@ int main(int argc, char** argv)
             std::fprintf(stderr, "ERROR: cant open file: %s\n", inputFile.c_str());  // src/tree_generation.cu:138-141
             return 1;
         }
-        AsyncDeviceContext adev(device);          // HIP start-up runs while the input is read
+        // one GPU: HIP start-up runs while the input is read; several: the ranks are started once it has been read
+        std::unique_ptr<AsyncDeviceContext> adev;
+        if (!multi) adev.reset(new AsyncDeviceContext(device));
         // fast path: records indexed in the mapped text and packed straight into the device interface's flat arrays;
         // as soon as the number of records is known the device thread allocates the NJ matrices (when NJ is the mode)
-        struct Hook { AsyncDeviceContext* adev; decltype(pick_mode)* pick; } hook{ &adev, &pick_mode };
+        struct Hook { AsyncDeviceContext* adev; decltype(pick_mode)* pick; } hook{ adev.get(), &pick_mode };
         PackedSequences packed;
         readSequencesPacked(inputFile, aligned, seed, packed, [](size_t n, void* u) {
             Hook* h = static_cast<Hook*>(u);
-            if (n >= 3 && (*h->pick)((long long)n) == 2) h->adev->reserveNJ(n);
+            if (h->adev && n >= 3 && (*h->pick)((long long)n) == 2) h->adev->reserveNJ(n);
         }, &hook);
         const long long parsed_ms = ms_since(inputStart);      // the file is read and packed (host side of the input phase)
         std::vector<std::string> seqs;
@@ -434,8 +476,9 @@ int main(int argc, char** argv)
         }
         const size_t numSequences = packed.ok ? packed.numSequences : seqs.size();
         if (numSequences < 3) die("ERROR: need at least three sequences in " + inputFile);
+        if (multi) { startRanks(ranks, device); adev.reset(new AsyncDeviceContext(rankInfo().device)); }
         auto output_ = open_out();
-        DeviceContext& dev = adev.get();
+        DeviceContext& dev = adev->get();
         MSADeviceArrays msaDeviceArrays;
         MashDeviceArrays mashDeviceArrays;
         const int mode = pick_mode((long long)numSequences);
@@ -449,7 +492,7 @@ int main(int argc, char** argv)
         std::cerr << "Input in: " << ms_since(inputStart) << " ms\n";
         // (not a line of the reference: how much of the input phase was the HIP runtime coming up on the helper thread --
         //  the input phase ends when BOTH the parsed input and the device context are there)
-        std::cerr << "Device ready in: " << (long long)adev.createMs() << " ms\n";
+        std::cerr << "Device ready in: " << (long long)adev->createMs() << " ms\n";
         std::cerr << "Parsed in: " << parsed_ms << " ms\n";      // (not a line of the reference either: the host side alone)
         auto createArrayStart = std::chrono::high_resolution_clock::now();
         if (!aligned) {
@@ -497,6 +540,7 @@ int main(int argc, char** argv)
             njDeviceArrays.findNeighbourJoiningTree(dev, names, *output_);
             std::cerr << "Tree Created in: " << ms_since(t0) << " ms\n";
         }
+        printRankSummary(dev.ctx);
         // the tree is written: close the output and leave without running the static destructors of the HIP runtime
         output_.reset();
         if (cliLog()) std::cerr << "Main in: " << ms_since(inputStart) << " ms\n";
@@ -516,10 +560,11 @@ int main(int argc, char** argv)
         matrixReader.read(inputFile);
         const int numSequences = matrixReader.numSequences;
         if (numSequences < 3) die("ERROR: need at least three taxa in " + inputFile);
-        auto output_ = open_out();
         const int mode = pick_mode(numSequences);
         if (mode == 3) { std::cerr << "Divide-and-conquer mode not supported with input matrix\n"; return 1; }
-        DeviceContext dev(device);
+        if (multi) startRanks(ranks, device);
+        auto output_ = open_out();
+        DeviceContext dev(multi ? rankInfo().device : device);
         if (mode == 1) {
             std::cerr << "Using " << (exact_mode ? " exact placement mode\n" : "k-closest placement mode\n");
             gpuCheck(dpr_set_matrix_lower(dev.ctx, matrixReader.lower.data(), numSequences), "dpr_set_matrix_lower");
@@ -536,6 +581,7 @@ int main(int argc, char** argv)
             njDeviceArrays.getDismatrix(dev, numSequences, params, &matrixReader);
             njDeviceArrays.findNeighbourJoiningTree(dev, matrixReader.name, *output_);
         }
+        printRankSummary(dev.ctx);
     } else {
         std::printf("Invalid input-output combinations!!!!!\n");
         return 1;

@@ -112,8 +112,31 @@ int dpr_comm_selftest(dpr_ctx *ctx);
 int dpr_comm_init_local(dpr_ctx *ctx, int rank, int world);
 int dpr_peer_export(dpr_ctx *ctx, int64_t n_tips, void *out192);
 int dpr_peer_attach(dpr_ctx *ctx, const void *all192);
-/* rank and rank count AS THE COMMUNICATOR REPORTS THEM (ncclCommUserRank / ncclCommCount); 0 / 1 without one */
+/* rank and rank count AS THE COMMUNICATOR REPORTS THEM (ncclCommUserRank / ncclCommCount; for ranks on the window transport of
+ * dpr_comm_init_shared: this rank and the number of ranks that have joined the shared region); 0 / 1 without one */
 int dpr_comm_info(dpr_ctx *ctx, int *rank, int *nranks);
+/* Ranks joined through a SHARED HOST REGION -- what `dipper --gpus G` does (dipper_amd/host/main.cpp forks its ranks around one
+ * anonymous shared mapping before any GPU call), and what any launcher can do that hands the G processes of one node the same
+ * DPR_COMM_SHARED_BYTES of zero-initialised shared memory (shm_open + mmap).  No reference counterpart: the reference drives one
+ * device (src/tree_generation.cu:240-245).  Call after dpr_create, before any dpr_set_* call, on every rank (collective).
+ * transport 1 = RCCL: rank 0's ncclUniqueId travels through the region, dpr_comm_init follows -- one rank per GPU;
+ * transport 2 = ipc: a device window per rank (DPR_COMM_WINDOW_MB, default 64), mapped by the other ranks through hipIpc; all-gathers
+ *   and integer all-reduces run through the windows in chunks between host barriers (synchronous with the host).  The ONLY
+ *   transport for ranks that share a device (RCCL refuses them), i.e. for rehearsing every multi-rank path on a single GPU;
+ * transport 0 = auto: ipc iff two ranks name the same device (PCI bus id), else RCCL.
+ * The region also carries a failure word: a rank that gives up (or the launcher, dpr_shared_abort, when a rank has died) sets it
+ * and every wait of every rank ends with DPR_ERR_COMM instead of hanging; DPR_COMM_TIMEOUT_MS (default 1 800 000) bounds a wait. */
+#define DPR_COMM_SHARED_BYTES 65536
+int dpr_comm_init_shared(dpr_ctx *ctx, int rank, int world, void *shared, uint64_t bytes, int transport);
+/* *transport: 0 = none (one rank / virtual ranks), 1 = RCCL, 2 = device windows over hipIpc, 3 = peers attached by the launcher
+ * (dpr_comm_init_local: mailbox NJ only); *collectives: device all-gathers + all-reduces this context has taken part in */
+int dpr_comm_stats(dpr_ctx *ctx, int *transport, int64_t *collectives);
+/* host-only pieces of that protocol (no GPU needed): the launcher's failure path, and the barrier / 512-byte-per-rank gather the
+ * library runs over the region (CPU tests drive them with several processes; *sense is a rank's private word, 0 at the start) */
+int dpr_shared_abort(void *shared);
+int dpr_shared_failed(const void *shared);
+int dpr_shared_barrier(void *shared, int world, uint32_t *sense, int timeout_ms);
+int dpr_shared_gather(void *shared, int rank, int world, uint32_t *sense, int timeout_ms, const void *mine, void *all, int bytes);
 
 /* ---- inputs ----------------------------------------------------------------------------------*/
 /* MSADeviceArrays::allocateDeviceArrays (src/MSA.cu:14-72): packed4 is [n][ceil(L/16)] words as
@@ -185,6 +208,9 @@ int dpr_set_nj_virtual_shards(int w);
  * src/tree_generation.cu:240-245).  dpr_nj_is_unit_sharded: what the last dpr_dist_matrix chose. */
 int dpr_set_nj_multi_plan(int plan);
 int dpr_nj_is_unit_sharded(dpr_ctx *ctx);
+/* the multi-rank NJ plan the last dpr_dist_matrix set up, in words ("single rank", "pruned, every rank runs ... (replicas)",
+ * "pruned, ... unit tests and scans sharded ...", "streaming, rows sharded ..., exchange ...", "row-sharded pruned NJ ...") */
+int dpr_get_nj_multi_info(dpr_ctx *ctx, char *buf, int cap);
 /* The three plan knobs above are process-wide DEFAULTS.  Per context (two contexts of one process may run different
  * plans): same meaning, value -1 = follow the process-wide default again; effective at that context's next
  * dpr_dist_matrix. */
