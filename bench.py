@@ -200,6 +200,24 @@ class Stage:
         return (np.fromfile(p["packed2"] + ".flat", dtype=np.uint64), np.fromfile(p["packed2"] + ".off", dtype=np.uint64),
                 np.fromfile(p["packed2"] + ".len", dtype=np.uint64))
 
+    def drop(self, p):
+        """remove the files of one input (the protocol-length ones are gigabytes of /dev/shm, which is host memory)"""
+        if self.rank != 0:
+            return
+        for f in (p.get("fasta"), p.get("packed4"), p.get("order")):
+            if f and os.path.exists(f):
+                os.unlink(f)
+        if p.get("packed2"):
+            for ext in (".flat", ".off", ".len"):
+                if os.path.exists(p["packed2"] + ext):
+                    os.unlink(p["packed2"] + ext)
+
+    def room_for(self, nbytes):
+        try:
+            return shutil.disk_usage(self.dir).free > nbytes
+        except OSError:
+            return False
+
     def cleanup(self):
         if self.rank == 0 and self.dir:
             shutil.rmtree(self.dir, ignore_errors=True)
@@ -356,8 +374,10 @@ def cli_phases(stderr_text):
     return ph
 
 
-def cli_step(fa, out, device, threads):
+def cli_step(fa, out, device, threads, idle_s=0.0):
     env = dict(os.environ, DPR_HOST_THREADS=str(threads))
+    if idle_s > 0:
+        time.sleep(idle_s)        # (isolated steps: the previous process's teardown in the kernel driver is over)
     t0 = time.perf_counter()
     r = subprocess.run([EXE, "-i", "m", "-I", fa, "-O", out, "-m", "2", "-d", "2", "--device", str(device)],
                        capture_output=True, text=True, env=env)
@@ -369,7 +389,21 @@ def cli_step(fa, out, device, threads):
 
 
 def join_comm(dip, rank, world, dist):
-    """the library's own RCCL communicator on `dip`; returns the rank count RCCL reports"""
+    """the library's own RCCL communicator on `dip`; returns the rank count RCCL reports.  DPR_BENCH_ONE_GPU=1 (every rank on
+    GPU 0, which RCCL refuses): the ranks join through a shared region instead and exchange through device windows over hipIpc
+    (dpr_comm_init_shared, transport ipc); the count is then the number of ranks the region has seen."""
+    from dipper_amd import capi
+    if ONE_GPU:
+        name = [("dpr_bench_%d_%d" % (os.getpid(), int(time.time() * 1e3) % 1000000)) if rank == 0 else None]
+        if rank == 0:
+            capi.SharedRegion(name[0], create=True)
+        dist.broadcast_object_list(name, src=0)
+        region = capi.SharedRegion(name[0])
+        dip.comm_init_shared(rank, world, region, capi.TRANSPORT_IPC)
+        dist.barrier()
+        if rank == 0:
+            region.unlink()
+        return dip.comm_info()[1]
     uid = [dip.comm_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(uid, src=0)
     dip.comm_init(rank, world, uid[0])
@@ -400,6 +434,8 @@ def main():
     ap.add_argument("--add-backbone", type=int, default=500000)
     ap.add_argument("--add-queries", type=int, default=50000)
     ap.add_argument("--no-add-leg", action="store_true", help="skip other_configs' configs[4] legs (--add of 50 000 queries onto 500 000 tips, aligned and Mash)")
+    ap.add_argument("--no-protocol-length", action="store_true",
+                    help="skip other_configs' legs at the authors' sequence length (10 000 sites / bases; scripts/experiment.sh:14) for configs[2]-[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cli", action="store_true",
                     help="skip the command-line steps: `value` is then the in-process hot path (used when profiling the kernels)")
@@ -542,6 +578,22 @@ def main():
                    "tips_per_s_median": n / (float(np.median(walls)) * 1e-3) if walls else None,
                    "fasta_bytes": os.path.getsize(fa), "newick_bytes": os.path.getsize(nwk) if os.path.exists(nwk) else None}
             log(f"[bench r{rank}] CLI steps: {cli['wall_ms']}")
+            # the same command with the GPU left alone for 0.4 s before every step: hip_startup_ms is then the process's OWN runtime
+            # start-up (~105 ms), not the wait for its predecessor's teardown -- separates the command's cost from the artefact of
+            # running steps back to back (round 5's verdict, item 8).  Untimed as far as `value` goes.
+            if rank == 0 and args.steps > 0 and budget.allows(12):
+                try:
+                    iw, ii, it_, ir, ipar = [], [], [], [], []
+                    for _ in range(min(args.steps, 5)):
+                        dt, ph = cli_step(fa, nwk, local_rank, threads, idle_s=0.4)
+                        iw.append(dt * 1e3); ii.append(ph.get("input", float("nan"))); it_.append(ph.get("tree", float("nan")))
+                        ir.append(ph.get("device_ready", float("nan"))); ipar.append(ph.get("parsed", float("nan")))
+                    cli["isolated"] = {"idle_before_each_step_ms": 400, "steps": len(iw), "wall_ms": stats_ms(iw), "input_ms": stats_ms(ii), "tree_ms": stats_ms(it_),
+                                       "other_ms": stats_ms([w - i - t for w, i, t in zip(iw, ii, it_)]), "hip_startup_ms": stats_ms(ir), "parse_ms": stats_ms(ipar),
+                                       "tips_per_s_median": n / (float(np.median(iw)) * 1e-3),
+                                       "note": "not part of `value`: the timed steps above run back to back, as the contract asks"}
+                except Exception as e:
+                    cli["isolated"] = {"error": repr(e)}
 
         # =====================================================================================================
         # B. the hot path alone, in process through the C ABI: inputs resident in HBM -> distances -> NJ merge log
@@ -828,6 +880,12 @@ def main():
                 out["sharded_100k"] = sharded_leg(args, rank, world, local_rank, dist, torch, barrier, stage, budget)
             except Exception as e:
                 out["sharded_100k"] = {"error": repr(e)}
+        # F2. the product's own multi-GPU boundary: the `dipper` command with one rank per GPU (configs[1]-[4]) next to one GPU
+        if run_sharded and not args.probe_only and not args.no_cli and os.path.exists(EXE):
+            try:
+                out["cli_ranks"] = cli_ranks_leg(args, rank, world, local_rank, dist if world > 1 else None, stage, budget, tmp, fa if want_cli else None)
+            except Exception as e:
+                out["cli_ranks"] = {"error": repr(e)}
         out["bench_wall_s"] = round(elapsed(), 1)
         try:
             out = with_scaling_summary(out, world)
@@ -917,9 +975,9 @@ def other_configs(args, local_rank, stage, budget, tmp):
                                                                                        res["bl_y"], res["last_d"], fmt=repr), tmp, "nj100k")
         return out
 
-    def place_100k_unaligned():
-        n, L = 100000, 3000
-        inp = stage.gen("reads100k", n, L, args.seed + 8, 2e-5, 2e-6, 2e-4, reads=True)
+    def place_100k_unaligned(L=3000):
+        n = 100000
+        inp = stage.gen("reads100k_%d" % L, n, L, args.seed + 8, 2e-5, 2e-6, 2e-4, reads=True)
         flat, off, lens = Stage.reads(inp)
         d = dipper_amd.Dipper(local_rank)
         try:
@@ -932,7 +990,7 @@ def other_configs(args, local_rank, stage, budget, tmp):
             dist_ms, tree_ms = d.place_timing()
             overlapped, busy_ms = d.place_overlap()
             out = {"workload": "configs[2]: %d unaligned tips x ~%d bases, Mash sketches (k 15, 1000 values) + k-closest placement, reads in HBM -> tree arrays" % (n, L),
-                   "tips": n, "seconds": wall, "tips_per_s": n / wall, "sketch_s": t1 - t0,
+                   "tips": n, "bases": L, "protocol_length": L >= 10000, "seconds": wall, "tips_per_s": n / wall, "sketch_s": t1 - t0,
                    "distance_wait_ms": dist_ms, "tree_part_ms": tree_ms, "distance_batches_overlapped": overlapped, "distance_busy_ms": busy_ms,
                    "trace_digest": hashlib.sha256(np.ascontiguousarray(st["trace"]).tobytes()).hexdigest()[:16]}
         finally:
@@ -940,11 +998,15 @@ def other_configs(args, local_rank, stage, budget, tmp):
         if budget.allows(20):
             names = ["T%d" % (i + 1) for i in range(n)]
             out["nrf_vs_generating_tree"] = nrf_of(inp["tree"], _util.newick_from_placement(names, st["head"], st["e"], st["nxt"], st["len"], n, fmt=repr), tmp, "place100k")
+        stage.drop(inp)
         return out
 
-    def dc_1m():
-        n, L = args.dc_tips, 400
-        inp = stage.gen("dc1m", n, L, args.seed + 9, 2e-3, 2e-4, 2e-2, shuffle=7, gap=None if args.no_indel_gaps else args.gap_frac)   # the CLI shuffles its input (src/tree_generation.cu:341-344)
+    def dc_1m(L=400):
+        n = args.dc_tips
+        # (400 sites: the branch lengths of rounds 2-5 -- 25 x the protocol's -- so that 400 sites carry the signal 10 000 do at the
+        #  protocol's; 10 000 sites: the protocol's own lengths x 10, the divergence of a 1 M-tip tree the authors' own runs have)
+        inp = stage.gen("dc1m" if L == 400 else "dc1m_%d" % L, n, L, args.seed + 9, 2e-3 if L == 400 else 2e-4, 2e-4 if L == 400 else 2e-5, 2e-2 if L == 400 else 2e-3,
+                        shuffle=7, gap=None if args.no_indel_gaps else args.gap_frac)   # the CLI shuffles its input (src/tree_generation.cu:341-344)
         packed = Stage.packed4(inp)
         d = dipper_amd.Dipper(local_rank)
         try:
@@ -953,7 +1015,7 @@ def other_configs(args, local_rank, stage, budget, tmp):
             st = d.dc_run(capi.SRC_MSA, n, n // 20, dist_type=capi.DIST_JC)
             wall = time.perf_counter() - t0
             out = {"workload": "configs[3] on one GPU: divide-and-conquer, %d aligned tips x %d sites, backbone %d, packed tips in HBM -> tree arrays" % (n, L, n // 20),
-                   "tips": n, "seconds": wall, "tips_per_s": n / wall,
+                   "tips": n, "sites": L, "protocol_length": L >= 10000, "seconds": wall, "tips_per_s": n / wall,
                    "device_s": (st["stats"]["backbone_ms"] + st["stats"]["assign_ms"] + st["stats"]["cluster_ms"]) * 1e-3,
                    "note": "seconds includes copying the tree arrays and closest lists (0.5 GB) back to the host",
                    "stats": {k: (float(v) if isinstance(v, float) else int(v)) for k, v in st["stats"].items()}}
@@ -963,17 +1025,21 @@ def other_configs(args, local_rank, stage, budget, tmp):
             order = np.fromfile(inp["order"], dtype=np.int32)
             names = ["T%d" % (k + 1) for k in order]
             out["nrf_vs_generating_tree"] = nrf_of(inp["tree"], _util.newick_from_placement(names, st["head"], st["e"], st["nxt"], st["len"], n, fmt=repr), tmp, "dc1m")
+        del packed
+        if L != 400:
+            stage.drop(inp)          # (5 GB of packed tips; the 400-site input is kept for the multi-rank leg)
         return out
 
-    def add_onto_backbone(kind):
+    def add_onto_backbone(kind, L=None, m=None, nq=None):
         """BASELINE configs[4]: 50 000 queries added to a 500 000-tip backbone (src/placement_close_k.cu:858-990 addQuery,
         :126-264 initializeDeviceArrays) through the `dipper` command itself -- the backbone tree is the command's own
         divide-and-conquer tree of the first 500 000 records (untimed set-up), the timed step is
         `dipper -a -t backbone.nwk -I all.fa`.  kind "m": aligned input (-i m -d 2), "r": unaligned reads through Mash (-i r)."""
-        m, nq = args.add_backbone, args.add_queries
+        m, nq = m or args.add_backbone, nq or args.add_queries
         n = m + nq
-        L = 1000 if kind == "m" else 3000
-        inp = stage.gen("add_%s" % kind, n, L, args.seed + (10 if kind == "m" else 11), 1e-3, 1e-4, 1e-2, fasta=True, reads=(kind == "r"), shuffle=7,
+        L = L or (1000 if kind == "m" else 3000)
+        scale = 1000.0 / L if kind == "m" else 1.0      # (aligned: the same expected substitutions per branch at every length)
+        inp = stage.gen("add_%s_%d_%d" % (kind, L, n), n, L, args.seed + (10 if kind == "m" else 11), 1e-3 * scale, 1e-4 * scale, 1e-2 * scale, fasta=True, reads=(kind == "r"), shuffle=7,
                         gap=(None if args.no_indel_gaps else args.gap_frac) if kind == "m" else None)
         fa_all = inp["fasta"]
         # the first m records as their own file (the backbone's tips)
@@ -1000,7 +1066,7 @@ def other_configs(args, local_rank, stage, budget, tmp):
         ph = cli_phases(r.stderr)
         out = {"workload": "configs[4] on one GPU: %d queries added to a %d-tip backbone, %s; the whole `dipper -a -t backbone.nwk` command "
                            "(FASTA of all %d records in, Newick out)" % (nq, m, "aligned x %d sites, -d 2" % L if kind == "m" else "unaligned reads x ~%d bases through Mash" % L, n),
-               "backbone": m, "queries": nq, "seconds": wall, "queries_per_s": nq / wall, "phases_ms": ph,
+               "backbone": m, "queries": nq, ("sites" if kind == "m" else "bases"): L, "protocol_length": L >= 10000, "seconds": wall, "queries_per_s": nq / wall, "phases_ms": ph,
                "addquery_s": (ph["distance_ms"] + ph["tree_op_ms"]) * 1e-3 if ("distance_ms" in ph and "tree_op_ms" in ph) else None,
                "note": "seconds = the whole command (FASTA parse of all records, packing, sketches, backbone import, addQuery, Newick write); addquery_s = the "
                        "command's own `Distance Operation Time` + `Tree Operation Time` lines (src/placement_close_k.cu:985-986)",
@@ -1012,14 +1078,34 @@ def other_configs(args, local_rank, stage, budget, tmp):
                 pass
         if budget.allows(40):
             out["nrf_vs_generating_tree"] = nrf_of(inp["tree"], out_nwk, tmp, "add_%s" % kind)
+        for f in (bb_nwk, out_nwk):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+        stage.drop(inp)
         return out
 
-    leg("nj_100k", nj_100k, 30)
-    leg("place_100k_unaligned", place_100k_unaligned, 25)
-    leg("dc_1m", dc_1m, 30)
+    # keys carry the sequence length: the authors' protocol is 10 000 sites for every size (scripts/experiment.sh:14,
+    # scripts/alisim.sh:14); the short inputs of rounds 2-5 stay beside the protocol-length ones
+    leg("nj_100k_10000_sites", nj_100k, 30)
+    leg("place_100k_unaligned_3000_bases", place_100k_unaligned, 25)
+    leg("dc_1m_400_sites", dc_1m, 30)
     if not args.no_add_leg:
-        leg("add_50k_onto_500k_aligned", lambda: add_onto_backbone("m"), 45)
-        leg("add_50k_onto_500k_mash", lambda: add_onto_backbone("r"), 75)
+        leg("add_50k_onto_500k_aligned_1000_sites", lambda: add_onto_backbone("m"), 45)
+        leg("add_50k_onto_500k_mash_3000_bases", lambda: add_onto_backbone("r"), 75)
+    if not args.no_protocol_length:
+        leg("place_100k_unaligned_10000_bases", lambda: place_100k_unaligned(10000), 40)
+        if stage.room_for(12 << 30):
+            leg("dc_1m_10000_sites", lambda: dc_1m(10000), 90)
+        else:
+            rec["dc_1m_10000_sites"] = {"skipped": "less than 12 GB of staging space for the 5 GB of packed tips"}
+        if not args.no_add_leg:
+            if stage.room_for(16 << 30) and budget.allows(150):
+                leg("add_50k_onto_500k_aligned_10000_sites", lambda: add_onto_backbone("m", L=10000), 150)
+            else:
+                # (the 5.5 GB FASTA + 2.8 GB of packed tips, or the time, are not there: a size that fits, said so in the key)
+                leg("add_20k_onto_200k_aligned_10000_sites", lambda: add_onto_backbone("m", L=10000, m=200000, nq=20000), 70)
     return rec
 
 
@@ -1437,12 +1523,17 @@ def sharded_leg(args, rank, world, local_rank, dist, torch, barrier, stage, budg
     inp = stage.gen("nj100k", ns, Ls, args.seed + 7, 2e-5 * 10000 / Ls, 2e-6 * 10000 / Ls, 2e-4 * 10000 / Ls, gap=None if args.no_indel_gaps else args.gap_frac)
     packed = Stage.packed4(inp)
     if ONE_GPU and world > 1:
-        rec["unit_sharded_plan"] = {"skipped": "needs RCCL (rehearsal with process ranks on one GPU)"}
-        rec["dc_1m"] = {"skipped": "needs RCCL (rehearsal with process ranks on one GPU)"}
+        rec["unit_sharded_plan"] = {"skipped": "rehearsal with process ranks on ONE GPU: two 80 GB matrices per rank do not fit beside each other"}
         try:
             rec["nj_scaling"] = nj_scaling(args, rank, world, local_rank, dist, torch, barrier, packed, ns, Ls, max(8, args.stream_iters // 4), None, budget)
         except Exception as e:
             rec["nj_scaling"] = {"error": repr(e)}
+        del packed
+        # (the divide-and-conquer leg runs here too since round 6: the ranks' all-reduces go through the device windows of dpr_comm_init_shared)
+        try:
+            rec["dc_1m"] = dc_leg(args, rank, world, local_rank, dist, torch, barrier, stage)
+        except Exception as e:
+            rec["dc_1m"] = {"error": repr(e)}
         return rec
     d = dipper_amd.Dipper(local_rank)
     try:
@@ -1511,6 +1602,96 @@ def sharded_leg(args, rank, world, local_rank, dist, torch, barrier, stage, budg
     return rec
 
 
+def cli_ranks_leg(args, rank, world, local_rank, dist, stage, budget, tmp, main_fasta):
+    """The `dipper` COMMAND over this run's GPUs -- `dipper ... --devices 0,1,..,G-1`: the command forks one rank per GPU once its
+    input is read, the ranks join through a shared region (RCCL over xGMI with one rank per GPU; device windows over hipIpc when
+    DPR_BENCH_ONE_GPU=1 puts every rank on GPU 0) -- next to the same command on one GPU, for configs[1]-[4].  Rank 0 runs the
+    commands (the bench's other ranks wait); `newick_identical` = the two output files are the same bytes; `ranks` / `transport`
+    / `device_collectives` are the command's own closing line (ranks = ncclCommCount with RCCL)."""
+    rec = {"devices": "0" if world == 1 else ",".join(str(0 if ONE_GPU else r) for r in range(world))}
+    G = max(world, 2) if (ONE_GPU or world == 1) else world
+    if world == 1:
+        rec["devices"] = ",".join("0" for _ in range(G))      # (DPR_BENCH_CHECK on one GPU: two ranks share it)
+    devices = rec["devices"]
+
+    def one(name, fmt, make_input, need):
+        if not budget.allows_all(need):
+            rec[name] = budget.skip(need)
+            return
+        out = {}
+        if rank == 0:
+            try:
+                t0 = time.perf_counter()
+                fa, extra, note = make_input()
+                out["workload"] = note
+                out["setup_s"] = time.perf_counter() - t0
+                env = dict(os.environ, DPR_HOST_THREADS=str(host_cores()))
+                res = {}
+                for tag, dev in (("one_gpu", ["--device", "0"]), ("ranks", ["--devices", devices])):
+                    o = os.path.join(tmp, "%s_%s.nwk" % (name, tag))
+                    ts = time.perf_counter()
+                    r = subprocess.run([EXE] + fmt + extra + ["-I", fa, "-O", o] + dev, capture_output=True, text=True, env=env)
+                    wall = time.perf_counter() - ts
+                    if r.returncode != 0:
+                        raise RuntimeError("dipper %s (%s) failed: %s" % (name, tag, r.stderr[-400:]))
+                    res[tag] = (wall, o, r.stderr)
+                    out[tag + "_s"] = wall
+                    out[tag + "_phases_ms"] = cli_phases(r.stderr)
+                same = open(res["one_gpu"][1], "rb").read() == open(res["ranks"][1], "rb").read()
+                out["newick_identical"] = bool(same)
+                out["speedup"] = res["one_gpu"][0] / res["ranks"][0]
+                for line in res["ranks"][2].splitlines():
+                    if line.startswith("Ranks: "):
+                        out["ranks"] = int(line.split()[1])
+                        out["transport"] = line.split("transport ")[1].split(",")[0]
+                        out["device_collectives"] = int(line.split(", ")[1].split()[0])
+                    if line.startswith("NJ over "):
+                        out["nj_plan"] = line.split(": ", 1)[1]
+                for tag in res:
+                    os.unlink(res[tag][1])
+            except Exception as e:
+                out["error"] = repr(e)
+            log(f"[bench] cli_ranks.{name}: {out}")
+        if dist is not None:
+            dist.barrier()
+        rec[name] = out
+
+    def nj_input():
+        return main_fasta, [], "configs[1]: %d aligned tips x %d sites, -m 2 -d 2 (below 65 536 tips every rank runs the single-GPU plan: replicas)" % (args.tips, args.sites)
+
+    def place_input():
+        inp = stage.gen("cli_reads100k", 100000, 3000, args.seed + 8, 2e-5, 2e-6, 2e-4, fasta=True, reads=True)
+        return inp["fasta"], [], "configs[2]: 100 000 unaligned tips x ~3 000 bases, -i r -m 1 (distance rows of a batch sharded + one all-gather per batch)"
+
+    def dc_input():
+        n = args.dc_tips
+        inp = stage.gen("cli_dc1m", n, 400, args.seed + 9, 2e-3, 2e-4, 2e-2, fasta=True, gap=None if args.no_indel_gaps else args.gap_frac)
+        return inp["fasta"], [], "configs[3]: divide-and-conquer, %d aligned tips x 400 sites, -m 3 -d 2 (query shares + clusters dealt to the ranks, all-reduces)" % n
+
+    def add_input():
+        m, nq = args.add_backbone, args.add_queries
+        inp = stage.gen("cli_add", m + nq, 1000, args.seed + 10, 1e-3, 1e-4, 1e-2, fasta=True, shuffle=7, gap=None if args.no_indel_gaps else args.gap_frac)
+        buf = np.memmap(inp["fasta"], dtype=np.uint8, mode="r")
+        starts = np.flatnonzero(buf == ord(">"))
+        fa_bb = os.path.join(tmp, "cli_bb.fa")
+        with open(fa_bb, "wb") as f:
+            f.write(buf[:int(starts[m])].tobytes())
+        del buf, starts
+        bb = os.path.join(tmp, "cli_bb.nwk")
+        r = subprocess.run([EXE, "-i", "m", "-d", "2", "-m", "3", "-I", fa_bb, "-O", bb, "--device", "0"], capture_output=True, text=True)
+        os.unlink(fa_bb)
+        if r.returncode != 0:
+            raise RuntimeError("dipper (backbone) failed: " + r.stderr[-300:])
+        return inp["fasta"], ["-a", "-t", bb], "configs[4]: %d queries added to a %d-tip backbone, aligned x 1 000 sites, -a -t backbone.nwk (distance rows sharded + all-gathers)" % (nq, m)
+
+    if main_fasta:
+        one("nj_30k", ["-i", "m", "-m", "2", "-d", "2"], nj_input, 15)
+    one("place_100k_unaligned", ["-i", "r", "-m", "1"], place_input, 40)
+    one("dc_1m", ["-i", "m", "-m", "3", "-d", "2"], dc_input, 60)
+    one("add_50k_onto_500k_aligned", ["-i", "m", "-d", "2"], add_input, 70)
+    return rec
+
+
 def dc_leg(args, rank, world, local_rank, dist, torch, barrier, stage):
     import dipper_amd
     from dipper_amd import capi
@@ -1534,8 +1715,12 @@ def dc_leg(args, rank, world, local_rank, dist, torch, barrier, stage):
     d = dipper_amd.Dipper(local_rank)
     try:
         if world > 1:
-            rec["rccl_ranks"] = join_comm(d, rank, world, dist)
+            nr = join_comm(d, rank, world, dist)
+            rec["transport"] = d.comm_stats()[0]
+            rec["rccl_ranks" if rec["transport"] == "rccl" else "ranks_joined"] = nr      # (never a window run reported as RCCL ranks)
         wall, stats, digest = run(d, world > 1)
+        if world > 1:
+            rec["device_collectives"] = d.comm_stats()[1]
     finally:
         d.close()
     if world > 1:
