@@ -24,7 +24,8 @@ class DipperError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libdipper_hip.so")
+    # (DPR_LIB: another build of the library -- kernel-variant experiments under profiles/)
+    return os.environ.get("DPR_LIB") or os.path.join(_HERE, "libdipper_hip.so")
 
 
 def load_library():
@@ -116,6 +117,7 @@ def load_library():
     L.dpr_get_matrix_row.argtypes = [C.c_void_p, C.c_int64, c_f64p]
     L.dpr_get_row_sums.argtypes = [C.c_void_p, c_f64p]
     L.dpr_get_msa_counts.argtypes = [C.c_void_p, C.c_int64, c_i32p, c_i32p]
+    L.dpr_msa_dist_block.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, c_f64p, C.c_int, C.POINTER(C.c_float)]
     L.dpr_get_kmer_hashes.argtypes = [C.c_void_p, C.c_int64, C.c_int, c_u64p, c_u64p, c_u64p]
     L.dpr_get_place_state.argtypes = [C.c_void_p, c_i32p, c_f64p, c_f64p]
     L.dpr_get_timing.argtypes = [C.c_void_p, c_f64p, c_f64p]
@@ -586,6 +588,14 @@ class Dipper:
         out = np.zeros(self.n_total(), dtype=np.float64)
         _chk(self.L, self.L.dpr_get_row_sums(self.h, _p(out, c_f64p)))
         return out
+
+    def msa_dist_block(self, row0, nrows, ncols, dist_type=2, transposed=False, fetch=True, reps=1):
+        """(block or None, average milliseconds per launch)"""
+        out = np.zeros((ncols, nrows) if transposed else (nrows, ncols), dtype=np.float64) if fetch else None
+        ms = C.c_float()
+        _chk(self.L, self.L.dpr_msa_dist_block(self.h, row0, nrows, ncols, dist_type, 1 if transposed else 0,
+                                               _p(out, c_f64p) if fetch else None, reps, C.byref(ms)))
+        return out, ms.value
 
     def msa_counts(self, row):
         u = np.zeros(max(row, 1), dtype=np.int32)

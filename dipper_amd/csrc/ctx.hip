@@ -494,6 +494,37 @@ int dpr_get_msa_counts(dpr_ctx* c, int64_t row, int32_t* useful, int32_t* match)
     return rc;
 }
 
+// test / measurement hook: the distance block of tips [row0, row0 + nrows) against tips [0, ncols) through the launcher the
+// placement batches, --add and the divide-and-conquer assignment use (msa_dist_block_rows; MSADistConstructionRangeDC of
+// src/divide_and_conquer/msa.cu:321-372 computes the same block a row at a time).  out (optional, host): row-major
+// [nrows][ncols], or [ncols][nrows] when transposed; reps >= 1 launches, *ms_avg their average duration (HIP events).
+int dpr_msa_dist_block(dpr_ctx* c, int64_t row0, int64_t nrows, int64_t ncols, int dist_type, int transposed, double* out, int reps, float* ms_avg)
+{
+    if (!c || !c->msa.planes || row0 < 0 || nrows < 1 || row0 + nrows > c->msa.n || ncols < 1 || ncols > c->msa.n || reps < 1) { set_error("dpr_msa_dist_block: bad argument"); return DPR_ERR_ARG; }
+    DPR_HIP(hipSetDevice(c->device));
+    double* d = nullptr;
+    const int64_t ld = transposed ? nrows : ncols;
+    DPR_HIP(hipMalloc(&d, sizeof(double) * (size_t)(nrows * ncols)));
+    int rc = msa_dist_block_rows(c->msa, row0, nrows, 0, 0, ncols, dist_type, d, ld, c->stream, transposed != 0);      // warm
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (rc == DPR_OK && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = DPR_ERR_HIP;
+    if (rc == DPR_OK) {
+        (void)hipEventRecord(e0, c->stream);
+        for (int r = 0; r < reps && rc == DPR_OK; ++r) rc = msa_dist_block_rows(c->msa, row0, nrows, 0, 0, ncols, dist_type, d, ld, c->stream, transposed != 0);
+        (void)hipEventRecord(e1, c->stream);
+    }
+    if (rc == DPR_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = DPR_ERR_HIP;
+    float ms = 0;
+    if (rc == DPR_OK) (void)hipEventElapsedTime(&ms, e0, e1);
+    if (ms_avg) *ms_avg = ms / (float)reps;
+    if (rc == DPR_OK && out && hipMemcpy(out, d, sizeof(double) * (size_t)(nrows * ncols), hipMemcpyDeviceToHost) != hipSuccess) rc = DPR_ERR_HIP;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d);
+    if (rc == DPR_ERR_HIP) { (void)hipGetLastError(); set_error("dpr_msa_dist_block: HIP error"); }
+    return rc;
+}
+
 int dpr_get_timing(dpr_ctx* c, double* dist_ms, double* nj_ms)
 {
     if (!c) { set_error("dpr_get_timing: null ctx"); return DPR_ERR_ARG; }

@@ -363,9 +363,12 @@ struct MsaBuffers {
     // alignments of at most kMsaTabSites sites: the distance of every (useful, match) pair of counts, types 1 and 2 -- the same
     // function of the same two integers as the epilogue computes, read instead of recomputed (a division and a log per pair are
     // half of the pair kernel's instructions at 400 sites)
-    double* jc_tab = nullptr;    // [2][(L + 1) * (L + 1)]
+    double* jc_tab = nullptr;    // [2][(L + 1) * (L + 1)]; longer alignments: the band [2][kMsaBand + 1][L + 1] (useful = L - g)
+    // per sequence: bit j = its 16-word stage j holds a not-a-base position (gap, N, padding); stages from 63 on share bit 63
+    unsigned long long* xstage = nullptr;
 };
 constexpr int64_t kMsaTabSites = 1024;
+constexpr int kMsaBand = 15;
 int msa_upload(MsaBuffers& m, const uint64_t* packed4, int64_t n, int64_t L, hipStream_t s);
 void msa_free(MsaBuffers& m);
 int msa_dist_rows(const MsaBuffers& m, NjBuffers& b, int dist_type, hipStream_t s);

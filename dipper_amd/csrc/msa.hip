@@ -13,11 +13,30 @@
 // the reference's  (a<4 || b<4)  and  (a<4 && a==b)  counts exactly, in 7 instead of 8 integer
 // operations per word pair (xor, xor, xor, or3, popcount+add; and, popcount+add).
 // The kernel is integer-VALU/LDS bound; HBM only sees the N^2 fp64 output.
+//
+// Round 6 (tools/valu_probe.hip measured the instruction costs on gfx950: v_xor / v_and / v_or 2 cycles per wave instruction with
+// two or more waves per SIMD, v_bcnt_u32_b32 and v_or3_b32 -- VOP3 encodings -- 4.3): the 7-operation body costs 20.9 cycles per
+// 32 sites of 64 pairs, of which the not-a-base bookkeeping (Xa ^ Xb, Xa & Xb and its popcount) is 8.3.  It is skipped wherever no
+// sequence involved has a not-a-base position: mismatch = popc((LOa ^ LOb) | (HIa ^ HIb)), both_invalid += 0 -- the same counts,
+// 10.3 cycles.  Two levels: a 16-word STAGE in which no sequence of the tile has one (MsaBuffers::xstage, a bit per sequence and
+// stage) stages two planes per side instead of three; in the other stages each wavefront takes the short body for the WORDS in
+// which none of its 16 rows and none of the 64 columns has one (bit masks filled while staging).  A per-pair correction of listed
+// words was built and measured first: at two such words per sequence its scattered loads cost more than the bookkeeping it
+// replaced (25.5 against 16.1 ms per 5 120 x 50 000 block, profiles/r6/msa_block_variants.txt); not kept.
+// Staging moves four words per load (a thread owns one sequence and one word quad of every plane).  Distances
+// of pairs whose useful count is within kMsaBand of L come from a (L - useful, match) table built with the epilogue's own function
+// (the band of the (useful, match) table that short alignments use in full).
 #include "dpr_internal.hpp"
 
 namespace dpr {
 
 constexpr int kKC = 16;   // plane words (32 bases each) staged per step
+#ifndef MSA_UNROLL
+#define MSA_UNROLL 2
+#endif
+#ifndef MSA_WAVES
+#define MSA_WAVES 4      // waves per SIMD the pair kernels are compiled for (128 registers): a wave alone on its SIMD issues a vector
+#endif                   // instruction every 4 cycles, two ready ones every 2 (tools/valu_probe.hip); 182 registers -> 2 waves cost 18 %
 
 __global__ __launch_bounds__(kThreads) void msa_planes_kernel(const uint64_t* __restrict__ packed4,
                                                               int64_t n, int64_t L, int64_t W64,
@@ -135,12 +154,41 @@ struct PairCounts<DPR_DIST_JC> {
         asm("v_or3_b32 %0, %1, %2, %3" : "=v"(m) : "v"(lr ^ lxc), "v"(hr ^ hc), "v"(xr ^ xc));
         mism += __popc(m);
     }
+    // a word in which neither sequence has a not-a-base position (X = 0 on both sides, so LX = LO)
+    __device__ __forceinline__ void add_fast(uint32_t lr, uint32_t hr, uint32_t lc, uint32_t hc) { mism += __popc((lr ^ lc) | (hr ^ hc)); }
     __device__ __forceinline__ double value(int dist_type) const { return msa_epilogue(sites - binv, sites - mism, dist_type); }
+    // tab_ld > 0: the full (useful, match) table of a short alignment; tab_ld < 0: the band useful >= L - kMsaBand of a long one
+    // (L = -tab_ld - 1, rows of L + 1 entries indexed by L - useful)
     __device__ __forceinline__ double value(int dist_type, const double* tab, int tab_ld) const
     {
-        return tab ? tab[(int64_t)(sites - binv) * tab_ld + (sites - mism)] : value(dist_type);
+        if (!tab) return value(dist_type);
+        if (tab_ld > 0) return tab[(int64_t)(sites - binv) * tab_ld + (sites - mism)];
+        const int L = -tab_ld - 1, g = L - (sites - binv);
+        return (g >= 0 && g <= kMsaBand) ? tab[(int64_t)g * (L + 1) + (sites - mism)] : value(dist_type);
     }
 };
+// long alignments: the band useful = L - g, g = 0 .. kMsaBand, of that table: tab[type][g][match]
+__global__ __launch_bounds__(kThreads) void msa_jc_band_kernel(int L, double* __restrict__ tab)
+{
+    const int64_t ld = (int64_t)L + 1, i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= ld * (kMsaBand + 1)) return;
+    const int g = (int)(i / ld), match = (int)(i % ld);
+    tab[i] = msa_epilogue(L - g, match, DPR_DIST_UNCORRECTED);
+    tab[ld * (kMsaBand + 1) + i] = msa_epilogue(L - g, match, DPR_DIST_JC);
+}
+// per sequence: bit j = its 16-word stage j holds a not-a-base position (a gap, an N, the positions >= L of the last word, padding
+// words); stages from 63 on share bit 63.  One thread per sequence, once per upload.
+__global__ __launch_bounds__(kThreads) void msa_xstage_kernel(const uint32_t* __restrict__ planes, int64_t n, int64_t W32, int64_t L,
+                                                              unsigned long long* __restrict__ xstage)
+{
+    const int64_t s = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (s >= n) return;
+    const int64_t nst = (W32 + kKC - 1) / kKC;
+    unsigned long long bits = ((W32 % kKC) != 0 || (L % 32) != 0) ? (1ull << (nst - 1 < 63 ? nst - 1 : 63)) : 0ull;
+    for (int64_t k = 0; k < W32; ++k)
+        if (planes[(0 * n + s) * W32 + k] != 0u) { const int64_t st = k / kKC; bits |= 1ull << (st < 63 ? st : 63); }
+    xstage[s] = bits;
+}
 // (useful, match) -> distance for both types 1 and 2
 __global__ __launch_bounds__(kThreads) void msa_jc_table_kernel(int L, double* __restrict__ tab)
 {
@@ -157,6 +205,7 @@ template <> struct TileOf<DPR_DIST_JC> { static constexpr int SUB = 4; };       
 // What a block computes: up to PT row sequences x PT column sequences (ids in LDS, -1 = none) and
 // where the PT x PT tile of distances goes.
 constexpr int64_t kNoDiag = (int64_t)1 << 40;
+struct MsaSparseX { const unsigned long long* stage; };
 struct TileOut {
     double* out;        // element (r, c) of the tile -> out[r * ld + c]            (row-major target)
     int64_t ld;
@@ -167,8 +216,9 @@ struct TileOut {
     int64_t mir_ld;
     bool skip_main;     // only the transposed target is written
     int64_t diag;       // element (r, c) with r + diag == c is a tip against itself -> 0 (kNoDiag: none)
-    const double* tab;  // types 1-2, short alignments: distance by (useful, match), row stride tab_ld (nullptr: computed)
-    int tab_ld;
+    const double* tab;  // types 1-2: distance by (useful, match): tab_ld > 0 the full table of a short alignment (row stride tab_ld),
+    int tab_ld;         // tab_ld < 0 the band useful >= L - kMsaBand of a long one (L = -tab_ld - 1); nullptr: computed
+    const unsigned long long* xstage;   // types 1-2: per sequence, the stages that hold a not-a-base position (nullptr: every stage of every sequence)
 };
 
 // Block of 256 threads = 16 x 16; thread (ty,tx) owns rows ty*SUB.., cols tx*SUB..
@@ -187,6 +237,105 @@ __device__ __forceinline__ void msa_tile(const uint32_t* __restrict__ planes, in
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
     PairCounts<TYPE> acc[SUB][SUB];
+    if constexpr (TYPE == DPR_DIST_JC) {
+        // ---- types 1-2 (round 6): the not-a-base bookkeeping only where there is such a position.
+        // Tile level: a 16-word stage in which NO sequence of the tile has one stages two planes per side and runs the
+        // four-operation body throughout.  Word level: in the other stages every wavefront runs the seven-operation body only for
+        // the words in which one of ITS 16 rows or one of the 64 columns has one (s_xm: bit masks the staging threads fill) --
+        // with a few such positions per sequence hardly any stage is clean for all 128 sequences, but most words are for 80.
+        __shared__ unsigned long long s_slow;
+        __shared__ unsigned int s_xm[2][8];      // [stage parity][wavefront 0..3 = its rows | 4 = the columns]
+        if (tid == 0) s_slow = o.xstage ? 0ull : ~0ull;
+        if (tid < 16) s_xm[tid >> 3][tid & 7] = 0u;
+        __syncthreads();
+        if (o.xstage && tid < 2 * PT) {
+            const int id = tid < PT ? s_rid[tid] : s_cid[tid - PT];
+            const unsigned long long f = id >= 0 ? o.xstage[id] : 0ull;      // (a missing sequence's pairs are never written)
+            if (f) atomicOr(&s_slow, f);
+        }
+        __syncthreads();
+        const unsigned long long slow = s_slow;
+        // staging: thread -> (sequence sq, word quad kq) of every plane of both sides; one 16-byte load per plane
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+        const int sq = tid >> 2, kq = tid & 3, wave = tid >> 6;
+        const int64_t ga = s_rid[sq], gb = s_cid[sq];
+        int64_t st = 0;
+        for (int64_t k0 = 0; k0 < W32; k0 += kKC, ++st) {
+            const bool fast = !((slow >> (st < 63 ? st : 63)) & 1ull);
+            const int set = (int)(st & 1);
+            const int64_t k = k0 + 4 * kq;
+            const bool whole = k + 3 < W32;
+#pragma unroll
+            for (int p = fast ? 1 : 0; p < 3; ++p) {
+                const int pb = p == 1 ? 3 : p;                 // rows (X, LO, HI), columns (X, LX, HI); LX = LO where X = 0
+                u32x4 va, vb;
+                const uint32_t pad_a = p == 0 ? ~0u : 0u, pad_b = (p == 0 || pb == 3) ? ~0u : 0u;      // padding = not a base
+                va = (u32x4)(fast ? 0u : pad_a); vb = (u32x4)(fast ? 0u : pad_b);
+                if (whole) {
+                    if (ga >= 0) va = *reinterpret_cast<const u32x4*>(planes + ((int64_t)p * n + ga) * W32 + k);
+                    if (gb >= 0) vb = *reinterpret_cast<const u32x4*>(planes + ((int64_t)pb * n + gb) * W32 + k);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (k + j < W32 && ga >= 0) va[j] = planes[((int64_t)p * n + ga) * W32 + k + j];
+                        if (k + j < W32 && gb >= 0) vb[j] = planes[((int64_t)pb * n + gb) * W32 + k + j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { sA[p][4 * kq + j][sq] = va[j]; sB[p][4 * kq + j][sq] = vb[j]; }
+                if (p == 0) {      // which words of this stage hold a not-a-base position: per wavefront's rows, and for the columns
+                    unsigned int ma = 0, mb = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { ma |= (va[j] ? 1u : 0u) << (4 * kq + j); mb |= (vb[j] ? 1u : 0u) << (4 * kq + j); }
+                    if (ma) atomicOr(&s_xm[set][sq >> 4], ma);
+                    if (mb) atomicOr(&s_xm[set][4], mb);
+                }
+            }
+            __syncthreads();
+            if (tid < 8) s_xm[set ^ 1][tid] = 0u;              // (the other set: last read before the barrier that ended the previous stage)
+            const unsigned int xm = fast ? 0u : (unsigned int)__builtin_amdgcn_readfirstlane((int)(s_xm[set][wave] | s_xm[set][4]));
+            auto body_fast = [&](int kk) {
+                const uint4 aL = *reinterpret_cast<const uint4*>(&sA[1][kk][ty * 4]);
+                const uint4 aH = *reinterpret_cast<const uint4*>(&sA[2][kk][ty * 4]);
+                const uint4 bL = *reinterpret_cast<const uint4*>(&sB[1][kk][tx * 4]);
+                const uint4 bH = *reinterpret_cast<const uint4*>(&sB[2][kk][tx * 4]);
+                const uint32_t al[4] = { aL.x, aL.y, aL.z, aL.w }, ah[4] = { aH.x, aH.y, aH.z, aH.w };
+                const uint32_t bl[4] = { bL.x, bL.y, bL.z, bL.w }, bh[4] = { bH.x, bH.y, bH.z, bH.w };
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[r][c].add_fast(al[r], ah[r], bl[c], bh[c]);
+            };
+            auto body_slow = [&](int kk) {
+                const uint4 aV = *reinterpret_cast<const uint4*>(&sA[0][kk][ty * 4]);
+                const uint4 aL = *reinterpret_cast<const uint4*>(&sA[1][kk][ty * 4]);
+                const uint4 aH = *reinterpret_cast<const uint4*>(&sA[2][kk][ty * 4]);
+                const uint4 bV = *reinterpret_cast<const uint4*>(&sB[0][kk][tx * 4]);
+                const uint4 bL = *reinterpret_cast<const uint4*>(&sB[1][kk][tx * 4]);
+                const uint4 bH = *reinterpret_cast<const uint4*>(&sB[2][kk][tx * 4]);
+                const uint32_t av[4] = { aV.x, aV.y, aV.z, aV.w }, al[4] = { aL.x, aL.y, aL.z, aL.w }, ah[4] = { aH.x, aH.y, aH.z, aH.w };
+                const uint32_t bv[4] = { bV.x, bV.y, bV.z, bV.w }, bl[4] = { bL.x, bL.y, bL.z, bL.w }, bh[4] = { bH.x, bH.y, bH.z, bH.w };
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[r][c].add(av[r], al[r], ah[r], bv[c], bl[c], bh[c]);
+            };
+            // (two loops over the words of each kind, not a branch per word: a branch makes the sixteen pairs' counters meet
+            //  at a join after every word -- register copies that cost what the short body saves, measured)
+            if (xm == 0u) {
+#pragma unroll MSA_UNROLL
+                for (int kk = 0; kk < kKC; ++kk) body_fast(kk);
+            } else if (xm == 0xffffu) {
+#pragma unroll MSA_UNROLL
+                for (int kk = 0; kk < kKC; ++kk) body_slow(kk);
+            } else {
+                unsigned int mf = ~xm & 0xffffu, ms = xm & 0xffffu;
+                while (mf) { const int kk = __builtin_ctz(mf); mf &= mf - 1u; body_fast(kk); }
+                while (ms) { const int kk = __builtin_ctz(ms); ms &= ms - 1u; body_slow(kk); }
+            }
+            __syncthreads();
+        }
+    } else
     for (int64_t k0 = 0; k0 < W32; k0 += kKC) {
         // stage: 2 sides x 3 planes x PT seqs x 16 words; consecutive lanes read consecutive words of
         // one sequence (64-byte runs)
@@ -285,10 +434,11 @@ template <int TYPE> constexpr size_t msa_tile_lds()
 // against columns col0 + [0, ncols).  world == 1: only tiles on or below the diagonal are computed and
 // mirrored (counts are symmetric, src/MSA.cu:121-122).  transposed: out[(c - col0) * ld + l].
 template <int TYPE>
-__global__ __launch_bounds__(kThreads) void msa_dist_kernel(const uint32_t* __restrict__ planes, int64_t n, int64_t W32,
+__global__ __launch_bounds__(kThreads, MSA_WAVES) void msa_dist_kernel(const uint32_t* __restrict__ planes, int64_t n, int64_t W32,
                                                             int dist_type, double* __restrict__ D, int64_t ld,
                                                             int64_t rows_local, int rank, int world, int64_t row0,
-                                                            int64_t col0, int64_t ncols, int transposed, const double* __restrict__ tab, int tab_ld)
+                                                            int64_t col0, int64_t ncols, int transposed, const double* __restrict__ tab, int tab_ld,
+                                                            MsaSparseX xs)
 {
     constexpr int PT = 16 * TileOf<TYPE>::SUB;
     __shared__ __attribute__((aligned(16))) char smem[msa_tile_lds<TYPE>()];
@@ -311,7 +461,7 @@ __global__ __launch_bounds__(kThreads) void msa_dist_kernel(const uint32_t* __re
     o.nc = (int)(ncl - c0 < PT ? ncl - c0 : PT);
     o.lower_base = -1; o.r_org = 0; o.c_org = 0;
     o.diag = g0 - c0;
-    o.tab = tab; o.tab_ld = tab_ld;
+    o.tab = tab; o.tab_ld = tab_ld; o.xstage = xs.stage;
     if (transposed) {
         o.skip_main = true; o.out = nullptr; o.ld = 0;
         o.mir = D + (c0 - col0) * ld + l0; o.mir_ld = ld;
@@ -327,8 +477,9 @@ __global__ __launch_bounds__(kThreads) void msa_dist_kernel(const uint32_t* __re
 // rows = the cluster's members, columns = its leaf list (ids, -1 = empty); element (t, u) with
 // u < 10 + t goes to out[cl_out + t * cl_ld + u].
 template <int TYPE>
-__global__ __launch_bounds__(kThreads) void msa_dist_jobs_kernel(const uint32_t* __restrict__ planes, int64_t n,
-                                                                 int64_t W32, int dist_type, PairJobs J, const double* __restrict__ tab, int tab_ld)
+__global__ __launch_bounds__(kThreads, MSA_WAVES) void msa_dist_jobs_kernel(const uint32_t* __restrict__ planes, int64_t n,
+                                                                 int64_t W32, int dist_type, PairJobs J, const double* __restrict__ tab, int tab_ld,
+                                                                 MsaSparseX xs)
 {
     constexpr int PT = 16 * TileOf<TYPE>::SUB;
     __shared__ __attribute__((aligned(16))) char smem[msa_tile_lds<TYPE>()];
@@ -347,7 +498,7 @@ __global__ __launch_bounds__(kThreads) void msa_dist_jobs_kernel(const uint32_t*
     o.nc = ncols - u0 < PT ? ncols - u0 : PT;
     o.lower_base = kDcLeaves; o.r_org = t0; o.c_org = u0;
     o.diag = kNoDiag; o.skip_main = false;
-    o.tab = tab; o.tab_ld = tab_ld;
+    o.tab = tab; o.tab_ld = tab_ld; o.xstage = xs.stage;
     o.out = J.out + J.cl_out[ci] + (int64_t)t0 * J.cl_ld[ci] + u0; o.ld = J.cl_ld[ci];
     o.mir = nullptr; o.mir_ld = 0;
     msa_tile<TYPE>(planes, n, W32, dist_type, s_rid, s_cid, o, smem);
@@ -356,16 +507,18 @@ __global__ __launch_bounds__(kThreads) void msa_dist_jobs_kernel(const uint32_t*
 static const double* msa_jc_tab(const MsaBuffers& m, int dist_type)
 {
     if (!m.jc_tab) return nullptr;
-    return m.jc_tab + (dist_type == DPR_DIST_JC ? (m.L + 1) * (m.L + 1) : 0);
+    return m.jc_tab + (dist_type == DPR_DIST_JC ? (m.L + 1) * (m.L <= kMsaTabSites ? m.L + 1 : kMsaBand + 1) : 0);
 }
+// row stride of the full table (short alignments), or -(L + 1) for the band table of a long one (PairCounts<JC>::value)
+static int msa_jc_tab_ld(const MsaBuffers& m) { return m.L <= kMsaTabSites ? (int)m.L + 1 : -((int)m.L + 1); }
 
 template <int TYPE>
 static int launch_matrix(dim3 grid, hipStream_t s, const uint32_t* planes, int64_t n, int64_t W32, int dist_type,
                          double* D, int64_t ld, int64_t rows, int rank, int world, int64_t row0, int64_t col0,
-                         int64_t ncols, int transposed, const double* tab, int tab_ld)
+                         int64_t ncols, int transposed, const double* tab, int tab_ld, MsaSparseX xs = MsaSparseX{ nullptr })
 {
     hipLaunchKernelGGL(msa_dist_kernel<TYPE>, grid, dim3(kThreads), 0, s, planes, n, W32, dist_type, D, ld, rows, rank,
-                       world, row0, col0, ncols, transposed, tab, tab_ld);
+                       world, row0, col0, ncols, transposed, tab, tab_ld, xs);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
@@ -377,7 +530,7 @@ static int msa_launch(int dist_type, hipStream_t s, const MsaBuffers& m, double*
     dim3 g((unsigned)((ncols + pt - 1) / pt), (unsigned)((rows + pt - 1) / pt));
     switch (dist_type) {
     case DPR_DIST_UNCORRECTED:
-    case DPR_DIST_JC:        return launch_matrix<DPR_DIST_JC>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed, msa_jc_tab(m, dist_type), (int)m.L + 1);
+    case DPR_DIST_JC:        return launch_matrix<DPR_DIST_JC>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed, msa_jc_tab(m, dist_type), msa_jc_tab_ld(m), MsaSparseX{ m.xstage });
     case DPR_DIST_TAJIMANEI: return launch_matrix<DPR_DIST_TAJIMANEI>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed, nullptr, 0);
     case DPR_DIST_K2P:       return launch_matrix<DPR_DIST_K2P>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed, nullptr, 0);
     case DPR_DIST_TAMURA:    return launch_matrix<DPR_DIST_TAMURA>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed, nullptr, 0);
@@ -393,11 +546,11 @@ int msa_dist_jobs(const MsaBuffers& m, int dist_type, const PairJobs& J, int njo
     if (njobs <= 0) return DPR_OK;
     switch (dist_type) {
     case DPR_DIST_UNCORRECTED:
-    case DPR_DIST_JC:        hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_JC>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J, msa_jc_tab(m, dist_type), (int)m.L + 1); break;
-    case DPR_DIST_TAJIMANEI: hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_TAJIMANEI>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J, (const double*)nullptr, 0); break;
-    case DPR_DIST_K2P:       hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_K2P>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J, (const double*)nullptr, 0); break;
-    case DPR_DIST_TAMURA:    hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_TAMURA>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J, (const double*)nullptr, 0); break;
-    case DPR_DIST_JINNEI:    hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_JINNEI>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J, (const double*)nullptr, 0); break;
+    case DPR_DIST_JC:        hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_JC>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J, msa_jc_tab(m, dist_type), msa_jc_tab_ld(m), MsaSparseX{ m.xstage }); break;
+    case DPR_DIST_TAJIMANEI: hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_TAJIMANEI>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J, (const double*)nullptr, 0, MsaSparseX{ nullptr }); break;
+    case DPR_DIST_K2P:       hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_K2P>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J, (const double*)nullptr, 0, MsaSparseX{ nullptr }); break;
+    case DPR_DIST_TAMURA:    hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_TAMURA>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J, (const double*)nullptr, 0, MsaSparseX{ nullptr }); break;
+    case DPR_DIST_JINNEI:    hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_JINNEI>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J, (const double*)nullptr, 0, MsaSparseX{ nullptr }); break;
     default: set_error("unknown distance type (valid: 1-6)"); return DPR_ERR_ARG;
     }
     DPR_HIP(hipGetLastError());
@@ -444,6 +597,16 @@ int msa_upload(MsaBuffers& m, const uint64_t* packed4, int64_t n, int64_t L, hip
         DPR_HIP(hipMalloc(&m.jc_tab, sizeof(double) * (size_t)(2 * cells)));
         hipLaunchKernelGGL(msa_jc_table_kernel, dim3((unsigned)((cells + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, (int)L, m.jc_tab);
         DPR_HIP(hipGetLastError());
+    } else if (L < (1 << 30) && !std::getenv("DPR_MSA_NO_BAND")) {
+        const int64_t cells = (L + 1) * (kMsaBand + 1);
+        DPR_HIP(hipMalloc(&m.jc_tab, sizeof(double) * (size_t)(2 * cells)));
+        hipLaunchKernelGGL(msa_jc_band_kernel, dim3((unsigned)((cells + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, (int)L, m.jc_tab);
+        DPR_HIP(hipGetLastError());
+    }
+    if (!std::getenv("DPR_MSA_NO_FAST")) {      // (the switch exists for the A/B runs of profiles/msa_block_bench.py and for the tests)
+        DPR_HIP(hipMalloc(&m.xstage, sizeof(unsigned long long) * (size_t)n));
+        hipLaunchKernelGGL(msa_xstage_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, (const uint32_t*)m.planes, n, m.W32, L, m.xstage);
+        DPR_HIP(hipGetLastError());
     }
     DPR_HIP(hipStreamSynchronize(s));
     DPR_HIP(hipFree(d_in));
@@ -454,6 +617,7 @@ void msa_free(MsaBuffers& m)
 {
     if (m.planes) (void)hipFree(m.planes);
     if (m.jc_tab) (void)hipFree(m.jc_tab);
+    if (m.xstage) (void)hipFree(m.xstage);
     m = MsaBuffers();
 }
 

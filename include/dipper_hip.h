@@ -294,6 +294,11 @@ int64_t dpr_n_total(dpr_ctx *ctx);
 int dpr_get_matrix_row(dpr_ctx *ctx, int64_t i, double *out /* n_total doubles */);
 int dpr_get_row_sums(dpr_ctx *ctx, double *out /* n_total doubles */);
 int dpr_get_msa_counts(dpr_ctx *ctx, int64_t row, int32_t *useful, int32_t *match /* row entries */);
+/* the distance block tips [row0, row0 + nrows) x tips [0, ncols) as the placement batches, --add and the divide-and-conquer
+ * assignment compute it (MSADistConstructionRangeDC, src/divide_and_conquer/msa.cu:321-372, a row per launch there); out
+ * (optional): [nrows][ncols], or [ncols][nrows] when transposed; *ms_avg: average duration of `reps` launches (HIP events) */
+int dpr_msa_dist_block(dpr_ctx *ctx, int64_t row0, int64_t nrows, int64_t ncols, int dist_type, int transposed, double *out,
+                       int reps, float *ms_avg);
 /* MurmurHash3 value of every k-mer position of read `seq` (len-k+1 values), sketch kernel's hash path */
 int dpr_get_kmer_hashes(dpr_ctx *ctx, int64_t seq, int k, const uint64_t *word_off, const uint64_t *len,
                         uint64_t *out);

@@ -156,6 +156,61 @@ def test_msa_dist_and_nj(gpu, orc, n, L, inv):
             assert np.array_equal(res["bl_x"], ref["bl_x"]) and np.array_equal(res["bl_y"], ref["bl_y"])
 
 
+def test_msa_fast_stages_band_table_and_block_hook_equal_the_plain_kernel(gpu, orc):
+    """Round 6: per 16-word stage of a tile the pair kernel skips the not-a-base bookkeeping when no sequence of the tile has such a
+    position there, and distances of pairs with useful >= L - 15 come from a band table (msa.hip).  An alignment of 2 300 sites in
+    which gaps sit in SOME stages of SOME sequences (runs inside one stage, a run across a stage boundary, a tip that is all
+    gaps, 40 tips with an unknown base each in different stages, everything else clean): every type-1 / type-2 distance must equal
+    the kernel with both switched off (DPR_MSA_NO_FAST / DPR_MSA_NO_BAND) bit for bit, the oracle's at rtol 1e-11, and the block
+    hook (the launcher of placement batches, --add and the divide-and-conquer assignment) must return the same numbers in both
+    orientations."""
+    import os
+    from dipper_amd import capi
+    n, L = 400, 2300
+    rng = np.random.default_rng(66)
+    seqs = [bytearray(q) for q in _util.synth_alignment(rng, n, L, mean_bl=4e-3, lo=1e-4, hi=4e-2)]
+    seqs[3][100:140] = b"-" * 40                 # inside stage 0 (512 sites per stage)
+    seqs[70][500:530] = b"N" * 30                # across the boundary of stages 0 and 1
+    seqs[71][1024:1030] = b"-" * 6
+    seqs[200] = bytearray(b"-" * L)              # a DENSE tip (every stage): p = 1 against everything
+    seqs[201] = bytearray(b"-" * L)              # ... and useful = 0 against tip 200: NaN
+    for k in range(0, 2000, 100):                # a tip with 20 listed-word candidates: dense too, in scattered stages
+        seqs[150][k] = ord("N")
+    for t in range(40):
+        seqs[260 + t][(t * 57) % L] = ord("n")
+    seqs[399][L - 1] = ord("-")                  # the last site
+    seqs = [bytes(q) for q in seqs]
+    packed = capi.pack4_many(seqs)
+    got = {}
+    for tag, env in (("fast", {}), ("plain", {"DPR_MSA_NO_FAST": "1", "DPR_MSA_NO_BAND": "1"})):
+        os.environ.update(env)
+        try:
+            gpu.set_msa(packed, L)
+            for dt in (capi.DIST_UNCORRECTED, capi.DIST_JC):
+                gpu.dist_matrix(capi.SRC_MSA, dt)
+                got[tag, dt] = gpu.matrix()
+                if tag == "fast":
+                    blk, _ = gpu.msa_dist_block(130, 200, 330, dist_type=dt)
+                    blk_t, _ = gpu.msa_dist_block(130, 200, 330, dist_type=dt, transposed=True)
+                    sub = got[tag, dt][130:330, :330].copy()
+                    sub[np.arange(200), np.arange(130, 330)] = blk[np.arange(200), np.arange(130, 330)]      # (the hook has no diagonal rule)
+                    assert np.array_equal(blk, sub, equal_nan=True) and np.array_equal(blk_t, sub.T, equal_nan=True)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    gpu.set_msa(packed, L)
+    for dt in (capi.DIST_UNCORRECTED, capi.DIST_JC):
+        assert np.array_equal(got["fast", dt], got["plain", dt], equal_nan=True)
+        ref = orc.msa_dist_lower(packed, L, dt)
+        lo = np.tril_indices(n, -1)
+        a, b = got["fast", dt][lo], ref[lo]
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        ok = np.isfinite(b)
+        assert np.allclose(a[ok], b[ok], rtol=1e-11, atol=1e-300)
+    u_ref, m_ref = orc.msa_counts(packed, L)
+    assert (u_ref[np.tril_indices(n, -1)] == L).mean() > 0.7          # most pairs are clean: the band table's first row
+
+
 def test_msa_short_alignment_table_equals_computed_epilogue(gpu):
     """alignments of at most 1 024 sites read the type-1 / type-2 distance of a (useful, match) count pair from a table filled with the
     epilogue function itself (msa.hip, msa_jc_table_kernel).  Appending columns of gaps leaves every count unchanged but takes the
