@@ -1619,10 +1619,16 @@ def cli_ranks_leg(args, rank, world, local_rank, dist, stage, budget, tmp, main_
             rec[name] = budget.skip(need)
             return
         out = {}
+        t0 = time.perf_counter()
+        try:
+            fa, prep, note = make_input()        # (collective: rank 0 generates, every rank waits inside stage.gen)
+        except Exception as e:
+            fa, prep, note = None, None, "input failed: %r" % (e,)
         if rank == 0:
             try:
-                t0 = time.perf_counter()
-                fa, extra, note = make_input()
+                if fa is None:
+                    raise RuntimeError(note)
+                extra = prep() if prep else []
                 out["workload"] = note
                 out["setup_s"] = time.perf_counter() - t0
                 env = dict(os.environ, DPR_HOST_THREADS=str(host_cores()))
@@ -1630,7 +1636,7 @@ def cli_ranks_leg(args, rank, world, local_rank, dist, stage, budget, tmp, main_
                 for tag, dev in (("one_gpu", ["--device", "0"]), ("ranks", ["--devices", devices])):
                     o = os.path.join(tmp, "%s_%s.nwk" % (name, tag))
                     ts = time.perf_counter()
-                    r = subprocess.run([EXE] + fmt + extra + ["-I", fa, "-O", o] + dev, capture_output=True, text=True, env=env)
+                    r = subprocess.run([EXE] + fmt + extra + ["-I", fa, "-O", o] + dev, capture_output=True, text=True, env=env, timeout=240)
                     wall = time.perf_counter() - ts
                     if r.returncode != 0:
                         raise RuntimeError("dipper %s (%s) failed: %s" % (name, tag, r.stderr[-400:]))
@@ -1657,32 +1663,35 @@ def cli_ranks_leg(args, rank, world, local_rank, dist, stage, budget, tmp, main_
         rec[name] = out
 
     def nj_input():
-        return main_fasta, [], "configs[1]: %d aligned tips x %d sites, -m 2 -d 2 (below 65 536 tips every rank runs the single-GPU plan: replicas)" % (args.tips, args.sites)
+        return main_fasta, None, "configs[1]: %d aligned tips x %d sites, -m 2 -d 2 (below 65 536 tips every rank runs the single-GPU plan: replicas)" % (args.tips, args.sites)
 
     def place_input():
         inp = stage.gen("cli_reads100k", 100000, 3000, args.seed + 8, 2e-5, 2e-6, 2e-4, fasta=True, reads=True)
-        return inp["fasta"], [], "configs[2]: 100 000 unaligned tips x ~3 000 bases, -i r -m 1 (distance rows of a batch sharded + one all-gather per batch)"
+        return inp["fasta"], None, "configs[2]: 100 000 unaligned tips x ~3 000 bases, -i r -m 1 (distance rows of a batch sharded + one all-gather per batch)"
 
     def dc_input():
         n = args.dc_tips
         inp = stage.gen("cli_dc1m", n, 400, args.seed + 9, 2e-3, 2e-4, 2e-2, fasta=True, gap=None if args.no_indel_gaps else args.gap_frac)
-        return inp["fasta"], [], "configs[3]: divide-and-conquer, %d aligned tips x 400 sites, -m 3 -d 2 (query shares + clusters dealt to the ranks, all-reduces)" % n
+        return inp["fasta"], None, "configs[3]: divide-and-conquer, %d aligned tips x 400 sites, -m 3 -d 2 (query shares + clusters dealt to the ranks, all-reduces)" % n
 
     def add_input():
         m, nq = args.add_backbone, args.add_queries
         inp = stage.gen("cli_add", m + nq, 1000, args.seed + 10, 1e-3, 1e-4, 1e-2, fasta=True, shuffle=7, gap=None if args.no_indel_gaps else args.gap_frac)
-        buf = np.memmap(inp["fasta"], dtype=np.uint8, mode="r")
-        starts = np.flatnonzero(buf == ord(">"))
-        fa_bb = os.path.join(tmp, "cli_bb.fa")
-        with open(fa_bb, "wb") as f:
-            f.write(buf[:int(starts[m])].tobytes())
-        del buf, starts
-        bb = os.path.join(tmp, "cli_bb.nwk")
-        r = subprocess.run([EXE, "-i", "m", "-d", "2", "-m", "3", "-I", fa_bb, "-O", bb, "--device", "0"], capture_output=True, text=True)
-        os.unlink(fa_bb)
-        if r.returncode != 0:
-            raise RuntimeError("dipper (backbone) failed: " + r.stderr[-300:])
-        return inp["fasta"], ["-a", "-t", bb], "configs[4]: %d queries added to a %d-tip backbone, aligned x 1 000 sites, -a -t backbone.nwk (distance rows sharded + all-gathers)" % (nq, m)
+
+        def prep():          # rank 0: the backbone tree = the command's own divide-and-conquer tree of the first m records (untimed)
+            buf = np.memmap(inp["fasta"], dtype=np.uint8, mode="r")
+            starts = np.flatnonzero(buf == ord(">"))
+            fa_bb = os.path.join(tmp, "cli_bb.fa")
+            with open(fa_bb, "wb") as f:
+                f.write(buf[:int(starts[m])].tobytes())
+            del buf, starts
+            bb = os.path.join(tmp, "cli_bb.nwk")
+            r = subprocess.run([EXE, "-i", "m", "-d", "2", "-m", "3", "-I", fa_bb, "-O", bb, "--device", "0"], capture_output=True, text=True)
+            os.unlink(fa_bb)
+            if r.returncode != 0:
+                raise RuntimeError("dipper (backbone) failed: " + r.stderr[-300:])
+            return ["-a", "-t", bb]
+        return inp["fasta"], prep, "configs[4]: %d queries added to a %d-tip backbone, aligned x 1 000 sites, -a -t backbone.nwk (distance rows sharded + all-gathers)" % (nq, m)
 
     if main_fasta:
         one("nj_30k", ["-i", "m", "-m", "2", "-d", "2"], nj_input, 15)
