@@ -120,6 +120,7 @@ def load_library():
     L.dpr_msa_dist_block.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, c_f64p, C.c_int, C.POINTER(C.c_float)]
     L.dpr_get_kmer_hashes.argtypes = [C.c_void_p, C.c_int64, C.c_int, c_u64p, c_u64p, c_u64p]
     L.dpr_get_place_state.argtypes = [C.c_void_p, c_i32p, c_f64p, c_f64p]
+    L.dpr_get_place_walks.argtypes = [C.c_void_p, c_i32p, C.POINTER(C.c_int64)]
     L.dpr_get_timing.argtypes = [C.c_void_p, c_f64p, c_f64p]
     L.dpr_place_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                 c_i32p, c_i32p, c_i32p, c_i32p, c_f64p]
@@ -543,6 +544,18 @@ class Dipper:
             if "scan" in nm:
                 rec["scan_kernel"], rec["scan_us_avg"] = nm, float(us[i])
         return rec
+
+    def place_walks(self):
+        """(reached[n], dict(spilled, largest, total, degree_walks)) of the last placement run's closest-list walks"""
+        st = (C.c_int64 * 6)()
+        _chk(self.L, self.L.dpr_get_place_walks(self.h, None, st))
+        return dict(spilled=int(st[0]), largest=int(st[1]), total=int(st[2]), degree_walks=int(st[3]), full_eval_dirty=int(st[4]), full_eval_rescans=int(st[5]))
+
+    def place_walks_per_tip(self, n):
+        out = np.zeros(n, dtype=np.int32)
+        st = (C.c_int64 * 6)()
+        _chk(self.L, self.L.dpr_get_place_walks(self.h, _p(out, c_i32p), st))
+        return out
 
     def place_timing(self):
         a = C.c_double()

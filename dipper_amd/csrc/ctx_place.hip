@@ -296,6 +296,7 @@ int dpr_place_run(dpr_ctx* c, int source, int dist_type, int k, int64_t first, i
     if (c->place_trace) { (void)hipFree(c->place_trace); c->place_trace = nullptr; }
     DPR_HIP(hipMalloc(&c->place_trace, sizeof(double) * (size_t)(3 * n)));
     DPR_HIP(hipMemsetAsync(c->place_trace, 0, sizeof(double) * (size_t)(3 * n), c->stream));
+    DPR_HIP(hipMemsetAsync(p.misc + 2, 0, 2 * sizeof(int32_t), c->stream));      // fallback counters of the four-tip launches (dpr_get_place_walks)
     if (first > 2) {
         DPR_HIP(hipMemcpyAsync(p.head, head, sizeof(int32_t) * (size_t)(2 * n), hipMemcpyHostToDevice, c->stream));
         DPR_HIP(hipMemcpyAsync(p.e, e, sizeof(int32_t) * (size_t)(8 * n), hipMemcpyHostToDevice, c->stream));
@@ -316,6 +317,13 @@ int dpr_place_run(dpr_ctx* c, int source, int dist_type, int k, int64_t first, i
     DPR_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
     c->nj_ms = ms;
     place_collect_dist_ms(c);
+    if (log_level("place") > 0) {
+        int64_t st[6] = { 0, 0, 0, 0, 0, 0 };
+        if (dpr_get_place_walks(c, nullptr, st) == DPR_OK)
+            std::fprintf(stderr, "[place] closest-list walks of %lld tips: %lld slots reached in all, largest walk %lld, %lld beyond the 2 048-entry LDS queue, %lld from a node of degree > 3; "
+                         "four-tip launches: %lld tips fell back to evaluating every slot (dirty set full), %lld (too many blocks to re-scan)\n",
+                         (long long)(n - first), (long long)st[2], (long long)st[1], (long long)st[0], (long long)st[3], (long long)st[4], (long long)st[5]);
+    }
     return DPR_OK;
 }
 
@@ -582,6 +590,40 @@ int dpr_get_dc_stats(dpr_ctx* c, int64_t* counts5, double* phase_ms3)
         counts5[3] = c->dc_stats.groups; counts5[4] = c->dc_stats.jobs;
     }
     if (phase_ms3) for (int i = 0; i < 3; ++i) phase_ms3[i] = c->dc_ms[i];
+    return DPR_OK;
+}
+
+// Per placed tip of the last placement run: how many slots its closest-list walk reached (updateClosestNodes,
+// src/placement_close_k.cu:86-124, serial there) beyond the two rounds the split applies in registers; negative = -(reached + 1):
+// the walk started at the new leaf because a node of degree > 3 lies behind the split edge (imported backbones only).  One
+// wavefront takes 64 queue entries per round trip, so a tip's update launch grows with this number: it is what the outliers of
+// place_update_kernel is made of.  The four-tip launch (place_update_multi_kernel) has a second kind: its speculative block
+// minima stand except where an earlier tip of the same launch changed an input (the "dirty" slots: the walks' slots and their
+// reverses); when those outgrow the set (2 048), or more than 128 blocks must be re-scanned, the launch evaluates EVERY slot itself --
+// milliseconds on a 500 000-tip tree.  stats6 (optional): tips whose walk left the 2 048-entry LDS queue, largest walk, sum over
+// the tips, tips that took the degree > 3 walk, tips of four-tip launches that fell back to the full evaluation because the dirty
+// set overflowed, ... because too many blocks had to be re-scanned.
+int dpr_get_place_walks(dpr_ctx* c, int32_t* reached /* n, or NULL */, int64_t* stats4)
+{
+    if (!c || !c->place.bfs_cnt) { set_error("dpr_get_place_walks: no placement state"); return DPR_ERR_STATE; }
+    DPR_HIP(hipStreamSynchronize(c->stream));
+    const int64_t n = c->place.N;
+    std::vector<int32_t> h((size_t)n);
+    DPR_HIP(hipMemcpy(h.data(), c->place.bfs_cnt, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    if (reached) std::copy(h.begin(), h.end(), reached);
+    if (stats4) {
+        stats4[0] = stats4[1] = stats4[2] = stats4[3] = 0;
+        int32_t misc[4] = { 0, 0, 0, 0 };
+        DPR_HIP(hipMemcpy(misc, c->place.misc, sizeof misc, hipMemcpyDeviceToHost));
+        stats4[4] = misc[2]; stats4[5] = misc[3];
+        for (int32_t v : h) {
+            const int64_t r = v < 0 ? -(int64_t)v - 1 : v;
+            if (r > 2048) ++stats4[0];
+            if (r > stats4[1]) stats4[1] = r;
+            stats4[2] += r;
+            if (v < 0) ++stats4[3];
+        }
+    }
     return DPR_OK;
 }
 

@@ -458,6 +458,7 @@ struct PlaceBuffers {
     int32_t* er_i = nullptr;     // [12][ecap]: cid of side 0 (0..4), of side 1 (5..9), slot of side 0 (10), slot of side 1 (11)
     int32_t* eidx = nullptr;     // [8N] slot -> 2 * edge + side
     int64_t ecap = 0;
+    int32_t* bfs_cnt = nullptr;  // [N] per placed tip: slots its closest-list walk reached beyond the two rounds the split applies (negative: -(n + 1), the walk of a node of degree > 3)
     int32_t* misc = nullptr;     // [0]: smallest live slot with belong < e (its tuple (0, 0, 2) competes for the first minimum); [1]: edge counter of an import
 };
 int place_alloc(PlaceBuffers& p, int64_t N, int64_t M = 0);   // M = 0: M = N

@@ -86,6 +86,9 @@ __device__ __forceinline__ void er_write_edge(const PlaceBuffers& p, int k, int 
     p.eidx[s0] = 2 * k; p.eidx[s1] = 2 * k + 1;
 }
 
+// (round 6: when a four-tip launch's earlier tips change more slots than the set holds -- or more than kRescanCap blocks must be
+//  re-scanned -- the launch evaluates all 2.2 M slots of a 500 000-tip tree itself: milliseconds.  Counted in misc[2] / misc[3]
+//  (dpr_get_place_walks); 0 of 50 000 queries on 500 000 tips, whose largest walk reaches 512 slots.)
 constexpr int kDirtyHash = 4096, kDirtyCap = 2048, kRescanCap = 128;
 struct DirtySet {          // slots whose evaluation inputs changed since the scan launch (LDS)
     int* hash;             // [kDirtyHash] open addressing, -1 = empty
@@ -179,9 +182,10 @@ __device__ __forceinline__ void bfs_pre_load(const PlaceBuffers& p, int sl, BfsP
     }
 }
 
+// returns the number of slots the walk reached (queue entries; the two rounds the split applies in registers are not in it)
 template <bool kRec>
-__device__ __forceinline__ void closest_update_wave_impl(const PlaceBuffers& p, int x, int ns, const DirtySet& ds, int32_t* sq_id, double* sq_dis,
-                                                         const BfsPre* pre = nullptr)
+__device__ __forceinline__ int closest_update_wave_impl(const PlaceBuffers& p, int x, int ns, const DirtySet& ds, int32_t* sq_id, double* sq_dis,
+                                                        const BfsPre* pre = nullptr)
 {
     const int lane = threadIdx.x & 63;
     int l = 0, r = ns;  // queue [l, r): the first ns entries are in sq_id / sq_dis (stored by a lane of this wavefront)
@@ -290,6 +294,7 @@ __device__ __forceinline__ void closest_update_wave_impl(const PlaceBuffers& p, 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
+    return r;
 }
 
 __device__ __forceinline__ void closest_update_wave(const PlaceBuffers& p, int x, int start_slot)
@@ -728,9 +733,11 @@ __device__ __forceinline__ void place_finish_and_update(const PlaceBuffers& p, c
     const unsigned long long tk2 = wall_clock64();
     if (bfs_ns < 0) {                       // (degree > 3 behind x or y) from the new leaf's only slot: outside -> middle
         if (lane == 0) { sq_id[0] = (int)edge_count + 2; sq_dis[0] = 0.0; }
-        closest_update_wave_impl<false>(p, placeId, 1, DirtySet{ nullptr, nullptr, nullptr }, sq_id, sq_dis);
+        const int reached = closest_update_wave_impl<false>(p, placeId, 1, DirtySet{ nullptr, nullptr, nullptr }, sq_id, sq_dis);
+        if (lane == 0) p.bfs_cnt[placeId] = -reached - 1;      // (negative: the walk of a node of degree > 3)
     } else if (bfs_ns > 0) {
-        closest_update_wave_impl<false>(p, placeId, 0, DirtySet{ nullptr, nullptr, nullptr }, sq_id, sq_dis, &pre);
+        const int reached = closest_update_wave_impl<false>(p, placeId, 0, DirtySet{ nullptr, nullptr, nullptr }, sq_id, sq_dis, &pre);
+        if (lane == 0) p.bfs_cnt[placeId] = reached;
     }
     if ((p.dbg & 4) && trace && lane == 0) {
         __builtin_amdgcn_s_waitcnt(0);
@@ -1062,6 +1069,7 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
         const int nres = s_nrescan;
         if (overflow || nres > kRescanCap) {
             // too much changed for the bookkeeping (small trees: every list still has room): scan everything here
+            if (tid == 0) atomicAdd(&p.misc[overflow ? 2 : 3], 1);
             badd = __builtin_inf(); bfrac = 0; bidx = 0x7fffffff; beid = 0; brev = -1;
             for (int sl = tid; sl < ec0; sl += nthr) {
                 double a, f; int e2, rv;
@@ -1114,9 +1122,11 @@ __global__ __launch_bounds__(kMultiMaxThreads) void place_update_multi_kernel(Pl
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 if (bfs_ns < 0) {            // (degree > 3 behind x or y) from the new leaf's only slot, outside -> middle, with distance 0
                     if (tid == 0) { sq_id[0] = ec0 + 2; sq_dis[0] = 0.0; }
-                    closest_update_wave_impl<true>(p, placeId, 1, ds, sq_id, sq_dis);
+                    const int reached = closest_update_wave_impl<true>(p, placeId, 1, ds, sq_id, sq_dis);
+                    if (tid == 0) p.bfs_cnt[placeId] = -reached - 1;
                 } else if (bfs_ns > 0) {     // from where the rounds done in registers got, records loaded ahead
-                    closest_update_wave_impl<true>(p, placeId, 0, ds, sq_id, sq_dis, &pre);
+                    const int reached = closest_update_wave_impl<true>(p, placeId, 0, ds, sq_id, sq_dis, &pre);
+                    if (tid == 0) p.bfs_cnt[placeId] = reached;
                 }
             }
         }
@@ -1158,6 +1168,8 @@ int place_alloc(PlaceBuffers& p, int64_t N, int64_t M)
     DPR_HIP(hipMemset(p.er_i, 0xff, sizeof(int32_t) * (size_t)(12 * p.ecap)));
     DPR_HIP(hipMemset(p.eidx, 0, sizeof(int32_t) * (size_t)(8 * N)));
     DPR_HIP(hipMemset(p.misc, 0, sizeof(int32_t) * 16));
+    DPR_HIP(hipMalloc(&p.bfs_cnt, sizeof(int32_t) * (size_t)(N + 64)));
+    DPR_HIP(hipMemset(p.bfs_cnt, 0, sizeof(int32_t) * (size_t)(N + 64)));
     DPR_HIP(hipMalloc(&p.q_id, sizeof(int32_t) * (size_t)(4 * N + 64)));      // BFS frontier: every slot at most once
     DPR_HIP(hipMalloc(&p.q_from, sizeof(int32_t) * (size_t)(2 * N + 64)));
     DPR_HIP(hipMalloc(&p.q_dis, sizeof(double) * (size_t)(4 * N + 64)));
@@ -1178,7 +1190,7 @@ int place_alloc(PlaceBuffers& p, int64_t N, int64_t M)
 void place_free(PlaceBuffers& p)
 {
     void* ptrs[] = { p.head, p.e, p.nxt, p.belong, p.rev, p.len, p.cid, p.cdis, p.q_id, p.q_from, p.q_dis, p.partials, p.partials_multi, p.cont,
-                     p.er_d, p.er_i, p.eidx, p.misc };
+                     p.er_d, p.er_i, p.eidx, p.misc, p.bfs_cnt };
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     p = PlaceBuffers();

@@ -330,6 +330,14 @@ int dpr_get_place_overlap(dpr_ctx *ctx, int *overlapped, double *dist_busy_ms);
  * DPR_PLACE_OVERLAP_ALWAYS=1: round 3's policy (every batch).  Results do not depend on it. */
 int dpr_get_place_policy(dpr_ctx *ctx, int64_t *batches, int64_t *overlapped_batches);
 
+/* Per placed tip of the last placement run: slots its closest-list walk reached (updateClosestNodes, src/placement_close_k.cu:
+ * 86-124) beyond the two rounds applied with the split; negative = -(reached + 1): the walk of a node of degree > 3 (imported
+ * backbones).  The update launch of a tip grows with it (64 queue entries per round trip): the outliers of those launches.
+ * stats6: tips whose walk left the 2 048-entry LDS queue, largest walk, sum, tips on the degree > 3 walk, and -- the second kind of
+ * outlier, four-tip launches only -- tips for which the launch evaluated EVERY slot itself because the set of slots changed by the
+ * launch's earlier tips overflowed / because more than 128 blocks had to be re-scanned.  DPR_LOG=place prints the six numbers. */
+int dpr_get_place_walks(dpr_ctx *ctx, int32_t *reached /* n entries or NULL */, int64_t *stats6);
+
 /* ---- exact placement mode: PlacementDeviceArrays::{allocateDeviceArrays,findPlacementTree}
  * (src/placement.cu:17-117,508-789), reached in the reference through `-m 0` with 30000 <= n < 1000000
  * (SURVEY 9.2).  Same inputs/outputs as dpr_place_run with first = 2; per tip the per-slot bounds come
