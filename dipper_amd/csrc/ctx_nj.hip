@@ -158,9 +158,13 @@ int dpr_dist_matrix(dpr_ctx* c, int source, int dist_type, int k)
         if (source == DPR_SRC_MSA) {
             if (int rc = msa_dist_rows(c->msa, b, dist_type, c->stream)) return rc;
         } else if (source == DPR_SRC_MASH) {
-            for (int64_t r0 = 0; r0 < b.rows_local; r0 += 32768) {
-                const int64_t nr = b.rows_local - r0 < 32768 ? b.rows_local - r0 : 32768;
-                if (int rc = mash_dist_rows(c->mash, r0, nr, b.rank, b.world, true, n, b.D + r0 * b.ld, b.ld, c->stream)) return rc;
+            if (b.world > 1) {
+                if (int rc = mash_dist_matrix_sharded(c->mash, b.rank, b.world, b.rows_local, b.D, b.ld, c->stream)) return rc;
+            } else {
+                for (int64_t r0 = 0; r0 < b.rows_local; r0 += 32768) {
+                    const int64_t nr = b.rows_local - r0 < 32768 ? b.rows_local - r0 : 32768;
+                    if (int rc = mash_dist_rows(c->mash, r0, nr, b.rank, b.world, true, n, b.D + r0 * b.ld, b.ld, c->stream)) return rc;
+                }
             }
         } else {
             if (int rc = nj_expand_lower(b, c->packed_lower, c->stream)) return rc;

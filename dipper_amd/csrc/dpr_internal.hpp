@@ -423,8 +423,10 @@ int mash_dist_jobs(const MashBuffers& m, const PairJobs& J, int njobs, hipStream
 // mash_index.hip
 int mash_index_build(MashBuffers& m, hipStream_t s);
 void mash_index_free(MashIndex& ix);
-int mash_dist_index(const MashBuffers& m, int64_t r0, int64_t nr, int64_t ncols, double* out, int64_t ld, bool mirror,
-                    bool transposed, hipStream_t s);
+int mash_dist_index(const MashBuffers& m, int64_t r0, int64_t nr, int64_t ncols, double* out, int64_t ld, double* mir,
+                    bool transposed, hipStream_t s, int rank, int world);
+// the whole Mash matrix of a rank whose rows are sharded by row blocks (world > 1): D_local holds its rows at full width
+int mash_dist_matrix_sharded(const MashBuffers& m, int rank, int world, int64_t rows_local, double* D_local, int64_t ld, hipStream_t s);
 int mash_jobs_rows();   // members per job
 int mash_jobs_cols();   // leaf-list positions per job
 int mash_hash_positions(const MashBuffers& m, int64_t seq, int k, uint64_t* d_out, uint64_t len, uint64_t word_off,

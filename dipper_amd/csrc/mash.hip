@@ -796,7 +796,11 @@ int mash_dist_rows(const MashBuffers& m, int64_t r0, int64_t nr, int rank, int w
     if (nr <= 0 || ncols <= 0) return DPR_OK;
     // lower-triangle pairs (placement batches; single-GPU NJ with a mirror write): token kernel while the sketches
     // resemble each other (at most 150 tokens per sketch on average, of up to S: the measured break-even with the table kernel), else the table kernel
-    const bool mirror = full && world == 1 && r0 == 0;
+    // (round 6: a row block that does not start at row 0 -- the whole matrix above 32 768 tips is built in such blocks -- mirrors
+    //  through the matrix base, out - r0 * ld; before, only the first block took the index / token / lookup kernels and the rest
+    //  the literal one, ~30 x slower)
+    const bool mirror = full && world == 1;
+    double* const mir = mirror ? out - r0 * ld : nullptr;
     const bool tokens_ok = m.tokens && m.tok_mean <= mash_tok_max();
     const bool use_index = m.index.post && mash_index_policy() != 0 && (mash_index_policy() == 1 || !(mash_tok_forced() && tokens_ok));
     // transposed output exists in the index, token and lookup kernels only: reject the call unless one of them WILL be
@@ -808,8 +812,8 @@ int mash_dist_rows(const MashBuffers& m, int64_t r0, int64_t nr, int rank, int w
         return DPR_ERR_ARG;
     }
     if (use_index && (!full || mirror) && world <= 1)
-        return mash_dist_index(m, r0, nr, ncols, out, ld, mirror, transposed, s);
-    if (tokens_ok && (!full || mirror) && world <= 1) {
+        return mash_dist_index(m, r0, nr, ncols, out, ld, mir, transposed, s, 0, 1);
+    if (tokens_ok && (!full || (mirror && r0 == 0)) && world <= 1) {
         // columns a wave walks through: 128 for a whole matrix, fewer when the launch has few row tiles (placement batches
         // of 256 rows), so that it still fills the chip (>= ~4096 waves) and no wave runs long after the others
         const int64_t tiles = (nr + 63) / 64;
@@ -821,7 +825,7 @@ int mash_dist_rows(const MashBuffers& m, int64_t r0, int64_t nr, int rank, int w
         DPR_HIP(hipGetLastError());
         return DPR_OK;
     }
-    if (m.S <= kLS && (!full || mirror) && world <= 1 && (transposed || mash_kernel_choice() != kMkLiteral)) {
+    if (m.S <= kLS && (!full || (mirror && r0 == 0)) && world <= 1 && (transposed || mash_kernel_choice() != kMkLiteral)) {
         if (int rc = lookup_attr()) return rc;
         const size_t tlds = kTLds;
         dim3 tgrid((unsigned)((ncols + kLColsPerBlock - 1) / kLColsPerBlock), (unsigned)((nr + kLRows - 1) / kLRows));
@@ -839,6 +843,40 @@ int mash_dist_rows(const MashBuffers& m, int64_t r0, int64_t nr, int rank, int w
         hipLaunchKernelGGL(mash_dist_rows_kernel<false>, grid, dim3(kThreads), lds, s, m.sketches, m.S, m.k, m.n,
                            r0, nr, rank, world, ncols, out, ld);
     DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+__global__ __launch_bounds__(kThreads) void mash_zero_diag_kernel(double* __restrict__ D, int64_t ld, int64_t rows_local, int rank, int world, int64_t n)
+{
+    const int64_t l = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (l >= rows_local) return;
+    const int64_t g = shard_global_row(l, rank, world);
+    if (g < n) D[l * ld + g] = 0.0;
+}
+
+// Whole matrix, rows sharded over `world` ranks by row blocks.  With the inverted index (the default) every rank walks ALL rows
+// against all column chunks and keeps the pairs of the rows it owns, direct and mirrored (mash_dist_index_kernel): the index
+// yields (row, chunk of columns below it), so the part of an own row above the diagonal only exists as the mirror of rows owned
+// by others -- redundant over the ranks, and still several times faster than the literal pair kernel on 1 / world of the pairs
+// (13 G against 0.4 G pairs per second).  Without the index: the literal kernel on the own rows, as before.
+int mash_dist_matrix_sharded(const MashBuffers& m, int rank, int world, int64_t rows_local, double* D_local, int64_t ld, hipStream_t s)
+{
+    const bool use_index = m.index.post && mash_index_policy() != 0;
+    if (!use_index) {
+        for (int64_t r0 = 0; r0 < rows_local; r0 += 32768) {
+            const int64_t nr = rows_local - r0 < 32768 ? rows_local - r0 : 32768;
+            if (int rc = mash_dist_rows(m, r0, nr, rank, world, true, m.n, D_local + r0 * ld, ld, s)) return rc;
+        }
+        return DPR_OK;
+    }
+    if (rows_local > 0) {
+        hipLaunchKernelGGL(mash_zero_diag_kernel, dim3((unsigned)((rows_local + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, D_local, ld, rows_local, rank, world, m.n);
+        DPR_HIP(hipGetLastError());
+    }
+    for (int64_t g0 = 0; g0 < m.n; g0 += 32768) {
+        const int64_t nr = m.n - g0 < 32768 ? m.n - g0 : 32768;
+        if (int rc = mash_dist_index(m, g0, nr, m.n, nullptr, ld, D_local, false, s, rank, world)) return rc;
+    }
     return DPR_OK;
 }
 

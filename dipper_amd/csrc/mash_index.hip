@@ -344,7 +344,7 @@ __global__ void mi_dtab_kernel(int S, int k, double* __restrict__ dtab)
 __global__ __launch_bounds__(64) void mash_dist_index_kernel(MashIndex ix, const uint64_t* __restrict__ sk, int S,
                                                              int64_t n, int64_t r0, int64_t nr, int64_t ncols,
                                                              int64_t cchunks, double* __restrict__ out, int64_t ld,
-                                                             int mirror, int transposed)
+                                                             double* __restrict__ mir, int transposed, int rank, int world)
 {
     __shared__ __attribute__((aligned(16))) uint16_t cnt[kIC];
     const int lane = threadIdx.x;
@@ -498,8 +498,16 @@ __global__ __launch_bounds__(64) void mash_dist_index_kernel(MashIndex ix, const
         if (j < lim) {
             const int x = (int)cnt[lane + 64 * m];
             const double d = ix.dtab[x > 1 ? x : 1];
-            if (transposed) out[j * ld + t] = d; else out[t * ld + j] = d;
-            if (mirror) out[j * ld + i] = d;
+            if (world > 1) {
+                // rows of a matrix sharded by row blocks: the pair (i, j), j < i, goes to row i where this rank owns it and, as
+                // (j, i), to row j where it owns that one (every rank walks every row: the index yields a row against a CHUNK of
+                // columns, so the pairs above the diagonal of an own row only come as mirrors of rows it does not own)
+                if (shard_owner(i, world) == rank) mir[shard_local_row(i, world) * ld + j] = d;
+                if (shard_owner(j, world) == rank) mir[shard_local_row(j, world) * ld + i] = d;
+            } else {
+                if (transposed) out[j * ld + t] = d; else out[t * ld + j] = d;
+                if (mir) mir[j * ld + i] = d;
+            }
         }
     }
     }
@@ -629,9 +637,11 @@ int mash_index_build(MashBuffers& m, hipStream_t s)
     return DPR_OK;
 }
 
-// rows r0 .. r0+nr x columns j < min(ncols, row): out[t*ld + j] (transposed: out[j*ld + t]); mirror: also out[j*ld + row]
-int mash_dist_index(const MashBuffers& m, int64_t r0, int64_t nr, int64_t ncols, double* out, int64_t ld, bool mirror,
-                    bool transposed, hipStream_t s)
+// rows r0 .. r0+nr x columns j < min(ncols, row): out[t*ld + j] (transposed: out[j*ld + t]); mir != nullptr: also mir[j*ld + row]
+// (the matrix base: the mirror of a row block that does not start at row 0 lands outside the block).  world > 1: mir = this
+// rank's row-sharded matrix; rows r0 .. r0+nr are GLOBAL rows, every rank walks all of them and keeps what it owns.
+int mash_dist_index(const MashBuffers& m, int64_t r0, int64_t nr, int64_t ncols, double* out, int64_t ld, double* mir,
+                    bool transposed, hipStream_t s, int rank, int world)
 {
     const MashIndex& ix = m.index;
     if (!ix.post) { set_error("mash_dist_index: no index"); return DPR_ERR_STATE; }
@@ -649,7 +659,7 @@ int mash_dist_index(const MashBuffers& m, int64_t r0, int64_t nr, int64_t ncols,
     if (m.share_chip && share_waves > 0 && blocks > 256ll * share_waves) blocks = 256ll * share_waves;
     const size_t pad = 0;
     hipLaunchKernelGGL(mash_dist_index_kernel, dim3((unsigned)blocks), dim3(64), pad, s, ix, m.sketches, m.S, m.n, r0, nr, ncols, cchunks,
-                       out, ld, mirror ? 1 : 0, transposed ? 1 : 0);
+                       out, ld, mir, transposed ? 1 : 0, rank, world);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }

@@ -331,3 +331,70 @@ def test_mash_index_kernel_edges(orc, monkeypatch, n, S, k):
             assert np.allclose(M[i, :i], ref, rtol=1e-12, atol=0), (i, np.nonzero(~np.isclose(M[i, :i], ref, rtol=1e-12, atol=0))[0][:5])
     finally:
         d.close()
+
+
+@pytest.mark.timeout(900)
+def test_mash_matrix_above_32768_tips_on_the_index_kernel(tmp_path, orc):
+    """`-i r -m 2` above 32 768 tips builds the matrix in row blocks of 32 768 (ctx_nj.hip); until round 6 only the first block took
+    the inverted-index kernel (its mirror write assumed the block starts at row 0) and the rest the literal pair kernel, ~30 x slower.
+    36 000 tips: sampled rows of both blocks against the oracle's merge (orc_mash_dist_row = mashDistConstruction,
+    src/mash.cu:426-455), symmetry across the block boundary, zero diagonal -- and the build takes index-kernel time."""
+    import time
+    import dipper_amd
+    from dipper_amd import capi
+    n = 36000
+    inp = _util.gen_synth(tmp_path, "r36k", n, 1200, 3, 2e-3, 2e-4, 2e-2, reads=True)
+    d = dipper_amd.Dipper(0)
+    try:
+        d.set_nj_mode(0)                   # plain slot-space matrix
+        d.set_reads_packed(*inp["reads"])
+        sk = d.sketch(15, 1000)
+        t0 = time.perf_counter()
+        d.dist_matrix(capi.SRC_MASH, 0, 15)
+        dt = time.perf_counter() - t0
+        rows = [1, 5, 700, 32767, 32768, 32769, 33000, 35999]
+        got = {i: d.matrix_row(i) for i in rows}
+        for i in rows:
+            ref = orc.mash_dist_row(sk, 15, i, i)
+            assert np.allclose(got[i][:i], ref, rtol=1e-12, atol=0), i
+            assert got[i][i] == 0.0
+        # the mirror of the second block's rows lives in the first block's rows and vice versa
+        r700, r33000 = got[700], got[33000]
+        assert r700[33000] == r33000[700] and r700[35999] == got[35999][700] and got[32767][32769] == got[32769][32767]
+        assert dt < 2.0, dt                # 6.5e8 pairs: ~0.1 s on the index kernel, > 1.5 s with the literal kernel on the second block
+    finally:
+        d.close()
+
+
+def test_mash_matrix_row_sharded_equals_single_rank():
+    """The Mash matrix of ranks that share it by row blocks (streaming NJ over several GPUs): every rank walks all rows on the
+    inverted index and keeps the pairs of the rows it owns, direct and mirrored (mash_dist_matrix_sharded).  Three virtual ranks:
+    every row == the single-rank matrix, and the sharded NJ run == the single-rank merge log."""
+    import dipper_amd
+    from dipper_amd import capi
+    rng = np.random.default_rng(77)
+    seqs = _reads(rng, 500, 1200, 2500)
+    n = len(seqs)
+    one = dipper_amd.Dipper(0)
+    try:
+        one.set_nj_mode(0)
+        one.set_reads(seqs)
+        one.sketch(k=15, S=1000, fetch=False)
+        one.dist_matrix(capi.SRC_MASH, 0, 15)
+        M1 = one.matrix()
+        ref = one.nj_run()
+    finally:
+        one.close()
+    sh = dipper_amd.Dipper(0, virtual_world=3)
+    try:
+        sh.set_nj_mode(0)
+        sh.set_reads(seqs)
+        sh.sketch(k=15, S=1000, fetch=False)
+        sh.dist_matrix(capi.SRC_MASH, 0, 15)
+        M3 = sh.matrix()
+        assert np.array_equal(M3, M1)
+        res = sh.nj_run()
+        for key in ("merge_x", "merge_y", "bl_x", "bl_y"):
+            assert np.array_equal(res[key], ref[key]), key
+    finally:
+        sh.close()
