@@ -477,6 +477,7 @@ struct XStep {                   // scalars of the last split (device), and the 
     int rrk, ysz, small;         // rank the new internal node takes (= old rank of y), size of y's subtree, last rank of the moved subtree
     int middle, outside;
     int nroot, ntop;
+    int poll_fail, poll_node, poll_pass;   // px_top_poll: a value never arrived (node on record, pass 0 bottom-up / 1 top-down): the run fails
     int quirk;                   // the reference's swap in updateTreeStructure was taken: its depths are no tree depths any more (see exact.hip)
 };
 struct ExactBuffers {
@@ -496,6 +497,8 @@ struct ExactBuffers {
     void* partials = nullptr;
     int32_t* dfsrk = nullptr;    // literal schedule: the reference's single rank array (alias of rk[0])
     bool literal = false;        // run the literal one-workgroup schedule (fallback / DPR_EXACT_LITERAL=1)
+    unsigned long long* clk = nullptr;   // DPR_EXACT_CLOCKS=1 (profiling): phase clocks of px_top_kernel, summed over the tips (100 MHz ticks)
+    bool top_levels = false;     // tests / A-B (DPR_EXACT_TOP_LEVELS=1): the top-tree pass level by level with a workgroup barrier per level (rounds 3-5)
     bool top_in_memory = false;  // tests (DPR_EXACT_TOP_MEM=1): the top-tree pass keeps its values in memory even when they fit LDS
 };
 int exact_alloc(ExactBuffers& x, int64_t N);

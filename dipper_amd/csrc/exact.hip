@@ -24,6 +24,7 @@ constexpr int kSm = 64;     // a "small" subtree has at most this many nodes: on
 constexpr int kTopLds = 6144;   // top nodes whose pass values fit the workgroup's LDS (2 x 8 bytes each)
 constexpr int kTopLevLds = 4094;   // levels of the top tree whose offsets fit LDS
 constexpr int kTopReg = 4;         // top nodes per thread whose contexts stay in registers over both passes
+constexpr unsigned long long kTopPollTicks = 20000000ull;      // 0.2 s of the 100 MHz clock: bound of one polling pass of px_top_poll
 
 struct PlacePartialX { double add; int32_t idx; int32_t eid; double frac; };
 
@@ -485,6 +486,7 @@ __global__ __launch_bounds__(256) void px_split_kernel(PlaceBuffers p, ExactBuff
     st.middle = middle; st.outside = outside;
     st.nroot = 0; st.ntop = 0;
     st.quirk = (x.st->quirk || quirk) ? 1 : 0;      // sticky: the host repeats the run with the literal schedule
+    st.poll_fail = x.st->poll_fail; st.poll_node = x.st->poll_node; st.poll_pass = x.st->poll_pass;      // sticky too (px_top_poll)
     x.dep[middle] = x.dep[xn]; x.dep[outside] = x.dep[middle] + 1;
     *x.st = st;
 }
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(kThreads) void px_patch_kernel(PlaceBuffers p, Exac
     if (threadIdx.x < 2 && s_cnt[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(threadIdx.x == 0 ? &x.st->nroot : &x.st->ntop, s_cnt[threadIdx.x]);
     __syncthreads();
     if (kind == 0) x.roots[s_base[0] + mine] = idx;
-    else if (kind == 1) x.tops[s_base[1] + mine] = idx;
+    else if (kind == 1) { x.tops[s_base[1] + mine] = idx; x.tix[idx] = s_base[1] + mine; }      // (tix: position in the top list, what px_top_kernel's contexts refer to)
 }
 
 __device__ __forceinline__ int wave_max_i32(int v)
@@ -636,6 +638,151 @@ __global__ __launch_bounds__(kThreads) void px_small_down_kernel(PlaceBuffers p,
 }
 
 // ------------------------------------------------------------------------------------------------
+// The top tree without level lists and without a barrier per level (round 6).  A node's bottom-up value is final once its
+// children's are, its top-down values once its parent's is: every thread keeps the contexts of its (at most R) top nodes in
+// registers and POLLS the LDS words of the values it waits for (a value is a maximum over terms >= 0, so -1 marks "not there
+// yet"); a node that has become ready is evaluated in the same iteration, and a wavefront none of whose nodes is ready only
+// runs the cheap check (two LDS reads per node) and yields its issue slots for a moment.  A level then costs the LDS round
+// trips of the wavefronts at the frontier instead of a 16-wavefront barrier, and the counting sort by depth that only fed the
+// level loop (maximum depth, histogram, scan, scatter: six barriers and global atomics) is gone -- a node's index is its position
+// in the top list (px_patch_kernel stores it in tix).  Same recurrences, same operands and the same order of the max() terms per
+// node as the level loops: lim[] bit for bit (tests/test_gpu_exact.py against the oracle, all three schedules).
+// R = nodes per thread: 1 up to 1 024 top nodes, 2 up to 2 048, else 4 (the loop bodies are unrolled R times).
+// ------------------------------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ void px_top_poll(const PlaceBuffers& p, const ExactBuffers& x, const double* __restrict__ dis, const int32_t* __restrict__ rk,
+                                            int T, double* up_l, double* in_l)
+{
+    const int tid = threadIdx.x;
+    struct RCtx { int slot[3]; int rf[3]; double len[3]; double cv[3]; };     // rf: -1 no edge; else (ref + 1) << 1 | down
+    RCtx rc[R];
+    const unsigned long long ck0 = wall_clock64();
+    unsigned long long* up_w = reinterpret_cast<unsigned long long*>(up_l);
+    unsigned long long* in_w = reinterpret_cast<unsigned long long*>(in_l);
+    const unsigned long long kNone = (unsigned long long)__double_as_longlong(-1.0);
+    for (int t = tid; t < T; t += kXT) { up_w[t] = kNone; in_w[t] = kNone; }
+#pragma unroll
+    for (int m = 0; m < R; ++m) {
+        const int t = tid + m * kXT;
+        const XCtx c = px_ctx(x, p, dis, rk, t < T ? x.tops[t] : -1, 0, true);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            rc[m].slot[k] = c.slot[k];
+            rc[m].rf[k] = c.slot[k] >= 0 ? (((c.ref[k] + 1) << 1) | (c.down[k] ? 1 : 0)) : -1;
+            rc[m].len[k] = c.len[k];
+            rc[m].cv[k] = (c.slot[k] >= 0 && c.down[k] && c.ref[k] < 0) ? x.lim[c.rslot[k]] : 0.0;    // child outside the top tree
+        }
+    }
+    __syncthreads();               // the marks are in place
+    if (x.clk) __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long ck1 = wall_clock64();
+    auto ld = [](const unsigned long long* w) { return __longlong_as_double((long long)__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); };
+    auto stv = [](unsigned long long* w, double v) { __hip_atomic_store(w, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    // ---- bottom-up: lim[node -> parent] = max(0, max over the child edges of lim[child -> node] - len)
+    unsigned pend = 0;
+#pragma unroll
+    for (int m = 0; m < R; ++m) pend |= (tid + m * kXT < T ? 1u : 0u) << m;
+    // (every poll is bounded: a value that never arrives -- a broken tree, a bug -- ends the launch with the stuck node on record
+    //  instead of hanging the device: status word x.st->poll_fail, checked by the host after the run)
+    const unsigned long long t_start = wall_clock64();
+    unsigned spins = 0;
+    // The loop condition is WAVE-UNIFORM (every lane stays until the whole wavefront is done): with `while (pend)` the compiler
+    // turned the R = 1 loop into "poll until ready, evaluate after the loop" -- a lane that is ready then waits at the loop exit
+    // for the lanes of its own wavefront that wait for ITS value: a parent and its child in one wavefront never finish
+    // (seen on hardware: the two top nodes of a 66-node tree).  Lanes without a pending node idle through the iterations.
+    while (__builtin_amdgcn_ballot_w64(pend != 0u) != 0ull) {
+        if ((++spins & 1023u) == 0u && wall_clock64() - t_start > kTopPollTicks) {      // (scalar clock: the whole wavefront leaves)
+            if (pend && atomicCAS(&x.st->poll_fail, 0, 1) == 0) { x.st->poll_node = x.tops[tid + (__builtin_ctz(pend)) * kXT]; x.st->poll_pass = 0; }
+            break;
+        }
+        unsigned rdy = 0;
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            if (!((pend >> m) & 1u)) continue;
+            bool ready = true;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (rc[m].rf[k] >= 0 && (rc[m].rf[k] & 1) && (rc[m].rf[k] >> 1) > 0) {      // a child inside the top tree
+                    const double v = ld(up_w + (rc[m].rf[k] >> 1) - 1);
+                    rc[m].cv[k] = v;                                   // (kept: the top-down pass needs the final value again)
+                    if (v < 0.0) ready = false;
+                }
+            if (ready) rdy |= 1u << m;
+        }
+        if (__builtin_amdgcn_ballot_w64(rdy != 0u) == 0ull) __builtin_amdgcn_s_sleep(1);      // (wave-uniform; no `continue`: structured flow around the ballot)
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            if (!((rdy >> m) & 1u)) continue;
+            double mx = 0.0;
+            int up = -1;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (rc[m].rf[k] >= 0) {
+                    if (rc[m].rf[k] & 1) { const double req = rc[m].cv[k] - rc[m].len[k]; if (req > mx) mx = req; }
+                    else up = rc[m].slot[k];
+                }
+            if (up >= 0) x.lim[up] = mx;
+            stv(up_w + tid + m * kXT, mx);
+        }
+        pend &= ~rdy;
+    }
+    if (x.clk) __syncthreads();
+    const unsigned long long ck2 = wall_clock64();
+    // ---- top-down: lim[node -> child] = max(0, max over the node's other edges of lim[other -> node] - len); a node's children's
+    // bottom-up values are final (its own is) and sit in cv; its parent's contribution arrives in in_l
+#pragma unroll
+    for (int m = 0; m < R; ++m) pend |= (tid + m * kXT < T ? 1u : 0u) << m;
+    spins = 0;
+    while (__builtin_amdgcn_ballot_w64(pend != 0u) != 0ull) {
+        if ((++spins & 1023u) == 0u && wall_clock64() - t_start > 2 * kTopPollTicks) {
+            if (pend && atomicCAS(&x.st->poll_fail, 0, 1) == 0) { x.st->poll_node = x.tops[tid + (__builtin_ctz(pend)) * kXT]; x.st->poll_pass = 1; }
+            break;
+        }
+        unsigned rdy = 0;
+        double inv[R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            inv[m] = 0.0;
+            if (!((pend >> m) & 1u)) continue;
+            const bool has_up = (rc[m].rf[0] >= 0 && !(rc[m].rf[0] & 1)) || (rc[m].rf[1] >= 0 && !(rc[m].rf[1] & 1)) || (rc[m].rf[2] >= 0 && !(rc[m].rf[2] & 1));
+            if (has_up) inv[m] = ld(in_w + tid + m * kXT);
+            if (!(inv[m] < 0.0)) rdy |= 1u << m;
+        }
+        if (__builtin_amdgcn_ballot_w64(rdy != 0u) == 0ull) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            if (!((rdy >> m) & 1u)) continue;
+            double rq[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double in = rc[m].rf[k] >= 0 ? ((rc[m].rf[k] & 1) ? rc[m].cv[k] : inv[m]) : 0.0;
+                rq[k] = rc[m].rf[k] >= 0 ? in - rc[m].len[k] : 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                if (rc[m].rf[a] >= 0 && (rc[m].rf[a] & 1)) {
+                    double mx = 0;
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+                        if (b != a && rc[m].rf[b] >= 0 && rq[b] > mx) mx = rq[b];
+                    x.lim[rc[m].slot[a]] = mx;
+                    const int ref = (rc[m].rf[a] >> 1) - 1;
+                    if (ref >= 0) stv(in_w + ref, mx);
+                }
+        }
+        pend &= ~rdy;
+    }
+    if (x.clk) {
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long ck3 = wall_clock64();
+            atomicAdd(&x.clk[0], ck1 - ck0); atomicAdd(&x.clk[1], ck2 - ck1); atomicAdd(&x.clk[2], ck3 - ck2);
+            atomicAdd(&x.clk[3], 1ull); atomicAdd(&x.clk[4], (unsigned long long)T);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // the top tree: level lists by counting sort on depth (replaces stable_sort_by_key :766 + updateLevelStEd :419-434; the
 // order inside a level is irrelevant to every result), then both passes level by level, one workgroup barrier per level;
 // values in LDS when the top tree fits (else in memory, as rounds 1-2 did for the whole tree)
@@ -647,11 +794,18 @@ __global__ __launch_bounds__(kXT) void px_top_kernel(PlaceBuffers p, ExactBuffer
     __shared__ int s_lv[kTopLevLds + 2];                                // level offsets (lists of at most kTopLevLds levels: else in memory)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int T = x.st->ntop;
-    if (T == 0) return;
+    if (T == 0 || x.st->poll_fail) return;      // (a poll of an earlier tip ran into its bound: the run has failed, its launches drain)
     const int32_t* __restrict__ rk = x.rk[par];
     const bool lds = T <= kTopLds && !x.top_in_memory;
     double* up_l = s_dyn;
     double* in_l = s_dyn + kTopLds;
+    if (lds && T <= kTopReg * kXT && !x.top_levels) {
+        // ---- round 6, the common case: NO level lists and NO barrier per level (px_top_poll above)
+        if (T <= kXT) px_top_poll<1>(p, x, dis, rk, T, up_l, in_l);
+        else if (T <= 2 * kXT) px_top_poll<2>(p, x, dis, rk, T, up_l, in_l);
+        else px_top_poll<kTopReg>(p, x, dis, rk, T, up_l, in_l);
+        return;
+    }
     int mymax = 0;
     for (int t = tid; t < T; t += kXT) mymax = max(mymax, x.dep[x.tops[t]]);
     mymax = wave_max_i32(mymax);
@@ -914,7 +1068,7 @@ __global__ void px_init_tree_kernel(PlaceBuffers p, ExactBuffers x, const double
     px_set_node(x, nv, 2, 0, 0, 3, 1, 1, -1, -1, -1);
     XStep st;
     st.rrk = 0; st.ysz = 0; st.small = 0; st.middle = -1; st.outside = -1;
-    st.nroot = 1; st.ntop = 0;
+    st.nroot = 1; st.ntop = 0; st.poll_fail = 0; st.poll_node = -1; st.poll_pass = 0;
     st.quirk = 0;
     x.roots[0] = nv;
     *x.st = st;
@@ -939,6 +1093,8 @@ int exact_alloc(ExactBuffers& x, int64_t N)
     DPR_HIP(hipMalloc(&x.nd, sizeof(int32_t) * (size_t)(12 * 2 * N)));
     x.dfsrk = x.rk[0];
     x.top_in_memory = std::getenv("DPR_EXACT_TOP_MEM") != nullptr;
+    x.top_levels = std::getenv("DPR_EXACT_TOP_LEVELS") != nullptr;
+    if (std::getenv("DPR_EXACT_CLOCKS")) { DPR_HIP(hipMalloc(&x.clk, 8 * sizeof(unsigned long long))); DPR_HIP(hipMemset(x.clk, 0, 8 * sizeof(unsigned long long))); }
     DPR_HIP(hipMalloc(&x.st, sizeof(XStep)));
     DPR_HIP(hipMemset(x.st, 0, sizeof(XStep)));
     DPR_HIP(hipMalloc(&x.partials, sizeof(PlacePartialX) * (size_t)((4 * N + kThreads - 1) / kThreads + 1)));
@@ -949,7 +1105,13 @@ int exact_alloc(ExactBuffers& x, int64_t N)
 
 void exact_free(ExactBuffers& x)
 {
-    void* ptrs[] = { x.lim, x.dep, x.rk[0], x.rk[1], x.sz[0], x.sz[1], x.nar, x.tix, x.roots, x.tops, x.order, x.lvoff, x.hist, x.partials, x.nd, x.st };
+    if (x.clk) {      // profiling: where px_top_kernel's time went, per tip
+        unsigned long long h[8] = { 0 };
+        if (hipMemcpy(h, x.clk, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[3] > 0)
+            std::fprintf(stderr, "[exact] px_top_kernel over %llu tips: %.1f top nodes; contexts %.2f us, bottom-up %.2f us, top-down %.2f us per tip\n", h[3],
+                         (double)h[4] / (double)h[3], h[0] * 0.01 / h[3], h[1] * 0.01 / h[3], h[2] * 0.01 / h[3]);
+    }
+    void* ptrs[] = { x.lim, x.dep, x.rk[0], x.rk[1], x.sz[0], x.sz[1], x.nar, x.tix, x.roots, x.tops, x.order, x.lvoff, x.hist, x.partials, x.nd, x.st, x.clk };
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     const bool literal = x.literal;
@@ -1018,6 +1180,11 @@ int exact_quirk(ExactBuffers& x, hipStream_t s, bool* quirk)
     DPR_HIP(hipMemcpyAsync(&st, x.st, sizeof(XStep), hipMemcpyDeviceToHost, s));
     DPR_HIP(hipStreamSynchronize(s));
     *quirk = st.quirk != 0;
+    if (st.poll_fail) {
+        set_error("exact placement: the top-tree pass waited for a value that never arrived (node " + std::to_string(st.poll_node) + ", " +
+                  (st.poll_pass ? "top-down" : "bottom-up") + " pass): internal error; DPR_EXACT_TOP_LEVELS=1 selects the level-by-level schedule");
+        return DPR_ERR_HIP;
+    }
     return DPR_OK;
 }
 
