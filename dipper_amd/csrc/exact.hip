@@ -646,7 +646,7 @@ __global__ __launch_bounds__(kThreads) void px_small_down_kernel(PlaceBuffers p,
 // trips of the wavefronts at the frontier instead of a 16-wavefront barrier, and the counting sort by depth that only fed the
 // level loop (maximum depth, histogram, scan, scatter: six barriers and global atomics) is gone -- a node's index is its position
 // in the top list (px_patch_kernel stores it in tix).  Same recurrences, same operands and the same order of the max() terms per
-// node as the level loops: lim[] bit for bit (tests/test_gpu_exact.py against the oracle, all three schedules).
+// node as the level loops: lim[] bit for bit (tests/test_gpu_exact.py runs all three schedules against the CPU restatement).
 // R = nodes per thread: 1 up to 1 024 top nodes, 2 up to 2 048, else 4 (the loop bodies are unrolled R times).
 // ------------------------------------------------------------------------------------------------
 template <int R>
