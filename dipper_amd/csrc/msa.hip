@@ -245,16 +245,20 @@ __device__ __forceinline__ void msa_tile(const uint32_t* __restrict__ planes, in
         // with a few such positions per sequence hardly any stage is clean for all 128 sequences, but most words are for 80.
         __shared__ unsigned long long s_slow;
         __shared__ unsigned int s_xm[2][8];      // [stage parity][wavefront 0..3 = its rows | 4 = the columns]
-        if (tid == 0) s_slow = o.xstage ? 0ull : ~0ull;
-        if (tid < 16) s_xm[tid >> 3][tid & 7] = 0u;
-        __syncthreads();
-        if (o.xstage && tid < 2 * PT) {
-            const int id = tid < PT ? s_rid[tid] : s_cid[tid - PT];
-            const unsigned long long f = id >= 0 ? o.xstage[id] : 0ull;      // (a missing sequence's pairs are never written)
-            if (f) atomicOr(&s_slow, f);
+        const bool track = o.xstage != nullptr;  // (nullptr: alignments of a single stage -- its last word is not-a-base for everybody -- and the A/B switch)
+        unsigned long long slow = ~0ull;
+        if (track) {
+            if (tid == 0) s_slow = 0ull;
+            if (tid < 16) s_xm[tid >> 3][tid & 7] = 0u;
+            __syncthreads();
+            if (tid < 2 * PT) {
+                const int id = tid < PT ? s_rid[tid] : s_cid[tid - PT];
+                const unsigned long long f = id >= 0 ? o.xstage[id] : 0ull;      // (a missing sequence's pairs are never written)
+                if (f) atomicOr(&s_slow, f);
+            }
+            __syncthreads();
+            slow = s_slow;
         }
-        __syncthreads();
-        const unsigned long long slow = s_slow;
         // staging: thread -> (sequence sq, word quad kq) of every plane of both sides; one 16-byte load per plane
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
         const int sq = tid >> 2, kq = tid & 3, wave = tid >> 6;
@@ -283,7 +287,7 @@ __device__ __forceinline__ void msa_tile(const uint32_t* __restrict__ planes, in
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { sA[p][4 * kq + j][sq] = va[j]; sB[p][4 * kq + j][sq] = vb[j]; }
-                if (p == 0) {      // which words of this stage hold a not-a-base position: per wavefront's rows, and for the columns
+                if (p == 0 && track) {      // which words of this stage hold a not-a-base position: per wavefront's rows, and for the columns
                     unsigned int ma = 0, mb = 0;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { ma |= (va[j] ? 1u : 0u) << (4 * kq + j); mb |= (vb[j] ? 1u : 0u) << (4 * kq + j); }
@@ -292,8 +296,8 @@ __device__ __forceinline__ void msa_tile(const uint32_t* __restrict__ planes, in
                 }
             }
             __syncthreads();
-            if (tid < 8) s_xm[set ^ 1][tid] = 0u;              // (the other set: last read before the barrier that ended the previous stage)
-            const unsigned int xm = fast ? 0u : (unsigned int)__builtin_amdgcn_readfirstlane((int)(s_xm[set][wave] | s_xm[set][4]));
+            if (track && tid < 8) s_xm[set ^ 1][tid] = 0u;     // (the other set: last read before the barrier that ended the previous stage)
+            const unsigned int xm = fast ? 0u : !track ? 0xffffu : (unsigned int)__builtin_amdgcn_readfirstlane((int)(s_xm[set][wave] | s_xm[set][4]));
             auto body_fast = [&](int kk) {
                 const uint4 aL = *reinterpret_cast<const uint4*>(&sA[1][kk][ty * 4]);
                 const uint4 aH = *reinterpret_cast<const uint4*>(&sA[2][kk][ty * 4]);
@@ -530,7 +534,7 @@ static int msa_launch(int dist_type, hipStream_t s, const MsaBuffers& m, double*
     dim3 g((unsigned)((ncols + pt - 1) / pt), (unsigned)((rows + pt - 1) / pt));
     switch (dist_type) {
     case DPR_DIST_UNCORRECTED:
-    case DPR_DIST_JC:        return launch_matrix<DPR_DIST_JC>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed, msa_jc_tab(m, dist_type), msa_jc_tab_ld(m), MsaSparseX{ m.xstage });
+    case DPR_DIST_JC:        return launch_matrix<DPR_DIST_JC>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed, msa_jc_tab(m, dist_type), msa_jc_tab_ld(m), MsaSparseX{ m.W32 > kKC ? m.xstage : nullptr });
     case DPR_DIST_TAJIMANEI: return launch_matrix<DPR_DIST_TAJIMANEI>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed, nullptr, 0);
     case DPR_DIST_K2P:       return launch_matrix<DPR_DIST_K2P>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed, nullptr, 0);
     case DPR_DIST_TAMURA:    return launch_matrix<DPR_DIST_TAMURA>(g, s, m.planes, m.n, m.W32, dist_type, D, ld, rows, rank, world, row0, col0, ncols, transposed, nullptr, 0);
@@ -546,7 +550,7 @@ int msa_dist_jobs(const MsaBuffers& m, int dist_type, const PairJobs& J, int njo
     if (njobs <= 0) return DPR_OK;
     switch (dist_type) {
     case DPR_DIST_UNCORRECTED:
-    case DPR_DIST_JC:        hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_JC>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J, msa_jc_tab(m, dist_type), msa_jc_tab_ld(m), MsaSparseX{ m.xstage }); break;
+    case DPR_DIST_JC:        hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_JC>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J, msa_jc_tab(m, dist_type), msa_jc_tab_ld(m), MsaSparseX{ m.W32 > kKC ? m.xstage : nullptr }); break;
     case DPR_DIST_TAJIMANEI: hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_TAJIMANEI>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J, (const double*)nullptr, 0, MsaSparseX{ nullptr }); break;
     case DPR_DIST_K2P:       hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_K2P>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J, (const double*)nullptr, 0, MsaSparseX{ nullptr }); break;
     case DPR_DIST_TAMURA:    hipLaunchKernelGGL(msa_dist_jobs_kernel<DPR_DIST_TAMURA>, dim3(njobs), dim3(kThreads), 0, s, m.planes, m.n, m.W32, dist_type, J, (const double*)nullptr, 0, MsaSparseX{ nullptr }); break;
