@@ -279,21 +279,37 @@ int dpr_comm_init_shared(dpr_ctx* c, int rank, int world, void* shared, uint64_t
         if (all[a].world != (uint32_t)world) { set_error("dpr_comm_init_shared: the ranks disagree about the number of ranks"); return fail(DPR_ERR_ARG); }
         for (int b = a + 1; b < world; ++b) shared_device = shared_device || std::strcmp(all[a].bus, all[b].bus) == 0;
     }
+    // (DPR_TEST_COMM_TRY_RCCL=1, tests: `auto` tries RCCL although ranks share a device -- RCCL refuses them, which exercises the
+    //  joint fall-back to the device windows on a one-GPU box)
+    if (transport == 0 && shared_device && std::getenv("DPR_TEST_COMM_TRY_RCCL")) shared_device = false;
     const int tr = transport != 0 ? transport : (shared_device ? 2 : 1);
     if (tr == 1) {
         if (shared_device) { set_error("dpr_comm_init_shared: RCCL refuses two ranks on one device; use the ipc transport"); return fail(DPR_ERR_ARG); }
-        // rank 0's unique id travels through the region
+        // rank 0's unique id travels through the region (id_ready: 1 = there, 2 = rank 0 could not make one)
         if (rank == 0) {
             char id[128];
-            if (int rc = dpr_comm_unique_id(id)) return fail(rc);
-            std::memcpy(h->rccl_id, id, 128);
-            st_rel(&h->id_ready, 1u);
+            const int rc0 = dpr_comm_unique_id(id);
+            if (rc0 == DPR_OK) std::memcpy(h->rccl_id, id, 128);
+            st_rel(&h->id_ready, rc0 == DPR_OK ? 1u : 2u);
         } else if (int rc = shm_wait(h, m->timeout_ms, "dpr_comm_init_shared (RCCL id)", [&] { return ld_acq(&h->id_ready) != 0; })) return rc;
-        char id[128];
-        std::memcpy(id, h->rccl_id, 128);
         // (the ShmComm stays: host gathers, barriers and the failure word go through the region; the data path is RCCL's)
-        if (int rc = dpr_comm_init(c, rank, world, id)) return fail(rc);
-        return shm_barrier(c);
+        uint32_t ok = 0, oks[kNjsMaxWorld];
+        if (ld_acq(&h->id_ready) == 1u) {
+            char id[128];
+            std::memcpy(id, h->rccl_id, 128);
+            ok = dpr_comm_init(c, rank, world, id) == DPR_OK ? 1u : 0u;
+        }
+        if (int rc = comm_gather_host(c, &ok, oks, sizeof(uint32_t))) return rc;
+        bool all_ok = true;
+        for (int r = 0; r < world; ++r) all_ok = all_ok && oks[r] != 0;
+        if (all_ok) return shm_barrier(c);
+        // RCCL did not come up on every rank (no librccl, a bootstrap interface that does not answer, ...): with `auto` every rank
+        // falls back TOGETHER -- the decision is taken on gathered flags -- to the device windows, which need nothing but hipIpc between
+        // the node's GPUs; an explicit `rccl` is an error
+        const std::string why = last_error();
+        if (c->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+        if (transport == 1) { set_error("dpr_comm_init_shared: RCCL did not come up on every rank (" + why + ")"); return fail(DPR_ERR_COMM); }
+        if (rank == 0) std::fprintf(stderr, "[dipper] RCCL did not come up on every rank (%s): the ranks exchange through device windows over hipIpc instead\n", why.c_str());
     }
     // ipc transport: one device window per rank, mapped by every other rank
     size_t win_mb = 64;

@@ -146,3 +146,18 @@ def test_ranks_started_from_outside_meet_in_a_named_region(tmp_path, aligned):
     assert outs[0].read_text() == o1.read_text()
     assert not outs[1].exists()               # (rank 1 writes nothing)
     assert "Ranks: 2 (transport ipc" in res[0][1]
+
+
+@pytest.mark.timeout(600)
+def test_ranks_fall_back_to_the_windows_when_rccl_does_not_come_up(tmp_path, aligned):
+    """`--transport auto` with one rank per GPU means RCCL; when RCCL does not come up on every rank (here: DPR_TEST_COMM_TRY_RCCL=1 makes
+    two ranks that share GPU 0 try it, and RCCL refuses a duplicate device) the ranks fall back TOGETHER to the device windows and the
+    run goes on: same Newick, transport ipc in the closing line, a note on stderr.  An explicit `--transport rccl` is an error instead."""
+    o1, o2 = tmp_path / "one.nwk", tmp_path / "two.nwk"
+    assert run("-i", "m", "-I", str(aligned), "-m", "1", "-d", "2", "-O", str(o1)).returncode == 0
+    r = run("-i", "m", "-I", str(aligned), "-m", "1", "-d", "2", "-O", str(o2), "--devices", "0,0", env={"DPR_TEST_COMM_TRY_RCCL": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "RCCL did not come up on every rank" in r.stderr and "Ranks: 2 (transport ipc" in r.stderr, r.stderr[-1500:]
+    assert o2.read_text() == o1.read_text()
+    r = run("-i", "m", "-I", str(aligned), "-m", "1", "-d", "2", "-O", str(o2), "--devices", "0,0", "--transport", "rccl")
+    assert r.returncode == 1 and "RCCL refuses two ranks on one device" in r.stderr
