@@ -39,7 +39,7 @@ struct ShmComm {
     ShmHeader* h = nullptr;
     int rank = 0, world = 1;
     uint32_t sense = 0;
-    int64_t timeout_ms = 1800000;
+    int64_t timeout_ms = 600000;
     // ipc transport
     char* win = nullptr;
     size_t win_bytes = 0;

@@ -233,7 +233,7 @@ int main(int argc, char** argv)
     const bool add = vm.count("add") != 0;
     long long seed = 1;
     try { if (vm.count("seed")) seed = std::stoll(vm["seed"]); } catch (...) {}
-    const int device = (int)stoiOr(vm, "device", 0);
+    int device = (int)stoiOr(vm, "device", 0);
     const std::string inputFile = vm["input-file"], outputFile = vm["output-file"];
     // several GPUs: one rank process per GPU, started once the input is read and before the first GPU call (startRanks)
     RankOptions ranks;
@@ -261,6 +261,7 @@ int main(int argc, char** argv)
             usageError("--world needs --rank (0 <= rank < world) and --rendezvous");
     }
     const bool multi = ranks.multi();
+    if (!multi && ranks.devices.size() == 1) device = ranks.devices[0];      // (`--devices 3` alone: one rank on GPU 3)
 
     const int placement_thr = 30000, dc_thr = 1000000;  // src/tree_generation.cu:247-248
     auto ms_since = [](std::chrono::high_resolution_clock::time_point t0) {

@@ -125,7 +125,7 @@ int dpr_comm_info(dpr_ctx *ctx, int *rank, int *nranks);
  *   transport for ranks that share a device (RCCL refuses them), i.e. for rehearsing every multi-rank path on a single GPU;
  * transport 0 = auto: ipc iff two ranks name the same device (PCI bus id), else RCCL.
  * The region also carries a failure word: a rank that gives up (or the launcher, dpr_shared_abort, when a rank has died) sets it
- * and every wait of every rank ends with DPR_ERR_COMM instead of hanging; DPR_COMM_TIMEOUT_MS (default 1 800 000) bounds a wait. */
+ * and every wait of every rank ends with DPR_ERR_COMM instead of hanging; DPR_COMM_TIMEOUT_MS (default 600 000) bounds a wait. */
 #define DPR_COMM_SHARED_BYTES 65536
 int dpr_comm_init_shared(dpr_ctx *ctx, int rank, int world, void *shared, uint64_t bytes, int transport);
 /* *transport: 0 = none (one rank / virtual ranks), 1 = RCCL, 2 = device windows over hipIpc, 3 = peers attached by the launcher
