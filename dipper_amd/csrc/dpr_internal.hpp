@@ -494,10 +494,12 @@ struct ExactBuffers {
     int32_t* hist = nullptr;     // [2N+2]
     int32_t* nd = nullptr;       // [2N][12] node records: slot[3], reverse slot[3], target node[3], pad
     XStep* st = nullptr;
+    void* tpack = nullptr;       // [kTopClimb] structural records of the top nodes, packed beside the small-subtree pass (px_top_climb)
     void* partials = nullptr;
     int32_t* dfsrk = nullptr;    // literal schedule: the reference's single rank array (alias of rk[0])
     bool literal = false;        // run the literal one-workgroup schedule (fallback / DPR_EXACT_LITERAL=1)
     unsigned long long* clk = nullptr;   // DPR_EXACT_CLOCKS=1 (profiling): phase clocks of px_top_kernel, summed over the tips (100 MHz ticks)
+    bool top_poll = false;       // tests / A-B (DPR_EXACT_TOP_POLL=1): the polling schedule of px_top_poll even where the climbing one applies
     bool top_levels = false;     // tests / A-B (DPR_EXACT_TOP_LEVELS=1): the top-tree pass level by level with a workgroup barrier per level (rounds 3-5)
     bool top_in_memory = false;  // tests (DPR_EXACT_TOP_MEM=1): the top-tree pass keeps its values in memory even when they fit LDS
 };

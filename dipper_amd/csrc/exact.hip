@@ -24,6 +24,9 @@ constexpr int kSm = 64;     // a "small" subtree has at most this many nodes: on
 constexpr int kTopLds = 6144;   // top nodes whose pass values fit the workgroup's LDS (2 x 8 bytes each)
 constexpr int kTopLevLds = 4094;   // levels of the top tree whose offsets fit LDS
 constexpr int kTopReg = 4;         // top nodes per thread whose contexts stay in registers over both passes
+constexpr int kTopClimb = 2048;    // the climbing schedule (px_top_climb) takes top trees of fewer nodes than this: 64 bytes of LDS each
+constexpr size_t kTopDynLds = (size_t)kTopClimb * 64 + 2 * 1024 + 16;     // >= 2 * kTopLds doubles of the other schedules
+static_assert(kTopDynLds >= sizeof(double) * 2 * kTopLds, "dynamic LDS of px_top_kernel");
 constexpr unsigned long long kTopPollTicks = 20000000ull;      // 0.2 s of the 100 MHz clock: bound of one polling pass of px_top_poll
 
 struct PlacePartialX { double add; int32_t idx; int32_t eid; double frac; };
@@ -543,6 +546,54 @@ __global__ __launch_bounds__(kThreads) void px_patch_kernel(PlaceBuffers p, Exac
     else if (kind == 1) { x.tops[s_base[1] + mine] = idx; x.tix[idx] = s_base[1] + mine; }      // (tix: position in the top list, what px_top_kernel's contexts refer to)
 }
 
+// ---- records of the top tree's climbing schedule (px_top_climb below)
+struct __attribute__((aligned(16))) TopUp { uint32_t m; int32_t upslot; double lenp; };      // what a climb needs of the parent
+struct __attribute__((aligned(16))) TopDn { uint32_t refs; int32_t slotA, slotB; uint32_t fv; };   // what the walk down needs besides
+struct __attribute__((aligned(16))) TopCC { double a, b; };                                   // clipped bottom-up terms of child A / B
+// TopUp::m: bits 0-12 parent's index, 13 has a parent, 14 the node is its parent's child B, 15 / 16 child A / B is a top node,
+// 17 / 18 child A / B exists.  (Child A: the child that follows the node in pre-order.)  TopDn::refs: index of A | index of B << 16;
+// TopDn::fv: the flag bits of m, and in bit 0 the child the node's climb came from (written by the climb).
+constexpr uint32_t kUpPar = 1u << 13, kUpB = 1u << 14, kUpTopA = 1u << 15, kUpTopB = 1u << 16, kUpHasA = 1u << 17, kUpHasB = 1u << 18;
+constexpr uint32_t kUpFlags = ~0x1fffu;
+// the structural part of a top node's records (everything but the values of this tip): packed by spare workgroups of the
+// small-subtree launch that runs before px_top_kernel, so that the single workgroup starts from ONE coalesced load instead of
+// the chain top list -> node record -> neighbours' ranks / indices / lengths
+struct __attribute__((aligned(16))) TopPack { TopUp u; TopDn d; double lenup, lenA, lenB; int32_t rslotA, rslotB; };
+static_assert(sizeof(TopPack) == 64, "TopPack");
+static_assert((size_t)kTopClimb * 64 + 2 * kXT + 16 <= kTopDynLds, "LDS records of px_top_climb");
+constexpr int kPackBlocks = kTopClimb / kThreads;      // spare workgroups of px_small_up_kernel
+
+__device__ __forceinline__ void px_top_pack(const PlaceBuffers& p, const ExactBuffers& x, const int32_t* __restrict__ rk, int t)
+{
+    const int v = x.tops[t];
+    const int4 a = reinterpret_cast<const int4*>(x.nd + 12 * (int64_t)v)[0];
+    const int4 b = reinterpret_cast<const int4*>(x.nd + 12 * (int64_t)v)[1];
+    const int4 c4 = reinterpret_cast<const int4*>(x.nd + 12 * (int64_t)v)[2];
+    const int slot[3] = { a.x, a.y, a.z }, rslot[3] = { a.w, b.x, b.y }, nb[3] = { b.z, b.w, c4.x };
+    const int myrk = rk[v];
+    TopPack k;
+    k.u.m = 0; k.u.upslot = -1; k.u.lenp = 0.0;
+    k.d.refs = 0; k.d.slotA = -1; k.d.slotB = -1; k.d.fv = 0;
+    k.lenup = 0.0; k.lenA = 0.0; k.lenB = 0.0; k.rslotA = -1; k.rslotB = -1;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        if (slot[e] < 0) continue;
+        const int nrk = rk[nb[e]];
+        const int ti = x.tix[nb[e]];
+        const double len = p.len[slot[e]];
+        if (nrk > myrk) {                        // a child; outside the top tree (ti < 0) its value is read from memory by px_top_climb
+            const uint32_t r = (uint32_t)(ti < 0 ? 0 : ti);
+            if (nrk == myrk + 1) { k.d.slotA = slot[e]; k.lenA = len; k.rslotA = ti < 0 ? rslot[e] : -1; k.d.refs |= r; k.u.m |= kUpHasA | (ti >= 0 ? kUpTopA : 0u); }
+            else { k.d.slotB = slot[e]; k.lenB = len; k.rslotB = ti < 0 ? rslot[e] : -1; k.d.refs |= r << 16; k.u.m |= kUpHasB | (ti >= 0 ? kUpTopB : 0u); }
+        } else {                                 // the parent (a top node, as its subtree is larger)
+            k.u.upslot = slot[e]; k.lenup = len; k.u.lenp = p.len[rslot[e]];
+            k.u.m |= kUpPar | (uint32_t)ti | (myrk == nrk + 1 ? 0u : kUpB);
+        }
+    }
+    k.d.fv = k.u.m & kUpFlags;
+    reinterpret_cast<TopPack*>(x.tpack)[t] = k;
+}
+
 __device__ __forceinline__ int wave_max_i32(int v)
 {
 #pragma unroll
@@ -566,7 +617,13 @@ __global__ __launch_bounds__(kThreads) void px_small_up_kernel(PlaceBuffers p, E
     const int nroot = x.st->nroot;
     const int32_t* __restrict__ rk = x.rk[par];
     const int32_t* __restrict__ sz = x.sz[par];
-    for (int r = (int)blockIdx.x * (kThreads / 64) + w; r < nroot; r += (int)gridDim.x * (kThreads / 64)) {
+    const int grid = (int)gridDim.x - kPackBlocks;
+    if ((int)blockIdx.x >= grid) {      // the spare workgroups: structural records of the top nodes for px_top_climb
+        const int t = ((int)blockIdx.x - grid) * kThreads + (int)threadIdx.x, T = x.st->ntop;
+        if (T < kTopClimb && t < T) px_top_pack(p, x, rk, t);
+        return;
+    }
+    for (int r = (int)blockIdx.x * (kThreads / 64) + w; r < nroot; r += grid * (kThreads / 64)) {
         const int v0 = x.roots[r];
         const int r0 = rk[v0], s = sz[v0], d0 = x.dep[v0];
         const int v = lane < s ? x.nar[r0 + lane] : -1;
@@ -782,6 +839,179 @@ __device__ __forceinline__ void px_top_poll(const PlaceBuffers& p, const ExactBu
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The top tree by CLIMBING (round 6, second step; top trees of fewer than kTopClimb nodes).  px_top_poll still spends ~0.3 us
+// per level: a node that becomes ready is noticed by its thread's next polling iteration, and an iteration walks over all of
+// the thread's nodes (the time is the instructions of that iteration, not contention: longer sleeps of the idle wavefronts and
+// s_setprio for the busy ones change nothing -- profiles/r6/exact_top_pass_variants.txt).  Here nobody waits in the bottom-up
+// pass.  Every top node WITHOUT top children is the start of a climb: its thread evaluates it and moves on to the parent; at a
+// parent with two top children the first to arrive leaves its contribution in the parent's LDS word (one 64-bit atomic max --
+// the contributions are doubles >= 0, whose bit patterns order like integers, and the word starts at the pattern of -1.0) and
+// stops, the second finds it there and goes on with the parent.  A level of the critical path costs ONE LDS round trip (the
+// atomic, with the parent's record loaded beside it) and ~35 instructions.  The starts are compacted (at most half of the
+// nodes: one climb per thread, wavefronts without one leave at once).  The climbs cut the top tree into vertical chains, each
+// evaluated by one thread; the top-down pass hands every chain to the SAME thread again, which waits for the value its top
+// node receives from above (the only polling left: one LDS word per thread, bounded as in px_top_poll) and then walks the
+// chain down without waiting, leaving the values for the chains that hang off it on the way.
+// Same recurrences and operands as the level loops; a maximum over terms "taken only if larger than the running maximum that
+// starts at 0" (src/placement.cu:320-326, :346-358) is the maximum of the terms clipped at 0, in any order: lim[] bit for bit.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void px_top_climb(const PlaceBuffers& p, const ExactBuffers& x, int T, double* s_dyn)
+{
+    (void)p;
+    constexpr int R = kTopClimb / kXT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    TopUp* up = reinterpret_cast<TopUp*>(s_dyn);
+    TopDn* dn = reinterpret_cast<TopDn*>(up + kTopClimb);
+    TopCC* cc = reinterpret_cast<TopCC*>(dn + kTopClimb);
+    double* lenup = reinterpret_cast<double*>(cc + kTopClimb);        // length of the node's own slot towards the parent (operand of its top-down term)
+    long long* acc = reinterpret_cast<long long*>(lenup + kTopClimb);  // bottom-up: meeting word of the children's climbs; then: the value received from the parent
+    unsigned short* starts = reinterpret_cast<unsigned short*>(acc + kTopClimb);     // [kXT] nodes without top children
+    int* nstart = reinterpret_cast<int*>(starts + kXT);
+    const long long kSent = __double_as_longlong(-1.0);
+    const unsigned long long ck0 = wall_clock64();
+    if (tid == 0) *nstart = 0;
+    __syncthreads();
+
+    // ---- records of this thread's nodes: the packed structure + the values of the children outside the top tree
+    const TopPack* __restrict__ pack = reinterpret_cast<const TopPack*>(x.tpack);
+#pragma unroll
+    for (int m = 0; m < R; ++m) {
+        const int t = tid + m * kXT;
+        bool is_start = false;
+        if (t < T) {
+            const TopPack k = pack[t];
+            TopCC c; c.a = 0.0; c.b = 0.0;
+            if (k.rslotA >= 0) { const double req = x.lim[k.rslotA] - k.lenA; if (req > 0.0) c.a = req; }
+            if (k.rslotB >= 0) { const double req = x.lim[k.rslotB] - k.lenB; if (req > 0.0) c.b = req; }
+            up[t] = k.u; dn[t] = k.d; cc[t] = c; lenup[t] = k.lenup;
+            const int ntop = ((k.u.m & kUpTopA) ? 1 : 0) + ((k.u.m & kUpTopB) ? 1 : 0);
+            // (one top child: the other child's term is there from the start and the climb finds it like a sibling's; none: unused)
+            acc[t] = ntop == 1 ? __double_as_longlong(c.a > c.b ? c.a : c.b) : kSent;
+            is_start = ntop == 0;
+        }
+        // the starts, compacted: one LDS counter update per wavefront
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(is_start);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(nstart, __builtin_popcountll(bal));
+        base = __shfl(base, 0, 64);
+        const int at = base + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+        if (is_start && at < kXT) starts[at] = (unsigned short)t;      // (a binary tree of T < 2 kXT nodes has at most kXT leaves)
+    }
+    __syncthreads();
+    if (x.clk) __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long ck1 = wall_clock64();
+
+    // ---- bottom-up: lim[node -> parent] = max(0, max over the child edges of lim[child -> node] - len)
+    if (*nstart > kXT) {      // not a binary tree: broken records
+        if (tid == 0 && atomicCAS(&x.st->poll_fail, 0, 1) == 0) { x.st->poll_node = -1; x.st->poll_pass = 0; }
+        return;
+    }
+    int n = -1;           // node the climb stands on (evaluated)
+    double val = 0.0;     // its bottom-up value
+    TopUp cur; cur.m = 0; cur.upslot = -1; cur.lenp = 0.0;
+    if (tid < *nstart) {
+        n = starts[tid];
+        cur = up[n];
+        const TopCC c = cc[n];
+        val = c.a > c.b ? c.a : c.b;
+        if (cur.upslot >= 0) x.lim[cur.upslot] = val;
+    }
+    bool act = n >= 0;
+    int steps = 0;
+    while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
+        if (++steps > kTopClimb) {                   // (a chain of parents longer than the tree: broken records -- never loop for ever)
+            if (act && atomicCAS(&x.st->poll_fail, 0, 1) == 0) { x.st->poll_node = x.tops[n]; x.st->poll_pass = 0; }
+            act = false;
+            break;
+        }
+        if (act) {
+            if (!(cur.m & kUpPar)) act = false;          // the root: the chain ends here
+            else {
+                const int par = (int)(cur.m & 0x1fffu);
+                const double req = val - cur.lenp;
+                const double c = req > 0.0 ? req : 0.0;
+                // one LDS round trip: the atomic on the parent's meeting word and the parent's record travel together
+                const long long old = __hip_atomic_fetch_max(acc + par, __double_as_longlong(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const TopUp pu = up[par];
+                asm volatile("" :: "v"(old), "v"(pu.m), "v"(pu.upslot), "v"(pu.lenp));
+                if (old == kSent) act = false;           // first of two: the sibling's climb goes on
+                else {
+                    const double o = __longlong_as_double(old);
+                    const double v = c > o ? c : o;
+                    const bool fromB = (cur.m & kUpB) != 0u;
+                    TopCC w; w.a = fromB ? o : c; w.b = fromB ? c : o;      // (one top child: o IS the other child's term, already there)
+                    cc[par] = w;
+                    dn[par].fv = (pu.m & kUpFlags) | (fromB ? 1u : 0u);
+                    __hip_atomic_store(acc + par, kSent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // from now on: the value from above
+                    if (pu.upslot >= 0) x.lim[pu.upslot] = v;
+                    n = par; val = v; cur = pu;
+                }
+            }
+        }
+    }
+    if (x.clk) __syncthreads();
+    const unsigned long long ck2 = wall_clock64();
+
+    // ---- top-down: lim[node -> child] = max(0, max over the node's other edges of lim[other -> node] - len)
+    // n: the top node of this thread's chain (-1: no chain).  The records of the node the walk stands on are in registers; those
+    // of the next node of the chain are loaded while the current one is evaluated: a level costs the LDS round trip of that load.
+    bool wait = n >= 0, walk = false;
+    double win = 0.0;     // value the node on which the walk stands received from above
+    const bool chain_has_par = (cur.m & kUpPar) != 0u;
+    const int n0 = n >= 0 ? n : kTopClimb - 1;
+    TopDn d = dn[n0];
+    TopCC c = cc[n0];
+    double lu = lenup[n0];
+    const unsigned long long t_start = wall_clock64();
+    unsigned spins = 0;
+    while (__builtin_amdgcn_ballot_w64(wait || walk) != 0ull) {
+        if ((++spins & 1023u) == 0u && wall_clock64() - t_start > kTopPollTicks) {      // (scalar clock: the whole wavefront leaves)
+            if ((wait || walk) && atomicCAS(&x.st->poll_fail, 0, 1) == 0) { x.st->poll_node = x.tops[n]; x.st->poll_pass = 1; }
+            break;
+        }
+        if (wait) {
+            const long long got = chain_has_par ? __hip_atomic_load(acc + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ll;
+            if (got != kSent) { win = __longlong_as_double(got); wait = false; walk = true; }
+        }
+        if (__builtin_amdgcn_ballot_w64(walk) == 0ull) __builtin_amdgcn_s_sleep(1);      // (wave-uniform: nobody has anything to do yet)
+        if (walk) {
+            const uint32_t m = d.fv;
+            const bool more = (m & (kUpTopA | kUpTopB)) != 0u;
+            const int ra = (int)(d.refs & 0xffffu), rb = (int)(d.refs >> 16);
+            const int nn = more ? ((m & 1u) ? rb : ra) : kTopClimb - 1;      // (the spare record when the chain ends here)
+            const TopDn d2 = dn[nn];
+            const TopCC c2 = cc[nn];
+            const double lu2 = lenup[nn];
+            double la = 0.0, lb = 0.0;
+            if (m & kUpPar) { const double rq = win - lu; if (rq > 0.0) { la = rq; lb = rq; } }
+            if (c.b > la) la = c.b;
+            if (c.a > lb) lb = c.a;
+            // (the value of the via child travels in a register; only the chains that hang off the walk get theirs through LDS)
+            if (m & kUpHasA) {
+                x.lim[d.slotA] = la;
+                if ((m & kUpTopA) && (m & 1u)) __hip_atomic_store(acc + ra, __double_as_longlong(la), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (m & kUpHasB) {
+                x.lim[d.slotB] = lb;
+                if ((m & kUpTopB) && !(m & 1u)) __hip_atomic_store(acc + rb, __double_as_longlong(lb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (!more || ++steps > 2 * kTopClimb) walk = false;      // the chain's first node (where the climb started): done
+            win = (m & 1u) ? lb : la;
+            n = nn; d = d2; c = c2; lu = lu2;
+        }
+    }
+    if (x.clk) {
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long ck3 = wall_clock64();
+            atomicAdd(&x.clk[0], ck1 - ck0); atomicAdd(&x.clk[1], ck2 - ck1); atomicAdd(&x.clk[2], ck3 - ck2);
+            atomicAdd(&x.clk[3], 1ull); atomicAdd(&x.clk[4], (unsigned long long)T);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // the top tree: level lists by counting sort on depth (replaces stable_sort_by_key :766 + updateLevelStEd :419-434; the
 // order inside a level is irrelevant to every result), then both passes level by level, one workgroup barrier per level;
@@ -799,8 +1029,13 @@ __global__ __launch_bounds__(kXT) void px_top_kernel(PlaceBuffers p, ExactBuffer
     const bool lds = T <= kTopLds && !x.top_in_memory;
     double* up_l = s_dyn;
     double* in_l = s_dyn + kTopLds;
+    if (lds && T < kTopClimb && !x.top_levels && !x.top_poll) {
+        // ---- round 6, the common case: no level lists, no barrier per level, no waiting in the bottom-up pass (px_top_climb above)
+        px_top_climb(p, x, T, s_dyn);
+        return;
+    }
     if (lds && T <= kTopReg * kXT && !x.top_levels) {
-        // ---- round 6, the common case: NO level lists and NO barrier per level (px_top_poll above)
+        // ---- larger top trees: NO level lists and NO barrier per level (px_top_poll above)
         if (T <= kXT) px_top_poll<1>(p, x, dis, rk, T, up_l, in_l);
         else if (T <= 2 * kXT) px_top_poll<2>(p, x, dis, rk, T, up_l, in_l);
         else px_top_poll<kTopReg>(p, x, dis, rk, T, up_l, in_l);
@@ -1094,12 +1329,14 @@ int exact_alloc(ExactBuffers& x, int64_t N)
     x.dfsrk = x.rk[0];
     x.top_in_memory = std::getenv("DPR_EXACT_TOP_MEM") != nullptr;
     x.top_levels = std::getenv("DPR_EXACT_TOP_LEVELS") != nullptr;
+    x.top_poll = std::getenv("DPR_EXACT_TOP_POLL") != nullptr;
     if (std::getenv("DPR_EXACT_CLOCKS")) { DPR_HIP(hipMalloc(&x.clk, 8 * sizeof(unsigned long long))); DPR_HIP(hipMemset(x.clk, 0, 8 * sizeof(unsigned long long))); }
+    DPR_HIP(hipMalloc(&x.tpack, sizeof(TopPack) * (size_t)kTopClimb));
     DPR_HIP(hipMalloc(&x.st, sizeof(XStep)));
     DPR_HIP(hipMemset(x.st, 0, sizeof(XStep)));
     DPR_HIP(hipMalloc(&x.partials, sizeof(PlacePartialX) * (size_t)((4 * N + kThreads - 1) / kThreads + 1)));
     DPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(px_top_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(sizeof(double) * 2 * kTopLds)));
+                                (int)kTopDynLds));
     return DPR_OK;
 }
 
@@ -1111,7 +1348,7 @@ void exact_free(ExactBuffers& x)
             std::fprintf(stderr, "[exact] px_top_kernel over %llu tips: %.1f top nodes; contexts %.2f us, bottom-up %.2f us, top-down %.2f us per tip\n", h[3],
                          (double)h[4] / (double)h[3], h[0] * 0.01 / h[3], h[1] * 0.01 / h[3], h[2] * 0.01 / h[3]);
     }
-    void* ptrs[] = { x.lim, x.dep, x.rk[0], x.rk[1], x.sz[0], x.sz[1], x.nar, x.tix, x.roots, x.tops, x.order, x.lvoff, x.hist, x.partials, x.nd, x.st, x.clk };
+    void* ptrs[] = { x.lim, x.dep, x.rk[0], x.rk[1], x.sz[0], x.sz[1], x.nar, x.tix, x.roots, x.tops, x.order, x.lvoff, x.hist, x.partials, x.nd, x.st, x.clk, x.tpack };
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     const bool literal = x.literal;
@@ -1124,8 +1361,8 @@ static int exact_passes(PlaceBuffers& p, ExactBuffers& x, const double* dis, int
 {
     int64_t g = (placed_nodes + 63) / 64;        // ~ one wavefront per 16 nodes: the subtree roots are a few per cent of the nodes
     g = g < 1 ? 1 : (g > 2048 ? 2048 : g);
-    hipLaunchKernelGGL(px_small_up_kernel, dim3((unsigned)g), dim3(kThreads), 0, s, p, x, dis, par);
-    hipLaunchKernelGGL(px_top_kernel, dim3(1), dim3(kXT), sizeof(double) * 2 * kTopLds, s, p, x, dis, par);
+    hipLaunchKernelGGL(px_small_up_kernel, dim3((unsigned)g + kPackBlocks), dim3(kThreads), 0, s, p, x, dis, par);
+    hipLaunchKernelGGL(px_top_kernel, dim3(1), dim3(kXT), kTopDynLds, s, p, x, dis, par);
     hipLaunchKernelGGL(px_small_down_kernel, dim3((unsigned)g), dim3(kThreads), 0, s, p, x, dis, par);
     DPR_HIP(hipGetLastError());
     return DPR_OK;

@@ -119,17 +119,20 @@ def test_exact_literal_schedule_forced(monkeypatch, orc, n):
         d.close()
 
 
-@pytest.mark.parametrize("top_mem", [False, True, "levels"], ids=["top_polling_lds", "top_in_memory", "top_levels_lds"])
+@pytest.mark.parametrize("top_mem", [False, "poll", True, "levels"], ids=["top_climbing_lds", "top_polling_lds", "top_in_memory", "top_levels_lds"])
 def test_exact_larger_tree_both_top_variants(monkeypatch, orc, top_mem):
-    """4 000 tips: hundreds of top nodes above the one-wavefront subtrees; the top-tree pass (round 6) with every node polling the
-    LDS words of the values it waits for, (forced: what trees beyond ~100 000 tips use) level by level with its values in memory,
-    and (forced: rounds 3-5) level by level with a workgroup barrier per level and the values in LDS"""
+    """4 000 tips: hundreds of top nodes above the one-wavefront subtrees; the top-tree pass (round 6) by climbs that meet at the
+    parents' LDS words, (forced: what top trees of 2 048 - 4 096 nodes use) with every node polling the LDS words of the values it
+    waits for, (forced: what trees beyond ~100 000 tips use) level by level with its values in memory, and (forced: rounds 3-5)
+    level by level with a workgroup barrier per level and the values in LDS"""
     import dipper_amd
     from dipper_amd import capi
     if top_mem is True:
         monkeypatch.setenv("DPR_EXACT_TOP_MEM", "1")
     elif top_mem == "levels":
         monkeypatch.setenv("DPR_EXACT_TOP_LEVELS", "1")
+    elif top_mem == "poll":
+        monkeypatch.setenv("DPR_EXACT_TOP_POLL", "1")
     rng = np.random.default_rng(77)
     n = 4000
     D = _util.random_additive_matrix(rng, n, zero_frac=0.2)
