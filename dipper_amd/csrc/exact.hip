@@ -100,7 +100,52 @@ __device__ __forceinline__ XCtx px_ctx(const ExactBuffers& x, const PlaceBuffers
     return c;
 }
 
-// calculateBranchLength over the live slots + block-level first minimum
+// calculateBranchLength (src/placement.cu:158-197) for one slot: pendant length `add` and the position `d1` on the branch
+__device__ __forceinline__ void px_candidate(double dis1, double dis2, double L, double& add, double& d1)
+{
+    double a = (dis1 + dis2 - L) / 2;
+    if (a < 0) a = 0;
+    dis1 -= a; dis2 -= a;
+    if (dis1 < 0) dis1 = 0;
+    if (dis2 < 0) dis2 = 0;
+    if (dis1 > L) { a += dis1 - L; dis1 = L; }
+    if (dis2 > L) { a += dis2 - L; dis2 = L; }
+    const double rest = L - dis1 - dis2;
+    dis1 += rest / 2; dis2 += rest / 2;
+    add = a; d1 = dis1;
+}
+
+// first minimum over (pendant length, slot): the running best of a lane, of a wavefront, of a workgroup -> partials[block]
+struct XBest { double key, add, frac; int idx; };      // key: the pendant length, +inf for a NaN (which never wins, as in px_scan_kernel)
+__device__ __forceinline__ void px_best_init(XBest& b) { b.key = __builtin_inf(); b.add = __builtin_inf(); b.frac = 0.0; b.idx = 0x7fffffff; }
+__device__ __forceinline__ void px_best_take(XBest& b, double add, double frac, int idx)
+{
+    const double key = add == add ? add : __builtin_inf();
+    if (key < b.key || (key == b.key && idx < b.idx)) { b.key = key; b.add = add; b.frac = frac; b.idx = idx; }
+}
+// (all threads of the workgroup call this once; s_* : kThreads / 64 entries each)
+__device__ __forceinline__ void px_best_store(XBest b, double* s_key, double* s_add, double* s_frac, int* s_idx, PlacePartialX* __restrict__ out)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ok = __shfl_down(b.key, off, 64), oa = __shfl_down(b.add, off, 64), of = __shfl_down(b.frac, off, 64);
+        const int oi = __shfl_down(b.idx, off, 64);
+        if (ok < b.key || (ok == b.key && oi < b.idx)) { b.key = ok; b.add = oa; b.frac = of; b.idx = oi; }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { s_key[w] = b.key; s_add[w] = b.add; s_frac[w] = b.frac; s_idx[w] = b.idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < kThreads / 64; ++i)
+            if (s_key[i] < b.key || (s_key[i] == b.key && s_idx[i] < b.idx)) { b.key = s_key[i]; b.add = s_add[i]; b.frac = s_frac[i]; b.idx = s_idx[i]; }
+        PlacePartialX pp;
+        pp.add = b.add; pp.idx = b.idx; pp.eid = b.idx == 0x7fffffff ? 0 : b.idx; pp.frac = b.frac;
+        *out = pp;
+    }
+}
+
+// calculateBranchLength over the live slots + block-level first minimum (the literal schedule; the fast one evaluates the slots
+// where their values are produced: px_small_down_kernel)
 __global__ __launch_bounds__(kThreads) void px_scan_kernel(PlaceBuffers p, ExactBuffers x, int64_t num,
                                                            PlacePartialX* __restrict__ partials)
 {
@@ -113,18 +158,7 @@ __global__ __launch_bounds__(kThreads) void px_scan_kernel(PlaceBuffers p, Exact
     const bool have = idx < live;
     if (have && !(x.dep[p.belong[idx]] > x.dep[p.e[idx]])) {
         eid = (int)idx;
-        double dis1 = x.lim[eid], dis2 = x.lim[p.rev[eid]];
-        const double L = p.len[eid];
-        double a = (dis1 + dis2 - L) / 2;
-        if (a < 0) a = 0;
-        dis1 -= a; dis2 -= a;
-        if (dis1 < 0) dis1 = 0;
-        if (dis2 < 0) dis2 = 0;
-        if (dis1 > L) { a += dis1 - L; dis1 = L; }
-        if (dis2 > L) { a += dis2 - L; dis2 = L; }
-        const double rest = L - dis1 - dis2;
-        dis1 += rest / 2; dis2 += rest / 2;
-        add = a; d1 = dis1;
+        px_candidate(x.lim[eid], x.lim[p.rev[eid]], p.len[eid], add, d1);
     }
     double badd = have ? add : __builtin_inf();
     int bidx = have ? (int)idx : 0x7fffffff;
@@ -650,14 +684,43 @@ __global__ __launch_bounds__(kThreads) void px_small_up_kernel(PlaceBuffers p, E
 
 // top-down pass inside the small subtrees (updateFromTopToBottom, :331-364): the value a node receives from its parent
 // comes from LDS (the subtree's root: from memory, written by the top-tree kernel); children's bottom-up values from memory
-__global__ __launch_bounds__(kThreads) void px_small_down_kernel(PlaceBuffers p, ExactBuffers x, const double* __restrict__ dis, int par)
+__global__ __launch_bounds__(kThreads) void px_small_down_kernel(PlaceBuffers p, ExactBuffers x, const double* __restrict__ dis, int par,
+                                                                 PlacePartialX* __restrict__ partials)
 {
     __shared__ double s_in[kThreads / 64][64];
+    __shared__ double s_key[kThreads / 64], s_add[kThreads / 64], s_frac[kThreads / 64];
+    __shared__ int s_idx[kThreads / 64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nroot = x.st->nroot;
     const int32_t* __restrict__ rk = x.rk[par];
     const int32_t* __restrict__ sz = x.sz[par];
-    for (int r = (int)blockIdx.x * (kThreads / 64) + w; r < nroot; r += (int)gridDim.x * (kThreads / 64)) {
+    // calculateBranchLength (:158-197) rides along: every node but the root owns ONE candidate, the slot parent -> node (the
+    // direction the reference evaluates: the shallower end first), whose two values are final here -- the one from above has just
+    // been computed (or, for the root of a small subtree and for the top nodes, written by px_top_kernel), the one from below is
+    // the bottom-up pass's.  The first minimum over (pendant length, slot) does not depend on who evaluates which slot: one
+    // partial per workgroup, finished by px_split_kernel as before.  (Was: px_scan_kernel, a launch of its own per tip.)
+    XBest best;
+    px_best_init(best);
+    const int grid = (int)gridDim.x - kPackBlocks;
+    if ((int)blockIdx.x >= grid) {      // the spare workgroups: the top nodes' candidates
+        const int T = x.st->ntop;
+        for (int t = ((int)blockIdx.x - grid) * kThreads + (int)threadIdx.x; t < T; t += kPackBlocks * kThreads) {
+            const int v = x.tops[t];
+            const int32_t* q = x.nd + 12 * (int64_t)v;
+            const int myrk = rk[v];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (q[k] >= 0 && rk[q[6 + k]] < myrk) {      // the edge to the parent
+                    const int idx = q[3 + k];
+                    double add, d1;
+                    px_candidate(x.lim[idx], x.lim[q[k]], p.len[idx], add, d1);
+                    px_best_take(best, add, d1, idx);
+                }
+        }
+        px_best_store(best, s_key, s_add, s_frac, s_idx, partials + blockIdx.x);
+        return;
+    }
+    for (int r = (int)blockIdx.x * (kThreads / 64) + w; r < nroot; r += grid * (kThreads / 64)) {
         const int v0 = x.roots[r];
         const int r0 = rk[v0], s = sz[v0], d0 = x.dep[v0];
         const int v = lane < s ? x.nar[r0 + lane] : -1;
@@ -669,6 +732,12 @@ __global__ __launch_bounds__(kThreads) void px_small_down_kernel(PlaceBuffers p,
 #pragma unroll
         for (int k = 0; k < 3; ++k)
             if (c.slot[k] >= 0 && (c.down[k] || lane == 0)) inc[k] = x.lim[c.rslot[k]];
+        // the candidate's operands that are there already: the node's own bottom-up value and the length of the parent's slot
+        int cand = -1;
+        double below = 0.0, plen = 0.0, above0 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (c.slot[k] >= 0 && !c.down[k]) { cand = c.rslot[k]; below = x.lim[c.slot[k]]; plen = p.len[c.rslot[k]]; above0 = inc[k]; }
         for (int lev = 0; lev <= maxld; ++lev) {
             if (ld == lev) {
                 double rq[3];
@@ -691,7 +760,14 @@ __global__ __launch_bounds__(kThreads) void px_small_down_kernel(PlaceBuffers p,
             }
             wave_lds_sync();
         }
+        if (cand >= 0) {
+            double add, d1;
+            px_candidate(lane == 0 ? above0 : s_in[w][lane], below, plen, add, d1);
+            px_best_take(best, add, d1, cand);
+        }
+        wave_lds_sync();      // (s_in is rewritten by the next subtree)
     }
+    px_best_store(best, s_key, s_add, s_frac, s_idx, partials + blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1334,7 +1410,10 @@ int exact_alloc(ExactBuffers& x, int64_t N)
     DPR_HIP(hipMalloc(&x.tpack, sizeof(TopPack) * (size_t)kTopClimb));
     DPR_HIP(hipMalloc(&x.st, sizeof(XStep)));
     DPR_HIP(hipMemset(x.st, 0, sizeof(XStep)));
-    DPR_HIP(hipMalloc(&x.partials, sizeof(PlacePartialX) * (size_t)((4 * N + kThreads - 1) / kThreads + 1)));
+    {   // literal schedule: one partial per workgroup of px_scan_kernel; fast schedule: one per workgroup of px_small_down_kernel
+        const size_t scan = (size_t)((4 * N + kThreads - 1) / kThreads + 1), down = (size_t)(2048 + kPackBlocks + 1);
+        DPR_HIP(hipMalloc(&x.partials, sizeof(PlacePartialX) * (scan > down ? scan : down)));
+    }
     DPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(px_top_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kTopDynLds));
     return DPR_OK;
@@ -1357,13 +1436,18 @@ void exact_free(ExactBuffers& x)
 }
 
 // the two passes for the tip whose distance row is `dis`, on the tree as it stands (rank / size buffers of parity `par`)
+static int64_t exact_pass_grid(int64_t placed_nodes)
+{
+    const int64_t g = (placed_nodes + 63) / 64;  // ~ one wavefront per 16 nodes: the subtree roots are a few per cent of the nodes
+    return g < 1 ? 1 : (g > 2048 ? 2048 : g);
+}
 static int exact_passes(PlaceBuffers& p, ExactBuffers& x, const double* dis, int par, int64_t placed_nodes, hipStream_t s)
 {
-    int64_t g = (placed_nodes + 63) / 64;        // ~ one wavefront per 16 nodes: the subtree roots are a few per cent of the nodes
-    g = g < 1 ? 1 : (g > 2048 ? 2048 : g);
+    const int64_t g = exact_pass_grid(placed_nodes);
     hipLaunchKernelGGL(px_small_up_kernel, dim3((unsigned)g + kPackBlocks), dim3(kThreads), 0, s, p, x, dis, par);
     hipLaunchKernelGGL(px_top_kernel, dim3(1), dim3(kXT), kTopDynLds, s, p, x, dis, par);
-    hipLaunchKernelGGL(px_small_down_kernel, dim3((unsigned)g), dim3(kThreads), 0, s, p, x, dis, par);
+    hipLaunchKernelGGL(px_small_down_kernel, dim3((unsigned)g + kPackBlocks), dim3(kThreads), 0, s, p, x, dis, par,
+                       reinterpret_cast<PlacePartialX*>(x.partials));
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
@@ -1392,15 +1476,18 @@ int exact_tip(PlaceBuffers& p, ExactBuffers& x, int64_t tip, const double* d_dis
               hipStream_t s)
 {
     const int64_t live = 4 * tip - 4;
-    const int nblk = (int)((live + kThreads - 1) / kThreads);
+    int nblk = (int)((live + kThreads - 1) / kThreads);
     PlacePartialX* parts = reinterpret_cast<PlacePartialX*>(x.partials);
-    hipLaunchKernelGGL(px_scan_kernel, dim3((unsigned)nblk), dim3(kThreads), 0, s, p, x, tip, parts);
     if (x.literal) {
+        hipLaunchKernelGGL(px_scan_kernel, dim3((unsigned)nblk), dim3(kThreads), 0, s, p, x, tip, parts);
         hipLaunchKernelGGL(px_step_literal_kernel, dim3(1), dim3(kXT), 0, s, p, x, (const PlacePartialX*)parts, nblk, tip,
                            (const double*)nullptr, d_dis_next, has_next ? 1 : 0, d_trace);
         DPR_HIP(hipGetLastError());
         return DPR_OK;
     }
+    // the candidates of this tip were evaluated by the top-down pass that ran for it (exact_passes of the previous step): one partial
+    // per workgroup of that launch
+    nblk = (int)exact_pass_grid(2 * tip - 1) + kPackBlocks;
     hipLaunchKernelGGL(px_split_kernel, dim3(1), dim3(256), 0, s, p, x, (const PlacePartialX*)parts, nblk, tip, d_trace);
     const int64_t tot = p.N + tip;
     hipLaunchKernelGGL(px_patch_kernel, dim3((unsigned)((tot + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, x, tip);
