@@ -473,10 +473,8 @@ int place_tips(PlaceBuffers& p, const double* d_dis0, int64_t ldb, int64_t tip0,
 int64_t place_multi_min();        // first tip of the four-tip launch pairs
 
 // exact.hip: exact placement mode (src/placement.cu)
-struct XStep {                   // scalars of the last split (device), and the counters of the two node lists
-    int rrk, ysz, small;         // rank the new internal node takes (= old rank of y), size of y's subtree, last rank of the moved subtree
-    int middle, outside;
-    int nroot, ntop;
+struct XStep {                   // counters of the two node lists, status words (device)
+    int nroot[2], ntop[2];       // [parity of the rank buffers the lists belong to]: px_patch_kernel of tip i fills [(i + 1) & 1] and clears [i & 1]
     int poll_fail, poll_node, poll_pass;   // px_top_poll: a value never arrived (node on record, pass 0 bottom-up / 1 top-down): the run fails
     int quirk;                   // the reference's swap in updateTreeStructure was taken: its depths are no tree depths any more (see exact.hip)
 };

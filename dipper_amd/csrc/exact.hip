@@ -29,7 +29,12 @@ constexpr size_t kTopDynLds = (size_t)kTopClimb * 64 + 2 * 1024 + 16;     // >= 
 static_assert(kTopDynLds >= sizeof(double) * 2 * kTopLds, "dynamic LDS of px_top_kernel");
 constexpr unsigned long long kTopPollTicks = 20000000ull;      // 0.2 s of the 100 MHz clock: bound of one polling pass of px_top_poll
 
-struct PlacePartialX { double add; int32_t idx; int32_t eid; double frac; };
+struct PlacePartialX {
+    double add; int32_t idx; int32_t eid; double frac;
+    // fast schedule only: what the split needs of the slot's state, carried with the candidate (px_patch_kernel must not read
+    // p.e / p.rev / p.len of the winning slot while one of its threads rewrites them)
+    int32_t xn, yn, ye, pad; double len;      // belong[eid], e[eid], rev[eid], len[eid]
+};
 
 __device__ __forceinline__ bool px_placed(int idx, int i, int N) { return !(idx > i && idx < N); }
 
@@ -116,32 +121,42 @@ __device__ __forceinline__ void px_candidate(double dis1, double dis2, double L,
 }
 
 // first minimum over (pendant length, slot): the running best of a lane, of a wavefront, of a workgroup -> partials[block]
-struct XBest { double key, add, frac; int idx; };      // key: the pendant length, +inf for a NaN (which never wins, as in px_scan_kernel)
-__device__ __forceinline__ void px_best_init(XBest& b) { b.key = __builtin_inf(); b.add = __builtin_inf(); b.frac = 0.0; b.idx = 0x7fffffff; }
-__device__ __forceinline__ void px_best_take(XBest& b, double add, double frac, int idx)
+struct XBest { double key, add, frac, len; int idx, xn, yn, ye; };      // key: the pendant length, +inf for a NaN (which never wins, as in px_scan_kernel)
+__device__ __forceinline__ void px_best_init(XBest& b) { b.key = __builtin_inf(); b.add = __builtin_inf(); b.frac = 0.0; b.len = 0.0; b.idx = 0x7fffffff; b.xn = b.yn = b.ye = -1; }
+// candidate of slot idx = xn -> yn (reverse slot ye, length len)
+__device__ __forceinline__ void px_best_take(XBest& b, double add, double frac, int idx, int xn, int yn, int ye, double len)
 {
     const double key = add == add ? add : __builtin_inf();
-    if (key < b.key || (key == b.key && idx < b.idx)) { b.key = key; b.add = add; b.frac = frac; b.idx = idx; }
+    if (key < b.key || (key == b.key && idx < b.idx)) { b.key = key; b.add = add; b.frac = frac; b.len = len; b.idx = idx; b.xn = xn; b.yn = yn; b.ye = ye; }
 }
 // (all threads of the workgroup call this once; s_* : kThreads / 64 entries each)
 __device__ __forceinline__ void px_best_store(XBest b, double* s_key, double* s_add, double* s_frac, int* s_idx, PlacePartialX* __restrict__ out)
 {
+    // (the winner's lane within the wavefront first, then its payload with one shuffle per field)
+    double k = b.key; int ki = b.idx;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        const double ok = __shfl_down(b.key, off, 64), oa = __shfl_down(b.add, off, 64), of = __shfl_down(b.frac, off, 64);
-        const int oi = __shfl_down(b.idx, off, 64);
-        if (ok < b.key || (ok == b.key && oi < b.idx)) { b.key = ok; b.add = oa; b.frac = of; b.idx = oi; }
+        const double ok = __shfl_xor(k, off, 64);
+        const int oi = __shfl_xor(ki, off, 64);
+        if (ok < k || (ok == k && oi < ki)) { k = ok; ki = oi; }
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) { s_key[w] = b.key; s_add[w] = b.add; s_frac[w] = b.frac; s_idx[w] = b.idx; }
+    const unsigned long long mine = __builtin_amdgcn_ballot_w64(b.idx == ki && (b.key == k));
+    const int src = mine ? __builtin_ctzll(mine) : 0;      // (no candidate in the wavefront: every lane holds the initial record)
+    b.key = __shfl(b.key, src, 64); b.add = __shfl(b.add, src, 64); b.frac = __shfl(b.frac, src, 64); b.len = __shfl(b.len, src, 64);
+    b.idx = __shfl(b.idx, src, 64); b.xn = __shfl(b.xn, src, 64); b.yn = __shfl(b.yn, src, 64); b.ye = __shfl(b.ye, src, 64);
+    if (lane == 0) { s_key[w] = b.key; s_idx[w] = b.idx; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < kThreads / 64; ++i)
-            if (s_key[i] < b.key || (s_key[i] == b.key && s_idx[i] < b.idx)) { b.key = s_key[i]; b.add = s_add[i]; b.frac = s_frac[i]; b.idx = s_idx[i]; }
+    int win = 0;
+    for (int i = 1; i < kThreads / 64; ++i)
+        if (s_key[i] < s_key[win] || (s_key[i] == s_key[win] && s_idx[i] < s_idx[win])) win = i;
+    if (w == win && lane == 0) {
         PlacePartialX pp;
         pp.add = b.add; pp.idx = b.idx; pp.eid = b.idx == 0x7fffffff ? 0 : b.idx; pp.frac = b.frac;
+        pp.xn = b.xn; pp.yn = b.yn; pp.ye = b.ye; pp.pad = 0; pp.len = b.len;
         *out = pp;
     }
+    (void)s_add; (void)s_frac;
 }
 
 // calculateBranchLength over the live slots + block-level first minimum (the literal schedule; the fast one evaluates the slots
@@ -180,10 +195,12 @@ __global__ __launch_bounds__(kThreads) void px_scan_kernel(PlaceBuffers p, Exact
     __syncthreads();
     if (have && (int)idx == sidx[0]) {
         PlacePartialX pp; pp.add = add; pp.idx = (int)idx; pp.eid = eid; pp.frac = d1;
+        pp.xn = pp.yn = pp.ye = -1; pp.pad = 0; pp.len = 0.0;      // (the literal schedule reads the slot's state itself)
         partials[blockIdx.x] = pp;
     }
     if (threadIdx.x == 0 && sidx[0] == 0x7fffffff) {
         PlacePartialX pp; pp.add = __builtin_inf(); pp.idx = 0x7fffffff; pp.eid = 0; pp.frac = 0;
+        pp.xn = pp.yn = pp.ye = -1; pp.pad = 0; pp.len = 0.0;
         partials[blockIdx.x] = pp;
     }
 }
@@ -459,122 +476,139 @@ __global__ __launch_bounds__(kXT) void px_step_literal_kernel(PlaceBuffers p, Ex
 
 
 // ------------------------------------------------------------------------------------------------
-// finish the argmin of the scan, split the edge (updateTreeStructure, src/placement.cu:199-243) and leave the scalars
-// of the split for the patch kernel.  One workgroup; thread 0 does the split.
+// One launch per placed tip for everything between the passes: finish the argmin over the candidates' partials (thrust::min_element
+// :688), split the edge (updateTreeStructure, src/placement.cu:199-243), updateDfsRk (:366-379), updateDepth (:400-416), subtree
+// sizes, node-at-rank table, small-subtree roots and top nodes.  (Was: px_split_kernel, one workgroup, + the elementwise
+// px_patch_kernel.)  EVERY workgroup finishes the argmin for itself -- a few hundred 48-byte records -- and derives the scalars of
+// the split from it and from the OLD rank / size buffers, which nobody writes here; then every new value is a pure function of the
+// old arrays and those scalars, as before.  The split itself is written by the threads that own the four nodes it touches: x and
+// y retarget their own records, the thread of the new internal node writes the adjacency arrays, the trace and the status words.
+// What the split needs of the winning slot (its ends, reverse slot and length) travels in the partial: the arrays being
+// rewritten are not read by anybody else.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void px_split_kernel(PlaceBuffers p, ExactBuffers x, const PlacePartialX* __restrict__ partials,
-                                                      int nparts, int64_t tip, double* __restrict__ trace)
-{
-    constexpr int kT = 256;
-    __shared__ double s_add[kT / 64], s_frac[kT / 64];
-    __shared__ int s_idx[kT / 64], s_eid[kT / 64];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int N = (int)p.N;
-    const int i = (int)tip;
-    const int32_t* __restrict__ rk_in = x.rk[i & 1];
-    const int32_t* __restrict__ sz_in = x.sz[i & 1];
-    // ---- thrust::min_element over all 4N-4 tuples, first occurrence
-    double badd = __builtin_inf(), bfrac = 0;
-    int bidx = 0x7fffffff, beid = 0;
-    for (int k = tid; k < nparts; k += kT) {
-        const PlacePartialX pp = partials[k];
-        if (pp.add < badd || (pp.add == badd && pp.idx < bidx)) { badd = pp.add; bidx = pp.idx; beid = pp.eid; bfrac = pp.frac; }
-    }
-    const int64_t live = 4 * (int64_t)i - 4, lim = 4 * (int64_t)N - 4;
-    if (tid == 0 && live < lim)   // slots >= 4i-4 all carry (0,0,2): the first of them competes
-        if (2.0 < badd || (2.0 == badd && (int)live < bidx)) { badd = 2.0; bidx = (int)live; beid = 0; bfrac = 0; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double oa = __shfl_down(badd, off, 64), of = __shfl_down(bfrac, off, 64);
-        const int oi = __shfl_down(bidx, off, 64), oe = __shfl_down(beid, off, 64);
-        if (oa < badd || (oa == badd && oi < bidx)) { badd = oa; bidx = oi; beid = oe; bfrac = of; }
-    }
-    if (lane == 0) { s_add[w] = badd; s_idx[w] = bidx; s_eid[w] = beid; s_frac[w] = bfrac; }
-    __syncthreads();
-    if (tid != 0) return;
-    for (int k = 1; k < kT / 64; ++k)
-        if (s_add[k] < badd || (s_add[k] == badd && s_idx[k] < bidx)) { badd = s_add[k]; bidx = s_idx[k]; beid = s_eid[k]; bfrac = s_frac[k]; }
-    const int eid = beid;
-    const double fracLen = bfrac, addLen = badd;
-    if (trace) { trace[3 * i] = eid; trace[3 * i + 1] = fracLen; trace[3 * i + 2] = addLen; }
-    int ec = 4 * i - 4;
-    const int middle = i + N - 1, outside = i;
-    int xn = p.belong[eid], yn = p.e[eid];
-    const double originalDis = p.len[eid];
-    const int xe = eid, ye = p.rev[eid];   // the reference finds them by walking head[x] / head[y]
-    p.e[xe] = middle; p.len[xe] = fracLen; p.rev[xe] = ec;
-    p.e[ye] = middle; p.len[ye] -= fracLen; p.rev[ye] = ec + 1;
-    p.e[ec] = xn; p.len[ec] = fracLen; p.nxt[ec] = p.head[middle]; p.head[middle] = ec; p.belong[ec] = middle; p.rev[ec] = xe; ec++;
-    p.e[ec] = yn; p.len[ec] = originalDis - fracLen; p.nxt[ec] = p.head[middle]; p.head[middle] = ec; p.belong[ec] = middle; p.rev[ec] = ye; ec++;
-    p.e[ec] = middle; p.len[ec] = addLen; p.nxt[ec] = p.head[outside]; p.head[outside] = ec; p.belong[ec] = outside; p.rev[ec] = ec + 1; ec++;
-    p.e[ec] = outside; p.len[ec] = addLen; p.nxt[ec] = p.head[middle]; p.head[middle] = ec; p.belong[ec] = middle; p.rev[ec] = ec - 1; ec++;
-    // node records: x and y keep their slots, which now lead to `middle`
-    px_retarget(x, xn, xe, ec - 4, middle);
-    px_retarget(x, yn, ye, ec - 3, middle);
-    px_set_node(x, middle, ec - 4, xe, xn, ec - 3, ye, yn, ec - 1, ec - 2, outside);
-    px_set_node(x, outside, ec - 2, ec - 1, middle, -1, -1, -1, -1, -1, -1);
-    const bool quirk = rk_in[xn] > rk_in[yn];
-    if (quirk) { const int t2 = xn; yn = xn; xn = t2; }   // the reference's swap, :236-239: taken only when the default tuple (slot 0) won
-    // dfsrk[middle] = dfsrk[y], dfsrk[outside] = dfsrk[middle] + 1 and the shift of the ranks >= it: the patch kernel, from these
-    XStep st;
-    st.rrk = rk_in[yn];
-    st.ysz = sz_in[yn];
-    st.small = st.rrk + 1 + st.ysz;      // last rank of the moved subtree after the shift (findEndRk + reduce of the reference)
-    st.middle = middle; st.outside = outside;
-    st.nroot = 0; st.ntop = 0;
-    st.quirk = (x.st->quirk || quirk) ? 1 : 0;      // sticky: the host repeats the run with the literal schedule
-    st.poll_fail = x.st->poll_fail; st.poll_node = x.st->poll_node; st.poll_pass = x.st->poll_pass;      // sticky too (px_top_poll)
-    x.dep[middle] = x.dep[xn]; x.dep[outside] = x.dep[middle] + 1;
-    *x.st = st;
-}
-
-// ------------------------------------------------------------------------------------------------
-// updateDfsRk (:366-379), updateDepth (:400-416), subtree sizes, node-at-rank table, small-subtree roots and top nodes:
-// elementwise over the placed nodes, every new value from the OLD rank / size arrays and the scalars of the split
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void px_patch_kernel(PlaceBuffers p, ExactBuffers x, int64_t tip)
+__global__ __launch_bounds__(kThreads) void px_patch_kernel(PlaceBuffers p, ExactBuffers x, const PlacePartialX* __restrict__ partials,
+                                                            int nparts, int64_t tip, double* __restrict__ trace)
 {
     __shared__ int s_cnt[2], s_base[2];
+    __shared__ double s_add[kThreads / 64], s_key[kThreads / 64];
+    __shared__ int s_idx[kThreads / 64], s_k[kThreads / 64], s_fidx[kThreads / 64], s_fk[kThreads / 64];
     const int N = (int)p.N, i = (int)tip;
     const int tot = N + i;
-    const int idx = (int)((int64_t)blockIdx.x * kThreads + threadIdx.x);
-    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int idx = (int)((int64_t)blockIdx.x * kThreads + tid);
+    if (tid < 2) s_cnt[tid] = 0;
+    // ---- thrust::min_element over all 4N-4 tuples, first occurrence (and, beside it, the first minimum with a NaN counted as
+    // +inf: the edge that is split when the default tuple wins, see below)
+    double badd = __builtin_inf(), fkey = __builtin_inf();
+    int bidx = 0x7fffffff, bk = -1, fidx = 0x7fffffff, fk = -1;
+    for (int k = tid; k < nparts; k += kThreads) {
+        const double a = partials[k].add;
+        const int id = partials[k].idx;
+        if (a < badd || (a == badd && id < bidx)) { badd = a; bidx = id; bk = k; }
+        const double key = a == a ? a : __builtin_inf();
+        if (id != 0x7fffffff && (key < fkey || (key == fkey && id < fidx))) { fkey = key; fidx = id; fk = k; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oa = __shfl_xor(badd, off, 64), ok = __shfl_xor(fkey, off, 64);
+        const int oi = __shfl_xor(bidx, off, 64), obk = __shfl_xor(bk, off, 64), ofi = __shfl_xor(fidx, off, 64), ofk = __shfl_xor(fk, off, 64);
+        if (oa < badd || (oa == badd && oi < bidx)) { badd = oa; bidx = oi; bk = obk; }
+        if (ok < fkey || (ok == fkey && ofi < fidx)) { fkey = ok; fidx = ofi; fk = ofk; }
+    }
+    if (lane == 0) { s_add[w] = badd; s_idx[w] = bidx; s_k[w] = bk; s_key[w] = fkey; s_fidx[w] = fidx; s_fk[w] = fk; }
     __syncthreads();
-    const bool live = idx < tot && px_placed(idx, i, N);
-    const XStep st = *x.st;            // (the two counters in it are being incremented: only the scalars of the split are used)
+#pragma unroll
+    for (int k = 0; k < kThreads / 64; ++k) {
+        if (s_add[k] < badd || (s_add[k] == badd && s_idx[k] < bidx)) { badd = s_add[k]; bidx = s_idx[k]; bk = s_k[k]; }
+        if (s_key[k] < fkey || (s_key[k] == fkey && s_fidx[k] < fidx)) { fkey = s_key[k]; fidx = s_fidx[k]; fk = s_fk[k]; }
+    }
+    const int64_t live_slots = 4 * (int64_t)i - 4, lim = 4 * (int64_t)N - 4;
+    // slots >= 4i-4 all carry (0,0,2): the first of them competes.  When it wins, the reference splits slot 0 -- a slot that leads
+    // UP the tree -- and its swap (:236-239) leaves depths that are no tree depths: the run is repeated with the literal schedule
+    // (XStep::quirk), and all that matters here is that the tree stays a tree: the best real candidate is split instead.
+    const bool dflt = (live_slots < lim && (2.0 < badd || (2.0 == badd && (int)live_slots < bidx))) || bk < 0;
+    const int wk = dflt ? fk : bk;
+    if (wk < 0) return;      // (no candidate at all: impossible for a tree with an edge; nothing to split)
+    const PlacePartialX win = partials[wk];
+    const int eid = win.eid;
+    const double fracLen = win.frac, addLen = win.add, originalDis = win.len;
+    const int xe = eid, ye = win.ye, xn0 = win.xn, yn0 = win.yn;      // the slot x -> y and its reverse
+    const int middle = i + N - 1, outside = i, ec0 = 4 * i - 4;
     const int32_t* __restrict__ rk_in = x.rk[i & 1];
     const int32_t* __restrict__ sz_in = x.sz[i & 1];
     int32_t* __restrict__ rk_out = x.rk[(i + 1) & 1];
     int32_t* __restrict__ sz_out = x.sz[(i + 1) & 1];
-    const int rrk = st.rrk;
-    auto new_rank = [&](int v) { if (v == st.middle) return rrk; if (v == st.outside) return rrk + 1; const int r = rk_in[v]; return r >= rrk ? r + 2 : r; };
+    const bool swapq = rk_in[xn0] > rk_in[yn0];
+    const int xn = xn0, yn = swapq ? xn0 : yn0;      // the reference's swap, :236-239 (`yn = xn; xn = t2`: both become x)
+    const bool quirk = dflt || swapq;
+    // dfsrk[middle] = dfsrk[y], dfsrk[outside] = dfsrk[middle] + 1 and the shift of the ranks >= it
+    const int rrk = rk_in[yn], ysz = sz_in[yn];
+    const int small = rrk + 1 + ysz;      // last rank of the moved subtree after the shift (findEndRk + reduce of the reference)
+    const int cpar = (i + 1) & 1;
+    const bool live = idx < tot && px_placed(idx, i, N);
+    auto new_rank = [&](int v) { if (v == middle) return rrk; if (v == outside) return rrk + 1; const int r = rk_in[v]; return r >= rrk ? r + 2 : r; };
     auto new_size = [&](int v) {
-        if (v == st.middle) return st.ysz + 2;
-        if (v == st.outside) return 1;
+        if (v == middle) return ysz + 2;
+        if (v == outside) return 1;
         const int r = rk_in[v], s = sz_in[v];
         return (r < rrk && r + s > rrk) ? s + 2 : s;      // the ancestors of y gain the two new nodes
     };
     int kind = -1, mine = 0;          // 0: root of a small subtree, 1: top node
     if (live) {
+        // the node's record after the split
+        int32_t* q = x.nd + 12 * (int64_t)idx;
+        int rec[9];
+        if (idx == middle) {
+            const int r[9] = { ec0, ec0 + 1, ec0 + 3, xe, ye, ec0 + 2, xn0, yn0, outside };
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { rec[k] = r[k]; q[k] = r[k]; }
+        } else if (idx == outside) {
+            const int r[9] = { ec0 + 2, -1, -1, ec0 + 3, -1, -1, middle, -1, -1 };
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { rec[k] = r[k]; q[k] = r[k]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) rec[k] = q[k];
+            if (idx == xn0 || idx == yn0) {      // x and y keep their slots, which now lead to `middle`
+                const int slot = idx == xn0 ? xe : ye, nrev = idx == xn0 ? ec0 : ec0 + 1;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if (rec[k] == slot) { rec[3 + k] = nrev; rec[6 + k] = middle; q[3 + k] = nrev; q[6 + k] = middle; }
+            }
+        }
         const int rn = new_rank(idx), sn = new_size(idx);
         rk_out[idx] = rn;
         sz_out[idx] = sn;
         x.nar[rn] = idx;
         x.tix[idx] = -1;
-        if (rn >= rrk && rn <= st.small) x.dep[idx] += 1;
+        if (idx == middle) x.dep[idx] = x.dep[xn] + 1;            // (dep[middle] = dep[x], then + 1 with the moved subtree, :400-416)
+        else if (idx == outside) x.dep[idx] = x.dep[xn] + 2;
+        else if (rn >= rrk && rn <= small) x.dep[idx] += 1;
         // parent = the neighbour with the smaller rank
-        const int32_t* q = x.nd + 12 * (int64_t)idx;
         int parent = -1;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            if (q[k] >= 0 && new_rank(q[6 + k]) < rn) parent = q[6 + k];
+            if (rec[k] >= 0 && new_rank(rec[6 + k]) < rn) parent = rec[6 + k];
         if (sn > kSm) kind = 1;
         else if (parent < 0 || new_size(parent) > kSm) kind = 0;
         if (kind >= 0) mine = atomicAdd(&s_cnt[kind], 1);
+        if (idx == middle) {
+            // ---- updateTreeStructure: the adjacency arrays
+            if (trace) { trace[3 * i] = dflt ? 0.0 : (double)eid; trace[3 * i + 1] = dflt ? 0.0 : fracLen; trace[3 * i + 2] = dflt ? 2.0 : addLen; }
+            int ec = ec0;
+            p.e[xe] = middle; p.len[xe] = fracLen; p.rev[xe] = ec;
+            p.e[ye] = middle; p.len[ye] -= fracLen; p.rev[ye] = ec + 1;
+            p.e[ec] = xn0; p.len[ec] = fracLen; p.nxt[ec] = p.head[middle]; p.head[middle] = ec; p.belong[ec] = middle; p.rev[ec] = xe; ec++;
+            p.e[ec] = yn0; p.len[ec] = originalDis - fracLen; p.nxt[ec] = p.head[middle]; p.head[middle] = ec; p.belong[ec] = middle; p.rev[ec] = ye; ec++;
+            p.e[ec] = middle; p.len[ec] = addLen; p.nxt[ec] = p.head[outside]; p.head[outside] = ec; p.belong[ec] = outside; p.rev[ec] = ec + 1; ec++;
+            p.e[ec] = outside; p.len[ec] = addLen; p.nxt[ec] = p.head[middle]; p.head[middle] = ec; p.belong[ec] = middle; p.rev[ec] = ec - 1; ec++;
+            if (quirk) x.st->quirk = 1;      // sticky: the host repeats the run with the literal schedule
+            x.st->nroot[cpar ^ 1] = 0; x.st->ntop[cpar ^ 1] = 0;      // the lists of the passes that have run: free for the next tip's
+        }
     }
     // one append per block and list (a few thousand single appends to one counter cost more than the rest of the kernel)
     __syncthreads();
-    if (threadIdx.x < 2 && s_cnt[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(threadIdx.x == 0 ? &x.st->nroot : &x.st->ntop, s_cnt[threadIdx.x]);
+    if (tid < 2 && s_cnt[tid] > 0) s_base[tid] = atomicAdd(tid == 0 ? &x.st->nroot[cpar] : &x.st->ntop[cpar], s_cnt[tid]);
     __syncthreads();
     if (kind == 0) x.roots[s_base[0] + mine] = idx;
     else if (kind == 1) { x.tops[s_base[1] + mine] = idx; x.tix[idx] = s_base[1] + mine; }      // (tix: position in the top list, what px_top_kernel's contexts refer to)
@@ -648,12 +682,12 @@ __global__ __launch_bounds__(kThreads) void px_small_up_kernel(PlaceBuffers p, E
 {
     __shared__ double s_val[kThreads / 64][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int nroot = x.st->nroot;
+    const int nroot = x.st->nroot[par];
     const int32_t* __restrict__ rk = x.rk[par];
     const int32_t* __restrict__ sz = x.sz[par];
     const int grid = (int)gridDim.x - kPackBlocks;
     if ((int)blockIdx.x >= grid) {      // the spare workgroups: structural records of the top nodes for px_top_climb
-        const int t = ((int)blockIdx.x - grid) * kThreads + (int)threadIdx.x, T = x.st->ntop;
+        const int t = ((int)blockIdx.x - grid) * kThreads + (int)threadIdx.x, T = x.st->ntop[par];
         if (T < kTopClimb && t < T) px_top_pack(p, x, rk, t);
         return;
     }
@@ -691,19 +725,19 @@ __global__ __launch_bounds__(kThreads) void px_small_down_kernel(PlaceBuffers p,
     __shared__ double s_key[kThreads / 64], s_add[kThreads / 64], s_frac[kThreads / 64];
     __shared__ int s_idx[kThreads / 64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int nroot = x.st->nroot;
+    const int nroot = x.st->nroot[par];
     const int32_t* __restrict__ rk = x.rk[par];
     const int32_t* __restrict__ sz = x.sz[par];
     // calculateBranchLength (:158-197) rides along: every node but the root owns ONE candidate, the slot parent -> node (the
     // direction the reference evaluates: the shallower end first), whose two values are final here -- the one from above has just
     // been computed (or, for the root of a small subtree and for the top nodes, written by px_top_kernel), the one from below is
     // the bottom-up pass's.  The first minimum over (pendant length, slot) does not depend on who evaluates which slot: one
-    // partial per workgroup, finished by px_split_kernel as before.  (Was: px_scan_kernel, a launch of its own per tip.)
+    // partial per workgroup, finished by px_patch_kernel.  (Was: px_scan_kernel, a launch of its own per tip.)
     XBest best;
     px_best_init(best);
     const int grid = (int)gridDim.x - kPackBlocks;
     if ((int)blockIdx.x >= grid) {      // the spare workgroups: the top nodes' candidates
-        const int T = x.st->ntop;
+        const int T = x.st->ntop[par];
         for (int t = ((int)blockIdx.x - grid) * kThreads + (int)threadIdx.x; t < T; t += kPackBlocks * kThreads) {
             const int v = x.tops[t];
             const int32_t* q = x.nd + 12 * (int64_t)v;
@@ -712,9 +746,10 @@ __global__ __launch_bounds__(kThreads) void px_small_down_kernel(PlaceBuffers p,
             for (int k = 0; k < 3; ++k)
                 if (q[k] >= 0 && rk[q[6 + k]] < myrk) {      // the edge to the parent
                     const int idx = q[3 + k];
+                    const double plen = p.len[idx];
                     double add, d1;
-                    px_candidate(x.lim[idx], x.lim[q[k]], p.len[idx], add, d1);
-                    px_best_take(best, add, d1, idx);
+                    px_candidate(x.lim[idx], x.lim[q[k]], plen, add, d1);
+                    px_best_take(best, add, d1, idx, q[6 + k], v, q[k], plen);
                 }
         }
         px_best_store(best, s_key, s_add, s_frac, s_idx, partials + blockIdx.x);
@@ -733,11 +768,14 @@ __global__ __launch_bounds__(kThreads) void px_small_down_kernel(PlaceBuffers p,
         for (int k = 0; k < 3; ++k)
             if (c.slot[k] >= 0 && (c.down[k] || lane == 0)) inc[k] = x.lim[c.rslot[k]];
         // the candidate's operands that are there already: the node's own bottom-up value and the length of the parent's slot
-        int cand = -1;
+        int cand = -1, cand_x = -1, cand_rev = -1;
         double below = 0.0, plen = 0.0, above0 = 0.0;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            if (c.slot[k] >= 0 && !c.down[k]) { cand = c.rslot[k]; below = x.lim[c.slot[k]]; plen = p.len[c.rslot[k]]; above0 = inc[k]; }
+            if (c.slot[k] >= 0 && !c.down[k]) {
+                cand = c.rslot[k]; cand_rev = c.slot[k]; cand_x = p.belong[c.rslot[k]];
+                below = x.lim[c.slot[k]]; plen = p.len[c.rslot[k]]; above0 = inc[k];
+            }
         for (int lev = 0; lev <= maxld; ++lev) {
             if (ld == lev) {
                 double rq[3];
@@ -763,7 +801,7 @@ __global__ __launch_bounds__(kThreads) void px_small_down_kernel(PlaceBuffers p,
         if (cand >= 0) {
             double add, d1;
             px_candidate(lane == 0 ? above0 : s_in[w][lane], below, plen, add, d1);
-            px_best_take(best, add, d1, cand);
+            px_best_take(best, add, d1, cand, cand_x, v, cand_rev, plen);
         }
         wave_lds_sync();      // (s_in is rewritten by the next subtree)
     }
@@ -1099,7 +1137,7 @@ __global__ __launch_bounds__(kXT) void px_top_kernel(PlaceBuffers p, ExactBuffer
     __shared__ int s_red[kXT / 64], s_maxdep;
     __shared__ int s_lv[kTopLevLds + 2];                                // level offsets (lists of at most kTopLevLds levels: else in memory)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int T = x.st->ntop;
+    const int T = x.st->ntop[par];
     if (T == 0 || x.st->poll_fail) return;      // (a poll of an earlier tip ran into its bound: the run has failed, its launches drain)
     const int32_t* __restrict__ rk = x.rk[par];
     const bool lds = T <= kTopLds && !x.top_in_memory;
@@ -1378,8 +1416,8 @@ __global__ void px_init_tree_kernel(PlaceBuffers p, ExactBuffers x, const double
     px_set_node(x, 1, 1, 3, nv, -1, -1, -1, -1, -1, -1);
     px_set_node(x, nv, 2, 0, 0, 3, 1, 1, -1, -1, -1);
     XStep st;
-    st.rrk = 0; st.ysz = 0; st.small = 0; st.middle = -1; st.outside = -1;
-    st.nroot = 1; st.ntop = 0; st.poll_fail = 0; st.poll_node = -1; st.poll_pass = 0;
+    st.nroot[0] = 1; st.ntop[0] = 0; st.nroot[1] = 0; st.ntop[1] = 0;      // (the passes for tip 2 read parity 0)
+    st.poll_fail = 0; st.poll_node = -1; st.poll_pass = 0;
     st.quirk = 0;
     x.roots[0] = nv;
     *x.st = st;
@@ -1488,9 +1526,9 @@ int exact_tip(PlaceBuffers& p, ExactBuffers& x, int64_t tip, const double* d_dis
     // the candidates of this tip were evaluated by the top-down pass that ran for it (exact_passes of the previous step): one partial
     // per workgroup of that launch
     nblk = (int)exact_pass_grid(2 * tip - 1) + kPackBlocks;
-    hipLaunchKernelGGL(px_split_kernel, dim3(1), dim3(256), 0, s, p, x, (const PlacePartialX*)parts, nblk, tip, d_trace);
     const int64_t tot = p.N + tip;
-    hipLaunchKernelGGL(px_patch_kernel, dim3((unsigned)((tot + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, x, tip);
+    hipLaunchKernelGGL(px_patch_kernel, dim3((unsigned)((tot + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, x, (const PlacePartialX*)parts, nblk, tip,
+                       d_trace);
     DPR_HIP(hipGetLastError());
     if (has_next) return exact_passes(p, x, d_dis_next, (int)((tip + 1) & 1), 2 * tip + 1, s);
     return DPR_OK;
