@@ -615,12 +615,14 @@ __global__ __launch_bounds__(kThreads) void px_patch_kernel(PlaceBuffers p, Exac
 }
 
 // ---- records of the top tree's climbing schedule (px_top_climb below)
-struct __attribute__((aligned(16))) TopUp { uint32_t m; int32_t upslot; double lenp; };      // what a climb needs of the parent
-struct __attribute__((aligned(16))) TopDn { uint32_t refs; int32_t slotA, slotB; uint32_t fv; };   // what the walk down needs besides
+struct __attribute__((aligned(16))) TopUp { uint32_t m; uint32_t upoff; double lenp; };      // what a climb needs of the parent
+struct __attribute__((aligned(16))) TopDn { uint32_t refs; uint32_t offA, offB; uint32_t fv; };   // what the walk down needs besides
 struct __attribute__((aligned(16))) TopCC { double a, b; };                                   // clipped bottom-up terms of child A / B
 // TopUp::m: bits 0-12 parent's index, 13 has a parent, 14 the node is its parent's child B, 15 / 16 child A / B is a top node,
-// 17 / 18 child A / B exists.  (Child A: the child that follows the node in pre-order.)  TopDn::refs: index of A | index of B << 16;
-// TopDn::fv: the flag bits of m, and in bit 0 the child the node's climb came from (written by the climb).
+// 17 / 18 child A / B exists.  (Child A: the child that follows the node in pre-order.)  TopDn::refs: index of A | index of B << 16
+// (a child outside the top tree: the spare record kTopClimb - 1); TopDn::fv: the flag bits of m, and in bit 0 the child the
+// node's climb came from (written by the climb).  upoff / offA / offB: BYTE offsets into lim[] of the slot to the parent / to
+// the children, the spare double at the end of lim[] for an edge that is not there (the loops store without asking).
 constexpr uint32_t kUpPar = 1u << 13, kUpB = 1u << 14, kUpTopA = 1u << 15, kUpTopB = 1u << 16, kUpHasA = 1u << 17, kUpHasB = 1u << 18;
 constexpr uint32_t kUpFlags = ~0x1fffu;
 // the structural part of a top node's records (everything but the values of this tip): packed by spare workgroups of the
@@ -640,8 +642,10 @@ __device__ __forceinline__ void px_top_pack(const PlaceBuffers& p, const ExactBu
     const int slot[3] = { a.x, a.y, a.z }, rslot[3] = { a.w, b.x, b.y }, nb[3] = { b.z, b.w, c4.x };
     const int myrk = rk[v];
     TopPack k;
-    k.u.m = 0; k.u.upslot = -1; k.u.lenp = 0.0;
-    k.d.refs = 0; k.d.slotA = -1; k.d.slotB = -1; k.d.fv = 0;
+    const uint32_t spare = (uint32_t)((8 * p.N - 1) * 8);      // (lim[] has 8N entries, slots end below 4N)
+    constexpr uint32_t kNoRef = (uint32_t)(kTopClimb - 1);
+    k.u.m = 0; k.u.upoff = spare; k.u.lenp = 0.0;
+    k.d.refs = kNoRef | (kNoRef << 16); k.d.offA = spare; k.d.offB = spare; k.d.fv = 0;
     k.lenup = 0.0; k.lenA = 0.0; k.lenB = 0.0; k.rslotA = -1; k.rslotB = -1;
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
@@ -650,11 +654,11 @@ __device__ __forceinline__ void px_top_pack(const PlaceBuffers& p, const ExactBu
         const int ti = x.tix[nb[e]];
         const double len = p.len[slot[e]];
         if (nrk > myrk) {                        // a child; outside the top tree (ti < 0) its value is read from memory by px_top_climb
-            const uint32_t r = (uint32_t)(ti < 0 ? 0 : ti);
-            if (nrk == myrk + 1) { k.d.slotA = slot[e]; k.lenA = len; k.rslotA = ti < 0 ? rslot[e] : -1; k.d.refs |= r; k.u.m |= kUpHasA | (ti >= 0 ? kUpTopA : 0u); }
-            else { k.d.slotB = slot[e]; k.lenB = len; k.rslotB = ti < 0 ? rslot[e] : -1; k.d.refs |= r << 16; k.u.m |= kUpHasB | (ti >= 0 ? kUpTopB : 0u); }
+            const uint32_t r = ti < 0 ? kNoRef : (uint32_t)ti;
+            if (nrk == myrk + 1) { k.d.offA = (uint32_t)slot[e] * 8u; k.lenA = len; k.rslotA = ti < 0 ? rslot[e] : -1; k.d.refs = (k.d.refs & 0xffff0000u) | r; k.u.m |= kUpHasA | (ti >= 0 ? kUpTopA : 0u); }
+            else { k.d.offB = (uint32_t)slot[e] * 8u; k.lenB = len; k.rslotB = ti < 0 ? rslot[e] : -1; k.d.refs = (k.d.refs & 0xffffu) | (r << 16); k.u.m |= kUpHasB | (ti >= 0 ? kUpTopB : 0u); }
         } else {                                 // the parent (a top node, as its subtree is larger)
-            k.u.upslot = slot[e]; k.lenup = len; k.u.lenp = p.len[rslot[e]];
+            k.u.upoff = (uint32_t)slot[e] * 8u; k.lenup = len; k.u.lenp = p.len[rslot[e]];
             k.u.m |= kUpPar | (uint32_t)ti | (myrk == nrk + 1 ? 0u : kUpB);
         }
     }
@@ -1024,13 +1028,15 @@ __device__ __forceinline__ void px_top_climb(const PlaceBuffers& p, const ExactB
     }
     int n = -1;           // node the climb stands on (evaluated)
     double val = 0.0;     // its bottom-up value
-    TopUp cur; cur.m = 0; cur.upslot = -1; cur.lenp = 0.0;
+    TopUp cur; cur.m = 0; cur.upoff = 0; cur.lenp = 0.0;
+    char* const lim8 = reinterpret_cast<char*>(x.lim);
+    auto lim_store = [&](uint32_t off, double v) { *reinterpret_cast<double*>(lim8 + off) = v; };
     if (tid < *nstart) {
         n = starts[tid];
         cur = up[n];
         const TopCC c = cc[n];
         val = c.a > c.b ? c.a : c.b;
-        if (cur.upslot >= 0) x.lim[cur.upslot] = val;
+        lim_store(cur.upoff, val);
     }
     bool act = n >= 0;
     int steps = 0;
@@ -1049,17 +1055,17 @@ __device__ __forceinline__ void px_top_climb(const PlaceBuffers& p, const ExactB
                 // one LDS round trip: the atomic on the parent's meeting word and the parent's record travel together
                 const long long old = __hip_atomic_fetch_max(acc + par, __double_as_longlong(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const TopUp pu = up[par];
-                asm volatile("" :: "v"(old), "v"(pu.m), "v"(pu.upslot), "v"(pu.lenp));
+                asm volatile("" :: "v"(old), "v"(pu.m), "v"(pu.upoff), "v"(pu.lenp));
                 if (old == kSent) act = false;           // first of two: the sibling's climb goes on
                 else {
                     const double o = __longlong_as_double(old);
-                    const double v = c > o ? c : o;
+                    const double v = __builtin_fmax(c, o);      // (both >= +0 and no NaN: the larger one)
                     const bool fromB = (cur.m & kUpB) != 0u;
                     TopCC w; w.a = fromB ? o : c; w.b = fromB ? c : o;      // (one top child: o IS the other child's term, already there)
                     cc[par] = w;
                     dn[par].fv = (pu.m & kUpFlags) | (fromB ? 1u : 0u);
                     __hip_atomic_store(acc + par, kSent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // from now on: the value from above
-                    if (pu.upslot >= 0) x.lim[pu.upslot] = v;
+                    lim_store(pu.upoff, v);
                     n = par; val = v; cur = pu;
                 }
             }
@@ -1091,28 +1097,24 @@ __device__ __forceinline__ void px_top_climb(const PlaceBuffers& p, const ExactB
         }
         if (__builtin_amdgcn_ballot_w64(walk) == 0ull) __builtin_amdgcn_s_sleep(1);      // (wave-uniform: nobody has anything to do yet)
         if (walk) {
+            // (a top node has both children; the root receives +0 over a slot of length 0: no case distinctions on the way down)
             const uint32_t m = d.fv;
-            const bool more = (m & (kUpTopA | kUpTopB)) != 0u;
+            const bool viaB = (m & 1u) != 0u;
             const int ra = (int)(d.refs & 0xffffu), rb = (int)(d.refs >> 16);
-            const int nn = more ? ((m & 1u) ? rb : ra) : kTopClimb - 1;      // (the spare record when the chain ends here)
+            const int nn = viaB ? rb : ra;                 // (the spare record when that child is outside the top tree)
             const TopDn d2 = dn[nn];
             const TopCC c2 = cc[nn];
             const double lu2 = lenup[nn];
-            double la = 0.0, lb = 0.0;
-            if (m & kUpPar) { const double rq = win - lu; if (rq > 0.0) { la = rq; lb = rq; } }
-            if (c.b > la) la = c.b;
-            if (c.a > lb) lb = c.a;
-            // (the value of the via child travels in a register; only the chains that hang off the walk get theirs through LDS)
-            if (m & kUpHasA) {
-                x.lim[d.slotA] = la;
-                if ((m & kUpTopA) && (m & 1u)) __hip_atomic_store(acc + ra, __double_as_longlong(la), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            if (m & kUpHasB) {
-                x.lim[d.slotB] = lb;
-                if ((m & kUpTopB) && !(m & 1u)) __hip_atomic_store(acc + rb, __double_as_longlong(lb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            if (!more || ++steps > 2 * kTopClimb) walk = false;      // the chain's first node (where the climb started): done
-            win = (m & 1u) ? lb : la;
+            const double rq = win - lu;
+            const double base = rq > 0.0 ? rq : 0.0;
+            const double la = __builtin_fmax(base, c.b), lb = __builtin_fmax(base, c.a);      // (all >= +0, no NaN)
+            lim_store(d.offA, la);
+            lim_store(d.offB, lb);
+            // the value of the via child travels in a register; the chain that hangs off the other child gets its through LDS
+            if ((m & (kUpTopA | kUpTopB)) == (kUpTopA | kUpTopB))
+                __hip_atomic_store(acc + (viaB ? ra : rb), __double_as_longlong(viaB ? la : lb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!(m & (kUpTopA | kUpTopB))) walk = false;      // the chain's first node (where the climb started): done
+            win = viaB ? lb : la;
             n = nn; d = d2; c = c2; lu = lu2;
         }
     }
