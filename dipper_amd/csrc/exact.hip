@@ -497,6 +497,26 @@ __global__ __launch_bounds__(kThreads) void px_patch_kernel(PlaceBuffers p, Exac
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int idx = (int)((int64_t)blockIdx.x * kThreads + tid);
     if (tid < 2) s_cnt[tid] = 0;
+    const int middle = i + N - 1, outside = i, ec0 = 4 * i - 4;
+    const int32_t* __restrict__ rk_in = x.rk[i & 1];
+    const int32_t* __restrict__ sz_in = x.sz[i & 1];
+    int32_t* __restrict__ rk_out = x.rk[(i + 1) & 1];
+    int32_t* __restrict__ sz_out = x.sz[(i + 1) & 1];
+    const bool live = idx < tot && px_placed(idx, i, N);
+    // ---- what the elementwise part reads of the OLD state does not depend on the split: in flight while the argmin is finished
+    // (the node's record, old rank and size; old ranks and sizes of its neighbours)
+    int32_t* const q = x.nd + 12 * (int64_t)(live ? idx : 0);
+    int rec[9], r_old = 0, s_old = 0, rnb[3] = { 0, 0, 0 }, snb[3] = { 0, 0, 0 };
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rec[k] = -1;
+    if (live && idx != middle && idx != outside) {
+        const int4 a = reinterpret_cast<const int4*>(q)[0], b = reinterpret_cast<const int4*>(q)[1];
+        rec[0] = a.x; rec[1] = a.y; rec[2] = a.z; rec[3] = a.w; rec[4] = b.x; rec[5] = b.y; rec[6] = b.z; rec[7] = b.w; rec[8] = q[8];
+        r_old = rk_in[idx]; s_old = sz_in[idx];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (rec[k] >= 0) { rnb[k] = rk_in[rec[6 + k]]; snb[k] = sz_in[rec[6 + k]]; }
+    }
     // ---- thrust::min_element over all 4N-4 tuples, first occurrence (and, beside it, the first minimum with a NaN counted as
     // +inf: the edge that is split when the default tuple wins, see below)
     double badd = __builtin_inf(), fkey = __builtin_inf();
@@ -533,64 +553,51 @@ __global__ __launch_bounds__(kThreads) void px_patch_kernel(PlaceBuffers p, Exac
     const int eid = win.eid;
     const double fracLen = win.frac, addLen = win.add, originalDis = win.len;
     const int xe = eid, ye = win.ye, xn0 = win.xn, yn0 = win.yn;      // the slot x -> y and its reverse
-    const int middle = i + N - 1, outside = i, ec0 = 4 * i - 4;
-    const int32_t* __restrict__ rk_in = x.rk[i & 1];
-    const int32_t* __restrict__ sz_in = x.sz[i & 1];
-    int32_t* __restrict__ rk_out = x.rk[(i + 1) & 1];
-    int32_t* __restrict__ sz_out = x.sz[(i + 1) & 1];
-    const bool swapq = rk_in[xn0] > rk_in[yn0];
-    const int xn = xn0, yn = swapq ? xn0 : yn0;      // the reference's swap, :236-239 (`yn = xn; xn = t2`: both become x)
+    const int rkx = rk_in[xn0], rky = rk_in[yn0], szx = sz_in[xn0], szy = sz_in[yn0], dxn = x.dep[xn0];
+    const bool swapq = rkx > rky;      // the reference's swap, :236-239 (`yn = xn; xn = t2`: both become x)
     const bool quirk = dflt || swapq;
     // dfsrk[middle] = dfsrk[y], dfsrk[outside] = dfsrk[middle] + 1 and the shift of the ranks >= it
-    const int rrk = rk_in[yn], ysz = sz_in[yn];
+    const int rrk = swapq ? rkx : rky, ysz = swapq ? szx : szy;
     const int small = rrk + 1 + ysz;      // last rank of the moved subtree after the shift (findEndRk + reduce of the reference)
     const int cpar = (i + 1) & 1;
-    const bool live = idx < tot && px_placed(idx, i, N);
-    auto new_rank = [&](int v) { if (v == middle) return rrk; if (v == outside) return rrk + 1; const int r = rk_in[v]; return r >= rrk ? r + 2 : r; };
-    auto new_size = [&](int v) {
-        if (v == middle) return ysz + 2;
-        if (v == outside) return 1;
-        const int r = rk_in[v], s = sz_in[v];
-        return (r < rrk && r + s > rrk) ? s + 2 : s;      // the ancestors of y gain the two new nodes
+    // new rank / size of node v from its old ones
+    auto new_rank = [&](int v, int r) { return v == middle ? rrk : v == outside ? rrk + 1 : (r >= rrk ? r + 2 : r); };
+    auto new_size = [&](int v, int r, int sz) {
+        return v == middle ? ysz + 2 : v == outside ? 1 : ((r < rrk && r + sz > rrk) ? sz + 2 : sz);      // the ancestors of y gain the two new nodes
     };
     int kind = -1, mine = 0;          // 0: root of a small subtree, 1: top node
     if (live) {
         // the node's record after the split
-        int32_t* q = x.nd + 12 * (int64_t)idx;
-        int rec[9];
         if (idx == middle) {
             const int r[9] = { ec0, ec0 + 1, ec0 + 3, xe, ye, ec0 + 2, xn0, yn0, outside };
 #pragma unroll
             for (int k = 0; k < 9; ++k) { rec[k] = r[k]; q[k] = r[k]; }
+            rnb[0] = rkx; snb[0] = szx; rnb[1] = rky; snb[1] = szy;
         } else if (idx == outside) {
             const int r[9] = { ec0 + 2, -1, -1, ec0 + 3, -1, -1, middle, -1, -1 };
 #pragma unroll
             for (int k = 0; k < 9; ++k) { rec[k] = r[k]; q[k] = r[k]; }
-        } else {
+        } else if (idx == xn0 || idx == yn0) {      // x and y keep their slots, which now lead to `middle`
+            const int slot = idx == xn0 ? xe : ye, nrev = idx == xn0 ? ec0 : ec0 + 1;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) rec[k] = q[k];
-            if (idx == xn0 || idx == yn0) {      // x and y keep their slots, which now lead to `middle`
-                const int slot = idx == xn0 ? xe : ye, nrev = idx == xn0 ? ec0 : ec0 + 1;
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    if (rec[k] == slot) { rec[3 + k] = nrev; rec[6 + k] = middle; q[3 + k] = nrev; q[6 + k] = middle; }
-            }
+            for (int k = 0; k < 3; ++k)
+                if (rec[k] == slot) { rec[3 + k] = nrev; rec[6 + k] = middle; q[3 + k] = nrev; q[6 + k] = middle; }
         }
-        const int rn = new_rank(idx), sn = new_size(idx);
+        const int rn = new_rank(idx, r_old), sn = new_size(idx, r_old, s_old);
         rk_out[idx] = rn;
         sz_out[idx] = sn;
         x.nar[rn] = idx;
         x.tix[idx] = -1;
-        if (idx == middle) x.dep[idx] = x.dep[xn] + 1;            // (dep[middle] = dep[x], then + 1 with the moved subtree, :400-416)
-        else if (idx == outside) x.dep[idx] = x.dep[xn] + 2;
+        if (idx == middle) x.dep[idx] = dxn + 1;            // (dep[middle] = dep[x], then + 1 with the moved subtree, :400-416)
+        else if (idx == outside) x.dep[idx] = dxn + 2;
         else if (rn >= rrk && rn <= small) x.dep[idx] += 1;
         // parent = the neighbour with the smaller rank
-        int parent = -1;
+        int parent = -1, psize = 0;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            if (rec[k] >= 0 && new_rank(rec[6 + k]) < rn) parent = rec[6 + k];
+            if (rec[k] >= 0 && new_rank(rec[6 + k], rnb[k]) < rn) { parent = rec[6 + k]; psize = new_size(rec[6 + k], rnb[k], snb[k]); }
         if (sn > kSm) kind = 1;
-        else if (parent < 0 || new_size(parent) > kSm) kind = 0;
+        else if (parent < 0 || psize > kSm) kind = 0;
         if (kind >= 0) mine = atomicAdd(&s_cnt[kind], 1);
         if (idx == middle) {
             // ---- updateTreeStructure: the adjacency arrays
