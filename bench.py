@@ -1086,11 +1086,31 @@ def other_configs(args, local_rank, stage, budget, tmp):
         stage.drop(inp)
         return out
 
+    def exact_30k():
+        # the exact placement mode (src/placement.cu:508-789), every tip against every edge of the growing tree
+        n, L = 30000, 2000
+        inp = stage.gen("exact30k", n, L, args.seed + 11, 1e-3, 1e-4, 1e-2, shuffle=7)
+        d = dipper_amd.Dipper(local_rank)
+        try:
+            d.set_msa(Stage.packed4(inp), L)
+            t0 = time.perf_counter()
+            st = d.place_exact_run(capi.SRC_MSA, n, dist_type=capi.DIST_JC)
+            wall = time.perf_counter() - t0
+            out = {"workload": "exact placement, %d aligned tips x %d sites in random order, -d 2, packed tips in HBM -> tree arrays" % (n, L),
+                   "tips": n, "sites": L, "seconds": wall, "tips_per_s": n / wall, "us_per_tip": wall / n * 1e6,
+                   "max_depth": int(st["dep"][:2 * n - 1].max()),
+                   "trace_digest": hashlib.sha256(np.ascontiguousarray(st["trace"]).tobytes()).hexdigest()[:16]}
+        finally:
+            d.close()
+        stage.drop(inp)
+        return out
+
     # keys carry the sequence length: the authors' protocol is 10 000 sites for every size (scripts/experiment.sh:14,
     # scripts/alisim.sh:14); the short inputs of rounds 2-5 stay beside the protocol-length ones
     leg("nj_100k_10000_sites", nj_100k, 30)
     leg("place_100k_unaligned_3000_bases", place_100k_unaligned, 25)
     leg("dc_1m_400_sites", dc_1m, 30)
+    leg("place_exact_30k_2000_sites", exact_30k, 10)
     if not args.no_add_leg:
         leg("add_50k_onto_500k_aligned_1000_sites", lambda: add_onto_backbone("m"), 45)
         leg("add_50k_onto_500k_mash_3000_bases", lambda: add_onto_backbone("r"), 75)
