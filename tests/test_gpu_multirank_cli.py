@@ -161,3 +161,16 @@ def test_ranks_fall_back_to_the_windows_when_rccl_does_not_come_up(tmp_path, ali
     assert o2.read_text() == o1.read_text()
     r = run("-i", "m", "-I", str(aligned), "-m", "1", "-d", "2", "-O", str(o2), "--devices", "0,0", "--transport", "rccl")
     assert r.returncode == 1 and "RCCL refuses two ranks on one device" in r.stderr
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode", ["2", "1"], ids=["nj", "placement"])
+@pytest.mark.parametrize("tips,devices", [(4, "0,0,0,0,0"), (7, "0,0,0"), (1501, "0,0,0,0,0")],
+                         ids=["4_tips_5_ranks", "7_tips_3_ranks", "1501_tips_5_ranks"])
+def test_more_ranks_than_work_and_uneven_shares(tmp_path, tips, devices, mode):
+    """five process ranks (the most a one-GPU box admits beside the launcher), fewer tips than ranks, shares that do not divide:
+    empty shares and ragged all-gather segments must leave the Newick file as the one-rank run writes it"""
+    p = tmp_path / "small.fa"
+    gen(p, tips, 300, seed=tips)
+    a, b, _ = both(tmp_path, ["-i", "m", "-I", str(p), "-m", mode, "-d", "2"], devices)
+    assert a == b and a.count(",") == tips - 1
