@@ -349,3 +349,46 @@ def test_config4_add_50k_onto_500k_mash_source(tmp_path, orc):
         assert np.array_equal(full["trace"][m:n2], part["trace"][m:n2])
     finally:
         d.close()
+
+
+@pytest.mark.timeout(900)
+def test_exact_placement_run_that_crosses_the_top_tree_schedules(monkeypatch):
+    """36 000 tips in random order: the top tree (nodes above the one-wavefront subtrees) grows past the 2 048 nodes the climbing
+    schedule of px_top_kernel keeps in LDS, so ONE run uses the climbing schedule first and the polling one after (exact.hip:
+    px_top_climb / px_top_poll; the structural records stop being packed at the same point).  The oracle needs hours at this
+    size; the bar is the level-by-level schedule of rounds 3-5 (DPR_EXACT_TOP_LEVELS=1), which the smaller cases pin to the
+    oracle: every array of the result bit for bit."""
+    import dipper_amd
+    from dipper_amd import capi
+    n, L = 36000, 400
+    seqs = _util.synth_alignment(np.random.default_rng(36), n, L, mean_bl=2e-3, lo=2e-4, hi=2e-2)
+    perm = np.random.default_rng(7).permutation(n)
+    packed = capi.pack4_many([seqs[i] for i in perm])
+    del seqs
+    res = {}
+    for tag in ("default", "levels"):
+        if tag == "levels":
+            monkeypatch.setenv("DPR_EXACT_TOP_LEVELS", "1")
+        d = dipper_amd.Dipper(0)
+        try:
+            d.set_msa(packed, L)
+            res[tag] = d.place_exact_run(capi.SRC_MSA, n, dist_type=capi.DIST_JC)
+        finally:
+            d.close()
+    a, b = res["default"], res["levels"]
+    nodes, live = 2 * n - 1, 4 * n - 4
+    assert np.array_equal(a["trace"][2:], b["trace"][2:])
+    for key in ("head", "e", "nxt", "belong", "len", "rev", "dep"):
+        m = nodes if key in ("head", "dep") else live
+        assert np.array_equal(a[key][:m], b[key][:m]), key
+    # the run did cross: nodes whose subtree has more than 64 nodes, counted on the final tree (parent = the neighbour one level up)
+    dep = a["dep"][:nodes].astype(np.int64)
+    src, dst = a["belong"][:live].astype(np.int64), a["e"][:live].astype(np.int64)
+    up = dep[dst] < dep[src]
+    parent = np.full(nodes, -1, dtype=np.int64)
+    parent[src[up]] = dst[up]
+    size = np.ones(nodes, dtype=np.int64)
+    for v in np.argsort(-dep, kind="stable"):
+        if parent[v] >= 0:
+            size[parent[v]] += size[v]
+    assert size.max() == nodes and int((size > 64).sum()) > 2048
