@@ -367,7 +367,8 @@ static int place_exact_attempt(dpr_ctx* c, int source, int dist_type, int k, int
     int rc = DPR_OK;
     while (!rc) {
         const int64_t nr = n - r0 < R + 1 ? n - r0 : R + 1;
-        rc = fill_rows(r0, nr);
+        if (r0 > 1) rc = exact_adapt(x, c->stream);
+        if (!rc) rc = fill_rows(r0, nr);
         if (!rc && r0 == 1) rc = exact_init(p, x, row_ptr(1), nr > 1 ? row_ptr(2) : nullptr, nr > 1, c->stream);
         for (int64_t i = r0 < 2 ? 2 : r0; !rc && i < r0 + nr - 1; ++i) rc = exact_tip(p, x, i, row_ptr(i + 1), true, c->place_trace, c->stream);
         if (rc) break;

@@ -497,6 +497,9 @@ struct ExactBuffers {
     int32_t* dfsrk = nullptr;    // literal schedule: the reference's single rank array (alias of rk[0])
     bool literal = false;        // run the literal one-workgroup schedule (fallback / DPR_EXACT_LITERAL=1)
     unsigned long long* clk = nullptr;   // DPR_EXACT_CLOCKS=1 (profiling): phase clocks of px_top_kernel, summed over the tips (100 MHz ticks)
+    int sm = 64;                 // nodes of a small subtree for the next patch launch (64 / 256 / 1 024: exact_adapt)
+    int sm_forced = 0;           // tests (DPR_EXACT_SM=64|256|1024): no adaptation
+    int pass_sm = 64;            // ... of the passes that are enqueued last (their workgroups' partials are what the next patch reads)
     bool top_poll = false;       // tests / A-B (DPR_EXACT_TOP_POLL=1): the polling schedule of px_top_poll even where the climbing one applies
     bool top_levels = false;     // tests / A-B (DPR_EXACT_TOP_LEVELS=1): the top-tree pass level by level with a workgroup barrier per level (rounds 3-5)
     bool top_in_memory = false;  // tests (DPR_EXACT_TOP_MEM=1): the top-tree pass keeps its values in memory even when they fit LDS
@@ -507,6 +510,7 @@ int exact_init(PlaceBuffers& p, ExactBuffers& x, const double* d_dis_row1, const
                hipStream_t s);
 int exact_tip(PlaceBuffers& p, ExactBuffers& x, int64_t tip, const double* d_dis_next, bool has_next, double* d_trace,
               hipStream_t s);
+int exact_adapt(ExactBuffers& x, hipStream_t s);                 // between batches of tips: larger small subtrees when the top tree approaches its LDS capacity
 int exact_quirk(ExactBuffers& x, hipStream_t s, bool* quirk);    // did the fast schedule meet the case only the literal one reproduces?
 
 // dc.hip: divide-and-conquer mode (cluster assignment + concurrent cluster trees)

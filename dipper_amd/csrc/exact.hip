@@ -20,7 +20,7 @@
 namespace dpr {
 
 constexpr int kXT = 1024;   // threads of the single-workgroup top-tree kernel
-constexpr int kSm = 64;     // a "small" subtree has at most this many nodes: one wavefront, one lane per node
+// (a "small" subtree has at most ExactBuffers::sm nodes, one thread per node: 64 = one wavefront; 256 / 1 024 = one workgroup)
 constexpr int kTopLds = 6144;   // top nodes whose pass values fit the workgroup's LDS (2 x 8 bytes each)
 constexpr int kTopLevLds = 4094;   // levels of the top tree whose offsets fit LDS
 constexpr int kTopReg = 4;         // top nodes per thread whose contexts stay in registers over both passes
@@ -129,8 +129,8 @@ __device__ __forceinline__ void px_best_take(XBest& b, double add, double frac, 
     const double key = add == add ? add : __builtin_inf();
     if (key < b.key || (key == b.key && idx < b.idx)) { b.key = key; b.add = add; b.frac = frac; b.len = len; b.idx = idx; b.xn = xn; b.yn = yn; b.ye = ye; }
 }
-// (all threads of the workgroup call this once; s_* : kThreads / 64 entries each)
-__device__ __forceinline__ void px_best_store(XBest b, double* s_key, double* s_add, double* s_frac, int* s_idx, PlacePartialX* __restrict__ out)
+// (all threads of the workgroup call this once; s_key / s_idx: one entry per wavefront of the workgroup)
+__device__ __forceinline__ void px_best_store(XBest b, double* s_key, int* s_idx, PlacePartialX* __restrict__ out)
 {
     // (the winner's lane within the wavefront first, then its payload with one shuffle per field)
     double k = b.key; int ki = b.idx;
@@ -140,15 +140,16 @@ __device__ __forceinline__ void px_best_store(XBest b, double* s_key, double* s_
         const int oi = __shfl_xor(ki, off, 64);
         if (ok < k || (ok == k && oi < ki)) { k = ok; ki = oi; }
     }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
     const unsigned long long mine = __builtin_amdgcn_ballot_w64(b.idx == ki && (b.key == k));
     const int src = mine ? __builtin_ctzll(mine) : 0;      // (no candidate in the wavefront: every lane holds the initial record)
     b.key = __shfl(b.key, src, 64); b.add = __shfl(b.add, src, 64); b.frac = __shfl(b.frac, src, 64); b.len = __shfl(b.len, src, 64);
     b.idx = __shfl(b.idx, src, 64); b.xn = __shfl(b.xn, src, 64); b.yn = __shfl(b.yn, src, 64); b.ye = __shfl(b.ye, src, 64);
+    __syncthreads();      // (the arrays may still be read as something else by a slower wavefront)
     if (lane == 0) { s_key[w] = b.key; s_idx[w] = b.idx; }
     __syncthreads();
     int win = 0;
-    for (int i = 1; i < kThreads / 64; ++i)
+    for (int i = 1; i < nw; ++i)
         if (s_key[i] < s_key[win] || (s_key[i] == s_key[win] && s_idx[i] < s_idx[win])) win = i;
     if (w == win && lane == 0) {
         PlacePartialX pp;
@@ -156,7 +157,6 @@ __device__ __forceinline__ void px_best_store(XBest b, double* s_key, double* s_
         pp.xn = b.xn; pp.yn = b.yn; pp.ye = b.ye; pp.pad = 0; pp.len = b.len;
         *out = pp;
     }
-    (void)s_add; (void)s_frac;
 }
 
 // calculateBranchLength over the live slots + block-level first minimum (the literal schedule; the fast one evaluates the slots
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(kXT) void px_step_literal_kernel(PlaceBuffers p, Ex
 // rewritten are not read by anybody else.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void px_patch_kernel(PlaceBuffers p, ExactBuffers x, const PlacePartialX* __restrict__ partials,
-                                                            int nparts, int64_t tip, double* __restrict__ trace)
+                                                            int nparts, int64_t tip, double* __restrict__ trace, int sm)
 {
     __shared__ int s_cnt[2], s_base[2];
     __shared__ double s_add[kThreads / 64], s_key[kThreads / 64];
@@ -596,8 +596,8 @@ __global__ __launch_bounds__(kThreads) void px_patch_kernel(PlaceBuffers p, Exac
 #pragma unroll
         for (int k = 0; k < 3; ++k)
             if (rec[k] >= 0 && new_rank(rec[6 + k], rnb[k]) < rn) { parent = rec[6 + k]; psize = new_size(rec[6 + k], rnb[k], snb[k]); }
-        if (sn > kSm) kind = 1;
-        else if (parent < 0 || psize > kSm) kind = 0;
+        if (sn > sm) kind = 1;
+        else if (parent < 0 || psize > sm) kind = 0;
         if (kind >= 0) mine = atomicAdd(&s_cnt[kind], 1);
         if (idx == middle) {
             // ---- updateTreeStructure: the adjacency arrays
@@ -686,29 +686,69 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 // ------------------------------------------------------------------------------------------------
-// bottom-up pass inside the small subtrees (updateFromBottomToTop, :296-329): one wavefront per subtree, lane = node in
-// pre-order, a node's value = lim[node -> parent]; children's values come from LDS
+// The passes inside the small subtrees.  A small subtree (at most B nodes: a contiguous run of pre-order ranks) is evaluated by B
+// threads, one per node, the values travelling through LDS, all small subtrees in parallel on all CUs.  B = 64: one WAVEFRONT per
+// subtree, four subtrees per workgroup, no barrier (rounds 3-6).  B = 256 / 1 024 (round 6): one WORKGROUP per subtree with a
+// barrier per level of the subtree -- for trees whose top tree (the nodes above the small subtrees) would outgrow the 2 047 nodes
+// the climbing schedule of px_top_kernel keeps in LDS: with 64-node subtrees that happens at ~30 000 - 60 000 tips, which is where
+// the reference's command starts to use this mode at all (`-m 0` with 30 000 <= N < 1 000 000); 256 nodes divide the top
+// tree by ~3.5, 1 024 by ~12 (exact_adapt picks B from the top tree's size as the run goes).  Same recurrences, any B: lim[] bit for bit.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void px_small_up_kernel(PlaceBuffers p, ExactBuffers x, const double* __restrict__ dis, int par)
+template <int B> struct SmallShape {
+    static constexpr int kTpb = B < kThreads ? kThreads : B;      // threads per workgroup
+    static constexpr int kSubs = kTpb / B;                        // subtrees a workgroup works on at a time
+};
+template <int B>
+__device__ __forceinline__ void small_sync()
 {
-    __shared__ double s_val[kThreads / 64][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if constexpr (B == 64) wave_lds_sync();
+    else __syncthreads();
+}
+// maximum over the B threads of a subtree (s_red: one int per wavefront of the workgroup)
+template <int B>
+__device__ __forceinline__ int small_max(int v, int* s_red)
+{
+    v = wave_max_i32(v);
+    if constexpr (B == 64) return v;
+    else {
+        constexpr int kW = SmallShape<B>::kTpb / 64;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        int m = s_red[0];
+#pragma unroll
+        for (int i = 1; i < kW; ++i) m = max(m, s_red[i]);
+        return m;
+    }
+}
+
+// bottom-up pass inside the small subtrees (updateFromBottomToTop, :296-329): thread = node in pre-order, a node's value =
+// lim[node -> parent]; children's values come from LDS
+template <int B>
+__global__ __launch_bounds__(SmallShape<B>::kTpb) void px_small_up_kernel(PlaceBuffers p, ExactBuffers x, const double* __restrict__ dis, int par)
+{
+    constexpr int kTpb = SmallShape<B>::kTpb, kSubs = SmallShape<B>::kSubs;
+    __shared__ double s_val[kSubs][B];
+    __shared__ int s_red[kTpb / 64];
+    const int t = (int)threadIdx.x % B, sub = (int)threadIdx.x / B;
     const int nroot = x.st->nroot[par];
     const int32_t* __restrict__ rk = x.rk[par];
     const int32_t* __restrict__ sz = x.sz[par];
     const int grid = (int)gridDim.x - kPackBlocks;
     if ((int)blockIdx.x >= grid) {      // the spare workgroups: structural records of the top nodes for px_top_climb
-        const int t = ((int)blockIdx.x - grid) * kThreads + (int)threadIdx.x, T = x.st->ntop[par];
-        if (T < kTopClimb && t < T) px_top_pack(p, x, rk, t);
+        const int T = x.st->ntop[par];
+        if (T < kTopClimb)
+            for (int q = ((int)blockIdx.x - grid) * kTpb + (int)threadIdx.x; q < T; q += kPackBlocks * kTpb) px_top_pack(p, x, rk, q);
         return;
     }
-    for (int r = (int)blockIdx.x * (kThreads / 64) + w; r < nroot; r += grid * (kThreads / 64)) {
-        const int v0 = x.roots[r];
-        const int r0 = rk[v0], s = sz[v0], d0 = x.dep[v0];
-        const int v = lane < s ? x.nar[r0 + lane] : -1;
+    for (int r = (int)blockIdx.x * kSubs + sub; r - sub < nroot; r += grid * kSubs) {      // (B > 64: the same trip count for the whole workgroup)
+        const bool have = r < nroot;
+        const int v0 = have ? x.roots[r] : 0;
+        const int r0 = have ? rk[v0] : 0, s = have ? sz[v0] : 0, d0 = have ? x.dep[v0] : 0;
+        const int v = t < s ? x.nar[r0 + t] : -1;
         const XCtx c = px_ctx(x, p, dis, rk, v, r0, false);
         const int ld = v >= 0 ? x.dep[v] - d0 : -1;
-        const int maxld = wave_max_i32(ld);
+        const int maxld = small_max<B>(ld, s_red);
         for (int lev = maxld; lev >= 0; --lev) {
             if (ld == lev) {
                 double mx = c.init;
@@ -716,26 +756,28 @@ __global__ __launch_bounds__(kThreads) void px_small_up_kernel(PlaceBuffers p, E
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
                     if (c.slot[k] >= 0) {
-                        if (c.down[k]) { const double req = s_val[w][c.ref[k]] - c.len[k]; if (req > mx) mx = req; }
+                        if (c.down[k]) { const double req = s_val[sub][c.ref[k]] - c.len[k]; if (req > mx) mx = req; }
                         else up = c.slot[k];
                     }
-                s_val[w][lane] = mx;
+                s_val[sub][t] = mx;
                 if (up >= 0) x.lim[up] = mx;
             }
-            wave_lds_sync();
+            small_sync<B>();
         }
     }
 }
 
 // top-down pass inside the small subtrees (updateFromTopToBottom, :331-364): the value a node receives from its parent
 // comes from LDS (the subtree's root: from memory, written by the top-tree kernel); children's bottom-up values from memory
-__global__ __launch_bounds__(kThreads) void px_small_down_kernel(PlaceBuffers p, ExactBuffers x, const double* __restrict__ dis, int par,
-                                                                 PlacePartialX* __restrict__ partials)
+template <int B>
+__global__ __launch_bounds__(SmallShape<B>::kTpb) void px_small_down_kernel(PlaceBuffers p, ExactBuffers x, const double* __restrict__ dis, int par,
+                                                                            PlacePartialX* __restrict__ partials)
 {
-    __shared__ double s_in[kThreads / 64][64];
-    __shared__ double s_key[kThreads / 64], s_add[kThreads / 64], s_frac[kThreads / 64];
-    __shared__ int s_idx[kThreads / 64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int kTpb = SmallShape<B>::kTpb, kSubs = SmallShape<B>::kSubs;
+    __shared__ double s_in[kSubs][B];
+    __shared__ double s_key[kTpb / 64];
+    __shared__ int s_idx[kTpb / 64], s_red[kTpb / 64];
+    const int t = (int)threadIdx.x % B, sub = (int)threadIdx.x / B;
     const int nroot = x.st->nroot[par];
     const int32_t* __restrict__ rk = x.rk[par];
     const int32_t* __restrict__ sz = x.sz[par];
@@ -749,8 +791,8 @@ __global__ __launch_bounds__(kThreads) void px_small_down_kernel(PlaceBuffers p,
     const int grid = (int)gridDim.x - kPackBlocks;
     if ((int)blockIdx.x >= grid) {      // the spare workgroups: the top nodes' candidates
         const int T = x.st->ntop[par];
-        for (int t = ((int)blockIdx.x - grid) * kThreads + (int)threadIdx.x; t < T; t += kPackBlocks * kThreads) {
-            const int v = x.tops[t];
+        for (int q0 = ((int)blockIdx.x - grid) * kTpb + (int)threadIdx.x; q0 < T; q0 += kPackBlocks * kTpb) {
+            const int v = x.tops[q0];
             const int32_t* q = x.nd + 12 * (int64_t)v;
             const int myrk = rk[v];
 #pragma unroll
@@ -763,21 +805,22 @@ __global__ __launch_bounds__(kThreads) void px_small_down_kernel(PlaceBuffers p,
                     px_best_take(best, add, d1, idx, q[6 + k], v, q[k], plen);
                 }
         }
-        px_best_store(best, s_key, s_add, s_frac, s_idx, partials + blockIdx.x);
+        px_best_store(best, s_key, s_idx, partials + blockIdx.x);
         return;
     }
-    for (int r = (int)blockIdx.x * (kThreads / 64) + w; r < nroot; r += grid * (kThreads / 64)) {
-        const int v0 = x.roots[r];
-        const int r0 = rk[v0], s = sz[v0], d0 = x.dep[v0];
-        const int v = lane < s ? x.nar[r0 + lane] : -1;
+    for (int r = (int)blockIdx.x * kSubs + sub; r - sub < nroot; r += grid * kSubs) {
+        const bool have = r < nroot;
+        const int v0 = have ? x.roots[r] : 0;
+        const int r0 = have ? rk[v0] : 0, s = have ? sz[v0] : 0, d0 = have ? x.dep[v0] : 0;
+        const int v = t < s ? x.nar[r0 + t] : -1;
         const XCtx c = px_ctx(x, p, dis, rk, v, r0, false);
         const int ld = v >= 0 ? x.dep[v] - d0 : -1;
-        const int maxld = wave_max_i32(ld);
+        const int maxld = small_max<B>(ld, s_red);
         // what does not depend on this pass: lim[child -> node] of the bottom-up pass, and for the subtree's root lim[parent -> root]
         double inc[3] = { 0.0, 0.0, 0.0 };
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            if (c.slot[k] >= 0 && (c.down[k] || lane == 0)) inc[k] = x.lim[c.rslot[k]];
+            if (c.slot[k] >= 0 && (c.down[k] || t == 0)) inc[k] = x.lim[c.rslot[k]];
         // the candidate's operands that are there already: the node's own bottom-up value and the length of the parent's slot
         int cand = -1, cand_x = -1, cand_rev = -1;
         double below = 0.0, plen = 0.0, above0 = 0.0;
@@ -793,7 +836,7 @@ __global__ __launch_bounds__(kThreads) void px_small_down_kernel(PlaceBuffers p,
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     double in = inc[k];
-                    if (c.slot[k] >= 0 && !c.down[k] && lane != 0) in = s_in[w][lane];
+                    if (c.slot[k] >= 0 && !c.down[k] && t != 0) in = s_in[sub][t];
                     rq[k] = c.slot[k] >= 0 ? in - c.len[k] : 0.0;
                 }
 #pragma unroll
@@ -804,19 +847,19 @@ __global__ __launch_bounds__(kThreads) void px_small_down_kernel(PlaceBuffers p,
                         for (int b = 0; b < 3; ++b)
                             if (b != a && c.slot[b] >= 0 && rq[b] > mx) mx = rq[b];
                         x.lim[c.slot[a]] = mx;
-                        s_in[w][c.ref[a]] = mx;
+                        s_in[sub][c.ref[a]] = mx;
                     }
             }
-            wave_lds_sync();
+            small_sync<B>();
         }
         if (cand >= 0) {
             double add, d1;
-            px_candidate(lane == 0 ? above0 : s_in[w][lane], below, plen, add, d1);
+            px_candidate(t == 0 ? above0 : s_in[sub][t], below, plen, add, d1);
             px_best_take(best, add, d1, cand, cand_x, v, cand_rev, plen);
         }
-        wave_lds_sync();      // (s_in is rewritten by the next subtree)
+        small_sync<B>();      // (s_in is rewritten by the next subtree)
     }
-    px_best_store(best, s_key, s_add, s_frac, s_idx, partials + blockIdx.x);
+    px_best_store(best, s_key, s_idx, partials + blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1453,6 +1496,11 @@ int exact_alloc(ExactBuffers& x, int64_t N)
     x.top_in_memory = std::getenv("DPR_EXACT_TOP_MEM") != nullptr;
     x.top_levels = std::getenv("DPR_EXACT_TOP_LEVELS") != nullptr;
     x.top_poll = std::getenv("DPR_EXACT_TOP_POLL") != nullptr;
+    x.sm = 64; x.pass_sm = 64; x.sm_forced = 0;
+    if (const char* e = std::getenv("DPR_EXACT_SM")) {
+        const int v = std::atoi(e);
+        if (v == 64 || v == 256 || v == 1024) { x.sm = v; x.sm_forced = v; }
+    }
     if (std::getenv("DPR_EXACT_CLOCKS")) { DPR_HIP(hipMalloc(&x.clk, 8 * sizeof(unsigned long long))); DPR_HIP(hipMemset(x.clk, 0, 8 * sizeof(unsigned long long))); }
     DPR_HIP(hipMalloc(&x.tpack, sizeof(TopPack) * (size_t)kTopClimb));
     DPR_HIP(hipMalloc(&x.st, sizeof(XStep)));
@@ -1483,18 +1531,26 @@ void exact_free(ExactBuffers& x)
 }
 
 // the two passes for the tip whose distance row is `dis`, on the tree as it stands (rank / size buffers of parity `par`)
-static int64_t exact_pass_grid(int64_t placed_nodes)
+static int64_t exact_pass_grid(int64_t placed_nodes, int sm)
 {
-    const int64_t g = (placed_nodes + 63) / 64;  // ~ one wavefront per 16 nodes: the subtree roots are a few per cent of the nodes
+    // sm = 64: ~ one wavefront per 16 nodes (the subtree roots are a few per cent of the nodes); larger subtrees: one workgroup per sm / 2 nodes
+    const int64_t g = sm == 64 ? (placed_nodes + 63) / 64 : (2 * placed_nodes + sm - 1) / sm;
     return g < 1 ? 1 : (g > 2048 ? 2048 : g);
 }
 static int exact_passes(PlaceBuffers& p, ExactBuffers& x, const double* dis, int par, int64_t placed_nodes, hipStream_t s)
 {
-    const int64_t g = exact_pass_grid(placed_nodes);
-    hipLaunchKernelGGL(px_small_up_kernel, dim3((unsigned)g + kPackBlocks), dim3(kThreads), 0, s, p, x, dis, par);
+    // (the lists these passes read were made by the patch launch before them, with x.sm nodes per small subtree)
+    const int64_t g = exact_pass_grid(placed_nodes, x.sm);
+    PlacePartialX* parts = reinterpret_cast<PlacePartialX*>(x.partials);
+    const dim3 grid((unsigned)g + kPackBlocks);
+    if (x.sm == 64) hipLaunchKernelGGL(px_small_up_kernel<64>, grid, dim3(SmallShape<64>::kTpb), 0, s, p, x, dis, par);
+    else if (x.sm == 256) hipLaunchKernelGGL(px_small_up_kernel<256>, grid, dim3(SmallShape<256>::kTpb), 0, s, p, x, dis, par);
+    else hipLaunchKernelGGL(px_small_up_kernel<1024>, grid, dim3(SmallShape<1024>::kTpb), 0, s, p, x, dis, par);
     hipLaunchKernelGGL(px_top_kernel, dim3(1), dim3(kXT), kTopDynLds, s, p, x, dis, par);
-    hipLaunchKernelGGL(px_small_down_kernel, dim3((unsigned)g + kPackBlocks), dim3(kThreads), 0, s, p, x, dis, par,
-                       reinterpret_cast<PlacePartialX*>(x.partials));
+    if (x.sm == 64) hipLaunchKernelGGL(px_small_down_kernel<64>, grid, dim3(SmallShape<64>::kTpb), 0, s, p, x, dis, par, parts);
+    else if (x.sm == 256) hipLaunchKernelGGL(px_small_down_kernel<256>, grid, dim3(SmallShape<256>::kTpb), 0, s, p, x, dis, par, parts);
+    else hipLaunchKernelGGL(px_small_down_kernel<1024>, grid, dim3(SmallShape<1024>::kTpb), 0, s, p, x, dis, par, parts);
+    x.pass_sm = x.sm;
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
@@ -1534,12 +1590,27 @@ int exact_tip(PlaceBuffers& p, ExactBuffers& x, int64_t tip, const double* d_dis
     }
     // the candidates of this tip were evaluated by the top-down pass that ran for it (exact_passes of the previous step): one partial
     // per workgroup of that launch
-    nblk = (int)exact_pass_grid(2 * tip - 1) + kPackBlocks;
+    nblk = (int)exact_pass_grid(2 * tip - 1, x.pass_sm) + kPackBlocks;
     const int64_t tot = p.N + tip;
     hipLaunchKernelGGL(px_patch_kernel, dim3((unsigned)((tot + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p, x, (const PlacePartialX*)parts, nblk, tip,
-                       d_trace);
+                       d_trace, x.sm);
     DPR_HIP(hipGetLastError());
     if (has_next) return exact_passes(p, x, d_dis_next, (int)((tip + 1) & 1), 2 * tip + 1, s);
+    return DPR_OK;
+}
+
+// Called between batches of tips (the stream is drained: a few microseconds per 256 tips).  The top tree -- the nodes above the small
+// subtrees -- must stay below kTopClimb nodes for the climbing schedule of px_top_kernel; it grows by at most two nodes per tip.  When
+// it comes near, the small subtrees become four times larger from the next tip on (64 -> 256 -> 1 024 nodes, one workgroup each
+// instead of one wavefront), which divides the top tree by ~3.5 each time; beyond that px_top_kernel's other schedules take over.
+int exact_adapt(ExactBuffers& x, hipStream_t s)
+{
+    if (x.literal || !x.st || x.sm_forced || x.sm >= 1024) return DPR_OK;
+    XStep st;
+    DPR_HIP(hipMemcpyAsync(&st, x.st, sizeof(XStep), hipMemcpyDeviceToHost, s));
+    DPR_HIP(hipStreamSynchronize(s));
+    const int ntop = st.ntop[0] > st.ntop[1] ? st.ntop[0] : st.ntop[1];      // (the list of the other parity is empty)
+    if (ntop > kTopClimb - 600) x.sm *= 4;                                    // (a batch of 256 tips adds at most 512)
     return DPR_OK;
 }
 

@@ -144,3 +144,23 @@ def test_exact_larger_tree_both_top_variants(monkeypatch, orc, top_mem):
         _same_exact_state(d.place_exact_run(capi.SRC_MATRIX, n), ref, n)
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("n", [300, 4000])
+@pytest.mark.parametrize("sm", [256, 1024])
+def test_exact_small_subtrees_of_one_workgroup(monkeypatch, orc, sm, n):
+    """DPR_EXACT_SM: small subtrees of up to 256 / 1 024 nodes, one WORKGROUP each with a barrier per level (what a run switches to
+    when its top tree approaches the 2 047 nodes of the climbing schedule; forced here from the first tip on)"""
+    import dipper_amd
+    from dipper_amd import capi
+    monkeypatch.setenv("DPR_EXACT_SM", str(sm))
+    rng = np.random.default_rng(sm + n)
+    D = _util.random_additive_matrix(rng, n, zero_frac=0.2)
+    D *= 0.9 / D.max()
+    ref = orc.place_exact_run(D)
+    d = dipper_amd.Dipper(0)
+    try:
+        d.set_matrix_full(D)
+        _same_exact_state(d.place_exact_run(capi.SRC_MATRIX, n), ref, n)
+    finally:
+        d.close()

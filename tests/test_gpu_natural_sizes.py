@@ -28,7 +28,7 @@ pytestmark = [pytest.mark.gpu,
 _OVERRIDES = ("DPR_NJ_EPOCH_MIN", "DPR_NJP_GRID", "DPR_NJ_STREAM_FRAC", "DPR_NJ_ADAPTIVE", "DPR_NJ_GRAPH_ITERS", "DPR_NJ_BIG_P",
               "DPR_NJ_MODE", "DPR_NJP_POST2", "DPR_NJ_EXCHANGE", "DPR_NJ_MULTI",
               "DPR_PLACE_BATCH", "DPR_PLACE_NO_OVERLAP", "DPR_PLACE_MULTI_MIN", "DPR_PLACE_MULTI_BIG",
-              "DPR_MASH_KERNEL", "DPR_DC_BUDGET_MB", "DPR_EXACT_LITERAL", "DPR_EXACT_TOP_MEM", "DPR_EXACT_TOP_LEVELS", "DPR_EXACT_TOP_POLL", "DPR_IMPORT_SERIAL", "DPR_MSA_NO_FAST", "DPR_MSA_NO_BAND")
+              "DPR_MASH_KERNEL", "DPR_DC_BUDGET_MB", "DPR_EXACT_LITERAL", "DPR_EXACT_TOP_MEM", "DPR_EXACT_TOP_LEVELS", "DPR_EXACT_TOP_POLL", "DPR_EXACT_SM", "DPR_IMPORT_SERIAL", "DPR_MSA_NO_FAST", "DPR_MSA_NO_BAND")
 
 
 @pytest.fixture(autouse=True)
