@@ -686,13 +686,15 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 // ------------------------------------------------------------------------------------------------
-// The passes inside the small subtrees.  A small subtree (at most B nodes: a contiguous run of pre-order ranks) is evaluated by B
-// threads, one per node, the values travelling through LDS, all small subtrees in parallel on all CUs.  B = 64: one WAVEFRONT per
-// subtree, four subtrees per workgroup, no barrier (rounds 3-6).  B = 256 / 1 024 (round 6): one WORKGROUP per subtree with a
-// barrier per level of the subtree -- for trees whose top tree (the nodes above the small subtrees) would outgrow the 2 047 nodes
-// the climbing schedule of px_top_kernel keeps in LDS: with 64-node subtrees that happens at ~30 000 - 60 000 tips, which is where
-// the reference's command starts to use this mode at all (`-m 0` with 30 000 <= N < 1 000 000); 256 nodes divide the top
-// tree by ~3.5, 1 024 by ~12 (exact_adapt picks B from the top tree's size as the run goes).  Same recurrences, any B: lim[] bit for bit.
+// The passes inside the small subtrees.  A small subtree (at most sm = B x NPT nodes: a contiguous run of pre-order ranks) is evaluated
+// by B threads with NPT nodes each, the values travelling through LDS, all small subtrees in parallel on all CUs.  sm = 64: one
+// WAVEFRONT per subtree, four subtrees per workgroup, no barrier (rounds 3-6).  sm = 256 / 512 / 1 024 (round 6): one 256-thread
+// WORKGROUP per subtree with a barrier per level of the subtree and 1 / 2 / 4 nodes per thread (a workgroup of 512 or 1 024 threads
+// per subtree was built first: most subtrees are far below the limit, the idle threads cost the residency of the launch -- two rounds
+// of workgroups instead of one) -- for trees whose top tree (the nodes above the small subtrees) would outgrow the 2 047 nodes the
+// climbing schedule of px_top_kernel keeps in LDS: with 64-node subtrees that happens at ~30 000 - 60 000 tips, which is where the
+// reference's command starts to use this mode at all (`-m 0` with 30 000 <= N < 1 000 000); 256 nodes divide the top tree
+// by ~3.5, 1 024 by ~12 (exact_adapt picks sm from the top tree's size as the run goes).  Same recurrences, any sm: lim[] bit for bit.
 // ------------------------------------------------------------------------------------------------
 template <int B> struct SmallShape {
     static constexpr int kTpb = B < kThreads ? kThreads : B;      // threads per workgroup
@@ -722,13 +724,13 @@ __device__ __forceinline__ int small_max(int v, int* s_red)
     }
 }
 
-// bottom-up pass inside the small subtrees (updateFromBottomToTop, :296-329): thread = node in pre-order, a node's value =
-// lim[node -> parent]; children's values come from LDS
-template <int B>
+// bottom-up pass inside the small subtrees (updateFromBottomToTop, :296-329): a node's value = lim[node -> parent]; children's values
+// come from LDS.  B threads per subtree, NPT nodes per thread (node j * B + t of the subtree's pre-order run belongs to thread t).
+template <int B, int NPT>
 __global__ __launch_bounds__(SmallShape<B>::kTpb) void px_small_up_kernel(PlaceBuffers p, ExactBuffers x, const double* __restrict__ dis, int par)
 {
     constexpr int kTpb = SmallShape<B>::kTpb, kSubs = SmallShape<B>::kSubs;
-    __shared__ double s_val[kSubs][B];
+    __shared__ double s_val[kSubs][B * NPT];
     __shared__ int s_red[kTpb / 64];
     const int t = (int)threadIdx.x % B, sub = (int)threadIdx.x / B;
     const int nroot = x.st->nroot[par];
@@ -745,23 +747,31 @@ __global__ __launch_bounds__(SmallShape<B>::kTpb) void px_small_up_kernel(PlaceB
         const bool have = r < nroot;
         const int v0 = have ? x.roots[r] : 0;
         const int r0 = have ? rk[v0] : 0, s = have ? sz[v0] : 0, d0 = have ? x.dep[v0] : 0;
-        const int v = t < s ? x.nar[r0 + t] : -1;
-        const XCtx c = px_ctx(x, p, dis, rk, v, r0, false);
-        const int ld = v >= 0 ? x.dep[v] - d0 : -1;
-        const int maxld = small_max<B>(ld, s_red);
-        for (int lev = maxld; lev >= 0; --lev) {
-            if (ld == lev) {
-                double mx = c.init;
-                int up = -1;
+        XCtx c[NPT];
+        int ld[NPT], mld = -1;
 #pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    if (c.slot[k] >= 0) {
-                        if (c.down[k]) { const double req = s_val[sub][c.ref[k]] - c.len[k]; if (req > mx) mx = req; }
-                        else up = c.slot[k];
-                    }
-                s_val[sub][t] = mx;
-                if (up >= 0) x.lim[up] = mx;
-            }
+        for (int j = 0; j < NPT; ++j) {
+            const int v = j * B + t < s ? x.nar[r0 + j * B + t] : -1;
+            c[j] = px_ctx(x, p, dis, rk, v, r0, false);
+            ld[j] = v >= 0 ? x.dep[v] - d0 : -1;
+            mld = max(mld, ld[j]);
+        }
+        const int maxld = small_max<B>(mld, s_red);
+        for (int lev = maxld; lev >= 0; --lev) {
+#pragma unroll
+            for (int j = 0; j < NPT; ++j)
+                if (ld[j] == lev) {
+                    double mx = c[j].init;
+                    int up = -1;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        if (c[j].slot[k] >= 0) {
+                            if (c[j].down[k]) { const double req = s_val[sub][c[j].ref[k]] - c[j].len[k]; if (req > mx) mx = req; }
+                            else up = c[j].slot[k];
+                        }
+                    s_val[sub][j * B + t] = mx;
+                    if (up >= 0) x.lim[up] = mx;
+                }
             small_sync<B>();
         }
     }
@@ -769,12 +779,12 @@ __global__ __launch_bounds__(SmallShape<B>::kTpb) void px_small_up_kernel(PlaceB
 
 // top-down pass inside the small subtrees (updateFromTopToBottom, :331-364): the value a node receives from its parent
 // comes from LDS (the subtree's root: from memory, written by the top-tree kernel); children's bottom-up values from memory
-template <int B>
+template <int B, int NPT>
 __global__ __launch_bounds__(SmallShape<B>::kTpb) void px_small_down_kernel(PlaceBuffers p, ExactBuffers x, const double* __restrict__ dis, int par,
                                                                             PlacePartialX* __restrict__ partials)
 {
     constexpr int kTpb = SmallShape<B>::kTpb, kSubs = SmallShape<B>::kSubs;
-    __shared__ double s_in[kSubs][B];
+    __shared__ double s_in[kSubs][B * NPT];
     __shared__ double s_key[kTpb / 64];
     __shared__ int s_idx[kTpb / 64], s_red[kTpb / 64];
     const int t = (int)threadIdx.x % B, sub = (int)threadIdx.x / B;
@@ -812,51 +822,66 @@ __global__ __launch_bounds__(SmallShape<B>::kTpb) void px_small_down_kernel(Plac
         const bool have = r < nroot;
         const int v0 = have ? x.roots[r] : 0;
         const int r0 = have ? rk[v0] : 0, s = have ? sz[v0] : 0, d0 = have ? x.dep[v0] : 0;
-        const int v = t < s ? x.nar[r0 + t] : -1;
-        const XCtx c = px_ctx(x, p, dis, rk, v, r0, false);
-        const int ld = v >= 0 ? x.dep[v] - d0 : -1;
-        const int maxld = small_max<B>(ld, s_red);
-        // what does not depend on this pass: lim[child -> node] of the bottom-up pass, and for the subtree's root lim[parent -> root]
-        double inc[3] = { 0.0, 0.0, 0.0 };
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (c.slot[k] >= 0 && (c.down[k] || t == 0)) inc[k] = x.lim[c.rslot[k]];
+        XCtx c[NPT];
+        int ld[NPT], vv[NPT], mld = -1;
+        // what does not depend on this pass: lim[child -> node] of the bottom-up pass, and for the subtree's root lim[parent -> root];
         // the candidate's operands that are there already: the node's own bottom-up value and the length of the parent's slot
-        int cand = -1, cand_x = -1, cand_rev = -1;
-        double below = 0.0, plen = 0.0, above0 = 0.0;
+        double inc[NPT][3], below[NPT], plen[NPT], above0[NPT];
+        int cand[NPT], cand_x[NPT], cand_rev[NPT];
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (c.slot[k] >= 0 && !c.down[k]) {
-                cand = c.rslot[k]; cand_rev = c.slot[k]; cand_x = p.belong[c.rslot[k]];
-                below = x.lim[c.slot[k]]; plen = p.len[c.rslot[k]]; above0 = inc[k];
+        for (int j = 0; j < NPT; ++j) {
+            const int v = j * B + t < s ? x.nar[r0 + j * B + t] : -1;
+            vv[j] = v;
+            c[j] = px_ctx(x, p, dis, rk, v, r0, false);
+            ld[j] = v >= 0 ? x.dep[v] - d0 : -1;
+            mld = max(mld, ld[j]);
+            const bool is_root = j == 0 && t == 0;
+            cand[j] = -1; cand_x[j] = -1; cand_rev[j] = -1; below[j] = 0.0; plen[j] = 0.0; above0[j] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                inc[j][k] = 0.0;
+                if (c[j].slot[k] >= 0 && (c[j].down[k] || is_root)) inc[j][k] = x.lim[c[j].rslot[k]];
             }
-        for (int lev = 0; lev <= maxld; ++lev) {
-            if (ld == lev) {
-                double rq[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    double in = inc[k];
-                    if (c.slot[k] >= 0 && !c.down[k] && t != 0) in = s_in[sub][t];
-                    rq[k] = c.slot[k] >= 0 ? in - c.len[k] : 0.0;
+            for (int k = 0; k < 3; ++k)
+                if (c[j].slot[k] >= 0 && !c[j].down[k]) {
+                    cand[j] = c[j].rslot[k]; cand_rev[j] = c[j].slot[k]; cand_x[j] = p.belong[c[j].rslot[k]];
+                    below[j] = x.lim[c[j].slot[k]]; plen[j] = p.len[c[j].rslot[k]]; above0[j] = inc[j][k];
                 }
+        }
+        const int maxld = small_max<B>(mld, s_red);
+        for (int lev = 0; lev <= maxld; ++lev) {
 #pragma unroll
-                for (int a = 0; a < 3; ++a)
-                    if (c.slot[a] >= 0 && c.down[a]) {
-                        double mx = 0;
+            for (int j = 0; j < NPT; ++j)
+                if (ld[j] == lev) {
+                    const bool is_root = j == 0 && t == 0;
+                    double rq[3];
 #pragma unroll
-                        for (int b = 0; b < 3; ++b)
-                            if (b != a && c.slot[b] >= 0 && rq[b] > mx) mx = rq[b];
-                        x.lim[c.slot[a]] = mx;
-                        s_in[sub][c.ref[a]] = mx;
+                    for (int k = 0; k < 3; ++k) {
+                        double in = inc[j][k];
+                        if (c[j].slot[k] >= 0 && !c[j].down[k] && !is_root) in = s_in[sub][j * B + t];
+                        rq[k] = c[j].slot[k] >= 0 ? in - c[j].len[k] : 0.0;
                     }
-            }
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+                        if (c[j].slot[a] >= 0 && c[j].down[a]) {
+                            double mx = 0;
+#pragma unroll
+                            for (int b = 0; b < 3; ++b)
+                                if (b != a && c[j].slot[b] >= 0 && rq[b] > mx) mx = rq[b];
+                            x.lim[c[j].slot[a]] = mx;
+                            s_in[sub][c[j].ref[a]] = mx;
+                        }
+                }
             small_sync<B>();
         }
-        if (cand >= 0) {
-            double add, d1;
-            px_candidate(t == 0 ? above0 : s_in[sub][t], below, plen, add, d1);
-            px_best_take(best, add, d1, cand, cand_x, v, cand_rev, plen);
-        }
+#pragma unroll
+        for (int j = 0; j < NPT; ++j)
+            if (cand[j] >= 0) {
+                double add, d1;
+                px_candidate((j == 0 && t == 0) ? above0[j] : s_in[sub][j * B + t], below[j], plen[j], add, d1);
+                px_best_take(best, add, d1, cand[j], cand_x[j], vv[j], cand_rev[j], plen[j]);
+            }
         small_sync<B>();      // (s_in is rewritten by the next subtree)
     }
     px_best_store(best, s_key, s_idx, partials + blockIdx.x);
@@ -1499,7 +1524,7 @@ int exact_alloc(ExactBuffers& x, int64_t N)
     x.sm = 64; x.pass_sm = 64; x.sm_forced = 0;
     if (const char* e = std::getenv("DPR_EXACT_SM")) {
         const int v = std::atoi(e);
-        if (v == 64 || v == 256 || v == 1024) { x.sm = v; x.sm_forced = v; }
+        if (v == 64 || v == 256 || v == 512 || v == 1024) { x.sm = v; x.sm_forced = v; }
     }
     if (std::getenv("DPR_EXACT_CLOCKS")) { DPR_HIP(hipMalloc(&x.clk, 8 * sizeof(unsigned long long))); DPR_HIP(hipMemset(x.clk, 0, 8 * sizeof(unsigned long long))); }
     DPR_HIP(hipMalloc(&x.tpack, sizeof(TopPack) * (size_t)kTopClimb));
@@ -1533,8 +1558,10 @@ void exact_free(ExactBuffers& x)
 // the two passes for the tip whose distance row is `dis`, on the tree as it stands (rank / size buffers of parity `par`)
 static int64_t exact_pass_grid(int64_t placed_nodes, int sm)
 {
-    // sm = 64: ~ one wavefront per 16 nodes (the subtree roots are a few per cent of the nodes); larger subtrees: one workgroup per sm / 2 nodes
-    const int64_t g = sm == 64 ? (placed_nodes + 63) / 64 : (2 * placed_nodes + sm - 1) / sm;
+    // one wavefront (sm = 64: four per workgroup) or workgroup per sm / 4 nodes: about as many as there are small subtrees (a workgroup
+    // that gets a second subtree works on it after the first)
+    const int64_t subs = sm < kThreads ? kThreads / sm : 1;                  // subtrees a workgroup works on at a time
+    const int64_t g = (4 * placed_nodes + sm * subs - 1) / (sm * subs);
     return g < 1 ? 1 : (g > 2048 ? 2048 : g);
 }
 static int exact_passes(PlaceBuffers& p, ExactBuffers& x, const double* dis, int par, int64_t placed_nodes, hipStream_t s)
@@ -1543,13 +1570,15 @@ static int exact_passes(PlaceBuffers& p, ExactBuffers& x, const double* dis, int
     const int64_t g = exact_pass_grid(placed_nodes, x.sm);
     PlacePartialX* parts = reinterpret_cast<PlacePartialX*>(x.partials);
     const dim3 grid((unsigned)g + kPackBlocks);
-    if (x.sm == 64) hipLaunchKernelGGL(px_small_up_kernel<64>, grid, dim3(SmallShape<64>::kTpb), 0, s, p, x, dis, par);
-    else if (x.sm == 256) hipLaunchKernelGGL(px_small_up_kernel<256>, grid, dim3(SmallShape<256>::kTpb), 0, s, p, x, dis, par);
-    else hipLaunchKernelGGL(px_small_up_kernel<1024>, grid, dim3(SmallShape<1024>::kTpb), 0, s, p, x, dis, par);
+    if (x.sm == 64) hipLaunchKernelGGL((px_small_up_kernel<64, 1>), grid, dim3(SmallShape<64>::kTpb), 0, s, p, x, dis, par);
+    else if (x.sm == 256) hipLaunchKernelGGL((px_small_up_kernel<256, 1>), grid, dim3(256), 0, s, p, x, dis, par);
+    else if (x.sm == 512) hipLaunchKernelGGL((px_small_up_kernel<256, 2>), grid, dim3(256), 0, s, p, x, dis, par);
+    else hipLaunchKernelGGL((px_small_up_kernel<256, 4>), grid, dim3(256), 0, s, p, x, dis, par);
     hipLaunchKernelGGL(px_top_kernel, dim3(1), dim3(kXT), kTopDynLds, s, p, x, dis, par);
-    if (x.sm == 64) hipLaunchKernelGGL(px_small_down_kernel<64>, grid, dim3(SmallShape<64>::kTpb), 0, s, p, x, dis, par, parts);
-    else if (x.sm == 256) hipLaunchKernelGGL(px_small_down_kernel<256>, grid, dim3(SmallShape<256>::kTpb), 0, s, p, x, dis, par, parts);
-    else hipLaunchKernelGGL(px_small_down_kernel<1024>, grid, dim3(SmallShape<1024>::kTpb), 0, s, p, x, dis, par, parts);
+    if (x.sm == 64) hipLaunchKernelGGL((px_small_down_kernel<64, 1>), grid, dim3(SmallShape<64>::kTpb), 0, s, p, x, dis, par, parts);
+    else if (x.sm == 256) hipLaunchKernelGGL((px_small_down_kernel<256, 1>), grid, dim3(256), 0, s, p, x, dis, par, parts);
+    else if (x.sm == 512) hipLaunchKernelGGL((px_small_down_kernel<256, 2>), grid, dim3(256), 0, s, p, x, dis, par, parts);
+    else hipLaunchKernelGGL((px_small_down_kernel<256, 4>), grid, dim3(256), 0, s, p, x, dis, par, parts);
     x.pass_sm = x.sm;
     DPR_HIP(hipGetLastError());
     return DPR_OK;
@@ -1600,9 +1629,9 @@ int exact_tip(PlaceBuffers& p, ExactBuffers& x, int64_t tip, const double* d_dis
 }
 
 // Called between batches of tips (the stream is drained: a few microseconds per 256 tips).  The top tree -- the nodes above the small
-// subtrees -- must stay below kTopClimb nodes for the climbing schedule of px_top_kernel; it grows by at most two nodes per tip.  When
-// it comes near, the small subtrees become four times larger from the next tip on (64 -> 256 -> 1 024 nodes, one workgroup each
-// instead of one wavefront), which divides the top tree by ~3.5 each time; beyond that px_top_kernel's other schedules take over.
+// subtrees -- must stay below kTopClimb nodes for the climbing schedule of px_top_kernel; it grows by at most two nodes per tip.  The
+// small subtrees grow with the run (64 -> 256 -> 512 -> 1 024 nodes: one workgroup each instead of one wavefront), which divides the
+// top tree by ~3.5, ~2, ~2; beyond that px_top_kernel's other schedules take over.
 int exact_adapt(ExactBuffers& x, hipStream_t s)
 {
     if (x.literal || !x.st || x.sm_forced || x.sm >= 1024) return DPR_OK;
@@ -1610,7 +1639,10 @@ int exact_adapt(ExactBuffers& x, hipStream_t s)
     DPR_HIP(hipMemcpyAsync(&st, x.st, sizeof(XStep), hipMemcpyDeviceToHost, s));
     DPR_HIP(hipStreamSynchronize(s));
     const int ntop = st.ntop[0] > st.ntop[1] ? st.ntop[0] : st.ntop[1];      // (the list of the other parity is empty)
-    if (ntop > kTopClimb - 600) x.sm *= 4;                                    // (a batch of 256 tips adds at most 512)
+    // 64 -> 256 early (a top tree of 100 nodes, ~2 000 tips): from there on the workgroup-sized subtrees cost less in their two launches
+    // than they save in px_top_kernel (30 000 tips: 47.5 us per tip against 53.8 with 64-node subtrees throughout; 128-node subtrees:
+    // 48.6); 256 -> 512 -> 1 024 late (600 nodes before the limit: a batch of 256 tips adds at most 512): those steps cost more than they save
+    if (x.sm == 64 ? ntop > 100 : ntop > kTopClimb - 600) x.sm = x.sm == 64 ? 256 : 2 * x.sm;
     return DPR_OK;
 }
 

@@ -147,9 +147,9 @@ def test_exact_larger_tree_both_top_variants(monkeypatch, orc, top_mem):
 
 
 @pytest.mark.parametrize("n", [300, 4000])
-@pytest.mark.parametrize("sm", [256, 1024])
+@pytest.mark.parametrize("sm", [256, 512, 1024])
 def test_exact_small_subtrees_of_one_workgroup(monkeypatch, orc, sm, n):
-    """DPR_EXACT_SM: small subtrees of up to 256 / 1 024 nodes, one WORKGROUP each with a barrier per level (what a run switches to
+    """DPR_EXACT_SM: small subtrees of up to 256 / 512 / 1 024 nodes, one WORKGROUP each with a barrier per level and 1 / 2 / 4 nodes per thread (what a run switches to
     when its top tree approaches the 2 047 nodes of the climbing schedule; forced here from the first tip on)"""
     import dipper_amd
     from dipper_amd import capi
