@@ -5,14 +5,16 @@
 // thrust::reduce :746, updateDepth :400-416, stable_sort_by_key :766, updateLevelStEd :419-434.
 //
 // Per tip the reference launches one kernel per tree level (twice), a Thrust reduction, a Thrust
-// stable sort of all node depths and four blocking device->host copies.  Here per tip:
-//   px_scan_kernel  (many blocks)  candidates of all live slots -> block-level first minima
-//   px_step_kernel  (one 1024-thread workgroup, everything that is inherently sequential):
-//       finish the argmin, split the edge, patch DFS ranks / depths (the reference's O(N) parallel
-//       scheme, unchanged), rebuild the level lists by a counting sort on depth (the order inside a
-//       level does not influence any result), then run the level-synchronous bottom-up / top-down
-//       pass for the NEXT tip with workgroup barriers between levels instead of kernel launches.
-// lim[], depths and level lists live in HBM/L2 (O(N) per tip); nothing returns to the host.
+// stable sort of all node depths and four blocking device->host copies.  Here per tip FOUR launches (round 6):
+//   px_patch_kernel       finish the argmin over the candidates' partials, split the edge, patch ranks / depths / sizes,
+//                         rebuild the lists of small-subtree roots and top nodes (elementwise over the nodes)
+//   px_small_up_kernel    bottom-up pass inside the small subtrees (a wavefront or a workgroup per subtree); spare workgroups
+//                         pack the top nodes' records
+//   px_top_kernel         both passes over the top tree (one workgroup; climbing / polling / level schedules)
+//   px_small_down_kernel  top-down pass inside the small subtrees + the candidates of the NEXT placement (one per node)
+// and the literal schedule of rounds 1-2 as the fallback for the reference's swap quirk (px_scan_kernel +
+// px_step_literal_kernel: one workgroup, one barrier per level).  lim[], depths, ranks and lists live in HBM/L2 (O(N) per
+// tip); between batches of 256 tips the host reads one counter (exact_adapt), nothing else returns to it.
 #include <cstdlib>
 
 #include "dpr_internal.hpp"
