@@ -392,3 +392,32 @@ def test_exact_placement_run_that_crosses_the_top_tree_schedules(monkeypatch):
         if parent[v] >= 0:
             size[parent[v]] += size[v]
     assert size.max() == nodes and int((size > 64).sum()) > 2048
+
+
+@pytest.mark.timeout(900)
+def test_exact_placement_on_poisoned_memory():
+    """exact placement (12 000 tips, the small subtrees switch from one wavefront to one workgroup on the way) on clean, 0xFF- and
+    0x40-poisoned device memory: records nobody wrote (the spare LDS record's global twin, pad fields, partials of workgroups
+    without a subtree) must not reach a result -- adjacency, lengths, depths and trace identical bit for bit."""
+    import dipper_amd
+    from dipper_amd import capi
+    n, L = 12000, 500
+    seqs = _util.synth_alignment(np.random.default_rng(12), n, L, mean_bl=2e-3, lo=2e-4, hi=2e-2)
+    perm = np.random.default_rng(5).permutation(n)
+    packed = capi.pack4_many([seqs[i] for i in perm])
+    outs = []
+    for fill in (None, 0xFF, 0x40):
+        d = dipper_amd.Dipper(0)
+        try:
+            if fill is not None:
+                _dirty_device_memory(8 << 30, fill)
+            d.set_msa(packed, L)
+            outs.append(d.place_exact_run(capi.SRC_MSA, n, dist_type=capi.DIST_JC))
+        finally:
+            d.close()
+    nodes, live = 2 * n - 1, 4 * n - 4
+    for other in outs[1:]:
+        assert np.array_equal(outs[0]["trace"][2:].view(np.uint64), other["trace"][2:].view(np.uint64))
+        for key in ("head", "e", "nxt", "belong", "len", "rev", "dep"):
+            m = nodes if key in ("head", "dep") else live
+            assert np.array_equal(outs[0][key][:m].view(np.uint8), other[key][:m].view(np.uint8)), key
