@@ -485,7 +485,7 @@ struct ExactBuffers {
     int32_t* sz[2] = { nullptr, nullptr };   // [2N] nodes in the subtree, same buffering
     int32_t* nar = nullptr;      // [2N] node at rank
     int32_t* tix = nullptr;      // [2N] top node -> index in the level-sorted top list (-1: not a top node)
-    int32_t* roots = nullptr;    // roots of the small subtrees (<= 64 nodes, parent's subtree larger)
+    int32_t* roots = nullptr;    // [2N] x int4: roots of the small subtrees (<= sm nodes, parent's subtree larger): node, rank, size, depth
     int32_t* tops = nullptr;     // nodes whose subtree has more than 64 nodes
     int32_t* order = nullptr;    // [2N] top nodes grouped by depth
     int32_t* lvoff = nullptr;    // [2N+2] first index of every level in order[]

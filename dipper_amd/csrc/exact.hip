@@ -508,13 +508,13 @@ __global__ __launch_bounds__(kThreads) void px_patch_kernel(PlaceBuffers p, Exac
     // ---- what the elementwise part reads of the OLD state does not depend on the split: in flight while the argmin is finished
     // (the node's record, old rank and size; old ranks and sizes of its neighbours)
     int32_t* const q = x.nd + 12 * (int64_t)(live ? idx : 0);
-    int rec[9], r_old = 0, s_old = 0, rnb[3] = { 0, 0, 0 }, snb[3] = { 0, 0, 0 };
+    int rec[9], r_old = 0, s_old = 0, d_old = 0, rnb[3] = { 0, 0, 0 }, snb[3] = { 0, 0, 0 };
 #pragma unroll
     for (int k = 0; k < 9; ++k) rec[k] = -1;
     if (live && idx != middle && idx != outside) {
         const int4 a = reinterpret_cast<const int4*>(q)[0], b = reinterpret_cast<const int4*>(q)[1];
         rec[0] = a.x; rec[1] = a.y; rec[2] = a.z; rec[3] = a.w; rec[4] = b.x; rec[5] = b.y; rec[6] = b.z; rec[7] = b.w; rec[8] = q[8];
-        r_old = rk_in[idx]; s_old = sz_in[idx];
+        r_old = rk_in[idx]; s_old = sz_in[idx]; d_old = x.dep[idx];
 #pragma unroll
         for (int k = 0; k < 3; ++k)
             if (rec[k] >= 0) { rnb[k] = rk_in[rec[6 + k]]; snb[k] = sz_in[rec[6 + k]]; }
@@ -568,6 +568,7 @@ __global__ __launch_bounds__(kThreads) void px_patch_kernel(PlaceBuffers p, Exac
         return v == middle ? ysz + 2 : v == outside ? 1 : ((r < rrk && r + sz > rrk) ? sz + 2 : sz);      // the ancestors of y gain the two new nodes
     };
     int kind = -1, mine = 0;          // 0: root of a small subtree, 1: top node
+    int4 root_rec = make_int4(0, 0, 0, 0);
     if (live) {
         // the node's record after the split
         if (idx == middle) {
@@ -590,9 +591,11 @@ __global__ __launch_bounds__(kThreads) void px_patch_kernel(PlaceBuffers p, Exac
         sz_out[idx] = sn;
         x.nar[rn] = idx;
         x.tix[idx] = -1;
-        if (idx == middle) x.dep[idx] = dxn + 1;            // (dep[middle] = dep[x], then + 1 with the moved subtree, :400-416)
-        else if (idx == outside) x.dep[idx] = dxn + 2;
-        else if (rn >= rrk && rn <= small) x.dep[idx] += 1;
+        int dn = d_old;
+        if (idx == middle) dn = dxn + 1;            // (dep[middle] = dep[x], then + 1 with the moved subtree, :400-416)
+        else if (idx == outside) dn = dxn + 2;
+        else if (rn >= rrk && rn <= small) dn = d_old + 1;
+        if (dn != d_old || idx == middle || idx == outside) x.dep[idx] = dn;
         // parent = the neighbour with the smaller rank
         int parent = -1, psize = 0;
 #pragma unroll
@@ -600,6 +603,7 @@ __global__ __launch_bounds__(kThreads) void px_patch_kernel(PlaceBuffers p, Exac
             if (rec[k] >= 0 && new_rank(rec[6 + k], rnb[k]) < rn) { parent = rec[6 + k]; psize = new_size(rec[6 + k], rnb[k], snb[k]); }
         if (sn > sm) kind = 1;
         else if (parent < 0 || psize > sm) kind = 0;
+        root_rec = make_int4(idx, rn, sn, dn);      // (what the small-subtree launches need of a root: no second round trip for it)
         if (kind >= 0) mine = atomicAdd(&s_cnt[kind], 1);
         if (idx == middle) {
             // ---- updateTreeStructure: the adjacency arrays
@@ -619,7 +623,7 @@ __global__ __launch_bounds__(kThreads) void px_patch_kernel(PlaceBuffers p, Exac
     __syncthreads();
     if (tid < 2 && s_cnt[tid] > 0) s_base[tid] = atomicAdd(tid == 0 ? &x.st->nroot[cpar] : &x.st->ntop[cpar], s_cnt[tid]);
     __syncthreads();
-    if (kind == 0) x.roots[s_base[0] + mine] = idx;
+    if (kind == 0) reinterpret_cast<int4*>(x.roots)[s_base[0] + mine] = root_rec;
     else if (kind == 1) { x.tops[s_base[1] + mine] = idx; x.tix[idx] = s_base[1] + mine; }      // (tix: position in the top list, what px_top_kernel's contexts refer to)
 }
 
@@ -737,7 +741,6 @@ __global__ __launch_bounds__(SmallShape<B>::kTpb) void px_small_up_kernel(PlaceB
     const int t = (int)threadIdx.x % B, sub = (int)threadIdx.x / B;
     const int nroot = x.st->nroot[par];
     const int32_t* __restrict__ rk = x.rk[par];
-    const int32_t* __restrict__ sz = x.sz[par];
     const int grid = (int)gridDim.x - kPackBlocks;
     if ((int)blockIdx.x >= grid) {      // the spare workgroups: structural records of the top nodes for px_top_climb
         const int T = x.st->ntop[par];
@@ -747,8 +750,8 @@ __global__ __launch_bounds__(SmallShape<B>::kTpb) void px_small_up_kernel(PlaceB
     }
     for (int r = (int)blockIdx.x * kSubs + sub; r - sub < nroot; r += grid * kSubs) {      // (B > 64: the same trip count for the whole workgroup)
         const bool have = r < nroot;
-        const int v0 = have ? x.roots[r] : 0;
-        const int r0 = have ? rk[v0] : 0, s = have ? sz[v0] : 0, d0 = have ? x.dep[v0] : 0;
+        const int4 root = have ? reinterpret_cast<const int4*>(x.roots)[r] : make_int4(0, 0, 0, 0);      // node, rank, size, depth
+        const int r0 = root.y, s = root.z, d0 = root.w;
         XCtx c[NPT];
         int ld[NPT], mld = -1;
 #pragma unroll
@@ -792,7 +795,6 @@ __global__ __launch_bounds__(SmallShape<B>::kTpb) void px_small_down_kernel(Plac
     const int t = (int)threadIdx.x % B, sub = (int)threadIdx.x / B;
     const int nroot = x.st->nroot[par];
     const int32_t* __restrict__ rk = x.rk[par];
-    const int32_t* __restrict__ sz = x.sz[par];
     // calculateBranchLength (:158-197) rides along: every node but the root owns ONE candidate, the slot parent -> node (the
     // direction the reference evaluates: the shallower end first), whose two values are final here -- the one from above has just
     // been computed (or, for the root of a small subtree and for the top nodes, written by px_top_kernel), the one from below is
@@ -822,8 +824,8 @@ __global__ __launch_bounds__(SmallShape<B>::kTpb) void px_small_down_kernel(Plac
     }
     for (int r = (int)blockIdx.x * kSubs + sub; r - sub < nroot; r += grid * kSubs) {
         const bool have = r < nroot;
-        const int v0 = have ? x.roots[r] : 0;
-        const int r0 = have ? rk[v0] : 0, s = have ? sz[v0] : 0, d0 = have ? x.dep[v0] : 0;
+        const int4 root = have ? reinterpret_cast<const int4*>(x.roots)[r] : make_int4(0, 0, 0, 0);      // node, rank, size, depth
+        const int r0 = root.y, s = root.z, d0 = root.w;
         XCtx c[NPT];
         int ld[NPT], vv[NPT], mld = -1;
         // what does not depend on this pass: lim[child -> node] of the bottom-up pass, and for the subtree's root lim[parent -> root];
@@ -1498,7 +1500,7 @@ __global__ void px_init_tree_kernel(PlaceBuffers p, ExactBuffers x, const double
     st.nroot[0] = 1; st.ntop[0] = 0; st.nroot[1] = 0; st.ntop[1] = 0;      // (the passes for tip 2 read parity 0)
     st.poll_fail = 0; st.poll_node = -1; st.poll_pass = 0;
     st.quirk = 0;
-    x.roots[0] = nv;
+    reinterpret_cast<int4*>(x.roots)[0] = make_int4(nv, 0, 3, 0);
     *x.st = st;
 }
 
@@ -1513,7 +1515,7 @@ int exact_alloc(ExactBuffers& x, int64_t N)
     }
     DPR_HIP(hipMalloc(&x.nar, sizeof(int32_t) * (size_t)(2 * N + 2)));
     DPR_HIP(hipMalloc(&x.tix, sizeof(int32_t) * (size_t)(2 * N)));
-    DPR_HIP(hipMalloc(&x.roots, sizeof(int32_t) * (size_t)(2 * N)));
+    DPR_HIP(hipMalloc(&x.roots, sizeof(int32_t) * 4 * (size_t)(2 * N)));
     DPR_HIP(hipMalloc(&x.tops, sizeof(int32_t) * (size_t)(2 * N)));
     DPR_HIP(hipMalloc(&x.order, sizeof(int32_t) * (size_t)(2 * N)));
     DPR_HIP(hipMalloc(&x.lvoff, sizeof(int32_t) * (size_t)(2 * N + 2)));
