@@ -156,6 +156,14 @@ struct PairCounts<DPR_DIST_JC> {
     }
     // a word in which neither sequence has a not-a-base position (X = 0 on both sides, so LX = LO)
     __device__ __forceinline__ void add_fast(uint32_t lr, uint32_t hr, uint32_t lc, uint32_t hc) { mism += __popc((lr ^ lc) | (hr ^ hc)); }
+    // a word in which only ONE side has such positions (x: that side's X word; the other side's is 0, so X_r & X_c = 0 and X_r ^ X_c = x):
+    // the same four operations as the clean word, with the three-input OR
+    __device__ __forceinline__ void add_one_sided(uint32_t x, uint32_t lr, uint32_t hr, uint32_t lxc, uint32_t hc)
+    {
+        uint32_t m;
+        asm("v_or3_b32 %0, %1, %2, %3" : "=v"(m) : "v"(lr ^ lxc), "v"(hr ^ hc), "v"(x));
+        mism += __popc(m);
+    }
     __device__ __forceinline__ double value(int dist_type) const { return msa_epilogue(sites - binv, sites - mism, dist_type); }
     // tab_ld > 0: the full (useful, match) table of a short alignment; tab_ld < 0: the band useful >= L - kMsaBand of a long one
     // (L = -tab_ld - 1, rows of L + 1 entries indexed by L - useful)
@@ -297,7 +305,10 @@ __device__ __forceinline__ void msa_tile(const uint32_t* __restrict__ planes, in
             }
             __syncthreads();
             if (track && tid < 8) s_xm[set ^ 1][tid] = 0u;     // (the other set: last read before the barrier that ended the previous stage)
-            const unsigned int xm = fast ? 0u : !track ? 0xffffu : (unsigned int)__builtin_amdgcn_readfirstlane((int)(s_xm[set][wave] | s_xm[set][4]));
+            // words of this stage in which a row of this wavefront / a column of the tile has a not-a-base position
+            const unsigned int xm_r = fast ? 0u : !track ? 0xffffu : (unsigned int)__builtin_amdgcn_readfirstlane((int)s_xm[set][wave]);
+            const unsigned int xm_c = fast ? 0u : !track ? 0xffffu : (unsigned int)__builtin_amdgcn_readfirstlane((int)s_xm[set][4]);
+            const unsigned int xm = xm_r & xm_c;            // both sides: the seven-operation body
             auto body_fast = [&](int kk) {
                 const uint4 aL = *reinterpret_cast<const uint4*>(&sA[1][kk][ty * 4]);
                 const uint4 aH = *reinterpret_cast<const uint4*>(&sA[2][kk][ty * 4]);
@@ -324,17 +335,47 @@ __device__ __forceinline__ void msa_tile(const uint32_t* __restrict__ planes, in
 #pragma unroll
                     for (int c = 0; c < 4; ++c) acc[r][c].add(av[r], al[r], ah[r], bv[c], bl[c], bh[c]);
             };
-            // (two loops over the words of each kind, not a branch per word: a branch makes the sixteen pairs' counters meet
+            // words with such positions on ONE side only: X_r & X_c = 0 (nothing to count as invalid on both sides) and X_r ^ X_c is
+            // that side's word -- four operations, like the clean word
+            auto body_rows = [&](int kk) {
+                const uint4 aV = *reinterpret_cast<const uint4*>(&sA[0][kk][ty * 4]);
+                const uint4 aL = *reinterpret_cast<const uint4*>(&sA[1][kk][ty * 4]);
+                const uint4 aH = *reinterpret_cast<const uint4*>(&sA[2][kk][ty * 4]);
+                const uint4 bL = *reinterpret_cast<const uint4*>(&sB[1][kk][tx * 4]);
+                const uint4 bH = *reinterpret_cast<const uint4*>(&sB[2][kk][tx * 4]);
+                const uint32_t av[4] = { aV.x, aV.y, aV.z, aV.w }, al[4] = { aL.x, aL.y, aL.z, aL.w }, ah[4] = { aH.x, aH.y, aH.z, aH.w };
+                const uint32_t bl[4] = { bL.x, bL.y, bL.z, bL.w }, bh[4] = { bH.x, bH.y, bH.z, bH.w };
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[r][c].add_one_sided(av[r], al[r], ah[r], bl[c], bh[c]);
+            };
+            auto body_cols = [&](int kk) {
+                const uint4 aL = *reinterpret_cast<const uint4*>(&sA[1][kk][ty * 4]);
+                const uint4 aH = *reinterpret_cast<const uint4*>(&sA[2][kk][ty * 4]);
+                const uint4 bV = *reinterpret_cast<const uint4*>(&sB[0][kk][tx * 4]);
+                const uint4 bL = *reinterpret_cast<const uint4*>(&sB[1][kk][tx * 4]);
+                const uint4 bH = *reinterpret_cast<const uint4*>(&sB[2][kk][tx * 4]);
+                const uint32_t al[4] = { aL.x, aL.y, aL.z, aL.w }, ah[4] = { aH.x, aH.y, aH.z, aH.w };
+                const uint32_t bv[4] = { bV.x, bV.y, bV.z, bV.w }, bl[4] = { bL.x, bL.y, bL.z, bL.w }, bh[4] = { bH.x, bH.y, bH.z, bH.w };
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[r][c].add_one_sided(bv[c], al[r], ah[r], bl[c], bh[c]);
+            };
+            // (one loop over the words of each kind, not a branch per word: a branch makes the sixteen pairs' counters meet
             //  at a join after every word -- register copies that cost what the short body saves, measured)
-            if (xm == 0u) {
+            if ((xm_r | xm_c) == 0u) {
 #pragma unroll MSA_UNROLL
                 for (int kk = 0; kk < kKC; ++kk) body_fast(kk);
             } else if (xm == 0xffffu) {
 #pragma unroll MSA_UNROLL
                 for (int kk = 0; kk < kKC; ++kk) body_slow(kk);
             } else {
-                unsigned int mf = ~xm & 0xffffu, ms = xm & 0xffffu;
+                unsigned int mf = ~(xm_r | xm_c) & 0xffffu, mr = xm_r & ~xm_c & 0xffffu, mc = xm_c & ~xm_r & 0xffffu, ms = xm & 0xffffu;
                 while (mf) { const int kk = __builtin_ctz(mf); mf &= mf - 1u; body_fast(kk); }
+                while (mc) { const int kk = __builtin_ctz(mc); mc &= mc - 1u; body_cols(kk); }
+                while (mr) { const int kk = __builtin_ctz(mr); mr &= mr - 1u; body_rows(kk); }
                 while (ms) { const int kk = __builtin_ctz(ms); ms &= ms - 1u; body_slow(kk); }
             }
             __syncthreads();
