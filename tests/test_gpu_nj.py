@@ -158,7 +158,9 @@ def test_msa_dist_and_nj(gpu, orc, n, L, inv):
 
 def test_msa_fast_stages_band_table_and_block_hook_equal_the_plain_kernel(gpu, orc):
     """Round 6: per 16-word stage of a tile the pair kernel skips the not-a-base bookkeeping when no sequence of the tile has such a
-    position there, and distances of pairs with useful >= L - 15 come from a band table (msa.hip).  An alignment of 2 300 sites in
+    position there, inside the other stages it takes the seven-operation body only for the words in which BOTH a row of the wavefront
+    and a column of the tile have one (words with such positions on one side only: a four-operation body with that side's X word),
+    and distances of pairs with useful >= L - 15 come from a band table (msa.hip).  An alignment of 2 300 sites in
     which gaps sit in SOME stages of SOME sequences (runs inside one stage, a run across a stage boundary, a tip that is all
     gaps, 40 tips with an unknown base each in different stages, everything else clean): every type-1 / type-2 distance must equal
     the kernel with both switched off (DPR_MSA_NO_FAST / DPR_MSA_NO_BAND) bit for bit, the oracle's at rtol 1e-11, and the block
