@@ -174,3 +174,12 @@ def test_more_ranks_than_work_and_uneven_shares(tmp_path, tips, devices, mode):
     gen(p, tips, 300, seed=tips)
     a, b, _ = both(tmp_path, ["-i", "m", "-I", str(p), "-m", mode, "-d", "2"], devices)
     assert a == b and a.count(",") == tips - 1
+
+
+@pytest.mark.timeout(600)
+def test_exact_placement_command_with_ranks_equals_one_rank(tmp_path, aligned):
+    """-m 1 -p 0 (src/placement.cu): the exact mode has no sharded part -- every rank runs the whole placement, rank 0 writes the
+    tree; the file must be the one-rank file (the per-batch read-back that sizes the small subtrees runs on every rank's own stream)"""
+    a, b, err = both(tmp_path, ["-i", "m", "-I", str(aligned), "-m", "1", "-p", "0", "-d", "2"], "0,0")
+    assert a == b and a.count(",") == 2599
+    assert "exact placement mode" in err
